@@ -1,0 +1,210 @@
+"""ctypes loader for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and only
+as the checker / reported CPU baseline (see oracle/oracle.h).  The product package
+(arrowspace-rs_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TAU_FIXED, TAU_MEDIAN, TAU_MEAN, TAU_PERCENTILE = 0, 1, 2, 3
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+ERRORS = {
+    -1: "items should be at least of shape (2,2)",
+    -2: "Query item contains invalid values (NaN or infinity). All values must be finite.",
+    -3: "Lambda of the item is 0.0, prepare the item before searching",
+    -4: "NaN score",
+    -5: "graph is larger than the signal",
+    -6: "allocation failed",
+}
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(ERRORS.get(code, "oracle error %d" % code))
+        self.code = code
+
+
+class GraphParams(C.Structure):
+    _fields_ = [
+        ("eps", C.c_double),
+        ("k", C.c_uint64),
+        ("topk", C.c_uint64),
+        ("p", C.c_double),
+        ("sigma", C.c_double),
+        ("has_sigma", C.c_int32),
+        ("normalise", C.c_int32),
+        ("sparsity_check", C.c_int32),
+        ("rectify", C.c_int32),
+    ]
+
+
+class Csr(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("nnz", C.c_uint64),
+        ("indptr", C.POINTER(C.c_uint64)),
+        ("indices", C.POINTER(C.c_uint64)),
+        ("data", C.POINTER(C.c_double)),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+        L.aso_define_result_k.restype = C.c_uint64
+        L.aso_define_result_k.argtypes = [C.c_uint64, C.c_uint64]
+        L.aso_knn_cosine.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), up, dp]
+        L.aso_build_laplacian.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), C.POINTER(Csr)]
+        L.aso_csr_free.argtypes = [C.POINTER(Csr)]
+        L.aso_csr_free.restype = None
+        L.aso_select_tau.restype = C.c_double
+        L.aso_select_tau.argtypes = [dp, C.c_uint64, C.c_int, C.c_double]
+        L.aso_synthetic_lambda.argtypes = [dp, C.c_uint64, C.POINTER(Csr), C.c_double, dp]
+        L.aso_taumode_lambdas.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(Csr), C.c_int, C.c_double, dp]
+        L.aso_prepare_query_item.argtypes = [dp, C.c_uint64, C.POINTER(Csr), C.c_int, C.c_double, dp]
+        L.aso_lambda_similarity.restype = C.c_double
+        L.aso_lambda_similarity.argtypes = [dp, C.c_double, dp, C.c_double, C.c_uint64, C.c_double]
+        L.aso_search_lambda_aware.restype = C.c_int64
+        L.aso_search_lambda_aware.argtypes = [dp, dp, C.c_uint64, C.c_uint64, dp, C.c_double, C.c_uint64, C.c_double, up, dp]
+        L.aso_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def graph_params(eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False, rectify=False):
+    return GraphParams(eps, k, topk, p, 0.0 if sigma is None else sigma, int(sigma is not None),
+                       int(normalise), int(sparsity_check), int(rectify))
+
+
+def _wrap_csr(n, indptr, indices, data):
+    c = Csr(n, len(indices), _up(indptr), _up(indices), _dp(data))
+    c._keep = (indptr, indices, data)
+    return c
+
+
+def csr_struct(indptr, indices, data):
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+    indices = np.ascontiguousarray(indices, dtype=np.uint64)
+    data = _f64(data)
+    return _wrap_csr(len(indptr) - 1, indptr, indices, data)
+
+
+def define_result_k(k, topk):
+    return int(lib().aso_define_result_k(k, topk))
+
+
+def knn_cosine(rows, params):
+    rows = _f64(rows)
+    n, d = rows.shape
+    K = params.topk + 1
+    idx = np.empty((n, K), dtype=np.uint64)
+    dist = np.empty((n, K), dtype=np.float64)
+    rc = lib().aso_knn_cosine(_dp(rows), n, d, C.byref(params), _up(idx), _dp(dist))
+    if rc:
+        raise OracleError(rc)
+    return idx, dist
+
+
+def build_laplacian(rows, params):
+    """rows are nodes.  Returns (indptr, indices, data) as numpy u64/u64/f64 (copied)."""
+    rows = _f64(rows)
+    if rows.ndim != 2:
+        raise OracleError(-1)
+    n, d = rows.shape
+    out = Csr()
+    rc = lib().aso_build_laplacian(_dp(rows), n, d, C.byref(params), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    indptr = np.ctypeslib.as_array(out.indptr, shape=(n + 1,)).copy()
+    indices = np.ctypeslib.as_array(out.indices, shape=(out.nnz,)).copy()
+    data = np.ctypeslib.as_array(out.data, shape=(out.nnz,)).copy()
+    lib().aso_csr_free(C.byref(out))
+    return indptr, indices, data
+
+
+def select_tau(v, mode, arg=0.0):
+    v = _f64(v).ravel()
+    return float(lib().aso_select_tau(_dp(v), len(v), mode, arg))
+
+
+def synthetic_lambda(x, csr, tau):
+    x = _f64(x).ravel()
+    c = csr_struct(*csr)
+    out = C.c_double()
+    rc = lib().aso_synthetic_lambda(_dp(x), len(x), C.byref(c), tau, C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
+def taumode_lambdas(items, csr, mode, arg=0.0):
+    items = _f64(items)
+    n, f = items.shape
+    c = csr_struct(*csr)
+    out = np.empty(n, dtype=np.float64)
+    rc = lib().aso_taumode_lambdas(_dp(items), n, f, C.byref(c), mode, arg, _dp(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def prepare_query_item(q, csr, mode, arg=0.0):
+    q = _f64(q).ravel()
+    c = csr_struct(*csr)
+    out = C.c_double()
+    rc = lib().aso_prepare_query_item(_dp(q), len(q), C.byref(c), mode, arg, C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
+def lambda_similarity(q, lq, x, lx, alpha):
+    q, x = _f64(q).ravel(), _f64(x).ravel()
+    return float(lib().aso_lambda_similarity(_dp(q), lq, _dp(x), lx, len(q), alpha))
+
+
+def search_lambda_aware(items, lambdas, q, lambda_q, k, alpha):
+    items, lambdas, q = _f64(items), _f64(lambdas).ravel(), _f64(q).ravel()
+    n, d = items.shape
+    kk = min(k, n)
+    idx = np.empty(max(kk, 1), dtype=np.uint64)
+    sc = np.empty(max(kk, 1), dtype=np.float64)
+    rc = lib().aso_search_lambda_aware(_dp(items), _dp(lambdas), n, d, _dp(q), lambda_q, k, alpha, _up(idx), _dp(sc))
+    if rc < 0:
+        raise OracleError(int(rc))
+    return idx[:rc].copy(), sc[:rc].copy()
+
+
+def num_threads():
+    return int(lib().aso_num_threads())
