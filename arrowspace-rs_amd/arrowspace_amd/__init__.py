@@ -1,1 +1,9 @@
-"""arrowspace_amd: host-side mirror of the arrowspace API over libarrowspace_hip.so (C ABI)."""
+"""arrowspace_amd: host-side mirror of the arrowspace lambda-tau API over libarrowspace_hip.so.
+
+The compute lives in the HIP library (arrowspace-rs_amd/csrc, C ABI in include/arrowspace_hip.h);
+this package only marshals pointers.  There is no CPU fallback.
+"""
+from ._lib import ArrowSpaceError, LIB_PATH, load  # noqa: F401
+from .api import (ArrowItem, ArrowSpace, ArrowSpaceBuilder, Context, CsrMatrix, GraphFactory,  # noqa: F401
+                  GraphLaplacian, GraphParams, TauMode, TAU_FLOOR, build_laplacian_matrix,
+                  compute_synthetic_lambda, default_context, knn_cosine, laplacian_from_knn, select_tau)

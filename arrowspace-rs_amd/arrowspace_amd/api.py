@@ -1,0 +1,506 @@
+"""Host-side mirror of the reference's public interface for the lambda-tau path, over the C ABI.
+
+Same names and argument meaning as the Rust crate (paths relative to /root/reference):
+  ArrowSpaceBuilder  src/builder.rs:20-455     (with_lambda_graph, with_synthesis, build, ...)
+  GraphParams        src/graph.rs:94-102
+  GraphLaplacian     src/graph.rs:127-135
+  GraphFactory       src/graph.rs:143-204
+  TauMode            src/taumode.rs:75-127
+  ArrowItem          src/core.rs:84-239
+  ArrowSpace         src/core.rs:366-1006      (prepare_query_item, search_lambda_aware, ...)
+Errors the reference raises by panicking surface as ArrowSpaceError with the same message.
+
+Out of scope here ("next"): the clustering pre-stage, inline sampling, JL
+projection.  `build(rows)` therefore takes the centroids as an argument; with none given every
+item is its own centroid (the radius -> 0 limit of the reference's clustering).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArrowSpaceError, GraphParamsC, ptr
+
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+class TauMode:
+    """src/taumode.rs:75-82.  TauMode.Median, TauMode.Mean, TauMode.Fixed(t), TauMode.Percentile(p)."""
+    FIXED, MEDIAN, MEAN, PERCENTILE = 0, 1, 2, 3
+
+    def __init__(self, kind, arg=0.0):
+        self.kind, self.arg = kind, float(arg)
+
+    @staticmethod
+    def Fixed(t):
+        return TauMode(TauMode.FIXED, t)
+
+    @staticmethod
+    def Percentile(p):
+        return TauMode(TauMode.PERCENTILE, p)
+
+    def __repr__(self):
+        return {0: "Fixed(%r)" % self.arg, 1: "Median", 2: "Mean", 3: "Percentile(%r)" % self.arg}[self.kind]
+
+    def __eq__(self, o):
+        return isinstance(o, TauMode) and (self.kind, self.arg) == (o.kind, o.arg)
+
+
+TauMode.Median = TauMode(TauMode.MEDIAN)
+TauMode.Mean = TauMode(TauMode.MEAN)
+TAU_FLOOR = 1e-10  # src/taumode.rs:84
+
+
+class GraphParams:
+    """src/graph.rs:94-102 (same field names)."""
+
+    def __init__(self, eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False):
+        self.eps, self.k, self.topk, self.p = float(eps), int(k), int(topk), float(p)
+        self.sigma, self.normalise, self.sparsity_check = sigma, bool(normalise), bool(sparsity_check)
+
+    def to_c(self):
+        return GraphParamsC(self.eps, self.k, self.topk, self.p, 0.0 if self.sigma is None else float(self.sigma),
+                            int(self.sigma is not None), int(self.normalise), int(self.sparsity_check), 0)
+
+    def __eq__(self, o):  # src/graph.rs:105-121 (sparsity_check and topk are not compared there)
+        return (self.k == o.k and np.isclose(self.eps, o.eps) and np.isclose(self.p, o.p) and
+                ((self.sigma is None) == (o.sigma is None)) and
+                (self.sigma is None or np.isclose(self.sigma, o.sigma)) and self.normalise == o.normalise)
+
+
+class Context:
+    """One as_ctx: device, stream and workspace.  Not re-entrant (one per host thread)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.as_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise ArrowSpaceError(rc, self.lib.as_status_message(rc).decode())
+        self.h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def check(self, rc):
+        if rc:
+            msg = self.lib.as_last_error(self.h).decode() or self.lib.as_status_message(rc).decode()
+            raise ArrowSpaceError(rc, msg)
+
+    def set_stream(self, stream):
+        self.check(self.lib.as_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def synchronize(self):
+        self.check(self.lib.as_ctx_synchronize(self.h))
+
+    def set_option(self, name, value):
+        self.check(self.lib.as_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def stat(self, name):
+        return int(self.lib.as_ctx_get_stat(self.h, name.encode()))
+
+    def profile(self, on=True):
+        self.lib.as_profile_enable(self.h, int(on))
+        self.lib.as_profile_reset(self.h)
+
+    def profile_get(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        self.lib.as_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, int(n.value)
+
+    def profile_all(self):
+        buf = C.create_string_buffer(4096)
+        self.lib.as_profile_names(self.h, buf, 4096)
+        return {n: self.profile_get(n) for n in buf.value.decode().split("\n") if n}
+
+    def close(self):
+        if self.h:
+            self.lib.as_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def _adopt_torch_stream(ctx):
+    """Device tensors are produced on PyTorch's current stream: run the library on it too."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    if getattr(ctx, "_stream", "own") != st:
+        ctx.set_stream(st)
+        ctx._stream = st
+
+
+def _f64(a, ctx=None):
+    if _lib.is_tensor(a):
+        if a.is_cuda and ctx is not None:
+            _adopt_torch_stream(ctx)
+        return a
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _shape2(a):
+    s = tuple(a.shape)
+    if len(s) != 2:
+        raise ArrowSpaceError(_lib.AS_ERR_SHAPE, "expected a 2-D matrix")
+    return int(s[0]), int(s[1])
+
+
+class CsrMatrix:
+    """Device-resident CSR (as_csr handle) with a lazily exported host view; the counterpart of
+    sprs::CsMat<f64> held in GraphLaplacian.matrix."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        self._host = None
+
+    @classmethod
+    def from_host(cls, ctx, indptr, indices, data):
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.as_csr_import(ctx.h, len(indptr) - 1, len(indices), ptr(indptr), ptr(indices), ptr(data),
+                                        C.byref(h)))
+        return cls(ctx, h)
+
+    def shape(self):
+        n = int(self.ctx.lib.as_csr_n(self.h))
+        return (n, n)
+
+    def nnz(self):
+        return int(self.ctx.lib.as_csr_nnz(self.h))
+
+    def to_host(self):
+        if self._host is None:
+            n, nnz = self.shape()[0], self.nnz()
+            indptr = np.empty(n + 1, dtype=np.uint64)
+            indices = np.empty(nnz, dtype=np.uint64)
+            data = np.empty(nnz, dtype=np.float64)
+            self.ctx.check(self.ctx.lib.as_csr_export(self.ctx.h, self.h, ptr(indptr), ptr(indices), ptr(data)))
+            self._host = (indptr, indices, data)
+        return self._host
+
+    def indptr(self):
+        return self.to_host()[0]
+
+    def indices(self):
+        return self.to_host()[1]
+
+    def data(self):
+        return self.to_host()[2]
+
+    def to_dense(self):
+        indptr, indices, data = self.to_host()
+        n = len(indptr) - 1
+        M = np.zeros((n, n))
+        for i in range(n):
+            s, e = int(indptr[i]), int(indptr[i + 1])
+            M[i, indices[s:e].astype(np.int64)] = data[s:e]
+        return M
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.as_csr_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class GraphLaplacian:
+    """src/graph.rs:127-135: init_data (the matrix the graph was built from, rows = nodes), the
+    CSR Laplacian, nnodes (= item count of the ORIGINAL data, not the matrix dimension) and the
+    GraphParams."""
+
+    def __init__(self, init_data, matrix, nnodes, graph_params):
+        self.init_data, self.matrix, self.nnodes, self.graph_params = init_data, matrix, nnodes, graph_params
+
+    @staticmethod
+    def sparsity(matrix):  # src/graph.rs:572-578
+        n = matrix.shape()[0]
+        return 1.0 - matrix.nnz() / float(n * n)
+
+
+def build_laplacian_matrix(transposed, params, n_items=None, ctx=None):
+    """src/laplacian.rs:122-178.  `transposed` is the matrix whose ROWS ARE NODES."""
+    ctx = ctx or default_context()
+    X = _f64(transposed, ctx)
+    if len(X.shape) != 2:
+        raise ArrowSpaceError(_lib.AS_ERR_SHAPE, "items should be at least of shape (2,2)")
+    n, d = _shape2(X)
+    gp = params.to_c()
+    h = C.c_void_p()
+    ctx.check(ctx.lib.as_build_laplacian(ctx.h, ptr(X), n, d, C.byref(gp), C.byref(h)))
+    return GraphLaplacian(X, CsrMatrix(ctx, h), n if n_items is None else int(n_items), params)
+
+
+def knn_cosine(rows, params, row_begin=0, row_count=None, ctx=None):
+    """Stage-level neighbour table (CosinePair::query_row_top_k for a row range)."""
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, d = _shape2(X)
+    row_count = n - row_begin if row_count is None else row_count
+    K = params.topk + 1
+    idx = np.empty((row_count, K), dtype=np.uint64)
+    dist = np.empty((row_count, K), dtype=np.float64)
+    gp = params.to_c()
+    ctx.check(ctx.lib.as_knn_cosine(ctx.h, ptr(X), n, d, row_begin, row_count, C.byref(gp), ptr(idx), ptr(dist)))
+    return idx, dist
+
+
+def laplacian_from_knn(nbr_idx, nbr_dist, params, ctx=None):
+    ctx = ctx or default_context()
+    nbr_idx = nbr_idx if _lib.is_tensor(nbr_idx) else np.ascontiguousarray(nbr_idx, dtype=np.uint64)
+    nbr_dist = _f64(nbr_dist, ctx)
+    n = int(nbr_idx.shape[0])
+    gp = params.to_c()
+    h = C.c_void_p()
+    ctx.check(ctx.lib.as_laplacian_from_knn(ctx.h, ptr(nbr_idx), ptr(nbr_dist), n, C.byref(gp), C.byref(h)))
+    return CsrMatrix(ctx, h)
+
+
+class GraphFactory:
+    @staticmethod
+    def build_laplacian_matrix_from_k_cluster(clustered, eps, k, topk, p, sigma_override, normalise, sparsity_check,
+                                              n_items, ctx=None):
+        """src/graph.rs:149-204: transposes the X x F centroid matrix (nodes = features) and
+        applies the optional sparsity check."""
+        Xc = np.ascontiguousarray(np.asarray(clustered, dtype=np.float64))
+        assert Xc.shape[0] <= n_items
+        params = GraphParams(eps, k, topk, p, sigma_override, normalise, sparsity_check)
+        gl = build_laplacian_matrix(np.ascontiguousarray(Xc.T), params, n_items, ctx=ctx)
+        if sparsity_check:
+            s = GraphLaplacian.sparsity(gl.matrix)
+            if s > 0.95:
+                raise ArrowSpaceError(_lib.AS_ERR_TOO_SPARSE, "Resulting laplacian matrix is too sparse %r" % s)
+        assert gl.nnodes == n_items
+        return gl
+
+
+class ArrowItem:
+    """src/core.rs:84-239."""
+
+    def __init__(self, item, lambda_):
+        self.item = np.asarray(item, dtype=np.float64)
+        self.lambda_ = float(lambda_)
+
+    def __len__(self):
+        return len(self.item)
+
+
+def select_tau(values, mode, ctx=None):
+    """TauMode::select_tau (src/taumode.rs:87-127) for one slice or a batch of rows."""
+    ctx = ctx or default_context()
+    v = np.asarray(values, dtype=np.float64)
+    single = v.ndim == 1
+    v = np.ascontiguousarray(v.reshape(1, -1) if single else v)
+    out = np.empty(v.shape[0], dtype=np.float64)
+    ctx.check(ctx.lib.as_select_tau(ctx.h, ptr(v) if v.size else None, v.shape[0], v.shape[1], mode.kind, mode.arg,
+                                    ptr(out)))
+    return float(out[0]) if single else out
+
+
+def compute_synthetic_lambda(x, matrix, tau, ctx=None):
+    """TauMode::compute_synthetic_lambda_csr (src/taumode.rs:552-660) for one vector."""
+    ctx = ctx or matrix.ctx
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(1, -1))
+    out = np.empty(1, dtype=np.float64)
+    ctx.check(ctx.lib.as_compute_taumode(ctx.h, ptr(x), 1, x.shape[1], matrix.h, TauMode.FIXED, float(tau), ptr(out)))
+    return float(out[0])
+
+
+class ArrowSpace:
+    """src/core.rs:366-1006 restricted to the lambda-tau path: dense N x F data, per-item
+    lambdas, taumode."""
+
+    def __init__(self, data, taumode=TauMode.Median, ctx=None):
+        self.ctx = ctx or default_context()
+        self.data = _f64(data, self.ctx)
+        self.nitems, self.nfeatures = _shape2(self.data)
+        self.taumode = taumode
+        self.lambdas_ = None
+        self._index = None
+        self.id_offset = 0
+
+    def lambdas(self):
+        return self.lambdas_
+
+    def get_item(self, i):  # src/core.rs:586-594
+        assert i < self.nitems, "item index out of bounds"
+        row = self.data[i]
+        row = row.cpu().numpy() if _lib.is_tensor(row) else row
+        return ArrowItem(np.array(row), float(self.lambdas_[i]))
+
+    def compute_taumode(self, gl):
+        """EigenMaps::compute_taumode (src/eigenmaps.rs:358-383) ->
+        TauMode::compute_taumode_lambdas_parallel (src/taumode.rs:174-312)."""
+        lib, ctx = self.ctx.lib, self.ctx
+        if _lib.is_tensor(self.data):
+            import torch
+            out = torch.empty(self.nitems, dtype=torch.float64, device=self.data.device)
+        else:
+            out = np.empty(self.nitems, dtype=np.float64)
+        ctx.check(lib.as_compute_taumode(ctx.h, ptr(self.data), self.nitems, self.nfeatures, gl.matrix.h,
+                                         self.taumode.kind, self.taumode.arg, ptr(out)))
+        self.update_lambdas(out)
+
+    def update_lambdas(self, lambdas):  # src/core.rs:979-1005
+        assert len(lambdas) == self.nitems
+        self.lambdas_ = lambdas
+        self._drop_index()
+
+    def prepare_query_item(self, item, gl):
+        """src/core.rs:533-549: returns the query's lambda."""
+        return float(self.prepare_query_items(np.asarray(item, dtype=np.float64).reshape(1, -1), gl)[0])
+
+    def prepare_query_items(self, queries, gl):
+        lib, ctx = self.ctx.lib, self.ctx
+        Q = _f64(queries, ctx)
+        nq, f = _shape2(Q)
+        if f != self.nfeatures:  # src/core.rs:510-516
+            raise ArrowSpaceError(_lib.AS_ERR_DIM, "Query dimension %d doesn't match index original dimension %d"
+                                  % (f, self.nfeatures))
+        if _lib.is_tensor(Q):
+            import torch
+            out = torch.empty(nq, dtype=torch.float64, device=Q.device)
+        else:
+            out = np.empty(nq, dtype=np.float64)
+        ctx.check(lib.as_prepare_query_items(ctx.h, ptr(Q), nq, f, gl.matrix.h, self.taumode.kind, self.taumode.arg,
+                                             ptr(out)))
+        return out
+
+    def _ensure_index(self):
+        if self._index is None:
+            if self.lambdas_ is None:  # src/eigenmaps.rs:425-431
+                raise ArrowSpaceError(_lib.AS_ERR_ARG, "call compute_taumode(...) before search")
+            h = C.c_void_p()
+            lam = self.lambdas_ if _lib.is_tensor(self.lambdas_) else np.ascontiguousarray(self.lambdas_, np.float64)
+            self._lam_keep = lam
+            self.ctx.check(self.ctx.lib.as_index_create(self.ctx.h, ptr(self.data), ptr(lam), self.nitems,
+                                                        self.nfeatures, C.byref(h)))
+            self._index = h
+        return self._index
+
+    def _drop_index(self):
+        if getattr(self, "_index", None):
+            self.ctx.lib.as_index_destroy(self._index)
+        self._index = None
+
+    def search_lambda_aware(self, query, k, alpha):
+        """src/core.rs:760-798: Vec<(usize, f64)> of the k best (index, score)."""
+        idx, sc = self.search_lambda_aware_batch(query.item.reshape(1, -1), np.array([query.lambda_]), k, alpha)
+        return [(int(i), float(s)) for i, s in zip(idx[0], sc[0]) if int(i) != U64_MAX]
+
+    def search_lambda_aware_batch(self, queries, q_lambdas, k, alpha):
+        lib, ctx = self.ctx.lib, self.ctx
+        ix = self._ensure_index()
+        Q = _f64(queries, ctx)
+        nq, f = _shape2(Q)
+        assert f == self.nfeatures, "items should be of the same length"  # src/core.rs:157-161
+        QL = _f64(q_lambdas, ctx)
+        kk = min(int(k), self.nitems)
+        if _lib.is_tensor(Q):
+            import torch
+            idx = torch.empty((nq, kk), dtype=torch.int64, device=Q.device)
+            sc = torch.empty((nq, kk), dtype=torch.float64, device=Q.device)
+        else:
+            idx = np.empty((nq, kk), dtype=np.uint64)
+            sc = np.empty((nq, kk), dtype=np.float64)
+        if kk > 0 and nq > 0:
+            ctx.check(lib.as_search_lambda_aware(ctx.h, ix, ptr(Q), ptr(QL), nq, kk, float(alpha), self.id_offset,
+                                                 ptr(idx), ptr(sc)))
+        return idx, sc
+
+    def search(self, item, gl, k, alpha):
+        """EigenMaps::search (src/eigenmaps.rs:410-455): prepare + search in one call."""
+        lam = self.prepare_query_item(item, gl)
+        return self.search_lambda_aware(ArrowItem(item, lam), k, alpha)
+
+    def __del__(self):
+        try:
+            self._drop_index()
+        except Exception:
+            pass
+
+
+class ArrowSpaceBuilder:
+    """src/builder.rs:20-455 (the lambda-tau subset)."""
+
+    def __init__(self, ctx=None):
+        # defaults: src/builder.rs:59-91
+        self.lambda_eps, self.lambda_k, self.lambda_topk, self.lambda_p = 1e-3, 6, 3, 2.0
+        self.lambda_sigma = None
+        self.normalise = False
+        self.sparsity_check = False
+        self.synthesis = TauMode.Median
+        self.ctx = ctx
+
+    @staticmethod
+    def new(ctx=None):
+        return ArrowSpaceBuilder(ctx)
+
+    def with_lambda_graph(self, eps, k, topk, p, sigma_override=None):  # src/builder.rs:109-137
+        self.lambda_eps, self.lambda_k, self.lambda_topk = eps, k, topk
+        self.lambda_p, self.lambda_sigma = p, sigma_override
+        return self
+
+    def with_synthesis(self, tau_mode):  # :141-145
+        self.synthesis = tau_mode
+        return self
+
+    def with_normalisation(self, normalise):
+        self.normalise = bool(normalise)
+        return self
+
+    def with_sparsity_check(self, flag):
+        self.sparsity_check = bool(flag)
+        return self
+
+    def with_inline_sampling(self, sampler):
+        if sampler is not None:
+            raise ArrowSpaceError(_lib.AS_ERR_UNSUPPORTED, "inline sampling is outside the accelerated path")
+        return self
+
+    def with_seed(self, seed):
+        return self
+
+    def define_result_k(self):  # src/builder.rs:225-233
+        self.lambda_topk = int(_lib.load().as_define_result_k(self.lambda_k, self.lambda_topk))
+
+    def graph_params(self):
+        return GraphParams(self.lambda_eps, self.lambda_k, self.lambda_topk, self.lambda_p, self.lambda_sigma,
+                           self.normalise, self.sparsity_check)
+
+    def build(self, rows, centroids=None):
+        """src/builder.rs:249-455 with the clustering stage replaced by supplied centroids
+        (X x F).  Stage 2: eigenmaps (F x F Laplacian over centroids^T); stage 4: taumode."""
+        ctx = self.ctx or default_context()
+        self.define_result_k()
+        aspace = ArrowSpace(rows, self.synthesis, ctx)
+        if centroids is None:
+            centroids = aspace.data.cpu().numpy() if _lib.is_tensor(aspace.data) else aspace.data
+        gl = GraphFactory.build_laplacian_matrix_from_k_cluster(
+            centroids, self.lambda_eps, self.lambda_k, self.lambda_topk, self.lambda_p, self.lambda_sigma,
+            self.normalise, self.sparsity_check, aspace.nitems, ctx=ctx)
+        aspace.compute_taumode(gl)
+        return aspace, gl
+
+    def build_item_graph(self, rows):
+        """build_laplacian_matrix on the untransposed rows (items are nodes), as
+        src/energymaps.rs:270 and benches/base_laplacian_bench.rs:62-70 call it."""
+        ctx = self.ctx or default_context()
+        self.define_result_k()
+        return build_laplacian_matrix(rows, self.graph_params(), None, ctx=ctx)

@@ -1,0 +1,445 @@
+// api.hip -- the extern "C" surface declared in include/arrowspace_hip.h.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+using namespace asx;
+
+namespace {
+
+__global__ void widen_idx_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t offset,
+                                 uint64_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] == kNoIdx ? ~0ull : (uint64_t)in[i] + offset;
+}
+__global__ void narrow_idx_kernel(const uint64_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] == ~0ull ? kNoIdx : (uint32_t)in[i];
+}
+__global__ void negate_kernel(const double *__restrict__ in, uint64_t n, double *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -in[i];
+}
+__global__ void any_zero_kernel(const double *__restrict__ v, uint64_t n, int *flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && v[i] == 0.0) atomicOr(flag, 1);
+}
+
+int check_ctx(as_ctx *ctx) {
+  if (!ctx) return AS_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AS_ERR_HIP, "hipSetDevice failed");
+  ctx->err.clear();
+  return AS_OK;
+}
+
+int knn_dispatch(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d, uint64_t row_begin,
+                 uint64_t row_count, uint32_t K, int rectify, uint32_t *idx, double *dist) {
+  if (ctx->opt_knn_mfma) return knn_mfma(ctx, rows, norms, n, d, row_begin, row_count, K, rectify, idx, dist);
+  return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, idx, dist, 0);
+}
+
+int validate_graph_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const as_graph_params *gp) {
+  if (!rows || !gp) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n < 2 || d < 2) {
+    // the reference prints (rows, cols) of the matrix as passed: src/laplacian.rs:128-134
+    return fail(ctx, AS_ERR_SHAPE,
+                "items should be at least of shape (2,2): (" + std::to_string(n) + "," + std::to_string(d) + ")");
+  }
+  if (n >= 0xFFFFFFFFull || d >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_nodes/dim must be < 2^32-1");
+  if (gp->normalise) return fail(ctx, AS_ERR_UNSUPPORTED, "normalise = true (StandardScaler) is not on the accelerated path");
+  if (gp->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  return AS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int as_abi_version(void) { return AS_ABI_VERSION; }
+
+const char *as_status_message(int status) {
+  switch (status) {
+    case AS_OK: return "ok";
+    case AS_ERR_SHAPE: return "items should be at least of shape (2,2)";
+    case AS_ERR_NONFINITE: return "Query item contains invalid values (NaN or infinity). All values must be finite.";
+    case AS_ERR_ZERO_LAMBDA: return "Lambda of the item is 0.0, prepare the item before searching";
+    case AS_ERR_NAN_SCORE: return "NaN similarity score (partial_cmp on NaN)";
+    case AS_ERR_DIM: return "dimension mismatch between graph and signal";
+    case AS_ERR_TOO_SPARSE: return "Resulting laplacian matrix is too sparse";
+    case AS_ERR_ARG: return "invalid argument";
+    case AS_ERR_UNSUPPORTED: return "unsupported on the accelerated path";
+    case AS_ERR_HIP: return "HIP runtime error";
+    case AS_ERR_NO_DEVICE: return "no gfx950 device available (libarrowspace_hip has no CPU fallback)";
+    default: return "unknown status";
+  }
+}
+
+int as_ctx_create(int device, as_ctx **out) {
+  if (!out) return AS_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return AS_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) return AS_ERR_ARG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return AS_ERR_HIP;
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return AS_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return AS_ERR_HIP;
+  as_ctx *c = new as_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return AS_ERR_HIP;
+  }
+  c->own_stream = true;
+  // keep freed stream-ordered allocations cached instead of returning them to the OS
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+    uint64_t thr = ~0ull;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+  }
+  *out = c;
+  return AS_OK;
+}
+
+void as_ctx_destroy(as_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_resolve(ctx);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *as_last_error(const as_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int as_ctx_set_stream(as_ctx *ctx, void *hip_stream) {
+  AS_TRY(check_ctx(ctx));
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_resolve(ctx);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->own_stream = false;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL = HIP's default (null) stream
+  return AS_OK;
+}
+
+int as_ctx_synchronize(as_ctx *ctx) {
+  AS_TRY(check_ctx(ctx));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return AS_ERR_ARG;
+  const std::string n(name);
+  if (n == "knn_mfma") ctx->opt_knn_mfma = value;
+  else if (n == "search_mfma") ctx->opt_search_mfma = value;
+  else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
+  else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
+  return AS_OK;
+}
+
+int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name) {
+  if (!ctx || !name) return -1;
+  auto it = ctx->stats.find(name);
+  return it == ctx->stats.end() ? -1 : it->second;
+}
+
+int as_profile_enable(as_ctx *ctx, int on) {
+  if (!ctx) return AS_ERR_ARG;
+  ctx->prof_on = on != 0;
+  return AS_OK;
+}
+int as_profile_reset(as_ctx *ctx) {
+  if (!ctx) return AS_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_resolve(ctx);
+  ctx->prof.clear();
+  return AS_OK;
+}
+int as_profile_get(as_ctx *ctx, const char *name, double *ms_total, uint64_t *launches) {
+  if (!ctx || !name) return AS_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  prof_resolve(ctx);
+  auto it = ctx->prof.find(name);
+  if (ms_total) *ms_total = it == ctx->prof.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+  return AS_OK;
+}
+int as_profile_names(as_ctx *ctx, char *buf, uint64_t cap) {
+  if (!ctx || !buf || cap == 0) return AS_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  prof_resolve(ctx);
+  std::string s;
+  for (auto &kv : ctx->prof) s += kv.first + "\n";
+  std::strncpy(buf, s.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return AS_OK;
+}
+
+uint64_t as_define_result_k(uint64_t k, uint64_t topk) {
+  if (k <= 5) return 3;
+  if (k < 10) return 4;
+  return topk;
+}
+
+// ---- graph --------------------------------------------------------------------------------
+
+int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                  uint64_t row_count, const as_graph_params *params, uint64_t *nbr_idx, double *nbr_dist) {
+  AS_TRY(check_ctx(ctx));
+  AS_TRY(validate_graph_args(ctx, rows, n_nodes, dim, params));
+  if (!nbr_idx || !nbr_dist) return fail(ctx, AS_ERR_ARG, "null output");
+  if (row_begin + row_count > n_nodes) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
+  const uint32_t K = (uint32_t)params->topk + 1;
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n_nodes * dim));
+  DevBuf<double> norms;
+  AS_TRY(norms.alloc(ctx, n_nodes));
+  AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
+  DevBuf<uint32_t> idx32;
+  AS_TRY(idx32.alloc(ctx, row_count * K));
+  DevOut<double> D;
+  AS_TRY(D.bind(ctx, nbr_dist, row_count * K));
+  DevOut<uint64_t> I;
+  AS_TRY(I.bind(ctx, nbr_idx, row_count * K));
+  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p));
+  hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
+                     row_count * K, 0ull, I.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(D.finish(ctx));
+  AS_TRY(I.finish(ctx));
+  return AS_OK;
+}
+
+int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
+                          const as_graph_params *params, as_csr **out) {
+  AS_TRY(check_ctx(ctx));
+  if (!nbr_idx || !nbr_dist || !params || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n_nodes < 2 || n_nodes >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad n_nodes");
+  if (params->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  const uint32_t K = (uint32_t)params->topk + 1;
+  DevIn<uint64_t> I;
+  AS_TRY(I.bind(ctx, nbr_idx, n_nodes * K));
+  DevIn<double> D;
+  AS_TRY(D.bind(ctx, nbr_dist, n_nodes * K));
+  DevBuf<uint32_t> idx32;
+  AS_TRY(idx32.alloc(ctx, n_nodes * K));
+  hipLaunchKernelGGL(narrow_idx_kernel, dim3(cdiv(n_nodes * K, 256)), dim3(256), 0, ctx->stream, I.p, n_nodes * K,
+                     idx32.p);
+  return laplacian_from_knn(ctx, idx32.p, D.p, n_nodes, K, params, out);
+}
+
+int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim,
+                       const as_graph_params *params, as_csr **out) {
+  AS_TRY(check_ctx(ctx));
+  if (!out) return fail(ctx, AS_ERR_ARG, "null output");
+  *out = nullptr;
+  AS_TRY(validate_graph_args(ctx, rows, n_nodes, dim, params));
+  const uint32_t K = (uint32_t)params->topk + 1;
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n_nodes * dim));
+  DevBuf<double> norms, dist;
+  DevBuf<uint32_t> idx;
+  AS_TRY(norms.alloc(ctx, n_nodes));
+  AS_TRY(idx.alloc(ctx, n_nodes * K));
+  AS_TRY(dist.alloc(ctx, n_nodes * K));
+  AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
+  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, 0, n_nodes, K, params->rectify, idx.p, dist.p));
+  AS_TRY(laplacian_from_knn(ctx, idx.p, dist.p, n_nodes, K, params, out));
+  return AS_OK;
+}
+
+uint64_t as_csr_n(const as_csr *m) { return m ? m->n : 0; }
+uint64_t as_csr_nnz(const as_csr *m) { return m ? m->nnz : 0; }
+
+int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indices, double *data) {
+  AS_TRY(check_ctx(ctx));
+  if (!m) return fail(ctx, AS_ERR_ARG, "null csr");
+  auto copy = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+    if (!dst || bytes == 0) return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          ctx->stream);
+  };
+  AS_HIP(ctx, copy(indptr, m->indptr, sizeof(uint64_t) * (m->n + 1)));
+  AS_HIP(ctx, copy(indices, m->indices, sizeof(uint64_t) * m->nnz));
+  AS_HIP(ctx, copy(data, m->data, sizeof(double) * m->nnz));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr, const uint64_t *indices,
+                  const double *data, as_csr **out) {
+  AS_TRY(check_ctx(ctx));
+  if (!indptr || (nnz && (!indices || !data)) || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  as_csr *m = new as_csr();
+  m->device = ctx->device;
+  m->n = n;
+  m->nnz = nnz;
+  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * (n + 1)));
+  AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
+  AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
+  auto kind = [&](const void *p) { return is_device_ptr(p) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; };
+  AS_HIP(ctx, hipMemcpyAsync(m->indptr, indptr, sizeof(uint64_t) * (n + 1), kind(indptr), ctx->stream));
+  if (nnz) {
+    AS_HIP(ctx, hipMemcpyAsync(m->indices, indices, sizeof(uint64_t) * nnz, kind(indices), ctx->stream));
+    AS_HIP(ctx, hipMemcpyAsync(m->data, data, sizeof(double) * nnz, kind(data), ctx->stream));
+  }
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = m;
+  return AS_OK;
+}
+
+void as_csr_free(as_csr *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipFree(m->indptr);
+  (void)hipFree(m->indices);
+  (void)hipFree(m->data);
+  if (m->packed) (void)hipFree(m->packed);
+  delete m;
+}
+
+// ---- lambda-tau ----------------------------------------------------------------------------
+
+static int lambdas_common(as_ctx *ctx, const double *items, uint64_t n, uint64_t F, const as_csr *L, int mode,
+                          double arg, bool check_finite, double *out) {
+  AS_TRY(check_ctx(ctx));
+  if (!items || !L || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (F >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_features too large");
+  DevIn<double> X;
+  AS_TRY(X.bind(ctx, items, n * F));
+  DevOut<double> O;
+  AS_TRY(O.bind(ctx, out, n));
+  AS_TRY(taumode_lambdas(ctx, X.p, n, F, const_cast<as_csr *>(L), mode, arg, check_finite, O.p));
+  AS_TRY(O.finish(ctx));
+  return AS_OK;
+}
+
+int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L,
+                       int tau_mode, double tau_arg, double *lambdas_out) {
+  return lambdas_common(ctx, items, n_items, n_features, L, tau_mode, tau_arg, false, lambdas_out);
+}
+
+int as_prepare_query_items(as_ctx *ctx, const double *queries, uint64_t nq, uint64_t n_features, const as_csr *L,
+                           int tau_mode, double tau_arg, double *lambdas_out) {
+  return lambdas_common(ctx, queries, nq, n_features, L, tau_mode, tau_arg, true, lambdas_out);
+}
+
+int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int tau_mode, double tau_arg,
+                  double *taus_out) {
+  AS_TRY(check_ctx(ctx));
+  if ((!rows && n_rows * len) || !taus_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (len == 0) {  // empty slices: every mode but a valid Fixed returns the floor
+    std::vector<double> h(n_rows, (tau_mode == AS_TAU_FIXED && std::isfinite(tau_arg) && tau_arg > 0.0) ? tau_arg : kTauFloor);
+    AS_HIP(ctx, hipMemcpy(taus_out, h.data(), sizeof(double) * n_rows, hipMemcpyDefault));
+    return AS_OK;
+  }
+  DevIn<double> X;
+  AS_TRY(X.bind(ctx, rows, n_rows * len));
+  DevOut<double> O;
+  AS_TRY(O.bind(ctx, taus_out, n_rows));
+  AS_TRY(select_tau_rows(ctx, X.p, n_rows, len, tau_mode, tau_arg, O.p));
+  AS_TRY(O.finish(ctx));
+  return AS_OK;
+}
+
+// ---- search --------------------------------------------------------------------------------
+
+int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uint64_t n_items, uint64_t n_features,
+                    as_index **out) {
+  AS_TRY(check_ctx(ctx));
+  if (!items || !lambdas || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n_items == 0 || n_features == 0 || n_items >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad index shape");
+  as_index *ix = new as_index();
+  ix->device = ctx->device;
+  ix->n = n_items;
+  ix->d = n_features;
+  if (is_device_ptr(items)) {
+    ix->items = items;  // borrowed: the caller keeps it alive (ArrowSpace.data)
+  } else {
+    double *p;
+    AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items * n_features));
+    AS_HIP(ctx, hipMemcpyAsync(p, items, sizeof(double) * n_items * n_features, hipMemcpyHostToDevice, ctx->stream));
+    ix->items = p;
+    ix->own_items = true;
+  }
+  if (is_device_ptr(lambdas)) {
+    ix->lambdas = lambdas;
+  } else {
+    double *p;
+    AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items));
+    AS_HIP(ctx, hipMemcpyAsync(p, lambdas, sizeof(double) * n_items, hipMemcpyHostToDevice, ctx->stream));
+    ix->lambdas = p;
+    ix->own_lambdas = true;
+  }
+  AS_HIP(ctx, hipMalloc((void **)&ix->norms, sizeof(double) * n_items));
+  AS_TRY(row_norms(ctx, ix->items, n_items, n_features, ix->norms));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = ix;
+  return AS_OK;
+}
+
+void as_index_destroy(as_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  if (ix->own_items) (void)hipFree((void *)ix->items);
+  if (ix->own_lambdas) (void)hipFree((void *)ix->lambdas);
+  (void)hipFree(ix->norms);
+  if (ix->packed) (void)hipFree(ix->packed);
+  delete ix;
+}
+
+uint64_t as_index_nitems(const as_index *ix) { return ix ? ix->n : 0; }
+
+int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *queries, const double *q_lambdas,
+                           uint64_t nq, uint64_t k, double alpha, uint64_t id_offset, uint64_t *idx_out,
+                           double *score_out) {
+  AS_TRY(check_ctx(ctx));
+  if (!index || (nq && (!queries || !q_lambdas))) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (nq == 0 || k == 0) return AS_OK;
+  if (!idx_out || !score_out) return fail(ctx, AS_ERR_ARG, "null output");
+  if (k > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "k must be <= 4096");
+  const uint64_t d = index->d;
+  DevIn<double> Q, QL;
+  AS_TRY(Q.bind(ctx, queries, nq * d));
+  AS_TRY(QL.bind(ctx, q_lambdas, nq));
+  // assert_ne!(query.lambda, 0.0), src/core.rs:773-776
+  DevBuf<int> flag;
+  AS_TRY(flag.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(any_zero_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, ctx->stream, QL.p, nq, flag.p);
+  int h = 0;
+  AS_HIP(ctx, hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h) return fail(ctx, AS_ERR_ZERO_LAMBDA, as_status_message(AS_ERR_ZERO_LAMBDA));
+
+  const uint32_t kk = (uint32_t)k;
+  DevBuf<double> qn, keys;
+  DevBuf<uint32_t> idx32;
+  AS_TRY(qn.alloc(ctx, nq));
+  AS_TRY(keys.alloc(ctx, nq * kk));
+  AS_TRY(idx32.alloc(ctx, nq * kk));
+  AS_TRY(row_norms(ctx, Q.p, nq, d, qn.p));
+  if (ctx->opt_search_mfma && kk <= 56)
+    AS_TRY(search_mfma(ctx, const_cast<as_index *>(index), Q.p, qn.p, QL.p, nq, kk, alpha, idx32.p, keys.p));
+  else
+    AS_TRY(search_exact(ctx, index, Q.p, qn.p, QL.p, nullptr, nq, nq, kk, alpha, idx32.p, keys.p));
+  DevOut<double> S;
+  DevOut<uint64_t> I;
+  AS_TRY(S.bind(ctx, score_out, nq * kk));
+  AS_TRY(I.bind(ctx, idx_out, nq * kk));
+  hipLaunchKernelGGL(negate_kernel, dim3(cdiv(nq * kk, 256)), dim3(256), 0, ctx->stream, keys.p, nq * kk, S.p);
+  hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(nq * kk, 256)), dim3(256), 0, ctx->stream, idx32.p, nq * kk,
+                     id_offset, I.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(S.finish(ctx));
+  AS_TRY(I.finish(ctx));
+  return AS_OK;
+}
+
+}  // extern "C"

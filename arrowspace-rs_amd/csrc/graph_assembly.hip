@@ -1,0 +1,363 @@
+// graph_assembly.hip -- K3..K5: neighbour table -> eps filter + kernel weights (+ optional 50 %
+// pruning) -> union symmetrisation -> CSR Laplacian with explicit diagonal.
+// Replaces src/laplacian.rs:217-417 (_build_adjacency's post-processing,
+// _symmetrise_adjancency, _build_sparse_laplacian) and TriMat::to_csr (:160).
+//
+// The reference symmetrises through a concurrent hash map and gathers each row by scanning the
+// whole map (O(n*E)).  Here: count in-edges, prefix-sum, scatter reverse edges, per-row union,
+// per-row sort.  All of it is HBM-bound integer/byte work (n*(topk+1)*16 B in, nnz*16 B out).
+#include "common.h"
+
+namespace asx {
+
+constexpr int kMaxK = 64;
+
+// ---- device exclusive scan (u32 in, u64 out, out[n] = total) -------------------------------
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums(const uint32_t *__restrict__ in, uint64_t n,
+                                                              uint64_t *__restrict__ bsum) {
+  __shared__ uint64_t s[kScanBlock / 64];
+  const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+  uint64_t v = i < n ? in[i] : 0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) t += s[w];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+__global__ void scan_of_sums(uint64_t *bsum, uint64_t nb, uint64_t *total_out) {
+  // single thread; nb <= a few thousand
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint64_t run = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+      uint64_t t = bsum[b];
+      bsum[b] = run;
+      run += t;
+    }
+    *total_out = run;
+  }
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_finish(const uint32_t *__restrict__ in, uint64_t n,
+                                                          const uint64_t *__restrict__ bsum,
+                                                          uint64_t *__restrict__ out) {
+  __shared__ uint64_t wsum[kScanBlock / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+  const uint64_t v = i < n ? in[i] : 0;
+  uint64_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint64_t base = bsum[blockIdx.x];
+  for (int w = 0; w < wv; ++w) base += wsum[w];
+  if (i < n) out[i] = base + inc - v;
+}
+
+int exclusive_scan_u32_u64(as_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out) {
+  const uint64_t nb = (n + kScanBlock - 1) / kScanBlock;
+  DevBuf<uint64_t> bsum;
+  AS_TRY(bsum.alloc(ctx, nb + 1));
+  if (n == 0) {
+    AS_HIP(ctx, hipMemsetAsync(out, 0, sizeof(uint64_t), ctx->stream));
+    return AS_OK;
+  }
+  hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, bsum.p);
+  hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(64), 0, ctx->stream, bsum.p, nb, out + n);
+  hipLaunchKernelGGL(scan_finish, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, bsum.p, out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// ---- K3a: degrees (src/laplacian.rs:217-227) -------------------------------------------------
+__global__ void degree_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist,
+                              uint32_t n, uint32_t K, double eps, uint32_t *__restrict__ deg,
+                              unsigned long long *__restrict__ deg_sum) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  if (i < n) {
+    for (uint32_t s = 0; s < K; ++s) {
+      const uint32_t j = nbr_idx[(uint64_t)i * K + s];
+      if (j != kNoIdx && j != i && nbr_dist[(uint64_t)i * K + s] <= eps) ++c;
+    }
+    deg[i] = c;
+  }
+  unsigned long long v = c;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(deg_sum, v);
+}
+
+// ---- K3b: weights + optional pruning (src/laplacian.rs:243-288) ------------------------------
+__device__ __forceinline__ double kernel_weight(double dist, double sigma, double p) {
+  // 1 / (1 + (dist/sigma)^p).  p = 2 and p = 1 are evaluated as the correctly rounded
+  // product / identity (what a correctly rounded powf returns); other exponents use pow().
+  const double x = __ddiv_rn(dist, sigma);
+  double xp;
+  if (p == 2.0) xp = __dmul_rn(x, x);
+  else if (p == 1.0) xp = x;
+  else xp = pow(x, p);
+  return __ddiv_rn(1.0, __dadd_rn(1.0, xp));
+}
+
+__global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist,
+                                 uint32_t n, uint32_t K, double eps, double sigma, double p,
+                                 const uint32_t *__restrict__ deg,
+                                 const unsigned long long *__restrict__ deg_sum,
+                                 uint32_t *__restrict__ adj_j, double *__restrict__ adj_w,
+                                 uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // avg_degree > 10.0 (src/laplacian.rs:229-230)
+  const bool sparsify = ((double)(*deg_sum) / (double)n) > 10.0;
+  uint32_t vj[kMaxK];
+  double vw[kMaxK], vs[kMaxK];
+  uint32_t len = 0;
+  for (uint32_t s = 0; s < K; ++s) {
+    const uint32_t j = nbr_idx[(uint64_t)i * K + s];
+    const double dist = nbr_dist[(uint64_t)i * K + s];
+    if (j == kNoIdx || j == i || !(dist <= eps)) continue;
+    const double w = kernel_weight(dist, sigma, p);
+    if (w > 1e-12) {
+      vj[len] = j;
+      vw[len] = w;
+      vs[len] = sparsify ? __dmul_rn(w, __dsqrt_rn((double)((uint64_t)deg[i] * (uint64_t)deg[j]))) : w;
+      ++len;
+    }
+  }
+  if (sparsify && len > 2) {
+    // stable insertion sort by score descending (reference: sort_unstable_by, ties unspecified)
+    for (uint32_t a = 1; a < len; ++a) {
+      const uint32_t tj = vj[a];
+      const double tw = vw[a], ts = vs[a];
+      uint32_t b = a;
+      while (b > 0 && vs[b - 1] < ts) {
+        vj[b] = vj[b - 1];
+        vw[b] = vw[b - 1];
+        vs[b] = vs[b - 1];
+        --b;
+      }
+      vj[b] = tj;
+      vw[b] = tw;
+      vs[b] = ts;
+    }
+    uint32_t keep = len / 2;
+    if (keep < 1) keep = 1;
+    len = keep;
+  }
+  adj_len[i] = len;
+  for (uint32_t s = 0; s < len; ++s) {
+    adj_j[(uint64_t)i * K + s] = vj[s];
+    adj_w[(uint64_t)i * K + s] = vw[s];
+    atomicAdd(&cnt_in[vj[s]], 1u);
+  }
+}
+
+// ---- K4: reverse edges ------------------------------------------------------------------------
+__global__ void fill_reverse_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+                                    const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
+                                    const uint64_t *__restrict__ rev_ptr, uint32_t *__restrict__ cursor,
+                                    uint32_t *__restrict__ rev_src, double *__restrict__ rev_w) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = adj_len[i];
+  for (uint32_t s = 0; s < len; ++s) {
+    const uint32_t j = adj_j[(uint64_t)i * K + s];
+    const uint64_t pos = rev_ptr[j] + atomicAdd(&cursor[j], 1u);
+    rev_src[pos] = i;
+    rev_w[pos] = adj_w[(uint64_t)i * K + s];
+  }
+}
+
+__device__ __forceinline__ bool in_adj(const uint32_t *aj, uint32_t len, uint32_t v) {
+  for (uint32_t s = 0; s < len; ++s)
+    if (aj[s] == v) return true;
+  return false;
+}
+
+// union size of row i: out-edges + in-edges whose source is not already an out-neighbour
+__global__ void union_count_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len,
+                                   uint32_t n, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+                                   const uint32_t *__restrict__ rev_src, uint32_t *__restrict__ ucnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = adj_len[i];
+  const uint32_t *aj = adj_j + (uint64_t)i * K;
+  uint32_t c = len;
+  for (uint64_t e = rev_ptr[i]; e < rev_ptr[i + 1]; ++e)
+    if (!in_adj(aj, len, rev_src[e])) ++c;
+  ucnt[i] = c;
+}
+
+__device__ void sort_row(uint32_t *col, double *w, uint32_t L) {
+  if (L <= 32) {
+    for (uint32_t a = 1; a < L; ++a) {
+      const uint32_t tc = col[a];
+      const double tw = w[a];
+      uint32_t b = a;
+      while (b > 0 && col[b - 1] > tc) {
+        col[b] = col[b - 1];
+        w[b] = w[b - 1];
+        --b;
+      }
+      col[b] = tc;
+      w[b] = tw;
+    }
+    return;
+  }
+  // heapsort for long (hub) rows
+  auto sift = [&](uint32_t start, uint32_t end) {
+    uint32_t root = start;
+    while (2 * root + 1 < end) {
+      uint32_t child = 2 * root + 1;
+      if (child + 1 < end && col[child] < col[child + 1]) ++child;
+      if (col[root] >= col[child]) return;
+      const uint32_t tc = col[root];
+      col[root] = col[child];
+      col[child] = tc;
+      const double tw = w[root];
+      w[root] = w[child];
+      w[child] = tw;
+      root = child;
+    }
+  };
+  for (int32_t s = (int32_t)(L / 2) - 1; s >= 0; --s) sift((uint32_t)s, L);
+  for (uint32_t end = L - 1; end > 0; --end) {
+    const uint32_t tc = col[0];
+    col[0] = col[end];
+    col[end] = tc;
+    const double tw = w[0];
+    w[0] = w[end];
+    w[end] = tw;
+    sift(0, end);
+  }
+}
+
+// ---- K5: per-row union, sort, degree, final CSR (src/laplacian.rs:339-341,369-411) -----------
+__global__ void write_rows_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+                                  const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
+                                  const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src,
+                                  const double *__restrict__ rev_w, const uint64_t *__restrict__ eptr,
+                                  uint32_t *__restrict__ ecol, double *__restrict__ ew,
+                                  uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
+                                  double *__restrict__ data) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    indptr[n] = eptr[n] + n;
+    return;
+  }
+  const uint32_t len = adj_len[i];
+  const uint32_t *aj = adj_j + (uint64_t)i * K;
+  const double *aw = adj_w + (uint64_t)i * K;
+  uint32_t *col = ecol + eptr[i];
+  double *w = ew + eptr[i];
+  uint32_t L = 0;
+  for (uint32_t s = 0; s < len; ++s) {
+    col[L] = aj[s];
+    w[L++] = aw[s];
+  }
+  for (uint64_t e = rev_ptr[i]; e < rev_ptr[i + 1]; ++e) {
+    const uint32_t src = rev_src[e];
+    if (!in_adj(aj, len, src)) {
+      col[L] = src;
+      w[L++] = rev_w[e];
+    }
+  }
+  sort_row(col, w, L);
+  double degree = 0.0;  // sequential sum in column order (src/laplacian.rs:369)
+  for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, w[s]);
+  uint64_t o = eptr[i] + i;
+  indptr[i] = o;
+  bool diag_done = false;
+  for (uint32_t s = 0; s < L; ++s) {
+    if (!diag_done && col[s] > i) {
+      indices[o] = i;
+      data[o++] = degree;
+      diag_done = true;
+    }
+    indices[o] = col[s];
+    data[o++] = -w[s];
+  }
+  if (!diag_done) {
+    indices[o] = i;
+    data[o] = degree;
+  }
+}
+
+int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n64,
+                       uint32_t K, const as_graph_params *gp, as_csr **out) {
+  if (K > kMaxK) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  const uint32_t n = (uint32_t)n64;
+  const double sigma = gp->has_sigma ? gp->sigma : 1.0;  // src/laplacian.rs:254
+  const unsigned gb = cdiv(n, 256);
+  hipStream_t st = ctx->stream;
+
+  DevBuf<uint32_t> deg, adj_j, adj_len, cnt_in, cursor, rev_src, ucnt, ecol;
+  DevBuf<double> adj_w, rev_w, ew;
+  DevBuf<unsigned long long> deg_sum;
+  DevBuf<uint64_t> rev_ptr, eptr;
+  AS_TRY(deg.alloc(ctx, n));
+  AS_TRY(deg_sum.alloc(ctx, 1));
+  AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
+  AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
+  AS_TRY(adj_len.alloc(ctx, n));
+  AS_TRY(cnt_in.alloc(ctx, n));
+  AS_TRY(cursor.alloc(ctx, n));
+  AS_TRY(rev_ptr.alloc(ctx, (size_t)n + 1));
+  AS_TRY(ucnt.alloc(ctx, n));
+  AS_TRY(eptr.alloc(ctx, (size_t)n + 1));
+  AS_HIP(ctx, hipMemsetAsync(deg_sum.p, 0, sizeof(unsigned long long), st));
+  AS_HIP(ctx, hipMemsetAsync(cnt_in.p, 0, sizeof(uint32_t) * n, st));
+  AS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * n, st));
+
+  uint64_t n_edges_dir = 0, n_union = 0;
+  {
+    ProfScope ps(ctx, "graph_assembly");
+    hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
+    hipLaunchKernelGGL(adjacency_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
+                       gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p);
+    AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, n, rev_ptr.p));
+    AS_HIP(ctx, hipMemcpyAsync(&n_edges_dir, rev_ptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(ctx, hipStreamSynchronize(st));
+    AS_TRY(rev_src.alloc(ctx, n_edges_dir));
+    AS_TRY(rev_w.alloc(ctx, n_edges_dir));
+    hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
+                       rev_ptr.p, cursor.p, rev_src.p, rev_w.p);
+    hipLaunchKernelGGL(union_count_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_len.p, n, K, rev_ptr.p,
+                       rev_src.p, ucnt.p);
+    AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, n, eptr.p));
+    AS_HIP(ctx, hipMemcpyAsync(&n_union, eptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(ctx, hipStreamSynchronize(st));
+  }
+  const uint64_t nnz = n_union + n;
+  as_csr *m = new as_csr();
+  m->device = ctx->device;
+  m->n = n;
+  m->nnz = nnz;
+  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * ((size_t)n + 1)));
+  AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
+  AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
+  AS_TRY(ecol.alloc(ctx, n_union));
+  AS_TRY(ew.alloc(ctx, n_union));
+  {
+    ProfScope ps(ctx, "graph_assembly");
+    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)n + 1, 256)), dim3(256), 0, st, adj_j.p, adj_w.p,
+                       adj_len.p, n, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,
+                       m->indices, m->data);
+  }
+  AS_HIP(ctx, hipGetLastError());
+  ctx->stats["graph_directed_edges"] = (int64_t)n_edges_dir;
+  ctx->stats["graph_nnz"] = (int64_t)nnz;
+  *out = m;
+  return AS_OK;
+}
+
+}  // namespace asx

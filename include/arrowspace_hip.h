@@ -1,0 +1,160 @@
+/*
+ * arrowspace_hip.h -- C ABI of libarrowspace_hip.so: the MI355X (gfx950) implementation of
+ * arrowspace's lambda-tau index build and lambda-aware search path.
+ *
+ * This is the drop-in boundary.  The reference (tuned-org-uk/arrowspace-rs v0.18.1) is a pure
+ * Rust rlib with no FFI of its own (Cargo.toml:60-62), so the boundary sits on the stage seams
+ * the reference already has (trait EigenMaps, src/eigenmaps.rs:93-172); every entry point below
+ * names the reference function whose body it replaces.  A Rust maintainer binds these with a
+ * plain `extern "C"` block (INTEGRATION.md shows the shim).
+ *
+ * Conventions
+ *   - All matrices are row-major f64; indices are u64 at the boundary (usize in the reference).
+ *   - Every data pointer may be a HOST pointer or a DEVICE (HBM) pointer; the library asks
+ *     the HIP runtime which it is.  Host buffers are staged over PCIe on the context's stream;
+ *     device buffers are used in place (this is how bench.py and the multi-GPU driver keep the
+ *     inputs resident in HBM).
+ *   - Inputs are borrowed for the duration of the call.  Outputs are either caller-provided
+ *     buffers or library-owned handles released by the matching *_free / *_destroy.
+ *   - Every function returns AS_OK (0) or an as_status error; as_last_error() gives the text.
+ *     The reference signals the same conditions by panicking; the messages are kept verbatim so
+ *     a host shim can re-panic with them.
+ *   - One as_ctx per host thread (not re-entrant).  There is NO CPU fallback: without a gfx950
+ *     device as_ctx_create fails with AS_ERR_NO_DEVICE.
+ */
+#ifndef ARROWSPACE_HIP_H
+#define ARROWSPACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AS_ABI_VERSION 1
+
+typedef enum {
+  AS_OK = 0,
+  AS_ERR_SHAPE = 1,       /* "items should be at least of shape (2,2): (d,n)"  src/laplacian.rs:129-134 */
+  AS_ERR_NONFINITE = 2,   /* "Query item contains invalid values (NaN or infinity)..." src/core.rs:534-537 */
+  AS_ERR_ZERO_LAMBDA = 3, /* "Lambda of the item is 0.0, prepare the item before searching" src/core.rs:773-776 */
+  AS_ERR_NAN_SCORE = 4,   /* partial_cmp().unwrap() on a NaN score, src/core.rs:785 */
+  AS_ERR_DIM = 5,         /* graph has more nodes than the signal has entries (src/taumode.rs:570-575 would index out of bounds); query dimension mismatch src/core.rs:510-516 */
+  AS_ERR_TOO_SPARSE = 6,  /* "Resulting laplacian matrix is too sparse" src/graph.rs:185-193 */
+  AS_ERR_ARG = 7,         /* null pointer / bad enum / unsupported size */
+  AS_ERR_UNSUPPORTED = 8, /* feature outside the accelerated path (e.g. normalise = true) */
+  AS_ERR_HIP = 9,         /* HIP runtime failure; text in as_last_error */
+  AS_ERR_NO_DEVICE = 10   /* no gfx950 device: there is no CPU fallback */
+} as_status;
+
+/* TauMode, src/taumode.rs:75-82 */
+typedef enum { AS_TAU_FIXED = 0, AS_TAU_MEDIAN = 1, AS_TAU_MEAN = 2, AS_TAU_PERCENTILE = 3 } as_tau_mode;
+
+/* GraphParams, src/graph.rs:94-102 (same field names) */
+typedef struct {
+  double eps;             /* maximum cosine distance kept */
+  uint64_t k;             /* stored only; the graph code reads topk (src/laplacian.rs:211,246) */
+  uint64_t topk;          /* neighbours requested per node = topk + 1 */
+  double p;               /* kernel exponent */
+  double sigma;           /* used when has_sigma != 0, else 1.0 (src/laplacian.rs:254) */
+  int32_t has_sigma;      /* Option<f64> discriminant */
+  int32_t normalise;      /* must be 0 (StandardScaler path not accelerated) */
+  int32_t sparsity_check; /* carried for the host-side GraphFactory check (src/graph.rs:185-193) */
+  int32_t rectify;        /* 0: distance = 1 - cos (default).  1: 1 - max(0, cos) */
+} as_graph_params;
+
+typedef struct as_ctx as_ctx;     /* device, stream, workspace */
+typedef struct as_csr as_csr;     /* CSR Laplacian resident in HBM (sprs::CsMat<f64> counterpart) */
+typedef struct as_index as_index; /* items + lambdas resident in HBM (ArrowSpace.data / .lambdas) */
+
+/* ---- context -------------------------------------------------------------------------- */
+int as_abi_version(void);
+int as_ctx_create(int device, as_ctx **out);
+void as_ctx_destroy(as_ctx *ctx);
+const char *as_last_error(const as_ctx *ctx);
+const char *as_status_message(int status); /* the reference's panic text for a status */
+/* Run on an existing HIP stream (e.g. PyTorch's current stream; NULL = HIP's default stream).
+ * Until this is called the context uses a private stream and every call is synchronous with
+ * the host.  Afterwards calls whose outputs are device buffers are stream-ordered (no host
+ * sync); host outputs are always complete on return. */
+int as_ctx_set_stream(as_ctx *ctx, void *hip_stream);
+int as_ctx_synchronize(as_ctx *ctx);
+/* Tuning knob: 0 = exact brute-force neighbour search (also the fall-back for rows the MFMA
+ * path cannot certify), 1 = f64 MFMA candidate pass + exact re-rank (default). */
+int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
+int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);
+
+/* Per-kernel device timing (HIP events on the context's stream).  Enable, run calls, then read
+ * the accumulated milliseconds / launch count of a named kernel group. */
+int as_profile_enable(as_ctx *ctx, int on);
+int as_profile_reset(as_ctx *ctx);
+int as_profile_get(as_ctx *ctx, const char *name, double *ms_total, uint64_t *launches);
+/* writes up to cap names separated by '\n' */
+int as_profile_names(as_ctx *ctx, char *buf, uint64_t cap);
+
+/* ---- builder helper --------------------------------------------------------------------- */
+/* ArrowSpaceBuilder::define_result_k, src/builder.rs:225-233 */
+uint64_t as_define_result_k(uint64_t k, uint64_t topk);
+
+/* ---- graph: replaces build_laplacian_matrix, src/laplacian.rs:122-178 -------------------- */
+/* rows: n_nodes x dim, ROWS ARE NODES (GraphFactory passes centroids^T, src/graph.rs:170-172;
+ * the item graph passes the items themselves, src/energymaps.rs:270).  Output: n_nodes x
+ * n_nodes CSR, columns ascending, explicit diagonal (also when 0, src/laplacian.rs:369-370). */
+int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim,
+                       const as_graph_params *params, as_csr **out);
+
+/* Stage-level entry: the neighbour search alone (CosinePair::query_row_top_k for every row of
+ * [row_begin, row_begin + row_count), src/laplacian.rs:211,221,246).  nbr_idx / nbr_dist are
+ * row_count x (topk+1), ordered (distance asc, index asc); missing entries idx = UINT64_MAX. */
+int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim,
+                  uint64_t row_begin, uint64_t row_count, const as_graph_params *params,
+                  uint64_t *nbr_idx, double *nbr_dist);
+
+/* Stage-level entry: _build_adjacency's filter/weight/sparsify + _symmetrise_adjancency +
+ * _build_sparse_laplacian (src/laplacian.rs:217-417) from a complete neighbour table. */
+int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist,
+                          uint64_t n_nodes, const as_graph_params *params, as_csr **out);
+
+uint64_t as_csr_n(const as_csr *m);
+uint64_t as_csr_nnz(const as_csr *m);
+/* copy out (host or device destinations): indptr[n+1], indices[nnz], data[nnz] */
+int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indices, double *data);
+/* wrap an existing CSR (e.g. one loaded by the host) */
+int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
+                  const uint64_t *indices, const double *data, as_csr **out);
+void as_csr_free(as_csr *m);
+
+/* ---- lambda-tau: replaces TauMode::compute_taumode_lambdas_parallel, src/taumode.rs:174-312 */
+/* items: n_items x n_features.  tau is taken from each item's own values (select_tau,
+ * src/taumode.rs:87-127), lambda from compute_synthetic_lambda_csr (src/taumode.rs:552-660).
+ * Requires as_csr_n(L) <= n_features. */
+int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features,
+                       const as_csr *L, int tau_mode, double tau_arg, double *lambdas_out);
+
+/* Batched ArrowSpace::prepare_query_item, src/core.rs:533-549 (projection off): fails with
+ * AS_ERR_NONFINITE if any query value is NaN/inf. */
+int as_prepare_query_items(as_ctx *ctx, const double *queries, uint64_t nq, uint64_t n_features,
+                           const as_csr *L, int tau_mode, double tau_arg, double *lambdas_out);
+
+/* TauMode::select_tau for a batch of rows (src/taumode.rs:87-127); taus_out[n_rows] */
+int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int tau_mode,
+                  double tau_arg, double *taus_out);
+
+/* ---- search: replaces ArrowSpace::search_lambda_aware, src/core.rs:760-798 ---------------- */
+int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uint64_t n_items,
+                    uint64_t n_features, as_index **out);
+void as_index_destroy(as_index *index);
+uint64_t as_index_nitems(const as_index *index);
+/* Batched: for each query the first min(k, n_items) items by (score desc, index asc) with
+ * score = alpha*cos + (1-alpha)*(1 - min(|lambda_q - lambda_i|, 1)) (src/core.rs:135-175).
+ * idx_out / score_out are nq x k (unused tail: idx = UINT64_MAX).  Fails with
+ * AS_ERR_ZERO_LAMBDA if any q_lambdas[j] == 0.0 and with AS_ERR_NAN_SCORE on a NaN score.
+ * id_offset is added to every returned index (row-sharded indexes pass their shard start). */
+int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *queries,
+                           const double *q_lambdas, uint64_t nq, uint64_t k, double alpha,
+                           uint64_t id_offset, uint64_t *idx_out, double *score_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROWSPACE_HIP_H */

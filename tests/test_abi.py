@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the
+header declares, and refuses to run without a gfx950 device (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import arrowspace_amd as A
+from arrowspace_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "arrowspace_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_is_built():
+    assert os.path.exists(A.LIB_PATH), "run __graft_entry__.build() first"
+
+
+def test_every_declared_symbol_is_exported():
+    lib = A.load()
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "header declares %s but the library does not export it" % s
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_abi_version_and_messages():
+    lib = A.load()
+    assert lib.as_abi_version() == 1
+    # the reference's panic texts travel through the boundary verbatim
+    assert lib.as_status_message(_lib.AS_ERR_ZERO_LAMBDA).decode() == \
+        "Lambda of the item is 0.0, prepare the item before searching"  # src/core.rs:773-776
+    assert lib.as_status_message(_lib.AS_ERR_NONFINITE).decode().startswith(
+        "Query item contains invalid values (NaN or infinity)")  # src/core.rs:534-537
+    assert "too sparse" in lib.as_status_message(_lib.AS_ERR_TOO_SPARSE).decode()  # src/graph.rs:185-193
+    assert "shape (2,2)" in lib.as_status_message(_lib.AS_ERR_SHAPE).decode()  # src/laplacian.rs:129-134
+
+
+def test_define_result_k_needs_no_device():
+    lib = A.load()
+    assert [lib.as_define_result_k(k, 9) for k in (1, 5, 6, 9, 10, 16)] == [3, 3, 4, 4, 9, 9]  # builder.rs:225-233
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(A.ArrowSpaceError) as e:
+        A.Context(0)
+    assert e.value.status == _lib.AS_ERR_NO_DEVICE
+
+
+def test_host_mirror_names():
+    # same public names as the reference's API for this path
+    for name in ("ArrowSpaceBuilder", "ArrowSpace", "ArrowItem", "GraphLaplacian", "GraphParams", "GraphFactory",
+                 "TauMode", "build_laplacian_matrix"):
+        assert hasattr(A, name)
+    b = A.ArrowSpaceBuilder.new().with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_synthesis(A.TauMode.Median)
+    assert (b.lambda_eps, b.lambda_k, b.lambda_topk, b.lambda_p, b.lambda_sigma) == (0.5, 16, 16, 2.0, 0.25)
+    d = A.ArrowSpaceBuilder.new()  # defaults: src/builder.rs:59-91
+    assert (d.lambda_eps, d.lambda_k, d.lambda_topk, d.lambda_p, d.lambda_sigma) == (1e-3, 6, 3, 2.0, None)
+    d.define_result_k()
+    assert d.lambda_topk == 4

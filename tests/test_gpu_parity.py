@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Bars (BASELINE.json north_star): neighbour / adjacency / search indices bit-exact;
+lambda-tau and scores within 1e-6 relative (asserted far tighter: 1e-12).
+
+Every test here needs a real MI355X: run with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+import arrowspace_amd as A
+from arrowspace_amd import _lib
+from oracle import oracle_ctypes as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+NAN, INF = float("nan"), float("inf")
+LAMBDA_RTOL = 1e-12   # north_star allows 1e-6
+WEIGHT_RTOL = 1e-13   # kernel weights: device pow/x*x vs glibc pow differ by <= 1 ulp
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return A.default_context()
+
+
+@pytest.fixture(params=[0, 1], ids=["exact", "mfma"])
+def mode(request, ctx):
+    ctx.set_option("knn_mfma", request.param)
+    ctx.set_option("search_mfma", request.param)
+    yield request.param
+    ctx.set_option("knn_mfma", 1)
+    ctx.set_option("search_mfma", 1)
+
+
+def ogp(p):
+    return O.graph_params(p.eps, p.k, p.topk, p.p, p.sigma)
+
+
+def assert_csr_equal(got, want, rtol=WEIGHT_RTOL):
+    gi, gj, gd = got
+    wi, wj, wd = want
+    assert np.array_equal(gi, wi), "indptr differs"
+    assert np.array_equal(gj, wj), "column indices differ"
+    np.testing.assert_allclose(gd, wd, rtol=rtol, atol=0)
+
+
+# ---- select_tau: the reference's exact table (src/tests/test_taumode.rs:13-159) ---------------
+
+def test_select_tau_table(ctx):
+    T = A.TauMode
+    e = [0.1, 0.5, 1.0]
+    assert A.select_tau(e, T.Fixed(0.3)) == 0.3
+    for bad in (-0.1, 0.0, NAN, INF):
+        assert A.select_tau(e, T.Fixed(bad)) == A.TAU_FLOOR
+    assert abs(A.select_tau([1.0, 2.0, 3.0], T.Mean) - 2.0) < 1e-12
+    assert abs(A.select_tau([1.0, NAN, 3.0, INF, 2.0], T.Mean) - 2.0) < 1e-12
+    assert A.select_tau([NAN, INF, -INF], T.Mean) == A.TAU_FLOOR
+    assert A.select_tau([], T.Mean) == A.TAU_FLOOR
+    assert A.select_tau([3.0, 1.0, 2.0], T.Median) == 2.0
+    assert abs(A.select_tau([1.0, 2.0, 3.0, 4.0], T.Median) - 2.5) < 1e-12
+    assert A.select_tau([5.0], T.Median) == 5.0
+    assert A.select_tau([NAN, 1.0, 3.0, INF, 2.0], T.Median) == 2.0
+    assert A.select_tau([NAN, INF], T.Median) == A.TAU_FLOOR
+    assert A.select_tau([], T.Median) == A.TAU_FLOOR
+    e = [1.0, 2.0, 3.0, 4.0, 5.0]
+    for p, want in ((0.0, 1.0), (1.0, 5.0), (0.5, 3.0), (-0.1, 1.0), (1.5, 5.0)):
+        assert A.select_tau(e, T.Percentile(p)) == want
+    assert A.select_tau([], T.Percentile(0.5)) == A.TAU_FLOOR
+    assert A.select_tau([A.TAU_FLOOR * 2.0], T.Mean) == A.TAU_FLOOR * 2.0
+    assert A.select_tau([A.TAU_FLOOR / 2.0], T.Mean) == A.TAU_FLOOR
+    assert A.select_tau([0.0], T.Mean) == A.TAU_FLOOR
+
+
+@pytest.mark.parametrize("length", [1, 2, 7, 24, 64, 128, 129, 384, 768, 1000])
+def test_select_tau_matches_oracle(ctx, length):
+    rng = np.random.default_rng(length)
+    X = rng.standard_normal((37, length))
+    X[3, : length // 2] = X[3, 0]                     # duplicates
+    if length > 4:
+        X[5, 1], X[5, 2], X[6, 0] = NAN, -INF, INF    # non-finite entries are filtered
+        X[7] = -np.abs(X[7])                          # all negative -> floor
+    for m, om, arg in ((A.TauMode.Median, O.TAU_MEDIAN, 0.0), (A.TauMode.Mean, O.TAU_MEAN, 0.0),
+                       (A.TauMode.Percentile(0.95), O.TAU_PERCENTILE, 0.95),
+                       (A.TauMode.Percentile(0.25), O.TAU_PERCENTILE, 0.25), (A.TauMode.Fixed(0.2), O.TAU_FIXED, 0.2)):
+        got = A.select_tau(X, m)
+        want = np.array([O.select_tau(r, om, arg) for r in X])
+        if om == O.TAU_MEAN:
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)  # sum order differs (lanes split the row)
+        else:
+            assert np.array_equal(got, want), (length, m)
+
+
+# ---- lambda: scale invariance (src/tests/test_taumode.rs:498-528) -----------------------------
+
+def test_rayleigh_scale_invariance(ctx):
+    L = A.CsrMatrix.from_host(ctx, [0, 2, 4], [0, 1, 0, 1], [1.0, 0.5, 0.5, 1.0])
+    l1 = A.compute_synthetic_lambda([1.0, 2.0], L, 0.5)
+    l2 = A.compute_synthetic_lambda([2.0, 4.0], L, 0.5)
+    assert l1 == pytest.approx(l2, rel=1e-10)
+    assert l1 == pytest.approx(0.5 * (1.4 / 1.9), rel=1e-15)
+
+
+# ---- graph: golden vectors -------------------------------------------------------------------
+
+def test_golden_graphs(ctx, golden, mode):
+    for name, c in golden.items():
+        p = c["params"]
+        gp = A.GraphParams(p["eps"], p["k"], p["topk"], p["p"], p["sigma"])
+        idx, dist = A.knn_cosine(c["nodes"], gp)
+        want_idx = c["knn_idx"].astype(np.int64)
+        got_idx = idx.astype(np.int64)
+        got_idx[idx == np.uint64(A.api.U64_MAX)] = -1
+        assert np.array_equal(got_idx, want_idx), name
+        assert np.array_equal(dist[want_idx >= 0], c["knn_dist"][want_idx >= 0]), name
+        gl = A.build_laplacian_matrix(c["nodes"], gp)
+        assert_csr_equal(gl.matrix.to_host(), c["csr"])
+        assert gl.matrix.shape() == (c["nodes"].shape[0],) * 2
+
+
+def test_golden_lambdas_and_search(ctx, golden, mode):
+    for name, c in golden.items():
+        if "lambdas" not in c:
+            continue
+        L = A.CsrMatrix.from_host(ctx, *c["csr"])
+        gl = A.GraphLaplacian(c["nodes"], L, len(c["rows"]), None)
+        tm = A.TauMode(c["tau_mode"], c["tau_arg"])
+        asp = A.ArrowSpace(c["rows"], tm, ctx)
+        asp.compute_taumode(gl)
+        np.testing.assert_allclose(asp.lambdas(), c["lambdas"], rtol=LAMBDA_RTOL, atol=1e-300, err_msg=name)
+        for q in c.get("queries", []):
+            lq = asp.prepare_query_item(q["q"], gl)
+            assert lq == pytest.approx(q["lambda_q"], rel=LAMBDA_RTOL), name
+            if "idx" in q:
+                # identical inputs (the oracle's lambdas) -> identical indices AND scores
+                asp.update_lambdas(c["lambdas"])
+                res = asp.search_lambda_aware(A.ArrowItem(q["q"], q["lambda_q"]), q["k"], q["alpha"])
+                assert [r[0] for r in res] == q["idx"], name
+                assert np.array_equal([r[1] for r in res], q["scores"]), name
+
+
+def test_proteins_alpha1_top3(ctx, proteins, mode):
+    """paper.md:124-133 / benches/index_compute_bench.rs:121-126 anchor."""
+    asp = A.ArrowSpace(proteins, A.TauMode.Median, ctx)
+    asp.update_lambdas(np.full(len(proteins), 0.25))
+    res = asp.search_lambda_aware(A.ArrowItem(proteins[3] * 1.02, 0.25), 3, 1.0)
+    assert [r[0] for r in res] == [3, 6, 0]
+    assert ["%.6f" % r[1] for r in res] == ["1.000000", "0.999573", "0.999325"]
+
+
+# ---- graph: reference error behaviour and literal-matrix invariants --------------------------
+
+def test_too_small_input_panics(ctx):  # src/tests/test_laplacian.rs:302-311
+    gp = A.GraphParams(0.5, 3, 2, 2.0, 0.1)
+    with pytest.raises(A.ArrowSpaceError, match=r"items should be at least of shape \(2,2\)") as e:
+        A.build_laplacian_matrix(np.ones((1, 5)), gp)
+    assert e.value.status == _lib.AS_ERR_SHAPE
+    with pytest.raises(A.ArrowSpaceError):
+        A.build_laplacian_matrix(np.ones((5, 1)), gp)
+
+
+def test_basic_laplacian_construction(ctx):  # src/tests/test_laplacian.rs:34-49
+    items = np.array([[1, 0, 0], [.8, .6, 0], [0, 1, 0], [0, .8, .6], [0, 0, 1]], dtype=np.float64)
+    params = A.GraphParams(0.5, 3, 2, 2.0, 0.1, False, True)
+    gl = A.build_laplacian_matrix(np.ascontiguousarray(items.T), params, None)
+    assert gl.matrix.shape() == (3, 3)
+    gl5 = A.build_laplacian_matrix(np.ascontiguousarray(items.T), params, 5)
+    assert gl5.nnodes == 5 and gl5.graph_params == params
+    M = gl.matrix.to_dense()
+    assert np.allclose(M.sum(axis=1), 0, atol=1e-12) and np.allclose(M, M.T, atol=1e-12)
+    assert np.all(np.diag(M) >= -1e-12) and np.all(M[~np.eye(3, dtype=bool)] <= 1e-12)
+
+
+def test_sparsity_check_panics(ctx):  # src/graph.rs:185-193
+    X, cent = synth.mixture(400, 64, seed=3, n_clusters=8, rank=4)
+    with pytest.raises(A.ArrowSpaceError, match="too sparse"):
+        A.GraphFactory.build_laplacian_matrix_from_k_cluster(synth.gaussian_rows(40, 64, seed=2), 1e-3, 6, 4, 2.0,
+                                                             None, False, True, 400)
+
+
+def test_query_errors(ctx, proteins):
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(proteins)
+    q = proteins[0].copy()
+    q[3] = NAN
+    with pytest.raises(A.ArrowSpaceError, match="invalid values") as e:  # src/tests/test_querying_proj.rs:277-291
+        asp.prepare_query_item(q, gl)
+    assert e.value.status == _lib.AS_ERR_NONFINITE
+    with pytest.raises(A.ArrowSpaceError, match="doesn't match index original dimension"):
+        asp.prepare_query_item(proteins[0][:10], gl)
+    with pytest.raises(A.ArrowSpaceError, match="Lambda of the item is 0.0"):  # src/core.rs:773-776
+        asp.search_lambda_aware(A.ArrowItem(proteins[0], 0.0), 3, 0.7)
+    # k > nitems -> nitems results, sorted descending (src/tests/test_querying_proj.rs:369-399)
+    res = asp.search_lambda_aware(A.ArrowItem(proteins[0], 0.1), 1000, 0.7)
+    assert len(res) == len(proteins)
+    assert all(res[i][1] >= res[i + 1][1] for i in range(len(res) - 1))
+
+
+# ---- seeded synthetic sets vs the oracle, both mappings --------------------------------------
+
+@pytest.mark.parametrize("n,d,topk,eps", [(1500, 64, 16, 0.5), (777, 33, 5, 0.3), (2048, 128, 16, 0.5), (300, 130, 3, 0.6)])
+def test_item_graph_matches_oracle(ctx, mode, n, d, topk, eps):
+    X, _ = synth.mixture(n, d, seed=11, n_clusters=16, rank=4)
+    gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    gl = A.build_laplacian_matrix(X, gp)
+    assert_csr_equal(gl.matrix.to_host(), O.build_laplacian(X, ogp(gp)))
+
+
+def test_duplicate_rows_tie_break(ctx, mode):
+    """Duplicated rows (src/tests/test_builder.rs:376-384 style): exact ties must resolve to
+    the lower index, identically to the oracle."""
+    X, _ = synth.mixture(200, 16, seed=5, n_clusters=4, rank=2)
+    X = np.concatenate([X, X[:90], X[:40]])  # 330 rows with exact duplicates / triplicates
+    gp = A.GraphParams(0.5, 8, 8, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
+
+
+def test_zero_and_tiny_rows(ctx, mode):
+    """cos := 0 when |a||b| <= 1e-12 (oracle rule set; src/tests/test_laplacian.rs:316 tiny values)."""
+    X, _ = synth.mixture(100, 8, seed=9, n_clusters=4, rank=2)
+    X[7] = 0.0
+    X[20] *= 1e-9
+    X[21] *= 1e-7
+    gp = A.GraphParams(1.5, 4, 4, 2.0, None)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
+
+
+@pytest.mark.parametrize("tm,om,arg", [(A.TauMode.Median, O.TAU_MEDIAN, 0.0), (A.TauMode.Mean, O.TAU_MEAN, 0.0),
+                                       (A.TauMode.Percentile(0.95), O.TAU_PERCENTILE, 0.95),
+                                       (A.TauMode.Fixed(0.4), O.TAU_FIXED, 0.4)])
+@pytest.mark.parametrize("n,f", [(5000, 128), (1000, 24), (600, 768)])
+def test_ref_mapping_chain_matches_oracle(ctx, mode, n, f, tm, om, arg):
+    """build() chain with supplied centroids: F x F graph bit-exact -> lambdas -> search."""
+    X, cent = synth.mixture(n, f, seed=21, n_clusters=32, rank=6)
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_synthesis(tm)
+    asp, gl = b.build(X, cent)
+    ocsr = O.build_laplacian(np.ascontiguousarray(cent.T), O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    assert_csr_equal(gl.matrix.to_host(), ocsr)
+    assert gl.nnodes == n and gl.matrix.shape() == (f, f)
+    olam = O.taumode_lambdas(X, gl.matrix.to_host(), om, arg)  # same CSR values on both sides
+    np.testing.assert_allclose(asp.lambdas(), olam, rtol=LAMBDA_RTOL, atol=1e-300)
+    assert np.all(np.isfinite(olam))
+    qi = np.array([3, 77, n - 1])
+    Q = X[qi] * 1.02
+    lq = asp.prepare_query_items(Q, gl)
+    olq = np.array([O.prepare_query_item(q, gl.matrix.to_host(), om, arg) for q in Q])
+    np.testing.assert_allclose(lq, olq, rtol=LAMBDA_RTOL)
+    asp.update_lambdas(olam)
+    idx, sc = asp.search_lambda_aware_batch(Q, olq, 10, 0.7)
+    for j in range(len(Q)):
+        oi, osc = O.search_lambda_aware(X, olam, Q[j], olq[j], 10, 0.7)
+        assert np.array_equal(idx[j], oi)
+        assert np.array_equal(sc[j], osc)
+
+
+def test_search_large_k_and_ties(ctx, mode):
+    X, _ = synth.mixture(500, 32, seed=2, n_clusters=5, rank=3)
+    X = np.concatenate([X, X[:100]])  # exact score ties -> lower index first
+    lam = np.linspace(0.05, 0.9, len(X))
+    lam[500:] = lam[:100]
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    Q = X[[1, 50, 420]] * 1.02
+    ql = np.array([0.3, 0.5, 0.7])
+    for k in (1, 10, 64, 100, 600):
+        idx, sc = asp.search_lambda_aware_batch(Q, ql, k, 0.7)
+        for j in range(3):
+            oi, osc = O.search_lambda_aware(X, lam, Q[j], ql[j], k, 0.7)
+            assert np.array_equal(idx[j], oi), k
+            assert np.array_equal(sc[j], osc), k
+
+
+def test_config1_plumbing(ctx):
+    """BASELINE config 1: 1000 x 64 i.i.d. Gaussian, default builder: empty feature graph,
+    lambda == 0 everywhere, search raises the zero-lambda error."""
+    X = synth.gaussian_rows(1000, 64, seed=1)
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).build(X, X)
+    assert gl.matrix.nnz() == 64 and np.all(gl.matrix.data() == 0.0)
+    assert np.all(asp.lambdas() == 0.0)
+    lq = asp.prepare_query_item(X[0] * 1.02, gl)
+    assert lq == 0.0
+    with pytest.raises(A.ArrowSpaceError, match="Lambda of the item is 0.0"):
+        asp.search_lambda_aware(A.ArrowItem(X[0] * 1.02, lq), 3, 0.7)
+
+
+def test_device_resident_inputs(ctx):
+    """Device pointers are used in place (how bench.py keeps inputs in HBM)."""
+    import torch
+    X, cent = synth.mixture(4000, 128, seed=4, n_clusters=32, rank=6)
+    Xd = torch.from_numpy(X).cuda()
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25)
+    asp_h, gl_h = b.build(X, cent)
+    asp_d, gl_d = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(Xd, cent)
+    assert torch.is_tensor(asp_d.lambdas()) and asp_d.lambdas().is_cuda
+    assert np.array_equal(asp_d.lambdas().cpu().numpy(), asp_h.lambdas())
+    Q = Xd[:5] * 1.02
+    lq = asp_d.prepare_query_items(Q, gl_d)
+    idx, sc = asp_d.search_lambda_aware_batch(Q, lq, 5, 0.7)
+    idx_h, sc_h = asp_h.search_lambda_aware_batch(Q.cpu().numpy(), lq.cpu().numpy(), 5, 0.7)
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint64), idx_h) and np.array_equal(sc.cpu().numpy(), sc_h)
