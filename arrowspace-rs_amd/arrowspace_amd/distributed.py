@@ -1,0 +1,175 @@
+"""Row-sharded lambda-tau build and search: one process per GPU, torch.distributed collectives
+(backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+
+The path shards by rows.  Exchange steps, nothing else crosses ranks:
+  item graph     all-gather of the row shards (the off-diagonal column blocks every rank needs),
+                 all-gather of the per-row neighbour tables (n x (topk+1) x 16 B), then the
+                 integer/byte CSR assembly is replicated (it is milliseconds);
+  lambda-tau     none for the values (tau is per item); one small all-reduce for min/max/sum;
+  search         all-gather of the per-shard top-k (nq x k pairs) + a stable merge.
+
+`ops` is the compute backend.  The product backend is HipOps (C ABI calls on device tensors);
+the CPU tests inject a stand-in defined under tests/ so that the sharding / exchange / merge
+logic is exercised with world_size 2 on gloo.  Nothing here imports the oracle.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api as A
+from ._lib import ptr
+
+I64_NONE = -1  # UINT64_MAX seen through int64
+
+
+def shard_range(n, rank, world):
+    """Contiguous row range of `rank`; shard starts are multiples of 128 (the MFMA row tile) so
+    every rank's A-side reads the shared packed image in place."""
+    per = (n + world - 1) // world
+    per = (per + 127) // 128 * 128
+    lo = min(n, rank * per)
+    hi = min(n, lo + per)
+    return lo, hi
+
+
+class HipOps:
+    """Compute backend over libarrowspace_hip.so; all tensors live in HBM."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def knn_rows(self, X_full, row_begin, row_count, gp):
+        n, d = X_full.shape
+        K = gp.topk + 1
+        idx = torch.empty((row_count, K), dtype=torch.int64, device=X_full.device)
+        dst = torch.empty((row_count, K), dtype=torch.float64, device=X_full.device)
+        c = gp.to_c()
+        import ctypes as C
+        A._adopt_torch_stream(self.ctx)
+        self.ctx.check(self.ctx.lib.as_knn_cosine(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
+                                                  ptr(idx), ptr(dst)))
+        return idx, dst
+
+    def laplacian_from_knn(self, idx, dist_, gp):
+        return A.laplacian_from_knn(idx, dist_, gp, ctx=self.ctx)
+
+    def feature_laplacian(self, centroids, gp, n_items):
+        return A.GraphFactory.build_laplacian_matrix_from_k_cluster(
+            centroids, gp.eps, gp.k, gp.topk, gp.p, gp.sigma, gp.normalise, gp.sparsity_check, n_items, ctx=self.ctx)
+
+    def lambdas(self, items, gl, taumode):
+        asp = A.ArrowSpace(items, taumode, self.ctx)
+        asp.compute_taumode(gl)
+        return asp.lambdas()
+
+    def prepare_queries(self, items, queries, gl, taumode):
+        return A.ArrowSpace(items, taumode, self.ctx).prepare_query_items(queries, gl)
+
+    def make_index(self, items, lambdas, taumode, id_offset):
+        asp = A.ArrowSpace(items, taumode, self.ctx)
+        asp.update_lambdas(lambdas)
+        asp.id_offset = int(id_offset)
+        return asp
+
+    def search(self, index, queries, q_lambdas, k, alpha):
+        idx, sc = index.search_lambda_aware_batch(queries, q_lambdas, k, alpha)
+        return idx, sc
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_rows(t, sizes):
+    """all-gather of row blocks with (possibly) unequal row counts; `sizes` = rows per rank."""
+    rank, world = _world()
+    if world == 1:
+        return t
+    mx = max(sizes)
+    pad = t
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+    out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    if all(s == mx for s in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+class ShardedArrowSpace:
+    """The row-sharded counterpart of (ArrowSpace, GraphLaplacian) for one rank."""
+
+    def __init__(self, ops, X_shard, n_total, gp, taumode=A.TauMode.Median):
+        self.ops, self.gp, self.taumode = ops, gp, taumode
+        self.rank, self.world = _world()
+        self.n = int(n_total)
+        self.lo, self.hi = shard_range(self.n, self.rank, self.world)
+        assert X_shard.shape[0] == self.hi - self.lo, (X_shard.shape, self.lo, self.hi)
+        self.X = X_shard
+        self.sizes = [shard_range(self.n, r, self.world)[1] - shard_range(self.n, r, self.world)[0]
+                      for r in range(self.world)]
+        self.lambdas = None
+        self.index = None
+
+    # -- item graph: n x n Laplacian over the items (build_laplacian_matrix on untransposed rows)
+    def build_item_graph(self):
+        X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
+        idx, dst = self.ops.knn_rows(X_full, self.lo, self.hi - self.lo, self.gp)
+        idx_all = all_gather_rows(idx, self.sizes)                        # RCCL all-gather #2
+        dst_all = all_gather_rows(dst, self.sizes)
+        return self.ops.laplacian_from_knn(idx_all, dst_all, self.gp)     # replicated assembly
+
+    # -- reference mapping: F x F graph over the supplied centroids, per-item lambda on the shard
+    def build_lambdas(self, centroids):
+        self.gl = self.ops.feature_laplacian(centroids, self.gp, self.n)
+        self.lambdas = self.ops.lambdas(self.X, self.gl, self.taumode)
+        lam = self.lambdas if torch.is_tensor(self.lambdas) else torch.from_numpy(np.asarray(self.lambdas))
+        stats = torch.stack([lam.min(), -lam.max(), lam.sum()]) if lam.numel() else \
+            torch.tensor([float("inf"), float("inf"), 0.0], dtype=torch.float64, device=lam.device)
+        if self.world > 1:                                                # logged stats, builder.rs:434-445
+            mm = stats[:2].clone()
+            dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+            sm = stats[2:].clone()
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            stats = torch.cat([mm, sm])
+        self.lambda_stats = (float(stats[0]), float(-stats[1]), float(stats[2]) / self.n)
+        self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo)
+        return self.gl
+
+    def prepare_queries(self, queries):
+        return self.ops.prepare_queries(self.X, queries, self.gl, self.taumode)
+
+    def search(self, queries, q_lambdas, k, alpha):
+        """Global top-k of every query: per-shard top-k (global ids), all-gather, stable merge."""
+        idx, sc = self.ops.search(self.index, queries, q_lambdas, k, alpha)
+        idx = idx if torch.is_tensor(idx) else torch.from_numpy(np.asarray(idx).astype(np.int64))
+        sc = sc if torch.is_tensor(sc) else torch.from_numpy(np.asarray(sc))
+        if self.world == 1:
+            return idx, sc
+        nq, kk = idx.shape
+        kmax = torch.tensor([kk], dtype=torch.int64, device=idx.device)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        kmax = int(kmax)
+        if kk < kmax:  # a shard smaller than k returns fewer columns
+            idx = torch.cat([idx, torch.full((nq, kmax - kk), I64_NONE, dtype=idx.dtype, device=idx.device)], 1)
+            sc = torch.cat([sc, torch.full((nq, kmax - kk), float("-inf"), dtype=sc.dtype, device=sc.device)], 1)
+        gi = torch.empty((self.world, nq, kmax), dtype=idx.dtype, device=idx.device)
+        gs = torch.empty((self.world, nq, kmax), dtype=sc.dtype, device=sc.device)
+        dist.all_gather_into_tensor(gi, idx.contiguous())                 # RCCL all-gather #3
+        dist.all_gather_into_tensor(gs, sc.contiguous())
+        return merge_topk(gi, gs, min(k, self.n))
+
+
+def merge_topk(gi, gs, k):
+    """gi/gs: world x nq x kk per-shard results, shards in ascending id order, each sorted by
+    (score desc, id asc).  A stable descending sort of the rank-major concatenation keeps the
+    lower id first among equal scores (src/core.rs:785 stable sort_by)."""
+    world, nq, kk = gi.shape
+    ci = gi.permute(1, 0, 2).reshape(nq, world * kk)
+    cs = gs.permute(1, 0, 2).reshape(nq, world * kk)
+    cs = torch.where(ci == I64_NONE, torch.full_like(cs, float("-inf")), cs)
+    order = torch.sort(cs, dim=1, descending=True, stable=True).indices[:, :k]
+    return torch.gather(ci, 1, order), torch.gather(cs, 1, order)

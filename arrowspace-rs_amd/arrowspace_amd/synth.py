@@ -68,3 +68,19 @@ def queries_from(rows_fn, n_total, nq, seed=42):
     u = _uniform(seed * 16 + 5, np.arange(nq, dtype=np.uint64))
     idx = np.minimum((u * n_total).astype(np.int64), n_total - 1)
     return idx, rows_fn(idx) * 1.02
+
+
+def mixture_at(indices, d, seed=42, n_clusters=256, rank=8, noise=0.3):
+    """The mixture rows with the given (arbitrary) global indices."""
+    cent = mixture_centres(d, seed, n_clusters, rank)
+    idx = np.asarray(indices, dtype=np.int64)
+    e = (idx[:, None].astype(np.uint64) * np.uint64(d) + np.arange(d, dtype=np.uint64)[None, :]).ravel()
+    u1 = _uniform(seed * 16 + 2, e * np.uint64(2))
+    u2 = _uniform(seed * 16 + 2, e * np.uint64(2) + np.uint64(1))
+    g = (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).reshape(len(idx), d)
+    return cent[idx % n_clusters] + noise * np.sqrt(float(rank)) * g
+
+
+def query_indices(n_total, nq, seed=42):
+    u = _uniform(seed * 16 + 5, np.arange(nq, dtype=np.uint64))
+    return np.minimum((u * n_total).astype(np.int64), n_total - 1)

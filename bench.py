@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- lambda-tau build items/s + lambda-aware search QPS on synthetic N x D rows.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--dim 128] [--nq 10000]
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the hot path over the whole synthetic set (BASELINE.json configs[2]):
+  build   item graph: cosine k-NN -> eps/top-k capped union CSR Laplacian over the N items
+          (with_lambda_graph(eps .5, k 16, topk 16, p 2, sigma .25); MFMA distance block + assembly),
+          then the reference mapping: F x F Laplacian over the supplied centroids and the per-item
+          lambda-tau (Median tau) for all N items;
+  search  prepare_query_item for nq queries + search_lambda_aware(k 10, alpha .7) over the N items.
+Inputs are resident in HBM before the timed region.  `value` = N / build seconds (whole job);
+`search_qps` = nq / search seconds.  N > 1 row-shards the same N (strong scaling) with RCCL
+all-gathers of the row blocks, the neighbour tables and the per-shard top-k.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 2048 flop / 64 cyc / SIMD x 1024 SIMDs x 2.4 GHz
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--dim", type=int, default=128)
+    p.add_argument("--nq", type=int, default=10_000)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--alpha", type=float, default=0.7)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-n", type=int, default=32000)
+    p.add_argument("--cpu-sample-nq", type=int, default=16)
+    return p.parse_args()
+
+
+def cpu_baseline(args, X_host_fn, cent, n_total):
+    """The oracle (CPU restatement of the reference algorithm, OpenMP over the host cores) timed
+    on a bounded sample of the same workload.  Reported baseline only."""
+    from oracle import oracle_ctypes as O
+    ns = min(args.cpu_sample_n, n_total)
+    Xs = X_host_fn(0, ns)
+    gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
+    t0 = time.time()
+    O.build_laplacian(Xs, gp)
+    t_graph = time.time() - t0
+    csrF = O.build_laplacian(np.ascontiguousarray(cent.T), gp)
+    t0 = time.time()
+    lam = O.taumode_lambdas(Xs, csrF, O.TAU_MEDIAN)
+    t_lam = time.time() - t0
+    nqs = args.cpu_sample_nq
+    t0 = time.time()
+    for j in range(nqs):
+        q = Xs[(j * 7919) % ns] * 1.02
+        lq = O.prepare_query_item(q, csrF, O.TAU_MEDIAN)
+        O.search_lambda_aware(Xs, lam, q, lq if lq != 0.0 else 1e-3, args.k, args.alpha)
+    t_search = time.time() - t0
+    # graph cost grows as n^2, lambda as n: time the sample, extrapolate to the full N
+    t_full = t_graph * (n_total / ns) ** 2 + t_lam * (n_total / ns)
+    qps_full = nqs / (t_search * (n_total / ns))
+    return {
+        "value": n_total / t_full, "unit": "items/s", "cores": O.num_threads(), "kind": "port",
+        "search_qps": qps_full,
+        "measured_sample_items_per_s": ns / (t_graph + t_lam),
+        "sample": "oracle (C restatement, OpenMP %d threads) on the first %d rows of the same mixture: item graph "
+                  "%.2fs + lambdas %.3fs, %d queries %.2fs; value/search_qps are the n^2 (graph) and n (lambda, scan) "
+                  "extrapolations to N=%d" % (O.num_threads(), ns, t_graph, t_lam, nqs, t_search, n_total),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from arrowspace_amd import synth
+
+    ctx = A.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx._stream = torch.cuda.current_stream().cuda_stream
+    ops = D.HipOps(ctx)
+
+    n, d, nq = args.n, args.dim, args.nq
+    lo, hi = D.shard_range(n, rank, world)
+    X_host, cent = synth.mixture(hi - lo, d, seed=42, row_start=lo)
+    Xd = torch.from_numpy(X_host).to(dev)
+    qidx = synth.query_indices(n, nq, seed=42)
+    Q = torch.from_numpy(synth.mixture_at(qidx, d, seed=42) * 1.02).to(dev)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    sas = D.ShardedArrowSpace(ops, Xd, n, gp, A.TauMode.Median)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = {}
+
+    def build_step():
+        gl_items = sas.build_item_graph()
+        sas.build_lambdas(cent)
+        state["nnz"] = gl_items.matrix.nnz() if hasattr(gl_items, "matrix") else gl_items.nnz()
+        return gl_items
+
+    def search_step():
+        lq = sas.prepare_queries(Q)
+        idx, sc = sas.search(Q, lq, args.k, args.alpha)
+        state["top"] = (idx, sc)
+
+    for _ in range(args.warmup):
+        build_step()
+        search_step()
+    ctx.profile(True)
+    t_build = t_search = 0.0
+    sync()
+    t_all0 = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        build_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        search_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        t_build += t1 - t0
+        t_search += t2 - t1
+    sync()
+    t_all = time.perf_counter() - t_all0
+    times = torch.tensor([t_all, t_build, t_search], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    t_all, t_build, t_search = [float(x) for x in times]
+    prof = ctx.profile_all()
+    ctx.profile(False)
+
+    if rank == 0:
+        steps = args.steps
+        build_s = t_build / steps
+        search_s = t_search / steps
+        ms, launches = prof.get("knn_mfma_candidates", (0.0, 0))
+        rows_here = hi - lo
+        flops_per_launch = 2.0 * rows_here * n * d  # algorithmic: 2*n^2*d over the rows this rank owns
+        roofline = None
+        if launches:
+            achieved = flops_per_launch / (ms / launches * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma_kernel (f64 v_mfma_f64_16x16x4_f64)",
+                        "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_ms": ms / launches, "launches": launches}
+        lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
+        extra = {}
+        if lam_n:
+            # two launches per step hit this group: the N items and the nq queries
+            bytes_per_step = (rows_here + nq) * (8.0 * d + 8.0)
+            extra["taumode_scan_GBps"] = bytes_per_step * steps / (lam_ms * 1e-3) / 1e9
+            extra["taumode_scan_frac_hbm"] = extra["taumode_scan_GBps"] / HBM_PEAK_GBS
+        out = {
+            "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: %d x %d low-rank Gaussian mixture (seed 42), item-graph "
+                                   "with_lambda_graph(eps=0.5,k=16,topk=16,p=2,sigma=0.25) + per-item lambda-tau "
+                                   "(Median) + %d-query prepare+search_lambda_aware(k=%d, alpha=%.1f)"
+                                   % (n, d, nq, args.k, args.alpha),
+                       "n_items": n, "dim": d, "n_queries": nq, "sharding": "rows x %d" % world},
+            "search_qps": nq / search_s, "build_ms": build_s * 1e3, "search_ms": search_s * 1e3,
+            "item_graph_nnz": int(state.get("nnz", -1)),
+            "knn_uncertified_rows": ctx.stat("knn_uncertified_rows"),
+            "search_uncertified_rows": ctx.stat("search_uncertified_rows"),
+            "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items())},
+            "roofline": roofline,
+        }
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, lambda a, b: X_host[a:b], cent, n)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
