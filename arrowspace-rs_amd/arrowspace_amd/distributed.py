@@ -156,11 +156,11 @@ class ShardedArrowSpace:
         if kk < kmax:  # a shard smaller than k returns fewer columns
             idx = torch.cat([idx, torch.full((nq, kmax - kk), I64_NONE, dtype=idx.dtype, device=idx.device)], 1)
             sc = torch.cat([sc, torch.full((nq, kmax - kk), float("-inf"), dtype=sc.dtype, device=sc.device)], 1)
-        gi = torch.empty((self.world, nq, kmax), dtype=idx.dtype, device=idx.device)
-        gs = torch.empty((self.world, nq, kmax), dtype=sc.dtype, device=sc.device)
+        gi = torch.empty((self.world * nq, kmax), dtype=idx.dtype, device=idx.device)
+        gs = torch.empty((self.world * nq, kmax), dtype=sc.dtype, device=sc.device)
         dist.all_gather_into_tensor(gi, idx.contiguous())                 # RCCL all-gather #3
         dist.all_gather_into_tensor(gs, sc.contiguous())
-        return merge_topk(gi, gs, min(k, self.n))
+        return merge_topk(gi.view(self.world, nq, kmax), gs.view(self.world, nq, kmax), min(k, self.n))
 
 
 def merge_topk(gi, gs, k):

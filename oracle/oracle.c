@@ -148,29 +148,14 @@ static int edge_by_col(const void *a, const void *b) {
   return (x->j > y->j) - (x->j < y->j);
 }
 
-int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
-                        aso_csr *out) {
+/* K3..K5 from a complete neighbour table: src/laplacian.rs:217-417 */
+int aso_laplacian_from_knn(const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n,
+                           const aso_graph_params *p, aso_csr *out) {
   memset(out, 0, sizeof(*out));
-  /* src/laplacian.rs:128-134 */
-  if (n < 2 || d < 2) return ASO_ERR_SHAPE;
   const uint64_t K = p->topk + 1;
   const double sigma = p->has_sigma ? p->sigma : 1.0; /* src/laplacian.rs:254 */
-
-  double *scaled = NULL;
-  const double *R = rows;
-  if (p->normalise) {
-    scaled = standardise(rows, n, d);
-    if (!scaled) return ASO_ERR_ALLOC;
-    R = scaled;
-  }
-
-  uint64_t *nbr_idx = (uint64_t *)malloc(sizeof(uint64_t) * n * K);
-  double *nbr_dist = (double *)malloc(sizeof(double) * n * K);
   uint64_t *deg = (uint64_t *)calloc(n, sizeof(uint64_t));
-  if (!nbr_idx || !nbr_dist || !deg) return ASO_ERR_ALLOC;
-  int rc = knn_core(R, n, d, p, nbr_idx, nbr_dist);
-  free(scaled);
-  if (rc) return rc;
+  if (!deg) return ASO_ERR_ALLOC;
 
   /* degrees: src/laplacian.rs:217-227 */
   uint64_t deg_sum = 0;
@@ -284,8 +269,6 @@ int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_gr
   }
   out->indptr[n] = o;
 
-  free(nbr_idx);
-  free(nbr_dist);
   free(deg);
   free(adj);
   free(adj_len);
@@ -294,6 +277,31 @@ int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_gr
   free(cur);
   free(sym_len);
   return ASO_OK;
+}
+
+
+int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
+                        aso_csr *out) {
+  memset(out, 0, sizeof(*out));
+  /* src/laplacian.rs:128-134 */
+  if (n < 2 || d < 2) return ASO_ERR_SHAPE;
+  const uint64_t K = p->topk + 1;
+  double *scaled = NULL;
+  const double *R = rows;
+  if (p->normalise) {
+    scaled = standardise(rows, n, d);
+    if (!scaled) return ASO_ERR_ALLOC;
+    R = scaled;
+  }
+  uint64_t *nbr_idx = (uint64_t *)malloc(sizeof(uint64_t) * n * K);
+  double *nbr_dist = (double *)malloc(sizeof(double) * n * K);
+  if (!nbr_idx || !nbr_dist) return ASO_ERR_ALLOC;
+  int rc = knn_core(R, n, d, p, nbr_idx, nbr_dist);
+  free(scaled);
+  if (!rc) rc = aso_laplacian_from_knn(nbr_idx, nbr_dist, n, p, out);
+  free(nbr_idx);
+  free(nbr_dist);
+  return rc;
 }
 
 void aso_csr_free(aso_csr *m) {

@@ -73,6 +73,9 @@ int aso_knn_cosine(const double *rows, uint64_t n, uint64_t d, const aso_graph_p
 /* laplacian.rs:122-417: rows are nodes (row-major n x d) -> n x n CSR Laplacian */
 int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
                         aso_csr *out);
+/* laplacian.rs:217-417 from a complete neighbour table (n x (topk+1), as aso_knn_cosine writes) */
+int aso_laplacian_from_knn(const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n,
+                           const aso_graph_params *p, aso_csr *out);
 void aso_csr_free(aso_csr *m);
 
 /* taumode.rs:87-127 */

@@ -74,6 +74,7 @@ def lib():
         L.aso_define_result_k.argtypes = [C.c_uint64, C.c_uint64]
         L.aso_knn_cosine.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), up, dp]
         L.aso_build_laplacian.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), C.POINTER(Csr)]
+        L.aso_laplacian_from_knn.argtypes = [up, dp, C.c_uint64, C.POINTER(GraphParams), C.POINTER(Csr)]
         L.aso_csr_free.argtypes = [C.POINTER(Csr)]
         L.aso_csr_free.restype = None
         L.aso_select_tau.restype = C.c_double
@@ -144,6 +145,21 @@ def build_laplacian(rows, params):
     n, d = rows.shape
     out = Csr()
     rc = lib().aso_build_laplacian(_dp(rows), n, d, C.byref(params), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    indptr = np.ctypeslib.as_array(out.indptr, shape=(n + 1,)).copy()
+    indices = np.ctypeslib.as_array(out.indices, shape=(out.nnz,)).copy()
+    data = np.ctypeslib.as_array(out.data, shape=(out.nnz,)).copy()
+    lib().aso_csr_free(C.byref(out))
+    return indptr, indices, data
+
+
+def laplacian_from_knn(nbr_idx, nbr_dist, params):
+    nbr_idx = np.ascontiguousarray(nbr_idx, dtype=np.uint64)
+    nbr_dist = _f64(nbr_dist)
+    n = nbr_idx.shape[0]
+    out = Csr()
+    rc = lib().aso_laplacian_from_knn(_up(nbr_idx), _dp(nbr_dist), n, C.byref(params), C.byref(out))
     if rc:
         raise OracleError(rc)
     indptr = np.ctypeslib.as_array(out.indptr, shape=(n + 1,)).copy()

@@ -1,0 +1,146 @@
+"""world_size-2 test of the row-sharded driver (arrowspace_amd.distributed) on CPU with gloo.
+
+The product's compute backend (HipOps) needs a GPU; here the sharding / exchange / merge logic
+is exercised with a stand-in backend defined in THIS file on top of the oracle (tests may use
+the oracle as the checker).  What is verified: the sharded build and search reproduce the
+single-process oracle results exactly, for equal and for ragged shards.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import arrowspace_amd as A
+from arrowspace_amd import distributed as D
+from oracle import oracle_ctypes as O
+from tests import synth
+
+
+class _Csr:
+    def __init__(self, csr):
+        self.csr = csr
+
+    def nnz(self):
+        return len(self.csr[1])
+
+
+class _Gl:
+    def __init__(self, csr):
+        self.matrix = _Csr(csr)
+
+
+class OracleOps:
+    """Test-only stand-in for HipOps (CPU tensors in, CPU tensors out)."""
+
+    @staticmethod
+    def _gp(gp):
+        return O.graph_params(gp.eps, gp.k, gp.topk, gp.p, gp.sigma)
+
+    def knn_rows(self, X_full, row_begin, row_count, gp):
+        idx, dst = O.knn_cosine(X_full.numpy(), self._gp(gp))
+        sl = slice(row_begin, row_begin + row_count)
+        return torch.from_numpy(idx[sl].astype(np.int64)), torch.from_numpy(dst[sl].copy())
+
+    def laplacian_from_knn(self, idx, dst, gp):
+        return _Csr(O.laplacian_from_knn(idx.numpy().astype(np.uint64), dst.numpy(), self._gp(gp)))
+
+    def feature_laplacian(self, centroids, gp, n_items):
+        return _Gl(O.build_laplacian(np.ascontiguousarray(np.asarray(centroids).T), self._gp(gp)))
+
+    def lambdas(self, items, gl, taumode):
+        return torch.from_numpy(O.taumode_lambdas(items.numpy(), gl.matrix.csr, taumode.kind, taumode.arg))
+
+    def prepare_queries(self, items, queries, gl, taumode):
+        return torch.tensor([O.prepare_query_item(q, gl.matrix.csr, taumode.kind, taumode.arg)
+                             for q in queries.numpy()], dtype=torch.float64)
+
+    def make_index(self, items, lambdas, taumode, id_offset):
+        return (items.numpy(), lambdas.numpy(), int(id_offset))
+
+    def search(self, index, queries, q_lambdas, k, alpha):
+        X, lam, off = index
+        kk = min(k, len(X))
+        idx = np.full((len(queries), kk), -1, dtype=np.int64)
+        sc = np.full((len(queries), kk), -np.inf)
+        for j, q in enumerate(queries.numpy()):
+            i, s = O.search_lambda_aware(X, lam, q, float(q_lambdas[j]), kk, alpha)
+            idx[j, : len(i)] = i.astype(np.int64) + off
+            sc[j, : len(s)] = s
+        return torch.from_numpy(idx), torch.from_numpy(sc)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, cent = synth.mixture(n, d, seed=13, n_clusters=8, rank=3)
+        lo, hi = D.shard_range(n, rank, world)
+        gp = A.GraphParams(0.5, 8, 8, 2.0, 0.25)
+        sas = D.ShardedArrowSpace(OracleOps(), torch.from_numpy(X[lo:hi].copy()), n, gp, A.TauMode.Median)
+        csr = sas.build_item_graph().csr
+        sas.build_lambdas(cent)
+        Q = torch.from_numpy(X[[1, n // 2, n - 1]] * 1.02)
+        lq = sas.prepare_queries(Q)
+        idx, sc = sas.search(Q, lq, k, 0.7)
+        lam_all = D.all_gather_rows(sas.lambdas.reshape(-1, 1), sas.sizes).reshape(-1)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2],
+                 lam=lam_all.numpy(), idx=idx.numpy(), sc=sc.numpy(), lq=lq.numpy(),
+                 stats=np.array(sas.lambda_stats), lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(512, 5), (300, 7), (200, 150)])
+def test_sharded_build_and_search_match_single_process(tmp_path, n, k):
+    d, world = 16, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, d, k, str(tmp_path)), nprocs=world, join=True)
+    X, cent = synth.mixture(n, d, seed=13, n_clusters=8, rank=3)
+    gp = O.graph_params(0.5, 8, 8, 2.0, 0.25)
+    csr = O.build_laplacian(X, gp)
+    csrF = O.build_laplacian(np.ascontiguousarray(cent.T), gp)
+    lam = O.taumode_lambdas(X, csrF, O.TAU_MEDIAN)
+    Q = X[[1, n // 2, n - 1]] * 1.02
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["hi"])) == (0, int(r1["lo"]), n)
+    assert int(r1["lo"]) % 128 == 0  # shard starts sit on MFMA row-tile boundaries
+    for r in (r0, r1):
+        assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
+        assert np.array_equal(r["data"], csr[2])
+        assert np.array_equal(r["lam"], lam)
+        np.testing.assert_allclose(r["stats"], [lam.min(), lam.max(), lam.mean()], rtol=1e-12)
+        for j in range(3):
+            lq = O.prepare_query_item(Q[j], csrF, O.TAU_MEDIAN)
+            assert r["lq"][j] == lq
+            oi, osc = O.search_lambda_aware(X, lam, Q[j], lq, k, 0.7)
+            assert np.array_equal(r["idx"][j][: len(oi)], oi.astype(np.int64))
+            assert np.array_equal(r["sc"][j][: len(oi)], osc)
+
+
+def test_merge_topk_prefers_lower_index_on_ties():
+    gi = torch.tensor([[[0, 3]], [[130, 131]]])
+    gs = torch.tensor([[[0.9, 0.5]], [[0.9, 0.5]]], dtype=torch.float64)
+    idx, sc = D.merge_topk(gi, gs, 3)
+    assert idx.tolist() == [[0, 130, 3]] and sc.tolist() == [[0.9, 0.9, 0.5]]
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 127, 128, 129, 1000, 1_000_000, 4_000_000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo % 128 == 0 or lo == n for lo, _ in spans)
