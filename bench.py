@@ -28,7 +28,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 2048 flop / 64 cyc / SIMD x 1024 SIMDs x 2.4 GHz
+# v_mfma_f64_16x16x4_f64 issues every 128 cycles per SIMD on MI355X (measured, scripts/micro/mfma_f64_peak.hip,
+# profiles/r01_mfma_f64_issue_rate.txt): 2048 flop / 128 cyc x 1024 SIMDs x 2.4 GHz.  MI355X_MICROARCH.md has no
+# f64 MFMA row; the datasheet's FP64-matrix figure is 78.6 TF (reported next to it as frac_of_datasheet_78p6).
+F64_MFMA_PEAK_TFLOPS = 39.3
+F64_MATRIX_DATASHEET_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table
 
 
@@ -171,6 +175,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": "pair_topk_mfma_kernel (f64 v_mfma_f64_16x16x4_f64)",
                         "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "frac_of_datasheet_78p6": achieved / F64_MATRIX_DATASHEET_TFLOPS,
                         "avg_launch_ms": ms / launches, "launches": launches}
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
         extra = {}

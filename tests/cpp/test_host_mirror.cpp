@@ -1,0 +1,188 @@
+// test_host_mirror.cpp -- the reference's own tests for the lambda-tau path, restated against the
+// C++ host mirror (arrowspace-rs_amd/host/arrowspace.hpp) over libarrowspace_hip.so.
+// Each case names the reference test it follows (paths relative to /root/reference).
+// Needs an MI355X; run by tests/test_host_mirror_cpp.py under `pytest -m gpu`.
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <limits>
+#include <string>
+
+#include "../../arrowspace-rs_amd/host/arrowspace.hpp"
+
+using namespace arrowspace;
+using Rows = std::vector<std::vector<double>>;
+
+static int failures = 0, checks = 0;
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    ++checks;                                                            \
+    if (!(cond)) {                                                       \
+      ++failures;                                                        \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+    }                                                                    \
+  } while (0)
+
+static bool panics_with(const std::function<void()> &f, const std::string &needle) {
+  try {
+    f();
+  } catch (const Panic &p) {
+    return std::string(p.what()).find(needle) != std::string::npos;
+  }
+  return false;
+}
+
+static Rows create_test_vectors() {  // src/tests/test_laplacian.rs:12-20
+  return {{1.0, 0.0, 0.0}, {0.8, 0.6, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.8, 0.6}, {0.0, 0.0, 1.0}};
+}
+static GraphParams default_params() {  // src/tests/test_laplacian.rs:22-32
+  return GraphParams{0.5, 3, 2, 2.0, 0.1, false, true};
+}
+
+static void test_select_tau() {  // src/tests/test_taumode.rs:13-159
+  const double nan = std::nan(""), inf = std::numeric_limits<double>::infinity();
+  std::vector<double> e{0.1, 0.5, 1.0};
+  CHECK(TauMode::select_tau(e, TauMode::Fixed(0.3)) == 0.3);
+  CHECK(TauMode::select_tau(e, TauMode::Fixed(-0.1)) == TAU_FLOOR);
+  CHECK(TauMode::select_tau(e, TauMode::Fixed(0.0)) == TAU_FLOOR);
+  CHECK(TauMode::select_tau(e, TauMode::Fixed(nan)) == TAU_FLOOR);
+  CHECK(TauMode::select_tau(e, TauMode::Fixed(inf)) == TAU_FLOOR);
+  CHECK(std::fabs(TauMode::select_tau({1.0, 2.0, 3.0}, TauMode::Mean()) - 2.0) < 1e-12);
+  CHECK(std::fabs(TauMode::select_tau({1.0, nan, 3.0, inf, 2.0}, TauMode::Mean()) - 2.0) < 1e-12);
+  CHECK(TauMode::select_tau({nan, inf, -inf}, TauMode::Mean()) == TAU_FLOOR);
+  CHECK(TauMode::select_tau({}, TauMode::Mean()) == TAU_FLOOR);
+  CHECK(TauMode::select_tau({3.0, 1.0, 2.0}, TauMode::Median()) == 2.0);
+  CHECK(std::fabs(TauMode::select_tau({1.0, 2.0, 3.0, 4.0}, TauMode::Median()) - 2.5) < 1e-12);
+  CHECK(TauMode::select_tau({5.0}, TauMode::Median()) == 5.0);
+  CHECK(TauMode::select_tau({nan, 1.0, 3.0, inf, 2.0}, TauMode::Median()) == 2.0);
+  CHECK(TauMode::select_tau({nan, inf}, TauMode::Median()) == TAU_FLOOR);
+  std::vector<double> p{1.0, 2.0, 3.0, 4.0, 5.0};
+  CHECK(TauMode::select_tau(p, TauMode::Percentile(0.0)) == 1.0);
+  CHECK(TauMode::select_tau(p, TauMode::Percentile(1.0)) == 5.0);
+  CHECK(TauMode::select_tau(p, TauMode::Percentile(0.5)) == 3.0);
+  CHECK(TauMode::select_tau(p, TauMode::Percentile(-0.1)) == 1.0);
+  CHECK(TauMode::select_tau(p, TauMode::Percentile(1.5)) == 5.0);
+  CHECK(TauMode::select_tau({TAU_FLOOR / 2.0}, TauMode::Mean()) == TAU_FLOOR);
+}
+
+static void test_basic_laplacian_construction() {  // src/tests/test_laplacian.rs:34-49
+  auto items = create_test_vectors();
+  auto params = default_params();
+  GraphLaplacian gl = build_laplacian_matrix(transpose(items), params, std::nullopt);
+  CHECK(gl.matrix->shape().first == 3 && gl.matrix->shape().second == 3);
+  GraphLaplacian gl5 = build_laplacian_matrix(transpose(items), params, 5);
+  CHECK(gl5.nnodes == 5);
+}
+
+static void test_laplacian_mathematical_properties() {  // src/tests/test_laplacian.rs:51-152
+  auto items = create_test_vectors();
+  GraphLaplacian gl = build_laplacian_matrix(transpose(items), default_params(), std::nullopt);
+  const auto &ip = gl.matrix->indptr();
+  const auto &ix = gl.matrix->indices();
+  const auto &dv = gl.matrix->data();
+  const std::size_t n = gl.matrix->rows();
+  for (std::size_t i = 0; i < n; ++i) {
+    double row_sum = 0.0;
+    for (uint64_t e = ip[i]; e < ip[i + 1]; ++e) {
+      row_sum += dv[e];
+      const std::size_t j = ix[e];
+      CHECK(std::fabs(dv[e] - gl.matrix->get(j, i)) < 1e-12);  // symmetric
+      if (i != j) CHECK(dv[e] <= 1e-12);                        // off-diagonal non-positive
+    }
+    CHECK(std::fabs(row_sum) < 1e-12);       // row sums zero
+    CHECK(gl.matrix->get(i, i) >= -1e-12);   // diagonal non-negative
+  }
+  CHECK(ix.size() == gl.matrix->nnz() && dv.size() == gl.matrix->nnz());
+}
+
+static void test_insufficient_data_panics() {  // src/tests/test_laplacian.rs:302-311
+  CHECK(panics_with([] { build_laplacian_matrix(Rows{{1.0, 0.0, 0.5}}, default_params()); },
+                    "items should be at least of shape (2,2)"));
+}
+
+static void test_rayleigh_quotient_scale_invariance() {  // src/tests/test_taumode.rs:498-528
+  auto ctx = Context::shared();
+  auto L = CsMat::from_parts({0, 2, 4}, {0, 1, 0, 1}, {1.0, 0.5, 0.5, 1.0}, ctx);
+  auto lam = [&](std::vector<double> x) {
+    double out = 0.0;
+    ctx->check(as_compute_taumode(ctx->get(), x.data(), 1, x.size(), L->handle(), AS_TAU_FIXED, 0.5, &out));
+    return out;
+  };
+  const double l1 = lam({1.0, 2.0}), l2 = lam({2.0, 4.0});
+  CHECK(std::fabs(l1 - l2) <= 1e-10 * std::fabs(l1));
+  CHECK(std::fabs(l1 - 0.5 * (1.4 / 1.9)) < 1e-15);
+}
+
+static Rows make_rows(std::size_t n, std::size_t d) {  // deterministic clustered rows
+  Rows r(n, std::vector<double>(d));
+  for (std::size_t i = 0; i < n; ++i)
+    for (std::size_t c = 0; c < d; ++c)
+      r[i][c] = std::sin(0.37 * double(c + 1) * double(i % 7 + 1)) + 0.05 * std::cos(double(i * 31 + c * 17)) + 1.2;
+  return r;
+}
+
+static void test_build_and_search() {  // src/tests/test_querying_proj.rs:30-72,369-399; test_eigenmaps.rs:331-356
+  Rows rows = make_rows(300, 24);
+  auto [aspace, gl] = ArrowSpaceBuilder::new_()
+                          .with_lambda_graph(0.5, 16, 16, 2.0, 0.25)
+                          .with_synthesis(TauMode::Median())
+                          .build(rows);
+  CHECK(gl.nnodes == 300);
+  CHECK(gl.matrix->shape().first == 24);  // F x F graph (src/tests/test_builder.rs:338-339)
+  CHECK(aspace->lambdas().size() == 300);
+  bool in_range = true;
+  for (double l : aspace->lambdas()) in_range = in_range && std::isfinite(l) && l >= 0.0;
+  CHECK(in_range);
+  std::vector<double> q = rows[3];
+  for (double &v : q) v *= 1.02;
+  const double lq = aspace->prepare_query_item(q, gl);
+  CHECK(std::isfinite(lq));
+  auto res = aspace->search_lambda_aware(ArrowItem(q, lq), 5, 0.7);
+  CHECK(res.size() == 5);
+  for (std::size_t i = 0; i + 1 < res.size(); ++i) CHECK(res[i].second >= res[i + 1].second);
+  auto res1 = aspace->search_lambda_aware(ArrowItem(q, lq), 1, 1.0);  // alpha = 1: pure cosine, scaled copy wins
+  CHECK(res1.size() == 1 && res1[0].first % 7 == 3 && std::fabs(res1[0].second - 1.0) < 1e-12);
+  // NaN query (src/tests/test_querying_proj.rs:277-291), wrong dimension (:262-275), zero lambda (core.rs:773-776)
+  std::vector<double> bad = q;
+  bad[2] = std::nan("");
+  CHECK(panics_with([&] { aspace->prepare_query_item(bad, gl); }, "Query item contains invalid values"));
+  CHECK(panics_with([&] { aspace->prepare_query_item(std::vector<double>(q.begin(), q.begin() + 5), gl); },
+                    "doesn't match index original dimension"));
+  CHECK(panics_with([&] { aspace->search_lambda_aware(ArrowItem(q, 0.0), 3, 0.7); }, "Lambda of the item is 0.0"));
+}
+
+static void test_builder_defaults() {  // src/builder.rs:59-91,225-233
+  ArrowSpaceBuilder b;
+  CHECK(b.lambda_eps == 1e-3 && b.lambda_k == 6 && b.lambda_topk == 3 && b.lambda_p == 2.0 && !b.lambda_sigma);
+  b.define_result_k();
+  CHECK(b.lambda_topk == 4);
+  b.with_lambda_graph(0.5, 3, 9, 2.0, std::nullopt).define_result_k();
+  CHECK(b.lambda_topk == 3);
+}
+
+static void test_sparsity_check() {  // src/graph.rs:185-193
+  Rows cent(30, std::vector<double>(40));
+  for (std::size_t i = 0; i < 30; ++i)
+    for (std::size_t c = 0; c < 40; ++c) cent[i][c] = std::sin(double(i * 131 + c * 71)) * std::cos(double(i + 3 * c));
+  CHECK(panics_with(
+      [&] { GraphFactory::build_laplacian_matrix_from_k_cluster(cent, 1e-6, 6, 4, 2.0, std::nullopt, false, true, 100); },
+      "too sparse"));
+}
+
+int main() {
+  try {
+    test_select_tau();
+    test_basic_laplacian_construction();
+    test_laplacian_mathematical_properties();
+    test_insufficient_data_panics();
+    test_rayleigh_quotient_scale_invariance();
+    test_builder_defaults();
+    test_build_and_search();
+    test_sparsity_check();
+  } catch (const std::exception &e) {
+    std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%d checks, %d failures\n", checks, failures);
+  return failures ? 1 : 0;
+}
