@@ -138,6 +138,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   if (n == "knn_mfma") ctx->opt_knn_mfma = value;
   else if (n == "search_mfma") ctx->opt_search_mfma = value;
   else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
+  else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
   return AS_OK;
 }
@@ -391,6 +392,7 @@ void as_index_destroy(as_index *ix) {
   if (ix->own_lambdas) (void)hipFree((void *)ix->lambdas);
   (void)hipFree(ix->norms);
   if (ix->packed) (void)hipFree(ix->packed);
+  if (ix->packed32) (void)hipFree(ix->packed32);
   delete ix;
 }
 

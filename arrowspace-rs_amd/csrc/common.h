@@ -39,6 +39,7 @@ struct as_ctx {
   int64_t opt_knn_mfma = 1;       // 1: MFMA candidates + exact re-rank, 0: exact scan only
   int64_t opt_search_mfma = 1;    // same for the search scan
   int64_t opt_cand_slack = 8;     // extra candidates kept by the MFMA pass beyond topk+1
+  int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // stats of the last call
   std::map<std::string, int64_t> stats;
   // profiling
@@ -65,8 +66,8 @@ struct as_index {
   const double *lambdas = nullptr;  // n (device); owned iff own_lambdas
   bool own_items = false, own_lambdas = false;
   double *norms = nullptr;          // n exact norms
-  double *packed = nullptr;         // fragment-packed unit rows for the MFMA pass (lazy)
-  uint64_t n_pad = 0, d_pad = 0;
+  double *packed = nullptr;         // fragment-packed unit rows, f64 image (lazy)
+  float *packed32 = nullptr;        // fragment-packed unit rows, f32 image (lazy)
 };
 
 namespace asx {

@@ -1,0 +1,90 @@
+// mfma_common.cuh -- shared pieces of the MFMA candidate passes (f64 and f32) of K2 / K9.
+//
+// Scheme (exactness first), see DESIGN.md section 4:
+//   1. CANDIDATES  per row, a superset of the wanted top-K from an MFMA contraction over
+//      fragment-packed unit rows (never materialising the n x n product);
+//   2. EXACT RE-RANK of those candidates with the reference's f64 arithmetic;
+//   3. CERTIFICATION against a rigorous rounding bound; rows that fail go to the next, more
+//      precise stage (f32 MFMA -> f64 MFMA -> exact scan), so the output is bit-identical to the
+//      exact path.
+#pragma once
+
+#include "scan_topk.cuh"
+
+namespace asx {
+
+constexpr int kTileRows = 128;       // rows per packed tile
+constexpr int kMaxNC = 4;            // A fragments stay in registers up to d_pad = 128 (NC = d_pad / 32)
+constexpr uint32_t kQueueCap = 512;  // per-wave queue of elements that passed the threshold filter
+
+// LDS traffic between lanes of ONE wave: the hardware keeps a wave's LDS operations in order, so
+// only the compiler has to be told not to move memory operations across this point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Which global row an A-side row r is (self exclusion, per-row epilogue data).
+struct ARows {
+  const uint32_t *ids;  // gathered list, or nullptr
+  uint32_t row0;        // contiguous range start when ids == nullptr
+  __device__ __forceinline__ uint32_t gid(uint32_t r) const { return ids ? ids[r] : row0 + r; }
+};
+
+// ---- stage launchers (implemented in mfma_topk_f64.hip / mfma_topk_f32.hip) -------------------
+// mode 0: graph (key = -cos, self excluded); mode 1: search (key = -(alpha cos + (1-alpha) lam)).
+struct CandProblem {
+  int mode;
+  // A side
+  const double *A;        // source rows (unpacked), leading dimension d
+  const double *a_norms;  // indexed by global A id
+  ARows arows;
+  uint32_t nA;            // rows in this stage (range length or list length)
+  // B side
+  const double *B;
+  const double *b_norms;
+  uint32_t nB;
+  uint32_t d;
+  // search-only epilogue data
+  const double *q_lambdas;  // by global A id
+  const double *x_lambdas;  // by B row
+  double alpha;
+  // output: nA x splits x KC candidates, key = approximate key (ascending = better), idx = B row
+  uint32_t KC, splits;
+  double *cand_key;
+  uint32_t *cand_idx;
+};
+
+// Packed operand images.  The B image of the full matrix is built once per call (or cached in an
+// index) and shared by all stages of the same precision.
+struct PackedF64 {
+  DevBuf<double> buf;
+  const double *p = nullptr;
+  uint32_t tiles = 0;
+};
+struct PackedF32 {
+  DevBuf<float> buf;
+  const float *p = nullptr;
+  uint32_t tiles = 0;
+};
+
+int pack_f64(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
+             uint32_t d, double *P, uint32_t tiles);
+int pack_f32(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
+             uint32_t d, float *P, uint32_t tiles);
+uint64_t packed_elems(uint32_t tiles, uint32_t d);  // elements of a packed image with `tiles` 128-row tiles
+
+int candidates_f64(as_ctx *ctx, const CandProblem &pb, const double *PA, uint32_t a_tiles, const double *PB,
+                   uint32_t b_tiles, const char *prof_name);
+int candidates_f32(as_ctx *ctx, const CandProblem &pb, const float *PA, uint32_t a_tiles, const float *PB,
+                   uint32_t b_tiles, const char *prof_name);
+
+// rounding bound between an approximate cosine of a stage and the exact (oracle) cosine
+inline double cos_delta_f64(uint32_t d) { return (double)(d + 16) * 2.3e-16; }
+inline double cos_delta_f32(uint32_t d) {
+  const uint32_t dp = (d + 31) / 32 * 32;
+  return (double)(dp + 4) * 5.9604644775390625e-08 * 1.01 + 1e-13;  // (d+4) 2^-24 + f64 slack
+}
+
+}  // namespace asx

@@ -1,0 +1,500 @@
+// mfma_drivers.hip -- staged drivers of the MFMA neighbour search (K2) and search scan (K9):
+// candidate pass (f32 MFMA, then f64 MFMA for what f32 cannot certify) -> exact re-rank ->
+// certification -> exact scan for the remainder.  See mfma_common.cuh / DESIGN.md section 4.
+#include "mfma_common.cuh"
+
+namespace asx {
+
+// ---- exact re-rank + certification ------------------------------------------------------------
+// One wave per A row.  C = splits*KC candidates.  Policy = the exact scan's policy (same formulas).
+struct GraphBound {
+  double delta;
+  int rectify;
+  // lower bound on the exact key (distance) of any column that is NOT a candidate, given the
+  // largest approximate key (= -smallest kept cosine) among full candidate lists
+  __device__ __forceinline__ double lower_bound(double worst_approx_key) const {
+    const double cmax = -worst_approx_key + delta;  // its exact cosine is at most this
+    return rectify ? 1.0 - fmax(cmax, 0.0) : 1.0 - cmax;
+  }
+};
+struct SearchBound {
+  double delta;
+  __device__ __forceinline__ double lower_bound(double worst_approx_key) const { return worst_approx_key - delta; }
+};
+
+template <class Policy, class Bound>
+__global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ A, uint64_t lda,
+                                                     const double *__restrict__ B, uint64_t ldb, uint32_t d,
+                                                     const uint32_t *__restrict__ a_ids, uint32_t a_begin,
+                                                     uint32_t a_count, uint32_t K, uint32_t KC,
+                                                     uint32_t splits, const double *__restrict__ cand_key,
+                                                     const uint32_t *__restrict__ cand_idx,
+                                                     const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd,
+                                                     double *__restrict__ out_key, uint32_t *__restrict__ out_idx,
+                                                     uint32_t *__restrict__ fail_rows,
+                                                     uint32_t *__restrict__ fail_count, int *__restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t C = splits * KC;
+  // per wave: row copy (d) + exact keys (C) + idx (C)
+  double *xrow = reinterpret_cast<double *>(smem) + (size_t)wv * (d + C);
+  double *ek = xrow + d;
+  uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(smem) + (size_t)4 * (d + C)) + (size_t)wv * C;
+
+  for (uint32_t r = blockIdx.x * 4 + wv; r < a_count; r += gridDim.x * 4) {
+    const uint32_t a = a_ids ? a_ids[r] : a_begin + r;
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = A[(uint64_t)a * lda + k];
+    wave_sync();
+    // worst approximate key over FULL lists (a list that is not full saw every column of its split)
+    double worst = __builtin_inf();
+    bool bounded = false;
+    for (uint32_t s = 0; s < splits; ++s) {
+      const size_t o = ((size_t)r * splits + s) * KC + KC - 1;
+      if (cand_idx[o] != kNoIdx) {  // full list: columns outside it have approx key >= its last key
+        bounded = true;
+        worst = fmin(worst, cand_key[o]);
+      }
+    }
+    // exact keys of the candidates
+    for (uint32_t c = lane; c < C; c += 64) {
+      const uint32_t j = cand_idx[(size_t)r * C + c];
+      double key = __builtin_inf();
+      uint32_t id = kNoIdx;
+      if (j != kNoIdx) {
+        const double *bj = B + (uint64_t)j * ldb;
+        double acc = 0.0;
+        for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
+        double kx;
+        if (pol.key(acc, a, j, kx, err_flag)) {
+          key = kx;
+          id = j;
+        }
+      }
+      ek[c] = key;
+      ei[c] = id;
+    }
+    wave_sync();
+    // rank by (key, idx); ranks < K go to the output
+    double kth = -__builtin_inf();
+    uint32_t n_valid = 0;
+    for (uint32_t c = lane; c < C; c += 64) {
+      const double kc = ek[c];
+      const uint32_t ic = ei[c];
+      if (ic == kNoIdx) continue;
+      ++n_valid;
+      uint32_t rank = 0;
+      for (uint32_t c2 = 0; c2 < C; ++c2) rank += lex_less(ek[c2], ei[c2], kc, ic) ? 1u : 0u;
+      if (rank < K) {
+        out_key[(uint64_t)r * K + rank] = kc;
+        out_idx[(uint64_t)r * K + rank] = ic;
+        kth = fmax(kth, kc);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      kth = fmax(kth, __shfl_xor(kth, o, 64));
+      n_valid += __shfl_xor(n_valid, o, 64);
+    }
+    for (uint32_t s = n_valid + lane; s < K; s += 64) {  // fewer than K candidates exist at all
+      out_key[(uint64_t)r * K + s] = __builtin_inf();
+      out_idx[(uint64_t)r * K + s] = kNoIdx;
+    }
+    bool ok = true;
+    if (bounded) ok = n_valid >= K && kth < bnd.lower_bound(worst);
+    if (force_exact && force_exact[a]) ok = false;
+    if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+  }
+}
+
+// Pairs with 0 < |a||b| <= 1e-12 get cos := 0 in the exact rule but a genuine cosine from the unit
+// rows; a row that can form such a pair is always re-done exactly.  (Exactly-zero rows are
+// consistent: their unit row is 0, so the product is 0 as well.)
+__global__ void flag_tiny_norm_rows_kernel(const double *__restrict__ norms, uint32_t n, double min_pos_norm,
+                                           uint8_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const double x = norms[i];
+    flag[i] = (x != x) || (x > 0.0 && !(x * min_pos_norm > 1e-12)) ? 1 : 0;
+  }
+}
+
+__global__ void min_norm_kernel(const double *__restrict__ norms, uint32_t n, unsigned long long *out) {
+  // norms are >= 0 (or NaN): the bit pattern of a non-negative double orders like the value
+  double v = __builtin_inf();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double x = norms[i];
+    if (x > 0.0 && x < v) v = x;  // smallest POSITIVE norm
+  }
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMin(out, (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void scatter_rows_kernel(const uint32_t *__restrict__ rows, uint32_t count, uint32_t K,
+                                    const double *__restrict__ src_key, const uint32_t *__restrict__ src_idx,
+                                    double *__restrict__ dst_key, uint32_t *__restrict__ dst_idx) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * K) return;
+  const uint32_t r = t / K, s = t - r * K;
+  dst_key[(uint64_t)rows[r] * K + s] = src_key[t];
+  dst_idx[(uint64_t)rows[r] * K + s] = src_idx[t];
+}
+
+
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ pos,
+                                  uint32_t count, uint32_t add, uint32_t *__restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) out[t] = (table ? table[pos[t]] : pos[t]) + add;
+}
+
+static uint32_t pick_splits(uint32_t a_items, uint32_t b_tiles) {
+  // keep >= ~4 work items per CU when the A side is short (query batches, small graphs, fall-back lists)
+  uint32_t s = 1;
+  while (a_items * s < 1024 && s * 2 <= b_tiles && s < 16) s *= 2;
+  return s;
+}
+
+static uint32_t cand_capacity(as_ctx *ctx, uint32_t K) {
+  uint32_t kc = K + (uint32_t)ctx->opt_cand_slack;
+  kc = (kc + 7) / 8 * 8;
+  return std::min<uint32_t>(kc, 64);
+}
+
+constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straight to the exact scan
+
+template <class Policy, class Bound>
+static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const double *B, uint32_t d,
+                         const uint32_t *a_ids, uint32_t a_begin, uint32_t a_count, uint32_t K, uint32_t KC,
+                         uint32_t splits, const double *ckey, const uint32_t *cidx, const uint8_t *force, Policy pol,
+                         Bound bnd, double *out_key, uint32_t *out_idx, uint32_t *fail_rows, uint32_t *fail_count,
+                         int *err) {
+  const uint32_t C = splits * KC;
+  const size_t lds = (size_t)4 * (d + C) * sizeof(double) + (size_t)4 * C * sizeof(uint32_t);
+  ProfScope ps(ctx, name);
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_kernel<Policy, Bound>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((rerank_kernel<Policy, Bound>), dim3(std::min<uint64_t>(cdiv(a_count, 4), 4096)), dim3(256), lds,
+                     ctx->stream, A, (uint64_t)d, B, (uint64_t)d, d, a_ids, a_begin, a_count, K, KC, splits, ckey, cidx,
+                     force, pol, bnd, out_key, out_idx, fail_rows, fail_count, err);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+static int read_u32(as_ctx *ctx, const uint32_t *dev, uint32_t *host) {
+  AS_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+// ---- K2 driver ----------------------------------------------------------------------------------
+int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64, uint64_t d64, uint64_t row_begin,
+             uint64_t row_count64, uint32_t K, int rectify, uint32_t *out_idx, double *out_dist) {
+  const uint32_t n = (uint32_t)n64, d = (uint32_t)d64, row_count = (uint32_t)row_count64;
+  const int NC = (int)((d + 31) / 32);
+  // one extra slot: a row's own index is the best candidate of its list and is dropped by the re-rank
+  const uint32_t KC = cand_capacity(ctx, K + 1);
+  if (NC > kMaxNC || K + 1 > 56 || n < 4 * kTileRows || row_count == 0)  // small or wide problems: exact scan
+    return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
+  const bool use_f32 = ctx->opt_cand_precision != 64;
+
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
+  const uint32_t b_alloc = (b_tiles + 1) & ~1u;  // even: the f32 pass reads A tiles in pairs
+
+  // rows whose pairs may hit the 0 < |a||b| <= 1e-12 rule are always re-done exactly
+  DevBuf<unsigned long long> minb;
+  DevBuf<uint8_t> force;
+  AS_TRY(minb.alloc(ctx, 1));
+  AS_TRY(force.alloc(ctx, n));
+  const unsigned long long inf_bits = 0x7FF0000000000000ull;
+  AS_HIP(ctx, hipMemcpyAsync(minb.p, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(min_norm_kernel, dim3(256), dim3(256), 0, ctx->stream, norms, n, minb.p);
+  unsigned long long mb = 0;
+  AS_HIP(ctx, hipMemcpyAsync(&mb, minb.p, sizeof(mb), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double min_norm;
+  std::memcpy(&min_norm, &mb, sizeof(double));
+  hipLaunchKernelGGL(flag_tiny_norm_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, n, min_norm,
+                     force.p);
+
+  DevBuf<uint32_t> fail1, fail_count;
+  DevBuf<int> err;
+  AS_TRY(fail1.alloc(ctx, row_count));
+  AS_TRY(fail_count.alloc(ctx, 1));
+  AS_TRY(err.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+  GraphDistPolicy pol{norms, rectify};
+
+  CandProblem pb{};
+  pb.mode = 0;
+  pb.A = rows;
+  pb.a_norms = norms;
+  pb.arows = ARows{nullptr, (uint32_t)row_begin};
+  pb.nA = row_count;
+  pb.B = rows;
+  pb.b_norms = norms;
+  pb.nB = n;
+  pb.d = d;
+  pb.KC = KC;
+
+  // ---- stage 1 over the contiguous row range ----
+  PackedF32 B32;
+  PackedF64 B64;
+  uint32_t n_fail = 0;
+  {
+    const uint32_t align = use_f32 ? 2 * kTileRows : kTileRows;
+    const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows;
+    const uint32_t a_items = use_f32 ? (a_tiles + 1) / 2 : a_tiles;
+    pb.splits = pick_splits(a_items, b_tiles);
+    DevBuf<double> ckey;
+    DevBuf<uint32_t> cidx;
+    AS_TRY(ckey.alloc(ctx, (size_t)row_count * pb.splits * KC));
+    AS_TRY(cidx.alloc(ctx, (size_t)row_count * pb.splits * KC));
+    pb.cand_key = ckey.p;
+    pb.cand_idx = cidx.p;
+    if (use_f32) {
+      AS_TRY(B32.buf.alloc(ctx, packed_elems(b_alloc, d)));
+      AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, B32.buf.p, b_alloc));
+      B32.p = B32.buf.p;
+      PackedF32 A32;
+      const float *PA = B32.p + (row_begin / kTileRows) * packed_elems(1, d);
+      if (row_begin % align != 0) {
+        const uint32_t at = (a_tiles + 1) & ~1u;
+        AS_TRY(A32.buf.alloc(ctx, packed_elems(at, d)));
+        AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, A32.buf.p, at));
+        PA = A32.buf.p;
+      }
+      AS_TRY(candidates_f32(ctx, pb, PA, a_tiles, B32.p, b_tiles, "knn_mfma_candidates_f32"));
+      GraphBound bnd{cos_delta_f32(d), rectify};
+      AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin, row_count, K, KC, pb.splits,
+                           ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p));
+    } else {
+      AS_TRY(B64.buf.alloc(ctx, packed_elems(b_alloc, d)));
+      AS_TRY(pack_f64(ctx, rows, norms, nullptr, 0, n, d, B64.buf.p, b_alloc));
+      B64.p = B64.buf.p;
+      PackedF64 A64;
+      const double *PA = B64.p + (row_begin / kTileRows) * packed_elems(1, d);
+      if (row_begin % align != 0) {
+        AS_TRY(A64.buf.alloc(ctx, packed_elems(a_tiles, d)));
+        AS_TRY(pack_f64(ctx, rows, norms, nullptr, row_begin, row_count, d, A64.buf.p, a_tiles));
+        PA = A64.buf.p;
+      }
+      AS_TRY(candidates_f64(ctx, pb, PA, a_tiles, B64.p, b_tiles, "knn_mfma_candidates"));
+      GraphBound bnd{cos_delta_f64(d), rectify};
+      AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin, row_count, K, KC, pb.splits,
+                           ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p));
+    }
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
+  }
+  ctx->stats["knn_uncertified_rows"] = n_fail;
+  ctx->stats["knn_uncertified_rows_stage2"] = 0;
+  ctx->stats["knn_cand_capacity"] = KC;
+  ctx->stats["knn_col_splits"] = pb.splits;
+  if (n_fail == 0) return AS_OK;
+
+  // global ids of the failed rows
+  DevBuf<uint32_t> gids;
+  AS_TRY(gids.alloc(ctx, n_fail));
+  hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t *)nullptr, fail1.p, n_fail, (uint32_t)row_begin, gids.p);
+  const uint32_t *exact_ids = gids.p;      // rows for the exact scan ...
+  const uint32_t *exact_pos = fail1.p;     // ... and where their results go (row positions in the range)
+  uint32_t n_exact = n_fail;
+  DevBuf<uint32_t> fail2, gids2, pos2;
+
+  // ---- stage 2: f64 MFMA over the gathered failed rows ----
+  if (use_f32 && n_fail > kExactDirect) {
+    const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
+    pb.arows = ARows{gids.p, 0};
+    pb.nA = n_fail;
+    pb.splits = pick_splits(a_tiles, b_tiles);
+    DevBuf<double> ckey, A64, ok;
+    DevBuf<uint32_t> cidx, oi;
+    AS_TRY(ckey.alloc(ctx, (size_t)n_fail * pb.splits * KC));
+    AS_TRY(cidx.alloc(ctx, (size_t)n_fail * pb.splits * KC));
+    pb.cand_key = ckey.p;
+    pb.cand_idx = cidx.p;
+    AS_TRY(B64.buf.alloc(ctx, packed_elems(b_alloc, d)));
+    AS_TRY(pack_f64(ctx, rows, norms, nullptr, 0, n, d, B64.buf.p, b_alloc));
+    AS_TRY(A64.alloc(ctx, packed_elems(a_tiles, d)));
+    AS_TRY(pack_f64(ctx, rows, norms, gids.p, 0, n_fail, d, A64.p, a_tiles));
+    AS_TRY(candidates_f64(ctx, pb, A64.p, a_tiles, B64.buf.p, b_tiles, "knn_mfma_candidates"));
+    AS_TRY(ok.alloc(ctx, (size_t)n_fail * K));
+    AS_TRY(oi.alloc(ctx, (size_t)n_fail * K));
+    AS_TRY(fail2.alloc(ctx, n_fail));
+    AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+    GraphBound bnd{cos_delta_f64(d), rectify};
+    AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, gids.p, 0u, n_fail, K, KC, pb.splits, ckey.p, cidx.p,
+                         force.p, pol, bnd, ok.p, oi.p, fail2.p, fail_count.p, err.p));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_fail * K, 256)), dim3(256), 0, ctx->stream, fail1.p,
+                       n_fail, K, ok.p, oi.p, out_dist, out_idx);
+    uint32_t n_fail2 = 0;
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail2));
+    ctx->stats["knn_uncertified_rows_stage2"] = n_fail2;
+    if (n_fail2 == 0) return AS_OK;
+    AS_TRY(gids2.alloc(ctx, n_fail2));
+    AS_TRY(pos2.alloc(ctx, n_fail2));
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail2, 256)), dim3(256), 0, ctx->stream, gids.p, fail2.p, n_fail2,
+                       0u, gids2.p);
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail2, 256)), dim3(256), 0, ctx->stream, fail1.p, fail2.p,
+                       n_fail2, 0u, pos2.p);
+    exact_ids = gids2.p;
+    exact_pos = pos2.p;
+    n_exact = n_fail2;
+  }
+
+  // ---- last stage: exact scan ----
+  DevBuf<double> fk;
+  DevBuf<uint32_t> fi;
+  AS_TRY(fk.alloc(ctx, (size_t)n_exact * K));
+  AS_TRY(fi.alloc(ctx, (size_t)n_exact * K));
+  AS_TRY(knn_exact(ctx, rows, norms, n, d, exact_ids, 0, n_exact, K, rectify, fi.p, fk.p, 0));
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_exact * K, 256)), dim3(256), 0, ctx->stream, exact_pos,
+                     n_exact, K, fk.p, fi.p, out_dist, out_idx);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// ---- K9 driver ----------------------------------------------------------------------------------
+int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms, const double *q_lambdas,
+                uint64_t nq64, uint32_t k, double alpha, uint32_t *out_idx, double *out_key) {
+  const uint32_t n = (uint32_t)ix->n, d = (uint32_t)ix->d, nq = (uint32_t)nq64;
+  const int NC = (int)((d + 31) / 32);
+  const uint32_t K = std::min<uint32_t>(k, n);
+  if (NC > kMaxNC || K > 56 || n < 4 * kTileRows || nq == 0)
+    return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
+  const bool use_f32 = ctx->opt_cand_precision != 64;
+  const uint32_t KC = cand_capacity(ctx, K);
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
+  const uint32_t b_alloc = (b_tiles + 1) & ~1u;
+  auto ensure64 = [&]() -> int {
+    if (!ix->packed) {
+      AS_HIP(ctx, hipMalloc((void **)&ix->packed, sizeof(double) * packed_elems(b_alloc, d)));
+      AS_TRY(pack_f64(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed, b_alloc));
+    }
+    return AS_OK;
+  };
+  auto ensure32 = [&]() -> int {
+    if (!ix->packed32) {
+      AS_HIP(ctx, hipMalloc((void **)&ix->packed32, sizeof(float) * packed_elems(b_alloc, d)));
+      AS_TRY(pack_f32(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed32, b_alloc));
+    }
+    return AS_OK;
+  };
+
+  DevBuf<uint32_t> fail1, fail_count;
+  DevBuf<int> err;
+  AS_TRY(fail1.alloc(ctx, nq));
+  AS_TRY(fail_count.alloc(ctx, 1));
+  AS_TRY(err.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+  SearchScorePolicy pol{q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
+
+  CandProblem pb{};
+  pb.mode = 1;
+  pb.A = queries;
+  pb.a_norms = q_norms;
+  pb.arows = ARows{nullptr, 0};
+  pb.nA = nq;
+  pb.B = ix->items;
+  pb.b_norms = ix->norms;
+  pb.nB = n;
+  pb.d = d;
+  pb.q_lambdas = q_lambdas;
+  pb.x_lambdas = ix->lambdas;
+  pb.alpha = alpha;
+  pb.KC = KC;
+
+  uint32_t n_fail = 0;
+  {
+    const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows;
+    const uint32_t a_items = use_f32 ? (a_tiles + 1) / 2 : a_tiles;
+    pb.splits = pick_splits(a_items, b_tiles);
+    DevBuf<double> ckey;
+    DevBuf<uint32_t> cidx;
+    AS_TRY(ckey.alloc(ctx, (size_t)nq * pb.splits * KC));
+    AS_TRY(cidx.alloc(ctx, (size_t)nq * pb.splits * KC));
+    pb.cand_key = ckey.p;
+    pb.cand_idx = cidx.p;
+    if (use_f32) {
+      AS_TRY(ensure32());
+      const uint32_t at = (a_tiles + 1) & ~1u;
+      DevBuf<float> PA;
+      AS_TRY(PA.alloc(ctx, packed_elems(at, d)));
+      AS_TRY(pack_f32(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, at));
+      AS_TRY(candidates_f32(ctx, pb, PA.p, a_tiles, ix->packed32, b_tiles, "search_mfma_candidates_f32"));
+      SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + 2e-6};
+      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, K, KC, pb.splits, ckey.p,
+                           cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
+    } else {
+      AS_TRY(ensure64());
+      DevBuf<double> PA;
+      AS_TRY(PA.alloc(ctx, packed_elems(a_tiles, d)));
+      AS_TRY(pack_f64(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, a_tiles));
+      AS_TRY(candidates_f64(ctx, pb, PA.p, a_tiles, ix->packed, b_tiles, "search_mfma_candidates"));
+      SearchBound bnd{std::fabs(alpha) * cos_delta_f64(d) + 1e-15};
+      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, K, KC, pb.splits, ckey.p,
+                           cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
+    }
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
+  }
+  ctx->stats["search_uncertified_rows"] = n_fail;
+  ctx->stats["search_uncertified_rows_stage2"] = 0;
+  ctx->stats["search_cand_capacity"] = KC;
+  ctx->stats["search_col_splits"] = pb.splits;
+
+  const uint32_t *exact_ids = fail1.p;
+  uint32_t n_exact = n_fail;
+  DevBuf<uint32_t> fail2, ids2;
+  if (use_f32 && n_fail > kExactDirect) {
+    const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
+    pb.arows = ARows{fail1.p, 0};
+    pb.nA = n_fail;
+    pb.splits = pick_splits(a_tiles, b_tiles);
+    DevBuf<double> ckey, PA, ok;
+    DevBuf<uint32_t> cidx, oi;
+    AS_TRY(ckey.alloc(ctx, (size_t)n_fail * pb.splits * KC));
+    AS_TRY(cidx.alloc(ctx, (size_t)n_fail * pb.splits * KC));
+    pb.cand_key = ckey.p;
+    pb.cand_idx = cidx.p;
+    AS_TRY(ensure64());
+    AS_TRY(PA.alloc(ctx, packed_elems(a_tiles, d)));
+    AS_TRY(pack_f64(ctx, queries, q_norms, fail1.p, 0, n_fail, d, PA.p, a_tiles));
+    AS_TRY(candidates_f64(ctx, pb, PA.p, a_tiles, ix->packed, b_tiles, "search_mfma_candidates"));
+    AS_TRY(ok.alloc(ctx, (size_t)n_fail * K));
+    AS_TRY(oi.alloc(ctx, (size_t)n_fail * K));
+    AS_TRY(fail2.alloc(ctx, n_fail));
+    AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+    SearchBound bnd{std::fabs(alpha) * cos_delta_f64(d) + 1e-15};
+    AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, fail1.p, 0u, n_fail, K, KC, pb.splits, ckey.p,
+                         cidx.p, (const uint8_t *)nullptr, pol, bnd, ok.p, oi.p, fail2.p, fail_count.p, err.p));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_fail * K, 256)), dim3(256), 0, ctx->stream, fail1.p,
+                       n_fail, K, ok.p, oi.p, out_key, out_idx);
+    uint32_t n_fail2 = 0;
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail2));
+    ctx->stats["search_uncertified_rows_stage2"] = n_fail2;
+    n_exact = n_fail2;
+    if (n_fail2) {
+      AS_TRY(ids2.alloc(ctx, n_fail2));
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail2, 256)), dim3(256), 0, ctx->stream, fail1.p, fail2.p,
+                         n_fail2, 0u, ids2.p);
+      exact_ids = ids2.p;
+    }
+  }
+  int h_err = 0;
+  AS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_err) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
+  if (n_exact) {
+    DevBuf<double> fk;
+    DevBuf<uint32_t> fi;
+    AS_TRY(fk.alloc(ctx, (size_t)n_exact * K));
+    AS_TRY(fi.alloc(ctx, (size_t)n_exact * K));
+    AS_TRY(search_exact(ctx, ix, queries, q_norms, q_lambdas, exact_ids, n_exact, nq, K, alpha, fi.p, fk.p));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_exact * K, 256)), dim3(256), 0, ctx->stream,
+                       exact_ids, n_exact, K, fk.p, fi.p, out_key, out_idx);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  return AS_OK;
+}
+
+}  // namespace asx

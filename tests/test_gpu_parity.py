@@ -24,13 +24,16 @@ def ctx():
     return A.default_context()
 
 
-@pytest.fixture(params=[0, 1], ids=["exact", "mfma"])
+@pytest.fixture(params=[0, 32, 64], ids=["exact", "mfma_f32", "mfma_f64"])
 def mode(request, ctx):
-    ctx.set_option("knn_mfma", request.param)
-    ctx.set_option("search_mfma", request.param)
+    """exact scan only / f32 MFMA candidates (then f64, then exact) / f64 MFMA candidates first"""
+    ctx.set_option("knn_mfma", int(request.param != 0))
+    ctx.set_option("search_mfma", int(request.param != 0))
+    ctx.set_option("cand_precision", request.param or 32)
     yield request.param
     ctx.set_option("knn_mfma", 1)
     ctx.set_option("search_mfma", 1)
+    ctx.set_option("cand_precision", 32)
 
 
 def ogp(p):
