@@ -138,6 +138,8 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   if (n == "knn_mfma") ctx->opt_knn_mfma = value;
   else if (n == "search_mfma") ctx->opt_search_mfma = value;
   else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
+  else if (n == "debug") ctx->opt_debug = value;
+  else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
   return AS_OK;
@@ -427,7 +429,7 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
   AS_TRY(keys.alloc(ctx, nq * kk));
   AS_TRY(idx32.alloc(ctx, nq * kk));
   AS_TRY(row_norms(ctx, Q.p, nq, d, qn.p));
-  if (ctx->opt_search_mfma && kk <= 56)
+  if (ctx->opt_search_mfma && kk <= 64)
     AS_TRY(search_mfma(ctx, const_cast<as_index *>(index), Q.p, qn.p, QL.p, nq, kk, alpha, idx32.p, keys.p));
   else
     AS_TRY(search_exact(ctx, index, Q.p, qn.p, QL.p, nullptr, nq, nq, kk, alpha, idx32.p, keys.p));

@@ -39,6 +39,8 @@ struct as_ctx {
   int64_t opt_knn_mfma = 1;       // 1: MFMA candidates + exact re-rank, 0: exact scan only
   int64_t opt_search_mfma = 1;    // same for the search scan
   int64_t opt_cand_slack = 8;     // extra candidates kept by the MFMA pass beyond topk+1
+  int64_t opt_waves_per_simd = 2; // f32 candidate pass: 2 = 8 waves x 32 rows, 1 = 4 waves x 64 rows
+  int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // stats of the last call
   std::map<std::string, int64_t> stats;

@@ -80,6 +80,9 @@ int candidates_f64(as_ctx *ctx, const CandProblem &pb, const double *PA, uint32_
 int candidates_f32(as_ctx *ctx, const CandProblem &pb, const float *PA, uint32_t a_tiles, const float *PB,
                    uint32_t b_tiles, const char *prof_name);
 
+bool fits_f32(uint32_t KC);  // does a candidate capacity fit the kernel's LDS budget?
+bool fits_f64(uint32_t KC);
+
 // rounding bound between an approximate cosine of a stage and the exact (oracle) cosine
 inline double cos_delta_f64(uint32_t d) { return (double)(d + 16) * 2.3e-16; }
 inline double cos_delta_f32(uint32_t d) {

@@ -191,9 +191,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const int NC = (int)((d + 31) / 32);
   // one extra slot: a row's own index is the best candidate of its list and is dropped by the re-rank
   const uint32_t KC = cand_capacity(ctx, K + 1);
-  if (NC > kMaxNC || K + 1 > 56 || n < 4 * kTileRows || row_count == 0)  // small or wide problems: exact scan
+  const bool use_f32 = ctx->opt_cand_precision != 64 && fits_f32(KC);
+  if (NC > kMaxNC || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0)  // small, wide or deep problems: exact scan
     return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
-  const bool use_f32 = ctx->opt_cand_precision != 64;
 
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;  // even: the f32 pass reads A tiles in pairs
@@ -263,6 +263,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         PA = A32.buf.p;
       }
       AS_TRY(candidates_f32(ctx, pb, PA, a_tiles, B32.p, b_tiles, "knn_mfma_candidates_f32"));
+      if (ctx->opt_debug) return AS_OK;  // timing experiment: candidate pass only, outputs undefined
       GraphBound bnd{cos_delta_f32(d), rectify};
       AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin, row_count, K, KC, pb.splits,
                            ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p));
@@ -359,10 +360,10 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t n = (uint32_t)ix->n, d = (uint32_t)ix->d, nq = (uint32_t)nq64;
   const int NC = (int)((d + 31) / 32);
   const uint32_t K = std::min<uint32_t>(k, n);
-  if (NC > kMaxNC || K > 56 || n < 4 * kTileRows || nq == 0)
-    return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
-  const bool use_f32 = ctx->opt_cand_precision != 64;
   const uint32_t KC = cand_capacity(ctx, K);
+  if (NC > kMaxNC || !fits_f64(KC) || n < 4 * kTileRows || nq == 0)
+    return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
+  const bool use_f32 = ctx->opt_cand_precision != 64 && fits_f32(KC);
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   auto ensure64 = [&]() -> int {

@@ -21,8 +21,8 @@ namespace asx {
 
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 
-constexpr int kKs2Chunk = 16;                     // k-steps (2 k each) per LDS chunk = 32 k values
-constexpr int kChunkFloats = kKs2Chunk * 4 * 64;  // 4096 floats = 16 KB
+constexpr int kKs2Unit = 16;                      // k-steps (2 k each) per packed 16 KB unit = 32 k values
+constexpr int kUnitFloats = kKs2Unit * 4 * 64;    // 4096 floats = 16 KB
 constexpr int kRows32 = 256;                      // A rows per workgroup
 
 __global__ void pack_f32_kernel(const double *__restrict__ R, const double *__restrict__ norms,
@@ -98,45 +98,58 @@ __device__ __forceinline__ void list_insert32(float *lv, uint32_t *li, int KC, i
   wave_sync();
 }
 
-// LDS-DMA copy of one 16 KB chunk: wave w moves 4 x 1 KB pieces (global_load_lds_dwordx4: per-lane
-// global address, wave-uniform LDS base + 16 B per lane).
+// LDS-DMA copy of one chunk of CPB x 16 KB: the 1 KB pieces are dealt to the waves
+// (global_load_lds_dwordx4: per-lane global address, wave-uniform LDS base + 16 B per lane).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+template <int CPB, int WAVES>
 __device__ __forceinline__ void stage_chunk(const float *src, float *dst_lds, int wv, int lane) {
+  constexpr int PER = 16 * CPB / WAVES;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int piece = wv * 4 + q;  // 1 KB pieces 0..15
+  for (int q = 0; q < PER; ++q) {
+    const int piece = wv * PER + q;
     __builtin_amdgcn_global_load_lds((gbl_void *)(src + piece * 256 + lane * 4), (lds_void *)(dst_lds + piece * 256), 16, 0,
                                      0);
   }
 }
 
-template <int NC, class Epi>
-__global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *__restrict__ PA, uint32_t a_items,
-                                                                   const float *__restrict__ PB, uint32_t b_tiles,
-                                                                   uint32_t nA, uint32_t nB, uint32_t KC,
-                                                                   uint32_t splits, Epi epi,
-                                                                   double *__restrict__ cand_key,
-                                                                   uint32_t *__restrict__ cand_idx) {
-  constexpr int KS2 = NC * kKs2Chunk;
+// NC  = 16 KB units per B tile (d_pad / 32);  CPB = units staged and consumed per barrier;
+// MW  = 32-row groups per wave: MW = 2 -> 4 waves x 64 rows (one wave per SIMD, 512 registers each),
+//       MW = 1 -> 8 waves x 32 rows (two waves per SIMD: one wave's epilogue overlaps the other's MFMAs).
+template <int NC, int CPB, int MW, class Epi>
+__global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
+    const float *__restrict__ PA, uint32_t a_items, const float *__restrict__ PB, uint32_t b_tiles, uint32_t nA,
+    uint32_t nB, uint32_t KC, uint32_t splits, Epi epi, double *__restrict__ cand_key,
+    uint32_t *__restrict__ cand_idx, int dbg) {
+  constexpr int WAVES = 8 / MW;
+  constexpr int NT = 64 * WAVES;
+  constexpr int WROWS = 32 * MW;                  // rows per wave
+  constexpr uint32_t QCAP = kQueueCap * MW / 2;   // per-wave queue entries
+  constexpr int KS2 = NC * kKs2Unit;
+  constexpr int kKs2Chunk = kKs2Unit * CPB;       // k-steps per staged chunk
+  constexpr int kChunkFloats = kUnitFloats * CPB;
+  constexpr int NCB = NC / CPB;                   // chunks (barriers) per B tile
+  static_assert(NC % CPB == 0, "CPB must divide NC");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *bufB = reinterpret_cast<float *>(smem);                  // 2 x 16 KB
-  float *lvals = bufB + 2 * kChunkFloats;                         // [4][64][KC]
-  uint32_t *lidx = reinterpret_cast<uint32_t *>(lvals + 4 * 64 * KC);
-  float *qvals = reinterpret_cast<float *>(lidx + 4 * 64 * KC);   // [4][kQueueCap]
-  uint32_t *qcols = reinterpret_cast<uint32_t *>(qvals + 4 * kQueueCap);
-  uint32_t *qrows = qcols + 4 * kQueueCap;
+  float *bufB = reinterpret_cast<float *>(smem);                        // 2 x chunk
+  float *lvals = bufB + 2 * kChunkFloats;                               // [256 rows][KC]
+  uint32_t *lidx = reinterpret_cast<uint32_t *>(lvals + kRows32 * KC);
+  float *qvals = reinterpret_cast<float *>(lidx + kRows32 * KC);        // [WAVES][QCAP]
+  uint32_t *qcols = reinterpret_cast<uint32_t *>(qvals + WAVES * QCAP);
+  uint32_t *qrows = qcols + WAVES * QCAP;
+  float *rowdata = reinterpret_cast<float *>(qrows + WAVES * QCAP);     // [256]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
   const int lh = lane >> 5;  // 0..1
   const int lc = lane & 31;
-  float *wl = lvals + (size_t)wv * 64 * KC;
-  uint32_t *wi = lidx + (size_t)wv * 64 * KC;
-  float *qv = qvals + wv * kQueueCap;
-  uint32_t *qc = qcols + wv * kQueueCap;
-  uint32_t *qr = qrows + wv * kQueueCap;
+  float *wl = lvals + (size_t)wv * WROWS * KC;
+  uint32_t *wi = lidx + (size_t)wv * WROWS * KC;
+  float *qv = qvals + wv * QCAP;
+  uint32_t *qc = qcols + wv * QCAP;
+  uint32_t *qr = qrows + wv * QCAP;
+  float *wrow = rowdata + wv * WROWS;
 
   const uint32_t items = a_items * splits;
   for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -144,48 +157,44 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
     const uint32_t j_lo = (uint32_t)(((uint64_t)b_tiles * sp) / splits);
     const uint32_t j_hi = (uint32_t)(((uint64_t)b_tiles * (sp + 1)) / splits);
 
-    // A fragments of this wave's 64 rows (packed tile 2I + (wv >> 1), 32-row groups 2 (wv & 1) + m)
-    float a[2][KS2];
+    // A fragments of this wave's rows: rows [wv*WROWS, +WROWS) of the 256-row workgroup tile
+    float a[MW][KS2];
     {
-      const size_t T = (size_t)2 * I + (wv >> 1);
-      const int s0 = 2 * (wv & 1);
+      const int row0 = wv * WROWS;
+      const size_t T = (size_t)2 * I + (row0 >> 7);
+      const int s0 = (row0 & 127) >> 5;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) a[m][ks] = PA[((T * KS2 + ks) * 4 + s0 + m) * 64 + lane];
+        for (int m = 0; m < MW; ++m) a[m][ks] = PA[((T * KS2 + ks) * 4 + s0 + m) * 64 + lane];
       }
     }
-    // row of (m, reg) inside the wave: 32 m + (reg & 3) + 8 (reg >> 2) + 4 lh
-    float rowv[2][16], thr[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t arow = I * kRows32 + wv * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        rowv[m][r] = 0.f;
-        if (arow < nA) epi.load_row(arow, rowv[m][r]);
-        thr[m][r] = -__builtin_inff();
-      }
-    for (int e = lane; e < 64 * (int)KC; e += 64) {
+    if (lane < WROWS) {  // per-row epilogue data (search: the query lambdas), kept in LDS
+      const uint32_t arow = I * kRows32 + wv * WROWS + lane;
+      float rv = 0.f;
+      if (arow < nA) epi.load_row(arow, rv);
+      wrow[lane] = rv;
+    }
+    for (int e = lane; e < WROWS * (int)KC; e += 64) {
       wl[e] = -__builtin_inff();
       wi[e] = kNoIdx;
     }
     wave_sync();
 
-    v16f32 acc[2][4];
+    v16f32 acc[MW][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const uint32_t n_chunks = (j_hi - j_lo) * NC;
-    const float *src = PB + (size_t)j_lo * NC * kChunkFloats;
+    const uint32_t n_chunks = (j_hi - j_lo) * NCB;
+    const float *src = PB + (size_t)j_lo * NCB * kChunkFloats;
     // LDS-DMA staging: chunk g+1 is copied global -> LDS (linear image, 16 B per lane) while chunk g
     // is consumed; the one barrier per chunk both retires the DMA (vmcnt) and frees the buffer.
     __syncthreads();
-    if (n_chunks > 0) stage_chunk(src, bufB, wv, lane);
+    if (n_chunks > 0) stage_chunk<CPB, WAVES>(src, bufB, wv, lane);
     __syncthreads();
     uint32_t g = 0;
     int pbuf = 0;
@@ -194,8 +203,9 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
 #pragma unroll
       for (int n = 0; n < 4; ++n) epi.load_col(J * kTileRows + n * 32 + lc, nB, colv[n]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c, ++g) {
-        if (g + 1 < n_chunks) stage_chunk(src + (size_t)(g + 1) * kChunkFloats, bufB + (pbuf ^ 1) * kChunkFloats, wv, lane);
+      for (int c = 0; c < NCB; ++c, ++g) {
+        if (g + 1 < n_chunks)
+          stage_chunk<CPB, WAVES>(src + (size_t)(g + 1) * kChunkFloats, bufB + (pbuf ^ 1) * kChunkFloats, wv, lane);
         const float *bb = bufB + pbuf * kChunkFloats;
 #pragma unroll
         for (int ks = 0; ks < kKs2Chunk; ++ks) {
@@ -204,10 +214,20 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
           for (int n = 0; n < 4; ++n) b[n] = bb[(ks * 4 + n) * 64 + lane];
 #pragma unroll
           for (int n = 0; n < 4; ++n) {
-            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c * kKs2Chunk + ks], b[n], acc[0][n], 0, 0, 0);
-            acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c * kKs2Chunk + ks], b[n], acc[1][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][c * kKs2Chunk + ks], b[n], acc[m][n], 0, 0, 0);
           }
         }
+        // Schedule shape for the chunk: LDS reads run one MFMA group ahead of their consumers so the
+        // LDS latency hides behind the matrix pipe (an in-order wave otherwise waits ~100 cycles per group).
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * kKs2Chunk - 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MW, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MW, 0);
         __syncthreads();  // DMA of the next chunk landed; everyone is done reading bufB[pbuf]
         pbuf ^= 1;
       }
@@ -217,35 +237,53 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
       // resumes from the slot that did not fit, with the tightened thresholds.
       {
         const bool tail = (J + 1 == b_tiles) && (nB % kTileRows != 0);
-        // one pass over the 128 accumulators of this lane, starting at slot `lim`; returns the slot to
-        // resume from when the queue filled up (0xFFFFFFFF: done).  TAIL masks the padded columns.
-        auto scan = [&](auto tail_c, uint32_t lim, uint32_t &qlen) -> uint32_t {
-          constexpr bool TAIL = decltype(tail_c)::value;
+        if (tail) {  // padded columns of the last tile can never win: overwrite their products once
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (J * kTileRows + n * 32 + lc >= nB) {
+#pragma unroll
+              for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = -__builtin_inff();
+            }
+          }
+        }
+        // one pass over this lane's accumulators starting at slot `lim`; returns the slot to resume
+        // from when the queue filled up (0xFFFFFFFF: done)
+        auto scan = [&](uint32_t lim, uint32_t &qlen) -> uint32_t {
           uint32_t resume = 0xFFFFFFFFu;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < MW; ++m) {
+            // thresholds / row data of this lane's 16 rows of group m (LDS, 2 addresses per read)
+            float thr[16], rowv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              thr[r] = wl[rl * KC + KC - 1];
+              rowv[r] = wrow[rl];
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
+              __builtin_amdgcn_sched_barrier(0);  // keep the accumulator reads of one group together
               const uint32_t base = (m * 4 + n) * 16;
               if (base + 15 >= lim) {
                 const uint32_t col = J * kTileRows + n * 32 + lc;
-                const bool colok = !TAIL || col < nB;
                 float vv[16];
                 uint64_t any = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                  vv[r] = epi.value(acc[m][n][r], rowv[m][r], colv[n]);
-                  any |= __ballot(vv[r] > thr[m][r] && colok);
+                  vv[r] = epi.value(acc[m][n][r], rowv[r], colv[n]);
+                  any |= __ballot(vv[r] > thr[r]);
                 }
                 if (any) {
 #pragma unroll
                   for (int r = 0; r < 16; ++r) {
                     if (base + r >= lim) {
-                      const bool pass = vv[r] > thr[m][r] && colok;
+                      const bool pass = vv[r] > thr[r];
                       const uint64_t mask = __ballot(pass);
                       if (mask) {
                         const uint32_t cnt = (uint32_t)__popcll(mask);
-                        if (qlen + cnt > kQueueCap) {
+                        if (qlen + cnt > QCAP) {
                           resume = base + r;
                           lim = 0xFFFFFFFFu;  // skip the remaining slots of this pass
                         } else {
@@ -270,25 +308,35 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
         uint32_t cur = 0;
         for (;;) {
           uint32_t qlen = 0;
-          const uint32_t resume = tail ? scan(std::true_type{}, cur, qlen) : scan(std::false_type{}, cur, qlen);
+          uint32_t resume = 0xFFFFFFFFu;
+          if (dbg != 2) resume = scan(cur, qlen);
+          if (dbg == 1) { qlen = 0; resume = 0xFFFFFFFFu; }  // diagnostic: filter only, no insertion
           if (qlen) {
+            // drain: queue entries are pulled into registers 64 at a time (one per lane) and broadcast
+            // with readlane, so the insertion loop has no dependent LDS read besides the list itself
             wave_sync();
-            for (uint32_t e = 0; e < qlen; ++e) {
-              const float v_s = qv[e];
-              const uint32_t c_s = qc[e], r_s = qr[e];
-              if (v_s > wl[r_s * KC + KC - 1]) list_insert32(wl + r_s * KC, wi + r_s * KC, (int)KC, lane, v_s, c_s);
+            for (uint32_t e0 = 0; e0 < qlen; e0 += 64) {
+              const uint32_t nb = min(64u, qlen - e0);
+              float ev = 0.f;
+              uint32_t ec = 0, er = 0;
+              if ((uint32_t)lane < nb) {
+                ev = qv[e0 + lane];
+                ec = qc[e0 + lane];
+                er = qr[e0 + lane];
+              }
+              for (uint32_t e = 0; e < nb; ++e) {
+                const float v_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), e));
+                const uint32_t c_s = (uint32_t)__builtin_amdgcn_readlane((int)ec, e);
+                const uint32_t r_s = (uint32_t)__builtin_amdgcn_readlane((int)er, e);
+                list_insert32(wl + r_s * KC, wi + r_s * KC, (int)KC, lane, v_s, c_s);
+              }
             }
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-              for (int rr = 0; rr < 16; ++rr)
-                thr[mm][rr] = wl[(mm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh) * KC + KC - 1];
           }
           if (resume == 0xFFFFFFFFu) break;
           cur = resume;
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -296,9 +344,9 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
       }
     }
     // ---- write this work item's candidate lists (key = -value, ascending = better) ----
-    for (int e = lane; e < 64 * (int)KC; e += 64) {
+    for (int e = lane; e < WROWS * (int)KC; e += 64) {
       const int rowl = e / (int)KC, slot = e - rowl * (int)KC;
-      const uint32_t arow = I * kRows32 + wv * 64 + rowl;
+      const uint32_t arow = I * kRows32 + wv * WROWS + rowl;
       if (arow < nA) {
         const size_t o = ((size_t)arow * splits + sp) * KC + slot;
         cand_key[o] = -(double)wl[e];
@@ -309,26 +357,45 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma32_kernel(const float *_
   }
 }
 
+static size_t lds_bytes_f32(uint32_t KC, int CPB) {
+  return (size_t)2 * kUnitFloats * CPB * sizeof(float) + (size_t)4 * 64 * KC * (sizeof(float) + sizeof(uint32_t)) +
+         (size_t)4 * kQueueCap * (sizeof(float) + 2 * sizeof(uint32_t)) + kRows32 * sizeof(float);
+}
+
+bool fits_f32(uint32_t KC) { return lds_bytes_f32(KC, 1) <= 160 * 1024; }
+
 template <class Epi>
 static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, const float *PB, uint32_t b_tiles,
                       uint32_t nA, uint32_t nB, uint32_t KC, uint32_t splits, Epi epi, double *cand_key,
                       uint32_t *cand_idx, const char *prof_name) {
-  const size_t lds = 2 * kChunkFloats * sizeof(float) + (size_t)4 * 64 * KC * (sizeof(float) + sizeof(uint32_t)) +
-                     (size_t)4 * kQueueCap * (sizeof(float) + 2 * sizeof(uint32_t));
+  // two 16 KB units per barrier when the LDS budget allows (half the barriers per tile)
+  const int CPB = (NC % 2 == 0 && lds_bytes_f32(KC, 2) <= 160 * 1024) ? 2 : 1;
+  const size_t lds = lds_bytes_f32(KC, CPB);
+  if (lds > 160 * 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "candidate capacity too large for the f32 MFMA pass");
   const unsigned grid = std::min<uint32_t>(a_items * splits, 256u);
+  const int MW = ctx->opt_waves_per_simd == 1 ? 2 : 1;
   ProfScope ps(ctx, prof_name);
-#define AS_CAND(N)                                                                                                  \
-  case N:                                                                                                           \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_topk_mfma32_kernel<N, Epi>,                                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-    hipLaunchKernelGGL((pair_topk_mfma32_kernel<N, Epi>), dim3(grid), dim3(256), lds, ctx->stream, PA, a_items, PB, \
-                       b_tiles, nA, nB, KC, splits, epi, cand_key, cand_idx);                                       \
-    break;
-  switch (NC) {
-    AS_CAND(1)
-    AS_CAND(2)
-    AS_CAND(3)
-    AS_CAND(4)
+#define AS_CAND(N, C)                                                                                                \
+  do {                                                                                                               \
+    if (MW == 2) {                                                                                                   \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_topk_mfma32_kernel<N, C, 2, Epi>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+      hipLaunchKernelGGL((pair_topk_mfma32_kernel<N, C, 2, Epi>), dim3(grid), dim3(256), lds, ctx->stream, PA,       \
+                         a_items, PB, b_tiles, nA, nB, KC, splits, epi, cand_key, cand_idx, (int)ctx->opt_debug);    \
+    } else {                                                                                                         \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_topk_mfma32_kernel<N, C, 1, Epi>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+      hipLaunchKernelGGL((pair_topk_mfma32_kernel<N, C, 1, Epi>), dim3(grid), dim3(512), lds, ctx->stream, PA,       \
+                         a_items, PB, b_tiles, nA, nB, KC, splits, epi, cand_key, cand_idx, (int)ctx->opt_debug);    \
+    }                                                                                                                \
+  } while (0)
+  switch (NC * 10 + CPB) {
+    case 11: AS_CAND(1, 1); break;
+    case 21: AS_CAND(2, 1); break;
+    case 22: AS_CAND(2, 2); break;
+    case 31: AS_CAND(3, 1); break;
+    case 41: AS_CAND(4, 1); break;
+    case 42: AS_CAND(4, 2); break;
     default: return fail(ctx, AS_ERR_UNSUPPORTED, "dim > 128 on the MFMA path");
   }
 #undef AS_CAND

@@ -293,12 +293,18 @@ __global__ __launch_bounds__(256, 1) void pair_topk_mfma_kernel(const double *__
   }
 }
 
+static size_t lds_bytes_f64(uint32_t KC) {
+  return 2 * kChunkDoubles * sizeof(double) + (size_t)4 * 32 * KC * (sizeof(double) + sizeof(uint32_t)) +
+         (size_t)4 * kQueueCap * (sizeof(double) + 2 * sizeof(uint32_t));
+}
+bool fits_f64(uint32_t KC) { return lds_bytes_f64(KC) <= 160 * 1024; }
+
 template <class Epi>
 static int launch_f64(as_ctx *ctx, int NC, const double *PA, uint32_t a_tiles, const double *PB, uint32_t b_tiles,
                       uint32_t nA, uint32_t nB, uint32_t KC, uint32_t splits, Epi epi, double *cand_key,
                       uint32_t *cand_idx, const char *prof_name) {
-  const size_t lds = 2 * kChunkDoubles * sizeof(double) + (size_t)4 * 32 * KC * (sizeof(double) + sizeof(uint32_t)) +
-                     (size_t)4 * kQueueCap * (sizeof(double) + 2 * sizeof(uint32_t));
+  const size_t lds = lds_bytes_f64(KC);
+  if (lds > 160 * 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "candidate capacity too large for the f64 MFMA pass");
   const unsigned grid = std::min<uint32_t>(a_tiles * splits, 256u);
   ProfScope ps(ctx, prof_name);
 #define AS_CAND(N)                                                                                               \
