@@ -95,12 +95,6 @@ int as_ctx_create(int device, as_ctx **out) {
     return AS_ERR_HIP;
   }
   c->own_stream = true;
-  // keep freed stream-ordered allocations cached instead of returning them to the OS
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-    uint64_t thr = ~0ull;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-  }
   *out = c;
   return AS_OK;
 }
@@ -111,6 +105,8 @@ void as_ctx_destroy(as_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   prof_resolve(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
   delete ctx;
 }
 
@@ -139,6 +135,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_mfma") ctx->opt_search_mfma = value;
   else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
   else if (n == "debug") ctx->opt_debug = value;
+  else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;
   else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
@@ -265,8 +262,8 @@ int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indi
   if (!m) return fail(ctx, AS_ERR_ARG, "null csr");
   auto copy = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
     if (!dst || bytes == 0) return hipSuccess;
-    return hipMemcpyAsync(dst, src, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                          ctx->stream);
+    if (is_device_ptr(dst)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    return copy_d2h(ctx, dst, src, bytes);
   };
   AS_HIP(ctx, copy(indptr, m->indptr, sizeof(uint64_t) * (m->n + 1)));
   AS_HIP(ctx, copy(indices, m->indices, sizeof(uint64_t) * m->nnz));
@@ -286,11 +283,14 @@ int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
   AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * (n + 1)));
   AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
   AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
-  auto kind = [&](const void *p) { return is_device_ptr(p) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; };
-  AS_HIP(ctx, hipMemcpyAsync(m->indptr, indptr, sizeof(uint64_t) * (n + 1), kind(indptr), ctx->stream));
+  auto put = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+    if (is_device_ptr(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    return copy_h2d(ctx, dst, src, bytes);
+  };
+  AS_HIP(ctx, put(m->indptr, indptr, sizeof(uint64_t) * (n + 1)));
   if (nnz) {
-    AS_HIP(ctx, hipMemcpyAsync(m->indices, indices, sizeof(uint64_t) * nnz, kind(indices), ctx->stream));
-    AS_HIP(ctx, hipMemcpyAsync(m->data, data, sizeof(double) * nnz, kind(data), ctx->stream));
+    AS_HIP(ctx, put(m->indices, indices, sizeof(uint64_t) * nnz));
+    AS_HIP(ctx, put(m->data, data, sizeof(double) * nnz));
   }
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = m;
@@ -304,6 +304,7 @@ void as_csr_free(as_csr *m) {
   (void)hipFree(m->indices);
   (void)hipFree(m->data);
   if (m->packed) (void)hipFree(m->packed);
+  if (m->packed_upper) (void)hipFree(m->packed_upper);
   delete m;
 }
 
@@ -339,7 +340,8 @@ int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len
   if ((!rows && n_rows * len) || !taus_out) return fail(ctx, AS_ERR_ARG, "null argument");
   if (len == 0) {  // empty slices: every mode but a valid Fixed returns the floor
     std::vector<double> h(n_rows, (tau_mode == AS_TAU_FIXED && std::isfinite(tau_arg) && tau_arg > 0.0) ? tau_arg : kTauFloor);
-    AS_HIP(ctx, hipMemcpy(taus_out, h.data(), sizeof(double) * n_rows, hipMemcpyDefault));
+    if (is_device_ptr(taus_out)) AS_HIP(ctx, copy_h2d(ctx, taus_out, h.data(), sizeof(double) * n_rows));
+    else std::memcpy(taus_out, h.data(), sizeof(double) * n_rows);
     return AS_OK;
   }
   DevIn<double> X;
@@ -367,7 +369,7 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
   } else {
     double *p;
     AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items * n_features));
-    AS_HIP(ctx, hipMemcpyAsync(p, items, sizeof(double) * n_items * n_features, hipMemcpyHostToDevice, ctx->stream));
+    AS_HIP(ctx, copy_h2d(ctx, p, items, sizeof(double) * n_items * n_features));
     ix->items = p;
     ix->own_items = true;
   }
@@ -376,7 +378,7 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
   } else {
     double *p;
     AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items));
-    AS_HIP(ctx, hipMemcpyAsync(p, lambdas, sizeof(double) * n_items, hipMemcpyHostToDevice, ctx->stream));
+    AS_HIP(ctx, copy_h2d(ctx, p, lambdas, sizeof(double) * n_items));
     ix->lambdas = p;
     ix->own_lambdas = true;
   }
@@ -418,7 +420,7 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
   AS_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(any_zero_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, ctx->stream, QL.p, nq, flag.p);
   int h = 0;
-  AS_HIP(ctx, hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, copy_d2h(ctx, &h, flag.p, sizeof(int)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h) return fail(ctx, AS_ERR_ZERO_LAMBDA, as_status_message(AS_ERR_ZERO_LAMBDA));
 

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,11 +36,14 @@ struct as_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  void *pinned = nullptr;  // staging buffer for host <-> device transfers
+  std::multimap<size_t, void *> free_blocks;  // workspace cache (capacity -> block)
   // options
   int64_t opt_knn_mfma = 1;       // 1: MFMA candidates + exact re-rank, 0: exact scan only
   int64_t opt_search_mfma = 1;    // same for the search scan
   int64_t opt_cand_slack = 8;     // extra candidates kept by the MFMA pass beyond topk+1
   int64_t opt_waves_per_simd = 2; // f32 candidate pass: 2 = 8 waves x 32 rows, 1 = 4 waves x 64 rows
+  int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // stats of the last call
@@ -58,7 +62,9 @@ struct as_csr {
   double *data = nullptr;       // nnz (device)
   // packed (row, col, value) entries for the lambda kernel, built on first use
   void *packed = nullptr;
-  bool symmetric_checked = false;
+  // upper-triangle stream (j >= i), present only when the matrix is bitwise symmetric
+  void *packed_upper = nullptr;
+  uint64_t nnz_upper = 0;
 };
 
 struct as_index {
@@ -106,32 +112,90 @@ inline bool is_device_ptr(const void *p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-// Stream-ordered device allocation that frees itself.
+// Transfers with a HOST endpoint go through a pinned staging buffer owned by the context, as
+// genuine stream operations (hipMemcpyAsync on pinned memory).  hipMemcpy / hipMemcpyAsync straight
+// from pageable memory is staged by the runtime outside the context's stream order: kernels queued
+// behind such a copy were observed reading the destination (recycled pool memory) before the bytes
+// were visible.  Device-resident callers never come through here.
+constexpr size_t kPinnedBytes = 64u << 20;
+inline hipError_t ensure_pinned(as_ctx *ctx) {
+  if (ctx->pinned) return hipSuccess;
+  return hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault);
+}
+inline hipError_t copy_h2d(as_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  hipError_t e = ensure_pinned(ctx);
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += kPinnedBytes) {
+    const size_t n = std::min(kPinnedBytes, bytes - off);
+    std::memcpy(ctx->pinned, (const char *)src + off, n);
+    e = hipMemcpyAsync((char *)dst + off, ctx->pinned, n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging buffer is reused
+  }
+  return e;
+}
+inline hipError_t copy_d2h(as_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  hipError_t e = ensure_pinned(ctx);
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += kPinnedBytes) {
+    const size_t n = std::min(kPinnedBytes, bytes - off);
+    e = hipMemcpyAsync(ctx->pinned, (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) std::memcpy((char *)dst + off, ctx->pinned, n);
+  }
+  return e;
+}
+
+// Workspace allocations.  The context keeps a cache of hipMalloc'd blocks; a DevBuf takes a block
+// for the duration of a call and hands it back.  All work of a context runs on ONE stream, so a
+// block handed back while kernels that use it are still queued can only be reused by later work on
+// the same stream, i.e. after those kernels.  (The runtime's stream-ordered pool, hipMallocAsync,
+// was dropped: mixed with the blocking hipMalloc/hipFree of the long-lived handles it produced
+// intermittent stale reads on this stack.)
+inline int ws_alloc(as_ctx *ctx, size_t bytes, void **out, size_t *cap) {
+  if (bytes == 0) bytes = 1;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = ctx->free_blocks.lower_bound(bytes);
+  if (it != ctx->free_blocks.end() && it->first <= bytes + bytes / 2 + 4096) {
+    *out = it->second;
+    *cap = it->first;
+    ctx->free_blocks.erase(it);
+    return AS_OK;
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {  // drop the cache and retry once
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+    ctx->free_blocks.clear();
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return AS_ERR_HIP;
+  }
+  *cap = bytes;
+  return AS_OK;
+}
+inline void ws_free(as_ctx *ctx, void *p, size_t cap) { ctx->free_blocks.emplace(cap, p); }
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
-  size_t count = 0;
-  hipStream_t s = nullptr;
+  size_t count = 0, cap = 0;
+  as_ctx *owner = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   int alloc(as_ctx *ctx, size_t n) {
     release();
-    s = ctx->stream;
+    owner = ctx;
     count = n;
-    if (n == 0) n = 1;
-    AS_HIP(ctx, hipMallocAsync((void **)&p, n * sizeof(T), s));
+    void *q = nullptr;
+    AS_TRY(ws_alloc(ctx, n * sizeof(T), &q, &cap));
+    p = (T *)q;
     return AS_OK;
   }
   void release() {
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) ws_free(owner, p, cap);
     p = nullptr;
-  }
-  T *take() {
-    T *q = p;
-    p = nullptr;
-    return q;
   }
 };
 
@@ -146,7 +210,7 @@ struct DevIn {
       return AS_OK;
     }
     AS_TRY(tmp.alloc(ctx, n));
-    AS_HIP(ctx, hipMemcpyAsync(tmp.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    AS_HIP(ctx, copy_h2d(ctx, tmp.p, src, n * sizeof(T)));
     p = tmp.p;
     return AS_OK;
   }
@@ -175,8 +239,7 @@ struct DevOut {
   // installed a stream (as_ctx_set_stream) results are ordered on that stream instead.
   int finish(as_ctx *ctx) {
     if (host && n) {
-      AS_HIP(ctx, hipMemcpyAsync(host, p, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      AS_HIP(ctx, copy_d2h(ctx, host, p, n * sizeof(T)));
     } else if (ctx->own_stream) {
       AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }

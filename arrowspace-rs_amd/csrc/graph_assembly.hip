@@ -325,7 +325,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
     hipLaunchKernelGGL(adjacency_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
                        gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p);
     AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, n, rev_ptr.p));
-    AS_HIP(ctx, hipMemcpyAsync(&n_edges_dir, rev_ptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + n, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
     AS_TRY(rev_src.alloc(ctx, n_edges_dir));
     AS_TRY(rev_w.alloc(ctx, n_edges_dir));
@@ -334,7 +334,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
     hipLaunchKernelGGL(union_count_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_len.p, n, K, rev_ptr.p,
                        rev_src.p, ucnt.p);
     AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, n, eptr.p));
-    AS_HIP(ctx, hipMemcpyAsync(&n_union, eptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + n, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
   }
   const uint64_t nnz = n_union + n;

@@ -139,6 +139,8 @@ __global__ void scatter_rows_kernel(const uint32_t *__restrict__ rows, uint32_t 
 }
 
 
+__global__ void set_u64_kernel(unsigned long long *p, unsigned long long v) { *p = v; }
+
 __global__ void gather_u32_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ pos,
                                   uint32_t count, uint32_t add, uint32_t *__restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,7 +181,7 @@ static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const d
 }
 
 static int read_u32(as_ctx *ctx, const uint32_t *dev, uint32_t *host) {
-  AS_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, copy_d2h(ctx, host, dev, sizeof(uint32_t)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
@@ -203,11 +205,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   DevBuf<uint8_t> force;
   AS_TRY(minb.alloc(ctx, 1));
   AS_TRY(force.alloc(ctx, n));
-  const unsigned long long inf_bits = 0x7FF0000000000000ull;
-  AS_HIP(ctx, hipMemcpyAsync(minb.p, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, ctx->stream, minb.p, 0x7FF0000000000000ull);  // +inf
   hipLaunchKernelGGL(min_norm_kernel, dim3(256), dim3(256), 0, ctx->stream, norms, n, minb.p);
   unsigned long long mb = 0;
-  AS_HIP(ctx, hipMemcpyAsync(&mb, minb.p, sizeof(mb), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, copy_d2h(ctx, &mb, minb.p, sizeof(mb)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double min_norm;
   std::memcpy(&min_norm, &mb, sizeof(double));
@@ -482,7 +483,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     }
   }
   int h_err = 0;
-  AS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, copy_d2h(ctx, &h_err, err.p, sizeof(int)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h_err) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
   if (n_exact) {

@@ -42,7 +42,7 @@ int search_exact(as_ctx *ctx, const as_index *ix, const double *queries, const d
     AS_HIP(ctx, hipGetLastError());
   }
   int h = 0;
-  AS_HIP(ctx, hipMemcpyAsync(&h, err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  AS_HIP(ctx, copy_d2h(ctx, &h, err.p, sizeof(int)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
   return AS_OK;

@@ -11,7 +11,10 @@
 // packed (row, col, value) entries read with wave-(near-)uniform loads.  One pass produces
 // num = x'Lx, the edge energy and the sum of squared edge shares; tau comes from a 64-step
 // bisection on order-preserving integer keys (no sort, the tile stays intact for the graph pass).
+#include <utility>
+
 #include "common.h"
+#include "sortnet.h"
 
 namespace asx {
 
@@ -33,12 +36,84 @@ __global__ void pack_csr_kernel(const uint64_t *__restrict__ indptr, const uint6
   }
 }
 
+// Is L bitwise symmetric (L_ij == L_ji for every stored entry)?  Per row: count of entries with j >= i.
+__global__ void csr_symmetry_kernel(const uint64_t *__restrict__ indptr, const uint64_t *__restrict__ indices,
+                                    const double *__restrict__ data, uint64_t n, uint32_t *__restrict__ upper_cnt,
+                                    int *__restrict__ not_symmetric) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t up = 0;
+  for (uint64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+    const uint64_t j = indices[e];
+    if (j >= i) ++up;
+    if (j == i) continue;
+    if (j >= n) {
+      atomicOr(not_symmetric, 1);
+      continue;
+    }
+    uint64_t lo = indptr[j], hi = indptr[j + 1];  // binary search column i in row j
+    bool found = false;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      const uint64_t c = indices[mid];
+      if (c == i) {
+        found = __double_as_longlong(data[mid]) == __double_as_longlong(data[e]);
+        break;
+      }
+      if (c < i) lo = mid + 1;
+      else hi = mid;
+    }
+    if (!found) atomicOr(not_symmetric, 1);
+  }
+  upper_cnt[i] = up;
+}
+
+__global__ void pack_upper_kernel(const uint64_t *__restrict__ indptr, const uint64_t *__restrict__ indices,
+                                  const double *__restrict__ data, uint64_t n, const uint64_t *__restrict__ uptr,
+                                  PackedEntry *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t o = uptr[i];
+  for (uint64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+    if (indices[e] < i) continue;
+    PackedEntry p;
+    p.i = (uint32_t)i;
+    p.j = (uint32_t)indices[e];
+    p.v = data[e];
+    out[o++] = p;
+  }
+}
+
 static int ensure_packed(as_ctx *ctx, as_csr *L) {
   if (L->packed || L->nnz == 0) return AS_OK;
   AS_HIP(ctx, hipMalloc(&L->packed, sizeof(PackedEntry) * L->nnz));
   hipLaunchKernelGGL(pack_csr_kernel, dim3(cdiv(L->n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices,
                      L->data, L->n, (PackedEntry *)L->packed);
   AS_HIP(ctx, hipGetLastError());
+  // symmetric matrices (every Laplacian this library builds) also get the upper-triangle stream
+  DevBuf<uint32_t> up;
+  DevBuf<uint64_t> uptr;
+  DevBuf<int> flag;
+  AS_TRY(up.alloc(ctx, L->n));
+  AS_TRY(uptr.alloc(ctx, L->n + 1));
+  AS_TRY(flag.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(csr_symmetry_kernel, dim3(cdiv(L->n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices,
+                     L->data, L->n, up.p, flag.p);
+  AS_TRY(exclusive_scan_u32_u64(ctx, up.p, L->n, uptr.p));
+  int h = 1;
+  uint64_t n_upper = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, flag.p, sizeof(int)));
+  AS_HIP(ctx, copy_d2h(ctx, &n_upper, uptr.p + L->n, sizeof(uint64_t)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h == 0 && n_upper > 0) {
+    AS_HIP(ctx, hipMalloc(&L->packed_upper, sizeof(PackedEntry) * n_upper));
+    hipLaunchKernelGGL(pack_upper_kernel, dim3(cdiv(L->n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices,
+                       L->data, L->n, uptr.p, (PackedEntry *)L->packed_upper);
+    AS_HIP(ctx, hipGetLastError());
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    L->nnz_upper = n_upper;
+  }
   return AS_OK;
 }
 
@@ -247,6 +322,214 @@ __global__ __launch_bounds__(64) void lambda_kernel(const double *__restrict__ i
   }
 }
 
+// ---- fast path (n_features <= 128): 2-wave workgroup per 64-item tile ---------------------------
+// Both waves stage the tile transposed into LDS.  Wave 0 then pulls each lane's item into registers
+// and runs a Batcher odd-even merge sort network on them (sortnet.h; no data-dependent control flow,
+// all indices static) to get tau; wave 1 meanwhile walks the packed CSR stream with wave-uniform
+// loads, one item per lane, accumulating x'Lx, the edge energy and the sum of squared edge terms.
+// The two meet in LDS and wave 0 writes lambda.  Sums are sequential in CSR order, so with an
+// unsymmetric stream lambda agrees with the oracle to the last bits of the G term.
+template <int NP, size_t... Is>
+__device__ __forceinline__ void sortnet_apply(double (&v)[NP], std::index_sequence<Is...>) {
+  auto ce = [&](int a, int b) {
+    const double lo = fmin(v[a], v[b]);
+    const double hi = fmax(v[a], v[b]);
+    v[a] = lo;
+    v[b] = hi;
+  };
+  (ce(SortNet<NP>::kA[Is], SortNet<NP>::kB[Is]), ...);
+}
+
+template <int NP>
+__device__ __forceinline__ double sorted_pick(const double (&v)[NP], uint32_t idx) {
+  double r = v[0];
+#pragma unroll
+  for (int f = 1; f < NP; ++f) r = idx == (uint32_t)f ? v[f] : r;
+  return r;
+}
+
+// tau of one item held in xcol[f * stride], f < F <= NP
+template <int NP>
+__device__ __forceinline__ double regs_select_tau(const double *xcol, uint32_t F, uint32_t stride, int mode,
+                                                  double arg, bool &bad) {
+  double v[NP];
+  uint32_t m = 0;
+  double sum = 0.0;
+  const double inf = __builtin_inf();
+#pragma unroll
+  for (int f = 0; f < NP; ++f) {
+    double x = inf;
+    if ((uint32_t)f < F) {
+      x = xcol[(size_t)f * stride];
+      if (finite_bits(x)) {
+        ++m;
+        sum = __dadd_rn(sum, x);
+      } else {
+        bad = true;
+        x = inf;
+      }
+    }
+    v[f] = x;
+  }
+  if (mode == AS_TAU_FIXED) return (finite_bits(arg) && arg > 0.0) ? arg : kTauFloor;
+  if (mode == AS_TAU_MEAN) return fmax(m > 0 ? __ddiv_rn(sum, (double)m) : 0.0, kTauFloor);
+  if (m == 0) return kTauFloor;
+  sortnet_apply<NP>(v, std::make_index_sequence<SortNet<NP>::kCount>{});
+  if (mode == AS_TAU_PERCENTILE) {
+    const double pp = arg != arg ? 0.0 : fmin(fmax(arg, 0.0), 1.0);
+    const uint32_t idx = (uint32_t)round((double)(m - 1) * pp);
+    return fmax(sorted_pick<NP>(v, idx), kTauFloor);
+  }
+  if (m & 1u) return fmax(sorted_pick<NP>(v, m / 2), kTauFloor);
+  const double mid = __dmul_rn(0.5, __dadd_rn(sorted_pick<NP>(v, m / 2 - 1), sorted_pick<NP>(v, m / 2)));
+  return fmax(mid, kTauFloor);
+}
+
+template <int NP>
+__global__ __launch_bounds__(128, 1) void lambda_kernel_v2(const double *__restrict__ items, uint64_t n_items,
+                                                           uint32_t F, const PackedEntry *__restrict__ ent,
+                                                           uint64_t nnz, int symmetric, int mode, double arg,
+                                                           int check_finite, int want_lambda,
+                                                           double *__restrict__ out, int *__restrict__ err_flag) {
+  constexpr int IPW = 64, STRIDE = 65;
+  extern __shared__ double xT[];            // [F][65] tile + [64] tau + [64][4] partials
+  double *s_tau = xT + (size_t)F * STRIDE;
+  double *s_part = s_tau + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t n_tiles = (n_items + IPW - 1) / IPW;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t item0 = tile * IPW;
+    const uint32_t rows_here = (uint32_t)min((uint64_t)IPW, n_items - item0);
+    __syncthreads();
+    const double *src = items + item0 * F;
+    // thread = feature, loop = row: coalesced row reads, 16 independent loads in flight per thread,
+    // conflict-free transposed LDS writes (row stride 65 doubles)
+    if ((uint32_t)tid < F) {
+#pragma unroll 16
+      for (uint32_t r = 0; r < (uint32_t)IPW; ++r)
+        xT[(size_t)tid * STRIDE + r] = r < rows_here ? src[(size_t)r * F + tid] : 0.0;
+    }
+    __syncthreads();
+    const double *xcol = xT + lane;
+    if (wv == 0) {
+      bool bad = false;
+      const double tau = regs_select_tau<NP>(xcol, F, STRIDE, mode, arg, bad);
+      s_tau[lane] = tau;
+      if (check_finite && __any(bad && (uint32_t)lane < rows_here) && lane == 0) atomicOr(err_flag, 1);
+    } else if (want_lambda) {
+      double num = 0.0, edge = 0.0, s2 = 0.0, lnum = 0.0, ledge = 0.0, xi = 0.0;
+      uint32_t cur_row = 0xFFFFFFFFu;
+      // entries are fetched 64 at a time (one per lane, coalesced) and broadcast with readlane:
+      // no memory latency inside the per-entry chain
+      for (uint64_t e0 = 0; e0 < nnz; e0 += 64) {
+        const uint32_t nb = (uint32_t)min((uint64_t)64, nnz - e0);
+        PackedEntry mine;
+        mine.i = mine.j = 0;
+        mine.v = 0.0;
+        if ((uint32_t)lane < nb) mine = ent[e0 + lane];
+        const int v_lo = (int)(__double_as_longlong(mine.v) & 0xFFFFFFFFll);
+        const int v_hi = (int)(__double_as_longlong(mine.v) >> 32);
+        for (uint32_t k = 0; k < nb; ++k) {
+          const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane((int)mine.i, k);
+          const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.j, k);
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(v_lo, k);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(v_hi, k);
+          const double pv = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+          if (pi != cur_row) {
+            num = __dadd_rn(num, lnum);
+            edge = __dadd_rn(edge, ledge);
+            lnum = 0.0;
+            ledge = 0.0;
+            cur_row = pi;
+            xi = xcol[(size_t)pi * STRIDE];
+          }
+          if (pi == pj) {
+            lnum = __dadd_rn(lnum, __dmul_rn(__dmul_rn(xi, pv), xi));
+          } else {
+            const double xj = xcol[(size_t)pj * STRIDE];
+            const double term = __dmul_rn(__dmul_rn(xi, pv), xj);  // xi * lij * xj
+            const double w = fmax(-pv, 0.0);
+            double t = 0.0;
+            if (w > 0.0) {
+              const double dd = __dsub_rn(xi, xj);
+              t = __dmul_rn(__dmul_rn(w, dd), dd);  // w * d * d
+            }
+            if (symmetric) {  // stream holds j > i only: each pair stands for (i,j) and (j,i)
+              lnum = __dadd_rn(lnum, __dadd_rn(term, term));
+              ledge = __dadd_rn(ledge, __dadd_rn(t, t));
+              s2 = __dadd_rn(s2, __dmul_rn(__dadd_rn(t, t), t));
+            } else {
+              lnum = __dadd_rn(lnum, term);
+              ledge = __dadd_rn(ledge, t);
+              s2 = __dadd_rn(s2, __dmul_rn(t, t));
+            }
+          }
+        }
+      }
+      num = __dadd_rn(num, lnum);
+      edge = __dadd_rn(edge, ledge);
+      double den = 0.0;
+      for (uint32_t f = 0; f < F; ++f) {
+        const double x = xcol[(size_t)f * STRIDE];
+        den = __dadd_rn(den, __dmul_rn(x, x));
+      }
+      s_part[lane * 4 + 0] = num;
+      s_part[lane * 4 + 1] = edge;
+      s_part[lane * 4 + 2] = s2;
+      s_part[lane * 4 + 3] = den;
+    }
+    __syncthreads();
+    if (wv == 0 && (uint32_t)lane < rows_here) {
+      const double tau = s_tau[lane];
+      if (!want_lambda) {
+        out[item0 + lane] = tau;
+      } else {
+        const double num = s_part[lane * 4 + 0], edge = s_part[lane * 4 + 1], s2 = s_part[lane * 4 + 2],
+                     den = s_part[lane * 4 + 3];
+        const double e_raw = den > 1e-12 ? __ddiv_rn(num, den) : 0.0;
+        double g = 0.0;
+        if (edge > 0.0) {
+          const double e2 = __dmul_rn(edge, edge);
+          if (finite_bits(s2) && finite_bits(e2) && e2 > 0.0 && s2 > 1e-280) {
+            g = __ddiv_rn(s2, e2);
+          } else {  // extreme magnitudes: literal two-pass form
+            double gs = 0.0;
+            for (uint64_t e = 0; e < nnz; ++e) {
+              const PackedEntry p = ent[e];
+              if (p.i == p.j) continue;
+              const double w = fmax(-p.v, 0.0);
+              if (w > 0.0) {
+                const double dd = __dsub_rn(xcol[(size_t)p.i * STRIDE], xcol[(size_t)p.j * STRIDE]);
+                const double share = __ddiv_rn(__dmul_rn(__dmul_rn(w, dd), dd), edge);
+                gs = __dadd_rn(gs, symmetric ? __dmul_rn(2.0, __dmul_rn(share, share)) : __dmul_rn(share, share));
+              }
+            }
+            g = gs;
+          }
+        }
+        const double g_raw = fmin(fmax(g, 0.0), 1.0);
+        const double e_b = __ddiv_rn(e_raw, __dadd_rn(e_raw, tau));
+        out[item0 + lane] = __dadd_rn(__dmul_rn(tau, e_b), __dmul_rn(__dsub_rn(1.0, tau), g_raw));
+      }
+    }
+  }
+}
+
+template <int NP>
+static int launch_lambda_v2(as_ctx *ctx, const double *items, uint64_t n_items, uint32_t F, const PackedEntry *ent,
+                            uint64_t nnz, int symmetric, int mode, double arg, int check_finite, int want_lambda,
+                            double *out, int *err) {
+  const size_t lds = ((size_t)F * 65 + 64 + 256) * sizeof(double);
+  const uint64_t n_tiles = (n_items + 63) / 64;
+  const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, 256ull * 8);
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v2<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(lambda_kernel_v2<NP>, dim3(blocks), dim3(128), lds, ctx->stream, items, n_items, F, ent, nnz,
+                     symmetric, mode, arg, check_finite, want_lambda, out, err);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 template <int S>
 static int launch_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uint32_t F, const PackedEntry *ent,
                          uint64_t nnz, int mode, double arg, int check_finite, int want_lambda, double *out,
@@ -264,13 +547,33 @@ static int launch_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uin
 }
 
 static int run_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F64, const PackedEntry *ent,
-                      uint64_t nnz, int mode, double arg, bool check_finite, bool want_lambda, double *out) {
+                      uint64_t nnz, const PackedEntry *ent_upper, uint64_t nnz_upper, int mode, double arg,
+                      bool check_finite, bool want_lambda, double *out) {
   if (n_items == 0) return AS_OK;
   if (mode < AS_TAU_FIXED || mode > AS_TAU_PERCENTILE) return fail(ctx, AS_ERR_ARG, "bad tau_mode");
   const uint32_t F = (uint32_t)F64;
   DevBuf<int> err;
   AS_TRY(err.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+  if (F <= 128 && ctx->opt_lambda_v2) {
+    ProfScope ps(ctx, want_lambda ? "taumode_lambda" : "select_tau");
+    const int sym = ent_upper != nullptr && ctx->opt_lambda_v2 != 2;
+    if (sym) {
+      ent = ent_upper;
+      nnz = nnz_upper;
+    }
+    if (F <= 16) AS_TRY(launch_lambda_v2<16>(ctx, items, n_items, F, ent, nnz, sym, mode, arg, check_finite, want_lambda, out, err.p));
+    else if (F <= 32) AS_TRY(launch_lambda_v2<32>(ctx, items, n_items, F, ent, nnz, sym, mode, arg, check_finite, want_lambda, out, err.p));
+    else if (F <= 64) AS_TRY(launch_lambda_v2<64>(ctx, items, n_items, F, ent, nnz, sym, mode, arg, check_finite, want_lambda, out, err.p));
+    else AS_TRY(launch_lambda_v2<128>(ctx, items, n_items, F, ent, nnz, sym, mode, arg, check_finite, want_lambda, out, err.p));
+    if (check_finite) {
+      int h = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h, err.p, sizeof(int)));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (h) return fail(ctx, AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
+    }
+    return AS_OK;
+  }
   // lanes per item: smallest S whose tile fits ~40 KB of LDS (4 waves per CU)
   const size_t budget = 40 * 1024;
   int S = 1;
@@ -295,7 +598,7 @@ static int run_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uint64
   }
   if (check_finite) {
     int h = 0;
-    AS_HIP(ctx, hipMemcpyAsync(&h, err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AS_HIP(ctx, copy_d2h(ctx, &h, err.p, sizeof(int)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h) return fail(ctx, AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
   }
@@ -306,13 +609,13 @@ int taumode_lambdas(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t
                     double arg, bool check_finite, double *lambdas_out) {
   if (L->n > F) return fail(ctx, AS_ERR_DIM, "graph has more nodes than the items have features");
   AS_TRY(ensure_packed(ctx, L));
-  return run_lambda(ctx, items, n_items, F, (const PackedEntry *)L->packed, L->nnz, mode, arg, check_finite, true,
-                    lambdas_out);
+  return run_lambda(ctx, items, n_items, F, (const PackedEntry *)L->packed, L->nnz,
+                    (const PackedEntry *)L->packed_upper, L->nnz_upper, mode, arg, check_finite, true, lambdas_out);
 }
 
 int select_tau_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode, double arg,
                     double *taus) {
-  return run_lambda(ctx, rows, n_rows, len, nullptr, 0, mode, arg, false, false, taus);
+  return run_lambda(ctx, rows, n_rows, len, nullptr, 0, nullptr, 0, mode, arg, false, false, taus);
 }
 
 }  // namespace asx

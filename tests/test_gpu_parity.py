@@ -310,3 +310,19 @@ def test_device_resident_inputs(ctx):
     idx, sc = asp_d.search_lambda_aware_batch(Q, lq, 5, 0.7)
     idx_h, sc_h = asp_h.search_lambda_aware_batch(Q.cpu().numpy(), lq.cpu().numpy(), 5, 0.7)
     assert np.array_equal(idx.cpu().numpy().astype(np.uint64), idx_h) and np.array_equal(sc.cpu().numpy(), sc_h)
+
+
+def test_repeated_small_calls_are_stable(ctx, proteins):
+    """Regression: workspace blocks and host staging are recycled between calls; results of many
+    back-to-back small calls (index re-creation included) must stay identical to the oracle."""
+    lam = np.linspace(0.05, 0.9, len(proteins))
+    want = {}
+    for j in (3, 10, 40):
+        want[j] = O.search_lambda_aware(proteins, lam, proteins[j] * 1.02, 0.3 + 0.01 * j, 3, 0.7)
+    for rep in range(60):
+        asp = A.ArrowSpace(proteins, A.TauMode.Median, ctx)
+        asp.update_lambdas(lam)
+        for j, (oi, osc) in want.items():
+            res = asp.search_lambda_aware(A.ArrowItem(proteins[j] * 1.02, 0.3 + 0.01 * j), 3, 0.7)
+            assert [r[0] for r in res] == oi.tolist(), (rep, j)
+            assert np.array_equal([r[1] for r in res], osc), (rep, j)
