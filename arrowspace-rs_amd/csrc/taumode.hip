@@ -386,16 +386,16 @@ __device__ __forceinline__ double regs_select_tau(const double *xcol, uint32_t F
 }
 
 template <int NP>
-__global__ __launch_bounds__(128, 1) void lambda_kernel_v2(const double *__restrict__ items, uint64_t n_items,
+__global__ __launch_bounds__(256, 2) void lambda_kernel_v2(const double *__restrict__ items, uint64_t n_items,
                                                            uint32_t F, const PackedEntry *__restrict__ ent,
                                                            uint64_t nnz, int symmetric, int mode, double arg,
                                                            int check_finite, int want_lambda,
                                                            double *__restrict__ out, int *__restrict__ err_flag) {
   constexpr int IPW = 64, STRIDE = 65;
-  extern __shared__ double xT[];            // [F][65] tile + [64] tau + [64][4] partials
+  extern __shared__ double xT[];            // [F][65] tile + [64] tau + [3][64][4] partials
   double *s_tau = xT + (size_t)F * STRIDE;
   double *s_part = s_tau + 64;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave 0: tau; waves 1..3: CSR stream thirds
   const uint64_t n_tiles = (n_items + IPW - 1) / IPW;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t item0 = tile * IPW;
@@ -404,10 +404,13 @@ __global__ __launch_bounds__(128, 1) void lambda_kernel_v2(const double *__restr
     const double *src = items + item0 * F;
     // thread = feature, loop = row: coalesced row reads, 16 independent loads in flight per thread,
     // conflict-free transposed LDS writes (row stride 65 doubles)
-    if ((uint32_t)tid < F) {
+    {  // 256 threads: feature = tid & 127, rows split in two halves
+      const uint32_t f = tid & 127, r0 = (tid >> 7) * (IPW / 2);
+      if (f < F) {
 #pragma unroll 16
-      for (uint32_t r = 0; r < (uint32_t)IPW; ++r)
-        xT[(size_t)tid * STRIDE + r] = r < rows_here ? src[(size_t)r * F + tid] : 0.0;
+        for (uint32_t r = r0; r < r0 + IPW / 2; ++r)
+          xT[(size_t)f * STRIDE + r] = r < rows_here ? src[(size_t)r * F + f] : 0.0;
+      }
     }
     __syncthreads();
     const double *xcol = xT + lane;
@@ -417,66 +420,68 @@ __global__ __launch_bounds__(128, 1) void lambda_kernel_v2(const double *__restr
       s_tau[lane] = tau;
       if (check_finite && __any(bad && (uint32_t)lane < rows_here) && lane == 0) atomicOr(err_flag, 1);
     } else if (want_lambda) {
-      double num = 0.0, edge = 0.0, s2 = 0.0, lnum = 0.0, ledge = 0.0, xi = 0.0;
-      uint32_t cur_row = 0xFFFFFFFFu;
-      // entries are fetched 64 at a time (one per lane, coalesced) and broadcast with readlane:
-      // no memory latency inside the per-entry chain
-      for (uint64_t e0 = 0; e0 < nnz; e0 += 64) {
+      double num = 0.0, edge = 0.0, s2 = 0.0;
+      // Entries are fetched 64 at a time (one per lane, coalesced) and broadcast with readlane; they
+      // are consumed four at a time so that the eight LDS reads of a group are in flight together
+      // (one wave per SIMD: nothing else hides the LDS latency).  Accumulation is flat in stream
+      // order (the reference folds row-local sums; the difference is rounding only).
+      constexpr int U = 4;
+      // this wave's third of the stream, in 64-entry batches
+      const uint64_t n_batches = (nnz + 63) / 64;
+      const uint64_t b_lo = n_batches * (wv - 1) / 3, b_hi = n_batches * wv / 3;
+      for (uint64_t e0 = b_lo * 64; e0 < b_hi * 64 && e0 < nnz; e0 += 64) {
         const uint32_t nb = (uint32_t)min((uint64_t)64, nnz - e0);
         PackedEntry mine;
         mine.i = mine.j = 0;
-        mine.v = 0.0;
+        mine.v = 0.0;  // padding entries (i = j = 0, v = 0) contribute exactly 0
         if ((uint32_t)lane < nb) mine = ent[e0 + lane];
         const int v_lo = (int)(__double_as_longlong(mine.v) & 0xFFFFFFFFll);
         const int v_hi = (int)(__double_as_longlong(mine.v) >> 32);
-        for (uint32_t k = 0; k < nb; ++k) {
-          const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane((int)mine.i, k);
-          const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.j, k);
-          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(v_lo, k);
-          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(v_hi, k);
-          const double pv = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-          if (pi != cur_row) {
-            num = __dadd_rn(num, lnum);
-            edge = __dadd_rn(edge, ledge);
-            lnum = 0.0;
-            ledge = 0.0;
-            cur_row = pi;
-            xi = xcol[(size_t)pi * STRIDE];
+        const uint32_t nbu = (nb + U - 1) / U * U;
+        for (uint32_t k = 0; k < nbu; k += U) {
+          uint32_t pi[U], pj[U];
+          double pv[U], xi[U], xj[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            pi[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.i, k + u);
+            pj[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.j, k + u);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(v_lo, k + u);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(v_hi, k + u);
+            pv[u] = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+            xi[u] = xcol[(size_t)pi[u] * STRIDE];
+            xj[u] = xcol[(size_t)pj[u] * STRIDE];
           }
-          if (pi == pj) {
-            lnum = __dadd_rn(lnum, __dmul_rn(__dmul_rn(xi, pv), xi));
-          } else {
-            const double xj = xcol[(size_t)pj * STRIDE];
-            const double term = __dmul_rn(__dmul_rn(xi, pv), xj);  // xi * lij * xj
-            const double w = fmax(-pv, 0.0);
-            double t = 0.0;
-            if (w > 0.0) {
-              const double dd = __dsub_rn(xi, xj);
-              t = __dmul_rn(__dmul_rn(w, dd), dd);  // w * d * d
-            }
-            if (symmetric) {  // stream holds j > i only: each pair stands for (i,j) and (j,i)
-              lnum = __dadd_rn(lnum, __dadd_rn(term, term));
-              ledge = __dadd_rn(ledge, __dadd_rn(t, t));
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double term = __dmul_rn(__dmul_rn(xi[u], pv[u]), xj[u]);  // xi * lij * xj
+            const bool off = pi[u] != pj[u];
+            const double w = off ? fmax(-pv[u], 0.0) : 0.0;
+            const double dd = __dsub_rn(xi[u], xj[u]);
+            const double t = __dmul_rn(__dmul_rn(w, dd), dd);  // w * d * d (0 on the diagonal / w = 0)
+            if (symmetric && off) {  // stream holds j > i only: each pair stands for (i,j) and (j,i)
+              num = __dadd_rn(num, __dadd_rn(term, term));
+              edge = __dadd_rn(edge, __dadd_rn(t, t));
               s2 = __dadd_rn(s2, __dmul_rn(__dadd_rn(t, t), t));
             } else {
-              lnum = __dadd_rn(lnum, term);
-              ledge = __dadd_rn(ledge, t);
+              num = __dadd_rn(num, term);
+              edge = __dadd_rn(edge, t);
               s2 = __dadd_rn(s2, __dmul_rn(t, t));
             }
           }
         }
       }
-      num = __dadd_rn(num, lnum);
-      edge = __dadd_rn(edge, ledge);
       double den = 0.0;
-      for (uint32_t f = 0; f < F; ++f) {
-        const double x = xcol[(size_t)f * STRIDE];
-        den = __dadd_rn(den, __dmul_rn(x, x));
+      if (wv == 1) {
+        for (uint32_t f = 0; f < F; ++f) {
+          const double x = xcol[(size_t)f * STRIDE];
+          den = __dadd_rn(den, __dmul_rn(x, x));
+        }
       }
-      s_part[lane * 4 + 0] = num;
-      s_part[lane * 4 + 1] = edge;
-      s_part[lane * 4 + 2] = s2;
-      s_part[lane * 4 + 3] = den;
+      double *sp = s_part + (size_t)(wv - 1) * 256;
+      sp[lane * 4 + 0] = num;
+      sp[lane * 4 + 1] = edge;
+      sp[lane * 4 + 2] = s2;
+      sp[lane * 4 + 3] = den;
     }
     __syncthreads();
     if (wv == 0 && (uint32_t)lane < rows_here) {
@@ -484,8 +489,13 @@ __global__ __launch_bounds__(128, 1) void lambda_kernel_v2(const double *__restr
       if (!want_lambda) {
         out[item0 + lane] = tau;
       } else {
-        const double num = s_part[lane * 4 + 0], edge = s_part[lane * 4 + 1], s2 = s_part[lane * 4 + 2],
-                     den = s_part[lane * 4 + 3];
+        double num = 0.0, edge = 0.0, s2 = 0.0;
+        const double den = s_part[lane * 4 + 3];
+        for (int w = 0; w < 3; ++w) {  // fixed combination order: deterministic
+          num = __dadd_rn(num, s_part[w * 256 + lane * 4 + 0]);
+          edge = __dadd_rn(edge, s_part[w * 256 + lane * 4 + 1]);
+          s2 = __dadd_rn(s2, s_part[w * 256 + lane * 4 + 2]);
+        }
         const double e_raw = den > 1e-12 ? __ddiv_rn(num, den) : 0.0;
         double g = 0.0;
         if (edge > 0.0) {
@@ -519,12 +529,12 @@ template <int NP>
 static int launch_lambda_v2(as_ctx *ctx, const double *items, uint64_t n_items, uint32_t F, const PackedEntry *ent,
                             uint64_t nnz, int symmetric, int mode, double arg, int check_finite, int want_lambda,
                             double *out, int *err) {
-  const size_t lds = ((size_t)F * 65 + 64 + 256) * sizeof(double);
+  const size_t lds = ((size_t)F * 65 + 64 + 3 * 256) * sizeof(double);
   const uint64_t n_tiles = (n_items + 63) / 64;
   const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, 256ull * 8);
   AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v2<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-  hipLaunchKernelGGL(lambda_kernel_v2<NP>, dim3(blocks), dim3(128), lds, ctx->stream, items, n_items, F, ent, nnz,
+  hipLaunchKernelGGL(lambda_kernel_v2<NP>, dim3(blocks), dim3(256), lds, ctx->stream, items, n_items, F, ent, nnz,
                      symmetric, mode, arg, check_finite, want_lambda, out, err);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
