@@ -73,6 +73,7 @@ int pack_f64(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
              uint32_t d, double *P, uint32_t tiles);
 int pack_f32(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
              uint32_t d, float *P, uint32_t tiles);
+uint32_t packed_units(uint32_t d);                  // 32-column units per packed row (whole 128-wide panels beyond 4)
 uint64_t packed_elems(uint32_t tiles, uint32_t d);  // elements of a packed image with `tiles` 128-row tiles
 
 int candidates_f64(as_ctx *ctx, const CandProblem &pb, const double *PA, uint32_t a_tiles, const double *PB,
@@ -86,7 +87,7 @@ bool fits_f64(uint32_t KC);
 // rounding bound between an approximate cosine of a stage and the exact (oracle) cosine
 inline double cos_delta_f64(uint32_t d) { return (double)(d + 16) * 2.3e-16; }
 inline double cos_delta_f32(uint32_t d) {
-  const uint32_t dp = (d + 31) / 32 * 32;
+  const uint32_t dp = packed_units(d) * 32;
   return (double)(dp + 4) * 5.9604644775390625e-08 * 1.01 + 1e-13;  // (d+4) 2^-24 + f64 slack
 }
 

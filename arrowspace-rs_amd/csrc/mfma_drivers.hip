@@ -193,8 +193,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const int NC = (int)((d + 31) / 32);
   // one extra slot: a row's own index is the best candidate of its list and is dropped by the re-rank
   const uint32_t KC = cand_capacity(ctx, K + 1);
-  const bool use_f32 = ctx->opt_cand_precision != 64 && fits_f32(KC);
-  if (NC > kMaxNC || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0)  // small, wide or deep problems: exact scan
+  const bool wide = NC > kMaxNC;  // dim > 128: only the f32 pass has the k-panel loop
+  const bool use_f32 = (ctx->opt_cand_precision != 64 || wide) && fits_f32(KC);
+  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0)  // small or deep problems: exact scan
     return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
 
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
@@ -303,7 +304,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   DevBuf<uint32_t> fail2, gids2, pos2;
 
   // ---- stage 2: f64 MFMA over the gathered failed rows ----
-  if (use_f32 && n_fail > kExactDirect) {
+  if (use_f32 && !wide && n_fail > kExactDirect) {
     const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
     pb.arows = ARows{gids.p, 0};
     pb.nA = n_fail;
@@ -362,9 +363,10 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const int NC = (int)((d + 31) / 32);
   const uint32_t K = std::min<uint32_t>(k, n);
   const uint32_t KC = cand_capacity(ctx, K);
-  if (NC > kMaxNC || !fits_f64(KC) || n < 4 * kTileRows || nq == 0)
+  const bool wide = NC > kMaxNC;
+  const bool use_f32 = (ctx->opt_cand_precision != 64 || wide) && fits_f32(KC);
+  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || nq == 0)
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
-  const bool use_f32 = ctx->opt_cand_precision != 64 && fits_f32(KC);
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   auto ensure64 = [&]() -> int {
@@ -447,7 +449,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t *exact_ids = fail1.p;
   uint32_t n_exact = n_fail;
   DevBuf<uint32_t> fail2, ids2;
-  if (use_f32 && n_fail > kExactDirect) {
+  if (use_f32 && !wide && n_fail > kExactDirect) {
     const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
     pb.arows = ARows{fail1.p, 0};
     pb.nA = n_fail;

@@ -48,7 +48,7 @@ __global__ void pack_f32_kernel(const double *__restrict__ R, const double *__re
 
 int pack_f32(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
              uint32_t d, float *P, uint32_t tiles) {
-  const uint32_t KS2 = (d + 31) / 32 * 16;
+  const uint32_t KS2 = packed_units(d) * 16;
   const uint64_t total = packed_elems(tiles, d);
   ProfScope ps(ctx, "pack_unit_rows");
   hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, row_ids, row0, n,
@@ -119,8 +119,10 @@ __device__ __forceinline__ void stage_chunk(const float *src, float *dst_lds, in
 template <int NC, int CPB, int MW, class Epi>
 __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
     const float *__restrict__ PA, uint32_t a_items, const float *__restrict__ PB, uint32_t b_tiles, uint32_t nA,
-    uint32_t nB, uint32_t KC, uint32_t splits, Epi epi, double *__restrict__ cand_key,
+    uint32_t nB, uint32_t KC, uint32_t splits, uint32_t panels, Epi epi, double *__restrict__ cand_key,
     uint32_t *__restrict__ cand_idx, int dbg) {
+  // panels = 128-wide k panels per row (1 for dim <= 128: the A fragments then stay in registers for
+  // the whole sweep; more: they are re-read from L2 once per (B tile, panel))
   constexpr int WAVES = 8 / MW;
   constexpr int NT = 64 * WAVES;
   constexpr int WROWS = 32 * MW;                  // rows per wave
@@ -159,16 +161,21 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
 
     // A fragments of this wave's rows: rows [wv*WROWS, +WROWS) of the 256-row workgroup tile
     float a[MW][KS2];
+    const float *a_src;
     {
       const int row0 = wv * WROWS;
       const size_t T = (size_t)2 * I + (row0 >> 7);
       const int s0 = (row0 & 127) >> 5;
+      a_src = PA + ((T * KS2 * panels) * 4 + s0) * 64 + lane;  // + (panel*KS2 + ks)*256 + m*64
+    }
+    auto load_a = [&](uint32_t panel) {
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m) a[m][ks] = PA[((T * KS2 + ks) * 4 + s0 + m) * 64 + lane];
+        for (int m = 0; m < MW; ++m) a[m][ks] = a_src[((size_t)panel * KS2 + ks) * 256 + m * 64];
       }
-    }
+    };
+    if (panels == 1) load_a(0);
     if (lane < WROWS) {  // per-row epilogue data (search: the query lambdas), kept in LDS
       const uint32_t arow = I * kRows32 + wv * WROWS + lane;
       float rv = 0.f;
@@ -189,8 +196,8 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const uint32_t n_chunks = (j_hi - j_lo) * NCB;
-    const float *src = PB + (size_t)j_lo * NCB * kChunkFloats;
+    const uint32_t n_chunks = (j_hi - j_lo) * panels * NCB;
+    const float *src = PB + (size_t)j_lo * panels * NCB * kChunkFloats;
     // LDS-DMA staging: chunk g+1 is copied global -> LDS (linear image, 16 B per lane) while chunk g
     // is consumed; the one barrier per chunk both retires the DMA (vmcnt) and frees the buffer.
     __syncthreads();
@@ -202,6 +209,8 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
       float colv[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) epi.load_col(J * kTileRows + n * 32 + lc, nB, colv[n]);
+      for (uint32_t panel = 0; panel < panels; ++panel) {
+      if (panels > 1) load_a(panel);
 #pragma unroll
       for (int c = 0; c < NCB; ++c, ++g) {
         if (g + 1 < n_chunks)
@@ -230,6 +239,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * MW, 0);
         __syncthreads();  // DMA of the next chunk landed; everyone is done reading bufB[pbuf]
         pbuf ^= 1;
+      }
       }
       // ---- epilogue of column tile J: threshold filter; passing elements (a few per tile once the
       // lists are warm) are compacted into a per-wave queue and inserted by ONE drain loop.  All
@@ -366,8 +376,8 @@ bool fits_f32(uint32_t KC) { return lds_bytes_f32(KC, 1) <= 160 * 1024; }
 
 template <class Epi>
 static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, const float *PB, uint32_t b_tiles,
-                      uint32_t nA, uint32_t nB, uint32_t KC, uint32_t splits, Epi epi, double *cand_key,
-                      uint32_t *cand_idx, const char *prof_name) {
+                      uint32_t nA, uint32_t nB, uint32_t KC, uint32_t splits, uint32_t panels, Epi epi,
+                      double *cand_key, uint32_t *cand_idx, const char *prof_name) {
   // two 16 KB units per barrier when the LDS budget allows (half the barriers per tile)
   const int CPB = (NC % 2 == 0 && lds_bytes_f32(KC, 2) <= 160 * 1024) ? 2 : 1;
   const size_t lds = lds_bytes_f32(KC, CPB);
@@ -381,12 +391,14 @@ static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, co
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_topk_mfma32_kernel<N, C, 2, Epi>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
       hipLaunchKernelGGL((pair_topk_mfma32_kernel<N, C, 2, Epi>), dim3(grid), dim3(256), lds, ctx->stream, PA,       \
-                         a_items, PB, b_tiles, nA, nB, KC, splits, epi, cand_key, cand_idx, (int)ctx->opt_debug);    \
+                         a_items, PB, b_tiles, nA, nB, KC, splits, panels, epi, cand_key, cand_idx,              \
+                         (int)ctx->opt_debug);                                                                      \
     } else {                                                                                                         \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_topk_mfma32_kernel<N, C, 1, Epi>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
       hipLaunchKernelGGL((pair_topk_mfma32_kernel<N, C, 1, Epi>), dim3(grid), dim3(512), lds, ctx->stream, PA,       \
-                         a_items, PB, b_tiles, nA, nB, KC, splits, epi, cand_key, cand_idx, (int)ctx->opt_debug);    \
+                         a_items, PB, b_tiles, nA, nB, KC, splits, panels, epi, cand_key, cand_idx,              \
+                         (int)ctx->opt_debug);                                                                      \
     }                                                                                                                \
   } while (0)
   switch (NC * 10 + CPB) {
@@ -396,7 +408,7 @@ static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, co
     case 31: AS_CAND(3, 1); break;
     case 41: AS_CAND(4, 1); break;
     case 42: AS_CAND(4, 2); break;
-    default: return fail(ctx, AS_ERR_UNSUPPORTED, "dim > 128 on the MFMA path");
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bad k-panel shape");
   }
 #undef AS_CAND
   AS_HIP(ctx, hipGetLastError());
@@ -406,14 +418,17 @@ static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, co
 // a_tiles counts 128-row packed tiles of the A image (allocated to an even count)
 int candidates_f32(as_ctx *ctx, const CandProblem &pb, const float *PA, uint32_t a_tiles, const float *PB,
                    uint32_t b_tiles, const char *prof_name) {
-  const int NC = (int)((pb.d + 31) / 32);
+  // dim <= 128: one panel of NC 32-wide units; larger: dim padded to a multiple of 128, 4 units per panel
+  const uint32_t units = packed_units(pb.d);
+  const int NC = units <= 4 ? (int)units : 4;
+  const uint32_t panels = units <= 4 ? 1 : units / 4;
   const uint32_t a_items = (a_tiles + 1) / 2;
   if (pb.mode == 0)
-    return launch_f32<GraphEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, GraphEpi32{},
-                                  pb.cand_key, pb.cand_idx, prof_name);
+    return launch_f32<GraphEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels,
+                                  GraphEpi32{}, pb.cand_key, pb.cand_idx, prof_name);
   SearchEpi32 epi{pb.arows, pb.q_lambdas, pb.x_lambdas, (float)pb.alpha, (float)(1.0 - pb.alpha)};
-  return launch_f32<SearchEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, epi, pb.cand_key,
-                                 pb.cand_idx, prof_name);
+  return launch_f32<SearchEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels, epi,
+                                 pb.cand_key, pb.cand_idx, prof_name);
 }
 
 }  // namespace asx

@@ -46,11 +46,15 @@ __global__ void pack_f64_kernel(const double *__restrict__ R, const double *__re
   P[g] = v;
 }
 
-uint64_t packed_elems(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * kTileRows * ((d + 31) / 32 * 32); }
+uint32_t packed_units(uint32_t d) {
+  const uint32_t u = (d + 31) / 32;
+  return u <= 4 ? u : (u + 3) / 4 * 4;  // beyond 128 columns: whole 128-wide panels
+}
+uint64_t packed_elems(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * kTileRows * packed_units(d) * 32; }
 
 int pack_f64(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
              uint32_t d, double *P, uint32_t tiles) {
-  const uint32_t KS = (d + 31) / 32 * 8;
+  const uint32_t KS = packed_units(d) * 8;
   const uint64_t total = packed_elems(tiles, d);
   ProfScope ps(ctx, "pack_unit_rows");
   hipLaunchKernelGGL(pack_f64_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, row_ids, row0, n,

@@ -200,7 +200,8 @@ def test_query_errors(ctx, proteins):
 
 # ---- seeded synthetic sets vs the oracle, both mappings --------------------------------------
 
-@pytest.mark.parametrize("n,d,topk,eps", [(1500, 64, 16, 0.5), (777, 33, 5, 0.3), (2048, 128, 16, 0.5), (300, 130, 3, 0.6)])
+@pytest.mark.parametrize("n,d,topk,eps", [(1500, 64, 16, 0.5), (777, 33, 5, 0.3), (2048, 128, 16, 0.5), (300, 130, 3, 0.6),
+                                          (1100, 200, 8, 0.5), (640, 768, 16, 0.5), (1300, 96, 30, 0.5), (900, 40, 45, 0.6)])
 def test_item_graph_matches_oracle(ctx, mode, n, d, topk, eps):
     X, _ = synth.mixture(n, d, seed=11, n_clusters=16, rank=4)
     gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
