@@ -26,7 +26,7 @@ template <class Policy, class Bound>
 __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ A, uint64_t lda,
                                                      const double *__restrict__ B, uint64_t ldb, uint32_t d,
                                                      const uint32_t *__restrict__ a_ids, uint32_t a_begin,
-                                                     uint32_t a_count, uint32_t K, uint32_t KC,
+                                                     uint32_t a_count, uint32_t out_row0, uint32_t K, uint32_t KC,
                                                      uint32_t splits, const double *__restrict__ cand_key,
                                                      const uint32_t *__restrict__ cand_idx,
                                                      const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd,
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ 
       uint32_t rank = 0;
       for (uint32_t c2 = 0; c2 < C; ++c2) rank += lex_less(ek[c2], ei[c2], kc, ic) ? 1u : 0u;
       if (rank < K) {
-        out_key[(uint64_t)r * K + rank] = kc;
-        out_idx[(uint64_t)r * K + rank] = ic;
+        out_key[(uint64_t)(r + out_row0) * K + rank] = kc;
+        out_idx[(uint64_t)(r + out_row0) * K + rank] = ic;
         kth = fmax(kth, kc);
       }
     }
@@ -95,13 +95,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ 
       n_valid += __shfl_xor(n_valid, o, 64);
     }
     for (uint32_t s = n_valid + lane; s < K; s += 64) {  // fewer than K candidates exist at all
-      out_key[(uint64_t)r * K + s] = __builtin_inf();
-      out_idx[(uint64_t)r * K + s] = kNoIdx;
+      out_key[(uint64_t)(r + out_row0) * K + s] = __builtin_inf();
+      out_idx[(uint64_t)(r + out_row0) * K + s] = kNoIdx;
     }
     bool ok = true;
     if (bounded) ok = n_valid >= K && kth < bnd.lower_bound(worst);
     if (force_exact && force_exact[a]) ok = false;
-    if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r + out_row0;
   }
 }
 
@@ -164,8 +164,8 @@ constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straig
 
 template <class Policy, class Bound>
 static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const double *B, uint32_t d,
-                         const uint32_t *a_ids, uint32_t a_begin, uint32_t a_count, uint32_t K, uint32_t KC,
-                         uint32_t splits, const double *ckey, const uint32_t *cidx, const uint8_t *force, Policy pol,
+                         const uint32_t *a_ids, uint32_t a_begin, uint32_t a_count, uint32_t out_row0, uint32_t K,
+                         uint32_t KC, uint32_t splits, const double *ckey, const uint32_t *cidx, const uint8_t *force, Policy pol,
                          Bound bnd, double *out_key, uint32_t *out_idx, uint32_t *fail_rows, uint32_t *fail_count,
                          int *err) {
   const uint32_t C = splits * KC;
@@ -174,7 +174,7 @@ static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const d
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_kernel<Policy, Bound>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((rerank_kernel<Policy, Bound>), dim3(std::min<uint64_t>(cdiv(a_count, 4), 4096)), dim3(256), lds,
-                     ctx->stream, A, (uint64_t)d, B, (uint64_t)d, d, a_ids, a_begin, a_count, K, KC, splits, ckey, cidx,
+                     ctx->stream, A, (uint64_t)d, B, (uint64_t)d, d, a_ids, a_begin, a_count, out_row0, K, KC, splits, ckey, cidx,
                      force, pol, bnd, out_key, out_idx, fail_rows, fail_count, err);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
@@ -238,53 +238,83 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   pb.KC = KC;
 
   // ---- stage 1 over the contiguous row range ----
-  PackedF32 B32;
-  PackedF64 B64;
+  // The bulk of the rows runs as whole rounds of 256 workgroups; a remainder that would leave most of
+  // the chip idle for a full sweep is launched separately with its column range split (tail quantisation).
+  PackedF32 B32, A32;
+  PackedF64 B64, A64;
   uint32_t n_fail = 0;
   {
-    const uint32_t align = use_f32 ? 2 * kTileRows : kTileRows;
-    const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows;
-    const uint32_t a_items = use_f32 ? (a_tiles + 1) / 2 : a_tiles;
-    pb.splits = pick_splits(a_items, b_tiles);
-    DevBuf<double> ckey;
-    DevBuf<uint32_t> cidx;
-    AS_TRY(ckey.alloc(ctx, (size_t)row_count * pb.splits * KC));
-    AS_TRY(cidx.alloc(ctx, (size_t)row_count * pb.splits * KC));
-    pb.cand_key = ckey.p;
-    pb.cand_idx = cidx.p;
+    const uint32_t item_rows = use_f32 ? 2 * kTileRows : kTileRows;  // A rows per work item
+    const uint32_t a_tiles_all = (row_count + kTileRows - 1) / kTileRows;
+    const float *PA32 = nullptr;
+    const double *PA64 = nullptr;
     if (use_f32) {
       AS_TRY(B32.buf.alloc(ctx, packed_elems(b_alloc, d)));
       AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, B32.buf.p, b_alloc));
       B32.p = B32.buf.p;
-      PackedF32 A32;
-      const float *PA = B32.p + (row_begin / kTileRows) * packed_elems(1, d);
-      if (row_begin % align != 0) {
-        const uint32_t at = (a_tiles + 1) & ~1u;
+      PA32 = B32.p + (row_begin / kTileRows) * packed_elems(1, d);
+      if (row_begin % item_rows != 0) {
+        const uint32_t at = (a_tiles_all + 1) & ~1u;
         AS_TRY(A32.buf.alloc(ctx, packed_elems(at, d)));
         AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, A32.buf.p, at));
-        PA = A32.buf.p;
+        PA32 = A32.buf.p;
       }
-      AS_TRY(candidates_f32(ctx, pb, PA, a_tiles, B32.p, b_tiles, "knn_mfma_candidates_f32"));
-      if (ctx->opt_debug) return AS_OK;  // timing experiment: candidate pass only, outputs undefined
-      GraphBound bnd{cos_delta_f32(d), rectify};
-      AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin, row_count, K, KC, pb.splits,
-                           ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p));
     } else {
       AS_TRY(B64.buf.alloc(ctx, packed_elems(b_alloc, d)));
       AS_TRY(pack_f64(ctx, rows, norms, nullptr, 0, n, d, B64.buf.p, b_alloc));
       B64.p = B64.buf.p;
-      PackedF64 A64;
-      const double *PA = B64.p + (row_begin / kTileRows) * packed_elems(1, d);
-      if (row_begin % align != 0) {
-        AS_TRY(A64.buf.alloc(ctx, packed_elems(a_tiles, d)));
-        AS_TRY(pack_f64(ctx, rows, norms, nullptr, row_begin, row_count, d, A64.buf.p, a_tiles));
-        PA = A64.buf.p;
+      PA64 = B64.p + (row_begin / kTileRows) * packed_elems(1, d);
+      if (row_begin % item_rows != 0) {
+        AS_TRY(A64.buf.alloc(ctx, packed_elems(a_tiles_all, d)));
+        AS_TRY(pack_f64(ctx, rows, norms, nullptr, row_begin, row_count, d, A64.buf.p, a_tiles_all));
+        PA64 = A64.buf.p;
       }
-      AS_TRY(candidates_f64(ctx, pb, PA, a_tiles, B64.p, b_tiles, "knn_mfma_candidates"));
-      GraphBound bnd{cos_delta_f64(d), rectify};
-      AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin, row_count, K, KC, pb.splits,
-                           ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p));
     }
+    const uint32_t items_all = (row_count + item_rows - 1) / item_rows;
+    uint32_t bulk_items = items_all;
+    if (items_all >= 512 && items_all % 256 != 0) bulk_items = items_all / 256 * 256;
+    uint32_t splits_used = 1;
+    for (int part = 0; part < 2; ++part) {
+      const uint32_t it0 = part == 0 ? 0 : bulk_items;
+      const uint32_t it1 = part == 0 ? bulk_items : items_all;
+      if (it0 >= it1) continue;
+      const uint32_t r0 = it0 * item_rows;                         // first row of this part (relative)
+      const uint32_t rc = std::min(row_count, it1 * item_rows) - r0;  // its row count
+      const uint32_t a_tiles = (rc + kTileRows - 1) / kTileRows;
+      pb.arows = ARows{nullptr, (uint32_t)row_begin + r0};
+      pb.nA = rc;
+      pb.splits = pick_splits(it1 - it0, b_tiles);
+      if (part == 1 && it1 - it0 < 256)  // remainder round: one work unit per workgroup, as short as possible
+        pb.splits = std::max(1u, std::min({16u, 256u / (it1 - it0), b_tiles}));
+      splits_used = std::max(splits_used, pb.splits);
+      DevBuf<double> ckey;
+      DevBuf<uint32_t> cidx;
+      AS_TRY(ckey.alloc(ctx, (size_t)rc * pb.splits * KC));
+      AS_TRY(cidx.alloc(ctx, (size_t)rc * pb.splits * KC));
+      pb.cand_key = ckey.p;
+      pb.cand_idx = cidx.p;
+      if (use_f32) {
+        AS_TRY(candidates_f32(ctx, pb, PA32 + (size_t)(r0 / kTileRows) * packed_elems(1, d), a_tiles, B32.p, b_tiles,
+                              "knn_mfma_candidates_f32"));
+        if (ctx->opt_debug) continue;  // timing experiment: candidate pass only, outputs undefined
+        GraphBound bnd{cos_delta_f32(d), rectify};
+        AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin + r0, rc, r0, K, KC,
+                             pb.splits, ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p,
+                             err.p));
+      } else {
+        AS_TRY(candidates_f64(ctx, pb, PA64 + (size_t)(r0 / kTileRows) * packed_elems(1, d), a_tiles, B64.p, b_tiles,
+                              "knn_mfma_candidates"));
+        GraphBound bnd{cos_delta_f64(d), rectify};
+        AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, nullptr, (uint32_t)row_begin + r0, rc, r0, K, KC,
+                             pb.splits, ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p,
+                             err.p));
+      }
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // candidate buffers go back to the workspace cache
+    }
+    if (ctx->opt_debug) return AS_OK;
+    pb.splits = splits_used;
+    pb.arows = ARows{nullptr, (uint32_t)row_begin};
+    pb.nA = row_count;
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   }
   ctx->stats["knn_uncertified_rows"] = n_fail;
@@ -325,7 +355,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(fail2.alloc(ctx, n_fail));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
     GraphBound bnd{cos_delta_f64(d), rectify};
-    AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, gids.p, 0u, n_fail, K, KC, pb.splits, ckey.p, cidx.p,
+    AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, gids.p, 0u, n_fail, 0u, K, KC, pb.splits, ckey.p, cidx.p,
                          force.p, pol, bnd, ok.p, oi.p, fail2.p, fail_count.p, err.p));
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_fail * K, 256)), dim3(256), 0, ctx->stream, fail1.p,
                        n_fail, K, ok.p, oi.p, out_dist, out_idx);
@@ -427,7 +457,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(pack_f32(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, at));
       AS_TRY(candidates_f32(ctx, pb, PA.p, a_tiles, ix->packed32, b_tiles, "search_mfma_candidates_f32"));
       SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + 2e-6};
-      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, K, KC, pb.splits, ckey.p,
+      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, 0u, K, KC, pb.splits, ckey.p,
                            cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
     } else {
       AS_TRY(ensure64());
@@ -436,7 +466,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(pack_f64(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, a_tiles));
       AS_TRY(candidates_f64(ctx, pb, PA.p, a_tiles, ix->packed, b_tiles, "search_mfma_candidates"));
       SearchBound bnd{std::fabs(alpha) * cos_delta_f64(d) + 1e-15};
-      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, K, KC, pb.splits, ckey.p,
+      AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, 0u, K, KC, pb.splits, ckey.p,
                            cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
     }
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
@@ -469,7 +499,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_TRY(fail2.alloc(ctx, n_fail));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
     SearchBound bnd{std::fabs(alpha) * cos_delta_f64(d) + 1e-15};
-    AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, fail1.p, 0u, n_fail, K, KC, pb.splits, ckey.p,
+    AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, fail1.p, 0u, n_fail, 0u, K, KC, pb.splits, ckey.p,
                          cidx.p, (const uint8_t *)nullptr, pol, bnd, ok.p, oi.p, fail2.p, fail_count.p, err.p));
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_fail * K, 256)), dim3(256), 0, ctx->stream, fail1.p,
                        n_fail, K, ok.p, oi.p, out_key, out_idx);

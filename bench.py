@@ -175,6 +175,9 @@ def main():
         roofline = None
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
+        # the candidate pass of one step may be split into a bulk launch and a remainder launch:
+        # "launch" below = all candidate launches of one step (their flops add up to flops_per_launch)
+        l32, l64 = min(l32, steps), min(l64, steps)
         if l32 and ms32 >= ms64:   # dominant kernel: the f32-input MFMA candidate pass
             achieved = flops_per_launch / (ms32 / l32 * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc; "
