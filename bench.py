@@ -192,6 +192,16 @@ def main():
                         "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                         "frac_of_datasheet_78p6": achieved / F64_MATRIX_DATASHEET_TFLOPS,
                         "avg_launch_ms": ms64 / l64, "launches": l64}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+        # committed rocprofv3 --pmc measurement of this very command is reported when it matches the workload
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if roofline and world == 1 and (n, d) == (1_000_000, 128) and "mfma32" in roofline["kernel"]:
+                roofline["traffic"] = pmc["hbm_bytes_per_step"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
         extra = {}
         if lam_n:
