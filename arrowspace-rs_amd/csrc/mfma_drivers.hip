@@ -456,7 +456,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(PA.alloc(ctx, packed_elems(at, d)));
       AS_TRY(pack_f32(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, at));
       AS_TRY(candidates_f32(ctx, pb, PA.p, a_tiles, ix->packed32, b_tiles, "search_mfma_candidates_f32"));
-      SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + 2e-6};
+      // f32 pass: cosine error scaled by |alpha|, plus one f32 rounding of a value bounded by |alpha| + |1 - alpha|
+      SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + (std::fabs(alpha) + std::fabs(1.0 - alpha)) * 1.3e-7 + 1e-12};
       AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, 0u, K, KC, pb.splits, ckey.p,
                            cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
     } else {

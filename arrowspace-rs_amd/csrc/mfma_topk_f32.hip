@@ -59,22 +59,24 @@ int pack_f32(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
 
 // epilogues: approximate VALUE of one (row, col) product, higher = better
 struct GraphEpi32 {
-  __device__ __forceinline__ void load_row(uint32_t, float &) const {}
-  __device__ __forceinline__ void load_col(uint32_t, uint32_t, float &) const {}
-  __device__ __forceinline__ float value(float s, float, float) const { return s; }
+  __device__ __forceinline__ void load_row(uint32_t, double &) const {}
+  __device__ __forceinline__ void load_col(uint32_t, uint32_t, double &) const {}
+  __device__ __forceinline__ float value(float s, double, double) const { return s; }
 };
 struct SearchEpi32 {
   ARows ar;
   const double *q_lambdas;
   const double *x_lambdas;
-  float alpha, beta;
-  __device__ __forceinline__ void load_row(uint32_t arow, float &v) const { v = (float)q_lambdas[ar.gid(arow)]; }
-  __device__ __forceinline__ void load_col(uint32_t col, uint32_t nB, float &v) const {
-    v = col < nB ? (float)x_lambdas[col] : 0.f;
+  double alpha, beta;
+  // the lambda term is evaluated in f64 (lambdas of any magnitude), only the sum is rounded to f32:
+  // |value - exact| <= |alpha| delta_cos + (|alpha| + |beta|) 2^-23
+  __device__ __forceinline__ void load_row(uint32_t arow, double &v) const { v = q_lambdas[ar.gid(arow)]; }
+  __device__ __forceinline__ void load_col(uint32_t col, uint32_t nB, double &v) const {
+    v = col < nB ? x_lambdas[col] : 0.0;
   }
-  __device__ __forceinline__ float value(float s, float lq, float lx) const {
-    const float lam = 1.f - fminf(fabsf(lq - lx), 1.f);
-    return fmaf(alpha, s, beta * lam);
+  __device__ __forceinline__ float value(float s, double lq, double lx) const {
+    const double lam = 1.0 - fmin(fabs(lq - lx), 1.0);
+    return (float)(alpha * (double)s + beta * lam);
   }
 };
 
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
   float *qvals = reinterpret_cast<float *>(lidx + kRows32 * KC);        // [WAVES][QCAP]
   uint32_t *qcols = reinterpret_cast<uint32_t *>(qvals + WAVES * QCAP);
   uint32_t *qrows = qcols + WAVES * QCAP;
-  float *rowdata = reinterpret_cast<float *>(qrows + WAVES * QCAP);     // [256]
+  double *rowdata = reinterpret_cast<double *>(qrows + WAVES * QCAP);   // [256] (8-byte aligned: all blocks above are multiples of 8 B)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
   float *qv = qvals + wv * QCAP;
   uint32_t *qc = qcols + wv * QCAP;
   uint32_t *qr = qrows + wv * QCAP;
-  float *wrow = rowdata + wv * WROWS;
+  double *wrow = rowdata + wv * WROWS;
 
   const uint32_t items = a_items * splits;
   for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
     if (panels == 1) load_a(0);
     if (lane < WROWS) {  // per-row epilogue data (search: the query lambdas), kept in LDS
       const uint32_t arow = I * kRows32 + wv * WROWS + lane;
-      float rv = 0.f;
+      double rv = 0.0;
       if (arow < nA) epi.load_row(arow, rv);
       wrow[lane] = rv;
     }
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
     uint32_t g = 0;
     int pbuf = 0;
     for (uint32_t J = j_lo; J < j_hi; ++J) {
-      float colv[4];
+      double colv[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) epi.load_col(J * kTileRows + n * 32 + lc, nB, colv[n]);
       for (uint32_t panel = 0; panel < panels; ++panel) {
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
 #pragma unroll
           for (int m = 0; m < MW; ++m) {
             // thresholds / row data of this lane's 16 rows of group m (LDS, 2 addresses per read)
-            float thr[16], rowv[16];
+            float thr[16];
+            double rowv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int rl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
 
 static size_t lds_bytes_f32(uint32_t KC, int CPB) {
   return (size_t)2 * kUnitFloats * CPB * sizeof(float) + (size_t)4 * 64 * KC * (sizeof(float) + sizeof(uint32_t)) +
-         (size_t)4 * kQueueCap * (sizeof(float) + 2 * sizeof(uint32_t)) + kRows32 * sizeof(float);
+         (size_t)4 * kQueueCap * (sizeof(float) + 2 * sizeof(uint32_t)) + kRows32 * sizeof(double);
 }
 
 bool fits_f32(uint32_t KC) { return lds_bytes_f32(KC, 1) <= 160 * 1024; }
@@ -426,7 +429,7 @@ int candidates_f32(as_ctx *ctx, const CandProblem &pb, const float *PA, uint32_t
   if (pb.mode == 0)
     return launch_f32<GraphEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels,
                                   GraphEpi32{}, pb.cand_key, pb.cand_idx, prof_name);
-  SearchEpi32 epi{pb.arows, pb.q_lambdas, pb.x_lambdas, (float)pb.alpha, (float)(1.0 - pb.alpha)};
+  SearchEpi32 epi{pb.arows, pb.q_lambdas, pb.x_lambdas, pb.alpha, 1.0 - pb.alpha};
   return launch_f32<SearchEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels, epi,
                                  pb.cand_key, pb.cand_idx, prof_name);
 }

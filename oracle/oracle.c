@@ -117,6 +117,45 @@ static int knn_core(const double *R, uint64_t n, uint64_t d, const aso_graph_par
   return ASO_OK;
 }
 
+/* the same neighbour rule for a list of rows only (sampled parity checks at full size) */
+int aso_knn_cosine_rows(const double *R, uint64_t n, uint64_t d, const aso_graph_params *p,
+                        const uint64_t *row_ids, uint64_t n_rows, uint64_t *nbr_idx, double *nbr_dist) {
+  if (n < 2 || d < 2) return ASO_ERR_SHAPE;
+  const uint64_t K = p->topk + 1;
+  double *norms = (double *)malloc(sizeof(double) * n);
+  if (!norms) return ASO_ERR_ALLOC;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) norms[i] = row_norm(R + (uint64_t)i * d, d);
+  const int rectify = p->rectify;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t rr = 0; rr < (int64_t)n_rows; ++rr) {
+    const uint64_t i = row_ids[rr];
+    uint64_t *bi = nbr_idx + (uint64_t)rr * K;
+    double *bd = nbr_dist + (uint64_t)rr * K;
+    uint64_t cnt = 0;
+    for (uint64_t j = 0; j < n; ++j) {
+      if (j == i) continue;
+      double dist = graph_distance(row_dot(R + i * d, R + j * d, d), norms[i], norms[j], rectify);
+      if (cnt == K && !(dist < bd[K - 1])) continue;
+      uint64_t pos = cnt < K ? cnt : K - 1;
+      while (pos > 0 && dist < bd[pos - 1]) {
+        bd[pos] = bd[pos - 1];
+        bi[pos] = bi[pos - 1];
+        --pos;
+      }
+      bd[pos] = dist;
+      bi[pos] = j;
+      if (cnt < K) ++cnt;
+    }
+    for (uint64_t s = cnt; s < K; ++s) {
+      bi[s] = UINT64_MAX;
+      bd[s] = INFINITY;
+    }
+  }
+  free(norms);
+  return ASO_OK;
+}
+
 int aso_knn_cosine(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
                    uint64_t *nbr_idx, double *nbr_dist) {
   if (n < 2 || d < 2) return ASO_ERR_SHAPE;

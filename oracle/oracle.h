@@ -70,6 +70,10 @@ uint64_t aso_define_result_k(uint64_t k, uint64_t topk);
 int aso_knn_cosine(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
                    uint64_t *nbr_idx, double *nbr_dist);
 
+/* the same rule for a list of rows (row_ids[n_rows]); outputs are n_rows x (topk+1) */
+int aso_knn_cosine_rows(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
+                        const uint64_t *row_ids, uint64_t n_rows, uint64_t *nbr_idx, double *nbr_dist);
+
 /* laplacian.rs:122-417: rows are nodes (row-major n x d) -> n x n CSR Laplacian */
 int aso_build_laplacian(const double *rows, uint64_t n, uint64_t d, const aso_graph_params *p,
                         aso_csr *out);

@@ -73,6 +73,7 @@ def lib():
         L.aso_define_result_k.restype = C.c_uint64
         L.aso_define_result_k.argtypes = [C.c_uint64, C.c_uint64]
         L.aso_knn_cosine.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), up, dp]
+        L.aso_knn_cosine_rows.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), up, C.c_uint64, up, dp]
         L.aso_build_laplacian.argtypes = [dp, C.c_uint64, C.c_uint64, C.POINTER(GraphParams), C.POINTER(Csr)]
         L.aso_laplacian_from_knn.argtypes = [up, dp, C.c_uint64, C.POINTER(GraphParams), C.POINTER(Csr)]
         L.aso_csr_free.argtypes = [C.POINTER(Csr)]
@@ -132,6 +133,19 @@ def knn_cosine(rows, params):
     idx = np.empty((n, K), dtype=np.uint64)
     dist = np.empty((n, K), dtype=np.float64)
     rc = lib().aso_knn_cosine(_dp(rows), n, d, C.byref(params), _up(idx), _dp(dist))
+    if rc:
+        raise OracleError(rc)
+    return idx, dist
+
+
+def knn_cosine_rows(rows, params, row_ids):
+    rows = _f64(rows)
+    n, d = rows.shape
+    ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
+    K = params.topk + 1
+    idx = np.empty((len(ids), K), dtype=np.uint64)
+    dist = np.empty((len(ids), K), dtype=np.float64)
+    rc = lib().aso_knn_cosine_rows(_dp(rows), n, d, C.byref(params), _up(ids), len(ids), _up(idx), _dp(dist))
     if rc:
         raise OracleError(rc)
     return idx, dist

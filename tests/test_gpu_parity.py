@@ -327,3 +327,76 @@ def test_repeated_small_calls_are_stable(ctx, proteins):
             res = asp.search_lambda_aware(A.ArrowItem(proteins[j] * 1.02, 0.3 + 0.01 * j), 3, 0.7)
             assert [r[0] for r in res] == oi.tolist(), (rep, j)
             assert np.array_equal([r[1] for r in res], osc), (rep, j)
+
+
+# ---- full-size checks: sampled rows against the oracle + size-independent properties ---------
+
+@pytest.mark.parametrize("n,d", [(200_000, 128), (60_000, 384)])
+def test_large_item_graph_sampled_parity_and_invariants(ctx, n, d):
+    """At sizes the oracle cannot finish, (a) a random sample of rows must match the oracle's
+    neighbour rows bit for bit, (b) the CSR must satisfy the reference's invariants
+    (src/tests/test_laplacian.rs:51-152): symmetric, zero row sums, sorted unique columns,
+    explicit diagonal, non-positive off-diagonals, nnz bound."""
+    import torch
+    X, _ = synth.mixture(n, d, seed=42)
+    Xd = torch.from_numpy(X).cuda()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    K = gp.topk + 1
+    import ctypes as C
+    idx = torch.empty((n, K), dtype=torch.int64, device="cuda")
+    dst = torch.empty((n, K), dtype=torch.float64, device="cuda")
+    A.api._adopt_torch_stream(ctx)
+    c = gp.to_c()
+    ctx.check(ctx.lib.as_knn_cosine(ctx.h, Xd.data_ptr(), n, d, 0, n, C.byref(c), idx.data_ptr(), dst.data_ptr()))
+    torch.cuda.synchronize()
+    assert ctx.stat("knn_cand_capacity") > 0  # the MFMA path ran
+    rng = np.random.default_rng(1)
+    sample = np.sort(rng.choice(n, size=96, replace=False))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    gi = idx[torch.from_numpy(sample).cuda()].cpu().numpy().astype(np.uint64)
+    gd = dst[torch.from_numpy(sample).cuda()].cpu().numpy()
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gd, od)
+    # neighbour rows are ordered by (distance, index) and exclude self
+    dd = dst.cpu().numpy()
+    ii = idx.cpu().numpy()
+    assert np.all(np.diff(dd, axis=1) >= 0)
+    assert not np.any(ii == np.arange(n)[:, None])
+    # CSR invariants on the full graph
+    csr = A.laplacian_from_knn(idx, dst, gp, ctx=ctx)
+    indptr, indices, data = csr.to_host()
+    assert indptr[-1] == len(indices) == len(data) and len(data) <= n * (2 * K + 1)
+    rows_of = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+    cols = indices.astype(np.int64)
+    assert np.all((np.diff(cols) > 0) | (np.diff(rows_of) > 0))          # sorted, unique per row
+    diag = cols == rows_of
+    assert diag.sum() == n                                                 # explicit diagonal everywhere
+    assert np.all(data[~diag] <= 0) and np.all(data[diag] >= 0)
+    row_sum = np.bincount(rows_of, weights=data, minlength=n)
+    assert np.max(np.abs(row_sum)) < 1e-12
+    # symmetry: the multiset of (min, max, value) must pair up
+    off = ~diag
+    key = np.minimum(rows_of[off], cols[off]) * n + np.maximum(rows_of[off], cols[off])
+    order = np.argsort(key, kind="stable")
+    k_sorted, v_sorted = key[order], data[off][order]
+    assert len(k_sorted) % 2 == 0 and np.array_equal(k_sorted[0::2], k_sorted[1::2])
+    assert np.array_equal(v_sorted[0::2], v_sorted[1::2])
+
+
+def test_large_search_sampled_parity(ctx):
+    """1e5 items x 128, 2000 queries through the MFMA path; 40 sampled queries against the oracle."""
+    import torch
+    n, d, nq = 100_000, 128, 2000
+    X, cent = synth.mixture(n, d, seed=42)
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(torch.from_numpy(X).cuda(), cent)
+    lam = asp.lambdas().cpu().numpy()
+    qi = synth.query_indices(n, nq, seed=3)
+    Q = X[qi] * 1.02
+    lq = asp.prepare_query_items(Q, gl)
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
+    assert ctx.stat("search_cand_capacity") > 0
+    for j in range(0, nq, 50):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 10, 0.7)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+    assert np.all(np.diff(sc, axis=1) <= 0)
