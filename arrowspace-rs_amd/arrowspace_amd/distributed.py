@@ -82,6 +82,30 @@ def _world():
     return 0, 1
 
 
+def _host_staged():
+    """gloo cannot move HBM tensors: stage through the host (test configurations only; the bench
+    runs on "nccl" = RCCL, device to device over xGMI)."""
+    return dist.get_backend() == "gloo"
+
+
+def _all_gather_into(out, inp):
+    if inp.is_cuda and _host_staged():
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp.contiguous())
+
+
+def _all_reduce(t, op):
+    if t.is_cuda and _host_staged():
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def all_gather_rows(t, sizes):
     """all-gather of row blocks with (possibly) unequal row counts; `sizes` = rows per rank."""
     rank, world = _world()
@@ -93,7 +117,7 @@ def all_gather_rows(t, sizes):
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
     out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    _all_gather_into(out, pad)
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
@@ -131,9 +155,9 @@ class ShardedArrowSpace:
             torch.tensor([float("inf"), float("inf"), 0.0], dtype=torch.float64, device=lam.device)
         if self.world > 1:                                                # logged stats, builder.rs:434-445
             mm = stats[:2].clone()
-            dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+            _all_reduce(mm, dist.ReduceOp.MIN)
             sm = stats[2:].clone()
-            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            _all_reduce(sm, dist.ReduceOp.SUM)
             stats = torch.cat([mm, sm])
         self.lambda_stats = (float(stats[0]), float(-stats[1]), float(stats[2]) / self.n)
         self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo)
@@ -151,15 +175,15 @@ class ShardedArrowSpace:
             return idx, sc
         nq, kk = idx.shape
         kmax = torch.tensor([kk], dtype=torch.int64, device=idx.device)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        _all_reduce(kmax, dist.ReduceOp.MAX)
         kmax = int(kmax)
         if kk < kmax:  # a shard smaller than k returns fewer columns
             idx = torch.cat([idx, torch.full((nq, kmax - kk), I64_NONE, dtype=idx.dtype, device=idx.device)], 1)
             sc = torch.cat([sc, torch.full((nq, kmax - kk), float("-inf"), dtype=sc.dtype, device=sc.device)], 1)
         gi = torch.empty((self.world * nq, kmax), dtype=idx.dtype, device=idx.device)
         gs = torch.empty((self.world * nq, kmax), dtype=sc.dtype, device=sc.device)
-        dist.all_gather_into_tensor(gi, idx.contiguous())                 # RCCL all-gather #3
-        dist.all_gather_into_tensor(gs, sc.contiguous())
+        _all_gather_into(gi, idx)                                         # RCCL all-gather #3
+        _all_gather_into(gs, sc)
         return merge_topk(gi.view(self.world, nq, kmax), gs.view(self.world, nq, kmax), min(k, self.n))
 
 
