@@ -424,6 +424,35 @@ class ArrowSpace:
                                                  ptr(idx), ptr(sc)))
         return idx, sc
 
+    def search_lambda_aware_hybrid(self, query, k, alpha):
+        """src/core.rs:802-928: lambda-aware top-k united with the near-exact cosine matches."""
+        if k == 0:
+            return []
+        lib, ctx = self.ctx.lib, self.ctx
+        ix = self._ensure_index()
+        Q = np.ascontiguousarray(np.asarray(query.item, dtype=np.float64).reshape(1, -1))
+        QL = np.array([query.lambda_], dtype=np.float64)
+        idx = np.empty((1, k), dtype=np.uint64)
+        sc = np.empty((1, k), dtype=np.float64)
+        ctx.check(lib.as_search_lambda_aware_hybrid(ctx.h, ix, ptr(Q), ptr(QL), 1, int(k), float(alpha), self.id_offset,
+                                                    ptr(idx), ptr(sc)))
+        return [(int(i), float(s)) for i, s in zip(idx[0], sc[0]) if int(i) != U64_MAX]
+
+    def range_search(self, query, gl, eps):
+        """src/core.rs:944-976: items with query.lambda - lambda_i <= eps, in index order."""
+        lq = query.lambda_
+        if abs(lq) <= 1e-9:  # relative_eq!(query.lambda, 0.0, epsilon = 1e-9): prepare it first
+            lq = self.prepare_query_item(query.item, gl)
+        lib, ctx = self.ctx.lib, self.ctx
+        ix = self._ensure_index()
+        idx = np.empty(self.nitems, dtype=np.uint64)
+        dist = np.empty(self.nitems, dtype=np.float64)
+        found = C.c_uint64()
+        ctx.check(lib.as_range_search(ctx.h, ix, float(lq), float(eps), self.id_offset, ptr(idx), ptr(dist), self.nitems,
+                                      C.byref(found)))
+        m = int(found.value)
+        return [(int(i), float(d)) for i, d in zip(idx[:m], dist[:m])]
+
     def search(self, item, gl, k, alpha):
         """EigenMaps::search (src/eigenmaps.rs:410-455): prepare + search in one call."""
         lam = self.prepare_query_item(item, gl)

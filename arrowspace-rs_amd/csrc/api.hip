@@ -26,6 +26,78 @@ __global__ void any_zero_kernel(const double *__restrict__ v, uint64_t n, int *f
   if (i < n && v[i] == 0.0) atomicOr(flag, 1);
 }
 
+// search_lambda_aware_hybrid merge (src/core.rs:888-923), one thread per query.
+// A = cosine top-k (key = -cos), B = lambda-aware top-k (key = -score); both sorted (key asc, idx asc).
+__global__ void hybrid_merge_kernel(const uint32_t *__restrict__ a_idx, const double *__restrict__ a_key,
+                                    const uint32_t *__restrict__ b_idx, const double *__restrict__ b_key, uint64_t nq,
+                                    uint32_t kk, uint32_t k_out, uint64_t id_offset, uint64_t *__restrict__ out_idx,
+                                    double *__restrict__ out_score) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t ui[129];
+  double us[129];
+  uint32_t m = 0;
+  const uint32_t *ai = a_idx + q * kk, *bi = b_idx + q * kk;
+  const double *ak = a_key + q * kk, *bk = b_key + q * kk;
+  // (a) high semantic matches: cosine > 0.9999 (only the best k of them can reach the output)
+  for (uint32_t t = 0; t < kk; ++t)
+    if (ai[t] != kNoIdx && -ak[t] > 0.9999) {
+      ui[m] = ai[t];
+      us[m++] = -ak[t];
+    }
+  // (b) lambda-aware top-k, score kept if the item is already present
+  for (uint32_t t = 0; t < kk; ++t) {
+    if (bi[t] == kNoIdx) continue;
+    bool present = false;
+    for (uint32_t u = 0; u < m; ++u) present |= ui[u] == bi[t];
+    if (!present) {
+      ui[m] = bi[t];
+      us[m++] = -bk[t];
+    }
+  }
+  // (c) the best-cosine item
+  if (kk > 0 && ai[0] != kNoIdx) {
+    bool present = false;
+    for (uint32_t u = 0; u < m; ++u) present |= ui[u] == ai[0];
+    if (!present) {
+      ui[m] = ai[0];
+      us[m++] = -ak[0];
+    }
+  }
+  // sort by (score desc, idx asc), truncate
+  for (uint32_t a = 1; a < m; ++a) {
+    const uint32_t ti = ui[a];
+    const double ts = us[a];
+    uint32_t b = a;
+    while (b > 0 && (us[b - 1] < ts || (us[b - 1] == ts && ui[b - 1] > ti))) {
+      ui[b] = ui[b - 1];
+      us[b] = us[b - 1];
+      --b;
+    }
+    ui[b] = ti;
+    us[b] = ts;
+  }
+  for (uint32_t t = 0; t < k_out; ++t) {
+    out_idx[q * k_out + t] = t < m ? (uint64_t)ui[t] + id_offset : ~0ull;
+    out_score[q * k_out + t] = t < m ? us[t] : -__builtin_inf();
+  }
+}
+
+__global__ void range_flag_kernel(const double *__restrict__ lambdas, uint64_t n, double lq, double eps,
+                                  uint32_t *__restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (lq - lambdas[i]) <= eps ? 1u : 0u;
+}
+__global__ void range_scatter_kernel(const double *__restrict__ lambdas, uint64_t n, double lq,
+                                     const uint32_t *__restrict__ flags, const uint64_t *__restrict__ pos, uint64_t cap,
+                                     uint64_t id_offset, uint64_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i] && pos[i] < cap) {
+    out_idx[pos[i]] = i + id_offset;
+    out_dist[pos[i]] = lq - lambdas[i];
+  }
+}
+
 int check_ctx(as_ctx *ctx) {
   if (!ctx) return AS_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AS_ERR_HIP, "hipSetDevice failed");
@@ -402,6 +474,14 @@ void as_index_destroy(as_index *ix) {
 
 uint64_t as_index_nitems(const as_index *ix) { return ix ? ix->n : 0; }
 
+// core: device queries/lambdas -> internal (u32 idx, key = -score) tables, nq x k
+static int search_core(as_ctx *ctx, const as_index *index, const double *Q, const double *qn, const double *QL,
+                       uint64_t nq, uint32_t kk, double alpha, uint32_t *idx32, double *keys) {
+  if (ctx->opt_search_mfma && kk <= 64)
+    return search_mfma(ctx, const_cast<as_index *>(index), Q, qn, QL, nq, kk, alpha, idx32, keys);
+  return search_exact(ctx, index, Q, qn, QL, nullptr, nq, nq, kk, alpha, idx32, keys);
+}
+
 int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *queries, const double *q_lambdas,
                            uint64_t nq, uint64_t k, double alpha, uint64_t id_offset, uint64_t *idx_out,
                            double *score_out) {
@@ -421,7 +501,6 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
   hipLaunchKernelGGL(any_zero_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, ctx->stream, QL.p, nq, flag.p);
   int h = 0;
   AS_HIP(ctx, copy_d2h(ctx, &h, flag.p, sizeof(int)));
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h) return fail(ctx, AS_ERR_ZERO_LAMBDA, as_status_message(AS_ERR_ZERO_LAMBDA));
 
   const uint32_t kk = (uint32_t)k;
@@ -431,10 +510,7 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
   AS_TRY(keys.alloc(ctx, nq * kk));
   AS_TRY(idx32.alloc(ctx, nq * kk));
   AS_TRY(row_norms(ctx, Q.p, nq, d, qn.p));
-  if (ctx->opt_search_mfma && kk <= 64)
-    AS_TRY(search_mfma(ctx, const_cast<as_index *>(index), Q.p, qn.p, QL.p, nq, kk, alpha, idx32.p, keys.p));
-  else
-    AS_TRY(search_exact(ctx, index, Q.p, qn.p, QL.p, nullptr, nq, nq, kk, alpha, idx32.p, keys.p));
+  AS_TRY(search_core(ctx, index, Q.p, qn.p, QL.p, nq, kk, alpha, idx32.p, keys.p));
   DevOut<double> S;
   DevOut<uint64_t> I;
   AS_TRY(S.bind(ctx, score_out, nq * kk));
@@ -444,6 +520,71 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
                      id_offset, I.p);
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(S.finish(ctx));
+  AS_TRY(I.finish(ctx));
+  return AS_OK;
+}
+
+int as_search_lambda_aware_hybrid(as_ctx *ctx, const as_index *index, const double *queries,
+                                  const double *q_lambdas, uint64_t nq, uint64_t k, double alpha, uint64_t id_offset,
+                                  uint64_t *idx_out, double *score_out) {
+  AS_TRY(check_ctx(ctx));
+  if (!index || (nq && (!queries || !q_lambdas))) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (nq == 0 || k == 0) return AS_OK;  // src/core.rs:811-813
+  if (!idx_out || !score_out) return fail(ctx, AS_ERR_ARG, "null output");
+  if (k > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "hybrid search supports k <= 64");
+  const uint64_t d = index->d;
+  const uint32_t kk = (uint32_t)std::min<uint64_t>(k, index->n);
+  DevIn<double> Q, QL;
+  AS_TRY(Q.bind(ctx, queries, nq * d));
+  AS_TRY(QL.bind(ctx, q_lambdas, nq));
+  DevBuf<double> qn, kb, ka;
+  DevBuf<uint32_t> ib, ia;
+  AS_TRY(qn.alloc(ctx, nq));
+  AS_TRY(kb.alloc(ctx, nq * kk));
+  AS_TRY(ka.alloc(ctx, nq * kk));
+  AS_TRY(ib.alloc(ctx, nq * kk));
+  AS_TRY(ia.alloc(ctx, nq * kk));
+  AS_TRY(row_norms(ctx, Q.p, nq, d, qn.p));
+  AS_TRY(search_core(ctx, index, Q.p, qn.p, QL.p, nq, kk, alpha, ib.p, kb.p));  // lambda-aware top-k
+  AS_TRY(search_core(ctx, index, Q.p, qn.p, QL.p, nq, kk, 1.0, ia.p, ka.p));    // alpha = 1: score == cosine exactly
+  DevOut<double> S;
+  DevOut<uint64_t> I;
+  AS_TRY(S.bind(ctx, score_out, nq * k));
+  AS_TRY(I.bind(ctx, idx_out, nq * k));
+  hipLaunchKernelGGL(hybrid_merge_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, ia.p, ka.p, ib.p, kb.p, nq,
+                     kk, (uint32_t)k, id_offset, I.p, S.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(S.finish(ctx));
+  AS_TRY(I.finish(ctx));
+  return AS_OK;
+}
+
+int as_range_search(as_ctx *ctx, const as_index *index, double lambda_q, double eps, uint64_t id_offset,
+                    uint64_t *idx_out, double *dist_out, uint64_t cap, uint64_t *n_found) {
+  AS_TRY(check_ctx(ctx));
+  if (!index || !n_found) return fail(ctx, AS_ERR_ARG, "null argument");
+  const uint64_t n = index->n;
+  DevBuf<uint32_t> flags;
+  DevBuf<uint64_t> pos;
+  AS_TRY(flags.alloc(ctx, n));
+  AS_TRY(pos.alloc(ctx, n + 1));
+  hipLaunchKernelGGL(range_flag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, index->lambdas, n, lambda_q, eps,
+                     flags.p);
+  AS_TRY(exclusive_scan_u32_u64(ctx, flags.p, n, pos.p));
+  uint64_t found = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &found, pos.p + n, sizeof(uint64_t)));
+  *n_found = found;
+  const uint64_t m = std::min<uint64_t>(found, cap);
+  if (m == 0) return AS_OK;
+  if (!idx_out || !dist_out) return fail(ctx, AS_ERR_ARG, "null output");
+  DevOut<double> D;
+  DevOut<uint64_t> I;
+  AS_TRY(D.bind(ctx, dist_out, m));
+  AS_TRY(I.bind(ctx, idx_out, m));
+  hipLaunchKernelGGL(range_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, index->lambdas, n, lambda_q,
+                     flags.p, pos.p, m, id_offset, I.p, D.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(D.finish(ctx));
   AS_TRY(I.finish(ctx));
   return AS_OK;
 }

@@ -17,6 +17,7 @@
 // std::vector<double> rows.  No CPU fallback exists.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <optional>
@@ -273,9 +274,7 @@ class ArrowSpace {
   // src/core.rs:760-798
   std::vector<std::pair<std::size_t, double>> search_lambda_aware(const ArrowItem &query, std::size_t k, double alpha) {
     if (query.len() != nfeatures) throw Panic(AS_ERR_DIM, "items should be of the same length");
-    if (lambdas_.empty()) throw Panic(AS_ERR_ARG, "call compute_taumode(...) before search");  // eigenmaps.rs:425-431
-    if (!index_)
-      ctx_->check(as_index_create(ctx_->get(), data_.data(), lambdas_.data(), nitems, nfeatures, &index_));
+    ensure_index();
     const std::size_t kk = k < nitems ? k : nitems;
     std::vector<uint64_t> idx(kk ? kk : 1);
     std::vector<double> sc(kk ? kk : 1);
@@ -286,6 +285,33 @@ class ArrowSpace {
       if (idx[i] != UINT64_MAX) out.emplace_back(idx[i], sc[i]);
     return out;
   }
+  // src/core.rs:802-928
+  std::vector<std::pair<std::size_t, double>> search_lambda_aware_hybrid(const ArrowItem &query, std::size_t k,
+                                                                          double alpha) {
+    if (k == 0) return {};
+    ensure_index();
+    std::vector<uint64_t> idx(k);
+    std::vector<double> sc(k);
+    ctx_->check(as_search_lambda_aware_hybrid(ctx_->get(), index_, query.item.data(), &query.lambda, 1, k, alpha, 0,
+                                              idx.data(), sc.data()));
+    std::vector<std::pair<std::size_t, double>> out;
+    for (std::size_t i = 0; i < k; ++i)
+      if (idx[i] != UINT64_MAX) out.emplace_back(idx[i], sc[i]);
+    return out;
+  }
+  // src/core.rs:944-976
+  std::vector<std::pair<std::size_t, double>> range_search(const ArrowItem &query, const GraphLaplacian &gl, double eps) {
+    double lq = query.lambda;
+    if (std::fabs(lq) <= 1e-9) lq = prepare_query_item(query.item, gl);  // relative_eq!(lambda, 0.0, epsilon = 1e-9)
+    ensure_index();
+    std::vector<uint64_t> idx(nitems);
+    std::vector<double> dist(nitems);
+    uint64_t found = 0;
+    ctx_->check(as_range_search(ctx_->get(), index_, lq, eps, 0, idx.data(), dist.data(), nitems, &found));
+    std::vector<std::pair<std::size_t, double>> out;
+    for (uint64_t i = 0; i < found; ++i) out.emplace_back(idx[i], dist[i]);
+    return out;
+  }
   // EigenMaps::search, src/eigenmaps.rs:410-455
   std::vector<std::pair<std::size_t, double>> search(const std::vector<double> &item, const GraphLaplacian &gl,
                                                      std::size_t k, double alpha) {
@@ -293,6 +319,11 @@ class ArrowSpace {
   }
 
  private:
+  void ensure_index() {
+    if (lambdas_.empty()) throw Panic(AS_ERR_ARG, "call compute_taumode(...) before search");  // eigenmaps.rs:425-431
+    if (!index_)
+      ctx_->check(as_index_create(ctx_->get(), data_.data(), lambdas_.data(), nitems, nfeatures, &index_));
+  }
   std::shared_ptr<Context> ctx_;
   std::vector<double> data_, lambdas_;
   as_index *index_ = nullptr;

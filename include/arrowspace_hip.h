@@ -154,6 +154,20 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
                            const double *q_lambdas, uint64_t nq, uint64_t k, double alpha,
                            uint64_t id_offset, uint64_t *idx_out, double *score_out);
 
+/* Batched ArrowSpace::search_lambda_aware_hybrid, src/core.rs:802-928: per query the union of
+ * (a) every item with cosine > 0.9999 (score = cosine), (b) the lambda-aware top-k (blended score
+ * unless already in (a)), (c) the best-cosine item; sorted by score descending (ties: lower index),
+ * truncated to k.  No zero-lambda check (the reference has none here).  k <= 64. */
+int as_search_lambda_aware_hybrid(as_ctx *ctx, const as_index *index, const double *queries,
+                                  const double *q_lambdas, uint64_t nq, uint64_t k, double alpha,
+                                  uint64_t id_offset, uint64_t *idx_out, double *score_out);
+
+/* ArrowSpace::range_search with a prepared query lambda, src/core.rs:944-976: every item with
+ * lambda_q - lambda_i <= eps, in index order, with that signed difference.  Writes the first
+ * min(cap, found) hits and the total count to *n_found (host pointer). */
+int as_range_search(as_ctx *ctx, const as_index *index, double lambda_q, double eps, uint64_t id_offset,
+                    uint64_t *idx_out, double *dist_out, uint64_t cap, uint64_t *n_found);
+
 #ifdef __cplusplus
 }
 #endif

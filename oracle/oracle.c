@@ -501,3 +501,93 @@ int64_t aso_search_lambda_aware(const double *items, const double *lambdas, uint
   }
   return (int64_t)kk;
 }
+
+/* src/core.rs:802-928 search_lambda_aware_hybrid.  Union of (a) every item with cosine > 0.9999
+ * (score = cosine), (b) the lambda-aware top-k (score = blended, unless already in (a)), (c) the
+ * best-cosine item (score = cosine unless already present); sorted by score descending
+ * (reference: sort_unstable_by, ties unspecified; oracle: index ascending), truncated to k.
+ * Returns the number of results written. */
+typedef struct {
+  uint64_t idx;
+  double score;
+} hyb_t;
+static int hyb_cmp(const void *a, const void *b) {
+  const hyb_t *x = (const hyb_t *)a, *y = (const hyb_t *)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+int64_t aso_search_lambda_aware_hybrid(const double *items, const double *lambdas, uint64_t n_items,
+                                       uint64_t d, const double *q, double lambda_q, uint64_t k,
+                                       double alpha, uint64_t *idx_out, double *score_out) {
+  if (k == 0 || n_items == 0) return 0;
+  const double beta = 1.0 - alpha;
+  const double qn = row_norm(q, d);
+  hyb_t *all = (hyb_t *)malloc(sizeof(hyb_t) * n_items);   /* blended score of everything */
+  double *cosv = (double *)malloc(sizeof(double) * n_items);
+  if (!all || !cosv) return ASO_ERR_ALLOC;
+  uint64_t sem_top = 0;
+  double sem_best = -INFINITY;
+  for (uint64_t i = 0; i < n_items; ++i) {
+    const double denom = qn * row_norm(items + i * d, d);
+    const double c = denom > 0.0 ? row_dot(q, items + i * d, d) / denom : 0.0; /* :229-239 */
+    const double diff = fabs(lambda_q - lambdas[i]);
+    const double lam = 1.0 - (diff < 1.0 ? diff : 1.0);
+    cosv[i] = c;
+    all[i].idx = i;
+    all[i].score = alpha * c + beta * lam; /* :830-832 */
+    if (c > sem_best) {                     /* :835-837 strict: first index of the maximum */
+      sem_best = c;
+      sem_top = i;
+    }
+  }
+  /* lambda top-k by (score desc, idx asc) */
+  qsort(all, n_items, sizeof(hyb_t), hyb_cmp);
+  const uint64_t kk = k < n_items ? k : n_items;
+  /* union */
+  hyb_t *u = (hyb_t *)malloc(sizeof(hyb_t) * (n_items + kk + 1));
+  char *in = (char *)calloc(n_items, 1);
+  if (!u || !in) return ASO_ERR_ALLOC;
+  uint64_t m = 0;
+  for (uint64_t i = 0; i < n_items; ++i)
+    if (cosv[i] > 0.9999) { /* :840-842 */
+      u[m].idx = i;
+      u[m++].score = cosv[i];
+      in[i] = 1;
+    }
+  for (uint64_t t = 0; t < kk; ++t)
+    if (!in[all[t].idx]) {
+      u[m++] = all[t];
+      in[all[t].idx] = 1;
+    }
+  if (!in[sem_top]) {
+    u[m].idx = sem_top;
+    u[m++].score = sem_best;
+  }
+  qsort(u, m, sizeof(hyb_t), hyb_cmp);
+  const uint64_t r = m < k ? m : k;
+  for (uint64_t t = 0; t < r; ++t) {
+    idx_out[t] = u[t].idx;
+    score_out[t] = u[t].score;
+  }
+  free(all);
+  free(cosv);
+  free(u);
+  free(in);
+  return (int64_t)r;
+}
+
+/* src/core.rs:944-976 range_search (query lambda already prepared): every item with
+ * lambda_q - lambda_i <= eps, in index order, with that signed difference. */
+int64_t aso_range_search(const double *lambdas, uint64_t n_items, double lambda_q, double eps,
+                         uint64_t *idx_out, double *dist_out) {
+  uint64_t m = 0;
+  for (uint64_t i = 0; i < n_items; ++i) {
+    const double dist = lambda_q - lambdas[i];
+    if (dist <= eps) {
+      idx_out[m] = i;
+      dist_out[m++] = dist;
+    }
+  }
+  return (int64_t)m;
+}

@@ -106,6 +106,15 @@ int64_t aso_search_lambda_aware(const double *items, const double *lambdas, uint
                                 uint64_t d, const double *q, double lambda_q, uint64_t k,
                                 double alpha, uint64_t *idx_out, double *score_out);
 
+/* core.rs:802-928; up to k results (the union can be smaller than k only when n_items < k) */
+int64_t aso_search_lambda_aware_hybrid(const double *items, const double *lambdas, uint64_t n_items,
+                                       uint64_t d, const double *q, double lambda_q, uint64_t k,
+                                       double alpha, uint64_t *idx_out, double *score_out);
+
+/* core.rs:944-976 with a prepared query lambda; outputs must hold n_items entries */
+int64_t aso_range_search(const double *lambdas, uint64_t n_items, double lambda_q, double eps,
+                         uint64_t *idx_out, double *dist_out);
+
 /* threads used by the OpenMP loops (for the cpu_baseline report) */
 int aso_num_threads(void);
 

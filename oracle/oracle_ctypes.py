@@ -87,6 +87,10 @@ def lib():
         L.aso_lambda_similarity.argtypes = [dp, C.c_double, dp, C.c_double, C.c_uint64, C.c_double]
         L.aso_search_lambda_aware.restype = C.c_int64
         L.aso_search_lambda_aware.argtypes = [dp, dp, C.c_uint64, C.c_uint64, dp, C.c_double, C.c_uint64, C.c_double, up, dp]
+        L.aso_search_lambda_aware_hybrid.restype = C.c_int64
+        L.aso_search_lambda_aware_hybrid.argtypes = [dp, dp, C.c_uint64, C.c_uint64, dp, C.c_double, C.c_uint64, C.c_double, up, dp]
+        L.aso_range_search.restype = C.c_int64
+        L.aso_range_search.argtypes = [dp, C.c_uint64, C.c_double, C.c_double, up, dp]
         L.aso_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -234,6 +238,25 @@ def search_lambda_aware(items, lambdas, q, lambda_q, k, alpha):
     if rc < 0:
         raise OracleError(int(rc))
     return idx[:rc].copy(), sc[:rc].copy()
+
+
+def search_lambda_aware_hybrid(items, lambdas, q, lambda_q, k, alpha):
+    items, lambdas, q = _f64(items), _f64(lambdas).ravel(), _f64(q).ravel()
+    n, d = items.shape
+    idx = np.empty(max(k, 1), dtype=np.uint64)
+    sc = np.empty(max(k, 1), dtype=np.float64)
+    rc = lib().aso_search_lambda_aware_hybrid(_dp(items), _dp(lambdas), n, d, _dp(q), lambda_q, k, alpha, _up(idx), _dp(sc))
+    if rc < 0:
+        raise OracleError(int(rc))
+    return idx[:rc].copy(), sc[:rc].copy()
+
+
+def range_search(lambdas, lambda_q, eps):
+    lambdas = _f64(lambdas).ravel()
+    idx = np.empty(max(len(lambdas), 1), dtype=np.uint64)
+    dist = np.empty(max(len(lambdas), 1), dtype=np.float64)
+    rc = lib().aso_range_search(_dp(lambdas), len(lambdas), lambda_q, eps, _up(idx), _dp(dist))
+    return idx[:rc].copy(), dist[:rc].copy()
 
 
 def num_threads():

@@ -142,6 +142,13 @@ static void test_build_and_search() {  // src/tests/test_querying_proj.rs:30-72,
   for (std::size_t i = 0; i + 1 < res.size(); ++i) CHECK(res[i].second >= res[i + 1].second);
   auto res1 = aspace->search_lambda_aware(ArrowItem(q, lq), 1, 1.0);  // alpha = 1: pure cosine, scaled copy wins
   CHECK(res1.size() == 1 && res1[0].first % 7 == 3 && std::fabs(res1[0].second - 1.0) < 1e-12);
+  // hybrid (src/core.rs:802-928): the scaled copy of row 3 has cosine 1 with every row congruent to 3 mod 7
+  auto hy = aspace->search_lambda_aware_hybrid(ArrowItem(q, lq), 5, 0.7);
+  CHECK(hy.size() == 5 && hy[0].second >= hy[4].second && hy[0].second > 0.9999);
+  // range search (src/core.rs:944-976): eps large -> every item, in index order
+  auto rs = aspace->range_search(ArrowItem(q, lq), gl, 10.0);
+  CHECK(rs.size() == 300 && rs[0].first == 0 && rs[299].first == 299);
+  CHECK(std::fabs(rs[7].second - (lq - aspace->lambdas()[7])) == 0.0);
   // NaN query (src/tests/test_querying_proj.rs:277-291), wrong dimension (:262-275), zero lambda (core.rs:773-776)
   std::vector<double> bad = q;
   bad[2] = std::nan("");

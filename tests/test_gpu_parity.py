@@ -400,3 +400,36 @@ def test_large_search_sampled_parity(ctx):
         assert np.array_equal(idx[j], oi), j
         assert np.array_equal(sc[j], osc), j
     assert np.all(np.diff(sc, axis=1) <= 0)
+
+
+# ---- callers of the same index: hybrid and range search (src/core.rs:802-976) ------------------
+
+def test_hybrid_search_matches_oracle(ctx, mode):
+    X, _ = synth.mixture(1500, 48, seed=8, n_clusters=10, rank=4)
+    X = np.concatenate([X, X[:20] * 1.000001, X[:5]])  # near-duplicates -> cosine > 0.9999 matches
+    lam = np.linspace(0.02, 0.95, len(X))
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    for j, lq, k in ((3, 0.4, 5), (7, 0.11, 10), (700, 0.8, 3), (1, 0.0, 4)):
+        q = X[j] * 1.02
+        got = asp.search_lambda_aware_hybrid(A.ArrowItem(q, lq), k, 0.7)
+        oi, osc = O.search_lambda_aware_hybrid(X, lam, q, lq, k, 0.7)
+        assert [g[0] for g in got] == oi.tolist(), (j, k)
+        assert np.array_equal([g[1] for g in got], osc), (j, k)
+    assert asp.search_lambda_aware_hybrid(A.ArrowItem(X[0], 0.3), 0, 0.7) == []
+
+
+def test_range_search_matches_oracle(ctx, proteins):
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(proteins)
+    lam = np.asarray(asp.lambdas())
+    for lq, eps in ((0.3, 0.05), (0.9, 0.0), (0.01, -0.5), (0.5, 10.0)):
+        got = asp.range_search(A.ArrowItem(proteins[2], lq), gl, eps)
+        oi, od = O.range_search(lam, lq, eps)
+        assert [g[0] for g in got] == oi.tolist()
+        assert np.array_equal([g[1] for g in got], od)
+    # lambda == 0 -> the query is prepared first (core.rs:953-957)
+    q = proteins[5] * 1.02
+    lq = asp.prepare_query_item(q, gl)
+    got = asp.range_search(A.ArrowItem(q, 0.0), gl, 0.02)
+    oi, od = O.range_search(lam, lq, 0.02)
+    assert [g[0] for g in got] == oi.tolist()
