@@ -119,7 +119,6 @@ int validate_graph_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d,
                 "items should be at least of shape (2,2): (" + std::to_string(n) + "," + std::to_string(d) + ")");
   }
   if (n >= 0xFFFFFFFFull || d >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_nodes/dim must be < 2^32-1");
-  if (gp->normalise) return fail(ctx, AS_ERR_UNSUPPORTED, "normalise = true (StandardScaler) is not on the accelerated path");
   if (gp->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
   return AS_OK;
 }
@@ -270,6 +269,12 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
   const uint32_t K = (uint32_t)params->topk + 1;
   DevIn<double> R;
   AS_TRY(R.bind(ctx, rows, n_nodes * dim));
+  DevBuf<double> scaled;
+  if (params->normalise) {
+    AS_TRY(scaled.alloc(ctx, n_nodes * dim));
+    AS_TRY(standardise_rows(ctx, R.p, n_nodes, dim, scaled.p));
+    R.p = scaled.p;
+  }
   DevBuf<double> norms;
   AS_TRY(norms.alloc(ctx, n_nodes));
   AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
@@ -315,6 +320,12 @@ int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   const uint32_t K = (uint32_t)params->topk + 1;
   DevIn<double> R;
   AS_TRY(R.bind(ctx, rows, n_nodes * dim));
+  DevBuf<double> scaled;
+  if (params->normalise) {
+    AS_TRY(scaled.alloc(ctx, n_nodes * dim));
+    AS_TRY(standardise_rows(ctx, R.p, n_nodes, dim, scaled.p));
+    R.p = scaled.p;
+  }
   DevBuf<double> norms, dist;
   DevBuf<uint32_t> idx;
   AS_TRY(norms.alloc(ctx, n_nodes));

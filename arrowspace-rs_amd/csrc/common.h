@@ -287,6 +287,8 @@ inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b
 // ---- stage entry points implemented in the .hip files ---------------------------------------
 // exact arithmetic row norms: norms[i] = sqrt(sum_c x[i][c]^2), sequential (src/core.rs:212-216)
 int row_norms(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *norms);
+// StandardScaler z-score of every column (normalise = true, src/laplacian.rs:146-151)
+int standardise_rows(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out);
 
 struct KnnOut {
   uint32_t *idx;  // rows x K, kNoIdx when missing

@@ -17,6 +17,48 @@ __global__ void row_norms_kernel(const double *__restrict__ rows, uint64_t n, ui
   norms[i] = __dsqrt_rn(s);
 }
 
+// StandardScaler (src/laplacian.rs:146-151): per-column z-score.  smartcore's source is absent;
+// the oracle's convention is used (population variance, zero std -> 1; PARITY UNPINNED).  One thread
+// per column walks the rows in order (the sums are sequential, as the oracle's), lanes read
+// consecutive columns of a row: coalesced.
+__global__ void column_stats_kernel(const double *__restrict__ rows, uint64_t n, uint64_t d,
+                                    double *__restrict__ mean, double *__restrict__ sd) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  double m = 0.0;
+  for (uint64_t r = 0; r < n; ++r) m = __dadd_rn(m, rows[r * d + c]);
+  m = __ddiv_rn(m, (double)n);
+  double v = 0.0;
+  for (uint64_t r = 0; r < n; ++r) {
+    const double t = __dsub_rn(rows[r * d + c], m);
+    v = __dadd_rn(v, __dmul_rn(t, t));
+  }
+  double s = __dsqrt_rn(__ddiv_rn(v, (double)n));
+  if (s == 0.0) s = 1.0;
+  mean[c] = m;
+  sd[c] = s;
+}
+__global__ void standardise_kernel(const double *__restrict__ rows, uint64_t total, uint64_t d,
+                                   const double *__restrict__ mean, const double *__restrict__ sd,
+                                   double *__restrict__ out) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint64_t c = g % d;
+  out[g] = __ddiv_rn(__dsub_rn(rows[g], mean[c]), sd[c]);
+}
+
+int standardise_rows(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out) {
+  DevBuf<double> mean, sd;
+  AS_TRY(mean.alloc(ctx, d));
+  AS_TRY(sd.alloc(ctx, d));
+  ProfScope ps(ctx, "standardise");
+  hipLaunchKernelGGL(column_stats_kernel, dim3(cdiv(d, 64)), dim3(64), 0, ctx->stream, rows, n, d, mean.p, sd.p);
+  hipLaunchKernelGGL(standardise_kernel, dim3(cdiv(n * d, 256)), dim3(256), 0, ctx->stream, rows, n * d, d, mean.p, sd.p,
+                     out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 int row_norms(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *norms) {
   if (n == 0) return AS_OK;
   ProfScope ps(ctx, "row_norms");

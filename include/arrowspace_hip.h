@@ -42,7 +42,7 @@ typedef enum {
   AS_ERR_DIM = 5,         /* graph has more nodes than the signal has entries (src/taumode.rs:570-575 would index out of bounds); query dimension mismatch src/core.rs:510-516 */
   AS_ERR_TOO_SPARSE = 6,  /* "Resulting laplacian matrix is too sparse" src/graph.rs:185-193 */
   AS_ERR_ARG = 7,         /* null pointer / bad enum / unsupported size */
-  AS_ERR_UNSUPPORTED = 8, /* feature outside the accelerated path (e.g. normalise = true) */
+  AS_ERR_UNSUPPORTED = 8, /* outside the accelerated path (e.g. topk + 1 > 64, hybrid k > 64) */
   AS_ERR_HIP = 9,         /* HIP runtime failure; text in as_last_error */
   AS_ERR_NO_DEVICE = 10   /* no gfx950 device: there is no CPU fallback */
 } as_status;
@@ -58,7 +58,7 @@ typedef struct {
   double p;               /* kernel exponent */
   double sigma;           /* used when has_sigma != 0, else 1.0 (src/laplacian.rs:254) */
   int32_t has_sigma;      /* Option<f64> discriminant */
-  int32_t normalise;      /* must be 0 (StandardScaler path not accelerated) */
+  int32_t normalise;      /* 1: per-column z-score first (StandardScaler, src/laplacian.rs:146-151; population variance, zero std -> 1: smartcore's convention is unpinned) */
   int32_t sparsity_check; /* carried for the host-side GraphFactory check (src/graph.rs:185-193) */
   int32_t rectify;        /* 0: distance = 1 - cos (default).  1: 1 - max(0, cos) */
 } as_graph_params;

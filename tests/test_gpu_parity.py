@@ -433,3 +433,13 @@ def test_range_search_matches_oracle(ctx, proteins):
     got = asp.range_search(A.ArrowItem(q, 0.0), gl, 0.02)
     oi, od = O.range_search(lam, lq, 0.02)
     assert [g[0] for g in got] == oi.tolist()
+
+
+def test_normalise_true_matches_oracle(ctx, mode):
+    """normalise = true: StandardScaler z-score per column before the graph (src/laplacian.rs:146-151;
+    oracle convention: population variance, zero std -> 1 -- smartcore's own is unpinned)."""
+    X, _ = synth.mixture(900, 24, seed=6, n_clusters=6, rank=3)
+    X[:, 5] = 3.25  # constant column: std 0 -> 1
+    gp = A.GraphParams(0.6, 8, 8, 2.0, 0.5, normalise=True)
+    og = O.graph_params(0.6, 8, 8, 2.0, 0.5, normalise=True)
+    assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, og))
