@@ -207,6 +207,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
   else if (n == "debug") ctx->opt_debug = value;
   else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;
+  else if (n == "lambda_v3") ctx->opt_lambda_v3 = value;
   else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
@@ -388,6 +389,9 @@ void as_csr_free(as_csr *m) {
   (void)hipFree(m->data);
   if (m->packed) (void)hipFree(m->packed);
   if (m->packed_upper) (void)hipFree(m->packed_upper);
+  if (m->v3_ent) (void)hipFree(m->v3_ent);
+  if (m->v3_w) (void)hipFree(m->v3_w);
+  if (m->v3_diag) (void)hipFree(m->v3_diag);
   delete m;
 }
 

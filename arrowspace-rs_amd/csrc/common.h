@@ -44,6 +44,7 @@ struct as_ctx {
   int64_t opt_cand_slack = 8;     // extra candidates kept by the MFMA pass beyond topk+1
   int64_t opt_waves_per_simd = 2; // f32 candidate pass: 2 = 8 waves x 32 rows, 1 = 4 waves x 64 rows
   int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
+  int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // stats of the last call
@@ -65,6 +66,12 @@ struct as_csr {
   // upper-triangle stream (j >= i), present only when the matrix is bitwise symmetric
   void *packed_upper = nullptr;
   uint64_t nnz_upper = 0;
+  // entry streams of the n_features == 128 streaming kernel (taumode_v3.hip), built on first use
+  int v3_state = 0;  // 0: not prepared, 1: ready, -1: outside that kernel's domain
+  void *v3_ent = nullptr, *v3_w = nullptr, *v3_diag = nullptr;
+  uint32_t v3_steps = 0;
+  double v3_scale = 1.0;
+  int v3_negw = 0;  // every off-diagonal entry <= 0: w = -L_ij
 };
 
 struct as_index {
@@ -310,6 +317,8 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
 
 int taumode_lambdas(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as_csr *L,
                     int mode, double arg, bool check_finite, double *lambdas_out);
+int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as_csr *L, int mode,
+              double arg, bool check_finite, double *out, bool *handled);
 int select_tau_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode,
                     double arg, double *taus);
 

@@ -619,6 +619,11 @@ int taumode_lambdas(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t
                     double arg, bool check_finite, double *lambdas_out) {
   if (L->n > F) return fail(ctx, AS_ERR_DIM, "graph has more nodes than the items have features");
   AS_TRY(ensure_packed(ctx, L));
+  if (ctx->opt_lambda_v3) {
+    bool handled = false;
+    AS_TRY(lambda_v3(ctx, items, n_items, F, L, mode, arg, check_finite, lambdas_out, &handled));
+    if (handled) return AS_OK;
+  }
   return run_lambda(ctx, items, n_items, F, (const PackedEntry *)L->packed, L->nnz,
                     (const PackedEntry *)L->packed_upper, L->nnz_upper, mode, arg, check_finite, true, lambdas_out);
 }

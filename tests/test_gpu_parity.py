@@ -443,3 +443,116 @@ def test_normalise_true_matches_oracle(ctx, mode):
     gp = A.GraphParams(0.6, 8, 8, 2.0, 0.5, normalise=True)
     og = O.graph_params(0.6, 8, 8, 2.0, 0.5, normalise=True)
     assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, og))
+
+
+# ---- streaming lambda-tau kernel (n_features == 128, csrc/taumode_v3.hip) ---------------------------
+
+def _lambda_case(ctx, X, csr, tm, om, arg, check=None, rtol=LAMBDA_RTOL):
+    L = A.CsrMatrix.from_host(ctx, *csr)
+    asp = A.ArrowSpace(X, tm, ctx)
+    gl = A.GraphLaplacian(None, L, len(X), None)
+    asp.compute_taumode(gl)
+    want = O.taumode_lambdas(X, csr, om, arg)
+    got = np.asarray(asp.lambdas())
+    both_nan = np.isnan(got) & np.isnan(want)
+    if check is not None:
+        both_nan = both_nan | ~check
+    np.testing.assert_allclose(np.where(both_nan, 0.0, got), np.where(both_nan, 0.0, want), rtol=rtol, atol=1e-300)
+    return got
+
+
+V3_MODES = [(A.TauMode.Median, O.TAU_MEDIAN, 0.0), (A.TauMode.Mean, O.TAU_MEAN, 0.0),
+            (A.TauMode.Percentile(0.95), O.TAU_PERCENTILE, 0.95), (A.TauMode.Percentile(0.0), O.TAU_PERCENTILE, 0.0),
+            (A.TauMode.Percentile(0.5), O.TAU_PERCENTILE, 0.5), (A.TauMode.Fixed(0.4), O.TAU_FIXED, 0.4)]
+
+
+@pytest.mark.parametrize("tm,om,arg", V3_MODES)
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 129, 4099, 70001])
+def test_streaming_lambda_ragged_sizes(ctx, n, tm, om, arg):
+    """Tiles of 16 items per wave: every ragged tail, one wave up to several tiles per wave."""
+    X, cent = synth.mixture(max(n, 64), 128, seed=5, n_clusters=32, rank=6)
+    csr = O.build_laplacian(np.ascontiguousarray(cent.T), O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    for v3 in (1, 0):  # streaming kernel and the generic kernels agree with the oracle alike
+        ctx.set_option("lambda_v3", v3)
+        try:
+            _lambda_case(ctx, X[:n], csr, tm, om, arg)
+        finally:
+            ctx.set_option("lambda_v3", 1)
+
+
+@pytest.mark.parametrize("tm,om,arg", V3_MODES)
+def test_streaming_lambda_nonfinite_and_extreme_rows(ctx, tm, om, arg):
+    """NaN / +-inf entries (not ranked by select_tau: src/taumode.rs:100-108), all-zero rows, constant
+    rows, duplicated values around the middle, magnitudes that overflow the one-pass G term (the
+    literal two-pass form takes over), an item that is non-finite everywhere."""
+    X, cent = synth.mixture(600, 128, seed=9, n_clusters=32, rank=6)
+    csr = O.build_laplacian(np.ascontiguousarray(cent.T), O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    X[5, 7] = INF
+    X[9, 100] = -INF
+    X[12, :] = 0.0
+    X[20, 3:90] = NAN
+    X[21] *= 1e-160
+    X[22] *= 1e150
+    X[23] *= 1e-100
+    X[24, :] = 3.25
+    X[25, :] = NAN
+    X[26, 60:70] = X[26, 59]
+    X[27, ::2] = INF
+    X[28, 1::2] = -1.0
+    X[28, ::2] = 2.0
+    X[29] = np.abs(X[29])
+    X[30] = -np.abs(X[30])
+    X[31, :64] = NAN       # one lane quarter-pair entirely non-finite
+    X[32, 32:] = INF
+    keep = np.ones(len(X), dtype=bool)
+    keep[24] = False
+    got = _lambda_case(ctx, X, csr, tm, om, arg, keep)
+    # A constant row has x'Lx = 0 exactly in real arithmetic; in floating point the Rayleigh sum is
+    # pure cancellation noise whose value depends on the summation order (the reference's rayon
+    # reduction is unordered there too: src/taumode.rs:565-588), so only its size is comparable.
+    want24 = O.taumode_lambdas(X[24:25], csr, om, arg)[0]
+    assert abs(got[24]) < 1e-14 and abs(want24) < 1e-14
+
+
+def test_streaming_lambda_general_csr(ctx):
+    """An imported CSR that is not a Laplacian: unsymmetric, positive off-diagonal entries (w = 0
+    there: src/taumode.rs:577), missing diagonal entries, fewer nodes than features.  With random signs
+    x'Lx is a cancelling sum, so the summation order shows up around 1e-11 relative: the bar here is
+    1e-9 (north_star: 1e-6); the point of the case is the semantics, not the conditioning."""
+    rng = np.random.default_rng(3)
+    n = 100  # graph nodes < 128 features: the denominator still runs over all 128 (src/taumode.rs:596)
+    dense = np.where(rng.random((n, n)) < 0.05, rng.normal(size=(n, n)), 0.0)
+    dense[np.arange(0, n, 3), np.arange(0, n, 3)] = 0.0
+    indptr = np.zeros(n + 1, dtype=np.uint64)
+    indices, data = [], []
+    for i in range(n):
+        js = np.nonzero(dense[i])[0]
+        indices.extend(js)
+        data.extend(dense[i, js])
+        indptr[i + 1] = len(indices)
+    csr = (indptr, np.array(indices, dtype=np.uint64), np.array(data, dtype=np.float64))
+    X, _ = synth.mixture(3000, 128, seed=4, n_clusters=16, rank=5)
+    for tm, om, arg in V3_MODES[:3]:
+        _lambda_case(ctx, X, csr, tm, om, arg, rtol=1e-9)
+    sym = dense + dense.T  # symmetric but with positive entries
+    indices, data = [], []
+    for i in range(n):
+        js = np.nonzero(sym[i])[0]
+        indices.extend(js)
+        data.extend(sym[i, js])
+        indptr[i + 1] = len(indices)
+    csr = (indptr, np.array(indices, dtype=np.uint64), np.array(data, dtype=np.float64))
+    _lambda_case(ctx, X, csr, A.TauMode.Median, O.TAU_MEDIAN, 0.0, rtol=1e-9)
+
+
+def test_streaming_lambda_query_nonfinite_is_an_error(ctx):
+    X, cent = synth.mixture(500, 128, seed=5, n_clusters=32, rank=6)
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(X, cent)
+    Q = X[:40] * 1.02
+    Q[33, 5] = NAN
+    with pytest.raises(A.ArrowSpaceError, match="invalid values"):
+        asp.prepare_query_items(Q, gl)
+    Q[33, 5] = 1e200  # finite, but its square is not: must not be taken for a non-finite value
+    lq = asp.prepare_query_items(Q, gl)
+    want = np.array([O.prepare_query_item(q, gl.matrix.to_host(), O.TAU_MEDIAN, 0.0) for q in Q])
+    np.testing.assert_allclose(lq, want, rtol=LAMBDA_RTOL)
