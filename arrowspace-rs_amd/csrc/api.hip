@@ -390,7 +390,6 @@ void as_csr_free(as_csr *m) {
   if (m->packed) (void)hipFree(m->packed);
   if (m->packed_upper) (void)hipFree(m->packed_upper);
   if (m->v3_ent) (void)hipFree(m->v3_ent);
-  if (m->v3_w) (void)hipFree(m->v3_w);
   if (m->v3_diag) (void)hipFree(m->v3_diag);
   delete m;
 }

@@ -68,10 +68,9 @@ struct as_csr {
   uint64_t nnz_upper = 0;
   // entry streams of the n_features == 128 streaming kernel (taumode_v3.hip), built on first use
   int v3_state = 0;  // 0: not prepared, 1: ready, -1: outside that kernel's domain
-  void *v3_ent = nullptr, *v3_w = nullptr, *v3_diag = nullptr;
+  void *v3_ent = nullptr, *v3_diag = nullptr;
   uint32_t v3_steps = 0;
   double v3_scale = 1.0;
-  int v3_negw = 0;  // every off-diagonal entry <= 0: w = -L_ij
 };
 
 struct as_index {

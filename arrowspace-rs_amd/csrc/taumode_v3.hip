@@ -12,7 +12,7 @@
 // Mapping (wave-autonomous, no workgroup barrier in the loop; 8 waves per CU = 2 per SIMD, which is
 // what the f64 vector pipe needs to issue at full rate: one wave alone gets half of it):
 //   * one wave owns a tile of 16 items; the tile is copied HBM -> LDS by LDS-DMA
-//     (global_load_lds_dwordx4: one instruction = one 1 KB row; LDS row pitch 1040 B);
+//     (global_load_lds_dwordx4: one instruction = one 1 KB row; LDS row pitch 1056 B);
 //   * four adjacent lanes share an item (lane = 4 * item + q).  Edge pass: the off-diagonal entries
 //     of L are dealt into four interleaved streams, lane q walks stream q; the entries (byte
 //     offsets of x_i, x_j, L_ij, w) sit in LDS and are read as broadcasts, x_i and x_j come from
@@ -25,6 +25,11 @@
 //     Percentile, and median with non-finite values present, finish the merge and pick by rank;
 //   * the DMA of the wave's next tile is issued as soon as the tile has been pulled into
 //     registers, so it lands while the sorting network runs.
+// LDS banks: a ds_read_b64 is served 32 lanes at a time (8 items x 4 streams) and the bank pair of
+// x_i in item row r is (4 r + i) mod 32 at this pitch, so the two x reads of a step are conflict-free
+// when the four entries of the step have pairwise different i mod 4 and j mod 4.  The host deals the
+// entries into steps with that property (an entry's two ends may be swapped: its terms are
+// symmetric in x_i, x_j) and pads with entries that point at the always-zero slots of the row.
 // Sums are accumulated in a fixed order (stream order per lane, then the quad), so results are
 // deterministic; they differ from the oracle's sequential sums by rounding only (1e-12 bar).
 #include <utility>
@@ -37,8 +42,9 @@ namespace asx {
 namespace {
 
 constexpr int kRows = 16;                  // items per wave tile
-constexpr int kRowB = 1040;                // LDS row pitch (bytes)
-constexpr int kTileB = kRows * kRowB;      // 16,640 B per wave
+constexpr int kRowB = 1056;                // LDS row pitch (bytes): 132 doubles, see the bank note below
+constexpr int kTileB = kRows * kRowB;      // 16,896 B per wave
+constexpr int kZeroSlot = 128;             // doubles 128..131 of every LDS row stay 0.0 (never written by the DMA)
 constexpr int kWaves = 8;                  // waves per workgroup (one workgroup per CU)
 constexpr int kU = 4;                      // edge steps per software-pipeline block
 constexpr size_t kLdsBudget = 160 * 1024;
@@ -48,11 +54,54 @@ struct __align__(16) V3Entry {
   double lij;
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ bool finite_bits(double x) {
   return (((uint32_t)__double2hiint(x) >> 20) & 0x7FFu) != 0x7FFu;
+}
+
+static_assert(kU == 4, "the asm helpers below are written for four steps per block");
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+
+// Asynchronous LDS reads: the destination registers are NOT valid until lds_landed() on them.
+__device__ __forceinline__ void read_entries(u32x4 (&e)[kU], uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+               "ds_read_b128 %3, %4 offset:192"
+               : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+               : "v"(addr));
+}
+// Same reads, issued inside the pipeline: the x values of the block about to be computed pass
+// through the statement, so none of that block's arithmetic can be scheduled above the issue.
+__device__ __forceinline__ void read_entries_before(u32x4 (&e)[kU], uint32_t addr, double (&xi)[kU], double (&xj)[kU]) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+               "ds_read_b128 %3, %4 offset:192"
+               : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+               : "v"(addr), "v"(xi[0])
+               :);
+  asm volatile("" : "+v"(xi[0]), "+v"(xi[1]), "+v"(xi[2]), "+v"(xi[3]), "+v"(xj[0]), "+v"(xj[1]), "+v"(xj[2]), "+v"(xj[3]));
+}
+__device__ __forceinline__ void read_x(double (&xi)[kU], double (&xj)[kU], const u32x4 (&e)[kU], uint32_t row_a) {
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    asm volatile("ds_read_b64 %0, %1" : "=v"(xi[u]) : "v"(row_a + e[u].x));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(xj[u]) : "v"(row_a + e[u].y));
+  }
+}
+// s_waitcnt lgkmcnt(0) that the register allocator sees as the definition of the given registers:
+// nothing that reads them can be scheduled above it.
+__device__ __forceinline__ void lds_landed(u32x4 (&a)[kU], u32x4 (&b)[kU]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+// The accumulators ride along so that the arithmetic of the block before stays above the wait (it
+// is what covers the latency of the reads being waited for).
+__device__ __forceinline__ void lds_landed(double (&xi)[kU], double (&xj)[kU], u32x4 (&e)[kU], double &a0, double &a1,
+                                           double &a2) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(xi[0]), "+v"(xi[1]), "+v"(xi[2]), "+v"(xi[3]), "+v"(xj[0]), "+v"(xj[1]), "+v"(xj[2]), "+v"(xj[3]),
+                 "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(a0), "+v"(a1), "+v"(a2));
 }
 
 // value held by another lane of the quad: DPP quad_perm, CTRL = p0 | p1 << 2 | p2 << 4 | p3 << 6
@@ -194,40 +243,37 @@ __device__ __forceinline__ void issue_tile(const double *items, uint64_t item0, 
   issue_rows(gbase, lds_tile, (uint32_t)lane * 16u, rows_here, std::make_index_sequence<kRows>{});
 }
 
-// NEGW: every off-diagonal entry of L is <= 0 (a Laplacian), so w = max(-L_ij, 0) = -L_ij and the
-// separate w stream is not read.
-template <bool NEGW>
+// Requires every off-diagonal entry of L to be <= 0 (a Laplacian): w = max(-L_ij, 0) = -L_ij.
 __global__ __launch_bounds__(kWaves * 64) void lambda_kernel_v3(
     const double *__restrict__ items, uint64_t n_items, const V3Entry *__restrict__ g_ent,
-    const double *__restrict__ g_w, const double *__restrict__ g_diag, uint32_t n_steps, double scale, int mode,
+    const double *__restrict__ g_diag, uint32_t n_steps, double scale, int mode,
     double arg, int check_finite, double *__restrict__ out, int *__restrict__ err_flag,
-    uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list, unsigned long long *__restrict__ dbg) {
+    uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list, unsigned long long *__restrict__ dbg, int stagger) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile addresses stay in SGPRs
   const int q = lane & 3;
   unsigned char *tile = smem + (size_t)wv * kTileB;
   V3Entry *s_ent = (V3Entry *)(smem + (size_t)nw * kTileB);
-  const uint32_t n_slots = 4 * (n_steps + kU);  // one zero block past the end for the prefetch
-  double *s_w = (double *)(s_ent + n_slots);
-  double *s_diag = s_w + n_slots;
+  const uint32_t n_slots = 4 * (n_steps + 2 * kU);  // two padding blocks past the end for the prefetch
+  double *s_diag = (double *)(s_ent + n_slots);
 
   const uint64_t n_tiles = (n_items + kRows - 1) / kRows;
-  const uint64_t total_w = (uint64_t)gridDim.x * nw;
-  uint64_t t = (uint64_t)blockIdx.x * nw + wv;
+  // Tiles of this workgroup: blockIdx.x + gridDim.x * k, k = 0, 1, ...; the waves draw k from a
+  // counter in LDS.  (With a fixed share per wave the older wave of each SIMD pair wins the issue
+  // arbitration, finishes early and leaves its partner to run alone at half the issue rate.)
+  uint32_t *s_ctr = (uint32_t *)(s_diag + 128);
+  if (tid == 0) *s_ctr = (uint32_t)nw;
+  uint64_t t = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * wv;
   const uint32_t lds_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lds_void *)tile);
   if (t < n_tiles) issue_tile(items, t * kRows, (uint32_t)min((uint64_t)kRows, n_items - t * kRows), lds_tile, lane);
 
-  for (uint32_t i = tid; i < n_slots; i += blockDim.x) {
-    s_ent[i] = g_ent[i];
-    s_w[i] = g_w[i];
-  }
+  for (uint32_t i = tid; i < n_slots; i += blockDim.x) s_ent[i] = g_ent[i];
   for (uint32_t i = tid; i < 128; i += blockDim.x) s_diag[i] = g_diag[i];
   __syncthreads();
 
   const unsigned char *row = tile + (lane >> 2) * kRowB;
-  const V3Entry *ep = s_ent + q;
-  const double *wp = s_w + q;
+  ((double *)(tile + (lane >> 2) * kRowB))[kZeroSlot + q] = 0.0;  // the row's four zero slots (padding entries read them)
   const double *dg = s_diag + q * 32;
 
   unsigned long long c_wait = 0, c_edge = 0, c_regs = 0, c_tau = 0, c_fin = 0, stamp = 0;
@@ -242,53 +288,57 @@ __global__ __launch_bounds__(kWaves * 64) void lambda_kernel_v3(
     stamp = t_begin = __builtin_amdgcn_s_memtime();
     r_begin = __builtin_amdgcn_s_memrealtime();
   }
-  for (; t < n_tiles; t += total_w) {
+  // Stagger: the second half of the waves (the SIMD partners of the first half) starts about half
+  // a tile late, so that one partner is in its LDS-heavy edge pass while the other sorts in
+  // registers.  Measured at 1 M items (Median): 0.41 ms in lockstep, 0.35 ms staggered.
+  if (stagger && wv >= nw / 2) __builtin_amdgcn_s_sleep(127);
+  while (t < n_tiles) {
     const uint64_t item0 = t * kRows;
     const uint32_t rows_here = (uint32_t)min((uint64_t)kRows, n_items - item0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile has landed in LDS
     V3_STAMP(c_wait)
 
     // ---- edge pass (src/taumode.rs:565-588, 611-639): lane q walks stream q ----
+    // Three-stage software pipeline, kU steps per stage: the entries of block b+2 and the x values
+    // of block b+1 are in flight while block b is computed.  The LDS reads are issued as asm
+    // (left to the optimiser, each prefetch sinks into the iteration that consumes it and the loop
+    // pays two LDS round trips per block); lds_landed() is the s_waitcnt that hands the registers
+    // back to compiled code.  The three register sets rotate by unrolling, not by copies.
     double numo = 0.0, eh = 0.0, s2 = 0.0;
     {
-      V3Entry e[kU];
-      double w[kU];
+      const uint32_t row_a = lds_addr(row);
+      uint32_t ent_a = lds_addr(s_ent) + (uint32_t)q * 16u;
+      u32x4 E[3][kU];
+      double XI[3][kU], XJ[3][kU];
+      read_entries(E[0], ent_a);
+      read_entries(E[1], ent_a + kU * 64);
+      ent_a += 2 * kU * 64;
+      lds_landed(E[0], E[1]);
+      read_x(XI[0], XJ[0], E[0], row_a);
+      for (uint32_t s = 0; s < n_steps; s += 3 * kU) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        e[u] = ep[4 * u];
-        w[u] = NEGW ? 0.0 : wp[4 * u];
-      }
-      for (uint32_t s = 0; s < n_steps; s += kU) {
-        double xi[kU], xj[kU];
+        for (int ph = 0; ph < 3; ++ph) {
+          constexpr int kNext[3] = {1, 2, 0};
+          const int b0 = ph, b1 = kNext[ph], b2 = kNext[kNext[ph]];
+          lds_landed(XI[b0], XJ[b0], E[b1], numo, eh, s2);  // x of this block, entries of the next
+          read_x(XI[b1], XJ[b1], E[b1], row_a);
+          read_entries_before(E[b2], ent_a, XI[b0], XJ[b0]);
+          ent_a += kU * 64;
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          xi[u] = *(const double *)(row + e[u].oi);
-          xj[u] = *(const double *)(row + e[u].oj);
-        }
-        V3Entry en[kU];
-        double wn[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          en[u] = ep[4 * (s + kU + u)];
-          if (!NEGW) wn[u] = wp[4 * (s + kU + u)];
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const double p = xi[u] * xj[u];
-          numo = __builtin_fma(e[u].lij, p, numo);  // L_ij * (x_i x_j)
-          const double dd = xi[u] - xj[u];
-          // NEGW: w = -L_ij, so the term is accumulated negated (no negation per entry) and the
-          // sign is restored once at the end; tt^2 does not see the sign
-          const double tt = ((NEGW ? e[u].lij : w[u]) * dd) * dd;  // +-(w * d * d)
-          eh = eh + tt;
-          s2 = __builtin_fma(tt, tt, s2);
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          e[u] = en[u];
-          w[u] = NEGW ? 0.0 : wn[u];
+          for (int u = 0; u < kU; ++u) {
+            const double lij = __hiloint2double((int)E[b0][u].w, (int)E[b0][u].z);
+            const double p = XI[b0][u] * XJ[b0][u];
+            numo = __builtin_fma(lij, p, numo);  // L_ij * (x_i x_j)
+            const double dd = XI[b0][u] - XJ[b0][u];
+            // w = -L_ij: the term is accumulated negated (no negation per entry) and the sign is
+            // restored once at the end; tt^2 does not see the sign
+            const double tt = (lij * dd) * dd;  // -(w * d * d)
+            eh = eh + tt;
+            s2 = __builtin_fma(tt, tt, s2);
+          }
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the two prefetched padding blocks
     }
     if (dbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     V3_STAMP(c_edge)
@@ -319,8 +369,11 @@ __global__ __launch_bounds__(kWaves * 64) void lambda_kernel_v3(
       for (int k = 0; k < 32; ++k) fin = fin && finite_bits(v[k]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of this tile has returned
+    uint64_t tn;
     {
-      const uint64_t tn = t + total_w;
+      uint32_t kn = 0;
+      if (lane == 0) kn = atomicAdd(s_ctr, 1u);
+      tn = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (uint32_t)__builtin_amdgcn_readfirstlane((int)kn);
       if (tn < n_tiles) issue_tile(items, tn * kRows, (uint32_t)min((uint64_t)kRows, n_items - tn * kRows), lds_tile, lane);
     }
     V3_STAMP(c_regs)
@@ -406,7 +459,7 @@ __global__ __launch_bounds__(kWaves * 64) void lambda_kernel_v3(
 
     // ---- combine the quad, lambda (src/taumode.rs:596-647) ----
     numo = quad_sum(numo);
-    eh = quad_sum(NEGW ? -eh : eh);
+    eh = quad_sum(-eh);
     s2 = quad_sum(s2);
     const double den = quad_sum(den0 + den1);
     const double nd = quad_sum(nd0 + nd1);
@@ -430,6 +483,7 @@ __global__ __launch_bounds__(kWaves * 64) void lambda_kernel_v3(
       if (redo) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)item;
     }
     V3_STAMP(c_fin)
+    t = tn;
   }
   if (dbg && lane == 0) {
     unsigned long long *d = dbg + ((size_t)blockIdx.x * nw + wv) * 8;
@@ -559,24 +613,69 @@ static int prepare_v3(as_ctx *ctx, as_csr *L) {
       w.push_back(ww);
       if (!(data[e] <= 0.0)) negw = false;
     }
-  const uint32_t n_steps = (uint32_t)(((ent.size() + 3) / 4 + kU - 1) / kU * kU);
-  const size_t n_slots = 4 * ((size_t)n_steps + kU);
-  V3Entry zero;
-  zero.oi = zero.oj = 0;
-  zero.lij = 0.0;
-  ent.resize(n_slots, zero);
-  w.resize(n_slots, 0.0);
-  const size_t fixed = n_slots * (sizeof(V3Entry) + sizeof(double)) + 128 * sizeof(double);
+  if (!negw) return AS_OK;  // a positive (or NaN) off-diagonal entry: w = max(-L_ij, 0) is not -L_ij; generic kernels
+  // Deal the entries into steps of four with pairwise different (i mod 4) and (j mod 4): see the
+  // bank note at the top.  Greedy: for each wanted i-residue take an unused entry (either
+  // orientation) whose other end has a j-residue still free in this step, preferring the fullest
+  // class; what cannot be filled is padded with an entry between two zero slots.
+  struct Cand {
+    V3Entry e;
+    double w;
+  };
+  std::vector<Cand> pool[4][4];
+  for (size_t k = 0; k < ent.size(); ++k) pool[(ent[k].oi / 8) % 4][(ent[k].oj / 8) % 4].push_back({ent[k], w[k]});
+  size_t left = ent.size();
+  std::vector<V3Entry> sched;
+  std::vector<double> sched_w;
+  while (left > 0) {
+    bool j_used[4] = {false, false, false, false};
+    for (int ri = 0; ri < 4; ++ri) {
+      int best_a = -1, best_b = -1;
+      size_t best_n = 0;
+      for (int rj = 0; rj < 4; ++rj) {
+        if (j_used[rj]) continue;
+        if (pool[ri][rj].size() > best_n) best_n = pool[ri][rj].size(), best_a = ri, best_b = rj;
+        if (pool[rj][ri].size() > best_n) best_n = pool[rj][ri].size(), best_a = rj, best_b = ri;
+      }
+      Cand c;
+      if (best_n > 0) {
+        c = pool[best_a][best_b].back();
+        pool[best_a][best_b].pop_back();
+        --left;
+        if (best_a != ri) std::swap(c.e.oi, c.e.oj);  // stored the other way round
+        j_used[(c.e.oj / 8) % 4] = true;
+      } else {
+        int rj = 0;
+        while (j_used[rj]) ++rj;
+        j_used[rj] = true;
+        c.e.oi = (uint32_t)((kZeroSlot + ri) * 8);
+        c.e.oj = (uint32_t)((kZeroSlot + rj) * 8);
+        c.e.lij = 0.0;
+        c.w = 0.0;
+      }
+      sched.push_back(c.e);
+      sched_w.push_back(c.w);
+    }
+  }
+  const uint32_t n_steps = (uint32_t)((sched.size() / 4 + 3 * kU - 1) / (3 * kU) * (3 * kU));  // whole pipeline rounds
+  const size_t n_slots = 4 * ((size_t)n_steps + 2 * kU);
+  for (size_t k = sched.size(); k < n_slots; ++k) {  // whole padding steps keep the residue pattern
+    V3Entry z;
+    z.oi = z.oj = (uint32_t)((kZeroSlot + k % 4) * 8);
+    z.lij = 0.0;
+    sched.push_back(z);
+    sched_w.push_back(0.0);
+  }
+  ent.swap(sched);
+  w.swap(sched_w);
+  const size_t fixed = n_slots * sizeof(V3Entry) + 128 * sizeof(double) + 16;
   if (fixed + kTileB > kLdsBudget) return AS_OK;  // entry table too large for LDS
   AS_HIP(ctx, hipMalloc(&L->v3_ent, n_slots * sizeof(V3Entry)));
-  AS_HIP(ctx, hipMalloc(&L->v3_w, n_slots * sizeof(double)));
   AS_HIP(ctx, hipMalloc(&L->v3_diag, 128 * sizeof(double)));
   AS_HIP(ctx, copy_h2d(ctx, L->v3_ent, ent.data(), n_slots * sizeof(V3Entry)));
-  AS_HIP(ctx, copy_h2d(ctx, L->v3_w, w.data(), n_slots * sizeof(double)));
   AS_HIP(ctx, copy_h2d(ctx, L->v3_diag, diag.data(), 128 * sizeof(double)));
   L->v3_steps = n_steps;
   L->v3_scale = sym ? 2.0 : 1.0;
-  L->v3_negw = negw ? 1 : 0;
   L->v3_state = 1;
   return AS_OK;
 }
@@ -590,8 +689,8 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
   if (mode < AS_TAU_FIXED || mode > AS_TAU_PERCENTILE) return AS_OK;
   AS_TRY(prepare_v3(ctx, L));
   if (L->v3_state != 1) return AS_OK;
-  const size_t n_slots = 4 * ((size_t)L->v3_steps + kU);
-  const size_t fixed = n_slots * (sizeof(V3Entry) + sizeof(double)) + 128 * sizeof(double);
+  const size_t n_slots = 4 * ((size_t)L->v3_steps + 2 * kU);
+  const size_t fixed = n_slots * sizeof(V3Entry) + 128 * sizeof(double) + 16;
   int nw = (int)std::min<size_t>(kWaves, (kLdsBudget - fixed) / kTileB);
   if (nw < 1) return AS_OK;
   const size_t lds = (size_t)nw * kTileB + fixed;
@@ -612,18 +711,10 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
   }
   {
     ProfScope ps(ctx, "taumode_lambda");
-#define V3_LAUNCH(NEGW)                                                                                          \
-  AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v3<NEGW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds));                                                                   \
-  hipLaunchKernelGGL(lambda_kernel_v3<NEGW>, dim3(blocks), dim3(nw * 64), lds, ctx->stream, items, n_items,         \
-                     (const V3Entry *)L->v3_ent, (const double *)L->v3_w, (const double *)L->v3_diag, L->v3_steps,  \
-                     L->v3_scale, mode, arg, check_finite ? 1 : 0, out, err.p, redo.p, redo.p + 1, dbg.p)
-    if (L->v3_negw) {
-      V3_LAUNCH(true);
-    } else {
-      V3_LAUNCH(false);
-    }
-#undef V3_LAUNCH
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lambda_kernel_v3, dim3(blocks), dim3(nw * 64), lds, ctx->stream, items, n_items,
+                       (const V3Entry *)L->v3_ent, (const double *)L->v3_diag, L->v3_steps, L->v3_scale, mode, arg,
+                       check_finite ? 1 : 0, out, err.p, redo.p, redo.p + 1, dbg.p, (int)(ctx->opt_debug != 4));
     AS_HIP(ctx, hipGetLastError());
     if (L->nnz) {
       hipLaunchKernelGGL(lambda_redo_kernel, dim3(64), dim3(256), 0, ctx->stream, items, (uint32_t)F,
@@ -637,6 +728,12 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (size_t w = 0; w < n_dbg / 8; ++w)
       for (int k = 0; k < 7; ++k) acc[k] += (double)hd[w * 8 + k];
+    double life_max = 0, life_min = 1e30;
+    for (size_t w = 0; w < n_dbg / 8; ++w) {
+      life_max = std::max(life_max, (double)hd[w * 8 + 6]);
+      life_min = std::min(life_min, (double)hd[w * 8 + 6]);
+    }
+    fprintf(stderr, "[v3 wave life] min %.1f us max %.1f us\n", life_min / 100.0, life_max / 100.0);
     const double per = (double)n_tiles;
     fprintf(stderr, "[v3 cycles per tile] wait %.0f edge %.0f regs %.0f tau %.0f final %.0f (memtime ticks; %llu tiles, %u waves; clock %.0f MHz, wave life %.1f us)\n",
             acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, (unsigned long long)n_tiles,

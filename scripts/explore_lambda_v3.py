@@ -50,6 +50,9 @@ for v3 in (1, 0):
     ctx.set_option("lambda_v3", v3)
     for name, mode, arg, _ in MODES:
         run("v3=%d %s" % (v3, name), lambda: ctx.check(lib.as_compute_taumode(ctx.h, Xd.data_ptr(), n, 128, gl.matrix.h, mode, arg, out.data_ptr())))
-ctx.set_option("lambda_v3", 1); ctx.set_option("debug", 3)
+ctx.set_option("lambda_v3", 1); ctx.set_option("debug", 4)
+for name, mode, arg, _ in MODES:
+    run("lockstep %s" % name, lambda: ctx.check(lib.as_compute_taumode(ctx.h, Xd.data_ptr(), n, 128, gl.matrix.h, mode, arg, out.data_ptr())))
+ctx.set_option("debug", 3)
 for name, mode, arg, _ in MODES:
     print(name); ctx.check(lib.as_compute_taumode(ctx.h, Xd.data_ptr(), n, 128, gl.matrix.h, mode, arg, out.data_ptr())); torch.cuda.synchronize()
