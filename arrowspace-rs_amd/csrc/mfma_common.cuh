@@ -50,6 +50,7 @@ struct CandProblem {
   const double *q_lambdas;  // by global A id
   const double *x_lambdas;  // by B row
   double alpha;
+  int lam_f32;              // f32 candidate pass: evaluate the lambda term in f32 (small lambdas), else f64
   // output: nA x splits x KC candidates, key = approximate key (ascending = better), idx = B row
   uint32_t KC, splits;
   double *cand_key;

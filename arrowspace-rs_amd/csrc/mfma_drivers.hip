@@ -387,6 +387,19 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
 }
 
 // ---- K9 driver ----------------------------------------------------------------------------------
+// max |v| over a vector as the bits of a non-negative double (atomicMax on the integer image is the
+// max on the value); a NaN counts as +inf so that the caller takes the f64 epilogue.
+__global__ void absmax_kernel(const double *__restrict__ v, uint64_t n, unsigned long long *__restrict__ out) {
+  double m = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const double a = fabs(v[i]);
+    m = a != a ? __builtin_inf() : fmax(m, a);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms, const double *q_lambdas,
                 uint64_t nq64, uint32_t k, double alpha, uint32_t *out_idx, double *out_key) {
   const uint32_t n = (uint32_t)ix->n, d = (uint32_t)ix->d, nq = (uint32_t)nq64;
@@ -455,9 +468,27 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       DevBuf<float> PA;
       AS_TRY(PA.alloc(ctx, packed_elems(at, d)));
       AS_TRY(pack_f32(ctx, queries, q_norms, nullptr, 0, nq, d, PA.p, at));
+      // lambda term of the epilogue: f32 when the lambdas are small enough for its error to stay far below
+      // the cosine error (the usual case: lambda in [0, 1]), f64 otherwise (mfma_topk_f32.hip)
+      DevBuf<unsigned long long> amax;
+      AS_TRY(amax.alloc(ctx, 2));
+      AS_HIP(ctx, hipMemsetAsync(amax.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(absmax_kernel, dim3(std::min<uint64_t>(1024, cdiv(nq, 256))), dim3(256), 0, ctx->stream,
+                         q_lambdas, (uint64_t)nq, amax.p);
+      hipLaunchKernelGGL(absmax_kernel, dim3(std::min<uint64_t>(1024, cdiv(n, 256))), dim3(256), 0, ctx->stream,
+                         ix->lambdas, (uint64_t)n, amax.p + 1);
+      AS_HIP(ctx, hipGetLastError());
+      double hmax[2] = {0.0, 0.0};
+      AS_HIP(ctx, copy_d2h(ctx, hmax, amax.p, sizeof(hmax)));
+      const double lsum = hmax[0] + hmax[1];
+      pb.lam_f32 = lsum <= 64.0 ? 1 : 0;
+      ctx->stats["search_lambda_term_f32"] = pb.lam_f32;
       AS_TRY(candidates_f32(ctx, pb, PA.p, a_tiles, ix->packed32, b_tiles, "search_mfma_candidates_f32"));
-      // f32 pass: cosine error scaled by |alpha|, plus one f32 rounding of a value bounded by |alpha| + |1 - alpha|
-      SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + (std::fabs(alpha) + std::fabs(1.0 - alpha)) * 1.3e-7 + 1e-12};
+      // f32 pass: cosine error scaled by |alpha|, the lambda term's error scaled by |beta| (f32 form only),
+      // plus the f32 roundings of a sum bounded by |alpha| + |beta| (product, fma)
+      const double beta_abs = std::fabs(1.0 - alpha);
+      const double lam_err = pb.lam_f32 ? beta_abs * (lsum * 0x1p-23 + 0x1p-22) : 0.0;
+      SearchBound bnd{std::fabs(alpha) * cos_delta_f32(d) + lam_err + (std::fabs(alpha) + beta_abs) * 2.6e-7 + 1e-12};
       AS_TRY(launch_rerank(ctx, "search_rerank", queries, ix->items, d, nullptr, 0u, nq, 0u, K, KC, pb.splits, ckey.p,
                            cidx.p, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p));
     } else {

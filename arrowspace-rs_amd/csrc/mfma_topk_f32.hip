@@ -59,22 +59,44 @@ int pack_f32(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
 
 // epilogues: approximate VALUE of one (row, col) product, higher = better
 struct GraphEpi32 {
-  __device__ __forceinline__ void load_row(uint32_t, double &) const {}
-  __device__ __forceinline__ void load_col(uint32_t, uint32_t, double &) const {}
-  __device__ __forceinline__ float value(float s, double, double) const { return s; }
+  using T = float;  // per-row / per-column epilogue data (unused here)
+  __device__ __forceinline__ void load_row(uint32_t, T &) const {}
+  __device__ __forceinline__ void load_col(uint32_t, uint32_t, T &) const {}
+  __device__ __forceinline__ float value(float s, T, T) const { return s; }
 };
+// Search epilogue, f32 lambda term.  Used when max|lambda_q| + max|lambda_x| = Lsum is small
+// (search_mfma checks): with lq, lx rounded to f32,
+//   | lam32 - (1 - min(|lq - lx|, 1)) | <= Lsum 2^-23 + 2^-24,
+// which the certification bound carries as |beta| (Lsum 2^-23 + 2^-22).
 struct SearchEpi32 {
+  using T = float;
+  ARows ar;
+  const double *q_lambdas;
+  const double *x_lambdas;
+  float alpha, beta;
+  __device__ __forceinline__ void load_row(uint32_t arow, T &v) const { v = (float)q_lambdas[ar.gid(arow)]; }
+  __device__ __forceinline__ void load_col(uint32_t col, uint32_t nB, T &v) const {
+    v = col < nB ? (float)x_lambdas[col] : 0.f;
+  }
+  __device__ __forceinline__ float value(float s, T lq, T lx) const {
+    const float lam = 1.f - fminf(fabsf(lq - lx), 1.f);
+    return fmaf(alpha, s, beta * lam);
+  }
+};
+// Search epilogue, f64 lambda term: lambdas of any magnitude (a large tau makes lambdas large), three
+// times the epilogue cost.  Only the sum is rounded to f32:
+// |value - exact| <= |alpha| delta_cos + (|alpha| + |beta|) 2^-23
+struct SearchEpi32D {
+  using T = double;
   ARows ar;
   const double *q_lambdas;
   const double *x_lambdas;
   double alpha, beta;
-  // the lambda term is evaluated in f64 (lambdas of any magnitude), only the sum is rounded to f32:
-  // |value - exact| <= |alpha| delta_cos + (|alpha| + |beta|) 2^-23
-  __device__ __forceinline__ void load_row(uint32_t arow, double &v) const { v = q_lambdas[ar.gid(arow)]; }
-  __device__ __forceinline__ void load_col(uint32_t col, uint32_t nB, double &v) const {
+  __device__ __forceinline__ void load_row(uint32_t arow, T &v) const { v = q_lambdas[ar.gid(arow)]; }
+  __device__ __forceinline__ void load_col(uint32_t col, uint32_t nB, T &v) const {
     v = col < nB ? x_lambdas[col] : 0.0;
   }
-  __device__ __forceinline__ float value(float s, double lq, double lx) const {
+  __device__ __forceinline__ float value(float s, T lq, T lx) const {
     const double lam = 1.0 - fmin(fabs(lq - lx), 1.0);
     return (float)(alpha * (double)s + beta * lam);
   }
@@ -141,7 +163,8 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
   float *qvals = reinterpret_cast<float *>(lidx + kRows32 * KC);        // [WAVES][QCAP]
   uint32_t *qcols = reinterpret_cast<uint32_t *>(qvals + WAVES * QCAP);
   uint32_t *qrows = qcols + WAVES * QCAP;
-  double *rowdata = reinterpret_cast<double *>(qrows + WAVES * QCAP);   // [256] (8-byte aligned: all blocks above are multiples of 8 B)
+  using ET = typename Epi::T;
+  ET *rowdata = reinterpret_cast<ET *>(qrows + WAVES * QCAP);   // [256] (8-byte aligned: all blocks above are multiples of 8 B)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,7 +176,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
   float *qv = qvals + wv * QCAP;
   uint32_t *qc = qcols + wv * QCAP;
   uint32_t *qr = qrows + wv * QCAP;
-  double *wrow = rowdata + wv * WROWS;
+  ET *wrow = rowdata + wv * WROWS;
 
   const uint32_t items = a_items * splits;
   for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -180,7 +203,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
     if (panels == 1) load_a(0);
     if (lane < WROWS) {  // per-row epilogue data (search: the query lambdas), kept in LDS
       const uint32_t arow = I * kRows32 + wv * WROWS + lane;
-      double rv = 0.0;
+      ET rv = 0;
       if (arow < nA) epi.load_row(arow, rv);
       wrow[lane] = rv;
     }
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
     uint32_t g = 0;
     int pbuf = 0;
     for (uint32_t J = j_lo; J < j_hi; ++J) {
-      double colv[4];
+      ET colv[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) epi.load_col(J * kTileRows + n * 32 + lc, nB, colv[n]);
       for (uint32_t panel = 0; panel < panels; ++panel) {
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
           for (int m = 0; m < MW; ++m) {
             // thresholds / row data of this lane's 16 rows of group m (LDS, 2 addresses per read)
             float thr[16];
-            double rowv[16];
+            ET rowv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int rl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -429,9 +452,14 @@ int candidates_f32(as_ctx *ctx, const CandProblem &pb, const float *PA, uint32_t
   if (pb.mode == 0)
     return launch_f32<GraphEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels,
                                   GraphEpi32{}, pb.cand_key, pb.cand_idx, prof_name);
-  SearchEpi32 epi{pb.arows, pb.q_lambdas, pb.x_lambdas, pb.alpha, 1.0 - pb.alpha};
-  return launch_f32<SearchEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels, epi,
-                                 pb.cand_key, pb.cand_idx, prof_name);
+  if (pb.lam_f32) {
+    SearchEpi32 epi{pb.arows, pb.q_lambdas, pb.x_lambdas, (float)pb.alpha, (float)(1.0 - pb.alpha)};
+    return launch_f32<SearchEpi32>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels, epi,
+                                   pb.cand_key, pb.cand_idx, prof_name);
+  }
+  SearchEpi32D epi{pb.arows, pb.q_lambdas, pb.x_lambdas, pb.alpha, 1.0 - pb.alpha};
+  return launch_f32<SearchEpi32D>(ctx, NC, PA, a_items, PB, b_tiles, pb.nA, pb.nB, pb.KC, pb.splits, panels, epi,
+                                  pb.cand_key, pb.cand_idx, prof_name);
 }
 
 }  // namespace asx

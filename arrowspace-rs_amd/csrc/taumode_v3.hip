@@ -697,6 +697,13 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
   const uint64_t n_tiles = (n_items + kRows - 1) / kRows;
   const unsigned blocks = (unsigned)std::min<uint64_t>((n_tiles + nw - 1) / nw, 256);
 
+  static bool attr_set_dev[64] = {};  // allow the full 160 KB of dynamic LDS: once per device, outside the timed region
+  bool &attr_set = attr_set_dev[ctx->device & 63];
+  if (!attr_set) {
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kLdsBudget));
+    attr_set = true;
+  }
   DevBuf<int> err;
   DevBuf<uint32_t> redo;  // [0] = count, [1..] = item ids
   AS_TRY(err.alloc(ctx, 1));
@@ -711,7 +718,6 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
   }
   {
     ProfScope ps(ctx, "taumode_lambda");
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)lambda_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lambda_kernel_v3, dim3(blocks), dim3(nw * 64), lds, ctx->stream, items, n_items,
                        (const V3Entry *)L->v3_ent, (const double *)L->v3_diag, L->v3_steps, L->v3_scale, mode, arg,
                        check_finite ? 1 : 0, out, err.p, redo.p, redo.p + 1, dbg.p, (int)(ctx->opt_debug != 4));

@@ -207,8 +207,15 @@ def main():
         if lam_n:
             # two launches per step hit this group: the N items and the nq queries
             bytes_per_step = (rows_here + nq) * (8.0 * d + 8.0)
-            extra["taumode_scan_GBps"] = bytes_per_step * steps / (lam_ms * 1e-3) / 1e9
-            extra["taumode_scan_frac_hbm"] = extra["taumode_scan_GBps"] / HBM_PEAK_GBS
+            gbps = bytes_per_step * steps / (lam_ms * 1e-3) / 1e9
+            extra["taumode_scan_GBps"] = gbps
+            extra["taumode_scan_frac_hbm"] = gbps / HBM_PEAK_GBS
+            # second roofline object: the lambda-tau scan (K6/K7/K8), HBM-side view.  The kernel itself is
+            # bound by f64 vector issue + LDS reads at this graph density.
+            extra["roofline_scan"] = {"bound": "hbm", "kernel": "lambda_kernel_v3 (tau select + Rayleigh/dispersion, items + queries)",
+                                      "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                      "traffic": None, "avg_step_ms": lam_ms / steps,
+                                      "algorithmic_bytes_per_step": bytes_per_step}
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
             "candidate_precision": "f32 MFMA -> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)"

@@ -402,6 +402,28 @@ def test_large_search_sampled_parity(ctx):
     assert np.all(np.diff(sc, axis=1) <= 0)
 
 
+@pytest.mark.parametrize("scale,want_f32", [(1.0, 1), (40.0, 0), (1e6, 0)])
+def test_search_lambda_term_precision_choice(ctx, scale, want_f32):
+    """The f32 candidate pass evaluates the lambda term in f32 while max|lambda_q| + max|lambda_x| <= 64 and in
+    f64 beyond (large tau makes lambdas large); results are bit-identical to the oracle either way."""
+    n, d, nq = 20_000, 128, 300
+    X, _ = synth.mixture(n, d, seed=11, n_clusters=64, rank=6)
+    rng = np.random.default_rng(8)
+    lam = rng.random(n) * scale
+    lam[::7] = lam[3] + np.arange(len(lam[::7])) * 1e-9 * scale  # near-ties in the lambda term
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=5)
+    Q = X[qi] * 1.02
+    lq = lam[qi] + rng.normal(size=nq) * 0.05 * scale
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
+    assert ctx.stat("search_lambda_term_f32") == want_f32
+    for j in range(0, nq, 10):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 10, 0.7)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+
+
 # ---- callers of the same index: hybrid and range search (src/core.rs:802-976) ------------------
 
 def test_hybrid_search_matches_oracle(ctx, mode):
