@@ -194,14 +194,15 @@ def main():
                         "avg_launch_ms": ms64 / l64, "launches": l64}
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed rocprofv3 --pmc measurement of this very command is reported when it matches the workload
+        pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if roofline and world == 1 and (n, d) == (1_000_000, 128) and "mfma32" in roofline["kernel"]:
                 roofline["traffic"] = pmc["hbm_bytes_per_step"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roofline["traffic_source"] = "profiles/r01c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except (OSError, KeyError, ValueError):
-            pass
+            pmc = {}
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
         extra = {}
         if lam_n:
@@ -216,6 +217,9 @@ def main():
                                       "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                                       "traffic": None, "avg_step_ms": lam_ms / steps,
                                       "algorithmic_bytes_per_step": bytes_per_step}
+            if world == 1 and (n, d, nq) == (1_000_000, 128, 10_000) and "lambda_scan_hbm_bytes_per_step" in pmc:
+                extra["roofline_scan"]["traffic"] = pmc["lambda_scan_hbm_bytes_per_step"]
+                extra["roofline_scan"]["traffic_source"] = "profiles/r01c_pmc_traffic.json"
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
             "candidate_precision": "f32 MFMA -> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)"
