@@ -82,6 +82,14 @@ def _world():
     return 0, 1
 
 
+def _collectives_on(world):
+    """Exchange steps run when there is more than one rank -- or, with ARROWSPACE_DIST_FORCE=1, also
+    on a single rank with an initialised process group: that is how the RCCL calls (dtypes, stream
+    ordering against the HIP kernels) are exercised on a one-GPU test box."""
+    import os
+    return world > 1 or (os.environ.get("ARROWSPACE_DIST_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def _host_staged():
     """gloo cannot move HBM tensors: stage through the host (test configurations only; the bench
     runs on "nccl" = RCCL, device to device over xGMI)."""
@@ -109,7 +117,7 @@ def _all_reduce(t, op):
 def all_gather_rows(t, sizes):
     """all-gather of row blocks with (possibly) unequal row counts; `sizes` = rows per rank."""
     rank, world = _world()
-    if world == 1:
+    if not _collectives_on(world):
         return t
     mx = max(sizes)
     pad = t
@@ -153,7 +161,7 @@ class ShardedArrowSpace:
         lam = self.lambdas if torch.is_tensor(self.lambdas) else torch.from_numpy(np.asarray(self.lambdas))
         stats = torch.stack([lam.min(), -lam.max(), lam.sum()]) if lam.numel() else \
             torch.tensor([float("inf"), float("inf"), 0.0], dtype=torch.float64, device=lam.device)
-        if self.world > 1:                                                # logged stats, builder.rs:434-445
+        if _collectives_on(self.world):                                   # logged stats, builder.rs:434-445
             mm = stats[:2].clone()
             _all_reduce(mm, dist.ReduceOp.MIN)
             sm = stats[2:].clone()
@@ -171,7 +179,7 @@ class ShardedArrowSpace:
         idx, sc = self.ops.search(self.index, queries, q_lambdas, k, alpha)
         idx = idx if torch.is_tensor(idx) else torch.from_numpy(np.asarray(idx).astype(np.int64))
         sc = sc if torch.is_tensor(sc) else torch.from_numpy(np.asarray(sc))
-        if self.world == 1:
+        if not _collectives_on(self.world):
             return idx, sc
         nq, kk = idx.shape
         kmax = torch.tensor([kk], dtype=torch.int64, device=idx.device)

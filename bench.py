@@ -94,7 +94,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # ARROWSPACE_DIST_FORCE=1 under a one-rank torch.distributed.run: the RCCL path on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("ARROWSPACE_DIST_FORCE") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -123,7 +125,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +162,7 @@ def main():
     sync()
     t_all = time.perf_counter() - t_all0
     times = torch.tensor([t_all, t_build, t_search], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     t_all, t_build, t_search = [float(x) for x in times]
     prof = ctx.profile_all()
@@ -243,7 +245,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, lambda a, b: X_host[a:b], cent, n)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

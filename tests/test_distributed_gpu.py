@@ -74,3 +74,56 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, n):
             oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
             assert np.array_equal(r["idx"][j], oi.astype(np.int64))
             assert np.array_equal(r["sc"][j], osc)
+
+
+def _rccl_worker(rank, world, port, n, d, out_dir):
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ARROWSPACE_DIST_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        ctx = A.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+        sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X).cuda(), n, gp, A.TauMode.Median)
+        for _ in range(3):  # repeated: collectives and kernels interleave on the streams
+            csr = sas.build_item_graph().to_host()
+            sas.build_lambdas(cent)
+            Q = torch.from_numpy(X[[1, n // 2, n - 1, 77]] * 1.02).cuda()
+            lq = sas.prepare_queries(Q)
+            idx, sc = sas.search(Q, lq, 10, 0.7)
+        dist.barrier()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rccl.npz"), indptr=csr[0], indices=csr[1], data=csr[2],
+                 lam=sas.lambdas.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
+                 stats=np.array(sas.lambda_stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collectives_match_oracle(tmp_path):
+    """backend "nccl" (= RCCL) with ONE rank and the exchange steps forced on: every collective of the sharded
+    driver (all-gather of f64 row blocks, i64 / f64 neighbour tables and top-k pairs, min/sum all-reduce,
+    barrier) runs through RCCL on device tensors, ordered against the HIP kernels on the context's stream."""
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    n, d = 5000, 64
+    mp.spawn(_rccl_worker, args=(1, _free_port(), n, d, str(tmp_path)), nprocs=1, join=True)
+    X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
+    csr = O.build_laplacian(X, gp)
+    lam = O.taumode_lambdas(X, O.build_laplacian(np.ascontiguousarray(cent.T), gp), O.TAU_MEDIAN)
+    r = np.load(tmp_path / "rccl.npz")
+    assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
+    np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
+    np.testing.assert_allclose(r["lam"], lam, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(r["stats"], [lam.min(), lam.max(), lam.mean()], rtol=1e-10)
+    Q = X[[1, n // 2, n - 1, 77]] * 1.02
+    for j in range(4):
+        oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
+        assert np.array_equal(r["idx"][j], oi.astype(np.int64))
+        assert np.array_equal(r["sc"][j], osc)
