@@ -69,6 +69,7 @@ class HipOps:
         asp = A.ArrowSpace(items, taumode, self.ctx)
         asp.update_lambdas(lambdas)
         asp.id_offset = int(id_offset)
+        asp._ensure_index()  # as_index_create (residency + exact row norms) belongs to the build, not to the first search
         return asp
 
     def search(self, index, queries, q_lambdas, k, alpha):
