@@ -208,6 +208,11 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "debug") ctx->opt_debug = value;
   else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;
   else if (n == "lambda_v3") ctx->opt_lambda_v3 = value;
+  else if (n == "knn_join") ctx->opt_knn_join = value;
+  else if (n == "join_sample") ctx->opt_join_sample = value;
+  else if (n == "join_rank") ctx->opt_join_rank = value;
+  else if (n == "join_cap") ctx->opt_join_cap = value;
+  else if (n == "join_min_rows") ctx->opt_join_min_rows = value;
   else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);

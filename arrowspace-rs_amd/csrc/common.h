@@ -45,6 +45,11 @@ struct as_ctx {
   int64_t opt_waves_per_simd = 2; // f32 candidate pass: 2 = 8 waves x 32 rows, 1 = 4 waves x 64 rows
   int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
   int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
+  int64_t opt_knn_join = 1;       // item graph over the whole matrix: symmetric threshold join (mfma_join_f32.hip)
+  int64_t opt_join_sample = 16;   // thresholds come from a 1-in-N sample of the rows ...
+  int64_t opt_join_rank = 5;      // ... as the m-th best sampled product of every row
+  int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
+  int64_t opt_join_min_rows = 32768;
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // stats of the last call

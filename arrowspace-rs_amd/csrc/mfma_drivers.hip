@@ -207,6 +207,208 @@ static int read_u32(as_ctx *ctx, const uint32_t *dev, uint32_t *host) {
   return AS_OK;
 }
 
+// ---- threshold join (mfma_join_f32.hip): thresholds, exact re-rank, stage driver ------------------
+// hashed 1-in-`rate` sample of the rows: id = rate * t + hash(t) % rate (a plain stride would alias
+// with periodic row orders)
+__global__ void sample_ids_kernel(uint32_t ns, uint32_t rate, uint32_t *__restrict__ ids) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ns) return;
+  uint32_t h = t * 2654435761u;
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+  ids[t] = rate * t + h % rate;
+}
+
+// theta[r] = the m-th best approximate cosine of row r against the sample (the value whose rank among ALL
+// rows is about m * rate); padding rows get +inf so that nothing is ever appended for them
+__global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_t *__restrict__ cidx, uint32_t n,
+                                  uint32_t KC, uint32_t m, uint32_t n_pad, float *__restrict__ theta) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_pad) return;
+  float t = __builtin_inff();
+  if (r < n) {
+    const size_t o = (size_t)r * KC + (m - 1);
+    t = cidx[o] != kNoIdx ? (float)(-ckey[o]) : -__builtin_inff();
+  }
+  theta[r] = t;
+}
+
+// candidates per row: total, maximum, rows over capacity (diagnostics for the threshold choice)
+__global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t cap,
+                                        unsigned long long *__restrict__ out) {
+  unsigned long long sum = 0, mx = 0, over = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t c = cnt[i];
+    sum += c;
+    mx = c > mx ? c : mx;
+    over += c > cap ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 64);
+    over += __shfl_xor(over, o, 64);
+    const unsigned long long t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, sum);
+    atomicMax(out + 1, mx);
+    atomicAdd(out + 2, over);
+  }
+}
+
+// Exact re-rank of the joined candidates of every row (one wave per row), certification against theta.
+template <class Policy, class Bound>
+__global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restrict__ X, uint32_t d, uint32_t n,
+                                                          const float *__restrict__ theta,
+                                                          const uint32_t *__restrict__ cnt,
+                                                          const uint32_t *__restrict__ cand, uint32_t cap, uint32_t K,
+                                                          const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd,
+                                                          double *__restrict__ out_key, uint32_t *__restrict__ out_idx,
+                                                          uint32_t *__restrict__ fail_rows,
+                                                          uint32_t *__restrict__ fail_count, int *__restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *xrow = reinterpret_cast<double *>(smem) + (size_t)wv * (d + cap);
+  double *ek = xrow + d;
+  uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(smem) + (size_t)4 * (d + cap)) + (size_t)wv * cap;
+  for (uint32_t r = blockIdx.x * 4 + wv; r < n; r += gridDim.x * 4) {
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)r * d + k];
+    const uint32_t total = cnt[r];
+    const uint32_t C = min(total, cap);
+    wave_sync();
+    for (uint32_t c = lane; c < C; c += 64) {
+      const uint32_t j = cand[(size_t)r * cap + c];
+      const double *bj = X + (uint64_t)j * d;
+      double acc = 0.0;
+      for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
+      double key = __builtin_inf(), kx;
+      uint32_t id = kNoIdx;
+      if (pol.key(acc, r, j, kx, err_flag)) {
+        key = kx;
+        id = j;
+      }
+      ek[c] = key;
+      ei[c] = id;
+    }
+    wave_sync();
+    double kth = -__builtin_inf();
+    uint32_t n_valid = 0;
+    for (uint32_t c = lane; c < C; c += 64) {
+      const double kc = ek[c];
+      const uint32_t ic = ei[c];
+      if (ic == kNoIdx) continue;
+      ++n_valid;
+      uint32_t rank = 0;
+      for (uint32_t c2 = 0; c2 < C; ++c2) rank += lex_less(ek[c2], ei[c2], kc, ic) ? 1u : 0u;
+      if (rank < K) {
+        out_key[(uint64_t)r * K + rank] = kc;
+        out_idx[(uint64_t)r * K + rank] = ic;
+        kth = fmax(kth, kc);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      kth = fmax(kth, __shfl_xor(kth, o, 64));
+      n_valid += __shfl_xor(n_valid, o, 64);
+    }
+    for (uint32_t s = n_valid + lane; s < K; s += 64) {
+      out_key[(uint64_t)r * K + s] = __builtin_inf();
+      out_idx[(uint64_t)r * K + s] = kNoIdx;
+    }
+    // every pair that is not in the list has an approximate cosine below theta[r]
+    bool ok = total <= cap && n_valid >= K && kth < bnd.lower_bound(-(double)theta[r]);
+    if (force_exact && force_exact[r]) ok = false;
+    if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    wave_sync();
+  }
+}
+
+int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count,
+             const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
+             const char *prof_name);
+
+// Stage 1 of the item graph when the row range is the whole matrix: thresholds from a sampled top-k pass,
+// symmetric threshold join, exact re-rank.  Rows that are not certified are listed in fail1.
+static int knn_join_stage(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K,
+                          int rectify, const uint8_t *force, GraphDistPolicy pol, uint32_t *out_idx, double *out_dist,
+                          uint32_t *fail1, uint32_t *fail_count, int *err, uint32_t *n_fail_out) {
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
+  const uint32_t b_alloc = (b_tiles + 1) & ~1u;
+  const uint32_t T2 = b_alloc / 2;
+  const uint32_t rate = (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample);
+  const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
+  const uint32_t cap = (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_join_cap, 1024));
+  DevBuf<float> P, theta;
+  AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
+  AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
+  AS_TRY(theta.alloc(ctx, (size_t)T2 * 256));
+  {
+    const uint32_t ns = n / rate;
+    const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows, s_alloc = (s_tiles + 1) & ~1u;
+    const uint32_t KC0 = std::max(8u, (m + 7) / 8 * 8);
+    DevBuf<uint32_t> sid, cidx;
+    DevBuf<float> S;
+    DevBuf<double> ckey;
+    AS_TRY(sid.alloc(ctx, ns));
+    hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sid.p);
+    AS_TRY(S.alloc(ctx, packed_elems(s_alloc, d)));
+    AS_TRY(pack_f32(ctx, rows, norms, sid.p, 0, ns, d, S.p, s_alloc));
+    AS_TRY(ckey.alloc(ctx, (size_t)n * KC0));
+    AS_TRY(cidx.alloc(ctx, (size_t)n * KC0));
+    CandProblem pb0{};
+    pb0.mode = 0;
+    pb0.A = rows;
+    pb0.a_norms = norms;
+    pb0.arows = ARows{nullptr, 0};
+    pb0.nA = n;
+    pb0.B = rows;
+    pb0.b_norms = norms;
+    pb0.nB = ns;
+    pb0.d = d;
+    pb0.KC = KC0;
+    pb0.splits = 1;
+    pb0.cand_key = ckey.p;
+    pb0.cand_idx = cidx.p;
+    AS_TRY(candidates_f32(ctx, pb0, P.p, b_tiles, S.p, s_tiles, "knn_join_thresholds"));
+    hipLaunchKernelGGL(join_theta_kernel, dim3(cdiv((uint64_t)T2 * 256, 256)), dim3(256), 0, ctx->stream, ckey.p, cidx.p, n,
+                       KC0, m, T2 * 256, theta.p);
+    AS_HIP(ctx, hipGetLastError());
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sampled-pass buffers go back to the workspace cache
+  }
+  DevBuf<uint32_t> cnt, cand, unitc;
+  AS_TRY(cnt.alloc(ctx, n));
+  AS_TRY(cand.alloc(ctx, (size_t)n * cap));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * n, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_TRY(join_f32(ctx, P.p, n, d, 0, T2, theta.p, cap, cnt.p, cand.p, unitc.p, "knn_mfma_join_f32"));
+  {
+    GraphBound bnd{cos_delta_f32(d), rectify};
+    const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
+    ProfScope ps(ctx, "knn_rerank");
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(n, 4), 8192)), dim3(256),
+                       lds, ctx->stream, rows, d, n, theta.p, cnt.p, cand.p, cap, K, force, pol, bnd, out_dist, out_idx,
+                       fail1, fail_count, err);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  {  // statistics: candidates per row
+    DevBuf<unsigned long long> st;
+    AS_TRY(st.alloc(ctx, 3));
+    AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, cnt.p, n, cap, st.p);
+    unsigned long long h[3] = {0, 0, 0};
+    AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
+    ctx->stats["knn_join_cap"] = cap;
+    ctx->stats["knn_join_candidates"] = (int64_t)h[0];
+    ctx->stats["knn_join_max_per_row"] = (int64_t)h[1];
+    ctx->stats["knn_join_overflow_rows"] = (int64_t)h[2];
+  }
+  AS_TRY(read_u32(ctx, fail_count, n_fail_out));
+  return AS_OK;
+}
+
 // ---- K2 driver ----------------------------------------------------------------------------------
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64, uint64_t d64, uint64_t row_begin,
              uint64_t row_count64, uint32_t K, int rectify, uint32_t *out_idx, double *out_dist) {
@@ -264,7 +466,14 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   PackedF32 B32, A32;
   PackedF64 B64, A64;
   uint32_t n_fail = 0;
-  {
+  // whole-matrix range at dim <= 128: symmetric threshold join (half the contractions)
+  const bool use_join = use_f32 && !wide && ctx->opt_knn_join && !ctx->opt_debug && row_begin == 0 && row_count == n &&
+                        n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows);
+  ctx->stats["knn_join"] = use_join ? 1 : 0;
+  if (use_join) {
+    AS_TRY(knn_join_stage(ctx, rows, norms, n, d, K, rectify, force.p, pol, out_idx, out_dist, fail1.p, fail_count.p,
+                          err.p, &n_fail));
+  } else {
     const uint32_t item_rows = use_f32 ? 2 * kTileRows : kTileRows;  // A rows per work item
     const uint32_t a_tiles_all = (row_count + kTileRows - 1) / kTileRows;
     const float *PA32 = nullptr;
@@ -339,70 +548,102 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   }
   ctx->stats["knn_uncertified_rows"] = n_fail;
+  ctx->stats["knn_uncertified_rows_stage1b"] = 0;
   ctx->stats["knn_uncertified_rows_stage2"] = 0;
   ctx->stats["knn_cand_capacity"] = KC;
   ctx->stats["knn_col_splits"] = pb.splits;
   if (n_fail == 0) return AS_OK;
 
-  // global ids of the failed rows
+  // Failed rows go through the stages that follow, each on the gathered list of what the one before
+  // could not certify: (after the join only) the f32 top-k pass, the f64 MFMA pass, the exact scan.
+  // cur_ids = global ids of the rows still open, cur_pos = their positions in the output range.
   DevBuf<uint32_t> gids;
   AS_TRY(gids.alloc(ctx, n_fail));
   hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream,
                      (const uint32_t *)nullptr, fail1.p, n_fail, (uint32_t)row_begin, gids.p);
-  const uint32_t *exact_ids = gids.p;      // rows for the exact scan ...
-  const uint32_t *exact_pos = fail1.p;     // ... and where their results go (row positions in the range)
-  uint32_t n_exact = n_fail;
-  DevBuf<uint32_t> fail2, gids2, pos2;
+  const uint32_t *cur_ids = gids.p;
+  const uint32_t *cur_pos = fail1.p;
+  uint32_t cur_n = n_fail;
+  DevBuf<uint32_t> ids_a, pos_a, ids_b, pos_b;
 
-  // ---- stage 2: f64 MFMA over the gathered failed rows ----
-  if (use_f32 && !wide && n_fail > kExactDirect) {
-    const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
-    pb.arows = ARows{gids.p, 0};
-    pb.nA = n_fail;
-    pb.splits = pick_splits(a_tiles, b_tiles);
-    DevBuf<double> ckey, A64, ok;
-    DevBuf<uint32_t> cidx, oi;
-    AS_TRY(ckey.alloc(ctx, (size_t)n_fail * pb.splits * KC));
-    AS_TRY(cidx.alloc(ctx, (size_t)n_fail * pb.splits * KC));
+  auto mfma_stage = [&](bool f32, DevBuf<uint32_t> &ids_out, DevBuf<uint32_t> &pos_out, const char *stat) -> int {
+    const uint32_t a_tiles = (cur_n + kTileRows - 1) / kTileRows;
+    pb.arows = ARows{cur_ids, 0};
+    pb.nA = cur_n;
+    pb.splits = pick_splits(f32 ? (a_tiles + 1) / 2 : a_tiles, b_tiles);
+    DevBuf<double> ckey, ok, A64g;
+    DevBuf<uint32_t> cidx, oi, failx;
+    DevBuf<float> A32g;
+    AS_TRY(ckey.alloc(ctx, (size_t)cur_n * pb.splits * KC));
+    AS_TRY(cidx.alloc(ctx, (size_t)cur_n * pb.splits * KC));
     pb.cand_key = ckey.p;
     pb.cand_idx = cidx.p;
-    AS_TRY(B64.buf.alloc(ctx, packed_elems(b_alloc, d)));
-    AS_TRY(pack_f64(ctx, rows, norms, nullptr, 0, n, d, B64.buf.p, b_alloc));
-    AS_TRY(A64.alloc(ctx, packed_elems(a_tiles, d)));
-    AS_TRY(pack_f64(ctx, rows, norms, gids.p, 0, n_fail, d, A64.p, a_tiles));
-    AS_TRY(candidates_f64(ctx, pb, A64.p, a_tiles, B64.buf.p, b_tiles, "knn_mfma_candidates"));
-    AS_TRY(ok.alloc(ctx, (size_t)n_fail * K));
-    AS_TRY(oi.alloc(ctx, (size_t)n_fail * K));
-    AS_TRY(fail2.alloc(ctx, n_fail));
+    if (f32) {
+      if (!B32.p) {
+        AS_TRY(B32.buf.alloc(ctx, packed_elems(b_alloc, d)));
+        AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, B32.buf.p, b_alloc));
+        B32.p = B32.buf.p;
+      }
+      const uint32_t at = (a_tiles + 1) & ~1u;
+      AS_TRY(A32g.alloc(ctx, packed_elems(at, d)));
+      AS_TRY(pack_f32(ctx, rows, norms, cur_ids, 0, cur_n, d, A32g.p, at));
+      AS_TRY(candidates_f32(ctx, pb, A32g.p, a_tiles, B32.p, b_tiles, "knn_mfma_candidates_f32"));
+    } else {
+      if (!B64.p) {
+        AS_TRY(B64.buf.alloc(ctx, packed_elems(b_alloc, d)));
+        AS_TRY(pack_f64(ctx, rows, norms, nullptr, 0, n, d, B64.buf.p, b_alloc));
+        B64.p = B64.buf.p;
+      }
+      AS_TRY(A64g.alloc(ctx, packed_elems(a_tiles, d)));
+      AS_TRY(pack_f64(ctx, rows, norms, cur_ids, 0, cur_n, d, A64g.p, a_tiles));
+      AS_TRY(candidates_f64(ctx, pb, A64g.p, a_tiles, B64.p, b_tiles, "knn_mfma_candidates"));
+    }
+    AS_TRY(ok.alloc(ctx, (size_t)cur_n * K));
+    AS_TRY(oi.alloc(ctx, (size_t)cur_n * K));
+    AS_TRY(failx.alloc(ctx, cur_n));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-    GraphBound bnd{cos_delta_f64(d), rectify};
-    AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, gids.p, 0u, n_fail, 0u, K, KC, pb.splits, ckey.p, cidx.p,
-                         force.p, pol, bnd, ok.p, oi.p, fail2.p, fail_count.p, err.p));
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_fail * K, 256)), dim3(256), 0, ctx->stream, fail1.p,
-                       n_fail, K, ok.p, oi.p, out_dist, out_idx);
-    uint32_t n_fail2 = 0;
-    AS_TRY(read_u32(ctx, fail_count.p, &n_fail2));
-    ctx->stats["knn_uncertified_rows_stage2"] = n_fail2;
-    if (n_fail2 == 0) return AS_OK;
-    AS_TRY(gids2.alloc(ctx, n_fail2));
-    AS_TRY(pos2.alloc(ctx, n_fail2));
-    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail2, 256)), dim3(256), 0, ctx->stream, gids.p, fail2.p, n_fail2,
-                       0u, gids2.p);
-    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail2, 256)), dim3(256), 0, ctx->stream, fail1.p, fail2.p,
-                       n_fail2, 0u, pos2.p);
-    exact_ids = gids2.p;
-    exact_pos = pos2.p;
-    n_exact = n_fail2;
+    GraphBound bnd{f32 ? cos_delta_f32(d) : cos_delta_f64(d), rectify};
+    AS_TRY(launch_rerank(ctx, "knn_rerank", rows, rows, d, cur_ids, 0u, cur_n, 0u, K, KC, pb.splits, ckey.p, cidx.p,
+                         force.p, pol, bnd, ok.p, oi.p, failx.p, fail_count.p, err.p));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)cur_n * K, 256)), dim3(256), 0, ctx->stream, cur_pos,
+                       cur_n, K, ok.p, oi.p, out_dist, out_idx);
+    uint32_t n_next = 0;
+    AS_TRY(read_u32(ctx, fail_count.p, &n_next));
+    ctx->stats[stat] = n_next;
+    if (n_next) {
+      AS_TRY(ids_out.alloc(ctx, n_next));
+      AS_TRY(pos_out.alloc(ctx, n_next));
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_ids, failx.p, n_next,
+                         0u, ids_out.p);
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_pos, failx.p, n_next,
+                         0u, pos_out.p);
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // failx goes back to the workspace cache
+      cur_ids = ids_out.p;
+      cur_pos = pos_out.p;
+    }
+    cur_n = n_next;
+    return AS_OK;
+  };
+
+  // ---- stage 1b (after the join): f32 top-k pass over the gathered rows ----
+  if (use_join && cur_n > kExactDirect) {
+    AS_TRY(mfma_stage(true, ids_a, pos_a, "knn_uncertified_rows_stage1b"));
+    if (cur_n == 0) return AS_OK;
+  }
+  // ---- stage 2: f64 MFMA over the gathered rows ----
+  if (use_f32 && !wide && cur_n > kExactDirect) {
+    AS_TRY(mfma_stage(false, ids_b, pos_b, "knn_uncertified_rows_stage2"));
+    if (cur_n == 0) return AS_OK;
   }
 
   // ---- last stage: exact scan ----
   DevBuf<double> fk;
   DevBuf<uint32_t> fi;
-  AS_TRY(fk.alloc(ctx, (size_t)n_exact * K));
-  AS_TRY(fi.alloc(ctx, (size_t)n_exact * K));
-  AS_TRY(knn_exact(ctx, rows, norms, n, d, exact_ids, 0, n_exact, K, rectify, fi.p, fk.p, 0));
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_exact * K, 256)), dim3(256), 0, ctx->stream, exact_pos,
-                     n_exact, K, fk.p, fi.p, out_dist, out_idx);
+  AS_TRY(fk.alloc(ctx, (size_t)cur_n * K));
+  AS_TRY(fi.alloc(ctx, (size_t)cur_n * K));
+  AS_TRY(knn_exact(ctx, rows, norms, n, d, cur_ids, 0, cur_n, K, rectify, fi.p, fk.p, 0));
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)cur_n * K, 256)), dim3(256), 0, ctx->stream, cur_pos,
+                     cur_n, K, fk.p, fi.p, out_dist, out_idx);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }

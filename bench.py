@@ -177,10 +177,27 @@ def main():
         roofline = None
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
+        msj, lj = prof.get("knn_mfma_join_f32", (0.0, 0))
         # the candidate pass of one step may be split into a bulk launch and a remainder launch:
         # "launch" below = all candidate launches of one step (their flops add up to flops_per_launch)
         l32, l64 = min(l32, steps), min(l64, steps)
-        if l32 and ms32 >= ms64:   # dominant kernel: the f32-input MFMA candidate pass
+        if lj and msj >= max(ms32, ms64):
+            # dominant kernel: the symmetric threshold join.  cos(i,j) = cos(j,i): every unordered pair of 256-row
+            # tiles is contracted once, so the launch EXECUTES half of the algorithmic 2 n^2 d (plus the diagonal
+            # blocks); `achieved` / `frac` price the kernel on what it executes, the reference-equivalent rate
+            # (what the reference's full square would need) is given next to it
+            t2 = (n + 255) // 256
+            pairs = t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)   # 256 x 256 blocks visited
+            executed = 2.0 * pairs * 256 * 256 * d
+            achieved = executed / (msj / lj * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc, symmetric "
+                                                   "threshold join; exact f64 re-rank + certification follow)",
+                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_ms": msj / lj, "launches": lj, "executed_flops_per_launch": executed,
+                        "algorithmic_flops_per_launch": flops_per_launch,
+                        "reference_equivalent_TFLOPs": flops_per_launch / (msj / lj * 1e-3) / 1e12}
+        elif l32 and ms32 >= ms64:   # dominant kernel: the f32-input MFMA candidate pass
             achieved = flops_per_launch / (ms32 / l32 * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc; "
                                                    "exact f64 re-rank + certification follow)",
@@ -200,7 +217,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if roofline and world == 1 and (n, d) == (1_000_000, 128) and "mfma32" in roofline["kernel"]:
+            if roofline and world == 1 and (n, d) == (1_000_000, 128) and pmc.get("dominant_kernel", "pair_topk_mfma32") in roofline["kernel"]:
                 roofline["traffic"] = pmc["hbm_bytes_per_step"]
                 roofline["traffic_source"] = "profiles/r01c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except (OSError, KeyError, ValueError):
@@ -224,7 +241,8 @@ def main():
                 extra["roofline_scan"]["traffic_source"] = "profiles/r01c_pmc_traffic.json"
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
-            "candidate_precision": "f32 MFMA -> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)"
+            "candidate_precision": ("f32 MFMA (symmetric threshold join on one GPU, top-k pass when sharded) -> f32 top-k "
+                                    "-> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)")
             if args.cand_precision == 32 else "f64 MFMA -> exact f64 scan",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -237,6 +255,7 @@ def main():
             "search_qps": nq / search_s, "build_ms": build_s * 1e3, "search_ms": search_s * 1e3,
             "item_graph_nnz": int(state.get("nnz", -1)),
             "knn_uncertified_rows": ctx.stat("knn_uncertified_rows"),
+            "knn_join": ctx.stat("knn_join"), "knn_join_candidates_per_row": ctx.stat("knn_join_candidates") / max(1, rows_here),
             "search_uncertified_rows": ctx.stat("search_uncertified_rows"),
             "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items())},
             "roofline": roofline,
