@@ -18,6 +18,7 @@ EXPORTS = [
     "as_abi_version", "as_ctx_create", "as_ctx_destroy", "as_last_error", "as_status_message", "as_ctx_set_stream",
     "as_ctx_synchronize", "as_ctx_set_option", "as_ctx_get_stat", "as_profile_enable", "as_profile_reset",
     "as_profile_get", "as_profile_names", "as_define_result_k", "as_build_laplacian", "as_knn_cosine",
+    "as_knn_join_thresholds", "as_knn_join_capacity", "as_knn_join_pairs", "as_knn_join_finish",
     "as_laplacian_from_knn", "as_csr_n", "as_csr_nnz", "as_csr_export", "as_csr_import", "as_csr_free",
     "as_compute_taumode", "as_prepare_query_items", "as_select_tau", "as_index_create", "as_index_destroy",
     "as_index_nitems", "as_search_lambda_aware", "as_search_lambda_aware_hybrid", "as_range_search",
@@ -67,6 +68,11 @@ def load():
         "as_define_result_k": (u64, [u64, u64]),
         "as_build_laplacian": (i32, [vp, vp, u64, u64, C.POINTER(GraphParamsC), C.POINTER(vp)]),
         "as_knn_cosine": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, vp]),
+        "as_knn_join_thresholds": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp]),
+        "as_knn_join_capacity": (C.c_uint32, [vp, C.POINTER(GraphParamsC)]),
+        "as_knn_join_pairs": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, C.c_uint32, vp, vp]),
+        "as_knn_join_finish": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, C.c_uint32, C.c_uint32, vp, vp,
+                                     vp, vp]),
         "as_laplacian_from_knn": (i32, [vp, vp, vp, u64, C.POINTER(GraphParamsC), C.POINTER(vp)]),
         "as_csr_n": (u64, [vp]),
         "as_csr_nnz": (u64, [vp]),

@@ -23,10 +23,11 @@ I64_NONE = -1  # UINT64_MAX seen through int64
 
 
 def shard_range(n, rank, world):
-    """Contiguous row range of `rank`; shard starts are multiples of 128 (the MFMA row tile) so
-    every rank's A-side reads the shared packed image in place."""
+    """Contiguous row range of `rank`; shard starts are multiples of 256 (the row tile of the MFMA
+    passes: every rank's A side reads the shared packed image in place, and the tile pairs of the
+    symmetric join are owned by whole 256-row tiles)."""
     per = (n + world - 1) // world
-    per = (per + 127) // 128 * 128
+    per = (per + 255) // 256 * 256
     lo = min(n, rank * per)
     hi = min(n, lo + per)
     return lo, hi
@@ -48,6 +49,45 @@ class HipOps:
         A._adopt_torch_stream(self.ctx)
         self.ctx.check(self.ctx.lib.as_knn_cosine(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
                                                   ptr(idx), ptr(dst)))
+        return idx, dst
+
+    # -- symmetric threshold join, sharded form (include/arrowspace_hip.h: as_knn_join_*) --
+    def join_thresholds(self, X_full, row_begin, row_count, gp):
+        """Thresholds of this rank's rows, or None when the join does not apply to this problem."""
+        import ctypes as C
+        from ._lib import AS_ERR_UNSUPPORTED
+        n, d = X_full.shape
+        theta = torch.empty(row_count, dtype=torch.float32, device=X_full.device)
+        c = gp.to_c()
+        A._adopt_torch_stream(self.ctx)
+        rc = self.ctx.lib.as_knn_join_thresholds(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c), ptr(theta))
+        if rc == AS_ERR_UNSUPPORTED:
+            return None
+        self.ctx.check(rc)
+        return theta
+
+    def join_pairs(self, X_full, row_begin, row_count, gp, theta_all):
+        import ctypes as C
+        n, d = X_full.shape
+        c = gp.to_c()
+        cap = int(self.ctx.lib.as_knn_join_capacity(self.ctx.h, C.byref(c)))
+        cnt = torch.empty(n, dtype=torch.int32, device=X_full.device)
+        cand = torch.empty((n, cap), dtype=torch.int32, device=X_full.device)
+        self.ctx.check(self.ctx.lib.as_knn_join_pairs(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
+                                                      ptr(theta_all), cap, ptr(cnt), ptr(cand)))
+        return cnt, cand
+
+    def join_finish(self, X_full, row_begin, row_count, gp, theta_all, cnt_src, cand_src):
+        import ctypes as C
+        n, d = X_full.shape
+        K = gp.topk + 1
+        n_src, cap = int(cand_src.shape[0]), int(cand_src.shape[2])
+        idx = torch.empty((row_count, K), dtype=torch.int64, device=X_full.device)
+        dst = torch.empty((row_count, K), dtype=torch.float64, device=X_full.device)
+        c = gp.to_c()
+        self.ctx.check(self.ctx.lib.as_knn_join_finish(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
+                                                       ptr(theta_all), n_src, cap, ptr(cnt_src.contiguous()),
+                                                       ptr(cand_src.contiguous()), ptr(idx), ptr(dst)))
         return idx, dst
 
     def laplacian_from_knn(self, idx, dist_, gp):
@@ -132,6 +172,26 @@ def all_gather_rows(t, sizes):
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+def exchange_row_blocks(t, sizes):
+    """t: [n, ...] indexed by GLOBAL row on every rank.  Returns [world, sizes[rank], ...]: from every rank
+    the slice of this rank's rows (all-to-all; RCCL over xGMI on the GPU box)."""
+    rank, world = _world()
+    starts = [sum(sizes[:r]) for r in range(world)]
+    mine = sizes[rank]
+    if not _collectives_on(world):
+        return t[starts[rank]: starts[rank] + mine].unsqueeze(0)
+    tail = tuple(t.shape[1:])
+    if _host_staged():  # gloo (tests): gather everything through the host, keep this rank's rows
+        tc = t.cpu().contiguous()
+        parts = [torch.empty_like(tc) for _ in range(world)]
+        dist.all_gather(parts, tc)
+        out = torch.stack([p[starts[rank]: starts[rank] + mine] for p in parts], 0)
+        return out.to(t.device)
+    out = torch.empty((world * mine,) + tail, dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(out, t.contiguous(), output_split_sizes=[mine] * world, input_split_sizes=list(sizes))
+    return out.view((world, mine) + tail)
+
+
 class ShardedArrowSpace:
     """The row-sharded counterpart of (ArrowSpace, GraphLaplacian) for one rank."""
 
@@ -150,7 +210,19 @@ class ShardedArrowSpace:
     # -- item graph: n x n Laplacian over the items (build_laplacian_matrix on untransposed rows)
     def build_item_graph(self):
         X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
-        idx, dst = self.ops.knn_rows(X_full, self.lo, self.hi - self.lo, self.gp)
+        rows_here = self.hi - self.lo
+        theta = self.ops.join_thresholds(X_full, self.lo, rows_here, self.gp) \
+            if hasattr(self.ops, "join_thresholds") and rows_here > 0 and _collectives_on(self.world) else None
+        if theta is not None:
+            # symmetric threshold join: every pair of 256-row tiles is contracted once, on the rank that owns
+            # one of the two; thresholds are all-gathered, candidate lists go to the owners of their rows
+            theta_all = all_gather_rows(theta.reshape(-1, 1), self.sizes).reshape(-1).contiguous()
+            cnt, cand = self.ops.join_pairs(X_full, self.lo, rows_here, self.gp, theta_all)
+            cnt_src = exchange_row_blocks(cnt, self.sizes)                # RCCL all-to-all
+            cand_src = exchange_row_blocks(cand, self.sizes)
+            idx, dst = self.ops.join_finish(X_full, self.lo, rows_here, self.gp, theta_all, cnt_src, cand_src)
+        else:
+            idx, dst = self.ops.knn_rows(X_full, self.lo, rows_here, self.gp)
         idx_all = all_gather_rows(idx, self.sizes)                        # RCCL all-gather #2
         dst_all = all_gather_rows(dst, self.sizes)
         return self.ops.laplacian_from_knn(idx_all, dst_all, self.gp)     # replicated assembly

@@ -299,6 +299,76 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
   return AS_OK;
 }
 
+// ---- row-sharded form of the symmetric threshold join (see include/arrowspace_hip.h) ----------------
+static int join_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, uint64_t row_begin, uint64_t row_count,
+                     const as_graph_params *params) {
+  AS_TRY(check_ctx(ctx));
+  AS_TRY(validate_graph_args(ctx, rows, n, d, params));
+  if (row_begin + row_count > n || row_count == 0) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
+  if (params->normalise) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join: normalise = true takes as_knn_cosine");
+  if (!is_device_ptr(rows)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join: rows must be resident in HBM");
+  return AS_OK;
+}
+
+int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                           uint64_t row_count, const as_graph_params *params, float *theta_out) {
+  AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
+  if (!theta_out || !is_device_ptr(theta_out)) return fail(ctx, AS_ERR_ARG, "theta_out must be a device pointer");
+  DevBuf<double> norms;
+  AS_TRY(norms.alloc(ctx, n_nodes));
+  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
+  return knn_join_thresholds(ctx, rows, norms.p, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin, (uint32_t)row_count,
+                             theta_out);
+}
+
+uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params) {
+  if (!ctx || !params) return 0;
+  return knn_join_cap(ctx, (uint32_t)params->topk + 1);
+}
+
+int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                      uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t cap,
+                      uint32_t *cnt, uint32_t *cand) {
+  AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
+  if (!theta_all || !cnt || !cand || !is_device_ptr(theta_all) || !is_device_ptr(cnt) || !is_device_ptr(cand))
+    return fail(ctx, AS_ERR_ARG, "theta_all / cnt / cand must be device pointers");
+  if (cap == 0) return fail(ctx, AS_ERR_ARG, "cap == 0");
+  DevBuf<double> norms;
+  AS_TRY(norms.alloc(ctx, n_nodes));
+  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
+  return knn_join_pairs(ctx, rows, norms.p, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin, (uint32_t)row_count,
+                        theta_all, cap, cnt, cand);
+}
+
+int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                       uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t n_src,
+                       uint32_t cap, const uint32_t *cnt_src, const uint32_t *cand_src, uint64_t *nbr_idx,
+                       double *nbr_dist) {
+  AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
+  if (!theta_all || !cnt_src || !cand_src || !nbr_idx || !nbr_dist || n_src == 0 || cap == 0)
+    return fail(ctx, AS_ERR_ARG, "null argument");
+  if (!is_device_ptr(theta_all) || !is_device_ptr(cnt_src) || !is_device_ptr(cand_src))
+    return fail(ctx, AS_ERR_ARG, "theta_all / cnt_src / cand_src must be device pointers");
+  const uint32_t K = (uint32_t)params->topk + 1;
+  DevBuf<double> norms;
+  AS_TRY(norms.alloc(ctx, n_nodes));
+  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
+  DevBuf<uint32_t> idx32;
+  AS_TRY(idx32.alloc(ctx, row_count * K));
+  DevOut<double> D;
+  AS_TRY(D.bind(ctx, nbr_dist, row_count * K));
+  DevOut<uint64_t> I;
+  AS_TRY(I.bind(ctx, nbr_idx, row_count * K));
+  const JoinSources js{theta_all, n_src, cap, cnt_src, cand_src};
+  AS_TRY(knn_mfma(ctx, rows, norms.p, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js));
+  hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
+                     row_count * K, 0ull, I.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(D.finish(ctx));
+  AS_TRY(I.finish(ctx));
+  return AS_OK;
+}
+
 int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
                           const as_graph_params *params, as_csr **out) {
   AS_TRY(check_ctx(ctx));

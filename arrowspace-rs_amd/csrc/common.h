@@ -311,10 +311,23 @@ int knn_exact(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, 
               const uint32_t *row_ids, uint64_t row_begin, uint64_t row_count, uint32_t K,
               int rectify, uint32_t *out_idx, double *out_dist, uint64_t out_stride_rows);
 
+// Candidate lists of a threshold join that has already been run (row-sharded build: every rank contracts
+// the tile pairs of its own super tiles, the lists are exchanged, each rank finishes its own rows).
+struct JoinSources {
+  const float *theta;     // thresholds of ALL rows (n)
+  uint32_t n_src, cap;    // lists per row, slots per list
+  const uint32_t *cnt;    // n_src x row_count
+  const uint32_t *cand;   // n_src x row_count x cap
+};
 // MFMA candidate pass + exact re-rank + certification + exact fall-back
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,
              uint64_t row_begin, uint64_t row_count, uint32_t K, int rectify, uint32_t *out_idx,
-             double *out_dist);
+             double *out_dist, const JoinSources *js = nullptr);
+int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
+                        uint32_t row_begin, uint32_t row_count, float *theta_out);
+int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
+                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand);
+uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K);
 
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,
                        uint32_t K, const as_graph_params *gp, as_csr **out);

@@ -234,6 +234,11 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
   theta[r] = t;
 }
 
+__global__ void pad_theta_kernel(const float *__restrict__ theta, uint32_t n, uint32_t n_pad, float *__restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_pad) out[r] = r < n ? theta[r] : __builtin_inff();
+}
+
 // candidates per row: total, maximum, rows over capacity (diagnostics for the threshold choice)
 __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t cap,
                                         unsigned long long *__restrict__ out) {
@@ -257,34 +262,51 @@ __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32
   }
 }
 
-// Exact re-rank of the joined candidates of every row (one wave per row), certification against theta.
+// Exact re-rank of the joined candidates of rows [row_begin, row_begin + row_count) (one wave per row),
+// certification against theta.  The candidates of a row come from n_src lists (one per rank that contracted
+// tile pairs touching it): cnt_src[s * row_count + r], cand_src[(s * row_count + r) * cap ..].
 template <class Policy, class Bound>
-__global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restrict__ X, uint32_t d, uint32_t n,
-                                                          const float *__restrict__ theta,
-                                                          const uint32_t *__restrict__ cnt,
-                                                          const uint32_t *__restrict__ cand, uint32_t cap, uint32_t K,
+__global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restrict__ X, uint32_t d, uint32_t row_begin,
+                                                          uint32_t row_count, const float *__restrict__ theta,
+                                                          uint32_t n_src, const uint32_t *__restrict__ cnt_src,
+                                                          const uint32_t *__restrict__ cand_src, uint32_t cap,
+                                                          uint32_t cmax, uint32_t K,
                                                           const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd,
                                                           double *__restrict__ out_key, uint32_t *__restrict__ out_idx,
                                                           uint32_t *__restrict__ fail_rows,
                                                           uint32_t *__restrict__ fail_count, int *__restrict__ err_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double *xrow = reinterpret_cast<double *>(smem) + (size_t)wv * (d + cap);
+  double *xrow = reinterpret_cast<double *>(smem) + (size_t)wv * (d + cmax);
   double *ek = xrow + d;
-  uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(smem) + (size_t)4 * (d + cap)) + (size_t)wv * cap;
-  for (uint32_t r = blockIdx.x * 4 + wv; r < n; r += gridDim.x * 4) {
-    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)r * d + k];
-    const uint32_t total = cnt[r];
-    const uint32_t C = min(total, cap);
+  uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(smem) + (size_t)4 * (d + cmax)) + (size_t)wv * cmax;
+  for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
+    const uint32_t a = row_begin + r;
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)a * d + k];
+    // gather the candidate ids of all sources into ei[0..C)
+    uint32_t C = 0;
+    bool overflow = false;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
+      const uint32_t total = cnt_src[(size_t)sidx * row_count + r];
+      uint32_t take = min(total, cap);
+      overflow = overflow || total > cap;
+      if (C + take > cmax) {
+        overflow = true;
+        take = cmax - C;
+      }
+      const uint32_t *src = cand_src + ((size_t)sidx * row_count + r) * cap;
+      for (uint32_t c = lane; c < take; c += 64) ei[C + c] = src[c];
+      C += take;
+    }
     wave_sync();
     for (uint32_t c = lane; c < C; c += 64) {
-      const uint32_t j = cand[(size_t)r * cap + c];
+      const uint32_t j = ei[c];
       const double *bj = X + (uint64_t)j * d;
       double acc = 0.0;
       for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
       double key = __builtin_inf(), kx;
       uint32_t id = kNoIdx;
-      if (pol.key(acc, r, j, kx, err_flag)) {
+      if (pol.key(acc, a, j, kx, err_flag)) {
         key = kx;
         id = j;
       }
@@ -315,9 +337,9 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
       out_key[(uint64_t)r * K + s] = __builtin_inf();
       out_idx[(uint64_t)r * K + s] = kNoIdx;
     }
-    // every pair that is not in the list has an approximate cosine below theta[r]
-    bool ok = total <= cap && n_valid >= K && kth < bnd.lower_bound(-(double)theta[r]);
-    if (force_exact && force_exact[r]) ok = false;
+    // every pair that is not in the lists has an approximate cosine below theta[a]
+    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[a]);
+    if (force_exact && force_exact[a]) ok = false;
     if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
     wave_sync();
   }
@@ -327,91 +349,86 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
 
-// Stage 1 of the item graph when the row range is the whole matrix: thresholds from a sampled top-k pass,
-// symmetric threshold join, exact re-rank.  Rows that are not certified are listed in fail1.
-static int knn_join_stage(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K,
-                          int rectify, const uint8_t *force, GraphDistPolicy pol, uint32_t *out_idx, double *out_dist,
-                          uint32_t *fail1, uint32_t *fail_count, int *err, uint32_t *n_fail_out) {
-  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
-  const uint32_t b_alloc = (b_tiles + 1) & ~1u;
-  const uint32_t T2 = b_alloc / 2;
+static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
+  return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && (d + 31) / 32 <= (uint32_t)kMaxNC &&
+         n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) && row_begin % 256 == 0;
+}
+
+// theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
+// hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
+int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
+                        uint32_t row_count, float *theta_out) {
+  if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t rate = (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample);
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
-  const uint32_t cap = (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_join_cap, 1024));
+  const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
+  const uint32_t ns = n / rate;
+  const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows, s_alloc = (s_tiles + 1) & ~1u;
+  const uint32_t KC0 = std::max(8u, (m + 7) / 8 * 8);
+  DevBuf<uint32_t> sid, cidx;
+  DevBuf<float> S, PA;
+  DevBuf<double> ckey;
+  AS_TRY(PA.alloc(ctx, packed_elems(a_alloc, d)));
+  AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
+  AS_TRY(sid.alloc(ctx, ns));
+  hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sid.p);
+  AS_TRY(S.alloc(ctx, packed_elems(s_alloc, d)));
+  AS_TRY(pack_f32(ctx, rows, norms, sid.p, 0, ns, d, S.p, s_alloc));
+  AS_TRY(ckey.alloc(ctx, (size_t)row_count * KC0));
+  AS_TRY(cidx.alloc(ctx, (size_t)row_count * KC0));
+  CandProblem pb0{};
+  pb0.mode = 0;
+  pb0.A = rows;
+  pb0.a_norms = norms;
+  pb0.arows = ARows{nullptr, row_begin};
+  pb0.nA = row_count;
+  pb0.B = rows;
+  pb0.b_norms = norms;
+  pb0.nB = ns;
+  pb0.d = d;
+  pb0.KC = KC0;
+  pb0.splits = 1;
+  pb0.cand_key = ckey.p;
+  pb0.cand_idx = cidx.p;
+  AS_TRY(candidates_f32(ctx, pb0, PA.p, a_tiles, S.p, s_tiles, "knn_join_thresholds"));
+  hipLaunchKernelGGL(join_theta_kernel, dim3(cdiv(row_count, 256)), dim3(256), 0, ctx->stream, ckey.p, cidx.p, row_count,
+                     KC0, m, row_count, theta_out);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  return AS_OK;
+}
+
+// Contracts the tile pairs owned by the super tiles of [row_begin, row_begin + row_count) and appends to
+// cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
+int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
+                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand) {
+  if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
+  const uint32_t T2 = b_alloc / 2;
+  const uint32_t I_begin = row_begin / 256;
+  const uint32_t I_end = (uint32_t)(((uint64_t)row_begin + row_count + 255) / 256);
   DevBuf<float> P, theta;
+  DevBuf<uint32_t> unitc;
   AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
   AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
   AS_TRY(theta.alloc(ctx, (size_t)T2 * 256));
-  {
-    const uint32_t ns = n / rate;
-    const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows, s_alloc = (s_tiles + 1) & ~1u;
-    const uint32_t KC0 = std::max(8u, (m + 7) / 8 * 8);
-    DevBuf<uint32_t> sid, cidx;
-    DevBuf<float> S;
-    DevBuf<double> ckey;
-    AS_TRY(sid.alloc(ctx, ns));
-    hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sid.p);
-    AS_TRY(S.alloc(ctx, packed_elems(s_alloc, d)));
-    AS_TRY(pack_f32(ctx, rows, norms, sid.p, 0, ns, d, S.p, s_alloc));
-    AS_TRY(ckey.alloc(ctx, (size_t)n * KC0));
-    AS_TRY(cidx.alloc(ctx, (size_t)n * KC0));
-    CandProblem pb0{};
-    pb0.mode = 0;
-    pb0.A = rows;
-    pb0.a_norms = norms;
-    pb0.arows = ARows{nullptr, 0};
-    pb0.nA = n;
-    pb0.B = rows;
-    pb0.b_norms = norms;
-    pb0.nB = ns;
-    pb0.d = d;
-    pb0.KC = KC0;
-    pb0.splits = 1;
-    pb0.cand_key = ckey.p;
-    pb0.cand_idx = cidx.p;
-    AS_TRY(candidates_f32(ctx, pb0, P.p, b_tiles, S.p, s_tiles, "knn_join_thresholds"));
-    hipLaunchKernelGGL(join_theta_kernel, dim3(cdiv((uint64_t)T2 * 256, 256)), dim3(256), 0, ctx->stream, ckey.p, cidx.p, n,
-                       KC0, m, T2 * 256, theta.p);
-    AS_HIP(ctx, hipGetLastError());
-    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sampled-pass buffers go back to the workspace cache
-  }
-  DevBuf<uint32_t> cnt, cand, unitc;
-  AS_TRY(cnt.alloc(ctx, n));
-  AS_TRY(cand.alloc(ctx, (size_t)n * cap));
+  hipLaunchKernelGGL(pad_theta_kernel, dim3(cdiv((uint64_t)T2 * 256, 256)), dim3(256), 0, ctx->stream, theta_all, n, T2 * 256,
+                     theta.p);
   AS_TRY(unitc.alloc(ctx, 1));
-  AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * n, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  AS_TRY(join_f32(ctx, P.p, n, d, 0, T2, theta.p, cap, cnt.p, cand.p, unitc.p, "knn_mfma_join_f32"));
-  {
-    GraphBound bnd{cos_delta_f32(d), rectify};
-    const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
-    ProfScope ps(ctx, "knn_rerank");
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(n, 4), 8192)), dim3(256),
-                       lds, ctx->stream, rows, d, n, theta.p, cnt.p, cand.p, cap, K, force, pol, bnd, out_dist, out_idx,
-                       fail1, fail_count, err);
-    AS_HIP(ctx, hipGetLastError());
-  }
-  {  // statistics: candidates per row
-    DevBuf<unsigned long long> st;
-    AS_TRY(st.alloc(ctx, 3));
-    AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, cnt.p, n, cap, st.p);
-    unsigned long long h[3] = {0, 0, 0};
-    AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
-    ctx->stats["knn_join_cap"] = cap;
-    ctx->stats["knn_join_candidates"] = (int64_t)h[0];
-    ctx->stats["knn_join_max_per_row"] = (int64_t)h[1];
-    ctx->stats["knn_join_overflow_rows"] = (int64_t)h[2];
-  }
-  AS_TRY(read_u32(ctx, fail_count, n_fail_out));
+  AS_TRY(join_f32(ctx, P.p, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
+}
+
+uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K) {
+  return (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_join_cap, 1024));
 }
 
 // ---- K2 driver ----------------------------------------------------------------------------------
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64, uint64_t d64, uint64_t row_begin,
-             uint64_t row_count64, uint32_t K, int rectify, uint32_t *out_idx, double *out_dist) {
+             uint64_t row_count64, uint32_t K, int rectify, uint32_t *out_idx, double *out_dist, const JoinSources *js) {
   const uint32_t n = (uint32_t)n64, d = (uint32_t)d64, row_count = (uint32_t)row_count64;
   const int NC = (int)((d + 31) / 32);
   // one extra slot: a row's own index is the best candidate of its list and is dropped by the re-rank
@@ -466,13 +483,52 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   PackedF32 B32, A32;
   PackedF64 B64, A64;
   uint32_t n_fail = 0;
-  // whole-matrix range at dim <= 128: symmetric threshold join (half the contractions)
-  const bool use_join = use_f32 && !wide && ctx->opt_knn_join && !ctx->opt_debug && row_begin == 0 && row_count == n &&
-                        n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows);
+  // dim <= 128: symmetric threshold join (half the contractions).  Either the caller has run the join and
+  // exchanged the candidate lists (row-sharded build: js), or the range is the whole matrix and it runs here.
+  const bool own_join = !js && use_f32 && !wide && !ctx->opt_debug && row_begin == 0 && row_count == n &&
+                        join_supported(ctx, n, d, 0);
+  const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
   if (use_join) {
-    AS_TRY(knn_join_stage(ctx, rows, norms, n, d, K, rectify, force.p, pol, out_idx, out_dist, fail1.p, fail_count.p,
-                          err.p, &n_fail));
+    DevBuf<float> theta_own;
+    DevBuf<uint32_t> cnt_own, cand_own;
+    JoinSources local{};
+    if (own_join) {
+      const uint32_t cap = knn_join_cap(ctx, K);
+      AS_TRY(theta_own.alloc(ctx, n));
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p));
+      AS_TRY(cnt_own.alloc(ctx, n));
+      AS_TRY(cand_own.alloc(ctx, (size_t)n * cap));
+      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p));
+      local = JoinSources{theta_own.p, 1, cap, cnt_own.p, cand_own.p};
+      js = &local;
+    }
+    {
+      const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
+      GraphBound bnd{cos_delta_f32(d), rectify};
+      const size_t lds = (size_t)4 * (d + cmax) * sizeof(double) + (size_t)4 * cmax * sizeof(uint32_t);
+      ProfScope ps(ctx, "knn_rerank");
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
+                         dim3(256), lds, ctx->stream, rows, d, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt,
+                         js->cand, js->cap, cmax, K, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p);
+      AS_HIP(ctx, hipGetLastError());
+    }
+    {  // statistics: candidates per row over all sources
+      DevBuf<unsigned long long> st;
+      AS_TRY(st.alloc(ctx, 3));
+      AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
+                         js->cap, st.p);
+      unsigned long long h[3] = {0, 0, 0};
+      AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
+      ctx->stats["knn_join_cap"] = js->cap;
+      ctx->stats["knn_join_candidates"] = (int64_t)h[0];
+      ctx->stats["knn_join_max_per_row"] = (int64_t)h[1];
+      ctx->stats["knn_join_overflow_rows"] = (int64_t)h[2];
+    }
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   } else {
     const uint32_t item_rows = use_f32 ? 2 * kTileRows : kTileRows;  // A rows per work item
     const uint32_t a_tiles_all = (row_count + kTileRows - 1) / kTileRows;

@@ -110,6 +110,32 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
                   uint64_t row_begin, uint64_t row_count, const as_graph_params *params,
                   uint64_t *nbr_idx, double *nbr_dist);
 
+/* Row-sharded form of the same neighbour search (one process per GPU).  cos(i,j) =
+ * cos(j,i): every unordered pair of 256-row tiles is contracted once, by the rank that owns one of the two
+ * tiles, and serves both rows -- so the candidate lists of a rank's rows are partly produced on other ranks.
+ * rows = ALL n_nodes rows in HBM (after the all-gather of the shards); [row_begin, row_begin + row_count) =
+ * this rank's rows, row_begin a multiple of 256.  All pointers below are device pointers.
+ *   1. as_knn_join_thresholds: theta_out[row_count], the per-row candidate thresholds of this rank's rows;
+ *      the host all-gathers them into theta_all[n_nodes].
+ *   2. as_knn_join_pairs: contracts this rank's tile pairs; cnt[n_nodes] (zeroed by the call) and
+ *      cand[n_nodes x cap] receive, indexed by GLOBAL row, every pair that reaches a threshold.  The host
+ *      sends each rank the slices of its rows (all-to-all): cnt_src[n_src x row_count],
+ *      cand_src[n_src x row_count x cap].
+ *   3. as_knn_join_finish: exact f64 re-rank + certification of this rank's rows from the n_src lists; rows
+ *      that cannot be certified go through the same later stages as in as_knn_cosine.  Output as there.
+ * AS_ERR_UNSUPPORTED when the join does not apply (dim > 128, small n, normalise, f64-first mode, host
+ * pointers): the caller then uses as_knn_cosine on its row range. */
+int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                           uint64_t row_count, const as_graph_params *params, float *theta_out);
+uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params);
+int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                      uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t cap,
+                      uint32_t *cnt, uint32_t *cand);
+int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
+                       uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t n_src,
+                       uint32_t cap, const uint32_t *cnt_src, const uint32_t *cand_src, uint64_t *nbr_idx,
+                       double *nbr_dist);
+
 /* Stage-level entry: _build_adjacency's filter/weight/sparsify + _symmetrise_adjancency +
  * _build_sparse_laplacian (src/laplacian.rs:217-417) from a complete neighbour table. */
 int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist,

@@ -116,7 +116,7 @@ def test_sharded_build_and_search_match_single_process(tmp_path, n, k):
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     assert (int(r0["lo"]), int(r0["hi"]), int(r1["hi"])) == (0, int(r1["lo"]), n)
-    assert int(r1["lo"]) % 128 == 0  # shard starts sit on MFMA row-tile boundaries
+    assert int(r1["lo"]) % 256 == 0 or int(r1["lo"]) == n  # shard starts sit on 256-row tile boundaries (or the shard is empty)
     for r in (r0, r1):
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         assert np.array_equal(r["data"], csr[2])

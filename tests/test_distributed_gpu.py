@@ -33,6 +33,7 @@ def _worker(rank, world, port, n, d, out_dir):
         ctx = A.Context(0)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)  # the symmetric threshold join, sharded form, at test sizes
         X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
         lo, hi = D.shard_range(n, rank, world)
         gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
@@ -46,7 +47,7 @@ def _worker(rank, world, port, n, d, out_dir):
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2],
                  lam=lam_all.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
-                 stats=np.array(sas.lambda_stats))
+                 stats=np.array(sas.lambda_stats), join=np.array(ctx.stat("knn_join")))
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +66,7 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, n):
     lam = O.taumode_lambdas(X, csrF, O.TAU_MEDIAN)
     Q = X[[1, n // 2, n - 1, 77]] * 1.02
     for r in (np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")):
+        assert int(r["join"]) == 1  # thresholds all-gathered, candidate lists exchanged, own rows finished
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
         np.testing.assert_allclose(r["lam"], lam, rtol=1e-12, atol=1e-300)
@@ -87,6 +89,7 @@ def _rccl_worker(rank, world, port, n, d, out_dir):
         ctx = A.Context(0)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)
         X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
         gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
         sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X).cuda(), n, gp, A.TauMode.Median)
