@@ -213,6 +213,58 @@ def test_item_graph_matches_oracle(ctx, mode, n, d, topk, eps):
     assert_csr_equal(gl.matrix.to_host(), O.build_laplacian(X, ogp(gp)))
 
 
+@pytest.fixture
+def join_on(ctx):
+    """The symmetric threshold join (csrc/mfma_join_f32.hip) at test sizes (it starts at 32,768 rows by default)."""
+    ctx.set_option("join_min_rows", 512)
+    yield
+    ctx.set_option("join_min_rows", 32768)
+    for name, v in (("join_sample", 16), ("join_rank", 5), ("join_cap", 192)):
+        ctx.set_option(name, v)
+
+
+@pytest.mark.parametrize("n,d,topk,eps", [(1500, 64, 16, 0.5), (777, 33, 5, 0.3), (2048, 128, 16, 0.5), (1200, 128, 16, 0.5),
+                                          (1300, 96, 30, 0.5), (900, 40, 45, 0.6), (513, 128, 3, 0.4), (6000, 100, 16, 0.5)])
+def test_item_graph_join_matches_oracle(ctx, join_on, n, d, topk, eps):
+    """Odd and even counts of 256-row tiles (the cyclic half pattern has an antipodal tile only when even), ragged
+    last tiles, list capacities from K + 1 up."""
+    X, _ = synth.mixture(n, d, seed=11, n_clusters=16, rank=4)
+    gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
+
+
+@pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 40, 1024)])
+def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap):
+    """The thresholds only decide how much work the later stages get: far too tight (lists overflow, rows fall
+    through to the top-k / f64 / exact stages) or far too loose, the tables are the oracle's."""
+    ctx.set_option("join_sample", sample)
+    ctx.set_option("join_rank", rank)
+    ctx.set_option("join_cap", cap)
+    X, _ = synth.mixture(3000, 64, seed=3, n_clusters=12, rank=4)
+    X = np.concatenate([X, X[:300]])   # exact duplicates: mass ties
+    X[17] = 0.0
+    X[900] *= 1e-9
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_item_graph_join_eps_above_one(ctx, join_on):
+    """eps > 1 admits negative cosines: thresholds and bounds below zero."""
+    X, _ = synth.mixture(2000, 32, seed=8, n_clusters=6, rank=3)
+    gp = A.GraphParams(1.2, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
 def test_duplicate_rows_tie_break(ctx, mode):
     """Duplicated rows (src/tests/test_builder.rs:376-384 style): exact ties must resolve to
     the lower index, identically to the oracle."""
