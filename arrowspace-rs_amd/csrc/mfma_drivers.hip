@@ -22,6 +22,28 @@ struct SearchBound {
   __device__ __forceinline__ double lower_bound(double worst_approx_key) const { return worst_approx_key - delta; }
 };
 
+// Exact dot product in the reference's arithmetic (sequential multiply-add chain over k, two roundings per
+// step, src/core.rs:204-210), with the operands fetched 32 B at a time: each lane walks its own candidate row,
+// so an 8-byte load per step would pull every cache line of that row eight times through L1.
+__device__ __forceinline__ double exact_dot_seq(const double *__restrict__ x_lds, const double *__restrict__ b,
+                                                uint32_t d) {
+  double acc = 0.0;
+  uint32_t k = 0;
+  if (((uintptr_t)b & 31) == 0) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const d4 *b4 = reinterpret_cast<const d4 *>(b);
+    for (; k + 4 <= d; k += 4) {
+      const d4 v = __builtin_nontemporal_load(b4 + (k >> 2));
+      acc = __dadd_rn(acc, __dmul_rn(x_lds[k], v.x));
+      acc = __dadd_rn(acc, __dmul_rn(x_lds[k + 1], v.y));
+      acc = __dadd_rn(acc, __dmul_rn(x_lds[k + 2], v.z));
+      acc = __dadd_rn(acc, __dmul_rn(x_lds[k + 3], v.w));
+    }
+  }
+  for (; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(x_lds[k], b[k]));
+  return acc;
+}
+
 template <class Policy, class Bound>
 __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ A, uint64_t lda,
                                                      const double *__restrict__ B, uint64_t ldb, uint32_t d,
@@ -61,9 +83,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ 
       double key = __builtin_inf();
       uint32_t id = kNoIdx;
       if (j != kNoIdx) {
-        const double *bj = B + (uint64_t)j * ldb;
-        double acc = 0.0;
-        for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
+        const double acc = exact_dot_seq(xrow, B + (uint64_t)j * ldb, d);
         double kx;
         if (pol.key(acc, a, j, kx, err_flag)) {
           key = kx;
@@ -301,9 +321,7 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
     wave_sync();
     for (uint32_t c = lane; c < C; c += 64) {
       const uint32_t j = ei[c];
-      const double *bj = X + (uint64_t)j * d;
-      double acc = 0.0;
-      for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
+      const double acc = exact_dot_seq(xrow, X + (uint64_t)j * d, d);
       double key = __builtin_inf(), kx;
       uint32_t id = kNoIdx;
       if (pol.key(acc, a, j, kx, err_flag)) {
@@ -485,7 +503,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   uint32_t n_fail = 0;
   // dim <= 128: symmetric threshold join (half the contractions).  Either the caller has run the join and
   // exchanged the candidate lists (row-sharded build: js), or the range is the whole matrix and it runs here.
-  const bool own_join = !js && use_f32 && !wide && !ctx->opt_debug && row_begin == 0 && row_count == n &&
+  const bool own_join = !js && use_f32 && !wide && row_begin == 0 && row_count == n &&
                         join_supported(ctx, n, d, 0);
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;

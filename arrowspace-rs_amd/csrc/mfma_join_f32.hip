@@ -56,7 +56,7 @@ template <int NC, int CPB>
 __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
     const float *__restrict__ P, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t segs, uint32_t n,
     const float *__restrict__ theta, uint32_t cap, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
-    uint32_t *__restrict__ unit_counter) {
+    uint32_t *__restrict__ unit_counter, int dbg) {
   constexpr int KS2 = NC * kKs2Unit;
   constexpr int kKs2Chunk = kKs2Unit * CPB;
   constexpr int kChunkFloats = kUnitFloats * CPB;
@@ -152,25 +152,27 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
         pbuf ^= 1;
       }
       // ---- epilogue: compare against the row and the column thresholds ----
-      bool hit[4];
+      if (dbg == 1) continue;  // diagnostic: contraction only (accumulators keep summing)
+      // Fast pass: per 32x32 block, does any lane hold a product that reaches a threshold?  Slow pass (about
+      // half of the blocks see one or two such products): the rows of the block are tested one by one with
+      // wave-uniform branches, so only rows that really carry a hit run the append code.
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) {
         bool h = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h = h || (acc[nn][r] >= tr[r]) || (acc[nn][r] >= tc[nn]);
-        hit[nn] = h;
-      }
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn) {
-        if (__any(hit[nn])) {  // rare once the thresholds are sensible: walk this 32x32 block again
+        if (dbg != 2 && __any(h)) {
           const uint32_t col = tile * kTileRows + nn * 32 + lc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[nn][r];
-            const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
-            const bool inside = row < n && col < n && row != col;
-            if (inside && v >= tr[r]) append(cnt, cand, cap, row, col);
-            if (inside && v >= tc[nn]) append(cnt, cand, cap, col, row);
+            const bool pr = v >= tr[r], pc = v >= tc[nn];
+            if (__any(pr || pc)) {
+              const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
+              const bool inside = row < n && col < n && row != col;
+              if (inside && pr) append(cnt, cand, cap, row, col);
+              if (inside && pc) append(cnt, cand, cap, col, row);
+            }
           }
         }
 #pragma unroll
@@ -203,7 +205,7 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(N, C)                                                                                             \
   hipLaunchKernelGGL((pair_join_mfma32_kernel<N, C>), dim3(grid), dim3(512), lds, ctx->stream, P, T2, I_begin,    \
-                     I_count, segs, n, theta, cap, cnt, cand, unit_counter)
+                     I_count, segs, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
   switch (NC * 10 + CPB) {
     case 11: AS_JOIN(1, 1); break;
     case 22: AS_JOIN(2, 2); break;
