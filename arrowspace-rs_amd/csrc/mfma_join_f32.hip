@@ -51,10 +51,13 @@ __device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__r
 }
 
 // P = packed unit-row image of ALL rows (tiles of 128 rows, even tile count, zero padded).
-// Work unit u = (I - I_begin) * segs + seg: super tile I against the seg-th slice of its offsets.
+// Work unit u = c * I_count + (I - I_begin): super tile I against the W column super tiles of block c
+// (those of them that fall into I's half pattern: one contiguous run of offsets).  Units are dealt
+// column block by column block, so the workgroups running at any one time read the same ~2 MB of
+// the B image (L2-resident per XCD) instead of 256 different places of it.
 template <int NC, int CPB>
 __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
-    const float *__restrict__ P, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t segs, uint32_t n,
+    const float *__restrict__ P, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
     const float *__restrict__ theta, uint32_t cap, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
     uint32_t *__restrict__ unit_counter, int dbg) {
   constexpr int KS2 = NC * kKs2Unit;
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lh = lane >> 5, lc = lane & 31;
   const uint32_t n_norm = (T2 - 1) / 2;
-  const uint32_t total_units = I_count * segs;
+  const uint32_t n_blocks = (T2 + W - 1) / W;
+  const uint32_t total_units = n_blocks * I_count;
 
   for (;;) {
     __syncthreads();
@@ -77,12 +81,22 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
     __syncthreads();
     const uint32_t u = s_unit;
     if (u >= total_units) break;
-    const uint32_t I = I_begin + u / segs, seg = u % segs;
+    const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
     const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
     const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
-    const uint32_t p_lo = (uint32_t)(((uint64_t)L * seg) / segs), p_hi = (uint32_t)(((uint64_t)L * (seg + 1)) / segs);
+    // offsets p (column super tile = I + p mod T2) that fall into block c = [B0, B0 + Wc)
+    const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
+    const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
+    uint32_t p_lo, p_hi;
+    if (delta + Wc <= T2) {
+      p_lo = delta;
+      p_hi = min(delta + Wc, L);
+    } else {  // the block straddles I: its tail is offsets 0 .. (W <= T2 / 4 keeps the head out of the pattern)
+      p_lo = 0;
+      p_hi = min(delta + Wc - T2, L);
+    }
+    if (p_hi <= p_lo) continue;
     const uint32_t steps = (p_hi - p_lo) * 2;  // 128-row B tiles to visit
-    if (steps == 0) continue;
 
     // A fragments of this wave's 32 rows, row thresholds of this lane's 16 rows
     float a[KS2];
@@ -199,13 +213,13 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
   const int NC = (int)units;
   const int CPB = NC % 2 == 0 ? 2 : 1;
   const size_t lds = join_lds_bytes(CPB);
-  // slices per super tile: enough units for the dynamic queue to even out the tail
-  const uint32_t segs = std::max(1u, std::min(16u, (16384u + I_count - 1) / std::max(1u, I_count)));
-  const unsigned grid = std::min<uint32_t>(I_count * segs, 256u);
+  // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
+  const uint32_t W = std::max(1u, std::min(16u, T2 / 4));
+  const unsigned grid = std::min<uint32_t>(I_count, 256u);
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(N, C)                                                                                             \
   hipLaunchKernelGGL((pair_join_mfma32_kernel<N, C>), dim3(grid), dim3(512), lds, ctx->stream, P, T2, I_begin,    \
-                     I_count, segs, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
+                     I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
   switch (NC * 10 + CPB) {
     case 11: AS_JOIN(1, 1); break;
     case 22: AS_JOIN(2, 2); break;
