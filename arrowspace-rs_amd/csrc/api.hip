@@ -177,6 +177,7 @@ void as_ctx_destroy(as_ctx *ctx) {
   prof_resolve(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  join_session_close(ctx);
   for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
   delete ctx;
 }
@@ -314,11 +315,12 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
                            uint64_t row_count, const as_graph_params *params, float *theta_out) {
   AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
   if (!theta_out || !is_device_ptr(theta_out)) return fail(ctx, AS_ERR_ARG, "theta_out must be a device pointer");
-  DevBuf<double> norms;
-  AS_TRY(norms.alloc(ctx, n_nodes));
-  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
-  return knn_join_thresholds(ctx, rows, norms.p, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin, (uint32_t)row_count,
-                             theta_out);
+  // first call of a sequence: norms and the packed image of all rows are built here and kept for the other two
+  AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
+  const int rc = knn_join_thresholds(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
+                                     (uint32_t)row_count, theta_out, ctx->join.packed);
+  if (rc != AS_OK) join_session_close(ctx);
+  return rc;
 }
 
 uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params) {
@@ -333,11 +335,9 @@ int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_
   if (!theta_all || !cnt || !cand || !is_device_ptr(theta_all) || !is_device_ptr(cnt) || !is_device_ptr(cand))
     return fail(ctx, AS_ERR_ARG, "theta_all / cnt / cand must be device pointers");
   if (cap == 0) return fail(ctx, AS_ERR_ARG, "cap == 0");
-  DevBuf<double> norms;
-  AS_TRY(norms.alloc(ctx, n_nodes));
-  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
-  return knn_join_pairs(ctx, rows, norms.p, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin, (uint32_t)row_count,
-                        theta_all, cap, cnt, cand);
+  if (!join_session_matches(ctx, rows, n_nodes, dim)) AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
+  return knn_join_pairs(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
+                        (uint32_t)row_count, theta_all, cap, cnt, cand, ctx->join.packed);
 }
 
 int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
@@ -350,23 +350,30 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   if (!is_device_ptr(theta_all) || !is_device_ptr(cnt_src) || !is_device_ptr(cand_src))
     return fail(ctx, AS_ERR_ARG, "theta_all / cnt_src / cand_src must be device pointers");
   const uint32_t K = (uint32_t)params->topk + 1;
-  DevBuf<double> norms;
-  AS_TRY(norms.alloc(ctx, n_nodes));
-  AS_TRY(row_norms(ctx, rows, n_nodes, dim, norms.p));
-  DevBuf<uint32_t> idx32;
-  AS_TRY(idx32.alloc(ctx, row_count * K));
-  DevOut<double> D;
-  AS_TRY(D.bind(ctx, nbr_dist, row_count * K));
-  DevOut<uint64_t> I;
-  AS_TRY(I.bind(ctx, nbr_idx, row_count * K));
-  const JoinSources js{theta_all, n_src, cap, cnt_src, cand_src};
-  AS_TRY(knn_mfma(ctx, rows, norms.p, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js));
-  hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
-                     row_count * K, 0ull, I.p);
-  AS_HIP(ctx, hipGetLastError());
-  AS_TRY(D.finish(ctx));
-  AS_TRY(I.finish(ctx));
-  return AS_OK;
+  if (!join_session_matches(ctx, rows, n_nodes, dim)) AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
+  int rc = AS_OK;
+  {
+    DevBuf<uint32_t> idx32;
+    DevOut<double> D;
+    DevOut<uint64_t> I;
+    rc = idx32.alloc(ctx, row_count * K);
+    if (rc == AS_OK) rc = D.bind(ctx, nbr_dist, row_count * K);
+    if (rc == AS_OK) rc = I.bind(ctx, nbr_idx, row_count * K);
+    if (rc == AS_OK) {
+      const JoinSources js{ctx->join.packed, theta_all, n_src, cap, cnt_src, cand_src};
+      rc = knn_mfma(ctx, rows, ctx->join.norms, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js);
+    }
+    if (rc == AS_OK) {
+      hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
+                         row_count * K, 0ull, I.p);
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, AS_ERR_HIP, "widen_idx_kernel launch failed");
+    }
+    if (rc == AS_OK) rc = D.finish(ctx);
+    if (rc == AS_OK) rc = I.finish(ctx);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  join_session_close(ctx);  // last call of the sequence
+  return rc;
 }
 
 int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,

@@ -52,6 +52,15 @@ struct as_ctx {
   int64_t opt_join_min_rows = 32768;
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
+  // Sharded join sequence (as_knn_join_thresholds -> _pairs -> _finish over the same `rows`): norms and the packed
+  // f32 image of all rows, built by the first call, reused by the other two, released by the last.
+  struct JoinSession {
+    const double *rows = nullptr;
+    uint64_t n = 0, d = 0;
+    double *norms = nullptr;
+    float *packed = nullptr;
+    size_t norms_cap = 0, packed_cap = 0;
+  } join;
   // stats of the last call
   std::map<std::string, int64_t> stats;
   // profiling
@@ -314,6 +323,7 @@ int knn_exact(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, 
 // Candidate lists of a threshold join that has already been run (row-sharded build: every rank contracts
 // the tile pairs of its own super tiles, the lists are exchanged, each rank finishes its own rows).
 struct JoinSources {
+  const float *packed;    // f32 image of all rows if the caller has one (else nullptr)
   const float *theta;     // thresholds of ALL rows (n)
   uint32_t n_src, cap;    // lists per row, slots per list
   const uint32_t *cnt;    // n_src x row_count
@@ -323,10 +333,15 @@ struct JoinSources {
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,
              uint64_t row_begin, uint64_t row_count, uint32_t K, int rectify, uint32_t *out_idx,
              double *out_dist, const JoinSources *js = nullptr);
+// packed = f32 image of ALL rows (even tile count) when the caller already has it, else nullptr
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
-                        uint32_t row_begin, uint32_t row_count, float *theta_out);
+                        uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr);
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
-                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand);
+                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
+                   const float *packed = nullptr);
+int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
+bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
+void join_session_close(as_ctx *ctx);
 uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K);
 
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,

@@ -375,7 +375,7 @@ static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t r
 // theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
 // hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
-                        uint32_t row_count, float *theta_out) {
+                        uint32_t row_count, float *theta_out, const float *packed) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t rate = (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample);
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
@@ -386,8 +386,12 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   DevBuf<uint32_t> sid, cidx;
   DevBuf<float> S, PA;
   DevBuf<double> ckey;
-  AS_TRY(PA.alloc(ctx, packed_elems(a_alloc, d)));
-  AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
+  const float *pa = packed ? packed + (size_t)(row_begin / kTileRows) * packed_elems(1, d) : nullptr;
+  if (!pa) {
+    AS_TRY(PA.alloc(ctx, packed_elems(a_alloc, d)));
+    AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
+    pa = PA.p;
+  }
   AS_TRY(sid.alloc(ctx, ns));
   hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sid.p);
   AS_TRY(S.alloc(ctx, packed_elems(s_alloc, d)));
@@ -408,7 +412,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   pb0.splits = 1;
   pb0.cand_key = ckey.p;
   pb0.cand_idx = cidx.p;
-  AS_TRY(candidates_f32(ctx, pb0, PA.p, a_tiles, S.p, s_tiles, "knn_join_thresholds"));
+  AS_TRY(candidates_f32(ctx, pb0, pa, a_tiles, S.p, s_tiles, "knn_join_thresholds"));
   hipLaunchKernelGGL(join_theta_kernel, dim3(cdiv(row_count, 256)), dim3(256), 0, ctx->stream, ckey.p, cidx.p, row_count,
                      KC0, m, row_count, theta_out);
   AS_HIP(ctx, hipGetLastError());
@@ -419,7 +423,8 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // Contracts the tile pairs owned by the super tiles of [row_begin, row_begin + row_count) and appends to
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
-                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand) {
+                   uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
+                   const float *packed) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const uint32_t T2 = b_alloc / 2;
@@ -427,17 +432,46 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   const uint32_t I_end = (uint32_t)(((uint64_t)row_begin + row_count + 255) / 256);
   DevBuf<float> P, theta;
   DevBuf<uint32_t> unitc;
-  AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
-  AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
+  if (!packed) {
+    AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
+    AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
+    packed = P.p;
+  }
   AS_TRY(theta.alloc(ctx, (size_t)T2 * 256));
   hipLaunchKernelGGL(pad_theta_kernel, dim3(cdiv((uint64_t)T2 * 256, 256)), dim3(256), 0, ctx->stream, theta_all, n, T2 * 256,
                      theta.p);
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  AS_TRY(join_f32(ctx, P.p, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
+  AS_TRY(join_f32(ctx, packed, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
+}
+
+int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
+  join_session_close(ctx);
+  auto &js = ctx->join;
+  const uint32_t b_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows), b_alloc = (b_tiles + 1) & ~1u;
+  void *p = nullptr;
+  AS_TRY(ws_alloc(ctx, sizeof(double) * n, &p, &js.norms_cap));
+  js.norms = (double *)p;
+  AS_TRY(ws_alloc(ctx, sizeof(float) * packed_elems(b_alloc, (uint32_t)d), &p, &js.packed_cap));
+  js.packed = (float *)p;
+  AS_TRY(row_norms(ctx, rows, n, d, js.norms));
+  AS_TRY(pack_f32(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed, b_alloc));
+  js.rows = rows;
+  js.n = n;
+  js.d = d;
+  return AS_OK;
+}
+bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
+  return ctx->join.rows == rows && ctx->join.n == n && ctx->join.d == d && ctx->join.norms && ctx->join.packed;
+}
+void join_session_close(as_ctx *ctx) {
+  auto &js = ctx->join;
+  if (js.norms) ws_free(ctx, js.norms, js.norms_cap);
+  if (js.packed) ws_free(ctx, js.packed, js.packed_cap);
+  js = as_ctx::JoinSession{};
 }
 
 uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K) {
@@ -507,10 +541,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                         join_supported(ctx, n, d, 0);
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
+  JoinSources local{};  // outlives the block below: the later stages still read js->packed
   if (use_join) {
     DevBuf<float> theta_own;
     DevBuf<uint32_t> cnt_own, cand_own;
-    JoinSources local{};
     if (own_join) {
       const uint32_t cap = knn_join_cap(ctx, K);
       AS_TRY(theta_own.alloc(ctx, n));
@@ -518,7 +552,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap));
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p));
-      local = JoinSources{theta_own.p, 1, cap, cnt_own.p, cand_own.p};
+      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p};
       js = &local;
     }
     {
@@ -653,6 +687,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     pb.cand_key = ckey.p;
     pb.cand_idx = cidx.p;
     if (f32) {
+      if (!B32.p && js && js->packed) B32.p = js->packed;
       if (!B32.p) {
         AS_TRY(B32.buf.alloc(ctx, packed_elems(b_alloc, d)));
         AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, B32.buf.p, b_alloc));

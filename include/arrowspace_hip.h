@@ -123,6 +123,9 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
  *      cand_src[n_src x row_count x cap].
  *   3. as_knn_join_finish: exact f64 re-rank + certification of this rank's rows from the n_src lists; rows
  *      that cannot be certified go through the same later stages as in as_knn_cosine.  Output as there.
+ * The three calls form ONE sequence over the same `rows` on one context: the first builds the row norms and the
+ * packed operand image and keeps them in the context, the last releases them (calling 2 or 3 out of sequence
+ * only costs rebuilding them).
  * AS_ERR_UNSUPPORTED when the join does not apply (dim > 128, small n, normalise, f64-first mode, host
  * pointers): the caller then uses as_knn_cosine on its row range. */
 int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
