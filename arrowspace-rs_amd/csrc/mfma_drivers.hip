@@ -133,7 +133,9 @@ __global__ void flag_tiny_norm_rows_kernel(const double *__restrict__ norms, uin
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const double x = norms[i];
-    flag[i] = (x != x) || (x > 0.0 && !(x * min_pos_norm > 1e-12)) ? 1 : 0;
+    // non-finite norms as well: an infinite norm meets a NaN norm as cos := 0 under the exact rule (the product of
+    // the norms is NaN, which is not > 1e-12), which the unit-row contraction cannot reproduce
+    flag[i] = (x != x) || !(x < __builtin_inf()) || (x > 0.0 && !(x * min_pos_norm > 1e-12)) ? 1 : 0;
   }
 }
 

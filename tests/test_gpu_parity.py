@@ -256,6 +256,35 @@ def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
+def test_item_graph_nonfinite_rows_same_on_every_path(ctx, join_on):
+    """Rows with NaN / inf entries.  The reference has no defined behaviour here (its in-tree model sorts with
+    partial_cmp().unwrap(), which panics on a NaN distance: src/tests/test_helpers.rs:115-119) and the oracle does
+    not pin one either; the library's rule is that a pair with a NaN cosine never enters a neighbour list (and a
+    pair whose norm product is NaN gets cos := 0 like any product that is not > 1e-12).  Checked: the symmetric
+    join, the top-k MFMA path and the exact scan produce identical tables, and finite rows never list one."""
+    X, _ = synth.mixture(1500, 64, seed=4, n_clusters=8, rank=3)
+    X[5, 3] = NAN
+    X[6, 0] = INF
+    X[700, :] = NAN
+    X[701, 10] = -INF
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    out = []
+    try:
+        for join, mfma in ((1, 1), (0, 1), (0, 0)):
+            ctx.set_option("knn_join", join)
+            ctx.set_option("knn_mfma", mfma)
+            idx, dist = A.knn_cosine(X, gp)
+            out.append((np.array(idx), np.array(dist)))
+    finally:
+        ctx.set_option("knn_join", 1)
+        ctx.set_option("knn_mfma", 1)
+    for i, d in out[1:]:
+        assert np.array_equal(i, out[0][0]) and np.array_equal(d, out[0][1], equal_nan=True)
+    bad = [5, 6, 700, 701]
+    finite_rows = np.setdiff1d(np.arange(len(X)), bad)
+    assert not np.isin(out[0][0][finite_rows], bad).any()
+
+
 def test_item_graph_join_eps_above_one(ctx, join_on):
     """eps > 1 admits negative cosines: thresholds and bounds below zero."""
     X, _ = synth.mixture(2000, 32, seed=8, n_clusters=6, rank=3)
