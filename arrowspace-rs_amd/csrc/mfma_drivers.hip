@@ -365,6 +365,127 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
   }
 }
 
+// The same re-rank for 128-wide rows (1 KB): candidate rows are staged through LDS, one LDS-DMA instruction per row
+// (the whole wave fetches 1 KB contiguously), a batch of rows at a time, then one lane per row runs the sequential
+// dot product from LDS.  The per-lane walk of the generic kernel fetches every candidate row
+// in 32-B pieces: 2-4x the bytes across the fabric (profiles/r01e_pmc_traffic.json) and 64 ms at 1 M rows.
+constexpr int kRrPitch = 1040;              // LDS pitch of a staged row (bytes): 16 lanes x 4 banks apart
+typedef __attribute__((address_space(3))) void rr_lds_void;
+typedef const __attribute__((address_space(1))) void rr_gbl_void;
+
+template <class Policy, class Bound, int kRrRows, int NBUF>
+__global__ __launch_bounds__(256) void rerank_join_d128_kernel(
+    const double *__restrict__ X, uint32_t row_begin, uint32_t row_count, const float *__restrict__ theta, uint32_t n_src,
+    const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src, uint32_t cap, uint32_t cmax, uint32_t K,
+    const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double *__restrict__ out_key,
+    uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows, uint32_t *__restrict__ fail_count,
+    int *__restrict__ err_flag) {
+  constexpr uint32_t d = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t per_wave = 1024 + (size_t)NBUF * kRrRows * kRrPitch + (size_t)cmax * 12;
+  unsigned char *base = smem + (size_t)wv * per_wave;
+  double *xrow = reinterpret_cast<double *>(base);
+  unsigned char *tiles = base + 1024;
+  double *ek = reinterpret_cast<double *>(tiles + NBUF * kRrRows * kRrPitch);
+  uint32_t *ei = reinterpret_cast<uint32_t *>(ek + cmax);
+
+  for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
+    const uint32_t a = row_begin + r;
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)a * d + k];
+    uint32_t C = 0;
+    bool overflow = false;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
+      const uint32_t total = cnt_src[(size_t)sidx * row_count + r];
+      uint32_t take = min(total, cap);
+      overflow = overflow || total > cap;
+      if (C + take > cmax) {
+        overflow = true;
+        take = cmax - C;
+      }
+      const uint32_t *src = cand_src + ((size_t)sidx * row_count + r) * cap;
+      for (uint32_t c = lane; c < take; c += 64) ei[C + c] = src[c];
+      C += take;
+    }
+    wave_sync();
+    const uint32_t n_batches = (C + kRrRows - 1) / kRrRows;
+    auto issue = [&](uint32_t b) {
+      unsigned char *dst = tiles + (size_t)(b % NBUF) * kRrRows * kRrPitch;
+#pragma unroll
+      for (int t = 0; t < kRrRows; ++t) {
+        const uint32_t c = b * kRrRows + t;
+        if (c < C) {  // wave-uniform
+          const uint32_t j = ei[c];
+          __builtin_amdgcn_global_load_lds((rr_gbl_void *)((const char *)(X + (uint64_t)j * d) + lane * 16),
+                                           (rr_lds_void *)(dst + t * kRrPitch), 16, 0, 0);
+        }
+      }
+    };
+    if (n_batches && NBUF == 2) issue(0);
+    for (uint32_t b = 0; b < n_batches; ++b) {
+      if (NBUF == 2) {
+        const bool more = b + 1 < n_batches;
+        if (more) issue(b + 1);
+        // batch b has landed once at most the rows of batch b + 1 are still in flight
+        if (more && (b + 2) * kRrRows <= C) {
+          if (kRrRows == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else {
+        issue(b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const uint32_t c = b * kRrRows + lane;
+      if (lane < kRrRows && c < C) {
+        const double *bj = reinterpret_cast<const double *>(tiles + (size_t)(b % NBUF) * kRrRows * kRrPitch + (size_t)lane * kRrPitch);
+        double acc = 0.0;
+#pragma unroll 8
+        for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(xrow[k], bj[k]));
+        const uint32_t j = ei[c];
+        double key = __builtin_inf(), kx;
+        uint32_t id = kNoIdx;
+        if (pol.key(acc, a, j, kx, err_flag)) {
+          key = kx;
+          id = j;
+        }
+        ek[c] = key;
+        ei[c] = id;
+      }
+      wave_sync();  // the tile of batch b is free for batch b + 2
+    }
+    double kth = -__builtin_inf();
+    uint32_t n_valid = 0;
+    for (uint32_t c = lane; c < C; c += 64) {
+      const double kc = ek[c];
+      const uint32_t ic = ei[c];
+      if (ic == kNoIdx) continue;
+      ++n_valid;
+      uint32_t rank = 0;
+      for (uint32_t c2 = 0; c2 < C; ++c2) rank += lex_less(ek[c2], ei[c2], kc, ic) ? 1u : 0u;
+      if (rank < K) {
+        out_key[(uint64_t)r * K + rank] = kc;
+        out_idx[(uint64_t)r * K + rank] = ic;
+        kth = fmax(kth, kc);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      kth = fmax(kth, __shfl_xor(kth, o, 64));
+      n_valid += __shfl_xor(n_valid, o, 64);
+    }
+    for (uint32_t s = n_valid + lane; s < K; s += 64) {
+      out_key[(uint64_t)r * K + s] = __builtin_inf();
+      out_idx[(uint64_t)r * K + s] = kNoIdx;
+    }
+    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[a]);
+    if (force_exact && force_exact[a]) ok = false;
+    if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    wave_sync();
+  }
+}
+
 int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count,
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
@@ -560,13 +681,33 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     {
       const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
       GraphBound bnd{cos_delta_f32(d), rectify};
-      const size_t lds = (size_t)4 * (d + cmax) * sizeof(double) + (size_t)4 * cmax * sizeof(uint32_t);
       ProfScope ps(ctx, "knn_rerank");
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
-                         dim3(256), lds, ctx->stream, rows, d, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt,
-                         js->cand, js->cap, cmax, K, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p);
+      // rows per batch x buffers.  Measured at 1 M rows (re-rank + fall-back re-rank): per-lane walk 66 ms, 8x1 39, 8x2 46,
+      // 16x1 37, 16x2 58: occupancy (LDS per wave) beats double buffering.  debug = 10 + {0: 8x1, 1: 8x2, 2: 16x1, 3: 16x2}.
+      const int rr_cfg = (int)(ctx->opt_debug >= 10 ? ctx->opt_debug - 10 : 2);
+      const int rr_rows = (rr_cfg & 2) ? 16 : 8, rr_nbuf = (rr_cfg & 1) ? 2 : 1;
+      const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + (size_t)cmax * 12);
+      if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
+#define AS_RR(R, NB)                                                                                                       \
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));                               \
+  hipLaunchKernelGGL((rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>),                                        \
+                     dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows,         \
+                     (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
+                     bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p)
+        if (rr_rows == 8 && rr_nbuf == 1) { AS_RR(8, 1); }
+        else if (rr_rows == 8) { AS_RR(8, 2); }
+        else if (rr_nbuf == 1) { AS_RR(16, 1); }
+        else { AS_RR(16, 2); }
+#undef AS_RR
+      } else {
+        const size_t lds = (size_t)4 * (d + cmax) * sizeof(double) + (size_t)4 * cmax * sizeof(uint32_t);
+        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
+                           dim3(256), lds, ctx->stream, rows, d, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt,
+                           js->cand, js->cap, cmax, K, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p);
+      }
       AS_HIP(ctx, hipGetLastError());
     }
     {  // statistics: candidates per row over all sources
