@@ -290,6 +290,19 @@ class GraphFactory:
         return gl
 
 
+def build_spectral_laplacian(aspace, gl):
+    """GraphFactory::build_spectral_laplacian (src/graph.rs:212-270): the Laplacian of the Laplacian.  The F x F
+    matrix of `gl` is made dense, transposed, and its rows become the nodes of a second build_laplacian_matrix
+    with the same GraphParams; the result is stored in aspace.signals, which compute_taumode then prefers
+    (queries keep using gl.matrix: src/core.rs:548)."""
+    dense_t = np.ascontiguousarray(gl.matrix.to_dense().T)
+    sig = build_laplacian_matrix(dense_t, gl.graph_params, aspace.nitems, ctx=aspace.ctx)
+    aspace.signals = sig.matrix
+    if gl.graph_params is not None and gl.graph_params.sparsity_check and GraphLaplacian.sparsity(sig.matrix) > 0.95:
+        raise ArrowSpaceError(_lib.AS_ERR_TOO_SPARSE, "Resulting spectral matrix is too sparse")
+    return aspace.signals
+
+
 class ArrowItem:
     """src/core.rs:84-239."""
 
@@ -332,6 +345,7 @@ class ArrowSpace:
         self.nitems, self.nfeatures = _shape2(self.data)
         self.taumode = taumode
         self.lambdas_ = None
+        self.signals = None  # F x F spectral Laplacian (src/core.rs:372), set by build_spectral_laplacian
         self._index = None
         self.id_offset = 0
 
@@ -353,7 +367,9 @@ class ArrowSpace:
             out = torch.empty(self.nitems, dtype=torch.float64, device=self.data.device)
         else:
             out = np.empty(self.nitems, dtype=np.float64)
-        ctx.check(lib.as_compute_taumode(ctx.h, ptr(self.data), self.nitems, self.nfeatures, gl.matrix.h,
+        # graph = aspace.signals if non-empty else gl.matrix (src/taumode.rs:195-200)
+        graph = self.signals if self.signals is not None else gl.matrix
+        ctx.check(lib.as_compute_taumode(ctx.h, ptr(self.data), self.nitems, self.nfeatures, graph.h,
                                          self.taumode.kind, self.taumode.arg, ptr(out)))
         self.update_lambdas(out)
 
@@ -475,6 +491,7 @@ class ArrowSpaceBuilder:
         self.normalise = False
         self.sparsity_check = False
         self.synthesis = TauMode.Median
+        self.prebuilt_spectral = False
         self.ctx = ctx
 
     @staticmethod
@@ -492,6 +509,10 @@ class ArrowSpaceBuilder:
 
     def with_normalisation(self, normalise):
         self.normalise = bool(normalise)
+        return self
+
+    def with_spectral(self, compute_spectral):  # src/builder.rs:157-162
+        self.prebuilt_spectral = bool(compute_spectral)
         return self
 
     def with_sparsity_check(self, flag):
@@ -524,6 +545,8 @@ class ArrowSpaceBuilder:
         gl = GraphFactory.build_laplacian_matrix_from_k_cluster(
             centroids, self.lambda_eps, self.lambda_k, self.lambda_topk, self.lambda_p, self.lambda_sigma,
             self.normalise, self.sparsity_check, aspace.nitems, ctx=ctx)
+        if self.prebuilt_spectral:  # stage 3, src/eigenmaps.rs:325-345
+            build_spectral_laplacian(aspace, gl)
         aspace.compute_taumode(gl)
         return aspace, gl
 

@@ -243,6 +243,10 @@ class ArrowSpace {
   ArrowSpace &operator=(const ArrowSpace &) = delete;
 
   const std::vector<double> &lambdas() const { return lambdas_; }
+  // F x F spectral Laplacian (src/core.rs:372), set by GraphFactory::build_spectral_laplacian; when present it is
+  // the graph of compute_taumode (src/taumode.rs:195-200) while queries keep gl.matrix (src/core.rs:548)
+  std::shared_ptr<CsMat> signals;
+  std::shared_ptr<Context> context() const { return ctx_; }
   ArrowItem get_item(std::size_t i) const {  // src/core.rs:586-594
     if (i >= nitems) throw Panic(AS_ERR_ARG, "item index out of bounds");
     return ArrowItem(std::vector<double>(data_.begin() + i * nfeatures, data_.begin() + (i + 1) * nfeatures),
@@ -251,7 +255,7 @@ class ArrowSpace {
   // EigenMaps::compute_taumode, src/eigenmaps.rs:358-383
   void compute_taumode(const GraphLaplacian &gl) {
     std::vector<double> out(nitems);
-    ctx_->check(as_compute_taumode(ctx_->get(), data_.data(), nitems, nfeatures, gl.matrix->handle(), taumode.kind,
+    ctx_->check(as_compute_taumode(ctx_->get(), data_.data(), nitems, nfeatures, (signals ? signals : gl.matrix)->handle(), taumode.kind,
                                    taumode.arg, out.data()));
     update_lambdas(std::move(out));
   }
@@ -329,6 +333,24 @@ class ArrowSpace {
   as_index *index_ = nullptr;
 };
 
+
+// GraphFactory::build_spectral_laplacian (src/graph.rs:212-270): the Laplacian of the Laplacian.  The F x F matrix
+// of `gl` is made dense, transposed, and its rows become the nodes of a second build_laplacian_matrix with the
+// same GraphParams; the result goes to aspace.signals.
+inline void build_spectral_laplacian(ArrowSpace &aspace, const GraphLaplacian &gl) {
+  const std::size_t n = gl.matrix->rows();
+  std::vector<std::vector<double>> dense_t(n, std::vector<double>(n, 0.0));
+  const auto &ip = gl.matrix->indptr();
+  const auto &ix = gl.matrix->indices();
+  const auto &dv = gl.matrix->data();
+  for (std::size_t i = 0; i < n; ++i)
+    for (uint64_t e = ip[i]; e < ip[i + 1]; ++e) dense_t[ix[e]][i] = dv[e];  // transposed
+  GraphLaplacian sig = build_laplacian_matrix(dense_t, gl.graph_params, aspace.nitems, aspace.context());
+  aspace.signals = sig.matrix;
+  if (gl.graph_params.sparsity_check && GraphLaplacian::sparsity(*aspace.signals) > 0.95)
+    throw Panic(AS_ERR_TOO_SPARSE, "Resulting spectral matrix is too sparse");
+}
+
 // ---- ArrowSpaceBuilder (src/builder.rs:20-455, lambda-tau subset) --------------------------------
 class ArrowSpaceBuilder {
  public:
@@ -337,7 +359,7 @@ class ArrowSpaceBuilder {
   std::size_t lambda_k = 6, lambda_topk = 3;
   double lambda_p = 2.0;
   std::optional<double> lambda_sigma;
-  bool normalise = false, sparsity_check = false;
+  bool normalise = false, sparsity_check = false, prebuilt_spectral = false;
   TauMode synthesis = TauMode::Median();
 
   static ArrowSpaceBuilder new_() { return ArrowSpaceBuilder(); }
@@ -354,6 +376,7 @@ class ArrowSpaceBuilder {
   ArrowSpaceBuilder &with_synthesis(TauMode tm) { return synthesis = tm, *this; }
   ArrowSpaceBuilder &with_normalisation(bool n) { return normalise = n, *this; }
   ArrowSpaceBuilder &with_sparsity_check(bool f) { return sparsity_check = f, *this; }
+  ArrowSpaceBuilder &with_spectral(bool f) { return prebuilt_spectral = f, *this; }  // src/builder.rs:157-162
   // src/builder.rs:225-233
   void define_result_k() { lambda_topk = as_define_result_k(lambda_k, lambda_topk); }
 
@@ -367,6 +390,7 @@ class ArrowSpaceBuilder {
     GraphLaplacian gl = GraphFactory::build_laplacian_matrix_from_k_cluster(
         centroids.empty() ? rows : centroids, lambda_eps, lambda_k, lambda_topk, lambda_p, lambda_sigma, normalise,
         sparsity_check, aspace->nitems, ctx);
+    if (prebuilt_spectral) build_spectral_laplacian(*aspace, gl);  // stage 3, src/eigenmaps.rs:325-345
     aspace->compute_taumode(gl);
     return {std::move(aspace), std::move(gl)};
   }

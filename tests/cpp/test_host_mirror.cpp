@@ -158,6 +158,31 @@ static void test_build_and_search() {  // src/tests/test_querying_proj.rs:30-72,
   CHECK(panics_with([&] { aspace->search_lambda_aware(ArrowItem(q, 0.0), 3, 0.7); }, "Lambda of the item is 0.0"));
 }
 
+static void test_spectral_laplacian() {  // src/graph.rs:212-270, src/builder.rs:157-162, src/taumode.rs:195-200
+  Rows rows = make_rows(300, 24);
+  auto [plain, gl0] = ArrowSpaceBuilder::new_().with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(rows);
+  auto [spec, gl] = ArrowSpaceBuilder::new_().with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_spectral(true).build(rows);
+  CHECK(!plain->signals);
+  CHECK(spec->signals && spec->signals->shape().first == 24 && spec->signals->shape().second == 24);
+  // "result should be a FxF matrix"; Laplacian invariants of the second-level graph
+  bool rows_sum_to_zero = true, diag_nonneg = true;
+  for (std::size_t i = 0; i < 24; ++i) {
+    double sum = 0.0;
+    for (std::size_t j = 0; j < 24; ++j) sum += spec->signals->get(i, j);
+    rows_sum_to_zero = rows_sum_to_zero && std::fabs(sum) < 1e-9;
+    diag_nonneg = diag_nonneg && spec->signals->get(i, i) >= 0.0;
+  }
+  CHECK(rows_sum_to_zero && diag_nonneg);
+  // the item lambdas come from `signals`: same as compute_taumode on a GraphLaplacian that holds it
+  GraphLaplacian as_gl = gl;
+  as_gl.matrix = spec->signals;
+  plain->compute_taumode(as_gl);
+  CHECK(plain->lambdas() == spec->lambdas());
+  // queries keep gl.matrix (src/core.rs:548)
+  std::vector<double> q = rows[3];
+  CHECK(spec->prepare_query_item(q, gl) == plain->prepare_query_item(q, gl0));
+}
+
 static void test_builder_defaults() {  // src/builder.rs:59-91,225-233
   ArrowSpaceBuilder b;
   CHECK(b.lambda_eps == 1e-3 && b.lambda_k == 6 && b.lambda_topk == 3 && b.lambda_p == 2.0 && !b.lambda_sigma);
@@ -186,6 +211,7 @@ int main() {
     test_builder_defaults();
     test_build_and_search();
     test_sparsity_check();
+    test_spectral_laplacian();
   } catch (const std::exception &e) {
     std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
     return 2;

@@ -347,6 +347,28 @@ def test_ref_mapping_chain_matches_oracle(ctx, mode, n, f, tm, om, arg):
         assert np.array_equal(sc[j], osc)
 
 
+@pytest.mark.parametrize("n,f", [(3000, 128), (800, 24)])
+def test_spectral_laplacian_chain_matches_oracle(ctx, n, f):
+    """with_spectral(true): signals = build_laplacian_matrix(dense(L)^T) (src/graph.rs:212-270); the item lambdas
+    come from `signals` (src/taumode.rs:195-200) while queries keep gl.matrix (src/core.rs:548)."""
+    X, cent = synth.mixture(n, f, seed=21, n_clusters=32, rank=6)
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_spectral(True)
+    asp, gl = b.build(X, cent)
+    gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
+    ocsr = O.build_laplacian(np.ascontiguousarray(cent.T), gp)
+    dense = np.zeros((f, f))
+    for i in range(f):
+        s, e = int(ocsr[0][i]), int(ocsr[0][i + 1])
+        dense[i, ocsr[1][s:e].astype(np.int64)] = ocsr[2][s:e]
+    osig = O.build_laplacian(np.ascontiguousarray(dense.T), gp)
+    assert asp.signals is not None and asp.signals.shape() == (f, f)
+    assert_csr_equal(asp.signals.to_host(), osig)
+    olam = O.taumode_lambdas(X, asp.signals.to_host(), O.TAU_MEDIAN)
+    np.testing.assert_allclose(asp.lambdas(), olam, rtol=LAMBDA_RTOL, atol=1e-300)
+    lq = asp.prepare_query_item(X[5] * 1.02, gl)
+    assert lq == pytest.approx(O.prepare_query_item(X[5] * 1.02, gl.matrix.to_host(), O.TAU_MEDIAN), rel=LAMBDA_RTOL)
+
+
 def test_search_large_k_and_ties(ctx, mode):
     X, _ = synth.mixture(500, 32, seed=2, n_clusters=5, rank=3)
     X = np.concatenate([X, X[:100]])  # exact score ties -> lower index first
