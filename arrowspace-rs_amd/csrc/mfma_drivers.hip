@@ -491,7 +491,7 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
              const char *prof_name);
 
 static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
-  return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && (d + 31) / 32 <= (uint32_t)kMaxNC &&
+  return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 &&
          n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) && row_begin % 256 == 0;
 }
 
@@ -660,7 +660,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   uint32_t n_fail = 0;
   // dim <= 128: symmetric threshold join (half the contractions).  Either the caller has run the join and
   // exchanged the candidate lists (row-sharded build: js), or the range is the whole matrix and it runs here.
-  const bool own_join = !js && use_f32 && !wide && row_begin == 0 && row_count == n &&
+  const bool own_join = !js && use_f32 && row_begin == 0 && row_count == n &&
                         join_supported(ctx, n, d, 0);
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__r
 // the B image (L2-resident per XCD) instead of 256 different places of it.
 template <int NC, int CPB>
 __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
-    const float *__restrict__ P, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
+    const float *__restrict__ P, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t panels, uint32_t n,
     const float *__restrict__ theta, uint32_t cap, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
     uint32_t *__restrict__ unit_counter, int dbg) {
   constexpr int KS2 = NC * kKs2Unit;
@@ -98,16 +98,21 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
     if (p_hi <= p_lo) continue;
     const uint32_t steps = (p_hi - p_lo) * 2;  // 128-row B tiles to visit
 
-    // A fragments of this wave's 32 rows, row thresholds of this lane's 16 rows
+    // A fragments of this wave's 32 rows (dim <= 128: one k panel, loaded once per unit; wider rows: re-read from
+    // L2 once per (B tile, 128-wide k panel)), row thresholds of this lane's 16 rows
     float a[KS2];
+    const float *a_src;
     {
       const int row0 = wv * 32;
       const size_t T = (size_t)2 * I + (row0 >> 7);
       const int s0 = (row0 & 127) >> 5;
-      const float *a_src = P + ((T * KS2) * 4 + s0) * 64 + lane;
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) a[ks] = a_src[(size_t)ks * 256];
+      a_src = P + ((T * KS2 * panels) * 4 + s0) * 64 + lane;  // + (panel * KS2 + ks) * 256
     }
+    auto load_a = [&](uint32_t panel) {
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) a[ks] = a_src[((size_t)panel * KS2 + ks) * 256];
+    };
+    if (panels == 1) load_a(0);
     const uint32_t row_base = I * kSuper + wv * 32 + 4 * lh;  // + (r & 3) + 8 * (r >> 2)
     float tr[16];
 #pragma unroll
@@ -124,11 +129,12 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
       S = S >= T2 ? S - T2 : S;
       return 2 * S + (step & 1u);
     };
+    const uint32_t cpt = panels * NCB;  // chunks per B tile
     auto chunk_src = [&](uint32_t g) -> const float * {
-      const uint32_t step = g / NCB, c = g - step * NCB;
-      return P + ((size_t)tile_of(step) * NCB + c) * kChunkFloats;
+      const uint32_t step = g / cpt, c = g - step * cpt;
+      return P + ((size_t)tile_of(step) * cpt + c) * kChunkFloats;
     };
-    const uint32_t n_chunks = steps * NCB;
+    const uint32_t n_chunks = steps * cpt;
     __syncthreads();
     stage_chunk<CPB>(chunk_src(0), bufB, wv, lane);
     __syncthreads();
@@ -141,6 +147,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
       float tc[4];
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc];
+      for (uint32_t panel = 0; panel < panels; ++panel) {
+      if (panels > 1) load_a(panel);
 #pragma unroll
       for (int c = 0; c < NCB; ++c, ++g) {
         if (g + 1 < n_chunks) stage_chunk<CPB>(chunk_src(g + 1), bufB + (pbuf ^ 1) * kChunkFloats, wv, lane);
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __syncthreads();  // DMA of the next chunk landed; everyone is done reading bufB[pbuf]
         pbuf ^= 1;
+      }
       }
       // ---- epilogue: compare against the row and the column thresholds ----
       if (dbg == 1) continue;  // diagnostic: contraction only (accumulators keep summing)
@@ -206,20 +215,22 @@ static size_t join_lds_bytes(int CPB) { return (size_t)2 * kUnitFloats * CPB * s
 int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count,
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name) {
-  const uint32_t units = packed_units(d);
-  if (units > 4 || units == 0) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join: dim > 128");
+  const uint32_t units = packed_units(d);  // 32-wide units; whole 128-wide panels beyond 4
+  if (units == 0) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join: dim == 0");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t T2 = (b_tiles + 1) / 2;
-  const int NC = (int)units;
+  const int NC = units <= 4 ? (int)units : 4;
+  const uint32_t panels = units <= 4 ? 1 : units / 4;
   const int CPB = NC % 2 == 0 ? 2 : 1;
   const size_t lds = join_lds_bytes(CPB);
   // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
-  const uint32_t W = std::max(1u, std::min(16u, T2 / 4));
+  // (wider rows: fewer super tiles per block, same bytes)
+  const uint32_t W = std::max(1u, std::min(std::max(1u, 16u / panels), T2 / 4));
   const unsigned grid = std::min<uint32_t>(I_count, 256u);
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(N, C)                                                                                             \
   hipLaunchKernelGGL((pair_join_mfma32_kernel<N, C>), dim3(grid), dim3(512), lds, ctx->stream, P, T2, I_begin,    \
-                     I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
+                     I_count, W, panels, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
   switch (NC * 10 + CPB) {
     case 11: AS_JOIN(1, 1); break;
     case 22: AS_JOIN(2, 2); break;

@@ -126,7 +126,7 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
  * The three calls form ONE sequence over the same `rows` on one context: the first builds the row norms and the
  * packed operand image and keeps them in the context, the last releases them (calling 2 or 3 out of sequence
  * only costs rebuilding them).
- * AS_ERR_UNSUPPORTED when the join does not apply (dim > 128, small n, normalise, f64-first mode, host
+ * AS_ERR_UNSUPPORTED when the join does not apply (small n, normalise, f64-first mode, host
  * pointers): the caller then uses as_knn_cosine on its row range. */
 int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
                            uint64_t row_count, const as_graph_params *params, float *theta_out);

@@ -224,10 +224,11 @@ def join_on(ctx):
 
 
 @pytest.mark.parametrize("n,d,topk,eps", [(1500, 64, 16, 0.5), (777, 33, 5, 0.3), (2048, 128, 16, 0.5), (1200, 128, 16, 0.5),
-                                          (1300, 96, 30, 0.5), (900, 40, 45, 0.6), (513, 128, 3, 0.4), (6000, 100, 16, 0.5)])
+                                          (1300, 96, 30, 0.5), (900, 40, 45, 0.6), (513, 128, 3, 0.4), (6000, 100, 16, 0.5),
+                                          (1100, 200, 8, 0.5), (640, 768, 16, 0.5), (2100, 384, 16, 0.5), (1500, 129, 16, 0.5)])
 def test_item_graph_join_matches_oracle(ctx, join_on, n, d, topk, eps):
     """Odd and even counts of 256-row tiles (the cyclic half pattern has an antipodal tile only when even), ragged
-    last tiles, list capacities from K + 1 up."""
+    last tiles, list capacities from K + 1 up, rows wider than 128 (k panels: the A fragments are re-read per panel)."""
     X, _ = synth.mixture(n, d, seed=11, n_clusters=16, rank=4)
     gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
     idx, dist = A.knn_cosine(X, gp)
