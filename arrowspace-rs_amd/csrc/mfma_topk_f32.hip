@@ -148,7 +148,6 @@ __global__ __launch_bounds__(512 / MW, 2 / MW) void pair_topk_mfma32_kernel(
   // panels = 128-wide k panels per row (1 for dim <= 128: the A fragments then stay in registers for
   // the whole sweep; more: they are re-read from L2 once per (B tile, panel))
   constexpr int WAVES = 8 / MW;
-  constexpr int NT = 64 * WAVES;
   constexpr int WROWS = 32 * MW;                  // rows per wave
   constexpr uint32_t QCAP = kQueueCap * MW / 2;   // per-wave queue entries
   constexpr int KS2 = NC * kKs2Unit;
