@@ -46,10 +46,12 @@ struct as_ctx {
   int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
   int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
   int64_t opt_knn_join = 1;       // item graph over the whole matrix: symmetric threshold join (mfma_join_f32.hip)
-  int64_t opt_join_sample = 16;   // thresholds come from a 1-in-N sample of the rows ...
-  int64_t opt_join_rank = 5;      // ... as the m-th best sampled product of every row
+  int64_t opt_join_sample = 12;   // thresholds come from a 1-in-N sample of the rows ...
+  int64_t opt_join_rank = 6;      // ... as the m-th best sampled product of every row (1 M x 128 sweep: 16/5 1172 ms,
+                                  // 12/6 1146, 10/7 1152, 8/8 1161 for the whole neighbour search)
   int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
   int64_t opt_join_min_rows = 32768;
+  int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // Sharded join sequence (as_knn_join_thresholds -> _pairs -> _finish over the same `rows`): norms and the packed

@@ -230,16 +230,41 @@ static int read_u32(as_ctx *ctx, const uint32_t *dev, uint32_t *host) {
 }
 
 // ---- threshold join (mfma_join_f32.hip): thresholds, exact re-rank, stage driver ------------------
-// hashed 1-in-`rate` sample of the rows: id = rate * t + hash(t) % rate (a plain stride would alias
-// with periodic row orders)
-__global__ void sample_ids_kernel(uint32_t ns, uint32_t rate, uint32_t *__restrict__ ids) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ns) return;
-  uint32_t h = t * 2654435761u;
-  h ^= h >> 15;
-  h *= 2246822519u;
-  h ^= h >> 13;
-  ids[t] = rate * t + h % rate;
+// hashed 1-in-`rate` sample of the rows, in pseudo-random order: position p holds the sample of block
+// t = perm(p), id = rate * t + hash(t) % rate.  A plain stride would alias with periodic row orders, and the ORDER
+// matters too: the split-bf16 threshold pass bins the sample by position (mod 32, tile parity) and wants a row's
+// best partners spread over the bins; a multiplicative map p * g mod ns keeps residues modulo gcd(ns, 32) and
+// leaves them in a few bins.  perm = cycle-walked 4-round Feistel network over the next even power of two.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__global__ void sample_ids_kernel(uint32_t ns, uint32_t rate, uint32_t half_bits, uint32_t *__restrict__ ids) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ns) return;
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint32_t x = p;
+  do {  // bijection on [0, 2^(2 half_bits)); walking the cycle until it lands below ns makes it one on [0, ns)
+    uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t nl = r;
+      r = l ^ (mix32(r * 0x9E3779B9u + k) & mask);
+      l = nl;
+    }
+    x = (l << half_bits) | r;
+  } while (x >= ns);
+  const uint32_t t = x;
+  ids[p] = rate * t + mix32(t ^ 0x5bd1e995u) % rate;
+}
+static uint32_t sample_half_bits(uint32_t ns) {
+  uint32_t b = 1;
+  while (b < 16 && (1ull << (2 * b)) < ns) ++b;
+  return b;
 }
 
 // theta[r] = the m-th best approximate cosine of row r against the sample (the value whose rank among ALL
@@ -490,6 +515,9 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
 
+int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
+                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out);
+
 static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
   return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 &&
          n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) && row_begin % 256 == 0;
@@ -509,14 +537,19 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   DevBuf<uint32_t> sid, cidx;
   DevBuf<float> S, PA;
   DevBuf<double> ckey;
+  AS_TRY(sid.alloc(ctx, ns));
+  hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sample_half_bits(ns), sid.p);
+  if (ctx->opt_join_bf16) {  // thresholds on the bf16 pipe (mfma_theta_bf16.hip); dims it does not cover take the f32 pass
+    const int rc = join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out);
+    if (rc != AS_ERR_UNSUPPORTED) return rc;
+  }
   const float *pa = packed ? packed + (size_t)(row_begin / kTileRows) * packed_elems(1, d) : nullptr;
   if (!pa) {
     AS_TRY(PA.alloc(ctx, packed_elems(a_alloc, d)));
     AS_TRY(pack_f32(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
     pa = PA.p;
   }
-  AS_TRY(sid.alloc(ctx, ns));
-  hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sid.p);
+
   AS_TRY(S.alloc(ctx, packed_elems(s_alloc, d)));
   AS_TRY(pack_f32(ctx, rows, norms, sid.p, 0, ns, d, S.p, s_alloc));
   AS_TRY(ckey.alloc(ctx, (size_t)row_count * KC0));

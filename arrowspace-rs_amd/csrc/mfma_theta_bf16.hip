@@ -1,0 +1,239 @@
+// mfma_theta_bf16.hip -- candidate thresholds of the symmetric join (mfma_join_f32.hip) on the bf16 matrix pipe.
+//
+// theta[r] only has to be a sensible cut: the join is exact for ANY threshold (the re-rank certifies against
+// whatever theta was used, mfma_drivers.hip), theta decides how many candidates a row collects and how many rows
+// fall through to the later stages.  So the products of every row with a hashed sample of the rows are taken on
+// the bf16 pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) with split operands, x = hi + lo, and three MFMAs
+// per k step (hi*hi + hi*lo + lo*hi: ~2^-16 relative; plain bf16 is too coarse: on clustered data thousands of
+// neighbours sit within 0.02 of the cut and 1e-3 of noise moves it by hundreds of candidates), and reduced with
+// one v_max per product: lane (h, c) of
+// a wave sees, for each of its 16 rows, the sample columns congruent to c mod 32, and keeps their maximum.  A row
+// (split again by the parity of the sample tile) therefore ends with 64 maxima over 64 disjoint sub-samples;
+// theta[r] is the m-th largest of them -- the m-th
+// best sampled product when the best m fall into different sub-samples, a little lower otherwise (which only
+// makes the cut more generous).  No lists, no insertions: the f32 top-k form of this pass took 11 % of the build.
+//
+// Geometry: 8 waves x 32 rows per workgroup (one 256-row super tile per work unit, dealt from an atomic
+// counter), the A fragments of a wave in registers (4 VGPRs per 16-wide k step), sample tiles of 128 rows
+// through a 2-deep LDS-DMA ring (32 KB per tile at dim 128), all workgroups walking the sample in the same order.
+#include <hip/hip_bf16.h>
+
+#include "mfma_common.cuh"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// Packed bf16 image: tiles of 128 rows; fragment (T, ks, s) = 64 lanes x 8 bf16 (16 B per lane):
+//   P[((T * KS + ks) * 4 + s) * 64 + l][j] = bf16( unit(R)[128 T + 32 s + (l & 31)][16 ks + 8 (l >> 5) + j] )
+// which is the A / B operand of v_mfma_f32_32x32x16_bf16 as it stands (cdna_hip_programming.md, operand lane maps).
+__global__ void pack_bf16_kernel(const double *__restrict__ R, const double *__restrict__ norms,
+                                 const uint32_t *__restrict__ row_ids, uint64_t row0, uint64_t n, uint32_t d, uint32_t KS,
+                                 uint64_t total_frag_lanes, bf16x8 *__restrict__ P /* hi plane, then lo plane per tile */) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_frag_lanes) return;
+  const uint32_t l = g & 63;
+  const uint32_t s = (g >> 6) & 3;
+  const uint64_t tk = g >> 8;
+  const uint32_t ks = (uint32_t)(tk % KS);
+  const uint64_t T = tk / KS;
+  const uint64_t row = T * kTileRows + s * 32 + (l & 31);
+  const uint32_t k0 = ks * 16 + 8 * (l >> 5);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) hi[j] = lo[j] = (__bf16)0.0f;
+  if (row < n) {
+    const uint64_t src = row_ids ? row_ids[row] : row0 + row;
+    const double nr = norms[src];
+    if (nr > 0.0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < d) {
+          const float x = (float)(R[src * d + k0 + j] / nr);
+          hi[j] = (__bf16)x;
+          lo[j] = (__bf16)(x - (float)hi[j]);
+        }
+    }
+  }
+  // tile T: [hi plane: KS*4*64 vectors][lo plane: the same]
+  const uint64_t per_tile = (uint64_t)KS * 4 * 64;
+  const uint64_t in_tile = g - T * per_tile;
+  P[T * 2 * per_tile + in_tile] = hi;
+  P[T * 2 * per_tile + per_tile + in_tile] = lo;
+}
+
+// KS = 16-wide k steps per row (d_pad / 16).  PA: image of the rows [row_begin, ...) whose thresholds are wanted
+// (a_tiles 128-row tiles, even count); PS: image of the ns sample rows.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__restrict__ PA, uint32_t a_supers,
+                                                            uint32_t row_count, const bf16x8 *__restrict__ PS,
+                                                            uint32_t s_tiles, uint32_t ns, uint32_t m,
+                                                            float *__restrict__ theta_out,
+                                                            uint32_t *__restrict__ unit_counter) {
+  constexpr int kPlaneVecs = KS * 4 * 64;   // 16-B vectors per plane of a 128-row tile
+  constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8 *bufB = reinterpret_cast<bf16x8 *>(smem);                               // 2 x tile
+  float *s_max = reinterpret_cast<float *>(bufB);  // [8 waves][32 rows][65], aliases the ring once the sweep is over
+  __shared__ uint32_t s_unit;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lh = lane >> 5, lc = lane & 31;
+
+  auto stage = [&](uint32_t J, int buf) {  // 128-row sample tile J -> LDS, 1 KB pieces dealt to the waves
+    const bf16x8 *src = PS + (size_t)J * kTileVecs;
+    bf16x8 *dst = bufB + (size_t)buf * kTileVecs;
+    constexpr int kPieces = kTileVecs / 64;
+    for (int p = wv; p < kPieces; p += 8)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + p * 64 + lane), (lds_void *)(dst + p * 64), 16, 0, 0);
+  };
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
+    __syncthreads();
+    const uint32_t I = s_unit;
+    if (I >= a_supers) break;
+
+    bf16x8 a_hi[KS], a_lo[KS];
+    {
+      const int row0 = wv * 32;
+      const size_t T = (size_t)2 * I + (row0 >> 7);
+      const int s0 = (row0 & 127) >> 5;
+      const bf16x8 *a_src = PA + T * kTileVecs + (size_t)s0 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_hi[ks] = a_src[(size_t)ks * 256];
+        a_lo[ks] = a_src[kPlaneVecs + (size_t)ks * 256];
+      }
+    }
+    float rmax[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax[0][r] = rmax[1][r] = -__builtin_inff();
+    v16f32 acc[4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (uint32_t J = 0; J < s_tiles; ++J) {
+      if (J + 1 < s_tiles) stage(J + 1, (J + 1) & 1);
+      const bf16x8 *bb = bufB + (size_t)(J & 1) * kTileVecs;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+          const bf16x8 b_hi = bb[(ks * 4 + nn) * 64 + lane], b_lo = bb[kPlaneVecs + (ks * 4 + nn) * 64 + lane];
+          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[nn], 0, 0, 0);
+          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[nn], 0, 0, 0);
+          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[nn], 0, 0, 0);
+        }
+      }
+      const bool tail = (J + 1 == s_tiles) && (ns % kTileRows != 0);
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        const bool live = !tail || (J * kTileRows + nn * 32 + lc < ns);  // padded sample columns never count
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = live ? acc[nn][r] : -__builtin_inff();
+          if (J & 1u) rmax[1][r] = __builtin_fmaxf(rmax[1][r], v);
+          else rmax[0][r] = __builtin_fmaxf(rmax[0][r], v);
+          acc[nn][r] = 0.f;
+        }
+      }
+      __syncthreads();  // the next tile has landed; everyone is done with this one
+    }
+    // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row][parity * 32 + lane column]
+    float *wm = s_max + (size_t)wv * 32 * 65;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wm[((r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + lc] = rmax[0][r];
+      wm[((r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + 32 + lc] = rmax[1][r];
+    }
+    wave_sync();
+    if (lane < 32) {
+      const uint32_t row = I * 256 + wv * 32 + lane;
+      float vals[64];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) vals[c] = wm[lane * 65 + c];
+      float t = -__builtin_inff();
+      for (uint32_t k = 0; k < m; ++k) {  // remove the current maximum m - 1 times
+        float best = -__builtin_inff();
+        int at = 0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          const bool gt = vals[c] > best;
+          best = gt ? vals[c] : best;
+          at = gt ? c : at;
+        }
+        t = best;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
+      }
+      if (row < row_count) theta_out[row] = t;
+    }
+    wave_sync();
+  }
+}
+
+}  // namespace
+
+// 16-B vectors of a split image (hi plane + lo plane per tile)
+uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * ((d + 15) / 16) * 4 * 64 * 2; }
+
+static int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
+                     uint32_t d, void *P, uint32_t tiles) {
+  const uint32_t KS = (d + 15) / 16;
+  const uint64_t total = packed_vecs_bf16(tiles, d) / 2;  // one thread per fragment lane (writes hi and lo)
+  ProfScope ps(ctx, "pack_unit_rows");
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, row_ids, row0, n, d, KS,
+                     total, (bf16x8 *)P);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// theta_out[r], r < row_count, for rows [row_begin, row_begin + row_count) against the sample `sample_ids`
+// (ns global row ids).  dim <= 128 (the split A fragments stay in registers); AS_ERR_UNSUPPORTED beyond.
+int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
+                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || ns < 128) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: sample too small");
+  const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
+  const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows;
+  DevBuf<unsigned char> PA, PS;
+  DevBuf<uint32_t> unitc;
+  AS_TRY(PA.alloc(ctx, packed_vecs_bf16(a_alloc, d) * 16));
+  AS_TRY(PS.alloc(ctx, packed_vecs_bf16(s_tiles, d) * 16));
+  AS_TRY(pack_bf16(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
+  AS_TRY(pack_bf16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  const uint32_t a_supers = a_alloc / 2;
+  const size_t lds = std::max((size_t)2 * 2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
+  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
+  ProfScope ps(ctx, "knn_join_thresholds");
+#define AS_THETA(K)                                                                                                    \
+  case K:                                                                                                              \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    (int)lds));                                                                        \
+    hipLaunchKernelGGL((theta_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)PA.p, a_supers, \
+                       row_count, (const bf16x8 *)PS.p, s_tiles, ns, m, theta_out, unitc.p);                          \
+    break;
+  switch (KS) {
+    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
+  }
+#undef AS_THETA
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the images go back to the workspace cache
+  return AS_OK;
+}
+
+}  // namespace asx

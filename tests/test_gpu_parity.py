@@ -219,7 +219,7 @@ def join_on(ctx):
     ctx.set_option("join_min_rows", 512)
     yield
     ctx.set_option("join_min_rows", 32768)
-    for name, v in (("join_sample", 16), ("join_rank", 5), ("join_cap", 192)):
+    for name, v in (("join_sample", 12), ("join_rank", 6), ("join_cap", 192)):
         ctx.set_option(name, v)
 
 
@@ -239,19 +239,24 @@ def test_item_graph_join_matches_oracle(ctx, join_on, n, d, topk, eps):
     assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
 
 
-@pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 40, 1024)])
-def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap):
+@pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 32, 1024)])
+@pytest.mark.parametrize("bf16", [1, 0])
+def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap, bf16):
     """The thresholds only decide how much work the later stages get: far too tight (lists overflow, rows fall
     through to the top-k / f64 / exact stages) or far too loose, the tables are the oracle's."""
     ctx.set_option("join_sample", sample)
     ctx.set_option("join_rank", rank)
     ctx.set_option("join_cap", cap)
+    ctx.set_option("join_bf16", bf16)  # thresholds from split-bf16 products / from the f32 top-k pass
     X, _ = synth.mixture(3000, 64, seed=3, n_clusters=12, rank=4)
     X = np.concatenate([X, X[:300]])   # exact duplicates: mass ties
     X[17] = 0.0
     X[900] *= 1e-9
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
-    idx, dist = A.knn_cosine(X, gp)
+    try:
+        idx, dist = A.knn_cosine(X, gp)
+    finally:
+        ctx.set_option("join_bf16", 1)
     assert ctx.stat("knn_join") == 1
     oi, od = O.knn_cosine(X, ogp(gp))
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
