@@ -221,7 +221,9 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
   const uint32_t T2 = (b_tiles + 1) / 2;
   const int NC = units <= 4 ? (int)units : 4;
   const uint32_t panels = units <= 4 ? 1 : units / 4;
-  const int CPB = NC % 2 == 0 ? 2 : 1;
+  // units staged per barrier: at 128-wide panels the whole tile (one barrier per tile, 2 x 64 KB of LDS: 1000 ms
+  // against 1008 ms with a barrier per half tile; debug 8 selects the latter)
+  const int CPB = NC == 4 ? (ctx->opt_debug == 8 ? 2 : 4) : (NC % 2 == 0 ? 2 : 1);
   const size_t lds = join_lds_bytes(CPB);
   // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
   // (wider rows: fewer super tiles per block, same bytes)
@@ -229,6 +231,8 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
   const unsigned grid = std::min<uint32_t>(I_count, 256u);
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(N, C)                                                                                             \
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_mfma32_kernel<N, C>,                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
   hipLaunchKernelGGL((pair_join_mfma32_kernel<N, C>), dim3(grid), dim3(512), lds, ctx->stream, P, T2, I_begin,    \
                      I_count, W, panels, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug)
   switch (NC * 10 + CPB) {
@@ -236,6 +240,7 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
     case 22: AS_JOIN(2, 2); break;
     case 31: AS_JOIN(3, 1); break;
     case 42: AS_JOIN(4, 2); break;
+    case 44: AS_JOIN(4, 4); break;
     default: return fail(ctx, AS_ERR_UNSUPPORTED, "bad k-panel shape");
   }
 #undef AS_JOIN
