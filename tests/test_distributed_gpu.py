@@ -52,12 +52,13 @@ def _worker(rank, world, port, n, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [3000, 1111])
-def test_two_ranks_one_gpu_match_single_process(tmp_path, n):
+@pytest.mark.parametrize("n,world", [(3000, 2), (1111, 2), (3000, 3)])
+def test_ranks_sharing_one_gpu_match_single_process(tmp_path, n, world):
+    """2 ranks; 2 ranks with an almost empty second shard; 3 ranks with uneven shards (1024 / 1024 / 952 rows)."""
     import arrowspace_amd as A
     from oracle import oracle_ctypes as O
     from tests import synth
-    d, world = 64, 2
+    d = 64
     mp.spawn(_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
     X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
     gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
@@ -65,7 +66,7 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, n):
     csrF = O.build_laplacian(np.ascontiguousarray(cent.T), gp)
     lam = O.taumode_lambdas(X, csrF, O.TAU_MEDIAN)
     Q = X[[1, n // 2, n - 1, 77]] * 1.02
-    for r in (np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")):
+    for r in [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]:
         assert int(r["join"]) == 1  # thresholds all-gathered, candidate lists exchanged, own rows finished
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
