@@ -6,13 +6,16 @@
 // delta = (d+4) 2^-24 (mfma_drivers.hip) make the final result bit-identical to the exact path;
 // rows that cannot be certified at this precision go to the f64 pass.
 //
-// Geometry: a workgroup (4 waves, one per SIMD) owns 256 A rows (two packed 128-row tiles); wave w
-// keeps the fragments of rows 64 w .. 64 w + 63 in registers for the whole sweep (2 x 64 k-steps at
-// d = 128) and accumulates a 64 x 128 block per B tile in 8 independent 32x32 accumulators
-// (128 VGPRs).  B tiles stream through a 2 x 16 KB LDS ring as linear copies of the packed image:
+// Geometry (default, MW = 1): a workgroup of 8 waves (two per SIMD: one wave's epilogue overlaps the other's
+// MFMAs) owns 256 A rows (two packed 128-row tiles); wave w keeps the fragments of rows 32 w .. 32 w + 31 in
+// registers for the whole sweep (64 k-steps at d = 128) and accumulates a 32 x 128 block per B tile in four
+// independent 32x32 accumulators.  (MW = 2: 4 waves x 64 rows, one wave per SIMD.)  B tiles stream through a 2-deep
+// LDS ring as linear copies of the packed image:
 //   P[((T*KS2 + ks)*4 + s)*64 + l] = (float) unit(R)[128 T + 32 s + (l & 31)][2 ks + (l >> 5)]
-// so each B fragment read is 256 contiguous bytes.  Top-KC lists (f32 value, index) per row live in
-// LDS; the 128 accumulators per lane are filtered against per-row thresholds held in registers.
+// so each B fragment read is 256 contiguous bytes.  Top-KC lists (f32 value, index) per row live in LDS; the
+// accumulators of a lane are filtered against per-row thresholds read from LDS.
+// This pass is the K9 search scan, the fall-back stage of the item graph and its form for sharded / small inputs;
+// the item graph over a whole matrix takes the symmetric threshold join (mfma_join_f32.hip).
 #include <type_traits>
 
 #include "mfma_common.cuh"
