@@ -215,6 +215,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_cap") ctx->opt_join_cap = value;
   else if (n == "join_min_rows") ctx->opt_join_min_rows = value;
   else if (n == "join_bf16") ctx->opt_join_bf16 = value;
+  else if (n == "join_pipe") ctx->opt_join_pipe = value == 32 ? 32 : 16;
   else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);

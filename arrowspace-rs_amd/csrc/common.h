@@ -51,6 +51,7 @@ struct as_ctx {
                                   // 12/6 1146, 10/7 1152, 8/8 1161 for the whole neighbour search)
   int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
   int64_t opt_join_min_rows = 32768;
+  int64_t opt_join_pipe = 16;     // contraction of the join: 16 = split bf16 (dim <= 128), 32 = f32 MFMA
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only

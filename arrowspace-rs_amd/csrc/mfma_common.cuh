@@ -92,4 +92,17 @@ inline double cos_delta_f32(uint32_t d) {
   return (double)(dp + 4) * 5.9604644775390625e-08 * 1.01 + 1e-13;  // (d+4) 2^-24 + f64 slack
 }
 
+// split-bf16 products (mfma_join_bf16.hip, mfma_theta_bf16.hip): x = hi + lo + e, |e| <= 2^-16 |x| (two roundings to
+// 8 significant bits), the pass sums hi*hi + hi*lo + lo*hi exactly representable products in f32:
+//   dropped terms  |lo lo'| + |e x'| + |x e'| <= 3 * 2^-16 |x||x'|, summed over k: <= 3 * 2^-16 (Cauchy-Schwarz, unit rows)
+//   accumulation   N = 3 * d_pad products plus the carried accumulator of every MFMA; 2^-23 per addition (covers
+//                  a truncating adder) on a running sum of magnitude <= 1 + 2^-7
+//   operands       two roundings of the unit rows to f32
+inline double cos_delta_bf16x3(uint32_t d) {
+  const uint32_t ks = (d + 15) / 16, dp = ks * 16;
+  const double split = 3.0 * 1.52587890625e-05 * 1.02;
+  const double accum = (double)(3 * dp + 3 * ks + 2) * 1.1920928955078125e-07 * 1.02;
+  return split + accum + 2.0 * 5.9604644775390625e-08 + 1e-13;
+}
+
 }  // namespace asx

@@ -515,8 +515,20 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
 
+int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
 int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
                          uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out);
+uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
+int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
+              uint32_t d, void *P, uint32_t tiles);
+
+// which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of
+// the two where the bf16 pipe may have been used: every rank of a sharded build derives the same value)
+static bool join_on_bf16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 16 && d <= 128; }
+static double join_delta(const as_ctx *ctx, uint32_t d) {
+  return join_on_bf16(ctx, d) ? std::max(cos_delta_bf16x3(d), cos_delta_f32(d)) : cos_delta_f32(d);
+}
 
 static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
   return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 &&
@@ -587,8 +599,13 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   const uint32_t I_begin = row_begin / 256;
   const uint32_t I_end = (uint32_t)(((uint64_t)row_begin + row_count + 255) / 256);
   DevBuf<float> P, theta;
+  DevBuf<unsigned char> P16;
   DevBuf<uint32_t> unitc;
-  if (!packed) {
+  const bool bf16 = join_on_bf16(ctx, d);
+  if (bf16) {
+    AS_TRY(P16.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
+    AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16.p, b_alloc));
+  } else if (!packed) {
     AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
     AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
     packed = P.p;
@@ -599,7 +616,10 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  AS_TRY(join_f32(ctx, packed, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
+  if (bf16)
+    AS_TRY(join_bf16(ctx, P16.p, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_bf16"));
+  else
+    AS_TRY(join_f32(ctx, packed, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
@@ -713,7 +733,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     }
     {
       const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
-      GraphBound bnd{cos_delta_f32(d), rectify};
+      GraphBound bnd{join_delta(ctx, d), rectify};
       ProfScope ps(ctx, "knn_rerank");
       // rows per batch x buffers.  Measured at 1 M rows (re-rank + fall-back re-rank): per-lane walk 66 ms, 8x1 39, 8x2 46,
       // 16x1 37, 16x2 58: occupancy (LDS per wave) beats double buffering.  debug = 10 + {0: 8x1, 1: 8x2, 2: 16x1, 3: 16x2}.

@@ -1,0 +1,279 @@
+// mfma_join_bf16.hip -- the symmetric threshold join (see mfma_join_f32.hip for the scheme and for what the
+// lists mean) contracted on the bf16 matrix pipe with split operands: x = hi + lo, three MFMAs per 16-wide k step
+// (lo*hi + hi*lo + hi*hi, v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate, so 16/3 of its throughput).
+//
+// Exactness does not depend on the precision of this pass: a pair is appended to row r's list when its
+// approximate cosine s reaches theta[r], so what is NOT in the list has s < theta[r] and therefore an exact cosine
+// below theta[r] + delta, delta = cos_delta_bf16x3(d) (mfma_common.cuh: split residual + dropped lo*lo + f32
+// accumulation); the exact f64 re-rank certifies a row only if its K-th neighbour is clear of that, everything
+// else falls through to the f32 / f64 / scan stages (mfma_drivers.hip).  The wider delta (1e-4 against 8e-6 at
+// dim 128) costs a few more uncertified rows, the contraction is 4-5x shorter.
+//
+// Geometry: 8 waves x 32 rows per workgroup (one 256-row super tile per work unit, the same cyclic half pattern
+// and column blocking as the f32 form), split A fragments of a wave in registers (8 VGPRs per k step), B tiles of
+// 128 rows (hi plane + lo plane, 64 KB at dim 128) through a 2-deep LDS-DMA ring, one barrier per tile.
+// The compare epilogue of a 32x32 block costs about as much vector issue as a quarter of its MFMAs, so it is
+// software-pipelined one block behind: the products of block b sit in one accumulator while block b + 1 is
+// contracted into the other, and the compares issue in the shadow of those MFMAs.
+#include <hip/hip_bf16.h>
+
+#include <type_traits>
+
+#include "mfma_common.cuh"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int kSuper = 256;  // rows per super tile (two packed 128-row tiles)
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+
+// LDS fragment reads whose latency the compiler must not wait out on the spot: issued by hand, waited for by
+// hand (the "+v" operands of lds_wait pin the consumers behind the wait; cdna_hip_programming.md, asm loads).
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(bf16x8 &x, bf16x8 &y) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(PENDING));
+}
+
+__device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand, uint32_t cap,
+                                       uint32_t target, uint32_t other) {
+  const uint32_t pos = atomicAdd(cnt + target, 1u);
+  if (pos < cap) cand[(size_t)target * cap + pos] = other;
+}
+
+// P = split bf16 image of ALL rows (mfma_theta_bf16.hip: tiles of 128 rows, hi plane then lo plane, even tile
+// count, zero padded).  Work units as in pair_join_mfma32_kernel.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__restrict__ P, uint32_t T2, uint32_t I_begin,
+                                                                uint32_t I_count, uint32_t W, uint32_t n,
+                                                                const float *__restrict__ theta, uint32_t cap,
+                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
+                                                                uint32_t *__restrict__ unit_counter, int dbg) {
+  constexpr int kPlaneVecs = KS * 4 * 64;    // 16-B vectors per plane of a 128-row tile
+  constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8 *bufB = reinterpret_cast<bf16x8 *>(smem);  // 2 x tile
+  __shared__ uint32_t s_unit;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lh = lane >> 5, lc = lane & 31;
+  const uint32_t n_norm = (T2 - 1) / 2;
+  const uint32_t n_blocks = (T2 + W - 1) / W;
+  const uint32_t total_units = n_blocks * I_count;
+
+  auto stage = [&](uint32_t tile, int buf) {  // 128-row tile -> LDS, 1 KB pieces dealt to the waves
+    const bf16x8 *src = P + (size_t)tile * kTileVecs;
+    bf16x8 *dst = bufB + (size_t)buf * kTileVecs;
+    constexpr int kPieces = kTileVecs / 64;
+#pragma unroll
+    for (int p = 0; p < kPieces / 8; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * (kPieces / 8) + p) * 64 + lane),
+                                       (lds_void *)(dst + (wv * (kPieces / 8) + p) * 64), 16, 0, 0);
+  };
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
+    __syncthreads();
+    const uint32_t u = s_unit;
+    if (u >= total_units) break;
+    const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
+    const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
+    const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
+    const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
+    const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
+    uint32_t p_lo, p_hi;
+    if (delta + Wc <= T2) {
+      p_lo = delta;
+      p_hi = min(delta + Wc, L);
+    } else {  // the block straddles I: its tail is offsets 0 .. (W <= T2 / 4 keeps the head out of the pattern)
+      p_lo = 0;
+      p_hi = min(delta + Wc - T2, L);
+    }
+    if (p_hi <= p_lo) continue;
+    const uint32_t steps = (p_hi - p_lo) * 2;  // 128-row B tiles to visit
+
+    bf16x8 a_hi[KS], a_lo[KS];
+    {
+      const int row0 = wv * 32;
+      const size_t T = (size_t)2 * I + (row0 >> 7);
+      const int s0 = (row0 & 127) >> 5;
+      const bf16x8 *a_src = P + T * kTileVecs + (size_t)s0 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_hi[ks] = a_src[(size_t)ks * 256];
+        a_lo[ks] = a_src[kPlaneVecs + (size_t)ks * 256];
+      }
+    }
+    const uint32_t row_base = I * kSuper + wv * 32 + 4 * lh;  // + (r & 3) + 8 * (r >> 2)
+    float tr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tr[r] = theta[row_base + (r & 3) + 8 * (r >> 2)];
+
+    auto tile_of = [&](uint32_t step) -> uint32_t {
+      uint32_t S = I + p_lo + (step >> 1);
+      S = S >= T2 ? S - T2 : S;
+      return 2 * S + (step & 1u);
+    };
+
+    // products of one 32x32 block: rows of this wave x columns [32 nn, 32 nn + 32) of the staged tile
+    // Fragment sets b_hi[s], b_lo[s], s = k step parity; the reads of step ks + 1 are issued before the wait for
+    // step ks.  ks = 0 of a block is issued by the block before it (AS_PREFETCH) or after the tile's barrier.
+    bf16x8 b_hi[2], b_lo[2];
+#define AS_READ(SET, KSTEP, NN)                                                   \
+  {                                                                               \
+    lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);                     \
+    lds_read16<(kPlaneVecs + ((KSTEP)*4 + (NN)) * 64) * 16>(b_lo[SET], b_addr);   \
+  }
+    // products of one 32x32 block: rows of this wave x columns [32 nn, 32 nn + 32) of the staged tile.
+    // NEXT_NN >= 0: the first fragments of that block of the same tile are requested before the last MFMAs.
+    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, v16f32 &acc) {
+      constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
+      constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
+      v16f32 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
+        bool more = true;
+        if (ks + 1 < KS) {
+          switch (ks + 1) {  // compile-time offsets
+#define AS_CASE(K) case K: if (nxt) AS_READ(1, K, nn) else AS_READ(0, K, nn) break;
+            AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
+#undef AS_CASE
+          }
+        } else if (next_nn >= 0) {
+          if (nxt) AS_READ(1, 0, (next_nn < 0 ? 0 : next_nn)) else AS_READ(0, 0, (next_nn < 0 ? 0 : next_nn))
+        } else {
+          more = false;
+        }
+        if (more) {
+          if (cur) lds_wait<2>(b_hi[1], b_lo[1]); else lds_wait<2>(b_hi[0], b_lo[0]);
+        } else {
+          if (cur) lds_wait<0>(b_hi[1], b_lo[1]); else lds_wait<0>(b_hi[0], b_lo[0]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi[cur], ks == 0 ? z : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo[cur], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi[cur], acc, 0, 0, 0);
+      }
+    };
+    // does any product of the block reach its row's or its column's threshold?
+    auto any_hit = [&](const v16f32 &acc, float tcv) -> bool {
+      bool h = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h = h || (acc[r] >= tr[r]) || (acc[r] >= tcv);
+      return h;
+    };
+    // the rows of a block that carries a hit are tested one by one with wave-uniform branches
+    auto emit = [&](const v16f32 &acc, float tcv, uint32_t col) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        const bool pr = v >= tr[r], pc = v >= tcv;
+        if (__any(pr || pc)) {
+          const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
+          const bool inside = row < n && col < n && row != col;
+          if (inside && pr) append(cnt, cand, cap, row, col);
+          if (inside && pc) append(cnt, cand, cap, col, row);
+        }
+      }
+    };
+
+    // block pipeline: accA / accB alternate; `prev` = the block whose products wait for their compares
+    v16f32 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending: never a hit
+    float tc_prev = __builtin_inff();
+    uint32_t col_prev = 0;
+
+    __syncthreads();
+    stage(tile_of(0), 0);
+    __syncthreads();
+    for (uint32_t step = 0; step < steps; ++step) {
+      const uint32_t tile = tile_of(step);
+      const int pbuf = (int)(step & 1u);
+      if (step + 1 < steps) stage(tile_of(step + 1), pbuf ^ 1);
+      const bool diag = (p_lo + (step >> 1)) == 0;
+      // column thresholds of this lane's four columns (the diagonal block is row-side only)
+      float tc[4];
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc];
+      const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kTileVecs) + (uint32_t)lane * 16u;
+      const uint32_t col0 = tile * kTileRows + lc;
+
+// one basic block per 32x32 block: two compares behind each MFMA
+#define AS_BLOCK(NN, NEXT, CUR, PREV)                               \
+  {                                                                 \
+    contract(b_addr, std::integral_constant<int, NN>{}, std::integral_constant<int, NEXT>{}, CUR); \
+    const bool h = any_hit(PREV, tc_prev);                          \
+    _Pragma("unroll") for (int i = 0; i < 3 * KS; ++i) {            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            \
+    }                                                               \
+    if (dbg != 2 && __any(h)) emit(PREV, tc_prev, col_prev);        \
+    tc_prev = tc[NN];                                               \
+    col_prev = col0 + NN * 32;                                      \
+  }
+      AS_READ(0, 0, 0)
+      AS_BLOCK(0, 1, accA, accB)
+      AS_BLOCK(1, 2, accB, accA)
+      AS_BLOCK(2, 3, accA, accB)
+      AS_BLOCK(3, -1, accB, accA)
+#undef AS_BLOCK
+      __syncthreads();  // DMA of the next tile landed; everyone is done reading bufB[pbuf]
+    }
+#undef AS_READ
+    // the last block of the unit
+    {
+      const bool h = any_hit(accB, tc_prev);
+      if (dbg != 2 && __any(h)) emit(accB, tc_prev, col_prev);
+    }
+  }
+}
+
+}  // namespace
+
+uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
+
+// Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 super tiles of the split bf16 image P
+// (all n rows).  cnt / cand (n x cap) are indexed by global row; cnt must be zeroed by the caller, unit_counter too.
+// dim <= 128 (the split A fragments stay in registers); AS_ERR_UNSUPPORTED beyond.
+int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
+  const uint32_t T2 = (b_tiles + 1) / 2;
+  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16;
+  // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
+  const uint32_t W = std::max(1u, std::min(16u, T2 / 4));
+  const unsigned grid = std::min<uint32_t>(I_count, 256u);
+  ProfScope ps(ctx, prof_name);
+#define AS_JOIN(K)                                                                                                     \
+  case K:                                                                                                              \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                        \
+    hipLaunchKernelGGL((pair_join_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)P, T2,     \
+                       I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug);              \
+    break;
+  switch (KS) {
+    AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
+  }
+#undef AS_JOIN
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+}  // namespace asx

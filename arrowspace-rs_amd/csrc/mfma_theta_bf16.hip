@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
 // 16-B vectors of a split image (hi plane + lo plane per tile)
 uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * ((d + 15) / 16) * 4 * 64 * 2; }
 
-static int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
+int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
                      uint32_t d, void *P, uint32_t tiles) {
   const uint32_t KS = (d + 15) / 16;
   const uint64_t total = packed_vecs_bf16(tiles, d) / 2;  // one thread per fragment lane (writes hi and lo)
