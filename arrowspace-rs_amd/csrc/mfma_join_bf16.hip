@@ -31,6 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 constexpr int kSuper = 256;  // rows per super tile (two packed 128-row tiles)
+constexpr uint32_t kQueue = 256;  // queued appends per wave (one 32x32 row step adds at most 128)
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
 
@@ -58,28 +59,63 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
                                                                 uint32_t I_count, uint32_t W, uint32_t n,
                                                                 const float *__restrict__ theta, uint32_t cap,
                                                                 uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
-                                                                uint32_t *__restrict__ unit_counter, int dbg) {
+                                                                uint32_t *__restrict__ unit_counter, int dbg,
+                                                                unsigned long long *__restrict__ stamps) {
   constexpr int kPlaneVecs = KS * 4 * 64;    // 16-B vectors per plane of a 128-row tile
   constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8 *bufB = reinterpret_cast<bf16x8 *>(smem);  // 2 x tile
   __shared__ uint32_t s_unit;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
+  // Passing pairs are queued per wave in LDS as (list owner, other row) and appended kQueue/2 or more at a time:
+  // an append is an atomic that returns the slot, ~2 us before the store can go out, and taken one by one inside
+  // the sweep those waits made the wave with the hit late at the tile's barrier, where the other seven wait for it
+  // (stamps: 17 % of the kernel).  From the queue 64 lanes take one entry each: one such wait per 64 appends.
+  uint2 *queue = reinterpret_cast<uint2 *>(smem + (size_t)2 * kTileVecs * 16) + (size_t)wv * kQueue;
+  uint32_t qn = 0;  // wave-uniform
+  auto lanes_below = [&](unsigned long long m) -> uint32_t {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
+  auto flush_queue = [&]() {
+    wave_sync();
+    for (uint32_t base = 0; base < qn; base += 64) {
+      const uint32_t e = base + lane;
+      if (e < qn) {
+        const uint2 v = queue[e];
+        append(cnt, cand, cap, v.x, v.y);
+      }
+    }
+    wave_sync();
+    qn = 0;
+  };
   const uint32_t n_norm = (T2 - 1) / 2;
   const uint32_t n_blocks = (T2 + W - 1) / W;
   const uint32_t total_units = n_blocks * I_count;
 
-  auto stage = [&](uint32_t tile, int buf) {  // 128-row tile -> LDS, 1 KB pieces dealt to the waves
+  // 128-row tile -> LDS: 1 KB pieces, KS per wave.  part < 0: all of them; part = 0..3: the pieces of that
+  // quarter (one quarter is issued inside each of the four blocks of the tile before, among its MFMAs: eight
+  // back-to-back pieces right after the barrier, from every wave at once, leave the matrix pipe idle)
+  auto stage = [&](uint32_t tile, int buf, int part) {
     const bf16x8 *src = P + (size_t)tile * kTileVecs;
     bf16x8 *dst = bufB + (size_t)buf * kTileVecs;
-    constexpr int kPieces = kTileVecs / 64;
 #pragma unroll
-    for (int p = 0; p < kPieces / 8; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * (kPieces / 8) + p) * 64 + lane),
-                                       (lds_void *)(dst + (wv * (kPieces / 8) + p) * 64), 16, 0, 0);
+    for (int p = 0; p < KS; ++p)
+      if (part < 0 || (p & 3) == part)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + p) * 64 + lane), (lds_void *)(dst + (wv * KS + p) * 64),
+                                         16, 0, 0);
   };
+
+  // dbg 8: cycle stamps (diagnostic build of the SAME kernel; the sums go to a buffer nothing else reads)
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  unsigned long long t_unit = 0, t_blocks = 0, t_dma = 0, t_bar = 0, t_mark = 0;
+  const bool stamp = (dbg & 8) != 0;
+  if (stamp) t_mark = now();
 
   for (;;) {
     __syncthreads();
@@ -137,14 +173,16 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
   }
     // products of one 32x32 block: rows of this wave x columns [32 nn, 32 nn + 32) of the staged tile.
     // NEXT_NN >= 0: the first fragments of that block of the same tile are requested before the last MFMAs.
-    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, v16f32 &acc) {
+    // k steps [K0, K1) of the block
+    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, auto k0_c, auto k1_c, v16f32 &acc) {
       constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
       constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
       v16f32 z;
 #pragma unroll
       for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = K0; ks < K1; ++ks) {
         const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
         bool more = true;
         if (ks + 1 < KS) {
@@ -175,8 +213,13 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       for (int r = 0; r < 16; ++r) h = h || (acc[r] >= tr[r]) || (acc[r] >= tcv);
       return h;
     };
-    // the rows of a block that carries a hit are tested one by one with wave-uniform branches
+    // the rows of a block that carries a hit are tested one by one with wave-uniform branches; what passes goes to
+    // the wave's queue (flush_queue below)
     auto emit = [&](const v16f32 &acc, float tcv, uint32_t col) {
+      // the fragments requested for the next block are still in flight: nothing may touch their registers
+      // before they land (the code below is long enough for the allocator to want to move things around)
+      lds_wait<0>(b_hi[0], b_lo[0]);
+      lds_wait<0>(b_hi[1], b_lo[1]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
@@ -184,8 +227,13 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
         if (__any(pr || pc)) {
           const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
           const bool inside = row < n && col < n && row != col;
-          if (inside && pr) append(cnt, cand, cap, row, col);
-          if (inside && pc) append(cnt, cand, cap, col, row);
+          const bool w1 = inside && pr, w2 = inside && pc;
+          const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
+          const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
+          if (qn + n1 + n2 > kQueue) flush_queue();
+          if (w1) queue[qn + lanes_below(m1)] = make_uint2(row, col);
+          if (w2) queue[qn + n1 + lanes_below(m2)] = make_uint2(col, row);
+          qn += n1 + n2;
         }
       }
     };
@@ -198,12 +246,18 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     uint32_t col_prev = 0;
 
     __syncthreads();
-    stage(tile_of(0), 0);
+    stage(tile_of(0), 0, -1);
     __syncthreads();
+    if (stamp) {
+      const unsigned long long t = now();
+      t_unit += t - t_mark;
+      t_mark = t;
+    }
     for (uint32_t step = 0; step < steps; ++step) {
       const uint32_t tile = tile_of(step);
       const int pbuf = (int)(step & 1u);
-      if (step + 1 < steps) stage(tile_of(step + 1), pbuf ^ 1);
+      const bool more_tiles = step + 1 < steps && !(dbg & 4);  // dbg 4: timing ablation
+      const uint32_t tile_next = more_tiles ? tile_of(step + 1) : 0;
       const bool diag = (p_lo + (step >> 1)) == 0;
       // column thresholds of this lane's four columns (the diagonal block is row-side only)
       float tc[4];
@@ -212,16 +266,24 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kTileVecs) + (uint32_t)lane * 16u;
       const uint32_t col0 = tile * kTileRows + lc;
 
-// one basic block per 32x32 block: two compares behind each MFMA
+// A 32x32 block in two halves of its k steps; the compares of the block before ride behind the MFMAs of the first
+// half.  The quarter of the next tile's DMA pieces that this block issues goes in front of the first half in waves
+// 0-3 and between the halves in waves 4-7: the two waves of a SIMD run in lockstep between barriers, and a DMA piece
+// holds its wave's issue for 60-190 cycles, so issued at the same moment they leave the matrix pipe idle.
+#define AS_IC(V) std::integral_constant<int, (V)>{}
 #define AS_BLOCK(NN, NEXT, CUR, PREV)                               \
   {                                                                 \
-    contract(b_addr, std::integral_constant<int, NN>{}, std::integral_constant<int, NEXT>{}, CUR); \
+    constexpr int KH = (KS + 1) / 2;                                \
+    if (more_tiles && wv < 4) stage(tile_next, pbuf ^ 1, NN);       \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR); \
     const bool h = any_hit(PREV, tc_prev);                          \
-    _Pragma("unroll") for (int i = 0; i < 3 * KS; ++i) {            \
+    _Pragma("unroll") for (int i = 0; i < 3 * KH; ++i) {            \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);            \
     }                                                               \
-    if (dbg != 2 && __any(h)) emit(PREV, tc_prev, col_prev);        \
+    if (more_tiles && wv >= 4) stage(tile_next, pbuf ^ 1, NN);      \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
+    if (!(dbg & 2) && __any(h)) emit(PREV, tc_prev, col_prev);      \
     tc_prev = tc[NN];                                               \
     col_prev = col0 + NN * 32;                                      \
   }
@@ -231,14 +293,37 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       AS_BLOCK(2, 3, accA, accB)
       AS_BLOCK(3, -1, accB, accA)
 #undef AS_BLOCK
+#undef AS_IC
+      if (stamp) {
+        unsigned long long t = now();
+        t_blocks += t - t_mark;
+        t_mark = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t = now();
+        t_dma += t - t_mark;
+        t_mark = t;
+      }
       __syncthreads();  // DMA of the next tile landed; everyone is done reading bufB[pbuf]
+      if (stamp) {
+        const unsigned long long t = now();
+        t_bar += t - t_mark;
+        t_mark = t;
+      }
     }
 #undef AS_READ
     // the last block of the unit
     {
       const bool h = any_hit(accB, tc_prev);
-      if (dbg != 2 && __any(h)) emit(accB, tc_prev, col_prev);
+      if (!(dbg & 2) && __any(h)) emit(accB, tc_prev, col_prev);
     }
+  }
+  flush_queue();
+  if (stamp && lane == 0) {
+    atomicAdd(stamps + 0, t_unit);
+    atomicAdd(stamps + 1, t_blocks);
+    atomicAdd(stamps + 2, t_dma);
+    atomicAdd(stamps + 3, t_bar);
+    atomicAdd(stamps + 4, 1ull);
   }
 }
 
@@ -255,17 +340,23 @@ int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_beg
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t T2 = (b_tiles + 1) / 2;
-  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16;
+  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + (size_t)8 * kQueue * sizeof(uint2);
   // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
   const uint32_t W = std::max(1u, std::min(16u, T2 / 4));
   const unsigned grid = std::min<uint32_t>(I_count, 256u);
+  DevBuf<unsigned long long> stamps;
+  if (ctx->opt_debug & 8) {
+    AS_TRY(stamps.alloc(ctx, 8));
+    AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  }
+  {
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                     \
   case K:                                                                                                              \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds));                                                                        \
     hipLaunchKernelGGL((pair_join_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)P, T2,     \
-                       I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug);              \
+                       I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug, stamps.p);    \
     break;
   switch (KS) {
     AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
@@ -273,6 +364,15 @@ int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_beg
   }
 #undef AS_JOIN
   AS_HIP(ctx, hipGetLastError());
+  }
+  if (ctx->opt_debug & 8) {
+    unsigned long long h[8];
+    AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double w = (double)std::max<unsigned long long>(1, h[4]);
+    std::fprintf(stderr, "[join_bf16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f\n",
+                 h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6);
+  }
   return AS_OK;
 }
 

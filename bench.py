@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 # f64 MFMA row; the datasheet's FP64-matrix figure is 78.6 TF (reported next to it as frac_of_datasheet_78p6).
 F64_MFMA_PEAK_TFLOPS = 39.3
 F64_MATRIX_DATASHEET_TFLOPS = 78.6
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16: 32768 flop / 32 clk / SIMD at 2.4 GHz)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 flop/clk/SIMD (155 TF measured)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table
 
@@ -178,16 +179,29 @@ def main():
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
         msj, lj = prof.get("knn_mfma_join_f32", (0.0, 0))
+        msb, lb = prof.get("knn_mfma_join_bf16", (0.0, 0))
         # the candidate pass of one step may be split into a bulk launch and a remainder launch:
         # "launch" below = all candidate launches of one step (their flops add up to flops_per_launch)
         l32, l64 = min(l32, steps), min(l64, steps)
-        if lj and msj >= max(ms32, ms64):
-            # dominant kernel: the symmetric threshold join.  cos(i,j) = cos(j,i): every unordered pair of 256-row
-            # tiles is contracted once, so the launch EXECUTES half of the algorithmic 2 n^2 d (plus the diagonal
-            # blocks); `achieved` / `frac` price the kernel on what it executes, the reference-equivalent rate
-            # (what the reference's full square would need) is given next to it
-            t2 = (n + 255) // 256
-            pairs = t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)   # 256 x 256 blocks visited
+        # the symmetric threshold join.  cos(i,j) = cos(j,i): every unordered pair of 256-row tiles is contracted once,
+        # so the launch EXECUTES half of the algorithmic 2 n^2 d (plus the diagonal blocks); `achieved` / `frac` price
+        # the kernel on the MFMA flops it executes, the reference-equivalent rate (what the reference's full square would
+        # need at 2 flops per multiply-add) is given next to it
+        t2 = (n + 255) // 256
+        pairs = t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)   # 256 x 256 blocks visited
+        if lb and msb >= max(ms32, ms64, msj):
+            # split-bf16 contraction: x = hi + lo, three bf16 MFMAs per 16-wide k step (lo*hi + hi*lo + hi*hi)
+            d_pad = (d + 15) // 16 * 16
+            executed = 3 * 2.0 * pairs * 256 * 256 * d_pad
+            achieved = executed / (msb / lb * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "pair_join_bf16_kernel (v_mfma_f32_32x32x16_bf16 on split operands, 3 MFMAs per "
+                                                   "k step, f32 acc, symmetric threshold join; exact f64 re-rank + certification follow)",
+                        "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_ms": msb / lb, "launches": lb, "executed_flops_per_launch": executed,
+                        "algorithmic_flops_per_launch": flops_per_launch,
+                        "reference_equivalent_TFLOPs": flops_per_launch / (msb / lb * 1e-3) / 1e12}
+        elif lj and msj >= max(ms32, ms64):
             executed = 2.0 * pairs * 256 * 256 * d
             achieved = executed / (msj / lj * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc, symmetric "
@@ -241,7 +255,7 @@ def main():
                 extra["roofline_scan"]["traffic_source"] = "profiles/r01f_pmc_traffic.json"
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
-            "candidate_precision": ("f32 MFMA (symmetric threshold join on one GPU, top-k pass when sharded) -> f32 top-k "
+            "candidate_precision": ("split-bf16 MFMA symmetric threshold join (f32 MFMA beyond dim 128) -> f32 top-k "
                                     "-> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)")
             if args.cand_precision == 32 else "f64 MFMA -> exact f64 scan",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,
