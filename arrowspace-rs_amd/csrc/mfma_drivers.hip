@@ -540,10 +540,12 @@ static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t r
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                         uint32_t row_count, float *theta_out, const float *packed) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
-  const uint32_t rate = (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample);
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
-  const uint32_t ns = n / rate;
+  // sample size: whole pairs of 128-row tiles (the bf16 pass bins the sample by tile parity and has no tail
+  // handling), about n / join_sample of them; n >= 512 here
+  const uint32_t ns = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample)) & ~255u);
+  const uint32_t rate = n / ns;
   const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows, s_alloc = (s_tiles + 1) & ~1u;
   const uint32_t KC0 = std::max(8u, (m + 7) / 8 * 8);
   DevBuf<uint32_t> sid, cidx;

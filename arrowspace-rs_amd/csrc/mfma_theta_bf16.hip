@@ -18,6 +18,8 @@
 // through a 2-deep LDS-DMA ring (32 KB per tile at dim 128), all workgroups walking the sample in the same order.
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "mfma_common.cuh"
 
 namespace asx {
@@ -67,13 +69,33 @@ __global__ void pack_bf16_kernel(const double *__restrict__ R, const double *__r
   P[T * 2 * per_tile + per_tile + in_tile] = lo;
 }
 
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+
+// LDS fragment reads issued and waited for by hand (see mfma_join_bf16.hip)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(bf16x8 &x, bf16x8 &y) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(PENDING));
+}
+
+__device__ __forceinline__ void pin16(float (&x)[16]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+               "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
+
 // KS = 16-wide k steps per row (d_pad / 16).  PA: image of the rows [row_begin, ...) whose thresholds are wanted
-// (a_tiles 128-row tiles, even count); PS: image of the ns sample rows.
+// (a_tiles 128-row tiles, even count); PS: image of the ns sample rows, ns a multiple of 256 (s_tiles even, no
+// padded sample columns).  The sweep is the block pipeline of pair_join_bf16_kernel: per staged sample tile a wave
+// contracts four 32x32 blocks, the fragment reads run one k step ahead of their MFMAs, the 16 v_max of a block ride
+// behind the MFMAs of the next one (two accumulators alternate), the DMA pieces of the next tile are spread over
+// the blocks.  The tile loop is unrolled by two so that the parity bin of a tile is static.
 template <int KS>
 __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__restrict__ PA, uint32_t a_supers,
                                                             uint32_t row_count, const bf16x8 *__restrict__ PS,
-                                                            uint32_t s_tiles, uint32_t ns, uint32_t m,
-                                                            float *__restrict__ theta_out,
+                                                            uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
                                                             uint32_t *__restrict__ unit_counter) {
   constexpr int kPlaneVecs = KS * 4 * 64;   // 16-B vectors per plane of a 128-row tile
   constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
@@ -81,15 +103,18 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
   bf16x8 *bufB = reinterpret_cast<bf16x8 *>(smem);                               // 2 x tile
   float *s_max = reinterpret_cast<float *>(bufB);  // [8 waves][32 rows][65], aliases the ring once the sweep is over
   __shared__ uint32_t s_unit;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
 
-  auto stage = [&](uint32_t J, int buf) {  // 128-row sample tile J -> LDS, 1 KB pieces dealt to the waves
+  // 128-row sample tile J -> LDS: 1 KB pieces, KS per wave; part < 0: all, else the pieces of that quarter
+  auto stage = [&](uint32_t J, int buf, int part) {
     const bf16x8 *src = PS + (size_t)J * kTileVecs;
     bf16x8 *dst = bufB + (size_t)buf * kTileVecs;
-    constexpr int kPieces = kTileVecs / 64;
-    for (int p = wv; p < kPieces; p += 8)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(src + p * 64 + lane), (lds_void *)(dst + p * 64), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < KS; ++p)
+      if (part < 0 || (p & 3) == part)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + p) * 64 + lane), (lds_void *)(dst + (wv * KS + p) * 64),
+                                         16, 0, 0);
   };
 
   for (;;) {
@@ -114,41 +139,100 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
     float rmax[2][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rmax[0][r] = rmax[1][r] = -__builtin_inff();
-    v16f32 acc[4];
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
 
-    stage(0, 0);
+    bf16x8 b_hi[2], b_lo[2];
+#define AS_READ(SET, KSTEP, NN)                                                   \
+  {                                                                               \
+    lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);                     \
+    lds_read16<(kPlaneVecs + ((KSTEP)*4 + (NN)) * 64) * 16>(b_lo[SET], b_addr);   \
+  }
+    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, auto k0_c, auto k1_c, v16f32 &acc) {
+      constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+      constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
+      v16f32 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+      for (int ks = K0; ks < K1; ++ks) {
+        const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
+        bool more = true;
+        if (ks + 1 < KS) {
+          switch (ks + 1) {  // compile-time offsets
+#define AS_CASE(K) case K: if (nxt) AS_READ(1, K, nn) else AS_READ(0, K, nn) break;
+            AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
+#undef AS_CASE
+          }
+        } else if (next_nn >= 0) {
+          if (nxt) AS_READ(1, 0, (next_nn < 0 ? 0 : next_nn)) else AS_READ(0, 0, (next_nn < 0 ? 0 : next_nn))
+        } else {
+          more = false;
+        }
+        if (more) {
+          if (cur) lds_wait<2>(b_hi[1], b_lo[1]); else lds_wait<2>(b_hi[0], b_lo[0]);
+        } else {
+          if (cur) lds_wait<0>(b_hi[1], b_lo[1]); else lds_wait<0>(b_hi[0], b_lo[0]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi[cur], ks == 0 ? z : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo[cur], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi[cur], acc, 0, 0, 0);
+      }
+    };
+
+    v16f32 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending
+
+    __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring)
+    stage(0, 0, -1);
     __syncthreads();
-    for (uint32_t J = 0; J < s_tiles; ++J) {
-      if (J + 1 < s_tiles) stage(J + 1, (J + 1) & 1);
-      const bf16x8 *bb = bufB + (size_t)(J & 1) * kTileVecs;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-          const bf16x8 b_hi = bb[(ks * 4 + nn) * 64 + lane], b_lo = bb[kPlaneVecs + (ks * 4 + nn) * 64 + lane];
-          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[nn], 0, 0, 0);
-          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[nn], 0, 0, 0);
-          acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[nn], 0, 0, 0);
-        }
+    const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
+    for (uint32_t J = 0; J < s_tiles; J += 2) {
+#define AS_IC(V) std::integral_constant<int, (V)>{}
+// block NN of the tile in buffer PAR (= its parity bin); PREV_PAR = bin of the block whose maxima are taken now
+#define AS_BLOCK(PAR, NN, NEXT, CUR, PREV, PREV_PAR, MORE, JN)      \
+  {                                                                 \
+    constexpr int KH = (KS + 1) / 2;                                \
+    const uint32_t b_addr = b_addr0 + (PAR) * kTileVecs * 16;       \
+    if ((MORE) && wv < 4) stage(JN, (PAR) ^ 1, NN);                 \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR); \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                  \
+        rmax[PREV_PAR][r] = __builtin_fmaxf(rmax[PREV_PAR][r], PREV[r]); \
+    _Pragma("unroll") for (int i = 0; i < 3 * KH; ++i) {            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            \
+    }                                                               \
+    if ((MORE) && wv >= 4) stage(JN, (PAR) ^ 1, NN);                \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
+    pin16(rmax[PREV_PAR]);  /* the maxima are taken by here: PREV's registers are free for the next block */ \
+  }
+      {  // even tile J (buffer 0, bin 0); tile J + 1 always exists
+        const uint32_t b_addr = b_addr0;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(0, 0, 1, accA, accB, 1, true, J + 1)
+        AS_BLOCK(0, 1, 2, accB, accA, 0, true, J + 1)
+        AS_BLOCK(0, 2, 3, accA, accB, 0, true, J + 1)
+        AS_BLOCK(0, 3, -1, accB, accA, 0, true, J + 1)
       }
-      const bool tail = (J + 1 == s_tiles) && (ns % kTileRows != 0);
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn) {
-        const bool live = !tail || (J * kTileRows + nn * 32 + lc < ns);  // padded sample columns never count
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = live ? acc[nn][r] : -__builtin_inff();
-          if (J & 1u) rmax[1][r] = __builtin_fmaxf(rmax[1][r], v);
-          else rmax[0][r] = __builtin_fmaxf(rmax[0][r], v);
-          acc[nn][r] = 0.f;
-        }
+      __syncthreads();  // tile J + 1 has landed; everyone is done with buffer 0
+      {  // odd tile J + 1 (buffer 1, bin 1)
+        const bool more = J + 2 < s_tiles;
+        const uint32_t b_addr = b_addr0 + kTileVecs * 16;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(1, 0, 1, accA, accB, 0, more, J + 2)
+        AS_BLOCK(1, 1, 2, accB, accA, 1, more, J + 2)
+        AS_BLOCK(1, 2, 3, accA, accB, 1, more, J + 2)
+        AS_BLOCK(1, 3, -1, accB, accA, 1, more, J + 2)
       }
-      __syncthreads();  // the next tile has landed; everyone is done with this one
+#undef AS_BLOCK
+#undef AS_IC
+      __syncthreads();
     }
+#undef AS_READ
+    // the last block of the sweep (bin 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax[1][r] = __builtin_fmaxf(rmax[1][r], accB[r]);
+
     // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row][parity * 32 + lane column]
     float *wm = s_max + (size_t)wv * 32 * 65;
 #pragma unroll
@@ -204,7 +288,8 @@ int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, u
                          uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
-  if (m < 1 || m > 32 || ns < 128) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: sample too small");
+  if (m < 1 || m > 32 || ns < 256 || ns % 256 != 0)
+    return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: the sample must be a multiple of 256 rows");
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
   const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows;
   DevBuf<unsigned char> PA, PS;
@@ -224,7 +309,7 @@ int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, u
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                     (int)lds));                                                                        \
     hipLaunchKernelGGL((theta_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)PA.p, a_supers, \
-                       row_count, (const bf16x8 *)PS.p, s_tiles, ns, m, theta_out, unitc.p);                          \
+                       row_count, (const bf16x8 *)PS.p, s_tiles, m, theta_out, unitc.p);                          \
     break;
   switch (KS) {
     AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
