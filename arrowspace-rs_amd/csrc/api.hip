@@ -216,6 +216,10 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_min_rows") ctx->opt_join_min_rows = value;
   else if (n == "join_bf16") ctx->opt_join_bf16 = value;
   else if (n == "join_pipe") ctx->opt_join_pipe = value == 32 ? 32 : 16;
+  else if (n == "search_scan") ctx->opt_search_scan = value;
+  else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
+  else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;
+  else if (n == "search_scan_cap") ctx->opt_search_scan_cap = value;
   else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
@@ -567,6 +571,10 @@ void as_index_destroy(as_index *ix) {
   (void)hipFree(ix->norms);
   if (ix->packed) (void)hipFree(ix->packed);
   if (ix->packed32) (void)hipFree(ix->packed32);
+  if (ix->packed16) (void)hipFree(ix->packed16);
+  if (ix->scan_sample) (void)hipFree(ix->scan_sample);
+  if (ix->scan_sample_lam) (void)hipFree(ix->scan_sample_lam);
+  if (ix->lam32) (void)hipFree(ix->lam32);
   delete ix;
 }
 

@@ -52,6 +52,10 @@ struct as_ctx {
   int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
   int64_t opt_join_min_rows = 32768;
   int64_t opt_join_pipe = 16;     // contraction of the join: 16 = split bf16 (dim <= 128), 32 = f32 MFMA
+  int64_t opt_search_scan = 1;    // search: threshold scan on the bf16 pipe before the top-k passes (dim <= 128, alpha > 0)
+  int64_t opt_search_scan_sample = 32;   // its score guess: the m-th best of a 1-in-N sample of the items
+  int64_t opt_search_scan_rank = 3;
+  int64_t opt_search_scan_cap = 512;     // candidate slots per query
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
@@ -99,6 +103,11 @@ struct as_index {
   double *norms = nullptr;          // n exact norms
   double *packed = nullptr;         // fragment-packed unit rows, f64 image (lazy)
   float *packed32 = nullptr;        // fragment-packed unit rows, f32 image (lazy)
+  void *packed16 = nullptr;         // split-bf16 image (lazy; the threshold scan of the search)
+  uint32_t *scan_sample = nullptr;  // sampled item ids of the threshold scan and their lambdas (lazy)
+  float *scan_sample_lam = nullptr;
+  float *lam32 = nullptr;           // f32 lambdas of all items, padded to whole tiles (lazy)
+  uint32_t scan_ns = 0;
 };
 
 namespace asx {

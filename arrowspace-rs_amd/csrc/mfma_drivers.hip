@@ -203,7 +203,10 @@ static uint32_t cand_capacity(as_ctx *ctx, uint32_t K) {
   return std::min<uint32_t>(kc, 64);
 }
 
-constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straight to the exact scan
+constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straight to the exact scan ...
+// ... when the matrix is small: the exact scan is one wave per row over ALL columns (300 ms at 1 M x 128 however
+// few the rows), an MFMA stage over the failed rows a few tens of ms
+static bool exact_direct(uint32_t n_rows, uint32_t n_cols) { return n_rows <= kExactDirect && n_cols < 16384; }
 
 template <class Policy, class Bound>
 static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const double *B, uint32_t d,
@@ -313,7 +316,8 @@ __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32
 // certification against theta.  The candidates of a row come from n_src lists (one per rank that contracted
 // tile pairs touching it): cnt_src[s * row_count + r], cand_src[(s * row_count + r) * cap ..].
 template <class Policy, class Bound>
-__global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restrict__ X, uint32_t d, uint32_t row_begin,
+__global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restrict__ X, const double *__restrict__ XA,
+                                                          const uint32_t *__restrict__ a_ids, uint32_t d, uint32_t row_begin,
                                                           uint32_t row_count, const float *__restrict__ theta,
                                                           uint32_t n_src, const uint32_t *__restrict__ cnt_src,
                                                           const uint32_t *__restrict__ cand_src, uint32_t cap,
@@ -328,8 +332,9 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
   double *ek = xrow + d;
   uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(smem) + (size_t)4 * (d + cmax)) + (size_t)wv * cmax;
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
-    const uint32_t a = row_begin + r;
-    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)a * d + k];
+    const uint32_t a = a_ids ? a_ids[r] : row_begin + r;  // A row (XA = the A matrix: X itself, or the queries)
+    const uint32_t ti = a_ids ? r : a;                     // thresholds of a gathered list are indexed by position
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = XA[(uint64_t)a * d + k];
     // gather the candidate ids of all sources into ei[0..C)
     uint32_t C = 0;
     bool overflow = false;
@@ -382,8 +387,8 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
       out_key[(uint64_t)r * K + s] = __builtin_inf();
       out_idx[(uint64_t)r * K + s] = kNoIdx;
     }
-    // every pair that is not in the lists has an approximate cosine below theta[a]
-    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[a]);
+    // every pair that is not in the lists has an approximate cosine below theta[ti]
+    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[ti]);
     if (force_exact && force_exact[a]) ok = false;
     if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
     wave_sync();
@@ -400,7 +405,8 @@ typedef const __attribute__((address_space(1))) void rr_gbl_void;
 
 template <class Policy, class Bound, int kRrRows, int NBUF>
 __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
-    const double *__restrict__ X, uint32_t row_begin, uint32_t row_count, const float *__restrict__ theta, uint32_t n_src,
+    const double *__restrict__ X, const double *__restrict__ XA, const uint32_t *__restrict__ a_ids, uint32_t row_begin,
+    uint32_t row_count, const float *__restrict__ theta, uint32_t n_src,
     const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src, uint32_t cap, uint32_t cmax, uint32_t K,
     const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double *__restrict__ out_key,
     uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows, uint32_t *__restrict__ fail_count,
@@ -417,8 +423,9 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
   uint32_t *ei = reinterpret_cast<uint32_t *>(ek + cmax);
 
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
-    const uint32_t a = row_begin + r;
-    for (uint32_t k = lane; k < d; k += 64) xrow[k] = X[(uint64_t)a * d + k];
+    const uint32_t a = a_ids ? a_ids[r] : row_begin + r;
+    const uint32_t ti = a_ids ? r : a;
+    for (uint32_t k = lane; k < d; k += 64) xrow[k] = XA[(uint64_t)a * d + k];
     uint32_t C = 0;
     bool overflow = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
       out_key[(uint64_t)r * K + s] = __builtin_inf();
       out_idx[(uint64_t)r * K + s] = kNoIdx;
     }
-    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[a]);
+    bool ok = !overflow && n_valid >= K && kth < bnd.lower_bound(-(double)theta[ti]);
     if (force_exact && force_exact[a]) ok = false;
     if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
     wave_sync();
@@ -519,6 +526,15 @@ int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_beg
               uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
 int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
                          uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out);
+int join_bf16_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
+                   const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
+                   const char *prof_name);
+int join_bf16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *guess,
+                     const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap, uint32_t *cnt,
+                     uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
+int search_thresholds_bf16(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
+                           const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam,
+                           float alpha, float beta, float *score_out, uint32_t m2, float *score2_out);
 uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
 int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
               uint32_t d, void *P, uint32_t tiles);
@@ -747,8 +763,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));                               \
   hipLaunchKernelGGL((rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>),                                        \
-                     dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows,         \
-                     (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
+                     dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows, rows,   \
+                     (const uint32_t *)nullptr, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
                      bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p)
         if (rr_rows == 8 && rr_nbuf == 1) { AS_RR(8, 1); }
         else if (rr_rows == 8) { AS_RR(8, 2); }
@@ -760,7 +776,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
-                           dim3(256), lds, ctx->stream, rows, d, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt,
+                           dim3(256), lds, ctx->stream, rows, rows, (const uint32_t *)nullptr, d, (uint32_t)row_begin, row_count,
+                           js->theta, js->n_src, js->cnt,
                            js->cand, js->cap, cmax, K, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p);
       }
       AS_HIP(ctx, hipGetLastError());
@@ -933,12 +950,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   };
 
   // ---- stage 1b (after the join): f32 top-k pass over the gathered rows ----
-  if (use_join && cur_n > kExactDirect) {
+  if (use_join && !exact_direct(cur_n, n)) {
     AS_TRY(mfma_stage(true, ids_a, pos_a, "knn_uncertified_rows_stage1b"));
     if (cur_n == 0) return AS_OK;
   }
   // ---- stage 2: f64 MFMA over the gathered rows ----
-  if (use_f32 && !wide && cur_n > kExactDirect) {
+  if (use_f32 && !wide && !exact_direct(cur_n, n)) {
     AS_TRY(mfma_stage(false, ids_b, pos_b, "knn_uncertified_rows_stage2"));
     if (cur_n == 0) return AS_OK;
   }
@@ -969,6 +986,34 @@ __global__ void absmax_kernel(const double *__restrict__ v, uint64_t n, unsigned
   if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
 
+// ---- threshold scan of the search (stage 0 of K9) --------------------------------------------------
+// score(q, i) = alpha cos(q, i) + beta lam(q, i), lam = 1 - min(|lambda_q - lambda_i|, 1) (src/core.rs:229-239).
+// Every query gets a guess g_q for its K-th best score (the m-th best approximate score over a sample of the items,
+// mfma_theta_bf16.hip); the search form of the one-sided bf16 join lists every item whose approximate score
+// reaches g_q; the exact re-rank scores the listed items in f64, and a query is certified when its K-th best exact
+// score is clear of what an unlisted item can reach, g_q + delta (delta: the cosine bound of the split-bf16
+// products scaled by alpha, the f32 evaluation of the lambda term, the f32 roundings of the sum).  Any guess is
+// correct; a guess above the true K-th score fails the certification and the query goes on to the MFMA top-k /
+// exact stages.
+__global__ void gather_lambda_f32_kernel(const double *__restrict__ lam, const uint32_t *__restrict__ ids, uint32_t count,
+                                         uint32_t padded, float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < padded) out[i] = i < count ? (float)lam[ids ? ids[i] : i] : 0.f;
+}
+// guesses padded to whole super tiles: +inf on padding rows (never a candidate), -inf for a NaN guess (everything
+// is listed, the list overflows, the query falls through)
+__global__ void scan_guess_kernel(const float *__restrict__ guess, const uint32_t *__restrict__ ids, uint32_t nq,
+                                  uint32_t padded, float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  float g = __builtin_inff();
+  if (i < nq) {
+    g = guess[ids ? ids[i] : i];
+    if (!(g == g)) g = -__builtin_inff();
+  }
+  out[i] = g;
+}
+
 int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms, const double *q_lambdas,
                 uint64_t nq64, uint32_t k, double alpha, uint32_t *out_idx, double *out_key) {
   const uint32_t n = (uint32_t)ix->n, d = (uint32_t)ix->d, nq = (uint32_t)nq64;
@@ -977,7 +1022,10 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t KC = cand_capacity(ctx, K);
   const bool wide = NC > kMaxNC;
   const bool use_f32 = (ctx->opt_cand_precision != 64 || wide) && fits_f32(KC);
-  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || nq == 0)
+  // deep lists (large k) and small matrices do not fit the MFMA top-k passes; the threshold scan (stage 0) has no
+  // such limit, so what it leaves open then goes straight to the exact scan
+  const bool mfma_ok = !((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows);
+  if (nq == 0 || n < 4 * kTileRows)
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
@@ -1021,7 +1069,180 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   pb.KC = KC;
 
   uint32_t n_fail = 0;
-  {
+  // ---- stage 0: threshold scan on the bf16 pipe (see the note above gather_lambda_f32_kernel) ----
+  bool scan = ctx->opt_search_scan && ctx->opt_cand_precision != 64 && !wide && d <= 128 && alpha > 0.0 && alpha <= 1.0 && K < 1024 &&
+              n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows);
+  double lsum = 0.0;
+  if (scan) {  // the f32 lambda term needs lambdas of moderate size (as in the f32 top-k pass below)
+    DevBuf<unsigned long long> amax;
+    AS_TRY(amax.alloc(ctx, 2));
+    AS_HIP(ctx, hipMemsetAsync(amax.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(absmax_kernel, dim3(std::min<uint64_t>(1024, cdiv(nq, 256))), dim3(256), 0, ctx->stream, q_lambdas,
+                       (uint64_t)nq, amax.p);
+    hipLaunchKernelGGL(absmax_kernel, dim3(std::min<uint64_t>(1024, cdiv(n, 256))), dim3(256), 0, ctx->stream, ix->lambdas,
+                       (uint64_t)n, amax.p + 1);
+    AS_HIP(ctx, hipGetLastError());
+    double hmax[2] = {0.0, 0.0};
+    AS_HIP(ctx, copy_d2h(ctx, hmax, amax.p, sizeof(hmax)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lsum = hmax[0] + hmax[1];
+    scan = lsum <= 64.0;  // NaN lambdas fail this too
+  }
+  ctx->stats["search_scan"] = scan ? 1 : 0;
+  if (!scan && !mfma_ok)
+    return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
+  if (scan) {
+    const double beta = 1.0 - alpha;
+    if (!ix->packed16) {
+      AS_HIP(ctx, hipMalloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
+      AS_TRY(pack_bf16(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed16, b_alloc));
+    }
+    if (!ix->lam32) {
+      AS_HIP(ctx, hipMalloc((void **)&ix->lam32, sizeof(float) * (size_t)b_alloc * kTileRows));
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)b_alloc * kTileRows, 256)), dim3(256), 0, ctx->stream,
+                         ix->lambdas, (const uint32_t *)nullptr, n, b_alloc * kTileRows, ix->lam32);
+    }
+    const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
+    if (ix->scan_sample && ix->scan_ns != ns_want) {  // the option changed since the sample was drawn
+      (void)hipFree(ix->scan_sample);
+      (void)hipFree(ix->scan_sample_lam);
+      ix->scan_sample = nullptr;
+      ix->scan_sample_lam = nullptr;
+    }
+    if (!ix->scan_sample) {
+      const uint32_t ns = ns_want;
+      AS_HIP(ctx, hipMalloc((void **)&ix->scan_sample, sizeof(uint32_t) * ns));
+      AS_HIP(ctx, hipMalloc((void **)&ix->scan_sample_lam, sizeof(float) * ns));
+      hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, n / ns, sample_half_bits(ns),
+                         ix->scan_sample);
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ix->lambdas,
+                         ix->scan_sample, ns, ns, ix->scan_sample_lam);
+      AS_HIP(ctx, hipGetLastError());
+      ix->scan_ns = ns;
+    }
+    const uint32_t ns = ix->scan_ns;
+    const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_search_scan_rank, 32));
+    const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u, padded = a_alloc * kTileRows;
+    const uint32_t cap = (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_search_scan_cap, 1024));
+    DevBuf<unsigned char> PQ;
+    DevBuf<float> qlam, guess, guess2, guess_pad;
+    // the looser guess of the second pass over what fails: rank 2 m + 6, as far as its ~rank x rate candidates fit the lists
+    const uint32_t m2 = std::max(m, std::min<uint32_t>(std::min<uint32_t>(48, 2 * m + 6), 512u / std::max(1u, n / ns)));
+    DevBuf<uint32_t> cnt, cand, unitc;
+    AS_TRY(PQ.alloc(ctx, packed_vecs_bf16(a_alloc, d) * 16));
+    AS_TRY(qlam.alloc(ctx, padded));
+    AS_TRY(guess.alloc(ctx, nq));
+    AS_TRY(guess2.alloc(ctx, nq));
+    AS_TRY(guess_pad.alloc(ctx, padded));
+    AS_TRY(cnt.alloc(ctx, padded));
+    AS_TRY(cand.alloc(ctx, (size_t)padded * cap));
+    AS_TRY(unitc.alloc(ctx, 1));
+    AS_TRY(pack_bf16(ctx, queries, q_norms, nullptr, 0, nq, d, PQ.p, a_alloc));
+    hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
+                       (const uint32_t *)nullptr, nq, padded, qlam.p);
+    AS_TRY(search_thresholds_bf16(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
+                                  (float)alpha, (float)beta, guess.p, m2, guess2.p));
+    hipLaunchKernelGGL(scan_guess_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
+                       nq, padded, guess_pad.p);
+    AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * padded, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+    AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQ.p, nq, guess_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
+                            cnt.p, cand.p, unitc.p, "search_scan_bf16"));
+    {
+      // unlisted items: approximate score < g_q.  Approximate vs exact score: alpha x the cosine bound of the pass,
+      // the lambda term in f32 with beta folded into its operands (four roundings on numbers of size <= lsum),
+      // the f32 roundings of alpha, beta and of the two fused multiply-adds.
+      const double lam_err = std::fabs(beta) * (lsum * 0x1p-22 + 0x1p-21);
+      const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
+                            1e-12};
+      ProfScope ps(ctx, "search_rerank");
+      const size_t lds128 = (size_t)4 * (1024 + (size_t)16 * kRrPitch + (size_t)cap * 12);
+      if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)ix->items & 15) == 0) {
+        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
+        hipLaunchKernelGGL((rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>),
+                           dim3(std::min<uint64_t>(cdiv(nq, 4), 256 * 16)), dim3(256), lds128, ctx->stream, ix->items, queries,
+                           (const uint32_t *)nullptr, 0u, nq, guess_pad.p, 1u, cnt.p, cand.p, cap, cap, K,
+                           (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p);
+      } else {
+        const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
+        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nq, 4), 8192)),
+                           dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)nullptr, d, 0u, nq, guess_pad.p, 1u,
+                           cnt.p, cand.p, cap, cap, K, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p,
+                           fail_count.p, err.p);
+      }
+      AS_HIP(ctx, hipGetLastError());
+    }
+    {  // statistics: candidates per query
+      DevBuf<unsigned long long> st;
+      AS_TRY(st.alloc(ctx, 3));
+      AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(join_count_stats_kernel, dim3(64), dim3(256), 0, ctx->stream, cnt.p, nq, cap, st.p);
+      unsigned long long h[3] = {0, 0, 0};
+      AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->stats["search_scan_candidates"] = (int64_t)h[0];
+      ctx->stats["search_scan_max_per_query"] = (int64_t)h[1];
+      ctx->stats["search_scan_overflow_queries"] = (int64_t)h[2];
+    }
+    AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
+    ctx->stats["search_scan_uncertified_first"] = n_fail;
+    // ---- stage 0b: the queries whose guess was too high, again with the looser one ----
+    if (n_fail > 0 && n_fail <= nq / 4 + 16) {
+      const uint32_t nf = n_fail;
+      const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad_b = b_al * kTileRows;
+      const uint32_t cap2 = 1024;
+      DevBuf<unsigned char> PQb;
+      DevBuf<float> qlam_b, guess_b;
+      DevBuf<uint32_t> cnt_b, cand_b, oi, fail_b, ids_b;
+      DevBuf<double> ok;
+      AS_TRY(PQb.alloc(ctx, packed_vecs_bf16(b_al, d) * 16));
+      AS_TRY(qlam_b.alloc(ctx, pad_b));
+      AS_TRY(guess_b.alloc(ctx, pad_b));
+      AS_TRY(cnt_b.alloc(ctx, pad_b));
+      AS_TRY(cand_b.alloc(ctx, (size_t)pad_b * cap2));
+      AS_TRY(ok.alloc(ctx, (size_t)nf * K));
+      AS_TRY(oi.alloc(ctx, (size_t)nf * K));
+      AS_TRY(fail_b.alloc(ctx, nf));
+      AS_TRY(ids_b.alloc(ctx, nf));
+      AS_TRY(pack_bf16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, q_lambdas, fail1.p, nf, pad_b,
+                         qlam_b.p);
+      hipLaunchKernelGGL(scan_guess_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, guess2.p, fail1.p, nf, pad_b,
+                         guess_b.p);
+      AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad_b, ctx->stream));
+      AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+      AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+      AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQb.p, nf, guess_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
+                              cnt_b.p, cand_b.p, unitc.p, "search_scan_bf16"));
+      {
+        const double lam_err = std::fabs(beta) * (lsum * 0x1p-22 + 0x1p-21);
+        const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
+                              1e-12};
+        ProfScope ps(ctx, "search_rerank");
+        const size_t lds = (size_t)4 * (d + cap2) * sizeof(double) + (size_t)4 * cap2 * sizeof(uint32_t);
+        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
+                           dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)fail1.p, d, 0u, nf, guess_b.p, 1u,
+                           cnt_b.p, cand_b.p, cap2, cap2, K, (const uint8_t *)nullptr, pol, bnd, ok.p, oi.p, fail_b.p, fail_count.p,
+                           err.p);
+        AS_HIP(ctx, hipGetLastError());
+      }
+      hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)nf * K, 256)), dim3(256), 0, ctx->stream, fail1.p, nf, K, ok.p,
+                         oi.p, out_key, out_idx);
+      uint32_t nf2 = 0;
+      AS_TRY(read_u32(ctx, fail_count.p, &nf2));
+      if (nf2) {  // what is still open: positions in the gathered list -> query ids, back into fail1
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nf2, 256)), dim3(256), 0, ctx->stream, fail1.p, fail_b.p, nf2, 0u, ids_b.p);
+        AS_HIP(ctx, hipMemcpyAsync(fail1.p, ids_b.p, sizeof(uint32_t) * nf2, hipMemcpyDeviceToDevice, ctx->stream));
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
+      n_fail = nf2;
+    }
+  } else {
     const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows;
     const uint32_t a_items = use_f32 ? (a_tiles + 1) / 2 : a_tiles;
     pb.splits = pick_splits_scan(a_items, b_tiles, n);
@@ -1080,7 +1301,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t *exact_ids = fail1.p;
   uint32_t n_exact = n_fail;
   DevBuf<uint32_t> fail2, ids2;
-  if (use_f32 && !wide && n_fail > kExactDirect) {
+  if (mfma_ok && (use_f32 || scan) && !wide && n_fail > 0 && !exact_direct(n_fail, n)) {
     const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
     pb.arows = ARows{fail1.p, 0};
     pb.nA = n_fail;

@@ -54,13 +54,32 @@ __device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__r
 
 // P = split bf16 image of ALL rows (mfma_theta_bf16.hip: tiles of 128 rows, hi plane then lo plane, even tile
 // count, zero padded).  Work units as in pair_join_mfma32_kernel.
-template <int KS>
-__global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__restrict__ P, uint32_t T2, uint32_t I_begin,
+//
+// RECT: the one-sided form.  The A rows are another matrix (the queries of a search) or a gathered subset of the
+// rows (what a stage left uncertified): image PA of nA rows, super tile I of it against EVERY column block, a pair
+// is appended to the A row's list only (row-side test), lists / thresholds are indexed by A row; a_ids (or nullptr)
+// gives the global row of an A row, for the self exclusion.
+//
+// MODE 2 (search): one-sided, and what is tested is not the product but the approximate search score built on it,
+// alpha * cos + beta * (1 - min(|lambda_q - lambda_x|, 1)) >= guess[q]  (0 < alpha <= 1, beta = 1 - alpha; src/core.rs:229-239),
+// rearranged as  alpha * s - min(|beta lq - beta lx|, beta) >= guess - beta  (four vector instructions per product).
+// theta = the score guesses of the queries (+inf on padding rows).
+struct JoinSearchTerm {
+  const float *a_lam;  // lambdas of the A rows (padded to whole super tiles)
+  const float *x_lam;  // lambdas of all rows of P (padded to whole tiles)
+  float alpha, beta;
+};
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__restrict__ P, const bf16x8 *__restrict__ PA,
+                                                                uint32_t nA, const uint32_t *__restrict__ a_ids,
+                                                                JoinSearchTerm st,
+                                                                uint32_t T2, uint32_t I_begin,
                                                                 uint32_t I_count, uint32_t W, uint32_t n,
                                                                 const float *__restrict__ theta, uint32_t cap,
                                                                 uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
                                                                 uint32_t *__restrict__ unit_counter, int dbg,
                                                                 unsigned long long *__restrict__ stamps) {
+  constexpr bool RECT = MODE >= 1, SEARCH = MODE == 2;
   constexpr int kPlaneVecs = KS * 4 * 64;    // 16-B vectors per plane of a 128-row tile
   constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,19 +143,21 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     const uint32_t u = s_unit;
     if (u >= total_units) break;
     const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
-    const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
-    const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
     const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
-    const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
-    uint32_t p_lo, p_hi;
-    if (delta + Wc <= T2) {
-      p_lo = delta;
-      p_hi = min(delta + Wc, L);
-    } else {  // the block straddles I: its tail is offsets 0 .. (W <= T2 / 4 keeps the head out of the pattern)
-      p_lo = 0;
-      p_hi = min(delta + Wc - T2, L);
+    uint32_t p_lo = 0, p_hi = Wc;  // RECT: the whole column block, offsets counted from B0
+    if (!RECT) {
+      const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
+      const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
+      const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
+      if (delta + Wc <= T2) {
+        p_lo = delta;
+        p_hi = min(delta + Wc, L);
+      } else {  // the block straddles I: its tail is offsets 0 .. (W <= T2 / 4 keeps the head out of the pattern)
+        p_lo = 0;
+        p_hi = min(delta + Wc - T2, L);
+      }
+      if (p_hi <= p_lo) continue;
     }
-    if (p_hi <= p_lo) continue;
     const uint32_t steps = (p_hi - p_lo) * 2;  // 128-row B tiles to visit
 
     bf16x8 a_hi[KS], a_lo[KS];
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       const int row0 = wv * 32;
       const size_t T = (size_t)2 * I + (row0 >> 7);
       const int s0 = (row0 & 127) >> 5;
-      const bf16x8 *a_src = P + T * kTileVecs + (size_t)s0 * 64 + lane;
+      const bf16x8 *a_src = (RECT ? PA : P) + T * kTileVecs + (size_t)s0 * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         a_hi[ks] = a_src[(size_t)ks * 256];
@@ -155,9 +176,22 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     float tr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) tr[r] = theta[row_base + (r & 3) + 8 * (r >> 2)];
+    float lqb[SEARCH ? 16 : 1];  // beta * lambda of this lane's 16 rows
+    if (SEARCH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        lqb[r] = st.beta * st.a_lam[row_base + (r & 3) + 8 * (r >> 2)];
+        tr[r] -= st.beta;  // guess - beta
+      }
+    }
+    // search: the tested quantity of a product (tcv = beta * lambda of the column)
+    auto weigh = [&](float sdot, int r, float tcv) -> float {
+      const float t = __builtin_fminf(__builtin_fabsf(lqb[SEARCH ? r : 0] - tcv), st.beta);
+      return __builtin_fmaf(st.alpha, sdot, -t);
+    };
 
     auto tile_of = [&](uint32_t step) -> uint32_t {
-      uint32_t S = I + p_lo + (step >> 1);
+      uint32_t S = (RECT ? B0 : I) + p_lo + (step >> 1);
       S = S >= T2 ? S - T2 : S;
       return 2 * S + (step & 1u);
     };
@@ -210,7 +244,10 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     auto any_hit = [&](const v16f32 &acc, float tcv) -> bool {
       bool h = false;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h = h || (acc[r] >= tr[r]) || (acc[r] >= tcv);
+      for (int r = 0; r < 16; ++r) {
+        if (SEARCH) h = h || (weigh(acc[r], r, tcv) >= tr[r]);
+        else h = h || (acc[r] >= tr[r]) || (acc[r] >= tcv);
+      }
       return h;
     };
     // the rows of a block that carries a hit are tested one by one with wave-uniform branches; what passes goes to
@@ -222,11 +259,13 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       lds_wait<0>(b_hi[1], b_lo[1]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[r];
-        const bool pr = v >= tr[r], pc = v >= tcv;
+        const float v = SEARCH ? weigh(acc[r], r, tcv) : acc[r];
+        const bool pr = v >= tr[r], pc = SEARCH ? false : v >= tcv;
         if (__any(pr || pc)) {
           const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
-          const bool inside = row < n && col < n && row != col;
+          bool inside;
+          if (RECT) inside = row < nA && col < n && (a_ids == nullptr || a_ids[row] != col);
+          else inside = row < n && col < n && row != col;
           const bool w1 = inside && pr, w2 = inside && pc;
           const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
           const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
@@ -258,11 +297,14 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       const int pbuf = (int)(step & 1u);
       const bool more_tiles = step + 1 < steps && !(dbg & 4);  // dbg 4: timing ablation
       const uint32_t tile_next = more_tiles ? tile_of(step + 1) : 0;
-      const bool diag = (p_lo + (step >> 1)) == 0;
+      const bool diag = RECT || (p_lo + (step >> 1)) == 0;
       // column thresholds of this lane's four columns (the diagonal block is row-side only)
       float tc[4];
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc];
+      for (int nn = 0; nn < 4; ++nn) {
+        if (SEARCH) tc[nn] = st.beta * st.x_lam[tile * kTileRows + nn * 32 + lc];  // the column's term, not a threshold
+        else tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc];
+      }
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kTileVecs) + (uint32_t)lane * 16u;
       const uint32_t col0 = tile * kTileRows + lc;
 
@@ -279,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     const bool h = any_hit(PREV, tc_prev);                          \
     _Pragma("unroll") for (int i = 0; i < 3 * KH; ++i) {            \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, SEARCH ? 6 : 3, 0); \
     }                                                               \
     if (more_tiles && wv >= 4) stage(tile_next, pbuf ^ 1, NN);      \
     contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
@@ -331,39 +373,43 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
 
 uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
 
-// Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 super tiles of the split bf16 image P
-// (all n rows).  cnt / cand (n x cap) are indexed by global row; cnt must be zeroed by the caller, unit_counter too.
-// dim <= 128 (the split A fragments stay in registers); AS_ERR_UNSUPPORTED beyond.
-int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, const void *P, const void *PA, uint32_t nA, const uint32_t *a_ids,
+                            uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta, uint32_t cap,
+                            uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t T2 = (b_tiles + 1) / 2;
   const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + (size_t)8 * kQueue * sizeof(uint2);
   // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
-  const uint32_t W = std::max(1u, std::min(16u, T2 / 4));
-  const unsigned grid = std::min<uint32_t>(I_count, 256u);
+  const bool rect = mode >= 1;
+  const uint32_t W = rect ? std::min(16u, T2) : std::max(1u, std::min(16u, T2 / 4));
+  const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
+  const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
   if (ctx->opt_debug & 8) {
     AS_TRY(stamps.alloc(ctx, 8));
     AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
   }
   {
-  ProfScope ps(ctx, prof_name);
+    ProfScope ps(ctx, prof_name);
+#define AS_JOIN1(K, R)                                                                                                 \
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_bf16_kernel<K, R>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds));                                                                          \
+  hipLaunchKernelGGL((pair_join_bf16_kernel<K, R>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)P,        \
+                     (const bf16x8 *)PA, nA, a_ids, st, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter, \
+                     (int)ctx->opt_debug, stamps.p)
 #define AS_JOIN(K)                                                                                                     \
   case K:                                                                                                              \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                        \
-    hipLaunchKernelGGL((pair_join_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)P, T2,     \
-                       I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug, stamps.p);    \
+    if (mode == 2) { AS_JOIN1(K, 2); } else if (mode == 1) { AS_JOIN1(K, 1); } else { AS_JOIN1(K, 0); }                \
     break;
-  switch (KS) {
-    AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
-    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
-  }
+    switch (KS) {
+      AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
+      default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
+    }
 #undef AS_JOIN
-  AS_HIP(ctx, hipGetLastError());
+#undef AS_JOIN1
+    AS_HIP(ctx, hipGetLastError());
   }
   if (ctx->opt_debug & 8) {
     unsigned long long h[8];
@@ -374,6 +420,35 @@ int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_beg
                  h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6);
   }
   return AS_OK;
+}
+
+// Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 super tiles of the split bf16 image P
+// (all n rows).  cnt / cand (n x cap) are indexed by global row; cnt must be zeroed by the caller, unit_counter too.
+// dim <= 128 (the split A fragments stay in registers); AS_ERR_UNSUPPORTED beyond.
+int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+  return join_bf16_launch(ctx, 0, JoinSearchTerm{nullptr, nullptr, 0.f, 0.f}, P, P, n, nullptr, n, d, I_begin, I_count, theta, cap,
+                          cnt, cand, unit_counter, prof_name);
+}
+
+// One-sided form: the nA rows of image PA (even tile count; theta_a padded to whole super tiles with +inf) against
+// all n rows of P; cnt / cand (nA x cap) are indexed by A row.  a_ids: global row of an A row (self exclusion) or nullptr.
+int join_bf16_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
+                   const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
+                   const char *prof_name) {
+  const uint32_t a_supers = (nA + 255) / 256;
+  return join_bf16_launch(ctx, 1, JoinSearchTerm{nullptr, nullptr, 0.f, 0.f}, P, PA, nA, a_ids, n, d, 0, a_supers, theta_a, cap, cnt,
+                          cand, unit_counter, prof_name);
+}
+
+// Search form of the one-sided join (MODE 2 of the kernel): the nq queries of image PQ against all n items of P;
+// guess (padded to whole super tiles with +inf): score guess per query; q_lam / x_lam: f32 lambdas, padded.
+int join_bf16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *guess,
+                     const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap, uint32_t *cnt,
+                     uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+  const uint32_t a_supers = (nq + 255) / 256;
+  return join_bf16_launch(ctx, 2, JoinSearchTerm{q_lam, x_lam, alpha, beta}, P, PQ, nq, nullptr, n, d, 0, a_supers, guess, cap, cnt,
+                          cand, unit_counter, prof_name);
 }
 
 }  // namespace asx

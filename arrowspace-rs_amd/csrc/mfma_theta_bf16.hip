@@ -92,11 +92,22 @@ __device__ __forceinline__ void pin16(float (&x)[16]) {
 // contracts four 32x32 blocks, the fragment reads run one k step ahead of their MFMAs, the 16 v_max of a block ride
 // behind the MFMAs of the next one (two accumulators alternate), the DMA pieces of the next tile are spread over
 // the blocks.  The tile loop is unrolled by two so that the parity bin of a tile is static.
-template <int KS>
+//
+// SEARCH: the rows are queries, the sample rows items, and what is reduced is the approximate search score
+// alpha * cos + beta * (1 - min(|lambda_q - lambda_x|, 1)) (src/core.rs:229-239) instead of the bare product: the
+// m-th largest sampled SCORE of a query is the guess for its K-th best score that the threshold scan of the search
+// works from (mfma_drivers.hip).  a_lam / s_lam: f32 lambdas of the rows (padded to whole super tiles) and of the
+// sample rows.
+struct SearchTerm {
+  const float *a_lam, *s_lam;
+  float alpha, beta;
+};
+template <int KS, bool SEARCH>
 __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__restrict__ PA, uint32_t a_supers,
                                                             uint32_t row_count, const bf16x8 *__restrict__ PS,
                                                             uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
-                                                            uint32_t *__restrict__ unit_counter) {
+                                                            uint32_t m2, float *__restrict__ theta2_out,
+                                                            uint32_t *__restrict__ unit_counter, SearchTerm st) {
   constexpr int kPlaneVecs = KS * 4 * 64;   // 16-B vectors per plane of a 128-row tile
   constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,6 +150,18 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
     float rmax[2][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rmax[0][r] = rmax[1][r] = -__builtin_inff();
+    float lq[SEARCH ? 16 : 1];  // lambdas of this lane's 16 rows
+    float lx_prev = 0.f;        // lambda of the column of the block whose maxima are pending
+    if (SEARCH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lq[r] = st.a_lam[I * 256 + wv * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
+    }
+    // what a pending product contributes: the product itself, or the score built on it
+    auto value = [&](float sdot, int r) -> float {
+      if (!SEARCH) return sdot;
+      const float t = __builtin_fminf(__builtin_fabsf(lq[SEARCH ? r : 0] - lx_prev), 1.f);
+      return __builtin_fmaf(-st.beta, t, __builtin_fmaf(st.alpha, sdot, st.beta));
+    };
 
     bf16x8 b_hi[2], b_lo[2];
 #define AS_READ(SET, KSTEP, NN)                                                   \
@@ -193,21 +216,34 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
 #define AS_BLOCK(PAR, NN, NEXT, CUR, PREV, PREV_PAR, MORE, JN)      \
   {                                                                 \
     constexpr int KH = (KS + 1) / 2;                                \
+    constexpr int kValu = SEARCH ? 4 : 2;                           \
     const uint32_t b_addr = b_addr0 + (PAR) * kTileVecs * 16;       \
     if ((MORE) && wv < 4) stage(JN, (PAR) ^ 1, NN);                 \
     contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR); \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                  \
-        rmax[PREV_PAR][r] = __builtin_fmaxf(rmax[PREV_PAR][r], PREV[r]); \
+        rmax[PREV_PAR][r] = __builtin_fmaxf(rmax[PREV_PAR][r], value(PREV[r], r)); \
     _Pragma("unroll") for (int i = 0; i < 3 * KH; ++i) {            \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);        \
     }                                                               \
     if ((MORE) && wv >= 4) stage(JN, (PAR) ^ 1, NN);                \
     contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
+    if (SEARCH) {                                                   \
+      _Pragma("unroll") for (int i = 0; i < 3 * (KS - KH); ++i) {   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);      \
+      }                                                             \
+    }                                                               \
     pin16(rmax[PREV_PAR]);  /* the maxima are taken by here: PREV's registers are free for the next block */ \
+    if (SEARCH) lx_prev = lx[NN];                                   \
   }
       {  // even tile J (buffer 0, bin 0); tile J + 1 always exists
         const uint32_t b_addr = b_addr0;
+        float lx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (SEARCH) {
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) lx[nn] = st.s_lam[(size_t)J * kTileRows + nn * 32 + lc];
+        }
         AS_READ(0, 0, 0)
         AS_BLOCK(0, 0, 1, accA, accB, 1, true, J + 1)
         AS_BLOCK(0, 1, 2, accB, accA, 0, true, J + 1)
@@ -218,6 +254,11 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
       {  // odd tile J + 1 (buffer 1, bin 1)
         const bool more = J + 2 < s_tiles;
         const uint32_t b_addr = b_addr0 + kTileVecs * 16;
+        float lx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (SEARCH) {
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) lx[nn] = st.s_lam[(size_t)(J + 1) * kTileRows + nn * 32 + lc];
+        }
         AS_READ(0, 0, 0)
         AS_BLOCK(1, 0, 1, accA, accB, 0, more, J + 2)
         AS_BLOCK(1, 1, 2, accB, accA, 1, more, J + 2)
@@ -231,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
 #undef AS_READ
     // the last block of the sweep (bin 1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rmax[1][r] = __builtin_fmaxf(rmax[1][r], accB[r]);
+    for (int r = 0; r < 16; ++r) rmax[1][r] = __builtin_fmaxf(rmax[1][r], value(accB[r], r));
 
     // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row][parity * 32 + lane column]
     float *wm = s_max + (size_t)wv * 32 * 65;
@@ -246,8 +287,9 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
       float vals[64];
 #pragma unroll
       for (int c = 0; c < 64; ++c) vals[c] = wm[lane * 65 + c];
-      float t = -__builtin_inff();
-      for (uint32_t k = 0; k < m; ++k) {  // remove the current maximum m - 1 times
+      float t = -__builtin_inff(), t1 = -__builtin_inff();
+      const uint32_t mm = theta2_out ? max(m, m2) : m;  // theta2_out: a second, looser order statistic (m2 >= m)
+      for (uint32_t k = 0; k < mm; ++k) {  // remove the current maximum mm - 1 times
         float best = -__builtin_inff();
         int at = 0;
 #pragma unroll
@@ -257,9 +299,12 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
           at = gt ? c : at;
         }
         t = best;
+        if (k + 1 == m) t1 = best;
 #pragma unroll
         for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
       }
+      if (row < row_count && theta2_out) theta2_out[row] = t;
+      t = t1;
       if (row < row_count) theta_out[row] = t;
     }
     wave_sync();
@@ -282,8 +327,40 @@ int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t 
   return AS_OK;
 }
 
+// one sweep: thresholds of the rows of image PA (a_supers super tiles) against the sample image PS
+static int launch_theta(as_ctx *ctx, uint32_t KS, const void *PA, uint32_t a_supers, uint32_t row_count, const void *PS,
+                        uint32_t s_tiles, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, const SearchTerm *st,
+                        const char *prof_name) {
+  DevBuf<uint32_t> unitc;
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  const size_t lds = std::max((size_t)2 * 2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
+  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
+  const SearchTerm none{nullptr, nullptr, 0.f, 0.f};
+  ProfScope ps(ctx, prof_name);
+#define AS_THETA1(K, S)                                                                                               \
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_bf16_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)lds));                                                                         \
+  hipLaunchKernelGGL((theta_bf16_kernel<K, S>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)PA, a_supers, \
+                     row_count, (const bf16x8 *)PS, s_tiles, m, theta_out, m2, theta2_out, unitc.p, st ? *st : none)
+#define AS_THETA(K)                                                                                                    \
+  case K:                                                                                                              \
+    if (st) { AS_THETA1(K, true); } else { AS_THETA1(K, false); }                                                      \
+    break;
+  switch (KS) {
+    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
+  }
+#undef AS_THETA
+#undef AS_THETA1
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's images may go back to the workspace cache
+  return AS_OK;
+}
+
 // theta_out[r], r < row_count, for rows [row_begin, row_begin + row_count) against the sample `sample_ids`
-// (ns global row ids).  dim <= 128 (the split A fragments stay in registers); AS_ERR_UNSUPPORTED beyond.
+// (ns global row ids, ns a multiple of 256).  dim <= 128 (the split A fragments stay in registers);
+// AS_ERR_UNSUPPORTED beyond.
 int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
                          uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out) {
   const uint32_t KS = (d + 15) / 16;
@@ -291,34 +368,33 @@ int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, u
   if (m < 1 || m > 32 || ns < 256 || ns % 256 != 0)
     return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: the sample must be a multiple of 256 rows");
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
-  const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows;
+  const uint32_t s_tiles = ns / kTileRows;
   DevBuf<unsigned char> PA, PS;
-  DevBuf<uint32_t> unitc;
   AS_TRY(PA.alloc(ctx, packed_vecs_bf16(a_alloc, d) * 16));
   AS_TRY(PS.alloc(ctx, packed_vecs_bf16(s_tiles, d) * 16));
   AS_TRY(pack_bf16(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
   AS_TRY(pack_bf16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
-  AS_TRY(unitc.alloc(ctx, 1));
-  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  const uint32_t a_supers = a_alloc / 2;
-  const size_t lds = std::max((size_t)2 * 2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
-  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
-  ProfScope ps(ctx, "knn_join_thresholds");
-#define AS_THETA(K)                                                                                                    \
-  case K:                                                                                                              \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_bf16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                    (int)lds));                                                                        \
-    hipLaunchKernelGGL((theta_bf16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)PA.p, a_supers, \
-                       row_count, (const bf16x8 *)PS.p, s_tiles, m, theta_out, unitc.p);                          \
-    break;
-  switch (KS) {
-    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
-    default: return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
-  }
-#undef AS_THETA
-  AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the images go back to the workspace cache
-  return AS_OK;
+  return launch_theta(ctx, KS, PA.p, a_alloc / 2, row_count, PS.p, s_tiles, m, theta_out, 0, nullptr, nullptr,
+                      "knn_join_thresholds");
+}
+
+// Search form: score_out[q] = the m-th largest approximate search score of query q over the sampled items.
+// PQ: split image of the nq queries (even tile count); items / sample as above; q_lam (padded to whole super
+// tiles) and s_lam (ns): f32 lambdas.
+int search_thresholds_bf16(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
+                           const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam,
+                           float alpha, float beta, float *score_out, uint32_t m2, float *score2_out) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || ns < 256 || ns % 256 != 0)
+    return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: the sample must be a multiple of 256 rows");
+  const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
+  const uint32_t s_tiles = ns / kTileRows;
+  DevBuf<unsigned char> PS;
+  AS_TRY(PS.alloc(ctx, packed_vecs_bf16(s_tiles, d) * 16));
+  AS_TRY(pack_bf16(ctx, items, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  const SearchTerm st{q_lam, s_lam, alpha, beta};
+  return launch_theta(ctx, KS, PQ, a_alloc / 2, nq, PS.p, s_tiles, m, score_out, m2, score2_out, &st, "search_thresholds");
 }
 
 }  // namespace asx

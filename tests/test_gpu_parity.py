@@ -533,6 +533,87 @@ def test_search_lambda_term_precision_choice(ctx, scale, want_f32):
         assert np.array_equal(sc[j], osc), j
 
 
+# ---- threshold scan of the search (stage 0 of K9, csrc/mfma_join_bf16.hip MODE 2) ---------------
+
+@pytest.fixture
+def scan_on(ctx):
+    """The threshold scan at test sizes (it starts at 32,768 items by default)."""
+    ctx.set_option("join_min_rows", 512)
+    yield
+    ctx.set_option("join_min_rows", 32768)
+    for name, v in (("search_scan", 1), ("search_scan_sample", 32), ("search_scan_rank", 3), ("search_scan_cap", 512)):
+        ctx.set_option(name, v)
+
+
+@pytest.mark.parametrize("n,d,nq,k,alpha", [(20_000, 128, 300, 10, 0.7), (5_000, 64, 77, 10, 0.7), (9_000, 100, 1, 5, 0.3),
+                                             (3_000, 33, 40, 25, 1.0), (12_000, 128, 513, 1, 0.9), (2_000, 16, 10, 64, 0.5)])
+def test_search_scan_matches_oracle(ctx, scan_on, n, d, nq, k, alpha):
+    """Stage 0 on: results bit-identical to the oracle (and to the search without it), for one query and many,
+    k below and above the usual, alpha = 1 (no lambda term) and small alpha (lambda term dominates)."""
+    X, _ = synth.mixture(n, d, seed=11, n_clusters=48, rank=6)
+    rng = np.random.default_rng(8)
+    lam = rng.random(n)
+    lam[::7] = lam[3] + np.arange(len(lam[::7])) * 1e-9  # near-ties in the lambda term
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=5)
+    Q = X[qi] * 1.02
+    lq = lam[qi] + rng.normal(size=nq) * 0.05
+    ctx.set_option("search_scan", 1)
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan") == 1
+    assert ctx.stat("search_scan_candidates") >= nq * min(k, 1)
+    ctx.set_option("search_scan", 0)
+    idx0, sc0 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan") == 0
+    assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0)
+    for j in range(0, nq, max(1, nq // 25)):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], k, alpha)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+
+
+@pytest.mark.parametrize("rate,rank,cap", [(2, 1, 16), (1000, 1, 512), (32, 32, 64), (8, 2, 1024)])
+def test_search_scan_any_guess_is_exact(ctx, scan_on, rate, rank, cap):
+    """The score guess only decides how many items are listed and how many queries fall through: guesses far too
+    high (rank 1 of half the items), far too low (rank 32 into 64 slots: the lists overflow) give the same results."""
+    n, d, nq = 6_000, 128, 200
+    X, _ = synth.mixture(n, d, seed=3, n_clusters=24, rank=5)
+    rng = np.random.default_rng(2)
+    lam = rng.random(n) * 0.8
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=9)
+    Q = X[qi] * 0.97
+    lq = rng.random(nq)
+    ctx.set_option("search_scan", 0)
+    idx0, sc0 = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
+    ctx.set_option("search_scan", 1)
+    for name, v in (("search_scan_sample", rate), ("search_scan_rank", rank), ("search_scan_cap", cap)):
+        ctx.set_option(name, v)
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
+    assert ctx.stat("search_scan") == 1
+    assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0)
+
+
+def test_search_scan_not_used_outside_its_range(ctx, scan_on):
+    """alpha outside (0, 1], rows wider than 128, large lambdas: the top-k passes run as before."""
+    n = 3_000
+    rng = np.random.default_rng(4)
+    for d, alpha, scale in ((64, 1.5, 1.0), (64, 0.0, 1.0), (200, 0.7, 1.0), (64, 0.7, 1e3)):
+        X, _ = synth.mixture(n, d, seed=6, n_clusters=16, rank=4)
+        lam = rng.random(n) * scale
+        asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+        asp.update_lambdas(lam)
+        Q = X[:20] * 1.02
+        lq = lam[:20] * 1.01
+        idx, sc = asp.search_lambda_aware_batch(Q, lq, 5, alpha)
+        assert ctx.stat("search_scan") == 0, (d, alpha, scale)
+        for j in (0, 7, 19):
+            oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 5, alpha)
+            assert np.array_equal(idx[j], oi) and np.array_equal(sc[j], osc)
+
+
 # ---- callers of the same index: hybrid and range search (src/core.rs:802-976) ------------------
 
 def test_hybrid_search_matches_oracle(ctx, mode):
