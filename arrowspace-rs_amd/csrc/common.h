@@ -346,11 +346,14 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, u
              uint64_t row_begin, uint64_t row_count, uint32_t K, int rectify, uint32_t *out_idx,
              double *out_dist, const JoinSources *js = nullptr);
 // packed = f32 image of ALL rows (even tile count) when the caller already has it, else nullptr
+// theta2_out (or nullptr): a second, looser threshold per row (bf16 pass only; left untouched otherwise, *has_theta2 = false)
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
-                        uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr);
+                        uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr,
+                        float *theta2_out = nullptr, bool *has_theta2 = nullptr);
+// packed16 = split-bf16 image of ALL rows when the caller already has it (bf16 pipe), else nullptr
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed = nullptr);
+                   const float *packed = nullptr, const void *packed16 = nullptr);
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

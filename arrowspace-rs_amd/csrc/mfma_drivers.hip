@@ -284,6 +284,20 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
   theta[r] = t;
 }
 
+// thresholds of the second pass: a row whose list overflowed keeps its threshold, the others get the looser one
+__global__ void second_theta_kernel(const float *__restrict__ theta, const float *__restrict__ theta2,
+                                    const uint32_t *__restrict__ cnt, uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count,
+                                    uint32_t padded, float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  float t = __builtin_inff();
+  if (i < count) {
+    const uint32_t g = ids[i];
+    t = cnt[g] > cap ? theta[g] : theta2[g];
+  }
+  out[i] = t;
+}
+
 __global__ void pad_theta_kernel(const float *__restrict__ theta, uint32_t n, uint32_t n_pad, float *__restrict__ out) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n_pad) out[r] = r < n ? theta[r] : __builtin_inff();
@@ -525,7 +539,8 @@ int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_beg
 int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
               uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
 int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
-                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out);
+                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out,
+                         uint32_t m2, float *theta2_out);
 int join_bf16_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
                    const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
                    const char *prof_name);
@@ -554,7 +569,8 @@ static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t r
 // theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
 // hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
-                        uint32_t row_count, float *theta_out, const float *packed) {
+                        uint32_t row_count, float *theta_out, const float *packed, float *theta2_out, bool *has_theta2) {
+  if (has_theta2) *has_theta2 = false;
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
@@ -570,7 +586,10 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   AS_TRY(sid.alloc(ctx, ns));
   hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sample_half_bits(ns), sid.p);
   if (ctx->opt_join_bf16) {  // thresholds on the bf16 pipe (mfma_theta_bf16.hip); dims it does not cover take the f32 pass
-    const int rc = join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out);
+    // second threshold: rank 2 m + 6 (about three times the candidates), for the second pass over what fails
+    const uint32_t m2 = std::min<uint32_t>(48, 2 * m + 6);
+    const int rc = join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out, m2, theta2_out);
+    if (rc == AS_OK && theta2_out && has_theta2) *has_theta2 = true;
     if (rc != AS_ERR_UNSUPPORTED) return rc;
   }
   const float *pa = packed ? packed + (size_t)(row_begin / kTileRows) * packed_elems(1, d) : nullptr;
@@ -610,7 +629,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed) {
+                   const float *packed, const void *packed16) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const uint32_t T2 = b_alloc / 2;
@@ -621,8 +640,11 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   DevBuf<uint32_t> unitc;
   const bool bf16 = join_on_bf16(ctx, d);
   if (bf16) {
-    AS_TRY(P16.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
-    AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16.p, b_alloc));
+    if (!packed16) {
+      AS_TRY(P16.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
+      AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16.p, b_alloc));
+      packed16 = P16.p;
+    }
   } else if (!packed) {
     AS_TRY(P.alloc(ctx, packed_elems(b_alloc, d)));
     AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
@@ -635,7 +657,7 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   if (bf16)
-    AS_TRY(join_bf16(ctx, P16.p, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_bf16"));
+    AS_TRY(join_bf16(ctx, packed16, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_bf16"));
   else
     AS_TRY(join_f32(ctx, packed, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -736,16 +758,25 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
   JoinSources local{};  // outlives the block below: the later stages still read js->packed
+  // own join on the bf16 pipe: the split image and the second (looser) thresholds stay for the second pass over
+  // the rows the first one leaves uncertified (rect_stage below)
+  DevBuf<unsigned char> P16own;
+  DevBuf<float> theta_own, theta2_own;
+  DevBuf<uint32_t> cnt_own, cand_own;
+  bool have_theta2 = false;
   if (use_join) {
-    DevBuf<float> theta_own;
-    DevBuf<uint32_t> cnt_own, cand_own;
     if (own_join) {
       const uint32_t cap = knn_join_cap(ctx, K);
       AS_TRY(theta_own.alloc(ctx, n));
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p));
+      AS_TRY(theta2_own.alloc(ctx, n));
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2));
+      if (join_on_bf16(ctx, d)) {
+        AS_TRY(P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
+        AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
+      }
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap));
-      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p));
+      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p));
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p};
       js = &local;
     }
@@ -948,6 +979,65 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     cur_n = n_next;
     return AS_OK;
   };
+
+  // ---- stage 1a (after a join of this call on the bf16 pipe): the one-sided join over the gathered rows ----
+  // A row fails the first pass because its list overflowed (threshold too low for its neighbourhood: same threshold,
+  // longer list) or because its K-th neighbour is not clear of the threshold (too high: the looser second threshold).
+  // ~1 % of the rows; as a one-sided sweep of the split image this is a few ms, the f32 top-k pass over them 11-22.
+  DevBuf<uint32_t> ids_r, pos_r;
+  if (own_join && have_theta2 && P16own.p && cur_n > 0 && cur_n <= n / 4) {
+    const uint32_t nf = cur_n, cap2 = 1024;
+    const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad = b_al * kTileRows;
+    DevBuf<unsigned char> PA;
+    DevBuf<float> theta_a;
+    DevBuf<uint32_t> cnt_b, cand_b, unitc, oi, failx;
+    DevBuf<double> ok;
+    AS_TRY(PA.alloc(ctx, packed_vecs_bf16(b_al, d) * 16));
+    AS_TRY(theta_a.alloc(ctx, pad));
+    AS_TRY(cnt_b.alloc(ctx, pad));
+    AS_TRY(cand_b.alloc(ctx, (size_t)pad * cap2));
+    AS_TRY(unitc.alloc(ctx, 1));
+    AS_TRY(ok.alloc(ctx, (size_t)nf * K));
+    AS_TRY(oi.alloc(ctx, (size_t)nf * K));
+    AS_TRY(failx.alloc(ctx, nf));
+    AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
+    hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, theta_own.p, theta2_own.p,
+                       cnt_own.p, local.cap, cur_ids, nf, pad, theta_a.p);
+    AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
+    AS_TRY(join_bf16_rect(ctx, P16own.p, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
+                          "knn_mfma_join_bf16_second"));
+    {
+      GraphBound bnd{join_delta(ctx, d), rectify};
+      ProfScope ps(ctx, "knn_rerank");
+      const size_t lds = (size_t)4 * (d + cap2) * sizeof(double) + (size_t)4 * cap2 * sizeof(uint32_t);
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
+                         dim3(256), lds, ctx->stream, rows, rows, cur_ids, d, 0u, nf, theta_a.p, 1u, cnt_b.p, cand_b.p, cap2, cap2,
+                         K, force.p, pol, bnd, ok.p, oi.p, failx.p, fail_count.p, err.p);
+      AS_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)nf * K, 256)), dim3(256), 0, ctx->stream, cur_pos, nf, K, ok.p,
+                       oi.p, out_dist, out_idx);
+    uint32_t n_next = 0;
+    AS_TRY(read_u32(ctx, fail_count.p, &n_next));
+    ctx->stats["knn_uncertified_rows_stage1a"] = n_next;
+    if (n_next) {
+      AS_TRY(ids_r.alloc(ctx, n_next));
+      AS_TRY(pos_r.alloc(ctx, n_next));
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_ids, failx.p, n_next, 0u,
+                         ids_r.p);
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_pos, failx.p, n_next, 0u,
+                         pos_r.p);
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // failx goes back to the workspace cache
+      cur_ids = ids_r.p;
+      cur_pos = pos_r.p;
+    }
+    cur_n = n_next;
+    if (cur_n == 0) return AS_OK;
+  }
 
   // ---- stage 1b (after the join): f32 top-k pass over the gathered rows ----
   if (use_join && !exact_direct(cur_n, n)) {

@@ -362,7 +362,8 @@ static int launch_theta(as_ctx *ctx, uint32_t KS, const void *PA, uint32_t a_sup
 // (ns global row ids, ns a multiple of 256).  dim <= 128 (the split A fragments stay in registers);
 // AS_ERR_UNSUPPORTED beyond.
 int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, uint32_t row_begin,
-                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out) {
+                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out,
+                         uint32_t m2, float *theta2_out) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || ns < 256 || ns % 256 != 0)
@@ -374,7 +375,7 @@ int join_thresholds_bf16(as_ctx *ctx, const double *rows, const double *norms, u
   AS_TRY(PS.alloc(ctx, packed_vecs_bf16(s_tiles, d) * 16));
   AS_TRY(pack_bf16(ctx, rows, norms, nullptr, row_begin, row_count, d, PA.p, a_alloc));
   AS_TRY(pack_bf16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
-  return launch_theta(ctx, KS, PA.p, a_alloc / 2, row_count, PS.p, s_tiles, m, theta_out, 0, nullptr, nullptr,
+  return launch_theta(ctx, KS, PA.p, a_alloc / 2, row_count, PS.p, s_tiles, m, theta_out, m2, theta2_out, nullptr,
                       "knn_join_thresholds");
 }
 
