@@ -51,6 +51,8 @@ struct as_ctx {
                                   // 12/6 1146, 10/7 1152, 8/8 1161 for the whole neighbour search)
   int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
   int64_t opt_join_min_rows = 32768;
+  int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128: 4 -> 304 ms, 8 -> 291, 16 -> 292, 32 -> 282, 64 -> 284:
+                                  // longer units amortise the unit prologue; 32 x 128 KB = 4 MB of the image in flight per unit)
   int64_t opt_join_pipe = 16;     // contraction of the join: 16 = split bf16 (dim <= 128), 32 = f32 MFMA
   int64_t opt_search_scan = 1;    // search: threshold scan on the bf16 pipe before the top-k passes (dim <= 128, alpha > 0)
   int64_t opt_search_scan_sample = 32;   // its score guess: the m-th best of a 1-in-N sample of the items

@@ -381,9 +381,10 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t T2 = (b_tiles + 1) / 2;
   const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + (size_t)8 * kQueue * sizeof(uint2);
-  // column super tiles per block: 16 x 2 x 64 KB = 2 MB of the B image in flight (the XCD's L2 holds 4 MB)
+
   const bool rect = mode >= 1;
-  const uint32_t W = rect ? std::min(16u, T2) : std::max(1u, std::min(16u, T2 / 4));
+  const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  const uint32_t W = rect ? std::min(w_opt, T2) : std::max(1u, std::min(w_opt, T2 / 4));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;

@@ -14,6 +14,7 @@ Xd = torch.from_numpy(X).cuda()
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 ctx.set_option("join_min_rows", 512)
 if os.environ.get("JOIN_PIPE"): ctx.set_option("join_pipe", int(os.environ["JOIN_PIPE"]))
+if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
 if os.environ.get("AS_DEBUG"): ctx.set_option("debug", int(os.environ["AS_DEBUG"]))
 res = {}
 CFGS = [(0, 16, 5, 192)] + [(1, int(a), int(b), int(c)) for a, b, c in (x.split(":") for x in sys.argv[3:])] if len(sys.argv) > 3 else [(0, 16, 5, 192), (1, 16, 5, 192)]
