@@ -324,8 +324,16 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
   if (!theta_out || !is_device_ptr(theta_out)) return fail(ctx, AS_ERR_ARG, "theta_out must be a device pointer");
   // first call of a sequence: norms and the packed image of all rows are built here and kept for the other two
   AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
+  {  // the looser second thresholds of these rows stay with the session (second pass of as_knn_join_finish)
+    void *p = nullptr;
+    AS_TRY(ws_alloc(ctx, sizeof(float) * row_count, &p, &ctx->join.theta2_cap));
+    ctx->join.theta2 = (float *)p;
+    ctx->join.theta2_begin = row_begin;
+    ctx->join.theta2_rows = row_count;
+  }
   const int rc = knn_join_thresholds(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
-                                     (uint32_t)row_count, theta_out, ctx->join.packed);
+                                     (uint32_t)row_count, theta_out, ctx->join.packed, ctx->join.theta2,
+                                     &ctx->join.theta2_valid);
   if (rc != AS_OK) join_session_close(ctx);
   return rc;
 }
@@ -344,7 +352,7 @@ int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_
   if (cap == 0) return fail(ctx, AS_ERR_ARG, "cap == 0");
   if (!join_session_matches(ctx, rows, n_nodes, dim)) AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
   return knn_join_pairs(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
-                        (uint32_t)row_count, theta_all, cap, cnt, cand, ctx->join.packed);
+                        (uint32_t)row_count, theta_all, cap, cnt, cand, ctx->join.packed, ctx->join.packed16);
 }
 
 int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
@@ -367,7 +375,9 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
     if (rc == AS_OK) rc = D.bind(ctx, nbr_dist, row_count * K);
     if (rc == AS_OK) rc = I.bind(ctx, nbr_idx, row_count * K);
     if (rc == AS_OK) {
-      const JoinSources js{ctx->join.packed, theta_all, n_src, cap, cnt_src, cand_src};
+      const bool second = ctx->join.theta2_valid && ctx->join.theta2_begin == row_begin && ctx->join.theta2_rows == row_count;
+      const JoinSources js{ctx->join.packed, theta_all, n_src, cap, cnt_src, cand_src, second ? ctx->join.theta2 : nullptr,
+                           ctx->join.packed16};
       rc = knn_mfma(ctx, rows, ctx->join.norms, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js);
     }
     if (rc == AS_OK) {

@@ -51,8 +51,8 @@ struct as_ctx {
                                   // 12/6 1146, 10/7 1152, 8/8 1161 for the whole neighbour search)
   int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
   int64_t opt_join_min_rows = 32768;
-  int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128: 4 -> 304 ms, 8 -> 291, 16 -> 292, 32 -> 282, 64 -> 284:
-                                  // longer units amortise the unit prologue; 32 x 128 KB = 4 MB of the image in flight per unit)
+  int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128 on one device: 4 -> 304 ms, 8 .. 64 ->
+                                  // 291-293: longer units amortise the unit prologue; devices differ by more than that)
   int64_t opt_join_pipe = 16;     // contraction of the join: 16 = split bf16 (dim <= 128), 32 = f32 MFMA
   int64_t opt_search_scan = 1;    // search: threshold scan on the bf16 pipe before the top-k passes (dim <= 128, alpha > 0)
   int64_t opt_search_scan_sample = 32;   // its score guess: the m-th best of a 1-in-N sample of the items
@@ -68,7 +68,11 @@ struct as_ctx {
     uint64_t n = 0, d = 0;
     double *norms = nullptr;
     float *packed = nullptr;
-    size_t norms_cap = 0, packed_cap = 0;
+    void *packed16 = nullptr;   // split-bf16 image of all rows (bf16 pipe of the join)
+    float *theta2 = nullptr;    // second (looser) thresholds of the rows of the last as_knn_join_thresholds call
+    uint64_t theta2_begin = 0, theta2_rows = 0;
+    bool theta2_valid = false;
+    size_t norms_cap = 0, packed_cap = 0, packed16_cap = 0, theta2_cap = 0;
   } join;
   // stats of the last call
   std::map<std::string, int64_t> stats;
@@ -342,6 +346,8 @@ struct JoinSources {
   uint32_t n_src, cap;    // lists per row, slots per list
   const uint32_t *cnt;    // n_src x row_count
   const uint32_t *cand;   // n_src x row_count x cap
+  const float *theta2 = nullptr;    // looser thresholds of the rows of the range (by position), or nullptr
+  const void *packed16 = nullptr;   // split-bf16 image of all rows, or nullptr (both: second pass over uncertified rows)
 };
 // MFMA candidate pass + exact re-rank + certification + exact fall-back
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,

@@ -284,16 +284,20 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
   theta[r] = t;
 }
 
-// thresholds of the second pass: a row whose list overflowed keeps its threshold, the others get the looser one
+// thresholds of the second pass: a row whose list overflowed (in any of its sources) keeps its threshold, the others
+// get the looser one.  theta by global row, theta2 / cnt by position in [row_begin, row_begin + row_count)
 __global__ void second_theta_kernel(const float *__restrict__ theta, const float *__restrict__ theta2,
-                                    const uint32_t *__restrict__ cnt, uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count,
-                                    uint32_t padded, float *__restrict__ out) {
+                                    const uint32_t *__restrict__ cnt, uint32_t n_src, uint32_t row_begin, uint32_t row_count,
+                                    uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded,
+                                    float *__restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
   if (i < count) {
-    const uint32_t g = ids[i];
-    t = cnt[g] > cap ? theta[g] : theta2[g];
+    const uint32_t g = ids[i], r = g - row_begin;
+    bool over = false;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + r] > cap;
+    t = over ? theta[g] : theta2[r];
   }
   out[i] = t;
 }
@@ -675,6 +679,11 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
   js.packed = (float *)p;
   AS_TRY(row_norms(ctx, rows, n, d, js.norms));
   AS_TRY(pack_f32(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed, b_alloc));
+  if (join_on_bf16(ctx, (uint32_t)d)) {
+    AS_TRY(ws_alloc(ctx, packed_vecs_bf16(b_alloc, (uint32_t)d) * 16, &p, &js.packed16_cap));
+    js.packed16 = p;
+    AS_TRY(pack_bf16(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed16, b_alloc));
+  }
   js.rows = rows;
   js.n = n;
   js.d = d;
@@ -687,6 +696,8 @@ void join_session_close(as_ctx *ctx) {
   auto &js = ctx->join;
   if (js.norms) ws_free(ctx, js.norms, js.norms_cap);
   if (js.packed) ws_free(ctx, js.packed, js.packed_cap);
+  if (js.packed16) ws_free(ctx, js.packed16, js.packed16_cap);
+  if (js.theta2) ws_free(ctx, js.theta2, js.theta2_cap);
   js = as_ctx::JoinSession{};
 }
 
@@ -777,7 +788,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap));
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p));
-      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p};
+      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
     }
     {
@@ -980,12 +991,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     return AS_OK;
   };
 
-  // ---- stage 1a (after a join of this call on the bf16 pipe): the one-sided join over the gathered rows ----
+  // ---- stage 1a (after a join on the bf16 pipe): the one-sided join over the gathered rows ----
   // A row fails the first pass because its list overflowed (threshold too low for its neighbourhood: same threshold,
   // longer list) or because its K-th neighbour is not clear of the threshold (too high: the looser second threshold).
   // ~1 % of the rows; as a one-sided sweep of the split image this is a few ms, the f32 top-k pass over them 11-22.
   DevBuf<uint32_t> ids_r, pos_r;
-  if (own_join && have_theta2 && P16own.p && cur_n > 0 && cur_n <= n / 4) {
+  if (use_join && js->theta2 && js->packed16 && join_on_bf16(ctx, d) && cur_n > 0 && cur_n <= n / 4) {
     const uint32_t nf = cur_n, cap2 = 1024;
     const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad = b_al * kTileRows;
     DevBuf<unsigned char> PA;
@@ -1001,12 +1012,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(oi.alloc(ctx, (size_t)nf * K));
     AS_TRY(failx.alloc(ctx, nf));
     AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
-    hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, theta_own.p, theta2_own.p,
-                       cnt_own.p, local.cap, cur_ids, nf, pad, theta_a.p);
+    hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
+                       js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p);
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-    AS_TRY(join_bf16_rect(ctx, P16own.p, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
+    AS_TRY(join_bf16_rect(ctx, js->packed16, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
                           "knn_mfma_join_bf16_second"));
     {
       GraphBound bnd{join_delta(ctx, d), rectify};
