@@ -79,8 +79,19 @@ const char *as_status_message(int status); /* the reference's panic text for a s
  * sync); host outputs are always complete on return. */
 int as_ctx_set_stream(as_ctx *ctx, void *hip_stream);
 int as_ctx_synchronize(as_ctx *ctx);
-/* Tuning knob: 0 = exact brute-force neighbour search (also the fall-back for rows the MFMA
- * path cannot certify), 1 = f64 MFMA candidate pass + exact re-rank (default). */
+/* Tuning knobs (none of them changes a result, only which stage produces it; defaults in
+ * csrc/common.h).  The ones a caller may want:
+ *   "knn_mfma" / "search_mfma"  0 = exact brute-force scan only, 1 = MFMA candidate passes + exact
+ *                               re-rank + certification (default)
+ *   "cand_precision"            32 (default) or 64: first MFMA candidate pass on the f32 / f64 pipe
+ *   "knn_join"                  symmetric threshold join for whole-matrix item graphs (default 1)
+ *   "join_pipe"                 16 = split-bf16 contraction (dim <= 128, default), 32 = f32 MFMA
+ *   "join_min_rows"             smallest n for the join and for the search scan (default 32768)
+ *   "join_sample", "join_rank", "join_cap", "join_block"   threshold sample 1-in-N, order statistic,
+ *                               list slots per row, column super tiles per work unit
+ *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
+ *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
+ *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);
 
