@@ -340,7 +340,7 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
 
 uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params) {
   if (!ctx || !params) return 0;
-  return knn_join_cap(ctx, (uint32_t)params->topk + 1);
+  return 2 * knn_join_cap(ctx, (uint32_t)params->topk + 1);  // words per row: a slot is (row id, approximate cosine)
 }
 
 int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
@@ -349,10 +349,10 @@ int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_
   AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
   if (!theta_all || !cnt || !cand || !is_device_ptr(theta_all) || !is_device_ptr(cnt) || !is_device_ptr(cand))
     return fail(ctx, AS_ERR_ARG, "theta_all / cnt / cand must be device pointers");
-  if (cap == 0) return fail(ctx, AS_ERR_ARG, "cap == 0");
+  if (cap < 2 || cap % 2 != 0) return fail(ctx, AS_ERR_ARG, "cap must be a positive even number of words");
   if (!join_session_matches(ctx, rows, n_nodes, dim)) AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
   return knn_join_pairs(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
-                        (uint32_t)row_count, theta_all, cap, cnt, cand, ctx->join.packed, ctx->join.packed16);
+                        (uint32_t)row_count, theta_all, cap / 2, cnt, cand, ctx->join.packed, ctx->join.packed16);
 }
 
 int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
@@ -360,7 +360,7 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
                        uint32_t cap, const uint32_t *cnt_src, const uint32_t *cand_src, uint64_t *nbr_idx,
                        double *nbr_dist) {
   AS_TRY(join_args(ctx, rows, n_nodes, dim, row_begin, row_count, params));
-  if (!theta_all || !cnt_src || !cand_src || !nbr_idx || !nbr_dist || n_src == 0 || cap == 0)
+  if (!theta_all || !cnt_src || !cand_src || !nbr_idx || !nbr_dist || n_src == 0 || cap < 2 || cap % 2 != 0)
     return fail(ctx, AS_ERR_ARG, "null argument");
   if (!is_device_ptr(theta_all) || !is_device_ptr(cnt_src) || !is_device_ptr(cand_src))
     return fail(ctx, AS_ERR_ARG, "theta_all / cnt_src / cand_src must be device pointers");
@@ -376,7 +376,7 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
     if (rc == AS_OK) rc = I.bind(ctx, nbr_idx, row_count * K);
     if (rc == AS_OK) {
       const bool second = ctx->join.theta2_valid && ctx->join.theta2_begin == row_begin && ctx->join.theta2_rows == row_count;
-      const JoinSources js{ctx->join.packed, theta_all, n_src, cap, cnt_src, cand_src, second ? ctx->join.theta2 : nullptr,
+      const JoinSources js{ctx->join.packed, theta_all, n_src, cap / 2, cnt_src, cand_src, second ? ctx->join.theta2 : nullptr,
                            ctx->join.packed16};
       rc = knn_mfma(ctx, rows, ctx->join.norms, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js);
     }

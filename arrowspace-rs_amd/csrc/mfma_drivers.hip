@@ -330,6 +330,52 @@ __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32
   }
 }
 
+// Pruning of a joined candidate list before any candidate row is fetched (one wave; ei / es = ids and approximate
+// cosines of the C gathered candidates in LDS).  tau = the K-th largest approximate cosine: K candidates have an
+// exact cosine >= tau - delta, so a candidate below tau - 2 delta is strictly worse than K others and cannot be in
+// the top K (nor tie with it).  The survivors are compacted in place (order kept); returns their count.
+// rectify: distances of negative cosines all collapse to 1 and tie by index, so nothing is dropped at or below 0.
+__device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, uint32_t C, uint32_t K, double delta, int rectify,
+                                                     int lane) {
+  if (C <= K) return C;
+  float tau = 0.f;
+  bool found = false;
+  for (uint32_t base = 0; base < C && !found; base += 64) {
+    const uint32_t c = base + lane;
+    bool mine = false;
+    float sc = 0.f;
+    if (c < C) {
+      sc = es[c];
+      uint32_t rank = 0;
+      for (uint32_t c2 = 0; c2 < C; ++c2) {
+        const float s2 = es[c2];
+        rank += (s2 > sc || (s2 == sc && c2 < c)) ? 1u : 0u;
+      }
+      mine = rank == K - 1;
+    }
+    const unsigned long long m = __ballot(mine);
+    if (m) {
+      tau = __shfl(sc, __ffsll((long long)m) - 1, 64);
+      found = true;
+    }
+  }
+  if (!found) return C;  // NaN scores: leave the list alone
+  const double thr = (double)tau - 2.0 * delta;
+  if (rectify && thr <= 0.0) return C;
+  uint32_t out = 0;
+  for (uint32_t base = 0; base < C; base += 64) {
+    const uint32_t c = base + lane;
+    const bool keep = c < C && (double)es[c] >= thr;
+    const uint32_t id = c < C ? ei[c] : 0u;
+    const unsigned long long m = __ballot(keep);
+    wave_sync();
+    if (keep) ei[out + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = id;
+    out += (uint32_t)__builtin_popcountll(m);
+  }
+  wave_sync();
+  return out;
+}
+
 // Exact re-rank of the joined candidates of rows [row_begin, row_begin + row_count) (one wave per row),
 // certification against theta.  The candidates of a row come from n_src lists (one per rank that contracted
 // tile pairs touching it): cnt_src[s * row_count + r], cand_src[(s * row_count + r) * cap ..].
@@ -341,6 +387,7 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
                                                           const uint32_t *__restrict__ cand_src, uint32_t cap,
                                                           uint32_t cmax, uint32_t K,
                                                           const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd,
+                                                          double prune_delta, int prune_rectify,
                                                           double *__restrict__ out_key, uint32_t *__restrict__ out_idx,
                                                           uint32_t *__restrict__ fail_rows,
                                                           uint32_t *__restrict__ fail_count, int *__restrict__ err_flag) {
@@ -364,11 +411,17 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
         overflow = true;
         take = cmax - C;
       }
-      const uint32_t *src = cand_src + ((size_t)sidx * row_count + r) * cap;
-      for (uint32_t c = lane; c < take; c += 64) ei[C + c] = src[c];
+      const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + r) * cap;
+      float *es = reinterpret_cast<float *>(ek);  // approximate cosines, until the exact keys overwrite them
+      for (uint32_t c = lane; c < take; c += 64) {
+        const uint2 e = src[c];
+        ei[C + c] = e.x;
+        es[C + c] = __uint_as_float(e.y);
+      }
       C += take;
     }
     wave_sync();
+    if (prune_delta >= 0.0) C = prune_candidates(ei, reinterpret_cast<float *>(ek), C, K, prune_delta, prune_rectify, lane);
     for (uint32_t c = lane; c < C; c += 64) {
       const uint32_t j = ei[c];
       const double acc = exact_dot_seq(xrow, X + (uint64_t)j * d, d);
@@ -426,7 +479,8 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
     const double *__restrict__ X, const double *__restrict__ XA, const uint32_t *__restrict__ a_ids, uint32_t row_begin,
     uint32_t row_count, const float *__restrict__ theta, uint32_t n_src,
     const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src, uint32_t cap, uint32_t cmax, uint32_t K,
-    const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double *__restrict__ out_key,
+    const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double prune_delta, int prune_rectify,
+    double *__restrict__ out_key,
     uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows, uint32_t *__restrict__ fail_count,
     int *__restrict__ err_flag) {
   constexpr uint32_t d = 128;
@@ -454,11 +508,17 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
         overflow = true;
         take = cmax - C;
       }
-      const uint32_t *src = cand_src + ((size_t)sidx * row_count + r) * cap;
-      for (uint32_t c = lane; c < take; c += 64) ei[C + c] = src[c];
+      const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + r) * cap;
+      float *es = reinterpret_cast<float *>(ek);  // approximate cosines, until the exact keys overwrite them
+      for (uint32_t c = lane; c < take; c += 64) {
+        const uint2 e = src[c];
+        ei[C + c] = e.x;
+        es[C + c] = __uint_as_float(e.y);
+      }
       C += take;
     }
     wave_sync();
+    if (prune_delta >= 0.0) C = prune_candidates(ei, reinterpret_cast<float *>(ek), C, K, prune_delta, prune_rectify, lane);
     const uint32_t n_batches = (C + kRrRows - 1) / kRrRows;
     auto issue = [&](uint32_t b) {
       unsigned char *dst = tiles + (size_t)(b % NBUF) * kRrRows * kRrPitch;
@@ -786,7 +846,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
       }
       AS_TRY(cnt_own.alloc(ctx, n));
-      AS_TRY(cand_own.alloc(ctx, (size_t)n * cap));
+      AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p));
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
@@ -794,6 +854,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     {
       const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
       GraphBound bnd{join_delta(ctx, d), rectify};
+      // candidates whose approximate cosine (stored with them) cannot reach the top K are dropped before any row is
+      // fetched: 74 -> ~20 rows of 1 KB per row of the table (debug 16: keep them all)
+      const double prune_delta = (ctx->opt_debug & 16) ? -1.0 : join_delta(ctx, d);
       ProfScope ps(ctx, "knn_rerank");
       // rows per batch x buffers.  Measured at 1 M rows (re-rank + fall-back re-rank): per-lane walk 66 ms, 8x1 39, 8x2 46,
       // 16x1 37, 16x2 58: occupancy (LDS per wave) beats double buffering.  debug = 10 + {0: 8x1, 1: 8x2, 2: 16x1, 3: 16x2}.
@@ -807,7 +870,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   hipLaunchKernelGGL((rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>),                                        \
                      dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows, rows,   \
                      (const uint32_t *)nullptr, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
-                     bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p)
+                     bnd, prune_delta, rectify, out_dist, out_idx, fail1.p, fail_count.p, err.p)
         if (rr_rows == 8 && rr_nbuf == 1) { AS_RR(8, 1); }
         else if (rr_rows == 8) { AS_RR(8, 2); }
         else if (rr_nbuf == 1) { AS_RR(16, 1); }
@@ -820,7 +883,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
                            dim3(256), lds, ctx->stream, rows, rows, (const uint32_t *)nullptr, d, (uint32_t)row_begin, row_count,
                            js->theta, js->n_src, js->cnt,
-                           js->cand, js->cap, cmax, K, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p, err.p);
+                           js->cand, js->cap, cmax, K, force.p, pol, bnd, prune_delta, rectify, out_dist, out_idx, fail1.p,
+                           fail_count.p, err.p);
       }
       AS_HIP(ctx, hipGetLastError());
     }
@@ -1006,7 +1070,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(PA.alloc(ctx, packed_vecs_bf16(b_al, d) * 16));
     AS_TRY(theta_a.alloc(ctx, pad));
     AS_TRY(cnt_b.alloc(ctx, pad));
-    AS_TRY(cand_b.alloc(ctx, (size_t)pad * cap2));
+    AS_TRY(cand_b.alloc(ctx, (size_t)pad * cap2 * 2));
     AS_TRY(unitc.alloc(ctx, 1));
     AS_TRY(ok.alloc(ctx, (size_t)nf * K));
     AS_TRY(oi.alloc(ctx, (size_t)nf * K));
@@ -1027,7 +1091,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
                          dim3(256), lds, ctx->stream, rows, rows, cur_ids, d, 0u, nf, theta_a.p, 1u, cnt_b.p, cand_b.p, cap2, cap2,
-                         K, force.p, pol, bnd, ok.p, oi.p, failx.p, fail_count.p, err.p);
+                         K, force.p, pol, bnd, (ctx->opt_debug & 16) ? -1.0 : join_delta(ctx, d), rectify, ok.p, oi.p, failx.p,
+                         fail_count.p, err.p);
       AS_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)nf * K, 256)), dim3(256), 0, ctx->stream, cur_pos, nf, K, ok.p,
@@ -1236,7 +1301,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_TRY(guess2.alloc(ctx, nq));
     AS_TRY(guess_pad.alloc(ctx, padded));
     AS_TRY(cnt.alloc(ctx, padded));
-    AS_TRY(cand.alloc(ctx, (size_t)padded * cap));
+    AS_TRY(cand.alloc(ctx, (size_t)padded * cap * 2));
     AS_TRY(unitc.alloc(ctx, 1));
     AS_TRY(pack_bf16(ctx, queries, q_norms, nullptr, 0, nq, d, PQ.p, a_alloc));
     hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
@@ -1264,14 +1329,14 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         hipLaunchKernelGGL((rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>),
                            dim3(std::min<uint64_t>(cdiv(nq, 4), 256 * 16)), dim3(256), lds128, ctx->stream, ix->items, queries,
                            (const uint32_t *)nullptr, 0u, nq, guess_pad.p, 1u, cnt.p, cand.p, cap, cap, K,
-                           (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p, fail_count.p, err.p);
+                           (const uint8_t *)nullptr, pol, bnd, -1.0, 0, out_key, out_idx, fail1.p, fail_count.p, err.p);
       } else {
         const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nq, 4), 8192)),
                            dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)nullptr, d, 0u, nq, guess_pad.p, 1u,
-                           cnt.p, cand.p, cap, cap, K, (const uint8_t *)nullptr, pol, bnd, out_key, out_idx, fail1.p,
+                           cnt.p, cand.p, cap, cap, K, (const uint8_t *)nullptr, pol, bnd, -1.0, 0, out_key, out_idx, fail1.p,
                            fail_count.p, err.p);
       }
       AS_HIP(ctx, hipGetLastError());
@@ -1303,7 +1368,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(qlam_b.alloc(ctx, pad_b));
       AS_TRY(guess_b.alloc(ctx, pad_b));
       AS_TRY(cnt_b.alloc(ctx, pad_b));
-      AS_TRY(cand_b.alloc(ctx, (size_t)pad_b * cap2));
+      AS_TRY(cand_b.alloc(ctx, (size_t)pad_b * cap2 * 2));
       AS_TRY(ok.alloc(ctx, (size_t)nf * K));
       AS_TRY(oi.alloc(ctx, (size_t)nf * K));
       AS_TRY(fail_b.alloc(ctx, nf));
@@ -1328,8 +1393,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
                            dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)fail1.p, d, 0u, nf, guess_b.p, 1u,
-                           cnt_b.p, cand_b.p, cap2, cap2, K, (const uint8_t *)nullptr, pol, bnd, ok.p, oi.p, fail_b.p, fail_count.p,
-                           err.p);
+                           cnt_b.p, cand_b.p, cap2, cap2, K, (const uint8_t *)nullptr, pol, bnd, -1.0, 0, ok.p, oi.p, fail_b.p,
+                           fail_count.p, err.p);
         AS_HIP(ctx, hipGetLastError());
       }
       hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)nf * K, 256)), dim3(256), 0, ctx->stream, fail1.p, nf, K, ok.p,

@@ -46,10 +46,12 @@ __device__ __forceinline__ void lds_wait(bf16x8 &x, bf16x8 &y) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(PENDING));
 }
 
+// a list slot is two words: the other row and the approximate score that put it there (the re-rank drops the
+// candidates whose score cannot reach the top K before it fetches any row)
 __device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand, uint32_t cap,
-                                       uint32_t target, uint32_t other) {
+                                       uint32_t target, uint32_t other, float score) {
   const uint32_t pos = atomicAdd(cnt + target, 1u);
-  if (pos < cap) cand[(size_t)target * cap + pos] = other;
+  if (pos < cap) reinterpret_cast<uint2 *>(cand)[(size_t)target * cap + pos] = make_uint2(other, __float_as_uint(score));
 }
 
 // P = split bf16 image of ALL rows (mfma_theta_bf16.hip: tiles of 128 rows, hi plane then lo plane, even tile
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
   // the sweep those waits made the wave with the hit late at the tile's barrier, where the other seven wait for it
   // (stamps: 17 % of the kernel).  From the queue 64 lanes take one entry each: one such wait per 64 appends.
   uint2 *queue = reinterpret_cast<uint2 *>(smem + (size_t)2 * kTileVecs * 16) + (size_t)wv * kQueue;
+  float *queue_s = reinterpret_cast<float *>(smem + (size_t)2 * kTileVecs * 16 + (size_t)8 * kQueue * sizeof(uint2)) + (size_t)wv * kQueue;
   uint32_t qn = 0;  // wave-uniform
   auto lanes_below = [&](unsigned long long m) -> uint32_t {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       const uint32_t e = base + lane;
       if (e < qn) {
         const uint2 v = queue[e];
-        append(cnt, cand, cap, v.x, v.y);
+        append(cnt, cand, cap, v.x, v.y, queue_s[e]);
       }
     }
     wave_sync();
@@ -270,8 +273,14 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
           const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
           const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
           if (qn + n1 + n2 > kQueue) flush_queue();
-          if (w1) queue[qn + lanes_below(m1)] = make_uint2(row, col);
-          if (w2) queue[qn + n1 + lanes_below(m2)] = make_uint2(col, row);
+          if (w1) {
+            queue[qn + lanes_below(m1)] = make_uint2(row, col);
+            queue_s[qn + lanes_below(m1)] = v;
+          }
+          if (w2) {
+            queue[qn + n1 + lanes_below(m2)] = make_uint2(col, row);
+            queue_s[qn + n1 + lanes_below(m2)] = v;
+          }
           qn += n1 + n2;
         }
       }
@@ -380,7 +389,7 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "bf16 join: dim not covered");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t T2 = (b_tiles + 1) / 2;
-  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + (size_t)8 * kQueue * sizeof(uint2);
+  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + (size_t)8 * kQueue * (sizeof(uint2) + sizeof(float));
 
   const bool rect = mode >= 1;
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));

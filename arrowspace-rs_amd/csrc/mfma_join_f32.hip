@@ -44,10 +44,11 @@ __device__ __forceinline__ void stage_chunk(const float *src, float *dst_lds, in
   }
 }
 
+// a list slot is two words: the other row and the approximate score that put it there
 __device__ __forceinline__ void append(uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand, uint32_t cap,
-                                       uint32_t target, uint32_t other) {
+                                       uint32_t target, uint32_t other, float score) {
   const uint32_t pos = atomicAdd(cnt + target, 1u);
-  if (pos < cap) cand[(size_t)target * cap + pos] = other;
+  if (pos < cap) reinterpret_cast<uint2 *>(cand)[(size_t)target * cap + pos] = make_uint2(other, __float_as_uint(score));
 }
 
 // P = packed unit-row image of ALL rows (tiles of 128 rows, even tile count, zero padded).
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_mfma32_kernel(
             if (__any(pr || pc)) {
               const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
               const bool inside = row < n && col < n && row != col;
-              if (inside && pr) append(cnt, cand, cap, row, col);
-              if (inside && pc) append(cnt, cand, cap, col, row);
+              if (inside && pr) append(cnt, cand, cap, row, col, v);
+              if (inside && pc) append(cnt, cand, cap, col, row, v);
             }
           }
         }

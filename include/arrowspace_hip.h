@@ -129,7 +129,10 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
  *   1. as_knn_join_thresholds: theta_out[row_count], the per-row candidate thresholds of this rank's rows;
  *      the host all-gathers them into theta_all[n_nodes].
  *   2. as_knn_join_pairs: contracts this rank's tile pairs; cnt[n_nodes] (zeroed by the call) and
- *      cand[n_nodes x cap] receive, indexed by GLOBAL row, every pair that reaches a threshold.  The host
+ *      cand[n_nodes x cap] receive, indexed by GLOBAL row, every pair that reaches a threshold.  cap =
+ *      as_knn_join_capacity() = 32-bit words per row: a list slot is two words, the other row's index and the
+ *      approximate cosine (f32 bits) that put it there (the re-rank uses it to drop, before fetching any row,
+ *      the candidates that cannot reach the top K); cnt counts slots.  The host
  *      sends each rank the slices of its rows (all-to-all): cnt_src[n_src x row_count],
  *      cand_src[n_src x row_count x cap].
  *   3. as_knn_join_finish: exact f64 re-rank + certification of this rank's rows from the n_src lists; rows
