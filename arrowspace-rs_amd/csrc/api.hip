@@ -340,7 +340,7 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
 
 uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params) {
   if (!ctx || !params) return 0;
-  return 2 * knn_join_cap(ctx, (uint32_t)params->topk + 1);  // words per row: a slot is (row id, approximate cosine)
+  return 2 * knn_join_cap(ctx, (uint32_t)params->topk + 1, true);  // words per row: a slot is (row id, approximate cosine)
 }
 
 int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,

@@ -46,10 +46,15 @@ struct as_ctx {
   int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
   int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
   int64_t opt_knn_join = 1;       // item graph over the whole matrix: symmetric threshold join (mfma_join_f32.hip)
-  int64_t opt_join_sample = 12;   // thresholds come from a 1-in-N sample of the rows ...
-  int64_t opt_join_rank = 6;      // ... as the m-th best sampled product of every row (1 M x 128 sweep: 16/5 1172 ms,
-                                  // 12/6 1146, 10/7 1152, 8/8 1161 for the whole neighbour search)
-  int64_t opt_join_cap = 192;     // candidate slots per row (overflowing rows go to the next stage)
+  // Thresholds of the join: the m-th best product of every row with a 1-in-N sample of the rows, and the list slots per
+  // row.  0 = automatic: 32 / 4 / 512 when one call joins the whole matrix, 12 / 6 / 192 for the sharded sequence
+  // (as_knn_join_*), whose lists cross the links between the GPUs.  1 M x 128 on one GPU, theta + join + second pass +
+  // re-rank: 12/6/192 387 ms, 16/5/256 378, 24/4/384 374, 32/4/512 370, 40/4/640 395 (the second pass starts to
+  // overflow), 48/4/768 395; a sparser sample costs candidates (74 -> 132 per row), which are cheap now that the
+  // re-rank prunes by the stored scores before it fetches anything.
+  int64_t opt_join_sample = 0;
+  int64_t opt_join_rank = 0;
+  int64_t opt_join_cap = 0;
   int64_t opt_join_min_rows = 32768;
   int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128 on one device: 4 -> 304 ms, 8 .. 64 ->
                                   // 291-293: longer units amortise the unit prologue; devices differ by more than that)
@@ -357,7 +362,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, u
 // theta2_out (or nullptr): a second, looser threshold per row (bf16 pass only; left untouched otherwise, *has_theta2 = false)
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
                         uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr,
-                        float *theta2_out = nullptr, bool *has_theta2 = nullptr);
+                        float *theta2_out = nullptr, bool *has_theta2 = nullptr, bool sharded = true);
 // packed16 = split-bf16 image of ALL rows when the caller already has it (bf16 pipe), else nullptr
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
@@ -365,7 +370,7 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);
-uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K);
+uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded);
 
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,
                        uint32_t K, const as_graph_params *gp, as_csr **out);

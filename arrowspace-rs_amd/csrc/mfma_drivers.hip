@@ -471,6 +471,10 @@ __global__ __launch_bounds__(256) void rerank_join_kernel(const double *__restri
 // dot product from LDS.  The per-lane walk of the generic kernel fetches every candidate row
 // in 32-B pieces: 2-4x the bytes across the fabric (profiles/r01e_pmc_traffic.json) and 64 ms at 1 M rows.
 constexpr int kRrPitch = 1040;              // LDS pitch of a staged row (bytes): 16 lanes x 4 banks apart
+__host__ __device__ inline size_t rr_key_bytes(uint32_t cmax, uint32_t kmax) {
+  const size_t a = (size_t)cmax * 4, b = (size_t)kmax * 8;
+  return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
 typedef __attribute__((address_space(3))) void rr_lds_void;
 typedef const __attribute__((address_space(1))) void rr_gbl_void;
 
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
     const double *__restrict__ X, const double *__restrict__ XA, const uint32_t *__restrict__ a_ids, uint32_t row_begin,
     uint32_t row_count, const float *__restrict__ theta, uint32_t n_src,
     const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src, uint32_t cap, uint32_t cmax, uint32_t K,
-    const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double prune_delta, int prune_rectify,
+    const uint8_t *__restrict__ force_exact, Policy pol, Bound bnd, double prune_delta, int prune_rectify, uint32_t kmax,
     double *__restrict__ out_key,
     uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows, uint32_t *__restrict__ fail_count,
     int *__restrict__ err_flag) {
@@ -487,12 +491,15 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const size_t per_wave = 1024 + (size_t)NBUF * kRrRows * kRrPitch + (size_t)cmax * 12;
+  // per wave: the row (1 KB), the staged candidate rows, the keys of up to kmax candidates that are scored exactly
+  // (the same bytes hold the approximate cosines of all cmax gathered candidates until the pruning is done), the ids
+  const size_t key_bytes = rr_key_bytes(cmax, kmax);
+  const size_t per_wave = 1024 + (size_t)NBUF * kRrRows * kRrPitch + key_bytes + (size_t)cmax * 4;
   unsigned char *base = smem + (size_t)wv * per_wave;
   double *xrow = reinterpret_cast<double *>(base);
   unsigned char *tiles = base + 1024;
   double *ek = reinterpret_cast<double *>(tiles + NBUF * kRrRows * kRrPitch);
-  uint32_t *ei = reinterpret_cast<uint32_t *>(ek + cmax);
+  uint32_t *ei = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ek) + key_bytes);
 
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     const uint32_t a = a_ids ? a_ids[r] : row_begin + r;
@@ -519,6 +526,10 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
     }
     wave_sync();
     if (prune_delta >= 0.0) C = prune_candidates(ei, reinterpret_cast<float *>(ek), C, K, prune_delta, prune_rectify, lane);
+    if (C > kmax) {  // more survivors than key slots: the row goes on to the next stage
+      overflow = true;
+      C = kmax;
+    }
     const uint32_t n_batches = (C + kRrRows - 1) / kRrRows;
     auto issue = [&](uint32_t b) {
       unsigned char *dst = tiles + (size_t)(b % NBUF) * kRrRows * kRrPitch;
@@ -633,14 +644,17 @@ static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t r
 // theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
 // hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
-                        uint32_t row_count, float *theta_out, const float *packed, float *theta2_out, bool *has_theta2) {
+                        uint32_t row_count, float *theta_out, const float *packed, float *theta2_out, bool *has_theta2,
+                        bool sharded) {
   if (has_theta2) *has_theta2 = false;
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
-  const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_rank, 64));
+  const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : (sharded ? 6 : 4);
+  const int64_t sample_opt = ctx->opt_join_sample > 0 ? ctx->opt_join_sample : (sharded ? 12 : 32);
+  const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 64));
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
   // sample size: whole pairs of 128-row tiles (the bf16 pass bins the sample by tile parity and has no tail
   // handling), about n / join_sample of them; n >= 512 here
-  const uint32_t ns = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_join_sample)) & ~255u);
+  const uint32_t ns = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, sample_opt)) & ~255u);
   const uint32_t rate = n / ns;
   const uint32_t s_tiles = (ns + kTileRows - 1) / kTileRows, s_alloc = (s_tiles + 1) & ~1u;
   const uint32_t KC0 = std::max(8u, (m + 7) / 8 * 8);
@@ -761,8 +775,9 @@ void join_session_close(as_ctx *ctx) {
   js = as_ctx::JoinSession{};
 }
 
-uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K) {
-  return (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_join_cap, 1024));
+uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
+  const int64_t cap_opt = ctx->opt_join_cap > 0 ? ctx->opt_join_cap : (sharded ? 192 : 512);
+  return (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(cap_opt, 1024));
 }
 
 // ---- K2 driver ----------------------------------------------------------------------------------
@@ -837,10 +852,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   bool have_theta2 = false;
   if (use_join) {
     if (own_join) {
-      const uint32_t cap = knn_join_cap(ctx, K);
+      const uint32_t cap = knn_join_cap(ctx, K, false);
       AS_TRY(theta_own.alloc(ctx, n));
       AS_TRY(theta2_own.alloc(ctx, n));
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2));
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2, false));
       if (join_on_bf16(ctx, d)) {
         AS_TRY(P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
         AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
@@ -860,9 +875,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       ProfScope ps(ctx, "knn_rerank");
       // rows per batch x buffers.  Measured at 1 M rows (re-rank + fall-back re-rank): per-lane walk 66 ms, 8x1 39, 8x2 46,
       // 16x1 37, 16x2 58: occupancy (LDS per wave) beats double buffering.  debug = 10 + {0: 8x1, 1: 8x2, 2: 16x1, 3: 16x2}.
-      const int rr_cfg = (int)(ctx->opt_debug >= 10 ? ctx->opt_debug - 10 : 2);
-      const int rr_rows = (rr_cfg & 2) ? 16 : 8, rr_nbuf = (rr_cfg & 1) ? 2 : 1;
-      const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + (size_t)cmax * 12);
+      // with the pruning ~20 candidates of a row are scored exactly: 8 staged rows per batch and key slots for 128
+      // candidates keep three workgroups per CU whatever the list capacity (without it: 16 rows, cmax slots)
+      const bool pruning = prune_delta >= 0.0;
+      const int rr_rows = pruning ? 8 : 16, rr_nbuf = 1;
+      const uint32_t kmax = pruning ? std::min<uint32_t>(cmax, std::max<uint32_t>(128, 2 * K)) : cmax;
+      const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + rr_key_bytes(cmax, kmax) + (size_t)cmax * 4);
       if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
 #define AS_RR(R, NB)                                                                                                       \
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \
@@ -870,11 +888,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   hipLaunchKernelGGL((rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>),                                        \
                      dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows, rows,   \
                      (const uint32_t *)nullptr, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
-                     bnd, prune_delta, rectify, out_dist, out_idx, fail1.p, fail_count.p, err.p)
-        if (rr_rows == 8 && rr_nbuf == 1) { AS_RR(8, 1); }
-        else if (rr_rows == 8) { AS_RR(8, 2); }
-        else if (rr_nbuf == 1) { AS_RR(16, 1); }
-        else { AS_RR(16, 2); }
+                     bnd, prune_delta, rectify, kmax, out_dist, out_idx, fail1.p, fail_count.p, err.p)
+        if (rr_rows == 8) { AS_RR(8, 1); }
+        else { AS_RR(16, 1); }
 #undef AS_RR
       } else {
         const size_t lds = (size_t)4 * (d + cmax) * sizeof(double) + (size_t)4 * cmax * sizeof(uint32_t);
@@ -1322,14 +1338,14 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
                             1e-12};
       ProfScope ps(ctx, "search_rerank");
-      const size_t lds128 = (size_t)4 * (1024 + (size_t)16 * kRrPitch + (size_t)cap * 12);
+      const size_t lds128 = (size_t)4 * (1024 + (size_t)16 * kRrPitch + rr_key_bytes(cap, cap) + (size_t)cap * 4);
       if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)ix->items & 15) == 0) {
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
         hipLaunchKernelGGL((rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>),
                            dim3(std::min<uint64_t>(cdiv(nq, 4), 256 * 16)), dim3(256), lds128, ctx->stream, ix->items, queries,
                            (const uint32_t *)nullptr, 0u, nq, guess_pad.p, 1u, cnt.p, cand.p, cap, cap, K,
-                           (const uint8_t *)nullptr, pol, bnd, -1.0, 0, out_key, out_idx, fail1.p, fail_count.p, err.p);
+                           (const uint8_t *)nullptr, pol, bnd, -1.0, 0, cap, out_key, out_idx, fail1.p, fail_count.p, err.p);
       } else {
         const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,

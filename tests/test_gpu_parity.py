@@ -219,7 +219,7 @@ def join_on(ctx):
     ctx.set_option("join_min_rows", 512)
     yield
     ctx.set_option("join_min_rows", 32768)
-    for name, v in (("join_sample", 12), ("join_rank", 6), ("join_cap", 192)):
+    for name, v in (("join_sample", 0), ("join_rank", 0), ("join_cap", 0)):  # 0 = automatic
         ctx.set_option(name, v)
 
 
