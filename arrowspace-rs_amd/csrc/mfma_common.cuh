@@ -102,7 +102,8 @@ inline double cos_delta_bf16x3(uint32_t d) {
   const uint32_t ks = (d + 15) / 16, dp = ks * 16;
   const double split = 3.0 * 1.52587890625e-05 * 1.02;
   const double accum = (double)(3 * dp + 3 * ks + 2) * 1.1920928955078125e-07 * 1.02;
-  return split + accum + 2.0 * 5.9604644775390625e-08 + 1e-13;
+  // + the thresholds of the two-phase join blocks: held lowered by eps, eps added back for the exact test (two f32 roundings)
+  return split + accum + 2.0 * 5.9604644775390625e-08 + 3e-7 + 1e-13;
 }
 
 }  // namespace asx

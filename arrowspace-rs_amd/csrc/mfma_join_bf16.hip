@@ -45,6 +45,18 @@ template <int PENDING>
 __device__ __forceinline__ void lds_wait(bf16x8 &x, bf16x8 &y) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(PENDING));
 }
+template <int PENDING>
+__device__ __forceinline__ void lds_wait1(bf16x8 &x) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(PENDING));
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+constexpr float kHiEps = 3.94e-3f;  // >= 2 * 2^-9 (1 + 2^-9)(1 + 1e-6): what the lo planes can add to a hi-only product
 
 // a list slot is two words: the other row and the approximate score that put it there (the re-rank drops the
 // candidates whose score cannot reach the top K before it fetches any row)
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     return t;
   };
   unsigned long long t_unit = 0, t_blocks = 0, t_dma = 0, t_bar = 0, t_mark = 0;
+  unsigned long long n_blk = 0, n_hit = 0, n_coarse = 0;  // dbg 32: blocks, -, blocks that pass the coarse test
   const bool stamp = (dbg & 8) != 0;
   if (stamp) t_mark = now();
 
@@ -176,17 +189,22 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       }
     }
     const uint32_t row_base = I * kSuper + wv * 32 + 4 * lh;  // + (r & 3) + 8 * (r >> 2)
-    float tr[16];
+    // Thresholds are held lowered by eps, the slack of the hi-only products of phase A (see the block comment
+    // below); the exact test of phase B adds eps back (two f32 roundings: 2.4e-7, carried by cos_delta_bf16x3).
+    const float eps = SEARCH ? kHiEps * st.alpha : kHiEps;
+    float tre[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tr[r] = theta[row_base + (r & 3) + 8 * (r >> 2)];
+    for (int r = 0; r < 16; ++r) tre[r] = theta[row_base + (r & 3) + 8 * (r >> 2)];
     float lqb[SEARCH ? 16 : 1];  // beta * lambda of this lane's 16 rows
     if (SEARCH) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         lqb[r] = st.beta * st.a_lam[row_base + (r & 3) + 8 * (r >> 2)];
-        tr[r] -= st.beta;  // guess - beta
+        tre[r] -= st.beta;  // guess - beta
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tre[r] -= eps;
     // search: the tested quantity of a product (tcv = beta * lambda of the column)
     auto weigh = [&](float sdot, int r, float tcv) -> float {
       const float t = __builtin_fminf(__builtin_fabsf(lqb[SEARCH ? r : 0] - tcv), st.beta);
@@ -199,71 +217,69 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       return 2 * S + (step & 1u);
     };
 
-    // products of one 32x32 block: rows of this wave x columns [32 nn, 32 nn + 32) of the staged tile
-    // Fragment sets b_hi[s], b_lo[s], s = k step parity; the reads of step ks + 1 are issued before the wait for
-    // step ks.  ks = 0 of a block is issued by the block before it (AS_PREFETCH) or after the tile's barrier.
-    bf16x8 b_hi[2], b_lo[2];
-#define AS_READ(SET, KSTEP, NN)                                                   \
-  {                                                                               \
-    lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);                     \
-    lds_read16<(kPlaneVecs + ((KSTEP)*4 + (NN)) * 64) * 16>(b_lo[SET], b_addr);   \
-  }
-    // products of one 32x32 block: rows of this wave x columns [32 nn, 32 nn + 32) of the staged tile.
-    // NEXT_NN >= 0: the first fragments of that block of the same tile are requested before the last MFMAs.
-    // k steps [K0, K1) of the block
-    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, auto k0_c, auto k1_c, v16f32 &acc) {
-      constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
-      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
-      constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
-      v16f32 z;
+    // ---- a 32x32 block in two phases -------------------------------------------------------------------------
+    // Phase A contracts the hi planes only (KS MFMAs instead of 3 KS).  |s - s_hi| = |sum hi lo' + lo hi'| <=
+    // 2 * 2^-9 (1 + 2^-9) sum |x||x'| <= 3.915e-3 for unit rows (Cauchy-Schwarz), so a block none of whose hi-only
+    // products reaches its threshold minus eps = 3.94e-3 cannot hold a pair that the full product would list: its
+    // other 2 KS MFMAs are skipped (89 % of the blocks at 1 M x 128).  The others run phase B (lo hi' + hi lo' on
+    // top of the same accumulator: the full split product) and the exact test.
+    // Pipeline: the coarse test of block b rides behind the phase-A MFMAs of block b + 1 (two accumulators
+    // alternate); phase B of b, when needed, follows.  Phase-A fragments (hi plane) are requested three k steps
+    // ahead through a ring of four registers sets, across block boundaries of the tile; phase B reads its own.
+    bf16x8 fa[4], fb_hi[2], fb_lo[2];
+    v16f32 zero16;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-      for (int ks = K0; ks < K1; ++ks) {
-        const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
-        bool more = true;
-        if (ks + 1 < KS) {
-          switch (ks + 1) {  // compile-time offsets
-#define AS_CASE(K) case K: if (nxt) AS_READ(1, K, nn) else AS_READ(0, K, nn) break;
-            AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
-#undef AS_CASE
-          }
-        } else if (next_nn >= 0) {
-          if (nxt) AS_READ(1, 0, (next_nn < 0 ? 0 : next_nn)) else AS_READ(0, 0, (next_nn < 0 ? 0 : next_nn))
-        } else {
-          more = false;
-        }
-        if (more) {
-          if (cur) lds_wait<2>(b_hi[1], b_lo[1]); else lds_wait<2>(b_hi[0], b_lo[0]);
-        } else {
-          if (cur) lds_wait<0>(b_hi[1], b_lo[1]); else lds_wait<0>(b_hi[0], b_lo[0]);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi[cur], ks == 0 ? z : acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo[cur], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi[cur], acc, 0, 0, 0);
-      }
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    // request the hi fragment of global k step G = nn * KS + ks of the staged tile
+    auto request_a = [&](uint32_t b_addr, auto g_c) {
+      constexpr int G = decltype(g_c)::value;
+      if constexpr (G < 4 * KS) lds_read16<((G % KS) * 4 + (G / KS)) * 1024>(fa[G & 3], b_addr);
     };
-    // does any product of the block reach its row's or its column's threshold?
-    auto any_hit = [&](const v16f32 &acc, float tcv) -> bool {
+    auto phase_a = [&](uint32_t b_addr, auto nn_c, v16f32 &acc) {
+      constexpr int nn = decltype(nn_c)::value;
+      static_for<0, KS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value, G = nn * KS + ks;
+        request_a(b_addr, std::integral_constant<int, G + 3>{});
+        constexpr int pending = (4 * KS - 1 - G) < 3 ? (4 * KS - 1 - G) : 3;  // younger requests in flight
+        lds_wait1<pending>(fa[G & 3]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], fa[G & 3], ks == 0 ? zero16 : acc, 0, 0, 0);
+      });
+    };
+    auto phase_b = [&](uint32_t b_addr, auto nn_c, v16f32 &acc) {
+      constexpr int nn = decltype(nn_c)::value;
+      lds_read16<nn * 1024>(fb_hi[0], b_addr);
+      lds_read16<(kPlaneVecs + nn * 64) * 16>(fb_lo[0], b_addr);
+      static_for<0, KS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value, cur = ks & 1, nxt = cur ^ 1;
+        if constexpr (ks + 1 < KS) {
+          lds_read16<((ks + 1) * 4 + nn) * 1024>(fb_hi[nxt], b_addr);
+          lds_read16<(kPlaneVecs + ((ks + 1) * 4 + nn) * 64) * 16>(fb_lo[nxt], b_addr);
+          lds_wait<2>(fb_hi[cur], fb_lo[cur]);
+        } else {
+          lds_wait<0>(fb_hi[cur], fb_lo[cur]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], fb_hi[cur], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], fb_lo[cur], acc, 0, 0, 0);
+      });
+    };
+    // coarse test on the hi-only products: can any full product of the block reach a threshold?
+    // tcv: the column's lowered threshold (join) or its lambda term (search)
+    auto coarse = [&](const v16f32 &acc, float tcv) -> bool {
       bool h = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (SEARCH) h = h || (weigh(acc[r], r, tcv) >= tr[r]);
-        else h = h || (acc[r] >= tr[r]) || (acc[r] >= tcv);
+        if (SEARCH) h = h || (weigh(acc[r], r, tcv) >= tre[r]);
+        else h = h || (acc[r] >= tre[r]) || (acc[r] >= tcv);
       }
       return h;
     };
-    // the rows of a block that carries a hit are tested one by one with wave-uniform branches; what passes goes to
-    // the wave's queue (flush_queue below)
+    // exact test on the full products, row by row with wave-uniform branches; what passes goes to the wave's queue
     auto emit = [&](const v16f32 &acc, float tcv, uint32_t col) {
-      // the fragments requested for the next block are still in flight: nothing may touch their registers
-      // before they land (the code below is long enough for the allocator to want to move things around)
-      lds_wait<0>(b_hi[0], b_lo[0]);
-      lds_wait<0>(b_hi[1], b_lo[1]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = SEARCH ? weigh(acc[r], r, tcv) : acc[r];
-        const bool pr = v >= tr[r], pc = SEARCH ? false : v >= tcv;
+        const bool pr = v >= tre[r] + eps, pc = SEARCH ? false : v >= tcv + eps;
         if (__any(pr || pc)) {
           const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
           bool inside;
@@ -286,13 +302,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       }
     };
 
-    // block pipeline: accA / accB alternate; `prev` = the block whose products wait for their compares
-    v16f32 accA, accB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending: never a hit
-    float tc_prev = __builtin_inff();
-    uint32_t col_prev = 0;
-
     __syncthreads();
     stage(tile_of(0), 0, -1);
     __syncthreads();
@@ -301,49 +310,65 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       t_unit += t - t_mark;
       t_mark = t;
     }
+    v16f32 accA, accB;
     for (uint32_t step = 0; step < steps; ++step) {
       const uint32_t tile = tile_of(step);
       const int pbuf = (int)(step & 1u);
       const bool more_tiles = step + 1 < steps && !(dbg & 4);  // dbg 4: timing ablation
       const uint32_t tile_next = more_tiles ? tile_of(step + 1) : 0;
       const bool diag = RECT || (p_lo + (step >> 1)) == 0;
-      // column thresholds of this lane's four columns (the diagonal block is row-side only)
+      // this lane's four columns: lowered thresholds (the diagonal block is row-side only), or lambda terms (search)
       float tc[4];
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) {
-        if (SEARCH) tc[nn] = st.beta * st.x_lam[tile * kTileRows + nn * 32 + lc];  // the column's term, not a threshold
-        else tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc];
+        if (SEARCH) tc[nn] = st.beta * st.x_lam[tile * kTileRows + nn * 32 + lc];
+        else tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc] - eps;
       }
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kTileVecs) + (uint32_t)lane * 16u;
       const uint32_t col0 = tile * kTileRows + lc;
 
-// A 32x32 block in two halves of its k steps; the compares of the block before ride behind the MFMAs of the first
-// half.  The quarter of the next tile's DMA pieces that this block issues goes in front of the first half in waves
-// 0-3 and between the halves in waves 4-7: the two waves of a SIMD run in lockstep between barriers, and a DMA piece
-// holds its wave's issue for 60-190 cycles, so issued at the same moment they leave the matrix pipe idle.
 #define AS_IC(V) std::integral_constant<int, (V)>{}
-#define AS_BLOCK(NN, NEXT, CUR, PREV)                               \
+// decide block NN (products in ACC): full products and the exact test only if the hi-only ones come close
+#define AS_DECIDE(NN, ACC, PASS)                                    \
   {                                                                 \
-    constexpr int KH = (KS + 1) / 2;                                \
+    if (dbg & 32) {                                                 \
+      n_blk += 1;                                                   \
+      n_coarse += __any(PASS) ? 1 : 0;                              \
+    }                                                               \
+    if (__any(PASS)) {                                              \
+      phase_b(b_addr, AS_IC(NN), ACC);                              \
+      if (!(dbg & 2)) emit(ACC, tc[NN], col0 + (NN) * 32);          \
+    }                                                               \
+  }
+// phase A of block NN into CUR; the coarse test of the block before it (PREV) rides behind these MFMAs.  The
+// quarter of the next tile's DMA pieces that this block issues goes in front in waves 0-3 and behind in waves 4-7:
+// a piece holds its wave's issue for 60-190 cycles, and the two waves of a SIMD run in lockstep between barriers.
+#define AS_BLOCK(NN, CUR, PREV)                                     \
+  {                                                                 \
     if (more_tiles && wv < 4) stage(tile_next, pbuf ^ 1, NN);       \
-    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR); \
-    const bool h = any_hit(PREV, tc_prev);                          \
-    _Pragma("unroll") for (int i = 0; i < 3 * KH; ++i) {            \
+    phase_a(b_addr, AS_IC(NN), CUR);                                \
+    bool pass = false;                                              \
+    if ((NN) > 0) pass = coarse(PREV, tc[(NN) > 0 ? (NN)-1 : 0]);   \
+    _Pragma("unroll") for (int i = 0; i < KS; ++i) {                \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-      __builtin_amdgcn_sched_group_barrier(0x002, SEARCH ? 6 : 3, 0); \
+      __builtin_amdgcn_sched_group_barrier(0x002, SEARCH ? 10 : 4, 0); \
     }                                                               \
     if (more_tiles && wv >= 4) stage(tile_next, pbuf ^ 1, NN);      \
-    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
-    if (!(dbg & 2) && __any(h)) emit(PREV, tc_prev, col_prev);      \
-    tc_prev = tc[NN];                                               \
-    col_prev = col0 + NN * 32;                                      \
+    if ((NN) > 0) AS_DECIDE((NN) > 0 ? (NN)-1 : 0, PREV, pass)      \
   }
-      AS_READ(0, 0, 0)
-      AS_BLOCK(0, 1, accA, accB)
-      AS_BLOCK(1, 2, accB, accA)
-      AS_BLOCK(2, 3, accA, accB)
-      AS_BLOCK(3, -1, accB, accA)
+      request_a(b_addr, AS_IC(0));
+      request_a(b_addr, AS_IC(1));
+      request_a(b_addr, AS_IC(2));
+      AS_BLOCK(0, accA, accB)
+      AS_BLOCK(1, accB, accA)
+      AS_BLOCK(2, accA, accB)
+      AS_BLOCK(3, accB, accA)
+      {  // the last block of the tile: its fragments go with the barrier
+        const bool pass = coarse(accB, tc[3]);
+        AS_DECIDE(3, accB, pass)
+      }
 #undef AS_BLOCK
+#undef AS_DECIDE
 #undef AS_IC
       if (stamp) {
         unsigned long long t = now();
@@ -361,12 +386,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
         t_mark = t;
       }
     }
-#undef AS_READ
-    // the last block of the unit
-    {
-      const bool h = any_hit(accB, tc_prev);
-      if (!(dbg & 2) && __any(h)) emit(accB, tc_prev, col_prev);
-    }
   }
   flush_queue();
   if (stamp && lane == 0) {
@@ -375,6 +394,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     atomicAdd(stamps + 2, t_dma);
     atomicAdd(stamps + 3, t_bar);
     atomicAdd(stamps + 4, 1ull);
+    atomicAdd(stamps + 5, n_blk);
+    atomicAdd(stamps + 6, n_hit);
+    atomicAdd(stamps + 7, n_coarse);
   }
 }
 
@@ -428,6 +450,8 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
     const double w = (double)std::max<unsigned long long>(1, h[4]);
     std::fprintf(stderr, "[join_bf16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f\n",
                  h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6);
+    if (h[5])
+      std::fprintf(stderr, "[join_bf16 blocks] %llu blocks, %.3f of them pass the coarse test\n", h[5], (double)h[7] / h[5]);
   }
   return AS_OK;
 }
