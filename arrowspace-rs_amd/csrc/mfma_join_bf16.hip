@@ -141,14 +141,16 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
                                          16, 0, 0);
   };
 
-  // dbg 8: cycle stamps (diagnostic build of the SAME kernel; the sums go to a buffer nothing else reads)
+  // Diagnostics (as_ctx_set_option("debug", bits); results are undefined except with 8 and 32): 2 no emit, 4 no DMA of
+  // the next tile, 8 cycle stamps, 64 no phase B, 128 no coarse test.
+  // dbg 8: cycle stamps (diagnostic run of the SAME kernel; the sums go to a buffer nothing else reads)
   auto now = [&]() -> unsigned long long {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
   };
   unsigned long long t_unit = 0, t_blocks = 0, t_dma = 0, t_bar = 0, t_mark = 0;
-  unsigned long long n_blk = 0, n_hit = 0, n_coarse = 0;  // dbg 32: blocks, -, blocks that pass the coarse test
+  unsigned long long n_blk = 0, n_coarse = 0;  // blocks contracted, blocks that pass the coarse test (phase B)
   const bool stamp = (dbg & 8) != 0;
   if (stamp) t_mark = now();
 
@@ -311,18 +313,33 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
       t_mark = t;
     }
     v16f32 accA, accB;
+    float tc_next[4];
+    {
+      const uint32_t tile0 = tile_of(0);
+      const bool diag0 = RECT || p_lo == 0;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        if (SEARCH) tc_next[nn] = st.beta * st.x_lam[tile0 * kTileRows + nn * 32 + lc];
+        else tc_next[nn] = diag0 ? __builtin_inff() : theta[tile0 * kTileRows + nn * 32 + lc] - eps;
+      }
+    }
     for (uint32_t step = 0; step < steps; ++step) {
       const uint32_t tile = tile_of(step);
       const int pbuf = (int)(step & 1u);
       const bool more_tiles = step + 1 < steps && !(dbg & 4);  // dbg 4: timing ablation
       const uint32_t tile_next = more_tiles ? tile_of(step + 1) : 0;
-      const bool diag = RECT || (p_lo + (step >> 1)) == 0;
-      // this lane's four columns: lowered thresholds (the diagonal block is row-side only), or lambda terms (search)
+      // this lane's four columns: lowered thresholds (the diagonal block is row-side only), or lambda terms (search).
+      // Loaded one tile ahead: a tile is ~4 us now and the first use comes 0.3 us after its start.
       float tc[4];
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) {
-        if (SEARCH) tc[nn] = st.beta * st.x_lam[tile * kTileRows + nn * 32 + lc];
-        else tc[nn] = diag ? __builtin_inff() : theta[tile * kTileRows + nn * 32 + lc] - eps;
+      for (int nn = 0; nn < 4; ++nn) tc[nn] = tc_next[nn];
+      if (more_tiles) {
+        const bool diag_next = RECT || (p_lo + ((step + 1) >> 1)) == 0;
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+          if (SEARCH) tc_next[nn] = st.beta * st.x_lam[tile_next * kTileRows + nn * 32 + lc];
+          else tc_next[nn] = diag_next ? __builtin_inff() : theta[tile_next * kTileRows + nn * 32 + lc] - eps;
+        }
       }
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kTileVecs) + (uint32_t)lane * 16u;
       const uint32_t col0 = tile * kTileRows + lc;
@@ -331,11 +348,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
 // decide block NN (products in ACC): full products and the exact test only if the hi-only ones come close
 #define AS_DECIDE(NN, ACC, PASS)                                    \
   {                                                                 \
-    if (dbg & 32) {                                                 \
-      n_blk += 1;                                                   \
-      n_coarse += __any(PASS) ? 1 : 0;                              \
-    }                                                               \
-    if (__any(PASS)) {                                              \
+    n_blk += 1;                                                     \
+    n_coarse += __any(PASS) ? 1 : 0;                                \
+    if (__any(PASS) && !(dbg & 64)) {                               \
       phase_b(b_addr, AS_IC(NN), ACC);                              \
       if (!(dbg & 2)) emit(ACC, tc[NN], col0 + (NN) * 32);          \
     }                                                               \
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     if (more_tiles && wv < 4) stage(tile_next, pbuf ^ 1, NN);       \
     phase_a(b_addr, AS_IC(NN), CUR);                                \
     bool pass = false;                                              \
-    if ((NN) > 0) pass = coarse(PREV, tc[(NN) > 0 ? (NN)-1 : 0]);   \
+    if ((NN) > 0 && !(dbg & 128)) pass = coarse(PREV, tc[(NN) > 0 ? (NN)-1 : 0]); \
     _Pragma("unroll") for (int i = 0; i < KS; ++i) {                \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
       __builtin_amdgcn_sched_group_barrier(0x002, SEARCH ? 10 : 4, 0); \
@@ -388,15 +403,16 @@ __global__ __launch_bounds__(512, 2) void pair_join_bf16_kernel(const bf16x8 *__
     }
   }
   flush_queue();
+  if (lane == 0) {  // blocks contracted, and how many of them in full (the executed MFMAs of the launch)
+    atomicAdd(stamps + 5, n_blk);
+    atomicAdd(stamps + 7, n_coarse);
+  }
   if (stamp && lane == 0) {
     atomicAdd(stamps + 0, t_unit);
     atomicAdd(stamps + 1, t_blocks);
     atomicAdd(stamps + 2, t_dma);
     atomicAdd(stamps + 3, t_bar);
     atomicAdd(stamps + 4, 1ull);
-    atomicAdd(stamps + 5, n_blk);
-    atomicAdd(stamps + 6, n_hit);
-    atomicAdd(stamps + 7, n_coarse);
   }
 }
 
@@ -419,10 +435,8 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
-  if (ctx->opt_debug & 8) {
-    AS_TRY(stamps.alloc(ctx, 8));
-    AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-  }
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
   {
     ProfScope ps(ctx, prof_name);
 #define AS_JOIN1(K, R)                                                                                                 \
@@ -443,15 +457,20 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
 #undef AS_JOIN1
     AS_HIP(ctx, hipGetLastError());
   }
-  if (ctx->opt_debug & 8) {
+  {
     unsigned long long h[8];
     AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const double w = (double)std::max<unsigned long long>(1, h[4]);
-    std::fprintf(stderr, "[join_bf16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f\n",
-                 h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6);
-    if (h[5])
-      std::fprintf(stderr, "[join_bf16 blocks] %llu blocks, %.3f of them pass the coarse test\n", h[5], (double)h[7] / h[5]);
+    // 32x32 blocks contracted on the hi planes (KS MFMAs each) and, of those, in full (2 KS more)
+    ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[5];
+    ctx->stats[std::string(prof_name) + "_blocks_full"] = (int64_t)h[7];
+    if (ctx->opt_debug & 8) {
+      const double w = (double)std::max<unsigned long long>(1, h[4]);
+      std::fprintf(stderr,
+                   "[join_bf16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f; %llu blocks, "
+                   "%.3f in full\n",
+                   h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5], h[5] ? (double)h[7] / h[5] : 0.0);
+    }
   }
   return AS_OK;
 }

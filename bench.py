@@ -190,15 +190,26 @@ def main():
         t2 = (n + 255) // 256
         pairs = t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)   # 256 x 256 blocks visited
         if lb and msb >= max(ms32, ms64, msj):
-            # split-bf16 contraction: x = hi + lo, three bf16 MFMAs per 16-wide k step (lo*hi + hi*lo + hi*hi)
+            # split-bf16 contraction in two phases per 32x32 block: the hi planes of every block (KS MFMAs of
+            # 32x32x16), the two cross terms (2 KS more) only for the blocks the hi-only products cannot rule out.
+            # `achieved` / `frac` price the kernel on the MFMA flops it really executes (block counts reported by the
+            # kernel itself); what the full three-term contraction of every visited block would take, and what the
+            # reference's full square takes, are given next to it.
             d_pad = (d + 15) // 16 * 16
-            executed = 3 * 2.0 * pairs * 256 * 256 * d_pad
+            blocks = ctx.stat("knn_mfma_join_bf16_blocks")
+            full = ctx.stat("knn_mfma_join_bf16_blocks_full")
+            per_block_phase = 2.0 * 32 * 32 * d_pad
+            executed = per_block_phase * (blocks + 2.0 * full) if blocks else 3 * 2.0 * pairs * 256 * 256 * d_pad
             achieved = executed / (msb / lb * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_join_bf16_kernel (v_mfma_f32_32x32x16_bf16 on split operands, 3 MFMAs per "
-                                                   "k step, f32 acc, symmetric threshold join; exact f64 re-rank + certification follow)",
+            roofline = {"bound": "mfma", "kernel": "pair_join_bf16_kernel (v_mfma_f32_32x32x16_bf16 on split operands: hi x hi for every "
+                                                   "32x32 block, the cross terms for the blocks it cannot rule out; f32 acc; symmetric "
+                                                   "threshold join; exact f64 re-rank + certification follow)",
                         "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                         "avg_launch_ms": msb / lb, "launches": lb, "executed_flops_per_launch": executed,
+                        "blocks_32x32": blocks, "blocks_contracted_in_full": full,
+                        "three_term_flops_of_the_visited_blocks": 3 * 2.0 * pairs * 256 * 256 * d_pad,
+                        "three_term_equivalent_TFLOPs": 3 * 2.0 * pairs * 256 * 256 * d_pad / (msb / lb * 1e-3) / 1e12,
                         "algorithmic_flops_per_launch": flops_per_launch,
                         "reference_equivalent_TFLOPs": flops_per_launch / (msb / lb * 1e-3) / 1e12}
         elif lj and msj >= max(ms32, ms64):
