@@ -241,19 +241,12 @@ __device__ void sort_row(uint32_t *col, double *w, uint32_t L) {
 }
 
 // ---- K5: per-row union, sort, degree, final CSR (src/laplacian.rs:339-341,369-411) -----------
-__global__ void write_rows_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
-                                  const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
-                                  const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src,
-                                  const double *__restrict__ rev_w, const uint64_t *__restrict__ eptr,
-                                  uint32_t *__restrict__ ecol, double *__restrict__ ew,
-                                  uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
-                                  double *__restrict__ data) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  if (i == n) {
-    indptr[n] = eptr[n] + n;
-    return;
-  }
+// serial form of one row (any length): gather into the global scratch, sort there, write
+__device__ void write_row_serial(uint32_t i, const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+                                 const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+                                 const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
+                                 const uint64_t *__restrict__ eptr, uint32_t *__restrict__ ecol, double *__restrict__ ew,
+                                 uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices, double *__restrict__ data) {
   const uint32_t len = adj_len[i];
   const uint32_t *aj = adj_j + (uint64_t)i * K;
   const double *aw = adj_w + (uint64_t)i * K;
@@ -289,6 +282,167 @@ __global__ void write_rows_kernel(const uint32_t *__restrict__ adj_j, const doub
   if (!diag_done) {
     indices[o] = i;
     data[o] = degree;
+  }
+}
+
+// One WAVE per row: lane e holds one entry of the union (out-edges first, then the in-edges whose source is not an
+// out-neighbour), a 64-lane bitonic network orders them by column, the degree is the sequential sum in column order
+// (src/laplacian.rs:369), and the lanes write the finished row side by side.  Rows with more than 64 entries before
+// the duplicate check (hubs) take the serial form on one lane.  (One thread per row with its insertion sort on the
+// global scratch arrays was 7 of the 11 ms of the assembly at 1 M rows.)
+__global__ __launch_bounds__(256) void write_rows_kernel(
+    const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t n,
+    uint32_t K, const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
+    const uint64_t *__restrict__ eptr, uint32_t *__restrict__ ecol, double *__restrict__ ew, uint64_t *__restrict__ indptr,
+    uint64_t *__restrict__ indices, double *__restrict__ data, uint32_t *__restrict__ big_rows,
+    uint32_t *__restrict__ big_count) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i > n) return;
+  if (i == n) {
+    if (lane == 0) indptr[n] = eptr[n] + n;
+    return;
+  }
+  const uint32_t len = adj_len[i];
+  const uint64_t rs = rev_ptr[i], re = rev_ptr[i + 1];
+  if (len + (re - rs) > 64) {  // hub rows (in-degree in the hundreds or thousands): one workgroup each, below
+    if (lane == 0) big_rows[atomicAdd(big_count, 1u)] = i;
+    return;
+  }
+  const uint32_t nrev = (uint32_t)(re - rs);
+  uint32_t col = 0xFFFFFFFFu;  // invalid entries sort to the end
+  double w = 0.0;
+  if ((uint32_t)lane < len) {
+    col = adj_j[(uint64_t)i * K + lane];
+    w = adj_w[(uint64_t)i * K + lane];
+  } else if ((uint32_t)lane < len + nrev) {
+    col = rev_src[rs + lane - len];
+    w = rev_w[rs + lane - len];
+  }
+  // in-edges whose source is already an out-neighbour are dropped (the out-edge carries the pair)
+  bool dup = false;
+  for (uint32_t s = 0; s < len; ++s) {
+    const uint32_t a = __shfl(col, (int)s, 64);
+    dup = dup || ((uint32_t)lane >= len && a == col);
+  }
+  if (dup) col = 0xFFFFFFFFu;
+  // bitonic sort of the 64 (col, w) pairs, ascending by column (columns of valid entries are distinct)
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t oc = __shfl_xor(col, j, 64);
+      const double ow = __shfl_xor(w, j, 64);
+      const bool up = (lane & k) == 0;          // this lane's pair sorts ascending
+      const bool lower = (lane & j) == 0;       // this lane keeps the smaller one when ascending
+      const bool take_min = up == lower;
+      const bool swap = take_min ? (oc < col) : (oc > col);
+      col = swap ? oc : col;
+      w = swap ? ow : w;
+    }
+  }
+  const unsigned long long valid = __ballot(col != 0xFFFFFFFFu);
+  const uint32_t L = (uint32_t)__builtin_popcountll(valid);  // = eptr[i + 1] - eptr[i]
+  double degree = 0.0;
+  for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, __shfl(w, (int)s, 64));
+  const uint64_t o = eptr[i] + i;
+  const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(col < i));  // entries left of the diagonal
+  if (lane == 0) {
+    indptr[i] = o;
+    indices[o + below] = i;
+    data[o + below] = degree;
+  }
+  if ((uint32_t)lane < L) {
+    const uint64_t at = o + lane + ((uint32_t)lane >= below ? 1 : 0);
+    indices[at] = col;
+    data[at] = -w;
+  }
+}
+
+// Hub rows: one workgroup per row, the union gathered into LDS (up to kBigMax entries before the duplicate check),
+// ordered by a bitonic network over LDS, degree summed sequentially by one thread, written side by side.  Longer rows
+// still take the serial form.  (k-NN graphs have hubs: at 1 M x 128, 9 % of the rows have more than 47 in-edges, the
+// largest 1 691; left to one thread each with a heap sort in global memory they were most of this stage's time.)
+constexpr uint32_t kBigMax = 4096;
+__global__ __launch_bounds__(256) void write_rows_big_kernel(
+    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ adj_j,
+    const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+    const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w, const uint64_t *__restrict__ eptr,
+    uint32_t *__restrict__ ecol, double *__restrict__ ew, uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
+    double *__restrict__ data) {
+  __shared__ uint32_t s_col[kBigMax];
+  __shared__ double s_w[kBigMax];
+  __shared__ double s_degree;
+  __shared__ uint32_t s_below;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t b = blockIdx.x; b < *big_count; b += gridDim.x) {
+    const uint32_t i = big_rows[b];
+    const uint32_t len = adj_len[i];
+    const uint64_t rs = rev_ptr[i];
+    const uint32_t nrev = (uint32_t)(rev_ptr[i + 1] - rs), total = len + nrev;
+    if (total > kBigMax) {
+      if (tid == 0) write_row_serial(i, adj_j, adj_w, adj_len, K, rev_ptr, rev_src, rev_w, eptr, ecol, ew, indptr, indices, data);
+      continue;
+    }
+    uint32_t P = 64;
+    while (P < total) P <<= 1;
+    __syncthreads();  // the row before is done with the arrays
+    if (tid == 0) s_below = 0;
+    for (uint32_t e = tid; e < P; e += blockDim.x) {
+      uint32_t c = 0xFFFFFFFFu;
+      double v = 0.0;
+      if (e < len) {
+        c = adj_j[(uint64_t)i * K + e];
+        v = adj_w[(uint64_t)i * K + e];
+      } else if (e < total) {
+        c = rev_src[rs + e - len];
+        v = rev_w[rs + e - len];
+        if (in_adj(adj_j + (uint64_t)i * K, len, c)) c = 0xFFFFFFFFu;  // the out-edge carries the pair
+      }
+      s_col[e] = c;
+      s_w[e] = v;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t e = tid; e < P; e += blockDim.x) {
+          const uint32_t partner = e ^ j;
+          if (partner > e) {
+            const bool up = (e & k) == 0;
+            const uint32_t a = s_col[e], c2 = s_col[partner];
+            if (up ? (a > c2) : (a < c2)) {
+              s_col[e] = c2;
+              s_col[partner] = a;
+              const double t = s_w[e];
+              s_w[e] = s_w[partner];
+              s_w[partner] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    const uint32_t L = (uint32_t)(eptr[i + 1] - eptr[i]);  // valid entries (the invalid ones sorted behind them)
+    uint32_t below = 0;
+    for (uint32_t e = tid; e < L; e += blockDim.x) below += s_col[e] < i ? 1u : 0u;
+    if (below) atomicAdd(&s_below, below);
+    if (tid == 0) {
+      double degree = 0.0;  // sequential sum in column order (src/laplacian.rs:369)
+      for (uint32_t e = 0; e < L; ++e) degree = __dadd_rn(degree, s_w[e]);
+      s_degree = degree;
+    }
+    __syncthreads();
+    const uint64_t o = eptr[i] + i;
+    const uint32_t nb = s_below;
+    if (tid == 0) {
+      indptr[i] = o;
+      indices[o + nb] = i;
+      data[o + nb] = s_degree;
+    }
+    for (uint32_t e = tid; e < L; e += blockDim.x) {
+      const uint64_t at = o + e + (e >= nb ? 1 : 0);
+      indices[at] = s_col[e];
+      data[at] = -s_w[e];
+    }
   }
 }
 
@@ -347,11 +501,17 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
   AS_TRY(ecol.alloc(ctx, n_union));
   AS_TRY(ew.alloc(ctx, n_union));
+  DevBuf<uint32_t> big_rows, big_count;
+  AS_TRY(big_rows.alloc(ctx, n));
+  AS_TRY(big_count.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(big_count.p, 0, sizeof(uint32_t), st));
   {
     ProfScope ps(ctx, "graph_assembly");
-    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)n + 1, 256)), dim3(256), 0, st, adj_j.p, adj_w.p,
+    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)n + 1, 4)), dim3(256), 0, st, adj_j.p, adj_w.p,
                        adj_len.p, n, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,
-                       m->indices, m->data);
+                       m->indices, m->data, big_rows.p, big_count.p);
+    hipLaunchKernelGGL(write_rows_big_kernel, dim3(4096), dim3(256), 0, st, big_rows.p, big_count.p, adj_j.p, adj_w.p, adj_len.p,
+                       K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr, m->indices, m->data);
   }
   AS_HIP(ctx, hipGetLastError());
   ctx->stats["graph_directed_edges"] = (int64_t)n_edges_dir;
