@@ -533,6 +533,33 @@ def test_search_lambda_term_precision_choice(ctx, scale, want_f32):
         assert np.array_equal(sc[j], osc), j
 
 
+def test_laplacian_hub_rows_match_oracle(ctx):
+    """k-NN graphs have hubs.  The CSR writer takes rows of up to 64 union entries on one wave, up to 4096 on one
+    workgroup (bitonic sort in LDS) and longer ones serially: a graph with one row that is everybody's nearest
+    neighbour, twenty sub-hubs (in-degree in the hundreds) and ordinary rows."""
+    rng = np.random.default_rng(12)
+    n, d = 5000, 48
+    v0 = rng.normal(size=d)
+    v0 /= np.linalg.norm(v0)
+    U = rng.normal(size=(n, d))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    X = 0.9 * v0 + 0.45 * U
+    X[0] = v0
+    centres = rng.normal(size=(20, d))
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    for c in range(20):
+        X[1 + c] = 0.9 * v0 + 0.3 * centres[c]
+        lo = 100 + 200 * c
+        X[lo:lo + 200] = 0.9 * v0 + 0.3 * centres[c] + 0.05 * U[lo:lo + 200]
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    got = A.build_laplacian_matrix(X, gp).matrix.to_host()
+    want = O.build_laplacian(X, ogp(gp))
+    assert_csr_equal(got, want)
+    indptr = np.asarray(want[0])
+    assert int(np.max(np.diff(indptr))) > 512          # a row that needs the ten-stage LDS network
+    assert int(np.sum(np.diff(indptr) > 65)) >= 20     # and a population of rows in the workgroup form
+
+
 # ---- threshold scan of the search (stage 0 of K9, csrc/mfma_join_bf16.hip MODE 2) ---------------
 
 @pytest.fixture
