@@ -1338,21 +1338,25 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
                             1e-12};
       ProfScope ps(ctx, "search_rerank");
-      const size_t lds128 = (size_t)4 * (1024 + (size_t)16 * kRrPitch + rr_key_bytes(cap, cap) + (size_t)cap * 4);
+      // the lists carry the approximate score minus beta: candidates that cannot reach the top K are dropped before
+      // their rows are fetched, as in the item graph (prune_candidates)
+      const uint32_t kmax = std::min<uint32_t>(cap, std::max<uint32_t>(128, 2 * K));
+      const size_t lds128 = (size_t)4 * (1024 + (size_t)8 * kRrPitch + rr_key_bytes(cap, kmax) + (size_t)cap * 4);
       if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)ix->items & 15) == 0) {
-        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>,
+        AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 8, 1>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
-        hipLaunchKernelGGL((rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 16, 1>),
+        hipLaunchKernelGGL((rerank_join_d128_kernel<SearchScorePolicy, SearchBound, 8, 1>),
                            dim3(std::min<uint64_t>(cdiv(nq, 4), 256 * 16)), dim3(256), lds128, ctx->stream, ix->items, queries,
                            (const uint32_t *)nullptr, 0u, nq, guess_pad.p, 1u, cnt.p, cand.p, cap, cap, K,
-                           (const uint8_t *)nullptr, pol, bnd, -1.0, 0, cap, out_key, out_idx, fail1.p, fail_count.p, err.p);
+                           (const uint8_t *)nullptr, pol, bnd, bnd.delta, 0, kmax, out_key, out_idx, fail1.p, fail_count.p,
+                           err.p);
       } else {
         const size_t lds = (size_t)4 * (d + cap) * sizeof(double) + (size_t)4 * cap * sizeof(uint32_t);
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nq, 4), 8192)),
                            dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)nullptr, d, 0u, nq, guess_pad.p, 1u,
-                           cnt.p, cand.p, cap, cap, K, (const uint8_t *)nullptr, pol, bnd, -1.0, 0, out_key, out_idx, fail1.p,
+                           cnt.p, cand.p, cap, cap, K, (const uint8_t *)nullptr, pol, bnd, bnd.delta, 0, out_key, out_idx, fail1.p,
                            fail_count.p, err.p);
       }
       AS_HIP(ctx, hipGetLastError());
@@ -1409,7 +1413,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<SearchScorePolicy, SearchBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
                            dim3(256), lds, ctx->stream, ix->items, queries, (const uint32_t *)fail1.p, d, 0u, nf, guess_b.p, 1u,
-                           cnt_b.p, cand_b.p, cap2, cap2, K, (const uint8_t *)nullptr, pol, bnd, -1.0, 0, ok.p, oi.p, fail_b.p,
+                           cnt_b.p, cand_b.p, cap2, cap2, K, (const uint8_t *)nullptr, pol, bnd, bnd.delta, 0, ok.p, oi.p, fail_b.p,
                            fail_count.p, err.p);
         AS_HIP(ctx, hipGetLastError());
       }
