@@ -240,11 +240,11 @@ def main():
         # committed rocprofv3 --pmc measurement of this very command is reported when it matches the workload
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if roofline and world == 1 and (n, d) == (1_000_000, 128) and pmc.get("dominant_kernel", "pair_topk_mfma32") in roofline["kernel"]:
                 roofline["traffic"] = pmc["hbm_bytes_per_step"]
-                roofline["traffic_source"] = "profiles/r01h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roofline["traffic_source"] = "profiles/r01i_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except (OSError, KeyError, ValueError):
             pmc = {}
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
@@ -263,7 +263,7 @@ def main():
                                       "algorithmic_bytes_per_step": bytes_per_step}
             if world == 1 and (n, d, nq) == (1_000_000, 128, 10_000) and "lambda_scan_hbm_bytes_per_step" in pmc:
                 extra["roofline_scan"]["traffic"] = pmc["lambda_scan_hbm_bytes_per_step"]
-                extra["roofline_scan"]["traffic_source"] = "profiles/r01h_pmc_traffic.json"
+                extra["roofline_scan"]["traffic_source"] = "profiles/r01i_pmc_traffic.json"
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
             "candidate_precision": ("split-bf16 MFMA symmetric threshold join (f32 MFMA beyond dim 128) -> f32 top-k "
