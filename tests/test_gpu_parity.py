@@ -239,6 +239,30 @@ def test_item_graph_join_matches_oracle(ctx, join_on, n, d, topk, eps):
     assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
 
 
+@pytest.mark.parametrize("n,d", [(1500, 64), (2048, 128), (3100, 17)])
+@pytest.mark.parametrize("pipe", [16, 32])
+def test_item_graph_join_on_either_pipe(ctx, join_on, n, d, pipe):
+    """The same join contracted as split-bf16 products (two-phase blocks) and on the f32 MFMA pipe: both certify
+    against their own rounding bound and give the oracle's tables; rows that can form a 0 < |a||b| <= 1e-12 pair and
+    zero rows included."""
+    X, _ = synth.mixture(n, d, seed=13, n_clusters=10, rank=4)
+    X[5] = 0.0
+    X[40] *= 1e-8
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    ctx.set_option("join_pipe", pipe)
+    try:
+        idx, dist = A.knn_cosine(X, gp)
+        blocks = ctx.stat("knn_mfma_join_bf16_blocks")
+    finally:
+        ctx.set_option("join_pipe", 16)
+    assert ctx.stat("knn_join") == 1
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    if pipe == 16:  # the kernel reports what it contracted: every block on the hi planes, some of them in full
+        assert blocks > 0 and 0 <= ctx.stat("knn_mfma_join_bf16_blocks_full") <= blocks
+
+
 @pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 32, 1024)])
 @pytest.mark.parametrize("bf16", [1, 0])
 def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap, bf16):
