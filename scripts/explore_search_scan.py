@@ -36,4 +36,6 @@ for scan, rate, m, cap in [(0, 32, 3, 512)] + [(1,) + c for c in cfgs]:
         ctx.stat("search_scan_candidates") / nq if scan else 0, ctx.stat("search_scan_max_per_query") if scan else 0,
         ctx.stat("search_scan_overflow_queries") if scan else 0), {k: round(v[0] / v[1], 2) for k, v in prof.items()})
     if scan:
+        b = ctx.stat("search_scan_bf16_blocks"); f = ctx.stat("search_scan_bf16_blocks_full")
+        print("   blocks of the last scan launch: %d, in full %.3f" % (b, f / max(1, b)))
         print("   identical:", np.array_equal(res[0][0], res[1][0]), np.array_equal(res[0][1], res[1][1]))
