@@ -5,5 +5,5 @@ this package only marshals pointers.  There is no CPU fallback.
 """
 from ._lib import ArrowSpaceError, LIB_PATH, load  # noqa: F401
 from .api import (ArrowItem, ArrowSpace, ArrowSpaceBuilder, Context, CsrMatrix, GraphFactory,  # noqa: F401
-                  GraphLaplacian, GraphParams, TauMode, TAU_FLOOR, build_laplacian_matrix, build_spectral_laplacian,
+                  GraphLaplacian, GraphParams, TauMode, TAU_FLOOR, build_laplacian_matrix, build_spectral_laplacian, nearest_centroids,
                   compute_synthetic_lambda, default_context, knn_cosine, laplacian_from_knn, select_tau)

@@ -261,6 +261,21 @@ def knn_cosine(rows, params, row_begin=0, row_count=None, ctx=None):
     return idx, dist
 
 
+def nearest_centroids(rows, centroids, ctx=None):
+    """Batch form of `nearest_centroid` (src/clustering.rs:913-928): (index of the nearest centroid, squared
+    distance) for every row, in the reference's arithmetic (first of equal minima)."""
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    Cn = _f64(centroids, ctx)
+    n, d = _shape2(X)
+    nc, dc = _shape2(Cn)
+    assert d == dc, "rows and centroids must have the same width"
+    idx = np.empty(n, dtype=np.uint64)
+    d2 = np.empty(n, dtype=np.float64)
+    ctx.check(ctx.lib.as_nearest_centroids(ctx.h, ptr(X), n, d, ptr(Cn), nc, ptr(idx), ptr(d2)))
+    return idx, d2
+
+
 def laplacian_from_knn(nbr_idx, nbr_dist, params, ctx=None):
     ctx = ctx or default_context()
     nbr_idx = nbr_idx if _lib.is_tensor(nbr_idx) else np.ascontiguousarray(nbr_idx, dtype=np.uint64)

@@ -307,6 +307,24 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
   return AS_OK;
 }
 
+int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t dim, const double *centroids,
+                         uint64_t n_centroids, uint64_t *out_idx, double *out_dist2) {
+  AS_TRY(check_ctx(ctx));
+  if (!rows || !centroids || !out_idx || !out_dist2) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (dim == 0 || n_centroids == 0) return fail(ctx, AS_ERR_ARG, "dim and n_centroids must be positive");
+  DevIn<double> R, Cn;
+  AS_TRY(R.bind(ctx, rows, n_rows * dim));
+  AS_TRY(Cn.bind(ctx, centroids, n_centroids * dim));
+  DevOut<uint64_t> I;
+  DevOut<double> D;
+  AS_TRY(I.bind(ctx, out_idx, n_rows));
+  AS_TRY(D.bind(ctx, out_dist2, n_rows));
+  AS_TRY(nearest_centroids(ctx, R.p, n_rows, dim, Cn.p, n_centroids, I.p, D.p));
+  AS_TRY(I.finish(ctx));
+  AS_TRY(D.finish(ctx));
+  return AS_OK;
+}
+
 // ---- row-sharded form of the symmetric threshold join (see include/arrowspace_hip.h) ----------------
 static int join_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, uint64_t row_begin, uint64_t row_count,
                      const as_graph_params *params) {

@@ -371,6 +371,9 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d); 
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);
 uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded);
+// batch nearest_centroid (src/clustering.rs:913-928), centroids.hip
+int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const double *cents, uint64_t n_cents,
+                      uint64_t *out_idx, double *out_d2);
 
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,
                        uint32_t K, const as_graph_params *gp, as_csr **out);

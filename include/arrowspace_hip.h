@@ -121,6 +121,15 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
                   uint64_t row_begin, uint64_t row_count, const as_graph_params *params,
                   uint64_t *nbr_idx, double *nbr_dist);
 
+/* ---- clustering pre-stage: replaces the row loops around nearest_centroid, src/clustering.rs:913-928 (callers
+ * :590, :721, :764) ------------------------------------------------------------------------------------------
+ * For every row the index of its nearest centroid and the squared Euclidean distance, in the reference's
+ * arithmetic (sequential sum of (a - b)^2 over the features; strict '<' over the centroids in index order, so the
+ * first of equal minima wins; (0, +inf) for a row whose distances are all NaN).  rows: n_rows x dim, centroids:
+ * n_centroids x dim, both host or device; out_idx[n_rows], out_dist2[n_rows]. */
+int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t dim, const double *centroids,
+                         uint64_t n_centroids, uint64_t *out_idx, double *out_dist2);
+
 /* Row-sharded form of the same neighbour search (one process per GPU).  cos(i,j) =
  * cos(j,i): every unordered pair of 256-row tiles is contracted once, by the rank that owns one of the two
  * tiles, and serves both rows -- so the candidate lists of a rank's rows are partly produced on other ranks.

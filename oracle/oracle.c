@@ -591,3 +591,32 @@ int64_t aso_range_search(const double *lambdas, uint64_t n_items, double lambda_
   }
   return (int64_t)m;
 }
+
+/* src/clustering.rs:913-928 nearest_centroid, applied to a batch of rows (its callers, :590, :721, :764, walk the rows):
+ * squared Euclidean distance as a sequential sum of (a - b)^2, strict '<' (the first of equal minima wins),
+ * (0, +inf) when no distance compares below +inf (NaN rows). */
+int aso_nearest_centroids(const double *rows, uint64_t n, uint64_t d, const double *centroids, uint64_t n_centroids,
+                          uint64_t *idx_out, double *dist2_out) {
+  if (!rows || !centroids || !idx_out || !dist2_out) return -1;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < (int64_t)n; ++r) {
+    const double *x = rows + (uint64_t)r * d;
+    uint64_t best = 0;
+    double best_d2 = INFINITY;
+    for (uint64_t c = 0; c < n_centroids; ++c) {
+      const double *y = centroids + c * d;
+      double d2 = 0.0;
+      for (uint64_t k = 0; k < d; ++k) {
+        const double diff = x[k] - y[k];
+        d2 += diff * diff;
+      }
+      if (d2 < best_d2) {
+        best_d2 = d2;
+        best = c;
+      }
+    }
+    idx_out[r] = best;
+    dist2_out[r] = best_d2;
+  }
+  return 0;
+}

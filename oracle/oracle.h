@@ -112,6 +112,8 @@ int64_t aso_search_lambda_aware_hybrid(const double *items, const double *lambda
                                        double alpha, uint64_t *idx_out, double *score_out);
 
 /* core.rs:944-976 with a prepared query lambda; outputs must hold n_items entries */
+int aso_nearest_centroids(const double *rows, uint64_t n, uint64_t d, const double *centroids, uint64_t n_centroids,
+                          uint64_t *idx_out, double *dist2_out);
 int64_t aso_range_search(const double *lambdas, uint64_t n_items, double lambda_q, double eps,
                          uint64_t *idx_out, double *dist_out);
 

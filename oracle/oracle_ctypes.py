@@ -89,6 +89,8 @@ def lib():
         L.aso_search_lambda_aware.argtypes = [dp, dp, C.c_uint64, C.c_uint64, dp, C.c_double, C.c_uint64, C.c_double, up, dp]
         L.aso_search_lambda_aware_hybrid.restype = C.c_int64
         L.aso_search_lambda_aware_hybrid.argtypes = [dp, dp, C.c_uint64, C.c_uint64, dp, C.c_double, C.c_uint64, C.c_double, up, dp]
+        L.aso_nearest_centroids.restype = C.c_int
+        L.aso_nearest_centroids.argtypes = [dp, C.c_uint64, C.c_uint64, dp, C.c_uint64, up, dp]
         L.aso_range_search.restype = C.c_int64
         L.aso_range_search.argtypes = [dp, C.c_uint64, C.c_double, C.c_double, up, dp]
         L.aso_num_threads.restype = C.c_int
@@ -257,6 +259,19 @@ def range_search(lambdas, lambda_q, eps):
     dist = np.empty(max(len(lambdas), 1), dtype=np.float64)
     rc = lib().aso_range_search(_dp(lambdas), len(lambdas), lambda_q, eps, _up(idx), _dp(dist))
     return idx[:rc].copy(), dist[:rc].copy()
+
+
+def nearest_centroids(rows, centroids):
+    """src/clustering.rs:913-928 over a batch of rows: (index of the nearest centroid, squared distance)."""
+    rows = _f64(rows)
+    centroids = _f64(centroids)
+    n, d = rows.shape
+    assert centroids.shape[1] == d
+    idx = np.empty(max(n, 1), dtype=np.uint64)
+    d2 = np.empty(max(n, 1), dtype=np.float64)
+    rc = lib().aso_nearest_centroids(_dp(rows), n, d, _dp(centroids), centroids.shape[0], _up(idx), _dp(d2))
+    assert rc == 0
+    return idx[:n].copy(), d2[:n].copy()
 
 
 def num_threads():

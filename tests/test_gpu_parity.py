@@ -7,6 +7,11 @@ Every test here needs a real MI355X: run with `pytest -m gpu`.
 import numpy as np
 import pytest
 
+try:  # before the library: both bring a HIP runtime, and the tests that hand over device tensors need torch's to
+    import torch  # noqa: F401   be the one that initialises the device (whatever subset of tests is selected)
+except ImportError:
+    torch = None
+
 import arrowspace_amd as A
 from arrowspace_amd import _lib
 from oracle import oracle_ctypes as O
@@ -582,6 +587,40 @@ def test_laplacian_hub_rows_match_oracle(ctx):
     indptr = np.asarray(want[0])
     assert int(np.max(np.diff(indptr))) > 512          # a row that needs the ten-stage LDS network
     assert int(np.sum(np.diff(indptr) > 65)) >= 20     # and a population of rows in the workgroup form
+
+
+# ---- clustering pre-stage: batch nearest_centroid (src/clustering.rs:913-928) -----------------------
+
+@pytest.mark.parametrize("n,d,nc", [(5000, 128, 256), (777, 33, 70), (64, 2, 1), (1, 5, 3), (3000, 200, 129), (4097, 16, 64)])
+def test_nearest_centroids_match_oracle(ctx, n, d, nc):
+    """Index and squared distance bit-identical to the oracle: ragged row / centroid / feature counts, duplicated
+    centroids (the first of equal minima wins), a row equal to a centroid (distance 0), rows with NaN and inf."""
+    rng = np.random.default_rng(n + d)
+    X = rng.normal(size=(n, d))
+    Cn = rng.normal(size=(nc, d))
+    if nc >= 6:
+        Cn[5] = Cn[2]           # duplicated centroid
+        Cn[nc - 1] = Cn[0]
+    if n >= 10:
+        X[3] = Cn[min(2, nc - 1)]   # a row that IS a centroid
+        X[7, 0] = NAN               # every distance NaN -> (0, +inf)
+        X[8, d - 1] = INF
+    idx, d2 = A.nearest_centroids(X, Cn)
+    oi, od = O.nearest_centroids(X, Cn)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2, od, equal_nan=True)
+    if n >= 10:
+        assert idx[7] == 0 and d2[7] == INF
+
+
+def test_nearest_centroids_device_inputs(ctx):
+    import torch
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(2000, 128))
+    Cn = rng.normal(size=(100, 128))
+    idx, d2 = A.nearest_centroids(torch.from_numpy(X).cuda(), torch.from_numpy(Cn).cuda())
+    oi, od = O.nearest_centroids(X, Cn)
+    assert np.array_equal(np.asarray(idx), oi) and np.array_equal(np.asarray(d2), od)
 
 
 # ---- threshold scan of the search (stage 0 of K9, csrc/mfma_join_bf16.hip MODE 2) ---------------
