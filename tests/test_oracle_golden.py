@@ -343,3 +343,27 @@ def test_config1_plumbing_empty_graph():
     assert lq == 0.0
     with pytest.raises(O.OracleError):
         O.search_lambda_aware(X, lam, X[0] * 1.02, lq, 3, 0.7)
+
+
+def test_nearest_centroids_restatement():
+    """src/clustering.rs:913-928 over a batch: sequential sum of squared differences, first of equal minima,
+    (0, +inf) for a row whose distances are all NaN -- against a literal numpy loop."""
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(200, 19))
+    Cn = rng.normal(size=(23, 19))
+    Cn[7] = Cn[3]
+    X[4] = Cn[3]
+    X[9, 2] = np.nan
+    idx, d2 = O.nearest_centroids(X, Cn)
+    for r in range(len(X)):
+        best, bi = np.inf, 0
+        for c in range(len(Cn)):
+            acc = 0.0
+            for k in range(X.shape[1]):
+                diff = X[r, k] - Cn[c, k]
+                acc += diff * diff
+            if acc < best:
+                best, bi = acc, c
+        assert idx[r] == bi and (d2[r] == best)
+    assert idx[4] == 3 and d2[4] == 0.0 and idx[9] == 0 and d2[9] == np.inf
+
