@@ -1,20 +1,26 @@
 // mfma_join_bf16.hip -- the symmetric threshold join (see mfma_join_f32.hip for the scheme and for what the
-// lists mean) contracted on the bf16 matrix pipe with split operands: x = hi + lo, three MFMAs per 16-wide k step
-// (lo*hi + hi*lo + hi*hi, v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate, so 16/3 of its throughput).
+// lists mean) contracted on the bf16 matrix pipe with split operands: x = hi + lo, and the product of two rows
+// taken as hi*hi' + lo*hi' + hi*lo' (v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate).
 //
 // Exactness does not depend on the precision of this pass: a pair is appended to row r's list when its
 // approximate cosine s reaches theta[r], so what is NOT in the list has s < theta[r] and therefore an exact cosine
 // below theta[r] + delta, delta = cos_delta_bf16x3(d) (mfma_common.cuh: split residual + dropped lo*lo + f32
 // accumulation); the exact f64 re-rank certifies a row only if its K-th neighbour is clear of that, everything
-// else falls through to the f32 / f64 / scan stages (mfma_drivers.hip).  The wider delta (1e-4 against 8e-6 at
-// dim 128) costs a few more uncertified rows, the contraction is 4-5x shorter.
+// else falls through to the second pass / f32 / f64 / scan stages (mfma_drivers.hip).
+//
+// Two phases per 32x32 block: the hi planes alone first (KS MFMAs); |s - s_hi| <= 3.915e-3 for unit rows, so a block
+// whose hi-only products all stay eps = 3.94e-3 below their thresholds cannot hold a pair the full product would
+// list, and its other 2 KS MFMAs are never issued (87 % of the blocks at 1 M x 128).  The rest run phase B (the two
+// cross terms on top of the same accumulator) and the exact test.  The three modes of the kernel: 0 = symmetric
+// join, 1 = one-sided (a gathered subset of the rows against everything: the second pass), 2 = one-sided with the
+// search score as the tested quantity (the threshold scan of the search).
 //
 // Geometry: 8 waves x 32 rows per workgroup (one 256-row super tile per work unit, the same cyclic half pattern
 // and column blocking as the f32 form), split A fragments of a wave in registers (8 VGPRs per k step), B tiles of
-// 128 rows (hi plane + lo plane, 64 KB at dim 128) through a 2-deep LDS-DMA ring, one barrier per tile.
-// The compare epilogue of a 32x32 block costs about as much vector issue as a quarter of its MFMAs, so it is
-// software-pipelined one block behind: the products of block b sit in one accumulator while block b + 1 is
-// contracted into the other, and the compares issue in the shadow of those MFMAs.
+// 128 rows (hi plane + lo plane, 64 KB at dim 128) through a 2-deep LDS-DMA ring, one barrier per tile.  What is
+// not an MFMA is arranged around the MFMA stream: hand-issued LDS fragment reads three k steps ahead, the coarse
+// test of a block behind the phase-A MFMAs of the next one, DMA pieces spread over the blocks, listed pairs through
+// a per-wave LDS queue (details at the block pipeline below; measurements in DESIGN.md section 4).
 #include <hip/hip_bf16.h>
 
 #include <type_traits>
