@@ -22,7 +22,7 @@ EXPORTS = [
     "as_laplacian_from_knn", "as_csr_n", "as_csr_nnz", "as_csr_export", "as_csr_import", "as_csr_free",
     "as_compute_taumode", "as_prepare_query_items", "as_select_tau", "as_index_create", "as_index_destroy",
     "as_index_nitems", "as_search_lambda_aware", "as_search_lambda_aware_hybrid", "as_range_search",
-    "as_nearest_centroids",
+    "as_nearest_centroids", "as_knn_join_pack", "as_knn_join_unpack",
 ]
 
 
@@ -90,6 +90,8 @@ def load():
         "as_search_lambda_aware_hybrid": (i32, [vp, vp, vp, vp, u64, u64, dbl, u64, vp, vp]),
         "as_range_search": (i32, [vp, vp, dbl, dbl, u64, vp, vp, u64, C.POINTER(u64)]),
         "as_nearest_centroids": (i32, [vp, vp, u64, u64, vp, u64, vp, vp]),
+        "as_knn_join_pack": (i32, [vp, vp, vp, u64, C.c_uint32, vp, vp]),
+        "as_knn_join_unpack": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

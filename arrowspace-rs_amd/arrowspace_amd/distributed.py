@@ -77,6 +77,24 @@ class HipOps:
                                                       ptr(theta_all), cap, ptr(cnt), ptr(cand)))
         return cnt, cand
 
+    def join_pack(self, cnt, cand):
+        """Used slots of (cnt, cand) side by side + row offsets in slots (as_knn_join_pack)."""
+        n, cap = int(cand.shape[0]), int(cand.shape[1])
+        offsets = torch.empty(n + 1, dtype=torch.int64, device=cand.device)
+        packed = torch.empty(n * cap, dtype=torch.int32, device=cand.device)
+        A._adopt_torch_stream(self.ctx)
+        self.ctx.check(self.ctx.lib.as_knn_join_pack(self.ctx.h, ptr(cnt), ptr(cand), n, cap, ptr(offsets), ptr(packed)))
+        return offsets, packed
+
+    def join_unpack(self, cnt_src, packed, cap):
+        """cnt_src [n_src, rows]; packed: the used slots of those n_src x rows lists in that order -> [n_src, rows, cap]."""
+        n_src, rows = int(cnt_src.shape[0]), int(cnt_src.shape[1])
+        cand_src = torch.empty((n_src, rows, cap), dtype=torch.int32, device=cnt_src.device)
+        A._adopt_torch_stream(self.ctx)
+        self.ctx.check(self.ctx.lib.as_knn_join_unpack(self.ctx.h, ptr(cnt_src.contiguous()), ptr(packed.contiguous()),
+                                                       n_src * rows, cap, ptr(cand_src)))
+        return cand_src
+
     def join_finish(self, X_full, row_begin, row_count, gp, theta_all, cnt_src, cand_src):
         import ctypes as C
         n, d = X_full.shape
@@ -192,6 +210,34 @@ def exchange_row_blocks(t, sizes):
     return out.view((world, mine) + tail)
 
 
+def exchange_packed(packed, row_offsets, sizes):
+    """Compact form of the list exchange: `packed` = the used slots (2 words each) of all n rows in row order,
+    row_offsets [n + 1] in slots.  Every rank receives, source by source, the slots of its own rows
+    (all-to-all with per-pair sizes; RCCL over xGMI on the GPU box).  Returns one int32 tensor."""
+    rank, world = _world()
+    starts = [sum(sizes[:r]) for r in range(world)]
+    bounds = row_offsets[torch.tensor(starts + [starts[-1] + sizes[-1]], device=row_offsets.device)].cpu().tolist()
+    send = [2 * (bounds[g + 1] - bounds[g]) for g in range(world)]           # words per destination
+    if not _collectives_on(world):
+        return packed[2 * bounds[rank]: 2 * bounds[rank + 1]]
+    if _host_staged():  # gloo (tests): everything through the host, keep what is addressed to this rank
+        mine = packed[: 2 * bounds[world]].cpu().contiguous()
+        objs = [None] * world
+        dist.all_gather_object(objs, (send, mine))
+        parts = []
+        for s_sizes, s_data in objs:
+            lo = sum(s_sizes[:rank])
+            parts.append(s_data[lo: lo + s_sizes[rank]])
+        return torch.cat(parts).to(packed.device)
+    send_t = torch.tensor(send, dtype=torch.int64, device=packed.device)
+    recv_t = torch.empty(world, dtype=torch.int64, device=packed.device)
+    dist.all_to_all_single(recv_t, send_t)
+    recv = [int(v) for v in recv_t.cpu().tolist()]
+    out = torch.empty(sum(recv), dtype=packed.dtype, device=packed.device)
+    dist.all_to_all_single(out, packed[: 2 * bounds[world]].contiguous(), output_split_sizes=recv, input_split_sizes=send)
+    return out
+
+
 class ShardedArrowSpace:
     """The row-sharded counterpart of (ArrowSpace, GraphLaplacian) for one rank."""
 
@@ -219,7 +265,13 @@ class ShardedArrowSpace:
             theta_all = all_gather_rows(theta.reshape(-1, 1), self.sizes).reshape(-1).contiguous()
             cnt, cand = self.ops.join_pairs(X_full, self.lo, rows_here, self.gp, theta_all)
             cnt_src = exchange_row_blocks(cnt, self.sizes)                # RCCL all-to-all
-            cand_src = exchange_row_blocks(cand, self.sizes)
+            if hasattr(self.ops, "join_pack"):
+                # the lists are dense arrays with a few slots used per (row, foreign rank): only those cross the links
+                offsets, packed = self.ops.join_pack(cnt, cand)
+                recv = exchange_packed(packed, offsets, self.sizes)
+                cand_src = self.ops.join_unpack(cnt_src, recv, int(cand.shape[1]))
+            else:
+                cand_src = exchange_row_blocks(cand, self.sizes)
             idx, dst = self.ops.join_finish(X_full, self.lo, rows_here, self.gp, theta_all, cnt_src, cand_src)
         else:
             idx, dst = self.ops.knn_rows(X_full, self.lo, rows_here, self.gp)

@@ -373,6 +373,66 @@ int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_
                         (uint32_t)row_count, theta_all, cap / 2, cnt, cand, ctx->join.packed, ctx->join.packed16);
 }
 
+// ---- compact form of the candidate lists for the exchange between ranks --------------------------
+// The lists are dense arrays (cap words per row) with a handful of slots used per (row, foreign rank); what crosses
+// the links is row_offsets + the used slots only.
+__global__ void join_used_kernel(const uint32_t *__restrict__ cnt, uint64_t n, uint32_t slots, uint32_t *__restrict__ used) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) used[i] = min(cnt[i], slots);
+}
+// one wave per row; pack: dense -> packed, else packed -> dense
+__global__ __launch_bounds__(256) void join_repack_kernel(int pack, const uint32_t *__restrict__ cnt, uint64_t n, uint32_t slots,
+                                                          const uint64_t *__restrict__ offsets, const uint2 *__restrict__ src,
+                                                          uint2 *__restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (uint64_t)gridDim.x * 4) {
+    const uint32_t used = min(cnt[r], slots);
+    const uint64_t o = offsets[r];
+    for (uint32_t e = lane; e < used; e += 64) {
+      if (pack) dst[o + e] = src[r * slots + e];
+      else dst[r * slots + e] = src[o + e];
+    }
+  }
+}
+
+int as_knn_join_pack(as_ctx *ctx, const uint32_t *cnt, const uint32_t *cand, uint64_t n_rows, uint32_t cap,
+                     uint64_t *row_offsets, uint32_t *packed) {
+  AS_TRY(check_ctx(ctx));
+  if (!cnt || !cand || !row_offsets || !packed || cap < 2 || cap % 2 != 0) return fail(ctx, AS_ERR_ARG, "bad argument");
+  if (!is_device_ptr(cnt) || !is_device_ptr(cand) || !is_device_ptr(row_offsets) || !is_device_ptr(packed))
+    return fail(ctx, AS_ERR_ARG, "cnt / cand / row_offsets / packed must be device pointers");
+  if (n_rows == 0) return AS_OK;
+  DevBuf<uint32_t> used;
+  AS_TRY(used.alloc(ctx, n_rows));
+  hipLaunchKernelGGL(join_used_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, ctx->stream, cnt, n_rows, cap / 2, used.p);
+  AS_TRY(exclusive_scan_u32_u64(ctx, used.p, n_rows, row_offsets));
+  hipLaunchKernelGGL(join_repack_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n_rows, 4), 1u << 20)), dim3(256), 0,
+                     ctx->stream, 1, cnt, n_rows, cap / 2, row_offsets, (const uint2 *)cand, (uint2 *)packed);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `used` goes back to the workspace cache
+  return AS_OK;
+}
+
+int as_knn_join_unpack(as_ctx *ctx, const uint32_t *cnt, const uint32_t *packed, uint64_t n_rows, uint32_t cap,
+                       uint32_t *cand_out) {
+  AS_TRY(check_ctx(ctx));
+  if (!cnt || !packed || !cand_out || cap < 2 || cap % 2 != 0) return fail(ctx, AS_ERR_ARG, "bad argument");
+  if (!is_device_ptr(cnt) || !is_device_ptr(packed) || !is_device_ptr(cand_out))
+    return fail(ctx, AS_ERR_ARG, "cnt / packed / cand_out must be device pointers");
+  if (n_rows == 0) return AS_OK;
+  DevBuf<uint32_t> used;
+  DevBuf<uint64_t> offsets;
+  AS_TRY(used.alloc(ctx, n_rows));
+  AS_TRY(offsets.alloc(ctx, n_rows + 1));
+  hipLaunchKernelGGL(join_used_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, ctx->stream, cnt, n_rows, cap / 2, used.p);
+  AS_TRY(exclusive_scan_u32_u64(ctx, used.p, n_rows, offsets.p));
+  hipLaunchKernelGGL(join_repack_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n_rows, 4), 1u << 20)), dim3(256), 0,
+                     ctx->stream, 0, cnt, n_rows, cap / 2, offsets.p, (const uint2 *)packed, (uint2 *)cand_out);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
 int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
                        uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t n_src,
                        uint32_t cap, const uint32_t *cnt_src, const uint32_t *cand_src, uint64_t *nbr_idx,

@@ -47,8 +47,8 @@ struct as_ctx {
   int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
   int64_t opt_knn_join = 1;       // item graph over the whole matrix: symmetric threshold join (mfma_join_f32.hip)
   // Thresholds of the join: the m-th best product of every row with a 1-in-N sample of the rows, and the list slots per
-  // row.  0 = automatic: 32 / 4 / 512 when one call joins the whole matrix, 12 / 6 / 192 for the sharded sequence
-  // (as_knn_join_*), whose lists cross the links between the GPUs.  1 M x 128 on one GPU, theta + join + second pass +
+  // row.  0 = automatic: 32 / 4 / 512 (also for the sharded sequence as_knn_join_*: its lists cross the links between
+  // the GPUs in compact form, as_knn_join_pack).  1 M x 128 on one GPU, theta + join + second pass +
   // re-rank: 12/6/192 387 ms, 16/5/256 378, 24/4/384 374, 32/4/512 370, 40/4/640 395 (the second pass starts to
   // overflow), 48/4/768 395; a sparser sample costs candidates (74 -> 132 per row), which are cheap now that the
   // re-rank prunes by the stored scores before it fetches anything.

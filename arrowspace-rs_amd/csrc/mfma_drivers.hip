@@ -648,8 +648,9 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
                         bool sharded) {
   if (has_theta2) *has_theta2 = false;
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
-  const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : (sharded ? 6 : 4);
-  const int64_t sample_opt = ctx->opt_join_sample > 0 ? ctx->opt_join_sample : (sharded ? 12 : 32);
+  (void)sharded;  // the lists cross the links in compact form (as_knn_join_pack), so both forms take the sparse sample
+  const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
+  const int64_t sample_opt = ctx->opt_join_sample > 0 ? ctx->opt_join_sample : 32;
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 64));
   const uint32_t a_tiles = (row_count + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u;
   // sample size: whole pairs of 128-row tiles (the bf16 pass bins the sample by tile parity and has no tail
@@ -776,7 +777,8 @@ void join_session_close(as_ctx *ctx) {
 }
 
 uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
-  const int64_t cap_opt = ctx->opt_join_cap > 0 ? ctx->opt_join_cap : (sharded ? 192 : 512);
+  (void)sharded;
+  const int64_t cap_opt = ctx->opt_join_cap > 0 ? ctx->opt_join_cap : 512;
   return (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(cap_opt, 1024));
 }
 

@@ -88,7 +88,7 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "join_pipe"                 16 = split-bf16 contraction (dim <= 128, default), 32 = f32 MFMA
  *   "join_min_rows"             smallest n for the join and for the search scan (default 32768)
  *   "join_sample", "join_rank", "join_cap", "join_block"   threshold sample 1-in-N, order statistic,
- *                               list slots per row, column super tiles per work unit
+ *                               list slots per row (0 = automatic: 32 / 4 / 512), column super tiles per work unit
  *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
  *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
  *   "debug"                     diagnostics only (outputs may be undefined) */
@@ -157,6 +157,16 @@ uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params);
 int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
                       uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t cap,
                       uint32_t *cnt, uint32_t *cand);
+/* The exchange between steps 2 and 3 in compact form (optional: the dense arrays work too).  as_knn_join_pack: the
+ * used slots of rows [0, n_rows) of (cnt, cand) written side by side into packed (capacity n_rows x cap words),
+ * row_offsets[n_rows + 1] = exclusive scan of min(cnt, cap / 2) in SLOTS (2 words each) -- the owner g of a row range
+ * gets packed[2 row_offsets[lo_g] .. 2 row_offsets[hi_g]) and cnt[lo_g .. hi_g).  as_knn_join_unpack: the inverse on
+ * the receiving side, for n_rows = n_src x row_count rows in source-major order: cand_out as as_knn_join_finish takes
+ * it (only the used slots are written).  Device pointers. */
+int as_knn_join_pack(as_ctx *ctx, const uint32_t *cnt, const uint32_t *cand, uint64_t n_rows, uint32_t cap,
+                     uint64_t *row_offsets, uint32_t *packed);
+int as_knn_join_unpack(as_ctx *ctx, const uint32_t *cnt, const uint32_t *packed, uint64_t n_rows, uint32_t cap,
+                       uint32_t *cand_out);
 int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
                        uint64_t row_count, const as_graph_params *params, const float *theta_all, uint32_t n_src,
                        uint32_t cap, const uint32_t *cnt_src, const uint32_t *cand_src, uint64_t *nbr_idx,
