@@ -750,11 +750,12 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
   void *p = nullptr;
   AS_TRY(ws_alloc(ctx, sizeof(double) * n, &p, &js.norms_cap));
   js.norms = (double *)p;
-  AS_TRY(ws_alloc(ctx, sizeof(float) * packed_elems(b_alloc, (uint32_t)d), &p, &js.packed_cap));
-  js.packed = (float *)p;
   AS_TRY(row_norms(ctx, rows, n, d, js.norms));
-  AS_TRY(pack_f32(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed, b_alloc));
-  if (join_on_bf16(ctx, (uint32_t)d)) {
+  if (!join_on_bf16(ctx, (uint32_t)d)) {  // the f32 image: only the f32 pipe needs it up front (a later f32 stage packs its own)
+    AS_TRY(ws_alloc(ctx, sizeof(float) * packed_elems(b_alloc, (uint32_t)d), &p, &js.packed_cap));
+    js.packed = (float *)p;
+    AS_TRY(pack_f32(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed, b_alloc));
+  } else {
     AS_TRY(ws_alloc(ctx, packed_vecs_bf16(b_alloc, (uint32_t)d) * 16, &p, &js.packed16_cap));
     js.packed16 = p;
     AS_TRY(pack_bf16(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed16, b_alloc));
@@ -765,7 +766,8 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
   return AS_OK;
 }
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
-  return ctx->join.rows == rows && ctx->join.n == n && ctx->join.d == d && ctx->join.norms && ctx->join.packed;
+  return ctx->join.rows == rows && ctx->join.n == n && ctx->join.d == d && ctx->join.norms &&
+         (ctx->join.packed || ctx->join.packed16);
 }
 void join_session_close(as_ctx *ctx) {
   auto &js = ctx->join;
