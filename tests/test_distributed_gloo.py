@@ -130,6 +130,50 @@ def test_sharded_build_and_search_match_single_process(tmp_path, n, k):
             assert np.array_equal(r["sc"][j][: len(oi)], osc)
 
 
+def _pack_reference(cnt, cand, slots):
+    """What as_knn_join_pack produces, in numpy: used slots side by side, offsets in slots."""
+    used = np.minimum(cnt, slots)
+    offsets = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
+    packed = np.concatenate([cand[r, : 2 * used[r]] for r in range(len(cnt))] + [np.zeros(0, dtype=np.int32)])
+    return offsets, packed.astype(np.int32)
+
+
+def _exchange_worker(rank, world, port, n, slots, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [D.shard_range(n, r, world)[1] - D.shard_range(n, r, world)[0] for r in range(world)]
+        rng = np.random.default_rng(100 + rank)                       # every rank has its own lists for ALL rows
+        cnt = rng.integers(0, slots + 3, size=n).astype(np.int32)     # some rows over capacity
+        cand = rng.integers(0, 1 << 30, size=(n, 2 * slots)).astype(np.int32)
+        offsets, packed = _pack_reference(cnt, cand, slots)
+        recv = D.exchange_packed(torch.from_numpy(packed), torch.from_numpy(offsets), sizes)
+        cnt_src = D.exchange_row_blocks(torch.from_numpy(cnt), sizes)
+        np.savez(os.path.join(out_dir, "x%d.npz" % rank), recv=recv.numpy(), cnt_src=cnt_src.numpy(), cnt=cnt, cand=cand)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(700, 2), (1300, 3)])
+def test_compact_list_exchange(tmp_path, n, world):
+    """The candidate lists of the sharded join cross the links as (counts, used slots): every rank must receive,
+    source by source and row by row, exactly the used slots of its own rows."""
+    slots = 6
+    port = _free_port()
+    mp.spawn(_exchange_worker, args=(world, port, n, slots, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / ("x%d.npz" % r)) for r in range(world)]
+    for g in range(world):
+        lo, hi = D.shard_range(n, g, world)
+        want, want_cnt = [], []
+        for s in range(world):
+            cnt, cand = outs[s]["cnt"], outs[s]["cand"]
+            want_cnt.append(cnt[lo:hi])
+            for r in range(lo, hi):
+                want.append(cand[r, : 2 * min(int(cnt[r]), slots)])
+        assert np.array_equal(outs[g]["cnt_src"], np.stack(want_cnt))
+        assert np.array_equal(outs[g]["recv"], np.concatenate(want + [np.zeros(0, dtype=np.int32)]))
+
+
 def test_merge_topk_prefers_lower_index_on_ties():
     gi = torch.tensor([[[0, 3]], [[130, 131]]])
     gs = torch.tensor([[[0.9, 0.5]], [[0.9, 0.5]]], dtype=torch.float64)
