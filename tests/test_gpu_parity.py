@@ -623,6 +623,28 @@ def test_nearest_centroids_device_inputs(ctx):
     assert np.array_equal(np.asarray(idx), oi) and np.array_equal(np.asarray(d2), od)
 
 
+def test_join_list_pack_unpack_round_trip(ctx):
+    """as_knn_join_pack / as_knn_join_unpack (the compact form in which candidate lists cross the links): used slots
+    side by side in row order, offsets in slots; rows over capacity contribute their first `slots` entries."""
+    import torch
+    from arrowspace_amd import distributed as D
+    ops = D.HipOps(ctx)
+    rng = np.random.default_rng(6)
+    n, slots = 5000, 12
+    cnt = rng.integers(0, slots + 4, size=n).astype(np.int32)
+    cnt[::97] = 0
+    cand = rng.integers(0, 1 << 30, size=(n, 2 * slots)).astype(np.int32)
+    offsets, packed = ops.join_pack(torch.from_numpy(cnt).cuda(), torch.from_numpy(cand).cuda())
+    used = np.minimum(cnt, slots)
+    want_off = np.concatenate([[0], np.cumsum(used)])
+    assert np.array_equal(offsets.cpu().numpy(), want_off)
+    want = np.concatenate([cand[r, : 2 * used[r]] for r in range(n)])
+    assert np.array_equal(packed.cpu().numpy()[: len(want)], want)
+    back = ops.join_unpack(torch.from_numpy(cnt).cuda().reshape(1, n), packed[: len(want)], 2 * slots).cpu().numpy()[0]
+    for r in range(0, n, 37):
+        assert np.array_equal(back[r, : 2 * used[r]], cand[r, : 2 * used[r]])
+
+
 # ---- threshold scan of the search (stage 0 of K9, csrc/mfma_join_bf16.hip MODE 2) ---------------
 
 @pytest.fixture
