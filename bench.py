@@ -208,6 +208,11 @@ def main():
                         "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                         "avg_launch_ms": msb / lb, "launches": lb, "executed_flops_per_launch": executed,
                         "blocks_32x32": blocks, "blocks_contracted_in_full": full,
+                        "note": "two-phase blocks: the hi planes of every 32x32 block, the cross terms only where a product comes "
+                                "within eps of a threshold, so most of the three-term MFMA work is never issued and the kernel is "
+                                "bound by what surrounds the MFMAs (LDS-DMA issue, tile barriers, the coarse test: DESIGN.md section 4, "
+                                "profiles/r01i_pmc_clock.txt); the three-term form ran at 52 % of this peak, within 8 % of the "
+                                "power-limited rate, and took 292 ms",
                         "three_term_flops_of_the_visited_blocks": 3 * 2.0 * pairs * 256 * 256 * d_pad,
                         "three_term_equivalent_TFLOPs": 3 * 2.0 * pairs * 256 * 256 * d_pad / (msb / lb * 1e-3) / 1e12,
                         "algorithmic_flops_per_launch": flops_per_launch,
