@@ -23,11 +23,11 @@ I64_NONE = -1  # UINT64_MAX seen through int64
 
 
 def shard_range(n, rank, world):
-    """Contiguous row range of `rank`; shard starts are multiples of 256 (the row tile of the MFMA
-    passes: every rank's A side reads the shared packed image in place, and the tile pairs of the
-    symmetric join are owned by whole 256-row tiles)."""
+    """Contiguous row range of `rank`; shard starts are multiples of 512 (the row super tile of the
+    symmetric join: every rank's A side reads the shared packed image in place, and the tile pairs
+    of the join are owned by whole 512-row super tiles)."""
     per = (n + world - 1) // world
-    per = (per + 255) // 256 * 256
+    per = (per + 511) // 512 * 512
     lo = min(n, rank * per)
     hi = min(n, lo + per)
     return lo, hi
@@ -73,6 +73,7 @@ class HipOps:
         cap = int(self.ctx.lib.as_knn_join_capacity(self.ctx.h, C.byref(c)))
         cnt = torch.empty(n, dtype=torch.int32, device=X_full.device)
         cand = torch.empty((n, cap), dtype=torch.int32, device=X_full.device)
+        A._adopt_torch_stream(self.ctx)
         self.ctx.check(self.ctx.lib.as_knn_join_pairs(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
                                                       ptr(theta_all), cap, ptr(cnt), ptr(cand)))
         return cnt, cand
@@ -90,9 +91,10 @@ class HipOps:
         """cnt_src [n_src, rows]; packed: the used slots of those n_src x rows lists in that order -> [n_src, rows, cap]."""
         n_src, rows = int(cnt_src.shape[0]), int(cnt_src.shape[1])
         cand_src = torch.empty((n_src, rows, cap), dtype=torch.int32, device=cnt_src.device)
+        cnt_c, packed_c = cnt_src.contiguous(), packed.contiguous()  # named: they must outlive the call
         A._adopt_torch_stream(self.ctx)
-        self.ctx.check(self.ctx.lib.as_knn_join_unpack(self.ctx.h, ptr(cnt_src.contiguous()), ptr(packed.contiguous()),
-                                                       n_src * rows, cap, ptr(cand_src)))
+        self.ctx.check(self.ctx.lib.as_knn_join_unpack(self.ctx.h, ptr(cnt_c), ptr(packed_c), n_src * rows, cap,
+                                                       ptr(cand_src)))
         return cand_src
 
     def join_finish(self, X_full, row_begin, row_count, gp, theta_all, cnt_src, cand_src):
@@ -103,9 +105,11 @@ class HipOps:
         idx = torch.empty((row_count, K), dtype=torch.int64, device=X_full.device)
         dst = torch.empty((row_count, K), dtype=torch.float64, device=X_full.device)
         c = gp.to_c()
+        cnt_c, cand_c = cnt_src.contiguous(), cand_src.contiguous()  # named: they must outlive the call
+        A._adopt_torch_stream(self.ctx)
         self.ctx.check(self.ctx.lib.as_knn_join_finish(self.ctx.h, ptr(X_full), n, d, row_begin, row_count, C.byref(c),
-                                                       ptr(theta_all), n_src, cap, ptr(cnt_src.contiguous()),
-                                                       ptr(cand_src.contiguous()), ptr(idx), ptr(dst)))
+                                                       ptr(theta_all), n_src, cap, ptr(cnt_c), ptr(cand_c), ptr(idx),
+                                                       ptr(dst)))
         return idx, dst
 
     def laplacian_from_knn(self, idx, dist_, gp):

@@ -84,3 +84,57 @@ def mixture_at(indices, d, seed=42, n_clusters=256, rank=8, noise=0.3):
 def query_indices(n_total, nq, seed=42):
     u = _uniform(seed * 16 + 5, np.arange(nq, dtype=np.uint64))
     return np.minimum((u * n_total).astype(np.int64), n_total - 1)
+
+
+# ---- the same generator on the device (torch) ------------------------------------------------------
+# numpy takes ~35 s for 1 M x 128 rows; the full-size parity tests and bench.py need 1 M x 768 and 4 M x 128.
+# Same counter-based scheme (SplitMix64 on int64 with wrap-around arithmetic + Box-Muller), evaluated by torch
+# on the GPU.  log / cos / sqrt come from a different math library than numpy's, so the rows agree with
+# `mixture` only to rounding; whoever needs the host copy (the oracle) takes it from the tensor.
+
+def _i64(c):
+    c = int(c) & 0xFFFFFFFFFFFFFFFF
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lsr_t(z, s):
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def _splitmix64_t(x):
+    z = x + _i64(_GOLD)
+    z = (z ^ _lsr_t(z, 30)) * _i64(_M1)
+    z = (z ^ _lsr_t(z, 27)) * _i64(_M2)
+    return z ^ _lsr_t(z, 31)
+
+
+def _uniform_t(stream, counter):
+    import torch
+    with np.errstate(over="ignore"):
+        key = int(_splitmix64(np.uint64(stream) * np.uint64(0xD1342543DE82EF95) + np.uint64(0x2545F4914F6CDD1D)))
+    bits = _splitmix64_t(counter ^ _i64(key))
+    return (_lsr_t(bits, 11).to(torch.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def gaussian_device(stream, start, count, device):
+    import torch
+    e = torch.arange(start, start + count, dtype=torch.int64, device=device)
+    u1 = _uniform_t(stream, e * 2)
+    u2 = _uniform_t(stream, e * 2 + 1)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)
+
+
+def mixture_device(n, d, device, seed=42, n_clusters=256, rank=8, noise=0.3, row_start=0, chunk=1 << 18):
+    """Rows [row_start, row_start + n) of the mixture as an f64 tensor on `device`, and the C x D centres (numpy)."""
+    import torch
+    cent = mixture_centres(d, seed, n_clusters, rank)
+    cent_t = torch.from_numpy(cent).to(device)
+    out = torch.empty((n, d), dtype=torch.float64, device=device)
+    scale = noise * np.sqrt(float(rank))
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        r0 = row_start + s
+        g = gaussian_device(seed * 16 + 2, r0 * d, m * d, device).reshape(m, d)
+        cid = torch.arange(r0, r0 + m, device=device) % n_clusters
+        out[s:s + m] = cent_t[cid] + scale * g
+    return out, cent

@@ -215,7 +215,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_cap") ctx->opt_join_cap = value;
   else if (n == "join_min_rows") ctx->opt_join_min_rows = value;
   else if (n == "join_bf16") ctx->opt_join_bf16 = value;
-  else if (n == "join_pipe") ctx->opt_join_pipe = value == 32 ? 32 : 16;
+  else if (n == "join_pipe") ctx->opt_join_pipe = (value == 32 || value == 48) ? value : 16;
   else if (n == "join_block") ctx->opt_join_block = value;
   else if (n == "search_scan") ctx->opt_search_scan = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
@@ -370,7 +370,8 @@ int as_knn_join_pairs(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_
   if (cap < 2 || cap % 2 != 0) return fail(ctx, AS_ERR_ARG, "cap must be a positive even number of words");
   if (!join_session_matches(ctx, rows, n_nodes, dim)) AS_TRY(join_session_open(ctx, rows, n_nodes, dim));
   return knn_join_pairs(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
-                        (uint32_t)row_count, theta_all, cap / 2, cnt, cand, ctx->join.packed, ctx->join.packed16);
+                        (uint32_t)row_count, theta_all, cap / 2, cnt, cand, ctx->join.packed, ctx->join.packed16,
+                        ctx->join.packedh);
 }
 
 // ---- compact form of the candidate lists for the exchange between ranks --------------------------

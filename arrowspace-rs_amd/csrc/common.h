@@ -58,7 +58,8 @@ struct as_ctx {
   int64_t opt_join_min_rows = 32768;
   int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128 on one device: 4 -> 304 ms, 8 .. 64 ->
                                   // 291-293: longer units amortise the unit prologue; devices differ by more than that)
-  int64_t opt_join_pipe = 16;     // contraction of the join: 16 = split bf16 (dim <= 128), 32 = f32 MFMA
+  int64_t opt_join_pipe = 16;     // contraction of the join: 16 = one f16 plane (dim <= 128; mfma_join_f16.hip), 48 = split bf16 in
+                                  // two phases (dim <= 128; mfma_join_bf16.hip), 32 = f32 MFMA
   int64_t opt_search_scan = 1;    // search: threshold scan on the bf16 pipe before the top-k passes (dim <= 128, alpha > 0)
   int64_t opt_search_scan_sample = 32;   // its score guess: the m-th best of a 1-in-N sample of the items
   int64_t opt_search_scan_rank = 3;
@@ -73,12 +74,14 @@ struct as_ctx {
     uint64_t n = 0, d = 0;
     double *norms = nullptr;
     float *packed = nullptr;
-    void *packed16 = nullptr;   // split-bf16 image of all rows (bf16 pipe of the join)
+    void *packed16 = nullptr;   // split-bf16 image of all rows (bf16 pipe of the join; the one-sided second pass)
+    void *packedh = nullptr;    // f16 image of all rows (f16 pipe of the join)
     float *theta2 = nullptr;    // second (looser) thresholds of the rows of the last as_knn_join_thresholds call
     uint64_t theta2_begin = 0, theta2_rows = 0;
     bool theta2_valid = false;
-    size_t norms_cap = 0, packed_cap = 0, packed16_cap = 0, theta2_cap = 0;
+    size_t norms_cap = 0, packed_cap = 0, packed16_cap = 0, packedh_cap = 0, theta2_cap = 0;
   } join;
+  double f16_err = -1.0;  // measured error of the f16 plane of the rows packed last (pack_f16_all), -1: none
   // stats of the last call
   std::map<std::string, int64_t> stats;
   // profiling
@@ -352,7 +355,7 @@ struct JoinSources {
   const uint32_t *cnt;    // n_src x row_count
   const uint32_t *cand;   // n_src x row_count x cap
   const float *theta2 = nullptr;    // looser thresholds of the rows of the range (by position), or nullptr
-  const void *packed16 = nullptr;   // split-bf16 image of all rows, or nullptr (both: second pass over uncertified rows)
+  const void *packed16 = nullptr;   // split-bf16 image of all rows, or nullptr (the second pass packs its own then)
 };
 // MFMA candidate pass + exact re-rank + certification + exact fall-back
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,
@@ -363,10 +366,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, u
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
                         uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr,
                         float *theta2_out = nullptr, bool *has_theta2 = nullptr, bool sharded = true);
-// packed16 = split-bf16 image of ALL rows when the caller already has it (bf16 pipe), else nullptr
+// packed16 / packedh = split-bf16 / f16 image of ALL rows when the caller already has the one its pipe needs, else nullptr
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed = nullptr, const void *packed16 = nullptr);
+                   const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr);
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

@@ -1,7 +1,7 @@
 // knn_exact.hip -- exact row norms and the exact neighbour scan (K1 + exact leg of K2).
 // Replaces the CosinePair queries of src/laplacian.rs:211,221,246 with the rule set of
 // SURVEY.md Appendix A/B (self excluded, (distance asc, index asc), cos := 0 on tiny norms).
-#include "scan_topk.cuh"
+#include "scan_topk.h"
 
 namespace asx {
 

@@ -1,4 +1,4 @@
-// mfma_common.cuh -- shared pieces of the MFMA candidate passes (f64 and f32) of K2 / K9.
+// mfma_common.h -- shared pieces of the MFMA candidate passes (f64 and f32) of K2 / K9.
 //
 // Scheme (exactness first), see DESIGN.md section 4:
 //   1. CANDIDATES  per row, a superset of the wanted top-K from an MFMA contraction over
@@ -9,7 +9,9 @@
 //      exact path.
 #pragma once
 
-#include "scan_topk.cuh"
+#include <cmath>
+
+#include "scan_topk.h"
 
 namespace asx {
 
@@ -104,6 +106,23 @@ inline double cos_delta_bf16x3(uint32_t d) {
   const double accum = (double)(3 * dp + 3 * ks + 2) * 1.1920928955078125e-07 * 1.02;
   // + the thresholds of the two-phase join blocks: held lowered by eps, eps added back for the exact test (two f32 roundings)
   return split + accum + 2.0 * 5.9604644775390625e-08 + 3e-7 + 1e-13;
+}
+
+
+// one f16 plane of the unit rows scaled by 2^7 (mfma_join_f16.hip): element error <= 2^-11 |x| + 2^-14 (the second term
+// covers a flushed subnormal), so  sum |e||x'| + |x||e'| + |e||e'|  <=  2 (2^-11 + 2^-14 sqrt(d_pad) / 128) (1 + 2^-10) in cosine
+// units (Cauchy-Schwarz over unit rows; the double rounding f64 -> f32 -> f16 of the packer is inside the 1 + 2^-10);
+// the f16 x f16 products are exact in f32; accumulation: d_pad products + the carried accumulator of every MFMA + the
+// threshold C = -theta 2^14 the sum starts from, |running sum| < 2^15 so 2^-8 per addition (a truncating adder allowed)
+// = 2^-22 in cosine units; one more rounding where the listed score is recovered as acc + theta.
+inline double cos_delta_f16_accum(uint32_t d) {
+  const uint32_t ks = (d + 15) / 16, dp = ks * 16;
+  return (double)(dp + ks + 4) * 0x1p-22 * 1.02 + 1e-7;
+}
+inline double cos_delta_f16(uint32_t d) {
+  const uint32_t ks = (d + 15) / 16, dp = ks * 16;
+  const double plane = 2.0 * (0x1p-11 + 0x1p-14 * std::sqrt((double)dp) / 128.0) * (1.0 + 0x1p-10);
+  return plane + cos_delta_f16_accum(d);
 }
 
 }  // namespace asx

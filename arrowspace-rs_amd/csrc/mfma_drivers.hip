@@ -1,7 +1,7 @@
 // mfma_drivers.hip -- staged drivers of the MFMA neighbour search (K2) and search scan (K9):
 // candidate pass (f32 MFMA, then f64 MFMA for what f32 cannot certify) -> exact re-rank ->
-// certification -> exact scan for the remainder.  See mfma_common.cuh / DESIGN.md section 4.
-#include "mfma_common.cuh"
+// certification -> exact scan for the remainder.  See mfma_common.h / DESIGN.md section 4.
+#include "mfma_common.h"
 
 namespace asx {
 
@@ -628,17 +628,37 @@ int search_thresholds_bf16(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d,
 uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
 int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
               uint32_t d, void *P, uint32_t tiles);
+int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
+uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
+uint32_t packed_tiles_f16(uint64_t n);
+int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
+             void *P, uint32_t tiles);
+int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of
 // the two where the bf16 pipe may have been used: every rank of a sharded build derives the same value)
-static bool join_on_bf16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 16 && d <= 128; }
+static bool join_on_f16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 16 && d <= 128; }
+static bool join_on_bf16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 48 && d <= 128; }
+// the one-sided second pass over what the join leaves open runs on the split-bf16 planes after either 16-bit join
+static bool second_pass_bf16(const as_ctx *ctx, uint32_t d) { return (ctx->opt_join_pipe == 16 || ctx->opt_join_pipe == 48) && d <= 128; }
+static double rect_delta(uint32_t d) { return std::max(cos_delta_bf16x3(d), cos_delta_f32(d)); }
+// f16 plane: with the measured plane error E of the rows (pack_f16_all) 2 E + E^2 replaces the worst-case plane term
 static double join_delta(const as_ctx *ctx, uint32_t d) {
-  return join_on_bf16(ctx, d) ? std::max(cos_delta_bf16x3(d), cos_delta_f32(d)) : cos_delta_f32(d);
+  if (join_on_f16(ctx, d)) {
+    const double worst = cos_delta_f16(d);
+    const double e = ctx->f16_err;
+    const double measured = e >= 0.0 ? 2.0 * e + e * e + cos_delta_f16_accum(d) : worst;
+    return std::max(std::min(worst, measured), rect_delta(d));
+  }
+  return join_on_bf16(ctx, d) ? rect_delta(d) : cos_delta_f32(d);
 }
 
+// shard starts are multiples of 512: the row super tile of the f16 join (256 for the other pipes)
 static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
   return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 &&
-         n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) && row_begin % 256 == 0;
+         n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) &&
+         row_begin % (join_on_f16(ctx, d) ? 512 : 256) == 0;
 }
 
 // theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
@@ -708,17 +728,25 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed, const void *packed16) {
+                   const float *packed, const void *packed16, const void *packedh) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
-  const uint32_t T2 = b_alloc / 2;
-  const uint32_t I_begin = row_begin / 256;
-  const uint32_t I_end = (uint32_t)(((uint64_t)row_begin + row_count + 255) / 256);
+  const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
+  const uint32_t super = f16 ? 512 : 256;
+  const uint32_t T2 = (n + super - 1) / super;
+  const uint32_t I_begin = row_begin / super;
+  const uint32_t I_end = (uint32_t)(((uint64_t)row_begin + row_count + super - 1) / super);
   DevBuf<float> P, theta;
   DevBuf<unsigned char> P16;
   DevBuf<uint32_t> unitc;
-  const bool bf16 = join_on_bf16(ctx, d);
-  if (bf16) {
+  if (f16) {
+    if (!packedh) {
+      const uint32_t tiles = packed_tiles_f16(n);
+      AS_TRY(P16.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
+      AS_TRY(pack_f16_all(ctx, rows, norms, n, d, P16.p, tiles));
+      packedh = P16.p;
+    }
+  } else if (bf16) {
     if (!packed16) {
       AS_TRY(P16.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16.p, b_alloc));
@@ -729,29 +757,44 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
     AS_TRY(pack_f32(ctx, rows, norms, nullptr, 0, n, d, P.p, b_alloc));
     packed = P.p;
   }
-  AS_TRY(theta.alloc(ctx, (size_t)T2 * 256));
-  hipLaunchKernelGGL(pad_theta_kernel, dim3(cdiv((uint64_t)T2 * 256, 256)), dim3(256), 0, ctx->stream, theta_all, n, T2 * 256,
+  AS_TRY(theta.alloc(ctx, (size_t)T2 * super));
+  hipLaunchKernelGGL(pad_theta_kernel, dim3(cdiv((uint64_t)T2 * super, 256)), dim3(256), 0, ctx->stream, theta_all, n, T2 * super,
                      theta.p);
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  if (bf16)
+  if (f16) {
+    AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16"));
+    ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_f16_blocks"];
+    ctx->stats["knn_join_pipe"] = 16;
+  } else if (bf16) {
     AS_TRY(join_bf16(ctx, packed16, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_bf16"));
-  else
+    ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_bf16_blocks"];
+    ctx->stats["knn_join_pipe"] = 48;
+  } else {
     AS_TRY(join_f32(ctx, packed, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f32"));
+    ctx->stats["knn_join_blocks"] = (int64_t)(I_end - I_begin) * 64;  // at least the diagonal super tiles
+    ctx->stats["knn_join_pipe"] = 32;
+  }
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
   join_session_close(ctx);
+  ctx->f16_err = -1.0;
   auto &js = ctx->join;
   const uint32_t b_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows), b_alloc = (b_tiles + 1) & ~1u;
   void *p = nullptr;
   AS_TRY(ws_alloc(ctx, sizeof(double) * n, &p, &js.norms_cap));
   js.norms = (double *)p;
   AS_TRY(row_norms(ctx, rows, n, d, js.norms));
-  if (!join_on_bf16(ctx, (uint32_t)d)) {  // the f32 image: only the f32 pipe needs it up front (a later f32 stage packs its own)
+  if (join_on_f16(ctx, (uint32_t)d)) {
+    const uint32_t tiles = packed_tiles_f16(n);
+    AS_TRY(ws_alloc(ctx, packed_vecs_f16(tiles, (uint32_t)d) * 16, &p, &js.packedh_cap));
+    js.packedh = p;
+    AS_TRY(pack_f16_all(ctx, rows, js.norms, n, (uint32_t)d, js.packedh, tiles));
+  } else if (!join_on_bf16(ctx, (uint32_t)d)) {  // the f32 image: only the f32 pipe needs it up front (a later f32 stage packs its own)
     AS_TRY(ws_alloc(ctx, sizeof(float) * packed_elems(b_alloc, (uint32_t)d), &p, &js.packed_cap));
     js.packed = (float *)p;
     AS_TRY(pack_f32(ctx, rows, js.norms, nullptr, 0, n, (uint32_t)d, js.packed, b_alloc));
@@ -767,13 +810,14 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
 }
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d) {
   return ctx->join.rows == rows && ctx->join.n == n && ctx->join.d == d && ctx->join.norms &&
-         (ctx->join.packed || ctx->join.packed16);
+         (ctx->join.packed || ctx->join.packed16 || ctx->join.packedh);
 }
 void join_session_close(as_ctx *ctx) {
   auto &js = ctx->join;
   if (js.norms) ws_free(ctx, js.norms, js.norms_cap);
   if (js.packed) ws_free(ctx, js.packed, js.packed_cap);
   if (js.packed16) ws_free(ctx, js.packed16, js.packed16_cap);
+  if (js.packedh) ws_free(ctx, js.packedh, js.packedh_cap);
   if (js.theta2) ws_free(ctx, js.theta2, js.theta2_cap);
   js = as_ctx::JoinSession{};
 }
@@ -856,6 +900,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   bool have_theta2 = false;
   if (use_join) {
     if (own_join) {
+      ctx->f16_err = -1.0;
       const uint32_t cap = knn_join_cap(ctx, K, false);
       AS_TRY(theta_own.alloc(ctx, n));
       AS_TRY(theta2_own.alloc(ctx, n));
@@ -866,7 +911,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       }
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
-      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p));
+      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, nullptr));
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
     }
@@ -997,6 +1042,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   }
   ctx->stats["knn_uncertified_rows"] = n_fail;
+  ctx->stats["knn_join_delta_e9"] = use_join ? (int64_t)(join_delta(ctx, d) * 1e9) : 0;
+  ctx->stats["knn_uncertified_rows_stage1a"] = 0;
   ctx->stats["knn_uncertified_rows_stage1b"] = 0;
   ctx->stats["knn_uncertified_rows_stage2"] = 0;
   ctx->stats["knn_cand_capacity"] = KC;
@@ -1080,8 +1127,15 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   // longer list) or because its K-th neighbour is not clear of the threshold (too high: the looser second threshold).
   // ~1 % of the rows; as a one-sided sweep of the split image this is a few ms, the f32 top-k pass over them 11-22.
   DevBuf<uint32_t> ids_r, pos_r;
-  if (use_join && js->theta2 && js->packed16 && join_on_bf16(ctx, d) && cur_n > 0 && cur_n <= n / 4) {
+  DevBuf<unsigned char> P16late;
+  if (use_join && js->theta2 && second_pass_bf16(ctx, d) && cur_n > 0 && cur_n <= n / 4) {
     const uint32_t nf = cur_n, cap2 = 1024;
+    const void *split_image = js->packed16;
+    if (!split_image) {  // the join ran on the f16 plane: the split-bf16 image of all rows is only built when rows are left
+      AS_TRY(P16late.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
+      AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16late.p, b_alloc));
+      split_image = P16late.p;
+    }
     const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad = b_al * kTileRows;
     DevBuf<unsigned char> PA;
     DevBuf<float> theta_a;
@@ -1101,17 +1155,17 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-    AS_TRY(join_bf16_rect(ctx, js->packed16, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
+    AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
                           "knn_mfma_join_bf16_second"));
     {
-      GraphBound bnd{join_delta(ctx, d), rectify};
+      GraphBound bnd{rect_delta(d), rectify};
       ProfScope ps(ctx, "knn_rerank");
       const size_t lds = (size_t)4 * (d + cap2) * sizeof(double) + (size_t)4 * cap2 * sizeof(uint32_t);
       AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
                          dim3(256), lds, ctx->stream, rows, rows, cur_ids, d, 0u, nf, theta_a.p, 1u, cnt_b.p, cand_b.p, cap2, cap2,
-                         K, force.p, pol, bnd, (ctx->opt_debug & 16) ? -1.0 : join_delta(ctx, d), rectify, ok.p, oi.p, failx.p,
+                         K, force.p, pol, bnd, (ctx->opt_debug & 16) ? -1.0 : rect_delta(d), rectify, ok.p, oi.p, failx.p,
                          fail_count.p, err.p);
       AS_HIP(ctx, hipGetLastError());
     }

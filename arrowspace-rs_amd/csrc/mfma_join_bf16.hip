@@ -4,7 +4,7 @@
 //
 // Exactness does not depend on the precision of this pass: a pair is appended to row r's list when its
 // approximate cosine s reaches theta[r], so what is NOT in the list has s < theta[r] and therefore an exact cosine
-// below theta[r] + delta, delta = cos_delta_bf16x3(d) (mfma_common.cuh: split residual + dropped lo*lo + f32
+// below theta[r] + delta, delta = cos_delta_bf16x3(d) (mfma_common.h: split residual + dropped lo*lo + f32
 // accumulation); the exact f64 re-rank certifies a row only if its K-th neighbour is clear of that, everything
 // else falls through to the second pass / f32 / f64 / scan stages (mfma_drivers.hip).
 //
@@ -25,7 +25,7 @@
 
 #include <type_traits>
 
-#include "mfma_common.cuh"
+#include "mfma_common.h"
 
 namespace asx {
 

@@ -1,0 +1,529 @@
+// mfma_join_f16.hip -- the symmetric threshold join (scheme and meaning of the lists: mfma_join_f32.hip) contracted
+// on the 16-bit matrix pipe from ONE f16 plane of the unit rows (v_mfma_f32_32x32x16_f16: the bf16 rate).
+//
+// Why f16 and why one plane.  A candidate pass only needs a rigorous bound between its product s and the exact
+// cosine: what is not in row r's list has s < theta[r], hence an exact cosine below theta[r] + delta, and the exact
+// f64 re-rank certifies a row only if its K-th neighbour is clear of that (mfma_drivers.hip).  bf16 keeps 8
+// significant bits: a single plane is good to 3.9e-3, too coarse to list by, so the bf16 form of this kernel carried
+// a second (lo) plane through LDS and a second MFMA phase for the blocks near a threshold.  f16 keeps 11 bits: unit
+// rows scaled by 2^7 (no element is subnormal unless it is below 5e-7 of the row's norm) give
+//     |s - cos| <= 2 * (2^-11 + 2^-14 sqrt(d_pad) / 128) + f32 accumulation  =  cos_delta_f16(d) ~ 1.02e-3 at d = 128,
+// which costs ~0.1 % more uncertified rows and a handful more row fetches in the re-rank than 1e-4 does -- and the
+// whole lo-plane machinery goes: half the bytes staged per tile, a third of the MFMAs on the blocks that listed
+// something, no second phase, 64 instead of 128 registers of A fragments per 64 rows.
+//
+// Geometry (chosen for bytes per flop: the bf16 form moved 32 B/clk/CU from L2 to LDS, half of what the path gives):
+// a workgroup = 8 waves x 64 rows = one 512-row super tile; B is staged 256 columns (64 KB at dim 128) at a time
+// through a 2-deep LDS-DMA ring, one barrier per stage; every LDS fragment read feeds two MFMAs (the wave's two 32-row
+// groups).  Per stage a wave issues 128 MFMAs, 64 ds_read_b128, 8 DMA pieces.
+//
+// Threshold test without per-element compares: the first MFMA of a block takes C = -theta_row (16 registers per row
+// group that stay put for the whole unit), so the block ends with acc = s - theta_row; "some product reaches its row's
+// threshold" is max(acc) >= 0 (8 v_max3), and the column side, s >= theta_col, is tested conservatively on the same
+// maximum as max(acc) >= min(0, theta_col - max_rows(theta_row)).  Blocks that pass (~13 %) run the exact element-wise
+// test and queue their pairs; listed scores are acc + theta_row.
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "mfma_common.h"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int kSuperH = 512;        // rows per super tile (four packed 128-row tiles)
+constexpr uint32_t kQueueH = 256;   // queued appends per wave (one accumulator register adds at most 128)
+constexpr float kOperandScale = 128.f;     // unit rows are stored times 2^7 ...
+constexpr float kProductScale = 16384.f;   // ... so products (and thresholds inside the kernel) carry 2^14
+
+// Packed f16 image: tiles of 128 rows; fragment (T, ks, s) = 64 lanes x 8 halves (16 B per lane):
+//   P[((T * KS + ks) * 4 + s) * 64 + l][j] = f16( 128 * unit(R)[128 T + 32 s + (l & 31)][16 ks + 8 (l >> 5) + j] )
+// = the A / B operand of v_mfma_f32_32x32x16_f16 as it stands.  Rows beyond n, columns beyond d and non-finite
+// quotients are 0 (a row with a non-finite norm is re-done exactly whatever its products say: flag_tiny_norm_rows_kernel).
+__global__ void pack_f16_kernel(const double *__restrict__ R, const double *__restrict__ norms,
+                                const uint32_t *__restrict__ row_ids, uint64_t row0, uint64_t n, uint32_t d, uint32_t KS,
+                                uint64_t total_frag_lanes, f16x8 *__restrict__ P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_frag_lanes) return;
+  const uint32_t l = g & 63;
+  const uint32_t s = (g >> 6) & 3;
+  const uint64_t tk = g >> 8;
+  const uint32_t ks = (uint32_t)(tk % KS);
+  const uint64_t T = tk / KS;
+  const uint64_t row = T * kTileRows + s * 32 + (l & 31);
+  const uint32_t k0 = ks * 16 + 8 * (l >> 5);
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+  if (row < n) {
+    const uint64_t src = row_ids ? row_ids[row] : row0 + row;
+    const double nr = norms[src];
+    if (nr > 0.0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < d) {
+          const float x = (float)(R[src * d + k0 + j] / nr) * kOperandScale;
+          v[j] = (x == x && __builtin_fabsf(x) <= 2.f * kOperandScale) ? (_Float16)x : (_Float16)0.0f;
+        }
+    }
+  }
+  P[g] = v;
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+
+// LDS fragment reads issued and waited for by hand (the compiler would wait each one out on the spot)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait1(f16x8 &x) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(PENDING));
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// thresholds inside the kernel: clamped to [-1.5, 1.5] (no product of unit rows is outside [-1.01, 1.01], so the
+// lists are the same and |C| stays below 2^15 for the accumulation bound), +inf beyond and for NaN; times 2^14
+__device__ __forceinline__ float thr_scaled(float t) {
+  if (!(t <= 1.5f)) return __builtin_inff();
+  return __builtin_fmaxf(t, -1.5f) * kProductScale;
+}
+
+__device__ __forceinline__ float max16(const v16f32 &a) {
+  float m = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[3]), a[4]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[5]), a[6]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[7]), a[8]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[9]), a[10]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[11]), a[12]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[13]), a[14]);
+  return __builtin_fmaxf(m, a[15]);
+}
+
+__device__ __forceinline__ void append16(uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand, uint32_t cap, uint32_t target,
+                                         uint32_t other, float score) {
+  const uint32_t pos = atomicAdd(cnt + target, 1u);
+  if (pos < cap) reinterpret_cast<uint2 *>(cand)[(size_t)target * cap + pos] = make_uint2(other, __float_as_uint(score));
+}
+
+// P = f16 image of ALL rows, T2 super tiles of 512 rows (zero padded).  theta: T2 * 512 thresholds, +inf on padding rows.
+// Work units (column block of W super tiles, row super tile I) are dealt from an atomic counter, column block by
+// column block, so that the workgroups running together stream the same columns.  Super tile I meets the column
+// super tiles I .. I + (T2 - 1) / 2 (mod T2), the antipodal one only from the smaller index: every unordered pair of
+// super tiles once, the same work for every I.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, uint32_t T2, uint32_t I_begin,
+                                                               uint32_t I_count, uint32_t W, uint32_t n,
+                                                               const float *__restrict__ theta, uint32_t cap,
+                                                               uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
+                                                               uint32_t *__restrict__ unit_counter, int dbg,
+                                                               unsigned long long *__restrict__ stamps) {
+  constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
+  constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
+  constexpr int kBlocks = 8;                 // 32-column blocks per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS: [2 stages of B][2 x 256 column thresholds][8 queues of (owner, other)][8 queues of scores][8 x 4 listing slots]
+  f16x8 *bufB = reinterpret_cast<f16x8 *>(smem);
+  float *colthr = reinterpret_cast<float *>(smem + (size_t)2 * kStageVecs * 16);
+  __shared__ uint32_t s_unit;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5, lc = lane & 31;
+  // passing pairs go to a per-wave LDS queue as (list owner, other row, score) and are appended 64 at a time: an append is
+  // a returning atomic (~2 us before its store can go out) and, taken one by one, makes its wave late at the barrier
+  constexpr size_t kQueueBase = (size_t)2 * kStageVecs * 16 + 2 * 256 * sizeof(float);
+  uint2 *queue = reinterpret_cast<uint2 *>(smem + kQueueBase) + (size_t)wv * kQueueH;
+  float *queue_s = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * sizeof(uint2)) + (size_t)wv * kQueueH;
+  // listing scratch of the wave: 4 slots of (16 acc, 16 acc + theta_row, lane, theta_col, 2 unused) floats
+  constexpr int kSlotFloats = 36;
+  float *ex = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + (size_t)wv * 4 * kSlotFloats;
+  uint32_t qn = 0;  // wave-uniform
+  auto lanes_below = [&](unsigned long long m) -> uint32_t {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
+  auto flush_queue = [&]() {
+    wave_sync();
+    for (uint32_t base = 0; base < qn; base += 64) {
+      const uint32_t e = base + lane;
+      if (e < qn) {
+        const uint2 v = queue[e];
+        append16(cnt, cand, cap, v.x, v.y, queue_s[e]);
+      }
+    }
+    wave_sync();
+    qn = 0;
+  };
+  const uint32_t n_norm = (T2 - 1) / 2;
+  const uint32_t n_cblocks = (T2 + W - 1) / W;
+  const uint32_t total_units = n_cblocks * I_count;
+
+  // DMA pieces (1 KB each) of the stage that starts at packed tile `tile0`: KS per wave (KS <= 8), plus the thresholds of
+  // its 256 columns (one piece, wave 7).  part < 0: all of them, else the pieces that go with block `part` of the stage before.
+  auto stage = [&](uint32_t tile0, int buf, int part) {
+    const f16x8 *src = P + (size_t)tile0 * kTileVecs + lane;
+    f16x8 *dst = bufB + (size_t)buf * kStageVecs;
+    if (part < 0) {
+#pragma unroll
+      for (int p = 0; p < KS; ++p)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + p) * 64), (lds_void *)(dst + (wv * KS + p) * 64), 16, 0, 0);
+    } else if constexpr (KS % kBlocks == 0) {  // KS / 8 pieces with every block
+#pragma unroll
+      for (int j = 0; j < KS / kBlocks; ++j) {
+        const int p = part * (KS / kBlocks) + j;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + p) * 64), (lds_void *)(dst + (wv * KS + p) * 64), 16, 0, 0);
+      }
+    } else if (part < KS) {  // one piece with each of the first KS blocks
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + part) * 64), (lds_void *)(dst + (wv * KS + part) * 64), 16, 0, 0);
+    }
+    if (wv == 7 && part <= 0)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)tile0 * kTileRows + lane * 4), (lds_void *)(colthr + buf * 256),
+                                       16, 0, 0);
+  };
+
+  // diagnostics (as_ctx_set_option("debug", bits)): 2 no listing, 4 no DMA of the next stage, 8 cycle stamps, 128 no test
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  unsigned long long t_unit = 0, t_blocks = 0, t_dma = 0, t_bar = 0, t_mark = 0;
+  unsigned long long n_blk = 0, n_pass = 0;  // 32x32 blocks contracted / blocks that went through the element-wise test
+  const bool stamp = (dbg & 8) != 0;
+  if (stamp) t_mark = now();
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
+    __syncthreads();
+    const uint32_t u = s_unit;
+    if (u >= total_units) break;
+    const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
+    const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
+    uint32_t p_lo, p_hi;
+    {
+      const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
+      const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
+      const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
+      if (delta + Wc <= T2) {
+        p_lo = delta;
+        p_hi = min(delta + Wc, L);
+      } else {  // the block straddles I: its tail is offsets 0 .. (W <= T2 / 4 keeps the head out of the pattern)
+        p_lo = 0;
+        p_hi = min(delta + Wc - T2, L);
+      }
+      if (p_hi <= p_lo) continue;
+    }
+    const uint32_t steps = (p_hi - p_lo) * 2;  // 256-column stages to visit
+
+    // the wave's 64 rows: two groups of 32, A fragments in registers for the whole unit
+    f16x8 a0[KS], a1[KS];
+    {
+      const size_t T = (size_t)4 * I + (wv >> 1);
+      const int s0 = 2 * (wv & 1);
+      const f16x8 *a_src = P + T * kTileVecs + (size_t)s0 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a0[ks] = a_src[(size_t)ks * 256];
+        a1[ks] = a_src[(size_t)ks * 256 + 64];
+      }
+    }
+    const uint32_t row_base0 = I * kSuperH + wv * 64 + 4 * lh, row_base1 = row_base0 + 32;  // + (r & 3) + 8 * (r >> 2)
+    v16f32 nth0, nth1;              // minus the scaled row thresholds: the C operand of a block's first MFMA
+    float tmax0 = -__builtin_inff(), tmax1 = -__builtin_inff();  // largest finite scaled threshold of each row group
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float t0 = thr_scaled(theta[row_base0 + (r & 3) + 8 * (r >> 2)]);
+      const float t1 = thr_scaled(theta[row_base1 + (r & 3) + 8 * (r >> 2)]);
+      nth0[r] = -t0;
+      nth1[r] = -t1;
+      if (t0 < __builtin_inff()) tmax0 = __builtin_fmaxf(tmax0, t0);
+      if (t1 < __builtin_inff()) tmax1 = __builtin_fmaxf(tmax1, t1);
+    }
+    tmax0 = __builtin_fmaxf(tmax0, __shfl_xor(tmax0, 32, 64));
+    tmax1 = __builtin_fmaxf(tmax1, __shfl_xor(tmax1, 32, 64));
+
+    auto tile_of = [&](uint32_t step) -> uint32_t {  // first packed tile of a stage
+      uint32_t S = I + p_lo + (step >> 1);
+      S = S >= T2 ? S - T2 : S;
+      return 4 * S + 2 * (step & 1u);
+    };
+
+    // Listing of a block that passed the coarse test.  Exact per-lane tests first (row side: max(acc) >= 0; column side:
+    // max(acc + theta_row) >= theta_col); the few lanes that hold a pair (a block of clustered data typically has one)
+    // put their 16 values into the wave's LDS slots, four lanes at a time, and the 64 lanes take one (slot, register)
+    // entry each: one pass of ballots and queue writes instead of a 16-step walk over the accumulator registers.
+    auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc) -> bool {
+      v16f32 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
+      const bool hit = max16(acc) >= 0.f || max16(v) >= tc;
+      unsigned long long m = __ballot(hit);
+      if (m == 0) return false;
+      do {
+        const uint32_t rank = lanes_below(m);
+        if (hit && ((m >> lane) & 1ull) && rank < 4) {
+          float *sl = ex + rank * kSlotFloats;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            reinterpret_cast<float4 *>(sl)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            reinterpret_cast<float4 *>(sl)[4 + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          }
+          sl[32] = __uint_as_float((uint32_t)lane);
+          sl[33] = tc;
+        }
+        wave_sync();
+        const uint32_t filled = min(4u, (uint32_t)__builtin_popcountll(m));
+        const uint32_t slot = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
+        const float *sl = ex + slot * kSlotFloats;
+        const bool valid = slot < filled;
+        const float ap = sl[r], vv = sl[16 + r], tcs = sl[33];
+        const uint32_t src = __float_as_uint(sl[32]);
+        const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
+        const bool inside = valid && row < n && col < n && row != col;
+        const bool w1 = inside && ap >= 0.f, w2 = inside && vv >= tcs;
+        const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
+        const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
+        if (qn + n1 + n2 > kQueueH) flush_queue();
+        const float sc = vv * (1.f / kProductScale);
+        if (w1) {
+          queue[qn + lanes_below(m1)] = make_uint2(row, col);
+          queue_s[qn + lanes_below(m1)] = sc;
+        }
+        if (w2) {
+          queue[qn + n1 + lanes_below(m2)] = make_uint2(col, row);
+          queue_s[qn + n1 + lanes_below(m2)] = sc;
+        }
+        qn += n1 + n2;
+        wave_sync();
+        m &= m - 1;  // the four lowest lanes are done
+        m &= m - 1;
+        m &= m - 1;
+        m &= m - 1;
+      } while (m);
+      return true;
+    };
+
+    f16x8 fa[4];
+    __syncthreads();
+    stage(tile_of(0), 0, -1);
+    __syncthreads();
+    if (stamp) {
+      const unsigned long long t = now();
+      t_unit += t - t_mark;
+      t_mark = t;
+    }
+    for (uint32_t step = 0; step < steps; ++step) {
+      const uint32_t tile0 = tile_of(step);
+      const int pbuf = (int)(step & 1u);
+      const bool diag = (p_lo + (step >> 1)) == 0;
+      const bool more = step + 1 < steps && !(dbg & 4);
+      const uint32_t tile_next = more ? tile_of(step + 1) : 0;
+      const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kStageVecs) + (uint32_t)lane * 16u;
+      const float *tcol = colthr + pbuf * 256 + lc;  // thresholds of this stage's columns (LDS)
+
+      // The 8 blocks of the stage, as a real loop (one copy of the listing code: unrolled, its rare path costs
+      // hundreds of registers in live ranges).  Fragments are requested three k steps ahead, across block boundaries;
+      // the last block requests into the bytes behind the stage, which nobody reads.
+      // kRing (KS a multiple of 4): the ring of four fragment registers runs across the block boundaries.  Other widths
+      // restart it at every block (one exposed LDS latency per block; not the benchmark shapes).
+      constexpr bool kRing = KS % 4 == 0;
+      uint32_t blk = b_addr;  // fragment base of the block
+      if constexpr (kRing) {
+        lds_read16<0 * 4 * 64 * 16>(fa[0], blk);
+        lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
+        lds_read16<2 * 4 * 64 * 16>(fa[2], blk);
+      }
+#pragma nounroll
+      for (int nn = 0; nn < kBlocks; ++nn) {
+        // fragment base of the next block: sub-tile nn + 1 of the stage (4 sub-tiles of 32 columns per packed tile)
+        const uint32_t nxt = b_addr + (uint32_t)((((nn + 1) >> 2) * kTileVecs + ((nn + 1) & 3) * 64) * 16);
+        if (more && wv < 4) stage(tile_next, pbuf ^ 1, nn);
+        if constexpr (!kRing) {
+          lds_read16<0>(fa[0], blk);
+          if constexpr (KS > 1) lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
+          if constexpr (KS > 2) lds_read16<2 * 4 * 64 * 16>(fa[2], blk);
+        }
+        v16f32 x0, x1;
+        static_for<0, KS>([&](auto ks_c) {
+          constexpr int ks = decltype(ks_c)::value;
+          constexpr int ahead = ks + 3;  // k step requested now: of this block, or (ring) of the next one
+          if constexpr (ahead < KS) lds_read16<ahead * 4 * 64 * 16>(fa[ahead & 3], blk);
+          else if constexpr (kRing) lds_read16<(ahead - KS) * 4 * 64 * 16>(fa[ahead & 3], nxt);
+          constexpr int pending = kRing ? 3 : ((KS - 1 - ks) < 3 ? (KS - 1 - ks) : 3);
+          lds_wait1<pending>(fa[ks & 3]);
+          x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks], fa[ks & 3], ks == 0 ? nth0 : x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], fa[ks & 3], ks == 0 ? nth1 : x1, 0, 0, 0);
+        });
+        if (more && wv >= 4) stage(tile_next, pbuf ^ 1, nn);
+        // coarse test: some product reaches its row's threshold (max(acc) >= 0) or may reach its column's (conservative:
+        // theta_col minus the largest row threshold of the group)
+        n_blk += 2;
+        if (!(dbg & 128)) {
+          const uint32_t colbase = tile0 * kTileRows + nn * 32;
+          const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]);
+          const bool h0 = max16(x0) >= __builtin_fminf(0.f, tc - tmax0), h1 = max16(x1) >= __builtin_fminf(0.f, tc - tmax1);
+          if (__any(h0 || h1) && !(dbg & 2)) {
+            if (__any(h0)) n_pass += emit(x0, nth0, row_base0 - 4 * lh, colbase, tc) ? 1 : 0;
+            if (__any(h1)) n_pass += emit(x1, nth1, row_base1 - 4 * lh, colbase, tc) ? 1 : 0;
+          }
+        }
+        blk = nxt;
+      }
+      if (stamp) {
+        unsigned long long t = now();
+        t_blocks += t - t_mark;
+        t_mark = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t = now();
+        t_dma += t - t_mark;
+        t_mark = t;
+      }
+      __syncthreads();  // the DMA of the next stage has landed; everyone is done reading bufB[pbuf]
+      if (stamp) {
+        const unsigned long long t = now();
+        t_bar += t - t_mark;
+        t_mark = t;
+      }
+    }
+  }
+  flush_queue();
+  if (lane == 0) {
+    atomicAdd(stamps + 5, n_blk);
+    atomicAdd(stamps + 7, n_pass);
+  }
+  if (stamp && lane == 0) {
+    atomicAdd(stamps + 0, t_unit);
+    atomicAdd(stamps + 1, t_blocks);
+    atomicAdd(stamps + 2, t_dma);
+    atomicAdd(stamps + 3, t_bar);
+    atomicAdd(stamps + 4, 1ull);
+  }
+}
+
+}  // namespace
+
+// 16-B vectors of an f16 image with `tiles` 128-row tiles
+uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * ((d + 15) / 16) * 4 * 64; }
+// tiles of the f16 image of n rows: whole 512-row super tiles
+uint32_t packed_tiles_f16(uint64_t n) { return (uint32_t)((n + kSuperH - 1) / kSuperH) * 4; }
+
+int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
+             void *P, uint32_t tiles) {
+  const uint32_t KS = (d + 15) / 16;
+  const uint64_t total = packed_vecs_f16(tiles, d);  // one thread per fragment lane
+  ProfScope ps(ctx, "pack_unit_rows");
+  hipLaunchKernelGGL(pack_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, row_ids, row0, n, d, KS, total,
+                     (f16x8 *)P);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// E = max over the rows of || stored row / 128 - unit row ||_2, the size of what the f16 plane lost (one wave per row,
+// the same arithmetic as the packer, differences taken in f64).  For unit rows a, b with stored rows a + ea, b + eb:
+// |stored product - cos| = |a.eb + ea.b + ea.eb| <= 2 E + E^2 (Cauchy-Schwarz), about half the worst case of 2^-11 per
+// element that cos_delta_f16 assumes: rounding errors of 128 elements do not all sit at the edge of their binade.
+__global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t n,
+                                                            uint32_t d, unsigned int *__restrict__ out_bits) {
+  const int lane = threadIdx.x & 63;
+  float worst = 0.f;
+  for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (uint64_t)gridDim.x * 4) {
+    const double nr = norms[row];
+    double e2 = 0.0;
+    if (nr > 0.0 && nr < __builtin_inf()) {
+      for (uint32_t k = lane; k < d; k += 64) {
+        const double u = R[row * d + k] / nr;
+        const float x = (float)u * kOperandScale;
+        const _Float16 h = (x == x && __builtin_fabsf(x) <= 2.f * kOperandScale) ? (_Float16)x : (_Float16)0.0f;
+        const double e = (double)(float)h * (1.0 / kOperandScale) - u;
+        e2 += e * e;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+    const float e = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6)) ;  // rounded up
+    if (e == e) worst = __builtin_fmaxf(worst, e);
+  }
+  if (lane == 0) atomicMax(out_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+}
+
+// packs ALL n rows and leaves the measured plane error in ctx->f16_err (what join_delta certifies against)
+int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles) {
+  AS_TRY(pack_f16(ctx, R, norms, nullptr, 0, n, d, P, tiles));
+  DevBuf<unsigned int> bits;
+  AS_TRY(bits.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
+  hipLaunchKernelGGL(f16_row_error_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n, 4), 256 * 32)), dim3(256), 0, ctx->stream, R, norms,
+                     n, d, bits.p);
+  AS_HIP(ctx, hipGetLastError());
+  unsigned int h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, bits.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float e;
+  std::memcpy(&e, &h, sizeof(e));
+  ctx->f16_err = (double)e;
+  return AS_OK;
+}
+
+// Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 = ceil(n / 512) super tiles of the f16 image P
+// (all n rows).  theta: T2 * 512 thresholds (+inf on padding).  cnt / cand (n x cap) are indexed by global row; cnt must be
+// zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
+int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
+  const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
+  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + 2 * 256 * sizeof(float) + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float)) +
+                     (size_t)8 * 4 * 36 * sizeof(float);
+  const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  const uint32_t W = std::max(1u, std::min(w_opt, T2 / 4));
+  const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
+  const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
+  DevBuf<unsigned long long> stamps;
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  {
+    ProfScope ps(ctx, prof_name);
+#define AS_JOIN(K)                                                                                                        \
+  case K:                                                                                                                 \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                    (int)lds));                                                                           \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P, T2, I_begin, \
+                       I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug, stamps.p);                \
+    break;
+    switch (KS) {
+      AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
+      default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
+    }
+#undef AS_JOIN
+    AS_HIP(ctx, hipGetLastError());
+  }
+  {
+    unsigned long long h[8];
+    AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[5];       // 32x32 blocks contracted (KS MFMAs each)
+    ctx->stats[std::string(prof_name) + "_blocks_listed"] = (int64_t)h[7];  // ... that listed at least one pair
+    if (ctx->opt_debug & 8) {
+      const double w = (double)std::max<unsigned long long>(1, h[4]);
+      std::fprintf(stderr,
+                   "[join_f16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f; %llu blocks, "
+                   "%.3f listed\n",
+                   h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5], h[5] ? (double)h[7] / h[5] : 0.0);
+    }
+  }
+  return AS_OK;
+}
+
+}  // namespace asx

@@ -19,7 +19,7 @@
 // (mod T2; for even T2 the antipodal one only from the smaller index), so every I carries the same
 // work, whichever rank owns it.  The epilogue is two compares per product against thresholds held
 // in registers; only waves that see a passing product walk their accumulators again.
-#include "mfma_common.cuh"
+#include "mfma_common.h"
 
 namespace asx {
 

@@ -20,7 +20,7 @@
 
 #include <type_traits>
 
-#include "mfma_common.cuh"
+#include "mfma_common.h"
 
 namespace asx {
 

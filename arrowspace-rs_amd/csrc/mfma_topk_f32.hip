@@ -18,7 +18,7 @@
 // the item graph over a whole matrix takes the symmetric threshold join (mfma_join_f32.hip).
 #include <type_traits>
 
-#include "mfma_common.cuh"
+#include "mfma_common.h"
 
 namespace asx {
 

@@ -14,7 +14,7 @@
 //
 // On MI355X this instruction issues every 128 cycles per SIMD (39.3 TF at 2.4 GHz): this pass is
 // the high-precision second stage behind the f32 pass (mfma_topk_f32.hip).
-#include "mfma_common.cuh"
+#include "mfma_common.h"
 
 namespace asx {
 

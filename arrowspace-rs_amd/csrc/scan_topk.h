@@ -1,4 +1,4 @@
-// scan_topk.cuh -- EXACT "one row against all rows" scan with a wave-resident top-K list.
+// scan_topk.h -- EXACT "one row against all rows" scan with a wave-resident top-K list.
 //
 // This is the arithmetic-exact leg of the neighbour search (K2) and of the search scan (K9):
 // every pair's dot product is a sequential k = 0..d-1 chain of separate f64 multiply and add

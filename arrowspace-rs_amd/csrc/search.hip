@@ -1,7 +1,7 @@
 // search.hip -- exact leg of K9: blended cosine + lambda scan with per-query top-k.
 // Replaces ArrowSpace::search_lambda_aware (src/core.rs:760-798) and
 // ArrowItem::lambda_similarity (src/core.rs:135-239), batched over queries.
-#include "scan_topk.cuh"
+#include "scan_topk.h"
 
 namespace asx {
 

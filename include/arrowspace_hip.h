@@ -85,7 +85,7 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               re-rank + certification (default)
  *   "cand_precision"            32 (default) or 64: first MFMA candidate pass on the f32 / f64 pipe
  *   "knn_join"                  symmetric threshold join for whole-matrix item graphs (default 1)
- *   "join_pipe"                 16 = split-bf16 contraction (dim <= 128, default), 32 = f32 MFMA
+ *   "join_pipe"                 16 = one f16 plane (dim <= 128, default), 48 = split bf16 in two phases, 32 = f32 MFMA
  *   "join_min_rows"             smallest n for the join and for the search scan (default 32768)
  *   "join_sample", "join_rank", "join_cap", "join_block"   threshold sample 1-in-N, order statistic,
  *                               list slots per row (0 = automatic: 32 / 4 / 512), column super tiles per work unit
@@ -134,7 +134,7 @@ int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint6
  * cos(j,i): every unordered pair of 256-row tiles is contracted once, by the rank that owns one of the two
  * tiles, and serves both rows -- so the candidate lists of a rank's rows are partly produced on other ranks.
  * rows = ALL n_nodes rows in HBM (after the all-gather of the shards); [row_begin, row_begin + row_count) =
- * this rank's rows, row_begin a multiple of 256.  All pointers below are device pointers.
+ * this rank's rows, row_begin a multiple of 512.  All pointers below are device pointers.
  *   1. as_knn_join_thresholds: theta_out[row_count], the per-row candidate thresholds of this rank's rows;
  *      the host all-gathers them into theta_all[n_nodes].
  *   2. as_knn_join_pairs: contracts this rank's tile pairs; cnt[n_nodes] (zeroed by the call) and

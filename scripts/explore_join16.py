@@ -1,0 +1,35 @@
+"""Dev check of the f16 join (mfma_join_f16.hip) against the split-bf16 form: identical neighbour tables, stage times,
+uncertified rows.  usage: explore_join16.py [n] [d] [pipes...]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+import numpy as np, torch
+import arrowspace_amd as A
+from arrowspace_amd import synth
+ctx = A.default_context()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+pipes = [int(x) for x in sys.argv[3:]] or [48, 16]
+Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
+gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+ctx.set_option("join_min_rows", 512)
+if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
+res = {}
+for pipe in pipes:
+    ctx.set_option("join_pipe", pipe)
+    for dbg in ([0, 0, 8] if os.environ.get("STAMPS") else [0, 0]):
+        ctx.set_option("debug", dbg)
+        ctx.profile(True)
+        torch.cuda.synchronize(); t0 = time.time()
+        idx, dist = A.knn_cosine(Xd, gp, ctx=ctx)
+        torch.cuda.synchronize(); t1 = time.time()
+        prof = ctx.profile_all()
+    ctx.set_option("debug", 0)
+    res[pipe] = (idx.cpu().numpy() if torch.is_tensor(idx) else idx, dist.cpu().numpy() if torch.is_tensor(dist) else dist)
+    print("pipe=%d  %.1f ms  cand/row %.1f max %d overflow %d  uncertified %d 1a %d 1b %d 2 %d  blocks %d" % (
+        pipe, (t1 - t0) * 1e3, ctx.stat("knn_join_candidates") / n, ctx.stat("knn_join_max_per_row"), ctx.stat("knn_join_overflow_rows"),
+        ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_uncertified_rows_stage1b"),
+        ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
+ks = list(res)
+for p in ks[1:]:
+    print("tables identical (pipe %d vs %d):" % (ks[0], p), np.array_equal(res[ks[0]][0], res[p][0]), np.array_equal(res[ks[0]][1], res[p][1]))

@@ -1,0 +1,198 @@
+"""BASELINE.json configs at their FULL sizes on one MI355X, through the C ABI.
+
+The oracle cannot finish an n^2 graph at these sizes, so each config is checked by
+  (a) sampled parity: neighbour rows, lambdas and search results of a random sample against the oracle
+      (bit-exact indices and distances / scores, lambdas <= 1e-12), on the very bytes the device used;
+  (b) size-independent properties of the whole result (src/tests/test_laplacian.rs:51-152): symmetric CSR, zero row
+      sums, sorted unique columns, explicit diagonal, sign pattern, nnz bound, ordered neighbour rows, no self;
+  (c) for the row-sharded config, equality of one rank's output with the single-GPU output of the same rows.
+Tolerances follow src/tests/test_eigenmaps.rs:117-329 (indices exact, lambdas and scores 1e-6), asserted tighter.
+
+  configs[2]  1 M x 128, full lambda-tau build + 10 k-query search_lambda_aware(alpha = 0.7)
+  configs[3]  4 M x 128 row-sharded over 8 GPUs: here rank 3 of 8 through as_knn_join_thresholds / _pairs / _finish
+              with the foreign ranks' lists produced by the same calls on this GPU
+  configs[4]  1 M x 768, Percentile(0.95), 100 k batched prepare_query_item + search
+The rows come from the device form of the seeded mixture generator (arrowspace_amd.synth.mixture_device); the
+oracle reads the host copy of that tensor.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+try:
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+import arrowspace_amd as A
+from arrowspace_amd import distributed as D
+from oracle import oracle_ctypes as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+LAMBDA_RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return A.default_context()
+
+
+def ogp(p):
+    return O.graph_params(p.eps, p.k, p.topk, p.p, p.sigma)
+
+
+def knn_device(ctx, Xd, gp, row_begin=0, row_count=None):
+    n, d = Xd.shape
+    row_count = n - row_begin if row_count is None else row_count
+    K = gp.topk + 1
+    idx = torch.empty((row_count, K), dtype=torch.int64, device=Xd.device)
+    dst = torch.empty((row_count, K), dtype=torch.float64, device=Xd.device)
+    A.api._adopt_torch_stream(ctx)
+    c = gp.to_c()
+    ctx.check(ctx.lib.as_knn_cosine(ctx.h, Xd.data_ptr(), n, d, row_begin, row_count, C.byref(c), idx.data_ptr(),
+                                    dst.data_ptr()))
+    torch.cuda.synchronize()
+    return idx, dst
+
+
+def assert_sampled_rows(X, gp, idx, dst, sample, row0=0):
+    """idx / dst hold rows [row0, row0 + len) of the table; `sample` are GLOBAL row ids inside that range."""
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    pos = torch.from_numpy(sample - row0).to(idx.device)
+    gi = idx[pos].cpu().numpy().astype(np.uint64)
+    gd = dst[pos].cpu().numpy()
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gd, od)
+
+
+def assert_table_invariants(idx, dst, row0=0):
+    dd = dst.cpu().numpy()
+    ii = idx.cpu().numpy()
+    assert np.all(np.diff(dd, axis=1) >= 0)                                  # (distance asc ...
+    same = np.diff(dd, axis=1) == 0
+    assert np.all(np.diff(ii, axis=1)[same] > 0)                             #  ... index asc)
+    assert not np.any(ii == (row0 + np.arange(ii.shape[0]))[:, None])        # self excluded
+
+
+def assert_csr_invariants(csr, n, K):
+    indptr, indices, data = csr.to_host()
+    assert indptr[-1] == len(indices) == len(data) and len(data) <= n * (2 * K + 1)
+    rows_of = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+    cols = indices.astype(np.int64)
+    assert np.all((np.diff(cols) > 0) | (np.diff(rows_of) > 0))              # sorted, unique per row
+    diag = cols == rows_of
+    assert diag.sum() == n                                                   # explicit diagonal everywhere
+    assert np.all(data[~diag] <= 0) and np.all(data[diag] >= 0)
+    row_sum = np.bincount(rows_of, weights=data, minlength=n)
+    assert np.max(np.abs(row_sum)) < 1e-10                                   # src/tests/test_laplacian.rs:599-603 (hub rows sum ~1e3 terms)
+    off = ~diag                                                              # symmetry: entries pair up
+    key = np.minimum(rows_of[off], cols[off]) * n + np.maximum(rows_of[off], cols[off])
+    order = np.argsort(key, kind="stable")
+    k_sorted, v_sorted = key[order], data[off][order]
+    assert len(k_sorted) % 2 == 0 and np.array_equal(k_sorted[0::2], k_sorted[1::2])
+    assert np.array_equal(v_sorted[0::2], v_sorted[1::2])
+
+
+def build_and_search(ctx, Xd, X, cent, gp, taumode, otau, oarg, nq, n_lambda_samples, n_query_samples, k=10, alpha=0.7):
+    """Reference mapping at full size: F x F graph over the centroids, lambda of every item, nq prepared queries,
+    search; sampled lambdas and sampled queries against the oracle."""
+    n, d = X.shape
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(gp.eps, gp.k, gp.topk, gp.p, gp.sigma).with_synthesis(taumode)
+    asp, gl = b.build(Xd, cent)
+    csrF = gl.matrix.to_host()
+    ocsrF = O.build_laplacian(np.ascontiguousarray(cent.T), ogp(gp))
+    assert np.array_equal(csrF[0], ocsrF[0]) and np.array_equal(csrF[1], ocsrF[1])
+    np.testing.assert_allclose(csrF[2], ocsrF[2], rtol=1e-13)
+    lam = asp.lambdas().cpu().numpy()
+    assert lam.shape == (n,) and np.all(np.isfinite(lam))
+    rng = np.random.default_rng(5)
+    ls = np.sort(rng.choice(n, size=n_lambda_samples, replace=False))
+    np.testing.assert_allclose(lam[ls], O.taumode_lambdas(X[ls], csrF, otau, oarg), rtol=LAMBDA_RTOL, atol=1e-300)
+    qi = synth.query_indices(n, nq, seed=42)
+    Q = Xd[torch.from_numpy(qi).to(Xd.device)] * 1.02
+    lq = asp.prepare_query_items(Q, gl)
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    torch.cuda.synchronize()
+    lq_h, idx_h, sc_h = lq.cpu().numpy(), idx.cpu().numpy(), sc.cpu().numpy()
+    assert np.all(np.diff(sc_h, axis=1) <= 0)
+    assert np.all((idx_h >= 0) & (idx_h < n))
+    for j in np.linspace(0, nq - 1, n_query_samples).astype(np.int64):
+        q = X[qi[j]] * 1.02
+        assert lq_h[j] == pytest.approx(O.prepare_query_item(q, csrF, otau, oarg), rel=LAMBDA_RTOL)
+        oi, osc = O.search_lambda_aware(X, lam, q, lq_h[j], k, alpha)
+        assert np.array_equal(idx_h[j], oi.astype(np.int64)), j
+        assert np.array_equal(sc_h[j], osc), j
+    return asp, gl
+
+
+def test_config2_1M_x_128_build_and_10k_query_search(ctx):
+    """configs[2] with the library's default options: the item graph goes through the symmetric threshold join."""
+    n, d, nq = 1_000_000, 128, 10_000
+    Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
+    X = Xd.cpu().numpy()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dst = knn_device(ctx, Xd, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_blocks") > 0     # the join kernel ran, on a 16-bit pipe
+    assert ctx.stat("knn_join_pipe") in (16, 48)
+    rng = np.random.default_rng(1)
+    assert_sampled_rows(X, gp, idx, dst, np.sort(rng.choice(n, size=96, replace=False)))
+    assert_table_invariants(idx, dst)
+    assert_csr_invariants(A.laplacian_from_knn(idx, dst, gp, ctx=ctx), n, gp.topk + 1)
+    del idx, dst
+    build_and_search(ctx, Xd, X, cent, gp, A.TauMode.Median, O.TAU_MEDIAN, 0.0, nq, 1000, 40)
+    assert ctx.stat("search_scan") == 1                                       # the threshold scan of the search ran
+
+
+def test_config4_1M_x_768_percentile_100k_queries(ctx):
+    """configs[4] on one GPU: BERT-width rows, Percentile(0.95) tau, 100 k batched queries."""
+    n, d, nq = 1_000_000, 768, 100_000
+    Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
+    X = Xd.cpu().numpy()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dst = knn_device(ctx, Xd, gp)
+    assert ctx.stat("knn_join") == 1
+    rng = np.random.default_rng(2)
+    assert_sampled_rows(X, gp, idx, dst, np.sort(rng.choice(n, size=32, replace=False)))
+    assert_table_invariants(idx, dst)
+    assert_csr_invariants(A.laplacian_from_knn(idx, dst, gp, ctx=ctx), n, gp.topk + 1)
+    del idx, dst
+    build_and_search(ctx, Xd, X, cent, gp, A.TauMode.Percentile(0.95), O.TAU_PERCENTILE, 0.95, nq, 400, 8)
+
+
+def test_config3_4M_x_128_shard_of_8(ctx):
+    """configs[3]: what rank 3 of 8 computes, on one GPU.  Every rank's as_knn_join_thresholds and as_knn_join_pairs
+    run here one after the other (the lists the other ranks would send are the slices of their cnt / cand arrays);
+    rank 3 finishes its rows from the eight sources.  Its table must equal the rows of the single-GPU table
+    (as_knn_cosine over all 4 M rows), and sampled rows must equal the oracle's."""
+    n, d, world, me = 4_000_000, 128, 8, 3
+    Xd, _ = synth.mixture_device(n, d, "cuda", seed=42)
+    X = Xd.cpu().numpy()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    ops = D.HipOps(ctx)
+    ranges = [D.shard_range(n, r, world) for r in range(world)]
+    lo, hi = ranges[me]
+    theta_all = torch.cat([ops.join_thresholds(Xd, a, b - a, gp) for a, b in ranges])
+    assert theta_all.shape == (n,)
+    cnt_src, cand_src = [], []
+    for a, b in ranges:                                   # every rank contracts the tile pairs of its own super tiles
+        cnt, cand = ops.join_pairs(Xd, a, b - a, gp, theta_all)
+        assert ctx.stat("knn_join_blocks") > 0
+        cnt_src.append(cnt[lo:hi].clone())
+        cand_src.append(cand[lo:hi].clone())
+        del cnt, cand
+    # the thresholds of rank `me` again: as_knn_join_finish takes the looser second thresholds of ITS rows from the
+    # sequence thresholds -> pairs -> finish of one rank
+    ops.join_thresholds(Xd, lo, hi - lo, gp)
+    idx, dst = ops.join_finish(Xd, lo, hi - lo, gp, theta_all, torch.stack(cnt_src), torch.stack(cand_src))
+    torch.cuda.synchronize()
+    del cnt_src, cand_src
+    rng = np.random.default_rng(3)
+    assert_sampled_rows(X, gp, idx, dst, np.sort(lo + rng.choice(hi - lo, size=48, replace=False)), row0=lo)
+    assert_table_invariants(idx, dst, row0=lo)
+    full_idx, full_dst = knn_device(ctx, Xd, gp)          # the same rows from the one-GPU build of all 4 M
+    assert ctx.stat("knn_join") == 1
+    assert torch.equal(full_idx[lo:hi], idx) and torch.equal(full_dst[lo:hi], dst)
+    assert_sampled_rows(X, gp, full_idx, full_dst, np.sort(rng.choice(n, size=32, replace=False)))

@@ -244,12 +244,12 @@ def test_item_graph_join_matches_oracle(ctx, join_on, n, d, topk, eps):
     assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
 
 
-@pytest.mark.parametrize("n,d", [(1500, 64), (2048, 128), (3100, 17)])
-@pytest.mark.parametrize("pipe", [16, 32])
+@pytest.mark.parametrize("n,d", [(1500, 64), (2048, 128), (3100, 17), (5000, 100), (1024, 128)])
+@pytest.mark.parametrize("pipe", [16, 48, 32])
 def test_item_graph_join_on_either_pipe(ctx, join_on, n, d, pipe):
-    """The same join contracted as split-bf16 products (two-phase blocks) and on the f32 MFMA pipe: both certify
-    against their own rounding bound and give the oracle's tables; rows that can form a 0 < |a||b| <= 1e-12 pair and
-    zero rows included."""
+    """The same join contracted from one f16 plane (512-row super tiles), as split-bf16 products (two-phase blocks) and
+    on the f32 MFMA pipe: each certifies against its own rounding bound and gives the oracle's tables; rows that can
+    form a 0 < |a||b| <= 1e-12 pair and zero rows included."""
     X, _ = synth.mixture(n, d, seed=13, n_clusters=10, rank=4)
     X[5] = 0.0
     X[40] *= 1e-8
@@ -257,15 +257,20 @@ def test_item_graph_join_on_either_pipe(ctx, join_on, n, d, pipe):
     ctx.set_option("join_pipe", pipe)
     try:
         idx, dist = A.knn_cosine(X, gp)
-        blocks = ctx.stat("knn_mfma_join_bf16_blocks")
+        blocks = ctx.stat("knn_join_blocks")
+        assert ctx.stat("knn_join_pipe") == pipe
     finally:
         ctx.set_option("join_pipe", 16)
     assert ctx.stat("knn_join") == 1
     oi, od = O.knn_cosine(X, ogp(gp))
     assert np.array_equal(idx, oi)
     assert np.array_equal(dist, od)
-    if pipe == 16:  # the kernel reports what it contracted: every block on the hi planes, some of them in full
-        assert blocks > 0 and 0 <= ctx.stat("knn_mfma_join_bf16_blocks_full") <= blocks
+    assert blocks > 0
+    if pipe == 48:  # the kernel reports what it contracted: every block on the hi planes, some of them in full
+        assert 0 <= ctx.stat("knn_mfma_join_bf16_blocks_full") <= blocks
+    if pipe == 16:  # ... and the f16 form how many blocks listed a pair, and the bound it certified against
+        assert 0 <= ctx.stat("knn_mfma_join_f16_blocks_listed") <= blocks
+        assert 0 < ctx.stat("knn_join_delta_e9") <= 1.1e6  # <= the worst-case bound of one f16 plane, 1.02e-3 at dim 128
 
 
 @pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 32, 1024)])
