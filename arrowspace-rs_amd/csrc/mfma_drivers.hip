@@ -912,6 +912,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, nullptr));
+      if (ctx->opt_debug & ~(int64_t)(8 | 16)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
     }

@@ -13,10 +13,21 @@ One STEP = one pass of the hot path over the whole synthetic set (BASELINE.json 
 Inputs are resident in HBM before the timed region.  `value` = N / build seconds (whole job);
 `search_qps` = nq / search seconds.  N > 1 row-shards the same N (strong scaling) with RCCL
 all-gathers of the row blocks, the neighbour tables and the per-shard top-k.
+
+Beside the contract's fields the JSON line carries (all measured in this run, HIP events on the library's stream):
+  roofline          the dominant kernel (the symmetric join): SURVEY.md 8(d) algorithmic flops 2 n^2 d per launch
+                    over its average launch time against the dense 16-bit MFMA peak, with the MFMA flops it really
+                    executes next to it
+  roofline_scan     the lambda-tau scan (K6/K7/K8): bytes n (8 D + 8) per launch against HBM
+  roofline_search   the search scan at the benchmark batch (K9, MFMA-bound at nq = 10 k): 2 nq N D flops
+  roofline_search_hbm  the search at nq = 1 and nq = 32 (bandwidth-bound regime): bytes N (8 D + 8) per pass
+  value_host_inputs the build with the item matrix starting in host memory (PCIe inclusive; never `value`)
+  cpu_baseline      the oracle on the host cores, bounded sample
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,20 +39,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# v_mfma_f64_16x16x4_f64 issues every 128 cycles per SIMD on MI355X (measured, scripts/micro/mfma_f64_peak.hip,
-# profiles/r01_mfma_f64_issue_rate.txt): 2048 flop / 128 cyc x 1024 SIMDs x 2.4 GHz.  MI355X_MICROARCH.md has no
-# f64 MFMA row; the datasheet's FP64-matrix figure is 78.6 TF (reported next to it as frac_of_datasheet_78p6).
+# peaks: /opt/skills/guides/MI355X_MICROARCH.md (chip table); f64 MFMA measured (scripts/micro/mfma_f64_peak.hip)
 F64_MFMA_PEAK_TFLOPS = 39.3
-F64_MATRIX_DATASHEET_TFLOPS = 78.6
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16: 32768 flop / 32 clk / SIMD at 2.4 GHz)
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 flop/clk/SIMD (155 TF measured)
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table
+MFMA16_PEAK_TFLOPS = 2500.0   # dense bf16 / f16 (v_mfma_f32_32x32x16_{bf16,f16}: 32768 flop / 32 clk / SIMD at 2.4 GHz)
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=128)
@@ -49,8 +57,11 @@ def parse():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--alpha", type=float, default=0.7)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra-legs", action="store_true", help="skip the host-input build and the small-batch search legs")
     p.add_argument("--cand-precision", type=int, default=32, choices=[32, 64],
-                   help="first candidate stage: 32 = f32 MFMA then f64 MFMA then exact (default); 64 = f64 MFMA first")
+                   help="first candidate stage: 32 = 16-bit / f32 MFMA then f64 MFMA then exact (default); 64 = f64 MFMA first")
+    p.add_argument("--join-pipe", type=int, default=16, choices=[16, 48, 32],
+                   help="contraction of the join: 16 = one f16 plane (default), 48 = split bf16 in two phases, 32 = f32 MFMA")
     p.add_argument("--cpu-sample-n", type=int, default=32000)
     p.add_argument("--cpu-sample-nq", type=int, default=16)
     return p.parse_args()
@@ -90,6 +101,33 @@ def cpu_baseline(args, X_host_fn, cent, n_total):
     }
 
 
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def recorded_traffic(kernel_substr, n, d):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (PMC counters cannot be read from inside this
+    process): reported as `traffic_recorded` with its source, never as this run's `traffic`."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not (name.startswith("r02") and name.endswith("_pmc_traffic.json")):
+            continue
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                j = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k in j.get("kernels", []):
+            if kernel_substr in k.get("kernel", "") and j.get("n") == n and j.get("dim") == d:
+                best = {"bytes_per_launch": k.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
+                        "commit": j.get("commit")}
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,12 +151,13 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx._stream = torch.cuda.current_stream().cuda_stream
     ctx.set_option("cand_precision", args.cand_precision)
+    ctx.set_option("join_pipe", args.join_pipe)
     ops = D.HipOps(ctx)
 
     n, d, nq = args.n, args.dim, args.nq
     lo, hi = D.shard_range(n, rank, world)
-    X_host, cent = synth.mixture(hi - lo, d, seed=42, row_start=lo)
-    Xd = torch.from_numpy(X_host).to(dev)
+    # seeded mixture rows, generated on the device (the numpy form of the same generator takes 35 s per 1 M x 128)
+    Xd, cent = synth.mixture_device(hi - lo, d, dev, seed=42, row_start=lo)
     qidx = synth.query_indices(n, nq, seed=42)
     Q = torch.from_numpy(synth.mixture_at(qidx, d, seed=42) * 1.02).to(dev)
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
@@ -168,110 +207,125 @@ def main():
     t_all, t_build, t_search = [float(x) for x in times]
     prof = ctx.profile_all()
     ctx.profile(False)
+    stats = {k: ctx.stat(k) for k in ("knn_join", "knn_join_pipe", "knn_join_blocks", "knn_join_candidates", "knn_uncertified_rows",
+                                      "knn_uncertified_rows_stage1a", "knn_join_delta_e9", "search_uncertified_rows", "search_scan",
+                                      "knn_mfma_join_bf16_blocks_full")}
+
+    # ---- untimed extra legs (rank 0, one GPU): small-batch search, host-resident inputs --------------------------------
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        legs = []
+        for b in (1, 32):
+            Qb = Q[:b].contiguous()
+            lqb = sas.prepare_queries(Qb)
+            for _ in range(2):
+                sas.search(Qb, lqb, args.k, args.alpha)
+            torch.cuda.synchronize()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sas.search(Qb, lqb, args.k, args.alpha)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            bytes_pass = float(n) * (8.0 * d + 8.0)
+            legs.append({"nq": b, "ms_per_batch": dt * 1e3, "qps": b / dt, "algorithmic_bytes_per_pass": bytes_pass,
+                         "achieved": bytes_pass / dt / 1e9, "frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS})
+        best = max(legs, key=lambda leg: leg["frac"])
+        extra["roofline_search_hbm"] = {"bound": "hbm", "kernel": "search_lambda_aware at small batches (wall time per batch, host launch included)",
+                                        "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"],
+                                        "traffic": None, "legs": legs}
+        # the reference's build() starts from host rows (Vec<Vec<f64>>): the same build with the item matrix in host memory
+        X_host = Xd.cpu().numpy()
+        A.build_laplacian_matrix(X_host[:4096], gp, ctx=ctx)  # staging buffers warm
+        t0 = time.perf_counter()
+        gl_h = A.build_laplacian_matrix(X_host, gp, ctx=ctx)
+        asp_h, _ = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(X_host, cent)
+        ctx.synchronize()
+        t_host = time.perf_counter() - t0
+        extra["value_host_inputs"] = {"value": n / t_host, "unit": "items/s", "build_ms": t_host * 1e3,
+                                      "note": "item matrix (%.2f GB) in pageable host memory at the start; the library stages it "
+                                              "through pinned buffers for the graph and again for the lambda pass" % (n * d * 8 / 1e9)}
+        del gl_h, asp_h, X_host
 
     if rank == 0:
         steps = args.steps
         build_s = t_build / steps
         search_s = t_search / steps
         rows_here = hi - lo
-        flops_per_launch = 2.0 * rows_here * n * d  # algorithmic: 2*n^2*d over the rows this rank owns
+        flops_alg = 2.0 * rows_here * n * d  # 2 n^2 d over the rows this rank owns
         roofline = None
+        names = {16: "knn_mfma_join_f16", 48: "knn_mfma_join_bf16", 32: "knn_mfma_join_f32"}
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
-        msj, lj = prof.get("knn_mfma_join_f32", (0.0, 0))
-        msb, lb = prof.get("knn_mfma_join_bf16", (0.0, 0))
-        # the candidate pass of one step may be split into a bulk launch and a remainder launch:
-        # "launch" below = all candidate launches of one step (their flops add up to flops_per_launch)
-        l32, l64 = min(l32, steps), min(l64, steps)
-        # the symmetric threshold join.  cos(i,j) = cos(j,i): every unordered pair of 256-row tiles is contracted once,
-        # so the launch EXECUTES half of the algorithmic 2 n^2 d (plus the diagonal blocks); `achieved` / `frac` price
-        # the kernel on the MFMA flops it executes, the reference-equivalent rate (what the reference's full square would
-        # need at 2 flops per multiply-add) is given next to it
-        t2 = (n + 255) // 256
-        pairs = t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)   # 256 x 256 blocks visited
-        if lb and msb >= max(ms32, ms64, msj):
-            # split-bf16 contraction in two phases per 32x32 block: the hi planes of every block (KS MFMAs of
-            # 32x32x16), the two cross terms (2 KS more) only for the blocks the hi-only products cannot rule out.
-            # `achieved` / `frac` price the kernel on the MFMA flops it really executes (block counts reported by the
-            # kernel itself); what the full three-term contraction of every visited block would take, and what the
-            # reference's full square takes, are given next to it.
+        pipe = stats["knn_join_pipe"]
+        msj, lj = prof.get(names.get(pipe, ""), (0.0, 0))
+        if stats["knn_join"] == 1 and lj:
+            avg_ms = msj / lj
             d_pad = (d + 15) // 16 * 16
-            blocks = ctx.stat("knn_mfma_join_bf16_blocks")
-            full = ctx.stat("knn_mfma_join_bf16_blocks_full")
-            per_block_phase = 2.0 * 32 * 32 * d_pad
-            executed = per_block_phase * (blocks + 2.0 * full) if blocks else 3 * 2.0 * pairs * 256 * 256 * d_pad
-            achieved = executed / (msb / lb * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_join_bf16_kernel (v_mfma_f32_32x32x16_bf16 on split operands: hi x hi for every "
-                                                   "32x32 block, the cross terms for the blocks it cannot rule out; f32 acc; symmetric "
-                                                   "threshold join; exact f64 re-rank + certification follow)",
-                        "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "avg_launch_ms": msb / lb, "launches": lb, "executed_flops_per_launch": executed,
-                        "blocks_32x32": blocks, "blocks_contracted_in_full": full,
-                        "note": "two-phase blocks: the hi planes of every 32x32 block, the cross terms only where a product comes "
-                                "within eps of a threshold, so most of the three-term MFMA work is never issued and the kernel is "
-                                "bound by what surrounds the MFMAs (LDS-DMA issue, tile barriers, the coarse test: DESIGN.md section 4, "
-                                "profiles/r01i_pmc_clock.txt); the three-term form ran at 52 % of this peak, within 8 % of the "
-                                "power-limited rate, and took 292 ms",
-                        "three_term_flops_of_the_visited_blocks": 3 * 2.0 * pairs * 256 * 256 * d_pad,
-                        "three_term_equivalent_TFLOPs": 3 * 2.0 * pairs * 256 * 256 * d_pad / (msb / lb * 1e-3) / 1e12,
-                        "algorithmic_flops_per_launch": flops_per_launch,
-                        "reference_equivalent_TFLOPs": flops_per_launch / (msb / lb * 1e-3) / 1e12}
-        elif lj and msj >= max(ms32, ms64):
-            executed = 2.0 * pairs * 256 * 256 * d
-            achieved = executed / (msj / lj * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc, symmetric "
-                                                   "threshold join; exact f64 re-rank + certification follow)",
-                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "avg_launch_ms": msj / lj, "launches": lj, "executed_flops_per_launch": executed,
-                        "algorithmic_flops_per_launch": flops_per_launch,
-                        "reference_equivalent_TFLOPs": flops_per_launch / (msj / lj * 1e-3) / 1e12}
-        elif l32 and ms32 >= ms64:   # dominant kernel: the f32-input MFMA candidate pass
-            achieved = flops_per_launch / (ms32 / l32 * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32, f32 in / f32 acc; "
-                                                   "exact f64 re-rank + certification follow)",
-                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "avg_launch_ms": ms32 / l32, "launches": l32}
+            blocks = stats["knn_join_blocks"]
+            if pipe == 16:
+                executed = 2.0 * 32 * 32 * d_pad * blocks
+                kern = ("pair_join_f16_kernel (v_mfma_f32_32x32x16_f16 on one f16 plane of the unit rows, f32 acc; symmetric threshold "
+                        "join: every unordered pair of 512-row super tiles once; exact f64 re-rank + certification follow)")
+                peak = MFMA16_PEAK_TFLOPS
+            elif pipe == 48:
+                executed = 2.0 * 32 * 32 * d_pad * (blocks + 2.0 * stats["knn_mfma_join_bf16_blocks_full"])
+                kern = "pair_join_bf16_kernel (split bf16, two-phase blocks)"
+                peak = MFMA16_PEAK_TFLOPS
+            else:
+                t2 = (n + 255) // 256
+                executed = 2.0 * (t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)) * 256 * 256 * d
+                kern = "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32)"
+                peak = F32_MFMA_PEAK_TFLOPS
+            achieved = flops_alg / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms, "launches": lj,
+                        "algorithmic_flops_per_launch": flops_alg,
+                        "executed_flops_per_launch": executed, "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
+                        "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                        "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d per launch over the measured launch time. "
+                                "cos(i,j) = cos(j,i), so the kernel contracts every unordered pair of row tiles once and EXECUTES half of "
+                                "that (executed_*: the MFMA flops really issued = pipe utilisation); frac can therefore exceed "
+                                "executed_frac_of_peak by up to 2x"}
+        elif l32 and ms32 >= ms64:
+            achieved = flops_alg / (ms32 / min(l32, steps) * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32; exact f64 re-rank + certification follow)",
+                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                        "traffic": None, "avg_launch_ms": ms32 / min(l32, steps), "launches": l32}
         elif l64:
-            achieved = flops_per_launch / (ms64 / l64 * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma_kernel (f64 v_mfma_f64_16x16x4_f64)",
-                        "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "frac_of_datasheet_78p6": achieved / F64_MATRIX_DATASHEET_TFLOPS,
-                        "avg_launch_ms": ms64 / l64, "launches": l64}
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-        # committed rocprofv3 --pmc measurement of this very command is reported when it matches the workload
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if roofline and world == 1 and (n, d) == (1_000_000, 128) and pmc.get("dominant_kernel", "pair_topk_mfma32") in roofline["kernel"]:
-                roofline["traffic"] = pmc["hbm_bytes_per_step"]
-                roofline["traffic_source"] = "profiles/r01i_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except (OSError, KeyError, ValueError):
-            pmc = {}
+            achieved = flops_alg / (ms64 / min(l64, steps) * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma_kernel (v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+                        "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_ms": ms64 / min(l64, steps), "launches": l64}
+        if roofline and world == 1:
+            rec = recorded_traffic(roofline["kernel"].split(" ")[0], n, d)
+            if rec:
+                roofline["traffic_recorded"] = rec
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
-        extra = {}
         if lam_n:
             # two launches per step hit this group: the N items and the nq queries
             bytes_per_step = (rows_here + nq) * (8.0 * d + 8.0)
             gbps = bytes_per_step * steps / (lam_ms * 1e-3) / 1e9
-            extra["taumode_scan_GBps"] = gbps
-            extra["taumode_scan_frac_hbm"] = gbps / HBM_PEAK_GBS
-            # second roofline object: the lambda-tau scan (K6/K7/K8), HBM-side view.  The kernel itself is
-            # bound by f64 vector issue + LDS reads at this graph density.
             extra["roofline_scan"] = {"bound": "hbm", "kernel": "lambda_kernel_v3 (tau select + Rayleigh/dispersion, items + queries)",
                                       "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-                                      "traffic": None, "avg_step_ms": lam_ms / steps,
-                                      "algorithmic_bytes_per_step": bytes_per_step}
-            if world == 1 and (n, d, nq) == (1_000_000, 128, 10_000) and "lambda_scan_hbm_bytes_per_step" in pmc:
-                extra["roofline_scan"]["traffic"] = pmc["lambda_scan_hbm_bytes_per_step"]
-                extra["roofline_scan"]["traffic_source"] = "profiles/r01i_pmc_traffic.json"
+                                      "traffic": None, "avg_step_ms": lam_ms / steps, "algorithmic_bytes_per_step": bytes_per_step}
+            if world == 1:
+                rec = recorded_traffic("lambda_kernel", n, d)
+                if rec:
+                    extra["roofline_scan"]["traffic_recorded"] = rec
+        ss_ms, ss_n = prof.get("search_scan_bf16", (0.0, 0))
+        if ss_n:
+            # the threshold scan of the search (stage 0 of K9) at the benchmark batch: one launch per step over all nq queries
+            # (+ a short second launch for the queries whose guess was too high)
+            fl = 2.0 * nq * rows_here * d
+            tf = fl * steps / (ss_ms * 1e-3) / 1e12
+            extra["roofline_search"] = {"bound": "mfma", "kernel": "pair_join_bf16_kernel<KS, 2> (threshold scan of the search: split-bf16 "
+                                                                    "products + lambda term against per-query score guesses)",
+                                        "achieved": tf, "peak": MFMA16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA16_PEAK_TFLOPS,
+                                        "traffic": None, "avg_step_ms": ss_ms / steps, "algorithmic_flops_per_step": fl}
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
-            "candidate_precision": ("split-bf16 MFMA symmetric threshold join (f32 MFMA beyond dim 128) -> f32 top-k "
+            "candidate_precision": ("f16-plane MFMA symmetric threshold join (f32 MFMA beyond dim 128) -> split-bf16 second pass -> f32 top-k "
                                     "-> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)")
             if args.cand_precision == 32 else "f64 MFMA -> exact f64 scan",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,
@@ -284,15 +338,17 @@ def main():
                        "n_items": n, "dim": d, "n_queries": nq, "sharding": "rows x %d" % world},
             "search_qps": nq / search_s, "build_ms": build_s * 1e3, "search_ms": search_s * 1e3,
             "item_graph_nnz": int(state.get("nnz", -1)),
-            "knn_uncertified_rows": ctx.stat("knn_uncertified_rows"),
-            "knn_join": ctx.stat("knn_join"), "knn_join_candidates_per_row": ctx.stat("knn_join_candidates") / max(1, rows_here),
-            "search_uncertified_rows": ctx.stat("search_uncertified_rows"),
+            "knn_uncertified_rows": stats["knn_uncertified_rows"], "knn_uncertified_rows_after_second_pass": stats["knn_uncertified_rows_stage1a"],
+            "knn_join": stats["knn_join"], "knn_join_pipe": pipe, "knn_join_delta": stats["knn_join_delta_e9"] * 1e-9,
+            "knn_join_candidates_per_row": stats["knn_join_candidates"] / max(1, rows_here),
+            "search_uncertified_rows": stats["search_uncertified_rows"],
             "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items())},
+            "commit": git_head(),
             "roofline": roofline,
         }
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, lambda a, b: X_host[a:b], cent, n)
+            out["cpu_baseline"] = cpu_baseline(args, lambda a, b: Xd[a:b].cpu().numpy(), cent, n)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -30,6 +30,14 @@ for pipe in pipes:
         pipe, (t1 - t0) * 1e3, ctx.stat("knn_join_candidates") / n, ctx.stat("knn_join_max_per_row"), ctx.stat("knn_join_overflow_rows"),
         ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_uncertified_rows_stage1b"),
         ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
+for dbg in [int(x) for x in os.environ.get("ABLATE", "").split(",") if x]:
+    ctx.set_option("join_pipe", pipes[-1]); ctx.set_option("debug", dbg)
+    for rep in range(2):
+        ctx.profile(True)
+        A.knn_cosine(Xd, gp, ctx=ctx); torch.cuda.synchronize()
+        prof = ctx.profile_all()
+    ctx.set_option("debug", 0)
+    print("debug=%d" % dbg, {k: round(v[0] / v[1], 2) for k, v in prof.items() if "join" in k}, flush=True)
 ks = list(res)
 for p in ks[1:]:
     print("tables identical (pipe %d vs %d):" % (ks[0], p), np.array_equal(res[ks[0]][0], res[p][0]), np.array_equal(res[ks[0]][1], res[p][1]))
