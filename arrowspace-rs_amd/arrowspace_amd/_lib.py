@@ -22,7 +22,8 @@ EXPORTS = [
     "as_laplacian_from_knn", "as_csr_n", "as_csr_nnz", "as_csr_export", "as_csr_import", "as_csr_free",
     "as_compute_taumode", "as_prepare_query_items", "as_select_tau", "as_index_create", "as_index_destroy",
     "as_index_nitems", "as_search_lambda_aware", "as_search_lambda_aware_hybrid", "as_range_search",
-    "as_nearest_centroids", "as_knn_join_pack", "as_knn_join_unpack",
+    "as_nearest_centroids", "as_knn_join_pack", "as_knn_join_unpack", "as_laplacian_from_knn_rows", "as_csr_cols",
+    "as_csr_row_begin", "as_knn_join_applies",
 ]
 
 
@@ -71,10 +72,14 @@ def load():
         "as_knn_cosine": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, vp]),
         "as_knn_join_thresholds": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp]),
         "as_knn_join_capacity": (C.c_uint32, [vp, C.POINTER(GraphParamsC)]),
+        "as_knn_join_applies": (i32, [vp, u64, u64, C.POINTER(GraphParamsC)]),
         "as_knn_join_pairs": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, C.c_uint32, vp, vp]),
         "as_knn_join_finish": (i32, [vp, vp, u64, u64, u64, u64, C.POINTER(GraphParamsC), vp, C.c_uint32, C.c_uint32, vp, vp,
                                      vp, vp]),
         "as_laplacian_from_knn": (i32, [vp, vp, vp, u64, C.POINTER(GraphParamsC), C.POINTER(vp)]),
+        "as_laplacian_from_knn_rows": (i32, [vp, vp, vp, u64, C.POINTER(GraphParamsC), u64, u64, C.POINTER(vp)]),
+        "as_csr_cols": (u64, [vp]),
+        "as_csr_row_begin": (u64, [vp]),
         "as_csr_n": (u64, [vp]),
         "as_csr_nnz": (u64, [vp]),
         "as_csr_export": (i32, [vp, vp, vp, vp, vp]),

@@ -177,8 +177,11 @@ class CsrMatrix:
         return cls(ctx, h)
 
     def shape(self):
-        n = int(self.ctx.lib.as_csr_n(self.h))
-        return (n, n)
+        """(rows, columns): square unless the handle is a row block of a sharded graph."""
+        return (int(self.ctx.lib.as_csr_n(self.h)), int(self.ctx.lib.as_csr_cols(self.h)))
+
+    def row_begin(self):
+        return int(self.ctx.lib.as_csr_row_begin(self.h))
 
     def nnz(self):
         return int(self.ctx.lib.as_csr_nnz(self.h))
@@ -276,14 +279,20 @@ def nearest_centroids(rows, centroids, ctx=None):
     return idx, d2
 
 
-def laplacian_from_knn(nbr_idx, nbr_dist, params, ctx=None):
+def laplacian_from_knn(nbr_idx, nbr_dist, params, ctx=None, row_begin=None, row_count=None):
+    """The CSR Laplacian from a complete neighbour table; with a row range, that row block of it (as a row-sharded
+    build assembles it: as_laplacian_from_knn_rows)."""
     ctx = ctx or default_context()
     nbr_idx = nbr_idx if _lib.is_tensor(nbr_idx) else np.ascontiguousarray(nbr_idx, dtype=np.uint64)
     nbr_dist = _f64(nbr_dist, ctx)
     n = int(nbr_idx.shape[0])
     gp = params.to_c()
     h = C.c_void_p()
-    ctx.check(ctx.lib.as_laplacian_from_knn(ctx.h, ptr(nbr_idx), ptr(nbr_dist), n, C.byref(gp), C.byref(h)))
+    if row_begin is None:
+        ctx.check(ctx.lib.as_laplacian_from_knn(ctx.h, ptr(nbr_idx), ptr(nbr_dist), n, C.byref(gp), C.byref(h)))
+    else:
+        ctx.check(ctx.lib.as_laplacian_from_knn_rows(ctx.h, ptr(nbr_idx), ptr(nbr_dist), n, C.byref(gp), int(row_begin),
+                                                     int(row_count), C.byref(h)))
     return CsrMatrix(ctx, h)
 
 

@@ -2,9 +2,10 @@
 (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
 
 The path shards by rows.  Exchange steps, nothing else crosses ranks:
-  item graph     all-gather of the row shards (the off-diagonal column blocks every rank needs),
-                 all-gather of the per-row neighbour tables (n x (topk+1) x 16 B), then the
-                 integer/byte CSR assembly is replicated (it is milliseconds);
+  item graph     all-gather of the row shards (the off-diagonal column blocks every rank needs), all-gather of the
+                 join thresholds, all-to-all of the candidate lists, all-gather of the per-row neighbour tables
+                 (n x (topk+1) x 16 B); the CSR assembly is sharded by rows (every rank assembles its row block from the
+                 gathered table: as_laplacian_from_knn_rows), one all-reduce for nnz;
   lambda-tau     none for the values (tau is per item); one small all-reduce for min/max/sum;
   search         all-gather of the per-shard top-k (nq x k pairs) + a stable merge.
 
@@ -52,6 +53,18 @@ class HipOps:
         return idx, dst
 
     # -- symmetric threshold join, sharded form (include/arrowspace_hip.h: as_knn_join_*) --
+    def join_applies(self, n, d, gp):
+        """Does the sharded join apply to an n x d problem?  Depends on n, d, the graph parameters and the context's
+        options only, so every rank of a job answers the same (a rank without rows included)."""
+        import ctypes as C
+        c = gp.to_c()
+        return bool(self.ctx.lib.as_knn_join_applies(self.ctx.h, int(n), int(d), C.byref(c)))
+
+    def join_capacity(self, gp):
+        import ctypes as C
+        c = gp.to_c()
+        return int(self.ctx.lib.as_knn_join_capacity(self.ctx.h, C.byref(c)))
+
     def join_thresholds(self, X_full, row_begin, row_count, gp):
         """Thresholds of this rank's rows, or None when the join does not apply to this problem."""
         import ctypes as C
@@ -114,6 +127,11 @@ class HipOps:
 
     def laplacian_from_knn(self, idx, dist_, gp):
         return A.laplacian_from_knn(idx, dist_, gp, ctx=self.ctx)
+
+    def laplacian_rows(self, idx_all, dist_all, gp, row_begin, row_count):
+        """This rank's row block of the Laplacian from the all-gathered neighbour table (as_laplacian_from_knn_rows)."""
+        A._adopt_torch_stream(self.ctx)
+        return A.laplacian_from_knn(idx_all, dist_all, gp, ctx=self.ctx, row_begin=row_begin, row_count=row_count)
 
     def feature_laplacian(self, centroids, gp, n_items):
         return A.GraphFactory.build_laplacian_matrix_from_k_cluster(
@@ -194,6 +212,18 @@ def all_gather_rows(t, sizes):
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+def _all_to_all(out, inp, out_splits, in_splits):
+    """all_to_all_single with per-pair split sizes.  ONE code path for every backend: RCCL moves HBM tensors as they
+    are; gloo (the CPU tests, and the tests in which several ranks share one GPU) cannot, so device tensors are staged
+    through the host around the very same call."""
+    if inp.is_cuda and _host_staged():
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
 def exchange_row_blocks(t, sizes):
     """t: [n, ...] indexed by GLOBAL row on every rank.  Returns [world, sizes[rank], ...]: from every rank
     the slice of this rank's rows (all-to-all; RCCL over xGMI on the GPU box)."""
@@ -203,14 +233,8 @@ def exchange_row_blocks(t, sizes):
     if not _collectives_on(world):
         return t[starts[rank]: starts[rank] + mine].unsqueeze(0)
     tail = tuple(t.shape[1:])
-    if _host_staged():  # gloo (tests): gather everything through the host, keep this rank's rows
-        tc = t.cpu().contiguous()
-        parts = [torch.empty_like(tc) for _ in range(world)]
-        dist.all_gather(parts, tc)
-        out = torch.stack([p[starts[rank]: starts[rank] + mine] for p in parts], 0)
-        return out.to(t.device)
     out = torch.empty((world * mine,) + tail, dtype=t.dtype, device=t.device)
-    dist.all_to_all_single(out, t.contiguous(), output_split_sizes=[mine] * world, input_split_sizes=list(sizes))
+    _all_to_all(out, t, [mine] * world, list(sizes))
     return out.view((world, mine) + tail)
 
 
@@ -224,22 +248,44 @@ def exchange_packed(packed, row_offsets, sizes):
     send = [2 * (bounds[g + 1] - bounds[g]) for g in range(world)]           # words per destination
     if not _collectives_on(world):
         return packed[2 * bounds[rank]: 2 * bounds[rank + 1]]
-    if _host_staged():  # gloo (tests): everything through the host, keep what is addressed to this rank
-        mine = packed[: 2 * bounds[world]].cpu().contiguous()
-        objs = [None] * world
-        dist.all_gather_object(objs, (send, mine))
-        parts = []
-        for s_sizes, s_data in objs:
-            lo = sum(s_sizes[:rank])
-            parts.append(s_data[lo: lo + s_sizes[rank]])
-        return torch.cat(parts).to(packed.device)
     send_t = torch.tensor(send, dtype=torch.int64, device=packed.device)
     recv_t = torch.empty(world, dtype=torch.int64, device=packed.device)
-    dist.all_to_all_single(recv_t, send_t)
+    _all_to_all(recv_t, send_t, [1] * world, [1] * world)
     recv = [int(v) for v in recv_t.cpu().tolist()]
     out = torch.empty(sum(recv), dtype=packed.dtype, device=packed.device)
-    dist.all_to_all_single(out, packed[: 2 * bounds[world]].contiguous(), output_split_sizes=recv, input_split_sizes=send)
+    _all_to_all(out, packed[: 2 * bounds[world]], recv, send)
     return out
+
+
+class ShardedCsr:
+    """The item-graph Laplacian of a row-sharded build: this rank's row block (CSR with global column ids, or None on
+    a rank without rows) and the global entry count."""
+
+    def __init__(self, block, lo, hi, n, nnz_total):
+        self.block, self.lo, self.hi, self.n, self._nnz = block, lo, hi, n, int(nnz_total)
+
+    def nnz(self):
+        return self._nnz
+
+    def shape(self):
+        return (self.n, self.n)
+
+    def to_host(self):
+        """The WHOLE matrix on every rank (tests, export): all-gather of the row blocks."""
+        rank, world = _world()
+        if self.block is None:
+            ip, ix, dv = np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros(0)
+        else:
+            ip, ix, dv = self.block.to_host()
+        if not _collectives_on(world):
+            return ip, ix, dv
+        parts = [None] * world
+        dist.all_gather_object(parts, (ip, ix, dv))
+        indptr, base = [np.zeros(1, dtype=np.uint64)], 0
+        for p_ip, _, _ in parts:
+            indptr.append(p_ip[1:] + np.uint64(base))
+            base += int(p_ip[-1])
+        return (np.concatenate(indptr), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
 
 
 class ShardedArrowSpace:
@@ -259,34 +305,58 @@ class ShardedArrowSpace:
 
     # -- item graph: n x n Laplacian over the items (build_laplacian_matrix on untransposed rows)
     def build_item_graph(self):
+        """Every rank takes part in every collective, with zero-length buffers when it owns no rows (shards are whole
+        512-row super tiles, so small inputs leave the last ranks empty); which path runs is decided from
+        rank-invariant inputs only."""
+        ops, gp, n = self.ops, self.gp, self.n
         X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
         rows_here = self.hi - self.lo
-        theta = self.ops.join_thresholds(X_full, self.lo, rows_here, self.gp) \
-            if hasattr(self.ops, "join_thresholds") and rows_here > 0 and _collectives_on(self.world) else None
-        if theta is not None:
-            # symmetric threshold join: every pair of 256-row tiles is contracted once, on the rank that owns
+        K = gp.topk + 1
+        dev = self.X.device
+        d = int(self.X.shape[1])
+        use_join = _collectives_on(self.world) and hasattr(ops, "join_applies") and ops.join_applies(n, d, gp)
+        if use_join:
+            # symmetric threshold join: every pair of 512-row super tiles is contracted once, on the rank that owns
             # one of the two; thresholds are all-gathered, candidate lists go to the owners of their rows
+            theta = ops.join_thresholds(X_full, self.lo, rows_here, gp) if rows_here else \
+                torch.empty(0, dtype=torch.float32, device=dev)
             theta_all = all_gather_rows(theta.reshape(-1, 1), self.sizes).reshape(-1).contiguous()
-            cnt, cand = self.ops.join_pairs(X_full, self.lo, rows_here, self.gp, theta_all)
+            cap = ops.join_capacity(gp)
+            if rows_here:
+                cnt, cand = ops.join_pairs(X_full, self.lo, rows_here, gp, theta_all)
+                offsets, packed = ops.join_pack(cnt, cand)
+            else:  # nothing contracted here: empty lists for every row
+                cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+                offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+                packed = torch.empty(0, dtype=torch.int32, device=dev)
             cnt_src = exchange_row_blocks(cnt, self.sizes)                # RCCL all-to-all
-            if hasattr(self.ops, "join_pack"):
-                # the lists are dense arrays with a few slots used per (row, foreign rank): only those cross the links
-                offsets, packed = self.ops.join_pack(cnt, cand)
-                recv = exchange_packed(packed, offsets, self.sizes)
-                cand_src = self.ops.join_unpack(cnt_src, recv, int(cand.shape[1]))
-            else:
-                cand_src = exchange_row_blocks(cand, self.sizes)
-            idx, dst = self.ops.join_finish(X_full, self.lo, rows_here, self.gp, theta_all, cnt_src, cand_src)
-        else:
-            idx, dst = self.ops.knn_rows(X_full, self.lo, rows_here, self.gp)
+            recv = exchange_packed(packed, offsets, self.sizes)           # the used slots only cross the links
+            if rows_here:
+                cand_src = ops.join_unpack(cnt_src, recv, cap)
+                idx, dst = ops.join_finish(X_full, self.lo, rows_here, gp, theta_all, cnt_src, cand_src)
+        elif rows_here:
+            idx, dst = ops.knn_rows(X_full, self.lo, rows_here, gp)
+        if not rows_here:
+            idx = torch.empty((0, K), dtype=torch.int64, device=dev)
+            dst = torch.empty((0, K), dtype=torch.float64, device=dev)
         idx_all = all_gather_rows(idx, self.sizes)                        # RCCL all-gather #2
         dst_all = all_gather_rows(dst, self.sizes)
-        return self.ops.laplacian_from_knn(idx_all, dst_all, self.gp)     # replicated assembly
+        if not _collectives_on(self.world) or not hasattr(ops, "laplacian_rows"):
+            return ops.laplacian_from_knn(idx_all, dst_all, gp)           # one rank: the whole matrix
+        # K3-K5 sharded by rows: the degree / weight passes over the table are replicated (cheap), the reverse-edge
+        # scatter, the unions and the CSR rows are done for this rank's rows only; nnz by all-reduce
+        block = ops.laplacian_rows(idx_all, dst_all, gp, self.lo, rows_here) if rows_here else None
+        nnz = torch.tensor([block.nnz() if block is not None else 0], dtype=torch.int64, device=dev)
+        _all_reduce(nnz, dist.ReduceOp.SUM)
+        return ShardedCsr(block, self.lo, self.hi, n, int(nnz))
 
     # -- reference mapping: F x F graph over the supplied centroids, per-item lambda on the shard
     def build_lambdas(self, centroids):
         self.gl = self.ops.feature_laplacian(centroids, self.gp, self.n)
-        self.lambdas = self.ops.lambdas(self.X, self.gl, self.taumode)
+        if self.hi > self.lo:
+            self.lambdas = self.ops.lambdas(self.X, self.gl, self.taumode)
+        else:  # a rank without rows: nothing to compute, but it still takes part in the collectives below
+            self.lambdas = torch.empty(0, dtype=torch.float64, device=self.X.device)
         lam = self.lambdas if torch.is_tensor(self.lambdas) else torch.from_numpy(np.asarray(self.lambdas))
         stats = torch.stack([lam.min(), -lam.max(), lam.sum()]) if lam.numel() else \
             torch.tensor([float("inf"), float("inf"), 0.0], dtype=torch.float64, device=lam.device)
@@ -297,7 +367,7 @@ class ShardedArrowSpace:
             _all_reduce(sm, dist.ReduceOp.SUM)
             stats = torch.cat([mm, sm])
         self.lambda_stats = (float(stats[0]), float(-stats[1]), float(stats[2]) / self.n)
-        self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo)
+        self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo) if self.hi > self.lo else None
         return self.gl
 
     def prepare_queries(self, queries):
@@ -305,7 +375,12 @@ class ShardedArrowSpace:
 
     def search(self, queries, q_lambdas, k, alpha):
         """Global top-k of every query: per-shard top-k (global ids), all-gather, stable merge."""
-        idx, sc = self.ops.search(self.index, queries, q_lambdas, k, alpha)
+        if self.index is not None:
+            idx, sc = self.ops.search(self.index, queries, q_lambdas, k, alpha)
+        else:  # no items here: an empty table (padded below to the width of the others)
+            nq0 = int(queries.shape[0])
+            idx = torch.empty((nq0, 0), dtype=torch.int64, device=queries.device)
+            sc = torch.empty((nq0, 0), dtype=torch.float64, device=queries.device)
         idx = idx if torch.is_tensor(idx) else torch.from_numpy(np.asarray(idx).astype(np.int64))
         sc = sc if torch.is_tensor(sc) else torch.from_numpy(np.asarray(sc))
         if not _collectives_on(self.world):

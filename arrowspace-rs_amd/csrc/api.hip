@@ -356,6 +356,11 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
   return rc;
 }
 
+int as_knn_join_applies(as_ctx *ctx, uint64_t n_nodes, uint64_t dim, const as_graph_params *params) {
+  if (!ctx || !params || params->normalise || n_nodes >= 0xFFFFFFFFull || dim >= 0xFFFFFFFFull || params->topk + 1 > 64) return 0;
+  return knn_join_applies(ctx, (uint32_t)n_nodes, (uint32_t)dim) ? 1 : 0;
+}
+
 uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params) {
   if (!ctx || !params) return 0;
   return 2 * knn_join_cap(ctx, (uint32_t)params->topk + 1, true);  // words per row: a slot is (row id, approximate cosine)
@@ -472,10 +477,11 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   return rc;
 }
 
-int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
-                          const as_graph_params *params, as_csr **out) {
+int as_laplacian_from_knn_rows(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
+                               const as_graph_params *params, uint64_t row_begin, uint64_t row_count, as_csr **out) {
   AS_TRY(check_ctx(ctx));
   if (!nbr_idx || !nbr_dist || !params || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (row_begin + row_count > n_nodes) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
   if (n_nodes < 2 || n_nodes >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad n_nodes");
   if (params->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
   const uint32_t K = (uint32_t)params->topk + 1;
@@ -487,7 +493,12 @@ int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nb
   AS_TRY(idx32.alloc(ctx, n_nodes * K));
   hipLaunchKernelGGL(narrow_idx_kernel, dim3(cdiv(n_nodes * K, 256)), dim3(256), 0, ctx->stream, I.p, n_nodes * K,
                      idx32.p);
-  return laplacian_from_knn(ctx, idx32.p, D.p, n_nodes, K, params, out);
+  return laplacian_from_knn(ctx, idx32.p, D.p, n_nodes, K, params, out, row_begin, row_count);
+}
+
+int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
+                          const as_graph_params *params, as_csr **out) {
+  return as_laplacian_from_knn_rows(ctx, nbr_idx, nbr_dist, n_nodes, params, 0, n_nodes, out);
 }
 
 int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim,
@@ -512,11 +523,13 @@ int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   AS_TRY(dist.alloc(ctx, n_nodes * K));
   AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
   AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, 0, n_nodes, K, params->rectify, idx.p, dist.p));
-  AS_TRY(laplacian_from_knn(ctx, idx.p, dist.p, n_nodes, K, params, out));
+  AS_TRY(laplacian_from_knn(ctx, idx.p, dist.p, n_nodes, K, params, out, 0, n_nodes));
   return AS_OK;
 }
 
 uint64_t as_csr_n(const as_csr *m) { return m ? m->n : 0; }
+uint64_t as_csr_cols(const as_csr *m) { return m ? (m->n_cols ? m->n_cols : m->n) : 0; }
+uint64_t as_csr_row_begin(const as_csr *m) { return m ? m->row_begin : 0; }
 uint64_t as_csr_nnz(const as_csr *m) { return m ? m->nnz : 0; }
 
 int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indices, double *data) {
@@ -541,6 +554,7 @@ int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
   as_csr *m = new as_csr();
   m->device = ctx->device;
   m->n = n;
+  m->n_cols = n;
   m->nnz = nnz;
   AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * (n + 1)));
   AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
@@ -578,6 +592,7 @@ static int lambdas_common(as_ctx *ctx, const double *items, uint64_t n, uint64_t
                           double arg, bool check_finite, double *out) {
   AS_TRY(check_ctx(ctx));
   if (!items || !L || !out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if ((L->n_cols && L->n_cols != L->n) || L->row_begin) return fail(ctx, AS_ERR_UNSUPPORTED, "a row block of a sharded graph is not a lambda graph");
   if (F >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_features too large");
   DevIn<double> X;
   AS_TRY(X.bind(ctx, items, n * F));

@@ -92,7 +92,9 @@ struct as_ctx {
 
 struct as_csr {
   int device = 0;
-  uint64_t n = 0, nnz = 0;
+  uint64_t n = 0, nnz = 0;      // rows, stored entries
+  uint64_t n_cols = 0;          // columns (= n unless the handle is a row block of a sharded graph: then the node count)
+  uint64_t row_begin = 0;       // first global row of a row block (0 for a whole matrix)
   uint64_t *indptr = nullptr;   // n+1 (device)
   uint64_t *indices = nullptr;  // nnz (device)
   double *data = nullptr;       // nnz (device)
@@ -374,12 +376,14 @@ int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d); 
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);
 uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded);
+bool knn_join_applies(const as_ctx *ctx, uint32_t n, uint32_t d);  // for shard starts on super-tile boundaries
 // batch nearest_centroid (src/clustering.rs:913-928), centroids.hip
 int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const double *cents, uint64_t n_cents,
                       uint64_t *out_idx, double *out_d2);
 
+// rows [row_begin, row_begin + row_count) of the n x n Laplacian (the whole matrix: 0, n)
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,
-                       uint32_t K, const as_graph_params *gp, as_csr **out);
+                       uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count);
 
 int taumode_lambdas(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as_csr *L,
                     int mode, double arg, bool check_finite, double *lambdas_out);

@@ -112,7 +112,7 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
                                  const uint32_t *__restrict__ deg,
                                  const unsigned long long *__restrict__ deg_sum,
                                  uint32_t *__restrict__ adj_j, double *__restrict__ adj_w,
-                                 uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in) {
+                                 uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in, uint32_t r0, uint32_t nr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // avg_degree > 10.0 (src/laplacian.rs:229-230)
@@ -156,7 +156,7 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
   for (uint32_t s = 0; s < len; ++s) {
     adj_j[(uint64_t)i * K + s] = vj[s];
     adj_w[(uint64_t)i * K + s] = vw[s];
-    atomicAdd(&cnt_in[vj[s]], 1u);
+    if (vj[s] - r0 < nr) atomicAdd(&cnt_in[vj[s] - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
   }
 }
 
@@ -164,12 +164,13 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
 __global__ void fill_reverse_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
                                     const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
                                     const uint64_t *__restrict__ rev_ptr, uint32_t *__restrict__ cursor,
-                                    uint32_t *__restrict__ rev_src, double *__restrict__ rev_w) {
+                                    uint32_t *__restrict__ rev_src, double *__restrict__ rev_w, uint32_t r0, uint32_t nr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t len = adj_len[i];
   for (uint32_t s = 0; s < len; ++s) {
-    const uint32_t j = adj_j[(uint64_t)i * K + s];
+    const uint32_t j = adj_j[(uint64_t)i * K + s] - r0;  // rev_ptr / cursor are indexed by position in the row range
+    if (j >= nr) continue;
     const uint64_t pos = rev_ptr[j] + atomicAdd(&cursor[j], 1u);
     rev_src[pos] = i;
     rev_w[pos] = adj_w[(uint64_t)i * K + s];
@@ -184,16 +185,17 @@ __device__ __forceinline__ bool in_adj(const uint32_t *aj, uint32_t len, uint32_
 
 // union size of row i: out-edges + in-edges whose source is not already an out-neighbour
 __global__ void union_count_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len,
-                                   uint32_t n, uint32_t K, const uint64_t *__restrict__ rev_ptr,
-                                   const uint32_t *__restrict__ rev_src, uint32_t *__restrict__ ucnt) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                   uint32_t nr, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+                                   const uint32_t *__restrict__ rev_src, uint32_t *__restrict__ ucnt, uint32_t r0) {
+  const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;  // position in the row range
+  if (li >= nr) return;
+  const uint32_t i = r0 + li;
   const uint32_t len = adj_len[i];
   const uint32_t *aj = adj_j + (uint64_t)i * K;
   uint32_t c = len;
-  for (uint64_t e = rev_ptr[i]; e < rev_ptr[i + 1]; ++e)
+  for (uint64_t e = rev_ptr[li]; e < rev_ptr[li + 1]; ++e)
     if (!in_adj(aj, len, rev_src[e])) ++c;
-  ucnt[i] = c;
+  ucnt[li] = c;
 }
 
 __device__ void sort_row(uint32_t *col, double *w, uint32_t L) {
@@ -242,7 +244,7 @@ __device__ void sort_row(uint32_t *col, double *w, uint32_t L) {
 
 // ---- K5: per-row union, sort, degree, final CSR (src/laplacian.rs:339-341,369-411) -----------
 // serial form of one row (any length): gather into the global scratch, sort there, write
-__device__ void write_row_serial(uint32_t i, const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+__device__ void write_row_serial(uint32_t i, uint32_t li, const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
                                  const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
                                  const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
                                  const uint64_t *__restrict__ eptr, uint32_t *__restrict__ ecol, double *__restrict__ ew,
@@ -250,14 +252,14 @@ __device__ void write_row_serial(uint32_t i, const uint32_t *__restrict__ adj_j,
   const uint32_t len = adj_len[i];
   const uint32_t *aj = adj_j + (uint64_t)i * K;
   const double *aw = adj_w + (uint64_t)i * K;
-  uint32_t *col = ecol + eptr[i];
-  double *w = ew + eptr[i];
+  uint32_t *col = ecol + eptr[li];
+  double *w = ew + eptr[li];
   uint32_t L = 0;
   for (uint32_t s = 0; s < len; ++s) {
     col[L] = aj[s];
     w[L++] = aw[s];
   }
-  for (uint64_t e = rev_ptr[i]; e < rev_ptr[i + 1]; ++e) {
+  for (uint64_t e = rev_ptr[li]; e < rev_ptr[li + 1]; ++e) {
     const uint32_t src = rev_src[e];
     if (!in_adj(aj, len, src)) {
       col[L] = src;
@@ -267,8 +269,8 @@ __device__ void write_row_serial(uint32_t i, const uint32_t *__restrict__ adj_j,
   sort_row(col, w, L);
   double degree = 0.0;  // sequential sum in column order (src/laplacian.rs:369)
   for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, w[s]);
-  uint64_t o = eptr[i] + i;
-  indptr[i] = o;
+  uint64_t o = eptr[li] + li;
+  indptr[li] = o;
   bool diag_done = false;
   for (uint32_t s = 0; s < L; ++s) {
     if (!diag_done && col[s] > i) {
@@ -295,18 +297,20 @@ __global__ __launch_bounds__(256) void write_rows_kernel(
     uint32_t K, const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
     const uint64_t *__restrict__ eptr, uint32_t *__restrict__ ecol, double *__restrict__ ew, uint64_t *__restrict__ indptr,
     uint64_t *__restrict__ indices, double *__restrict__ data, uint32_t *__restrict__ big_rows,
-    uint32_t *__restrict__ big_count) {
+    uint32_t *__restrict__ big_count, uint32_t r0) {
+  // n = rows of the range [r0, r0 + n): li = position in it (eptr, rev_ptr, indptr), i = global row (adj_*, the diagonal)
   const int lane = threadIdx.x & 63;
-  const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i > n) return;
-  if (i == n) {
+  const uint32_t li = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (li > n) return;
+  if (li == n) {
     if (lane == 0) indptr[n] = eptr[n] + n;
     return;
   }
+  const uint32_t i = r0 + li;
   const uint32_t len = adj_len[i];
-  const uint64_t rs = rev_ptr[i], re = rev_ptr[i + 1];
+  const uint64_t rs = rev_ptr[li], re = rev_ptr[li + 1];
   if (len + (re - rs) > 64) {  // hub rows (in-degree in the hundreds or thousands): one workgroup each, below
-    if (lane == 0) big_rows[atomicAdd(big_count, 1u)] = i;
+    if (lane == 0) big_rows[atomicAdd(big_count, 1u)] = li;
     return;
   }
   const uint32_t nrev = (uint32_t)(re - rs);
@@ -345,10 +349,10 @@ __global__ __launch_bounds__(256) void write_rows_kernel(
   const uint32_t L = (uint32_t)__builtin_popcountll(valid);  // = eptr[i + 1] - eptr[i]
   double degree = 0.0;
   for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, __shfl(w, (int)s, 64));
-  const uint64_t o = eptr[i] + i;
+  const uint64_t o = eptr[li] + li;
   const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(col < i));  // entries left of the diagonal
   if (lane == 0) {
-    indptr[i] = o;
+    indptr[li] = o;
     indices[o + below] = i;
     data[o + below] = degree;
   }
@@ -369,19 +373,19 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
     const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
     const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w, const uint64_t *__restrict__ eptr,
     uint32_t *__restrict__ ecol, double *__restrict__ ew, uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
-    double *__restrict__ data) {
+    double *__restrict__ data, uint32_t r0) {
   __shared__ uint32_t s_col[kBigMax];
   __shared__ double s_w[kBigMax];
   __shared__ double s_degree;
   __shared__ uint32_t s_below;
   const uint32_t tid = threadIdx.x;
   for (uint32_t b = blockIdx.x; b < *big_count; b += gridDim.x) {
-    const uint32_t i = big_rows[b];
+    const uint32_t li = big_rows[b], i = r0 + li;
     const uint32_t len = adj_len[i];
-    const uint64_t rs = rev_ptr[i];
-    const uint32_t nrev = (uint32_t)(rev_ptr[i + 1] - rs), total = len + nrev;
+    const uint64_t rs = rev_ptr[li];
+    const uint32_t nrev = (uint32_t)(rev_ptr[li + 1] - rs), total = len + nrev;
     if (total > kBigMax) {
-      if (tid == 0) write_row_serial(i, adj_j, adj_w, adj_len, K, rev_ptr, rev_src, rev_w, eptr, ecol, ew, indptr, indices, data);
+      if (tid == 0) write_row_serial(i, li, adj_j, adj_w, adj_len, K, rev_ptr, rev_src, rev_w, eptr, ecol, ew, indptr, indices, data);
       continue;
     }
     uint32_t P = 64;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
         }
         __syncthreads();
       }
-    const uint32_t L = (uint32_t)(eptr[i + 1] - eptr[i]);  // valid entries (the invalid ones sorted behind them)
+    const uint32_t L = (uint32_t)(eptr[li + 1] - eptr[li]);  // valid entries (the invalid ones sorted behind them)
     uint32_t below = 0;
     for (uint32_t e = tid; e < L; e += blockDim.x) below += s_col[e] < i ? 1u : 0u;
     if (below) atomicAdd(&s_below, below);
@@ -431,10 +435,10 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
       s_degree = degree;
     }
     __syncthreads();
-    const uint64_t o = eptr[i] + i;
+    const uint64_t o = eptr[li] + li;
     const uint32_t nb = s_below;
     if (tid == 0) {
-      indptr[i] = o;
+      indptr[li] = o;
       indices[o + nb] = i;
       data[o + nb] = s_degree;
     }
@@ -446,12 +450,19 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
   }
 }
 
+// Rows [row_begin, row_begin + row_count) of the Laplacian of the n-node graph whose complete neighbour table is given
+// (row-sharded builds: every rank holds the all-gathered table and assembles its own row block; the whole matrix is the
+// range [0, n)).  Weights and the pruning need the degrees of ALL rows (two passes over the table, replicated: they are
+// the cheap part); the reverse-edge scatter, the unions, the sorts and the CSR rows are done for the range only.
+// The CSR that comes out has row_count rows, GLOBAL column ids, indptr starting at 0.
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n64,
-                       uint32_t K, const as_graph_params *gp, as_csr **out) {
+                       uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count) {
   if (K > kMaxK) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
   const uint32_t n = (uint32_t)n64;
+  if (row_begin + row_count > n64) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
+  const uint32_t r0 = (uint32_t)row_begin, nr = (uint32_t)row_count;
   const double sigma = gp->has_sigma ? gp->sigma : 1.0;  // src/laplacian.rs:254
-  const unsigned gb = cdiv(n, 256);
+  const unsigned gb = cdiv(n, 256), gr = std::max(1u, cdiv(nr, 256));
   hipStream_t st = ctx->stream;
 
   DevBuf<uint32_t> deg, adj_j, adj_len, cnt_in, cursor, rev_src, ucnt, ecol;
@@ -463,55 +474,57 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
   AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
   AS_TRY(adj_len.alloc(ctx, n));
-  AS_TRY(cnt_in.alloc(ctx, n));
-  AS_TRY(cursor.alloc(ctx, n));
-  AS_TRY(rev_ptr.alloc(ctx, (size_t)n + 1));
-  AS_TRY(ucnt.alloc(ctx, n));
-  AS_TRY(eptr.alloc(ctx, (size_t)n + 1));
+  AS_TRY(cnt_in.alloc(ctx, (size_t)nr + 1));
+  AS_TRY(cursor.alloc(ctx, (size_t)nr + 1));
+  AS_TRY(rev_ptr.alloc(ctx, (size_t)nr + 1));
+  AS_TRY(ucnt.alloc(ctx, (size_t)nr + 1));
+  AS_TRY(eptr.alloc(ctx, (size_t)nr + 1));
   AS_HIP(ctx, hipMemsetAsync(deg_sum.p, 0, sizeof(unsigned long long), st));
-  AS_HIP(ctx, hipMemsetAsync(cnt_in.p, 0, sizeof(uint32_t) * n, st));
-  AS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * n, st));
+  AS_HIP(ctx, hipMemsetAsync(cnt_in.p, 0, sizeof(uint32_t) * ((size_t)nr + 1), st));
+  AS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * ((size_t)nr + 1), st));
 
   uint64_t n_edges_dir = 0, n_union = 0;
   {
     ProfScope ps(ctx, "graph_assembly");
     hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
     hipLaunchKernelGGL(adjacency_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
-                       gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p);
-    AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, n, rev_ptr.p));
-    AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + n, sizeof(uint64_t)));
+                       gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
+    AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, nr, rev_ptr.p));
+    AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
     AS_TRY(rev_src.alloc(ctx, n_edges_dir));
     AS_TRY(rev_w.alloc(ctx, n_edges_dir));
     hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
-                       rev_ptr.p, cursor.p, rev_src.p, rev_w.p);
-    hipLaunchKernelGGL(union_count_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_len.p, n, K, rev_ptr.p,
-                       rev_src.p, ucnt.p);
-    AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, n, eptr.p));
-    AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + n, sizeof(uint64_t)));
+                       rev_ptr.p, cursor.p, rev_src.p, rev_w.p, r0, nr);
+    hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
+                       rev_src.p, ucnt.p, r0);
+    AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, nr, eptr.p));
+    AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + nr, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
   }
-  const uint64_t nnz = n_union + n;
+  const uint64_t nnz = n_union + nr;
   as_csr *m = new as_csr();
   m->device = ctx->device;
-  m->n = n;
+  m->n = nr;
+  m->n_cols = n;
+  m->row_begin = r0;
   m->nnz = nnz;
-  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * ((size_t)n + 1)));
+  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * ((size_t)nr + 1)));
   AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
   AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
   AS_TRY(ecol.alloc(ctx, n_union));
   AS_TRY(ew.alloc(ctx, n_union));
   DevBuf<uint32_t> big_rows, big_count;
-  AS_TRY(big_rows.alloc(ctx, n));
+  AS_TRY(big_rows.alloc(ctx, (size_t)nr + 1));
   AS_TRY(big_count.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(big_count.p, 0, sizeof(uint32_t), st));
   {
     ProfScope ps(ctx, "graph_assembly");
-    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)n + 1, 4)), dim3(256), 0, st, adj_j.p, adj_w.p,
-                       adj_len.p, n, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,
-                       m->indices, m->data, big_rows.p, big_count.p);
+    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)nr + 1, 4)), dim3(256), 0, st, adj_j.p, adj_w.p,
+                       adj_len.p, nr, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,
+                       m->indices, m->data, big_rows.p, big_count.p, r0);
     hipLaunchKernelGGL(write_rows_big_kernel, dim3(4096), dim3(256), 0, st, big_rows.p, big_count.p, adj_j.p, adj_w.p, adj_len.p,
-                       K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr, m->indices, m->data);
+                       K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr, m->indices, m->data, r0);
   }
   AS_HIP(ctx, hipGetLastError());
   ctx->stats["graph_directed_edges"] = (int64_t)n_edges_dir;

@@ -203,6 +203,11 @@ static uint32_t cand_capacity(as_ctx *ctx, uint32_t K) {
   return std::min<uint32_t>(kc, 64);
 }
 
+// The exact re-rank kernels stage the A row and up to 1024 candidate keys per wave in LDS: 4 x ((d + C) x 8 + C x 4)
+// bytes with C <= 1024 must fit the 160 KB of a CU.  Wider rows (a feature graph over thousands of centroids, build(rows)
+// with every item its own centroid) take the exact scan, which tiles k.
+static bool rerank_fits(uint64_t d) { return 32 * d + 49152 <= 160 * 1024; }
+
 constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straight to the exact scan ...
 // ... when the matrix is small: the exact scan is one wave per row over ALL columns (300 ms at 1 M x 128 however
 // few the rows), an MFMA stage over the failed rows a few tens of ms
@@ -656,10 +661,12 @@ static double join_delta(const as_ctx *ctx, uint32_t d) {
 
 // shard starts are multiples of 512: the row super tile of the f16 join (256 for the other pipes)
 static bool join_supported(const as_ctx *ctx, uint32_t n, uint32_t d, uint64_t row_begin) {
-  return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 &&
+  return ctx->opt_knn_join && ctx->opt_cand_precision != 64 && d >= 1 && rerank_fits(d) &&
          n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows) &&
          row_begin % (join_on_f16(ctx, d) ? 512 : 256) == 0;
 }
+
+bool knn_join_applies(const as_ctx *ctx, uint32_t n, uint32_t d) { return join_supported(ctx, n, d, 0); }
 
 // theta_out[r] for r in [row_begin, row_begin + row_count): the m-th best approximate cosine of the row against a
 // hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
@@ -837,7 +844,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const uint32_t KC = cand_capacity(ctx, K + 1);
   const bool wide = NC > kMaxNC;  // dim > 128: only the f32 pass has the k-panel loop
   const bool use_f32 = (ctx->opt_cand_precision != 64 || wide) && fits_f32(KC);
-  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0)  // small or deep problems: exact scan
+  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0 || !rerank_fits(d))  // small, deep or very wide problems: exact scan
     return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
 
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
@@ -1266,7 +1273,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   // deep lists (large k) and small matrices do not fit the MFMA top-k passes; the threshold scan (stage 0) has no
   // such limit, so what it leaves open then goes straight to the exact scan
   const bool mfma_ok = !((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows);
-  if (nq == 0 || n < 4 * kTileRows)
+  if (nq == 0 || n < 4 * kTileRows || !rerank_fits(d))
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;

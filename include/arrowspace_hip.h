@@ -150,7 +150,10 @@ int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint6
  * packed operand image and keeps them in the context, the last releases them (calling 2 or 3 out of sequence
  * only costs rebuilding them).
  * AS_ERR_UNSUPPORTED when the join does not apply (small n, normalise, f64-first mode, host
- * pointers): the caller then uses as_knn_cosine on its row range. */
+ * pointers): the caller then uses as_knn_cosine on its row range.
+ * as_knn_join_applies: 1 when the sequence applies to an n_nodes x dim problem under the context's options (it depends
+ * on nothing else, so every rank of a job gets the same answer, a rank that owns no rows included), else 0. */
+int as_knn_join_applies(as_ctx *ctx, uint64_t n_nodes, uint64_t dim, const as_graph_params *params);
 int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t dim, uint64_t row_begin,
                            uint64_t row_count, const as_graph_params *params, float *theta_out);
 uint32_t as_knn_join_capacity(as_ctx *ctx, const as_graph_params *params);
@@ -177,7 +180,19 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
 int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist,
                           uint64_t n_nodes, const as_graph_params *params, as_csr **out);
 
-uint64_t as_csr_n(const as_csr *m);
+/* Row-sharded form: rows [row_begin, row_begin + row_count) of the same Laplacian, from the complete (all-gathered)
+ * neighbour table.  Every rank of a sharded build assembles its own row block: the table passes that need all rows
+ * (degrees, weights, pruning: src/laplacian.rs:217-288) are replicated, the reverse-edge scatter, the unions and the
+ * CSR rows (src/laplacian.rs:295-417) are done for the range only.  The handle that comes out is a ROW BLOCK:
+ * as_csr_n = row_count rows, as_csr_cols = n_nodes, GLOBAL column ids, indptr starting at 0, as_csr_row_begin = its
+ * first row.  Stacking the blocks of consecutive ranges gives exactly the CSR of as_laplacian_from_knn.  A row block is
+ * not accepted as the graph of as_compute_taumode (AS_ERR_UNSUPPORTED). */
+int as_laplacian_from_knn_rows(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
+                               const as_graph_params *params, uint64_t row_begin, uint64_t row_count, as_csr **out);
+
+uint64_t as_csr_n(const as_csr *m);         /* rows */
+uint64_t as_csr_cols(const as_csr *m);      /* columns (= rows unless the handle is a row block) */
+uint64_t as_csr_row_begin(const as_csr *m); /* first global row of a row block, else 0 */
 uint64_t as_csr_nnz(const as_csr *m);
 /* copy out (host or device destinations): indptr[n+1], indices[nnz], data[nnz] */
 int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indices, double *data);

@@ -33,12 +33,107 @@ class _Gl:
         self.matrix = _Csr(csr)
 
 
+class _CsrBlock:
+    """Row block [lo, lo + count) of a CSR (what as_laplacian_from_knn_rows returns), cut from the oracle's matrix."""
+
+    def __init__(self, csr, lo, count):
+        ip, ix, dv = csr
+        a, b = int(ip[lo]), int(ip[lo + count])
+        self.csr = ((ip[lo: lo + count + 1] - ip[lo]).astype(np.uint64), ix[a:b].copy(), dv[a:b].copy())
+
+    def nnz(self):
+        return len(self.csr[1])
+
+    def to_host(self):
+        return self.csr
+
+
+JOIN_SLOTS = 64  # list slots per row of the emulated join
+
+
 class OracleOps:
-    """Test-only stand-in for HipOps (CPU tensors in, CPU tensors out)."""
+    """Test-only stand-in for HipOps (CPU tensors in, CPU tensors out).  With `join=True` it also emulates the sharded
+    threshold join in numpy -- thresholds, the pairs a rank contracts (those of the rows it owns against the half of
+    the matrix "ahead" of them, listed for BOTH rows of a pair), pack / unpack -- so that the driver's list exchange
+    runs on gloo exactly as it does on RCCL; join_finish checks that what arrived is the complete list of every row."""
+
+    def __init__(self, join=False):
+        if join:
+            self.join_applies = lambda n, d, gp: True
+            self.join_capacity = lambda gp: 2 * JOIN_SLOTS
 
     @staticmethod
     def _gp(gp):
         return O.graph_params(gp.eps, gp.k, gp.topk, gp.p, gp.sigma)
+
+    @staticmethod
+    def _cos(X):
+        U = X / np.linalg.norm(X, axis=1, keepdims=True)
+        return U @ U.T
+
+    def join_thresholds(self, X_full, row_begin, row_count, gp):
+        S = self._cos(X_full.numpy())[row_begin: row_begin + row_count]
+        kth = np.sort(S, axis=1)[:, -min(S.shape[1], gp.topk + 6)]   # a cut that keeps a few more than topk + 1 per row
+        return torch.from_numpy(kth.astype(np.float32))
+
+    def join_pairs(self, X_full, row_begin, row_count, gp, theta_all):
+        n = X_full.shape[0]
+        S, th = self._cos(X_full.numpy()), theta_all.numpy()
+        cnt = np.zeros(n, dtype=np.int32)
+        cand = np.zeros((n, 2 * JOIN_SLOTS), dtype=np.int32)
+
+        def put(r, other, score):
+            if cnt[r] < JOIN_SLOTS:
+                cand[r, 2 * cnt[r]] = other
+                cand[r, 2 * cnt[r] + 1] = np.float32(score).view(np.int32)
+            cnt[r] += 1
+        for i in range(row_begin, row_begin + row_count):
+            for off in range(1, n // 2 + 1):        # the pairs this row's owner contracts: the half of the ring ahead
+                j = (i + off) % n
+                if 2 * off == n and j < i:           # the antipodal pair once, from the smaller index
+                    continue
+                if S[i, j] >= th[i]:
+                    put(i, j, S[i, j])
+                if S[i, j] >= th[j]:
+                    put(j, i, S[i, j])
+        return torch.from_numpy(cnt), torch.from_numpy(cand)
+
+    def join_pack(self, cnt, cand):
+        c, a = cnt.numpy(), cand.numpy()
+        used = np.minimum(c, JOIN_SLOTS)
+        offsets = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
+        packed = np.concatenate([a[r, : 2 * used[r]] for r in range(len(c))] + [np.zeros(0, dtype=np.int32)])
+        return torch.from_numpy(offsets), torch.from_numpy(packed.astype(np.int32))
+
+    def join_unpack(self, cnt_src, packed, cap):
+        n_src, rows = cnt_src.shape
+        out = np.zeros((n_src, rows, cap), dtype=np.int32)
+        c, p, at = cnt_src.numpy(), packed.numpy(), 0
+        for s in range(n_src):
+            for r in range(rows):
+                u = 2 * min(int(c[s, r]), cap // 2)
+                out[s, r, :u] = p[at: at + u]
+                at += u
+        assert at == len(p)
+        return torch.from_numpy(out)
+
+    def join_finish(self, X_full, row_begin, row_count, gp, theta_all, cnt_src, cand_src):
+        S, th = self._cos(X_full.numpy()), theta_all.numpy()
+        c, a = cnt_src.numpy(), cand_src.numpy()
+        for r in range(row_count):                  # the exchanged lists hold exactly the pairs at or above the cut
+            i = row_begin + r
+            got = sorted(int(a[s, r, 2 * e]) for s in range(c.shape[0]) for e in range(int(c[s, r])))
+            want = [j for j in range(S.shape[0]) if j != i and S[i, j] >= th[i]]
+            assert got == want, (i, got, want)
+            for s in range(c.shape[0]):
+                for e in range(int(c[s, r])):
+                    j = int(a[s, r, 2 * e])
+                    assert a[s, r, 2 * e + 1] == np.float32(S[i, j]).view(np.int32)
+        return self.knn_rows(X_full, row_begin, row_count, gp)
+
+    def laplacian_rows(self, idx_all, dst_all, gp, row_begin, row_count):
+        full = O.laplacian_from_knn(idx_all.numpy().astype(np.uint64), dst_all.numpy(), self._gp(gp))
+        return _CsrBlock(full, row_begin, row_count)
 
     def knn_rows(self, X_full, row_begin, row_count, gp):
         idx, dst = O.knn_cosine(X_full.numpy(), self._gp(gp))
@@ -81,15 +176,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, d, k, out_dir):
+def _worker(rank, world, port, n, d, k, out_dir, join=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         X, cent = synth.mixture(n, d, seed=13, n_clusters=8, rank=3)
         lo, hi = D.shard_range(n, rank, world)
         gp = A.GraphParams(0.5, 8, 8, 2.0, 0.25)
-        sas = D.ShardedArrowSpace(OracleOps(), torch.from_numpy(X[lo:hi].copy()), n, gp, A.TauMode.Median)
-        csr = sas.build_item_graph().csr
+        sas = D.ShardedArrowSpace(OracleOps(join), torch.from_numpy(X[lo:hi].copy()), n, gp, A.TauMode.Median)
+        gl = sas.build_item_graph()
+        assert isinstance(gl, D.ShardedCsr) and (gl.lo, gl.hi) == (lo, hi)
+        assert (gl.block is None) == (hi == lo)      # every rank assembled its own row block and nothing else
+        csr = gl.to_host()
+        assert gl.nnz() == len(csr[1])
         sas.build_lambdas(cent)
         Q = torch.from_numpy(X[[1, n // 2, n - 1]] * 1.02)
         lq = sas.prepare_queries(Q)
@@ -102,22 +201,27 @@ def _worker(rank, world, port, n, d, k, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,k", [(512, 5), (300, 7), (200, 150)])
-def test_sharded_build_and_search_match_single_process(tmp_path, n, k):
-    d, world = 16, 2
+@pytest.mark.parametrize("n,k,world,join", [(1024, 5, 2, False), (700, 7, 2, False), (200, 150, 2, False), (600, 5, 3, False),
+                                             (1100, 5, 2, True), (1300, 4, 3, True), (600, 6, 3, True)])
+def test_sharded_build_and_search_match_single_process(tmp_path, n, k, world, join):
+    """Two and three ranks, equal and ragged shards, shards that leave the last ranks WITHOUT rows (n = 600 on three
+    ranks: 512 + 88 + 0; n = 200: everything on rank 0) -- every rank still takes part in every collective -- with the
+    plain row-range search and with the sharded threshold join (thresholds all-gathered, candidate lists exchanged by
+    all_to_all_single with per-pair sizes, the same calls the RCCL run makes)."""
+    d = 16
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, d, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, d, k, str(tmp_path), join), nprocs=world, join=True)
     X, cent = synth.mixture(n, d, seed=13, n_clusters=8, rank=3)
     gp = O.graph_params(0.5, 8, 8, 2.0, 0.25)
     csr = O.build_laplacian(X, gp)
     csrF = O.build_laplacian(np.ascontiguousarray(cent.T), gp)
     lam = O.taumode_lambdas(X, csrF, O.TAU_MEDIAN)
     Q = X[[1, n // 2, n - 1]] * 1.02
-    r0 = np.load(tmp_path / "rank0.npz")
-    r1 = np.load(tmp_path / "rank1.npz")
-    assert (int(r0["lo"]), int(r0["hi"]), int(r1["hi"])) == (0, int(r1["lo"]), n)
-    assert int(r1["lo"]) % 256 == 0 or int(r1["lo"]) == n  # shard starts sit on 256-row tile boundaries (or the shard is empty)
-    for r in (r0, r1):
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert int(rs[0]["lo"]) == 0 and int(rs[-1]["hi"]) == n
+    assert all(int(a["hi"]) == int(b["lo"]) for a, b in zip(rs, rs[1:]))
+    assert all(int(r["lo"]) % 512 == 0 or int(r["lo"]) == n for r in rs)  # shard starts sit on super-tile boundaries (or the shard is empty)
+    for r in rs:
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         assert np.array_equal(r["data"], csr[2])
         assert np.array_equal(r["lam"], lam)
@@ -187,4 +291,4 @@ def test_shard_range_covers_everything():
             spans = [D.shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-            assert all(lo % 128 == 0 or lo == n for lo, _ in spans)
+            assert all(lo % 512 == 0 or lo == n for lo, _ in spans)

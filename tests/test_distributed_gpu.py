@@ -38,7 +38,9 @@ def _worker(rank, world, port, n, d, out_dir):
         lo, hi = D.shard_range(n, rank, world)
         gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
         sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp, A.TauMode.Median)
-        csr = sas.build_item_graph().to_host()
+        gl = sas.build_item_graph()
+        assert isinstance(gl, D.ShardedCsr) and (gl.block is None) == (hi == lo)
+        csr = gl.to_host()
         sas.build_lambdas(cent)
         Q = torch.from_numpy(X[[1, n // 2, n - 1, 77]] * 1.02).cuda()
         lq = sas.prepare_queries(Q)
@@ -47,14 +49,15 @@ def _worker(rank, world, port, n, d, out_dir):
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2],
                  lam=lam_all.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
-                 stats=np.array(sas.lambda_stats), join=np.array(ctx.stat("knn_join")))
+                 stats=np.array(sas.lambda_stats), join=np.array(ctx.stat("knn_join") if hi > lo else 1))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(3000, 2), (1111, 2), (3000, 3)])
+@pytest.mark.parametrize("n,world", [(3000, 2), (1111, 2), (3000, 3), (1000, 3)])
 def test_ranks_sharing_one_gpu_match_single_process(tmp_path, n, world):
-    """2 ranks; 2 ranks with an almost empty second shard; 3 ranks with uneven shards (1024 / 1024 / 952 rows)."""
+    """2 ranks; 2 ranks with a short second shard; 3 ranks with uneven shards (1024 / 1024 / 952 rows); 3 ranks of
+    which the last owns NO rows (512 / 488 / 0) and still takes part in every collective."""
     import arrowspace_amd as A
     from oracle import oracle_ctypes as O
     from tests import synth
@@ -131,3 +134,65 @@ def test_one_rank_rccl_collectives_match_oracle(tmp_path):
         oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
         assert np.array_equal(r["idx"][j], oi.astype(np.int64))
         assert np.array_equal(r["sc"][j], osc)
+
+
+def _rccl_multi_worker(rank, world, port, n, d, out_dir):
+    """One GPU per rank, backend "nccl": the path bench.py takes under torch.distributed.run."""
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        ctx = A.Context(rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)
+        X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        lo, hi = D.shard_range(n, rank, world)
+        gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+        sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp, A.TauMode.Median)
+        for _ in range(2):
+            gl = sas.build_item_graph()
+            sas.build_lambdas(cent)
+            Q = torch.from_numpy(X[[1, n // 2, n - 1, 77]] * 1.02).cuda()
+            lq = sas.prepare_queries(Q)
+            idx, sc = sas.search(Q, lq, 10, 0.7)
+        csr = gl.to_host()
+        lam_all = D.all_gather_rows(sas.lambdas.reshape(-1, 1), sas.sizes).reshape(-1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2],
+                 lam=lam_all.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
+                 stats=np.array(sas.lambda_stats), join=np.array(ctx.stat("knn_join") if hi > lo else 1), nnz=np.array(gl.nnz()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs (RCCL wants one GPU per rank)")
+@pytest.mark.parametrize("n", [20_000, 3_000])
+def test_multi_rank_rccl_matches_oracle(tmp_path, n):
+    """world = min(device_count, 8) ranks, one GPU each, over RCCL: the all_to_all_single calls with per-pair split
+    sizes (thresholds, counts, packed candidate lists), the all-gathers and the sharded CSR assembly of the build the
+    driver's scaling run times.  n = 3000 leaves the last ranks of an 8-rank job without rows.  Skipped on the one-GPU
+    test box, where the same calls run on gloo with several ranks (test_ranks_sharing_one_gpu_*) and on RCCL with one."""
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    world, d = min(torch.cuda.device_count(), 8), 64
+    mp.spawn(_rccl_multi_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
+    csr = O.build_laplacian(X, gp)
+    lam = O.taumode_lambdas(X, O.build_laplacian(np.ascontiguousarray(cent.T), gp), O.TAU_MEDIAN)
+    Q = X[[1, n // 2, n - 1, 77]] * 1.02
+    for r in [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]:
+        assert int(r["join"]) == 1 or n < 512 * world
+        assert int(r["nnz"]) == len(csr[1])
+        assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
+        np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
+        np.testing.assert_allclose(r["lam"], lam, rtol=1e-12, atol=1e-300)
+        for j in range(4):
+            oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
+            assert np.array_equal(r["idx"][j], oi.astype(np.int64))
+            assert np.array_equal(r["sc"][j], osc)

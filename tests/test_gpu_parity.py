@@ -594,6 +594,52 @@ def test_laplacian_hub_rows_match_oracle(ctx):
     assert int(np.sum(np.diff(indptr) > 65)) >= 20     # and a population of rows in the workgroup form
 
 
+def test_laplacian_row_blocks_stack_to_the_whole_matrix(ctx):
+    """as_laplacian_from_knn_rows (the sharded assembly: every rank its own row block from the gathered table): blocks
+    of consecutive ranges, hub rows and an empty range included, stacked = the CSR of as_laplacian_from_knn."""
+    X, _ = synth.mixture(6000, 32, seed=17, n_clusters=12, rank=4)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    whole = A.laplacian_from_knn(idx, dist, gp).to_host()
+    assert_csr_equal(whole, O.build_laplacian(X, ogp(gp)))
+    n = len(X)
+    for cuts in ([0, 2048, 4096, 6000], [0, 512, 512, 5999, 6000], [0, 6000]):
+        ip, ix, dv, base = [np.zeros(1, dtype=np.uint64)], [], [], 0
+        for a, b in zip(cuts, cuts[1:]):
+            blk = A.laplacian_from_knn(idx, dist, gp, row_begin=a, row_count=b - a)
+            assert blk.shape() == (b - a, n) and blk.row_begin() == a
+            bip, bix, bdv = blk.to_host()
+            assert bip[0] == 0 and len(bip) == b - a + 1
+            ip.append(bip[1:] + np.uint64(base))
+            base += int(bip[-1])
+            ix.append(bix)
+            dv.append(bdv)
+        got = (np.concatenate(ip), np.concatenate(ix), np.concatenate(dv))
+        assert np.array_equal(got[0], whole[0]) and np.array_equal(got[1], whole[1]) and np.array_equal(got[2], whole[2])
+    blk = A.laplacian_from_knn(idx, dist, gp, row_begin=0, row_count=100)
+    with pytest.raises(A.ArrowSpaceError, match="row block"):   # a row block is not a lambda graph
+        A.compute_synthetic_lambda(np.ones(n), blk, 0.5)
+
+
+def test_very_wide_rows_take_the_exact_scan(ctx):
+    """Rows wider than the exact re-rank can stage in LDS (a feature graph over thousands of centroids; build(rows)
+    with every item its own centroid): the MFMA stages are skipped, results are the oracle's."""
+    rng = np.random.default_rng(4)
+    n, d = 600, 6000
+    base = rng.normal(size=(8, d))
+    X = base[rng.integers(0, 8, size=n)] + 0.4 * rng.normal(size=(n, d))
+    gp = A.GraphParams(0.5, 6, 6, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    lam = rng.random(n)
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    res = asp.search_lambda_aware(A.ArrowItem(X[3] * 1.02, 0.4), 5, 0.7)
+    oi, osc = O.search_lambda_aware(X, lam, X[3] * 1.02, 0.4, 5, 0.7)
+    assert [r[0] for r in res] == oi.tolist() and np.array_equal([r[1] for r in res], osc)
+
+
 # ---- clustering pre-stage: batch nearest_centroid (src/clustering.rs:913-928) -----------------------
 
 @pytest.mark.parametrize("n,d,nc", [(5000, 128, 256), (777, 33, 70), (64, 2, 1), (1, 5, 3), (3000, 200, 129), (4097, 16, 64)])
