@@ -30,7 +30,8 @@ EXPORTS = [
 class GraphParamsC(C.Structure):
     _fields_ = [("eps", C.c_double), ("k", C.c_uint64), ("topk", C.c_uint64), ("p", C.c_double),
                 ("sigma", C.c_double), ("has_sigma", C.c_int32), ("normalise", C.c_int32),
-                ("sparsity_check", C.c_int32), ("rectify", C.c_int32)]
+                ("sparsity_check", C.c_int32), ("rectify", C.c_int32), ("self_in_results", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class ArrowSpaceError(RuntimeError):

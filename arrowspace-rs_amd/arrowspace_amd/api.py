@@ -54,13 +54,18 @@ TAU_FLOOR = 1e-10  # src/taumode.rs:84
 class GraphParams:
     """src/graph.rs:94-102 (same field names)."""
 
-    def __init__(self, eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False):
+    def __init__(self, eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False, rectify=False,
+                 self_in_results=False):
         self.eps, self.k, self.topk, self.p = float(eps), int(k), int(topk), float(p)
         self.sigma, self.normalise, self.sparsity_check = sigma, bool(normalise), bool(sparsity_check)
+        # the two CosinePair variants of SURVEY.md Appendix A (not fields of the reference's GraphParams: they select
+        # which reading of the absent smartcore source the library follows; defaults = the oracle's rule set)
+        self.rectify, self.self_in_results = bool(rectify), bool(self_in_results)
 
     def to_c(self):
         return GraphParamsC(self.eps, self.k, self.topk, self.p, 0.0 if self.sigma is None else float(self.sigma),
-                            int(self.sigma is not None), int(self.normalise), int(self.sparsity_check), 0)
+                            int(self.sigma is not None), int(self.normalise), int(self.sparsity_check), int(self.rectify),
+                            int(self.self_in_results), 0)
 
     def __eq__(self, o):  # src/graph.rs:105-121 (sparsity_check and topk are not compared there)
         return (self.k == o.k and np.isclose(self.eps, o.eps) and np.isclose(self.p, o.p) and

@@ -28,14 +28,16 @@ __global__ void any_zero_kernel(const double *__restrict__ v, uint64_t n, int *f
 
 // search_lambda_aware_hybrid merge (src/core.rs:888-923), one thread per query.
 // A = cosine top-k (key = -cos), B = lambda-aware top-k (key = -score); both sorted (key asc, idx asc).
+// ui / us: scratch of 2 kk + 1 entries per query (global memory: k is not bounded by a register array).
 __global__ void hybrid_merge_kernel(const uint32_t *__restrict__ a_idx, const double *__restrict__ a_key,
                                     const uint32_t *__restrict__ b_idx, const double *__restrict__ b_key, uint64_t nq,
-                                    uint32_t kk, uint32_t k_out, uint64_t id_offset, uint64_t *__restrict__ out_idx,
+                                    uint32_t kk, uint32_t k_out, uint64_t id_offset, uint32_t *__restrict__ scratch_i,
+                                    double *__restrict__ scratch_s, uint64_t *__restrict__ out_idx,
                                     double *__restrict__ out_score) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  uint32_t ui[129];
-  double us[129];
+  uint32_t *ui = scratch_i + q * (2 * (uint64_t)kk + 1);
+  double *us = scratch_s + q * (2 * (uint64_t)kk + 1);
   uint32_t m = 0;
   const uint32_t *ai = a_idx + q * kk, *bi = b_idx + q * kk;
   const double *ak = a_key + q * kk, *bk = b_key + q * kk;
@@ -105,10 +107,13 @@ int check_ctx(as_ctx *ctx) {
   return AS_OK;
 }
 
+// K > 64 (topk + 1 beyond the list depth of the MFMA stages) goes straight to the exact scan, which continues in passes
 int knn_dispatch(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d, uint64_t row_begin,
-                 uint64_t row_count, uint32_t K, int rectify, uint32_t *idx, double *dist) {
-  if (ctx->opt_knn_mfma) return knn_mfma(ctx, rows, norms, n, d, row_begin, row_count, K, rectify, idx, dist);
-  return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, idx, dist, 0);
+                 uint64_t row_count, uint32_t K, const as_graph_params *gp, uint32_t *idx, double *dist) {
+  if (ctx->opt_knn_mfma && K <= 64) AS_TRY(knn_mfma(ctx, rows, norms, n, d, row_begin, row_count, K, gp->rectify, idx, dist));
+  else AS_TRY(knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, gp->rectify, idx, dist, 0));
+  if (gp->self_in_results) AS_TRY(apply_self_in_results(ctx, rows, norms, d, row_begin, row_count, K, gp->rectify, idx, dist));
+  return AS_OK;
 }
 
 int validate_graph_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const as_graph_params *gp) {
@@ -119,7 +124,7 @@ int validate_graph_args(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d,
                 "items should be at least of shape (2,2): (" + std::to_string(n) + "," + std::to_string(d) + ")");
   }
   if (n >= 0xFFFFFFFFull || d >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_nodes/dim must be < 2^32-1");
-  if (gp->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  if (gp->topk + 1 > 256) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 256");
   return AS_OK;
 }
 
@@ -298,7 +303,7 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
   AS_TRY(D.bind(ctx, nbr_dist, row_count * K));
   DevOut<uint64_t> I;
   AS_TRY(I.bind(ctx, nbr_idx, row_count * K));
-  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p));
+  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, row_begin, row_count, K, params, idx32.p, D.p));
   hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
                      row_count * K, 0ull, I.p);
   AS_HIP(ctx, hipGetLastError());
@@ -357,7 +362,7 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
 }
 
 int as_knn_join_applies(as_ctx *ctx, uint64_t n_nodes, uint64_t dim, const as_graph_params *params) {
-  if (!ctx || !params || params->normalise || n_nodes >= 0xFFFFFFFFull || dim >= 0xFFFFFFFFull || params->topk + 1 > 64) return 0;
+  if (!ctx || !params || params->normalise || n_nodes >= 0xFFFFFFFFull || dim >= 0xFFFFFFFFull || params->topk + 1 > 64) return 0;  // the join's lists serve K <= 64
   return knn_join_applies(ctx, (uint32_t)n_nodes, (uint32_t)dim) ? 1 : 0;
 }
 
@@ -463,6 +468,8 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
       const JoinSources js{ctx->join.packed, theta_all, n_src, cap / 2, cnt_src, cand_src, second ? ctx->join.theta2 : nullptr,
                            ctx->join.packed16};
       rc = knn_mfma(ctx, rows, ctx->join.norms, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js);
+      if (rc == AS_OK && params->self_in_results)
+        rc = apply_self_in_results(ctx, rows, ctx->join.norms, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p);
     }
     if (rc == AS_OK) {
       hipLaunchKernelGGL(widen_idx_kernel, dim3(cdiv(row_count * K, 256)), dim3(256), 0, ctx->stream, idx32.p,
@@ -483,7 +490,7 @@ int as_laplacian_from_knn_rows(as_ctx *ctx, const uint64_t *nbr_idx, const doubl
   if (!nbr_idx || !nbr_dist || !params || !out) return fail(ctx, AS_ERR_ARG, "null argument");
   if (row_begin + row_count > n_nodes) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
   if (n_nodes < 2 || n_nodes >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad n_nodes");
-  if (params->topk + 1 > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  if (params->topk + 1 > 256) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 256");
   const uint32_t K = (uint32_t)params->topk + 1;
   DevIn<uint64_t> I;
   AS_TRY(I.bind(ctx, nbr_idx, n_nodes * K));
@@ -522,7 +529,7 @@ int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   AS_TRY(idx.alloc(ctx, n_nodes * K));
   AS_TRY(dist.alloc(ctx, n_nodes * K));
   AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
-  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, 0, n_nodes, K, params->rectify, idx.p, dist.p));
+  AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, 0, n_nodes, K, params, idx.p, dist.p));
   AS_TRY(laplacian_from_knn(ctx, idx.p, dist.p, n_nodes, K, params, out, 0, n_nodes));
   return AS_OK;
 }
@@ -742,7 +749,7 @@ int as_search_lambda_aware_hybrid(as_ctx *ctx, const as_index *index, const doub
   if (!index || (nq && (!queries || !q_lambdas))) return fail(ctx, AS_ERR_ARG, "null argument");
   if (nq == 0 || k == 0) return AS_OK;  // src/core.rs:811-813
   if (!idx_out || !score_out) return fail(ctx, AS_ERR_ARG, "null output");
-  if (k > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "hybrid search supports k <= 64");
+  if (k > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "k must be <= 4096");
   const uint64_t d = index->d;
   const uint32_t kk = (uint32_t)std::min<uint64_t>(k, index->n);
   DevIn<double> Q, QL;
@@ -762,8 +769,12 @@ int as_search_lambda_aware_hybrid(as_ctx *ctx, const as_index *index, const doub
   DevOut<uint64_t> I;
   AS_TRY(S.bind(ctx, score_out, nq * k));
   AS_TRY(I.bind(ctx, idx_out, nq * k));
+  DevBuf<uint32_t> ui;
+  DevBuf<double> us;
+  AS_TRY(ui.alloc(ctx, nq * (2 * (uint64_t)kk + 1)));
+  AS_TRY(us.alloc(ctx, nq * (2 * (uint64_t)kk + 1)));
   hipLaunchKernelGGL(hybrid_merge_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, ia.p, ka.p, ib.p, kb.p, nq,
-                     kk, (uint32_t)k, id_offset, I.p, S.p);
+                     kk, (uint32_t)k, id_offset, ui.p, us.p, I.p, S.p);
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(S.finish(ctx));
   AS_TRY(I.finish(ctx));

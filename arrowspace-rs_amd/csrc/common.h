@@ -348,6 +348,10 @@ int knn_exact(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, 
               const uint32_t *row_ids, uint64_t row_begin, uint64_t row_count, uint32_t K,
               int rectify, uint32_t *out_idx, double *out_dist, uint64_t out_stride_rows);
 
+// self_in_results variant of the neighbour rule: post-process of a finished table (knn_exact.hip)
+int apply_self_in_results(as_ctx *ctx, const double *rows, const double *norms, uint64_t d, uint64_t row_begin,
+                          uint64_t row_count, uint32_t K, int rectify, uint32_t *idx, double *dist);
+
 // Candidate lists of a threshold join that has already been run (row-sharded build: every rank contracts
 // the tile pairs of its own super tiles, the lists are exchanged, each rank finishes its own rows).
 struct JoinSources {

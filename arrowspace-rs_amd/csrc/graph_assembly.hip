@@ -10,7 +10,7 @@
 
 namespace asx {
 
-constexpr int kMaxK = 64;
+constexpr int kMaxK = 256;  // neighbours per row of the table (topk + 1)
 
 // ---- device exclusive scan (u32 in, u64 out, out[n] = total) -------------------------------
 constexpr int kScanBlock = 1024;
@@ -107,6 +107,7 @@ __device__ __forceinline__ double kernel_weight(double dist, double sigma, doubl
   return __ddiv_rn(1.0, __dadd_rn(1.0, xp));
 }
 
+template <int KMAX>
 __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist,
                                  uint32_t n, uint32_t K, double eps, double sigma, double p,
                                  const uint32_t *__restrict__ deg,
@@ -117,8 +118,8 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
   if (i >= n) return;
   // avg_degree > 10.0 (src/laplacian.rs:229-230)
   const bool sparsify = ((double)(*deg_sum) / (double)n) > 10.0;
-  uint32_t vj[kMaxK];
-  double vw[kMaxK], vs[kMaxK];
+  uint32_t vj[KMAX];  // K <= KMAX (64 for the usual depths, 256 beyond: per-thread scratch)
+  double vw[KMAX], vs[KMAX];
   uint32_t len = 0;
   for (uint32_t s = 0; s < K; ++s) {
     const uint32_t j = nbr_idx[(uint64_t)i * K + s];
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
 // The CSR that comes out has row_count rows, GLOBAL column ids, indptr starting at 0.
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n64,
                        uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count) {
-  if (K > kMaxK) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 64");
+  if (K > kMaxK) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 256");
   const uint32_t n = (uint32_t)n64;
   if (row_begin + row_count > n64) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
   const uint32_t r0 = (uint32_t)row_begin, nr = (uint32_t)row_count;
@@ -487,8 +488,12 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   {
     ProfScope ps(ctx, "graph_assembly");
     hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
-    hipLaunchKernelGGL(adjacency_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
-                       gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
+    if (K <= 64)
+      hipLaunchKernelGGL(adjacency_kernel<64>, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
+                         gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
+    else
+      hipLaunchKernelGGL(adjacency_kernel<kMaxK>, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
+                         gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
     AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, nr, rev_ptr.p));
     AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));

@@ -84,23 +84,80 @@ int row_norms(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *n
   return AS_OK;
 }
 
+// k > 64 is served by repeated passes, each continuing strictly after the last (distance, index) of the one before
+// (the wave-resident list holds 64 entries), as the search scan does.
 int knn_exact(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,
               const uint32_t *row_ids, uint64_t row_begin, uint64_t row_count, uint32_t K,
               int rectify, uint32_t *out_idx, double *out_dist, uint64_t /*unused*/) {
   if (row_count == 0) return AS_OK;
-  if (K == 0 || K > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be in 1..64");
+  if (K == 0 || K > 256) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be in 1..256");
   DevBuf<int> err;
   AS_TRY(err.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
   GraphDistPolicy pol{norms, rectify};
   const unsigned blocks = (unsigned)std::min<uint64_t>(cdiv(row_count, kScanWaves), 2048);
-  {
+  DevBuf<double> lo_key;
+  DevBuf<uint32_t> lo_idx;
+  for (uint32_t off = 0; off < K; off += 64) {
+    const uint32_t kk = std::min<uint32_t>(64, K - off);
+    const double *lk = nullptr;
+    const uint32_t *li = nullptr;
+    if (off > 0) {  // continue after entry off - 1 of every row (a row that ran out of neighbours keeps +inf / none)
+      if (!lo_key.p) {
+        AS_TRY(lo_key.alloc(ctx, row_count));
+        AS_TRY(lo_idx.alloc(ctx, row_count));
+      }
+      AS_HIP(ctx, hipMemcpy2DAsync(lo_key.p, sizeof(double), out_dist + (off - 1), sizeof(double) * K, sizeof(double), row_count,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+      AS_HIP(ctx, hipMemcpy2DAsync(lo_idx.p, sizeof(uint32_t), out_idx + (off - 1), sizeof(uint32_t) * K, sizeof(uint32_t),
+                                   row_count, hipMemcpyDeviceToDevice, ctx->stream));
+      lk = lo_key.p;
+      li = lo_idx.p;
+    }
     ProfScope ps(ctx, "knn_exact_scan");
     hipLaunchKernelGGL(scan_topk_kernel<GraphDistPolicy>, dim3(blocks), dim3(256), 0, ctx->stream,
                        rows, d, rows, d, (uint32_t)n, (uint32_t)d, row_ids, (uint32_t)row_begin,
-                       (uint32_t)row_count, K, (const double *)nullptr, (const uint32_t *)nullptr, pol,
-                       out_dist, out_idx, K, 0u, err.p);
+                       (uint32_t)row_count, kk, lk, li, pol, out_dist, out_idx, K, off, err.p);
+    AS_HIP(ctx, hipGetLastError());
   }
+  return AS_OK;
+}
+
+// self_in_results (include/arrowspace_hip.h): the row itself competes for one of the K places with its own distance
+// 1 - x.x / (|x||x|) in the reference arithmetic; if it lands inside the first K (ties: lower index) the last
+// neighbour is pushed out.  One thread per row of the table.
+__global__ void self_in_results_kernel(const double *__restrict__ rows, const double *__restrict__ norms, uint64_t d,
+                                       uint64_t row_begin, uint64_t row_count, uint32_t K, int rectify,
+                                       uint32_t *__restrict__ idx, double *__restrict__ dist) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= row_count) return;
+  const uint32_t last = idx[r * K + K - 1];
+  if (last == kNoIdx) return;  // fewer than K other rows: nobody is pushed out
+  const uint64_t i = row_begin + r;
+  double s = 0.0;
+  for (uint64_t c = 0; c < d; ++c) {
+    const double v = rows[i * d + c];
+    s = __dadd_rn(s, __dmul_rn(v, v));
+  }
+  const double denom = __dmul_rn(norms[i], norms[i]);
+  double c = denom > 1e-12 ? __ddiv_rn(s, denom) : 0.0;
+  if (rectify) {
+    c = fmin(fmax(c, -1.0), 1.0);
+    c = fmax(c, 0.0);
+  }
+  const double ds = __dsub_rn(1.0, c);
+  const double dl = dist[r * K + K - 1];
+  if (ds < dl || (ds == dl && (uint32_t)i < last)) {
+    idx[r * K + K - 1] = kNoIdx;
+    dist[r * K + K - 1] = __builtin_inf();
+  }
+}
+
+int apply_self_in_results(as_ctx *ctx, const double *rows, const double *norms, uint64_t d, uint64_t row_begin,
+                          uint64_t row_count, uint32_t K, int rectify, uint32_t *idx, double *dist) {
+  if (row_count == 0) return AS_OK;
+  hipLaunchKernelGGL(self_in_results_kernel, dim3(cdiv(row_count, 256)), dim3(256), 0, ctx->stream, rows, norms, d, row_begin,
+                     row_count, K, rectify, idx, dist);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }

@@ -88,6 +88,9 @@ struct GraphParams {
   std::optional<double> sigma;
   bool normalise = false;
   bool sparsity_check = false;
+  // the two CosinePair variants of SURVEY.md Appendix A (not fields of the reference's struct; defaults = the oracle's rules)
+  bool rectify = false;
+  bool self_in_results = false;
   as_graph_params to_c() const {
     as_graph_params c{};
     c.eps = eps;
@@ -98,7 +101,9 @@ struct GraphParams {
     c.has_sigma = sigma.has_value();
     c.normalise = normalise;
     c.sparsity_check = sparsity_check;
-    c.rectify = 0;
+    c.rectify = rectify ? 1 : 0;
+    c.self_in_results = self_in_results ? 1 : 0;
+    c.reserved = 0;
     return c;
   }
 };

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AS_ABI_VERSION 1
+#define AS_ABI_VERSION 2
 
 typedef enum {
   AS_OK = 0,
@@ -42,7 +42,7 @@ typedef enum {
   AS_ERR_DIM = 5,         /* graph has more nodes than the signal has entries (src/taumode.rs:570-575 would index out of bounds); query dimension mismatch src/core.rs:510-516 */
   AS_ERR_TOO_SPARSE = 6,  /* "Resulting laplacian matrix is too sparse" src/graph.rs:185-193 */
   AS_ERR_ARG = 7,         /* null pointer / bad enum / unsupported size */
-  AS_ERR_UNSUPPORTED = 8, /* outside the accelerated path (e.g. topk + 1 > 64, hybrid k > 64) */
+  AS_ERR_UNSUPPORTED = 8, /* outside the accelerated path (e.g. topk + 1 > 256, k > 4096) */
   AS_ERR_HIP = 9,         /* HIP runtime failure; text in as_last_error */
   AS_ERR_NO_DEVICE = 10   /* no gfx950 device: there is no CPU fallback */
 } as_status;
@@ -61,6 +61,12 @@ typedef struct {
   int32_t normalise;      /* 1: per-column z-score first (StandardScaler, src/laplacian.rs:146-151; population variance, zero std -> 1: smartcore's convention is unpinned) */
   int32_t sparsity_check; /* carried for the host-side GraphFactory check (src/graph.rs:185-193) */
   int32_t rectify;        /* 0: distance = 1 - cos (default).  1: 1 - max(0, cos) */
+  /* smartcore's CosinePair (source absent) either leaves the query row out of
+   * query_row_top_k(i, topk + 1) or returns it as its own nearest neighbour; the reference then filters i != j
+   * (src/laplacian.rs:224,252), so a node keeps up to topk + 1 neighbours in the first case (0, default) and up to topk
+   * in the second (1: the row competes with its own distance 1 - x.x / (|x||x|) for one of the topk + 1 places). */
+  int32_t self_in_results;
+  int32_t reserved;       /* 0 */
 } as_graph_params;
 
 typedef struct as_ctx as_ctx;     /* device, stream, workspace */
@@ -234,7 +240,7 @@ int as_search_lambda_aware(as_ctx *ctx, const as_index *index, const double *que
 /* Batched ArrowSpace::search_lambda_aware_hybrid, src/core.rs:802-928: per query the union of
  * (a) every item with cosine > 0.9999 (score = cosine), (b) the lambda-aware top-k (blended score
  * unless already in (a)), (c) the best-cosine item; sorted by score descending (ties: lower index),
- * truncated to k.  No zero-lambda check (the reference has none here).  k <= 64. */
+ * truncated to k.  No zero-lambda check (the reference has none here).  k <= 4096. */
 int as_search_lambda_aware_hybrid(as_ctx *ctx, const as_index *index, const double *queries,
                                   const double *q_lambdas, uint64_t nq, uint64_t k, double alpha,
                                   uint64_t id_offset, uint64_t *idx_out, double *score_out);

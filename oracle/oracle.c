@@ -78,6 +78,20 @@ static double *standardise(const double *rows, uint64_t n, uint64_t d) {
   return out;
 }
 
+
+/* self_in_results: the query row takes part in the ranking with its own distance,
+ * 1 - x.x / (|x||x|) in the same arithmetic (not exactly 0), ties by index; if it lands inside the first K it is
+ * dropped afterwards (src/laplacian.rs:224,252 filter i != j), which leaves K - 1 neighbours. */
+static void apply_self_in_results(const double *R, uint64_t d, const double *norms, uint64_t i, int rectify, uint64_t K,
+                                  uint64_t cnt, uint64_t *bi, double *bd) {
+  if (cnt < K) return; /* fewer than K other rows exist: the row pushes nobody out */
+  const double ds = graph_distance(row_dot(R + i * d, R + i * d, d), norms[i], norms[i], rectify);
+  if (ds < bd[K - 1] || (ds == bd[K - 1] && i < bi[K - 1])) {
+    bi[K - 1] = UINT64_MAX;
+    bd[K - 1] = INFINITY;
+  }
+}
+
 /* K2: per node the first (topk+1) candidates j != i ordered by (distance asc, index asc).
  * src/laplacian.rs:211,221,246 via CosinePair; ordering of src/tests/test_helpers.rs:115-119 */
 static int knn_core(const double *R, uint64_t n, uint64_t d, const aso_graph_params *p,
@@ -112,6 +126,7 @@ static int knn_core(const double *R, uint64_t n, uint64_t d, const aso_graph_par
       bi[s] = UINT64_MAX;
       bd[s] = INFINITY;
     }
+    if (p->self_in_results) apply_self_in_results(R, d, norms, i, rectify, K, cnt, bi, bd);
   }
   free(norms);
   return ASO_OK;
@@ -151,6 +166,7 @@ int aso_knn_cosine_rows(const double *R, uint64_t n, uint64_t d, const aso_graph
       bi[s] = UINT64_MAX;
       bd[s] = INFINITY;
     }
+    if (p->self_in_results) apply_self_in_results(R, d, norms, i, rectify, K, cnt, bi, bd);
   }
   free(norms);
   return ASO_OK;

@@ -39,6 +39,10 @@ typedef struct {
   int32_t normalise;      /* StandardScaler z-score (src/laplacian.rs:146-151); parity unpinned */
   int32_t sparsity_check; /* src/graph.rs:185-193, enforced by the factory, not here */
   int32_t rectify;        /* 0: dist = 1 - cos (default); 1: dist = 1 - max(0, cos) */
+  int32_t self_in_results; /* 0 (default): query_row_top_k does not return the query row, up to
+                            * topk + 1 neighbours; 1: it does (the row itself competes for one of the topk + 1 places
+                            * with its own distance and is then dropped by the caller's i != j: src/laplacian.rs:224,252) */
+  int32_t reserved;
 } aso_graph_params;
 
 typedef struct {

@@ -43,6 +43,8 @@ class GraphParams(C.Structure):
         ("normalise", C.c_int32),
         ("sparsity_check", C.c_int32),
         ("rectify", C.c_int32),
+        ("self_in_results", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -110,9 +112,9 @@ def _f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
-def graph_params(eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False, rectify=False):
+def graph_params(eps, k, topk, p, sigma=None, normalise=False, sparsity_check=False, rectify=False, self_in_results=False):
     return GraphParams(eps, k, topk, p, 0.0 if sigma is None else sigma, int(sigma is not None),
-                       int(normalise), int(sparsity_check), int(rectify))
+                       int(normalise), int(sparsity_check), int(rectify), int(self_in_results), 0)
 
 
 def _wrap_csr(n, indptr, indices, data):

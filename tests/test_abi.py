@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_messages():
     lib = A.load()
-    assert lib.as_abi_version() == 1
+    assert lib.as_abi_version() == 2
     # the reference's panic texts travel through the boundary verbatim
     assert lib.as_status_message(_lib.AS_ERR_ZERO_LAMBDA).decode() == \
         "Lambda of the item is 0.0, prepare the item before searching"  # src/core.rs:773-776
@@ -73,3 +73,22 @@ def test_host_mirror_names():
     assert (d.lambda_eps, d.lambda_k, d.lambda_topk, d.lambda_p, d.lambda_sigma) == (1e-3, 6, 3, 2.0, None)
     d.define_result_k()
     assert d.lambda_topk == 4
+
+
+def test_rust_extern_block_lists_every_export():
+    """the `extern "C"` block a maintainer of the reference crate adds
+    (arrowspace-rs_amd/host/rust/src/hip.rs, generated from the header, not compiled here: no rustc in the image)
+    declares exactly the header's exports, and the committed file is what the generator produces."""
+    import subprocess
+    import sys
+    rs = open(os.path.join(ROOT, "arrowspace-rs_amd", "host", "rust", "src", "hip.rs")).read()
+    declared = sorted(set(re.findall(r"pub fn (as_[a-z0-9_]+)\(", rs)))
+    assert declared == _header_symbols()
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_rust_bindings.py"), "--check"]) == 0
+    # the parameter struct has the header's fields in the header's order
+    hdr = open(os.path.join(ROOT, "include", "arrowspace_hip.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} as_graph_params;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = re.findall(r"\b(\w+);", body)
+    rs_fields = re.findall(r"pub (\w+):", re.search(r"pub struct AsGraphParams \{(.*?)\n\}", rs, flags=re.S).group(1))
+    assert c_fields == rs_fields == [f[0] for f in _lib.GraphParamsC._fields_]

@@ -594,6 +594,50 @@ def test_laplacian_hub_rows_match_oracle(ctx):
     assert int(np.sum(np.diff(indptr) > 65)) >= 20     # and a population of rows in the workgroup form
 
 
+def test_self_in_results_variant_matches_oracle(ctx, mode):
+    """The second CosinePair reading of SURVEY.md Appendix A as a flag (as_graph_params.self_in_results): tables and
+    Laplacian equal the oracle's with the same flag; duplicates (places go by index) and a zero row included."""
+    X, _ = synth.mixture(1400, 24, seed=9, n_clusters=8, rank=3)
+    X[:7] = X[0]
+    X[50] = 0.0
+    gp = A.GraphParams(0.5, 6, 4, 2.0, 0.25, self_in_results=True)
+    og = O.graph_params(0.5, 6, 4, 2.0, 0.25, self_in_results=True)
+    idx, dist = A.knn_cosine(X, gp)
+    oi, od = O.knn_cosine(X, og)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert (idx[:, -1] == np.uint64(A.api.U64_MAX)).sum() > 1000      # generic rows keep topk neighbours, not topk + 1
+    assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, og))
+
+
+def test_deep_neighbour_lists_take_the_exact_scan(ctx):
+    """topk + 1 beyond the 64 entries the MFMA stages keep per row: the exact scan continues in passes of 64
+    (AS_ERR_UNSUPPORTED before), the assembly takes rows of up to 256 neighbours."""
+    X, _ = synth.mixture(900, 16, seed=12, n_clusters=4, rank=3)
+    for topk in (70, 130):
+        gp = A.GraphParams(0.8, 20, topk, 2.0, 0.5)
+        idx, dist = A.knn_cosine(X, gp)
+        oi, od = O.knn_cosine(X, ogp(gp))
+        assert idx.shape == (900, topk + 1)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+        assert_csr_equal(A.build_laplacian_matrix(X, gp).matrix.to_host(), O.build_laplacian(X, ogp(gp)))
+    with pytest.raises(A.ArrowSpaceError, match="256"):
+        A.knn_cosine(X, A.GraphParams(0.8, 20, 300, 2.0, 0.5))
+
+
+def test_hybrid_search_beyond_64(ctx):
+    X, _ = synth.mixture(1500, 48, seed=8, n_clusters=10, rank=4)
+    X = np.concatenate([X, X[:20] * 1.000001])
+    lam = np.linspace(0.02, 0.95, len(X))
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    for j, lq, k in ((3, 0.4, 65), (7, 0.11, 200)):
+        q = X[j] * 1.02
+        got = asp.search_lambda_aware_hybrid(A.ArrowItem(q, lq), k, 0.7)
+        oi, osc = O.search_lambda_aware_hybrid(X, lam, q, lq, k, 0.7)
+        assert [g[0] for g in got] == oi.tolist(), (j, k)
+        assert np.array_equal([g[1] for g in got], osc), (j, k)
+
+
 def test_laplacian_row_blocks_stack_to_the_whole_matrix(ctx):
     """as_laplacian_from_knn_rows (the sharded assembly: every rank its own row block from the gathered table): blocks
     of consecutive ranges, hub rows and an empty range included, stacked = the CSR of as_laplacian_from_knn."""

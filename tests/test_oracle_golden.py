@@ -367,3 +367,22 @@ def test_nearest_centroids_restatement():
         assert idx[r] == bi and (d2[r] == best)
     assert idx[4] == 3 and d2[4] == 0.0 and idx[9] == 0 and d2[9] == np.inf
 
+
+
+def test_self_in_results_variant():
+    """SURVEY.md Appendix A, second reading of CosinePair::query_row_top_k: the query row is among the topk + 1 results
+    (and is then dropped by the reference's `i != j`, src/laplacian.rs:224,252).  On generic rows the row is its own
+    nearest neighbour, so every node keeps the first topk of the default table; among exact duplicates the places go by
+    index, so a row with topk + 1 duplicates of lower index keeps all topk + 1."""
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(60, 7))
+    X[:6] = X[0]                      # rows 0..5 identical
+    topk = 3
+    base = O.knn_cosine(X, O.graph_params(0.9, 6, topk, 2.0, 0.5))
+    flag = O.knn_cosine(X, O.graph_params(0.9, 6, topk, 2.0, 0.5, self_in_results=True))
+    none = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for i in range(6, 60):            # generic rows: one neighbour fewer
+        assert np.array_equal(flag[0][i, :topk], base[0][i, :topk]) and flag[0][i, topk] == none
+    assert flag[0][0, topk] == none and np.array_equal(flag[0][0, :topk], [1, 2, 3])   # row 0 is inside its own top 4
+    assert np.array_equal(flag[0][5], [0, 1, 2, 3])   # row 5: four duplicates of lower index come first
+    assert np.array_equal(flag[0][4], base[0][4]) and flag[0][4, topk] == 3             # row 4: duplicates 0..3 tie, 4 > 3
