@@ -223,6 +223,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_pipe") ctx->opt_join_pipe = (value == 32 || value == 48) ? value : 16;
   else if (n == "join_block") ctx->opt_join_block = value;
   else if (n == "search_scan") ctx->opt_search_scan = value;
+  else if (n == "stream_scan") ctx->opt_stream_scan = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
   else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;
   else if (n == "search_scan_cap") ctx->opt_search_scan_cap = value;

@@ -65,6 +65,7 @@ struct as_ctx {
   int64_t opt_search_scan_rank = 3;
   int64_t opt_search_scan_cap = 512;     // candidate slots per query
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
+  int64_t opt_stream_scan = 1;    // small batches / leftover rows: one exact pass over the matrix (stream_scan.hip)
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // Sharded join sequence (as_knn_join_thresholds -> _pairs -> _finish over the same `rows`): norms and the packed
@@ -402,6 +403,9 @@ int search_exact(as_ctx *ctx, const as_index *ix, const double *queries, const d
 int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms,
                 const double *q_lambdas, uint64_t nq, uint32_t k, double alpha, uint32_t *out_idx,
                 double *out_score);
+
+// exact scan of a few rows (<= 32 per pass) against all rows in one pass at HBM speed (stream_scan.hip), dim 128
+bool stream_scan_applies(uint64_t nA, uint64_t nB, uint64_t d, uint32_t K);
 
 // device exclusive scan of uint32 -> uint64 (out has n+1 entries, out[n] = total)
 int exclusive_scan_u32_u64(as_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out);

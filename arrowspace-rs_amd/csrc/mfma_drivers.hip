@@ -615,6 +615,11 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
 int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count,
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
+int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids, uint32_t nq, const double *items, uint32_t n, uint32_t K,
+                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
+int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
+                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
+constexpr uint32_t kStreamRowsMax = 128;  // leftover rows up to this many take the streaming exact scan, 32 per pass
 
 int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
               uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
@@ -1197,6 +1202,48 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     if (cur_n == 0) return AS_OK;
   }
 
+  // ---- a handful of rows left: one exact pass over the matrix per 32 of them (stream_scan.hip) instead of MFMA sweeps ----
+  if (ctx->opt_stream_scan && cur_n <= kStreamRowsMax && stream_scan_applies(std::min<uint32_t>(cur_n, 32), n, d, K)) {
+    DevBuf<double> fk;
+    DevBuf<uint32_t> fi, redo_ids, redo_pos_d;
+    AS_TRY(fk.alloc(ctx, (size_t)cur_n * K));
+    AS_TRY(fi.alloc(ctx, (size_t)cur_n * K));
+    std::vector<uint32_t> redo_all;
+    for (uint32_t c0 = 0; c0 < cur_n; c0 += 32) {
+      const uint32_t cn = std::min<uint32_t>(32, cur_n - c0);
+      std::vector<uint32_t> redo;
+      AS_TRY(stream_scan_graph(ctx, rows, cur_ids + c0, cn, n, K, pol, fk.p + (size_t)c0 * K, fi.p + (size_t)c0 * K, err.p, &redo));
+      for (uint32_t r : redo) redo_all.push_back(c0 + r);
+    }
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)cur_n * K, 256)), dim3(256), 0, ctx->stream, cur_pos, cur_n, K, fk.p,
+                       fi.p, out_dist, out_idx);
+    AS_HIP(ctx, hipGetLastError());
+    ctx->stats["knn_stream_scan_rows"] = cur_n;
+    if (redo_all.empty()) return AS_OK;
+    // rows whose candidate list overflowed (a sample that misses their neighbourhood): the exact scan, below
+    AS_TRY(redo_pos_d.alloc(ctx, redo_all.size()));
+    AS_HIP(ctx, copy_h2d(ctx, redo_pos_d.p, redo_all.data(), sizeof(uint32_t) * redo_all.size()));
+    const uint32_t nr = (uint32_t)redo_all.size();
+    AS_TRY(ids_r.alloc(ctx, nr));
+    AS_TRY(pos_r.alloc(ctx, nr));
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nr, 256)), dim3(256), 0, ctx->stream, cur_ids, redo_pos_d.p, nr, 0u, ids_r.p);
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nr, 256)), dim3(256), 0, ctx->stream, cur_pos, redo_pos_d.p, nr, 0u, pos_r.p);
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cur_ids = ids_r.p;
+    cur_pos = pos_r.p;
+    cur_n = nr;
+    DevBuf<double> fk2;
+    DevBuf<uint32_t> fi2;
+    AS_TRY(fk2.alloc(ctx, (size_t)cur_n * K));
+    AS_TRY(fi2.alloc(ctx, (size_t)cur_n * K));
+    AS_TRY(knn_exact(ctx, rows, norms, n, d, cur_ids, 0, cur_n, K, rectify, fi2.p, fk2.p, 0));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)cur_n * K, 256)), dim3(256), 0, ctx->stream, cur_pos, cur_n, K, fk2.p,
+                       fi2.p, out_dist, out_idx);
+    AS_HIP(ctx, hipGetLastError());
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AS_OK;
+  }
+
   // ---- stage 1b (after the join): f32 top-k pass over the gathered rows ----
   if (use_join && !exact_direct(cur_n, n)) {
     AS_TRY(mfma_stage(true, ids_a, pos_a, "knn_uncertified_rows_stage1b"));
@@ -1275,6 +1322,25 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const bool mfma_ok = !((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows);
   if (nq == 0 || n < 4 * kTileRows || !rerank_fits(d))
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
+  // one query or a small batch: the bandwidth-bound regime.  One exact pass over the items (stream_scan.hip), no
+  // candidate stages, nothing to certify.
+  if (ctx->opt_stream_scan && stream_scan_applies(nq, n, d, K) && K == k) {
+    DevBuf<int> err0;
+    AS_TRY(err0.alloc(ctx, 1));
+    AS_HIP(ctx, hipMemsetAsync(err0.p, 0, sizeof(int), ctx->stream));
+    SearchScorePolicy pol0{q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
+    std::vector<uint32_t> redo;
+    AS_TRY(stream_scan_search(ctx, queries, nullptr, nq, ix->items, n, K, pol0, out_key, out_idx, err0.p, &redo));
+    int h_err0 = 0;
+    AS_HIP(ctx, copy_d2h(ctx, &h_err0, err0.p, sizeof(int)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err0) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
+    ctx->stats["search_scan"] = 0;
+    ctx->stats["search_stream_scan"] = 1;
+    if (redo.empty()) return AS_OK;
+    // a candidate list overflowed (a sample that misses the query's neighbourhood): the whole batch takes the staged path
+  }
+  else ctx->stats["search_stream_scan"] = 0;
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   auto ensure64 = [&]() -> int {

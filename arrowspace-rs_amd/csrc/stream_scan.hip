@@ -1,0 +1,463 @@
+// stream_scan.hip -- exact scan of a FEW rows against all rows in one pass over the matrix at HBM speed.
+//
+// The bandwidth-bound regime of K9 (ArrowSpace::search_lambda_aware for one query or a small batch,
+// src/core.rs:760-798: every call reads all N items, N (8 D + 8) bytes) and the tail of K2 (the handful of graph rows
+// the MFMA stages cannot certify).  The MFMA pipeline (guesses, threshold scan, re-rank, certification) is built for
+// thousands of rows per call: at one query its launches and host round trips cost 1.4 ms for 1 GB of items.  Here the
+// scores are the EXACT ones from the start -- the reference's sequential f64 multiply / add chain over k (scan_topk.h
+// policies) -- so there is nothing to certify:
+//   1. sample pass   exact keys of every A row against 1 in 16 of the 8-row tiles of B (a hashed pick per 16 tiles);
+//   2. guess         g_a = the K-th smallest sampled key of row a.  The K-th smallest key over ALL of B is <= g_a, so
+//                    every member of the true top K has key <= g_a: a guaranteed superset, not a heuristic;
+//   3. list pass     all of B once: (column, key) with key <= g_a appended to row a's list (~16 K entries);
+//   4. final         per row, the listed entries ordered by (key, column), the first K written.
+// A list that overflows (a sample that misses the good region entirely: ordered data) is reported and the caller
+// takes the old path for that row.
+//
+// Geometry (dim 128, rows of 1 KB): 6 waves per workgroup, a wave owns tiles of 8 B rows which arrive by LDS-DMA (one
+// global_load_lds per row, whole cache lines, 1040-B pitch) into a 2-deep ring: ~100 KB in flight per CU.  Eight lanes
+// share a B row and split the A rows (lane s takes rows s, s + 8, ...: up to 4 accumulators); B values are LDS
+// broadcasts, A values come from an LDS copy of the A rows at the same pitch (8 rows per read, 32 distinct banks).
+#include <type_traits>
+
+#include "scan_topk.h"
+
+namespace asx {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void ss_lds_void;
+typedef const __attribute__((address_space(1))) void ss_gbl_void;
+
+constexpr int kSsWaves = 6;
+constexpr int kSsTile = 8;            // B rows per wave tile
+constexpr int kSsPitchB = 1040;       // bytes between staged B rows
+constexpr int kSsPitchA = 1040;       // bytes between A rows (16-B aligned rows, 4 banks apart)
+constexpr int kSsMaxA = 32;           // A rows per launch
+constexpr uint32_t kSsSampleStride = 16;  // 1 in 16 tiles is sampled
+constexpr uint32_t kSsD = 128;
+constexpr uint32_t kSsShares = 4096;  // running minima per A row in the sample pass (disjoint shares of the sample)
+
+__global__ void fill_u64_kernel(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ uint32_t ss_lds_addr(const void *p) { return (uint32_t)(size_t)(ss_lds_void *)p; }
+template <int B, int E, class F>
+__device__ __forceinline__ void ss_static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    ss_static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ void ss_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// order-preserving map of a double onto uint64 (ascending) and back
+__device__ __forceinline__ unsigned long long ss_orderable(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ss_from_orderable(unsigned long long u) {
+  const unsigned long long b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+  return __longlong_as_double((long long)b);
+}
+
+// LIST = false: sample pass, 4096 running minima per row over disjoint shares of the sampled columns.
+// LIST = true: list pass over all tiles, entries with key <= guess[a] to list[a].
+// LDS reads of the chain are issued by hand: behind a pending LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of
+// every LDS read it generates itself (the DMA is a pending LDS write it cannot tell apart), which drained the whole ring
+// before each tile: one tile in flight instead of NBUF - 1 (2.6 TB/s).
+template <int OFF>
+__device__ __forceinline__ void ss_lds_read16(double2 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void ss_lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // consumers of the registers just waited for stay behind the wait
+}
+
+// The per-row operands of the policies (norms, lambdas) without a plain global load inside the sweep: a plain load
+// issued behind the DMA of the next tiles cannot complete before them (vmcnt retires in order), so waiting for it
+// would drain the ring.  The B-side values ride with the tile (one more DMA piece: 8 norms + 8 lambdas), the A-side
+// values are read once before the sweep.
+template <class Policy>
+struct StreamOperands;
+template <>
+struct StreamOperands<SearchScorePolicy> {
+  static constexpr bool kLambda = true;
+  double qn, ql;  // of one A row
+  __device__ __forceinline__ void load_a(const SearchScorePolicy &p, uint32_t ga) {
+    qn = p.q_norms[ga];
+    ql = p.q_lambdas[ga];
+  }
+  __device__ static __forceinline__ const double *b_norms(const SearchScorePolicy &p) { return p.x_norms; }
+  __device__ static __forceinline__ const double *b_lambdas(const SearchScorePolicy &p) { return p.x_lambdas; }
+  // the arithmetic of SearchScorePolicy::key (scan_topk.h), operands passed by value
+  __device__ __forceinline__ bool key(const SearchScorePolicy &p, double dot, uint32_t, uint32_t, double xn, double xl, double &out,
+                                      int *err) const {
+    const double denom = __dmul_rn(qn, xn);
+    const double c = denom > 0.0 ? __ddiv_rn(dot, denom) : 0.0;
+    const double diff = fabs(__dsub_rn(ql, xl));
+    const double lam = __dsub_rn(1.0, fmin(diff, 1.0));
+    const double sc = __dadd_rn(__dmul_rn(p.alpha, c), __dmul_rn(__dsub_rn(1.0, p.alpha), lam));
+    if (sc != sc) {
+      atomicOr(err, 1);
+      return false;
+    }
+    out = -sc;
+    return true;
+  }
+};
+template <>
+struct StreamOperands<GraphDistPolicy> {
+  static constexpr bool kLambda = false;
+  double na;
+  __device__ __forceinline__ void load_a(const GraphDistPolicy &p, uint32_t ga) { na = p.norms[ga]; }
+  __device__ static __forceinline__ const double *b_norms(const GraphDistPolicy &p) { return p.norms; }
+  __device__ static __forceinline__ const double *b_lambdas(const GraphDistPolicy &) { return nullptr; }
+  // the arithmetic of GraphDistPolicy::key
+  __device__ __forceinline__ bool key(const GraphDistPolicy &p, double dot, uint32_t a, uint32_t j, double nj, double, double &out,
+                                      int *) const {
+    if (a == j) return false;
+    const double denom = __dmul_rn(na, nj);
+    double c = denom > 1e-12 ? __ddiv_rn(dot, denom) : 0.0;
+    if (p.rectify) {
+      c = fmin(fmax(c, -1.0), 1.0);
+      c = fmax(c, 0.0);
+    }
+    out = __dsub_rn(1.0, c);
+    return !(out != out);
+  }
+};
+
+constexpr int kSsTileBytes = kSsTile * kSsPitchB + 128;  // 8 rows + 8 norms + 8 lambdas
+constexpr int kSsPieces = kSsTile + 1;                   // DMA instructions per tile
+
+// G = accumulators per lane = ceil(nA / 8): lane s holds the A rows s, s + 8, ...
+template <class Policy, bool LIST, int NBUF, int G>
+__global__ __launch_bounds__(kSsWaves * 64) void stream_scan_d128_kernel(
+    const double *__restrict__ A, const uint32_t *__restrict__ a_ids, uint32_t a_begin, uint32_t nA,
+    const double *__restrict__ B, uint32_t nB, uint32_t n_tiles, Policy pol, unsigned long long *__restrict__ sample_min,
+    const double *__restrict__ guess, uint32_t cap, uint32_t *__restrict__ cnt,
+    uint32_t *__restrict__ list_idx, double *__restrict__ list_key, int *__restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [A rows: 8 ceil(nA / 8) x 1040][per wave: NBUF tiles]   (NBUF = 3 while the A rows leave room: nA <= 8)
+  unsigned char *sA = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char *ring = smem + (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)wv * NBUF * kSsTileBytes;
+  for (uint32_t e = tid; e < nA * kSsD; e += blockDim.x) {
+    const uint32_t a = e / kSsD, k = e - a * kSsD;
+    const uint32_t ga = a_ids ? a_ids[a] : a_begin + a;
+    *reinterpret_cast<double *>(sA + (size_t)a * kSsPitchA + (size_t)k * 8) = A[(uint64_t)ga * kSsD + k];
+  }
+  const int item = lane >> 3, s = lane & 7;
+  uint32_t ga[G];
+  StreamOperands<Policy> ops[G];
+  double my_guess[G];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const uint32_t a = (uint32_t)s + 8u * q;
+    ga[q] = a < nA ? (a_ids ? a_ids[a] : a_begin + a) : 0u;
+    ops[q].load_a(pol, ga[q]);
+    my_guess[q] = (LIST && a < nA) ? guess[a] : 0.0;
+  }
+  __syncthreads();  // (also: every plain global load above has been waited for before the first DMA is issued)
+  const double *b_norms = StreamOperands<Policy>::b_norms(pol);
+  const double *b_lams = StreamOperands<Policy>::b_lambdas(pol);
+  // this wave's tiles: all of them (LIST) or one in kSsSampleStride (sample), dealt round-robin over the waves of the grid
+  const uint32_t n_my = LIST ? n_tiles : (n_tiles + kSsSampleStride - 1) / kSsSampleStride;
+  const uint32_t wave_id = blockIdx.x * kSsWaves + wv, n_waves = gridDim.x * kSsWaves;
+  // sampled tile of group t: a hashed member of tiles [16 t, 16 t + 16) -- a plain stride aliases with periodic row
+  // orders (rows dealt round-robin over clusters: every sampled row would come from the same few clusters)
+  auto tile_of = [&](uint32_t t) -> uint32_t {
+    if (LIST) return t;
+    uint32_t h = t * 0x9E3779B9u;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    const uint32_t pick = t * kSsSampleStride + (h & (kSsSampleStride - 1));
+    return pick < n_tiles ? pick : t * kSsSampleStride;
+  };
+  // kSsPieces DMA instructions per tile, always (rows past the end of B are clamped to its last row: their keys are
+  // never used), so that the vmcnt arithmetic below is exact
+  auto issue = [&](uint32_t t, int buf) {
+    const uint32_t row0 = tile_of(t) * kSsTile;
+    unsigned char *dst = ring + (size_t)buf * kSsTileBytes;
+#pragma unroll
+    for (int r = 0; r < kSsTile; ++r) {
+      const uint32_t row = min(row0 + (uint32_t)r, nB - 1);
+      __builtin_amdgcn_global_load_lds((ss_gbl_void *)((const char *)(B + (uint64_t)row * kSsD) + lane * 16),
+                                       (ss_lds_void *)(dst + r * kSsPitchB), 16, 0, 0);
+    }
+    if (lane < 8) {  // lanes 0-3: the 8 norms, lanes 4-7: the 8 lambdas (two doubles per lane; the other lanes are masked off)
+      // a partial last tile reads a safe address instead (its operands are fetched by plain loads, below)
+      const uint32_t r2 = row0 + kSsTile <= nB ? row0 + 2u * (uint32_t)(lane & 3) : 0u;
+      const double *src = (lane < 4 || !StreamOperands<Policy>::kLambda) ? b_norms + r2 : b_lams + r2;
+      __builtin_amdgcn_global_load_lds((ss_gbl_void *)src, (ss_lds_void *)(dst + kSsTile * kSsPitchB), 16, 0, 0);
+    }
+  };
+  // NBUF - 1 tiles are in flight while one is being consumed
+  uint32_t t = wave_id;
+  int buf = 0;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p)
+    if (t + (uint32_t)p * n_waves < n_my) issue(t + (uint32_t)p * n_waves, p);
+  for (; t < n_my; t += n_waves) {
+    const uint32_t t_pre = t + (uint32_t)(NBUF - 1) * n_waves;
+    if (t_pre < n_my) issue(t_pre, (buf + NBUF - 1) % NBUF);
+    // tile t has landed once only the pieces of the younger tiles are in flight: `ahead` of them were issued
+    uint32_t ahead = 0;
+#pragma unroll
+    for (int p = 1; p < NBUF; ++p) ahead += (t + (uint32_t)p * n_waves < n_my) ? 1u : 0u;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(kSsPieces == 9 && NBUF <= 3, "the vmcnt constants above are kSsPieces x tiles ahead");
+    const unsigned char *tile = ring + (size_t)buf * kSsTileBytes;
+    const unsigned char *xrow = tile + (size_t)item * kSsPitchB;
+    double acc[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) acc[q] = 0.0;
+    // the reference's chain: k ascending, multiply and add rounded separately (src/core.rs:185-197).  Chunks of 2 H k:
+    // the B values and the A values of every accumulator go to registers first (LDS latency once per chunk, not once
+    // per step of the dependent add chain); two register sets alternate, the next chunk's reads fly during this one's
+    // arithmetic.
+    constexpr int H = G == 1 ? 8 : (G == 2 ? 4 : 2);  // double2 per chunk and operand (register budget: 2 sets x (1 + G) x H x 4)
+    struct Set {
+      double2 x[H];
+      double2 a[G][H];
+    };
+    const uint32_t x_addr = ss_lds_addr(xrow), a_addr = ss_lds_addr(sA) + (uint32_t)s * kSsPitchA;
+    auto load = [&](Set &R, uint32_t k0) {
+      ss_static_for<0, H>([&](auto h_c) {
+        constexpr int h = decltype(h_c)::value;
+        ss_lds_read16<h * 16>(R.x[h], x_addr + k0 * 8u);
+      });
+      ss_static_for<0, G * H>([&](auto e_c) {
+        constexpr int q = decltype(e_c)::value / H, h = decltype(e_c)::value % H;
+        ss_lds_read16<q * 8 * kSsPitchA + h * 16>(R.a[q][h], a_addr + k0 * 8u);
+      });
+    };
+    auto compute = [&](const Set &R) {
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          acc[q] = __dadd_rn(acc[q], __dmul_rn(R.a[q][h].x, R.x[h].x));
+          acc[q] = __dadd_rn(acc[q], __dmul_rn(R.a[q][h].y, R.x[h].y));
+        }
+    };
+    Set ra, rb;
+    // the policy operands of this lane's B row: norm and lambda, staged behind the rows
+    double2 meta;  // (norm, lambda)
+    {
+      double2 nn, ll;
+      ss_lds_read16<0>(nn, ss_lds_addr(tile + kSsTile * kSsPitchB) + (uint32_t)(item >> 1) * 16u);
+      ss_lds_read16<64>(ll, ss_lds_addr(tile + kSsTile * kSsPitchB) + (uint32_t)(item >> 1) * 16u);
+      load(ra, 0);
+      ss_lds_wait_all();
+      meta.x = (item & 1) ? nn.y : nn.x;
+      meta.y = (item & 1) ? ll.y : ll.x;
+    }
+    if ((tile_of(t) + 1) * kSsTile > nB) {  // the partial last tile of B (wave-uniform, once per sweep): plain loads
+      const uint32_t jj = min(tile_of(t) * kSsTile + (uint32_t)item, nB - 1);
+      meta.x = b_norms[jj];
+      if (StreamOperands<Policy>::kLambda) meta.y = b_lams[jj];
+    }
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < kSsD; k0 += 4 * H) {
+      ss_lds_wait_all();
+      load(rb, k0 + 2 * H);
+      compute(ra);
+      ss_lds_wait_all();
+      if (k0 + 4 * H < kSsD) load(ra, k0 + 4 * H);
+      compute(rb);
+    }
+    const uint32_t j = tile_of(t) * kSsTile + (uint32_t)item;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const uint32_t a = (uint32_t)s + 8u * q;
+      if (a < nA && j < nB) {
+        double key;
+        const bool valid = ops[q].key(pol, acc[q], ga[q], j, meta.x, meta.y, key, err_flag);
+        if (LIST) {
+          if (valid && key <= my_guess[q]) {
+            const uint32_t pos = atomicAdd(cnt + a, 1u);
+            if (pos < cap) {
+              list_idx[(size_t)a * cap + pos] = j;
+              list_key[(size_t)a * cap + pos] = key;
+            }
+          }
+        } else if (valid) {
+          // running minima per row over disjoint shares of the sample (share = sampled column mod 4096), kept as
+          // order-preserving integers so that atomicMin orders them like the keys
+          atomicMin(sample_min + (size_t)a * kSsShares + ((t * kSsTile + (uint32_t)item) & (kSsShares - 1)), ss_orderable(key));
+        }
+      }
+    }
+    ss_wave_sync();  // everyone is done reading buffer `buf` before the next DMA into it is issued
+    buf = (buf + 1) % NBUF;
+  }
+}
+
+// guess[a] >= the K-th smallest sampled key of row a: K of the 256 share minima are K distinct sampled keys, so the
+// K-th smallest minimum bounds the K-th smallest sampled key (and with it the K-th smallest key over all of B) from
+// above.  +inf when fewer than K shares hold a key: everything is listed then (and the list overflows).
+__global__ __launch_bounds__(256) void stream_guess_kernel(const unsigned long long *__restrict__ sample_min, uint32_t K,
+                                                           double *__restrict__ guess) {
+  __shared__ unsigned long long s_min[256];
+  {  // 4096 share minima -> 256 (the minimum of 16 shares is the minimum of their union: still disjoint shares)
+    unsigned long long v = ~0ull;
+    for (uint32_t e = 0; e < kSsShares / 256; ++e) {
+      const unsigned long long w = sample_min[(size_t)blockIdx.x * kSsShares + e * 256 + threadIdx.x];
+      v = w < v ? w : v;
+    }
+    s_min[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= 256; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t e = threadIdx.x, partner = e ^ j;
+      if (partner > e) {
+        const bool up = (e & k) == 0;
+        const unsigned long long a = s_min[e], b = s_min[partner];
+        if (up ? (a > b) : (a < b)) {
+          s_min[e] = b;
+          s_min[partner] = a;
+        }
+      }
+      __syncthreads();
+    }
+  if (threadIdx.x == 0) guess[blockIdx.x] = ss_from_orderable(s_min[K - 1]);
+}
+
+// per row: the listed entries ordered by (key, column), the first K written; overflow[a] = 1 when the list ran over
+constexpr uint32_t kSsSortMax = 4096;
+__global__ __launch_bounds__(256) void stream_final_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ list_idx,
+                                                           const double *__restrict__ list_key, uint32_t cap, uint32_t K,
+                                                           uint32_t out_ld, uint32_t out_off, double *__restrict__ out_key,
+                                                           uint32_t *__restrict__ out_idx, int *__restrict__ overflow) {
+  __shared__ double s_key[kSsSortMax];
+  __shared__ uint32_t s_idx[kSsSortMax];
+  const uint32_t a = blockIdx.x, c = cnt[a];
+  if (c > cap) {
+    if (threadIdx.x == 0) overflow[a] = 1;
+    return;
+  }
+  uint32_t P = 64;
+  while (P < c) P <<= 1;
+  for (uint32_t e = threadIdx.x; e < P; e += blockDim.x) {
+    s_key[e] = e < c ? list_key[(size_t)a * cap + e] : __builtin_inf();
+    s_idx[e] = e < c ? list_idx[(size_t)a * cap + e] : kNoIdx;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= P; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t e = threadIdx.x; e < P; e += blockDim.x) {
+        const uint32_t partner = e ^ j;
+        if (partner > e) {
+          const bool up = (e & k) == 0;
+          const bool swap = up ? lex_less(s_key[partner], s_idx[partner], s_key[e], s_idx[e])
+                               : lex_less(s_key[e], s_idx[e], s_key[partner], s_idx[partner]);
+          if (swap) {
+            const double tk = s_key[e];
+            s_key[e] = s_key[partner];
+            s_key[partner] = tk;
+            const uint32_t ti = s_idx[e];
+            s_idx[e] = s_idx[partner];
+            s_idx[partner] = ti;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) {
+    const bool have = e < c && s_idx[e] != kNoIdx;
+    out_key[(size_t)a * out_ld + out_off + e] = have ? s_key[e] : __builtin_inf();
+    out_idx[(size_t)a * out_ld + out_off + e] = have ? s_idx[e] : kNoIdx;
+  }
+}
+
+}  // namespace
+
+bool stream_scan_applies(uint64_t nA, uint64_t nB, uint64_t d, uint32_t K) {
+  return nA >= 1 && nA <= kSsMaxA && d == kSsD && K >= 1 && K <= 64 && nB >= 65536 && nB < 0xFFFFFFF0ull;
+}
+
+// The K best (key asc, column asc) of every listed A row against all nB rows of B (both 128 wide).  Rows of out are in
+// list order.  *n_redo / redo_pos: the rows (positions in the list) whose candidate list overflowed; their output is
+// undefined and the caller re-does them on the older path.
+template <class Policy>
+static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, const uint32_t *a_ids, uint32_t a_begin, uint32_t nA,
+                       const double *B, uint32_t nB, uint32_t K, Policy pol, double *out_key, uint32_t *out_idx, uint32_t out_ld,
+                       int *err_flag, std::vector<uint32_t> *redo_pos) {
+  const uint32_t n_tiles = (nB + kSsTile - 1) / kSsTile;
+  const uint32_t n_stiles = (n_tiles + kSsSampleStride - 1) / kSsSampleStride;
+  const uint32_t cap = kSsSortMax;
+  DevBuf<double> guess, lkey;
+  DevBuf<unsigned long long> smin;
+  DevBuf<uint32_t> cnt, lidx;
+  DevBuf<int> over;
+  AS_TRY(smin.alloc(ctx, (size_t)nA * kSsShares));
+  AS_TRY(guess.alloc(ctx, nA));
+  AS_TRY(cnt.alloc(ctx, nA));
+  AS_TRY(lidx.alloc(ctx, (size_t)nA * cap));
+  AS_TRY(lkey.alloc(ctx, (size_t)nA * cap));
+  AS_TRY(over.alloc(ctx, nA));
+  AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(over.p, 0, sizeof(int) * nA, ctx->stream));
+  const int nbuf = nA <= 8 ? 3 : 2;  // a third tile in flight per wave while the A rows leave the LDS for it
+  const size_t lds = (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)kSsWaves * nbuf * kSsTileBytes;
+  {
+    ProfScope ps(ctx, prof_name);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(cdiv((uint64_t)nA * kSsShares, 256)), dim3(256), 0, ctx->stream, smin.p,
+                       (uint64_t)nA * kSsShares, 0xFFF0000000000000ull);  // +inf as an order-preserving integer
+#define AS_SS1(LISTV, NB, GV, GRID)                                                                                          \
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)stream_scan_d128_kernel<Policy, LISTV, NB, GV>,                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
+  hipLaunchKernelGGL((stream_scan_d128_kernel<Policy, LISTV, NB, GV>), dim3(GRID), dim3(kSsWaves * 64), lds, ctx->stream, A,   \
+                     a_ids, a_begin, nA, B, nB, n_tiles, pol, smin.p, guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag)
+#define AS_SS(LISTV, GRID)                                                             \
+  switch ((nA + 7) / 8) {                                                              \
+    case 1: AS_SS1(LISTV, 3, 1, GRID); break;                                          \
+    case 2: AS_SS1(LISTV, 2, 2, GRID); break;                                          \
+    case 3: AS_SS1(LISTV, 2, 3, GRID); break;                                          \
+    default: AS_SS1(LISTV, 2, 4, GRID); break;                                         \
+  }
+    const unsigned g_s = std::min<uint32_t>(256, cdiv(n_stiles, kSsWaves));
+    AS_SS(false, g_s)
+    hipLaunchKernelGGL(stream_guess_kernel, dim3(nA), dim3(256), 0, ctx->stream, smin.p, K, guess.p);
+    AS_SS(true, 256u)
+#undef AS_SS1
+#undef AS_SS
+    hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
+                       out_idx, over.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  std::vector<int> h(nA);
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), over.p, sizeof(int) * nA));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  redo_pos->clear();
+  for (uint32_t a = 0; a < nA; ++a)
+    if (h[a]) redo_pos->push_back(a);
+  ctx->stats["stream_scan_rows"] = nA;
+  ctx->stats["stream_scan_overflow_rows"] = (int64_t)redo_pos->size();
+  return AS_OK;
+}
+
+int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids, uint32_t nq, const double *items, uint32_t n, uint32_t K,
+                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
+  return stream_scan<SearchScorePolicy>(ctx, "search_stream_scan", queries, q_ids, 0, nq, items, n, K, pol, out_key, out_idx, K, err_flag, redo);
+}
+int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
+                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
+  return stream_scan<GraphDistPolicy>(ctx, "knn_stream_scan", rows, row_ids, 0, n_rows, rows, n, K, pol, out_key, out_idx, K, err_flag, redo);
+}
+
+}  // namespace asx

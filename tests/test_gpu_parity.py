@@ -821,6 +821,84 @@ def test_search_scan_not_used_outside_its_range(ctx, scan_on):
             assert np.array_equal(idx[j], oi) and np.array_equal(sc[j], osc)
 
 
+# ---- one query / small batches: the exact streaming scan (csrc/stream_scan.hip) ------------------------------------
+
+@pytest.mark.parametrize("nq,k", [(1, 10), (7, 1), (32, 10), (5, 64), (9, 17)])
+def test_small_batch_search_streams_the_items_once(ctx, nq, k):
+    """nq <= 32 queries against >= 65,536 items of width 128: sample pass -> guaranteed guess -> list pass -> final
+    sort, all in the reference's arithmetic; every query compared with the oracle."""
+    n, d = 70_001, 128
+    X, _ = synth.mixture(n, d, seed=21, n_clusters=64, rank=6)
+    rng = np.random.default_rng(nq + k)
+    lam = rng.random(n)
+    lam[::5] = lam[2]                                  # ties in the lambda term
+    X[100:140] = X[7]                                  # exact duplicates of an item: equal scores, order by index
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=3)
+    qi[0] = 7
+    Q = X[qi] * 1.02
+    lq = rng.random(nq) + 0.01
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, k, 0.7)
+    assert ctx.stat("search_stream_scan") == 1 and ctx.stat("stream_scan_overflow_rows") == 0
+    for j in range(nq):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], k, 0.7)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+    ctx.set_option("stream_scan", 0)                   # and the staged path gives the same
+    try:
+        idx0, sc0 = asp.search_lambda_aware_batch(Q, lq, k, 0.7)
+    finally:
+        ctx.set_option("stream_scan", 1)
+    assert ctx.stat("search_stream_scan") == 0
+    assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0)
+
+
+def test_small_batch_search_with_a_useless_sample(ctx):
+    """The guess comes from 1 in 16 of the 8-row tiles.  Items ordered so that every sampled tile is far from the query:
+    the guess is loose, the candidate list overflows, the query is re-done on the staged path -- same result."""
+    n, d = 66_000, 128
+    X, _ = synth.mixture(n, d, seed=22, n_clusters=16, rank=5)
+    q = X[9] * 1.02
+    tiles = np.arange(n) // 8
+    sampled = (tiles % 16) == 0
+    X[sampled] = -np.abs(X[sampled]) * np.sign(q)      # sampled rows point away from the query
+    lam = np.full(n, 0.5)
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    res = asp.search_lambda_aware(A.ArrowItem(q, 0.5), 10, 1.0)
+    oi, osc = O.search_lambda_aware(X, lam, q, 0.5, 10, 1.0)
+    assert [r[0] for r in res] == oi.tolist() and np.array_equal([r[1] for r in res], osc)
+    assert ctx.stat("search_stream_scan") == 1
+
+
+def test_leftover_graph_rows_take_the_streaming_scan(ctx):
+    """Rows the MFMA stages never certify (here: rows that can form a 0 < |a||b| <= 1e-12 pair are always re-done
+    exactly) go through one exact pass over the matrix instead of a 300 ms one-wave-per-row scan."""
+    n, d = 66_000, 128
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=32, rank=6)
+    tiny = [40, 9000, 33333, 65999]
+    for t in tiny:
+        X[t] *= 1e-8
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    import torch
+    Xd = torch.from_numpy(X).cuda()
+    import ctypes as C
+    K = gp.topk + 1
+    idx = torch.empty((n, K), dtype=torch.int64, device="cuda")
+    dst = torch.empty((n, K), dtype=torch.float64, device="cuda")
+    A.api._adopt_torch_stream(ctx)
+    c = gp.to_c()
+    ctx.check(ctx.lib.as_knn_cosine(ctx.h, Xd.data_ptr(), n, d, 0, n, C.byref(c), idx.data_ptr(), dst.data_ptr()))
+    torch.cuda.synchronize()
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_stream_scan_rows") >= len(tiny)
+    sample = np.array(sorted(tiny + [0, 41, 12345, 50000]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    pos = torch.from_numpy(sample).cuda()
+    assert np.array_equal(idx[pos].cpu().numpy().astype(np.uint64), oi)
+    assert np.array_equal(dst[pos].cpu().numpy(), od)
+
+
 # ---- callers of the same index: hybrid and range search (src/core.rs:802-976) ------------------
 
 def test_hybrid_search_matches_oracle(ctx, mode):
