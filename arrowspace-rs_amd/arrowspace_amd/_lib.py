@@ -23,7 +23,9 @@ EXPORTS = [
     "as_compute_taumode", "as_prepare_query_items", "as_select_tau", "as_index_create", "as_index_destroy",
     "as_index_nitems", "as_search_lambda_aware", "as_search_lambda_aware_hybrid", "as_range_search",
     "as_nearest_centroids", "as_knn_join_pack", "as_knn_join_unpack", "as_laplacian_from_knn_rows", "as_csr_cols",
-    "as_csr_row_begin", "as_knn_join_applies",
+    "as_csr_row_begin", "as_knn_join_applies", "as_two_nn_ratios", "as_kmeans_lloyd", "as_calinski_harabasz",
+    "as_compute_optimal_k", "as_incremental_clustering", "as_jl_dimension", "as_jl_create", "as_jl_destroy",
+    "as_jl_original_dim", "as_jl_reduced_dim", "as_jl_matrix", "as_jl_project",
 ]
 
 
@@ -97,6 +99,18 @@ def load():
         "as_range_search": (i32, [vp, vp, dbl, dbl, u64, vp, vp, u64, C.POINTER(u64)]),
         "as_nearest_centroids": (i32, [vp, vp, u64, u64, vp, u64, vp, vp]),
         "as_knn_join_pack": (i32, [vp, vp, vp, u64, C.c_uint32, vp, vp]),
+        "as_two_nn_ratios": (i32, [vp, vp, u64, u64, vp, u64, vp]),
+        "as_kmeans_lloyd": (i32, [vp, vp, u64, u64, u64, u64, u64, vp, vp]),
+        "as_calinski_harabasz": (i32, [vp, vp, u64, u64, vp, u64, C.POINTER(dbl)]),
+        "as_compute_optimal_k": (i32, [vp, vp, u64, u64, u64, C.POINTER(u64), C.POINTER(dbl), C.POINTER(u64)]),
+        "as_incremental_clustering": (i32, [vp, vp, u64, u64, u64, dbl, u64, vp, C.POINTER(u64), vp, vp]),
+        "as_jl_dimension": (u64, [u64, dbl]),
+        "as_jl_create": (i32, [vp, u64, u64, u64, C.POINTER(vp)]),
+        "as_jl_destroy": (None, [vp]),
+        "as_jl_original_dim": (u64, [vp]),
+        "as_jl_reduced_dim": (u64, [vp]),
+        "as_jl_matrix": (i32, [vp, vp, vp]),
+        "as_jl_project": (i32, [vp, vp, vp, u64, vp]),
         "as_knn_join_unpack": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
     }
     for name, (res, args) in sig.items():

@@ -10,9 +10,9 @@ Same names and argument meaning as the Rust crate (paths relative to /root/refer
   ArrowSpace         src/core.rs:366-1006      (prepare_query_item, search_lambda_aware, ...)
 Errors the reference raises by panicking surface as ArrowSpaceError with the same message.
 
-Out of scope here ("next"): the clustering pre-stage, inline sampling, JL
-projection.  `build(rows)` therefore takes the centroids as an argument; with none given every
-item is its own centroid (the radius -> 0 limit of the reference's clustering).
+`build(rows)` runs the reference's stages: clustering pre-stage (compute_optimal_k + incremental clustering,
+src/eigenmaps.rs:175-235; `build(rows, centroids)` skips it), optional JL projection of the centroids
+(with_dims_reduction), the F x F graph, the per-item lambdas.  Inline sampling (src/sampling.rs) is not on the path.
 """
 import ctypes as C
 
@@ -332,6 +332,112 @@ def build_spectral_laplacian(aspace, gl):
     return aspace.signals
 
 
+# ---- clustering pre-stage (src/clustering.rs) and JL projection (src/reduction.rs) --------------------------------------
+
+CLUSTERING_SEED = 128  # src/clustering.rs:30
+
+
+def compute_optimal_k(rows, seed=None, ctx=None):
+    """ClusteringHeuristic::compute_optimal_k (src/clustering.rs:36-72): (k_optimal, radius, intrinsic dimension)."""
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, f = _shape2(X)
+    k, rad, idd = C.c_uint64(), C.c_double(), C.c_uint64()
+    ctx.check(ctx.lib.as_compute_optimal_k(ctx.h, ptr(X), n, f, CLUSTERING_SEED if seed is None else int(seed), C.byref(k),
+                                           C.byref(rad), C.byref(idd)))
+    return int(k.value), float(rad.value), int(idd.value)
+
+
+def incremental_clustering(rows, max_clusters, radius, batch=4096, ctx=None):
+    """run_incremental_clustering_with_sampling without a sampler (src/clustering.rs:547-910): (centroids X x F,
+    assignments (-1 = dropped), cluster sizes).  batch = 1 is the reference's sequential mode exactly."""
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, f = _shape2(X)
+    cents = np.zeros((max_clusters, f), dtype=np.float64)
+    assign = np.empty(n, dtype=np.int64)
+    counts = np.zeros(max_clusters, dtype=np.uint64)
+    nc = C.c_uint64()
+    ctx.check(ctx.lib.as_incremental_clustering(ctx.h, ptr(X), n, f, int(max_clusters), float(radius), int(batch), ptr(cents),
+                                                C.byref(nc), ptr(assign), ptr(counts)))
+    return cents[: nc.value].copy(), assign, counts[: nc.value].copy()
+
+
+def two_nn_ratios(rows, sample_ids, ctx=None):
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, f = _shape2(X)
+    ids = np.ascontiguousarray(sample_ids, dtype=np.uint64)
+    out = np.empty(len(ids), dtype=np.float64)
+    ctx.check(ctx.lib.as_two_nn_ratios(ctx.h, ptr(X), n, f, ptr(ids), len(ids), ptr(out)))
+    return out
+
+
+def kmeans_lloyd(rows, k, max_iter, seed, ctx=None):
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, f = _shape2(X)
+    assign = np.empty(n, dtype=np.uint64)
+    cents = np.zeros((min(k, n), f), dtype=np.float64)
+    ctx.check(ctx.lib.as_kmeans_lloyd(ctx.h, ptr(X), n, f, int(k), int(max_iter), int(seed), ptr(assign), ptr(cents)))
+    return assign, cents
+
+
+def calinski_harabasz(rows, assign, k, ctx=None):
+    ctx = ctx or default_context()
+    X = _f64(rows, ctx)
+    n, f = _shape2(X)
+    a = np.ascontiguousarray(assign, dtype=np.uint64)
+    out = C.c_double()
+    ctx.check(ctx.lib.as_calinski_harabasz(ctx.h, ptr(X), n, f, ptr(a), int(k), C.byref(out)))
+    return float(out.value)
+
+
+def compute_jl_dimension(n_points, epsilon):
+    """src/reduction.rs:126-140"""
+    return int(_lib.load().as_jl_dimension(int(n_points), float(epsilon)))
+
+
+class ImplicitProjection:
+    """src/reduction.rs:166-203: a seeded Gaussian projection, here an as_jl handle (the matrix lives in HBM)."""
+
+    def __init__(self, original_dim, reduced_dim, seed=0, ctx=None):
+        self.ctx = ctx or default_context()
+        self.original_dim, self.reduced_dim, self.seed = int(original_dim), int(reduced_dim), int(seed)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.as_jl_create(self.ctx.h, self.original_dim, self.reduced_dim, self.seed, C.byref(h)))
+        self.h = h
+
+    def matrix(self):
+        G = np.empty((self.original_dim, self.reduced_dim), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.as_jl_matrix(self.ctx.h, self.h, ptr(G)))
+        return G
+
+    def project(self, rows):
+        """project_matrix (:142-164) / project (:180-203) for one vector or a batch (host or device rows)."""
+        X = _f64(rows, self.ctx)
+        single = len(X.shape) == 1
+        if single:
+            X = X.reshape(1, -1)
+        n, d = _shape2(X)
+        assert d == self.original_dim
+        if _lib.is_tensor(X):
+            import torch
+            out = torch.empty((n, self.reduced_dim), dtype=torch.float64, device=X.device)
+        else:
+            out = np.empty((n, self.reduced_dim), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.as_jl_project(self.ctx.h, self.h, ptr(X), n, ptr(out)))
+        return out[0] if single else out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.as_jl_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class ArrowItem:
     """src/core.rs:84-239."""
 
@@ -377,6 +483,9 @@ class ArrowSpace:
         self.signals = None  # F x F spectral Laplacian (src/core.rs:372), set by build_spectral_laplacian
         self._index = None
         self.id_offset = 0
+        # clustering metadata and projection state (src/core.rs:373-384), set by the builder
+        self.n_clusters, self.cluster_assignments, self.cluster_sizes, self.cluster_radius = 0, None, None, 0.0
+        self.projection_matrix, self.reduced_dim = None, None
 
     def lambdas(self):
         return self.lambdas_
@@ -423,9 +532,20 @@ class ArrowSpace:
             out = torch.empty(nq, dtype=torch.float64, device=Q.device)
         else:
             out = np.empty(nq, dtype=np.float64)
+        if self.projection_matrix is not None:  # src/core.rs:541-546: the query is projected first
+            if not np.all(np.isfinite(Q.cpu().numpy() if _lib.is_tensor(Q) else Q)):
+                raise ArrowSpaceError(_lib.AS_ERR_NONFINITE, ctx.lib.as_status_message(_lib.AS_ERR_NONFINITE).decode())
+            Q = self.project_query(Q)
+            f = self.reduced_dim
         ctx.check(lib.as_prepare_query_items(ctx.h, ptr(Q), nq, f, gl.matrix.h, self.taumode.kind, self.taumode.arg,
                                              ptr(out)))
         return out
+
+    def project_query(self, query):
+        """src/core.rs:509-529"""
+        if self.projection_matrix is None:
+            return query
+        return self.projection_matrix.project(query)
 
     def _ensure_index(self):
         if self._index is None:
@@ -522,6 +642,11 @@ class ArrowSpaceBuilder:
         self.synthesis = TauMode.Median
         self.prebuilt_spectral = False
         self.ctx = ctx
+        # clustering / projection (src/builder.rs:44-57,80-90)
+        self.cluster_max_clusters, self.cluster_radius = None, 1.0
+        self.clustering_seed, self.deterministic_clustering = None, False
+        self.clustering_batch = 4096
+        self.use_dims_reduction, self.rp_eps = False, 0.3
 
     @staticmethod
     def new(ctx=None):
@@ -553,8 +678,38 @@ class ArrowSpaceBuilder:
             raise ArrowSpaceError(_lib.AS_ERR_UNSUPPORTED, "inline sampling is outside the accelerated path")
         return self
 
-    def with_seed(self, seed):
+    def with_seed(self, seed):  # src/builder.rs:191-195: fixes the seed and makes the clustering sequential
+        self.clustering_seed = int(seed)
+        self.deterministic_clustering = True
         return self
+
+    def with_dims_reduction(self, enable, eps=None):  # src/builder.rs:164-172
+        self.use_dims_reduction = bool(enable)
+        if eps is not None:
+            self.rp_eps = float(eps)
+        return self
+
+    def start_clustering(self, aspace):
+        """EigenMaps::start_clustering (src/eigenmaps.rs:175-290): optimal K + radius, incremental clustering, optional
+        JL projection of the centroids.  Returns the (possibly projected) centroids."""
+        ctx = aspace.ctx
+        k_opt, radius, _ = compute_optimal_k(aspace.data, self.clustering_seed, ctx=ctx)
+        self.cluster_max_clusters, self.cluster_radius = k_opt, radius
+        batch = 1 if self.deterministic_clustering else self.clustering_batch
+        cents, assign, sizes = incremental_clustering(aspace.data, k_opt, radius, batch, ctx=ctx)
+        aspace.n_clusters, aspace.cluster_assignments, aspace.cluster_sizes = len(cents), assign, sizes
+        aspace.cluster_radius = radius
+        return self._maybe_project(aspace, cents)
+
+    def _maybe_project(self, aspace, cents):
+        nf = aspace.nfeatures
+        if self.use_dims_reduction and nf > 64:  # src/eigenmaps.rs:247-280
+            target = min(compute_jl_dimension(len(cents), self.rp_eps), nf // 2)
+            if target < nf:
+                proj = ImplicitProjection(nf, target, seed=self.clustering_seed or CLUSTERING_SEED, ctx=aspace.ctx)
+                aspace.projection_matrix, aspace.reduced_dim = proj, target
+                return proj.project(cents)
+        return cents
 
     def define_result_k(self):  # src/builder.rs:225-233
         self.lambda_topk = int(_lib.load().as_define_result_k(self.lambda_k, self.lambda_topk))
@@ -564,13 +719,15 @@ class ArrowSpaceBuilder:
                            self.normalise, self.sparsity_check)
 
     def build(self, rows, centroids=None):
-        """src/builder.rs:249-455 with the clustering stage replaced by supplied centroids
-        (X x F).  Stage 2: eigenmaps (F x F Laplacian over centroids^T); stage 4: taumode."""
+        """src/builder.rs:249-455.  Stage 1: clustering (skipped when the centroids, X x F, are supplied) + optional JL
+        projection; stage 2: eigenmaps (Laplacian over centroids^T); stage 3 (optional): spectral; stage 4: taumode."""
         ctx = self.ctx or default_context()
         self.define_result_k()
         aspace = ArrowSpace(rows, self.synthesis, ctx)
         if centroids is None:
-            centroids = aspace.data.cpu().numpy() if _lib.is_tensor(aspace.data) else aspace.data
+            centroids = self.start_clustering(aspace)       # stage 1, src/builder.rs:296-300
+        else:
+            centroids = self._maybe_project(aspace, np.ascontiguousarray(np.asarray(centroids, dtype=np.float64)))
         gl = GraphFactory.build_laplacian_matrix_from_k_cluster(
             centroids, self.lambda_eps, self.lambda_k, self.lambda_topk, self.lambda_p, self.lambda_sigma,
             self.normalise, self.sparsity_check, aspace.nitems, ctx=ctx)

@@ -1,0 +1,665 @@
+// prestage.hip -- the clustering pre-stage (src/clustering.rs) and the JL projection (src/reduction.rs) behind the
+// C ABI: what runs immediately before the hot path inside ArrowSpaceBuilder::build.
+//
+// Division of labour.  Everything that touches all N rows runs on the device in the reference's arithmetic:
+//   - Two-NN intrinsic dimension (src/clustering.rs:101-164): 500 sampled rows against all N rows, the two smallest
+//     Euclidean distances of each                                                              two_nn_kernel
+//   - the nearest-centroid searches of the incremental clustering (:571-594) and of Lloyd's assignment step
+//                                                                                               nearest_centroids (centroids.hip)
+//   - the JL projection of rows / queries (src/reduction.rs:180-203)                            jl_project_kernel
+// What works on the <= 1000-row sample or on one centroid at a time (Lloyd's update, the Calinski-Harabasz score,
+// the pilot threshold, the decisions and running means of the incremental clustering) is sequential bookkeeping on the
+// host, in the same order as the reference so that the oracle's restatement matches bit for bit.
+//
+// The reference's random draws (StdRng shuffles, smartcore's k-means, the ChaCha8 Gaussian stream) cannot be reproduced
+// without its Rust dependencies: the build's own seeded definitions replace them (same in oracle/prestage.c), so
+// agreement with a reference run is statistical, agreement with the oracle exact.
+#include <cmath>
+
+#include "common.h"
+
+namespace asx {
+
+namespace {
+
+inline uint64_t sm64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// m distinct indices of [0, n): the first m steps of a Fisher-Yates shuffle driven by SplitMix64
+std::vector<uint64_t> sample_indices(uint64_t n, uint64_t m, uint64_t seed) {
+  std::vector<uint64_t> idx(n), out;
+  for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+  m = std::min(m, n);
+  out.reserve(m);
+  for (uint64_t t = 0; t < m; ++t) {
+    const uint64_t j = t + sm64(sm64(seed) ^ sm64(t + 0x51ED270B27B4F3CFull)) % (n - t);
+    std::swap(idx[t], idx[j]);
+    out.push_back(idx[t]);
+  }
+  return out;
+}
+
+inline double dist2(const double *a, const double *b, uint64_t f) {
+  double d2 = 0.0;
+  for (uint64_t j = 0; j < f; ++j) {
+    const double diff = a[j] - b[j];
+    d2 += diff * diff;  // -ffp-contract=off: two roundings, as the reference
+  }
+  return d2;
+}
+
+// ---- Two-NN: per sampled row the two smallest squared distances to the other rows ---------------------------------
+// One workgroup = 64 sampled rows x one chunk of the rows; the geometry of nearest_centroids_kernel (features in
+// chunks of 32 through LDS, wave g owns the columns g, g + 4, ..., lane r owns sample row r, 16 partial sums per
+// lane in registers, every sum over the features in order).  Partial (b1, b2) per (chunk, sample row).
+constexpr int kTnRows = 64, kTnCols = 64, kTnFeat = 32, kTnPitch = kTnFeat + 1;
+
+__global__ __launch_bounds__(256) void two_nn_kernel(const double *__restrict__ rows, uint64_t n, uint64_t d,
+                                                     const uint64_t *__restrict__ sample_ids, uint64_t ns, uint64_t chunk,
+                                                     double *__restrict__ part /* [chunks][ns][2] */) {
+  __shared__ double s_a[kTnRows * kTnPitch];
+  __shared__ double s_b[kTnCols * kTnPitch];
+  __shared__ double s_m[4][kTnRows][2];
+  const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+  const uint64_t s0 = (uint64_t)blockIdx.x * kTnRows;  // first sample row of this workgroup
+  const uint64_t c_begin = (uint64_t)blockIdx.y * chunk, c_end = c_begin + chunk < n ? c_begin + chunk : n;
+  const uint64_t my = s0 + r < ns ? sample_ids[s0 + r] : ~0ull;
+  double b1 = __builtin_inf(), b2 = __builtin_inf();
+  for (uint64_t c0 = c_begin; c0 < c_end; c0 += kTnCols) {
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    for (uint64_t k0 = 0; k0 < d; k0 += kTnFeat) {
+      const int feats = (int)((d - k0) < (uint64_t)kTnFeat ? (d - k0) : (uint64_t)kTnFeat);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = q * 256 + tid, rr = e >> 5, kk = e & 31;
+        const uint64_t sr = s0 + rr < ns ? sample_ids[s0 + rr] : ~0ull;
+        s_a[rr * kTnPitch + kk] = (sr != ~0ull && kk < feats) ? rows[sr * d + k0 + kk] : 0.0;
+        s_b[rr * kTnPitch + kk] = (c0 + rr < c_end && kk < feats) ? rows[(c0 + rr) * d + k0 + kk] : 0.0;
+      }
+      __syncthreads();
+      for (int kk = 0; kk < feats; ++kk) {
+        const double a = s_a[r * kTnPitch + kk];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double diff = __dsub_rn(a, s_b[(g + 4 * j) * kTnPitch + kk]);
+          acc[j] = __dadd_rn(acc[j], __dmul_rn(diff, diff));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t c = c0 + g + 4 * j;
+      if (c < c_end && c != my) {
+        const double v = acc[j];
+        if (v < b1) {
+          b2 = b1;
+          b1 = v;
+        } else if (v < b2) {
+          b2 = v;
+        }
+      }
+    }
+  }
+  s_m[g][r][0] = b1;
+  s_m[g][r][1] = b2;
+  __syncthreads();
+  if (g == 0 && s0 + r < ns) {
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    for (int w = 0; w < 4; ++w)
+      for (int e = 0; e < 2; ++e) {
+        const double v = s_m[w][r][e];
+        if (v < m1) {
+          m2 = m1;
+          m1 = v;
+        } else if (v < m2) {
+          m2 = v;
+        }
+      }
+    part[((uint64_t)blockIdx.y * ns + s0 + r) * 2] = m1;
+    part[((uint64_t)blockIdx.y * ns + s0 + r) * 2 + 1] = m2;
+  }
+}
+
+// ---- JL projection ---------------------------------------------------------------------------------------------------
+// G[i][r] ~ N(0, 1), i < original_dim, r < reduced_dim: counter-based SplitMix64 + Box-Muller (the build's own seed
+// format; the reference draws the same shape from ChaCha8, src/reduction.rs:186-199)
+__global__ void jl_gaussian_kernel(uint64_t seed, uint64_t total, double *__restrict__ G) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  auto mix = [](uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  };
+  const uint64_t key = mix(seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
+  const double u1 = ((double)(mix((2 * e) ^ key) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(mix((2 * e + 1) ^ key) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  G[e] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+// out[row][t] = sum_i (x[row][i] * G[i][t]) * scale in the reference's order and rounding: result += original * sample * scale,
+// original-major (src/reduction.rs:191-199).  One thread per (row, t); the row's values are LDS broadcasts.
+__global__ __launch_bounds__(256) void jl_project_kernel(const double *__restrict__ X, uint64_t n, uint64_t d,
+                                                         const double *__restrict__ G, uint64_t r, double scale,
+                                                         double *__restrict__ out) {
+  extern __shared__ double s_x[];
+  const uint64_t row = blockIdx.x;
+  for (uint64_t i = threadIdx.x; i < d; i += blockDim.x) s_x[i] = X[row * d + i];
+  __syncthreads();
+  for (uint64_t t = threadIdx.x; t < r; t += blockDim.x) {
+    double acc = 0.0;
+    for (uint64_t i = 0; i < d; ++i) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(s_x[i], G[i * r + t]), scale));
+    out[row * r + t] = acc;
+  }
+}
+
+// rows [begin, begin + count) of a host- or device-resident matrix as a host pointer
+struct HostRows {
+  std::vector<double> buf;
+  const double *p = nullptr;
+  int get(as_ctx *ctx, const double *rows, bool on_device, uint64_t begin, uint64_t count, uint64_t f) {
+    if (!on_device) {
+      p = rows + begin * f;
+      return AS_OK;
+    }
+    buf.resize((size_t)count * f);
+    AS_HIP(ctx, copy_d2h(ctx, buf.data(), rows + begin * f, sizeof(double) * count * f));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p = buf.data();
+    return AS_OK;
+  }
+};
+
+int gather_rows_host(as_ctx *ctx, const double *rows, bool on_device, const std::vector<uint64_t> &ids, uint64_t f,
+                     std::vector<double> &out) {
+  out.resize(ids.size() * f);
+  for (size_t s = 0; s < ids.size(); ++s) {
+    if (on_device) AS_HIP(ctx, copy_d2h(ctx, out.data() + s * f, rows + ids[s] * f, sizeof(double) * f));
+    else std::memcpy(out.data() + s * f, rows + ids[s] * f, sizeof(double) * f);
+  }
+  if (on_device) AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+}  // namespace
+
+// ---- stage functions (also the C ABI's workers) -------------------------------------------------------------------------
+
+int two_nn_ratios(as_ctx *ctx, const double *rows_dev, uint64_t n, uint64_t f, const uint64_t *sample_ids_host, uint64_t ns,
+                  double *ratios_host) {
+  if (ns == 0) return AS_OK;
+  const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(256, cdiv(n, 4096)));
+  const uint64_t chunk = (cdiv(n, chunks) + kTnCols - 1) / kTnCols * kTnCols;
+  const uint64_t n_chunks = cdiv(n, chunk);
+  DevBuf<uint64_t> ids;
+  DevBuf<double> part;
+  AS_TRY(ids.alloc(ctx, ns));
+  AS_TRY(part.alloc(ctx, n_chunks * ns * 2));
+  AS_HIP(ctx, copy_h2d(ctx, ids.p, sample_ids_host, sizeof(uint64_t) * ns));
+  {
+    ProfScope ps(ctx, "two_nn");
+    hipLaunchKernelGGL(two_nn_kernel, dim3(cdiv(ns, kTnRows), (unsigned)n_chunks), dim3(256), 0, ctx->stream, rows_dev, n, f, ids.p, ns,
+                       chunk, part.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  std::vector<double> h(n_chunks * ns * 2);
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), part.p, sizeof(double) * h.size()));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint64_t s = 0; s < ns; ++s) {
+    double b1 = INFINITY, b2 = INFINITY;
+    for (uint64_t c = 0; c < n_chunks; ++c)
+      for (int e = 0; e < 2; ++e) {
+        const double v = h[(c * ns + s) * 2 + e];
+        if (v < b1) {
+          b2 = b1;
+          b1 = v;
+        } else if (v < b2) {
+          b2 = v;
+        }
+      }
+    const double d1 = std::sqrt(b1), d2 = std::sqrt(b2);  // src/clustering.rs:135,141-147
+    ratios_host[s] = (n >= 3 && d1 > 1e-12) ? d2 / d1 : NAN;
+  }
+  return AS_OK;
+}
+
+static uint64_t intrinsic_dimension(uint64_t n, uint64_t f, const double *ratios, uint64_t ns) {  // src/clustering.rs:101-164
+  if (n < 10) return std::min<uint64_t>(f, 2);
+  double sum = 0.0;
+  uint64_t cnt = 0;
+  for (uint64_t s = 0; s < ns; ++s)
+    if (ratios[s] == ratios[s]) {
+      sum += ratios[s];
+      ++cnt;
+    }
+  if (cnt == 0) return std::min<uint64_t>(f, 3);
+  const double mean = sum / (double)cnt;
+  const double id = mean > 1.001 ? 1.0 / std::log(mean) : (double)f;
+  double r = std::round(id);
+  r = std::max(1.0, std::min((double)f, r));
+  return (uint64_t)r;
+}
+
+// Lloyd's k-means on rows that live on BOTH sides (the <= 1000-row sample): assignment on the device (nearest_centroids: the
+// reference's nearest_centroid arithmetic and tie rule), update on the host in row order.
+int kmeans_lloyd(as_ctx *ctx, const double *rows_dev, const double *rows_host, uint64_t n, uint64_t f, uint64_t k, uint64_t max_iter,
+                 uint64_t seed, std::vector<uint64_t> &assign, std::vector<double> &cents) {
+  assign.assign(n, 0);
+  if (n == 0) return AS_OK;
+  k = std::min(k, n);
+  cents.resize(k * f);
+  const std::vector<uint64_t> init = sample_indices(n, k, seed);
+  for (uint64_t c = 0; c < k; ++c) std::memcpy(cents.data() + c * f, rows_host + init[c] * f, sizeof(double) * f);
+  DevBuf<double> cd, d2d;
+  DevBuf<uint64_t> idxd;
+  AS_TRY(cd.alloc(ctx, k * f));
+  AS_TRY(d2d.alloc(ctx, n));
+  AS_TRY(idxd.alloc(ctx, n));
+  std::vector<uint64_t> prev(n), count(k);
+  std::vector<double> sum(k * f);
+  for (uint64_t it = 0;; ++it) {
+    AS_HIP(ctx, copy_h2d(ctx, cd.p, cents.data(), sizeof(double) * k * f));
+    AS_TRY(nearest_centroids(ctx, rows_dev, n, f, cd.p, k, idxd.p, d2d.p));
+    AS_HIP(ctx, copy_d2h(ctx, assign.data(), idxd.p, sizeof(uint64_t) * n));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool same = it > 0;
+    if (it > 0)
+      for (uint64_t i = 0; i < n && same; ++i) same = prev[i] == assign[i];
+    if (same || it == max_iter) break;
+    prev = assign;
+    std::fill(sum.begin(), sum.end(), 0.0);
+    std::fill(count.begin(), count.end(), 0);
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t a = assign[i];
+      for (uint64_t j = 0; j < f; ++j) sum[a * f + j] += rows_host[i * f + j];
+      ++count[a];
+    }
+    for (uint64_t c = 0; c < k; ++c)
+      if (count[c] > 0)
+        for (uint64_t j = 0; j < f; ++j) cents[c * f + j] = sum[c * f + j] / (double)count[c];
+  }
+  return AS_OK;
+}
+
+static void centroids_of(const double *rows, uint64_t n, uint64_t f, const std::vector<uint64_t> &assign, uint64_t k,
+                         std::vector<double> &cents, std::vector<uint64_t> &count) {
+  cents.assign(k * f, 0.0);
+  count.assign(k, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t a = assign[i];
+    if (a >= k) continue;
+    for (uint64_t j = 0; j < f; ++j) cents[a * f + j] += rows[i * f + j];
+    ++count[a];
+  }
+  for (uint64_t c = 0; c < k; ++c)
+    if (count[c] > 0)
+      for (uint64_t j = 0; j < f; ++j) cents[c * f + j] /= (double)count[c];
+}
+
+double calinski_harabasz(const double *rows, uint64_t n, uint64_t f, const std::vector<uint64_t> &assign, uint64_t k) {  // :314-381
+  if (k <= 1 || k >= n) return 0.0;
+  std::vector<double> g(f), cents;
+  std::vector<uint64_t> count;
+  for (uint64_t j = 0; j < f; ++j) {
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s += rows[i * f + j];
+    g[j] = s / (double)n;
+  }
+  centroids_of(rows, n, f, assign, k, cents, count);
+  double bgss = 0.0;
+  for (uint64_t c = 0; c < k; ++c)
+    if (count[c] > 0) bgss += (double)count[c] * dist2(cents.data() + c * f, g.data(), f);
+  double wgss = 0.0;
+  for (uint64_t i = 0; i < n; ++i)
+    if (assign[i] < k) wgss += dist2(rows + i * f, cents.data() + assign[i] * f, f);
+  if (wgss < 1e-10) return 0.0;
+  return (bgss / (double)(k - 1)) / (wgss / (double)(n - k));
+}
+
+static int best_ch(as_ctx *ctx, const double *rd, const double *rh, uint64_t n, uint64_t f, uint64_t k, uint64_t seed0, double *out) {
+  double best = 0.0;
+  bool have = false;
+  std::vector<uint64_t> assign;
+  std::vector<double> cents;
+  for (uint64_t trial = 0; trial < 3; ++trial) {
+    AS_TRY(kmeans_lloyd(ctx, rd, rh, n, f, k, 20, seed0 + trial, assign, cents));
+    const double s = calinski_harabasz(rh, n, f, assign, k);
+    if (!have || s >= best) {
+      best = s;
+      have = true;
+    }
+  }
+  *out = best;
+  return AS_OK;
+}
+
+static int step2_calinski_harabasz(as_ctx *ctx, const double *rd, const double *rh, uint64_t n, uint64_t f, uint64_t k_min,
+                                   uint64_t k_max, uint64_t seed, uint64_t *k_out) {  // :167-310
+  if (n < 10) {
+    *k_out = k_min;
+    return AS_OK;
+  }
+  const uint64_t range = k_max - k_min, step = range <= 5 ? 1 : (range <= 15 ? 2 : 3);
+  uint64_t best_k = k_min;
+  double best_score = -INFINITY;
+  bool have = false;
+  for (uint64_t k = k_min; k <= k_max; k += step) {
+    if (!(k < n && k >= 2)) continue;
+    double ch;
+    AS_TRY(best_ch(ctx, rd, rh, n, f, k, seed + k * 1000, &ch));
+    const double sc = ch - 0.8 * (double)k * std::log((double)n);
+    if (!have || !(sc < best_score)) {  // max_by: the greater score; equal or incomparable: the larger k
+      best_k = k;
+      best_score = sc;
+      have = true;
+    }
+  }
+  if (step > 1) {
+    const uint64_t fine[5] = {best_k >= step - 1 ? best_k - (step - 1) : 0, best_k >= 1 ? best_k - 1 : 0, best_k,
+                              std::min(best_k + 1, k_max), std::min(best_k + step - 1, k_max)};
+    uint64_t fk = 0;
+    double fs = 0.0;
+    bool fhave = false;
+    for (int t = 0; t < 5; ++t) {
+      const uint64_t k = fine[t];
+      if (!(k >= k_min && k <= k_max && k < n)) continue;
+      if ((k - k_min) % step == 0) continue;  // already a candidate
+      double ch;
+      AS_TRY(best_ch(ctx, rd, rh, n, f, k, seed + k * 10000, &ch));
+      const double sc = ch - 0.8 * (double)k * std::log((double)n);
+      if (!fhave || !(sc < fs)) {
+        fk = k;
+        fs = sc;
+        fhave = true;
+      }
+    }
+    if (fhave && fs > best_score) {
+      best_k = fk;
+      best_score = fs;
+    }
+  }
+  *k_out = best_k < k_max ? best_k : k_max;
+  return AS_OK;
+}
+
+static int threshold_from_pilot(as_ctx *ctx, const double *rd, const double *rh, uint64_t n, uint64_t f, uint64_t k, uint64_t seed,
+                                double *radius_out) {  // :384-492
+  k = std::min(k, n);
+  std::vector<uint64_t> assign, count;
+  std::vector<double> cents, dists;
+  AS_TRY(kmeans_lloyd(ctx, rd, rh, n, f, k, 20, seed + 100000, assign, cents));
+  centroids_of(rh, n, f, assign, k, cents, count);
+  for (uint64_t i = 0; i < n; ++i)
+    if (assign[i] < k) dists.push_back(dist2(rh + i * f, cents.data() + assign[i] * f, f));
+  if (dists.empty()) {
+    *radius_out = 1.0;
+    return AS_OK;
+  }
+  std::sort(dists.begin(), dists.end());
+  const uint64_t idx = std::min<uint64_t>((uint64_t)std::ceil((double)dists.size() * 0.9), dists.size() - 1);
+  const double p90 = dists[idx];
+  double min_inter = INFINITY;
+  bool any_inter = false;
+  for (uint64_t a = 0; a < k; ++a)
+    for (uint64_t b = a + 1; b < k; ++b)
+      if (count[a] > 0 && count[b] > 0) {
+        const double d = dist2(cents.data() + a * f, cents.data() + b * f, f);
+        any_inter = true;
+        if (d < min_inter) min_inter = d;
+      }
+  const double ratio = (min_inter < INFINITY && min_inter > 0.0) ? p90 / min_inter : 1.0;
+  if (p90 < 1e-8 || ratio < 0.01) *radius_out = any_inter ? std::max(min_inter * 0.15, 1e-6) : 1e-6;
+  else *radius_out = std::max(p90 * 1.5, 1e-6);
+  return AS_OK;
+}
+
+}  // namespace asx
+
+using namespace asx;
+
+struct as_jl {
+  int device = 0;
+  uint64_t original_dim = 0, reduced_dim = 0, seed = 0;
+  double *G = nullptr;  // original_dim x reduced_dim (device)
+};
+
+static int pre_check(as_ctx *ctx) {
+  if (!ctx) return AS_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AS_ERR_HIP, "hipSetDevice failed");
+  ctx->err.clear();
+  return AS_OK;
+}
+
+extern "C" {
+
+int as_two_nn_ratios(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, const uint64_t *sample_ids,
+                     uint64_t n_samples, double *ratios_out) {
+  AS_TRY(pre_check(ctx));
+  if (!rows || (n_samples && (!sample_ids || !ratios_out))) return fail(ctx, AS_ERR_ARG, "null argument");
+  for (uint64_t s = 0; s < n_samples; ++s)
+    if (sample_ids[s] >= n_rows) return fail(ctx, AS_ERR_ARG, "sample id out of range");
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n_rows * n_features));
+  return two_nn_ratios(ctx, R.p, n_rows, n_features, sample_ids, n_samples, ratios_out);
+}
+
+int as_kmeans_lloyd(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, uint64_t k, uint64_t max_iter,
+                    uint64_t seed, uint64_t *assignments_out, double *centroids_out) {
+  AS_TRY(pre_check(ctx));
+  if (!rows || !assignments_out || k == 0) return fail(ctx, AS_ERR_ARG, "null argument");
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n_rows * n_features));
+  HostRows H;
+  AS_TRY(H.get(ctx, rows, is_device_ptr(rows), 0, n_rows, n_features));
+  std::vector<uint64_t> assign;
+  std::vector<double> cents;
+  AS_TRY(kmeans_lloyd(ctx, R.p, H.p, n_rows, n_features, k, max_iter, seed, assign, cents));
+  std::memcpy(assignments_out, assign.data(), sizeof(uint64_t) * n_rows);
+  if (centroids_out) std::memcpy(centroids_out, cents.data(), sizeof(double) * cents.size());
+  return AS_OK;
+}
+
+int as_calinski_harabasz(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, const uint64_t *assignments,
+                         uint64_t k, double *score_out) {
+  AS_TRY(pre_check(ctx));
+  if (!rows || !assignments || !score_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  HostRows H;
+  AS_TRY(H.get(ctx, rows, is_device_ptr(rows), 0, n_rows, n_features));
+  const std::vector<uint64_t> a(assignments, assignments + n_rows);
+  *score_out = calinski_harabasz(H.p, n_rows, n_features, a, k);
+  return AS_OK;
+}
+
+// ClusteringHeuristic::compute_optimal_k, src/clustering.rs:36-72
+int as_compute_optimal_k(as_ctx *ctx, const double *rows, uint64_t n, uint64_t f, uint64_t seed, uint64_t *k_out, double *radius_out,
+                         uint64_t *id_out) {
+  AS_TRY(pre_check(ctx));
+  if (!rows || !k_out || !radius_out || !id_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n < 2 || f == 0) return fail(ctx, AS_ERR_SHAPE, "compute_optimal_k needs at least two rows");
+  const bool on_dev = is_device_ptr(rows);
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n * f));
+  // step 1: bounds from N / F and the Two-NN intrinsic dimension (:75-164)
+  uint64_t id_est;
+  if (n < 10) {
+    id_est = std::min<uint64_t>(f, 2);
+  } else {
+    const std::vector<uint64_t> ids = sample_indices(n, std::min<uint64_t>(n, 500), seed + 1);
+    std::vector<double> ratios(ids.size());
+    AS_TRY(two_nn_ratios(ctx, R.p, n, f, ids.data(), ids.size(), ratios.data()));
+    id_est = intrinsic_dimension(n, f, ratios.data(), ratios.size());
+  }
+  uint64_t k_min = std::max<uint64_t>((uint64_t)std::ceil(std::sqrt((double)n / 10.0)), 2);
+  uint64_t k_max = std::min({f, n / 10, 5 * id_est, (uint64_t)std::pow((double)n, 0.5)});
+  k_max = std::min(std::max(k_max, k_min + 1), n / 2);
+  // the <= 1000-row sample of steps 2 and 3 (:52-64), on both sides
+  const uint64_t ss = std::min<uint64_t>(n, 1000);
+  std::vector<double> sample;
+  if (n > ss) {
+    AS_TRY(gather_rows_host(ctx, R.p, true, sample_indices(n, ss, seed), f, sample));
+  } else {
+    HostRows H;
+    AS_TRY(H.get(ctx, rows, on_dev, 0, n, f));
+    sample.assign(H.p, H.p + n * f);
+  }
+  DevBuf<double> sd;
+  AS_TRY(sd.alloc(ctx, ss * f));
+  AS_HIP(ctx, copy_h2d(ctx, sd.p, sample.data(), sizeof(double) * ss * f));
+  uint64_t k_opt = k_min;
+  AS_TRY(step2_calinski_harabasz(ctx, sd.p, sample.data(), ss, f, k_min, k_max, seed, &k_opt));
+  AS_TRY(threshold_from_pilot(ctx, sd.p, sample.data(), ss, f, k_opt, seed, radius_out));
+  *k_out = k_opt;
+  *id_out = id_est;
+  return AS_OK;
+}
+
+// run_incremental_clustering_with_sampling without a sampler, src/clustering.rs:547-910, for a batch size (see the top of
+// the file and oracle/prestage.c): nearest centroids of a batch against the snapshot on the device, decisions and running
+// means in row order on the host.
+int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint64_t f, uint64_t max_clusters, double radius,
+                              uint64_t batch, double *centroids_out, uint64_t *n_clusters_out, int64_t *assignments_out,
+                              uint64_t *counts_out) {
+  AS_TRY(pre_check(ctx));
+  if (!rows || !centroids_out || !n_clusters_out || !assignments_out || !counts_out || max_clusters == 0)
+    return fail(ctx, AS_ERR_ARG, "null argument");
+  if (batch == 0) batch = 1;
+  const bool on_dev = is_device_ptr(rows);
+  DevIn<double> R;
+  AS_TRY(R.bind(ctx, rows, n * f));
+  DevBuf<double> cd, d2d;
+  DevBuf<uint64_t> idxd;
+  AS_TRY(cd.alloc(ctx, max_clusters * f));
+  AS_TRY(d2d.alloc(ctx, batch));
+  AS_TRY(idxd.alloc(ctx, batch));
+  std::vector<double> snap_d2(batch);
+  std::vector<uint64_t> snap_i(batch);
+  double *cents = centroids_out;
+  uint64_t nc = 0;
+  for (uint64_t i = 0; i < n; ++i) assignments_out[i] = -1;
+  HostRows H;
+  for (uint64_t b0 = 0; b0 < n; b0 += batch) {
+    const uint64_t bn = std::min(batch, n - b0), nc_snap = nc;
+    if (nc_snap == 0) {
+      std::fill(snap_d2.begin(), snap_d2.begin() + bn, INFINITY);
+      std::fill(snap_i.begin(), snap_i.begin() + bn, 0);
+    } else {
+      AS_HIP(ctx, copy_h2d(ctx, cd.p, cents, sizeof(double) * nc_snap * f));
+      AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc_snap, idxd.p, d2d.p));
+      AS_HIP(ctx, copy_d2h(ctx, snap_i.data(), idxd.p, sizeof(uint64_t) * bn));
+      AS_HIP(ctx, copy_d2h(ctx, snap_d2.data(), d2d.p, sizeof(double) * bn));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    AS_TRY(H.get(ctx, rows, on_dev, b0, bn, f));
+    for (uint64_t r = 0; r < bn; ++r) {
+      const double *row = H.p + r * f;
+      uint64_t bi = snap_i[r];
+      double bd = snap_d2[r];
+      for (uint64_t c = nc_snap; c < nc; ++c) {  // centroids created earlier in this batch, current values
+        const double d = dist2(row, cents + c * f, f);
+        if (d < bd) {
+          bd = d;
+          bi = c;
+        }
+      }
+      if (nc == 0) {
+        std::memcpy(cents, row, sizeof(double) * f);
+        counts_out[0] = 1;
+        assignments_out[b0 + r] = 0;
+        nc = 1;
+        continue;
+      }
+      if (nc < max_clusters && bd > radius * 0.5) {
+        std::memcpy(cents + nc * f, row, sizeof(double) * f);
+        counts_out[nc] = 1;
+        assignments_out[b0 + r] = (int64_t)nc;
+        ++nc;
+      } else if (bd <= radius) {
+        const double k_new = (double)counts_out[bi] + 1.0;
+        for (uint64_t j = 0; j < f; ++j) cents[bi * f + j] += (row[j] - cents[bi * f + j]) / k_new;
+        counts_out[bi] += 1;
+        assignments_out[b0 + r] = (int64_t)bi;
+      } else if (bd <= radius * 1.5) {
+        counts_out[bi] += 1;
+        assignments_out[b0 + r] = (int64_t)bi;
+      }
+    }
+  }
+  *n_clusters_out = nc;
+  return AS_OK;
+}
+
+// compute_jl_dimension, src/reduction.rs:126-140
+uint64_t as_jl_dimension(uint64_t n_points, double epsilon) {
+  const double log_n = std::log((double)n_points);
+  const double eps_sq = std::pow(epsilon, 2.0);
+  const uint64_t jl = (uint64_t)std::ceil(8.0 * log_n / eps_sq);
+  return std::max<uint64_t>(jl, 32);
+}
+
+int as_jl_create(as_ctx *ctx, uint64_t original_dim, uint64_t reduced_dim, uint64_t seed, as_jl **out) {
+  AS_TRY(pre_check(ctx));
+  if (!out || original_dim == 0 || reduced_dim == 0) return fail(ctx, AS_ERR_ARG, "bad projection shape");
+  as_jl *j = new as_jl();
+  j->device = ctx->device;
+  j->original_dim = original_dim;
+  j->reduced_dim = reduced_dim;
+  j->seed = seed;
+  AS_HIP(ctx, hipMalloc((void **)&j->G, sizeof(double) * original_dim * reduced_dim));
+  const uint64_t total = original_dim * reduced_dim;
+  hipLaunchKernelGGL(jl_gaussian_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, seed, total, j->G);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = j;
+  return AS_OK;
+}
+
+void as_jl_destroy(as_jl *jl) {
+  if (!jl) return;
+  (void)hipSetDevice(jl->device);
+  (void)hipFree(jl->G);
+  delete jl;
+}
+
+uint64_t as_jl_original_dim(const as_jl *jl) { return jl ? jl->original_dim : 0; }
+uint64_t as_jl_reduced_dim(const as_jl *jl) { return jl ? jl->reduced_dim : 0; }
+
+int as_jl_matrix(as_ctx *ctx, const as_jl *jl, double *g_out) {
+  AS_TRY(pre_check(ctx));
+  if (!jl || !g_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  const size_t bytes = sizeof(double) * jl->original_dim * jl->reduced_dim;
+  if (is_device_ptr(g_out)) AS_HIP(ctx, hipMemcpyAsync(g_out, jl->G, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  else AS_HIP(ctx, copy_d2h(ctx, g_out, jl->G, bytes));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+// project_matrix / ImplicitProjection::project, src/reduction.rs:142-203 (batched)
+int as_jl_project(as_ctx *ctx, const as_jl *jl, const double *rows, uint64_t n_rows, double *out) {
+  AS_TRY(pre_check(ctx));
+  if (!jl || (n_rows && (!rows || !out))) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n_rows == 0) return AS_OK;
+  const uint64_t d = jl->original_dim, r = jl->reduced_dim;
+  if (d * sizeof(double) > 64 * 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "original dimension too large for the projection kernel");
+  DevIn<double> X;
+  AS_TRY(X.bind(ctx, rows, n_rows * d));
+  DevOut<double> O;
+  AS_TRY(O.bind(ctx, out, n_rows * r));
+  {
+    ProfScope ps(ctx, "jl_project");
+    hipLaunchKernelGGL(jl_project_kernel, dim3((unsigned)n_rows), dim3(256), d * sizeof(double), ctx->stream, X.p, n_rows, d, jl->G, r,
+                       1.0 / std::sqrt((double)r), O.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  AS_TRY(O.finish(ctx));
+  return AS_OK;
+}
+
+}  // extern "C"

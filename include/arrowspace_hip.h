@@ -72,6 +72,7 @@ typedef struct {
 typedef struct as_ctx as_ctx;     /* device, stream, workspace */
 typedef struct as_csr as_csr;     /* CSR Laplacian resident in HBM (sprs::CsMat<f64> counterpart) */
 typedef struct as_index as_index; /* items + lambdas resident in HBM (ArrowSpace.data / .lambdas) */
+typedef struct as_jl as_jl;       /* a seeded Gaussian projection resident in HBM (ImplicitProjection, src/reduction.rs:166-203) */
 
 /* ---- context -------------------------------------------------------------------------- */
 int as_abi_version(void);
@@ -135,6 +136,50 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
  * n_centroids x dim, both host or device; out_idx[n_rows], out_dist2[n_rows]. */
 int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t dim, const double *centroids,
                          uint64_t n_centroids, uint64_t *out_idx, double *out_dist2);
+
+/* ---- clustering pre-stage: ClusteringHeuristic + run_incremental_clustering_with_sampling, src/clustering.rs ---------
+ * What runs inside ArrowSpaceBuilder::build immediately before the graph (start_clustering, src/eigenmaps.rs:175-235).
+ * Every pass over all N rows runs on the device in the reference's arithmetic (the 500 x N Two-NN distances, the
+ * nearest-centroid searches); the bookkeeping on the <= 1000-row sample and the centroid updates run on the host in
+ * the reference's order.  The reference's random draws (StdRng shuffles, smartcore KMeans, both absent here) are
+ * replaced by the build's own seeded definitions (csrc/prestage.hip), so results agree with the oracle bit for bit
+ * and with a reference run statistically (src/tests/test_taumode.rs:328-428 asks no more of its own two runs).
+ * Small outputs (k, radius, ratios, centroids, assignments, counts) are HOST pointers; `rows` may be host or device. */
+/* Two-NN ratios d2 / d1 of the sampled rows (estimate_intrinsic_dimension, :117-147); NaN where the reference skips a row */
+int as_two_nn_ratios(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, const uint64_t *sample_ids,
+                     uint64_t n_samples, double *ratios_out);
+/* kmeans_lloyd (:494-531) with the build's own seeded Lloyd in place of smartcore's: assignments_out[n_rows],
+ * centroids_out[k x n_features] (or NULL) */
+int as_kmeans_lloyd(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, uint64_t k, uint64_t max_iter,
+                    uint64_t seed, uint64_t *assignments_out, double *centroids_out);
+/* calinski_harabasz_score (:314-381) */
+int as_calinski_harabasz(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, const uint64_t *assignments,
+                         uint64_t k, double *score_out);
+/* compute_optimal_k (:36-72): step 1 bounds + Two-NN intrinsic dimension, step 2 Calinski-Harabasz sweep on a 1000-row
+ * sample, step 3 radius from a pilot k-means */
+int as_compute_optimal_k(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, uint64_t seed, uint64_t *k_out,
+                         double *radius_out, uint64_t *id_out);
+/* run_incremental_clustering_with_sampling without a sampler (:547-910).  batch = 1 is the reference's sequential mode
+ * (with_seed) exactly; a larger batch takes the snapshot of :571-594 once per batch (a legal schedule of its parallel
+ * mode) and lets a row also see the centroids created earlier in its batch.  centroids_out: max_clusters x n_features,
+ * assignments_out[n_rows] (-1: dropped), counts_out[max_clusters]. */
+int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, uint64_t max_clusters,
+                              double radius, uint64_t batch, double *centroids_out, uint64_t *n_clusters_out,
+                              int64_t *assignments_out, uint64_t *counts_out);
+
+/* ---- JL projection: src/reduction.rs ------------------------------------------------------------------------------------ */
+uint64_t as_jl_dimension(uint64_t n_points, double epsilon); /* compute_jl_dimension, :126-140 */
+/* ImplicitProjection (:166-203): an original_dim x reduced_dim N(0,1) matrix drawn from `seed` (the build's own
+ * counter-based stream: the reference's ChaCha8 draw is not reproducible without its crate), kept in HBM */
+int as_jl_create(as_ctx *ctx, uint64_t original_dim, uint64_t reduced_dim, uint64_t seed, as_jl **out);
+void as_jl_destroy(as_jl *jl);
+uint64_t as_jl_original_dim(const as_jl *jl);
+uint64_t as_jl_reduced_dim(const as_jl *jl);
+int as_jl_matrix(as_ctx *ctx, const as_jl *jl, double *g_out); /* the matrix, original_dim x reduced_dim, row-major */
+/* project_matrix / ImplicitProjection::project (:142-164,180-203), batched: out[n_rows x reduced_dim];
+ * out[t] = sum_i (x[i] * G[i][t]) * (1 / sqrt(reduced_dim)), i ascending, rounded as the reference rounds it.
+ * ArrowSpace::project_query (src/core.rs:509-529) is this call on the queries. */
+int as_jl_project(as_ctx *ctx, const as_jl *jl, const double *rows, uint64_t n_rows, double *out);
 
 /* Row-sharded form of the same neighbour search (one process per GPU).  cos(i,j) =
  * cos(j,i): every unordered pair of 256-row tiles is contracted once, by the rank that owns one of the two

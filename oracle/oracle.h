@@ -121,6 +121,23 @@ int aso_nearest_centroids(const double *rows, uint64_t n, uint64_t d, const doub
 int64_t aso_range_search(const double *lambdas, uint64_t n_items, double lambda_q, double eps,
                          uint64_t *idx_out, double *dist_out);
 
+/* ---- clustering pre-stage and JL projection (prestage.c; see its header for what is pinned) ------------------------- */
+int aso_pre_sample_indices(uint64_t n, uint64_t m, uint64_t seed, uint64_t *out);
+/* src/clustering.rs:117-147; NaN where the reference skips the row */
+int aso_two_nn_ratios(const double *rows, uint64_t n, uint64_t f, const uint64_t *sample_ids, uint64_t ns, double *ratios);
+uint64_t aso_intrinsic_dimension(uint64_t n, uint64_t f, const double *ratios, uint64_t ns);
+int aso_kmeans_lloyd(const double *rows, uint64_t n, uint64_t f, uint64_t k, uint64_t max_iter, uint64_t seed,
+                     uint64_t *assign, double *cents);
+double aso_calinski_harabasz(const double *rows, uint64_t n, uint64_t f, const uint64_t *assign, uint64_t k);
+uint64_t aso_step2_calinski_harabasz(const double *rows, uint64_t n, uint64_t f, uint64_t k_min, uint64_t k_max, uint64_t seed);
+double aso_threshold_from_pilot(const double *rows, uint64_t n, uint64_t f, uint64_t k, uint64_t seed);
+int aso_compute_optimal_k(const double *rows, uint64_t n, uint64_t f, uint64_t seed, uint64_t *k_out, double *radius_out,
+                          uint64_t *id_out);
+int64_t aso_incremental_clustering(const double *rows, uint64_t n, uint64_t f, uint64_t max_clusters, double radius,
+                                   uint64_t batch, double *cents, int64_t *assign, uint64_t *counts);
+uint64_t aso_jl_dimension(uint64_t n_points, double epsilon);
+int aso_jl_project(const double *rows, uint64_t n, uint64_t d, const double *G, uint64_t r, double *out);
+
 /* threads used by the OpenMP loops (for the cpu_baseline report) */
 int aso_num_threads(void);
 

