@@ -443,3 +443,29 @@ def test_prestage_oracle_pieces():
     G = rng.normal(size=(9, 4))
     P = O.jl_project(X[:7], G)
     np.testing.assert_allclose(P, X[:7] @ G / 2.0, rtol=1e-12)
+
+
+def test_parquet_formats_round_trip(tmp_path):
+    """The reference's on-disk formats (src/storage/parquet.rs:192-289,354-460,664-760): schema, order and a round
+    trip of what the oracle computes for a small set (pyarrow; no GPU)."""
+    import pyarrow.parquet as pq
+    from arrowspace_amd import storage as S
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(40, 6))
+    csr = O.build_laplacian(X, O.graph_params(0.9, 4, 4, 2.0, 0.5))
+    lam = rng.random(40)
+    fd = S.save_dense_matrix(X, str(tmp_path), "m", {"lambda_k": 4})
+    t = pq.read_table(fd)
+    assert t.column_names == ["name_id", "n_rows", "n_cols"] + ["col_%d" % c for c in range(6)] and t.num_rows == 40
+    assert np.array_equal(S.load_dense_matrix(fd), X)
+    fs = S.save_sparse_matrix(csr, str(tmp_path), "gl", {"lambda_k": 4})
+    t = pq.read_table(fs)
+    assert t.column_names == ["name_id", "n_rows", "n_cols", "nnz", "row", "col", "value"] and t.num_rows == len(csr[1])
+    (ip, ix, dv), shape = S.load_sparse_matrix(fs)
+    assert shape == (40, 40) and np.array_equal(ip, csr[0]) and np.array_equal(ix, csr[1]) and np.array_equal(dv, csr[2])
+    fl = S.save_lambda(lam, str(tmp_path), "lam")
+    assert pq.read_table(fl).column_names == ["name_id", "n_values", "row_index", "lambda"]
+    assert np.array_equal(S.load_lambda(fl), lam)
+    import json
+    meta = json.load(open(tmp_path / "gl_metadata.json"))
+    assert meta["files"]["matrix"]["file_type"] == "sparse" and meta["files"]["matrix"]["nnz"] == len(csr[1])
