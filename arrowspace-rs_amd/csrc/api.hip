@@ -357,7 +357,7 @@ int as_knn_join_thresholds(as_ctx *ctx, const double *rows, uint64_t n_nodes, ui
   }
   const int rc = knn_join_thresholds(ctx, rows, ctx->join.norms, (uint32_t)n_nodes, (uint32_t)dim, (uint32_t)row_begin,
                                      (uint32_t)row_count, theta_out, ctx->join.packed, ctx->join.theta2,
-                                     &ctx->join.theta2_valid);
+                                     &ctx->join.theta2_valid, ctx->join.packedh);
   if (rc != AS_OK) join_session_close(ctx);
   return rc;
 }

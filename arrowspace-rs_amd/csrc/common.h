@@ -372,7 +372,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, u
 // theta2_out (or nullptr): a second, looser threshold per row (bf16 pass only; left untouched otherwise, *has_theta2 = false)
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d,
                         uint32_t row_begin, uint32_t row_count, float *theta_out, const float *packed = nullptr,
-                        float *theta2_out = nullptr, bool *has_theta2 = nullptr, bool sharded = true);
+                        float *theta2_out = nullptr, bool *has_theta2 = nullptr, const void *packedh = nullptr);
 // packed16 / packedh = split-bf16 / f16 image of ALL rows when the caller already has the one its pipe needs, else nullptr
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,

@@ -645,6 +645,9 @@ uint32_t packed_tiles_f16(uint64_t n);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles);
+int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
+                        uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
+                        float *theta2_out);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of
 // the two where the bf16 pipe may have been used: every rank of a sharded build derives the same value)
@@ -677,10 +680,9 @@ bool knn_join_applies(const as_ctx *ctx, uint32_t n, uint32_t d) { return join_s
 // hashed 1-in-`rate` sample of ALL rows (the existing top-k pass with a short list).
 int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                         uint32_t row_count, float *theta_out, const float *packed, float *theta2_out, bool *has_theta2,
-                        bool sharded) {
+                        const void *packedh) {
   if (has_theta2) *has_theta2 = false;
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
-  (void)sharded;  // the lists cross the links in compact form (as_knn_join_pack), so both forms take the sparse sample
   const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
   const int64_t sample_opt = ctx->opt_join_sample > 0 ? ctx->opt_join_sample : 32;
   const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 64));
@@ -696,10 +698,14 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   DevBuf<double> ckey;
   AS_TRY(sid.alloc(ctx, ns));
   hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, rate, sample_half_bits(ns), sid.p);
-  if (ctx->opt_join_bf16) {  // thresholds on the bf16 pipe (mfma_theta_bf16.hip); dims it does not cover take the f32 pass
+  if (ctx->opt_join_bf16) {  // thresholds on a 16-bit pipe (mfma_theta_{f16,bf16}.hip); dims they do not cover take the f32 pass
     // second threshold: rank 2 m + 6 (about three times the candidates), for the second pass over what fails
     const uint32_t m2 = std::min<uint32_t>(48, 2 * m + 6);
-    const int rc = join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out, m2, theta2_out);
+    // the f16 image of all rows, when the join runs on it, serves as the row operand: one MFMA per k step
+    const int rc = (packedh && join_on_f16(ctx, d) && !(ctx->opt_debug & 32))
+                       ? join_thresholds_f16(ctx, rows, norms, d, packedh, row_begin, row_count, sid.p, ns, m, theta_out, m2,
+                                             theta2_out)
+                       : join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out, m2, theta2_out);
     if (rc == AS_OK && theta2_out && has_theta2) *has_theta2 = true;
     if (rc != AS_ERR_UNSUPPORTED) return rc;
   }
@@ -906,7 +912,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   JoinSources local{};  // outlives the block below: the later stages still read js->packed
   // own join on the bf16 pipe: the split image and the second (looser) thresholds stay for the second pass over
   // the rows the first one leaves uncertified (rect_stage below)
-  DevBuf<unsigned char> P16own;
+  DevBuf<unsigned char> P16own, Phown;
   DevBuf<float> theta_own, theta2_own;
   DevBuf<uint32_t> cnt_own, cand_own;
   bool have_theta2 = false;
@@ -916,15 +922,20 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t cap = knn_join_cap(ctx, K, false);
       AS_TRY(theta_own.alloc(ctx, n));
       AS_TRY(theta2_own.alloc(ctx, n));
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2, false));
+      if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
+        const uint32_t tiles = packed_tiles_f16(n);
+        AS_TRY(Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
+        AS_TRY(pack_f16_all(ctx, rows, norms, n, d, Phown.p, tiles));
+      }
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2, Phown.p));
       if (join_on_bf16(ctx, d)) {
         AS_TRY(P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
         AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
       }
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
-      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, nullptr));
-      if (ctx->opt_debug & ~(int64_t)(8 | 16)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
+      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, Phown.p));
+      if (ctx->opt_debug & ~(int64_t)(8 | 16 | 32)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
     }

@@ -1,0 +1,272 @@
+// mfma_theta_f16.hip -- candidate thresholds of the symmetric join from ONE f16 plane of the unit rows (the form the
+// join itself contracts: mfma_join_f16.hip): the kernel of mfma_theta_bf16.hip (scheme, geometry and what theta means
+// are described there) with one MFMA per k step instead of the three of the split-bf16 form.  theta only has to be a
+// sensible cut (any threshold is correct), and an f16 plane is good to ~2.5e-4 typically, far inside the spacing of the
+// order statistics the cut is taken from; the kernel is power-limited on the matrix pipe, so a third of the MFMAs is a
+// third of the time.  The A rows are read straight from the f16 image of ALL rows that the join packs anyway.
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "mfma_common.h"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+
+// LDS fragment reads issued and waited for by hand (see mfma_join_bf16.hip)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(f16x8 &x) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(PENDING));
+}
+
+__device__ __forceinline__ void pin16(float (&x)[16]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+               "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
+
+// KS = 16-wide k steps per row (d_pad / 16).  PA: image of the rows [row_begin, ...) whose thresholds are wanted
+// (a_tiles 128-row tiles, even count); PS: image of the ns sample rows, ns a multiple of 256 (s_tiles even, no
+// padded sample columns).  The sweep is the block pipeline of pair_join_bf16_kernel: per staged sample tile a wave
+// contracts four 32x32 blocks, the fragment reads run one k step ahead of their MFMAs, the 16 v_max of a block ride
+// behind the MFMAs of the next one (two accumulators alternate), the DMA pieces of the next tile are spread over
+// the blocks.  The tile loop is unrolled by two so that the parity bin of a tile is static.
+//
+// SEARCH: the rows are queries, the sample rows items, and what is reduced is the approximate search score
+// alpha * cos + beta * (1 - min(|lambda_q - lambda_x|, 1)) (src/core.rs:229-239) instead of the bare product: the
+// m-th largest sampled SCORE of a query is the guess for its K-th best score that the threshold scan of the search
+// works from (mfma_drivers.hip).  a_lam / s_lam: f32 lambdas of the rows (padded to whole super tiles) and of the
+// sample rows.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restrict__ PA, uint32_t a_supers,
+                                                           uint32_t row_count, const f16x8 *__restrict__ PS,
+                                                           uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
+                                                           uint32_t m2, float *__restrict__ theta2_out,
+                                                           uint32_t *__restrict__ unit_counter) {
+  constexpr bool SEARCH = false;
+  constexpr int kTileVecs = KS * 4 * 64;  // 16-B vectors of a 128-row tile (one plane)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f16x8 *bufB = reinterpret_cast<f16x8 *>(smem);                               // 2 x tile
+  float *s_max = reinterpret_cast<float *>(bufB);  // [8 waves][32 rows][65], aliases the ring once the sweep is over
+  __shared__ uint32_t s_unit;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5, lc = lane & 31;
+
+  // 128-row sample tile J -> LDS: 4 KS pieces of 1 KB, piece p by wave p mod 8; part < 0: all of a wave's pieces, else
+  // those that go with block `part` of the tile before
+  auto stage = [&](uint32_t J, int buf, int part) {
+    const f16x8 *src = PS + (size_t)J * kTileVecs;
+    f16x8 *dst = bufB + (size_t)buf * kTileVecs;
+#pragma unroll
+    for (int i = 0; i < (4 * KS + 7) / 8; ++i) {
+      const int p = wv + 8 * i;
+      if (p < 4 * KS && (part < 0 || (i & 3) == part))
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + p * 64 + lane), (lds_void *)(dst + p * 64), 16, 0, 0);
+    }
+  };
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
+    __syncthreads();
+    const uint32_t I = s_unit;
+    if (I >= a_supers) break;
+
+    f16x8 a_hi[KS];
+    {
+      const int row0 = wv * 32;
+      const size_t T = (size_t)2 * I + (row0 >> 7);
+      const int s0 = (row0 & 127) >> 5;
+      const f16x8 *a_src = PA + T * kTileVecs + (size_t)s0 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_hi[ks] = a_src[(size_t)ks * 256];
+      }
+    }
+    float rmax[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax[0][r] = rmax[1][r] = -__builtin_inff();
+    auto value = [&](float sdot, int) -> float { return sdot; };
+
+    f16x8 b_hi[2];
+#define AS_READ(SET, KSTEP, NN) lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);
+    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, auto k0_c, auto k1_c, v16f32 &acc) {
+      constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+      constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
+      v16f32 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+      for (int ks = K0; ks < K1; ++ks) {
+        const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
+        bool more = true;
+        if (ks + 1 < KS) {
+          switch (ks + 1) {  // compile-time offsets
+#define AS_CASE(K) case K: if (nxt) AS_READ(1, K, nn) else AS_READ(0, K, nn) break;
+            AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
+#undef AS_CASE
+          }
+        } else if (next_nn >= 0) {
+          if (nxt) AS_READ(1, 0, (next_nn < 0 ? 0 : next_nn)) else AS_READ(0, 0, (next_nn < 0 ? 0 : next_nn))
+        } else {
+          more = false;
+        }
+        if (more) {
+          if (cur) lds_wait<1>(b_hi[1]); else lds_wait<1>(b_hi[0]);
+        } else {
+          if (cur) lds_wait<0>(b_hi[1]); else lds_wait<0>(b_hi[0]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[ks], b_hi[cur], ks == 0 ? z : acc, 0, 0, 0);
+      }
+    };
+
+    v16f32 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending
+
+    __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring)
+    stage(0, 0, -1);
+    __syncthreads();
+    const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
+    for (uint32_t J = 0; J < s_tiles; J += 2) {
+#define AS_IC(V) std::integral_constant<int, (V)>{}
+// block NN of the tile in buffer PAR (= its parity bin); PREV_PAR = bin of the block whose maxima are taken now
+#define AS_BLOCK(PAR, NN, NEXT, CUR, PREV, PREV_PAR, MORE, JN)      \
+  {                                                                 \
+    constexpr int KH = (KS + 1) / 2;                                \
+    constexpr int kValu = SEARCH ? 4 : 2;                           \
+    const uint32_t b_addr = b_addr0 + (PAR) * kTileVecs * 16;       \
+    if ((MORE) && wv < 4) stage(JN, (PAR) ^ 1, NN);                 \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR); \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                  \
+        rmax[PREV_PAR][r] = __builtin_fmaxf(rmax[PREV_PAR][r], value(PREV[r], r)); \
+    _Pragma("unroll") for (int i = 0; i < KH; ++i) {                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);        \
+    }                                                               \
+    if ((MORE) && wv >= 4) stage(JN, (PAR) ^ 1, NN);                \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR); \
+    pin16(rmax[PREV_PAR]);  /* the maxima are taken by here: PREV's registers are free for the next block */ \
+  }
+      {  // even tile J (buffer 0, bin 0); tile J + 1 always exists
+        const uint32_t b_addr = b_addr0;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(0, 0, 1, accA, accB, 1, true, J + 1)
+        AS_BLOCK(0, 1, 2, accB, accA, 0, true, J + 1)
+        AS_BLOCK(0, 2, 3, accA, accB, 0, true, J + 1)
+        AS_BLOCK(0, 3, -1, accB, accA, 0, true, J + 1)
+      }
+      __syncthreads();  // tile J + 1 has landed; everyone is done with buffer 0
+      {  // odd tile J + 1 (buffer 1, bin 1)
+        const bool more = J + 2 < s_tiles;
+        const uint32_t b_addr = b_addr0 + kTileVecs * 16;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(1, 0, 1, accA, accB, 0, more, J + 2)
+        AS_BLOCK(1, 1, 2, accB, accA, 1, more, J + 2)
+        AS_BLOCK(1, 2, 3, accA, accB, 1, more, J + 2)
+        AS_BLOCK(1, 3, -1, accB, accA, 1, more, J + 2)
+      }
+#undef AS_BLOCK
+#undef AS_IC
+      __syncthreads();
+    }
+#undef AS_READ
+    // the last block of the sweep (bin 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax[1][r] = __builtin_fmaxf(rmax[1][r], value(accB[r], r));
+
+    // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row][parity * 32 + lane column]
+    float *wm = s_max + (size_t)wv * 32 * 65;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wm[((r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + lc] = rmax[0][r];
+      wm[((r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + 32 + lc] = rmax[1][r];
+    }
+    wave_sync();
+    if (lane < 32) {
+      const uint32_t row = I * 256 + wv * 32 + lane;
+      float vals[64];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) vals[c] = wm[lane * 65 + c];
+      float t = -__builtin_inff(), t1 = -__builtin_inff();
+      const uint32_t mm = theta2_out ? max(m, m2) : m;  // theta2_out: a second, looser order statistic (m2 >= m)
+      for (uint32_t k = 0; k < mm; ++k) {  // remove the current maximum mm - 1 times
+        float best = -__builtin_inff();
+        int at = 0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          const bool gt = vals[c] > best;
+          best = gt ? vals[c] : best;
+          at = gt ? c : at;
+        }
+        t = best;
+        if (k + 1 == m) t1 = best;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
+      }
+      // the image carries 2^7 per operand: products are 2^14 times the cosines
+      if (row < row_count && theta2_out) theta2_out[row] = t * (1.f / 16384.f);
+      t = t1;
+      if (row < row_count) theta_out[row] = t * (1.f / 16384.f);
+    }
+    wave_sync();
+  }
+}
+
+}  // namespace
+
+uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
+int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
+             void *P, uint32_t tiles);
+
+// theta_out[r], r < row_count, for rows [row_begin, row_begin + row_count) (row_begin a multiple of 256) against the
+// sample `sample_ids` (ns global row ids, ns a multiple of 256).  P_all: the f16 image of ALL rows (whole 512-row super
+// tiles: pack_f16_all).  dim <= 128; AS_ERR_UNSUPPORTED beyond.
+int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
+                        uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
+                        float *theta2_out) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || ns < 256 || ns % 256 != 0 || row_begin % 256 != 0)
+    return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: the sample must be a multiple of 256 rows");
+  const uint32_t s_tiles = ns / kTileRows;
+  const uint32_t a_supers = (row_count + 255) / 256;
+  DevBuf<unsigned char> PS;
+  DevBuf<uint32_t> unitc;
+  AS_TRY(PS.alloc(ctx, packed_vecs_f16(s_tiles, d) * 16));
+  AS_TRY(pack_f16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  const f16x8 *PA = (const f16x8 *)P_all + (size_t)(row_begin / kTileRows) * KS * 4 * 64;
+  const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
+  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
+  ProfScope ps(ctx, "knn_join_thresholds");
+#define AS_THETA(K)                                                                                                          \
+  case K:                                                                                                                    \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA, a_supers, row_count,              \
+                       (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p);                                 \
+    break;
+  switch (KS) {
+    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  }
+#undef AS_THETA
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sample image goes back to the workspace cache
+  return AS_OK;
+}
+
+}  // namespace asx
