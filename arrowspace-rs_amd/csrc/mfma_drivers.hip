@@ -343,28 +343,35 @@ __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32
 __device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, uint32_t C, uint32_t K, double delta, int rectify,
                                                      int lane) {
   if (C <= K) return C;
-  float tau = 0.f;
-  bool found = false;
-  for (uint32_t base = 0; base < C && !found; base += 64) {
-    const uint32_t c = base + lane;
-    bool mine = false;
-    float sc = 0.f;
-    if (c < C) {
-      sc = es[c];
-      uint32_t rank = 0;
-      for (uint32_t c2 = 0; c2 < C; ++c2) {
-        const float s2 = es[c2];
-        rank += (s2 > sc || (s2 == sc && c2 < c)) ? 1u : 0u;
-      }
-      mine = rank == K - 1;
-    }
-    const unsigned long long m = __ballot(mine);
-    if (m) {
-      tau = __shfl(sc, __ffsll((long long)m) - 1, 64);
-      found = true;
+  // tau by bisection over the order-preserving integer image of the scores: the largest v with |{s >= v}| >= K.
+  // Counting is a compare + ballot + popcount per 64 scores and round (the scores stay in registers); ranking every
+  // score against every other one took 3 x C LDS round trips per row and made the pruning pass compute-bound.
+  constexpr int kSlots = 16;  // 64 x 16 = 1024 scores
+  if (C > 64u * kSlots) return C;
+  uint32_t key[kSlots];
+  bool has_nan = false;
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) {
+    const uint32_t c = (uint32_t)q * 64u + lane;
+    key[q] = 0u;
+    if ((uint32_t)q * 64u < C && c < C) {  // (first test wave-uniform)
+      const float sc = es[c];
+      has_nan = has_nan || sc != sc;
+      const uint32_t b = __float_as_uint(sc);
+      key[q] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     }
   }
-  if (!found) return C;  // NaN scores: leave the list alone
+  if (__ballot(has_nan)) return C;  // NaN scores: leave the list alone
+  uint32_t prefix = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = prefix | (1u << bit);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q)
+      if ((uint32_t)q * 64u < C) cnt += (uint32_t)__builtin_popcountll(__ballot(key[q] >= trial));
+    if (cnt >= K) prefix = trial;
+  }
+  const float tau = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix);
   const double thr = (double)tau - 2.0 * delta;
   if (rectify && thr <= 0.0) return C;
   uint32_t out = 0;
@@ -380,6 +387,10 @@ __device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, ui
   wave_sync();
   return out;
 }
+
+}  // namespace asx
+#include "rerank_split.h"
+namespace asx {
 
 // Exact re-rank of the joined candidates of rows [row_begin, row_begin + row_count) (one wave per row),
 // certification against theta.  The candidates of a row come from n_src lists (one per rank that contracted
@@ -935,7 +946,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, Phown.p));
-      if (ctx->opt_debug & ~(int64_t)(8 | 16 | 32)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
+      if (ctx->opt_debug & 0xFF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
       js = &local;
     }
@@ -954,7 +965,19 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const int rr_rows = pruning ? 8 : 16, rr_nbuf = 1;
       const uint32_t kmax = pruning ? std::min<uint32_t>(cmax, std::max<uint32_t>(128, 2 * K)) : cmax;
       const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + rr_key_bytes(cmax, kmax) + (size_t)cmax * 4);
-      if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
+      DevBuf<uint32_t> records;
+      if (d == 128 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 8 <= 64 * 1024 && ctx->opt_debug != 5 &&
+          ctx->opt_rerank_split) {
+        // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
+        AS_TRY(records.alloc(ctx, (size_t)row_count * kRsWords + kRsRows));  // the last batch of a full record reads past it
+        hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
+                           ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
+                           force.p, prune_delta, rectify, records.p);
+        AS_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(rerank_score_d128_kernel, dim3(std::min<uint32_t>(row_count, 256 * 7 * 8)), dim3(64), kRsLds, ctx->stream, rows,
+                           (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p,
+                           (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u);
+      } else if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
 #define AS_RR(R, NB)                                                                                                       \
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));                               \

@@ -1,0 +1,351 @@
+// rerank_split.h -- exact re-rank of the joined candidate lists of the item graph (128-wide rows) as two kernels.
+// (included by mfma_drivers.hip behind prune_candidates / GraphBound)
+//
+// The one-kernel form (rerank_join_d128_kernel) serialises, per row and wave, list -> pruning -> four batches of
+// eight row fetches with their arithmetic in between: 21 ms at 1 M rows for 31 GB, 1.5 TB/s, latency-bound.  Here
+//   1. rerank_prune_kernel streams the lists (cheap LDS footprint: 32 waves per CU), prunes them by their stored
+//      scores and leaves one 512-byte record per row: count, flags, theta, the row's norm, up to 124 survivor ids;
+//   2. rerank_score_d128_kernel (one autonomous wave per workgroup) turns the rows of a wave into ONE stream of
+//      batches of eight candidate rows and keeps TWO batches in flight behind the one whose sequential f64 chains run.
+//      A 1 KB row gather takes ~6.5 us to land under load, so what sets the rate is the bytes in flight per CU; LDS
+//      (160 KB) holds 56 KB of them as LDS-DMA targets next to the rest of a wave's state (measured: 16 ms, no better
+//      than the one-kernel form), the VGPR file (512 KB) holds 192 KB: the rows are fetched INTO REGISTERS (one
+//      global_load_dwordx4 per row: the wave's 64 lanes take 16 B each), three register sets rotate, and a set is
+//      written to a single LDS tile only once it has landed.  The loads are asm so that their waits can be counted
+//      by hand (vmcnt retires in order: "at most 16 younger" = the set is there); everything data-dependent (counts,
+//      ids, theta, the norms of the row and of its candidates, gathered by the pruning kernel) comes through the
+//      scalar cache, which has its own counter -- a compiler-generated vector load in the loop would be waited for with
+//      vmcnt(0) and drain the pipeline.
+#pragma once
+
+namespace asx {
+
+constexpr int kRsWords = 384;          // u32 words of a record (1.5 KB)
+constexpr int kRsIdsAt = 4;            // word 0: count | overflow << 8 | force << 9; 1: theta; 2-3: norm of the row
+constexpr int kRsMaxIds = 124;         // survivor ids in words 4 .. 127
+constexpr int kRsNormsAt = 128;        // ... and their norms (f64) from word 128 on: what GraphDistPolicy::key reads per pair
+constexpr int kRsRows = 16;            // candidate rows per batch
+constexpr int kRsPitch = 1040;         // LDS pitch of a staged row (bytes)
+constexpr size_t kRsLds = 1024 + kRsRows * kRsPitch + 128 * 8 + 128 * 4;
+
+__global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, uint32_t row_count, const float *__restrict__ theta,
+                                                           const double *__restrict__ norms, uint32_t n_src,
+                                                           const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src,
+                                                           uint32_t cap, uint32_t cmax, uint32_t K,
+                                                           const uint8_t *__restrict__ force_exact, double prune_delta, int prune_rectify,
+                                                           uint32_t *__restrict__ records) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *es = reinterpret_cast<float *>(smem) + (size_t)wv * 2 * cmax;
+  uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
+  for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
+    const uint32_t a = row_begin + r;
+    uint32_t C = 0;
+    bool overflow = false;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
+      const uint32_t total = cnt_src[(size_t)sidx * row_count + r];
+      uint32_t take = min(total, cap);
+      overflow = overflow || total > cap;
+      if (C + take > cmax) {
+        overflow = true;
+        take = cmax - C;
+      }
+      const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + r) * cap;
+      for (uint32_t c = lane; c < take; c += 64) {
+        const uint2 e = src[c];
+        ei[C + c] = e.x;
+        es[C + c] = __uint_as_float(e.y);
+      }
+      C += take;
+    }
+    wave_sync();
+    C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
+    if (C > (uint32_t)kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
+      overflow = true;
+      C = kRsMaxIds;
+    }
+    uint32_t *rec = records + (size_t)r * kRsWords;
+    for (uint32_t c = lane; c < C; c += 64) {
+      const uint32_t j = ei[c];
+      rec[kRsIdsAt + c] = j;
+      reinterpret_cast<double *>(rec + kRsNormsAt)[c] = norms[j];
+    }
+    if (lane == 0) {
+      const bool force = force_exact && force_exact[a];
+      rec[0] = C | (overflow ? 0x100u : 0u) | (force ? 0x200u : 0u);
+      rec[1] = __float_as_uint(theta[a]);
+      const unsigned long long nb = (unsigned long long)__double_as_longlong(norms[a]);
+      rec[2] = (uint32_t)nb;
+      rec[3] = (uint32_t)(nb >> 32);
+    }
+    wave_sync();
+  }
+}
+
+typedef double rs_d2 __attribute__((ext_vector_type(2)));  // (a native vector: asm operands of struct type go through memory)
+struct RsSet {
+  rs_d2 v[kRsRows];  // this lane's 16 B of each candidate row of a batch
+  rs_d2 x;             // ... and of the row the batch belongs to (stored at the row's first batch; otherwise an L2 hit
+                       // that keeps every batch at the same number of loads)
+};
+constexpr int kRsLoads = kRsRows + 1;
+// row j of X -> one register per lane (lane l: bytes [16 l, 16 l + 16) of the row).  NOT valid before rs_landed.
+__device__ __forceinline__ void rs_gload16(rs_d2 &dst, uint32_t lane_off, const double *row) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+// at most N vector-memory operations younger than the set are pending: it has landed (vmcnt retires in order)
+template <int N>
+__device__ __forceinline__ void rs_landed(RsSet &s) {
+  static_assert(kRsRows == 16, "operand lists below");
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]), "+v"(s.v[6]), "+v"(s.v[7]), "+v"(s.x)
+               : "n"(N));
+  asm volatile("" : "+v"(s.v[8]), "+v"(s.v[9]), "+v"(s.v[10]), "+v"(s.v[11]), "+v"(s.v[12]), "+v"(s.v[13]), "+v"(s.v[14]), "+v"(s.v[15]));
+}
+
+__device__ __forceinline__ double rs_readlane(double v, uint32_t l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// the rows of a wave as a stream of batches: (row, batch in row); a row without survivors still has one (empty) batch
+struct RsCursor {
+  uint32_t r, b, C, nb;
+  bool done;
+  __device__ __forceinline__ void enter(const uint32_t *__restrict__ records, uint32_t row, uint32_t row_count) {
+    r = row;
+    b = 0;
+    done = row >= row_count;
+    C = done ? 0u : (records[(size_t)row * kRsWords] & 0xFFu);
+    nb = C ? (C + kRsRows - 1) / kRsRows : 1u;
+  }
+};
+
+__global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__restrict__ X, uint32_t row_begin, uint32_t row_count,
+                                                               const uint32_t *__restrict__ records, uint32_t K, int rectify,
+                                                               GraphBound bnd, double *__restrict__ out_key,
+                                                               uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows,
+                                                               uint32_t *__restrict__ fail_count, uint32_t dbg) {
+  constexpr uint32_t d = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  double *xrow = reinterpret_cast<double *>(smem);                       // the row itself
+  unsigned char *tile = smem + 1024;                                      // the batch whose chains run
+  double *ek = reinterpret_cast<double *>(tile + kRsRows * kRsPitch);     // keys and ids of the scored candidates
+  uint32_t *ei = reinterpret_cast<uint32_t *>(ek + 128);
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const uint32_t stride = gridDim.x;
+  const uint32_t chain_len = (dbg & 1) ? 16u : d;  // dbg: timing experiments only (outputs undefined)
+
+  RsCursor is, ps;  // issue side (two batches ahead), process side
+  is.enter(records, blockIdx.x, row_count);
+  ps = is;
+  if (ps.done) return;
+
+  // the ids of a batch come through the scalar cache (uniform addresses); slots past the count fetch the row itself
+  // (L2-hot), so that every batch is exactly kRsLoads loads and the waits can be counted
+  auto batch_ids = [&](const RsCursor &cu, uint32_t (&ids)[kRsRows]) __attribute__((always_inline)) {
+    const uint32_t row = cu.done ? 0u : cu.r;
+    const uint32_t *rec = records + (size_t)row * kRsWords + kRsIdsAt + (cu.done ? 0u : cu.b * kRsRows);
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(rec), q1 = *reinterpret_cast<const uint4 *>(rec + 4);
+    const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8), q3 = *reinterpret_cast<const uint4 *>(rec + 12);
+    const uint32_t raw[kRsRows] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+    for (int t = 0; t < kRsRows; ++t) ids[t] = (!cu.done && cu.b * kRsRows + t < cu.C) ? raw[t] : row_begin + row;
+  };
+#define AS_GL(S, T) rs_gload16(S.v[T], lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)ids_[T]) * d);
+#define AS_ISSUE(S)                                                                                                         \
+  {                                                                                                                         \
+    uint32_t ids_[kRsRows];                                                                                                 \
+    batch_ids(is, ids_);                                                                                                    \
+    AS_GL(S, 0) AS_GL(S, 1) AS_GL(S, 2) AS_GL(S, 3) AS_GL(S, 4) AS_GL(S, 5) AS_GL(S, 6) AS_GL(S, 7)                         \
+    AS_GL(S, 8) AS_GL(S, 9) AS_GL(S, 10) AS_GL(S, 11) AS_GL(S, 12) AS_GL(S, 13) AS_GL(S, 14) AS_GL(S, 15)                   \
+    rs_gload16(S.x, lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)(row_begin + (is.done ? 0u : is.r))) * d); \
+    if (!is.done && ++is.b == is.nb) is.enter(records, is.r + stride, row_count);                                           \
+  }
+
+  bool p_overflow = false, p_force = false;  // header of the process side's row
+  float p_theta = 0.f;
+  double p_na = 0.0;
+
+  // a landed set -> the LDS tile (and, at the first batch of a row, the row itself)
+#define AS_ST(S, T) *reinterpret_cast<rs_d2 *>(tile + T * kRsPitch + lane_off) = S.v[T];
+#define AS_STAGE(S)                                                                                                 \
+  {                                                                                                                 \
+    if (ps.b == 0) *reinterpret_cast<rs_d2 *>(reinterpret_cast<unsigned char *>(xrow) + lane_off) = S.x;          \
+    AS_ST(S, 0) AS_ST(S, 1) AS_ST(S, 2) AS_ST(S, 3) AS_ST(S, 4) AS_ST(S, 5) AS_ST(S, 6) AS_ST(S, 7)                 \
+    AS_ST(S, 8) AS_ST(S, 9) AS_ST(S, 10) AS_ST(S, 11) AS_ST(S, 12) AS_ST(S, 13) AS_ST(S, 14) AS_ST(S, 15)           \
+  }
+  auto process = [&]() {
+    uint32_t ids[kRsRows];
+    batch_ids(ps, ids);
+    double nrm[kRsRows];  // norms of the batch's candidates (slots past the count: whatever follows, unused)
+    {
+      const double *np = reinterpret_cast<const double *>(records + (size_t)ps.r * kRsWords + kRsNormsAt) + ps.b * kRsRows;
+#pragma unroll
+      for (int t = 0; t < kRsRows; ++t) nrm[t] = np[t];
+    }
+    if (ps.b == 0) {  // row entry
+      const uint4 h = *reinterpret_cast<const uint4 *>(records + (size_t)ps.r * kRsWords);
+      p_overflow = (h.x & 0x100u) != 0;
+      p_force = (h.x & 0x200u) != 0;
+      p_theta = __uint_as_float(h.y);
+      p_na = __longlong_as_double((long long)(((unsigned long long)h.w << 32) | h.z));
+    }
+    wave_sync();
+    const uint32_t c = ps.b * kRsRows + (uint32_t)lane;
+    if (!(dbg & 4) && lane < kRsRows && c < ps.C) {
+      // the reference's chain (src/core.rs:204-210): k ascending, multiply and add rounded separately
+      const rs_d2 *bj = reinterpret_cast<const rs_d2 *>(tile + (size_t)lane * kRsPitch);
+      const rs_d2 *xj = reinterpret_cast<const rs_d2 *>(xrow);
+      double acc = 0.0;
+      // groups of 8 k: the next group's LDS reads are issued before this group's chain
+      rs_d2 xa[4], ba[4], xb[4], bb[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        xa[h] = xj[h];
+        ba[h] = bj[h];
+      }
+#pragma unroll 1
+      for (uint32_t g = 0; g < chain_len / 16; ++g) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          xb[h] = xj[g * 8 + 4 + h];
+          bb[h] = bj[g * 8 + 4 + h];
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          acc = __dadd_rn(acc, __dmul_rn(xa[h].x, ba[h].x));
+          acc = __dadd_rn(acc, __dmul_rn(xa[h].y, ba[h].y));
+        }
+        if (g + 1 < chain_len / 16) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            xa[h] = xj[g * 8 + 8 + h];
+            ba[h] = bj[g * 8 + 8 + h];
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          acc = __dadd_rn(acc, __dmul_rn(xb[h].x, bb[h].x));
+          acc = __dadd_rn(acc, __dmul_rn(xb[h].y, bb[h].y));
+        }
+      }
+      double nj = nrm[0];
+#pragma unroll
+      for (int t = 1; t < kRsRows; ++t) nj = lane == t ? nrm[t] : nj;
+      uint32_t jj = ids[0];
+#pragma unroll
+      for (int t = 1; t < kRsRows; ++t) jj = lane == t ? ids[t] : jj;
+      const uint32_t a = row_begin + ps.r;
+      double key = __builtin_inf();
+      uint32_t id = kNoIdx;
+      if (a != jj) {  // GraphDistPolicy::key with the operands at hand
+        const double denom = __dmul_rn(p_na, nj);
+        double cs = denom > 1e-12 ? __ddiv_rn(acc, denom) : 0.0;
+        if (rectify) {
+          cs = fmin(fmax(cs, -1.0), 1.0);
+          cs = fmax(cs, 0.0);
+        }
+        const double kx = __dsub_rn(1.0, cs);
+        if (!(kx != kx)) {
+          key = kx;
+          id = jj;
+        }
+      }
+      ek[c] = key;
+      ei[c] = id;
+    }
+    wave_sync();
+    if (++ps.b < ps.nb) return;
+    // ---- the row is scored: rank, write its K best, certify ----
+    const uint32_t r = ps.r, C = ps.C;
+    double kth = -__builtin_inf();
+    uint32_t n_valid = 0;
+    if (!(dbg & 2)) {
+      // lane l holds candidates l and 64 + l; every candidate's (key, id) passes by as a wave-uniform value (readlane:
+      // no LDS round trip per comparison)
+      double k0v = __builtin_inf(), k1v = __builtin_inf();
+      uint32_t i0 = kNoIdx, i1 = kNoIdx;
+      if ((uint32_t)lane < C) {
+        k0v = ek[lane];
+        i0 = ei[lane];
+      }
+      if ((uint32_t)lane + 64 < C) {
+        k1v = ek[lane + 64];
+        i1 = ei[lane + 64];
+      }
+      uint32_t rank0 = 0, rank1 = 0;
+      const uint32_t c_lo = C < 64u ? C : 64u;
+      for (uint32_t c2 = 0; c2 < c_lo; ++c2) {
+        const double kc = rs_readlane(k0v, c2);
+        const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)i0, (int)c2);
+        rank0 += lex_less(kc, ic, k0v, i0) ? 1u : 0u;
+        rank1 += lex_less(kc, ic, k1v, i1) ? 1u : 0u;
+      }
+      for (uint32_t c2 = 64; c2 < C; ++c2) {
+        const double kc = rs_readlane(k1v, c2 - 64);
+        const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)i1, (int)(c2 - 64));
+        rank0 += lex_less(kc, ic, k0v, i0) ? 1u : 0u;
+        rank1 += lex_less(kc, ic, k1v, i1) ? 1u : 0u;
+      }
+      if (i0 != kNoIdx) {
+        ++n_valid;
+        if (rank0 < K) {
+          out_key[(uint64_t)r * K + rank0] = k0v;
+          out_idx[(uint64_t)r * K + rank0] = i0;
+          kth = fmax(kth, k0v);
+        }
+      }
+      if (i1 != kNoIdx) {
+        ++n_valid;
+        if (rank1 < K) {
+          out_key[(uint64_t)r * K + rank1] = k1v;
+          out_idx[(uint64_t)r * K + rank1] = i1;
+          kth = fmax(kth, k1v);
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      kth = fmax(kth, __shfl_xor(kth, o, 64));
+      n_valid += __shfl_xor(n_valid, o, 64);
+    }
+    for (uint32_t s = n_valid + lane; s < K; s += 64) {
+      out_key[(uint64_t)r * K + s] = __builtin_inf();
+      out_idx[(uint64_t)r * K + s] = kNoIdx;
+    }
+    // every pair that is not in the lists has an approximate cosine below theta
+    const bool ok = !p_overflow && !p_force && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
+    if (!ok && lane == 0 && !dbg) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    wave_sync();
+    ps.enter(records, ps.r + stride, row_count);
+  };
+
+  RsSet sA, sB;
+  AS_ISSUE(sA)
+  AS_ISSUE(sB)
+  for (;;) {
+    // a step: the older set has landed (the other one's loads are younger) -> LDS tile; its registers take the batch two
+    // ahead at once; then the chains run from the tile with two batches in flight
+#define AS_STEP(P)             \
+  {                            \
+    rs_landed<kRsLoads>(P);    \
+    AS_STAGE(P)                \
+    AS_ISSUE(P)                \
+    process();                 \
+    if (ps.done) break;        \
+  }
+    AS_STEP(sA)
+    AS_STEP(sB)
+#undef AS_STEP
+  }
+#undef AS_ISSUE
+#undef AS_STAGE
+#undef AS_GL
+#undef AS_ST
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batches issued past the end
+}
+
+}  // namespace asx
