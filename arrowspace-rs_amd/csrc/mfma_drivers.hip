@@ -866,7 +866,13 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const uint32_t KC = cand_capacity(ctx, K + 1);
   const bool wide = NC > kMaxNC;  // dim > 128: only the f32 pass has the k-panel loop
   const bool use_f32 = (ctx->opt_cand_precision != 64 || wide) && fits_f32(KC);
-  if ((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows || row_count == 0 || !rerank_fits(d))  // small, deep or very wide problems: exact scan
+  // deep tables (K beyond what the top-k kernels keep in LDS: KC > 40) still take the 16-bit join -- its lists hold 512
+  // candidates whatever K is -- and hand what it leaves open straight to the exact scans
+  const bool stages_fit = !(wide && !use_f32) && fits_f64(KC);
+  const bool deep_join = !stages_fit && !wide && K <= 64 && ctx->opt_cand_precision != 64 &&
+                         (join_on_f16(ctx, d) || join_on_bf16(ctx, d)) &&
+                         (js != nullptr || (row_begin == 0 && row_count == n && join_supported(ctx, n, d, 0)));
+  if ((!stages_fit && !deep_join) || n < 4 * kTileRows || row_count == 0 || !rerank_fits(d))  // small, deep or very wide problems: exact scan
     return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
 
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
@@ -916,7 +922,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   uint32_t n_fail = 0;
   // dim <= 128: symmetric threshold join (half the contractions).  Either the caller has run the join and
   // exchanged the candidate lists (row-sharded build: js), or the range is the whole matrix and it runs here.
-  const bool own_join = !js && use_f32 && row_begin == 0 && row_count == n &&
+  const bool own_join = !js && (use_f32 || deep_join) && row_begin == 0 && row_count == n &&
                         join_supported(ctx, n, d, 0);
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
@@ -1279,12 +1285,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   }
 
   // ---- stage 1b (after the join): f32 top-k pass over the gathered rows ----
-  if (use_join && !exact_direct(cur_n, n)) {
+  if (use_join && stages_fit && !exact_direct(cur_n, n)) {
     AS_TRY(mfma_stage(true, ids_a, pos_a, "knn_uncertified_rows_stage1b"));
     if (cur_n == 0) return AS_OK;
   }
   // ---- stage 2: f64 MFMA over the gathered rows ----
-  if (use_f32 && !wide && !exact_direct(cur_n, n)) {
+  if (use_f32 && stages_fit && !wide && !exact_direct(cur_n, n)) {
     AS_TRY(mfma_stage(false, ids_b, pos_b, "knn_uncertified_rows_stage2"));
     if (cur_n == 0) return AS_OK;
   }

@@ -273,6 +273,26 @@ def test_item_graph_join_on_either_pipe(ctx, join_on, n, d, pipe):
         assert 0 < ctx.stat("knn_join_delta_e9") <= 1.1e6  # <= the worst-case bound of one f16 plane, 1.02e-3 at dim 128
 
 
+@pytest.mark.parametrize("topk", [40, 63])
+@pytest.mark.parametrize("pipe", [16, 48])
+def test_item_graph_deep_tables_take_the_join(ctx, join_on, topk, pipe):
+    """topk + 1 beyond what the top-k kernels keep in LDS (41 .. 64): the 16-bit join still produces the candidates (its
+    lists do not depend on K) and what it leaves open goes straight to the exact scans; tables are the oracle's."""
+    X, _ = synth.mixture(3000, 96, seed=21, n_clusters=6, rank=4)
+    X[7] = 0.0
+    gp = A.GraphParams(0.9, 16, topk, 2.0, 0.25)
+    ctx.set_option("join_pipe", pipe)
+    try:
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_pipe") == pipe
+        assert ctx.stat("knn_uncertified_rows_stage1b") == 0 and ctx.stat("knn_uncertified_rows_stage2") == 0
+    finally:
+        ctx.set_option("join_pipe", 16)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+
+
 @pytest.mark.parametrize("sample,rank,cap", [(16, 5, 192), (2, 1, 24), (64, 8, 18), (4, 32, 1024)])
 @pytest.mark.parametrize("bf16", [1, 0])
 def test_item_graph_join_any_threshold_is_exact(ctx, join_on, sample, rank, cap, bf16):
