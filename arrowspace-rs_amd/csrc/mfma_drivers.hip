@@ -656,13 +656,16 @@ uint32_t packed_tiles_f16(uint64_t n);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles);
+int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of
 // the two where the bf16 pipe may have been used: every rank of a sharded build derives the same value)
-static bool join_on_f16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 16 && d <= 128; }
+// (rows wider than 128 take the panelled form of the f16 kernel: mfma_join_f16_wide.hip)
+static bool join_on_f16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 16 && d <= 2048; }
 static bool join_on_bf16(const as_ctx *ctx, uint32_t d) { return ctx->opt_join_pipe == 48 && d <= 128; }
 // the one-sided second pass over what the join leaves open runs on the split-bf16 planes after either 16-bit join
 static bool second_pass_bf16(const as_ctx *ctx, uint32_t d) { return (ctx->opt_join_pipe == 16 || ctx->opt_join_pipe == 48) && d <= 128; }
@@ -793,7 +796,8 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   if (f16) {
-    AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16"));
+    if (d <= 128) AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16"));
+    else AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16"));
     ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_f16_blocks"];
     ctx->stats["knn_join_pipe"] = 16;
   } else if (bf16) {

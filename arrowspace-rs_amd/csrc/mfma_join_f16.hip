@@ -30,6 +30,8 @@
 
 namespace asx {
 
+uint32_t f16_ksteps(uint32_t d);  // mfma_join_f16_wide.hip: ceil(d / 16), whole 64-wide panels beyond 128
+
 namespace {
 
 typedef float v16f32 __attribute__((ext_vector_type(16)));
@@ -416,13 +418,13 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
 }  // namespace
 
 // 16-B vectors of an f16 image with `tiles` 128-row tiles
-uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * ((d + 15) / 16) * 4 * 64; }
+uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d) { return (uint64_t)tiles * f16_ksteps(d) * 4 * 64; }
 // tiles of the f16 image of n rows: whole 512-row super tiles
 uint32_t packed_tiles_f16(uint64_t n) { return (uint32_t)((n + kSuperH - 1) / kSuperH) * 4; }
 
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles) {
-  const uint32_t KS = (d + 15) / 16;
+  const uint32_t KS = f16_ksteps(d);
   const uint64_t total = packed_vecs_f16(tiles, d);  // one thread per fragment lane
   ProfScope ps(ctx, "pack_unit_rows");
   hipLaunchKernelGGL(pack_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, row_ids, row0, n, d, KS, total,

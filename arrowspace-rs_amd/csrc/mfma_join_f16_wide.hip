@@ -1,0 +1,439 @@
+// mfma_join_f16_wide.hip -- the symmetric threshold join on one f16 plane (mfma_join_f16.hip: scheme, bound, meaning of the
+// lists) for rows WIDER than 128: configs[4] of the baseline is 1 M x 768.
+//
+// The narrow kernel keeps a wave's A fragments in registers for a whole sweep of B and finishes a 64 x 32 block -- test
+// included -- before it starts the next.  With 768 columns the fragments of 64 rows are 384 registers, and re-reading them
+// per block from L2 costs 8 x the bytes the matrix pipe can be fed with.  So the wide form is shaped like a GEMM: the
+// products of a pair of 256-row super tiles stay in the accumulators over the whole k range (a wave owns 128 x 128 of them:
+// 16 blocks of 32 x 32 = 256 accumulator registers; four waves, one workgroup per CU so that a wave has 512 registers),
+// A and B arrive as panels of 64 columns of k (32 KB each) through a 2-deep LDS-DMA ring with one barrier per panel, and
+// every fragment read from LDS feeds four MFMAs.  Per panel a wave issues 64 MFMAs, 32 ds_read_b128 and 16 DMA pieces.
+// The threshold test runs once per super-tile pair, on the finished accumulators: as in the narrow form the accumulators
+// start at -theta_row (scaled), so "some product reaches its row's threshold" is max(acc) >= 0, the column side is tested
+// conservatively on the same maximum, and only blocks that pass go through the element-wise test.
+//
+// Bytes: a pair of super tiles moves 2 x 256 x d x 2 B through L2 -> LDS for 2 x 256 x 256 x d flop: 7.8 B per kflop
+// (the narrow form: 1.9).  The workgroups of an XCD (32 CUs, one L2) therefore walk the pairs in rectangles of
+// 4 row super tiles x 8 column offsets, each XCD from its own counter: 15 distinct tiles per 32 pairs reach its L2
+// instead of 64.
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "mfma_common.h"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int kWS = 256;                  // rows per super tile of the wide form (two packed 128-row tiles)
+constexpr int kPK = 4;                    // 16-wide k steps per staged panel
+constexpr int kPanelVecs = kPK * 4 * 64;  // 16-B vectors of one 128-row tile's share of a panel (16 KB)
+constexpr uint32_t kQueueW = 256;         // queued appends per wave
+constexpr float kProductScaleW = 16384.f;
+constexpr int kSlotFloatsW = 36;
+constexpr size_t kBufBytes = (size_t)4 * kPanelVecs * 16;                    // A (2 tiles) + B (2 tiles) of a panel: 64 KB
+constexpr size_t kThrAt = 2 * kBufBytes;                                     // [2 units][row 256 | col 256] floats
+constexpr size_t kQueueAt = kThrAt + (size_t)2 * 512 * sizeof(float);
+constexpr size_t kSlotsAt = kQueueAt + (size_t)4 * kQueueW * (sizeof(uint2) + sizeof(float));
+constexpr size_t kWideLds = kSlotsAt + (size_t)4 * 4 * kSlotFloatsW * sizeof(float);
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_w(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_w<B + 1, E>(f);
+  }
+}
+__device__ __forceinline__ uint32_t lds_addr_w(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_read16_w(f16x8 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16f_w(v4f32 &dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_read4f_w(float &dst, uint32_t addr) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+// at most N LDS reads younger than these eight fragments are pending
+template <int N>
+__device__ __forceinline__ void lds_wait8_w(f16x8 (&a)[4], f16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+__device__ __forceinline__ void lds_write16f_w(uint32_t addr, const v4f32 &v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write8_w(uint32_t addr, uint2 v) {
+  const unsigned long long b = ((unsigned long long)v.y << 32) | v.x;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(b) : "memory");
+}
+__device__ __forceinline__ void lds_write4f_w(uint32_t addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_wait_all_w() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float thr_scaled_w(float t) {  // as thr_scaled of the narrow form
+  if (!(t <= 1.5f)) return __builtin_inff();
+  return __builtin_fmaxf(t, -1.5f) * kProductScaleW;
+}
+__device__ __forceinline__ float max16_w(const v16f32 &a) {
+  float m = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[3]), a[4]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[5]), a[6]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[7]), a[8]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[9]), a[10]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[11]), a[12]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[13]), a[14]);
+  return __builtin_fmaxf(m, a[15]);
+}
+__device__ __forceinline__ void append_w(uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand, uint32_t cap, uint32_t target,
+                                         uint32_t other, float score) {
+  const uint32_t pos = atomicAdd(cnt + target, 1u);
+  if (pos < cap) reinterpret_cast<uint2 *>(cand)[(size_t)target * cap + pos] = make_uint2(other, __float_as_uint(score));
+}
+
+// P: f16 image of ALL rows with KS = a multiple of kPK k steps per row (zero padded), T2 super tiles of 256 rows (the image
+// is padded to whole 512-row super tiles: an even number of them).  theta: T2 * 256 thresholds, +inf on padding rows.
+// Super tile I meets the column super tiles I .. I + (T2 - 1) / 2 (mod T2), the antipodal one only from the smaller index.
+__global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 *__restrict__ P, uint32_t KS, uint32_t T2,
+                                                                    uint32_t I_begin, uint32_t I_count, uint32_t n,
+                                                                    const float *__restrict__ theta, uint32_t cap,
+                                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
+                                                                    uint32_t *__restrict__ unit_counters, int dbg,
+                                                                    unsigned long long *__restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_next[2];  // (I, J) of the unit after the current one; I = ~0: none
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5, lc = lane & 31;
+  const int wr = wv >> 1, wc = wv & 1;  // the wave's 128 x 128 share: tile wr of the A super tile, tile wc of the B one
+  uint2 *queue = reinterpret_cast<uint2 *>(smem + kQueueAt) + (size_t)wv * kQueueW;
+  float *queue_s = reinterpret_cast<float *>(smem + kQueueAt + (size_t)4 * kQueueW * sizeof(uint2)) + (size_t)wv * kQueueW;
+  float *ex = reinterpret_cast<float *>(smem + kSlotsAt) + (size_t)wv * 4 * kSlotFloatsW;
+  uint32_t qn = 0;  // wave-uniform
+  auto lanes_below = [&](unsigned long long m) -> uint32_t {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
+  auto flush_queue = [&]() {
+    wave_sync();
+    for (uint32_t base = 0; base < qn; base += 64) {
+      const uint32_t e = base + lane;
+      if (e < qn) {
+        const uint2 v = queue[e];
+        append_w(cnt, cand, cap, v.x, v.y, queue_s[e]);
+      }
+    }
+    wave_sync();
+    qn = 0;
+  };
+
+  // ---- the pairs of this workgroup's XCD: rectangles of 4 row super tiles x 8 offsets, from the XCD's own counter ----
+  const uint32_t n_norm = (T2 - 1) / 2;
+  const uint32_t l_max = 1 + n_norm + 1;
+  const uint32_t n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8;
+  const uint32_t xcd = blockIdx.x & 7u;
+  auto fetch_unit = [&]() {  // thread 0: the next valid pair of this XCD into s_next
+    for (;;) {
+      const uint32_t v = atomicAdd(unit_counters + xcd, 1u);
+      const uint32_t sb = xcd + 8u * (v >> 5), w = v & 31u;
+      if (sb >= n_ib * n_ob) {
+        s_next[0] = 0xFFFFFFFFu;
+        return;
+      }
+      const uint32_t ib = sb / n_ob, ob = sb - ib * n_ob;
+      const uint32_t di = w & 3u, off = ob * 8u + (w >> 2);
+      if (ib * 4u + di >= I_count) continue;
+      const uint32_t I = I_begin + ib * 4u + di;
+      const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
+      if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) continue;
+      uint32_t J = I + off;
+      J = J >= T2 ? J - T2 : J;
+      s_next[0] = I;
+      s_next[1] = J;
+      return;
+    }
+  };
+
+  // DMA of panel p of the pair (I, J) into ring buffer `buf`: 64 pieces of 1 KB, 16 per wave (wave 0 / 1: the two tiles of
+  // A, 2 / 3: of B); pieces [q0, q0 + 4) of the wave's 16 with every k step of the panel before
+  const uint32_t np = KS / kPK;
+  auto dma_panel = [&](uint32_t I, uint32_t J, uint32_t p, int buf, int part) {
+    const uint32_t S = (wv < 2 ? I : J), tile = 2u * S + (uint32_t)(wv & 1);
+    const f16x8 *src = P + ((size_t)tile * KS + (size_t)p * kPK) * 256 + lane;
+    unsigned char *dst = smem + (size_t)buf * kBufBytes + (size_t)wv * kPanelVecs * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = part * 4 + i;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + q * 64), (lds_void *)(dst + q * 1024), 16, 0, 0);
+    }
+  };
+  // thresholds of the pair's rows and columns -> LDS (slot = parity of the unit): 1 KB each, waves 0 and 2
+  auto dma_thr = [&](uint32_t I, uint32_t J, int slot) {
+    if (wv == 0)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)I * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048), 16, 0, 0);
+    if (wv == 2)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)J * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048 + 1024),
+                                       16, 0, 0);
+  };
+
+  unsigned long long n_blk = 0, n_pass = 0;
+  if (tid == 0) fetch_unit();
+  __syncthreads();
+  uint32_t I = s_next[0], J = s_next[1];
+  if (I == 0xFFFFFFFFu) return;
+  __syncthreads();
+  int buf = 0, slot = 0;
+  static_for_w<0, 4>([&](auto part) { dma_panel(I, J, 0, 0, decltype(part)::value); });
+  dma_thr(I, J, 0);
+
+  v16f32 acc[4][4];
+  for (;;) {
+    if (tid == 0) fetch_unit();  // visible after the first barrier of the panel loop
+    uint32_t In = 0xFFFFFFFFu, Jn = 0;
+    f16x8 fa[2][4], fb[2][4];
+#define AS_FRAGS(SET, KSTEP, A_ADDR, B_ADDR)                        \
+  {                                                                 \
+    lds_read16_w<((KSTEP)*4 + 0) * 1024>(fa[SET][0], A_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 1) * 1024>(fa[SET][1], A_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 2) * 1024>(fa[SET][2], A_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 3) * 1024>(fa[SET][3], A_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 0) * 1024>(fb[SET][0], B_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 1) * 1024>(fb[SET][1], B_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 2) * 1024>(fb[SET][2], B_ADDR);       \
+    lds_read16_w<((KSTEP)*4 + 3) * 1024>(fb[SET][3], B_ADDR);       \
+  }
+    for (uint32_t p = 0; p < np; ++p) {
+      // fragments: A (ks, sa) of the wave's A tile, B (ks, sb) of its B tile
+      const uint32_t a_addr = lds_addr_w(smem + (size_t)buf * kBufBytes + (size_t)wr * kPanelVecs * 16) + (uint32_t)lane * 16u;
+      const uint32_t b_addr = lds_addr_w(smem + (size_t)buf * kBufBytes + (size_t)(2 + wc) * kPanelVecs * 16) + (uint32_t)lane * 16u;
+      const uint32_t a_next = lds_addr_w(smem + (size_t)(buf ^ 1) * kBufBytes + (size_t)wr * kPanelVecs * 16) + (uint32_t)lane * 16u;
+      const uint32_t b_next = lds_addr_w(smem + (size_t)(buf ^ 1) * kBufBytes + (size_t)(2 + wc) * kPanelVecs * 16) + (uint32_t)lane * 16u;
+      if (p == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // panel 0 and the thresholds of the pair have landed for everyone
+        In = s_next[0];
+        Jn = s_next[1];
+        AS_FRAGS(0, 0, a_addr, b_addr)
+      }
+      const bool last = p + 1 == np;
+      const bool more = !last || In != 0xFFFFFFFFu;
+      const uint32_t Id = last ? In : I, Jd = last ? Jn : J, pd = last ? 0u : p + 1;
+      if (p == 0) {  // the accumulators start at minus the scaled row thresholds
+        const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
+        static_for_w<0, 4>([&](auto sa_c) {
+          constexpr int sa = decltype(sa_c)::value;
+          v4f32 t[4];
+          lds_read16f_w<(sa * 32 + 0) * 4>(t[0], ra);
+          lds_read16f_w<(sa * 32 + 8) * 4>(t[1], ra);
+          lds_read16f_w<(sa * 32 + 16) * 4>(t[2], ra);
+          lds_read16f_w<(sa * 32 + 24) * 4>(t[3], ra);
+          lds_wait_all_w();
+          v16f32 nth;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nth[r] = -thr_scaled_w(t[r >> 2][r & 3]);
+          acc[sa][0] = nth;
+          acc[sa][1] = nth;
+          acc[sa][2] = nth;
+          acc[sa][3] = nth;
+        });
+      }
+      // The set of k step 0 has been requested (behind the barrier that made the panel visible).  Every k step requests
+      // the next one's fragments before its own MFMAs; the last one instead waits for the next panel's DMA and meets the
+      // barrier while its 16 MFMAs are still in the pipe, and requests the first fragments of the next panel behind it:
+      // at that point every wave holds all its fragments of this panel in registers, so its buffer may be overwritten.
+      static_for_w<0, kPK>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value, cur = ks & 1;
+        if (more && !(dbg & 4)) dma_panel(Id, Jd, pd, buf ^ 1, ks);
+        if constexpr (ks + 1 < kPK) {
+          if constexpr (cur == 0) AS_FRAGS(1, ks + 1, a_addr, b_addr) else AS_FRAGS(0, ks + 1, a_addr, b_addr)
+          lds_wait8_w<8>(fa[cur], fb[cur]);
+        } else {
+          if (last && more) dma_thr(Id, Jd, slot ^ 1);
+          lds_wait8_w<0>(fa[cur], fb[cur]);
+        }
+        static_for_w<0, 16>([&](auto e_c) {
+          constexpr int sa = decltype(e_c)::value >> 2, sb = decltype(e_c)::value & 3;
+          acc[sa][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][sa], fb[cur][sb], acc[sa][sb], 0, 0, 0);
+        });
+        if constexpr (ks + 1 == kPK) {
+          if (!last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            AS_FRAGS(0, 0, a_next, b_next)
+          }
+        }
+      });
+      buf ^= 1;
+    }
+#undef AS_FRAGS
+    // ---- the pair is contracted: coarse test per 32 x 32 block, element-wise test and listing for the few that pass ----
+    n_blk += 16;
+    if (!(dbg & 128)) {
+      const bool diag = I == J;
+      const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
+      const uint32_t ca = lds_addr_w(smem + kThrAt + (size_t)slot * 2048 + 1024) + (uint32_t)(wc * 128 + lc) * 4u;
+      float tcs[4];
+      lds_read4f_w(tcs[0], ca);
+      lds_read4f_w(tcs[1], ca + 32 * 4);
+      lds_read4f_w(tcs[2], ca + 64 * 4);
+      lds_read4f_w(tcs[3], ca + 96 * 4);
+      lds_wait_all_w();
+      // one copy of the listing code: a rolled loop over the 16 blocks (unrolled, its rare path costs hundreds of
+      // registers in live ranges); the block's accumulator is picked by a wave-uniform switch
+      v16f32 nth;
+      float tmax = -__builtin_inff();
+#pragma nounroll
+      for (int e = 0; e < 16; ++e) {
+        const int sa = e >> 2, sb = e & 3;
+        if (sb == 0) {  // thresholds of the 32 rows of this block row
+          v4f32 t[4];
+          const uint32_t rb = ra + (uint32_t)sa * 128u;
+          lds_read16f_w<0>(t[0], rb);
+          lds_read16f_w<32>(t[1], rb);
+          lds_read16f_w<64>(t[2], rb);
+          lds_read16f_w<96>(t[3], rb);
+          lds_wait_all_w();
+          tmax = -__builtin_inff();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ts = thr_scaled_w(t[r >> 2][r & 3]);
+            nth[r] = -ts;
+            if (ts < __builtin_inff()) tmax = __builtin_fmaxf(tmax, ts);
+          }
+          tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+        v16f32 x;
+        switch (e) {
+#define AS_PICK(E) case E: x = acc[(E) >> 2][(E)&3]; break;
+          AS_PICK(0) AS_PICK(1) AS_PICK(2) AS_PICK(3) AS_PICK(4) AS_PICK(5) AS_PICK(6) AS_PICK(7)
+          AS_PICK(8) AS_PICK(9) AS_PICK(10) AS_PICK(11) AS_PICK(12) AS_PICK(13) AS_PICK(14)
+          default: x = acc[3][3]; break;
+#undef AS_PICK
+        }
+        const uint32_t row_group0 = I * kWS + wr * 128 + sa * 32;
+        const uint32_t colbase = J * kWS + wc * 128 + sb * 32;
+        const float tcr = sb == 0 ? tcs[0] : (sb == 1 ? tcs[1] : (sb == 2 ? tcs[2] : tcs[3]));
+        const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled_w(tcr);
+        const bool h = max16_w(x) >= __builtin_fminf(0.f, tc - tmax);
+        if (__any(h) && !(dbg & 2)) {
+          // exact per-lane tests, then the lanes that hold a pair go through the wave's LDS slots four at a time
+          // (the listing of mfma_join_f16.hip)
+          v16f32 v;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = x[r] - nth[r];
+          const bool hit = max16_w(x) >= 0.f || max16_w(v) >= tc;
+          unsigned long long m = __ballot(hit);
+          n_pass += m ? 1 : 0;
+          // (LDS accesses by hand: the first panel of the next pair is in flight by LDS-DMA, and the compiler would wait
+          // it out in front of every LDS access it generates itself)
+          const uint32_t ex_addr = lds_addr_w(ex), q_addr = lds_addr_w(queue), qs_addr = lds_addr_w(queue_s);
+          while (m) {
+            const uint32_t rank = lanes_below(m);
+            if (hit && ((m >> lane) & 1ull) && rank < 4) {
+              const uint32_t sl = ex_addr + rank * (kSlotFloatsW * 4);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                v4f32 w0, w1;
+                w0[0] = x[4 * q]; w0[1] = x[4 * q + 1]; w0[2] = x[4 * q + 2]; w0[3] = x[4 * q + 3];
+                w1[0] = v[4 * q]; w1[1] = v[4 * q + 1]; w1[2] = v[4 * q + 2]; w1[3] = v[4 * q + 3];
+                lds_write16f_w(sl + q * 16, w0);
+                lds_write16f_w(sl + 64 + q * 16, w1);
+              }
+              lds_write4f_w(sl + 32 * 4, __uint_as_float((uint32_t)lane));
+              lds_write4f_w(sl + 33 * 4, tc);
+            }
+            const uint32_t filled = min(4u, (uint32_t)__builtin_popcountll(m));
+            const uint32_t sl_i = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
+            const uint32_t sl = ex_addr + sl_i * (kSlotFloatsW * 4);
+            const bool valid = sl_i < filled;
+            float ap, vv, tcx, srcf;
+            lds_read4f_w(ap, sl + r * 4);
+            lds_read4f_w(vv, sl + (16 + r) * 4);
+            lds_read4f_w(tcx, sl + 33 * 4);
+            lds_read4f_w(srcf, sl + 32 * 4);
+            lds_wait_all_w();
+            const uint32_t src = __float_as_uint(srcf);
+            const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
+            const bool inside = valid && row < n && col < n && row != col;
+            const bool w1 = inside && ap >= 0.f, w2 = inside && vv >= tcx;
+            const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
+            const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
+            if (qn + n1 + n2 > kQueueW) flush_queue();
+            const float sc = vv * (1.f / kProductScaleW);
+            if (w1) {
+              const uint32_t at = qn + lanes_below(m1);
+              lds_write8_w(q_addr + at * 8, make_uint2(row, col));
+              lds_write4f_w(qs_addr + at * 4, sc);
+            }
+            if (w2) {
+              const uint32_t at = qn + n1 + lanes_below(m2);
+              lds_write8_w(q_addr + at * 8, make_uint2(col, row));
+              lds_write4f_w(qs_addr + at * 4, sc);
+            }
+            qn += n1 + n2;
+            m &= m - 1;  // the four lowest lanes are done
+            m &= m - 1;
+            m &= m - 1;
+            m &= m - 1;
+          }
+        }
+      }
+    }
+    if (In == 0xFFFFFFFFu) break;
+    __syncthreads();  // s_next has been read by everyone before thread 0 fetches again
+    I = In;
+    J = Jn;
+    slot ^= 1;
+  }
+  flush_queue();
+  if (lane == 0) {
+    atomicAdd(stamps + 5, n_blk);
+    atomicAdd(stamps + 7, n_pass);
+  }
+}
+
+}  // namespace
+
+// k steps (16 wide) per row of the f16 image: rows wider than 128 are padded to whole 64-wide panels
+uint32_t f16_ksteps(uint32_t d) {
+  const uint32_t ks = (d + 15) / 16;
+  return ks <= 8 ? ks : (ks + kPK - 1) / kPK * kPK;
+}
+
+// The wide form of join_f16 (same contract; I_begin / I_count in 512-row super tiles as there): 128 < dim.
+int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
+  const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;  // 256-row super tiles of the image (whole 512-row ones)
+  DevBuf<unsigned long long> stamps;
+  DevBuf<uint32_t> counters;
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_TRY(counters.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(counters.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+  {
+    ProfScope ps(ctx, prof_name);
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
+    hipLaunchKernelGGL(pair_join_f16_wide_kernel, dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P, KS, T2, 2 * I_begin,
+                       std::min(2 * I_count, T2 - 2 * I_begin), n, theta, cap, cnt, cand, counters.p, (int)ctx->opt_debug, stamps.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  unsigned long long h[8];
+  AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[5];         // 32x32 blocks contracted (KS MFMAs each)
+  ctx->stats[std::string(prof_name) + "_blocks_listed"] = (int64_t)h[7];  // ... that listed at least one pair
+  return AS_OK;
+}
+
+}  // namespace asx

@@ -54,14 +54,14 @@ def _worker(rank, world, port, n, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(3000, 2), (1111, 2), (3000, 3), (1000, 3)])
-def test_ranks_sharing_one_gpu_match_single_process(tmp_path, n, world):
+@pytest.mark.parametrize("n,world,d", [(3000, 2, 64), (1111, 2, 64), (3000, 3, 64), (1000, 3, 64), (3000, 2, 200)])
+def test_ranks_sharing_one_gpu_match_single_process(tmp_path, n, world, d):
     """2 ranks; 2 ranks with a short second shard; 3 ranks with uneven shards (1024 / 1024 / 952 rows); 3 ranks of
-    which the last owns NO rows (512 / 488 / 0) and still takes part in every collective."""
+    which the last owns NO rows (512 / 488 / 0) and still takes part in every collective; rows wider than 128 (the
+    panelled f16 join over a rank's own super tiles)."""
     import arrowspace_amd as A
     from oracle import oracle_ctypes as O
     from tests import synth
-    d = 64
     mp.spawn(_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
     X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
     gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)

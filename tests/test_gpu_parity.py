@@ -273,6 +273,28 @@ def test_item_graph_join_on_either_pipe(ctx, join_on, n, d, pipe):
         assert 0 < ctx.stat("knn_join_delta_e9") <= 1.1e6  # <= the worst-case bound of one f16 plane, 1.02e-3 at dim 128
 
 
+@pytest.mark.parametrize("n,d", [(1100, 200), (640, 768), (2100, 384), (1500, 129), (3000, 300), (5200, 144)])
+@pytest.mark.parametrize("pipe", [16, 32])
+def test_item_graph_join_wide_rows_on_either_pipe(ctx, join_on, n, d, pipe):
+    """Rows wider than 128: the panelled f16 form (mfma_join_f16_wide.hip: 256-row super tiles, accumulators over the
+    whole k range, zero-padded to whole 64-wide panels) and the f32 MFMA form give the oracle's tables; zero rows and
+    rows that can form a tiny-norm pair included."""
+    X, _ = synth.mixture(n, d, seed=17, n_clusters=10, rank=4)
+    X[5] = 0.0
+    X[40] *= 1e-8
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    ctx.set_option("join_pipe", pipe)
+    try:
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_pipe") == pipe
+        assert ctx.stat("knn_join_blocks") > 0
+    finally:
+        ctx.set_option("join_pipe", 16)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+
+
 @pytest.mark.parametrize("topk", [40, 63])
 @pytest.mark.parametrize("pipe", [16, 48])
 def test_item_graph_deep_tables_take_the_join(ctx, join_on, topk, pipe):
