@@ -468,7 +468,7 @@ int as_knn_join_finish(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
     if (rc == AS_OK) {
       const bool second = ctx->join.theta2_valid && ctx->join.theta2_begin == row_begin && ctx->join.theta2_rows == row_count;
       const JoinSources js{ctx->join.packed, theta_all, n_src, cap / 2, cnt_src, cand_src, second ? ctx->join.theta2 : nullptr,
-                           ctx->join.packed16};
+                           ctx->join.packed16, ctx->join.packedh};
       rc = knn_mfma(ctx, rows, ctx->join.norms, n_nodes, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p, &js);
       if (rc == AS_OK && params->self_in_results)
         rc = apply_self_in_results(ctx, rows, ctx->join.norms, dim, row_begin, row_count, K, params->rectify, idx32.p, D.p);

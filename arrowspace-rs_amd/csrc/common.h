@@ -364,6 +364,7 @@ struct JoinSources {
   const uint32_t *cand;   // n_src x row_count x cap
   const float *theta2 = nullptr;    // looser thresholds of the rows of the range (by position), or nullptr
   const void *packed16 = nullptr;   // split-bf16 image of all rows, or nullptr (the second pass packs its own then)
+  const void *packedh = nullptr;    // f16 image of all rows (what the second pass over rows wider than 128 contracts)
 };
 // MFMA candidate pass + exact re-rank + certification + exact fall-back
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,

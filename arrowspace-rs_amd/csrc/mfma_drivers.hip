@@ -658,6 +658,11 @@ int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles);
 int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
                   uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
+int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
+                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
+int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
+                             uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
+                             float *theta2_out);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out);
@@ -716,7 +721,11 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
     // second threshold: rank 2 m + 6 (about three times the candidates), for the second pass over what fails
     const uint32_t m2 = std::min<uint32_t>(48, 2 * m + 6);
     // the f16 image of all rows, when the join runs on it, serves as the row operand: one MFMA per k step
-    const int rc = (packedh && join_on_f16(ctx, d) && !(ctx->opt_debug & 32))
+    const bool on_f16 = packedh && join_on_f16(ctx, d) && !(ctx->opt_debug & 32);
+    const int rc = on_f16 && d > 128
+                       ? join_thresholds_f16_wide(ctx, rows, norms, d, packedh, row_begin, row_count, sid.p, ns, m, theta_out, m2,
+                                                  theta2_out)
+                   : on_f16
                        ? join_thresholds_f16(ctx, rows, norms, d, packedh, row_begin, row_count, sid.p, ns, m, theta_out, m2,
                                              theta2_out)
                        : join_thresholds_bf16(ctx, rows, norms, d, row_begin, row_count, sid.p, ns, m, theta_out, m2, theta2_out);
@@ -957,7 +966,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, Phown.p));
       if (ctx->opt_debug & 0xFF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
-      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p};
+      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
       js = &local;
     }
     {
@@ -1185,9 +1194,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   // ~1 % of the rows; as a one-sided sweep of the split image this is a few ms, the f32 top-k pass over them 11-22.
   DevBuf<uint32_t> ids_r, pos_r;
   DevBuf<unsigned char> P16late;
-  if (use_join && js->theta2 && second_pass_bf16(ctx, d) && cur_n > 0 && cur_n <= n / 4) {
+  // rows wider than 128 after the f16 join: the same pass on the f16 plane (one-sided form of mfma_join_f16_wide.hip);
+  // the looser thresholds carry it, the bound stays the f16 one
+  const bool second_wide = join_on_f16(ctx, d) && d > 128 && js && js->packedh;
+  if (use_join && js->theta2 && (second_pass_bf16(ctx, d) || second_wide) && cur_n > 0 && cur_n <= n / 4) {
     const uint32_t nf = cur_n, cap2 = 1024;
-    const void *split_image = js->packed16;
+    const void *split_image = second_wide ? js->packedh : js->packed16;
     if (!split_image) {  // the join ran on the f16 plane: the split-bf16 image of all rows is only built when rows are left
       AS_TRY(P16late.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16late.p, b_alloc));
@@ -1198,7 +1210,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     DevBuf<float> theta_a;
     DevBuf<uint32_t> cnt_b, cand_b, unitc, oi, failx;
     DevBuf<double> ok;
-    AS_TRY(PA.alloc(ctx, packed_vecs_bf16(b_al, d) * 16));
+    AS_TRY(PA.alloc(ctx, (second_wide ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
     AS_TRY(theta_a.alloc(ctx, pad));
     AS_TRY(cnt_b.alloc(ctx, pad));
     AS_TRY(cand_b.alloc(ctx, (size_t)pad * cap2 * 2));
@@ -1206,23 +1218,28 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(ok.alloc(ctx, (size_t)nf * K));
     AS_TRY(oi.alloc(ctx, (size_t)nf * K));
     AS_TRY(failx.alloc(ctx, nf));
-    AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
+    if (second_wide) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
+    else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
                        js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p);
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-    AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
-                          "knn_mfma_join_bf16_second"));
+    if (second_wide)
+      AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second"));
+    else
+      AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
+                            "knn_mfma_join_bf16_second"));
+    const double delta2 = second_wide ? join_delta(ctx, d) : rect_delta(d);
     {
-      GraphBound bnd{rect_delta(d), rectify};
+      GraphBound bnd{delta2, rectify};
       ProfScope ps(ctx, "knn_rerank");
       const size_t lds = (size_t)4 * (d + cap2) * sizeof(double) + (size_t)4 * cap2 * sizeof(uint32_t);
       AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(nf, 4), 8192)),
                          dim3(256), lds, ctx->stream, rows, rows, cur_ids, d, 0u, nf, theta_a.p, 1u, cnt_b.p, cand_b.p, cap2, cap2,
-                         K, force.p, pol, bnd, (ctx->opt_debug & 16) ? -1.0 : rect_delta(d), rectify, ok.p, oi.p, failx.p,
+                         K, force.p, pol, bnd, (ctx->opt_debug & 16) ? -1.0 : delta2, rectify, ok.p, oi.p, failx.p,
                          fail_count.p, err.p);
       AS_HIP(ctx, hipGetLastError());
     }

@@ -103,14 +103,24 @@ __device__ __forceinline__ void append_w(uint32_t *__restrict__ cnt, uint32_t *_
 }
 
 // P: f16 image of ALL rows with KS = a multiple of kPK k steps per row (zero padded), T2 super tiles of 256 rows (the image
-// is padded to whole 512-row super tiles: an even number of them).  theta: T2 * 256 thresholds, +inf on padding rows.
-// Super tile I meets the column super tiles I .. I + (T2 - 1) / 2 (mod T2), the antipodal one only from the smaller index.
-__global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 *__restrict__ P, uint32_t KS, uint32_t T2,
-                                                                    uint32_t I_begin, uint32_t I_count, uint32_t n,
+// is padded to whole 512-row super tiles: an even number of them).
+// MODE 0: the symmetric join.  theta: T2 * 256 thresholds, +inf on padding rows.  Super tile I meets the column super
+//   tiles I .. I + (T2 - 1) / 2 (mod T2), the antipodal one only from the smaller index.
+// MODE 1: one-sided (the second pass over the rows the join left open).  PA: image of the nA gathered rows (I_count super
+//   tiles of 256, zero padded), a_ids their global ids, theta their thresholds by POSITION (+inf on padding); every PA super
+//   tile meets every super tile of P; lists (cnt / cand) are indexed by position.
+// MODE 2: thresholds.  PA = the image of the sample (I_count = its super tiles, no padding rows), rows = super tiles
+//   [I_begin, I_begin + T2) of P; a workgroup sweeps the whole sample for one row super tile at a time and leaves, per row,
+//   64 maxima over 64 disjoint sub-samples (column position mod 32 x parity of the 128-row tile, as mfma_theta_bf16.hip)
+//   in maxima[row - 256 I_begin][64]; a second kernel picks the order statistics.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA,
+                                                                    const uint32_t *__restrict__ a_ids, uint32_t KS, uint32_t T2,
+                                                                    uint32_t I_begin, uint32_t I_count, uint32_t n_rows, uint32_t n,
                                                                     const float *__restrict__ theta, uint32_t cap,
                                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
-                                                                    uint32_t *__restrict__ unit_counters, int dbg,
-                                                                    unsigned long long *__restrict__ stamps) {
+                                                                    float *__restrict__ maxima, uint32_t *__restrict__ unit_counters,
+                                                                    int dbg, unsigned long long *__restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_next[2];  // (I, J) of the unit after the current one; I = ~0: none
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,12 +146,28 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
     qn = 0;
   };
 
-  // ---- the pairs of this workgroup's XCD: rectangles of 4 row super tiles x 8 offsets, from the XCD's own counter ----
+  // ---- MODE 0 / 1: the pairs of this workgroup's XCD, rectangles of 4 row super tiles x 8 column offsets, from the XCD's
+  // own counter.  MODE 2: a row super tile from the one counter, then the sample super tiles in order.
   const uint32_t n_norm = (T2 - 1) / 2;
-  const uint32_t l_max = 1 + n_norm + 1;
+  const uint32_t l_max = MODE == 0 ? 1 + n_norm + 1 : T2;
   const uint32_t n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8;
   const uint32_t xcd = blockIdx.x & 7u;
-  auto fetch_unit = [&]() {  // thread 0: the next valid pair of this XCD into s_next
+  uint32_t t_row = 0xFFFFFFFFu, t_col = 0;  // MODE 2, thread 0: where the sweep stands
+  auto fetch_unit = [&]() {  // thread 0: the next valid pair into s_next
+    if (MODE == 2) {
+      if (t_row == 0xFFFFFFFFu || ++t_col == I_count) {
+        const uint32_t v = atomicAdd(unit_counters, 1u);
+        t_row = v < T2 ? v : 0xFFFFFFFFu;
+        t_col = 0;
+        if (v >= T2) {
+          s_next[0] = 0xFFFFFFFFu;
+          return;
+        }
+      }
+      s_next[0] = I_begin + t_row;
+      s_next[1] = t_col;
+      return;
+    }
     for (;;) {
       const uint32_t v = atomicAdd(unit_counters + xcd, 1u);
       const uint32_t sb = xcd + 8u * (v >> 5), w = v & 31u;
@@ -153,6 +179,12 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       const uint32_t di = w & 3u, off = ob * 8u + (w >> 2);
       if (ib * 4u + di >= I_count) continue;
       const uint32_t I = I_begin + ib * 4u + di;
+      if (MODE == 1) {
+        if (off >= T2) continue;
+        s_next[0] = I;
+        s_next[1] = off;
+        return;
+      }
       const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
       if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) continue;
       uint32_t J = I + off;
@@ -167,8 +199,10 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   // A, 2 / 3: of B); pieces [q0, q0 + 4) of the wave's 16 with every k step of the panel before
   const uint32_t np = KS / kPK;
   auto dma_panel = [&](uint32_t I, uint32_t J, uint32_t p, int buf, int part) {
+    // rows (waves 0, 1): the gathered rows' image in MODE 1; columns (waves 2, 3): the sample's in MODE 2
     const uint32_t S = (wv < 2 ? I : J), tile = 2u * S + (uint32_t)(wv & 1);
-    const f16x8 *src = P + ((size_t)tile * KS + (size_t)p * kPK) * 256 + lane;
+    const f16x8 *img = (MODE == 1 && wv < 2) || (MODE == 2 && wv >= 2) ? PA : P;
+    const f16x8 *src = img + ((size_t)tile * KS + (size_t)p * kPK) * 256 + lane;
     unsigned char *dst = smem + (size_t)buf * kBufBytes + (size_t)wv * kPanelVecs * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -178,9 +212,10 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   };
   // thresholds of the pair's rows and columns -> LDS (slot = parity of the unit): 1 KB each, waves 0 and 2
   auto dma_thr = [&](uint32_t I, uint32_t J, int slot) {
+    if (MODE == 2) return;
     if (wv == 0)
       __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)I * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048), 16, 0, 0);
-    if (wv == 2)
+    if (wv == 2 && MODE == 0)
       __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)J * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048 + 1024),
                                        16, 0, 0);
   };
@@ -196,6 +231,13 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   dma_thr(I, J, 0);
 
   v16f32 acc[4][4];
+  v16f32 rmax[MODE == 2 ? 4 : 1];  // MODE 2: running maxima of the wave's rows over the columns = lc (mod 32) of its half
+  if (MODE == 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rmax[MODE == 2 ? q : 0][r] = -__builtin_inff();
+  }
   for (;;) {
     if (tid == 0) fetch_unit();  // visible after the first barrier of the panel loop
     uint32_t In = 0xFFFFFFFFu, Jn = 0;
@@ -227,7 +269,13 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       const bool last = p + 1 == np;
       const bool more = !last || In != 0xFFFFFFFFu;
       const uint32_t Id = last ? In : I, Jd = last ? Jn : J, pd = last ? 0u : p + 1;
-      if (p == 0) {  // the accumulators start at minus the scaled row thresholds
+      if (p == 0 && MODE == 2) {
+        static_for_w<0, 16>([&](auto e_c) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[decltype(e_c)::value >> 2][decltype(e_c)::value & 3][r] = 0.f;
+        });
+      }
+      if (p == 0 && MODE != 2) {  // the accumulators start at minus the scaled row thresholds
         const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
         static_for_w<0, 4>([&](auto sa_c) {
           constexpr int sa = decltype(sa_c)::value;
@@ -277,16 +325,35 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
 #undef AS_FRAGS
     // ---- the pair is contracted: coarse test per 32 x 32 block, element-wise test and listing for the few that pass ----
     n_blk += 16;
-    if (!(dbg & 128)) {
-      const bool diag = I == J;
+    if (MODE == 2) {
+      static_for_w<0, 16>([&](auto e_c) {
+        constexpr int sa = decltype(e_c)::value >> 2, sb = decltype(e_c)::value & 3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rmax[MODE == 2 ? sa : 0][r] = __builtin_fmaxf(rmax[MODE == 2 ? sa : 0][r], acc[sa][sb][r]);
+      });
+      if (In != I) {  // the sweep of this row super tile is over: its maxima go out (32 consecutive floats per row and half wave)
+        static_for_w<0, 4>([&](auto sa_c) {
+          constexpr int sa = decltype(sa_c)::value;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t row = (I - I_begin) * kWS + wr * 128 + sa * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            maxima[(size_t)row * 64 + wc * 32 + lc] = rmax[MODE == 2 ? sa : 0][r] * (1.f / kProductScaleW);
+            rmax[MODE == 2 ? sa : 0][r] = -__builtin_inff();
+          }
+        });
+      }
+    } else if (!(dbg & 128)) {
+      const bool diag = MODE == 0 && I == J;
       const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
       const uint32_t ca = lds_addr_w(smem + kThrAt + (size_t)slot * 2048 + 1024) + (uint32_t)(wc * 128 + lc) * 4u;
-      float tcs[4];
-      lds_read4f_w(tcs[0], ca);
-      lds_read4f_w(tcs[1], ca + 32 * 4);
-      lds_read4f_w(tcs[2], ca + 64 * 4);
-      lds_read4f_w(tcs[3], ca + 96 * 4);
-      lds_wait_all_w();
+      float tcs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0) {
+        lds_read4f_w(tcs[0], ca);
+        lds_read4f_w(tcs[1], ca + 32 * 4);
+        lds_read4f_w(tcs[2], ca + 64 * 4);
+        lds_read4f_w(tcs[3], ca + 96 * 4);
+        lds_wait_all_w();
+      }
       // one copy of the listing code: a rolled loop over the 16 blocks (unrolled, its rare path costs hundreds of
       // registers in live ranges); the block's accumulator is picked by a wave-uniform switch
       v16f32 nth;
@@ -322,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
         const uint32_t row_group0 = I * kWS + wr * 128 + sa * 32;
         const uint32_t colbase = J * kWS + wc * 128 + sb * 32;
         const float tcr = sb == 0 ? tcs[0] : (sb == 1 ? tcs[1] : (sb == 2 ? tcs[2] : tcs[3]));
-        const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled_w(tcr);
+        const float tc = (MODE != 0 || diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled_w(tcr);
         const bool h = max16_w(x) >= __builtin_fminf(0.f, tc - tmax);
         if (__any(h) && !(dbg & 2)) {
           // exact per-lane tests, then the lanes that hold a pair go through the wave's LDS slots four at a time
@@ -363,7 +430,9 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
             lds_wait_all_w();
             const uint32_t src = __float_as_uint(srcf);
             const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
-            const bool inside = valid && row < n && col < n && row != col;
+            bool inside = valid && col < n && row < n_rows;
+            if (MODE == 1) inside = inside && a_ids[row < n_rows ? row : 0] != col;  // lists by position, self by global id
+            else inside = inside && row != col;
             const bool w1 = inside && ap >= 0.f, w2 = inside && vv >= tcx;
             const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
             const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
@@ -409,12 +478,44 @@ uint32_t f16_ksteps(uint32_t d) {
   return ks <= 8 ? ks : (ks + kPK - 1) / kPK * kPK;
 }
 
-// The wide form of join_f16 (same contract; I_begin / I_count in 512-row super tiles as there): 128 < dim.
-int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
-  const uint32_t KS = f16_ksteps(d);
-  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
-  const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;  // 256-row super tiles of the image (whole 512-row ones)
+// m-th (and m2-th) largest of the 64 sub-sample maxima of every row (mfma_theta_bf16.hip: what theta means)
+__global__ void theta_select_wide_kernel(const float *__restrict__ maxima, uint32_t row_count, uint32_t m, uint32_t m2,
+                                         float *__restrict__ theta_out, float *__restrict__ theta2_out) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= row_count) return;
+  float vals[64];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const float4 q = reinterpret_cast<const float4 *>(maxima + (size_t)row * 64)[c];
+    vals[4 * c] = q.x;
+    vals[4 * c + 1] = q.y;
+    vals[4 * c + 2] = q.z;
+    vals[4 * c + 3] = q.w;
+  }
+  float t = -__builtin_inff(), t1 = -__builtin_inff();
+  const uint32_t mm = theta2_out ? max(m, m2) : m;
+  for (uint32_t k = 0; k < mm; ++k) {  // remove the current maximum mm - 1 times
+    float best = -__builtin_inff();
+    int at = 0;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      const bool gt = vals[c] > best;
+      best = gt ? vals[c] : best;
+      at = gt ? c : at;
+    }
+    t = best;
+    if (k + 1 == m) t1 = best;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
+  }
+  if (theta2_out) theta2_out[row] = t;
+  theta_out[row] = t1;
+}
+
+template <int MODE>
+static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const void *PA, const uint32_t *a_ids, uint32_t KS,
+                       uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_rows, uint32_t n, const float *theta,
+                       uint32_t cap, uint32_t *cnt, uint32_t *cand, float *maxima) {
   DevBuf<unsigned long long> stamps;
   DevBuf<uint32_t> counters;
   AS_TRY(stamps.alloc(ctx, 8));
@@ -423,9 +524,11 @@ int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I
   AS_HIP(ctx, hipMemsetAsync(counters.p, 0, 8 * sizeof(uint32_t), ctx->stream));
   {
     ProfScope ps(ctx, prof_name);
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
-    hipLaunchKernelGGL(pair_join_f16_wide_kernel, dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P, KS, T2, 2 * I_begin,
-                       std::min(2 * I_count, T2 - 2 * I_begin), n, theta, cap, cnt, cand, counters.p, (int)ctx->opt_debug, stamps.p);
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kWideLds));
+    hipLaunchKernelGGL((pair_join_f16_wide_kernel<MODE>), dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P,
+                       (const f16x8 *)PA, a_ids, KS, T2, I_begin, I_count, n_rows, n, theta, cap, cnt, cand, maxima, counters.p,
+                       (int)ctx->opt_debug, stamps.p);
     AS_HIP(ctx, hipGetLastError());
   }
   unsigned long long h[8];
@@ -433,6 +536,54 @@ int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[5];         // 32x32 blocks contracted (KS MFMAs each)
   ctx->stats[std::string(prof_name) + "_blocks_listed"] = (int64_t)h[7];  // ... that listed at least one pair
+  return AS_OK;
+}
+
+// The wide form of join_f16 (same contract; I_begin / I_count in 512-row super tiles as there): 128 < dim.
+int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
+                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
+  const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;  // 256-row super tiles of the image (whole 512-row ones)
+  return launch_wide<0>(ctx, prof_name, P, nullptr, nullptr, KS, T2, 2 * I_begin, std::min(2 * I_count, T2 - 2 * I_begin), n, n, theta,
+                        cap, cnt, cand, nullptr);
+}
+
+// One-sided pass: the nA gathered rows (image PA: whole 256-row super tiles, zero padded; a_ids their global ids; theta_a
+// their thresholds by position, +inf on padding) against all n rows of P.  cnt / cand (by position; cnt zeroed by the caller).
+int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
+                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
+  const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
+  return launch_wide<1>(ctx, prof_name, P, PA, a_ids, KS, T2, 0, (nA + kWS - 1) / kWS, nA, n, theta_a, cap, cnt, cand, nullptr);
+}
+
+int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
+             void *P, uint32_t tiles);
+uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
+
+// Thresholds of rows [row_begin, row_begin + row_count) (row_begin a multiple of 256) against the sample (ns ids, ns a
+// multiple of 256) for rows wider than 128: the contract of join_thresholds_f16 (mfma_theta_f16.hip).
+int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
+                             uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
+                             float *theta2_out) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || ns < 256 || ns % 256 != 0 || row_begin % 256 != 0)
+    return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: the sample must be a multiple of 256 rows");
+  const uint32_t s_tiles = ns / kTileRows, row_supers = (row_count + kWS - 1) / kWS;
+  DevBuf<unsigned char> PS;
+  DevBuf<float> maxima;
+  AS_TRY(PS.alloc(ctx, packed_vecs_f16(s_tiles, d) * 16));
+  AS_TRY(pack_f16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));
+  AS_TRY(launch_wide<2>(ctx, "knn_join_thresholds", P_all, PS.p, nullptr, KS, row_supers, row_begin / kWS, ns / kWS, row_count, ns,
+                        nullptr, 0, nullptr, nullptr, maxima.p));
+  hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(row_count, 64)), dim3(64), 0, ctx->stream, maxima.p, row_count, m, m2, theta_out,
+                     theta2_out);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
   return AS_OK;
 }
 
