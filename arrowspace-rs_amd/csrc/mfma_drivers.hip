@@ -985,17 +985,27 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t kmax = pruning ? std::min<uint32_t>(cmax, std::max<uint32_t>(128, 2 * K)) : cmax;
       const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + rr_key_bytes(cmax, kmax) + (size_t)cmax * 4);
       DevBuf<uint32_t> records;
-      if (d == 128 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 8 <= 64 * 1024 && ctx->opt_debug != 5 &&
-          ctx->opt_rerank_split) {
+      if (d % 128 == 0 && d <= 1024 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 8 <= 64 * 1024 &&
+          ctx->opt_debug != 5 && ctx->opt_rerank_split) {
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
-        AS_TRY(records.alloc(ctx, (size_t)row_count * kRsWords + kRsRows));  // the last batch of a full record reads past it
+        const int slots = d == 128 ? 2 : 4;  // 124 / 252 survivors per record
+        AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
         hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
                            ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                           force.p, prune_delta, rectify, records.p);
+                           force.p, prune_delta, rectify, records.p, slots);
         AS_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(rerank_score_d128_kernel, dim3(std::min<uint32_t>(row_count, 256 * 7 * 8)), dim3(64), kRsLds, ctx->stream, rows,
-                           (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p,
-                           (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u);
+#define AS_SCORE(PC)                                                                                                             \
+  case PC:                                                                                                                       \
+    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(std::min<uint32_t>(row_count, 256 * 7 * 8)), dim3(64), \
+                       rs_lds(PC == 1 ? 2 : 4), ctx->stream, \
+                       rows, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, \
+                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u);                                             \
+    break;
+        switch (d / 128) {
+          AS_SCORE(1) AS_SCORE(2) AS_SCORE(3) AS_SCORE(4) AS_SCORE(5) AS_SCORE(6) AS_SCORE(7) AS_SCORE(8)
+          default: return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: row width not covered");
+        }
+#undef AS_SCORE
       } else if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
 #define AS_RR(R, NB)                                                                                                       \
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \

@@ -20,22 +20,24 @@
 
 namespace asx {
 
-constexpr int kRsWords = 384;          // u32 words of a record (1.5 KB)
+// A record of SLOTS x 64 id slots (SLOTS = 2 for 128-wide rows, 4 for wider ones, whose lists prune less): u32 words
 constexpr int kRsIdsAt = 4;            // word 0: count | overflow << 8 | force << 9; 1: theta; 2-3: norm of the row
-constexpr int kRsMaxIds = 124;         // survivor ids in words 4 .. 127
-constexpr int kRsNormsAt = 128;        // ... and their norms (f64) from word 128 on: what GraphDistPolicy::key reads per pair
+__host__ __device__ constexpr int rs_max_ids(int slots) { return 64 * slots - kRsIdsAt; }  // survivor ids behind the header
+__host__ __device__ constexpr int rs_norms_at(int slots) { return 64 * slots; }            // their norms (f64): what GraphDistPolicy::key reads per pair
+__host__ __device__ constexpr int rs_words(int slots) { return 192 * slots; }              // 1.5 KB / 3 KB per row
 constexpr int kRsRows = 16;            // candidate rows per batch
 constexpr int kRsPitch = 1040;         // LDS pitch of a staged row (bytes)
-constexpr size_t kRsLds = 1024 + kRsRows * kRsPitch + 128 * 8 + 128 * 4;
+__host__ __device__ constexpr size_t rs_lds(int slots) { return 1024 + kRsRows * kRsPitch + (size_t)64 * slots * 12; }
 
 __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, uint32_t row_count, const float *__restrict__ theta,
                                                            const double *__restrict__ norms, uint32_t n_src,
                                                            const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src,
                                                            uint32_t cap, uint32_t cmax, uint32_t K,
                                                            const uint8_t *__restrict__ force_exact, double prune_delta, int prune_rectify,
-                                                           uint32_t *__restrict__ records) {
+                                                           uint32_t *__restrict__ records, int slots) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
   float *es = reinterpret_cast<float *>(smem) + (size_t)wv * 2 * cmax;
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     }
     wave_sync();
     C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
-    if (C > (uint32_t)kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
+    if (C > kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
       overflow = true;
       C = kRsMaxIds;
     }
@@ -110,36 +112,51 @@ __device__ __forceinline__ double rs_readlane(double v, uint32_t l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// the rows of a wave as a stream of batches: (row, batch in row); a row without survivors still has one (empty) batch
+// the rows of a wave as a stream of steps: (row, batch in row, 128-wide piece of the rows); a row without survivors
+// still has one (empty) batch
 struct RsCursor {
-  uint32_t r, b, C, nb;
+  uint32_t r, b, q, C, nb;
   bool done;
+  uint32_t words;  // of a record
   __device__ __forceinline__ void enter(const uint32_t *__restrict__ records, uint32_t row, uint32_t row_count) {
     r = row;
     b = 0;
+    q = 0;
     done = row >= row_count;
-    C = done ? 0u : (records[(size_t)row * kRsWords] & 0xFFu);
+    C = done ? 0u : (records[(size_t)row * words] & 0xFFu);
     nb = C ? (C + kRsRows - 1) / kRsRows : 1u;
+  }
+  // next step: the next piece of the batch, the next batch, the wave's next row
+  __device__ __forceinline__ void advance(const uint32_t *__restrict__ records, uint32_t pieces, uint32_t stride, uint32_t row_count) {
+    if (done) return;
+    if (++q < pieces) return;
+    q = 0;
+    if (++b == nb) enter(records, r + stride, row_count);
   }
 };
 
+// Rows of d = 128 x pieces values: a step stages one 128-wide piece of the batch's 16 candidate rows (and of the row itself);
+// the chains of a batch run on across its pieces.
+template <uint32_t PIECES, int SLOTS>
 __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__restrict__ X, uint32_t row_begin, uint32_t row_count,
                                                                const uint32_t *__restrict__ records, uint32_t K, int rectify,
                                                                GraphBound bnd, double *__restrict__ out_key,
                                                                uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows,
                                                                uint32_t *__restrict__ fail_count, uint32_t dbg) {
-  constexpr uint32_t d = 128;
+  constexpr uint32_t pieces = PIECES, d = 128u * PIECES;
+  constexpr uint32_t kRsWords = (uint32_t)rs_words(SLOTS), kRsNormsAt = (uint32_t)rs_norms_at(SLOTS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   double *xrow = reinterpret_cast<double *>(smem);                       // the row itself
   unsigned char *tile = smem + 1024;                                      // the batch whose chains run
   double *ek = reinterpret_cast<double *>(tile + kRsRows * kRsPitch);     // keys and ids of the scored candidates
-  uint32_t *ei = reinterpret_cast<uint32_t *>(ek + 128);
+  uint32_t *ei = reinterpret_cast<uint32_t *>(ek + 64 * SLOTS);
   const uint32_t lane_off = (uint32_t)lane * 16u;
   const uint32_t stride = gridDim.x;
-  const uint32_t chain_len = (dbg & 1) ? 16u : d;  // dbg: timing experiments only (outputs undefined)
+  const uint32_t chain_len = (dbg & 1) ? 16u : 128u;  // dbg: timing experiments only (outputs undefined)
 
   RsCursor is, ps;  // issue side (two batches ahead), process side
+  is.words = kRsWords;
   is.enter(records, blockIdx.x, row_count);
   ps = is;
   if (ps.done) return;
@@ -155,29 +172,31 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
 #pragma unroll
     for (int t = 0; t < kRsRows; ++t) ids[t] = (!cu.done && cu.b * kRsRows + t < cu.C) ? raw[t] : row_begin + row;
   };
-#define AS_GL(S, T) rs_gload16(S.v[T], lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)ids_[T]) * d);
+#define AS_GL(S, T) rs_gload16(S.v[T], lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)ids_[T]) * d + is.q * 128u);
 #define AS_ISSUE(S)                                                                                                         \
   {                                                                                                                         \
     uint32_t ids_[kRsRows];                                                                                                 \
     batch_ids(is, ids_);                                                                                                    \
     AS_GL(S, 0) AS_GL(S, 1) AS_GL(S, 2) AS_GL(S, 3) AS_GL(S, 4) AS_GL(S, 5) AS_GL(S, 6) AS_GL(S, 7)                         \
     AS_GL(S, 8) AS_GL(S, 9) AS_GL(S, 10) AS_GL(S, 11) AS_GL(S, 12) AS_GL(S, 13) AS_GL(S, 14) AS_GL(S, 15)                   \
-    rs_gload16(S.x, lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)(row_begin + (is.done ? 0u : is.r))) * d); \
-    if (!is.done && ++is.b == is.nb) is.enter(records, is.r + stride, row_count);                                           \
+    rs_gload16(S.x, lane_off,                                                                                               \
+               X + (uint64_t)__builtin_amdgcn_readfirstlane((int)(row_begin + (is.done ? 0u : is.r))) * d + is.q * 128u);   \
+    is.advance(records, pieces, stride, row_count);                                                                         \
   }
 
   bool p_overflow = false, p_force = false;  // header of the process side's row
   float p_theta = 0.f;
   double p_na = 0.0;
 
-  // a landed set -> the LDS tile (and, at the first batch of a row, the row itself)
+  // a landed set -> the LDS tile and the row's own piece
 #define AS_ST(S, T) *reinterpret_cast<rs_d2 *>(tile + T * kRsPitch + lane_off) = S.v[T];
 #define AS_STAGE(S)                                                                                                 \
   {                                                                                                                 \
-    if (ps.b == 0) *reinterpret_cast<rs_d2 *>(reinterpret_cast<unsigned char *>(xrow) + lane_off) = S.x;          \
+    *reinterpret_cast<rs_d2 *>(reinterpret_cast<unsigned char *>(xrow) + lane_off) = S.x; /* piece q of the row */   \
     AS_ST(S, 0) AS_ST(S, 1) AS_ST(S, 2) AS_ST(S, 3) AS_ST(S, 4) AS_ST(S, 5) AS_ST(S, 6) AS_ST(S, 7)                 \
     AS_ST(S, 8) AS_ST(S, 9) AS_ST(S, 10) AS_ST(S, 11) AS_ST(S, 12) AS_ST(S, 13) AS_ST(S, 14) AS_ST(S, 15)           \
   }
+  double acc = 0.0;  // this lane's chain, carried across the pieces of a batch
   auto process = [&]() {
     uint32_t ids[kRsRows];
     batch_ids(ps, ids);
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
 #pragma unroll
       for (int t = 0; t < kRsRows; ++t) nrm[t] = np[t];
     }
-    if (ps.b == 0) {  // row entry
+    if (ps.b == 0 && ps.q == 0) {  // row entry
       const uint4 h = *reinterpret_cast<const uint4 *>(records + (size_t)ps.r * kRsWords);
       p_overflow = (h.x & 0x100u) != 0;
       p_force = (h.x & 0x200u) != 0;
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
       // the reference's chain (src/core.rs:204-210): k ascending, multiply and add rounded separately
       const rs_d2 *bj = reinterpret_cast<const rs_d2 *>(tile + (size_t)lane * kRsPitch);
       const rs_d2 *xj = reinterpret_cast<const rs_d2 *>(xrow);
-      double acc = 0.0;
+      if (ps.q == 0) acc = 0.0;
       // groups of 8 k: the next group's LDS reads are issued before this group's chain
       rs_d2 xa[4], ba[4], xb[4], bb[4];
 #pragma unroll
@@ -233,33 +252,41 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
           acc = __dadd_rn(acc, __dmul_rn(xb[h].y, bb[h].y));
         }
       }
-      double nj = nrm[0];
+      if (ps.q + 1 == pieces) {
+        double nj = nrm[0];
 #pragma unroll
-      for (int t = 1; t < kRsRows; ++t) nj = lane == t ? nrm[t] : nj;
-      uint32_t jj = ids[0];
+        for (int t = 1; t < kRsRows; ++t) nj = lane == t ? nrm[t] : nj;
+        uint32_t jj = ids[0];
 #pragma unroll
-      for (int t = 1; t < kRsRows; ++t) jj = lane == t ? ids[t] : jj;
-      const uint32_t a = row_begin + ps.r;
-      double key = __builtin_inf();
-      uint32_t id = kNoIdx;
-      if (a != jj) {  // GraphDistPolicy::key with the operands at hand
-        const double denom = __dmul_rn(p_na, nj);
-        double cs = denom > 1e-12 ? __ddiv_rn(acc, denom) : 0.0;
-        if (rectify) {
-          cs = fmin(fmax(cs, -1.0), 1.0);
-          cs = fmax(cs, 0.0);
+        for (int t = 1; t < kRsRows; ++t) jj = lane == t ? ids[t] : jj;
+        const uint32_t a = row_begin + ps.r;
+        double key = __builtin_inf();
+        uint32_t id = kNoIdx;
+        if (a != jj) {  // GraphDistPolicy::key with the operands at hand
+          const double denom = __dmul_rn(p_na, nj);
+          double cs = denom > 1e-12 ? __ddiv_rn(acc, denom) : 0.0;
+          if (rectify) {
+            cs = fmin(fmax(cs, -1.0), 1.0);
+            cs = fmax(cs, 0.0);
+          }
+          const double kx = __dsub_rn(1.0, cs);
+          if (!(kx != kx)) {
+            key = kx;
+            id = jj;
+          }
         }
-        const double kx = __dsub_rn(1.0, cs);
-        if (!(kx != kx)) {
-          key = kx;
-          id = jj;
-        }
+        ek[c] = key;
+        ei[c] = id;
       }
-      ek[c] = key;
-      ei[c] = id;
     }
     wave_sync();
-    if (++ps.b < ps.nb) return;
+    {
+      const bool row_done = ps.q + 1 == pieces && ps.b + 1 == ps.nb;
+      if (!row_done) {
+        ps.advance(records, pieces, stride, row_count);
+        return;
+      }
+    }
     // ---- the row is scored: rank, write its K best, certify ----
     const uint32_t r = ps.r, C = ps.C;
     double kth = -__builtin_inf();
@@ -267,46 +294,38 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     if (!(dbg & 2)) {
       // lane l holds candidates l and 64 + l; every candidate's (key, id) passes by as a wave-uniform value (readlane:
       // no LDS round trip per comparison)
-      double k0v = __builtin_inf(), k1v = __builtin_inf();
-      uint32_t i0 = kNoIdx, i1 = kNoIdx;
-      if ((uint32_t)lane < C) {
-        k0v = ek[lane];
-        i0 = ei[lane];
-      }
-      if ((uint32_t)lane + 64 < C) {
-        k1v = ek[lane + 64];
-        i1 = ei[lane + 64];
-      }
-      uint32_t rank0 = 0, rank1 = 0;
-      const uint32_t c_lo = C < 64u ? C : 64u;
-      for (uint32_t c2 = 0; c2 < c_lo; ++c2) {
-        const double kc = rs_readlane(k0v, c2);
-        const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)i0, (int)c2);
-        rank0 += lex_less(kc, ic, k0v, i0) ? 1u : 0u;
-        rank1 += lex_less(kc, ic, k1v, i1) ? 1u : 0u;
-      }
-      for (uint32_t c2 = 64; c2 < C; ++c2) {
-        const double kc = rs_readlane(k1v, c2 - 64);
-        const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)i1, (int)(c2 - 64));
-        rank0 += lex_less(kc, ic, k0v, i0) ? 1u : 0u;
-        rank1 += lex_less(kc, ic, k1v, i1) ? 1u : 0u;
-      }
-      if (i0 != kNoIdx) {
-        ++n_valid;
-        if (rank0 < K) {
-          out_key[(uint64_t)r * K + rank0] = k0v;
-          out_idx[(uint64_t)r * K + rank0] = i0;
-          kth = fmax(kth, k0v);
+      double kv[SLOTS];
+      uint32_t iv[SLOTS], rank[SLOTS];
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q) {
+        kv[q] = __builtin_inf();
+        iv[q] = kNoIdx;
+        rank[q] = 0;
+        if ((uint32_t)(64 * q + lane) < C) {
+          kv[q] = ek[64 * q + lane];
+          iv[q] = ei[64 * q + lane];
         }
       }
-      if (i1 != kNoIdx) {
-        ++n_valid;
-        if (rank1 < K) {
-          out_key[(uint64_t)r * K + rank1] = k1v;
-          out_idx[(uint64_t)r * K + rank1] = i1;
-          kth = fmax(kth, k1v);
+#pragma unroll
+      for (int q2 = 0; q2 < SLOTS; ++q2) {
+        const uint32_t c_hi = C < 64u * (q2 + 1) ? C : 64u * (q2 + 1);
+        for (uint32_t c2 = 64u * q2; c2 < c_hi; ++c2) {  // (no iterations when C <= 64 q2)
+          const double kc = rs_readlane(kv[q2], c2 - 64u * q2);
+          const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)iv[q2], (int)(c2 - 64u * q2));
+#pragma unroll
+          for (int q = 0; q < SLOTS; ++q) rank[q] += lex_less(kc, ic, kv[q], iv[q]) ? 1u : 0u;
         }
       }
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q)
+        if (iv[q] != kNoIdx) {
+          ++n_valid;
+          if (rank[q] < K) {
+            out_key[(uint64_t)r * K + rank[q]] = kv[q];
+            out_idx[(uint64_t)r * K + rank[q]] = iv[q];
+            kth = fmax(kth, kv[q]);
+          }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
       kth = fmax(kth, __shfl_xor(kth, o, 64));

@@ -1,5 +1,5 @@
 """Dev check of the split re-rank (rerank_split.h) against the one-kernel form: identical neighbour tables, stage times.
-usage: explore_rerank.py [n] [K]"""
+usage: explore_rerank.py [n] [K] [d]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
@@ -9,7 +9,8 @@ from arrowspace_amd import synth
 ctx = A.default_context()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 topk = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-Xd, cent = synth.mixture_device(n, 128, "cuda", seed=42)
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
 gp = A.GraphParams(0.5, 16, topk, 2.0, 0.25)
 ctx.set_option("join_min_rows", 512)
 res = {}
