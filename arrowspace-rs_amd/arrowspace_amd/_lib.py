@@ -26,7 +26,21 @@ EXPORTS = [
     "as_csr_row_begin", "as_knn_join_applies", "as_two_nn_ratios", "as_kmeans_lloyd", "as_calinski_harabasz",
     "as_compute_optimal_k", "as_incremental_clustering", "as_jl_dimension", "as_jl_create", "as_jl_destroy",
     "as_jl_original_dim", "as_jl_reduced_dim", "as_jl_matrix", "as_jl_project",
+    "as_comm_unique_id", "as_comm_create_rccl", "as_comm_create_custom", "as_comm_destroy", "as_comm_rank", "as_comm_world",
+    "as_shard_range", "as_build_laplacian_sharded",
 ]
+
+# transport callbacks of as_comm_create_custom (device buffers; byte counts / offsets are arrays of `world` entries)
+AllGatherV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                         C.c_void_p)
+AllToAllV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+AllReduceSumU64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class CommOpsC(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather_v", AllGatherV), ("all_to_all_v", AllToAllV),
+                ("all_reduce_sum_u64", AllReduceSumU64)]
 
 
 class GraphParamsC(C.Structure):
@@ -112,6 +126,14 @@ def load():
         "as_jl_matrix": (i32, [vp, vp, vp]),
         "as_jl_project": (i32, [vp, vp, vp, u64, vp]),
         "as_knn_join_unpack": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
+        "as_comm_unique_id": (i32, [vp]),
+        "as_comm_create_rccl": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "as_comm_create_custom": (i32, [vp, C.POINTER(CommOpsC), i32, i32, C.POINTER(vp)]),
+        "as_comm_destroy": (None, [vp]),
+        "as_comm_rank": (i32, [vp]),
+        "as_comm_world": (i32, [vp]),
+        "as_shard_range": (None, [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]),
+        "as_build_laplacian_sharded": (i32, [vp, vp, vp, u64, u64, C.POINTER(GraphParamsC), C.POINTER(vp), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -409,3 +409,123 @@ def merge_topk(gi, gs, k):
     cs = torch.where(ci == I64_NONE, torch.full_like(cs, float("-inf")), cs)
     order = torch.sort(cs, dim=1, descending=True, stable=True).indices[:, :k]
     return torch.gather(ci, 1, order), torch.gather(cs, 1, order)
+
+
+# ---- the same build through the library's own communicator (include/arrowspace_hip.h: as_comm_*) ----------------------
+class LibComm:
+    """as_comm handle: the sharded build runs inside the library (csrc/sharded.hip), the host only supplies a transport.
+    `rccl`: RCCL over xGMI, bootstrapped with a 128-byte id (rank 0: LibComm.unique_id(), shipped to the others by the
+    host -- here through torch.distributed).  `torch_transport`: the three primitives as callbacks on top of
+    torch.distributed with host staging: what lets several ranks share one GPU in the tests, where RCCL cannot run."""
+
+    def __init__(self, ctx, handle, keep=None):
+        self.ctx, self.h, self._keep = ctx, handle, keep
+
+    @staticmethod
+    def unique_id(ctx):
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        ctx.check(ctx.lib.as_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, unique_id, rank, world):
+        import ctypes as C
+        h = C.c_void_p()
+        ctx.check(ctx.lib.as_comm_create_rccl(ctx.h, C.c_char_p(unique_id), rank, world, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def torch_transport(cls, ctx):
+        """Callbacks over torch.distributed (any backend), device buffers staged through the host."""
+        import ctypes as C
+        from . import _lib as L
+        rank, world = _world()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+        def d2h(src, nbytes):
+            out = np.empty(int(nbytes), dtype=np.uint8)
+            if nbytes:
+                assert hip.hipMemcpy(out.ctypes.data, src, int(nbytes), 2) == 0
+            return out
+
+        def h2d(dst, arr):
+            if arr.size:
+                arr = np.ascontiguousarray(arr)
+                assert hip.hipMemcpy(dst, arr.ctypes.data, arr.size, 1) == 0
+
+        def all_gather_v(user, send, send_bytes, recv, recv_bytes, recv_offsets, stream):
+            try:
+                hip.hipStreamSynchronize(stream)
+                parts = [None] * world
+                dist.all_gather_object(parts, d2h(send, send_bytes))
+                for r in range(world):
+                    assert parts[r].size == recv_bytes[r]
+                    h2d((recv or 0) + recv_offsets[r], parts[r])
+                return 0
+            except Exception:  # noqa: BLE001 -- a Python exception must not cross the C frame
+                return 9
+
+        def all_to_all_v(user, send, send_bytes, send_offsets, recv, recv_bytes, recv_offsets, stream):
+            try:
+                hip.hipStreamSynchronize(stream)
+                outgoing = [d2h((send or 0) + send_offsets[p], send_bytes[p]) for p in range(world)]
+                table = [None] * world
+                dist.all_gather_object(table, outgoing)  # (test transport: everything everywhere, then pick)
+                for p in range(world):
+                    part = table[p][rank]
+                    assert part.size == recv_bytes[p]
+                    h2d((recv or 0) + recv_offsets[p], part)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 9
+
+        def all_reduce_sum_u64(user, buf, count, stream):
+            try:
+                hip.hipStreamSynchronize(stream)
+                mine = d2h(buf, 8 * count).view(np.uint64)
+                parts = [None] * world
+                dist.all_gather_object(parts, mine)
+                h2d(buf, np.sum(np.stack(parts), axis=0, dtype=np.uint64).view(np.uint8))
+                return 0
+            except Exception:  # noqa: BLE001
+                return 9
+
+        cbs = (L.AllGatherV(all_gather_v), L.AllToAllV(all_to_all_v), L.AllReduceSumU64(all_reduce_sum_u64))
+        ops = L.CommOpsC(None, *cbs)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.as_comm_create_custom(ctx.h, C.byref(ops), rank, world, C.byref(h)))
+        return cls(ctx, h, keep=(cbs, ops, hip))
+
+    def rank(self):
+        return int(self.ctx.lib.as_comm_rank(self.h))
+
+    def world(self):
+        return int(self.ctx.lib.as_comm_world(self.h))
+
+    def shard_range(self, n, rank=None):
+        import ctypes as C
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.ctx.lib.as_shard_range(int(n), self.rank() if rank is None else rank, self.world(), C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    def build_laplacian(self, X_shard, n_total, gp):
+        """as_build_laplacian_sharded: this rank's row block (ShardedCsr; block None when the rank owns no rows)."""
+        import ctypes as C
+        ctx = self.ctx
+        lo, hi = self.shard_range(n_total)
+        assert X_shard.is_cuda and X_shard.is_contiguous() and X_shard.shape[0] == hi - lo
+        c = gp.to_c()
+        h, nnz = C.c_void_p(), C.c_uint64()
+        A._adopt_torch_stream(ctx)
+        ctx.check(ctx.lib.as_build_laplacian_sharded(ctx.h, self.h, ptr(X_shard) if hi > lo else None, int(n_total),
+                                                     int(X_shard.shape[1]), C.byref(c), C.byref(h), C.byref(nnz)))
+        block = A.CsrMatrix(ctx, h) if h.value else None
+        return ShardedCsr(block, lo, hi, int(n_total), int(nnz.value))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.as_comm_destroy(self.h)
+            self.h = None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AS_ABI_VERSION 2
+#define AS_ABI_VERSION 3
 
 typedef enum {
   AS_OK = 0,
@@ -251,6 +251,44 @@ int as_csr_export(as_ctx *ctx, const as_csr *m, uint64_t *indptr, uint64_t *indi
 int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
                   const uint64_t *indices, const double *data, as_csr **out);
 void as_csr_free(as_csr *m);
+
+/* ---- row-sharded build, one process per GPU: what replaces build_laplacian_matrix
+ * (src/laplacian.rs:122-178) when the items are spread over several GPUs.  The library runs the whole exchange
+ * sequence (all-gather of the row shards, all-gather of the join thresholds, all-to-all of the candidate lists in
+ * compact form, all-gather of the neighbour tables, all-reduce of nnz) through a communicator:
+ *   - as_comm_create_rccl: RCCL over xGMI.  Rank 0 calls as_comm_unique_id and ships the 128 bytes to the other ranks
+ *     by whatever means the host has; every rank then creates its communicator.  librccl is loaded at run time
+ *     (AS_ERR_UNSUPPORTED when it is not there).  Collectives are issued on the context's stream.
+ *   - as_comm_create_custom: the caller's own transport, three primitives over DEVICE buffers.  Byte counts and offsets
+ *     are arrays of `world` entries indexed by peer; every rank calls them in the same order; a primitive must have
+ *     completed, or be ordered on `stream`, when it returns.
+ * as_shard_range: the rows of a rank, contiguous, shard starts multiples of 512 (the row super tile of the join); ranks
+ * past the end own no rows and still take part in every step.
+ * as_build_laplacian_sharded: rows_shard = this rank's rows (device pointer, (hi - lo) x dim); *out_block = its ROW
+ * BLOCK of the Laplacian (see as_laplacian_from_knn_rows; NULL when the rank owns no rows), *nnz_total = nnz of the
+ * whole matrix.  Stacking the blocks of ranks 0 .. world - 1 gives exactly the CSR of as_build_laplacian on all rows.
+ * Every rank must make the call; a rank that fails locally returns early and leaves its peers waiting. */
+typedef struct as_comm as_comm;
+typedef struct as_comm_ops {
+  void *user;
+  /* every rank contributes send_bytes bytes; rank r's contribution lands at recv + recv_offsets[r] (recv_bytes[r] bytes) */
+  int (*all_gather_v)(void *user, const void *send, uint64_t send_bytes, void *recv, const uint64_t *recv_bytes,
+                      const uint64_t *recv_offsets, void *stream);
+  /* send + send_offsets[p] (send_bytes[p] bytes) goes to peer p; peer p's part lands at recv + recv_offsets[p] */
+  int (*all_to_all_v)(void *user, const void *send, const uint64_t *send_bytes, const uint64_t *send_offsets, void *recv,
+                      const uint64_t *recv_bytes, const uint64_t *recv_offsets, void *stream);
+  /* in place, element-wise sum over the ranks */
+  int (*all_reduce_sum_u64)(void *user, uint64_t *buf, uint64_t count, void *stream);
+} as_comm_ops;
+int as_comm_unique_id(void *id128);
+int as_comm_create_rccl(as_ctx *ctx, const void *id128, int rank, int world, as_comm **out);
+int as_comm_create_custom(as_ctx *ctx, const as_comm_ops *ops, int rank, int world, as_comm **out);
+void as_comm_destroy(as_comm *comm);
+int as_comm_rank(const as_comm *comm);
+int as_comm_world(const as_comm *comm);
+void as_shard_range(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi);
+int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_shard, uint64_t n_total, uint64_t dim,
+                               const as_graph_params *params, as_csr **out_block, uint64_t *nnz_total);
 
 /* ---- lambda-tau: replaces TauMode::compute_taumode_lambdas_parallel, src/taumode.rs:174-312 */
 /* items: n_items x n_features.  tau is taken from each item's own values (select_tau,

@@ -196,3 +196,113 @@ def test_multi_rank_rccl_matches_oracle(tmp_path, n):
             oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
             assert np.array_equal(r["idx"][j], oi.astype(np.int64))
             assert np.array_equal(r["sc"][j], osc)
+
+
+# ---- the same build inside the library: as_comm_* + as_build_laplacian_sharded (csrc/sharded.hip) ----------------------
+def _lib_worker(rank, world, port, n, d, out_dir):
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = A.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)
+        comm = D.LibComm.torch_transport(ctx)  # the library's exchange sequence over callbacks (ranks share the GPU)
+        assert (comm.rank(), comm.world()) == (rank, world)
+        lo, hi = comm.shard_range(n)
+        assert (lo, hi) == D.shard_range(n, rank, world)
+        X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+        gl = comm.build_laplacian(torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp)
+        assert (gl.block is None) == (hi == lo)
+        if gl.block is not None:
+            assert gl.block.shape() == (hi - lo, n) and gl.block.row_begin() == lo
+        csr = gl.to_host()
+        np.savez(os.path.join(out_dir, "lib%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()),
+                 join=np.array(ctx.stat("sharded_join")))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,d", [(3000, 2, 64), (1111, 2, 64), (3000, 3, 64), (1000, 3, 64), (3000, 2, 200)])
+def test_library_sharded_build_matches_single_process(tmp_path, n, world, d):
+    """as_build_laplacian_sharded with 2 and 3 ranks on the one GPU (transport callbacks over gloo): the stacked row blocks
+    are the oracle's Laplacian; uneven shards, a rank without rows, rows wider than 128."""
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    mp.spawn(_lib_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    csr = O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    for r in [np.load(tmp_path / ("lib%d.npz" % k)) for k in range(world)]:
+        assert int(r["join"]) == 1 and int(r["nnz"]) == len(csr[1])
+        assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
+        np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
+
+
+def test_library_sharded_build_one_rank_rccl():
+    """The RCCL transport of the library with one rank: librccl is loaded at run time, the communicator comes from a unique
+    id, and every exchange step of the build runs through ncclSend / ncclRecv / ncclAllReduce on the context's stream."""
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    ctx = A.default_context()
+    n, d = 2000, 48
+    X, _ = synth.mixture(n, d, seed=5, n_clusters=8, rank=4)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    comm = D.LibComm.rccl(ctx, D.LibComm.unique_id(ctx), 0, 1)
+    try:
+        assert comm.shard_range(n) == (0, n)
+        gl = comm.build_laplacian(torch.from_numpy(X).cuda(), n, gp)
+        ip, ix, dv = gl.block.to_host()
+    finally:
+        comm.close()
+    csr = O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    assert gl.nnz() == len(csr[1]) and np.array_equal(ip, csr[0]) and np.array_equal(ix, csr[1])
+    np.testing.assert_allclose(dv, csr[2], rtol=1e-13)
+
+
+def _lib_rccl_multi_worker(rank, world, port, n, d, out_dir):
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # only carries the 128-byte id and the result gather
+    try:
+        torch.cuda.set_device(rank)
+        ctx = A.Context(rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)
+        box = [D.LibComm.unique_id(ctx) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = D.LibComm.rccl(ctx, box[0], rank, world)
+        lo, hi = comm.shard_range(n)
+        X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        gl = comm.build_laplacian(torch.from_numpy(X[lo:hi].copy()).cuda(), n, A.GraphParams(0.5, 16, 16, 2.0, 0.25))
+        csr = gl.to_host()
+        np.savez(os.path.join(out_dir, "librccl%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs (RCCL wants one GPU per rank)")
+@pytest.mark.parametrize("n", [20_000, 3_000])
+def test_library_sharded_build_multi_rank_rccl(tmp_path, n):
+    """as_build_laplacian_sharded over the library's RCCL transport with min(device_count, 8) ranks, one GPU each."""
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    world, d = min(torch.cuda.device_count(), 8), 64
+    mp.spawn(_lib_rccl_multi_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    csr = O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    for r in [np.load(tmp_path / ("librccl%d.npz" % k)) for k in range(world)]:
+        assert int(r["nnz"]) == len(csr[1])
+        assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
+        np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
