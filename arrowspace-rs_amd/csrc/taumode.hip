@@ -556,6 +556,9 @@ static int launch_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uin
   return AS_OK;
 }
 
+int lambda_wide(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, const void *ent, uint64_t nnz, bool sym, int mode,
+                double arg, bool check_finite, bool want_lambda, double *out, int *err, bool *handled);
+
 static int run_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F64, const PackedEntry *ent,
                       uint64_t nnz, const PackedEntry *ent_upper, uint64_t nnz_upper, int mode, double arg,
                       bool check_finite, bool want_lambda, double *out) {
@@ -583,6 +586,21 @@ static int run_lambda(as_ctx *ctx, const double *items, uint64_t n_items, uint64
       if (h) return fail(ctx, AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
     }
     return AS_OK;
+  }
+  if (F > 128 && ctx->opt_lambda_wide) {  // one wave per item, values in registers (taumode_wide.hip)
+    const bool sym = ent_upper != nullptr;
+    bool handled = false;
+    AS_TRY(lambda_wide(ctx, items, n_items, F, sym ? (const void *)ent_upper : (const void *)ent, sym ? nnz_upper : nnz, sym, mode, arg,
+                       check_finite, want_lambda, out, err.p, &handled));
+    if (handled) {
+      if (check_finite) {
+        int h = 0;
+        AS_HIP(ctx, copy_d2h(ctx, &h, err.p, sizeof(int)));
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h) return fail(ctx, AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
+      }
+      return AS_OK;
+    }
   }
   // lanes per item: smallest S whose tile fits ~40 KB of LDS (4 waves per CU)
   const size_t budget = 40 * 1024;
