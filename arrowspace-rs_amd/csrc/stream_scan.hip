@@ -342,14 +342,13 @@ constexpr uint32_t kSsSortMax = 4096;
 __global__ __launch_bounds__(256) void stream_final_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ list_idx,
                                                            const double *__restrict__ list_key, uint32_t cap, uint32_t K,
                                                            uint32_t out_ld, uint32_t out_off, double *__restrict__ out_key,
-                                                           uint32_t *__restrict__ out_idx, int *__restrict__ overflow) {
+                                                           uint32_t *__restrict__ out_idx, int *__restrict__ overflow,
+                                                           double *__restrict__ guess, int *__restrict__ done) {
   __shared__ double s_key[kSsSortMax];
   __shared__ uint32_t s_idx[kSsSortMax];
-  const uint32_t a = blockIdx.x, c = cnt[a];
-  if (c > cap) {
-    if (threadIdx.x == 0) overflow[a] = 1;
-    return;
-  }
+  const uint32_t a = blockIdx.x;
+  if (done[a]) return;  // finished in an earlier round (its guess is -inf: nothing was listed for it since)
+  const uint32_t c_all = cnt[a], c = min(c_all, cap);
   uint32_t P = 64;
   while (P < c) P <<= 1;
   for (uint32_t e = threadIdx.x; e < P; e += blockDim.x) {
@@ -377,6 +376,20 @@ __global__ __launch_bounds__(256) void stream_final_kernel(const uint32_t *__res
       }
       __syncthreads();
     }
+  if (c_all > cap) {
+    // The list ran over (a sample that misses the row's neighbourhood gives a cut that is far too loose).  The K-th best of
+    // what WAS listed bounds the K-th best over all of B from above: it is the cut of the next round.
+    if (threadIdx.x == 0) {
+      overflow[a] = 1;
+      guess[a] = s_key[K - 1];
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    overflow[a] = 0;
+    done[a] = 1;
+    guess[a] = -__builtin_inf();
+  }
   for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) {
     const bool have = e < c && s_idx[e] != kNoIdx;
     out_key[(size_t)a * out_ld + out_off + e] = have ? s_key[e] : __builtin_inf();
@@ -403,7 +416,10 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   DevBuf<double> guess, lkey;
   DevBuf<unsigned long long> smin;
   DevBuf<uint32_t> cnt, lidx;
-  DevBuf<int> over;
+  DevBuf<int> over, done;
+  std::vector<int> h(nA);
+  int64_t retries = 0;
+  AS_TRY(done.alloc(ctx, nA));
   AS_TRY(smin.alloc(ctx, (size_t)nA * kSsShares));
   AS_TRY(guess.alloc(ctx, nA));
   AS_TRY(cnt.alloc(ctx, nA));
@@ -412,6 +428,7 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   AS_TRY(over.alloc(ctx, nA));
   AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(over.p, 0, sizeof(int) * nA, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(done.p, 0, sizeof(int) * nA, ctx->stream));
   const int nbuf = nA <= 8 ? 3 : 2;  // a third tile in flight per wave while the A rows leave the LDS for it
   const size_t lds = (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)kSsWaves * nbuf * kSsTileBytes;
   {
@@ -434,18 +451,33 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
     AS_SS(false, g_s)
     hipLaunchKernelGGL(stream_guess_kernel, dim3(nA), dim3(256), 0, ctx->stream, smin.p, K, guess.p);
     AS_SS(true, 256u)
+    hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
+                       out_idx, over.p, guess.p, done.p);
+    AS_HIP(ctx, hipGetLastError());
+    // rows whose list ran over: two more rounds of the list pass with the cut their truncated list gives (one more sweep of
+    // B each: 0.3 ms; the exact scan they would otherwise fall to walks B with ONE wave per row: 300 ms at 1 M x 128)
+    for (int round = 0; round < 2; ++round) {
+      AS_HIP(ctx, copy_d2h(ctx, h.data(), over.p, sizeof(int) * nA));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      bool any = false;
+      for (uint32_t a = 0; a < nA; ++a) any = any || h[a] != 0;
+      if (!any) break;
+      AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
+      AS_SS(true, 256u)
+      hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
+                         out_idx, over.p, guess.p, done.p);
+      AS_HIP(ctx, hipGetLastError());
+      ++retries;
+    }
 #undef AS_SS1
 #undef AS_SS
-    hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
-                       out_idx, over.p);
-    AS_HIP(ctx, hipGetLastError());
   }
-  std::vector<int> h(nA);
   AS_HIP(ctx, copy_d2h(ctx, h.data(), over.p, sizeof(int) * nA));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   redo_pos->clear();
   for (uint32_t a = 0; a < nA; ++a)
     if (h[a]) redo_pos->push_back(a);
+  ctx->stats["stream_scan_retries"] = retries;
   ctx->stats["stream_scan_rows"] = nA;
   ctx->stats["stream_scan_overflow_rows"] = (int64_t)redo_pos->size();
   return AS_OK;
