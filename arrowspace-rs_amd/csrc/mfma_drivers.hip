@@ -208,6 +208,14 @@ static uint32_t cand_capacity(as_ctx *ctx, uint32_t K) {
 // with every item its own centroid) take the exact scan, which tiles k.
 static bool rerank_fits(uint64_t d) { return 32 * d + 49152 <= 160 * 1024; }
 
+// column pieces of a top-k pass: the re-rank stages the row and the splits x KC candidates of a wave in LDS
+// (launch_rerank: 4 x ((d + C) x 8 + C x 4) bytes), which bounds how finely the columns may be cut
+static uint32_t clamp_splits(uint32_t splits, uint32_t d, uint32_t KC) {
+  const uint64_t budget = 160 * 1024 / 4;
+  const uint64_t room = budget > 8ull * d ? (budget - 8ull * d) / 12 : 0;  // candidates per wave
+  return std::max<uint32_t>(1, std::min<uint64_t>(splits, room / std::max<uint32_t>(KC, 1)));
+}
+
 constexpr uint32_t kExactDirect = 128;  // fewer failed rows than this go straight to the exact scan ...
 // ... when the matrix is small: the exact scan is one wave per row over ALL columns (300 ms at 1 M x 128 however
 // few the rows), an MFMA stage over the failed rows a few tens of ms
@@ -1083,9 +1091,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t a_tiles = (rc + kTileRows - 1) / kTileRows;
       pb.arows = ARows{nullptr, (uint32_t)row_begin + r0};
       pb.nA = rc;
-      pb.splits = pick_splits(it1 - it0, b_tiles);
+      pb.splits = clamp_splits(pick_splits(it1 - it0, b_tiles), d, KC);
       if (part == 1 && it1 - it0 < 256)  // remainder round: one work unit per workgroup, as short as possible
-        pb.splits = std::max(1u, std::min({16u, 256u / (it1 - it0), b_tiles}));
+        pb.splits = clamp_splits(std::max(1u, std::min({16u, 256u / (it1 - it0), b_tiles})), d, KC);
       splits_used = std::max(splits_used, pb.splits);
       DevBuf<double> ckey;
       DevBuf<uint32_t> cidx;
@@ -1142,7 +1150,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     const uint32_t a_tiles = (cur_n + kTileRows - 1) / kTileRows;
     pb.arows = ARows{cur_ids, 0};
     pb.nA = cur_n;
-    pb.splits = pick_splits(f32 ? (a_tiles + 1) / 2 : a_tiles, b_tiles);
+    pb.splits = clamp_splits(pick_splits(f32 ? (a_tiles + 1) / 2 : a_tiles, b_tiles), d, KC);
     DevBuf<double> ckey, ok, A64g;
     DevBuf<uint32_t> cidx, oi, failx;
     DevBuf<float> A32g;
@@ -1634,7 +1642,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   } else {
     const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows;
     const uint32_t a_items = use_f32 ? (a_tiles + 1) / 2 : a_tiles;
-    pb.splits = pick_splits_scan(a_items, b_tiles, n);
+    pb.splits = clamp_splits(pick_splits_scan(a_items, b_tiles, n), d, KC);
     DevBuf<double> ckey;
     DevBuf<uint32_t> cidx;
     AS_TRY(ckey.alloc(ctx, (size_t)nq * pb.splits * KC));
@@ -1694,7 +1702,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     const uint32_t a_tiles = (n_fail + kTileRows - 1) / kTileRows;
     pb.arows = ARows{fail1.p, 0};
     pb.nA = n_fail;
-    pb.splits = pick_splits(a_tiles, b_tiles);
+    pb.splits = clamp_splits(pick_splits(a_tiles, b_tiles), d, KC);
     DevBuf<double> ckey, PA, ok;
     DevBuf<uint32_t> cidx, oi;
     AS_TRY(ckey.alloc(ctx, (size_t)n_fail * pb.splits * KC));

@@ -995,6 +995,27 @@ def test_small_batch_search_streams_the_items_once(ctx, nq, k):
     assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0)
 
 
+@pytest.mark.parametrize("nq,d", [(1, 768), (3, 300), (1, 1024)])
+def test_small_batch_search_of_wide_items(ctx, nq, d):
+    """One query (or a few) against items wider than 128: the top-k pass cuts the columns into many pieces to fill the
+    chip, and the re-rank that follows stages a wave's splits x KC candidates next to the row in LDS -- the cut is
+    bounded by that (it used to fail with `invalid argument` at d = 768)."""
+    n = 40_000
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=32, rank=6)
+    rng = np.random.default_rng(nq + d)
+    lam = rng.random(n)
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=5)
+    Q = X[qi] * 1.02
+    lq = rng.random(nq) + 0.01
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
+    for j in range(nq):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 10, 0.7)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+
+
 def test_small_batch_search_with_a_useless_sample(ctx):
     """The guess comes from 1 in 16 of the 8-row tiles.  Items ordered so that every sampled tile is far from the query:
     the guess is loose, the candidate list overflows, the query is re-done on the staged path -- same result."""
