@@ -690,6 +690,7 @@ void as_index_destroy(as_index *ix) {
   if (ix->scan_sample) (void)hipFree(ix->scan_sample);
   if (ix->scan_sample_lam) (void)hipFree(ix->scan_sample_lam);
   if (ix->lam32) (void)hipFree(ix->lam32);
+  if (ix->packedh) (void)hipFree(ix->packedh);
   delete ix;
 }
 

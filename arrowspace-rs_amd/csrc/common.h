@@ -126,6 +126,8 @@ struct as_index {
   uint32_t *scan_sample = nullptr;  // sampled item ids of the threshold scan and their lambdas (lazy)
   float *scan_sample_lam = nullptr;
   float *lam32 = nullptr;           // f32 lambdas of all items, padded to whole tiles (lazy)
+  void *packedh = nullptr;          // f16 image of the items (lazy; the threshold scan of the search for items wider than 128)
+  double f16_err = -1.0;            // measured plane error of that image (mfma_join_f16.hip)
   uint32_t scan_ns = 0;
 };
 

@@ -671,6 +671,12 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
 int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                              uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                              float *theta2_out);
+int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
+                               const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam, float alpha,
+                               float beta, float *score_out, uint32_t m2, float *score2_out);
+int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
+                         const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
+                         uint32_t *cnt, uint32_t *cand, const char *prof_name);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out);
@@ -1388,6 +1394,21 @@ __global__ void scan_guess_kernel(const float *__restrict__ guess, const uint32_
   out[i] = g;
 }
 
+// the same for the wide form of the scan (mfma_join_f16_wide.hip): what the cosine alone must reach, (g - beta) / alpha,
+// and g - beta
+__global__ void scan_guess_wide_kernel(const float *__restrict__ guess, const uint32_t *__restrict__ ids, uint32_t nq, uint32_t padded,
+                                       float alpha, float beta, float *__restrict__ cos_floor, float *__restrict__ g_minus_beta) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  float g = __builtin_inff();
+  if (i < nq) {
+    g = guess[ids ? ids[i] : i];
+    if (!(g == g)) g = -__builtin_inff();
+  }
+  g_minus_beta[i] = g - beta;
+  cos_floor[i] = (g - beta) / alpha;
+}
+
 int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms, const double *q_lambdas,
                 uint64_t nq64, uint32_t k, double alpha, uint32_t *out_idx, double *out_key) {
   const uint32_t n = (uint32_t)ix->n, d = (uint32_t)ix->d, nq = (uint32_t)nq64;
@@ -1463,7 +1484,9 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
 
   uint32_t n_fail = 0;
   // ---- stage 0: threshold scan on the bf16 pipe (see the note above gather_lambda_f32_kernel) ----
-  bool scan = ctx->opt_search_scan && ctx->opt_cand_precision != 64 && !wide && d <= 128 && alpha > 0.0 && alpha <= 1.0 && K < 1024 &&
+  // (items wider than 128: the same scan on the panelled f16 kernel, mfma_join_f16_wide.hip)
+  const bool scan_wide = wide && d <= 2048 && d % 2 == 0 && ctx->opt_join_pipe == 16;
+  bool scan = ctx->opt_search_scan && ctx->opt_cand_precision != 64 && (!wide || scan_wide) && alpha > 0.0 && alpha <= 1.0 && K < 1024 &&
               n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows);
   double lsum = 0.0;
   if (scan) {  // the f32 lambda term needs lambdas of moderate size (as in the f32 top-k pass below)
@@ -1486,14 +1509,21 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   if (scan) {
     const double beta = 1.0 - alpha;
-    if (!ix->packed16) {
+    if (scan_wide && !ix->packedh) {
+      const uint32_t tiles = packed_tiles_f16(n);
+      AS_HIP(ctx, hipMalloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
+      AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles));
+      ix->f16_err = ctx->f16_err;
+    }
+    if (!scan_wide && !ix->packed16) {
       AS_HIP(ctx, hipMalloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed16, b_alloc));
     }
-    if (!ix->lam32) {
-      AS_HIP(ctx, hipMalloc((void **)&ix->lam32, sizeof(float) * (size_t)b_alloc * kTileRows));
-      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)b_alloc * kTileRows, 256)), dim3(256), 0, ctx->stream,
-                         ix->lambdas, (const uint32_t *)nullptr, n, b_alloc * kTileRows, ix->lam32);
+    if (!ix->lam32) {  // padded to whole 512-row super tiles (the images of both forms of the scan end there)
+      const uint32_t lpad = (n + 511) / 512 * 512;
+      AS_HIP(ctx, hipMalloc((void **)&ix->lam32, sizeof(float) * (size_t)lpad));
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream,
+                         ix->lambdas, (const uint32_t *)nullptr, n, lpad, ix->lam32);
     }
     const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
     if (ix->scan_sample && ix->scan_ns != ns_want) {  // the option changed since the sample was drawn
@@ -1522,7 +1552,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // the looser guess of the second pass over what fails: rank 2 m + 6, as far as its ~rank x rate candidates fit the lists
     const uint32_t m2 = std::max(m, std::min<uint32_t>(std::min<uint32_t>(48, 2 * m + 6), 512u / std::max(1u, n / ns)));
     DevBuf<uint32_t> cnt, cand, unitc;
-    AS_TRY(PQ.alloc(ctx, packed_vecs_bf16(a_alloc, d) * 16));
+    AS_TRY(PQ.alloc(ctx, (scan_wide ? packed_vecs_f16(a_alloc, d) : packed_vecs_bf16(a_alloc, d)) * 16));
     AS_TRY(qlam.alloc(ctx, padded));
     AS_TRY(guess.alloc(ctx, nq));
     AS_TRY(guess2.alloc(ctx, nq));
@@ -1530,24 +1560,45 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_TRY(cnt.alloc(ctx, padded));
     AS_TRY(cand.alloc(ctx, (size_t)padded * cap * 2));
     AS_TRY(unitc.alloc(ctx, 1));
-    AS_TRY(pack_bf16(ctx, queries, q_norms, nullptr, 0, nq, d, PQ.p, a_alloc));
+    double cos_delta = cos_delta_bf16x3(d);  // bound between a listed product and the exact cosine
+    DevBuf<float> floor_pad, gmb_pad;
+    if (scan_wide) {  // one f16 plane: the measured plane errors of the two images (mfma_join_f16.hip)
+      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQ.p, a_alloc));
+      const double e = std::max(ctx->f16_err, ix->f16_err);
+      cos_delta = (ctx->f16_err >= 0.0 && ix->f16_err >= 0.0) ? std::min(cos_delta_f16(d), 2.0 * e + e * e + cos_delta_f16_accum(d))
+                                                                : cos_delta_f16(d);
+      AS_TRY(floor_pad.alloc(ctx, padded));
+      AS_TRY(gmb_pad.alloc(ctx, padded));
+    } else {
+      AS_TRY(pack_bf16(ctx, queries, q_norms, nullptr, 0, nq, d, PQ.p, a_alloc));
+    }
     hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
                        (const uint32_t *)nullptr, nq, padded, qlam.p);
-    AS_TRY(search_thresholds_bf16(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
-                                  (float)alpha, (float)beta, guess.p, m2, guess2.p));
+    if (scan_wide)
+      AS_TRY(search_thresholds_f16_wide(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
+                                        (float)alpha, (float)beta, guess.p, m2, guess2.p));
+    else
+      AS_TRY(search_thresholds_bf16(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
+                                    (float)alpha, (float)beta, guess.p, m2, guess2.p));
     hipLaunchKernelGGL(scan_guess_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
                        nq, padded, guess_pad.p);
     AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * padded, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-    AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQ.p, nq, guess_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
-                            cnt.p, cand.p, unitc.p, "search_scan_bf16"));
+    if (scan_wide) {
+      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
+                         nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
+      AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQ.p, nq, floor_pad.p, gmb_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta,
+                                  cap, cnt.p, cand.p, "search_scan_f16"));
+    } else {
+      AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQ.p, nq, guess_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
+                              cnt.p, cand.p, unitc.p, "search_scan_bf16"));
+    }
     {
       // unlisted items: approximate score < g_q.  Approximate vs exact score: alpha x the cosine bound of the pass,
       // the lambda term in f32 with beta folded into its operands (four roundings on numbers of size <= lsum),
       // the f32 roundings of alpha, beta and of the two fused multiply-adds.
       const double lam_err = std::fabs(beta) * (lsum * 0x1p-22 + 0x1p-21);
-      const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
-                            1e-12};
+      const SearchBound bnd{std::fabs(alpha) * cos_delta + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 + 1e-12};
       ProfScope ps(ctx, "search_rerank");
       // the lists carry the approximate score minus beta: candidates that cannot reach the top K are dropped before
       // their rows are fetched, as in the item graph (prune_candidates)
@@ -1595,7 +1646,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       DevBuf<float> qlam_b, guess_b;
       DevBuf<uint32_t> cnt_b, cand_b, oi, fail_b, ids_b;
       DevBuf<double> ok;
-      AS_TRY(PQb.alloc(ctx, packed_vecs_bf16(b_al, d) * 16));
+      AS_TRY(PQb.alloc(ctx, (scan_wide ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
       AS_TRY(qlam_b.alloc(ctx, pad_b));
       AS_TRY(guess_b.alloc(ctx, pad_b));
       AS_TRY(cnt_b.alloc(ctx, pad_b));
@@ -1604,7 +1655,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(oi.alloc(ctx, (size_t)nf * K));
       AS_TRY(fail_b.alloc(ctx, nf));
       AS_TRY(ids_b.alloc(ctx, nf));
-      AS_TRY(pack_bf16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
+      if (scan_wide) AS_TRY(pack_f16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
+      else AS_TRY(pack_bf16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, q_lambdas, fail1.p, nf, pad_b,
                          qlam_b.p);
       hipLaunchKernelGGL(scan_guess_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, guess2.p, fail1.p, nf, pad_b,
@@ -1612,12 +1664,21 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad_b, ctx->stream));
       AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
       AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-      AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQb.p, nf, guess_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
-                              cnt_b.p, cand_b.p, unitc.p, "search_scan_bf16"));
+      if (scan_wide) {
+        DevBuf<float> floor_b, gmb_b;
+        AS_TRY(floor_b.alloc(ctx, pad_b));
+        AS_TRY(gmb_b.alloc(ctx, pad_b));
+        hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, guess2.p, fail1.p, nf, pad_b,
+                           (float)alpha, (float)beta, floor_b.p, gmb_b.p);
+        AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta,
+                                    cap2, cnt_b.p, cand_b.p, "search_scan_f16"));
+      } else {
+        AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQb.p, nf, guess_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
+                                cnt_b.p, cand_b.p, unitc.p, "search_scan_bf16"));
+      }
       {
         const double lam_err = std::fabs(beta) * (lsum * 0x1p-22 + 0x1p-21);
-        const SearchBound bnd{std::fabs(alpha) * cos_delta_bf16x3(d) + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 +
-                              1e-12};
+        const SearchBound bnd{std::fabs(alpha) * cos_delta + lam_err + (std::fabs(alpha) + std::fabs(beta)) * 5.2e-7 + 1e-12};
         ProfScope ps(ctx, "search_rerank");
         const size_t lds = (size_t)4 * (d + cap2) * sizeof(double) + (size_t)4 * cap2 * sizeof(uint32_t);
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<SearchScorePolicy, SearchBound>,

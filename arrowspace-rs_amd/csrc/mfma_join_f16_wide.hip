@@ -39,8 +39,9 @@ constexpr uint32_t kQueueW = 256;         // queued appends per wave
 constexpr float kProductScaleW = 16384.f;
 constexpr int kSlotFloatsW = 36;
 constexpr size_t kBufBytes = (size_t)4 * kPanelVecs * 16;                    // A (2 tiles) + B (2 tiles) of a panel: 64 KB
-constexpr size_t kThrAt = 2 * kBufBytes;                                     // [2 units][row 256 | col 256] floats
-constexpr size_t kQueueAt = kThrAt + (size_t)2 * 512 * sizeof(float);
+constexpr size_t kThrAt = 2 * kBufBytes;  // [2 units][row thresholds | column thresholds or lambdas | row lambdas | row guesses] x 256 floats
+constexpr size_t kSlotBytes = 4 * 256 * sizeof(float);
+constexpr size_t kQueueAt = kThrAt + 2 * kSlotBytes;
 constexpr size_t kSlotsAt = kQueueAt + (size_t)4 * kQueueW * (sizeof(uint2) + sizeof(float));
 constexpr size_t kWideLds = kSlotsAt + (size_t)4 * 4 * kSlotFloatsW * sizeof(float);
 
@@ -113,6 +114,12 @@ __device__ __forceinline__ void append_w(uint32_t *__restrict__ cnt, uint32_t *_
 //   [I_begin, I_begin + T2) of P; a workgroup sweeps the whole sample for one row super tile at a time and leaves, per row,
 //   64 maxima over 64 disjoint sub-samples (column position mod 32 x parity of the 128-row tile, as mfma_theta_bf16.hip)
 //   in maxima[row - 256 I_begin][64]; a second kernel picks the order statistics.
+// MODE 3: MODE 2 for the search: P = image of the queries, PA of the sampled items; what is reduced is the approximate SCORE
+//   alpha cos + beta (1 - min(|lambda_q - lambda_x|, 1)) (src/core.rs:229-239): row_lam / col_lam = f32 lambdas of the queries
+//   (padded) and of the sample.
+// MODE 4: MODE 1 for the search: PA = image of the queries, theta = (g_q - beta) / alpha (what the cosine alone must reach:
+//   the coarse test), row_g = g_q - beta, row_lam / col_lam = f32 lambdas of the queries / of ALL items (padded); a pair is
+//   listed when alpha s - min(|beta lambda_q - beta lambda_x|, beta) >= g_q - beta, with that value as its score.
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA,
                                                                     const uint32_t *__restrict__ a_ids, uint32_t KS, uint32_t T2,
@@ -120,7 +127,9 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
                                                                     const float *__restrict__ theta, uint32_t cap,
                                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
                                                                     float *__restrict__ maxima, uint32_t *__restrict__ unit_counters,
-                                                                    int dbg, unsigned long long *__restrict__ stamps) {
+                                                                    int dbg, unsigned long long *__restrict__ stamps,
+                                                                    const float *__restrict__ col_lam, const float *__restrict__ row_lam,
+                                                                    const float *__restrict__ row_g, float alpha, float beta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_next[2];  // (I, J) of the unit after the current one; I = ~0: none
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,12 +158,14 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   // ---- MODE 0 / 1: the pairs of this workgroup's XCD, rectangles of 4 row super tiles x 8 column offsets, from the XCD's
   // own counter.  MODE 2: a row super tile from the one counter, then the sample super tiles in order.
   const uint32_t n_norm = (T2 - 1) / 2;
+  constexpr bool kSweep = MODE == 2 || MODE == 3;   // a row super tile at a time against every column super tile of PA
+  constexpr bool kOneSided = MODE == 1 || MODE == 4;
   const uint32_t l_max = MODE == 0 ? 1 + n_norm + 1 : T2;
   const uint32_t n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8;
   const uint32_t xcd = blockIdx.x & 7u;
   uint32_t t_row = 0xFFFFFFFFu, t_col = 0;  // MODE 2, thread 0: where the sweep stands
   auto fetch_unit = [&]() {  // thread 0: the next valid pair into s_next
-    if (MODE == 2) {
+    if (kSweep) {
       if (t_row == 0xFFFFFFFFu || ++t_col == I_count) {
         const uint32_t v = atomicAdd(unit_counters, 1u);
         t_row = v < T2 ? v : 0xFFFFFFFFu;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       const uint32_t di = w & 3u, off = ob * 8u + (w >> 2);
       if (ib * 4u + di >= I_count) continue;
       const uint32_t I = I_begin + ib * 4u + di;
-      if (MODE == 1) {
+      if (kOneSided) {
         if (off >= T2) continue;
         s_next[0] = I;
         s_next[1] = off;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   auto dma_panel = [&](uint32_t I, uint32_t J, uint32_t p, int buf, int part) {
     // rows (waves 0, 1): the gathered rows' image in MODE 1; columns (waves 2, 3): the sample's in MODE 2
     const uint32_t S = (wv < 2 ? I : J), tile = 2u * S + (uint32_t)(wv & 1);
-    const f16x8 *img = (MODE == 1 && wv < 2) || (MODE == 2 && wv >= 2) ? PA : P;
+    const f16x8 *img = (kOneSided && wv < 2) || (kSweep && wv >= 2) ? PA : P;
     const f16x8 *src = img + ((size_t)tile * KS + (size_t)p * kPK) * 256 + lane;
     unsigned char *dst = smem + (size_t)buf * kBufBytes + (size_t)wv * kPanelVecs * 16;
 #pragma unroll
@@ -212,12 +223,15 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   };
   // thresholds of the pair's rows and columns -> LDS (slot = parity of the unit): 1 KB each, waves 0 and 2
   auto dma_thr = [&](uint32_t I, uint32_t J, int slot) {
-    if (MODE == 2) return;
-    if (wv == 0)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)I * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048), 16, 0, 0);
-    if (wv == 2 && MODE == 0)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)J * kWS + lane * 4), (lds_void *)(smem + kThrAt + (size_t)slot * 2048 + 1024),
-                                       16, 0, 0);
+    unsigned char *dst = smem + kThrAt + (size_t)slot * kSlotBytes;
+    const float *src = nullptr;
+    if (wv == 0 && MODE != 2 && MODE != 3) src = theta + (size_t)I * kWS;                 // row thresholds
+    if (wv == 1 && MODE == 0) src = theta + (size_t)J * kWS;                               // column thresholds
+    if (wv == 1 && MODE == 3) src = col_lam + (size_t)J * kWS;                             // lambdas of the sample
+    if (wv == 1 && MODE == 4) src = col_lam + (size_t)J * kWS;                             // lambdas of the items
+    if (wv == 2 && (MODE == 3 || MODE == 4)) src = row_lam + (size_t)(I - (MODE == 3 ? I_begin : 0u)) * kWS;
+    if (wv == 3 && MODE == 4) src = row_g + (size_t)I * kWS;
+    if (src) __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane * 4), (lds_void *)(dst + (size_t)wv * 1024), 16, 0, 0);
   };
 
   unsigned long long n_blk = 0, n_pass = 0;
@@ -231,12 +245,12 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   dma_thr(I, J, 0);
 
   v16f32 acc[4][4];
-  v16f32 rmax[MODE == 2 ? 4 : 1];  // MODE 2: running maxima of the wave's rows over the columns = lc (mod 32) of its half
-  if (MODE == 2) {
+  v16f32 rmax[kSweep ? 4 : 1];  // MODE 2: running maxima of the wave's rows over the columns = lc (mod 32) of its half
+  if (kSweep) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rmax[MODE == 2 ? q : 0][r] = -__builtin_inff();
+      for (int r = 0; r < 16; ++r) rmax[kSweep ? q : 0][r] = -__builtin_inff();
   }
   for (;;) {
     if (tid == 0) fetch_unit();  // visible after the first barrier of the panel loop
@@ -269,14 +283,14 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       const bool last = p + 1 == np;
       const bool more = !last || In != 0xFFFFFFFFu;
       const uint32_t Id = last ? In : I, Jd = last ? Jn : J, pd = last ? 0u : p + 1;
-      if (p == 0 && MODE == 2) {
+      if (p == 0 && kSweep) {
         static_for_w<0, 16>([&](auto e_c) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[decltype(e_c)::value >> 2][decltype(e_c)::value & 3][r] = 0.f;
         });
       }
-      if (p == 0 && MODE != 2) {  // the accumulators start at minus the scaled row thresholds
-        const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
+      if (p == 0 && !kSweep) {  // the accumulators start at minus the scaled row thresholds
+        const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
         static_for_w<0, 4>([&](auto sa_c) {
           constexpr int sa = decltype(sa_c)::value;
           v4f32 t[4];
@@ -325,11 +339,42 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
 #undef AS_FRAGS
     // ---- the pair is contracted: coarse test per 32 x 32 block, element-wise test and listing for the few that pass ----
     n_blk += 16;
-    if (MODE == 2) {
-      static_for_w<0, 16>([&](auto e_c) {
-        constexpr int sa = decltype(e_c)::value >> 2, sb = decltype(e_c)::value & 3;
+    if (kSweep) {
+      float lx[4] = {0.f, 0.f, 0.f, 0.f};  // MODE 3: lambdas of the lane's columns
+      const uint32_t la = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes + 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
+      if (MODE == 3) {
+        const uint32_t ca = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes + 1024) + (uint32_t)(wc * 128 + lc) * 4u;
+        lds_read4f_w(lx[0], ca);
+        lds_read4f_w(lx[1], ca + 32 * 4);
+        lds_read4f_w(lx[2], ca + 64 * 4);
+        lds_read4f_w(lx[3], ca + 96 * 4);
+        lds_wait_all_w();
+      }
+      static_for_w<0, 4>([&](auto sa_c) {
+        constexpr int sa = decltype(sa_c)::value;
+        float lq[16];  // MODE 3: lambdas of the lane's rows of this block row
+        if (MODE == 3) {
+          v4f32 t[4];
+          lds_read16f_w<(sa * 32 + 0) * 4>(t[0], la);
+          lds_read16f_w<(sa * 32 + 8) * 4>(t[1], la);
+          lds_read16f_w<(sa * 32 + 16) * 4>(t[2], la);
+          lds_read16f_w<(sa * 32 + 24) * 4>(t[3], la);
+          lds_wait_all_w();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rmax[MODE == 2 ? sa : 0][r] = __builtin_fmaxf(rmax[MODE == 2 ? sa : 0][r], acc[sa][sb][r]);
+          for (int r = 0; r < 16; ++r) lq[r] = t[r >> 2][r & 3];
+        }
+        static_for_w<0, 4>([&](auto sb_c) {
+          constexpr int sb = decltype(sb_c)::value;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float val = acc[sa][sb][r];
+            if (MODE == 3) {  // the approximate score: alpha s + beta (1 - min(|lambda_q - lambda_x|, 1))
+              const float tt = __builtin_fminf(__builtin_fabsf(lq[r] - lx[sb]), 1.f);
+              val = __builtin_fmaf(-beta, tt, __builtin_fmaf(alpha * (1.f / kProductScaleW), val, beta));
+            }
+            rmax[kSweep ? sa : 0][r] = __builtin_fmaxf(rmax[kSweep ? sa : 0][r], val);
+          }
+        });
       });
       if (In != I) {  // the sweep of this row super tile is over: its maxima go out (32 consecutive floats per row and half wave)
         static_for_w<0, 4>([&](auto sa_c) {
@@ -337,15 +382,15 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const uint32_t row = (I - I_begin) * kWS + wr * 128 + sa * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-            maxima[(size_t)row * 64 + wc * 32 + lc] = rmax[MODE == 2 ? sa : 0][r] * (1.f / kProductScaleW);
-            rmax[MODE == 2 ? sa : 0][r] = -__builtin_inff();
+            maxima[(size_t)row * 64 + wc * 32 + lc] = rmax[kSweep ? sa : 0][r] * (MODE == 3 ? 1.f : 1.f / kProductScaleW);
+            rmax[kSweep ? sa : 0][r] = -__builtin_inff();
           }
         });
       }
     } else if (!(dbg & 128)) {
       const bool diag = MODE == 0 && I == J;
-      const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
-      const uint32_t ca = lds_addr_w(smem + kThrAt + (size_t)slot * 2048 + 1024) + (uint32_t)(wc * 128 + lc) * 4u;
+      const uint32_t ra = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
+      const uint32_t ca = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes + 1024) + (uint32_t)(wc * 128 + lc) * 4u;
       float tcs[4] = {0.f, 0.f, 0.f, 0.f};
       if (MODE == 0) {
         lds_read4f_w(tcs[0], ca);
@@ -432,12 +477,25 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
             const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
             bool inside = valid && col < n && row < n_rows;
             if (MODE == 1) inside = inside && a_ids[row < n_rows ? row : 0] != col;  // lists by position, self by global id
-            else inside = inside && row != col;
-            const bool w1 = inside && ap >= 0.f, w2 = inside && vv >= tcx;
+            else if (MODE == 0) inside = inside && row != col;
+            float sc = vv * (1.f / kProductScaleW);
+            bool w1 = inside && ap >= 0.f;
+            if (MODE == 4) {  // alpha s - min(|beta lambda_q - beta lambda_x|, beta) >= g_q - beta
+              const uint32_t lbase = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes);
+              const uint32_t rl = (uint32_t)(wr * 128 + sa * 32) + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2);
+              const uint32_t cl = (uint32_t)(wc * 128 + sb * 32) + (src & 31);
+              float lqv, lxv, gq;
+              lds_read4f_w(lqv, lbase + 2048 + rl * 4);
+              lds_read4f_w(lxv, lbase + 1024 + cl * 4);
+              lds_read4f_w(gq, lbase + 3072 + rl * 4);
+              lds_wait_all_w();
+              sc = __builtin_fmaf(alpha, sc, -__builtin_fminf(__builtin_fabsf(__builtin_fmaf(beta, lqv, -beta * lxv)), beta));
+              w1 = inside && sc >= gq;
+            }
+            const bool w2 = MODE == 0 && inside && vv >= tcx;
             const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
             const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
             if (qn + n1 + n2 > kQueueW) flush_queue();
-            const float sc = vv * (1.f / kProductScaleW);
             if (w1) {
               const uint32_t at = qn + lanes_below(m1);
               lds_write8_w(q_addr + at * 8, make_uint2(row, col));
@@ -515,7 +573,8 @@ __global__ void theta_select_wide_kernel(const float *__restrict__ maxima, uint3
 template <int MODE>
 static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const void *PA, const uint32_t *a_ids, uint32_t KS,
                        uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_rows, uint32_t n, const float *theta,
-                       uint32_t cap, uint32_t *cnt, uint32_t *cand, float *maxima) {
+                       uint32_t cap, uint32_t *cnt, uint32_t *cand, float *maxima, const float *col_lam = nullptr,
+                       const float *row_lam = nullptr, const float *row_g = nullptr, float alpha = 0.f, float beta = 0.f) {
   DevBuf<unsigned long long> stamps;
   DevBuf<uint32_t> counters;
   AS_TRY(stamps.alloc(ctx, 8));
@@ -528,7 +587,7 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
                                     (int)kWideLds));
     hipLaunchKernelGGL((pair_join_f16_wide_kernel<MODE>), dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P,
                        (const f16x8 *)PA, a_ids, KS, T2, I_begin, I_count, n_rows, n, theta, cap, cnt, cand, maxima, counters.p,
-                       (int)ctx->opt_debug, stamps.p);
+                       (int)ctx->opt_debug, stamps.p, col_lam, row_lam, row_g, alpha, beta);
     AS_HIP(ctx, hipGetLastError());
   }
   unsigned long long h[8];
@@ -585,6 +644,43 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
   return AS_OK;
+}
+
+// ---- the search on the same kernel (items wider than 128): score guesses and the one-sided scan ----
+// PQ: f16 image of the nq queries (whole 256-row super tiles, zero padded).  guesses of every query = the m-th (and m2-th)
+// largest approximate score over the sample (ns item ids, a multiple of 256; s_lam their f32 lambdas); q_lam: f32 lambdas
+// of the queries, padded to the image.  The contract of search_thresholds_bf16 (mfma_theta_bf16.hip).
+int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
+                               const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam, float alpha,
+                               float beta, float *score_out, uint32_t m2, float *score2_out) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 search thresholds: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || ns < 256 || ns % 256 != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 search thresholds: sample size");
+  const uint32_t s_tiles = ns / kTileRows, q_supers = (nq + kWS - 1) / kWS;
+  DevBuf<unsigned char> PS;
+  DevBuf<float> maxima;
+  AS_TRY(PS.alloc(ctx, packed_vecs_f16(s_tiles, d) * 16));
+  AS_TRY(pack_f16(ctx, items, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  AS_TRY(maxima.alloc(ctx, (size_t)q_supers * kWS * 64));
+  AS_TRY(launch_wide<3>(ctx, "search_thresholds", PQ, PS.p, nullptr, KS, q_supers, 0, ns / kWS, nq, ns, nullptr, 0, nullptr, nullptr, maxima.p,
+                        s_lam, q_lam, nullptr, alpha, beta));
+  hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, maxima.p, nq, m, m2, score_out, score2_out);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+// Lists, per query (position), every item whose approximate score reaches its guess.  P: f16 image of the n items; PQ: of
+// the nq queries; cos_floor = (g_q - beta) / alpha and g_minus_beta = g_q - beta by position (padded to the image: +inf);
+// q_lam / x_lam: f32 lambdas of the queries / the items (padded).  The contract of join_bf16_search (mfma_join_bf16.hip).
+int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
+                         const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
+                         uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 search: dim not covered");
+  const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
+  return launch_wide<4>(ctx, prof_name, P, PQ, nullptr, KS, T2, 0, (nq + kWS - 1) / kWS, nq, n, cos_floor, cap, cnt, cand, nullptr, x_lam,
+                        q_lam, g_minus_beta, alpha, beta);
 }
 
 }  // namespace asx

@@ -846,18 +846,24 @@ def test_search_scan_any_guess_is_exact(ctx, scan_on, rate, rank, cap):
 
 
 def test_search_scan_not_used_outside_its_range(ctx, scan_on):
-    """alpha outside (0, 1], rows wider than 128, large lambdas: the top-k passes run as before."""
+    """alpha outside (0, 1], large lambdas, rows wider than 128 with the f16 pipe switched off: the top-k passes run as before
+    (wide rows on the f16 pipe take the scan too: the last case, and test_search_scan_of_wide_items)."""
     n = 3_000
     rng = np.random.default_rng(4)
-    for d, alpha, scale in ((64, 1.5, 1.0), (64, 0.0, 1.0), (200, 0.7, 1.0), (64, 0.7, 1e3)):
+    for d, alpha, scale, pipe, want in ((64, 1.5, 1.0, 16, 0), (64, 0.0, 1.0, 16, 0), (200, 0.7, 1.0, 32, 0), (64, 0.7, 1e3, 16, 0),
+                                        (200, 0.7, 1.0, 16, 1)):
+        ctx.set_option("join_pipe", pipe)
         X, _ = synth.mixture(n, d, seed=6, n_clusters=16, rank=4)
         lam = rng.random(n) * scale
         asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
         asp.update_lambdas(lam)
         Q = X[:20] * 1.02
         lq = lam[:20] * 1.01
-        idx, sc = asp.search_lambda_aware_batch(Q, lq, 5, alpha)
-        assert ctx.stat("search_scan") == 0, (d, alpha, scale)
+        try:
+            idx, sc = asp.search_lambda_aware_batch(Q, lq, 5, alpha)
+        finally:
+            ctx.set_option("join_pipe", 16)
+        assert ctx.stat("search_scan") == want, (d, alpha, scale, pipe)
         for j in (0, 7, 19):
             oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 5, alpha)
             assert np.array_equal(idx[j], oi) and np.array_equal(sc[j], osc)
@@ -1012,6 +1018,31 @@ def test_small_batch_search_of_wide_items(ctx, nq, d):
     idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, 0.7)
     for j in range(nq):
         oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 10, 0.7)
+        assert np.array_equal(idx[j], oi), j
+        assert np.array_equal(sc[j], osc), j
+
+
+@pytest.mark.parametrize("nq,d,alpha", [(300, 768, 0.7), (257, 300, 0.4), (1000, 200, 1.0)])
+def test_search_scan_of_wide_items(ctx, nq, d, alpha):
+    """Batches against items wider than 128: score guesses and the one-sided scan on the panelled f16 kernel (modes 3 / 4
+    of pair_join_f16_wide_kernel), exact re-rank and certification as for 128-wide items; every query compared with the
+    oracle, ties in the lambda term and duplicated items included."""
+    n = 40_000
+    X, _ = synth.mixture(n, d, seed=29, n_clusters=32, rank=6)
+    rng = np.random.default_rng(nq + d)
+    lam = rng.random(n)
+    lam[::5] = lam[2]
+    X[100:140] = X[7]
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    qi = synth.query_indices(n, nq, seed=5)
+    qi[0] = 7
+    Q = X[qi] * 1.02
+    lq = rng.random(nq) + 0.01
+    idx, sc = asp.search_lambda_aware_batch(Q, lq, 10, alpha)
+    assert ctx.stat("search_scan") == 1 and ctx.stat("search_scan_candidates") > 0
+    for j in range(0, nq, 7):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 10, alpha)
         assert np.array_equal(idx[j], oi), j
         assert np.array_equal(sc[j], osc), j
 
