@@ -671,6 +671,9 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
 int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                              uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                              float *theta2_out);
+int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
+                    const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
 int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
                                const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam, float alpha,
                                float beta, float *score_out, uint32_t m2, float *score2_out);
@@ -1486,6 +1489,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   // ---- stage 0: threshold scan on the bf16 pipe (see the note above gather_lambda_f32_kernel) ----
   // (items wider than 128: the same scan on the panelled f16 kernel, mfma_join_f16_wide.hip)
   const bool scan_wide = wide && d <= 2048 && d % 2 == 0 && ctx->opt_join_pipe == 16;
+  // up to 128 wide: the scan itself on one f16 plane (MODE 1 of pair_join_f16_kernel), guesses still from split-bf16 products
+  const bool scan_h = !wide && ctx->opt_join_pipe == 16 && ctx->opt_search_scan_f16;
   bool scan = ctx->opt_search_scan && ctx->opt_cand_precision != 64 && (!wide || scan_wide) && alpha > 0.0 && alpha <= 1.0 && K < 1024 &&
               n >= (uint32_t)std::max<int64_t>(4 * kTileRows, ctx->opt_join_min_rows);
   double lsum = 0.0;
@@ -1509,13 +1514,13 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   if (scan) {
     const double beta = 1.0 - alpha;
-    if (scan_wide && !ix->packedh) {
+    if ((scan_wide || scan_h) && !ix->packedh) {
       const uint32_t tiles = packed_tiles_f16(n);
       AS_HIP(ctx, hipMalloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
       AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles));
       ix->f16_err = ctx->f16_err;
     }
-    if (!scan_wide && !ix->packed16) {
+    if (!scan_wide && !scan_h && !ix->packed16) {
       AS_HIP(ctx, hipMalloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed16, b_alloc));
     }
@@ -1545,9 +1550,10 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     }
     const uint32_t ns = ix->scan_ns;
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_search_scan_rank, 32));
-    const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = (a_tiles + 1) & ~1u, padded = a_alloc * kTileRows;
+    const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = scan_h ? (a_tiles + 3) & ~3u : (a_tiles + 1) & ~1u;
+    const uint32_t padded = a_alloc * kTileRows;  // whole super tiles of the kernel that scans (512 rows on the f16 plane, else 256)
     const uint32_t cap = (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(ctx->opt_search_scan_cap, 1024));
-    DevBuf<unsigned char> PQ;
+    DevBuf<unsigned char> PQ, PQh;
     DevBuf<float> qlam, guess, guess2, guess_pad;
     // the looser guess of the second pass over what fails: rank 2 m + 6, as far as its ~rank x rate candidates fit the lists
     const uint32_t m2 = std::max(m, std::min<uint32_t>(std::min<uint32_t>(48, 2 * m + 6), 512u / std::max(1u, n / ns)));
@@ -1562,6 +1568,15 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_TRY(unitc.alloc(ctx, 1));
     double cos_delta = cos_delta_bf16x3(d);  // bound between a listed product and the exact cosine
     DevBuf<float> floor_pad, gmb_pad;
+    if (scan_h) {
+      AS_TRY(PQh.alloc(ctx, packed_vecs_f16(a_alloc, d) * 16));
+      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQh.p, a_alloc));
+      const double e = std::max(ctx->f16_err, ix->f16_err);
+      cos_delta = (ctx->f16_err >= 0.0 && ix->f16_err >= 0.0) ? std::min(cos_delta_f16(d), 2.0 * e + e * e + cos_delta_f16_accum(d))
+                                                                : cos_delta_f16(d);
+      AS_TRY(floor_pad.alloc(ctx, padded));
+      AS_TRY(gmb_pad.alloc(ctx, padded));
+    }
     if (scan_wide) {  // one f16 plane: the measured plane errors of the two images (mfma_join_f16.hip)
       AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQ.p, a_alloc));
       const double e = std::max(ctx->f16_err, ix->f16_err);
@@ -1584,7 +1599,12 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
                        nq, padded, guess_pad.p);
     AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * padded, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-    if (scan_wide) {
+    if (scan_h) {
+      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
+                         nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
+      AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQh.p, nq, floor_pad.p, gmb_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
+                             cnt.p, cand.p, unitc.p, "search_scan_f16"));
+    } else if (scan_wide) {
       hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
                          nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
       AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQ.p, nq, floor_pad.p, gmb_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta,
@@ -1640,13 +1660,13 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // ---- stage 0b: the queries whose guess was too high, again with the looser one ----
     if (n_fail > 0 && n_fail <= nq / 4 + 16) {
       const uint32_t nf = n_fail;
-      const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad_b = b_al * kTileRows;
+      const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = scan_h ? (bt + 3) & ~3u : (bt + 1) & ~1u, pad_b = b_al * kTileRows;
       const uint32_t cap2 = 1024;
       DevBuf<unsigned char> PQb;
       DevBuf<float> qlam_b, guess_b;
       DevBuf<uint32_t> cnt_b, cand_b, oi, fail_b, ids_b;
       DevBuf<double> ok;
-      AS_TRY(PQb.alloc(ctx, (scan_wide ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
+      AS_TRY(PQb.alloc(ctx, ((scan_wide || scan_h) ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
       AS_TRY(qlam_b.alloc(ctx, pad_b));
       AS_TRY(guess_b.alloc(ctx, pad_b));
       AS_TRY(cnt_b.alloc(ctx, pad_b));
@@ -1655,7 +1675,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(oi.alloc(ctx, (size_t)nf * K));
       AS_TRY(fail_b.alloc(ctx, nf));
       AS_TRY(ids_b.alloc(ctx, nf));
-      if (scan_wide) AS_TRY(pack_f16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
+      if (scan_wide || scan_h) AS_TRY(pack_f16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
       else AS_TRY(pack_bf16(ctx, queries, q_norms, fail1.p, 0, nf, d, PQb.p, b_al));
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, q_lambdas, fail1.p, nf, pad_b,
                          qlam_b.p);
@@ -1664,13 +1684,17 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad_b, ctx->stream));
       AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
       AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-      if (scan_wide) {
+      if (scan_wide || scan_h) {
         DevBuf<float> floor_b, gmb_b;
         AS_TRY(floor_b.alloc(ctx, pad_b));
         AS_TRY(gmb_b.alloc(ctx, pad_b));
         hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, guess2.p, fail1.p, nf, pad_b,
                            (float)alpha, (float)beta, floor_b.p, gmb_b.p);
-        AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta,
+        if (scan_h)
+          AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
+                                 cnt_b.p, cand_b.p, unitc.p, "search_scan_f16"));
+        else
+          AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta,
                                     cap2, cnt_b.p, cand_b.p, "search_scan_f16"));
       } else {
         AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQb.p, nf, guess_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,

@@ -40,7 +40,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 constexpr int kSuperH = 512;        // rows per super tile (four packed 128-row tiles)
-constexpr uint32_t kQueueH = 256;   // queued appends per wave (one accumulator register adds at most 128)
+constexpr uint32_t kQueueJoin = 256;    // queued appends per wave (one accumulator register adds at most 128)
+constexpr uint32_t kQueueSearch = 160;  // ... in the search mode, whose per-unit arrays take the room (one side is listed: <= 64 per pass)
 constexpr float kOperandScale = 128.f;     // unit rows are stored times 2^7 ...
 constexpr float kProductScale = 16384.f;   // ... so products (and thresholds inside the kernel) carry 2^14
 
@@ -126,13 +127,23 @@ __device__ __forceinline__ void append16(uint32_t *__restrict__ cnt, uint32_t *_
 // column block, so that the workgroups running together stream the same columns.  Super tile I meets the column
 // super tiles I .. I + (T2 - 1) / 2 (mod T2), the antipodal one only from the smaller index: every unordered pair of
 // super tiles once, the same work for every I.
-template <int KS>
-__global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, uint32_t T2, uint32_t I_begin,
-                                                               uint32_t I_count, uint32_t W, uint32_t n,
+// MODE 1: the threshold scan of the search on the same machinery (one-sided).  PA = f16 image of the queries (whole 512-row
+// super tiles, [I_begin, I_begin + I_count) of them), every one of which meets every column super tile of P (the items);
+// theta = what the cosine alone must reach, (g_q - beta) / alpha, by query position (+inf on padding): the coarse test;
+// s.q_g = g_q - beta, s.q_lam / s.x_lam = f32 lambdas of the queries / of all items (padded to whole super tiles).  A pair
+// is listed for its query when alpha s - min(|beta lambda_q - beta lambda_x|, beta) >= g_q - beta, with that value as score.
+struct F16SearchTerm {
+  const float *q_lam, *q_g, *x_lam;
+  float alpha, beta;
+  uint32_t nq;
+};
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
+                                                               uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
                                                                const float *__restrict__ theta, uint32_t cap,
                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
                                                                uint32_t *__restrict__ unit_counter, int dbg,
-                                                               unsigned long long *__restrict__ stamps) {
+                                                               unsigned long long *__restrict__ stamps, F16SearchTerm st) {
   constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
   constexpr int kBlocks = 8;                 // 32-column blocks per stage
@@ -147,11 +158,15 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   // passing pairs go to a per-wave LDS queue as (list owner, other row, score) and are appended 64 at a time: an append is
   // a returning atomic (~2 us before its store can go out) and, taken one by one, makes its wave late at the barrier
   constexpr size_t kQueueBase = (size_t)2 * kStageVecs * 16 + 2 * 256 * sizeof(float);
+  constexpr uint32_t kQueueH = MODE == 1 ? kQueueSearch : kQueueJoin;
   uint2 *queue = reinterpret_cast<uint2 *>(smem + kQueueBase) + (size_t)wv * kQueueH;
   float *queue_s = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * sizeof(uint2)) + (size_t)wv * kQueueH;
   // listing scratch of the wave: 4 slots of (16 acc, 16 acc + theta_row, lane, theta_col, 2 unused) floats
   constexpr int kSlotFloats = 36;
   float *ex = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + (size_t)wv * 4 * kSlotFloats;
+  // MODE 1: lambda and g - beta of the unit's 512 queries
+  float *s_qlam = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + 8 * 4 * kSlotFloats;
+  float *s_qg = s_qlam + kSuperH;
   uint32_t qn = 0;  // wave-uniform
   auto lanes_below = [&](unsigned long long m) -> uint32_t {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -190,9 +205,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     } else if (part < KS) {  // one piece with each of the first KS blocks
       __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * KS + part) * 64), (lds_void *)(dst + (wv * KS + part) * 64), 16, 0, 0);
     }
-    if (wv == 7 && part <= 0)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(theta + (size_t)tile0 * kTileRows + lane * 4), (lds_void *)(colthr + buf * 256),
-                                       16, 0, 0);
+    if (wv == 7 && part <= 0)  // thresholds of the stage's columns (MODE 1: their lambdas)
+      __builtin_amdgcn_global_load_lds((gbl_void *)((MODE == 1 ? st.x_lam : theta) + (size_t)tile0 * kTileRows + lane * 4),
+                                       (lds_void *)(colthr + buf * 256), 16, 0, 0);
   };
 
   // diagnostics (as_ctx_set_option("debug", bits)): 2 no listing, 4 no DMA of the next stage, 8 cycle stamps, 128 no test
@@ -215,7 +230,10 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
     const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
     uint32_t p_lo, p_hi;
-    {
+    if (MODE == 1) {  // every column super tile of the block, by absolute index
+      p_lo = B0;
+      p_hi = B0 + Wc;
+    } else {
       const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
       const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);  // offsets of this super tile: 0 = diagonal
       const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;  // offset of the block's first super tile
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     {
       const size_t T = (size_t)4 * I + (wv >> 1);
       const int s0 = 2 * (wv & 1);
-      const f16x8 *a_src = P + T * kTileVecs + (size_t)s0 * 64 + lane;
+      const f16x8 *a_src = (MODE == 1 ? PA : P) + T * kTileVecs + (size_t)s0 * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         a0[ks] = a_src[(size_t)ks * 256];
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     tmax1 = __builtin_fmaxf(tmax1, __shfl_xor(tmax1, 32, 64));
 
     auto tile_of = [&](uint32_t step) -> uint32_t {  // first packed tile of a stage
-      uint32_t S = I + p_lo + (step >> 1);
+      uint32_t S = (MODE == 1 ? 0u : I) + p_lo + (step >> 1);
       S = S >= T2 ? S - T2 : S;
       return 4 * S + 2 * (step & 1u);
     };
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       v16f32 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
-      const bool hit = max16(acc) >= 0.f || max16(v) >= tc;
+      const bool hit = max16(acc) >= 0.f || (MODE == 0 && max16(v) >= tc);
       unsigned long long m = __ballot(hit);
       if (m == 0) return false;
       do {
@@ -294,12 +312,23 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         const float ap = sl[r], vv = sl[16 + r], tcs = sl[33];
         const uint32_t src = __float_as_uint(sl[32]);
         const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
-        const bool inside = valid && row < n && col < n && row != col;
-        const bool w1 = inside && ap >= 0.f, w2 = inside && vv >= tcs;
+        bool inside = valid && col < n;
+        float sc = vv * (1.f / kProductScale);
+        bool w1, w2;
+        if (MODE == 1) {  // tcs = lambda of the column; the query's lambda and g - beta from the unit's arrays
+          const uint32_t rl = row - I * kSuperH;
+          inside = inside && row < st.nq;
+          sc = __builtin_fmaf(st.alpha, sc, -__builtin_fminf(__builtin_fabsf(__builtin_fmaf(st.beta, s_qlam[rl & (kSuperH - 1)], -st.beta * tcs)), st.beta));
+          w1 = inside && ap >= 0.f && sc >= s_qg[rl & (kSuperH - 1)];
+          w2 = false;
+        } else {
+          inside = inside && row < n && row != col;
+          w1 = inside && ap >= 0.f;
+          w2 = inside && vv >= tcs;
+        }
         const unsigned long long m1 = __ballot(w1), m2 = __ballot(w2);
         const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2);
         if (qn + n1 + n2 > kQueueH) flush_queue();
-        const float sc = vv * (1.f / kProductScale);
         if (w1) {
           queue[qn + lanes_below(m1)] = make_uint2(row, col);
           queue_s[qn + lanes_below(m1)] = sc;
@@ -320,6 +349,10 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
 
     f16x8 fa[4];
     __syncthreads();
+    if (MODE == 1) {  // (no DMA is pending here)
+      s_qlam[tid] = st.q_lam[(size_t)I * kSuperH + tid];
+      s_qg[tid] = st.q_g[(size_t)I * kSuperH + tid];
+    }
     stage(tile_of(0), 0, -1);
     __syncthreads();
     if (stamp) {
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     for (uint32_t step = 0; step < steps; ++step) {
       const uint32_t tile0 = tile_of(step);
       const int pbuf = (int)(step & 1u);
-      const bool diag = (p_lo + (step >> 1)) == 0;
+      const bool diag = MODE == 0 && (p_lo + (step >> 1)) == 0;
       const bool more = step + 1 < steps && !(dbg & 4);
       const uint32_t tile_next = more ? tile_of(step + 1) : 0;
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kStageVecs) + (uint32_t)lane * 16u;
@@ -375,8 +408,10 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         n_blk += 2;
         if (!(dbg & 128)) {
           const uint32_t colbase = tile0 * kTileRows + nn * 32;
-          const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]);
-          const bool h0 = max16(x0) >= __builtin_fminf(0.f, tc - tmax0), h1 = max16(x1) >= __builtin_fminf(0.f, tc - tmax1);
+          const float tc = MODE == 1 ? tcol[nn * 32] /* lambda of the lane's column */
+                                     : ((diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]));
+          const bool h0 = MODE == 1 ? max16(x0) >= 0.f : max16(x0) >= __builtin_fminf(0.f, tc - tmax0);
+          const bool h1 = MODE == 1 ? max16(x1) >= 0.f : max16(x1) >= __builtin_fminf(0.f, tc - tmax1);
           if (__any(h0 || h1) && !(dbg & 2)) {
             if (__any(h0)) n_pass += emit(x0, nth0, row_base0 - 4 * lh, colbase, tc) ? 1 : 0;
             if (__any(h1)) n_pass += emit(x1, nth1, row_base1 - 4 * lh, colbase, tc) ? 1 : 0;
@@ -478,6 +513,12 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
   return AS_OK;
 }
 
+static size_t f16_join_lds(uint32_t KS, bool search) {
+  return (size_t)2 * 2 * KS * 4 * 64 * 16 + 2 * 256 * sizeof(float) +
+         (size_t)8 * (search ? kQueueSearch : kQueueJoin) * (sizeof(uint2) + sizeof(float)) + (size_t)8 * 4 * 36 * sizeof(float) +
+         (search ? (size_t)2 * kSuperH * sizeof(float) : 0);
+}
+
 // Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 = ceil(n / 512) super tiles of the f16 image P
 // (all n rows).  theta: T2 * 512 thresholds (+inf on padding).  cnt / cand (n x cap) are indexed by global row; cnt must be
 // zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
@@ -486,8 +527,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
-  const size_t lds = (size_t)2 * 2 * KS * 4 * 64 * 16 + 2 * 256 * sizeof(float) + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float)) +
-                     (size_t)8 * 4 * 36 * sizeof(float);
+  const size_t lds = f16_join_lds(KS, false);
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
   const uint32_t W = std::max(1u, std::min(w_opt, T2 / 4));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
@@ -499,10 +539,11 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
     ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds));                                                                           \
-    hipLaunchKernelGGL((pair_join_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P, T2, I_begin, \
-                       I_count, W, n, theta, cap, cnt, cand, unit_counter, (int)ctx->opt_debug, stamps.p);                \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K, 0>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
+                       (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,           \
+                       (int)ctx->opt_debug, stamps.p, F16SearchTerm{});                                                   \
     break;
     switch (KS) {
       AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
@@ -525,6 +566,42 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
                    h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5], h[5] ? (double)h[7] / h[5] : 0.0);
     }
   }
+  return AS_OK;
+}
+
+// The threshold scan of the search on one f16 plane (MODE 1 of the kernel; the contract of join_bf16_search in
+// mfma_join_bf16.hip, with the guess handed over as cos_floor = (g - beta) / alpha and g_minus_beta, both by query position and
+// padded to whole 512-row super tiles with +inf).  PQ: f16 image of the queries (whole 512-row super tiles).
+int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
+                    const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
+  const uint32_t T2 = (n + kSuperH - 1) / kSuperH, a_supers = (nq + kSuperH - 1) / kSuperH;
+  const size_t lds = f16_join_lds(KS, true);
+  const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  const uint32_t W = std::max(1u, std::min(w_opt, std::max(1u, T2 / 4)));
+  const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
+  const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
+  DevBuf<unsigned long long> stamps;
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq};
+  ProfScope ps(ctx, prof_name);
+#define AS_JOIN(K)                                                                                                        \
+  case K:                                                                                                                 \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                           \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
+                       (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,                \
+                       (int)(ctx->opt_debug & ~8), stamps.p, st);                                                         \
+    break;
+  switch (KS) {
+    AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
+  }
+#undef AS_JOIN
+  AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 

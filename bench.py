@@ -313,19 +313,24 @@ def main():
                 rec = recorded_traffic("lambda_kernel", n, d)
                 if rec:
                     extra["roofline_scan"]["traffic_recorded"] = rec
-        ss_ms, ss_n = prof.get("search_scan_bf16", (0.0, 0))
+        ss_kernel = ("pair_join_f16_kernel<KS, 1> (threshold scan of the search: one-f16-plane products, coarse test on the cosine, "
+                     "lambda term against per-query score guesses in the listing)")
+        ss_ms, ss_n = prof.get("search_scan_f16", (0.0, 0))
+        if not ss_n:
+            ss_ms, ss_n = prof.get("search_scan_bf16", (0.0, 0))
+            ss_kernel = ("pair_join_bf16_kernel<KS, 2> (threshold scan of the search: split-bf16 products + lambda term against "
+                         "per-query score guesses)")
         if ss_n:
             # the threshold scan of the search (stage 0 of K9) at the benchmark batch: one launch per step over all nq queries
             # (+ a short second launch for the queries whose guess was too high)
             fl = 2.0 * nq * rows_here * d
             tf = fl * steps / (ss_ms * 1e-3) / 1e12
-            extra["roofline_search"] = {"bound": "mfma", "kernel": "pair_join_bf16_kernel<KS, 2> (threshold scan of the search: split-bf16 "
-                                                                    "products + lambda term against per-query score guesses)",
+            extra["roofline_search"] = {"bound": "mfma", "kernel": ss_kernel,
                                         "achieved": tf, "peak": MFMA16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA16_PEAK_TFLOPS,
                                         "traffic": None, "avg_step_ms": ss_ms / steps, "algorithmic_flops_per_step": fl}
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
-            "candidate_precision": ("f16-plane MFMA symmetric threshold join (f32 MFMA beyond dim 128) -> split-bf16 second pass -> f32 top-k "
+            "candidate_precision": ("f16-plane MFMA symmetric threshold join (panelled f16 form beyond dim 128) -> split-bf16 second pass -> f32 top-k "
                                     "-> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)")
             if args.cand_precision == 32 else "f64 MFMA -> exact f64 scan",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,
