@@ -226,6 +226,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "stream_scan") ctx->opt_stream_scan = value;
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
+  else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
   else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;

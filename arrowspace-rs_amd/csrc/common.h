@@ -67,6 +67,7 @@ struct as_ctx {
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_stream_scan = 1;    // small batches / leftover rows: one exact pass over the matrix (stream_scan.hip)
   int64_t opt_search_scan_f16 = 1; // threshold scan of the search (items up to 128 wide) on one f16 plane; 0: split bf16
+  int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
   int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production

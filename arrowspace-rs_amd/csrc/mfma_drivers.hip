@@ -1224,20 +1224,26 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   // rows wider than 128 after the f16 join: the same pass on the f16 plane (one-sided form of mfma_join_f16_wide.hip);
   // the looser thresholds carry it, the bound stays the f16 one
   const bool second_wide = join_on_f16(ctx, d) && d > 128 && js && js->packedh;
+  // up to 128 wide after the f16 join: the pass on the f16 plane as well -- the search mode of pair_join_f16_kernel with
+  // alpha = 1, beta = 0 and zero lambdas is exactly a one-sided threshold pass (a row lists itself; the re-rank drops it) --
+  // which saves building the split-bf16 image of all rows for half a percent of them (opt second_pass_f16 = 0: as before)
+  // (where the streaming exact scan takes what is left: the f16 bound leaves a few more rows open than the split form)
+  const bool second_h = join_on_f16(ctx, d) && d == 128 && js && js->packedh && ctx->opt_second_pass_f16 && ctx->opt_stream_scan &&
+                        stream_scan_applies(1, n, d, K);
   if (use_join && js->theta2 && (second_pass_bf16(ctx, d) || second_wide) && cur_n > 0 && cur_n <= n / 4) {
     const uint32_t nf = cur_n, cap2 = 1024;
-    const void *split_image = second_wide ? js->packedh : js->packed16;
+    const void *split_image = (second_wide || second_h) ? js->packedh : js->packed16;
     if (!split_image) {  // the join ran on the f16 plane: the split-bf16 image of all rows is only built when rows are left
       AS_TRY(P16late.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16late.p, b_alloc));
       split_image = P16late.p;
     }
-    const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (bt + 1) & ~1u, pad = b_al * kTileRows;
+    const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = second_h ? (bt + 3) & ~3u : (bt + 1) & ~1u, pad = b_al * kTileRows;
     DevBuf<unsigned char> PA;
-    DevBuf<float> theta_a;
+    DevBuf<float> theta_a, zeros;
     DevBuf<uint32_t> cnt_b, cand_b, unitc, oi, failx;
     DevBuf<double> ok;
-    AS_TRY(PA.alloc(ctx, (second_wide ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
+    AS_TRY(PA.alloc(ctx, ((second_wide || second_h) ? packed_vecs_f16(b_al, d) : packed_vecs_bf16(b_al, d)) * 16));
     AS_TRY(theta_a.alloc(ctx, pad));
     AS_TRY(cnt_b.alloc(ctx, pad));
     AS_TRY(cand_b.alloc(ctx, (size_t)pad * cap2 * 2));
@@ -1245,19 +1251,25 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(ok.alloc(ctx, (size_t)nf * K));
     AS_TRY(oi.alloc(ctx, (size_t)nf * K));
     AS_TRY(failx.alloc(ctx, nf));
-    if (second_wide) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
+    if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
                        js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p);
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
-    if (second_wide)
+    if (second_h) {
+      const size_t zn = std::max<size_t>(((size_t)n + 511) / 512 * 512, pad);
+      AS_TRY(zeros.alloc(ctx, zn));
+      AS_HIP(ctx, hipMemsetAsync(zeros.p, 0, sizeof(float) * zn, ctx->stream));
+      AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
+                             unitc.p, "knn_mfma_join_f16_second"));
+    } else if (second_wide)
       AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second"));
     else
       AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
                             "knn_mfma_join_bf16_second"));
-    const double delta2 = second_wide ? join_delta(ctx, d) : rect_delta(d);
+    const double delta2 = (second_wide || second_h) ? join_delta(ctx, d) : rect_delta(d);
     {
       GraphBound bnd{delta2, rectify};
       ProfScope ps(ctx, "knn_rerank");
