@@ -200,7 +200,12 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
   shard_range(n_total, R, W, &lo, &hi);
   const uint64_t rows_here = hi - lo, K = params->topk + 1, n = n_total;
   if (rows_here && !rows_shard) return fail(ctx, AS_ERR_ARG, "null argument");
-  if (rows_here && !is_device_ptr(rows_shard)) return fail(ctx, AS_ERR_ARG, "rows_shard must be a device pointer");
+  DevBuf<double> staged;  // a host shard is staged once; the exchange works on device buffers
+  if (rows_here && !is_device_ptr(rows_shard)) {
+    AS_TRY(staged.alloc(ctx, (size_t)rows_here * dim));
+    AS_HIP(ctx, copy_h2d(ctx, staged.p, rows_shard, sizeof(double) * rows_here * dim));
+    rows_shard = staged.p;
+  }
 
   // ---- all rows on every rank (B side of the neighbour search, candidates' rows for the exact re-rank) ----
   DevBuf<double> X;

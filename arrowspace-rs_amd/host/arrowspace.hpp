@@ -17,6 +17,8 @@
 // std::vector<double> rows.  No CPU fallback exists.
 #pragma once
 
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -123,7 +125,9 @@ class CsMat {
                              data.data(), &h));
     return std::make_shared<CsMat>(ctx, h);
   }
-  std::pair<std::size_t, std::size_t> shape() const { return {as_csr_n(h_), as_csr_n(h_)}; }
+  // (rows, columns): square unless the handle is a row block of a sharded graph
+  std::pair<std::size_t, std::size_t> shape() const { return {as_csr_n(h_), as_csr_cols(h_)}; }
+  std::size_t row_begin() const { return as_csr_row_begin(h_); }
   std::size_t rows() const { return as_csr_n(h_); }
   std::size_t nnz() const { return as_csr_nnz(h_); }
   as_csr *handle() const { return h_; }
@@ -223,6 +227,84 @@ struct GraphFactory {
 };
 
 // ---- ArrowItem (src/core.rs:84-239) -----------------------------------------------------------
+// ---- clustering pre-stage (src/clustering.rs) and JL projection (src/reduction.rs) --------------
+constexpr uint64_t kClusteringSeed = 128;  // src/clustering.rs:30
+
+struct OptimalK {
+  std::size_t k = 0, intrinsic_dim = 0;
+  double radius = 0.0;  // squared-distance threshold of the incremental clustering
+};
+// ClusteringHeuristic::compute_optimal_k, src/clustering.rs:36-72 (seeded: DESIGN.md section 2 on what is statistical)
+inline OptimalK compute_optimal_k(const std::vector<double> &flat, std::size_t n, std::size_t f, uint64_t seed = kClusteringSeed,
+                                  std::shared_ptr<Context> ctx = Context::shared()) {
+  uint64_t k = 0, idd = 0;
+  OptimalK out;
+  ctx->check(as_compute_optimal_k(ctx->get(), flat.data(), n, f, seed, &k, &out.radius, &idd));
+  out.k = k;
+  out.intrinsic_dim = idd;
+  return out;
+}
+struct Clustering {
+  std::vector<std::vector<double>> centroids;  // X x F
+  std::vector<int64_t> assignments;            // -1: dropped as an outlier
+  std::vector<uint64_t> sizes;
+};
+// run_incremental_clustering_with_sampling without a sampler, src/clustering.rs:547-910; batch = 1 is its sequential mode
+inline Clustering incremental_clustering(const std::vector<double> &flat, std::size_t n, std::size_t f, std::size_t max_clusters,
+                                         double radius, std::size_t batch = 4096,
+                                         std::shared_ptr<Context> ctx = Context::shared()) {
+  std::vector<double> cents(max_clusters * f, 0.0);
+  std::vector<uint64_t> counts(max_clusters, 0);
+  Clustering out;
+  out.assignments.resize(n);
+  uint64_t nc = 0;
+  ctx->check(as_incremental_clustering(ctx->get(), flat.data(), n, f, max_clusters, radius, batch, cents.data(), &nc,
+                                       out.assignments.data(), counts.data()));
+  for (uint64_t c = 0; c < nc; ++c) out.centroids.emplace_back(cents.begin() + c * f, cents.begin() + (c + 1) * f);
+  out.sizes.assign(counts.begin(), counts.begin() + nc);
+  return out;
+}
+inline std::size_t compute_jl_dimension(std::size_t n_points, double epsilon) {  // src/reduction.rs:126-140
+  return as_jl_dimension(n_points, epsilon);
+}
+// ImplicitProjection, src/reduction.rs:166-203: a seeded Gaussian projection held in HBM
+class ImplicitProjection {
+ public:
+  std::size_t original_dim, reduced_dim;
+  ImplicitProjection(std::size_t original, std::size_t reduced, uint64_t seed, std::shared_ptr<Context> ctx = Context::shared())
+      : original_dim(original), reduced_dim(reduced), ctx_(std::move(ctx)) {
+    ctx_->check(as_jl_create(ctx_->get(), original, reduced, seed, &h_));
+  }
+  ~ImplicitProjection() { as_jl_destroy(h_); }
+  ImplicitProjection(const ImplicitProjection &) = delete;
+  ImplicitProjection &operator=(const ImplicitProjection &) = delete;
+  std::vector<double> project(const std::vector<double> &row) const {  // :180-203
+    if (row.size() != original_dim) throw Panic(AS_ERR_DIM, "projection: dimension mismatch");
+    std::vector<double> out(reduced_dim);
+    ctx_->check(as_jl_project(ctx_->get(), h_, row.data(), 1, out.data()));
+    return out;
+  }
+  std::vector<std::vector<double>> project_matrix(const std::vector<std::vector<double>> &rows) const {  // :142-164
+    std::size_t n = 0, d = 0;
+    std::vector<double> flat;
+    for (const auto &r : rows) {
+      if (r.size() != original_dim) throw Panic(AS_ERR_DIM, "projection: dimension mismatch");
+      flat.insert(flat.end(), r.begin(), r.end());
+      ++n;
+    }
+    (void)d;
+    std::vector<double> out(n * reduced_dim);
+    if (n) ctx_->check(as_jl_project(ctx_->get(), h_, flat.data(), n, out.data()));
+    std::vector<std::vector<double>> res;
+    for (std::size_t i = 0; i < n; ++i) res.emplace_back(out.begin() + i * reduced_dim, out.begin() + (i + 1) * reduced_dim);
+    return res;
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  as_jl *h_ = nullptr;
+};
+
 struct ArrowItem {
   std::vector<double> item;
   double lambda = 0.0;
@@ -251,7 +333,19 @@ class ArrowSpace {
   // F x F spectral Laplacian (src/core.rs:372), set by GraphFactory::build_spectral_laplacian; when present it is
   // the graph of compute_taumode (src/taumode.rs:195-200) while queries keep gl.matrix (src/core.rs:548)
   std::shared_ptr<CsMat> signals;
+  // clustering metadata and projection state (src/core.rs:373-384), set by the builder
+  std::size_t n_clusters = 0;
+  std::vector<int64_t> cluster_assignments;
+  std::vector<uint64_t> cluster_sizes;
+  double cluster_radius = 0.0;
+  std::shared_ptr<ImplicitProjection> projection_matrix;
+  std::size_t reduced_dim = 0;
   std::shared_ptr<Context> context() const { return ctx_; }
+  const std::vector<double> &flat() const { return data_; }
+  // src/core.rs:509-529
+  std::vector<double> project_query(const std::vector<double> &query) const {
+    return projection_matrix ? projection_matrix->project(query) : query;
+  }
   ArrowItem get_item(std::size_t i) const {  // src/core.rs:586-594
     if (i >= nitems) throw Panic(AS_ERR_ARG, "item index out of bounds");
     return ArrowItem(std::vector<double>(data_.begin() + i * nfeatures, data_.begin() + (i + 1) * nfeatures),
@@ -276,6 +370,13 @@ class ArrowSpace {
       throw Panic(AS_ERR_DIM, "Query dimension " + std::to_string(item.size()) +
                                   " doesn't match index original dimension " + std::to_string(nfeatures));
     double out = 0.0;
+    if (projection_matrix) {  // src/core.rs:541-546: the query is projected first
+      for (double v : item)
+        if (!std::isfinite(v)) throw Panic(AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
+      const std::vector<double> q = projection_matrix->project(item);
+      ctx_->check(as_prepare_query_items(ctx_->get(), q.data(), 1, q.size(), gl.matrix->handle(), taumode.kind, taumode.arg, &out));
+      return out;
+    }
     ctx_->check(as_prepare_query_items(ctx_->get(), item.data(), 1, nfeatures, gl.matrix->handle(), taumode.kind,
                                        taumode.arg, &out));
     return out;
@@ -366,6 +467,13 @@ class ArrowSpaceBuilder {
   std::optional<double> lambda_sigma;
   bool normalise = false, sparsity_check = false, prebuilt_spectral = false;
   TauMode synthesis = TauMode::Median();
+  // clustering / projection (src/builder.rs:38-57)
+  bool use_dims_reduction = false, deterministic_clustering = false;
+  double rp_eps = 0.3;
+  uint64_t clustering_seed = kClusteringSeed;
+  std::size_t clustering_batch = 4096;
+  std::size_t cluster_max_clusters = 0;
+  double cluster_radius = 0.0;
 
   static ArrowSpaceBuilder new_() { return ArrowSpaceBuilder(); }
   // src/builder.rs:109-137
@@ -382,23 +490,100 @@ class ArrowSpaceBuilder {
   ArrowSpaceBuilder &with_normalisation(bool n) { return normalise = n, *this; }
   ArrowSpaceBuilder &with_sparsity_check(bool f) { return sparsity_check = f, *this; }
   ArrowSpaceBuilder &with_spectral(bool f) { return prebuilt_spectral = f, *this; }  // src/builder.rs:157-162
+  // src/builder.rs:164-187: a seed makes the clustering sequential (deterministic); dims reduction = JL projection
+  ArrowSpaceBuilder &with_seed(uint64_t seed) { return clustering_seed = seed, deterministic_clustering = true, *this; }
+  ArrowSpaceBuilder &with_dims_reduction(bool enable, std::optional<double> eps = std::nullopt) {
+    use_dims_reduction = enable;
+    if (eps) rp_eps = *eps;
+    return *this;
+  }
+  // EigenMaps::start_clustering, src/eigenmaps.rs:175-290: optimal K + radius, incremental clustering, optional projection
+  std::vector<std::vector<double>> start_clustering(ArrowSpace &aspace) {
+    auto ctx = aspace.context();
+    const OptimalK ok = compute_optimal_k(aspace.flat(), aspace.nitems, aspace.nfeatures, clustering_seed, ctx);
+    cluster_max_clusters = ok.k;
+    cluster_radius = ok.radius;
+    Clustering cl = incremental_clustering(aspace.flat(), aspace.nitems, aspace.nfeatures, ok.k, ok.radius,
+                                           deterministic_clustering ? 1 : clustering_batch, ctx);
+    aspace.n_clusters = cl.centroids.size();
+    aspace.cluster_assignments = std::move(cl.assignments);
+    aspace.cluster_sizes = std::move(cl.sizes);
+    aspace.cluster_radius = ok.radius;
+    return maybe_project(aspace, std::move(cl.centroids));
+  }
+  std::vector<std::vector<double>> maybe_project(ArrowSpace &aspace, std::vector<std::vector<double>> cents) {
+    const std::size_t nf = aspace.nfeatures;
+    if (use_dims_reduction && nf > 64) {  // src/eigenmaps.rs:247-280
+      const std::size_t target = std::min<std::size_t>(compute_jl_dimension(cents.size(), rp_eps), nf / 2);
+      if (target < nf) {
+        aspace.projection_matrix = std::make_shared<ImplicitProjection>(nf, target, clustering_seed ? clustering_seed : kClusteringSeed,
+                                                                        aspace.context());
+        aspace.reduced_dim = target;
+        return aspace.projection_matrix->project_matrix(cents);
+      }
+    }
+    return cents;
+  }
   // src/builder.rs:225-233
   void define_result_k() { lambda_topk = as_define_result_k(lambda_k, lambda_topk); }
 
-  // src/builder.rs:249-455 with the clustering stage replaced by supplied centroids (X x F);
-  // an empty `centroids` means every item is its own centroid.
+  // src/builder.rs:249-455.  Stage 1: clustering (skipped when the centroids, X x F, are supplied) + optional JL
+  // projection; stage 2: eigenmaps (Laplacian over centroids^T); stage 3 (optional): spectral; stage 4: taumode.
   std::pair<std::unique_ptr<ArrowSpace>, GraphLaplacian> build(const std::vector<std::vector<double>> &rows,
                                                                const std::vector<std::vector<double>> &centroids = {},
                                                                std::shared_ptr<Context> ctx = Context::shared()) {
     define_result_k();
     auto aspace = std::make_unique<ArrowSpace>(rows, synthesis, ctx);
+    const std::vector<std::vector<double>> cents = centroids.empty() ? start_clustering(*aspace) : maybe_project(*aspace, centroids);
     GraphLaplacian gl = GraphFactory::build_laplacian_matrix_from_k_cluster(
-        centroids.empty() ? rows : centroids, lambda_eps, lambda_k, lambda_topk, lambda_p, lambda_sigma, normalise,
+        cents, lambda_eps, lambda_k, lambda_topk, lambda_p, lambda_sigma, normalise,
         sparsity_check, aspace->nitems, ctx);
     if (prebuilt_spectral) build_spectral_laplacian(*aspace, gl);  // stage 3, src/eigenmaps.rs:325-345
     aspace->compute_taumode(gl);
     return {std::move(aspace), std::move(gl)};
   }
+};
+
+// ---- row-sharded build, one process per GPU (include/arrowspace_hip.h: as_comm_*) --------------
+// The exchange sequence runs inside the library; this only owns the handle.  rows_shard: this rank's rows (host or HBM).
+class Comm {
+ public:
+  static std::array<unsigned char, 128> unique_id() {
+    std::array<unsigned char, 128> id{};
+    const int rc = as_comm_unique_id(id.data());
+    if (rc) throw Panic(rc, as_status_message(rc));
+    return id;
+  }
+  Comm(const std::array<unsigned char, 128> &id, int rank, int world, std::shared_ptr<Context> ctx = Context::shared())
+      : ctx_(std::move(ctx)) {
+    ctx_->check(as_comm_create_rccl(ctx_->get(), id.data(), rank, world, &h_));
+  }
+  Comm(const as_comm_ops &ops, int rank, int world, std::shared_ptr<Context> ctx = Context::shared()) : ctx_(std::move(ctx)) {
+    ctx_->check(as_comm_create_custom(ctx_->get(), &ops, rank, world, &h_));
+  }
+  ~Comm() { as_comm_destroy(h_); }
+  Comm(const Comm &) = delete;
+  Comm &operator=(const Comm &) = delete;
+  int rank() const { return as_comm_rank(h_); }
+  int world() const { return as_comm_world(h_); }
+  std::pair<uint64_t, uint64_t> shard_range(uint64_t n) const {
+    uint64_t lo = 0, hi = 0;
+    as_shard_range(n, rank(), world(), &lo, &hi);
+    return {lo, hi};
+  }
+  // this rank's row block of the item-graph Laplacian (nullptr when it owns no rows) and nnz of the whole matrix
+  std::pair<std::shared_ptr<CsMat>, uint64_t> build_laplacian(const double *rows_shard, uint64_t n_total, uint64_t dim,
+                                                             const GraphParams &gp) {
+    const as_graph_params c = gp.to_c();
+    as_csr *block = nullptr;
+    uint64_t nnz = 0;
+    ctx_->check(as_build_laplacian_sharded(ctx_->get(), h_, rows_shard, n_total, dim, &c, &block, &nnz));
+    return {block ? std::make_shared<CsMat>(ctx_, block) : nullptr, nnz};
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  as_comm *h_ = nullptr;
 };
 
 }  // namespace arrowspace

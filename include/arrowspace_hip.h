@@ -264,7 +264,7 @@ void as_csr_free(as_csr *m);
  *     completed, or be ordered on `stream`, when it returns.
  * as_shard_range: the rows of a rank, contiguous, shard starts multiples of 512 (the row super tile of the join); ranks
  * past the end own no rows and still take part in every step.
- * as_build_laplacian_sharded: rows_shard = this rank's rows (device pointer, (hi - lo) x dim); *out_block = its ROW
+ * as_build_laplacian_sharded: rows_shard = this rank's rows ((hi - lo) x dim; host or device, a host shard is staged once); *out_block = its ROW
  * BLOCK of the Laplacian (see as_laplacian_from_knn_rows; NULL when the rank owns no rows), *nnz_total = nnz of the
  * whole matrix.  Stacking the blocks of ranks 0 .. world - 1 gives exactly the CSR of as_build_laplacian on all rows.
  * Every rank must make the call; a rank that fails locally returns early and leaves its peers waiting. */

@@ -201,6 +201,71 @@ static void test_sparsity_check() {  // src/graph.rs:185-193
       "too sparse"));
 }
 
+
+// blobs around a few directions: what the clustering stage is for
+static Rows blobs(std::size_t n, std::size_t f, std::size_t k) {
+  Rows rows(n, std::vector<double>(f));
+  for (std::size_t i = 0; i < n; ++i)
+    for (std::size_t c = 0; c < f; ++c)
+      rows[i][c] = 3.0 * std::sin(double((i % k) * 37 + c * 11)) + 0.2 * std::sin(double(i * 131 + c * 71)) * std::cos(double(i + 3 * c));
+  return rows;
+}
+
+static void test_build_without_centroids() {  // src/builder.rs:249-455 with stage 1 = EigenMaps::start_clustering (src/eigenmaps.rs:175-290)
+  const Rows rows = blobs(600, 24, 5);
+  ArrowSpaceBuilder b;
+  auto [asp, gl] = b.with_lambda_graph(0.9, 6, 4, 2.0, 0.25).with_seed(7).build(rows);
+  CHECK(asp->n_clusters >= 2 && asp->n_clusters <= b.cluster_max_clusters);
+  CHECK(asp->cluster_assignments.size() == 600 && asp->cluster_sizes.size() == asp->n_clusters);
+  CHECK(gl.matrix->rows() == 24 && gl.nnodes == 600);  // the graph is over the features
+  CHECK(asp->lambdas().size() == 600);
+  bool finite = true;
+  for (double l : asp->lambdas()) finite = finite && std::isfinite(l) && l >= 0.0;
+  CHECK(finite);
+  // the same seed gives the same clustering (sequential mode), and the stage-level calls agree with the builder
+  ArrowSpaceBuilder b2;
+  auto [asp2, gl2] = b2.with_lambda_graph(0.9, 6, 4, 2.0, 0.25).with_seed(7).build(rows);
+  CHECK(asp2->cluster_assignments == asp->cluster_assignments && asp2->lambdas() == asp->lambdas());
+  const OptimalK ok = compute_optimal_k(asp->flat(), 600, 24, 7);
+  CHECK(ok.k == b.cluster_max_clusters && ok.radius == b.cluster_radius && ok.intrinsic_dim >= 1);
+}
+
+static void test_jl_projection() {  // src/reduction.rs:126-203, src/core.rs:509-549
+  CHECK(compute_jl_dimension(100, 0.3) == (std::size_t)std::ceil(8.0 * std::log(100.0) / 0.09));
+  const Rows rows = blobs(300, 96, 4);
+  ArrowSpaceBuilder b;
+  auto [asp, gl] = b.with_lambda_graph(0.9, 6, 4, 2.0, 0.25).with_seed(3).with_dims_reduction(true, 0.9).build(rows);
+  const std::size_t target = std::min<std::size_t>(compute_jl_dimension(asp->n_clusters, 0.9), 48);  // src/eigenmaps.rs:247-280
+  CHECK(asp->projection_matrix && asp->reduced_dim == target && asp->projection_matrix->reduced_dim == target && target < 96);
+  CHECK(gl.matrix->rows() == target);  // the feature graph lives in the reduced space
+  const std::vector<double> q = rows[17];
+  const std::vector<double> pq = asp->project_query(q);
+  CHECK(pq.size() == target);
+  // distances survive the projection to within the JL tolerance (statistical: src/tests/test_reduction.rs)
+  const std::vector<double> pr = asp->project_query(rows[18]);
+  double d0 = 0.0, d1 = 0.0;
+  for (std::size_t c = 0; c < 96; ++c) d0 += (q[c] - rows[18][c]) * (q[c] - rows[18][c]);
+  for (std::size_t c = 0; c < target; ++c) d1 += (pq[c] - pr[c]) * (pq[c] - pr[c]);
+  CHECK(d1 > 0.2 * d0 && d1 < 5.0 * d0);
+  CHECK(std::isfinite(asp->prepare_query_item(q, gl)));
+  CHECK(panics_with([&] { asp->prepare_query_item(std::vector<double>(96, std::nan("")), gl); }, "NaN"));
+}
+
+static void test_sharded_build_one_rank() {  // the library's exchange sequence over RCCL with one rank (csrc/sharded.hip)
+  const Rows rows = blobs(1200, 32, 6);
+  std::size_t n = 0, d = 0;
+  const std::vector<double> flat = flatten(rows, n, d);
+  const GraphParams gp{0.6, 8, 8, 2.0, 0.25, false, false};
+  GraphLaplacian whole = build_laplacian_matrix(rows, gp);
+  Comm comm(Comm::unique_id(), 0, 1);
+  const auto range = comm.shard_range(n);
+  CHECK(comm.rank() == 0 && comm.world() == 1 && range.first == 0 && range.second == n);
+  auto [block, nnz] = comm.build_laplacian(flat.data(), n, d, gp);
+  CHECK(block && nnz == whole.matrix->nnz() && block->shape().first == 1200 && block->shape().second == 1200);
+  CHECK(block->row_begin() == 0 && block->indptr() == whole.matrix->indptr() && block->indices() == whole.matrix->indices());
+  CHECK(block->data() == whole.matrix->data());
+}
+
 int main() {
   try {
     test_select_tau();
@@ -212,6 +277,9 @@ int main() {
     test_build_and_search();
     test_sparsity_check();
     test_spectral_laplacian();
+    test_build_without_centroids();
+    test_jl_projection();
+    test_sharded_build_one_rank();
   } catch (const std::exception &e) {
     std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
     return 2;
