@@ -227,6 +227,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
+  else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
   else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;

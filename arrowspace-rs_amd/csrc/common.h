@@ -67,6 +67,7 @@ struct as_ctx {
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_stream_scan = 1;    // small batches / leftover rows: one exact pass over the matrix (stream_scan.hip)
   int64_t opt_search_scan_f16 = 1; // threshold scan of the search (items up to 128 wide) on one f16 plane; 0: split bf16
+  int64_t opt_join_row_order = 1;  // own join, dim <= 128: operand image packed with the rows grouped by direction (row_order.hip)
   int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
   int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
@@ -383,7 +384,8 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // packed16 / packedh = split-bf16 / f16 image of ALL rows when the caller already has the one its pipe needs, else nullptr
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr);
+                   const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr,
+                   const uint32_t *perm = nullptr);  // perm: image position -> row when packedh is packed in a permuted order
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

@@ -302,17 +302,23 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
 __global__ void second_theta_kernel(const float *__restrict__ theta, const float *__restrict__ theta2,
                                     const uint32_t *__restrict__ cnt, uint32_t n_src, uint32_t row_begin, uint32_t row_count,
                                     uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded,
-                                    float *__restrict__ out) {
+                                    float *__restrict__ out, const uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
   if (i < count) {
     const uint32_t g = ids[i], r = g - row_begin;
+    const uint32_t lr = inv ? inv[g] : r;  // lists kept by image position (row_order.hip)
     bool over = false;
-    for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + r] > cap;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + lr] > cap;
     t = over ? theta[g] : theta2[r];
   }
   out[i] = t;
+}
+
+__global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = i;
 }
 
 __global__ void pad_theta_kernel(const float *__restrict__ theta, uint32_t n, uint32_t n_pad, float *__restrict__ out) {
@@ -658,12 +664,15 @@ uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
 int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
               uint32_t d, void *P, uint32_t tiles);
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr);
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm);
+int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
-int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles);
+int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
+                 const uint32_t *perm = nullptr);
 int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
                   uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
 int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
@@ -673,7 +682,7 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
                              float *theta2_out);
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name);
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr);
 int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
                                const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam, float alpha,
                                float beta, float *score_out, uint32_t m2, float *score2_out);
@@ -786,7 +795,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed, const void *packed16, const void *packedh) {
+                   const float *packed, const void *packed16, const void *packedh, const uint32_t *perm) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
@@ -822,7 +831,7 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   if (f16) {
-    if (d <= 128) AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16"));
+    if (d <= 128) AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm));
     else AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16"));
     ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_f16_blocks"];
     ctx->stats["knn_join_pipe"] = 16;
@@ -960,7 +969,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   // own join on the bf16 pipe: the split image and the second (looser) thresholds stay for the second pass over
   // the rows the first one leaves uncertified (rect_stage below)
   DevBuf<unsigned char> P16own, Phown;
-  DevBuf<float> theta_own, theta2_own;
+  DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos;
+  DevBuf<uint32_t> perm_own, inv_own;
+  const uint32_t *perm_used = nullptr;  // image position -> row of the own join's f16 image
+  bool lists_by_pos = false;            // ... and whether the lists of the own join are indexed by (and hold) positions
   DevBuf<uint32_t> cnt_own, cand_own;
   bool have_theta2 = false;
   if (use_join) {
@@ -969,19 +981,44 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t cap = knn_join_cap(ctx, K, false);
       AS_TRY(theta_own.alloc(ctx, n));
       AS_TRY(theta2_own.alloc(ctx, n));
+      // rows grouped by direction in the operand image (row_order.hip): the thresholds come out by image position
+      const bool reorder = join_on_f16(ctx, d) && d <= 128 && ctx->opt_join_row_order && n >= 65536 && ctx->opt_join_bf16 &&
+                           !(ctx->opt_debug & 32);  // (the f16 threshold pass is what reads the image)
+      if (reorder) {
+        AS_TRY(perm_own.alloc(ctx, n));
+        AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
+        AS_TRY(theta_pos.alloc(ctx, n));
+        AS_TRY(theta2_pos.alloc(ctx, n));
+      }
+      ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
       if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
         const uint32_t tiles = packed_tiles_f16(n);
         AS_TRY(Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
-        AS_TRY(pack_f16_all(ctx, rows, norms, n, d, Phown.p, tiles));
+        AS_TRY(pack_f16_all(ctx, rows, norms, n, d, Phown.p, tiles, reorder ? perm_own.p : nullptr));
       }
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_own.p, nullptr, theta2_own.p, &have_theta2, Phown.p));
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, nullptr,
+                                 reorder ? theta2_pos.p : theta2_own.p, &have_theta2, Phown.p));
+      if (reorder) {  // ... and go back to row order for everything behind the join
+        AS_TRY(scatter_by_perm(ctx, theta_pos.p, perm_own.p, n, theta_own.p));
+        if (have_theta2) AS_TRY(scatter_by_perm(ctx, theta2_pos.p, perm_own.p, n, theta2_own.p));
+      }
       if (join_on_bf16(ctx, d)) {
         AS_TRY(P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
         AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
       }
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
-      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, theta_own.p, cap, cnt_own.p, cand_own.p, nullptr, P16own.p, Phown.p));
+      // 128 columns: the lists stay in image positions and the pruning kernel of the re-rank translates the ~30 survivors of
+      // a row (rerank_split.h); other widths: the join kernel translates every entry where it appends it
+      lists_by_pos = reorder && d == 128 && ctx->opt_rerank_split && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
+                     ctx->opt_debug != 5;
+      if (lists_by_pos) {
+        AS_TRY(inv_own.alloc(ctx, n));
+        hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, perm_own.p, n, inv_own.p);
+      }
+      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p, nullptr,
+                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr));
+      perm_used = reorder ? perm_own.p : nullptr;
       if (ctx->opt_debug & 0xFF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
       js = &local;
@@ -1009,7 +1046,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
         hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
                            ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                           force.p, prune_delta, rectify, records.p, slots);
+                           force.p, prune_delta, rectify, records.p, slots, lists_by_pos ? perm_own.p : nullptr,
+                           lists_by_pos ? inv_own.p : nullptr);
         AS_HIP(ctx, hipGetLastError());
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
@@ -1023,6 +1061,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
           default: return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: row width not covered");
         }
 #undef AS_SCORE
+      } else if (lists_by_pos) {
+        return fail(ctx, AS_ERR_HIP, "internal: lists by image position need the two-kernel re-rank");
       } else if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {
 #define AS_RR(R, NB)                                                                                                       \
   AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>,               \
@@ -1254,7 +1294,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
-                       js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p);
+                       js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_by_pos ? inv_own.p : nullptr);
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
@@ -1263,7 +1303,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(zeros.alloc(ctx, zn));
       AS_HIP(ctx, hipMemsetAsync(zeros.p, 0, sizeof(float) * zn, ctx->stream));
       AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
-                             unitc.p, "knn_mfma_join_f16_second"));
+                             unitc.p, "knn_mfma_join_f16_second", perm_used));
     } else if (second_wide)
       AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second"));
     else

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
                                                                const float *__restrict__ theta, uint32_t cap,
                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
                                                                uint32_t *__restrict__ unit_counter, int dbg,
-                                                               unsigned long long *__restrict__ stamps, F16SearchTerm st) {
+                                                               unsigned long long *__restrict__ stamps, F16SearchTerm st,
+                                                               const uint32_t *__restrict__ perm) {
   constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
   constexpr int kBlocks = 8;                 // 32-column blocks per stage
@@ -176,8 +177,11 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     for (uint32_t base = 0; base < qn; base += 64) {
       const uint32_t e = base + lane;
       if (e < qn) {
+        // positions in the image -> row ids where the image is packed in a permuted order (row_order.hip); a list of the
+        // search mode is owned by a query position, which stays
         const uint2 v = queue[e];
-        append16(cnt, cand, cap, v.x, v.y, queue_s[e]);
+        const uint32_t owner = (perm && MODE == 0) ? perm[v.x] : v.x, other = perm ? perm[v.y] : v.y;
+        append16(cnt, cand, cap, owner, other, queue_s[e]);
       }
     }
     wave_sync();
@@ -496,8 +500,10 @@ __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__rest
 }
 
 // packs ALL n rows and leaves the measured plane error in ctx->f16_err (what join_delta certifies against)
-int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles) {
-  AS_TRY(pack_f16(ctx, R, norms, nullptr, 0, n, d, P, tiles));
+// (perm: image position -> row, or nullptr)
+int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
+                 const uint32_t *perm) {
+  AS_TRY(pack_f16(ctx, R, norms, perm, 0, n, d, P, tiles));
   DevBuf<unsigned int> bits;
   AS_TRY(bits.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
@@ -523,7 +529,7 @@ static size_t f16_join_lds(uint32_t KS, bool search) {
 // (all n rows).  theta: T2 * 512 thresholds (+inf on padding).  cnt / cand (n x cap) are indexed by global row; cnt must be
 // zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
@@ -543,7 +549,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
                                     (int)lds));                                                                           \
     hipLaunchKernelGGL((pair_join_f16_kernel<K, 0>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
                        (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,           \
-                       (int)ctx->opt_debug, stamps.p, F16SearchTerm{});                                                   \
+                       (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm);                                             \
     break;
     switch (KS) {
       AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
@@ -574,7 +580,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 // padded to whole 512-row super tiles with +inf).  PQ: f16 image of the queries (whole 512-row super tiles).
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name) {
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH, a_supers = (nq + kSuperH - 1) / kSuperH;
@@ -594,7 +600,7 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
                                     (int)lds));                                                                           \
     hipLaunchKernelGGL((pair_join_f16_kernel<K, 1>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
                        (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,                \
-                       (int)(ctx->opt_debug & ~8), stamps.p, st);                                                         \
+                       (int)(ctx->opt_debug & ~8), stamps.p, st, perm);                                                   \
     break;
   switch (KS) {
     AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)

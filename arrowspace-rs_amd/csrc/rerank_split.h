@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            const uint32_t *__restrict__ cnt_src, const uint32_t *__restrict__ cand_src,
                                                            uint32_t cap, uint32_t cmax, uint32_t K,
                                                            const uint8_t *__restrict__ force_exact, double prune_delta, int prune_rectify,
-                                                           uint32_t *__restrict__ records, int slots) {
+                                                           uint32_t *__restrict__ records, int slots,
+                                                           const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
@@ -42,17 +43,20 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     const uint32_t a = row_begin + r;
+    // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
+    // holds positions; what leaves this kernel is row ids again
+    const uint32_t lr = inv ? inv[a] : r;
     uint32_t C = 0;
     bool overflow = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
-      const uint32_t total = cnt_src[(size_t)sidx * row_count + r];
+      const uint32_t total = cnt_src[(size_t)sidx * row_count + lr];
       uint32_t take = min(total, cap);
       overflow = overflow || total > cap;
       if (C + take > cmax) {
         overflow = true;
         take = cmax - C;
       }
-      const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + r) * cap;
+      const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + lr) * cap;
       for (uint32_t c = lane; c < take; c += 64) {
         const uint2 e = src[c];
         ei[C + c] = e.x;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     }
     uint32_t *rec = records + (size_t)r * kRsWords;
     for (uint32_t c = lane; c < C; c += 64) {
-      const uint32_t j = ei[c];
+      const uint32_t j = perm ? perm[ei[c]] : ei[c];
       rec[kRsIdsAt + c] = j;
       reinterpret_cast<double *>(rec + kRsNormsAt)[c] = norms[j];
     }

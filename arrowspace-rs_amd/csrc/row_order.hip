@@ -1,0 +1,146 @@
+// row_order.hip -- an order of the rows in which neighbours sit together, for the OPERAND IMAGE of the symmetric join only.
+//
+// The join (mfma_join_f16.hip) contracts every pair of row tiles whatever the order of the rows, but what happens AFTER the
+// MFMAs of a 64 x 32 block depends on it: a block that holds a pair above a threshold goes through the element-wise test
+// and the listing, and with neighbours scattered over the whole image (the bench's generator deals the mixture components
+// round-robin: row i belongs to component i mod 256) a quarter of all blocks hold one.  With the rows grouped by direction
+// the same pairs fall into few, dense blocks: measured at 1 M x 128 with the rows sorted by their true component the join
+// drops from 110 to 97 ms.  So the image is packed in a permuted order -- rows assigned to the nearest (by cosine) of 256
+// rows sampled as pivots, stable counting sort by pivot -- and the kernel translates positions back to row ids where it
+// appends to the lists.  Nothing else sees the permutation: thresholds are scattered back to row order, the re-rank, its
+// tie-breaks by row id and every later stage work on the rows as given.  Any permutation is correct; this one is cheap
+// (about 2 ms at 1 M x 128) and needs no clustering from the caller.
+#include "common.h"
+
+namespace asx {
+
+namespace {
+
+constexpr int kPivots = 256;
+constexpr int kPivotChunk = 32;  // pivots per LDS pass
+
+// unit pivots, f32, P x dp (dp = d rounded up to 4, zero padded)
+__global__ void gather_pivots_kernel(const double *__restrict__ rows, const double *__restrict__ norms, const uint32_t *__restrict__ ids,
+                                     uint32_t d, uint32_t dp, float *__restrict__ piv) {
+  const uint32_t p = blockIdx.x;
+  const uint32_t r = ids[p];
+  const double nr = norms[r];
+  for (uint32_t k = threadIdx.x; k < dp; k += blockDim.x)
+    piv[(size_t)p * dp + k] = (k < d && nr > 0.0 && nr < __builtin_inf()) ? (float)(rows[(size_t)r * d + k] / nr) : 0.f;
+}
+
+// pivot of every row: the one with the largest dot product (the row's own norm does not matter for the argmax; rows with a
+// zero or non-finite norm go to pivot 0).  One thread per row, the row in registers, pivots through LDS (broadcast reads).
+template <int DP>  // padded width, a multiple of 4, <= 128
+__global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__restrict__ rows, uint32_t n, uint32_t d,
+                                                            const float *__restrict__ piv, uint32_t *__restrict__ assign) {
+  __shared__ float s_piv[kPivotChunk * DP];
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  float x[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) x[k] = (row < n && (uint32_t)k < d) ? (float)rows[(size_t)row * d + k] : 0.f;
+  float best = -__builtin_inff();
+  uint32_t arg = 0;
+  for (int p0 = 0; p0 < kPivots; p0 += kPivotChunk) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < kPivotChunk * DP; e += 256) s_piv[e] = piv[(size_t)p0 * DP + e];
+    __syncthreads();
+    for (int p = 0; p < kPivotChunk; ++p) {
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < DP; k += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(&s_piv[p * DP + k]);
+        acc0 = __builtin_fmaf(x[k], q.x, acc0);
+        acc1 = __builtin_fmaf(x[k + 1], q.y, acc1);
+        acc2 = __builtin_fmaf(x[k + 2], q.z, acc2);
+        acc3 = __builtin_fmaf(x[k + 3], q.w, acc3);
+      }
+      const float s = (acc0 + acc1) + (acc2 + acc3);
+      if (s > best) {
+        best = s;
+        arg = (uint32_t)(p0 + p);
+      }
+    }
+  }
+  if (row < n) assign[row] = arg;
+}
+
+// stable counting sort by pivot, blocks of 256 rows: counts[c * n_blocks + b] -> (exclusive scan) -> positions
+__global__ __launch_bounds__(256) void order_count_kernel(const uint32_t *__restrict__ assign, uint32_t n, uint32_t n_blocks,
+                                                          uint32_t *__restrict__ counts) {
+  __shared__ uint32_t s_cnt[kPivots];
+  s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  if (row < n) atomicAdd(&s_cnt[assign[row]], 1u);
+  __syncthreads();
+  counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void order_place_kernel(const uint32_t *__restrict__ assign, uint32_t n, uint32_t n_blocks,
+                                                          const uint64_t *__restrict__ offsets, uint32_t *__restrict__ perm) {
+  __shared__ uint32_t s_c[256];
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t c = row < n ? assign[row] : 0xFFFFFFFFu;
+  s_c[threadIdx.x] = c;
+  __syncthreads();
+  if (row >= n) return;
+  uint32_t rank = 0;  // earlier rows of this block with the same pivot: keeps the sort stable (and deterministic)
+  for (uint32_t t = 0; t < threadIdx.x; ++t) rank += s_c[t] == c ? 1u : 0u;
+  perm[offsets[(size_t)c * n_blocks + blockIdx.x] + rank] = row;
+}
+
+__global__ void scatter_f32_by_perm_kernel(const float *__restrict__ in, const uint32_t *__restrict__ perm, uint32_t n,
+                                           float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[perm[i]] = in[i];
+}
+
+__global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < kPivots) ids[p] = (uint32_t)(((uint64_t)p * n) / kPivots + (((uint64_t)p * 2654435761ull) % (n / kPivots)));
+}
+
+}  // namespace
+
+// perm[pos] = row: the rows grouped by their nearest pivot (device array of n).  dim <= 128, n >= 256 * 256.
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm) {
+  if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
+  ProfScope ps(ctx, "knn_join_row_order");
+  const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
+  DevBuf<uint32_t> ids, assign, counts;
+  DevBuf<uint64_t> offsets;
+  DevBuf<float> piv;
+  AS_TRY(ids.alloc(ctx, kPivots));
+  AS_TRY(assign.alloc(ctx, n));
+  AS_TRY(counts.alloc(ctx, (size_t)kPivots * n_blocks));
+  AS_TRY(offsets.alloc(ctx, (size_t)kPivots * n_blocks + 1));
+  AS_TRY(piv.alloc(ctx, (size_t)kPivots * 128));
+  hipLaunchKernelGGL(order_pivot_ids_kernel, dim3(1), dim3(256), 0, ctx->stream, n, ids.p);
+  const uint32_t dpv = (dp + 31) / 32 * 32;  // pitch of the pivots = the kernel's register count
+  hipLaunchKernelGGL(gather_pivots_kernel, dim3(kPivots), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv.p);
+#define AS_ASSIGN(DPV)                                                                                                         \
+  hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv.p, assign.p)
+  switch (dpv / 32) {
+    case 1: AS_ASSIGN(32); break;
+    case 2: AS_ASSIGN(64); break;
+    case 3: AS_ASSIGN(96); break;
+    default: AS_ASSIGN(128); break;
+  }
+#undef AS_ASSIGN
+  hipLaunchKernelGGL(order_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, counts.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, (uint64_t)kPivots * n_blocks, offsets.p));
+  hipLaunchKernelGGL(order_place_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, offsets.p, perm);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  return AS_OK;
+}
+
+// out[perm[i]] = in[i], i < n
+int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out) {
+  hipLaunchKernelGGL(scatter_f32_by_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, in, perm, n, out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+}  // namespace asx

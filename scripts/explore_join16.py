@@ -11,6 +11,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 pipes = [int(x) for x in sys.argv[3:]] or [48, 16]
 Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
+if os.environ.get("SORTED"):  # rows grouped by their mixture component (the generator interleaves them: row i -> component i % 256)
+    Xd = Xd[torch.argsort(torch.arange(n, device="cuda") % 256, stable=True)].contiguous()
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 ctx.set_option("join_min_rows", 512)
 if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
