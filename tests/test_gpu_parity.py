@@ -295,6 +295,30 @@ def test_item_graph_join_wide_rows_on_either_pipe(ctx, join_on, n, d, pipe):
     assert np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("n,d", [(70_000, 128), (66_000, 64), (131_072, 100)])
+def test_item_graph_join_on_a_reordered_image(ctx, n, d):
+    """From 65,536 rows on, the operand image of the join is packed with the rows grouped by direction (row_order.hip): at 128
+    columns the lists stay in image positions and the pruning kernel translates them, at other widths the join kernel does
+    where it appends.  Either way the tables are those of the run without the reordering, rows with exact duplicates (ties
+    by row id) and a sample of oracle rows included."""
+    X, _ = synth.mixture(n, d, seed=31, n_clusters=40, rank=5)
+    X[5000:5040] = X[77]          # duplicates: equal distances, order by row id
+    X[9] = 0.0
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_row_order") == 1
+    ctx.set_option("join_row_order", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_row_order") == 0
+    finally:
+        ctx.set_option("join_row_order", 1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.concatenate([[9, 77, 5000, 5039], np.sort(np.random.default_rng(2).choice(n, size=40, replace=False))])
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("topk", [40, 63])
 @pytest.mark.parametrize("pipe", [16, 48])
 def test_item_graph_deep_tables_take_the_join(ctx, join_on, topk, pipe):
