@@ -228,6 +228,8 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
+  else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
+  else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
   else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;

@@ -67,6 +67,9 @@ struct as_ctx {
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_stream_scan = 1;    // small batches / leftover rows: one exact pass over the matrix (stream_scan.hip)
   int64_t opt_search_scan_f16 = 1; // threshold scan of the search (items up to 128 wide) on one f16 plane; 0: split bf16
+  int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
+                                   // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off
+  int64_t opt_join_prefilter_min_rows = 65536;
   int64_t opt_join_row_order = 1;  // own join, dim <= 128: operand image packed with the rows grouped by direction (row_order.hip)
   int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
@@ -385,7 +388,8 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
                    const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr,
-                   const uint32_t *perm = nullptr);  // perm: image position -> row when packedh is packed in a permuted order
+                   const uint32_t *perm = nullptr,         // image position -> row when packedh is packed in a permuted order
+                   const uint32_t *image_perm = nullptr);  // ... when it is, but the lists are to be kept by image position
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

@@ -114,12 +114,13 @@ inline double cos_delta_bf16x3(uint32_t d) {
 // units (Cauchy-Schwarz over unit rows; the double rounding f64 -> f32 -> f16 of the packer is inside the 1 + 2^-10);
 // the f16 x f16 products are exact in f32; accumulation: d_pad products + the carried accumulator of every MFMA + the
 // threshold C = -theta 2^14 the sum starts from, |running sum| < 2^15 so 2^-8 per addition (a truncating adder allowed)
-// = 2^-22 in cosine units; one more rounding where the listed score is recovered as acc + theta.
+// = 2^-22 in cosine units; one more rounding where the listed score is recovered as acc + theta, and up to three ulps (of a
+// value below 2: 3.6e-7) where the masked pass keeps two flag bits in the mantissa of a queued score.
 inline double cos_delta_f16_accum(uint32_t d) {
   uint32_t ks = (d + 15) / 16;
   if (ks > 8) ks = (ks + 3) / 4 * 4;  // wide rows are contracted in whole 64-wide panels (zero padded)
   const uint32_t dp = ks * 16;
-  return (double)(dp + ks + 4) * 0x1p-22 * 1.02 + 1e-7;
+  return (double)(dp + ks + 4) * 0x1p-22 * 1.02 + 5e-7;
 }
 inline double cos_delta_f16(uint32_t d) {
   const uint32_t ks = (d + 15) / 16, dp = ks * 16;

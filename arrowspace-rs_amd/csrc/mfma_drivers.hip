@@ -664,7 +664,11 @@ uint64_t packed_vecs_bf16(uint32_t tiles, uint32_t d);
 int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n,
               uint32_t d, void *P, uint32_t tiles);
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr);
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr,
+             const unsigned char *mask = nullptr);
+uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
+int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
+                 uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
@@ -795,7 +799,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed, const void *packed16, const void *packedh, const uint32_t *perm) {
+                   const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
@@ -831,8 +835,18 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   AS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * n, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   if (f16) {
-    if (d <= 128) AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm));
-    else AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16"));
+    if (d <= 128) {
+      // int8 first pass (mfma_prefilter_i8.hip): the f16 pass then visits only the ~2 % of the blocks that can list something
+      DevBuf<unsigned char> mask;
+      const bool pre = ctx->opt_join_prefilter && n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows);
+      if (pre) {
+        AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end - I_begin)));
+        AS_TRY(prefilter_i8(ctx, packedh, rows, norms, n, d, I_begin, I_end - I_begin, theta.p, mask.p, image_perm ? image_perm : perm));
+      }
+      ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
+      AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm,
+                      pre ? mask.p : nullptr));
+    } else AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16"));
     ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_f16_blocks"];
     ctx->stats["knn_join_pipe"] = 16;
   } else if (bf16) {
@@ -1017,9 +1031,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, perm_own.p, n, inv_own.p);
       }
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p, nullptr,
-                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr));
+                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr, reorder ? perm_own.p : nullptr));
       perm_used = reorder ? perm_own.p : nullptr;
-      if (ctx->opt_debug & 0xFF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
+      if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
       js = &local;
     }

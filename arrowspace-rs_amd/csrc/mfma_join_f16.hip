@@ -137,14 +137,18 @@ struct F16SearchTerm {
   float alpha, beta;
   uint32_t nq;
 };
-template <int KS, int MODE>
+// MASKED (MODE 0): mask = what the int8 first pass found (mfma_prefilter_i8.hip): one byte per (row super tile, stage of 256
+// columns, wave), a bit per 32-column block that may hold a pair.  The unit visits only the stages with a bit set and a wave
+// contracts only its own blocks (the fragment ring then restarts at every block).
+template <int KS, int MODE, bool MASKED>
 __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
                                                                uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
                                                                const float *__restrict__ theta, uint32_t cap,
                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
                                                                uint32_t *__restrict__ unit_counter, int dbg,
                                                                unsigned long long *__restrict__ stamps, F16SearchTerm st,
-                                                               const uint32_t *__restrict__ perm) {
+                                                               const uint32_t *__restrict__ perm,
+                                                               const unsigned long long *__restrict__ mask) {
   constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
   constexpr int kBlocks = 8;                 // 32-column blocks per stage
@@ -153,6 +157,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   f16x8 *bufB = reinterpret_cast<f16x8 *>(smem);
   float *colthr = reinterpret_cast<float *>(smem + (size_t)2 * kStageVecs * 16);
   __shared__ uint32_t s_unit;
+  __shared__ uint32_t s_nlist[2];                  // MASKED: the unit's stages that hold something, in order
+  __shared__ unsigned char s_step[128];            // (bytes: at 128 columns the kernel's LDS is within 2 KB of the 160 KB)
+  __shared__ unsigned long long s_bits[128];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
@@ -172,20 +179,38 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   auto lanes_below = [&](unsigned long long m) -> uint32_t {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
   };
+  unsigned long long t_flush = 0, t_emit = 0;
   auto flush_queue = [&]() {
+    unsigned long long tf0 = 0;
+    if (dbg & 8) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tf0)::"memory");
     wave_sync();
     for (uint32_t base = 0; base < qn; base += 64) {
       const uint32_t e = base + lane;
-      if (e < qn) {
+      if (e < qn && !(dbg & 16384)) {
         // positions in the image -> row ids where the image is packed in a permuted order (row_order.hip); a list of the
         // search mode is owned by a query position, which stays
         const uint2 v = queue[e];
-        const uint32_t owner = (perm && MODE == 0) ? perm[v.x] : v.x, other = perm ? perm[v.y] : v.y;
-        append16(cnt, cand, cap, owner, other, queue_s[e]);
+        if constexpr (MODE == 0 && MASKED) {  // one entry per pair (row, column): bit 0 / 1 of the score = listed for the row / column
+          const uint32_t sb = __float_as_uint(queue_s[e]);
+          const float sc = __uint_as_float(sb & ~3u);
+          if (v.x != v.y) {
+            const uint32_t a = perm ? perm[v.x] : v.x, b = perm ? perm[v.y] : v.y;
+            if (sb & 1u) append16(cnt, cand, cap, a, b, sc);
+            if (sb & 2u) append16(cnt, cand, cap, b, a, sc);
+          }
+        } else {
+          const uint32_t owner = (perm && MODE == 0) ? perm[v.x] : v.x, other = perm ? perm[v.y] : v.y;
+          append16(cnt, cand, cap, owner, other, queue_s[e]);
+        }
       }
     }
     wave_sync();
     qn = 0;
+    if (dbg & 8) {
+      unsigned long long tf1;
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tf1)::"memory");
+      t_flush += tf1 - tf0;
+    }
   };
   const uint32_t n_norm = (T2 - 1) / 2;
   const uint32_t n_cblocks = (T2 + W - 1) / W;
@@ -250,7 +275,30 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       }
       if (p_hi <= p_lo) continue;
     }
-    const uint32_t steps = (p_hi - p_lo) * 2;  // 256-column stages to visit
+    uint32_t steps = (p_hi - p_lo) * 2;  // 256-column stages to visit
+    if constexpr (MASKED) {  // ... of which only those the first pass flagged (steps <= 2 W <= 128)
+      if (tid < 128) {
+        unsigned long long b = 0;
+        if ((uint32_t)tid < steps) {
+          uint32_t S = I + p_lo + ((uint32_t)tid >> 1);
+          S = S >= T2 ? S - T2 : S;
+          b = mask[(size_t)(I - I_begin) * 2 * T2 + 2 * S + ((uint32_t)tid & 1u)];
+        }
+        const unsigned long long have = __ballot(b != 0);
+        if (lane == 0) s_nlist[wv] = (uint32_t)__builtin_popcountll(have);
+        __syncthreads();
+        if (b != 0) {
+          const uint32_t at = (wv == 1 ? s_nlist[0] : 0u) + lanes_below(have);
+          s_step[at] = (unsigned char)tid;
+          s_bits[at] = b;
+        }
+      } else {
+        __syncthreads();
+      }
+      __syncthreads();
+      steps = s_nlist[0] + s_nlist[1];
+      if (steps == 0) continue;
+    }
 
     // the wave's 64 rows: two groups of 32, A fragments in registers for the whole unit
     f16x8 a0[KS], a1[KS];
@@ -290,6 +338,59 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     // put their 16 values into the wave's LDS slots, four lanes at a time, and the 64 lanes take one (slot, register)
     // entry each: one pass of ballots and queue writes instead of a 16-step walk over the accumulator registers.
     auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc) -> bool {
+      if constexpr (MODE == 0 && MASKED) {
+        // Most blocks that get here hold dozens of pairs (a block inside a cluster; the int8 first pass has removed the rest), so
+        // the listing is written for instruction count: per accumulator register two compares, one ballot and ONE queue entry
+        // per pair -- (row, column, score) with the two low mantissa bits of the score saying whose list it goes to (the flush
+        // expands them; cos_delta_f16_accum allows for the three ulps).  Rows beyond n never list (theta = +inf makes acc = -inf
+        // and acc - nth a NaN), columns beyond n have tc = +inf and z = +inf, the pair (i, i) is dropped by the flush.
+        const uint32_t col = colbase + lc, row0 = row_group0 + 4 * lh;
+        const float z = col < n ? 0.f : __builtin_inff();
+        auto count_regs = [&](auto r0_c, auto r1_c) -> uint32_t {
+          constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
+          uint32_t total = 0;
+#pragma unroll
+          for (int r = R0; r < R1; ++r) total += (uint32_t)__builtin_popcountll(__ballot(acc[r] >= z || acc[r] - nth[r] >= tc));
+          return total;
+        };
+        auto list_regs = [&](auto r0_c, auto r1_c) {  // (room for them is the caller's business)
+          constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
+#pragma unroll
+          for (int r = R0; r < R1; ++r) {
+            const float vr = acc[r] - nth[r];
+            const bool w1 = acc[r] >= z, w2 = vr >= tc;
+            const unsigned long long mm = __ballot(w1 || w2);
+            if (mm == 0) continue;
+            if (w1 || w2) {
+              const uint32_t o = qn + lanes_below(mm);
+              queue[o] = make_uint2(row0 + (r & 3) + 8 * (r >> 2), col);
+              queue_s[o] = __uint_as_float((__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | (w1 ? 1u : 0u) | (w2 ? 2u : 0u));
+            }
+            qn += (uint32_t)__builtin_popcountll(mm);
+          }
+        };
+        using ic0 = std::integral_constant<int, 0>;
+        using ic16 = std::integral_constant<int, 16>;
+        const uint32_t total = count_regs(ic0{}, ic16{});
+        if (total == 0) return false;
+        if (qn + total > kQueueH) flush_queue();
+        if (total <= kQueueH) {
+          list_regs(ic0{}, ic16{});
+        } else {  // more than the queue holds: four registers (at most 256 pairs) at a time
+#pragma nounroll
+          for (int g = 0; g < 4; ++g) {
+            if (qn) flush_queue();
+            switch (g) {
+              case 0: list_regs(ic0{}, std::integral_constant<int, 4>{}); break;
+              case 1: list_regs(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}); break;
+              case 2: list_regs(std::integral_constant<int, 8>{}, std::integral_constant<int, 12>{}); break;
+              default: list_regs(std::integral_constant<int, 12>{}, ic16{}); break;
+            }
+          }
+        }
+        wave_sync();
+        return true;
+      } else {
       v16f32 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
@@ -349,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         m &= m - 1;
       } while (m);
       return true;
+      }
     };
 
     f16x8 fa[4];
@@ -357,19 +459,22 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       s_qlam[tid] = st.q_lam[(size_t)I * kSuperH + tid];
       s_qg[tid] = st.q_g[(size_t)I * kSuperH + tid];
     }
-    stage(tile_of(0), 0, -1);
+    auto step_at = [&](uint32_t li) -> uint32_t { return MASKED ? __builtin_amdgcn_readfirstlane((uint32_t)s_step[li]) : li; };
+    stage(tile_of(step_at(0)), 0, -1);
     __syncthreads();
     if (stamp) {
       const unsigned long long t = now();
       t_unit += t - t_mark;
       t_mark = t;
     }
-    for (uint32_t step = 0; step < steps; ++step) {
+    for (uint32_t li = 0; li < steps; ++li) {
+      const uint32_t step = step_at(li);
+      const uint32_t my_blocks = MASKED ? __builtin_amdgcn_readfirstlane((uint32_t)(s_bits[li] >> (8 * wv)) & 0xFFu) : 0xFFu;
       const uint32_t tile0 = tile_of(step);
-      const int pbuf = (int)(step & 1u);
+      const int pbuf = (int)(li & 1u);
       const bool diag = MODE == 0 && (p_lo + (step >> 1)) == 0;
-      const bool more = step + 1 < steps && !(dbg & 4);
-      const uint32_t tile_next = more ? tile_of(step + 1) : 0;
+      const bool more = li + 1 < steps && !(dbg & 4);
+      const uint32_t tile_next = more ? tile_of(step_at(li + 1)) : 0;
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kStageVecs) + (uint32_t)lane * 16u;
       const float *tcol = colthr + pbuf * 256 + lc;  // thresholds of this stage's columns (LDS)
 
@@ -378,18 +483,54 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       // the last block requests into the bytes behind the stage, which nobody reads.
       // kRing (KS a multiple of 4): the ring of four fragment registers runs across the block boundaries.  Other widths
       // restart it at every block (one exposed LDS latency per block; not the benchmark shapes).
-      constexpr bool kRing = KS % 4 == 0;
+      constexpr bool kRing = KS % 4 == 0 && !MASKED;
       uint32_t blk = b_addr;  // fragment base of the block
       if constexpr (kRing) {
         lds_read16<0 * 4 * 64 * 16>(fa[0], blk);
         lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
         lds_read16<2 * 4 * 64 * 16>(fa[2], blk);
       }
+      // MASKED: a wave that lists something issues its share of the next stage behind its blocks -- the compiler waits for
+      // every pending LDS-DMA (vmcnt(0)) in front of the LDS accesses of the listing, which with the pieces in flight cost
+      // 4 000 cycles per listed block; a wave without blocks in this stage issues at once
+      if (MASKED && more && my_blocks == 0) stage(tile_next, pbuf ^ 1, -1);
 #pragma nounroll
       for (int nn = 0; nn < kBlocks; ++nn) {
         // fragment base of the next block: sub-tile nn + 1 of the stage (4 sub-tiles of 32 columns per packed tile)
         const uint32_t nxt = b_addr + (uint32_t)((((nn + 1) >> 2) * kTileVecs + ((nn + 1) & 3) * 64) * 16);
-        if (more && wv < 4) stage(tile_next, pbuf ^ 1, nn);
+        if (!MASKED && more && wv < 4) stage(tile_next, pbuf ^ 1, nn);
+        if constexpr (MASKED) {
+          // only the blocks the first pass flagged for this wave (its share of the DMA goes out either way); the two row groups
+          // one after the other through one set of accumulators (the listing below wants the registers)
+          if ((my_blocks >> nn) & 1u) {
+            const uint32_t colbase = tile0 * kTileRows + nn * 32;
+            const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]);
+            auto half = [&](const f16x8(&a)[KS], const v16f32 &nth, float tmax, uint32_t row_base) {
+              lds_read16<0>(fa[0], blk);
+              if constexpr (KS > 1) lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
+              if constexpr (KS > 2) lds_read16<2 * 4 * 64 * 16>(fa[2], blk);
+              v16f32 x;
+              static_for<0, KS>([&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+                constexpr int ahead = ks + 3;
+                if constexpr (ahead < KS) lds_read16<ahead * 4 * 64 * 16>(fa[ahead & 3], blk);
+                constexpr int pending = (KS - 1 - ks) < 3 ? (KS - 1 - ks) : 3;
+                lds_wait1<pending>(fa[ks & 3]);
+                x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], fa[ks & 3], ks == 0 ? nth : x, 0, 0, 0);
+              });
+              n_blk += 1;
+              if (!(dbg & 128) && __any(max16(x) >= __builtin_fminf(0.f, tc - tmax)) && !(dbg & 2)) {
+                const unsigned long long te0 = stamp ? now() : 0;
+                n_pass += emit(x, nth, row_base - 4 * lh, colbase, tc) ? 1 : 0;
+                if (stamp) t_emit += now() - te0;
+              }
+            };
+            half(a0, nth0, tmax0, row_base0);
+            half(a1, nth1, tmax1, row_base1);
+          }
+          blk = nxt;
+          continue;
+        }
         if constexpr (!kRing) {
           lds_read16<0>(fa[0], blk);
           if constexpr (KS > 1) lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
@@ -423,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         }
         blk = nxt;
       }
+      if (MASKED && more && my_blocks != 0) stage(tile_next, pbuf ^ 1, -1);
       if (stamp) {
         unsigned long long t = now();
         t_blocks += t - t_mark;
@@ -451,6 +593,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     atomicAdd(stamps + 2, t_dma);
     atomicAdd(stamps + 3, t_bar);
     atomicAdd(stamps + 4, 1ull);
+    atomicAdd(stamps + 6, t_emit);
+    atomicAdd(stamps + 8, t_flush);
   }
 }
 
@@ -529,7 +673,8 @@ static size_t f16_join_lds(uint32_t KS, bool search) {
 // (all n rows).  theta: T2 * 512 thresholds (+inf on padding).  cnt / cand (n x cap) are indexed by global row; cnt must be
 // zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm) {
+             uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm,
+             const unsigned char *mask) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
@@ -539,17 +684,25 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
-  AS_TRY(stamps.alloc(ctx, 8));
-  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  AS_TRY(stamps.alloc(ctx, 10));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   {
     ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                           \
-    hipLaunchKernelGGL((pair_join_f16_kernel<K, 0>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
-                       (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,           \
-                       (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm);                                             \
+    if (mask) {                                                                                                           \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true>,                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
+                         (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
+                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask);         \
+    } else {                                                                                                              \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, false>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,  \
+                         (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
+                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)nullptr);      \
+    }                                                                                                                     \
     break;
     switch (KS) {
       AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
@@ -559,7 +712,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
     AS_HIP(ctx, hipGetLastError());
   }
   {
-    unsigned long long h[8];
+    unsigned long long h[10];
     AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[5];       // 32x32 blocks contracted (KS MFMAs each)
@@ -568,8 +721,9 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
       const double w = (double)std::max<unsigned long long>(1, h[4]);
       std::fprintf(stderr,
                    "[join_f16 stamps] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f; %llu blocks, "
-                   "%.3f listed\n",
-                   h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5], h[5] ? (double)h[7] / h[5] : 0.0);
+                   "%.3f listed; in the listing %.2f of which flushing %.2f\n",
+                   h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5], h[5] ? (double)h[7] / h[5] : 0.0, h[6] / w / 1e6,
+                   h[8] / w / 1e6);
     }
   }
   return AS_OK;
@@ -596,11 +750,11 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                           \
-    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,           \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, false>,                                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,    \
                        (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,                \
-                       (int)(ctx->opt_debug & ~8), stamps.p, st, perm);                                                   \
+                       (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)nullptr);              \
     break;
   switch (KS) {
     AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)

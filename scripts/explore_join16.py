@@ -15,6 +15,8 @@ if os.environ.get("SORTED"):  # rows grouped by their mixture component (the gen
     Xd = Xd[torch.argsort(torch.arange(n, device="cuda") % 256, stable=True)].contiguous()
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 ctx.set_option("join_min_rows", 512)
+if os.environ.get("PREFILTER") is not None: ctx.set_option("join_prefilter", int(os.environ["PREFILTER"]))
+if os.environ.get("PREFILTER_MIN") is not None: ctx.set_option("join_prefilter_min_rows", int(os.environ["PREFILTER_MIN"]))
 if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
 res = {}
 for pipe in pipes:
@@ -31,7 +33,10 @@ for pipe in pipes:
     print("pipe=%d  %.1f ms  cand/row %.1f max %d overflow %d  uncertified %d 1a %d 1b %d 2 %d  blocks %d" % (
         pipe, (t1 - t0) * 1e3, ctx.stat("knn_join_candidates") / n, ctx.stat("knn_join_max_per_row"), ctx.stat("knn_join_overflow_rows"),
         ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_uncertified_rows_stage1b"),
-        ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
+        ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")),
+        "prefilter %d blocks %d flagged %d delta %.5f rotated %d tail %.4f" % (ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_blocks"),
+            ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_join_prefilter_delta_e6") * 1e-6, ctx.stat("knn_join_prefilter_rotated"),
+            ctx.stat("knn_join_prefilter_tail_e6") * 1e-6), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
 for dbg in [int(x) for x in os.environ.get("ABLATE", "").split(",") if x]:
     ctx.set_option("join_pipe", pipes[-1]); ctx.set_option("debug", dbg)
     for rep in range(2):
@@ -40,6 +45,14 @@ for dbg in [int(x) for x in os.environ.get("ABLATE", "").split(",") if x]:
         prof = ctx.profile_all()
     ctx.set_option("debug", 0)
     print("debug=%d" % dbg, {k: round(v[0] / v[1], 2) for k, v in prof.items() if "join" in k}, flush=True)
+for dbg in [int(x) for x in os.environ.get("ABLATE_PRE", "").split(",") if x]:  # bits of the int8 first pass (the rest runs on)
+    ctx.set_option("join_pipe", pipes[-1]); ctx.set_option("debug", dbg)
+    for rep in range(2):
+        ctx.profile(True)
+        A.knn_cosine(Xd, gp, ctx=ctx); torch.cuda.synchronize()
+        prof = ctx.profile_all()
+    ctx.set_option("debug", 0)
+    print("debug=%d" % dbg, {k: round(v[0] / v[1], 2) for k, v in prof.items() if "prefilter" in k}, flush=True)
 ks = list(res)
 for p in ks[1:]:
     print("tables identical (pipe %d vs %d):" % (ks[0], p), np.array_equal(res[ks[0]][0], res[p][0]), np.array_equal(res[ks[0]][1], res[p][1]))

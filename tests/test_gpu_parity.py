@@ -319,6 +319,48 @@ def test_item_graph_join_on_a_reordered_image(ctx, n, d):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,mode,isotropic", [(3000, 128, 2, False), (3000, 128, 3, False), (2600, 128, 3, True),
+                                                  (2600, 128, 1, True), (4100, 100, 2, False), (4100, 100, 3, False),
+                                                  (1500, 48, 2, False), (1500, 48, 3, False), (2000, 24, 1, False),
+                                                  (1027, 33, 3, False), (5000, 64, 1, False)])
+def test_item_graph_join_behind_the_int8_first_pass(ctx, join_on, n, d, mode, isotropic):
+    """The int8 first pass (csrc/mfma_prefilter_i8.hip) decides which blocks the f16 join contracts at all: full-width image
+    (mode 2), the rotated 32-wide one (31 dominant directions + the tail norm; mode 3 forces it, also on isotropic rows for
+    which its bound is useless but must still hold), the automatic choice (mode 1), rows of one, two and four int8 k steps,
+    ragged tiles, duplicates and a zero row.  The tables are the oracle's and those of the run without the first pass."""
+    if isotropic:
+        X = np.random.default_rng(5).standard_normal((n, d))
+    else:
+        X, _ = synth.mixture(n, d, seed=23, n_clusters=9, rank=4)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, 12, 2.0, 0.25)
+    ctx.set_option("join_prefilter_min_rows", 0)
+    ctx.set_option("join_prefilter", mode)
+    try:
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_pipe") == 16 and ctx.stat("knn_join_prefilter") == 1
+        rotated = ctx.stat("knn_join_prefilter_rotated")
+        if d <= 32 or mode == 2:
+            assert rotated == 0
+        elif mode == 3:
+            assert rotated == 1
+        elif isotropic:
+            assert rotated == 0  # 31 of 128 directions of white noise hold a quarter of the energy
+        flagged, blocks = ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_join_prefilter_blocks")
+        assert 0 < flagged <= blocks // 2
+        ctx.set_option("join_prefilter", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_prefilter") == 0
+    finally:
+        ctx.set_option("join_prefilter", 1)
+        ctx.set_option("join_prefilter_min_rows", 65536)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    oi, od = O.knn_cosine(X, ogp(gp))
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+
+
 @pytest.mark.parametrize("topk", [40, 63])
 @pytest.mark.parametrize("pipe", [16, 48])
 def test_item_graph_deep_tables_take_the_join(ctx, join_on, topk, pipe):
