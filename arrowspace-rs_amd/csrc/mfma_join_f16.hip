@@ -339,57 +339,70 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     // entry each: one pass of ballots and queue writes instead of a 16-step walk over the accumulator registers.
     auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc) -> bool {
       if constexpr (MODE == 0 && MASKED) {
-        // Most blocks that get here hold dozens of pairs (a block inside a cluster; the int8 first pass has removed the rest), so
-        // the listing is written for instruction count: per accumulator register two compares, one ballot and ONE queue entry
-        // per pair -- (row, column, score) with the two low mantissa bits of the score saying whose list it goes to (the flush
-        // expands them; cos_delta_f16_accum allows for the three ulps).  Rows beyond n never list (theta = +inf makes acc = -inf
-        // and acc - nth a NaN), columns beyond n have tc = +inf and z = +inf, the pair (i, i) is dropped by the flush.
+        // A block that gets here (the int8 first pass has removed the rest) holds ~9 pairs on average, dozens inside a cluster,
+        // and the listing is written for instruction count.  Per accumulator register: two compares into scalar masks, nothing
+        // more if both are empty; else ONE queue entry per pair -- (row, column, score) with the two low mantissa bits of the
+        // score saying whose list it goes to (the flush expands them; cos_delta_f16_accum allows for the three ulps) -- written
+        // under the mask as exec.  Compares, selects and the predicated LDS writes are hand-issued: from bool expressions the
+        // compiler builds every mask twice and spills them.  Rows beyond n never list (theta = +inf makes acc = -inf and
+        // acc - nth a NaN), columns beyond n have tc = +inf and z = +inf, the pair (i, i) is dropped by the flush.  When the
+        // queue cannot take a register's pairs the walk stops, the queue is flushed (one call site) and the walk resumes there.
         const uint32_t col = colbase + lc, row0 = row_group0 + 4 * lh;
         const float z = col < n ? 0.f : __builtin_inff();
-        auto count_regs = [&](auto r0_c, auto r1_c) -> uint32_t {
-          constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
-          uint32_t total = 0;
-#pragma unroll
-          for (int r = R0; r < R1; ++r) total += (uint32_t)__builtin_popcountll(__ballot(acc[r] >= z || acc[r] - nth[r] >= tc));
-          return total;
+        const uint32_t q_addr = lds_addr(queue), s_addr = lds_addr(queue_s);
+        auto cmp_ge = [](float a, float b) -> unsigned long long {
+          unsigned long long m;
+          asm("v_cmp_ge_f32 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+          return m;
         };
-        auto list_regs = [&](auto r0_c, auto r1_c) {  // (room for them is the caller's business)
-          constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
-#pragma unroll
-          for (int r = R0; r < R1; ++r) {
-            const float vr = acc[r] - nth[r];
-            const bool w1 = acc[r] >= z, w2 = vr >= tc;
-            const unsigned long long mm = __ballot(w1 || w2);
-            if (mm == 0) continue;
-            if (w1 || w2) {
-              const uint32_t o = qn + lanes_below(mm);
-              queue[o] = make_uint2(row0 + (r & 3) + 8 * (r >> 2), col);
-              queue_s[o] = __uint_as_float((__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | (w1 ? 1u : 0u) | (w2 ? 2u : 0u));
-            }
-            qn += (uint32_t)__builtin_popcountll(mm);
-          }
+        auto pick = [](unsigned long long m, uint32_t v) -> uint32_t {  // v where the lane's bit of m is set, else 0
+          uint32_t r;
+          asm("v_cndmask_b32 %0, 0, %2, %1" : "=v"(r) : "s"(m), "v"(v));
+          return r;
         };
-        using ic0 = std::integral_constant<int, 0>;
-        using ic16 = std::integral_constant<int, 16>;
-        const uint32_t total = count_regs(ic0{}, ic16{});
-        if (total == 0) return false;
-        if (qn + total > kQueueH) flush_queue();
-        if (total <= kQueueH) {
-          list_regs(ic0{}, ic16{});
-        } else {  // more than the queue holds: four registers (at most 256 pairs) at a time
-#pragma nounroll
-          for (int g = 0; g < 4; ++g) {
-            if (qn) flush_queue();
-            switch (g) {
-              case 0: list_regs(ic0{}, std::integral_constant<int, 4>{}); break;
-              case 1: list_regs(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}); break;
-              case 2: list_regs(std::integral_constant<int, 8>{}, std::integral_constant<int, 12>{}); break;
-              default: list_regs(std::integral_constant<int, 12>{}, ic16{}); break;
-            }
-          }
+        {  // most blocks hold no pair at all: two maxima per lane settle that before the walk
+          v16f32 v;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
+          if (!__any(max16(acc) >= z || max16(v) >= tc)) return false;
         }
+        uint32_t resume = 0;
+        bool listed = false;
+        for (;;) {
+          bool full = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (full || (uint32_t)r < resume) continue;
+            const float vr = acc[r] - nth[r];
+            const unsigned long long m1 = cmp_ge(acc[r], z), m2 = cmp_ge(vr, tc), mm = m1 | m2;
+            if (mm == 0) continue;
+            const uint32_t cnt_r = (uint32_t)__builtin_popcountll(mm);
+            if (qn + cnt_r > kQueueH) {
+              full = true;
+              resume = (uint32_t)r;
+              continue;
+            }
+            const uint32_t o = qn + lanes_below(mm);
+            const uint32_t sb = (__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | pick(m1, 1u) | pick(m2, 2u);
+            const unsigned long long rc = ((unsigned long long)col << 32) | (row0 + (r & 3) + 8 * (r >> 2));
+            unsigned long long saved;
+            asm volatile(
+                "s_and_saveexec_b64 %0, %1\n\t"
+                "ds_write_b64 %2, %3\n\t"
+                "ds_write_b32 %4, %5\n\t"
+                "s_mov_b64 exec, %0"
+                : "=&s"(saved)
+                : "s"(mm), "v"(q_addr + 8u * o), "v"(rc), "v"(s_addr + 4u * o), "v"(sb)
+                : "memory");
+            qn += cnt_r;
+            listed = true;
+          }
+          if (!full) break;
+          flush_queue();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_sync();
-        return true;
+        return listed;
       } else {
       v16f32 v;
 #pragma unroll
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
                 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], fa[ks & 3], ks == 0 ? nth : x, 0, 0, 0);
               });
               n_blk += 1;
-              if (!(dbg & 128) && __any(max16(x) >= __builtin_fminf(0.f, tc - tmax)) && !(dbg & 2)) {
+              if (!(dbg & 128) && !(dbg & 2)) {  // (no coarse test: the first pass was one)
                 const unsigned long long te0 = stamp ? now() : 0;
                 n_pass += emit(x, nth, row_base - 4 * lh, colbase, tc) ? 1 : 0;
                 if (stamp) t_emit += now() - te0;

@@ -42,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 # peaks: /opt/skills/guides/MI355X_MICROARCH.md (chip table); f64 MFMA measured (scripts/micro/mfma_f64_peak.hip)
 F64_MFMA_PEAK_TFLOPS = 39.3
 MFMA16_PEAK_TFLOPS = 2500.0   # dense bf16 / f16 (v_mfma_f32_32x32x16_{bf16,f16}: 32768 flop / 32 clk / SIMD at 2.4 GHz)
+INT8_PEAK_TOPS = 5000.0       # dense int8 (v_mfma_i32_32x32x32_i8: twice the 16-bit rate, MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
 
@@ -209,7 +210,8 @@ def main():
     ctx.profile(False)
     stats = {k: ctx.stat(k) for k in ("knn_join", "knn_join_pipe", "knn_join_blocks", "knn_join_candidates", "knn_uncertified_rows",
                                       "knn_uncertified_rows_stage1a", "knn_join_delta_e9", "search_uncertified_rows", "search_scan",
-                                      "knn_mfma_join_bf16_blocks_full")}
+                                      "knn_mfma_join_bf16_blocks_full", "knn_join_prefilter", "knn_join_prefilter_rotated",
+                                      "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged")}
 
     # ---- untimed extra legs (rank 0, one GPU): small-batch search, host-resident inputs --------------------------------
     extra = {}
@@ -277,16 +279,48 @@ def main():
                 executed = 2.0 * (t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)) * 256 * 256 * d
                 kern = "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32)"
                 peak = F32_MFMA_PEAK_TFLOPS
-            achieved = flops_alg / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            msp, lp = prof.get("knn_join_prefilter", (0.0, 0))
+            if pipe == 16 and stats.get("knn_join_prefilter", 0) == 1 and lp:
+                # two launches make the join: the int8 first pass over all block pairs (the dominant kernel) and the f16 pass
+                # over the blocks it leaves.  8(d) prices the pair against the reference's 2 n^2 d; each kernel's own MFMA
+                # work against the peak of its pipe is reported next to it.
+                pre_ms = msp / lp
+                rotated = stats.get("knn_join_prefilter_rotated", 0) == 1
+                k8 = 32 if rotated else (d + 31) // 32 * 32
+                pre_exec = 2.0 * 32 * 32 * k8 * stats["knn_join_prefilter_blocks"]
+                kern = ("pair_prefilter_i8%s_kernel + pair_join_f16_kernel<masked> (v_mfma_i32_32x32x32_i8 first pass over every unordered "
+                        "pair of 512-row super tiles on %s, then v_mfma_f32_32x32x16_f16 on the %.1f %% of the 64 x 32 blocks it "
+                        "cannot rule out; exact f64 re-rank + certification follow)" % (
+                            "_narrow" if k8 <= 64 else "", "the rotated 32-wide int8 image (31 dominant directions + tail norm)"
+                            if rotated else "the int8 image of the unit rows",
+                            100.0 * stats["knn_join_prefilter_blocks_flagged"] * 2.0 / max(1, stats["knn_join_prefilter_blocks"])))
+                achieved = flops_alg / ((avg_ms + pre_ms) * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                            "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms + pre_ms, "launches": lj,
+                            "algorithmic_flops_per_launch": flops_alg,
+                            "first_pass": {"avg_launch_ms": pre_ms, "executed_ops_per_launch": pre_exec,
+                                           "executed_TOPs": pre_exec / (pre_ms * 1e-3) / 1e12, "peak_TOPs": INT8_PEAK_TOPS,
+                                           "executed_frac_of_peak": pre_exec / (pre_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS,
+                                           "bound_note": "16 outputs per lane and 32-wide MFMA: the v_max3 of the block test, not the "
+                                                         "matrix pipe, limits it (DESIGN.md section 4)"},
+                            "f16_pass": {"avg_launch_ms": avg_ms, "executed_flops_per_launch": executed,
+                                         "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
+                                         "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak},
+                            "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d over the measured time of the two "
+                                    "launches that replace its all-pairs loop. The first pass rules out ~94 % of the blocks on an 8-bit "
+                                    "upper bound of the cosine and every unordered pair is visited once, so frac is far above 1; the "
+                                    "pipe utilisation of each kernel is under first_pass / f16_pass"}
+            else:
+              achieved = flops_alg / (avg_ms * 1e-3) / 1e12
+              roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms, "launches": lj,
-                        "algorithmic_flops_per_launch": flops_alg,
-                        "executed_flops_per_launch": executed, "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
-                        "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak,
-                        "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d per launch over the measured launch time. "
-                                "cos(i,j) = cos(j,i), so the kernel contracts every unordered pair of row tiles once and EXECUTES half of "
-                                "that (executed_*: the MFMA flops really issued = pipe utilisation); frac can therefore exceed "
-                                "executed_frac_of_peak by up to 2x"}
+                          "algorithmic_flops_per_launch": flops_alg,
+                          "executed_flops_per_launch": executed, "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
+                          "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                          "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d per launch over the measured launch time. "
+                                  "cos(i,j) = cos(j,i), so the kernel contracts every unordered pair of row tiles once and EXECUTES half of "
+                                  "that (executed_*: the MFMA flops really issued = pipe utilisation); frac can therefore exceed "
+                                  "executed_frac_of_peak by up to 2x"}
         elif l32 and ms32 >= ms64:
             achieved = flops_alg / (ms32 / min(l32, steps) * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32; exact f64 re-rank + certification follow)",
@@ -330,7 +364,8 @@ def main():
                                         "traffic": None, "avg_step_ms": ss_ms / steps, "algorithmic_flops_per_step": fl}
         out = {
             "metric": "lambda_tau_build_items_per_s", "value": n / build_s, "unit": "items/s",
-            "candidate_precision": ("f16-plane MFMA symmetric threshold join (panelled f16 form beyond dim 128) -> split-bf16 second pass -> f32 top-k "
+            "candidate_precision": ("int8 first pass (blocks that can hold a pair) -> f16-plane MFMA symmetric threshold join on those (panelled f16 form, no "
+                                    "first pass, beyond dim 128) -> second pass -> f32 top-k "
                                     "-> f64 MFMA -> exact f64 scan (results bit-identical to the exact path)")
             if args.cand_precision == 32 else "f64 MFMA -> exact f64 scan",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": t_all / steps * 1e3,

@@ -17,6 +17,8 @@ gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 ctx.set_option("join_min_rows", 512)
 if os.environ.get("PREFILTER") is not None: ctx.set_option("join_prefilter", int(os.environ["PREFILTER"]))
 if os.environ.get("PREFILTER_MIN") is not None: ctx.set_option("join_prefilter_min_rows", int(os.environ["PREFILTER_MIN"]))
+for name in ("join_rank", "join_sample", "join_cap"):
+    if os.environ.get(name.upper()): ctx.set_option(name, int(os.environ[name.upper()]))
 if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
 res = {}
 for pipe in pipes:
