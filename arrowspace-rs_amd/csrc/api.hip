@@ -229,6 +229,9 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
+  else if (n == "search_scan_order") ctx->opt_search_scan_order = value;
+  else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
+  else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
   else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
@@ -696,6 +699,11 @@ void as_index_destroy(as_index *ix) {
   if (ix->scan_sample_lam) (void)hipFree(ix->scan_sample_lam);
   if (ix->lam32) (void)hipFree(ix->lam32);
   if (ix->packedh) (void)hipFree(ix->packedh);
+  if (ix->scan_perm) (void)hipFree(ix->scan_perm);
+  if (ix->lam32_pos) (void)hipFree(ix->lam32_pos);
+  if (ix->scan_piv) (void)hipFree(ix->scan_piv);
+  if (ix->packed8) (void)hipFree(ix->packed8);
+  if (ix->rot_q) (void)hipFree(ix->rot_q);
   delete ix;
 }
 

@@ -67,6 +67,11 @@ struct as_ctx {
   int64_t opt_join_bf16 = 1;      // thresholds from bf16 products (any threshold is correct; bf16 is 16x cheaper)
   int64_t opt_stream_scan = 1;    // small batches / leftover rows: one exact pass over the matrix (stream_scan.hip)
   int64_t opt_search_scan_f16 = 1; // threshold scan of the search (items up to 128 wide) on one f16 plane; 0: split bf16
+  int64_t opt_search_scan_order = 1;  // search scan, dim <= 128: items (from 65,536) and large query batches grouped by direction:
+                                      // 1 = from the second scan of an index on, 2 = at once, 0 = never
+  int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
+  int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
+                                                  // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
                                    // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off
   int64_t opt_join_prefilter_min_rows = 65536;
@@ -134,6 +139,17 @@ struct as_index {
   float *lam32 = nullptr;           // f32 lambdas of all items, padded to whole tiles (lazy)
   void *packedh = nullptr;          // f16 image of the items (lazy; the threshold scan of the search for items wider than 128)
   double f16_err = -1.0;            // measured plane error of that image (mfma_join_f16.hip)
+  // items up to 128 wide, 65,536 of them or more: the f16 image (and lam32) are kept in an order that groups the items by
+  // direction (row_order.hip), with the pivots for ordering a batch of queries the same way, and a rotated int8 image for
+  // the first pass of the scan (mfma_prefilter_i8.hip)
+  uint32_t *scan_perm = nullptr;    // image position -> item (nullptr: the items as given)
+  float *lam32_pos = nullptr;       // f32 lambdas by image position, padded
+  float *scan_piv = nullptr;        // 256 x 128 pivots
+  void *packed8 = nullptr;          // rotated int8 image, by image position
+  float *rot_q = nullptr;           // its 31 directions (32 x 128)
+  double rot_err = -1.0;            // its largest quantisation error norm
+  int rot_state = 0;                // 0 not tried, 1 usable, -1 the directions do not carry the items
+  uint32_t scan_calls = 0;          // searches run on this index so far
   uint32_t scan_ns = 0;
 };
 

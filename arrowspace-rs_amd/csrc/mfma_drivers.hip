@@ -669,7 +669,8 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
-int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm);
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr);
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
@@ -686,7 +687,14 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
                              float *theta2_out);
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr);
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr,
+                    const uint32_t *perm_a = nullptr, const unsigned char *mask = nullptr);
+int rotated_image_pack(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
+                       const float *Qd, void *P8, uint32_t tiles, double *err_out);
+int rotated_basis(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, float *Qd, double *tail_out);
+uint64_t rotated_image_bytes(uint32_t tiles);
+int prefilter_i8_rect(as_ctx *ctx, const void *P8, uint32_t n, const void *PA, uint32_t a_supers, const float *cos_floor, double delta8,
+                      unsigned char *mask, const char *prof_name);
 int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_t d, const double *items, const double *norms,
                                const uint32_t *sample_ids, uint32_t ns, uint32_t m, const float *q_lam, const float *s_lam, float alpha,
                                float beta, float *score_out, uint32_t m2, float *score2_out);
@@ -838,7 +846,11 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
     if (d <= 128) {
       // int8 first pass (mfma_prefilter_i8.hip): the f16 pass then visits only the ~2 % of the blocks that can list something
       DevBuf<unsigned char> mask;
-      const bool pre = ctx->opt_join_prefilter && n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows);
+      // (only on an image whose rows are grouped by direction, row_order.hip: in the order of a caller's rows -- the bench
+      // generator deals its components round-robin -- every block holds some pair of neighbours and the pass rules out nothing;
+      // join_prefilter_min_rows = 0 forces it, for the tests)
+      const bool pre = ctx->opt_join_prefilter && n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) &&
+                       (perm || image_perm || ctx->opt_join_prefilter_min_rows == 0);
       if (pre) {
         AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end - I_begin)));
         AS_TRY(prefilter_i8(ctx, packedh, rows, norms, n, d, I_begin, I_end - I_begin, theta.p, mask.p, image_perm ? image_perm : perm));
@@ -1491,9 +1503,17 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const bool mfma_ok = !((wide && !use_f32) || !fits_f64(KC) || n < 4 * kTileRows);
   if (nq == 0 || n < 4 * kTileRows || !rerank_fits(d))
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
+  // an index that is searched again gets its items ordered by direction and a rotated int8 image (below); with those a small
+  // batch reads 32 MB + the few blocks its queries can reach instead of streaming the 1 GB of rows
+  const uint32_t prior_calls = ix->scan_calls;
+  ix->scan_calls += 1;
+  const bool ordered_ok = !wide && n >= 65536 && ctx->opt_join_pipe == 16 && ctx->opt_search_scan_f16 && ctx->opt_search_scan &&
+                          (ctx->opt_search_scan_order == 2 || (ctx->opt_search_scan_order == 1 && prior_calls >= 1));
+  const bool prefer_staged = ordered_ok && ctx->opt_search_prefilter && d > 32 && ix->rot_state >= 0 && alpha > 0.0 && alpha <= 1.0 &&
+                             nq >= (uint32_t)std::max<int64_t>(1, ctx->opt_search_staged_min_batch);
   // one query or a small batch: the bandwidth-bound regime.  One exact pass over the items (stream_scan.hip), no
   // candidate stages, nothing to certify.
-  if (ctx->opt_stream_scan && stream_scan_applies(nq, n, d, K) && K == k) {
+  if (ctx->opt_stream_scan && stream_scan_applies(nq, n, d, K) && K == k && !prefer_staged) {
     DevBuf<int> err0;
     AS_TRY(err0.alloc(ctx, 1));
     AS_HIP(ctx, hipMemsetAsync(err0.p, 0, sizeof(int), ctx->stream));
@@ -1580,11 +1600,36 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   if (scan) {
     const double beta = 1.0 - alpha;
+    // up to 128 wide: the image in an order that groups the items by direction (the listing of the scan then meets its pairs in
+    // few blocks, and the first pass below can rule the others out); the scan translates positions back.  Ordering the items,
+    // finding their directions and the second image cost ~5 ms at 1 M items, so an index gets them at its SECOND scan
+    // (search_scan_order = 2: at the first): one-shot use pays nothing, a serving index pays once.
+    const bool want_order = scan_h && ordered_ok;
+    if (want_order && !ix->scan_perm && ix->packedh) {  // (the image of the first scan was in the order of the items)
+      (void)hipFree(ix->packedh);
+      ix->packedh = nullptr;
+    }
     if ((scan_wide || scan_h) && !ix->packedh) {
       const uint32_t tiles = packed_tiles_f16(n);
+      if (want_order) {
+        AS_HIP(ctx, hipMalloc((void **)&ix->scan_perm, sizeof(uint32_t) * (size_t)n));
+        AS_HIP(ctx, hipMalloc((void **)&ix->scan_piv, sizeof(float) * 256 * 128));
+        AS_TRY(cluster_order(ctx, ix->items, ix->norms, n, d, ix->scan_perm, ix->scan_piv));
+      }
       AS_HIP(ctx, hipMalloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
-      AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles));
+      AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles, ix->scan_perm));
       ix->f16_err = ctx->f16_err;
+    }
+    if (scan_h && ix->scan_perm && ix->rot_state == 0 && ctx->opt_search_prefilter && d > 32) {
+      const uint32_t tiles = packed_tiles_f16(n);
+      double tail = 1.0;
+      AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+      AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
+      ix->rot_state = tail <= 0.10 ? 1 : -1;
+      if (ix->rot_state == 1) {
+        AS_HIP(ctx, hipMalloc(&ix->packed8, rotated_image_bytes(tiles)));
+        AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, ix->scan_perm, n, d, ix->rot_q, ix->packed8, tiles, &ix->rot_err));
+      }
     }
     if (!scan_wide && !scan_h && !ix->packed16) {
       AS_HIP(ctx, hipMalloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
@@ -1596,6 +1641,13 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream,
                          ix->lambdas, (const uint32_t *)nullptr, n, lpad, ix->lam32);
     }
+    if (scan_h && ix->scan_perm && !ix->lam32_pos) {  // ... and by position in the ordered image
+      const uint32_t lpad = (n + 511) / 512 * 512;
+      AS_HIP(ctx, hipMalloc((void **)&ix->lam32_pos, sizeof(float) * (size_t)lpad));
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream, ix->lambdas,
+                         (const uint32_t *)ix->scan_perm, n, lpad, ix->lam32_pos);
+    }
+    const float *x_lam_h = (scan_h && ix->scan_perm) ? ix->lam32_pos : ix->lam32;  // what the f16 scan of narrow items reads
     const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
     if (ix->scan_sample && ix->scan_ns != ns_want) {  // the option changed since the sample was drawn
       (void)hipFree(ix->scan_sample);
@@ -1634,9 +1686,16 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_TRY(unitc.alloc(ctx, 1));
     double cos_delta = cos_delta_bf16x3(d);  // bound between a listed product and the exact cosine
     DevBuf<float> floor_pad, gmb_pad;
+    // a large batch is put in the order of the items' image too (the same pivots): positions in the query image -> queries
+    DevBuf<uint32_t> qperm;
+    const bool q_order = scan_h && ix->scan_perm && nq >= 2048;
+    if (q_order) {
+      AS_TRY(qperm.alloc(ctx, nq));
+      AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
+    }
     if (scan_h) {
       AS_TRY(PQh.alloc(ctx, packed_vecs_f16(a_alloc, d) * 16));
-      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQh.p, a_alloc));
+      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQh.p, a_alloc, q_order ? qperm.p : nullptr));
       const double e = std::max(ctx->f16_err, ix->f16_err);
       cos_delta = (ctx->f16_err >= 0.0 && ix->f16_err >= 0.0) ? std::min(cos_delta_f16(d), 2.0 * e + e * e + cos_delta_f16_accum(d))
                                                                 : cos_delta_f16(d);
@@ -1655,6 +1714,12 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     }
     hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
                        (const uint32_t *)nullptr, nq, padded, qlam.p);
+    DevBuf<float> qlam_pos;  // ... by position in the query image, for the f16 scan
+    if (q_order) {
+      AS_TRY(qlam_pos.alloc(ctx, padded));
+      hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
+                         (const uint32_t *)qperm.p, nq, padded, qlam_pos.p);
+    }
     if (scan_wide)
       AS_TRY(search_thresholds_f16_wide(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
                                         (float)alpha, (float)beta, guess.p, m2, guess2.p));
@@ -1666,10 +1731,26 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * padded, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     if (scan_h) {
-      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
-                         nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
-      AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQh.p, nq, floor_pad.p, gmb_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
-                             cnt.p, cand.p, unitc.p, "search_scan_f16"));
+      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p,
+                         (const uint32_t *)(q_order ? qperm.p : nullptr), nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
+      // int8 first pass on the rotated images of the items (kept with the index) and of this batch: which blocks can hold a
+      // pair whose cosine alone reaches what the query's guess asks for
+      DevBuf<unsigned char> PQ8, mask;
+      const bool pre = ix->scan_perm && ix->rot_state == 1 && ctx->opt_search_prefilter;
+      if (pre) {
+        double eq = 0.0;
+        AS_TRY(PQ8.alloc(ctx, rotated_image_bytes(a_alloc)));
+        AS_TRY(rotated_image_pack(ctx, queries, q_norms, q_order ? qperm.p : nullptr, nq, d, ix->rot_q, PQ8.p, a_alloc, &eq));
+        const double E = std::max(eq, ix->rot_err), delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + 1e-4;
+        const uint32_t T2i = (n + 511) / 512, a_supers = a_alloc / 4;
+        AS_TRY(mask.alloc(ctx, (size_t)a_supers * 2 * T2i * 8));
+        AS_TRY(prefilter_i8_rect(ctx, ix->packed8, n, PQ8.p, a_supers, floor_pad.p, delta8, mask.p, "search_scan_prefilter"));
+      }
+      ctx->stats["search_scan_prefilter"] = pre ? 1 : 0;
+      ctx->stats["search_scan_order"] = q_order ? 1 : 0;
+      AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQh.p, nq, floor_pad.p, gmb_pad.p, q_order ? qlam_pos.p : qlam.p, x_lam_h,
+                             (float)alpha, (float)beta, cap, cnt.p, cand.p, unitc.p, "search_scan_f16", ix->scan_perm,
+                             q_order ? qperm.p : nullptr, pre ? mask.p : nullptr));
     } else if (scan_wide) {
       hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
                          nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
@@ -1757,8 +1838,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(pad_b, 256)), dim3(256), 0, ctx->stream, guess2.p, fail1.p, nf, pad_b,
                            (float)alpha, (float)beta, floor_b.p, gmb_b.p);
         if (scan_h)
-          AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
-                                 cnt_b.p, cand_b.p, unitc.p, "search_scan_f16"));
+          AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, x_lam_h, (float)alpha, (float)beta, cap2,
+                                 cnt_b.p, cand_b.p, unitc.p, "search_scan_f16", ix->scan_perm));
         else
           AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta,
                                     cap2, cnt_b.p, cand_b.p, "search_scan_f16"));

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
                                                                uint32_t *__restrict__ unit_counter, int dbg,
                                                                unsigned long long *__restrict__ stamps, F16SearchTerm st,
                                                                const uint32_t *__restrict__ perm,
-                                                               const unsigned long long *__restrict__ mask) {
+                                                               const unsigned long long *__restrict__ mask,
+                                                               const uint32_t *__restrict__ perm_a) {
   constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
   constexpr int kBlocks = 8;                 // 32-column blocks per stage
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
             if (sb & 2u) append16(cnt, cand, cap, b, a, sc);
           }
         } else {
-          const uint32_t owner = (perm && MODE == 0) ? perm[v.x] : v.x, other = perm ? perm[v.y] : v.y;
+          // (MODE 1: a list is owned by a query, perm_a: position in the query image -> query)
+          const uint32_t owner = MODE == 0 ? (perm ? perm[v.x] : v.x) : (perm_a ? perm_a[v.x] : v.x), other = perm ? perm[v.y] : v.y;
           append16(cnt, cand, cap, owner, other, queue_s[e]);
         }
       }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       if (tid < 128) {
         unsigned long long b = 0;
         if ((uint32_t)tid < steps) {
-          uint32_t S = I + p_lo + ((uint32_t)tid >> 1);
+          uint32_t S = (MODE == 1 ? 0u : I) + p_lo + ((uint32_t)tid >> 1);
           S = S >= T2 ? S - T2 : S;
           b = mask[(size_t)(I - I_begin) * 2 * T2 + 2 * S + ((uint32_t)tid & 1u)];
         }
@@ -517,7 +519,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           // one after the other through one set of accumulators (the listing below wants the registers)
           if ((my_blocks >> nn) & 1u) {
             const uint32_t colbase = tile0 * kTileRows + nn * 32;
-            const float tc = (diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]);
+            const float tc = MODE == 1 ? tcol[nn * 32] /* lambda of the lane's column */
+                                       : ((diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]));
             auto half = [&](const f16x8(&a)[KS], const v16f32 &nth, float tmax, uint32_t row_base) {
               lds_read16<0>(fa[0], blk);
               if constexpr (KS > 1) lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
@@ -708,13 +711,15 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
       hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
                          (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
-                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask);         \
+                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
+                         (const uint32_t *)nullptr);                                                                      \
     } else {                                                                                                              \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, false>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
       hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,  \
                          (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
-                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)nullptr);      \
+                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)nullptr,       \
+                         (const uint32_t *)nullptr);                                                                      \
     }                                                                                                                     \
     break;
     switch (KS) {
@@ -747,27 +752,38 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 // padded to whole 512-row super tiles with +inf).  PQ: f16 image of the queries (whole 512-row super tiles).
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm) {
+                    uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm,
+                    const uint32_t *perm_a, const unsigned char *mask) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH, a_supers = (nq + kSuperH - 1) / kSuperH;
   const size_t lds = f16_join_lds(KS, true);
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
-  const uint32_t W = std::max(1u, std::min(w_opt, std::max(1u, T2 / 4)));
+  // (on an image ordered by direction, and all the more behind the first pass, a unit's work is what its blocks hold, not how
+  // many columns it spans: small units balance it)
+  const uint32_t W = std::max(1u, std::min((mask || perm) ? std::min(w_opt, 2u) : w_opt, std::max(1u, T2 / 4)));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
-  AS_TRY(stamps.alloc(ctx, 8));
-  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  AS_TRY(stamps.alloc(ctx, 10));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq};
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, false>,                                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,    \
-                       (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,                \
-                       (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)nullptr);              \
+    if (mask) {                                                                                                           \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, true>,                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
+                         (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
+                         (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)mask, perm_a);       \
+    } else {                                                                                                              \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, false>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,  \
+                         (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
+                         (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)nullptr, perm_a);    \
+    }                                                                                                                     \
     break;
   switch (KS) {
     AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)

@@ -502,8 +502,11 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_kernel(const i32x4 *
 // the barrier, the ring of four fragment registers running across blocks and packed tiles (a trip of the loop = the four
 // blocks of one packed tile, fully unrolled), the test of a block issued behind the MFMAs of the next (two sets of
 // accumulators), and the column thresholds read by hand -- a compiler-generated LDS read would wait for the pending DMA.
-template <int KS8>
-__global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const i32x4 *__restrict__ P8, uint32_t T2, uint32_t I_begin,
+// RECT: the one-sided form of the search scan -- the rows are those of a second image PA (the queries: I_count super tiles of
+// it, thresholds thr_a by their position), every one of which meets every column super tile of P8; no column side.
+template <int KS8, bool RECT>
+__global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const i32x4 *__restrict__ P8, const i32x4 *__restrict__ PA,
+                                                                          const int *__restrict__ thr_a, uint32_t T2, uint32_t I_begin,
                                                                           uint32_t I_count, uint32_t W, uint32_t n,
                                                                           const int *__restrict__ thr, const int *__restrict__ thr_min,
                                                                           unsigned char *__restrict__ mask,
@@ -540,10 +543,10 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
 #pragma unroll
     for (int p = 0; p < 2 * KS8; ++p)
       __builtin_amdgcn_global_load_lds((gbl_void *)(src + (wv * 2 * KS8 + p) * 64), (lds_void *)(dst + (wv * 2 * KS8 + p) * 64), 16, 0, 0);
-    if (wv >= 6)
+    if (!RECT && wv >= 6)
       __builtin_amdgcn_global_load_lds((gbl_void *)(thr + (size_t)S * kSuperH + (wv - 6) * 256 + lane * 4),
                                        (lds_void *)(colthr + buf * 512 + (wv - 6) * 256), 16, 0, 0);
-    if (wv == 5)  // the minima of its 16 blocks (lanes 16 .. repeat them)
+    if (!RECT && wv == 5)  // the minima of its 16 blocks (lanes 16 .. repeat them)
       __builtin_amdgcn_global_load_lds((gbl_void *)(thr_min + (size_t)S * 16 + (lane & 15)), (lds_void *)(colmin + buf * 64), 4, 0, 0);
   };
 
@@ -556,7 +559,10 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
     const uint32_t c = u / I_count, I = I_begin + (u - c * I_count);
     const uint32_t B0 = c * W, Wc = min(W, T2 - B0);
     uint32_t p_lo, p_hi;
-    {
+    if (RECT) {  // every column super tile of the block, by absolute index
+      p_lo = B0;
+      p_hi = B0 + Wc;
+    } else {
       const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
       const uint32_t L = 1 + n_norm + (antipodal ? 1u : 0u);
       const uint32_t delta = B0 >= I ? B0 - I : B0 + T2 - I;
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
     {
       const size_t T = (size_t)4 * I + (wv >> 1);
       const int s0 = 2 * (wv & 1);
-      const i32x4 *a_src = P8 + T * kTileVecs + (size_t)s0 * 64 + lane;
+      const i32x4 *a_src = (RECT ? PA : P8) + T * kTileVecs + (size_t)s0 * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < KS8; ++ks) {
         a0[ks] = a_src[(size_t)ks * 256];
@@ -587,8 +593,8 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
     int tmax0 = -kNever, tmax1 = -kNever;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int t0 = thr[row_base0 + (r & 3) + 8 * (r >> 2)];
-      const int t1 = thr[row_base1 + (r & 3) + 8 * (r >> 2)];
+      const int t0 = (RECT ? thr_a : thr)[row_base0 + (r & 3) + 8 * (r >> 2)];
+      const int t1 = (RECT ? thr_a : thr)[row_base1 + (r & 3) + 8 * (r >> 2)];
       nth0[r] = -t0;
       nth1[r] = -t1;
       if (t0 < kNever) tmax0 = max(tmax0, t0);
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
     tmax1 = max(tmax1, __shfl_xor(tmax1, 32, 64));
     const int tmaxw = __builtin_amdgcn_readfirstlane(max(tmax0, tmax1));  // the largest finite threshold of the wave's 64 rows
     auto super_of = [&](uint32_t step) -> uint32_t {
-      const uint32_t S = I + p_lo + step;
+      const uint32_t S = (RECT ? 0u : I) + p_lo + step;
       return S >= T2 ? S - T2 : S;
     };
 
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
     for (uint32_t step = 0; step < steps; ++step) {
       const uint32_t S = super_of(step);
       const int pbuf = (int)(step & 1u);
-      const bool diag = (p_lo + step) == 0;
+      const bool diag = RECT || (p_lo + step) == 0;  // no column side
       if (step + 1 < steps) stage(super_of(step + 1), pbuf ^ 1);  // (buffer pbuf ^ 1 was let go at the barrier)
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kStageVecs) + (uint32_t)lane * 16u;
       const uint32_t t_addr = lds_addr(colthr + pbuf * 512) + (uint32_t)lc * 4u;
@@ -625,8 +631,9 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
       // The test of a block.  Coarse, per lane one maximum over its 32 values against a SCALAR: some product reaches its row's
       // threshold (>= 0) or may reach a column's (the smallest threshold of the block's 32 columns minus the largest of the
       // wave's rows) -- 16 v_max3 and a compare.  The blocks that pass (~10 %) take the two tests per lane on the values.
-      int bm;  // lane l (mod 16): the smallest column threshold of block l of this stage
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bm) : "v"(lds_addr(colmin + pbuf * 64) + (uint32_t)(lane & 15) * 4u) : "memory");
+      int bm = kNever;  // lane l (mod 16): the smallest column threshold of block l of this stage
+      if (!RECT)
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bm) : "v"(lds_addr(colmin + pbuf * 64) + (uint32_t)(lane & 15) * 4u) : "memory");
       auto test = [&](int nn, const v16i32 &x0, const v16i32 &x1) {
         // (four independent chains: a single one of 16 dependent v_max3 leaves the wave waiting on itself)
         int ma = max(max(x0[0], x0[1]), x0[2]), mb = max(max(x0[8], x0[9]), x0[10]);
@@ -796,6 +803,95 @@ static double dominant_directions(const float *cov, uint32_t d, float *Q /* 32 x
   return trace > 0.0 ? std::max(0.0, 1.0 - captured / trace) : 1.0;
 }
 
+// The rotated image of `positions` = tiles * 128 image positions (position p = row perm[p], or p; zero beyond n) for a given
+// basis Qd (device, 32 x 128).  err_out: the largest quantisation error norm of a row's coordinates.
+int rotated_image_pack(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
+                       const float *Qd, void *P8, uint32_t tiles, double *err_out) {
+  DevBuf<unsigned int> bits;
+  AS_TRY(bits.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
+  const uint32_t positions = tiles * kTileRows;
+#define AS_ROT(DPV)                                                                                                          \
+  hipLaunchKernelGGL(rotate_pack_i8_kernel<DPV>, dim3(cdiv(positions, 256)), dim3(256), 0, ctx->stream, rows, norms, perm, n, d, \
+                     positions, Qd, (i32x4 *)P8, bits.p)
+  switch ((d + 31) / 32) {
+    case 1: AS_ROT(32); break;
+    case 2: AS_ROT(64); break;
+    case 3: AS_ROT(96); break;
+    default: AS_ROT(128); break;
+  }
+#undef AS_ROT
+  AS_HIP(ctx, hipGetLastError());
+  unsigned int h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, bits.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float e;
+  std::memcpy(&e, &h, sizeof(e));
+  *err_out = (double)e;
+  return AS_OK;
+}
+
+// 31 dominant directions of the rows (covariance of a 32 k sample, subspace iteration on the host) -> Qd (device, 32 x 128
+// floats); tail_out: the share of the sample's energy outside them.
+int rotated_basis(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, float *Qd, double *tail_out) {
+  if (d > 128) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated image: dim not covered");
+  DevBuf<float> covd;
+  AS_TRY(covd.alloc(ctx, 128 * 128));
+  AS_HIP(ctx, hipMemsetAsync(covd.p, 0, 128 * 128 * sizeof(float), ctx->stream));
+  const uint64_t stride = std::max<uint64_t>(1, n / 32768);
+  const uint32_t n_sample = (uint32_t)((n + stride - 1) / stride);
+  hipLaunchKernelGGL(cov_sample_kernel, dim3((unsigned)std::min<uint32_t>(cdiv(n_sample, 64), 256)), dim3(256), 0, ctx->stream, rows,
+                     norms, (uint64_t)n, d, stride, n_sample, covd.p);
+  AS_HIP(ctx, hipGetLastError());
+  std::vector<float> cov(128 * 128), Q(32 * 128);
+  AS_HIP(ctx, copy_d2h(ctx, cov.data(), covd.p, cov.size() * sizeof(float)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *tail_out = dominant_directions(cov.data(), d, Q.data());
+  AS_HIP(ctx, hipMemcpyAsync(Qd, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q is a local)
+  return AS_OK;
+}
+
+uint64_t rotated_image_bytes(uint32_t tiles) { return (uint64_t)tiles * 4 * 64 * 16; }
+
+// One-sided first pass of the search scan on rotated images: PA = image of the queries (a_supers super tiles of 512 positions),
+// cos_floor = what the cosine of a pair must reach, by query position (+inf on padding), delta8 = the bound of the two images.
+// mask: a_supers x 2 T2 x 8 bytes, as pair_join_f16_kernel<KS, 1, true> reads it.
+int prefilter_i8_rect(as_ctx *ctx, const void *P8, uint32_t n, const void *PA, uint32_t a_supers, const float *cos_floor, double delta8,
+                      unsigned char *mask, const char *prof_name) {
+  const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
+  DevBuf<int> thr_a;
+  DevBuf<uint32_t> unitc;
+  DevBuf<unsigned long long> stamps;
+  AS_TRY(thr_a.alloc(ctx, (size_t)a_supers * kSuperH));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(i8_thresholds_kernel, dim3(cdiv((uint64_t)a_supers * kSuperH, 256)), dim3(256), 0, ctx->stream, cos_floor,
+                     (uint64_t)a_supers * kSuperH, delta8, 127.0 * 127.0, thr_a.p);
+  const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  const uint32_t W = std::max(1u, std::min(std::min(w_opt, 8u), std::max(1u, T2 / 4)));
+  const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
+  const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
+  const size_t lds_n = (size_t)2 * 4 * 4 * 64 * 16 + 2 * 512 * sizeof(int) + 2 * 64 * sizeof(int) + 8192;
+  {
+    ProfScope ps(ctx, prof_name);
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_n));
+    hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<1, true>), dim3(grid), dim3(512), lds_n, ctx->stream, (const i32x4 *)P8,
+                       (const i32x4 *)PA, (const int *)thr_a.p, T2, 0u, a_supers, W, n, (const int *)nullptr, (const int *)nullptr, mask,
+                       unitc.p, (int)(ctx->opt_debug & ~8), stamps.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  unsigned long long h[8];
+  AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stats[std::string(prof_name) + "_blocks"] = (int64_t)h[0];
+  ctx->stats[std::string(prof_name) + "_blocks_flagged"] = (int64_t)h[1];
+  return AS_OK;
+}
+
 uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count) { return (uint64_t)I_count * 2 * ((n + kSuperH - 1) / kSuperH) * 8; }
 
 // Ph: f16 image of all n rows (packed_tiles_f16(n) tiles, any row order); rows / norms: the rows themselves (any order: only the
@@ -810,25 +906,14 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH, tiles = packed_tiles_f16(n);
   // rows wider than one k step: 31 dominant directions + the tail norm, if they carry the rows (opt: 1 decide, 2 never, 3 always)
   bool rotated = false;
-  DevBuf<float> covd, Qd;
+  DevBuf<float> Qd;
   if (KS8 > 1 && ctx->opt_join_prefilter != 2) {
     ProfScope ps(ctx, "knn_join_prefilter_basis");
-    AS_TRY(covd.alloc(ctx, 128 * 128));
     AS_TRY(Qd.alloc(ctx, 32 * 128));
-    AS_HIP(ctx, hipMemsetAsync(covd.p, 0, 128 * 128 * sizeof(float), ctx->stream));
-    const uint64_t stride = std::max<uint64_t>(1, n / 32768);
-    const uint32_t n_sample = (uint32_t)((n + stride - 1) / stride);
-    hipLaunchKernelGGL(cov_sample_kernel, dim3((unsigned)std::min<uint32_t>(cdiv(n_sample, 64), 256)), dim3(256), 0, ctx->stream, rows,
-                       norms, (uint64_t)n, d, stride, n_sample, covd.p);
-    AS_HIP(ctx, hipGetLastError());
-    std::vector<float> cov(128 * 128), Q(32 * 128);
-    AS_HIP(ctx, copy_d2h(ctx, cov.data(), covd.p, cov.size() * sizeof(float)));
-    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const double tail = dominant_directions(cov.data(), d, Q.data());
+    double tail = 1.0;
+    AS_TRY(rotated_basis(ctx, rows, norms, n, d, Qd.p, &tail));
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
     rotated = ctx->opt_join_prefilter == 3 || tail <= 0.10;
-    if (rotated) AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (rotated) AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q is a local)
   }
   ctx->stats["knn_join_prefilter_rotated"] = rotated ? 1 : 0;
   if (rotated) KS8 = 1;
@@ -849,22 +934,9 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
   float c = 1.f, e8 = 0.f;
   if (rotated) {
     ProfScope ps(ctx, "knn_join_prefilter_pack");
-    const uint32_t positions = tiles * kTileRows;
-#define AS_ROT(DPV)                                                                                                          \
-  hipLaunchKernelGGL(rotate_pack_i8_kernel<DPV>, dim3(cdiv(positions, 256)), dim3(256), 0, ctx->stream, rows, norms, perm, n, d, \
-                     positions, Qd.p, (i32x4 *)P8.p, bits.p + 1)
-    switch ((d + 31) / 32) {
-      case 1: AS_ROT(32); break;
-      case 2: AS_ROT(64); break;
-      case 3: AS_ROT(96); break;
-      default: AS_ROT(128); break;
-    }
-#undef AS_ROT
-    AS_HIP(ctx, hipGetLastError());
-    unsigned int h = 0;
-    AS_HIP(ctx, copy_d2h(ctx, &h, bits.p + 1, sizeof(h)));
-    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(&e8, &h, sizeof(e8));
+    double e = 0.0;
+    AS_TRY(rotated_image_pack(ctx, rows, norms, perm, n, d, Qd.p, P8.p, tiles, &e));
+    e8 = (float)e;
     c = 127.f / kOperandScale;  // (128 c)^2 = 127^2 below
   } else {
     ProfScope ps(ctx, "knn_join_prefilter_pack");
@@ -913,10 +985,11 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
 #define AS_PRE_NARROW(K)                                                                                                     \
   case K: {                                                                                                                  \
     const size_t lds_n = (size_t)2 * 4 * K * 4 * 64 * 16 + 2 * 512 * sizeof(int) + 2 * 64 * sizeof(int) + 8192;              \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K>,                                        \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K, false>,                                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                                \
-    hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K>), dim3(grid), dim3(512), lds_n, ctx->stream, (const i32x4 *)P8.p, \
-                       T2, I_begin, I_count, W, n, thr.p, thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p);          \
+    hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K, false>), dim3(grid), dim3(512), lds_n, ctx->stream,               \
+                       (const i32x4 *)P8.p, (const i32x4 *)nullptr, (const int *)nullptr, T2, I_begin, I_count, W, n, thr.p,  \
+                       thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p);                                             \
   } break;
     switch (KS8) {
       AS_PRE_NARROW(1) AS_PRE_NARROW(2) AS_PRE(3) AS_PRE(4)

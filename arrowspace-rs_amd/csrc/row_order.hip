@@ -102,24 +102,19 @@ __global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids) {
 
 }  // namespace
 
-// perm[pos] = row: the rows grouped by their nearest pivot (device array of n).  dim <= 128, n >= 256 * 256.
-int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm) {
-  if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
-  ProfScope ps(ctx, "knn_join_row_order");
+// perm[pos] = row: the rows grouped by the nearest (by cosine) of 256 GIVEN unit pivots (piv: 256 rows of pitch = dim rounded up
+// to 32, f32, device), stable within a pivot.  Any n >= 1, dim <= 128.
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm) {
+  if (d > 128 || n == 0) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
-  DevBuf<uint32_t> ids, assign, counts;
+  const uint32_t dpv = (dp + 31) / 32 * 32;  // pitch of the pivots = the kernel's register count
+  DevBuf<uint32_t> assign, counts;
   DevBuf<uint64_t> offsets;
-  DevBuf<float> piv;
-  AS_TRY(ids.alloc(ctx, kPivots));
   AS_TRY(assign.alloc(ctx, n));
   AS_TRY(counts.alloc(ctx, (size_t)kPivots * n_blocks));
   AS_TRY(offsets.alloc(ctx, (size_t)kPivots * n_blocks + 1));
-  AS_TRY(piv.alloc(ctx, (size_t)kPivots * 128));
-  hipLaunchKernelGGL(order_pivot_ids_kernel, dim3(1), dim3(256), 0, ctx->stream, n, ids.p);
-  const uint32_t dpv = (dp + 31) / 32 * 32;  // pitch of the pivots = the kernel's register count
-  hipLaunchKernelGGL(gather_pivots_kernel, dim3(kPivots), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv.p);
 #define AS_ASSIGN(DPV)                                                                                                         \
-  hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv.p, assign.p)
+  hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p)
   switch (dpv / 32) {
     case 1: AS_ASSIGN(32); break;
     case 2: AS_ASSIGN(64); break;
@@ -134,6 +129,27 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
   return AS_OK;
+}
+
+// perm[pos] = row: the rows grouped by their nearest pivot (device array of n), the pivots being 256 of the rows themselves.
+// dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out) {
+  if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
+  ProfScope ps(ctx, "knn_join_row_order");
+  const uint32_t dp = (d + 3) / 4 * 4;
+  DevBuf<uint32_t> ids;
+  DevBuf<float> piv_own;
+  AS_TRY(ids.alloc(ctx, kPivots));
+  float *piv = piv_out;
+  if (!piv) {
+    AS_TRY(piv_own.alloc(ctx, (size_t)kPivots * 128));
+    piv = piv_own.p;
+  }
+  hipLaunchKernelGGL(order_pivot_ids_kernel, dim3(1), dim3(256), 0, ctx->stream, n, ids.p);
+  const uint32_t dpv = (dp + 31) / 32 * 32;
+  hipLaunchKernelGGL(gather_pivots_kernel, dim3(kPivots), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
+  AS_HIP(ctx, hipGetLastError());
+  return order_by_pivots(ctx, rows, n, d, piv, perm);
 }
 
 // out[perm[i]] = in[i], i < n

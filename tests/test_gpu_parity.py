@@ -888,6 +888,54 @@ def test_search_scan_matches_oracle(ctx, scan_on, n, d, nq, k, alpha):
         assert np.array_equal(sc[j], osc), j
 
 
+@pytest.mark.parametrize("n,d,nq,k,alpha", [(70_000, 128, 2500, 10, 0.7), (66_000, 64, 2100, 5, 1.0), (131_072, 100, 3000, 10, 0.4)])
+def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
+    """An index of 65,536 items or more that is searched again keeps its f16 image grouped by direction, orders large query
+    batches the same way and runs an int8 first pass on rotated images in front of the scan (csrc/mfma_prefilter_i8.hip):
+    first scan in the order of the items, second and third with everything on (the switch happens between them), a small
+    batch through the same stages, and a fresh index with the ordering at once but without the first pass.  All of them
+    give the oracle's results."""
+    X, _ = synth.mixture(n, d, seed=19, n_clusters=30, rank=5)
+    rng = np.random.default_rng(4)
+    lam = rng.random(n) * 0.4
+    lam[::5] = lam[2] + np.arange(len(lam[::5])) * 1e-9
+    qi = synth.query_indices(n, nq, seed=6)
+    Q = X[qi] * 1.03 + rng.normal(size=(nq, d)) * 0.01
+    lq = lam[qi] + rng.normal(size=nq) * 0.02
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    idx1, sc1 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan") == 1 and ctx.stat("search_scan_order") == 0 and ctx.stat("search_scan_prefilter") == 0
+    idx2, sc2 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan_order") == 1 and ctx.stat("search_scan_prefilter") == 1
+    assert 0 < ctx.stat("search_scan_prefilter_blocks_flagged") < ctx.stat("search_scan_prefilter_blocks") // 2
+    idx3, sc3 = asp.search_lambda_aware_batch(Q[::-1].copy(), lq[::-1].copy(), k, alpha)
+    assert np.array_equal(idx1, idx2) and np.array_equal(sc1, sc2)
+    assert np.array_equal(idx1, idx3[::-1]) and np.array_equal(sc1, sc3[::-1])
+    ctx.set_option("search_staged_min_batch", 1)
+    try:
+        idx4, sc4 = asp.search_lambda_aware_batch(Q[:37], lq[:37], k, alpha)  # small batch: items ordered, queries not
+        assert ctx.stat("search_stream_scan") == 0 and ctx.stat("search_scan_prefilter") == 1 and ctx.stat("search_scan_order") == 0
+    finally:
+        ctx.set_option("search_staged_min_batch", 1 << 30)
+    assert np.array_equal(idx1[:37], idx4) and np.array_equal(sc1[:37], sc4)
+    ctx.set_option("search_scan_order", 2)
+    ctx.set_option("search_prefilter", 0)
+    try:
+        asp2 = A.ArrowSpace(X, A.TauMode.Median, ctx)
+        asp2.update_lambdas(lam)
+        idx5, sc5 = asp2.search_lambda_aware_batch(Q, lq, k, alpha)
+        assert ctx.stat("search_scan_order") == 1 and ctx.stat("search_scan_prefilter") == 0
+    finally:
+        ctx.set_option("search_scan_order", 1)
+        ctx.set_option("search_prefilter", 1)
+    assert np.array_equal(idx1, idx5) and np.array_equal(sc1, sc5)
+    for j in range(0, nq, max(1, nq // 20)):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], k, alpha)
+        assert np.array_equal(idx1[j], oi), j
+        assert np.array_equal(sc1[j], osc), j
+
+
 @pytest.mark.parametrize("rate,rank,cap", [(2, 1, 16), (1000, 1, 512), (32, 32, 64), (8, 2, 1024)])
 def test_search_scan_any_guess_is_exact(ctx, scan_on, rate, rank, cap):
     """The score guess only decides how many items are listed and how many queries fall through: guesses far too
