@@ -405,7 +405,8 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
                    const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr,
                    const uint32_t *perm = nullptr,         // image position -> row when packedh is packed in a permuted order
-                   const uint32_t *image_perm = nullptr);  // ... when it is, but the lists are to be kept by image position
+                   const uint32_t *image_perm = nullptr,   // ... when it is, but the lists are to be kept by image position
+                   const double *rot_z = nullptr);         // rows wider than 128: their rotated coordinates (n x 32), for the first pass
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

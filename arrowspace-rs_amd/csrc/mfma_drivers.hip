@@ -679,9 +679,17 @@ int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
                  const uint32_t *perm = nullptr);
 int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
+                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm = nullptr,
+                  const unsigned char *mask = nullptr);
 int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
-                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name);
+                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name,
+                       const uint32_t *perm = nullptr);
+bool rotated_wide_supported(uint32_t d);
+int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
+                      double *tail_out);
+int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
+int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
+                         unsigned char *mask);
 int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                              uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                              float *theta2_out);
@@ -807,7 +815,8 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 // cnt / cand (indexed by GLOBAL row, n x cap; zeroed here) every pair that reaches a threshold.
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
-                   const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm) {
+                   const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm,
+                   const double *rot_z) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
@@ -858,7 +867,27 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
       AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm,
                       pre ? mask.p : nullptr));
-    } else AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16"));
+    } else {
+      // rows wider than 128: the same first pass on the rotated coordinates the caller has (rotate_wide.hip), reduced to "which
+      // pairs of 256-row super tiles hold anything" for the panelled kernel
+      DevBuf<unsigned char> mask, P8;
+      const bool pre = rot_z && I_begin == 0 && (uint64_t)I_end * 512 >= n;
+      if (pre) {
+        const uint32_t tiles = packed_tiles_f16(n);
+        double err = 0.0;
+        AS_TRY(P8.alloc(ctx, (size_t)tiles * 4 * 64 * 16));
+        AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end)));
+        AS_HIP(ctx, hipMemsetAsync(mask.p, 0, prefilter_mask_bytes(n, I_end), ctx->stream));  // (both orientations of a pair are looked up)
+        {
+          ProfScope ps(ctx, "knn_join_prefilter_pack");
+          AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
+        }
+        AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, 0, I_end, theta.p, mask.p));
+      }
+      ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
+      AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16", perm,
+                           pre ? mask.p : nullptr));
+    }
     ctx->stats["knn_join_blocks"] = ctx->stats["knn_mfma_join_f16_blocks"];
     ctx->stats["knn_join_pipe"] = 16;
   } else if (bf16) {
@@ -1008,13 +1037,31 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(theta_own.alloc(ctx, n));
       AS_TRY(theta2_own.alloc(ctx, n));
       // rows grouped by direction in the operand image (row_order.hip): the thresholds come out by image position
-      const bool reorder = join_on_f16(ctx, d) && d <= 128 && ctx->opt_join_row_order && n >= 65536 && ctx->opt_join_bf16 &&
-                           !(ctx->opt_debug & 32);  // (the f16 threshold pass is what reads the image)
-      if (reorder) {
+      const bool reorder_narrow = join_on_f16(ctx, d) && d <= 128 && ctx->opt_join_row_order && n >= 65536 && ctx->opt_join_bf16 &&
+                                  !(ctx->opt_debug & 32);  // (the f16 threshold pass is what reads the image)
+      bool reorder = reorder_narrow;
+      // rows wider than 128 (up to 1024): their rotated coordinates (31 dominant directions + tail norm, rotate_wide.hip) serve
+      // the int8 first pass and, being 32 wide, the row order as well
+      DevBuf<double> rot_z, rot_norm;
+      bool wide_pre = false;
+      if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
+          n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
+        ProfScope ps(ctx, "knn_join_prefilter_basis");
+        double tail = 1.0;
+        AS_TRY(rot_z.alloc(ctx, (size_t)n * 32));
+        AS_TRY(rot_norm.alloc(ctx, n));
+        AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, rot_z.p, rot_norm.p, &tail));
+        ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
+        wide_pre = ctx->opt_join_prefilter == 3 || tail <= 0.10;
+      }
+      const bool reorder_wide = wide_pre && ctx->opt_join_row_order && n >= 65536;
+      if (reorder || reorder_wide) {
         AS_TRY(perm_own.alloc(ctx, n));
-        AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
+        if (reorder_narrow) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
+        else AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p));
         AS_TRY(theta_pos.alloc(ctx, n));
         AS_TRY(theta2_pos.alloc(ctx, n));
+        reorder = true;
       }
       ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
       if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
@@ -1043,7 +1090,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, perm_own.p, n, inv_own.p);
       }
       AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p, nullptr,
-                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr, reorder ? perm_own.p : nullptr));
+                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr, reorder ? perm_own.p : nullptr,
+                            wide_pre ? rot_z.p : nullptr));
       perm_used = reorder ? perm_own.p : nullptr;
       if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
@@ -1331,7 +1379,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
                              unitc.p, "knn_mfma_join_f16_second", perm_used));
     } else if (second_wide)
-      AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second"));
+      AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second",
+                                perm_used));
     else
       AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
                             "knn_mfma_join_bf16_second"));

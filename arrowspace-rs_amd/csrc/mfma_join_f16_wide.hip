@@ -129,7 +129,13 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
                                                                     float *__restrict__ maxima, uint32_t *__restrict__ unit_counters,
                                                                     int dbg, unsigned long long *__restrict__ stamps,
                                                                     const float *__restrict__ col_lam, const float *__restrict__ row_lam,
-                                                                    const float *__restrict__ row_g, float alpha, float beta) {
+                                                                    const float *__restrict__ row_g, float alpha, float beta,
+                                                                    const uint32_t *__restrict__ perm,
+                                                                    const unsigned long long *__restrict__ mask, uint32_t mask_pitch) {
+  // perm (MODE 0 / 1): P is packed in a permuted order (image position -> row): list entries are translated where they are
+  // appended.  mask (MODE 0): what the int8 first pass found (mfma_prefilter_i8.hip; zeroed where it did not look): a word per
+  // (512-row super tile, 256-column stage), a byte per 64-row wave; a pair of 256-row super tiles none of whose bits is set in
+  // either orientation holds no pair of rows that reaches a threshold and is skipped.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_next[2];  // (I, J) of the unit after the current one; I = ~0: none
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +154,9 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       const uint32_t e = base + lane;
       if (e < qn) {
         const uint2 v = queue[e];
-        append_w(cnt, cand, cap, v.x, v.y, queue_s[e]);
+        if (perm && MODE == 0) append_w(cnt, cand, cap, perm[v.x], perm[v.y], queue_s[e]);
+        else if (perm && MODE == 1) append_w(cnt, cand, cap, v.x, perm[v.y], queue_s[e]);
+        else append_w(cnt, cand, cap, v.x, v.y, queue_s[e]);
       }
     }
     wave_sync();
@@ -200,6 +208,11 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) continue;
       uint32_t J = I + off;
       J = J >= T2 ? J - T2 : J;
+      if (MODE == 0 && mask) {  // (rows of I against columns of J, or the other way round: the first pass saw one of the two)
+        const unsigned long long a = mask[(size_t)(I >> 1) * mask_pitch + J] >> (32u * (I & 1u));
+        const unsigned long long b = mask[(size_t)(J >> 1) * mask_pitch + I] >> (32u * (J & 1u));
+        if ((uint32_t)(a | b) == 0u) continue;
+      }
       s_next[0] = I;
       s_next[1] = J;
       return;
@@ -476,7 +489,8 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
             const uint32_t src = __float_as_uint(srcf);
             const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
             bool inside = valid && col < n && row < n_rows;
-            if (MODE == 1) inside = inside && a_ids[row < n_rows ? row : 0] != col;  // lists by position, self by global id
+            if (MODE == 1)  // lists by position, self by global id
+              inside = inside && a_ids[row < n_rows ? row : 0] != (perm ? perm[col < n ? col : 0] : col);
             else if (MODE == 0) inside = inside && row != col;
             float sc = vv * (1.f / kProductScaleW);
             bool w1 = inside && ap >= 0.f;
@@ -574,7 +588,8 @@ template <int MODE>
 static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const void *PA, const uint32_t *a_ids, uint32_t KS,
                        uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_rows, uint32_t n, const float *theta,
                        uint32_t cap, uint32_t *cnt, uint32_t *cand, float *maxima, const float *col_lam = nullptr,
-                       const float *row_lam = nullptr, const float *row_g = nullptr, float alpha = 0.f, float beta = 0.f) {
+                       const float *row_lam = nullptr, const float *row_g = nullptr, float alpha = 0.f, float beta = 0.f,
+                       const uint32_t *perm = nullptr, const unsigned char *mask = nullptr, uint32_t mask_pitch = 0) {
   DevBuf<unsigned long long> stamps;
   DevBuf<uint32_t> counters;
   AS_TRY(stamps.alloc(ctx, 8));
@@ -587,7 +602,8 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
                                     (int)kWideLds));
     hipLaunchKernelGGL((pair_join_f16_wide_kernel<MODE>), dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P,
                        (const f16x8 *)PA, a_ids, KS, T2, I_begin, I_count, n_rows, n, theta, cap, cnt, cand, maxima, counters.p,
-                       (int)ctx->opt_debug, stamps.p, col_lam, row_lam, row_g, alpha, beta);
+                       (int)ctx->opt_debug, stamps.p, col_lam, row_lam, row_g, alpha, beta, perm, (const unsigned long long *)mask,
+                       mask_pitch);
     AS_HIP(ctx, hipGetLastError());
   }
   unsigned long long h[8];
@@ -600,22 +616,24 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
 
 // The wide form of join_f16 (same contract; I_begin / I_count in 512-row super tiles as there): 128 < dim.
 int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
-                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+                  uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm, const unsigned char *mask) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
   const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;  // 256-row super tiles of the image (whole 512-row ones)
+  if (mask && I_begin != 0) return fail(ctx, AS_ERR_ARG, "wide f16 join: a mask covers the whole matrix");
   return launch_wide<0>(ctx, prof_name, P, nullptr, nullptr, KS, T2, 2 * I_begin, std::min(2 * I_count, T2 - 2 * I_begin), n, n, theta,
-                        cap, cnt, cand, nullptr);
+                        cap, cnt, cand, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, perm, mask, T2);
 }
 
 // One-sided pass: the nA gathered rows (image PA: whole 256-row super tiles, zero padded; a_ids their global ids; theta_a
 // their thresholds by position, +inf on padding) against all n rows of P.  cnt / cand (by position; cnt zeroed by the caller).
 int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
-                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
   const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
-  return launch_wide<1>(ctx, prof_name, P, PA, a_ids, KS, T2, 0, (nA + kWS - 1) / kWS, nA, n, theta_a, cap, cnt, cand, nullptr);
+  return launch_wide<1>(ctx, prof_name, P, PA, a_ids, KS, T2, 0, (nA + kWS - 1) / kWS, nA, n, theta_a, cap, cnt, cand, nullptr, nullptr,
+                        nullptr, nullptr, 0.f, 0.f, perm);
 }
 
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,

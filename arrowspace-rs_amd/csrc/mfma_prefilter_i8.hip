@@ -897,13 +897,24 @@ uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count) { return (uint64_t)I
 // Ph: f16 image of all n rows (packed_tiles_f16(n) tiles, any row order); rows / norms: the rows themselves (any order: only the
 // largest quantisation error over them is taken); theta: T2 * 512 thresholds by image position (+inf on padding), as join_f16
 // takes them.  mask: prefilter_mask_bytes(n, I_count) bytes, every byte the f16 pass reads is written.  dim <= 128.
+int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, double inv_step2, uint32_t n, uint32_t I_begin,
+                     uint32_t I_count, const float *theta, unsigned char *mask);
+
+// The pass on a rotated image the caller has (rows wider than 128: rotate_wide.hip): err = its largest quantisation error norm.
+int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
+                         unsigned char *mask) {
+  const double delta8 = (2.0 * err + err * err) * (1.0 + 1e-6) + 1e-4;
+  ctx->stats["knn_join_prefilter_rotated"] = 1;
+  return prefilter_launch(ctx, P8, 1, delta8, 127.0 * 127.0, n, I_begin, I_count, theta, mask);
+}
+
 // perm: image position -> row of Ph (nullptr: the rows as given).
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm) {
   const uint32_t KS = (d + 15) / 16;
   uint32_t KS8 = (KS + 1) / 2;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "int8 prefilter: dim not covered");
-  const uint32_t T2 = (n + kSuperH - 1) / kSuperH, tiles = packed_tiles_f16(n);
+  const uint32_t tiles = packed_tiles_f16(n);
   // rows wider than one k step: 31 dominant directions + the tail norm, if they carry the rows (opt: 1 decide, 2 never, 3 always)
   bool rotated = false;
   DevBuf<float> Qd;
@@ -920,17 +931,9 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
   const uint64_t vecs_h = (uint64_t)tiles * KS * 4 * 64, vecs_8 = (uint64_t)tiles * KS8 * 4 * 64;
   DevBuf<unsigned char> P8;
   DevBuf<unsigned int> bits;
-  DevBuf<int> thr;
-  DevBuf<uint32_t> unitc;
-  DevBuf<unsigned long long> stamps;
   AS_TRY(P8.alloc(ctx, vecs_8 * 16));
   AS_TRY(bits.alloc(ctx, 2));
-  AS_TRY(thr.alloc(ctx, (size_t)T2 * kSuperH));
-  AS_TRY(unitc.alloc(ctx, 1));
-  AS_TRY(stamps.alloc(ctx, 8));
   AS_HIP(ctx, hipMemsetAsync(bits.p, 0, 2 * sizeof(unsigned int), ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
   float c = 1.f, e8 = 0.f;
   if (rotated) {
     ProfScope ps(ctx, "knn_join_prefilter_pack");
@@ -960,6 +963,22 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
   }
   const double E = (double)e8, delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + (rotated ? 1e-4 : 1e-9);
   const double inv_step2 = ((double)c * (double)kOperandScale) * ((double)c * (double)kOperandScale);
+  return prefilter_launch(ctx, P8.p, KS8, delta8, inv_step2, n, I_begin, I_count, theta, mask);
+}
+
+// the pass itself on a finished int8 image of KS8 k steps: s8 >= T  <=>  s8 / inv_step2 >= theta - delta8
+int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, double inv_step2, uint32_t n, uint32_t I_begin,
+                     uint32_t I_count, const float *theta, unsigned char *mask) {
+  const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
+  struct { const void *p; } P8{P8v};
+  DevBuf<int> thr;
+  DevBuf<uint32_t> unitc;
+  DevBuf<unsigned long long> stamps;
+  AS_TRY(thr.alloc(ctx, (size_t)T2 * kSuperH));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_TRY(stamps.alloc(ctx, 8));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
   ctx->stats["knn_join_prefilter_delta_e6"] = (int64_t)(delta8 * 1e6);
   hipLaunchKernelGGL(i8_thresholds_kernel, dim3(cdiv((uint64_t)T2 * kSuperH, 256)), dim3(256), 0, ctx->stream, theta,
                      (uint64_t)T2 * kSuperH, delta8, inv_step2, thr.p);

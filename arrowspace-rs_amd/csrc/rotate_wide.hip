@@ -1,0 +1,248 @@
+// rotate_wide.hip -- the rotated coordinates of rows WIDER than 128 (mfma_prefilter_i8.hip: 31 dominant directions + the norm of
+// what is left bound the cosine of two unit rows from above by a 32-wide product), where a covariance matrix is no longer a
+// small thing to iterate on the host: the directions come from subspace iteration on a SAMPLE of the rows with both products on
+// the device -- Z = S Q (sample x 31), Y = S^T Z (dim x 31) -- and only the orthonormalisation of Y (dim x 31, f64) on the host.
+// The coordinates of all rows are kept (n x 32 doubles: z_0 .. z_30, tail norm t): the row order of the join's image is found on
+// them (cluster_order on 32 columns instead of dim), and the int8 image is packed from them once the order is known.
+#include <vector>
+
+#include "common.h"
+
+namespace asx {
+
+namespace {
+
+constexpr int kDirs = 31;
+constexpr uint32_t kMaxWide = 1024;  // 31 directions of that width fit LDS as f32 (127 KB)
+
+// z = Q^T u for `count` rows (row index = first + i * stride), one wave per row and trip: the row in registers (lane l holds
+// columns l, l + 64, ...), the directions in LDS.  out: count x 32 doubles (z_0 .. z_30 as computed in f32, then t = sqrt(max(0,
+// 1 - |z|^2) + 2e-5): the tail norm rounded up by what f32 and a basis orthonormal to 1e-6 can lose), rows with a zero or
+// non-finite norm all zero.  tail_sum (optional): sum of 1 - |z|^2 over the rows.
+template <int NV>  // columns per lane = ceil(dim / 64) <= 16
+__global__ __launch_bounds__(256) void zproj_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t first,
+                                                    uint64_t stride, uint32_t count, uint32_t d, const float *__restrict__ Q,
+                                                    uint32_t pitch, double *__restrict__ out, double *__restrict__ tail_sum) {
+  extern __shared__ float s_q[];  // kDirs x pitch
+  for (uint32_t e = threadIdx.x; e < (uint32_t)kDirs * pitch; e += 256) s_q[e] = Q[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  double tails = 0.0;
+  for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
+    const uint64_t row = first + (uint64_t)i * stride;
+    const double nr = norms[row];
+    const bool live = nr > 0.0 && nr < __builtin_inf();
+    float x[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t k = (uint32_t)lane + 64u * j;
+      const float v = (live && k < d) ? (float)(R[row * d + k] / nr) : 0.f;
+      x[j] = v == v ? v : 0.f;
+    }
+    float zz = 0.f, mine = 0.f;  // lane j < 31 keeps z_j
+    for (int dir = 0; dir < kDirs; ++dir) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) a = __builtin_fmaf(x[j], s_q[dir * pitch + lane + 64 * j], a);
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      zz = __builtin_fmaf(a, a, zz);
+      if (lane == dir) mine = a;
+    }
+    const float t = live ? __builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.f;
+    if (lane == kDirs) mine = t;
+    if (lane < 32) out[(size_t)i * 32 + lane] = (double)mine;
+    if (live) tails += (double)__builtin_fmaxf(1.f - zz, 0.f);
+  }
+  if (tail_sum && lane == 0 && tails != 0.0) atomicAdd(tail_sum, tails);
+}
+
+// Y[dir][k] += sum over the sample rows of z[row][dir] * u[row][k]   (Y: kDirs x pitch floats, zeroed by the caller)
+__global__ __launch_bounds__(256) void yacc_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t stride,
+                                                   uint32_t count, uint32_t d, const double *__restrict__ Z, uint32_t pitch,
+                                                   float *__restrict__ Y) {
+  __shared__ float s_z[32];
+  float acc[kDirs][4];
+#pragma unroll
+  for (int a = 0; a < kDirs; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const uint64_t row = (uint64_t)i * stride;
+    const double nr = norms[row];
+    __syncthreads();
+    if (threadIdx.x < 32) s_z[threadIdx.x] = (float)Z[(size_t)i * 32 + threadIdx.x];
+    __syncthreads();
+    if (!(nr > 0.0 && nr < __builtin_inf())) continue;
+    float u[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t k = threadIdx.x + 256u * c;
+      const float v = k < d ? (float)(R[row * d + k] / nr) : 0.f;
+      u[c] = v == v ? v : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < kDirs; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_fmaf(s_z[a], u[c], acc[a][c]);
+  }
+#pragma unroll
+  for (int a = 0; a < kDirs; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t k = threadIdx.x + 256u * c;
+      if (k < d && acc[a][c] != 0.f) atomicAdd(&Y[(size_t)a * pitch + k], acc[a][c]);
+    }
+}
+
+__global__ void znorm_kernel(const double *__restrict__ Z, uint32_t n, double *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int j = 0; j < 32; ++j) s += Z[(size_t)i * 32 + j] * Z[(size_t)i * 32 + j];
+  out[i] = __builtin_sqrt(s);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// the int8 image (one k step: mfma_prefilter_i8.hip) of image position p = row perm[p] (or p) from the kept coordinates:
+// q_k = rint(127 z_k), the tail upwards; err_bits: the largest || q / 127 - z || of a row
+__global__ __launch_bounds__(256) void pack_from_z_kernel(const double *__restrict__ Z, const uint32_t *__restrict__ perm, uint32_t n,
+                                                          uint32_t positions, i32x4 *__restrict__ P8, unsigned int *__restrict__ err_bits) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  uint32_t bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float e2 = 0.f;
+  if (p < n) {
+    const double *z = Z + (size_t)(perm ? perm[p] : p) * 32;
+    for (int j = 0; j < kDirs; ++j) {
+      const float zj = (float)z[j];
+      const float q = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(zj * 127.f), -127.f), 127.f);
+      const float e = q * (1.f / 127.f) - zj;
+      e2 = __builtin_fmaf(e, e, e2);
+      bytes[j >> 2] |= ((uint32_t)(int)q & 0xFFu) << (8 * (j & 3));
+    }
+    const float t = (float)z[kDirs];
+    const int tq = t > 0.f ? (int)__builtin_fminf(__builtin_ceilf(t * 127.f), 127.f) : 0;
+    bytes[7] |= (uint32_t)tq << 24;
+  }
+  if (p < positions) {
+    const size_t v = ((size_t)(p >> 7) * 4 + ((p >> 5) & 3)) * 64 + (p & 31);
+    P8[v] = i32x4{(int)bytes[0], (int)bytes[1], (int)bytes[2], (int)bytes[3]};
+    P8[v + 32] = i32x4{(int)bytes[4], (int)bytes[5], (int)bytes[6], (int)bytes[7]};
+  }
+  float e = __builtin_sqrtf(e2) * (1.f + 1e-6f);
+  for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(err_bits, __float_as_uint(e));
+}
+
+template <class... A>
+int launch_zproj(as_ctx *ctx, uint32_t nv, unsigned grid, size_t lds, A... a) {
+#define AS_Z(NV)                                                                                                              \
+  case NV:                                                                                                                    \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)zproj_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL(zproj_kernel<NV>, dim3(grid), dim3(256), lds, ctx->stream, a...);                                      \
+    break;
+  switch (nv) {
+    AS_Z(3) AS_Z(4) AS_Z(6) AS_Z(8) AS_Z(12) AS_Z(16)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
+  }
+#undef AS_Z
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+}  // namespace
+
+bool rotated_wide_supported(uint32_t d) { return d > 128 && d <= kMaxWide; }
+
+// Z: n x 32 doubles (device), znorm: n doubles (their norms, ~1): the rotated coordinates of all rows.  tail_out: the share of
+// the sample's energy outside the 31 directions (the caller decides whether the bound is worth using).
+int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
+                      double *tail_out) {
+  if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
+  const uint32_t pitch = (d + 63) / 64 * 64;
+  uint32_t nv = pitch / 64;  // round up to an instantiated width
+  for (uint32_t c : {3u, 4u, 6u, 8u, 12u, 16u})
+    if (nv <= c) {
+      nv = c;
+      break;
+    }
+  const size_t lds = (size_t)kDirs * pitch * sizeof(float);
+  const uint64_t stride = std::max<uint64_t>(1, n / 16384);
+  const uint32_t ns = (uint32_t)((n + stride - 1) / stride);
+  DevBuf<float> Qd, Yd;
+  DevBuf<double> Zs, tsum;
+  AS_TRY(Qd.alloc(ctx, (size_t)kDirs * pitch));
+  AS_TRY(Yd.alloc(ctx, (size_t)kDirs * pitch));
+  AS_TRY(Zs.alloc(ctx, (size_t)ns * 32));
+  AS_TRY(tsum.alloc(ctx, 1));
+  std::vector<float> Q((size_t)kDirs * pitch, 0.f), Yh((size_t)kDirs * pitch);
+  std::vector<double> V((size_t)kDirs * d);
+  uint64_t seed = 0x9E3779B97F4A7C15ull;
+  for (auto &v : V) {
+    seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+    v = (double)((seed >> 11) & 0xFFFFF) / 1048576.0 - 0.5;
+  }
+  auto orthonormalise = [&]() {  // modified Gram-Schmidt, twice; a direction the others span is left out (zero)
+    for (int j = 0; j < kDirs; ++j) {
+      double *vj = &V[(size_t)j * d];
+      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < j; ++i) {
+          const double *vi = &V[(size_t)i * d];
+          double dot = 0.0;
+          for (uint32_t k = 0; k < d; ++k) dot += vi[k] * vj[k];
+          for (uint32_t k = 0; k < d; ++k) vj[k] -= dot * vi[k];
+        }
+      double nn = 0.0;
+      for (uint32_t k = 0; k < d; ++k) nn += vj[k] * vj[k];
+      const double inv = nn > 1e-300 ? 1.0 / std::sqrt(nn) : 0.0;
+      for (uint32_t k = 0; k < d; ++k) vj[k] *= inv;
+    }
+    for (int j = 0; j < kDirs; ++j)
+      for (uint32_t k = 0; k < pitch; ++k) Q[(size_t)j * pitch + k] = k < d ? (float)V[(size_t)j * d + k] : 0.f;
+  };
+  orthonormalise();
+  for (int it = 0; it < 3; ++it) {  // Q <- orth(S^T S Q)
+    AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(Yd.p, 0, Yh.size() * sizeof(float), ctx->stream));
+    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, rows, norms, (uint64_t)0, stride, ns, d, (const float *)Qd.p,
+                        pitch, Zs.p, (double *)nullptr));
+    hipLaunchKernelGGL(yacc_kernel, dim3(std::min<uint32_t>(ns, 512)), dim3(256), 0, ctx->stream, rows, norms, stride, ns, d,
+                       (const double *)Zs.p, pitch, Yd.p);
+    AS_HIP(ctx, hipGetLastError());
+    AS_HIP(ctx, copy_d2h(ctx, Yh.data(), Yd.p, Yh.size() * sizeof(float)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < kDirs; ++j)
+      for (uint32_t k = 0; k < d; ++k) V[(size_t)j * d + k] = (double)Yh[(size_t)j * pitch + k];
+    orthonormalise();
+  }
+  AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(tsum.p, 0, sizeof(double), ctx->stream));
+  AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(n, 4), 256 * 8), lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p,
+                      pitch, Z, tsum.p));
+  hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
+  AS_HIP(ctx, hipGetLastError());
+  double ts = 0.0;
+  AS_HIP(ctx, copy_d2h(ctx, &ts, tsum.p, sizeof(ts)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
+  *tail_out = ts / std::max<double>(1.0, (double)n);
+  return AS_OK;
+}
+
+// P8: tiles * 128 positions (zero beyond n); err_out: the largest quantisation error norm of a row
+int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out) {
+  DevBuf<unsigned int> bits;
+  AS_TRY(bits.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
+  const uint32_t positions = tiles * 128;
+  hipLaunchKernelGGL(pack_from_z_kernel, dim3(cdiv(positions, 256)), dim3(256), 0, ctx->stream, Z, perm, n, positions, (i32x4 *)P8, bits.p);
+  AS_HIP(ctx, hipGetLastError());
+  unsigned int h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, bits.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float e;
+  std::memcpy(&e, &h, sizeof(e));
+  *err_out = (double)e;
+  return AS_OK;
+}
+
+}  // namespace asx
