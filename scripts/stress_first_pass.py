@@ -1,0 +1,55 @@
+"""Randomised stress of the int8 first pass (join and search): tables / results with it must equal those without, over random
+sizes, widths, cluster structure, duplicates and zero rows.  usage: stress_first_pass.py [cases] [seed]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+import numpy as np, torch
+import arrowspace_amd as A
+from arrowspace_amd import synth
+ctx = A.default_context()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx.set_option("join_min_rows", 512)
+bad = 0
+for c in range(cases):
+    big = rng.random() < 0.25
+    n = int(rng.integers(66000, 220000)) if big else int(rng.integers(600, 9000))
+    d = int(rng.choice([8, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 129, 200, 256, 384, 500, 768, 1000, 1024]))
+    if big and d > 256: d = int(rng.choice([64, 128, 192]))
+    topk = int(rng.integers(3, 40)); eps = float(rng.choice([0.3, 0.5, 0.9]))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        X = rng.standard_normal((n, d))
+    else:
+        X, _ = synth.mixture(n, d, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.integers(2, 80)), rank=int(rng.integers(1, 9)))
+    X[rng.integers(0, n, 5)] = X[rng.integers(0, n)]
+    X[rng.integers(0, n)] = 0.0
+    if rng.random() < 0.3: X *= rng.uniform(1e-3, 1e3, size=(n, 1))
+    gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
+    mode = int(rng.choice([1, 2, 3]))
+    ctx.set_option("join_prefilter", 0)
+    i0, d0 = A.knn_cosine(X, gp)
+    ctx.set_option("join_prefilter", mode); ctx.set_option("join_prefilter_min_rows", 0)
+    i1, d1 = A.knn_cosine(X, gp)
+    used, rot = ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_rotated")
+    ctx.set_option("join_prefilter", 1); ctx.set_option("join_prefilter_min_rows", 65536)
+    ok = np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    bad += 0 if ok else 1
+    print("join n=%d d=%d topk=%d eps=%.1f kind=%d mode=%d used=%d rotated=%d join=%d: %s" % (n, d, topk, eps, kind, mode, used, rot, ctx.stat("knn_join"), "ok" if ok else "MISMATCH"), flush=True)
+for c in range(max(2, cases // 6)):
+    n = int(rng.integers(66000, 180000)); d = int(rng.choice([33, 64, 100, 128])); nq = int(rng.integers(1, 6000)); k = int(rng.integers(1, 30))
+    alpha = float(rng.choice([0.2, 0.7, 1.0]))
+    X, _ = synth.mixture(n, d, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.integers(2, 80)), rank=int(rng.integers(1, 9)))
+    lam = rng.random(n); qi = rng.integers(0, n, nq); Q = X[qi] * 1.01 + rng.normal(size=(nq, d)) * 0.01; lq = lam[qi] + rng.normal(size=nq) * 0.03
+    res = []
+    for order, pre in ((0, 0), (2, 1)):
+        ctx.set_option("search_scan_order", order); ctx.set_option("search_prefilter", pre)
+        asp = A.ArrowSpace(X, A.TauMode.Median, ctx); asp.update_lambdas(lam)
+        res.append(asp.search_lambda_aware_batch(Q, lq, k, alpha))
+        st = (ctx.stat("search_scan"), ctx.stat("search_scan_order"), ctx.stat("search_scan_prefilter"))
+    ctx.set_option("search_scan_order", 1); ctx.set_option("search_prefilter", 1)
+    ok = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    bad += 0 if ok else 1
+    print("search n=%d d=%d nq=%d k=%d alpha=%.1f scan/order/prefilter=%s: %s" % (n, d, nq, k, alpha, st, "ok" if ok else "MISMATCH"), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
