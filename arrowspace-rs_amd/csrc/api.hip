@@ -231,6 +231,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
   else if (n == "search_scan_order") ctx->opt_search_scan_order = value;
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
+  else if (n == "search_stream_filter") ctx->opt_search_stream_filter = value;
   else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
   else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
@@ -703,6 +704,7 @@ void as_index_destroy(as_index *ix) {
   if (ix->lam32_pos) (void)hipFree(ix->lam32_pos);
   if (ix->scan_piv) (void)hipFree(ix->scan_piv);
   if (ix->packed8) (void)hipFree(ix->packed8);
+  if (ix->packed8_nat) (void)hipFree(ix->packed8_nat);
   if (ix->rot_q) (void)hipFree(ix->rot_q);
   delete ix;
 }

@@ -70,6 +70,7 @@ struct as_ctx {
   int64_t opt_search_scan_order = 1;  // search scan, dim <= 128: items (from 65,536) and large query batches grouped by direction:
                                       // 1 = from the second scan of an index on, 2 = at once, 0 = never
   int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
+  int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
@@ -142,6 +143,9 @@ struct as_index {
   // items up to 128 wide, 65,536 of them or more: the f16 image (and lam32) are kept in an order that groups the items by
   // direction (row_order.hip), with the pivots for ordering a batch of queries the same way, and a rotated int8 image for
   // the first pass of the scan (mfma_prefilter_i8.hip)
+  void *packed8_nat = nullptr;      // rotated int8 image in the order of the items (the filter of the streaming scan)
+  double rot_err_nat = -1.0;
+  int weird_items = -1;             // items with a non-finite norm or lambda (-1: not counted yet): the filter is not used then
   uint32_t *scan_perm = nullptr;    // image position -> item (nullptr: the items as given)
   float *lam32_pos = nullptr;       // f32 lambdas by image position, padded
   float *scan_piv = nullptr;        // 256 x 128 pivots
@@ -430,6 +434,19 @@ int select_tau_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t l
 int search_exact(as_ctx *ctx, const as_index *ix, const double *queries, const double *q_norms,
                  const double *q_lambdas, const uint32_t *q_ids, uint64_t nq_sel, uint64_t nq,
                  uint32_t k, double alpha, uint32_t *out_idx, double *out_score);
+// the rotated int8 image of the items (natural order) and what the filter of the small-batch search needs next to it
+struct StreamFilter {
+  const void *P8;
+  float err_items;
+  const float *Qd;          // the 31 directions (32 x 128)
+  const double *a_norms;    // norms and lambdas of the queries
+  const double *a_lams;
+  const double *x_norms, *x_lams;
+  double alpha;
+};
+int rotated_image_pack_async(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
+                             const float *Qd, void *P8, uint32_t tiles, unsigned int *err_bits_dev);
+uint64_t rotated_image_bytes(uint32_t tiles);
 int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *q_norms,
                 const double *q_lambdas, uint64_t nq, uint32_t k, double alpha, uint32_t *out_idx,
                 double *out_score);

@@ -640,8 +640,15 @@ __global__ __launch_bounds__(256) void rerank_join_d128_kernel(
 int join_f32(as_ctx *ctx, const float *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count,
              const float *theta, uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter,
              const char *prof_name);
+__global__ void count_weird_items_kernel(const double *__restrict__ norms, const double *__restrict__ lams, uint32_t n, int *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = norms[i], b = lams[i];
+  if (!(a == a) || !(b == b) || a >= __builtin_inf() || b >= __builtin_inf() || b <= -__builtin_inf()) atomicAdd(out, 1);
+}
 int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids, uint32_t nq, const double *items, uint32_t n, uint32_t K,
-                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
+                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
+                       const StreamFilter *filter = nullptr);
 int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
                       const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
 constexpr uint32_t kStreamRowsMax = 128;  // leftover rows up to this many take the streaming exact scan, 32 per pass
@@ -1568,7 +1575,38 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     AS_HIP(ctx, hipMemsetAsync(err0.p, 0, sizeof(int), ctx->stream));
     SearchScorePolicy pol0{q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
     std::vector<uint32_t> redo;
-    AS_TRY(stream_scan_search(ctx, queries, nullptr, nq, ix->items, n, K, pol0, out_key, out_idx, err0.p, &redo));
+    // an index that is searched again keeps a rotated int8 image of its items (32 bytes each, in their own order): the list
+    // pass then streams the ~1-3 % of the items that can reach some query's cut instead of all of them
+    StreamFilter flt{};
+    const StreamFilter *use_filter = nullptr;
+    if (ctx->opt_search_stream_filter && prior_calls >= 1 && alpha > 0.0 && alpha <= 1.0 && ix->rot_state >= 0 && ix->weird_items != 1) {
+      if (ix->weird_items < 0) {  // (a non-finite norm or lambda must reach the exact arithmetic: no filter for such an index)
+        DevBuf<int> wc;
+        AS_TRY(wc.alloc(ctx, 1));
+        AS_HIP(ctx, hipMemsetAsync(wc.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(count_weird_items_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ix->norms, ix->lambdas, n, wc.p);
+        int h = 0;
+        AS_HIP(ctx, copy_d2h(ctx, &h, wc.p, sizeof(h)));
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ix->weird_items = h ? 1 : 0;
+      }
+      if (ix->weird_items == 0 && ix->rot_state == 0) {
+        double tail = 1.0;
+        AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+        AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
+        ix->rot_state = tail <= 0.10 ? 1 : -1;
+      }
+      if (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat) {
+        const uint32_t tiles = packed_tiles_f16(n);
+        AS_HIP(ctx, hipMalloc(&ix->packed8_nat, rotated_image_bytes(tiles)));
+        AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, nullptr, n, d, ix->rot_q, ix->packed8_nat, tiles, &ix->rot_err_nat));
+      }
+      if (ix->weird_items == 0 && ix->rot_state == 1 && ix->packed8_nat) {
+        flt = StreamFilter{ix->packed8_nat, (float)(ix->rot_err_nat * (1.0 + 1e-6)), ix->rot_q, q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
+        use_filter = &flt;
+      }
+    }
+    AS_TRY(stream_scan_search(ctx, queries, nullptr, nq, ix->items, n, K, pol0, out_key, out_idx, err0.p, &redo, use_filter));
     int h_err0 = 0;
     AS_HIP(ctx, copy_d2h(ctx, &h_err0, err0.p, sizeof(int)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));

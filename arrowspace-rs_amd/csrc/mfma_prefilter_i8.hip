@@ -805,6 +805,23 @@ static double dominant_directions(const float *cov, uint32_t d, float *Q /* 32 x
 
 // The rotated image of `positions` = tiles * 128 image positions (position p = row perm[p], or p; zero beyond n) for a given
 // basis Qd (device, 32 x 128).  err_out: the largest quantisation error norm of a row's coordinates.
+int rotated_image_pack_async(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
+                             const float *Qd, void *P8, uint32_t tiles, unsigned int *err_bits_dev) {
+  struct { unsigned int *p; } bits{err_bits_dev};  // (atomicMax into it: zeroed by the caller)
+  const uint32_t positions = tiles * kTileRows;
+#define AS_ROT(DPV)                                                                                                          \
+  hipLaunchKernelGGL(rotate_pack_i8_kernel<DPV>, dim3(cdiv(positions, 256)), dim3(256), 0, ctx->stream, rows, norms, perm, n, d, \
+                     positions, Qd, (i32x4 *)P8, bits.p)
+  switch ((d + 31) / 32) {
+    case 1: AS_ROT(32); break;
+    case 2: AS_ROT(64); break;
+    case 3: AS_ROT(96); break;
+    default: AS_ROT(128); break;
+  }
+#undef AS_ROT
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
 int rotated_image_pack(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
                        const float *Qd, void *P8, uint32_t tiles, double *err_out) {
   DevBuf<unsigned int> bits;

@@ -140,13 +140,149 @@ constexpr int kSsTileBytes = kSsTile * kSsPitchB + 128;  // 8 rows + 8 norms + 8
 constexpr int kSsPieces = kSsTile + 1;                   // DMA instructions per tile
 
 // G = accumulators per lane = ceil(nA / 8): lane s holds the A rows s, s + 8, ...
+typedef int ssf_i32x4 __attribute__((ext_vector_type(4)));
+typedef int ssf_v16i32 __attribute__((ext_vector_type(16)));
+
+// The filter of the small-batch search on an index that keeps a rotated int8 image of its items (mfma_prefilter_i8.hip: 31
+// dominant directions + tail norm, 32 bytes per item: 32 MB for a million items instead of the 1 GB of rows).  score =
+// alpha cos + (1 - alpha) lam with lam in [0, 1], and cos <= s8 / 127^2 + delta8, so an item can only reach query a's cut
+// S_a = -guess[a] (guaranteed to keep its top K: stream_guess_kernel) if  s8 >= T_a = ceil(((S_a - (1 - alpha)) / alpha -
+// delta8) 127^2): one v_mfma_i32_32x32x32_i8 per 32 items against the (up to 32) queries with -T_a as its C operand.  Items
+// that pass, and still pass with the lambda term of the pair in place of its largest value, are queued as (query, item) pairs
+// for stream_pairs_kernel: ~0.4 % of all pairs.
+__global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *__restrict__ P8, uint32_t n, const ssf_i32x4 *__restrict__ PQ8,
+                                                              uint32_t nq, const double *__restrict__ guess,
+                                                              const double *__restrict__ q_lams, double alpha,
+                                                              float err_items, const unsigned int *__restrict__ err_q_bits,
+                                                              const double *__restrict__ x_lams, uint32_t cap,
+                                                              uint32_t *__restrict__ count, uint32_t *__restrict__ pairs,
+                                                              int *__restrict__ overflow) {
+  const int lane = threadIdx.x & 63, lh = lane >> 5;
+  const double E = (double)__builtin_fmaxf(err_items, __uint_as_float(*err_q_bits));
+  const double delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + 1e-4;
+  ssf_v16i32 nth;
+  double cutv[16], qlv[16];  // the cut and the lambda of the lane's 16 query rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t a = 4u * lh + (r & 3) + 8u * (r >> 2);
+    int T = 1 << 29;  // rows beyond the batch: never
+    cutv[r] = __builtin_inf();
+    qlv[r] = 0.0;
+    if (a < nq) {
+      const double cut = -guess[a];
+      cutv[r] = cut == cut ? cut : -__builtin_inf();
+      qlv[r] = q_lams[a];
+      // (a NaN or -inf cut -- fewer than K sampled keys -- lets everything through)
+      const double x = __builtin_ceil((((cut - (1.0 - alpha)) / alpha) - delta8 - 1e-9) * (127.0 * 127.0));
+      T = x == x ? (int)__builtin_fmax(__builtin_fmin(x, 536870911.0), -536870911.0) : -(1 << 29);
+    }
+    nth[r] = -T;
+  }
+  const ssf_i32x4 aq = PQ8[lane];  // the first 32 positions of the queries' image
+  // the wave's finds -- (query << 27 | item) -- are queued in LDS and go out with ONE reservation on the global counter per
+  // flush (a returning atomic per find on one address serialises in L2: 0.3 ms for 50 k finds)
+  constexpr uint32_t kQ = 2304;  // a trip of four sub tiles adds at most 4096 -> flushed before every sub tile that might not fit
+  __shared__ uint32_t s_q[4][kQ];
+  __shared__ uint32_t s_qn[4];
+  uint32_t *q = s_q[threadIdx.x >> 6];
+  uint32_t *qn_p = &s_qn[threadIdx.x >> 6];
+  if (lane == 0) *qn_p = 0;
+  ss_wave_sync();
+  auto flush = [&]() {
+    ss_wave_sync();
+    const uint32_t qn = *qn_p;
+    if (qn != 0) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count, qn);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + qn > cap) {
+        if (lane == 0) *overflow = 1;
+      } else {
+        for (uint32_t e = lane; e < qn; e += 64) pairs[base + e] = q[e];
+      }
+    }
+    ss_wave_sync();
+    if (lane == 0) *qn_p = 0;
+    ss_wave_sync();
+  };
+  const uint32_t n_sub = (n + 31) / 32, wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  for (uint32_t st0 = wave * 4; st0 < n_sub; st0 += n_waves * 4) {  // four sub tiles per trip: their loads fly together
+    ssf_i32x4 bx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bx[u] = P8[(size_t)min(st0 + (uint32_t)u, n_sub - 1) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t st = st0 + (uint32_t)u;
+      const ssf_v16i32 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, bx[u], nth, 0, 0, 0);
+      int m = max(max(acc[0], acc[1]), acc[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m = max(max(m, acc[r]), acc[r + 1]);
+      m = max(m, acc[15]);
+      const uint32_t j = st * 32 + (uint32_t)(lane & 31);
+      const bool ok = m >= 0 && st < n_sub && j < n;
+      if (!__any(ok)) continue;
+      if (*qn_p + 1024 > kQ) flush();  // (wave-uniform: every lane reads the same word)
+      if (ok) {  // the lambda term as the score computes it, in place of its largest value 1 (rare path: a few lanes)
+        const double lx = x_lams[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc[r] < 0) continue;
+          const double cos_ub = (double)(acc[r] - nth[r]) * (1.0 / (127.0 * 127.0)) + delta8;
+          const double diff = fabs(__dsub_rn(qlv[r], lx));
+          const double lam = __dsub_rn(1.0, fmin(diff, 1.0));
+          // (a NaN lambda keeps the pair: the exact arithmetic has to see it)
+          if (!(alpha * cos_ub + (1.0 - alpha) * lam + 1e-9 < cutv[r])) {
+            const uint32_t a = 4u * lh + (r & 3) + 8u * (r >> 2);
+            q[atomicAdd(qn_p, 1u)] = (a << 27) | j;
+          }
+        }
+      }
+    }
+  }
+  flush();
+}
+
+// The exact keys of the pairs the filter left: one lane per (query, item) pair, the reference's chain over k (multiply and add
+// rounded separately, k ascending: src/core.rs:185-197) with the query rows in LDS; keys at or below the query's cut are listed
+// for stream_final_kernel exactly as the list pass of the streaming scan lists them.
+__global__ __launch_bounds__(256) void stream_pairs_kernel(const double *__restrict__ A, uint32_t nA, const double *__restrict__ B,
+                                                          SearchScorePolicy pol, const uint32_t *__restrict__ pairs,
+                                                          const uint32_t *__restrict__ count, const int *__restrict__ overflow,
+                                                          const double *__restrict__ guess, uint32_t cap, uint32_t *__restrict__ cnt,
+                                                          uint32_t *__restrict__ list_idx, double *__restrict__ list_key,
+                                                          int *__restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *sA = reinterpret_cast<double *>(smem);  // nA x 129 (the pad keeps the rows of different queries in different banks)
+  if (*overflow) return;
+  for (uint32_t e = threadIdx.x; e < nA * kSsD; e += blockDim.x) sA[(e / kSsD) * 129 + (e % kSsD)] = A[e];
+  __syncthreads();
+  const uint32_t n_pairs = *count;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
+    const uint32_t w = pairs[p], a = w >> 27, j = w & 0x7FFFFFFu;
+    const double *x = B + (uint64_t)j * kSsD, *qa = sA + a * 129;
+    double acc = 0.0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < kSsD; ++k) acc = __dadd_rn(acc, __dmul_rn(qa[k], x[k]));
+    double key;
+    if (pol.key(acc, a, j, key, err_flag) && key <= guess[a]) {
+      const uint32_t pos = atomicAdd(cnt + a, 1u);
+      if (pos < cap) {
+        list_idx[(size_t)a * cap + pos] = j;
+        list_key[(size_t)a * cap + pos] = key;
+      }
+    }
+  }
+}
+
 template <class Policy, bool LIST, int NBUF, int G>
 __global__ __launch_bounds__(kSsWaves * 64) void stream_scan_d128_kernel(
     const double *__restrict__ A, const uint32_t *__restrict__ a_ids, uint32_t a_begin, uint32_t nA,
     const double *__restrict__ B, uint32_t nB, uint32_t n_tiles, Policy pol, unsigned long long *__restrict__ sample_min,
     const double *__restrict__ guess, uint32_t cap, uint32_t *__restrict__ cnt,
-    uint32_t *__restrict__ list_idx, double *__restrict__ list_key, int *__restrict__ err_flag) {
+    uint32_t *__restrict__ list_idx, double *__restrict__ list_key, int *__restrict__ err_flag, const int *__restrict__ run_if) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // (LIST behind the int8 filter: only when its pair list ran out of room -- stream_pairs_kernel did the work otherwise)
+  if (run_if && *run_if == 0) return;
   // [A rows: 8 ceil(nA / 8) x 1040][per wave: NBUF tiles]   (NBUF = 3 while the A rows leave room: nA <= 8)
   unsigned char *sA = smem;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,7 +545,8 @@ bool stream_scan_applies(uint64_t nA, uint64_t nB, uint64_t d, uint32_t K) {
 template <class Policy>
 static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, const uint32_t *a_ids, uint32_t a_begin, uint32_t nA,
                        const double *B, uint32_t nB, uint32_t K, Policy pol, double *out_key, uint32_t *out_idx, uint32_t out_ld,
-                       int *err_flag, std::vector<uint32_t> *redo_pos) {
+                       int *err_flag, std::vector<uint32_t> *redo_pos, const StreamFilter *filter_in = nullptr) {
+  const StreamFilter *filter = (filter_in && !a_ids && a_begin == 0 && nB < (1u << 27)) ? filter_in : nullptr;  // (pairs: query << 27 | item)
   const uint32_t n_tiles = (nB + kSsTile - 1) / kSsTile;
   const uint32_t n_stiles = (n_tiles + kSsSampleStride - 1) / kSsSampleStride;
   const uint32_t cap = kSsSortMax;
@@ -417,7 +554,7 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   DevBuf<unsigned long long> smin;
   DevBuf<uint32_t> cnt, lidx;
   DevBuf<int> over, done;
-  std::vector<int> h(nA);
+  std::vector<int> h(nA + 2);  // [nA], [nA + 1]: the filter's count and overflow flag (one copy back for all of it)
   int64_t retries = 0;
   AS_TRY(done.alloc(ctx, nA));
   AS_TRY(smin.alloc(ctx, (size_t)nA * kSsShares));
@@ -425,12 +562,26 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   AS_TRY(cnt.alloc(ctx, nA));
   AS_TRY(lidx.alloc(ctx, (size_t)nA * cap));
   AS_TRY(lkey.alloc(ctx, (size_t)nA * cap));
-  AS_TRY(over.alloc(ctx, nA));
+  AS_TRY(over.alloc(ctx, nA + 2));
   AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(over.p, 0, sizeof(int) * nA, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(over.p, 0, sizeof(int) * (nA + 2), ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(done.p, 0, sizeof(int) * nA, ctx->stream));
+  // the int8 filter in front of the list pass (search on an index that keeps a rotated image)
+  DevBuf<uint32_t> g_pairs;
+  DevBuf<unsigned char> pq8;
+  DevBuf<unsigned int> q_err;
+  uint32_t *const g_count = reinterpret_cast<uint32_t *>(over.p + nA);
+  int *const g_over = over.p + nA + 1;
+  const uint32_t g_cap = 1u << 20;
+  if (filter) {
+    AS_TRY(g_pairs.alloc(ctx, g_cap));
+    AS_TRY(pq8.alloc(ctx, rotated_image_bytes(1)));
+    AS_TRY(q_err.alloc(ctx, 1));
+    AS_HIP(ctx, hipMemsetAsync(q_err.p, 0, sizeof(unsigned int), ctx->stream));
+  }
   const int nbuf = nA <= 8 ? 3 : 2;  // a third tile in flight per wave while the A rows leave the LDS for it
   const size_t lds = (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)kSsWaves * nbuf * kSsTileBytes;
+  bool first_list = true;  // (the retries sweep all of B: their cut is the tighter one of a truncated list)
   {
     ProfScope ps(ctx, prof_name);
     hipLaunchKernelGGL(fill_u64_kernel, dim3(cdiv((uint64_t)nA * kSsShares, 256)), dim3(256), 0, ctx->stream, smin.p,
@@ -439,7 +590,8 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   AS_HIP(ctx, hipFuncSetAttribute((const void *)stream_scan_d128_kernel<Policy, LISTV, NB, GV>,                              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
   hipLaunchKernelGGL((stream_scan_d128_kernel<Policy, LISTV, NB, GV>), dim3(GRID), dim3(kSsWaves * 64), lds, ctx->stream, A,   \
-                     a_ids, a_begin, nA, B, nB, n_tiles, pol, smin.p, guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag)
+                     a_ids, a_begin, nA, B, nB, n_tiles, pol, smin.p, guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag,       \
+                     (LISTV && filter && first_list) ? (const int *)g_over : (const int *)nullptr)
 #define AS_SS(LISTV, GRID)                                                             \
   switch ((nA + 7) / 8) {                                                              \
     case 1: AS_SS1(LISTV, 3, 1, GRID); break;                                          \
@@ -450,6 +602,18 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
     const unsigned g_s = std::min<uint32_t>(256, cdiv(n_stiles, kSsWaves));
     AS_SS(false, g_s)
     hipLaunchKernelGGL(stream_guess_kernel, dim3(nA), dim3(256), 0, ctx->stream, smin.p, K, guess.p);
+    if constexpr (std::is_same<Policy, SearchScorePolicy>::value) {
+      if (filter) {
+        ProfScope pf(ctx, "search_stream_filter");
+        AS_TRY(rotated_image_pack_async(ctx, A, filter->a_norms, a_ids, nA, kSsD, filter->Qd, pq8.p, 1, q_err.p));
+        hipLaunchKernelGGL(stream_filter_i8_kernel, dim3(256), dim3(256), 0, ctx->stream, (const ssf_i32x4 *)filter->P8, nB,
+                           (const ssf_i32x4 *)pq8.p, nA, (const double *)guess.p, filter->a_lams, filter->alpha, filter->err_items,
+                           (const unsigned int *)q_err.p, filter->x_lams, g_cap, g_count, g_pairs.p, g_over);
+        const size_t lds_p = (size_t)nA * 129 * sizeof(double);
+        hipLaunchKernelGGL(stream_pairs_kernel, dim3(256), dim3(256), lds_p, ctx->stream, A, nA, B, pol, (const uint32_t *)g_pairs.p,
+                           (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag);
+      }
+    }
     AS_SS(true, 256u)
     hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
                        out_idx, over.p, guess.p, done.p);
@@ -463,6 +627,7 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
       for (uint32_t a = 0; a < nA; ++a) any = any || h[a] != 0;
       if (!any) break;
       AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
+      first_list = false;
       AS_SS(true, 256u)
       hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
                          out_idx, over.p, guess.p, done.p);
@@ -472,11 +637,16 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
 #undef AS_SS1
 #undef AS_SS
   }
-  AS_HIP(ctx, copy_d2h(ctx, h.data(), over.p, sizeof(int) * nA));
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), over.p, sizeof(int) * (nA + 2)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t h_count = (uint32_t)h[nA];
+  const int h_gover = h[nA + 1];
   redo_pos->clear();
   for (uint32_t a = 0; a < nA; ++a)
     if (h[a]) redo_pos->push_back(a);
+  ctx->stats["stream_scan_filter"] = filter ? 1 : 0;
+  ctx->stats["stream_scan_filter_items"] = (int64_t)h_count;
+  ctx->stats["stream_scan_filter_overflow"] = h_gover;
   ctx->stats["stream_scan_retries"] = retries;
   ctx->stats["stream_scan_rows"] = nA;
   ctx->stats["stream_scan_overflow_rows"] = (int64_t)redo_pos->size();
@@ -484,8 +654,10 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
 }
 
 int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids, uint32_t nq, const double *items, uint32_t n, uint32_t K,
-                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
-  return stream_scan<SearchScorePolicy>(ctx, "search_stream_scan", queries, q_ids, 0, nq, items, n, K, pol, out_key, out_idx, K, err_flag, redo);
+                       const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
+                       const StreamFilter *filter) {
+  return stream_scan<SearchScorePolicy>(ctx, "search_stream_scan", queries, q_ids, 0, nq, items, n, K, pol, out_key, out_idx, K, err_flag, redo,
+                                        filter);
 }
 int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
                       const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {

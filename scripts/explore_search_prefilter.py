@@ -37,15 +37,24 @@ ks = list(res)
 for k in ks[1:]:
     print("identical to the unordered scan:", k, np.array_equal(res[ks[0]][0], res[k][0]), np.array_equal(res[ks[0]][1], res[k][1]))
 
-# small batches on the last index (ordered + first pass) against the streaming scan
-for b in (1, 8, 32, 128):
-    for staged in (1000000, 1):
-        ctx.set_option("search_staged_min_batch", staged)
+# small batches: the streaming scan with and without the int8 filter (the index has been searched before)
+for b in (1, 8, 32):
+    for flt in (0, 1):
+        ctx.set_option("search_stream_filter", flt)
         Qb, lb = Q[:b].contiguous(), lq[:b].contiguous()
         for rep in range(3): out = asp.search_lambda_aware_batch(Qb, lb, 10, 0.7)
+        ctx.profile(True)
+        out = asp.search_lambda_aware_batch(Qb, lb, 10, 0.7)
+        prof = ctx.profile_all()
+        print("   ", {k: round(v[0], 3) for k, v in prof.items()})
+        ctx.profile(False)
         torch.cuda.synchronize(); t0 = time.time()
         for rep in range(20): out = asp.search_lambda_aware_batch(Qb, lb, 10, 0.7)
         torch.cuda.synchronize(); t1 = time.time()
         oi = out[0].cpu().numpy() if torch.is_tensor(out[0]) else np.asarray(out[0])
-        print("nq=%d %s: %.3f ms per batch (stream scan used: %d)  same as the big batch: %s" % (
-            b, "staged" if staged == 1 else "stream", (t1 - t0) / 20 * 1e3, ctx.stat("search_stream_scan"), np.array_equal(oi, res[ks[0]][0][:b])), flush=True)
+        osc = out[1].cpu().numpy() if torch.is_tensor(out[1]) else np.asarray(out[1])
+        print("nq=%d filter=%d: %.3f ms per batch (stream %d filter %d items kept %d overflow %d retries %d)  same as the big batch: %s %s" % (
+            b, flt, (t1 - t0) / 20 * 1e3, ctx.stat("search_stream_scan"), ctx.stat("stream_scan_filter"), ctx.stat("stream_scan_filter_items"),
+            ctx.stat("stream_scan_filter_overflow"), ctx.stat("stream_scan_retries"), np.array_equal(oi, res[ks[0]][0][:b]),
+            np.array_equal(osc, res[ks[0]][1][:b])), flush=True)
+ctx.set_option("search_stream_filter", 1)

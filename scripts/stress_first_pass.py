@@ -37,7 +37,7 @@ for c in range(cases):
     bad += 0 if ok else 1
     print("join n=%d d=%d topk=%d eps=%.1f kind=%d mode=%d used=%d rotated=%d join=%d: %s" % (n, d, topk, eps, kind, mode, used, rot, ctx.stat("knn_join"), "ok" if ok else "MISMATCH"), flush=True)
 for c in range(max(2, cases // 6)):
-    n = int(rng.integers(66000, 180000)); d = int(rng.choice([33, 64, 100, 128])); nq = int(rng.integers(1, 6000)); k = int(rng.integers(1, 30))
+    n = int(rng.integers(66000, 180000)); d = int(rng.choice([33, 64, 128, 128, 128])); nq = int(rng.integers(40, 6000)); k = int(rng.integers(1, 30))
     alpha = float(rng.choice([0.2, 0.7, 1.0]))
     X, _ = synth.mixture(n, d, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.integers(2, 80)), rank=int(rng.integers(1, 9)))
     lam = rng.random(n); qi = rng.integers(0, n, nq); Q = X[qi] * 1.01 + rng.normal(size=(nq, d)) * 0.01; lq = lam[qi] + rng.normal(size=nq) * 0.03
@@ -49,6 +49,13 @@ for c in range(max(2, cases // 6)):
         st = (ctx.stat("search_scan"), ctx.stat("search_scan_order"), ctx.stat("search_scan_prefilter"))
     ctx.set_option("search_scan_order", 1); ctx.set_option("search_prefilter", 1)
     ok = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    if d == 128 and k <= 64:  # small batches on the index searched before: the int8 filter of the streaming scan
+        for b in (1, int(rng.integers(2, 33))):
+            o = int(rng.integers(0, max(1, nq - b)))
+            sm = asp.search_lambda_aware_batch(Q[o:o + b], lq[o:o + b], k, alpha)
+            bb = min(b, nq - o)
+            ok = ok and np.array_equal(res[0][0][o:o + bb], sm[0]) and np.array_equal(res[0][1][o:o + bb], sm[1])
+            st = st + (ctx.stat("search_stream_scan"), ctx.stat("stream_scan_filter"), ctx.stat("stream_scan_filter_items"))
     bad += 0 if ok else 1
     print("search n=%d d=%d nq=%d k=%d alpha=%.1f scan/order/prefilter=%s: %s" % (n, d, nq, k, alpha, st, "ok" if ok else "MISMATCH"), flush=True)
 print("mismatches:", bad)

@@ -928,6 +928,19 @@ def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
     finally:
         ctx.set_option("search_staged_min_batch", 1 << 30)
     assert np.array_equal(idx1[:37], idx4) and np.array_equal(sc1[:37], sc4)
+    if d == 128:  # small batches on an index searched before: the int8 filter in front of the streaming scan (stream_scan.hip)
+        for b in (1, 7, 32):
+            idx6, sc6 = asp.search_lambda_aware_batch(Q[100:100 + b], lq[100:100 + b], k, alpha)
+            assert ctx.stat("search_stream_scan") == 1 and ctx.stat("stream_scan_filter") == 1
+            assert 0 < ctx.stat("stream_scan_filter_items") < n * b // 4 and ctx.stat("stream_scan_filter_overflow") == 0
+            assert np.array_equal(idx1[100:100 + b], idx6) and np.array_equal(sc1[100:100 + b], sc6)
+        ctx.set_option("search_stream_filter", 0)
+        try:
+            idx7, sc7 = asp.search_lambda_aware_batch(Q[:9], lq[:9], k, alpha)
+            assert ctx.stat("search_stream_scan") == 1 and ctx.stat("stream_scan_filter") == 0
+        finally:
+            ctx.set_option("search_stream_filter", 1)
+        assert np.array_equal(idx1[:9], idx7) and np.array_equal(sc1[:9], sc7)
     ctx.set_option("search_scan_order", 2)
     ctx.set_option("search_prefilter", 0)
     try:
