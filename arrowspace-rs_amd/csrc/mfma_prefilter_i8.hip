@@ -244,6 +244,50 @@ __global__ void i8_block_min_kernel(const int *__restrict__ thr, uint64_t blocks
   out[b] = m;
 }
 
+// The same image for a handful of rows (the queries of a small batch: a thread per row takes 60 us of dependent loads for one
+// row): a wave per row, lane l holds columns l and l + 64, the directions straight from L2.  dim <= 128.
+__global__ __launch_bounds__(64) void rotate_pack_i8_few_kernel(const double *__restrict__ R, const double *__restrict__ norms,
+                                                                const uint32_t *__restrict__ perm, uint32_t n, uint32_t d,
+                                                                const float *__restrict__ Q /* [32][128] */, i32x4 *__restrict__ P8,
+                                                                unsigned int *__restrict__ err_bits) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  float x0 = 0.f, x1 = 0.f;
+  bool live = false;
+  if (p < n) {
+    const uint64_t row = perm ? perm[p] : p;
+    const double nr = norms[row];
+    live = nr > 0.0 && nr < __builtin_inf();
+    if (live && lane < d) x0 = (float)(R[row * d + lane] / nr);
+    if (live && lane + 64 < d) x1 = (float)(R[row * d + lane + 64] / nr);
+    x0 = x0 == x0 ? x0 : 0.f;
+    x1 = x1 == x1 ? x1 : 0.f;
+  }
+  float zz = 0.f, e2 = 0.f;
+  int mine = 0;  // lane j < 31: q_j, lane 31: the tail
+  for (int j = 0; j < kRotDims; ++j) {
+    float a = __builtin_fmaf(x0, Q[j * 128 + lane], x1 * Q[j * 128 + 64 + lane]);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    zz = __builtin_fmaf(a, a, zz);
+    const int q8 = quantise(a, 127.f);
+    const float e = (float)q8 * (1.f / 127.f) - a;
+    e2 = __builtin_fmaf(e, e, e2);
+    if ((int)lane == j) mine = q8;
+  }
+  if (lane == kRotDims && live) mine = (int)__builtin_fminf(__builtin_ceilf(__builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) * 127.f), 127.f);
+  // bytes 0 .. 31 of the row = lanes 0 .. 31; words of four
+  uint32_t w = ((uint32_t)mine & 0xFFu) << (8 * (lane & 3));
+  w |= __shfl_xor(w, 1, 64);
+  w |= __shfl_xor(w, 2, 64);  // lanes 4 k .. 4 k + 3 hold word k
+  const uint32_t w0 = __shfl(w, 0, 64), w1 = __shfl(w, 4, 64), w2 = __shfl(w, 8, 64), w3 = __shfl(w, 12, 64);
+  const uint32_t w4 = __shfl(w, 16, 64), w5 = __shfl(w, 20, 64), w6 = __shfl(w, 24, 64), w7 = __shfl(w, 28, 64);
+  if (lane == 0) {
+    const size_t v = ((size_t)(p >> 7) * 4 + ((p >> 5) & 3)) * 64 + (p & 31);
+    P8[v] = i32x4{(int)w0, (int)w1, (int)w2, (int)w3};
+    P8[v + 32] = i32x4{(int)w4, (int)w5, (int)w6, (int)w7};
+    atomicMax(err_bits, __float_as_uint(__builtin_sqrtf(e2) * (1.f + 1e-6f)));
+  }
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
 template <int OFF>
 __device__ __forceinline__ void lds_read16(i32x4 &dst, uint32_t addr) {
@@ -809,6 +853,11 @@ int rotated_image_pack_async(as_ctx *ctx, const double *rows, const double *norm
                              const float *Qd, void *P8, uint32_t tiles, unsigned int *err_bits_dev) {
   struct { unsigned int *p; } bits{err_bits_dev};  // (atomicMax into it: zeroed by the caller)
   const uint32_t positions = tiles * kTileRows;
+  if (positions <= 512) {  // a small batch of queries: a wave per position (the thread-per-row form is latency-bound there)
+    hipLaunchKernelGGL(rotate_pack_i8_few_kernel, dim3(positions), dim3(64), 0, ctx->stream, rows, norms, perm, n, d, Qd, (i32x4 *)P8, bits.p);
+    AS_HIP(ctx, hipGetLastError());
+    return AS_OK;
+  }
 #define AS_ROT(DPV)                                                                                                          \
   hipLaunchKernelGGL(rotate_pack_i8_kernel<DPV>, dim3(cdiv(positions, 256)), dim3(256), 0, ctx->stream, rows, norms, perm, n, d, \
                      positions, Qd, (i32x4 *)P8, bits.p)

@@ -552,32 +552,33 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   const uint32_t cap = kSsSortMax;
   DevBuf<double> guess, lkey;
   DevBuf<unsigned long long> smin;
-  DevBuf<uint32_t> cnt, lidx;
-  DevBuf<int> over, done;
+  DevBuf<uint32_t> lidx;
+  // one block for the small zeroed arrays (one memset): cnt[nA] | over[nA + 2] | done[nA] | the queries' image error
+  DevBuf<uint32_t> small;
+  struct { uint32_t *p; } cnt{nullptr};
+  struct { int *p; } over{nullptr}, done{nullptr};
+  struct { unsigned int *p; } q_err{nullptr};
   std::vector<int> h(nA + 2);  // [nA], [nA + 1]: the filter's count and overflow flag (one copy back for all of it)
   int64_t retries = 0;
-  AS_TRY(done.alloc(ctx, nA));
   AS_TRY(smin.alloc(ctx, (size_t)nA * kSsShares));
   AS_TRY(guess.alloc(ctx, nA));
-  AS_TRY(cnt.alloc(ctx, nA));
   AS_TRY(lidx.alloc(ctx, (size_t)nA * cap));
   AS_TRY(lkey.alloc(ctx, (size_t)nA * cap));
-  AS_TRY(over.alloc(ctx, nA + 2));
-  AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * nA, ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(over.p, 0, sizeof(int) * (nA + 2), ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(done.p, 0, sizeof(int) * nA, ctx->stream));
+  AS_TRY(small.alloc(ctx, (size_t)3 * nA + 3));
+  AS_HIP(ctx, hipMemsetAsync(small.p, 0, sizeof(uint32_t) * ((size_t)3 * nA + 3), ctx->stream));
+  cnt.p = small.p;
+  over.p = reinterpret_cast<int *>(small.p + nA);
+  done.p = reinterpret_cast<int *>(small.p + 2 * nA + 2);
+  q_err.p = small.p + 3 * nA + 2;
   // the int8 filter in front of the list pass (search on an index that keeps a rotated image)
   DevBuf<uint32_t> g_pairs;
   DevBuf<unsigned char> pq8;
-  DevBuf<unsigned int> q_err;
   uint32_t *const g_count = reinterpret_cast<uint32_t *>(over.p + nA);
   int *const g_over = over.p + nA + 1;
   const uint32_t g_cap = 1u << 20;
   if (filter) {
     AS_TRY(g_pairs.alloc(ctx, g_cap));
     AS_TRY(pq8.alloc(ctx, rotated_image_bytes(1)));
-    AS_TRY(q_err.alloc(ctx, 1));
-    AS_HIP(ctx, hipMemsetAsync(q_err.p, 0, sizeof(unsigned int), ctx->stream));
   }
   const int nbuf = nA <= 8 ? 3 : 2;  // a third tile in flight per wave while the A rows leave the LDS for it
   const size_t lds = (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)kSsWaves * nbuf * kSsTileBytes;
