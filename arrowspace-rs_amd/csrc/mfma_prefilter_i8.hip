@@ -548,8 +548,10 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_kernel(const i32x4 *
 // accumulators), and the column thresholds read by hand -- a compiler-generated LDS read would wait for the pending DMA.
 // RECT: the one-sided form of the search scan -- the rows are those of a second image PA (the queries: I_count super tiles of
 // it, thresholds thr_a by their position), every one of which meets every column super tile of P8; no column side.
-template <int KS8, bool RECT>
-__global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const i32x4 *__restrict__ P8, const i32x4 *__restrict__ PA,
+// OCC4: one accumulator set (the test of a block right behind its MFMAs) in 128 registers, so that two workgroups share a CU:
+// four waves per SIMD instead of two interleave by themselves and cover each other's barriers.
+template <int KS8, bool RECT, bool OCC4 = false>
+__global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_kernel(const i32x4 *__restrict__ P8, const i32x4 *__restrict__ PA,
                                                                           const int *__restrict__ thr_a, uint32_t T2, uint32_t I_begin,
                                                                           uint32_t I_count, uint32_t W, uint32_t n,
                                                                           const int *__restrict__ thr, const int *__restrict__ thr_min,
@@ -701,14 +703,13 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
           if (!diag && !__any(hit)) {
             int tc;
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tc) : "v"(t_addr + (uint32_t)nn * 128u) : "memory");
-            if (tc < kNever) {
-              v16i32 v0, v1;
+            if (tc < kNever) {  // (rare path, written for few live registers: a running maximum, no second set of 32 values)
+              int mv = x0[0] - nth0[0];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                v0[r] = x0[r] - nth0[r];
-                v1[r] = x1[r] - nth1[r];
-              }
-              hit = hit || max16(v0) >= tc || max16(v1) >= tc;
+              for (int r = 1; r < 16; ++r) mv = max(mv, x0[r] - nth0[r]);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mv = max(mv, x1[r] - nth1[r]);
+              hit = hit || mv >= tc;
             }
           }
           if (__any(hit)) {
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
             constexpr int f = b * KS8 + ks;
             lds_read16<frag_off(f + 3)>(fa[(f + 3) & 3], base);
             lds_wait1<3>(fa[f & 3]);
-            if constexpr ((b & 1) == 0) {
+            if constexpr (OCC4 || (b & 1) == 0) {
               xa0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[ks], fa[f & 3], ks == 0 ? nth0 : xa0, 0, 0, 0);
               xa1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[ks], fa[f & 3], ks == 0 ? nth1 : xa1, 0, 0, 0);
             } else {
@@ -739,8 +740,9 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
               xb1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[ks], fa[f & 3], ks == 0 ? nth1 : xb1, 0, 0, 0);
             }
           });
-          // the block before this one, in the shadow of the MFMAs just issued
-          if constexpr (b == 0) {
+          if constexpr (OCC4) {
+            test(4 * trip + b, xa0, xa1);
+          } else if constexpr (b == 0) {  // the block before this one, in the shadow of the MFMAs just issued
             if (trip > 0) test(4 * trip - 1, xb0, xb1);
           } else if constexpr ((b & 1) == 1) {
             test(4 * trip + b - 1, xa0, xa1);
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_narrow_kernel(const 
         });
         n_blk += 8;
       }
-      test(15, xb0, xb1);
+      if constexpr (!OCC4) test(15, xb0, xb1);
       if (lane < 2)
         mask[((size_t)(I - I_begin) * 2 * T2 + 2 * S + (uint32_t)lane) * 8 + wv] = (unsigned char)(bits >> (8 * lane));
       if (stamp) {
@@ -1070,11 +1072,19 @@ int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, 
 #define AS_PRE_NARROW(K)                                                                                                     \
   case K: {                                                                                                                  \
     const size_t lds_n = (size_t)2 * 4 * K * 4 * 64 * 16 + 2 * 512 * sizeof(int) + 2 * 64 * sizeof(int) + 8192;              \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K, false>,                                 \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                                \
-    hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K, false>), dim3(grid), dim3(512), lds_n, ctx->stream,               \
-                       (const i32x4 *)P8.p, (const i32x4 *)nullptr, (const int *)nullptr, T2, I_begin, I_count, W, n, thr.p,  \
-                       thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p);                                             \
+    if (!(ctx->opt_debug & 2048)) {  /* (debug bit 2048: the two-set form at one workgroup per CU) */                       \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K, false, true>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                              \
+      hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K, false, true>), dim3((unsigned)std::min<uint64_t>(units, 512u)), \
+                         dim3(512), lds_n, ctx->stream, (const i32x4 *)P8.p, (const i32x4 *)nullptr, (const int *)nullptr,   \
+                         T2, I_begin, I_count, W, n, thr.p, thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p);        \
+    } else {                                                                                                                 \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K, false>,                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                              \
+      hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K, false>), dim3(grid), dim3(512), lds_n, ctx->stream,             \
+                         (const i32x4 *)P8.p, (const i32x4 *)nullptr, (const int *)nullptr, T2, I_begin, I_count, W, n,      \
+                         thr.p, thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p);                                    \
+    }                                                                                                                        \
   } break;
     switch (KS8) {
       AS_PRE_NARROW(1) AS_PRE_NARROW(2) AS_PRE(3) AS_PRE(4)
