@@ -869,7 +869,19 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
                        (perm || image_perm || ctx->opt_join_prefilter_min_rows == 0);
       if (pre) {
         AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end - I_begin)));
-        AS_TRY(prefilter_i8(ctx, packedh, rows, norms, n, d, I_begin, I_end - I_begin, theta.p, mask.p, image_perm ? image_perm : perm));
+        if (rot_z) {  // the caller has the rotated coordinates of the rows (own join: they also gave the row order)
+          DevBuf<unsigned char> P8;
+          const uint32_t tiles = packed_tiles_f16(n);
+          double err = 0.0;
+          AS_TRY(P8.alloc(ctx, (size_t)tiles * 4 * 64 * 16));
+          {
+            ProfScope ps(ctx, "knn_join_prefilter_pack");
+            AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
+          }
+          AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p));
+        } else {
+          AS_TRY(prefilter_i8(ctx, packedh, rows, norms, n, d, I_begin, I_end - I_begin, theta.p, mask.p, image_perm ? image_perm : perm));
+        }
       }
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
       AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm,
@@ -1061,10 +1073,11 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
         wide_pre = ctx->opt_join_prefilter == 3 || tail <= 0.10;
       }
+      // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
       const bool reorder_wide = wide_pre && ctx->opt_join_row_order && n >= 65536;
       if (reorder || reorder_wide) {
         AS_TRY(perm_own.alloc(ctx, n));
-        if (reorder_narrow) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
+        if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
         else AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p));
         AS_TRY(theta_pos.alloc(ctx, n));
         AS_TRY(theta2_pos.alloc(ctx, n));
@@ -1096,9 +1109,17 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(inv_own.alloc(ctx, n));
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, perm_own.p, n, inv_own.p);
       }
-      AS_TRY(knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p, nullptr,
-                            P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr, reorder ? perm_own.p : nullptr,
-                            wide_pre ? rot_z.p : nullptr));
+      {
+        // (the directions were tried above and do not carry the rows: the first pass, if any, takes the full-width image without
+        // looking for them again)
+        const int64_t saved_mode = ctx->opt_join_prefilter;
+        if (rot_z.p && !wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
+        const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p,
+                                            nullptr, P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr,
+                                            reorder ? perm_own.p : nullptr, wide_pre ? rot_z.p : nullptr);
+        ctx->opt_join_prefilter = saved_mode;
+        if (rc_pairs != AS_OK) return rc_pairs;
+      }
       perm_used = reorder ? perm_own.p : nullptr;
       if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};

@@ -1,6 +1,6 @@
-// rotate_wide.hip -- the rotated coordinates of rows WIDER than 128 (mfma_prefilter_i8.hip: 31 dominant directions + the norm of
-// what is left bound the cosine of two unit rows from above by a 32-wide product), where a covariance matrix is no longer a
-// small thing to iterate on the host: the directions come from subspace iteration on a SAMPLE of the rows with both products on
+// rotate_wide.hip -- the rotated coordinates of the rows of the own join (mfma_prefilter_i8.hip: 31 dominant directions + the norm
+// of what is left bound the cosine of two unit rows from above by a 32-wide product).  Written for rows wider than 128, where a
+// covariance matrix is no longer a small thing to iterate on the host, and used from 33 columns on: the directions come from subspace iteration on a SAMPLE of the rows with both products on
 // the device -- Z = S Q (sample x 31), Y = S^T Z (dim x 31) -- and only the orthonormalisation of Y (dim x 31, f64) on the host.
 // The coordinates of all rows are kept (n x 32 doubles: z_0 .. z_30, tail norm t): the row order of the join's image is found on
 // them (cluster_order on 32 columns instead of dim), and the int8 image is packed from them once the order is known.
@@ -54,6 +54,49 @@ __global__ __launch_bounds__(256) void zproj_kernel(const double *__restrict__ R
     if (live) tails += (double)__builtin_fmaxf(1.f - zz, 0.f);
   }
   if (tail_sum && lane == 0 && tails != 0.0) atomicAdd(tail_sum, tails);
+}
+
+// the same for ALL rows up to 128 wide: a thread per row with the row in registers and the directions broadcast from LDS (the
+// 186 cross-lane shuffles per row of the wave-per-row form cost more than its coalesced loads save: 1.9 against 0.9 ms at 1 M x 128)
+template <int DP>  // row width padded to 32
+__global__ __launch_bounds__(256) void zproj_thread_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
+                                                           uint32_t d, const float *__restrict__ Q, uint32_t pitch,
+                                                           double *__restrict__ out, double *__restrict__ tail_sum) {
+  __shared__ float s_q[kDirs * DP];
+  for (int e = threadIdx.x; e < kDirs * DP; e += 256) s_q[e] = Q[(size_t)(e / DP) * pitch + (e % DP)];
+  __syncthreads();
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  double tails = 0.0;
+  if (row < n) {
+    const double nr = norms[row];
+    const bool live = nr > 0.0 && nr < __builtin_inf();
+    float x[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const float v = (live && (uint32_t)k < d) ? (float)(R[(uint64_t)row * d + k] / nr) : 0.f;
+      x[k] = v == v ? v : 0.f;
+    }
+    float zz = 0.f;
+    double *o = out + (size_t)row * 32;
+    for (int j = 0; j < kDirs; ++j) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < DP; k += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(&s_q[j * DP + k]);
+        a0 = __builtin_fmaf(x[k], q.x, a0);
+        a1 = __builtin_fmaf(x[k + 1], q.y, a1);
+        a2 = __builtin_fmaf(x[k + 2], q.z, a2);
+        a3 = __builtin_fmaf(x[k + 3], q.w, a3);
+      }
+      const float z = (a0 + a1) + (a2 + a3);
+      zz = __builtin_fmaf(z, z, zz);
+      o[j] = (double)z;
+    }
+    o[kDirs] = live ? (double)__builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.0;
+    if (live) tails = (double)__builtin_fmaxf(1.f - zz, 0.f);
+  }
+  for (int o2 = 32; o2 > 0; o2 >>= 1) tails += __shfl_xor(tails, o2, 64);
+  if (tail_sum && (threadIdx.x & 63) == 0 && tails != 0.0) atomicAdd(tail_sum, tails);
 }
 
 // Y[dir][k] += sum over the sample rows of z[row][dir] * u[row][k]   (Y: kDirs x pitch floats, zeroed by the caller)
@@ -142,7 +185,7 @@ int launch_zproj(as_ctx *ctx, uint32_t nv, unsigned grid, size_t lds, A... a) {
     hipLaunchKernelGGL(zproj_kernel<NV>, dim3(grid), dim3(256), lds, ctx->stream, a...);                                      \
     break;
   switch (nv) {
-    AS_Z(3) AS_Z(4) AS_Z(6) AS_Z(8) AS_Z(12) AS_Z(16)
+    AS_Z(1) AS_Z(2) AS_Z(3) AS_Z(4) AS_Z(6) AS_Z(8) AS_Z(12) AS_Z(16)
     default: return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
   }
 #undef AS_Z
@@ -152,7 +195,7 @@ int launch_zproj(as_ctx *ctx, uint32_t nv, unsigned grid, size_t lds, A... a) {
 
 }  // namespace
 
-bool rotated_wide_supported(uint32_t d) { return d > 128 && d <= kMaxWide; }
+bool rotated_wide_supported(uint32_t d) { return d > 32 && d <= kMaxWide; }  // (up to 32 wide the rows themselves are one k step)
 
 // Z: n x 32 doubles (device), znorm: n doubles (their norms, ~1): the rotated coordinates of all rows.  tail_out: the share of
 // the sample's energy outside the 31 directions (the caller decides whether the bound is worth using).
@@ -161,7 +204,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
   const uint32_t pitch = (d + 63) / 64 * 64;
   uint32_t nv = pitch / 64;  // round up to an instantiated width
-  for (uint32_t c : {3u, 4u, 6u, 8u, 12u, 16u})
+  for (uint32_t c : {1u, 2u, 3u, 4u, 6u, 8u, 12u, 16u})
     if (nv <= c) {
       nv = c;
       break;
@@ -217,8 +260,19 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   }
   AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(tsum.p, 0, sizeof(double), ctx->stream));
-  AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(n, 4), 256 * 8), lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p,
-                      pitch, Z, tsum.p));
+  if (d <= 128) {
+#define AS_ZT(DPV) hipLaunchKernelGGL(zproj_thread_kernel<DPV>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, rows, norms, n, d, (const float *)Qd.p, pitch, Z, tsum.p)
+    switch ((d + 31) / 32) {
+      case 2: AS_ZT(64); break;
+      case 3: AS_ZT(96); break;
+      default: AS_ZT(128); break;
+    }
+#undef AS_ZT
+    AS_HIP(ctx, hipGetLastError());
+  } else {
+    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(n, 4), 256 * 8), lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p,
+                        pitch, Z, tsum.p));
+  }
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
   double ts = 0.0;
