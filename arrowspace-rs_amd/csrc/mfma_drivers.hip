@@ -676,8 +676,9 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
-int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr);
-int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm);
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
+                  uint32_t n_pivots = 0);
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
@@ -1078,7 +1079,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       if (reorder || reorder_wide) {
         AS_TRY(perm_own.alloc(ctx, n));
         if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
-        else AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p));
+        else AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p, nullptr, (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots)));
         AS_TRY(theta_pos.alloc(ctx, n));
         AS_TRY(theta2_pos.alloc(ctx, n));
         reorder = true;

@@ -16,7 +16,9 @@ namespace asx {
 
 namespace {
 
-constexpr int kPivots = 256;
+constexpr int kPivots = 256;      // pivots of an order found on the rows themselves
+constexpr int kPivotsMax = 1024;  // ... on 32 rotated coordinates (a quarter of the arithmetic per pivot: csrc/rotate_wide.hip), where
+                                  // 1024 instead of 256 pivots leave the f16 pass of the join half the blocks
 constexpr int kPivotChunk = 32;  // pivots per LDS pass
 
 // unit pivots, f32, P x dp (dp = d rounded up to 4, zero padded)
@@ -33,7 +35,7 @@ __global__ void gather_pivots_kernel(const double *__restrict__ rows, const doub
 // zero or non-finite norm go to pivot 0).  One thread per row, the row in registers, pivots through LDS (broadcast reads).
 template <int DP>  // padded width, a multiple of 4, <= 128
 __global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__restrict__ rows, uint32_t n, uint32_t d,
-                                                            const float *__restrict__ piv, uint32_t *__restrict__ assign) {
+                                                            const float *__restrict__ piv, uint32_t *__restrict__ assign, int np) {
   __shared__ float s_piv[kPivotChunk * DP];
   const uint32_t row = blockIdx.x * 256 + threadIdx.x;
   float x[DP];
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__rest
   for (int k = 0; k < DP; ++k) x[k] = (row < n && (uint32_t)k < d) ? (float)rows[(size_t)row * d + k] : 0.f;
   float best = -__builtin_inff();
   uint32_t arg = 0;
-  for (int p0 = 0; p0 < kPivots; p0 += kPivotChunk) {
+  for (int p0 = 0; p0 < np; p0 += kPivotChunk) {
     __syncthreads();
     for (int e = threadIdx.x; e < kPivotChunk * DP; e += 256) s_piv[e] = piv[(size_t)p0 * DP + e];
     __syncthreads();
@@ -67,14 +69,14 @@ __global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__rest
 
 // stable counting sort by pivot, blocks of 256 rows: counts[c * n_blocks + b] -> (exclusive scan) -> positions
 __global__ __launch_bounds__(256) void order_count_kernel(const uint32_t *__restrict__ assign, uint32_t n, uint32_t n_blocks,
-                                                          uint32_t *__restrict__ counts) {
-  __shared__ uint32_t s_cnt[kPivots];
-  s_cnt[threadIdx.x] = 0;
+                                                          uint32_t *__restrict__ counts, int np) {
+  __shared__ uint32_t s_cnt[kPivotsMax];
+  for (int c = threadIdx.x; c < np; c += 256) s_cnt[c] = 0;
   __syncthreads();
   const uint32_t row = blockIdx.x * 256 + threadIdx.x;
   if (row < n) atomicAdd(&s_cnt[assign[row]], 1u);
   __syncthreads();
-  counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
+  for (int c = threadIdx.x; c < np; c += 256) counts[(size_t)c * n_blocks + blockIdx.x] = s_cnt[c];
 }
 __global__ __launch_bounds__(256) void order_place_kernel(const uint32_t *__restrict__ assign, uint32_t n, uint32_t n_blocks,
                                                           const uint64_t *__restrict__ offsets, uint32_t *__restrict__ perm) {
@@ -95,26 +97,27 @@ __global__ void scatter_f32_by_perm_kernel(const float *__restrict__ in, const u
   if (i < n) out[perm[i]] = in[i];
 }
 
-__global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids) {
+__global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids, uint32_t np) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < kPivots) ids[p] = (uint32_t)(((uint64_t)p * n) / kPivots + (((uint64_t)p * 2654435761ull) % (n / kPivots)));
+  if (p < np) ids[p] = (uint32_t)(((uint64_t)p * n) / np + (((uint64_t)p * 2654435761ull) % (n / np)));
 }
 
 }  // namespace
 
 // perm[pos] = row: the rows grouped by the nearest (by cosine) of 256 GIVEN unit pivots (piv: 256 rows of pitch = dim rounded up
 // to 32, f32, device), stable within a pivot.  Any n >= 1, dim <= 128.
-int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm) {
-  if (d > 128 || n == 0) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np) {
+  if (d > 128 || n == 0 || np == 0 || np > (uint32_t)kPivotsMax || np % kPivotChunk != 0)
+    return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
   const uint32_t dpv = (dp + 31) / 32 * 32;  // pitch of the pivots = the kernel's register count
   DevBuf<uint32_t> assign, counts;
   DevBuf<uint64_t> offsets;
   AS_TRY(assign.alloc(ctx, n));
-  AS_TRY(counts.alloc(ctx, (size_t)kPivots * n_blocks));
-  AS_TRY(offsets.alloc(ctx, (size_t)kPivots * n_blocks + 1));
+  AS_TRY(counts.alloc(ctx, (size_t)np * n_blocks));
+  AS_TRY(offsets.alloc(ctx, (size_t)np * n_blocks + 1));
 #define AS_ASSIGN(DPV)                                                                                                         \
-  hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p)
+  hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
   switch (dpv / 32) {
     case 1: AS_ASSIGN(32); break;
     case 2: AS_ASSIGN(64); break;
@@ -122,9 +125,9 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
     default: AS_ASSIGN(128); break;
   }
 #undef AS_ASSIGN
-  hipLaunchKernelGGL(order_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, counts.p);
+  hipLaunchKernelGGL(order_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, counts.p, (int)np);
   AS_HIP(ctx, hipGetLastError());
-  AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, (uint64_t)kPivots * n_blocks, offsets.p));
+  AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, (uint64_t)np * n_blocks, offsets.p));
   hipLaunchKernelGGL(order_place_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, offsets.p, perm);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
@@ -133,23 +136,27 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 
 // perm[pos] = row: the rows grouped by their nearest pivot (device array of n), the pivots being 256 of the rows themselves.
 // dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
-int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out) {
+// n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 64 rows or more).  piv_out: n_pivots x 128.
+int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
+                  uint32_t n_pivots) {
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
+  const uint32_t np = std::min<uint32_t>(std::max<uint32_t>(n_pivots ? n_pivots : (uint32_t)kPivots, 32u) / 32u * 32u,
+                                         std::min<uint32_t>((uint32_t)kPivotsMax, n / 64u / 32u * 32u));
   ProfScope ps(ctx, "knn_join_row_order");
   const uint32_t dp = (d + 3) / 4 * 4;
   DevBuf<uint32_t> ids;
   DevBuf<float> piv_own;
-  AS_TRY(ids.alloc(ctx, kPivots));
+  AS_TRY(ids.alloc(ctx, np));
   float *piv = piv_out;
   if (!piv) {
-    AS_TRY(piv_own.alloc(ctx, (size_t)kPivots * 128));
+    AS_TRY(piv_own.alloc(ctx, (size_t)np * 128));
     piv = piv_own.p;
   }
-  hipLaunchKernelGGL(order_pivot_ids_kernel, dim3(1), dim3(256), 0, ctx->stream, n, ids.p);
+  hipLaunchKernelGGL(order_pivot_ids_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ctx->stream, n, ids.p, np);
   const uint32_t dpv = (dp + 31) / 32 * 32;
-  hipLaunchKernelGGL(gather_pivots_kernel, dim3(kPivots), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
+  hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
   AS_HIP(ctx, hipGetLastError());
-  return order_by_pivots(ctx, rows, n, d, piv, perm);
+  return order_by_pivots(ctx, rows, n, d, piv, perm, np);
 }
 
 // out[perm[i]] = in[i], i < n

@@ -93,3 +93,26 @@ for m in (15, 31, 63):
         hit = Sb >= (torch.minimum(tp[r0:r0 + 64, None], tp[None, : nb * 32]) - dz)
         tot += hit.view(64, nb, 32).any(dim=2).any(dim=0).float().mean().item()
     print("   64x32 blocks flagged %.4f" % (tot / len(groups)))
+
+# ---- how the number of pivots of the row order (found on the 32 rotated coordinates) moves the share of flagged blocks ----
+m = 31
+Zall = U @ V[:, :m]
+tall = (1.0 - (Zall * Zall).sum(dim=1)).clamp_min(0).sqrt()
+ZT = torch.cat([Zall, tall[:, None]], dim=1)
+for npiv in (256, 512, 1024, 2048):
+    pid = torch.randperm(n, device="cuda", generator=g)[:npiv]
+    pz = ZT[pid]
+    asg = torch.empty(n, dtype=torch.long, device="cuda")
+    for a in range(0, n, 65536): asg[a:a + 65536] = (ZT[a:a + 65536] @ pz.T).argmax(dim=1)
+    pm = torch.argsort(asg, stable=True)
+    Zp = ZT[pm]; tpp = theta[pm]
+    stepz = 1.0 / 127.0
+    Zq = torch.cat([torch.round(Zp[:, :m] / stepz).clamp(-127, 127), torch.ceil(Zp[:, m:] / stepz).clamp(max=127)], dim=1) * stepz
+    Ez = (Zq[:, :m] - Zp[:, :m]).norm(dim=1).max(); dz = 2 * Ez + Ez * Ez
+    tot = 0.0
+    for gi in groups.tolist():
+        r0 = gi * 64
+        Sb = Zq[r0:r0 + 64] @ Zq[: nb * 32].T
+        hit = Sb >= (torch.minimum(tpp[r0:r0 + 64, None], tpp[None, : nb * 32]) - dz)
+        tot += hit.view(64, nb, 32).any(dim=2).any(dim=0).float().mean().item()
+    print("pivots %4d: 64x32 blocks flagged %.4f" % (npiv, tot / len(groups)))
