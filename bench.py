@@ -307,7 +307,7 @@ def main():
                                          "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
                                          "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak},
                             "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d over the measured time of the two "
-                                    "launches that replace its all-pairs loop. The first pass rules out ~94 % of the blocks on an 8-bit "
+                                    "launches that replace its all-pairs loop. The first pass rules out most of the blocks on an 8-bit "
                                     "upper bound of the cosine and every unordered pair is visited once, so frac is far above 1; the "
                                     "pipe utilisation of each kernel is under first_pass / f16_pass"}
             else:
