@@ -230,6 +230,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
   else if (n == "join_order_pivots") ctx->opt_join_order_pivots = value;
+  else if (n == "join_theta_grouped") ctx->opt_join_theta_grouped = value;
   else if (n == "search_scan_order") ctx->opt_search_scan_order = value;
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
   else if (n == "search_stream_filter") ctx->opt_search_stream_filter = value;

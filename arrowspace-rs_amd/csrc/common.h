@@ -73,6 +73,7 @@ struct as_ctx {
   int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
+  int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest groups
   int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 1024)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
                                    // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off
@@ -444,6 +445,11 @@ struct StreamFilter {
   const double *a_lams;
   const double *x_norms, *x_lams;
   double alpha;
+  // the item graph's leftover rows (GraphDistPolicy: key = 1 - cos): the image of the A rows is given (PQ8, with its error),
+  // P8 is in the order of the join's image (perm: position -> row)
+  const void *PQ8 = nullptr;
+  float err_a = 0.f;
+  const uint32_t *perm = nullptr;
 };
 int rotated_image_pack_async(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
                              const float *Qd, void *P8, uint32_t tiles, unsigned int *err_bits_dev);

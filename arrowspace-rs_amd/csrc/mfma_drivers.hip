@@ -316,6 +316,27 @@ __global__ void second_theta_kernel(const float *__restrict__ theta, const float
   out[i] = t;
 }
 
+// ... with thresholds computed afresh for the gathered rows (t1 / t2 by position in ids)
+__global__ void second_theta_fresh_kernel(const float *__restrict__ t1, const float *__restrict__ t2, const float *__restrict__ theta_first,
+                                          const uint32_t *__restrict__ cnt,
+                                          uint32_t n_src, uint32_t row_begin, uint32_t row_count, uint32_t cap,
+                                          const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded, float *__restrict__ out,
+                                          const uint32_t *__restrict__ inv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  float t = __builtin_inff();
+  if (i < count) {
+    const uint32_t g = ids[i], r = g - row_begin;
+    const uint32_t lr = inv ? inv[g] : r;
+    bool over = false;
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + lr] > cap;
+    // a list that ran over although the first threshold was the right one is a dense neighbourhood: the tight threshold and
+    // twice the room; one that ran over because the first threshold was far too low is an ordinary row: the looser threshold
+    t = (over && !(t1[i] - theta_first[g] > 1e-3f)) ? t1[i] : t2[i];
+  }
+  out[i] = t;
+}
+
 __global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) inv[perm[i]] = i;
@@ -650,7 +671,8 @@ int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids
                        const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
                        const StreamFilter *filter = nullptr);
 int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
-                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
+                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
+                      const StreamFilter *filter = nullptr);
 constexpr uint32_t kStreamRowsMax = 128;  // leftover rows up to this many take the streaming exact scan, 32 per pass
 
 int join_bf16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
@@ -677,8 +699,9 @@ uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
-                  uint32_t n_pivots = 0);
-int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256);
+                  uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr);
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
+                    uint32_t *group_start = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
@@ -717,6 +740,9 @@ int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_
 int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                          const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
                          uint32_t *cnt, uint32_t *cand, const char *prof_name);
+int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
+                                const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out);
@@ -1046,6 +1072,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   DevBuf<unsigned char> P16own, Phown;
   DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos;
   DevBuf<uint32_t> perm_own, inv_own;
+  bool grouped_theta = false;           // thresholds of the own join from the sample of the nearest pivot groups
+  DevBuf<double> rot_z, rot_norm;       // own join: the rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
+  DevBuf<float> order_piv;              // the pivots of the order found on them (np x 32), where the rows of each begin
+  DevBuf<uint32_t> order_starts;
+  uint32_t order_np = 0;
+  bool wide_pre = false;                // ... are in use (the directions carry the rows)
   const uint32_t *perm_used = nullptr;  // image position -> row of the own join's f16 image
   bool lists_by_pos = false;            // ... and whether the lists of the own join are indexed by (and hold) positions
   DevBuf<uint32_t> cnt_own, cand_own;
@@ -1062,8 +1094,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       bool reorder = reorder_narrow;
       // rows wider than 128 (up to 1024): their rotated coordinates (31 dominant directions + tail norm, rotate_wide.hip) serve
       // the int8 first pass and, being 32 wide, the row order as well
-      DevBuf<double> rot_z, rot_norm;
-      bool wide_pre = false;
+      wide_pre = false;
       if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
           n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
         ProfScope ps(ctx, "knn_join_prefilter_basis");
@@ -1079,7 +1110,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       if (reorder || reorder_wide) {
         AS_TRY(perm_own.alloc(ctx, n));
         if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
-        else AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p, nullptr, (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots)));
+        else {
+          AS_TRY(order_piv.alloc(ctx, (size_t)1024 * 128));
+          AS_TRY(order_starts.alloc(ctx, 1025));
+          AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p, order_piv.p,
+                               (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), order_starts.p, &order_np));
+        }
         AS_TRY(theta_pos.alloc(ctx, n));
         AS_TRY(theta2_pos.alloc(ctx, n));
         reorder = true;
@@ -1090,8 +1126,22 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
         AS_TRY(pack_f16_all(ctx, rows, norms, n, d, Phown.p, tiles, reorder ? perm_own.p : nullptr));
       }
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, nullptr,
-                                 reorder ? theta2_pos.p : theta2_own.p, &have_theta2, Phown.p));
+      // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
+      // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
+      if (reorder_wide && d <= 128 && order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 && !(ctx->opt_debug & 32) &&
+          ctx->opt_join_sample <= 0) {
+        const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
+        const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
+        AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, Phown.p, perm_own.p, order_starts.p, order_np, order_piv.p, 32, 32, m,
+                                           theta_pos.p, m2, theta2_pos.p));
+        have_theta2 = true;
+        grouped_theta = true;
+        ctx->stats["knn_join_theta_grouped"] = 1;
+      } else {
+        ctx->stats["knn_join_theta_grouped"] = 0;
+        AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, nullptr,
+                                   reorder ? theta2_pos.p : theta2_own.p, &have_theta2, Phown.p));
+      }
       if (reorder) {  // ... and go back to row order for everything behind the join
         AS_TRY(scatter_by_perm(ctx, theta_pos.p, perm_own.p, n, theta_own.p));
         if (have_theta2) AS_TRY(scatter_by_perm(ctx, theta2_pos.p, perm_own.p, n, theta2_own.p));
@@ -1396,8 +1446,27 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(failx.alloc(ctx, nf));
     if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
-    hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
-                       js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_by_pos ? inv_own.p : nullptr);
+    if (grouped_theta && second_h) {
+      // the thresholds of the first pass came from the sampled rows of the nearest pivot groups only; a row that is open after it
+      // may be one whose neighbours live elsewhere (a cluster without a pivot of its own), so the second pass takes thresholds
+      // against the whole sample for the few thousand rows it sweeps (PA is their f16 image)
+      const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
+      const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
+      const uint32_t ns = std::max(256u, (n / 32u) & ~255u);
+      DevBuf<uint32_t> sid;
+      DevBuf<float> t1, t2;
+      AS_TRY(sid.alloc(ctx, ns));
+      AS_TRY(t1.alloc(ctx, pad));
+      AS_TRY(t2.alloc(ctx, pad));
+      hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, n / ns, sample_half_bits(ns), sid.p);
+      AS_TRY(join_thresholds_f16(ctx, rows, norms, d, PA.p, 0, nf, sid.p, ns, m, t1.p, m2, t2.p));
+      hipLaunchKernelGGL(second_theta_fresh_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, (const float *)t1.p, (const float *)t2.p,
+                         js->theta, js->cnt, js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p,
+                         lists_by_pos ? inv_own.p : nullptr);
+    } else {
+      hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
+                         js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_by_pos ? inv_own.p : nullptr);
+    }
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(fail_count.p, 0, sizeof(uint32_t), ctx->stream));
@@ -1453,10 +1522,32 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(fk.alloc(ctx, (size_t)cur_n * K));
     AS_TRY(fi.alloc(ctx, (size_t)cur_n * K));
     std::vector<uint32_t> redo_all;
+    // with the rotated coordinates of the own join at hand the list pass of the scan is the int8 filter + the pairs it leaves
+    // (stream_scan.hip): the image of all rows and of each batch are packed from the coordinates
+    DevBuf<unsigned char> f_p8, f_q8;
+    StreamFilter flt{};
+    bool use_flt = false;
+    if (wide_pre && rot_z.p && d == 128 && ctx->opt_search_stream_filter && n < (1u << 27)) {
+      const uint32_t tiles = packed_tiles_f16(n);
+      double e_items = 0.0;
+      AS_TRY(f_p8.alloc(ctx, (size_t)tiles * 4 * 64 * 16));
+      AS_TRY(f_q8.alloc(ctx, (size_t)4 * 64 * 16));
+      AS_TRY(pack_rotated_from_z(ctx, rot_z.p, nullptr, n, tiles, f_p8.p, &e_items));
+      flt.P8 = f_p8.p;
+      flt.err_items = (float)(e_items * (1.0 + 1e-6));
+      use_flt = true;
+    }
     for (uint32_t c0 = 0; c0 < cur_n; c0 += 32) {
       const uint32_t cn = std::min<uint32_t>(32, cur_n - c0);
       std::vector<uint32_t> redo;
-      AS_TRY(stream_scan_graph(ctx, rows, cur_ids + c0, cn, n, K, pol, fk.p + (size_t)c0 * K, fi.p + (size_t)c0 * K, err.p, &redo));
+      if (use_flt) {
+        double e_a = 0.0;
+        AS_TRY(pack_rotated_from_z(ctx, rot_z.p, cur_ids + c0, cn, 1, f_q8.p, &e_a));
+        flt.PQ8 = f_q8.p;
+        flt.err_a = (float)(e_a * (1.0 + 1e-6));
+      }
+      AS_TRY(stream_scan_graph(ctx, rows, cur_ids + c0, cn, n, K, pol, fk.p + (size_t)c0 * K, fi.p + (size_t)c0 * K, err.p, &redo,
+                               use_flt ? &flt : nullptr));
       for (uint32_t r : redo) redo_all.push_back(c0 + r);
     }
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)cur_n * K, 256)), dim3(256), 0, ctx->stream, cur_pos, cur_n, K, fk.p,

@@ -64,7 +64,7 @@ __global__ void pack_f16_kernel(const double *__restrict__ R, const double *__re
   f16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-  if (row < n) {
+  if (row < n && !(row_ids && row_ids[row] == 0xFFFFFFFFu)) {  // (an id of ~0: an empty slot, a zero row)
     const uint64_t src = row_ids ? row_ids[row] : row0 + row;
     const double nr = norms[src];
     if (nr > 0.0) {

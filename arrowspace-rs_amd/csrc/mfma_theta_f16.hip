@@ -53,7 +53,11 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
                                                            uint32_t row_count, const f16x8 *__restrict__ PS,
                                                            uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
                                                            uint32_t m2, float *__restrict__ theta2_out,
-                                                           uint32_t *__restrict__ unit_counter) {
+                                                           uint32_t *__restrict__ unit_counter,
+                                                           const uint32_t *__restrict__ unit_groups) {
+  // unit_groups (2 per unit: first and last pivot group of its 256 image positions): the sample is not one image for all rows
+  // but s_tiles tiles per GROUP (the sampled rows of the groups nearest to it: join_thresholds_f16_grouped), and a unit sweeps
+  // those of the groups it covers.
   constexpr bool SEARCH = false;
   constexpr int kTileVecs = KS * 4 * 64;  // 16-B vectors of a 128-row tile (one plane)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,8 +69,9 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
 
   // 128-row sample tile J -> LDS: 4 KS pieces of 1 KB, piece p by wave p mod 8; part < 0: all of a wave's pieces, else
   // those that go with block `part` of the tile before
+  const f16x8 *PSc = PS;  // the sample image of the current sweep
   auto stage = [&](uint32_t J, int buf, int part) {
-    const f16x8 *src = PS + (size_t)J * kTileVecs;
+    const f16x8 *src = PSc + (size_t)J * kTileVecs;
     f16x8 *dst = bufB + (size_t)buf * kTileVecs;
 #pragma unroll
     for (int i = 0; i < (4 * KS + 7) / 8; ++i) {
@@ -136,7 +141,10 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending
 
-    __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring)
+    const uint32_t g_lo = unit_groups ? unit_groups[2 * I] : 0u, g_hi = unit_groups ? unit_groups[2 * I + 1] : 0u;
+    for (uint32_t g = g_lo; g <= g_hi; ++g) {
+    if (unit_groups) PSc = PS + (size_t)g * s_tiles * kTileVecs;
+    __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring); the sweep before with its buffers
     stage(0, 0, -1);
     __syncthreads();
     const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
@@ -185,7 +193,11 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
 #undef AS_READ
     // the last block of the sweep (bin 1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rmax[1][r] = __builtin_fmaxf(rmax[1][r], value(accB[r], r));
+    for (int r = 0; r < 16; ++r) {
+      rmax[1][r] = __builtin_fmaxf(rmax[1][r], value(accB[r], r));
+      accA[r] = accB[r] = -__builtin_inff();  // nothing pending for the next sweep
+    }
+    }
 
     // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row][parity * 32 + lane column]
     float *wm = s_max + (size_t)wv * 32 * 65;
@@ -225,6 +237,96 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
   }
 }
 
+// ---- the sample by pivot group (own join with the row order found on the rotated coordinates, row_order.hip) -------------------
+// The 4th best product of a row against a 1-in-32 sample of all rows is a product with a row of its own cluster: with the
+// image ordered by 1024 pivots, restricting a row's sample to the sampled rows of the 16 pivot groups nearest to its own
+// moves the threshold of 0.5 % of the rows by more than 1e-3 and of none by 1e-2 (scripts/explore_theta_window.py) -- and
+// any threshold is correct -- for 1.7 % of the products.  So every group gets its own small sample image (the sampled rows
+// of its nearest groups, kGroupTiles tiles, zero rows beyond), and a unit sweeps the images of the groups it covers.
+constexpr uint32_t kGroupNear = 16, kGroupTiles = 4, kGroupSlots = kGroupTiles * 128;
+
+// near[g][0 .. 16): the pivots most similar to pivot g (itself first).  piv: np x pitch floats.
+__global__ __launch_bounds__(256) void near_groups_kernel(const float *__restrict__ piv, uint32_t pitch, uint32_t dim, uint32_t np,
+                                                          uint32_t *__restrict__ near) {
+  __shared__ float s_sim[1024];
+  __shared__ float s_best[256];
+  __shared__ uint32_t s_at[256];
+  const uint32_t g = blockIdx.x;
+  for (uint32_t h = threadIdx.x; h < np; h += 256) {
+    float a = 0.f;
+    for (uint32_t k = 0; k < dim; ++k) a = __builtin_fmaf(piv[(size_t)g * pitch + k], piv[(size_t)h * pitch + k], a);
+    s_sim[h] = h == g ? __builtin_inff() : a;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < kGroupNear; ++k) {
+    float best = -__builtin_inff();
+    uint32_t at = 0xFFFFFFFFu;
+    for (uint32_t h = threadIdx.x; h < np; h += 256)
+      if (s_sim[h] > best) {
+        best = s_sim[h];
+        at = h;
+      }
+    s_best[threadIdx.x] = best;
+    s_at[threadIdx.x] = at;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o && (s_best[threadIdx.x + o] > s_best[threadIdx.x] ||
+                                   (s_best[threadIdx.x + o] == s_best[threadIdx.x] && s_at[threadIdx.x + o] < s_at[threadIdx.x]))) {
+        s_best[threadIdx.x] = s_best[threadIdx.x + o];
+        s_at[threadIdx.x] = s_at[threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      near[(size_t)g * kGroupNear + k] = s_at[0];
+      if (s_at[0] != 0xFFFFFFFFu) s_sim[s_at[0]] = -__builtin_inff();
+    }
+    __syncthreads();
+  }
+}
+
+// ids[g][slot]: the sampled rows (one image position in 32, hashed) of the groups near g, ~0 beyond; one thread per group
+__global__ void group_sample_ids_kernel(const uint32_t *__restrict__ near, const uint32_t *__restrict__ group_start, uint32_t np,
+                                        const uint32_t *__restrict__ perm, uint32_t *__restrict__ ids) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= np) return;
+  uint32_t *out = ids + (size_t)g * kGroupSlots;
+  uint32_t at = 0;
+  for (uint32_t k = 0; k < kGroupNear && at < kGroupSlots; ++k) {
+    const uint32_t h = near[(size_t)g * kGroupNear + k];
+    if (h >= np) continue;
+    const uint32_t lo = group_start[h], hi = group_start[h + 1];
+    for (uint32_t j = lo / 32; j * 32 < hi && at < kGroupSlots; ++j) {
+      uint32_t x = j * 0x9E3779B9u;
+      x ^= x >> 15;
+      x *= 0x85EBCA6Bu;
+      x ^= x >> 13;
+      const uint32_t p = j * 32 + (x & 31u);
+      if (p >= lo && p < hi) out[at++] = perm[p];
+    }
+  }
+  for (; at < kGroupSlots; ++at) out[at] = 0xFFFFFFFFu;
+}
+
+// first and last pivot group of the 256 image positions of every unit
+__global__ void unit_groups_kernel(const uint32_t *__restrict__ group_start, uint32_t np, uint32_t n, uint32_t units,
+                                   uint32_t *__restrict__ out) {
+  const uint32_t I = blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= units) return;
+  auto group_of = [&](uint32_t p) -> uint32_t {  // the last g with group_start[g] <= p
+    uint32_t lo = 0, hi = np;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) / 2;
+      if (group_start[mid] <= p) lo = mid;
+      else hi = mid;
+    }
+    return lo;
+  };
+  const uint32_t p0 = min(I * 256u, n - 1), p1 = min(I * 256u + 255u, n - 1);
+  out[2 * I] = group_of(p0);
+  out[2 * I + 1] = group_of(p1);
+}
+
 }  // namespace
 
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
@@ -257,7 +359,7 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   case K:                                                                                                                    \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA, a_supers, row_count,              \
-                       (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p);                                 \
+                       (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)nullptr);      \
     break;
   switch (KS) {
     AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
@@ -266,6 +368,49 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
 #undef AS_THETA
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sample image goes back to the workspace cache
+  return AS_OK;
+}
+
+// The same for ALL rows of an image ordered by pivot groups (perm: image position -> row; group_start: np + 1 positions; piv:
+// the np pivots, `piv_dim` coordinates of pitch `piv_pitch`): thresholds by image position against the sampled rows of the 16
+// groups nearest to a row's own.
+int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
+                                const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
+  const uint32_t a_supers = (n + 255) / 256;
+  DevBuf<unsigned char> PS;
+  DevBuf<uint32_t> unitc, near, ids, ug;
+  AS_TRY(PS.alloc(ctx, packed_vecs_f16(np * kGroupTiles, d) * 16));
+  AS_TRY(near.alloc(ctx, (size_t)np * kGroupNear));
+  AS_TRY(ids.alloc(ctx, (size_t)np * kGroupSlots));
+  AS_TRY(ug.alloc(ctx, (size_t)2 * a_supers));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  ProfScope ps(ctx, "knn_join_thresholds");
+  hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
+  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(cdiv(np, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm,
+                     ids.p);
+  hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, group_start, np, n, a_supers, ug.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
+  const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
+  const unsigned grid = std::min<uint32_t>(a_supers, 512u);
+#define AS_THETA(K)                                                                                                          \
+  case K:                                                                                                                    \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P_all, a_supers, n,    \
+                       (const f16x8 *)PS.p, kGroupTiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)ug.p);     \
+    break;
+  switch (KS) {
+    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  }
+#undef AS_THETA
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 

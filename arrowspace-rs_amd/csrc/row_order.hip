@@ -106,7 +106,16 @@ __global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids, u
 
 // perm[pos] = row: the rows grouped by the nearest (by cosine) of 256 GIVEN unit pivots (piv: 256 rows of pitch = dim rounded up
 // to 32, f32, device), stable within a pivot.  Any n >= 1, dim <= 128.
-int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np) {
+__global__ void order_group_starts_kernel(const uint64_t *__restrict__ offsets, uint32_t n_blocks, uint32_t np, uint32_t n,
+                                          uint32_t *__restrict__ out) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < np) out[g] = (uint32_t)offsets[(size_t)g * n_blocks];
+  if (g == np) out[g] = n;
+}
+
+// group_start (optional, np + 1 values, device): where the rows of every pivot begin in the order
+int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np,
+                    uint32_t *group_start) {
   if (d > 128 || n == 0 || np == 0 || np > (uint32_t)kPivotsMax || np % kPivotChunk != 0)
     return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
@@ -129,6 +138,8 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, (uint64_t)np * n_blocks, offsets.p));
   hipLaunchKernelGGL(order_place_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, offsets.p, perm);
+  if (group_start)
+    hipLaunchKernelGGL(order_group_starts_kernel, dim3(cdiv(np + 1, 256)), dim3(256), 0, ctx->stream, offsets.p, n_blocks, np, n, group_start);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
   return AS_OK;
@@ -137,8 +148,9 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 // perm[pos] = row: the rows grouped by their nearest pivot (device array of n), the pivots being 256 of the rows themselves.
 // dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
 // n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 64 rows or more).  piv_out: n_pivots x 128.
+// group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
-                  uint32_t n_pivots) {
+                  uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out) {
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t np = std::min<uint32_t>(std::max<uint32_t>(n_pivots ? n_pivots : (uint32_t)kPivots, 32u) / 32u * 32u,
                                          std::min<uint32_t>((uint32_t)kPivotsMax, n / 64u / 32u * 32u));
@@ -156,7 +168,8 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   const uint32_t dpv = (dp + 31) / 32 * 32;
   hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
   AS_HIP(ctx, hipGetLastError());
-  return order_by_pivots(ctx, rows, n, d, piv, perm, np);
+  if (np_out) *np_out = np;
+  return order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start);
 }
 
 // out[perm[i]] = in[i], i < n

@@ -151,7 +151,7 @@ typedef int ssf_v16i32 __attribute__((ext_vector_type(16)));
 // that pass, and still pass with the lambda term of the pair in place of its largest value, are queued as (query, item) pairs
 // for stream_pairs_kernel: ~0.4 % of all pairs.
 __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *__restrict__ P8, uint32_t n, const ssf_i32x4 *__restrict__ PQ8,
-                                                              uint32_t nq, const double *__restrict__ guess,
+                                                              uint32_t nq, const double *__restrict__ guess, double key_offset,
                                                               const double *__restrict__ q_lams, double alpha,
                                                               float err_items, const unsigned int *__restrict__ err_q_bits,
                                                               const double *__restrict__ x_lams, uint32_t cap,
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
     cutv[r] = __builtin_inf();
     qlv[r] = 0.0;
     if (a < nq) {
-      const double cut = -guess[a];
+      const double cut = key_offset - guess[a];  // the score (search: key = -score) / cosine (graph: key = 1 - cos) to reach
       cutv[r] = cut == cut ? cut : -__builtin_inf();
-      qlv[r] = q_lams[a];
+      qlv[r] = q_lams ? q_lams[a] : 0.0;
       // (a NaN or -inf cut -- fewer than K sampled keys -- lets everything through)
       const double x = __builtin_ceil((((cut - (1.0 - alpha)) / alpha) - delta8 - 1e-9) * (127.0 * 127.0));
       T = x == x ? (int)__builtin_fmax(__builtin_fmin(x, 536870911.0), -536870911.0) : -(1 << 29);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
       if (!__any(ok)) continue;
       if (*qn_p + 1024 > kQ) flush();  // (wave-uniform: every lane reads the same word)
       if (ok) {  // the lambda term as the score computes it, in place of its largest value 1 (rare path: a few lanes)
-        const double lx = x_lams[j];
+        const double lx = x_lams ? x_lams[j] : 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (acc[r] < 0) continue;
@@ -245,8 +245,10 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
 // The exact keys of the pairs the filter left: one lane per (query, item) pair, the reference's chain over k (multiply and add
 // rounded separately, k ascending: src/core.rs:185-197) with the query rows in LDS; keys at or below the query's cut are listed
 // for stream_final_kernel exactly as the list pass of the streaming scan lists them.
-__global__ __launch_bounds__(256) void stream_pairs_kernel(const double *__restrict__ A, uint32_t nA, const double *__restrict__ B,
-                                                          SearchScorePolicy pol, const uint32_t *__restrict__ pairs,
+template <class Policy>
+__global__ __launch_bounds__(256) void stream_pairs_kernel(const double *__restrict__ A, const uint32_t *__restrict__ a_ids, uint32_t nA,
+                                                          const double *__restrict__ B, const uint32_t *__restrict__ perm, Policy pol,
+                                                          const uint32_t *__restrict__ pairs,
                                                           const uint32_t *__restrict__ count, const int *__restrict__ overflow,
                                                           const double *__restrict__ guess, uint32_t cap, uint32_t *__restrict__ cnt,
                                                           uint32_t *__restrict__ list_idx, double *__restrict__ list_key,
@@ -254,17 +256,21 @@ __global__ __launch_bounds__(256) void stream_pairs_kernel(const double *__restr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *sA = reinterpret_cast<double *>(smem);  // nA x 129 (the pad keeps the rows of different queries in different banks)
   if (*overflow) return;
-  for (uint32_t e = threadIdx.x; e < nA * kSsD; e += blockDim.x) sA[(e / kSsD) * 129 + (e % kSsD)] = A[e];
+  for (uint32_t e = threadIdx.x; e < nA * kSsD; e += blockDim.x) {
+    const uint32_t a = e / kSsD, k = e % kSsD;
+    sA[a * 129 + k] = A[(uint64_t)(a_ids ? a_ids[a] : a) * kSsD + k];
+  }
   __syncthreads();
   const uint32_t n_pairs = *count;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
-    const uint32_t w = pairs[p], a = w >> 27, j = w & 0x7FFFFFFu;
+    const uint32_t w = pairs[p], a = w >> 27, jpos = w & 0x7FFFFFFu;
+    const uint32_t j = perm ? perm[jpos] : jpos, ga = a_ids ? a_ids[a] : a;  // (the filter's image may be in a permuted order)
     const double *x = B + (uint64_t)j * kSsD, *qa = sA + a * 129;
     double acc = 0.0;
 #pragma unroll 8
     for (uint32_t k = 0; k < kSsD; ++k) acc = __dadd_rn(acc, __dmul_rn(qa[k], x[k]));
     double key;
-    if (pol.key(acc, a, j, key, err_flag) && key <= guess[a]) {
+    if (pol.key(acc, ga, j, key, err_flag) && key <= guess[a]) {
       const uint32_t pos = atomicAdd(cnt + a, 1u);
       if (pos < cap) {
         list_idx[(size_t)a * cap + pos] = j;
@@ -546,7 +552,7 @@ template <class Policy>
 static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, const uint32_t *a_ids, uint32_t a_begin, uint32_t nA,
                        const double *B, uint32_t nB, uint32_t K, Policy pol, double *out_key, uint32_t *out_idx, uint32_t out_ld,
                        int *err_flag, std::vector<uint32_t> *redo_pos, const StreamFilter *filter_in = nullptr) {
-  const StreamFilter *filter = (filter_in && !a_ids && a_begin == 0 && nB < (1u << 27)) ? filter_in : nullptr;  // (pairs: query << 27 | item)
+  const StreamFilter *filter = (filter_in && (filter_in->PQ8 || (!a_ids && a_begin == 0)) && nB < (1u << 27)) ? filter_in : nullptr;  // (pairs: query << 27 | item)
   const uint32_t n_tiles = (nB + kSsTile - 1) / kSsTile;
   const uint32_t n_stiles = (n_tiles + kSsSampleStride - 1) / kSsSampleStride;
   const uint32_t cap = kSsSortMax;
@@ -603,17 +609,22 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
     const unsigned g_s = std::min<uint32_t>(256, cdiv(n_stiles, kSsWaves));
     AS_SS(false, g_s)
     hipLaunchKernelGGL(stream_guess_kernel, dim3(nA), dim3(256), 0, ctx->stream, smin.p, K, guess.p);
-    if constexpr (std::is_same<Policy, SearchScorePolicy>::value) {
-      if (filter) {
-        ProfScope pf(ctx, "search_stream_filter");
+    if (filter) {
+      ProfScope pf(ctx, "search_stream_filter");
+      constexpr bool kSearch = std::is_same<Policy, SearchScorePolicy>::value;
+      const void *q_img = filter->PQ8;
+      if (!q_img) {
         AS_TRY(rotated_image_pack_async(ctx, A, filter->a_norms, a_ids, nA, kSsD, filter->Qd, pq8.p, 1, q_err.p));
-        hipLaunchKernelGGL(stream_filter_i8_kernel, dim3(256), dim3(256), 0, ctx->stream, (const ssf_i32x4 *)filter->P8, nB,
-                           (const ssf_i32x4 *)pq8.p, nA, (const double *)guess.p, filter->a_lams, filter->alpha, filter->err_items,
-                           (const unsigned int *)q_err.p, filter->x_lams, g_cap, g_count, g_pairs.p, g_over);
-        const size_t lds_p = (size_t)nA * 129 * sizeof(double);
-        hipLaunchKernelGGL(stream_pairs_kernel, dim3(256), dim3(256), lds_p, ctx->stream, A, nA, B, pol, (const uint32_t *)g_pairs.p,
-                           (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag);
+        q_img = pq8.p;
       }
+      hipLaunchKernelGGL(stream_filter_i8_kernel, dim3(256), dim3(256), 0, ctx->stream, (const ssf_i32x4 *)filter->P8, nB,
+                         (const ssf_i32x4 *)q_img, nA, (const double *)guess.p, kSearch ? 0.0 : 1.0, kSearch ? filter->a_lams : nullptr,
+                         kSearch ? filter->alpha : 1.0, std::max(filter->err_items, filter->err_a), (const unsigned int *)q_err.p,
+                         kSearch ? filter->x_lams : nullptr, g_cap, g_count, g_pairs.p, g_over);
+      const size_t lds_p = (size_t)nA * 129 * sizeof(double);
+      hipLaunchKernelGGL(stream_pairs_kernel<Policy>, dim3(256), dim3(256), lds_p, ctx->stream, A, a_ids, nA, B, filter->perm, pol,
+                         (const uint32_t *)g_pairs.p, (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p,
+                         lidx.p, lkey.p, err_flag);
     }
     AS_SS(true, 256u)
     hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
@@ -661,8 +672,10 @@ int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids
                                         filter);
 }
 int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t K,
-                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
-  return stream_scan<GraphDistPolicy>(ctx, "knn_stream_scan", rows, row_ids, 0, n_rows, rows, n, K, pol, out_key, out_idx, K, err_flag, redo);
+                      const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
+                      const StreamFilter *filter) {
+  return stream_scan<GraphDistPolicy>(ctx, "knn_stream_scan", rows, row_ids, 0, n_rows, rows, n, K, pol, out_key, out_idx, K, err_flag, redo,
+                                      filter);
 }
 
 }  // namespace asx
