@@ -337,6 +337,33 @@ __global__ void second_theta_fresh_kernel(const float *__restrict__ t1, const fl
   out[i] = t;
 }
 
+// the check of the grouped thresholds: rows perm[i * stride] (count of them), and how many have a grouped threshold more than
+// `slack` below the one against the whole sample
+__global__ void theta_checksum_kernel(const float *__restrict__ t, uint32_t n, unsigned long long *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(out, (unsigned long long)__float_as_uint(t[i]) * (unsigned long long)(i % 1021 + 1));
+}
+__global__ void theta_check_ids_kernel(const uint32_t *__restrict__ perm, uint32_t stride, uint32_t count, uint32_t *__restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) ids[i] = perm[(size_t)i * stride];
+}
+// the sample the grouped thresholds draw from, whole: image position 32 j + hash(j) of every 32 (mfma_theta_f16.hip)
+__global__ void theta_check_sample_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t ns, uint32_t *__restrict__ ids) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  uint32_t x = j * 0x9E3779B9u;
+  x ^= x >> 15;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  const uint32_t p = j * 32 + (x & 31u);
+  ids[j] = perm[p < n ? p : n - 1];
+}
+__global__ void theta_check_count_kernel(const float *__restrict__ theta_pos, uint32_t stride, const float *__restrict__ t_full, uint32_t count,
+                                         float slack, uint32_t *__restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count && theta_pos[(size_t)i * stride] < t_full[i] - slack) atomicAdd(bad, 1u);
+}
+
 __global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) inv[perm[i]] = i;
@@ -1134,9 +1161,50 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
         AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, Phown.p, perm_own.p, order_starts.p, order_np, order_piv.p, 32, 32, m,
                                            theta_pos.p, m2, theta2_pos.p));
-        have_theta2 = true;
-        grouped_theta = true;
-        ctx->stats["knn_join_theta_grouped"] = 1;
+        if (ctx->opt_debug & 65536) {  // diagnostic: a checksum of the thresholds (are they the same from run to run?)
+          DevBuf<unsigned long long> cs;
+          AS_TRY(cs.alloc(ctx, 1));
+          AS_HIP(ctx, hipMemsetAsync(cs.p, 0, sizeof(unsigned long long), ctx->stream));
+          hipLaunchKernelGGL(theta_checksum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const float *)theta_pos.p, n, cs.p);
+          unsigned long long h = 0;
+          AS_HIP(ctx, copy_d2h(ctx, &h, cs.p, sizeof(h)));
+          ctx->stats["knn_join_theta_checksum"] = (int64_t)(h & 0x7FFFFFFFFFFFFFFFull);
+        }
+        // How good they are depends on the data (do the pivots cover its clusters?), so they are CHECKED: 4096 rows spread over
+        // the image get their threshold against the whole sample as well (0.1 ms), and if more than 0.6 % of them sit more than
+        // 5e-3 below it (rows whose neighbours live in groups the sample of their own group does not reach: every one of them
+        // lists thousands of pairs) the grouped thresholds are dropped for the plain pass.  (1 M x 128 bench mixture, 1024
+        // pivots: 0.24 %; 700 k rows: 0.27 %; 400 k rows, 768 pivots: 2.9 %; 200 k rows: 4.1 %.)
+        const uint32_t n_chk = 4096, stride = n / n_chk;
+        DevBuf<uint32_t> chk_ids, chk_bad, chk_sid;
+        DevBuf<float> chk_t1, chk_t2;
+        DevBuf<unsigned char> chk_img;
+        const uint32_t ns_all = std::max(256u, (n / 32u) & ~255u);
+        AS_TRY(chk_ids.alloc(ctx, n_chk));
+        AS_TRY(chk_bad.alloc(ctx, 1));
+        AS_TRY(chk_sid.alloc(ctx, ns_all));
+        AS_TRY(chk_t1.alloc(ctx, n_chk));
+        AS_TRY(chk_t2.alloc(ctx, n_chk));
+        AS_TRY(chk_img.alloc(ctx, packed_vecs_f16(n_chk / kTileRows, d) * 16));
+        AS_HIP(ctx, hipMemsetAsync(chk_bad.p, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(theta_check_ids_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)perm_own.p, stride,
+                           n_chk, chk_ids.p);
+        hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_all, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)perm_own.p, n,
+                           ns_all, chk_sid.p);  // (the same sampled positions, all of them: what differs is the restriction alone)
+        AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
+        AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
+        hipLaunchKernelGGL(theta_check_count_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const float *)theta_pos.p, stride,
+                           (const float *)chk_t1.p, n_chk, 5e-3f, chk_bad.p);
+        uint32_t h_bad = 0;
+        AS_TRY(read_u32(ctx, chk_bad.p, &h_bad));
+        ctx->stats["knn_join_theta_grouped_bad"] = h_bad;
+        if (h_bad * 1000u <= 6u * n_chk) {
+          have_theta2 = true;
+          grouped_theta = true;
+        } else {
+          AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_pos.p, nullptr, theta2_pos.p, &have_theta2, Phown.p));
+        }
+        ctx->stats["knn_join_theta_grouped"] = grouped_theta ? 1 : 0;
       } else {
         ctx->stats["knn_join_theta_grouped"] = 0;
         AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, nullptr,

@@ -147,13 +147,15 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 
 // perm[pos] = row: the rows grouped by their nearest pivot (device array of n), the pivots being 256 of the rows themselves.
 // dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
-// n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 64 rows or more).  piv_out: n_pivots x 128.
+// n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 512 rows or more, 256 at least).  piv_out: n_pivots x 128.
 // group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
                   uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out) {
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
+  // (more than 256 only where a pivot still stands for 512 rows or more: the thresholds of the own join are taken against the
+  // sampled rows -- one in 32 -- of a few groups)
   const uint32_t np = std::min<uint32_t>(std::max<uint32_t>(n_pivots ? n_pivots : (uint32_t)kPivots, 32u) / 32u * 32u,
-                                         std::min<uint32_t>((uint32_t)kPivotsMax, n / 64u / 32u * 32u));
+                                         std::min<uint32_t>((uint32_t)kPivotsMax, std::max<uint32_t>((uint32_t)kPivots, n / 512u / 32u * 32u)));
   ProfScope ps(ctx, "knn_join_row_order");
   const uint32_t dp = (d + 3) / 4 * 4;
   DevBuf<uint32_t> ids;

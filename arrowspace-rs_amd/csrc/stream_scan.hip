@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
   ss_wave_sync();
   auto flush = [&]() {
     ss_wave_sync();
-    const uint32_t qn = *qn_p;
+    const uint32_t qn = *(volatile uint32_t *)qn_p;
     if (qn != 0) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(count, qn);
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
       const uint32_t j = st * 32 + (uint32_t)(lane & 31);
       const bool ok = m >= 0 && st < n_sub && j < n;
       if (!__any(ok)) continue;
-      if (*qn_p + 1024 > kQ) flush();  // (wave-uniform: every lane reads the same word)
+      // (wave-uniform: every lane reads the same word -- through a volatile access: the count is advanced by LDS atomics of this
+      // wave's lanes, and a value the compiler kept from an earlier trip would let the queue run into the next wave's)
+      ss_wave_sync();
+      if (*(volatile uint32_t *)qn_p + 1024 > kQ) flush();
       if (ok) {  // the lambda term as the score computes it, in place of its largest value 1 (rare path: a few lanes)
         const double lx = x_lams ? x_lams[j] : 0.0;
 #pragma unroll

@@ -19,6 +19,8 @@ if os.environ.get("PREFILTER") is not None: ctx.set_option("join_prefilter", int
 if os.environ.get("PREFILTER_MIN") is not None: ctx.set_option("join_prefilter_min_rows", int(os.environ["PREFILTER_MIN"]))
 for name in ("join_rank", "join_sample", "join_cap"):
     if os.environ.get(name.upper()): ctx.set_option(name, int(os.environ[name.upper()]))
+if os.environ.get("JOIN_THETA_GROUPED") is not None: ctx.set_option("join_theta_grouped", int(os.environ["JOIN_THETA_GROUPED"]))
+if os.environ.get("JOIN_ORDER_PIVOTS"): ctx.set_option("join_order_pivots", int(os.environ["JOIN_ORDER_PIVOTS"]))
 if os.environ.get("JOIN_BLOCK"): ctx.set_option("join_block", int(os.environ["JOIN_BLOCK"]))
 res = {}
 for pipe in pipes:
@@ -36,7 +38,7 @@ for pipe in pipes:
         pipe, (t1 - t0) * 1e3, ctx.stat("knn_join_candidates") / n, ctx.stat("knn_join_max_per_row"), ctx.stat("knn_join_overflow_rows"),
         ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_uncertified_rows_stage1b"),
         ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")),
-        "prefilter %d blocks %d flagged %d delta %.5f rotated %d tail %.4f" % (ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_blocks"),
+        "grouped theta %d bad %d; prefilter %d blocks %d flagged %d delta %.5f rotated %d tail %.4f" % (ctx.stat("knn_join_theta_grouped"), ctx.stat("knn_join_theta_grouped_bad"), ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_blocks"),
             ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_join_prefilter_delta_e6") * 1e-6, ctx.stat("knn_join_prefilter_rotated"),
             ctx.stat("knn_join_prefilter_tail_e6") * 1e-6), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
 for dbg in [int(x) for x in os.environ.get("ABLATE", "").split(",") if x]:

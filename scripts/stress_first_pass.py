@@ -27,15 +27,29 @@ for c in range(cases):
     if rng.random() < 0.3: X *= rng.uniform(1e-3, 1e3, size=(n, 1))
     gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
     mode = int(rng.choice([1, 2, 3]))
+    if os.environ.get("ONLY") and int(os.environ["ONLY"]) != c: continue
     ctx.set_option("join_prefilter", 0)
     i0, d0 = A.knn_cosine(X, gp)
     ctx.set_option("join_prefilter", mode); ctx.set_option("join_prefilter_min_rows", 0)
-    i1, d1 = A.knn_cosine(X, gp)
+    for kv in os.environ.get("OPTS", "").split(","):
+        if "=" in kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    for rep in range(int(os.environ.get("REPEAT", "1"))):
+        i1, d1 = A.knn_cosine(X, gp)
+        if os.environ.get("CHECKSUM"): print("   rep %d theta checksum %d leftover %d uncertified %d cand %d" % (rep, ctx.stat("knn_join_theta_checksum"), ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")), flush=True)
+        if not (np.array_equal(i0, i1) and np.array_equal(d0, d1)):
+            bad_rows = np.nonzero((i0 != i1).any(axis=1) | (d0 != d1).any(axis=1))[0]
+            print("   rep %d: %d rows differ, first %s; stats: leftover %d stream rows %d filter %d items %d overflow %d grouped %d" % (
+                rep, len(bad_rows), bad_rows[:5], ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_stream_scan_rows"), ctx.stat("stream_scan_filter"),
+                ctx.stat("stream_scan_filter_items"), ctx.stat("stream_scan_filter_overflow"), ctx.stat("knn_join_theta_grouped")), flush=True)
+            r = int(bad_rows[0])
+            print("   base idx", i0[r][:12], "...", i0[r][-6:], "\n   got  idx", i1[r][:12], "...", i1[r][-6:], "\n   base d", d0[r][-4:], "got d", d1[r][-4:],
+                  "first diff at", int(np.nonzero((i0[r] != i1[r]) | (d0[r] != d1[r]))[0][0]), flush=True)
+            break
     used, rot = ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_rotated")
     ctx.set_option("join_prefilter", 1); ctx.set_option("join_prefilter_min_rows", 65536)
     ok = np.array_equal(i0, i1) and np.array_equal(d0, d1)
     bad += 0 if ok else 1
-    print("join n=%d d=%d topk=%d eps=%.1f kind=%d mode=%d used=%d rotated=%d join=%d: %s" % (n, d, topk, eps, kind, mode, used, rot, ctx.stat("knn_join"), "ok" if ok else "MISMATCH"), flush=True)
+    print("join #%d n=%d d=%d topk=%d eps=%.1f kind=%d mode=%d used=%d rotated=%d join=%d: %s" % (c, n, d, topk, eps, kind, mode, used, rot, ctx.stat("knn_join"), "ok" if ok else "MISMATCH"), flush=True)
 for c in range(max(2, cases // 6)):
     n = int(rng.integers(66000, 180000)); d = int(rng.choice([33, 64, 128, 128, 128])); nq = int(rng.integers(40, 6000)); k = int(rng.integers(1, 30))
     alpha = float(rng.choice([0.2, 0.7, 1.0]))
