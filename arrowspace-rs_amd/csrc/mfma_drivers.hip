@@ -754,7 +754,7 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
                     uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr,
-                    const uint32_t *perm_a = nullptr, const unsigned char *mask = nullptr);
+                    const uint32_t *perm_a = nullptr, const unsigned char *mask = nullptr, const uint32_t *self_ids = nullptr);
 int rotated_image_pack(as_ctx *ctx, const double *rows, const double *norms, const uint32_t *perm, uint32_t n, uint32_t d,
                        const float *Qd, void *P8, uint32_t tiles, double *err_out);
 int rotated_basis(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, float *Qd, double *tail_out);
@@ -1514,7 +1514,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(failx.alloc(ctx, nf));
     if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
-    if (grouped_theta && second_h) {
+    if (grouped_theta && second_h && !(ctx->opt_debug & 131072)) {  // (debug bit 131072: the first pass's own second thresholds)
       // the thresholds of the first pass came from the sampled rows of the nearest pivot groups only; a row that is open after it
       // may be one whose neighbours live elsewhere (a cluster without a pivot of its own), so the second pass takes thresholds
       // against the whole sample for the few thousand rows it sweeps (PA is their f16 image)
@@ -1543,7 +1543,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(zeros.alloc(ctx, zn));
       AS_HIP(ctx, hipMemsetAsync(zeros.p, 0, sizeof(float) * zn, ctx->stream));
       AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
-                             unitc.p, "knn_mfma_join_f16_second", perm_used));
+                             unitc.p, "knn_mfma_join_f16_second", perm_used, nullptr, nullptr, cur_ids));
     } else if (second_wide)
       AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second",
                                 perm_used));

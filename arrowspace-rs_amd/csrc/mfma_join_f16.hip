@@ -136,6 +136,12 @@ struct F16SearchTerm {
   const float *q_lam, *q_g, *x_lam;
   float alpha, beta;
   uint32_t nq;
+  // the one-sided second pass of the item graph on this mode: the row ids of the "queries" (by position in their image), so
+  // that a row does not list ITSELF.  (It used to, "the re-rank drops it" -- but the pruning of the re-rank takes its cut from
+  // the K-th best listed score, and with the row's own 1.0 in the list that is the (K - 1)-th best of the others: one rank too
+  // high, enough to prune the true K-th neighbour when two candidates are 4e-6 apart and the f16 errors point the wrong way.
+  // Found by scripts/stress_first_pass.py, n = 211 570, K = 39.)
+  const uint32_t *self_ids;
 };
 // MASKED (MODE 0): mask = what the int8 first pass found (mfma_prefilter_i8.hip): one byte per (row super tile, stage of 256
 // columns, wave), a bit per 32-column block that may hold a pair.  The unit visits only the stages with a bit set and a wave
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         if (MODE == 1) {  // tcs = lambda of the column; the query's lambda and g - beta from the unit's arrays
           const uint32_t rl = row - I * kSuperH;
           inside = inside && row < st.nq;
+          if (st.self_ids && inside) inside = st.self_ids[row] != (perm ? perm[col] : col);
           sc = __builtin_fmaf(st.alpha, sc, -__builtin_fminf(__builtin_fabsf(__builtin_fmaf(st.beta, s_qlam[rl & (kSuperH - 1)], -st.beta * tcs)), st.beta));
           w1 = inside && ap >= 0.f && sc >= s_qg[rl & (kSuperH - 1)];
           w2 = false;
@@ -753,7 +760,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                     const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
                     uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm,
-                    const uint32_t *perm_a, const unsigned char *mask) {
+                    const uint32_t *perm_a, const unsigned char *mask, const uint32_t *self_ids) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH, a_supers = (nq + kSuperH - 1) / kSuperH;
@@ -761,13 +768,13 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
   // (on an image ordered by direction, and all the more behind the first pass, a unit's work is what its blocks hold, not how
   // many columns it spans: small units balance it)
-  const uint32_t W = std::max(1u, std::min((mask || perm) ? std::min(w_opt, 2u) : w_opt, std::max(1u, T2 / 4)));
+  const uint32_t W = std::max(1u, std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_opt, 2u) : w_opt, std::max(1u, T2 / 4)));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
   AS_TRY(stamps.alloc(ctx, 10));
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
-  const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq};
+  const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq, self_ids};
   ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \

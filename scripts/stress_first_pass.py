@@ -42,6 +42,8 @@ for c in range(cases):
                 rep, len(bad_rows), bad_rows[:5], ctx.stat("knn_uncertified_rows_stage1a"), ctx.stat("knn_stream_scan_rows"), ctx.stat("stream_scan_filter"),
                 ctx.stat("stream_scan_filter_items"), ctx.stat("stream_scan_filter_overflow"), ctx.stat("knn_join_theta_grouped")), flush=True)
             r = int(bad_rows[0])
+            print("   row %d: norm %.6g, rows equal to it: %d; last base d %r got d %r; base idx tail %r got %r" % (
+                r, float(np.linalg.norm(X[r])), int((X == X[r]).all(axis=1).sum()), d0[r][-3:].tolist(), d1[r][-3:].tolist(), i0[r][-3:].tolist(), i1[r][-3:].tolist()), flush=True)
             print("   base idx", i0[r][:12], "...", i0[r][-6:], "\n   got  idx", i1[r][:12], "...", i1[r][-6:], "\n   base d", d0[r][-4:], "got d", d1[r][-4:],
                   "first diff at", int(np.nonzero((i0[r] != i1[r]) | (d0[r] != d1[r]))[0][0]), flush=True)
             break
