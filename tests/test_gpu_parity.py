@@ -370,6 +370,58 @@ def test_item_graph_join_behind_the_int8_first_pass(ctx, join_on, n, d, mode, is
     assert np.array_equal(dist, od)
 
 
+def _stress_case(seed, index):
+    """Case `index` of scripts/stress_first_pass.py for `seed` (the same draws in the same order)."""
+    rng = np.random.default_rng(seed)
+    for c in range(index + 1):
+        big = rng.random() < 0.25
+        n = int(rng.integers(66000, 220000)) if big else int(rng.integers(600, 9000))
+        d = int(rng.choice([8, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 129, 200, 256, 384, 500, 768, 1000, 1024]))
+        if big and d > 256:
+            d = int(rng.choice([64, 128, 192]))
+        topk = int(rng.integers(3, 40))
+        eps = float(rng.choice([0.3, 0.5, 0.9]))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            X = rng.standard_normal((n, d))
+        else:
+            X, _ = synth.mixture(n, d, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.integers(2, 80)), rank=int(rng.integers(1, 9)))
+        X[rng.integers(0, n, 5)] = X[rng.integers(0, n)]
+        X[rng.integers(0, n)] = 0.0
+        if rng.random() < 0.3:
+            X *= rng.uniform(1e-3, 1e3, size=(n, 1))
+        mode = int(rng.choice([1, 2, 3]))
+    return X, topk, eps, mode
+
+
+def test_item_graph_second_pass_does_not_list_the_row_itself(ctx, join_on):
+    """The case of the randomised stress (seed 55, case 9: 211,570 x 128, K = 39) that came out with a wrong 39th neighbour in
+    one run of five: the f16 second pass listed a row itself, so the pruning cut of the re-rank -- the K-th best LISTED score --
+    sat one rank too high and the true K-th neighbour, 4e-6 from the next one, could be pruned.  (The row order, and with it
+    which rows reach the second pass, varies from run to run: the subspace iteration accumulates with float atomics; hence the
+    repeats.)  Tables with the first pass and the grouped thresholds must equal those of the plain join, and a sample of
+    rows, the one that failed among them, the oracle's."""
+    X, topk, eps, mode = _stress_case(55, 9)
+    assert X.shape == (211570, 128) and topk == 38
+    gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
+    ctx.set_option("join_prefilter", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+    finally:
+        ctx.set_option("join_prefilter", 1)
+    ctx.set_option("join_prefilter_min_rows", 0)
+    try:
+        for _ in range(4):
+            idx, dist = A.knn_cosine(X, gp)
+            assert ctx.stat("knn_join_prefilter") == 1
+            assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    finally:
+        ctx.set_option("join_prefilter_min_rows", 65536)
+    sample = np.concatenate([[119342], np.sort(np.random.default_rng(3).choice(len(X), size=23, replace=False))])
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx0[sample], oi) and np.array_equal(dist0[sample], od)
+
+
 @pytest.mark.parametrize("topk", [40, 63])
 @pytest.mark.parametrize("pipe", [16, 48])
 def test_item_graph_deep_tables_take_the_join(ctx, join_on, topk, pipe):
