@@ -1244,6 +1244,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
       js = &local;
     }
+    DevBuf<unsigned long long> scored;
     {
       const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
       GraphBound bnd{join_delta(ctx, d), rectify};
@@ -1265,10 +1266,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
         const int slots = d == 128 ? 2 : 4;  // 124 / 252 survivors per record
         AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
+        AS_TRY(scored.alloc(ctx, 1));
+        AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
                            ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
                            force.p, prune_delta, rectify, records.p, slots, lists_by_pos ? perm_own.p : nullptr,
-                           lists_by_pos ? inv_own.p : nullptr);
+                           lists_by_pos ? inv_own.p : nullptr, scored.p);
         AS_HIP(ctx, hipGetLastError());
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
@@ -1319,6 +1322,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       ctx->stats["knn_join_candidates"] = (int64_t)h[0];
       ctx->stats["knn_join_max_per_row"] = (int64_t)h[1];
       ctx->stats["knn_join_overflow_rows"] = (int64_t)h[2];
+      if (scored.p) {  // candidates that survived the pruning: the rows the scoring kernel fetched
+        unsigned long long hs = 0;
+        AS_HIP(ctx, copy_d2h(ctx, &hs, scored.p, sizeof(hs)));
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stats["knn_rerank_scored"] = (int64_t)hs;
+      }
     }
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   } else {

@@ -171,7 +171,15 @@ __global__ __launch_bounds__(256) void cov_sample_kernel(const double *__restric
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&cov[(8 * a + i) * 128 + 8 * b + j], acc[i][j]);
+    for (int j = 0; j < 8; ++j) cov[(size_t)blockIdx.x * 128 * 128 + (8 * a + i) * 128 + 8 * b + j] = acc[i][j];
+}
+// ... whose per-block parts (cov above: gridDim.x x 128 x 128) are added in block order: a fixed order, so that the directions are
+// the same from run to run (a float atomicAdd is not)
+__global__ void cov_reduce_kernel(const float *__restrict__ part, uint32_t blocks, float *__restrict__ cov) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  for (uint32_t b = 0; b < blocks; ++b) s += part[(size_t)b * 128 * 128 + e];
+  cov[e] = s;
 }
 
 // image position p (row perm[p], or p) -> 32 bytes: q_k = rint(127 z_k) for the 31 directions, then ceil(127 t); laid out as
@@ -903,13 +911,14 @@ int rotated_image_pack(as_ctx *ctx, const double *rows, const double *norms, con
 // floats); tail_out: the share of the sample's energy outside them.
 int rotated_basis(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, float *Qd, double *tail_out) {
   if (d > 128) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated image: dim not covered");
-  DevBuf<float> covd;
+  DevBuf<float> covd, covp;
   AS_TRY(covd.alloc(ctx, 128 * 128));
-  AS_HIP(ctx, hipMemsetAsync(covd.p, 0, 128 * 128 * sizeof(float), ctx->stream));
   const uint64_t stride = std::max<uint64_t>(1, n / 32768);
   const uint32_t n_sample = (uint32_t)((n + stride - 1) / stride);
-  hipLaunchKernelGGL(cov_sample_kernel, dim3((unsigned)std::min<uint32_t>(cdiv(n_sample, 64), 256)), dim3(256), 0, ctx->stream, rows,
-                     norms, (uint64_t)n, d, stride, n_sample, covd.p);
+  const uint32_t cov_blocks = (uint32_t)std::min<uint64_t>(cdiv(n_sample, 64), 256);
+  AS_TRY(covp.alloc(ctx, (size_t)cov_blocks * 128 * 128));
+  hipLaunchKernelGGL(cov_sample_kernel, dim3(cov_blocks), dim3(256), 0, ctx->stream, rows, norms, (uint64_t)n, d, stride, n_sample, covp.p);
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, ctx->stream, (const float *)covp.p, cov_blocks, covd.p);
   AS_HIP(ctx, hipGetLastError());
   std::vector<float> cov(128 * 128), Q(32 * 128);
   AS_HIP(ctx, copy_d2h(ctx, cov.data(), covd.p, cov.size() * sizeof(float)));

@@ -35,12 +35,14 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            uint32_t cap, uint32_t cmax, uint32_t K,
                                                            const uint8_t *__restrict__ force_exact, double prune_delta, int prune_rectify,
                                                            uint32_t *__restrict__ records, int slots,
-                                                           const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv) {
+                                                           const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv,
+                                                           unsigned long long *__restrict__ scored_total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
   float *es = reinterpret_cast<float *>(smem) + (size_t)wv * 2 * cmax;
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
+  unsigned long long scored = 0;  // candidates this wave hands to the scoring kernel (the rows it fetches: bench.py's algorithmic bytes)
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     const uint32_t a = row_begin + r;
     // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
       overflow = true;
       C = kRsMaxIds;
     }
+    scored += C;
     uint32_t *rec = records + (size_t)r * kRsWords;
     for (uint32_t c = lane; c < C; c += 64) {
       const uint32_t j = perm ? perm[ei[c]] : ei[c];
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     }
     wave_sync();
   }
+  if (scored_total && lane == 0 && scored) atomicAdd(scored_total, scored);
 }
 
 typedef double rs_d2 __attribute__((ext_vector_type(2)));  // (a native vector: asm operands of struct type go through memory)

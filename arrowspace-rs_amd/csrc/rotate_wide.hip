@@ -18,11 +18,13 @@ constexpr uint32_t kMaxWide = 1024;  // 31 directions of that width fit LDS as f
 // z = Q^T u for `count` rows (row index = first + i * stride), one wave per row and trip: the row in registers (lane l holds
 // columns l, l + 64, ...), the directions in LDS.  out: count x 32 doubles (z_0 .. z_30 as computed in f32, then t = sqrt(max(0,
 // 1 - |z|^2) + 2e-5): the tail norm rounded up by what f32 and a basis orthonormal to 1e-6 can lose), rows with a zero or
-// non-finite norm all zero.  tail_sum (optional): sum of 1 - |z|^2 over the rows.
+// non-finite norm all zero.  tail_part (optional): per WAVE of the grid (4 * gridDim.x doubles) its sum of 1 - |z|^2 over its rows, added
+// up by the host in index order: every sum on this path has a fixed order, so that the directions, the row order found on them and
+// with it which rows reach which stage are the same from run to run (a float atomicAdd here made a failure reproduce 1 time in 5).
 template <int NV>  // columns per lane = ceil(dim / 64) <= 16
 __global__ __launch_bounds__(256) void zproj_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t first,
                                                     uint64_t stride, uint32_t count, uint32_t d, const float *__restrict__ Q,
-                                                    uint32_t pitch, double *__restrict__ out, double *__restrict__ tail_sum) {
+                                                    uint32_t pitch, double *__restrict__ out, double *__restrict__ tail_part) {
   extern __shared__ float s_q[];  // kDirs x pitch
   for (uint32_t e = threadIdx.x; e < (uint32_t)kDirs * pitch; e += 256) s_q[e] = Q[e];
   __syncthreads();
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void zproj_kernel(const double *__restrict__ R
     if (lane < 32) out[(size_t)i * 32 + lane] = (double)mine;
     if (live) tails += (double)__builtin_fmaxf(1.f - zz, 0.f);
   }
-  if (tail_sum && lane == 0 && tails != 0.0) atomicAdd(tail_sum, tails);
+  if (tail_part && lane == 0) tail_part[blockIdx.x * 4 + (threadIdx.x >> 6)] = tails;
 }
 
 // the same for ALL rows up to 128 wide: a thread per row with the row in registers and the directions broadcast from LDS (the
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void zproj_kernel(const double *__restrict__ R
 template <int DP>  // row width padded to 32
 __global__ __launch_bounds__(256) void zproj_thread_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
                                                            uint32_t d, const float *__restrict__ Q, uint32_t pitch,
-                                                           double *__restrict__ out, double *__restrict__ tail_sum) {
+                                                           double *__restrict__ out, double *__restrict__ tail_part) {
   __shared__ float s_q[kDirs * DP];
   for (int e = threadIdx.x; e < kDirs * DP; e += 256) s_q[e] = Q[(size_t)(e / DP) * pitch + (e % DP)];
   __syncthreads();
@@ -95,11 +97,13 @@ __global__ __launch_bounds__(256) void zproj_thread_kernel(const double *__restr
     o[kDirs] = live ? (double)__builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.0;
     if (live) tails = (double)__builtin_fmaxf(1.f - zz, 0.f);
   }
-  for (int o2 = 32; o2 > 0; o2 >>= 1) tails += __shfl_xor(tails, o2, 64);
-  if (tail_sum && (threadIdx.x & 63) == 0 && tails != 0.0) atomicAdd(tail_sum, tails);
+  for (int o2 = 32; o2 > 0; o2 >>= 1) tails += __shfl_xor(tails, o2, 64);  // (butterfly: the same tree in every lane and run)
+  if (tail_part && (threadIdx.x & 63) == 0) tail_part[blockIdx.x * 4 + (threadIdx.x >> 6)] = tails;
 }
 
-// Y[dir][k] += sum over the sample rows of z[row][dir] * u[row][k]   (Y: kDirs x pitch floats, zeroed by the caller)
+// Y[block][dir][k] = sum over the sample rows of the block (i = block, block + grid, ...: a fixed order) of z[row][dir] * u[row][k];
+// yreduce_kernel adds the blocks' parts in block order.  (Was a float atomicAdd into one Y: the directions differed in their last
+// bits from run to run, and with them the row order and the routing of rows through the stages.)
 __global__ __launch_bounds__(256) void yacc_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t stride,
                                                    uint32_t count, uint32_t d, const double *__restrict__ Z, uint32_t pitch,
                                                    float *__restrict__ Y) {
@@ -133,8 +137,15 @@ __global__ __launch_bounds__(256) void yacc_kernel(const double *__restrict__ R,
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint32_t k = threadIdx.x + 256u * c;
-      if (k < d && acc[a][c] != 0.f) atomicAdd(&Y[(size_t)a * pitch + k], acc[a][c]);
+      if (k < d) Y[((size_t)blockIdx.x * kDirs + a) * pitch + k] = acc[a][c];
     }
+}
+__global__ void yreduce_kernel(const float *__restrict__ part, uint32_t blocks, uint32_t elems, float *__restrict__ Y) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.f;
+  for (uint32_t b = 0; b < blocks; ++b) s += part[(size_t)b * elems + e];
+  Y[e] = s;
 }
 
 __global__ void znorm_kernel(const double *__restrict__ Z, uint32_t n, double *__restrict__ out) {
@@ -212,12 +223,15 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   const size_t lds = (size_t)kDirs * pitch * sizeof(float);
   const uint64_t stride = std::max<uint64_t>(1, n / 16384);
   const uint32_t ns = (uint32_t)((n + stride - 1) / stride);
-  DevBuf<float> Qd, Yd;
-  DevBuf<double> Zs, tsum;
+  DevBuf<float> Qd, Yd, Ypart;
+  DevBuf<double> Zs, tpart;
+  const uint32_t y_blocks = std::min<uint32_t>(ns, 512);
+  const uint32_t z_grid = d <= 128 ? (uint32_t)cdiv(n, 256) : std::min<uint32_t>((uint32_t)cdiv(n, 4), 256 * 8);
   AS_TRY(Qd.alloc(ctx, (size_t)kDirs * pitch));
   AS_TRY(Yd.alloc(ctx, (size_t)kDirs * pitch));
+  AS_TRY(Ypart.alloc(ctx, (size_t)y_blocks * kDirs * pitch));
   AS_TRY(Zs.alloc(ctx, (size_t)ns * 32));
-  AS_TRY(tsum.alloc(ctx, 1));
+  AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
   std::vector<float> Q((size_t)kDirs * pitch, 0.f), Yh((size_t)kDirs * pitch);
   std::vector<double> V((size_t)kDirs * d);
   uint64_t seed = 0x9E3779B97F4A7C15ull;
@@ -246,11 +260,13 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   orthonormalise();
   for (int it = 0; it < 3; ++it) {  // Q <- orth(S^T S Q)
     AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    AS_HIP(ctx, hipMemsetAsync(Yd.p, 0, Yh.size() * sizeof(float), ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(Ypart.p, 0, (size_t)y_blocks * kDirs * pitch * sizeof(float), ctx->stream));  // (columns d .. pitch stay 0)
     AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, rows, norms, (uint64_t)0, stride, ns, d, (const float *)Qd.p,
                         pitch, Zs.p, (double *)nullptr));
-    hipLaunchKernelGGL(yacc_kernel, dim3(std::min<uint32_t>(ns, 512)), dim3(256), 0, ctx->stream, rows, norms, stride, ns, d,
-                       (const double *)Zs.p, pitch, Yd.p);
+    hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, rows, norms, stride, ns, d,
+                       (const double *)Zs.p, pitch, Ypart.p);
+    hipLaunchKernelGGL(yreduce_kernel, dim3(cdiv((uint32_t)kDirs * pitch, 256)), dim3(256), 0, ctx->stream, (const float *)Ypart.p, y_blocks,
+                       (uint32_t)kDirs * pitch, Yd.p);
     AS_HIP(ctx, hipGetLastError());
     AS_HIP(ctx, copy_d2h(ctx, Yh.data(), Yd.p, Yh.size() * sizeof(float)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -259,9 +275,8 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
     orthonormalise();
   }
   AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(tsum.p, 0, sizeof(double), ctx->stream));
   if (d <= 128) {
-#define AS_ZT(DPV) hipLaunchKernelGGL(zproj_thread_kernel<DPV>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, rows, norms, n, d, (const float *)Qd.p, pitch, Z, tsum.p)
+#define AS_ZT(DPV) hipLaunchKernelGGL(zproj_thread_kernel<DPV>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, rows, norms, n, d, (const float *)Qd.p, pitch, Z, tpart.p)
     switch ((d + 31) / 32) {
       case 2: AS_ZT(64); break;
       case 3: AS_ZT(96); break;
@@ -270,14 +285,15 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
 #undef AS_ZT
     AS_HIP(ctx, hipGetLastError());
   } else {
-    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(n, 4), 256 * 8), lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p,
-                        pitch, Z, tsum.p));
+    AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p, pitch, Z, tpart.p));
   }
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
-  double ts = 0.0;
-  AS_HIP(ctx, copy_d2h(ctx, &ts, tsum.p, sizeof(ts)));
+  std::vector<double> tp((size_t)z_grid * 4);
+  AS_HIP(ctx, copy_d2h(ctx, tp.data(), tpart.p, tp.size() * sizeof(double)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
+  double ts = 0.0;
+  for (double v : tp) ts += v;
   *tail_out = ts / std::max<double>(1.0, (double)n);
   return AS_OK;
 }

@@ -13,9 +13,21 @@ import sys
 
 
 def short(name):
+    """Kernel name without return type, namespaces and the argument list.  The anonymous-namespace marker goes FIRST: it
+    contains a parenthesis, and cutting at the first "(" before removing it turned every asx::(anonymous namespace)::kernel
+    into the empty string (r02: 53 launches and 11.3 GB under "kernel": "")."""
     name = re.sub(r"^void ", "", name)
-    name = name.split("(")[0]
-    return name.replace("asx::(anonymous namespace)::", "").replace("asx::", "")[:110]
+    name = name.replace("(anonymous namespace)::", "").replace("asx::", "")
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):   # the argument list opens at the first "(" outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return name[:cut][:110]
 
 
 def load(d, counter):

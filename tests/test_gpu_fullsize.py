@@ -137,6 +137,23 @@ def test_config2_1M_x_128_build_and_10k_query_search(ctx):
     idx, dst = knn_device(ctx, Xd, gp)
     assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_blocks") > 0     # the join kernel ran, on a 16-bit pipe
     assert ctx.stat("knn_join_pipe") in (16, 48)
+    # ... behind the rotated int8 first pass, on the image ordered by direction, with the grouped thresholds: the path the
+    # bench line times is the path this test checks
+    assert ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_prefilter_rotated") == 1
+    assert ctx.stat("knn_join_row_order") == 1 and ctx.stat("knn_join_theta_grouped") == 1
+    # the WHOLE table against two independent forms of the join (src/laplacian.rs:211-252 is what all of them replace):
+    # the plain dense f16 join (no row order used by a first pass, no mask), and the join on the f32 pipe (another
+    # contraction, another rounding bound, no f16 image at all)
+    for opt, val, restore in (("join_prefilter", 0, 1), ("join_pipe", 32, 16)):
+        ctx.set_option(opt, val)
+        try:
+            idx2, dst2 = knn_device(ctx, Xd, gp)
+            assert ctx.stat("knn_join") == 1
+            assert ctx.stat("knn_join_prefilter") == 0 and ctx.stat("knn_join_pipe") == (32 if opt == "join_pipe" else 16)
+        finally:
+            ctx.set_option(opt, restore)
+        assert torch.equal(idx, idx2) and torch.equal(dst, dst2), opt
+        del idx2, dst2
     rng = np.random.default_rng(1)
     assert_sampled_rows(X, gp, idx, dst, np.sort(rng.choice(n, size=96, replace=False)))
     assert_table_invariants(idx, dst)
@@ -193,6 +210,15 @@ def test_config3_4M_x_128_shard_of_8(ctx):
     assert_sampled_rows(X, gp, idx, dst, np.sort(lo + rng.choice(hi - lo, size=48, replace=False)), row0=lo)
     assert_table_invariants(idx, dst, row0=lo)
     full_idx, full_dst = knn_device(ctx, Xd, gp)          # the same rows from the one-GPU build of all 4 M
-    assert ctx.stat("knn_join") == 1
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_prefilter_rotated") == 1
     assert torch.equal(full_idx[lo:hi], idx) and torch.equal(full_dst[lo:hi], dst)
+    del idx, dst
+    ctx.set_option("join_prefilter", 0)                    # the whole 4 M table against the plain dense join
+    try:
+        idx2, dst2 = knn_device(ctx, Xd, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 0
+    finally:
+        ctx.set_option("join_prefilter", 1)
+    assert torch.equal(full_idx, idx2) and torch.equal(full_dst, dst2)
+    del idx2, dst2
     assert_sampled_rows(X, gp, full_idx, full_dst, np.sort(rng.choice(n, size=32, replace=False)))

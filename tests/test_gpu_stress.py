@@ -1,0 +1,114 @@
+"""A bounded, fixed-seed form of scripts/stress_first_pass.py inside the -m gpu suite.
+
+The script draws random sizes (600 .. 220 k rows), widths (8 .. 1024), depths (K = 4 .. 40), cluster structures,
+duplicates, zero rows and rescaled rows; it found the one real bug of round 2 (the f16 second pass listing a row itself,
+n = 211 570, K = 39) that a 96-row sample at the bench size would never have seen.  Here: twelve fixed cases of the same
+generator -- two of them above 200 k rows, one with K >= 39 -- whose tables with the int8 first pass (+ row order, grouped
+thresholds, masked f16 pass, second pass) must be bit-identical with the tables of the plain dense join (join_prefilter = 0),
+and sampled rows of them with the oracle's (src/laplacian.rs:211-252 is what every one of these stages stands in for).
+Plus a run-to-run determinism check: since the subspace iteration adds in a fixed order (rotate_wide.hip) the row order, the
+thresholds and the routing of rows through the stages are the same in every run, so a failure reproduces.
+"""
+import numpy as np
+import pytest
+
+import arrowspace_amd as A
+from arrowspace_amd import synth
+from oracle import oracle_ctypes as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = A.default_context()
+    c.set_option("join_min_rows", 512)
+    yield c
+    c.set_option("join_min_rows", 32768)
+
+
+def _draw(rng, big):
+    """One case of scripts/stress_first_pass.py with the size class fixed."""
+    n = int(rng.integers(66000, 220000)) if big else int(rng.integers(600, 9000))
+    d = int(rng.choice([8, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 129, 200, 256, 384, 500, 768, 1000, 1024]))
+    if big and d > 256:
+        d = int(rng.choice([64, 128, 192]))
+    topk = int(rng.integers(3, 40))
+    eps = float(rng.choice([0.3, 0.5, 0.9]))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        X = rng.standard_normal((n, d))
+    else:
+        X, _ = synth.mixture(n, d, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.integers(2, 80)), rank=int(rng.integers(1, 9)))
+    X[rng.integers(0, n, 5)] = X[rng.integers(0, n)]
+    X[rng.integers(0, n)] = 0.0
+    if rng.random() < 0.3:
+        X *= rng.uniform(1e-3, 1e3, size=(n, 1))
+    mode = int(rng.choice([1, 2, 3]))
+    return X, topk, eps, mode
+
+
+# (seed, big, overrides): twelve cases; the overrides pin the properties the verdict asks for whatever the draws give
+CASES = [
+    (101, False, {}), (102, False, {}), (103, False, {}), (104, False, {}), (105, False, {}), (106, False, {}),
+    (107, False, {"topk": 39}), (108, False, {"mode": 2}),
+    (201, True, {}), (202, True, {"mode": 1}),
+    (203, True, {"n_min": 200_000, "d": 128, "mode": 1}),             # >= 200 k rows
+    (204, True, {"n_min": 200_000, "d": 128, "topk": 39, "mode": 1}),  # >= 200 k rows and K >= 39 (the shape of the round-2 bug)
+]
+
+
+def _case(seed, big, ov):
+    rng = np.random.default_rng(seed)
+    X, topk, eps, mode = _draw(rng, big)
+    if "n_min" in ov and (len(X) < ov["n_min"] or X.shape[1] != ov["d"]):
+        n = ov["n_min"] + int(rng.integers(0, 20000))
+        X, _ = synth.mixture(n, ov["d"], seed=seed, n_clusters=int(rng.integers(8, 80)), rank=int(rng.integers(2, 9)))
+        X[rng.integers(0, n, 5)] = X[rng.integers(0, n)]
+        X[rng.integers(0, n)] = 0.0
+    return X, ov.get("topk", topk), eps, ov.get("mode", mode)
+
+
+@pytest.mark.parametrize("seed,big,ov", CASES, ids=["s%d" % c[0] for c in CASES])
+def test_first_pass_tables_equal_plain_join(ctx, seed, big, ov):
+    X, topk, eps, mode = _case(seed, big, ov)
+    n, d = X.shape
+    gp = A.GraphParams(eps, 16, topk, 2.0, 0.25)
+    try:
+        ctx.set_option("join_prefilter", 0)
+        i0, d0 = A.knn_cosine(X, gp)
+        joined = ctx.stat("knn_join")
+        assert ctx.stat("knn_join_prefilter") == 0
+        ctx.set_option("join_prefilter", mode)
+        ctx.set_option("join_prefilter_min_rows", 0)
+        i1, d1 = A.knn_cosine(X, gp)
+        if joined and d <= 128:
+            assert ctx.stat("knn_join_prefilter") == 1
+    finally:
+        ctx.set_option("join_prefilter", 1)
+        ctx.set_option("join_prefilter_min_rows", 65536)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    sample = np.sort(np.random.default_rng(seed).choice(n, size=16 if big else 48, replace=False))
+    oi, od = O.knn_cosine_rows(X, O.graph_params(eps, 16, topk, 2.0, 0.25), sample)
+    assert np.array_equal(i1[sample], oi) and np.array_equal(d1[sample], od)
+
+
+def test_build_is_the_same_from_run_to_run(ctx):
+    """Directions, row order, thresholds and stage routing of the own join do not vary between runs (debug bit 65536 makes
+    the library publish a checksum of the thresholds by image position)."""
+    X, _ = synth.mixture(150_000, 128, seed=9, n_clusters=128, rank=8)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    seen = []
+    try:
+        ctx.set_option("debug", 65536)
+        ctx.set_option("join_prefilter_min_rows", 0)
+        for _ in range(3):
+            idx, dist = A.knn_cosine(X, gp)
+            assert ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_prefilter_rotated") == 1
+            seen.append((ctx.stat("knn_join_theta_checksum"), ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"),
+                         ctx.stat("knn_join_candidates"), ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_join_theta_grouped")))
+    finally:
+        ctx.set_option("debug", 0)
+        ctx.set_option("join_prefilter_min_rows", 65536)
+    assert seen[0][0] != 0
+    assert seen[0] == seen[1] == seen[2], seen
