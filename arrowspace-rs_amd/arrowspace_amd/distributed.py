@@ -291,8 +291,13 @@ class ShardedCsr:
 class ShardedArrowSpace:
     """The row-sharded counterpart of (ArrowSpace, GraphLaplacian) for one rank."""
 
-    def __init__(self, ops, X_shard, n_total, gp, taumode=A.TauMode.Median):
-        self.ops, self.gp, self.taumode = ops, gp, taumode
+    def __init__(self, ops, X_shard, n_total, gp, taumode=A.TauMode.Median, libcomm=None):
+        """libcomm (a LibComm): the exchange steps of the build, of the lambda statistics and of the search run INSIDE the
+        library (csrc/sharded.hip: as_build_laplacian_sharded, as_lambda_stats_sharded, as_search_lambda_aware_sharded) over its
+        communicator -- the sharded form of the one-GPU algorithm (row order + int8 first pass + masked f16 pass, every rank on
+        its own range of image positions).  Without it the same steps run here on torch.distributed with the stage-level entry
+        points (the join in the order of the caller's rows)."""
+        self.ops, self.gp, self.taumode, self.libcomm = ops, gp, taumode, libcomm
         self.rank, self.world = _world()
         self.n = int(n_total)
         self.lo, self.hi = shard_range(self.n, self.rank, self.world)
@@ -309,6 +314,8 @@ class ShardedArrowSpace:
         512-row super tiles, so small inputs leave the last ranks empty); which path runs is decided from
         rank-invariant inputs only."""
         ops, gp, n = self.ops, self.gp, self.n
+        if self.libcomm is not None:
+            return self.libcomm.build_laplacian(self.X, n, gp)
         X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
         rows_here = self.hi - self.lo
         K = gp.topk + 1
@@ -358,6 +365,10 @@ class ShardedArrowSpace:
         else:  # a rank without rows: nothing to compute, but it still takes part in the collectives below
             self.lambdas = torch.empty(0, dtype=torch.float64, device=self.X.device)
         lam = self.lambdas if torch.is_tensor(self.lambdas) else torch.from_numpy(np.asarray(self.lambdas))
+        if self.libcomm is not None:                                      # logged stats, builder.rs:434-445, inside the library
+            self.lambda_stats = self.libcomm.lambda_stats(lam)
+            self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo) if self.hi > self.lo else None
+            return self.gl
         stats = torch.stack([lam.min(), -lam.max(), lam.sum()]) if lam.numel() else \
             torch.tensor([float("inf"), float("inf"), 0.0], dtype=torch.float64, device=lam.device)
         if _collectives_on(self.world):                                   # logged stats, builder.rs:434-445
@@ -375,6 +386,8 @@ class ShardedArrowSpace:
 
     def search(self, queries, q_lambdas, k, alpha):
         """Global top-k of every query: per-shard top-k (global ids), all-gather, stable merge."""
+        if self.libcomm is not None:
+            return self.libcomm.search(self.index, queries, q_lambdas, min(k, self.n), alpha, self.lo)
         if self.index is not None:
             idx, sc = self.ops.search(self.index, queries, q_lambdas, k, alpha)
         else:  # no items here: an empty table (padded below to the width of the others)
@@ -524,6 +537,38 @@ class LibComm:
                                                      int(X_shard.shape[1]), C.byref(c), C.byref(h), C.byref(nnz)))
         block = A.CsrMatrix(ctx, h) if h.value else None
         return ShardedCsr(block, lo, hi, int(n_total), int(nnz.value))
+
+    def lambda_stats(self, lambdas_shard):
+        """as_lambda_stats_sharded: (min, max, mean) of all ranks' lambdas (src/builder.rs:434-445), the same on every rank."""
+        import ctypes as C
+        ctx = self.ctx
+        mn, mx, mean = C.c_double(), C.c_double(), C.c_double()
+        lam = lambdas_shard.contiguous() if torch.is_tensor(lambdas_shard) else np.ascontiguousarray(lambdas_shard, dtype=np.float64)
+        n_here = int(lam.numel() if torch.is_tensor(lam) else lam.size)
+        A._adopt_torch_stream(ctx)
+        ctx.check(ctx.lib.as_lambda_stats_sharded(ctx.h, self.h, ptr(lam) if n_here else None, n_here, C.byref(mn), C.byref(mx), C.byref(mean)))
+        return (mn.value, mx.value, mean.value)
+
+    def search(self, index, queries, q_lambdas, k, alpha, id_offset):
+        """as_search_lambda_aware_sharded: index = this rank's ArrowSpace (None on a rank without rows); queries / q_lambdas
+        replicated.  Returns the global (idx, scores), nq x k, on every rank (device tensors when the queries are)."""
+        ctx = self.ctx
+        nq = int(queries.shape[0])
+        if torch.is_tensor(queries):
+            Q, LQ = queries.contiguous(), q_lambdas.contiguous()
+            idx = torch.empty((nq, k), dtype=torch.int64, device=Q.device)
+            sc = torch.empty((nq, k), dtype=torch.float64, device=Q.device)
+        else:
+            Q, LQ = np.ascontiguousarray(queries, dtype=np.float64), np.ascontiguousarray(q_lambdas, dtype=np.float64)
+            idx, sc = np.empty((nq, k), dtype=np.int64), np.empty((nq, k), dtype=np.float64)
+        h = None
+        if index is not None:
+            index._ensure_index()
+            h = index._index
+        A._adopt_torch_stream(ctx)
+        ctx.check(ctx.lib.as_search_lambda_aware_sharded(ctx.h, self.h, h, ptr(Q), ptr(LQ), nq, int(k), float(alpha), int(id_offset),
+                                                         ptr(idx), ptr(sc)))
+        return idx, sc
 
     def close(self):
         if self.h:

@@ -388,6 +388,28 @@ int apply_self_in_results(as_ctx *ctx, const double *rows, const double *norms, 
 
 // Candidate lists of a threshold join that has already been run (row-sharded build: every rank contracts
 // the tile pairs of its own super tiles, the lists are exchanged, each rank finishes its own rows).
+// The join on an image in the library's own row order, prepared (own_join_prepare, mfma_drivers.hip): what the contraction
+// of the tile pairs and every stage behind it need.  One per build; a build sharded by image positions (sharded.hip) prepares
+// the same object on every rank.
+struct OwnJoin {
+  DevBuf<unsigned char> P16own, Phown;                        // split-bf16 / f16 image of all rows (Phown in the order `perm`)
+  DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos; // thresholds (and the looser second ones) by row / by image position
+  DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
+  DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
+  DevBuf<float> order_piv;                                    // the pivots of the order found on them (np x 32), where the rows of each begin
+  DevBuf<uint32_t> order_starts;
+  uint32_t order_np = 0, cap = 0;                             // pivots used; list slots per row
+  bool wide_pre = false;       // the coordinates are in use (their directions carry the rows)
+  bool reorder = false;        // the image is packed in the order perm_own (else: the rows as given)
+  bool grouped_theta = false;  // thresholds from the sample of the nearest pivot groups
+  bool have_theta2 = false;
+  const uint32_t *perm = nullptr;       // perm_own.p or nullptr
+  const float *theta_image = nullptr;   // thresholds in the order of the image: theta_pos.p or theta_own.p
+};
+int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj);
+int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos);
+
 struct JoinSources {
   const float *packed;    // f32 image of all rows if the caller has one (else nullptr)
   const float *theta;     // thresholds of ALL rows (n)
@@ -397,6 +419,13 @@ struct JoinSources {
   const float *theta2 = nullptr;    // looser thresholds of the rows of the range (by position), or nullptr
   const void *packed16 = nullptr;   // split-bf16 image of all rows, or nullptr (the second pass packs its own then)
   const void *packedh = nullptr;    // f16 image of all rows (what the second pass over rows wider than 128 contracts)
+  // a range of IMAGE POSITIONS [row_begin, row_begin + row_count) of a prepared join (build sharded by positions): the rows are
+  // a_ids[r] = perm[row_begin + r], list r belongs to a_ids[r] and holds ROW ids; theta / theta2 are by global row,
+  // theta_local[r] = theta[a_ids[r]]; oj->inv_own maps a row back to its position (list index = inv[g] - list_base)
+  const uint32_t *a_ids = nullptr;
+  const float *theta_local = nullptr;
+  const OwnJoin *oj = nullptr;
+  uint32_t list_base = 0;
 };
 // MFMA candidate pass + exact re-rank + certification + exact fall-back
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n, uint64_t d,

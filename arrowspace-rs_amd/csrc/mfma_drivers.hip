@@ -298,17 +298,19 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
 }
 
 // thresholds of the second pass: a row whose list overflowed (in any of its sources) keeps its threshold, the others
-// get the looser one.  theta by global row, theta2 / cnt by position in [row_begin, row_begin + row_count)
+// get the looser one.  theta by global row; theta2 by (row - t2_base); the lists of row g are those of index
+// (inv ? inv[g] : g) - list_base: kept by row of the range (sharded by rows), by image position (own join on a permuted image,
+// row_order.hip) or by image position of a range of positions (sharded by positions)
 __global__ void second_theta_kernel(const float *__restrict__ theta, const float *__restrict__ theta2,
-                                    const uint32_t *__restrict__ cnt, uint32_t n_src, uint32_t row_begin, uint32_t row_count,
+                                    const uint32_t *__restrict__ cnt, uint32_t n_src, uint32_t t2_base, uint32_t list_base, uint32_t row_count,
                                     uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded,
                                     float *__restrict__ out, const uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
   if (i < count) {
-    const uint32_t g = ids[i], r = g - row_begin;
-    const uint32_t lr = inv ? inv[g] : r;  // lists kept by image position (row_order.hip)
+    const uint32_t g = ids[i], r = g - t2_base;
+    const uint32_t lr = (inv ? inv[g] : g) - list_base;
     bool over = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + lr] > cap;
     t = over ? theta[g] : theta2[r];
@@ -319,15 +321,15 @@ __global__ void second_theta_kernel(const float *__restrict__ theta, const float
 // ... with thresholds computed afresh for the gathered rows (t1 / t2 by position in ids)
 __global__ void second_theta_fresh_kernel(const float *__restrict__ t1, const float *__restrict__ t2, const float *__restrict__ theta_first,
                                           const uint32_t *__restrict__ cnt,
-                                          uint32_t n_src, uint32_t row_begin, uint32_t row_count, uint32_t cap,
+                                          uint32_t n_src, uint32_t list_base, uint32_t row_count, uint32_t cap,
                                           const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded, float *__restrict__ out,
                                           const uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
   if (i < count) {
-    const uint32_t g = ids[i], r = g - row_begin;
-    const uint32_t lr = inv ? inv[g] : r;
+    const uint32_t g = ids[i];
+    const uint32_t lr = (inv ? inv[g] : g) - list_base;
     bool over = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + lr] > cap;
     // a list that ran over although the first threshold was the right one is a dense neighbourhood: the tight threshold and
@@ -1024,6 +1026,144 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
   return (uint32_t)std::max<int64_t>(K + 1, std::min<int64_t>(cap_opt, 1024));
 }
 
+// ---- the join on an image in the library's own row order: preparation ------------------------------------------------------
+// Everything in front of the contraction of the tile pairs: the rotated coordinates of the rows (rotate_wide.hip), the row
+// order found on them (row_order.hip), the f16 image packed in that order, the thresholds (grouped sample + check, or the
+// plain sample).  All of it is a function of the rows and the options alone and every sum on the way has a fixed order, so
+// every rank of a sharded build that holds all rows computes the SAME order, image and thresholds (csrc/sharded.hip calls
+// this on every rank and then contracts only the tile pairs of its own range of image positions).
+int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj) {
+  const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
+  const uint32_t b_alloc = (b_tiles + 1) & ~1u;
+  ctx->f16_err = -1.0;
+  oj.cap = knn_join_cap(ctx, K, false);
+  AS_TRY(oj.theta_own.alloc(ctx, n));
+  AS_TRY(oj.theta2_own.alloc(ctx, n));
+  // rows grouped by direction in the operand image (row_order.hip): the thresholds come out by image position
+  const bool reorder_narrow = join_on_f16(ctx, d) && d <= 128 && ctx->opt_join_row_order && n >= 65536 && ctx->opt_join_bf16 &&
+                              !(ctx->opt_debug & 32);  // (the f16 threshold pass is what reads the image)
+  bool &reorder = oj.reorder;
+  reorder = reorder_narrow;
+  // rows wider than 128 (up to 1024): their rotated coordinates (31 dominant directions + tail norm, rotate_wide.hip) serve
+  // the int8 first pass and, being 32 wide, the row order as well
+  oj.wide_pre = false;
+  if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
+      n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
+    ProfScope ps(ctx, "knn_join_prefilter_basis");
+    double tail = 1.0;
+    AS_TRY(oj.rot_z.alloc(ctx, (size_t)n * 32));
+    AS_TRY(oj.rot_norm.alloc(ctx, n));
+    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail));
+    ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
+    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= 0.10;
+  }
+  // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
+  const bool reorder_wide = oj.wide_pre && ctx->opt_join_row_order && n >= 65536;
+  if (reorder || reorder_wide) {
+    AS_TRY(oj.perm_own.alloc(ctx, n));
+    if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, oj.perm_own.p));
+    else {
+      AS_TRY(oj.order_piv.alloc(ctx, (size_t)1024 * 128));
+      AS_TRY(oj.order_starts.alloc(ctx, 1025));
+      AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
+                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np));
+    }
+    AS_TRY(oj.theta_pos.alloc(ctx, n));
+    AS_TRY(oj.theta2_pos.alloc(ctx, n));
+    reorder = true;
+  }
+  ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
+  if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
+    const uint32_t tiles = packed_tiles_f16(n);
+    AS_TRY(oj.Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
+    AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr));
+  }
+  // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
+  // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
+  if (reorder_wide && d <= 128 && oj.order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 && !(ctx->opt_debug & 32) &&
+      ctx->opt_join_sample <= 0) {
+    const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
+    const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
+    AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
+                                       oj.theta_pos.p, m2, oj.theta2_pos.p));
+    if (ctx->opt_debug & 65536) {  // diagnostic: a checksum of the thresholds (are they the same from run to run?)
+      DevBuf<unsigned long long> cs;
+      AS_TRY(cs.alloc(ctx, 1));
+      AS_HIP(ctx, hipMemsetAsync(cs.p, 0, sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(theta_checksum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const float *)oj.theta_pos.p, n, cs.p);
+      unsigned long long h = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h, cs.p, sizeof(h)));
+      ctx->stats["knn_join_theta_checksum"] = (int64_t)(h & 0x7FFFFFFFFFFFFFFFull);
+    }
+    // How good they are depends on the data (do the pivots cover its clusters?), so they are CHECKED: 4096 rows spread over
+    // the image get their threshold against the whole sample as well (0.1 ms), and if more than 0.6 % of them sit more than
+    // 5e-3 below it (rows whose neighbours live in groups the sample of their own group does not reach: every one of them
+    // lists thousands of pairs) the grouped thresholds are dropped for the plain pass.  (1 M x 128 bench mixture, 1024
+    // pivots: 0.24 %; 700 k rows: 0.27 %; 400 k rows, 768 pivots: 2.9 %; 200 k rows: 4.1 %.)
+    const uint32_t n_chk = 4096, stride = n / n_chk;
+    DevBuf<uint32_t> chk_ids, chk_bad, chk_sid;
+    DevBuf<float> chk_t1, chk_t2;
+    DevBuf<unsigned char> chk_img;
+    const uint32_t ns_all = std::max(256u, (n / 32u) & ~255u);
+    AS_TRY(chk_ids.alloc(ctx, n_chk));
+    AS_TRY(chk_bad.alloc(ctx, 1));
+    AS_TRY(chk_sid.alloc(ctx, ns_all));
+    AS_TRY(chk_t1.alloc(ctx, n_chk));
+    AS_TRY(chk_t2.alloc(ctx, n_chk));
+    AS_TRY(chk_img.alloc(ctx, packed_vecs_f16(n_chk / kTileRows, d) * 16));
+    AS_HIP(ctx, hipMemsetAsync(chk_bad.p, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(theta_check_ids_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, stride,
+                       n_chk, chk_ids.p);
+    hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_all, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n,
+                       ns_all, chk_sid.p);  // (the same sampled positions, all of them: what differs is the restriction alone)
+    AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
+    AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
+    hipLaunchKernelGGL(theta_check_count_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const float *)oj.theta_pos.p, stride,
+                       (const float *)chk_t1.p, n_chk, 5e-3f, chk_bad.p);
+    uint32_t h_bad = 0;
+    AS_TRY(read_u32(ctx, chk_bad.p, &h_bad));
+    ctx->stats["knn_join_theta_grouped_bad"] = h_bad;
+    if (h_bad * 1000u <= 6u * n_chk) {
+      oj.have_theta2 = true;
+      oj.grouped_theta = true;
+    } else {
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, oj.theta_pos.p, nullptr, oj.theta2_pos.p, &oj.have_theta2, oj.Phown.p));
+    }
+    ctx->stats["knn_join_theta_grouped"] = oj.grouped_theta ? 1 : 0;
+  } else {
+    ctx->stats["knn_join_theta_grouped"] = 0;
+    AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? oj.theta_pos.p : oj.theta_own.p, nullptr,
+                               reorder ? oj.theta2_pos.p : oj.theta2_own.p, &oj.have_theta2, oj.Phown.p));
+  }
+  if (reorder) {  // ... and go back to row order for everything behind the join
+    AS_TRY(scatter_by_perm(ctx, oj.theta_pos.p, oj.perm_own.p, n, oj.theta_own.p));
+    if (oj.have_theta2) AS_TRY(scatter_by_perm(ctx, oj.theta2_pos.p, oj.perm_own.p, n, oj.theta2_own.p));
+  }
+  if (join_on_bf16(ctx, d)) {
+    AS_TRY(oj.P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
+    AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, oj.P16own.p, b_alloc));
+  }
+  oj.perm = oj.reorder ? oj.perm_own.p : nullptr;
+  oj.theta_image = oj.reorder ? oj.theta_pos.p : oj.theta_own.p;
+  return AS_OK;
+}
+
+// Contracts the tile pairs owned by the 512-position super tiles of [pos_begin, pos_begin + pos_count) of the prepared image.
+// cnt (n) / cand (n x cap slots of two words): lists_by_pos = indexed by image position and holding positions, else indexed
+// by row and holding rows (the join kernel translates where it appends).
+int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos) {
+  // (the directions were tried above and do not carry the rows: the first pass, if any, takes the full-width image without
+  // looking for them again)
+  const int64_t saved_mode = ctx->opt_join_prefilter;
+  if (oj.rot_z.p && !oj.wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
+  const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_image, oj.cap, cnt, cand, nullptr, oj.P16own.p,
+                                      oj.Phown.p, (oj.reorder && !lists_by_pos) ? oj.perm_own.p : nullptr,
+                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr);
+  ctx->opt_join_prefilter = saved_mode;
+  return rc_pairs;
+}
+
 // ---- K2 driver ----------------------------------------------------------------------------------
 int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64, uint64_t d64, uint64_t row_begin,
              uint64_t row_count64, uint32_t K, int rectify, uint32_t *out_idx, double *out_dist, const JoinSources *js) {
@@ -1040,7 +1180,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                          (join_on_f16(ctx, d) || join_on_bf16(ctx, d)) &&
                          (js != nullptr || (row_begin == 0 && row_count == n && join_supported(ctx, n, d, 0)));
   if ((!stages_fit && !deep_join) || n < 4 * kTileRows || row_count == 0 || !rerank_fits(d))  // small, deep or very wide problems: exact scan
-    return knn_exact(ctx, rows, norms, n, d, nullptr, row_begin, row_count, K, rectify, out_idx, out_dist, 0);
+    return knn_exact(ctx, rows, norms, n, d, (js && js->a_ids) ? js->a_ids : nullptr, (js && js->a_ids) ? 0 : row_begin, row_count, K, rectify,
+                     out_idx, out_dist, 0);
 
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;  // even: the f32 pass reads A tiles in pairs
@@ -1094,157 +1235,38 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
   JoinSources local{};  // outlives the block below: the later stages still read js->packed
-  // own join on the bf16 pipe: the split image and the second (looser) thresholds stay for the second pass over
-  // the rows the first one leaves uncertified (rect_stage below)
-  DevBuf<unsigned char> P16own, Phown;
-  DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos;
-  DevBuf<uint32_t> perm_own, inv_own;
-  bool grouped_theta = false;           // thresholds of the own join from the sample of the nearest pivot groups
-  DevBuf<double> rot_z, rot_norm;       // own join: the rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
-  DevBuf<float> order_piv;              // the pivots of the order found on them (np x 32), where the rows of each begin
-  DevBuf<uint32_t> order_starts;
-  uint32_t order_np = 0;
-  bool wide_pre = false;                // ... are in use (the directions carry the rows)
-  const uint32_t *perm_used = nullptr;  // image position -> row of the own join's f16 image
-  bool lists_by_pos = false;            // ... and whether the lists of the own join are indexed by (and hold) positions
+  // own join: the images, the order, the rotated coordinates and the thresholds (own_join_prepare) stay for the later stages;
+  // a build sharded by image positions (csrc/sharded.hip) has prepared the same thing and hands it in with the lists
+  OwnJoin oj_local;
+  const OwnJoin *oj = js ? js->oj : nullptr;
+  bool lists_by_pos = false;            // the lists of the own join are indexed by (and hold) image positions
   DevBuf<uint32_t> cnt_own, cand_own;
-  bool have_theta2 = false;
   if (use_join) {
     if (own_join) {
-      ctx->f16_err = -1.0;
-      const uint32_t cap = knn_join_cap(ctx, K, false);
-      AS_TRY(theta_own.alloc(ctx, n));
-      AS_TRY(theta2_own.alloc(ctx, n));
-      // rows grouped by direction in the operand image (row_order.hip): the thresholds come out by image position
-      const bool reorder_narrow = join_on_f16(ctx, d) && d <= 128 && ctx->opt_join_row_order && n >= 65536 && ctx->opt_join_bf16 &&
-                                  !(ctx->opt_debug & 32);  // (the f16 threshold pass is what reads the image)
-      bool reorder = reorder_narrow;
-      // rows wider than 128 (up to 1024): their rotated coordinates (31 dominant directions + tail norm, rotate_wide.hip) serve
-      // the int8 first pass and, being 32 wide, the row order as well
-      wide_pre = false;
-      if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
-          n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
-        ProfScope ps(ctx, "knn_join_prefilter_basis");
-        double tail = 1.0;
-        AS_TRY(rot_z.alloc(ctx, (size_t)n * 32));
-        AS_TRY(rot_norm.alloc(ctx, n));
-        AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, rot_z.p, rot_norm.p, &tail));
-        ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
-        wide_pre = ctx->opt_join_prefilter == 3 || tail <= 0.10;
-      }
-      // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
-      const bool reorder_wide = wide_pre && ctx->opt_join_row_order && n >= 65536;
-      if (reorder || reorder_wide) {
-        AS_TRY(perm_own.alloc(ctx, n));
-        if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, perm_own.p));
-        else {
-          AS_TRY(order_piv.alloc(ctx, (size_t)1024 * 128));
-          AS_TRY(order_starts.alloc(ctx, 1025));
-          AS_TRY(cluster_order(ctx, rot_z.p, rot_norm.p, n, 32, perm_own.p, order_piv.p,
-                               (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), order_starts.p, &order_np));
-        }
-        AS_TRY(theta_pos.alloc(ctx, n));
-        AS_TRY(theta2_pos.alloc(ctx, n));
-        reorder = true;
-      }
-      ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
-      if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
-        const uint32_t tiles = packed_tiles_f16(n);
-        AS_TRY(Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
-        AS_TRY(pack_f16_all(ctx, rows, norms, n, d, Phown.p, tiles, reorder ? perm_own.p : nullptr));
-      }
-      // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
-      // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
-      if (reorder_wide && d <= 128 && order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 && !(ctx->opt_debug & 32) &&
-          ctx->opt_join_sample <= 0) {
-        const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
-        const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
-        AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, Phown.p, perm_own.p, order_starts.p, order_np, order_piv.p, 32, 32, m,
-                                           theta_pos.p, m2, theta2_pos.p));
-        if (ctx->opt_debug & 65536) {  // diagnostic: a checksum of the thresholds (are they the same from run to run?)
-          DevBuf<unsigned long long> cs;
-          AS_TRY(cs.alloc(ctx, 1));
-          AS_HIP(ctx, hipMemsetAsync(cs.p, 0, sizeof(unsigned long long), ctx->stream));
-          hipLaunchKernelGGL(theta_checksum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const float *)theta_pos.p, n, cs.p);
-          unsigned long long h = 0;
-          AS_HIP(ctx, copy_d2h(ctx, &h, cs.p, sizeof(h)));
-          ctx->stats["knn_join_theta_checksum"] = (int64_t)(h & 0x7FFFFFFFFFFFFFFFull);
-        }
-        // How good they are depends on the data (do the pivots cover its clusters?), so they are CHECKED: 4096 rows spread over
-        // the image get their threshold against the whole sample as well (0.1 ms), and if more than 0.6 % of them sit more than
-        // 5e-3 below it (rows whose neighbours live in groups the sample of their own group does not reach: every one of them
-        // lists thousands of pairs) the grouped thresholds are dropped for the plain pass.  (1 M x 128 bench mixture, 1024
-        // pivots: 0.24 %; 700 k rows: 0.27 %; 400 k rows, 768 pivots: 2.9 %; 200 k rows: 4.1 %.)
-        const uint32_t n_chk = 4096, stride = n / n_chk;
-        DevBuf<uint32_t> chk_ids, chk_bad, chk_sid;
-        DevBuf<float> chk_t1, chk_t2;
-        DevBuf<unsigned char> chk_img;
-        const uint32_t ns_all = std::max(256u, (n / 32u) & ~255u);
-        AS_TRY(chk_ids.alloc(ctx, n_chk));
-        AS_TRY(chk_bad.alloc(ctx, 1));
-        AS_TRY(chk_sid.alloc(ctx, ns_all));
-        AS_TRY(chk_t1.alloc(ctx, n_chk));
-        AS_TRY(chk_t2.alloc(ctx, n_chk));
-        AS_TRY(chk_img.alloc(ctx, packed_vecs_f16(n_chk / kTileRows, d) * 16));
-        AS_HIP(ctx, hipMemsetAsync(chk_bad.p, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(theta_check_ids_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)perm_own.p, stride,
-                           n_chk, chk_ids.p);
-        hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_all, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)perm_own.p, n,
-                           ns_all, chk_sid.p);  // (the same sampled positions, all of them: what differs is the restriction alone)
-        AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
-        AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
-        hipLaunchKernelGGL(theta_check_count_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const float *)theta_pos.p, stride,
-                           (const float *)chk_t1.p, n_chk, 5e-3f, chk_bad.p);
-        uint32_t h_bad = 0;
-        AS_TRY(read_u32(ctx, chk_bad.p, &h_bad));
-        ctx->stats["knn_join_theta_grouped_bad"] = h_bad;
-        if (h_bad * 1000u <= 6u * n_chk) {
-          have_theta2 = true;
-          grouped_theta = true;
-        } else {
-          AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, theta_pos.p, nullptr, theta2_pos.p, &have_theta2, Phown.p));
-        }
-        ctx->stats["knn_join_theta_grouped"] = grouped_theta ? 1 : 0;
-      } else {
-        ctx->stats["knn_join_theta_grouped"] = 0;
-        AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, nullptr,
-                                   reorder ? theta2_pos.p : theta2_own.p, &have_theta2, Phown.p));
-      }
-      if (reorder) {  // ... and go back to row order for everything behind the join
-        AS_TRY(scatter_by_perm(ctx, theta_pos.p, perm_own.p, n, theta_own.p));
-        if (have_theta2) AS_TRY(scatter_by_perm(ctx, theta2_pos.p, perm_own.p, n, theta2_own.p));
-      }
-      if (join_on_bf16(ctx, d)) {
-        AS_TRY(P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
-        AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16own.p, b_alloc));
-      }
+      AS_TRY(own_join_prepare(ctx, rows, norms, n, d, K, oj_local));
+      const uint32_t cap = oj_local.cap;
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       // 128 columns: the lists stay in image positions and the pruning kernel of the re-rank translates the ~30 survivors of
       // a row (rerank_split.h); other widths: the join kernel translates every entry where it appends it
-      lists_by_pos = reorder && d == 128 && ctx->opt_rerank_split && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
+      lists_by_pos = oj_local.reorder && d == 128 && ctx->opt_rerank_split && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
                      ctx->opt_debug != 5;
       if (lists_by_pos) {
-        AS_TRY(inv_own.alloc(ctx, n));
-        hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, perm_own.p, n, inv_own.p);
+        AS_TRY(oj_local.inv_own.alloc(ctx, n));
+        hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
-      {
-        // (the directions were tried above and do not carry the rows: the first pass, if any, takes the full-width image without
-        // looking for them again)
-        const int64_t saved_mode = ctx->opt_join_prefilter;
-        if (rot_z.p && !wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
-        const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, 0, n, reorder ? theta_pos.p : theta_own.p, cap, cnt_own.p, cand_own.p,
-                                            nullptr, P16own.p, Phown.p, (reorder && !lists_by_pos) ? perm_own.p : nullptr,
-                                            reorder ? perm_own.p : nullptr, wide_pre ? rot_z.p : nullptr);
-        ctx->opt_join_prefilter = saved_mode;
-        if (rc_pairs != AS_OK) return rc_pairs;
-      }
-      perm_used = reorder ? perm_own.p : nullptr;
+      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos));
       if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
-      local = JoinSources{nullptr, theta_own.p, 1, cap, cnt_own.p, cand_own.p, have_theta2 ? theta2_own.p : nullptr, P16own.p, Phown.p};
+      local = JoinSources{nullptr, oj_local.theta_own.p, 1, cap, cnt_own.p, cand_own.p, oj_local.have_theta2 ? oj_local.theta2_own.p : nullptr,
+                          oj_local.P16own.p, oj_local.Phown.p};
       js = &local;
+      oj = &oj_local;
     }
     DevBuf<unsigned long long> scored;
+    // the rows of the range: [row_begin, row_begin + row_count), or the list js->a_ids (a range of image positions)
+    const uint32_t *a_ids = js->a_ids;
+    const uint32_t *ent_perm = lists_by_pos ? oj->perm_own.p : nullptr;   // list entries are image positions: position -> row
+    const uint32_t *list_inv = lists_by_pos ? oj->inv_own.p : nullptr;    // ... and the list of row a sits at inv[a]
     {
       const uint32_t cmax = std::min<uint32_t>(js->n_src * js->cap, std::max<uint32_t>(512, js->cap));
       GraphBound bnd{join_delta(ctx, d), rectify};
@@ -1270,15 +1292,14 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
                            ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                           force.p, prune_delta, rectify, records.p, slots, lists_by_pos ? perm_own.p : nullptr,
-                           lists_by_pos ? inv_own.p : nullptr, scored.p);
+                           force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids);
         AS_HIP(ctx, hipGetLastError());
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
     hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(std::min<uint32_t>(row_count, 256 * 7 * 8)), dim3(64), \
                        rs_lds(PC == 1 ? 2 : 4), ctx->stream, \
                        rows, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, \
-                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u);                                             \
+                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u, a_ids);                                      \
     break;
         switch (d / 128) {
           AS_SCORE(1) AS_SCORE(2) AS_SCORE(3) AS_SCORE(4) AS_SCORE(5) AS_SCORE(6) AS_SCORE(7) AS_SCORE(8)
@@ -1293,7 +1314,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));                               \
   hipLaunchKernelGGL((rerank_join_d128_kernel<GraphDistPolicy, GraphBound, R, NB>),                                        \
                      dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 16)), dim3(256), lds128, ctx->stream, rows, rows,   \
-                     (const uint32_t *)nullptr, (uint32_t)row_begin, row_count, js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
+                     a_ids, (uint32_t)row_begin, row_count, a_ids ? js->theta_local : js->theta, js->n_src, js->cnt, js->cand, js->cap, cmax, K, force.p, pol, \
                      bnd, prune_delta, rectify, kmax, out_dist, out_idx, fail1.p, fail_count.p, err.p)
         if (rr_rows == 8) { AS_RR(8, 1); }
         else { AS_RR(16, 1); }
@@ -1303,8 +1324,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_join_kernel<GraphDistPolicy, GraphBound>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rerank_join_kernel<GraphDistPolicy, GraphBound>), dim3(std::min<uint64_t>(cdiv(row_count, 4), 8192)),
-                           dim3(256), lds, ctx->stream, rows, rows, (const uint32_t *)nullptr, d, (uint32_t)row_begin, row_count,
-                           js->theta, js->n_src, js->cnt,
+                           dim3(256), lds, ctx->stream, rows, rows, a_ids, d, (uint32_t)row_begin, row_count,
+                           a_ids ? js->theta_local : js->theta, js->n_src, js->cnt,
                            js->cand, js->cap, cmax, K, force.p, pol, bnd, prune_delta, rectify, out_dist, out_idx, fail1.p,
                            fail_count.p, err.p);
       }
@@ -1413,13 +1434,25 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   ctx->stats["knn_col_splits"] = pb.splits;
   if (n_fail == 0) return AS_OK;
 
+  // what the later stages need to know about the join behind the lists
+  const bool grouped_theta = oj && oj->grouped_theta;                                // thresholds from the sample of the nearest pivot groups
+  const bool wide_pre = oj && oj->wide_pre;                                          // the rotated coordinates of the rows are in use
+  const double *rot_z = oj ? oj->rot_z.p : nullptr;                                  // ... n x 32
+  const uint32_t *perm_used = (oj && oj->reorder) ? oj->perm_own.p : nullptr;        // image position -> row of the f16 image js->packedh
+  // the lists of row g: index (lists_inv ? lists_inv[g] : g) - list_base (second_theta_kernel); its looser threshold: theta2[g - t2_base]
+  const uint32_t *lists_inv = (lists_by_pos || (js && js->a_ids)) ? oj->inv_own.p : nullptr;
+  const uint32_t list_base = (js && js->a_ids) ? js->list_base : (lists_by_pos ? 0u : (uint32_t)row_begin);
+  const uint32_t t2_base = (js && js->a_ids) ? 0u : (uint32_t)row_begin;
   // Failed rows go through the stages that follow, each on the gathered list of what the one before
   // could not certify: (after the join only) the f32 top-k pass, the f64 MFMA pass, the exact scan.
   // cur_ids = global ids of the rows still open, cur_pos = their positions in the output range.
   DevBuf<uint32_t> gids;
   AS_TRY(gids.alloc(ctx, n_fail));
-  hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream,
-                     (const uint32_t *)nullptr, fail1.p, n_fail, (uint32_t)row_begin, gids.p);
+  {
+    const uint32_t *a_ids_f = js ? js->a_ids : nullptr;  // (a range of image positions: the rows are a list)
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream, a_ids_f, fail1.p, n_fail,
+                       a_ids_f ? 0u : (uint32_t)row_begin, gids.p);
+  }
   const uint32_t *cur_ids = gids.p;
   const uint32_t *cur_pos = fail1.p;
   uint32_t cur_n = n_fail;
@@ -1538,11 +1571,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, n / ns, sample_half_bits(ns), sid.p);
       AS_TRY(join_thresholds_f16(ctx, rows, norms, d, PA.p, 0, nf, sid.p, ns, m, t1.p, m2, t2.p));
       hipLaunchKernelGGL(second_theta_fresh_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, (const float *)t1.p, (const float *)t2.p,
-                         js->theta, js->cnt, js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p,
-                         lists_by_pos ? inv_own.p : nullptr);
+                         js->theta, js->cnt, js->n_src, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv);
     } else {
       hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
-                         js->n_src, (uint32_t)row_begin, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_by_pos ? inv_own.p : nullptr);
+                         js->n_src, t2_base, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv);
     }
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
@@ -1604,12 +1636,12 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     DevBuf<unsigned char> f_p8, f_q8;
     StreamFilter flt{};
     bool use_flt = false;
-    if (wide_pre && rot_z.p && d == 128 && ctx->opt_search_stream_filter && n < (1u << 27)) {
+    if (wide_pre && rot_z && d == 128 && ctx->opt_search_stream_filter && n < (1u << 27)) {
       const uint32_t tiles = packed_tiles_f16(n);
       double e_items = 0.0;
       AS_TRY(f_p8.alloc(ctx, (size_t)tiles * 4 * 64 * 16));
       AS_TRY(f_q8.alloc(ctx, (size_t)4 * 64 * 16));
-      AS_TRY(pack_rotated_from_z(ctx, rot_z.p, nullptr, n, tiles, f_p8.p, &e_items));
+      AS_TRY(pack_rotated_from_z(ctx, rot_z, nullptr, n, tiles, f_p8.p, &e_items));
       flt.P8 = f_p8.p;
       flt.err_items = (float)(e_items * (1.0 + 1e-6));
       use_flt = true;
@@ -1619,7 +1651,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       std::vector<uint32_t> redo;
       if (use_flt) {
         double e_a = 0.0;
-        AS_TRY(pack_rotated_from_z(ctx, rot_z.p, cur_ids + c0, cn, 1, f_q8.p, &e_a));
+        AS_TRY(pack_rotated_from_z(ctx, rot_z, cur_ids + c0, cn, 1, f_q8.p, &e_a));
         flt.PQ8 = f_q8.p;
         flt.err_a = (float)(e_a * (1.0 + 1e-6));
       }

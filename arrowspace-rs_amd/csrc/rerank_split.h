@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            const uint8_t *__restrict__ force_exact, double prune_delta, int prune_rectify,
                                                            uint32_t *__restrict__ records, int slots,
                                                            const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv,
-                                                           unsigned long long *__restrict__ scored_total) {
+                                                           unsigned long long *__restrict__ scored_total,
+                                                           const uint32_t *__restrict__ a_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
   unsigned long long scored = 0;  // candidates this wave hands to the scoring kernel (the rows it fetches: bench.py's algorithmic bytes)
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
-    const uint32_t a = row_begin + r;
+    // (a_ids: the rows of the range as a list -- a rank of a build sharded by image positions finishes the rows perm[pb .. pe))
+    const uint32_t a = a_ids ? a_ids[r] : row_begin + r;
     // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
     // holds positions; what leaves this kernel is row ids again
     const uint32_t lr = inv ? inv[a] : r;
@@ -150,8 +152,11 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
                                                                const uint32_t *__restrict__ records, uint32_t K, int rectify,
                                                                GraphBound bnd, double *__restrict__ out_key,
                                                                uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows,
-                                                               uint32_t *__restrict__ fail_count, uint32_t dbg) {
+                                                               uint32_t *__restrict__ fail_count, uint32_t dbg,
+                                                               const uint32_t *__restrict__ a_ids) {
   constexpr uint32_t pieces = PIECES, d = 128u * PIECES;
+  // row of the range at index r (wave-uniform: a_ids comes through the scalar cache)
+  auto arow = [&](uint32_t r) __attribute__((always_inline)) { return a_ids ? a_ids[r] : row_begin + r; };
   constexpr uint32_t kRsWords = (uint32_t)rs_words(SLOTS), kRsNormsAt = (uint32_t)rs_norms_at(SLOTS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     const uint4 q0 = *reinterpret_cast<const uint4 *>(rec), q1 = *reinterpret_cast<const uint4 *>(rec + 4);
     const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8), q3 = *reinterpret_cast<const uint4 *>(rec + 12);
     const uint32_t raw[kRsRows] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const uint32_t self = arow(row);
 #pragma unroll
-    for (int t = 0; t < kRsRows; ++t) ids[t] = (!cu.done && cu.b * kRsRows + t < cu.C) ? raw[t] : row_begin + row;
+    for (int t = 0; t < kRsRows; ++t) ids[t] = (!cu.done && cu.b * kRsRows + t < cu.C) ? raw[t] : self;
   };
 #define AS_GL(S, T) rs_gload16(S.v[T], lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)ids_[T]) * d + is.q * 128u);
 #define AS_ISSUE(S)                                                                                                         \
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     AS_GL(S, 0) AS_GL(S, 1) AS_GL(S, 2) AS_GL(S, 3) AS_GL(S, 4) AS_GL(S, 5) AS_GL(S, 6) AS_GL(S, 7)                         \
     AS_GL(S, 8) AS_GL(S, 9) AS_GL(S, 10) AS_GL(S, 11) AS_GL(S, 12) AS_GL(S, 13) AS_GL(S, 14) AS_GL(S, 15)                   \
     rs_gload16(S.x, lane_off,                                                                                               \
-               X + (uint64_t)__builtin_amdgcn_readfirstlane((int)(row_begin + (is.done ? 0u : is.r))) * d + is.q * 128u);   \
+               X + (uint64_t)__builtin_amdgcn_readfirstlane((int)arow(is.done ? 0u : is.r)) * d + is.q * 128u);              \
     is.advance(records, pieces, stride, row_count);                                                                         \
   }
 
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
         uint32_t jj = ids[0];
 #pragma unroll
         for (int t = 1; t < kRsRows; ++t) jj = lane == t ? ids[t] : jj;
-        const uint32_t a = row_begin + ps.r;
+        const uint32_t a = arow(ps.r);
         double key = __builtin_inf();
         uint32_t id = kNoIdx;
         if (a != jj) {  // GraphDistPolicy::key with the operands at hand

@@ -75,15 +75,15 @@ int rccl_all_to_all_v(void *user, const void *send, const uint64_t *send_bytes, 
   as_comm *c = static_cast<as_comm *>(user);
   Rccl &r = rccl();
   if (r.GroupStart() != ncclSuccess) return AS_ERR_HIP;
-  for (int p = 0; p < c->world; ++p) {
+  bool ok = true;
+  for (int p = 0; p < c->world && ok; ++p) {
     if (send_bytes[p])
-      if (r.Send(static_cast<const char *>(send) + send_offsets[p], send_bytes[p], ncclInt8, p, c->nccl, (hipStream_t)stream) != ncclSuccess)
-        return AS_ERR_HIP;
-    if (recv_bytes[p])
-      if (r.Recv(static_cast<char *>(recv) + recv_offsets[p], recv_bytes[p], ncclInt8, p, c->nccl, (hipStream_t)stream) != ncclSuccess)
-        return AS_ERR_HIP;
+      ok = r.Send(static_cast<const char *>(send) + send_offsets[p], send_bytes[p], ncclInt8, p, c->nccl, (hipStream_t)stream) == ncclSuccess;
+    if (ok && recv_bytes[p])
+      ok = r.Recv(static_cast<char *>(recv) + recv_offsets[p], recv_bytes[p], ncclInt8, p, c->nccl, (hipStream_t)stream) == ncclSuccess;
   }
-  return r.GroupEnd() == ncclSuccess ? AS_OK : AS_ERR_HIP;
+  // (the group is closed on the error path too: an open group would swallow every later call on this communicator)
+  return (r.GroupEnd() == ncclSuccess && ok) ? AS_OK : AS_ERR_HIP;
 }
 int rccl_all_gather_v(void *user, const void *send, uint64_t send_bytes, void *recv, const uint64_t *recv_bytes,
                       const uint64_t *recv_offsets, void *stream) {
@@ -116,6 +116,178 @@ int gather_rows(as_ctx *ctx, as_comm *c, const void *mine, void *all, uint64_t n
   }
   const int rc = c->ops.all_gather_v(c->ops.user, mine, my, all, rb.data(), ro.data(), ctx->stream);
   return rc == AS_OK ? AS_OK : fail(ctx, rc, "sharded build: all-gather failed");
+}
+
+// ---- lists of a build sharded by IMAGE POSITIONS ---------------------------------------------------------------------------
+// Every rank has prepared the same join (own_join_prepare: order, image, thresholds) and contracted the tile pairs of its own
+// range of positions; what it listed for positions of other ranks has crossed the links in compact form.  Here, per local
+// position r (one wave): source `me` (this rank's own pairs) becomes list 0, all other sources are appended into list 1, and
+// every entry is translated from image position to row id (perm; nullptr: the image is in row order).  A foreign source whose
+// list ran over, or a merged list longer than `slots`, is reported as slots + 1 entries: the re-rank takes that as an overflow
+// and the row goes on to the second pass.
+// cnt_src: W x rows (raw counts); recv: the used slots, source-major; off: exclusive scan of min(cnt, slots) in that order.
+__global__ __launch_bounds__(256) void merge_lists_kernel(const uint32_t *__restrict__ cnt_src, const uint2 *__restrict__ recv,
+                                                          const uint64_t *__restrict__ off, uint32_t W, uint32_t me, uint32_t rows,
+                                                          uint32_t slots, const uint32_t *__restrict__ perm, uint32_t *__restrict__ cnt2,
+                                                          uint2 *__restrict__ cand2) {
+  const int lane = threadIdx.x & 63;
+  for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+    uint32_t foreign = 0;
+    bool over = false;
+    for (uint32_t sidx = 0; sidx < W; ++sidx) {
+      const uint32_t raw = cnt_src[(size_t)sidx * rows + r], used = min(raw, slots);
+      const uint2 *src = recv + off[(size_t)sidx * rows + r];
+      if (sidx == me) {
+        for (uint32_t e = lane; e < used; e += 64) {
+          uint2 v = src[e];
+          v.x = perm ? perm[v.x] : v.x;
+          cand2[(size_t)r * slots + e] = v;
+        }
+        if (lane == 0) cnt2[r] = raw;
+      } else {
+        over = over || raw > slots;
+        for (uint32_t e = lane; e < used; e += 64) {
+          if (foreign + e < slots) {
+            uint2 v = src[e];
+            v.x = perm ? perm[v.x] : v.x;
+            cand2[((size_t)rows + r) * slots + foreign + e] = v;
+          }
+        }
+        foreign += used;
+      }
+    }
+    if (lane == 0) cnt2[(size_t)rows + r] = (over || foreign > slots) ? slots + 1 : foreign;
+  }
+}
+
+// table rows by image position -> by row: out[perm[p]] = in[p] (K entries per row)
+__global__ void unpermute_table_kernel(const uint64_t *__restrict__ idx_in, const double *__restrict__ dst_in,
+                                       const uint32_t *__restrict__ perm, uint64_t n, uint32_t K, uint64_t *__restrict__ idx_out,
+                                       double *__restrict__ dst_out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * K) return;
+  const uint64_t p = t / K, s_ = t - p * K;
+  const uint64_t r = perm[p];
+  idx_out[r * K + s_] = idx_in[t];
+  dst_out[r * K + s_] = dst_in[t];
+}
+__global__ void invert_perm_u32_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = i;
+}
+__global__ void used_slots_kernel(const uint32_t *__restrict__ cnt, uint64_t n, uint32_t slots, uint32_t *__restrict__ used) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) used[i] = min(cnt[i], slots);
+}
+__global__ __launch_bounds__(256) void pack_lists_kernel(const uint32_t *__restrict__ cnt, uint64_t n, uint32_t slots,
+                                                         const uint64_t *__restrict__ offsets, const uint2 *__restrict__ src,
+                                                         uint2 *__restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (uint64_t)gridDim.x * 4) {
+    const uint32_t used = min(cnt[r], slots);
+    const uint64_t o = offsets[r];
+    for (uint32_t e = lane; e < used; e += 64) dst[o + e] = src[r * slots + e];
+  }
+}
+__global__ void narrow_u64_kernel(const uint64_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] == 0xFFFFFFFFFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)in[i];
+}
+__global__ void widen_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] == 0xFFFFFFFFu ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)in[i];
+}
+
+// ---- lambda statistics and search of a sharded index -----------------------------------------------------------------------
+// min / max / sum of a shard's lambdas: 256 blocks, each a fixed stride through the shard and a fixed tree inside, so the
+// partial of a block is the same in every run; the host adds the blocks, and then the ranks, in index order.
+__global__ __launch_bounds__(256) void lambda_stats_kernel(const double *__restrict__ lam, uint64_t n, double *__restrict__ part /* gridDim.x x 3 */) {
+  __shared__ double s_mn[256], s_mx[256], s_sm[256];
+  double mn = __builtin_inf(), mx = -__builtin_inf(), sm = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const double v = lam[i];
+    mn = v < mn ? v : mn;  // (f64::min / max folds of src/builder.rs:434-445: a NaN never replaces the running value)
+    mx = v > mx ? v : mx;
+    sm += v;
+  }
+  s_mn[threadIdx.x] = mn;
+  s_mx[threadIdx.x] = mx;
+  s_sm[threadIdx.x] = sm;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_mn[threadIdx.x] = s_mn[threadIdx.x + o] < s_mn[threadIdx.x] ? s_mn[threadIdx.x + o] : s_mn[threadIdx.x];
+      s_mx[threadIdx.x] = s_mx[threadIdx.x + o] > s_mx[threadIdx.x] ? s_mx[threadIdx.x + o] : s_mx[threadIdx.x];
+      s_sm[threadIdx.x] += s_sm[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 3 + 0] = s_mn[0];
+    part[blockIdx.x * 3 + 1] = s_mx[0];
+    part[blockIdx.x * 3 + 2] = s_sm[0];
+  }
+}
+
+// Global top-k of every query from the per-shard top-k lists (src/core.rs:778-798 sorts ALL items by score with a stable
+// sort and truncates: ties keep the lower index first).  gi / gs: W x nq x k, shard s's list of query q sorted by (score desc,
+// id asc), ids global and shards in ascending id order, exhausted slots id = UINT64_MAX.  One thread per query walks the W
+// heads: the best head by (score desc, id asc) is the next result -- the order the stable sort of the whole table gives.
+__global__ void merge_topk_kernel(const uint64_t *__restrict__ gi, const double *__restrict__ gs, uint32_t W, uint64_t nq, uint32_t k,
+                                  uint64_t *__restrict__ out_i, double *__restrict__ out_s) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t head[64];
+  for (uint32_t w = 0; w < W; ++w) head[w] = 0;
+  for (uint32_t t = 0; t < k; ++t) {
+    int best = -1;
+    double bs = 0.0;
+    uint64_t bi = 0;
+    for (uint32_t w = 0; w < W; ++w) {
+      if (head[w] >= k) continue;
+      const size_t o = ((size_t)w * nq + q) * k + head[w];
+      const uint64_t id = gi[o];
+      if (id == 0xFFFFFFFFFFFFFFFFull) continue;
+      const double sc = gs[o];
+      if (best < 0 || sc > bs || (sc == bs && id < bi)) best = (int)w, bs = sc, bi = id;
+    }
+    if (best < 0) {
+      out_i[q * k + t] = 0xFFFFFFFFFFFFFFFFull;
+      out_s[q * k + t] = -__builtin_inf();
+    } else {
+      out_i[q * k + t] = bi;
+      out_s[q * k + t] = bs;
+      ++head[best];
+    }
+  }
+}
+// nq x ks lists -> nq x k (ks < k: a shard with fewer than k items), the tail exhausted
+__global__ void widen_topk_kernel(const uint64_t *__restrict__ si, const double *__restrict__ ss, uint64_t nq, uint32_t ks, uint32_t k,
+                                  uint64_t *__restrict__ di, double *__restrict__ ds) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq * k) return;
+  const uint64_t q = t / k;
+  const uint32_t c = (uint32_t)(t - q * k);
+  di[t] = c < ks ? si[q * ks + c] : 0xFFFFFFFFFFFFFFFFull;
+  ds[t] = c < ks ? ss[q * ks + c] : -__builtin_inf();
+}
+__global__ void fill_empty_topk_kernel(uint64_t *__restrict__ idx, double *__restrict__ sc, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    idx[i] = 0xFFFFFFFFFFFFFFFFull;
+    sc[i] = -__builtin_inf();
+  }
+}
+
+// self_in_results on a whole table (u64 ids): through the u32 form the one-GPU path uses
+int table_self_in_results(as_ctx *ctx, const double *X, const double *norms, uint64_t n, uint64_t dim, uint32_t K, int rectify,
+                          uint64_t *idx, double *dst, uint32_t *t32) {
+  hipLaunchKernelGGL(narrow_u64_kernel, dim3(cdiv(n * K, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idx, n * K, t32);
+  AS_TRY(apply_self_in_results(ctx, X, norms, dim, 0, n, K, rectify, t32, dst));
+  hipLaunchKernelGGL(widen_u32_kernel, dim3(cdiv(n * K, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)t32, n * K, idx);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
 }
 
 }  // namespace
@@ -216,29 +388,46 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
   DevBuf<double> dst, dst_all;
   AS_TRY(idx.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1) * K));
   AS_TRY(dst.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1) * K));
-  if (W > 1 && as_knn_join_applies(ctx, n, dim, params)) {
-    // symmetric threshold join: thresholds all-gathered, lists to the owners of their rows in compact form
-    DevBuf<float> theta, theta_all;
-    AS_TRY(theta.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1)));
-    AS_TRY(theta_all.alloc(ctx, (size_t)n));
-    if (rows_here) AS_TRY(as_knn_join_thresholds(ctx, X.p, n, dim, lo, rows_here, params, theta.p));
-    AS_TRY(gather_rows(ctx, comm, theta.p, theta_all.p, n, sizeof(float)));
-    const uint32_t cap = as_knn_join_capacity(ctx, params);
-    DevBuf<uint32_t> cnt, cand, packed, cnt_src, recv, cand_src;
-    DevBuf<uint64_t> offsets, sizes_d;
+  AS_TRY(idx_all.alloc(ctx, (size_t)n * K));
+  AS_TRY(dst_all.alloc(ctx, (size_t)n * K));
+  const bool join = W > 1 && as_knn_join_applies(ctx, n, dim, params);
+  ctx->stats["sharded_join"] = join ? 1 : 0;
+  ctx->stats["sharded_by_positions"] = 0;
+  if (join) {
+    // ---- the one-GPU algorithm, sharded by IMAGE POSITIONS --------------------------------------------------------------
+    // Every rank holds all rows, so every rank prepares the SAME join (own_join_prepare: rotated coordinates, row order,
+    // f16 / int8 images, thresholds -- functions of the rows alone, every sum in a fixed order).  Rank g then owns the 512-
+    // position super tiles [lo_g, hi_g) of the IMAGE: it runs the int8 first pass and the masked f16 pass over their tile
+    // pairs only, sends what it listed for other ranks' positions to their owners, and finishes (exact re-rank, second pass,
+    // exact scans) the rows perm[lo_g .. hi_g).  The tables come back by position and are put in row order at the end.
+    // With the rows grouped by direction nearly all of a position's partners sit in its own or a neighbouring super tile, so
+    // the foreign lists are short: the exchange is a few per cent of what the row-order join shipped.
+    const uint32_t n32 = (uint32_t)n, d32 = (uint32_t)dim, K32 = (uint32_t)K, lo32 = (uint32_t)lo, here32 = (uint32_t)rows_here;
+    DevBuf<double> norms;
+    AS_TRY(norms.alloc(ctx, (size_t)n));
+    AS_TRY(row_norms(ctx, X.p, n, dim, norms.p));
+    OwnJoin oj;
+    AS_TRY(own_join_prepare(ctx, X.p, norms.p, n32, d32, K32, oj));
+    if (oj.reorder) {
+      AS_TRY(oj.inv_own.alloc(ctx, (size_t)n));
+      hipLaunchKernelGGL(invert_perm_u32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n32, oj.inv_own.p);
+    }
+    ctx->stats["sharded_by_positions"] = oj.reorder ? 1 : 0;
+    const uint32_t slots = oj.cap;
+    DevBuf<uint32_t> cnt, cand, used, packed, cnt_src, recv, cnt2, cand2;
+    DevBuf<uint64_t> offsets, sizes_d, off_src;
     AS_TRY(cnt.alloc(ctx, (size_t)n));
     AS_TRY(offsets.alloc(ctx, (size_t)n + 1));
     if (rows_here) {
-      AS_TRY(cand.alloc(ctx, (size_t)n * cap));
-      AS_TRY(packed.alloc(ctx, (size_t)n * cap));
-      AS_TRY(as_knn_join_pairs(ctx, X.p, n, dim, lo, rows_here, params, theta_all.p, cap, cnt.p, cand.p));
-      AS_TRY(as_knn_join_pack(ctx, cnt.p, cand.p, n, cap, offsets.p, packed.p));
-    } else {  // nothing contracted here: empty lists for every row
+      AS_TRY(cand.alloc(ctx, (size_t)n * slots * 2));
+      AS_TRY(own_join_pairs(ctx, X.p, norms.p, n32, d32, lo32, here32, oj, cnt.p, cand.p, /*lists by position*/ true));
+    } else {  // nothing contracted here: empty lists for every position
       AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * n, ctx->stream));
-      AS_HIP(ctx, hipMemsetAsync(offsets.p, 0, sizeof(uint64_t) * (n + 1), ctx->stream));
-      AS_TRY(packed.alloc(ctx, 1));
     }
-    // counts of every rank's rows, source by source
+    // compact form: the used slots side by side, sized by what was listed (not n x cap)
+    AS_TRY(used.alloc(ctx, (size_t)n));
+    hipLaunchKernelGGL(used_slots_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)cnt.p, n, slots, used.p);
+    AS_TRY(exclusive_scan_u32_u64(ctx, used.p, n, offsets.p));
     std::vector<uint64_t> sb((size_t)W), so((size_t)W), rb((size_t)W), ro((size_t)W), bounds((size_t)W + 1);
     for (int g = 0; g < W; ++g) {
       uint64_t a, b;
@@ -251,12 +440,20 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
       if (g == W - 1) AS_HIP(ctx, copy_d2h(ctx, &bounds[(size_t)W], offsets.p + b, sizeof(uint64_t)));
     }
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t listed = bounds[(size_t)W];
+    ctx->stats["sharded_listed_slots"] = (int64_t)listed;
+    ctx->stats["sharded_foreign_slots"] = (int64_t)(listed - (bounds[(size_t)R + 1] - bounds[(size_t)R]));
+    AS_TRY(packed.alloc(ctx, (size_t)std::max<uint64_t>(2 * listed, 2)));
+    if (rows_here)
+      hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n, 4), 1u << 20)), dim3(256), 0, ctx->stream,
+                         (const uint32_t *)cnt.p, n, slots, (const uint64_t *)offsets.p, (const uint2 *)cand.p, (uint2 *)packed.p);
+    AS_HIP(ctx, hipGetLastError());
     AS_TRY(cnt_src.alloc(ctx, (size_t)std::max<uint64_t>((uint64_t)W * rows_here, 1)));
     {
       const int rc = comm->ops.all_to_all_v(comm->ops.user, cnt.p, sb.data(), so.data(), cnt_src.p, rb.data(), ro.data(), ctx->stream);
       if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-to-all of the list counts failed");
     }
-    // the used slots (2 words each) of every destination's rows: sizes first, then the slots
+    // the used slots (2 words each) of every destination's positions: sizes first, then the slots
     std::vector<uint64_t> send_bytes((size_t)W), send_off((size_t)W), recv_bytes((size_t)W), recv_off((size_t)W), eight((size_t)W, 8), at8((size_t)W);
     for (int g = 0; g < W; ++g) {
       send_bytes[(size_t)g] = 2 * (bounds[(size_t)g + 1] - bounds[(size_t)g]) * sizeof(uint32_t);
@@ -276,28 +473,70 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
       recv_off[(size_t)g] = total;
       total += recv_bytes[(size_t)g];
     }
-    AS_TRY(recv.alloc(ctx, (size_t)std::max<uint64_t>(total / sizeof(uint32_t), 1)));
+    AS_TRY(recv.alloc(ctx, (size_t)std::max<uint64_t>(total / sizeof(uint32_t), 2)));
     {
       const int rc = comm->ops.all_to_all_v(comm->ops.user, packed.p, send_bytes.data(), send_off.data(), recv.p, recv_bytes.data(), recv_off.data(),
                                             ctx->stream);
       if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-to-all of the candidate lists failed");
     }
+    cand.release();  // (the dense lists are done with: 4 KB per position of the whole image; stream-ordered reuse)
+    packed.release();
     if (rows_here) {
-      AS_TRY(cand_src.alloc(ctx, (size_t)W * rows_here * cap));
-      AS_TRY(as_knn_join_unpack(ctx, cnt_src.p, recv.p, (uint64_t)W * rows_here, cap, cand_src.p));
-      AS_TRY(as_knn_join_finish(ctx, X.p, n, dim, lo, rows_here, params, theta_all.p, (uint32_t)W, cap, cnt_src.p, cand_src.p, idx.p, dst.p));
+      // own pairs -> list 0, all foreign sources -> list 1, positions -> rows
+      AS_TRY(used.alloc(ctx, (size_t)W * rows_here));
+      AS_TRY(off_src.alloc(ctx, (size_t)W * rows_here + 1));
+      hipLaunchKernelGGL(used_slots_kernel, dim3(cdiv((uint64_t)W * rows_here, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)cnt_src.p,
+                         (uint64_t)W * rows_here, slots, used.p);
+      AS_TRY(exclusive_scan_u32_u64(ctx, used.p, (uint64_t)W * rows_here, off_src.p));
+      AS_TRY(cnt2.alloc(ctx, (size_t)2 * rows_here));
+      AS_TRY(cand2.alloc(ctx, (size_t)2 * rows_here * slots * 2));
+      hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(rows_here, 4), 1u << 16)), dim3(256), 0, ctx->stream,
+                         (const uint32_t *)cnt_src.p, (const uint2 *)recv.p, (const uint64_t *)off_src.p, (uint32_t)W, (uint32_t)R, here32, slots,
+                         oj.perm, cnt2.p, (uint2 *)cand2.p);
+      AS_HIP(ctx, hipGetLastError());
+      DevBuf<uint32_t> idx32;
+      AS_TRY(idx32.alloc(ctx, (size_t)rows_here * K));
+      JoinSources js{nullptr, oj.theta_own.p, 2u, slots, cnt2.p, cand2.p, nullptr, oj.P16own.p, oj.Phown.p};
+      if (oj.have_theta2) js.theta2 = oj.reorder ? oj.theta2_own.p : oj.theta2_own.p + lo;  // (by global row with a_ids, else by row of the range)
+      if (oj.reorder) {
+        js.a_ids = oj.perm_own.p + lo;
+        js.theta_local = oj.theta_pos.p + lo;
+        js.list_base = lo32;
+      }
+      js.oj = &oj;
+      AS_TRY(knn_mfma(ctx, X.p, norms.p, n, dim, lo, rows_here, K32, params->rectify, idx32.p, dst.p, &js));
+      hipLaunchKernelGGL(widen_u32_kernel, dim3(cdiv(rows_here * K, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)idx32.p, rows_here * K, idx.p);
+      AS_HIP(ctx, hipGetLastError());
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // idx32 goes back to the workspace cache
     }
-    ctx->stats["sharded_join"] = 1;
+    // ---- tables of all positions on every rank, then back to row order ----
+    if (oj.reorder) {
+      DevBuf<uint64_t> idx_pos;
+      DevBuf<double> dst_pos;
+      AS_TRY(idx_pos.alloc(ctx, (size_t)n * K));
+      AS_TRY(dst_pos.alloc(ctx, (size_t)n * K));
+      AS_TRY(gather_rows(ctx, comm, idx.p, idx_pos.p, n, K * sizeof(uint64_t)));
+      AS_TRY(gather_rows(ctx, comm, dst.p, dst_pos.p, n, K * sizeof(double)));
+      hipLaunchKernelGGL(unpermute_table_kernel, dim3(cdiv(n * K, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idx_pos.p,
+                         (const double *)dst_pos.p, (const uint32_t *)oj.perm_own.p, n, K32, idx_all.p, dst_all.p);
+      AS_HIP(ctx, hipGetLastError());
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      AS_TRY(gather_rows(ctx, comm, idx.p, idx_all.p, n, K * sizeof(uint64_t)));
+      AS_TRY(gather_rows(ctx, comm, dst.p, dst_all.p, n, K * sizeof(double)));
+    }
+    if (params->self_in_results) {
+      // CosinePair returning the query row itself (as_graph_params): applied to the whole table, the same on every rank
+      DevBuf<uint32_t> t32;
+      AS_TRY(t32.alloc(ctx, (size_t)n * K));
+      AS_TRY(table_self_in_results(ctx, X.p, norms.p, n, dim, K32, params->rectify, idx_all.p, dst_all.p, t32.p));
+    }
   } else {
     if (rows_here) AS_TRY(as_knn_cosine(ctx, X.p, n, dim, lo, rows_here, params, idx.p, dst.p));
-    ctx->stats["sharded_join"] = 0;
+    // ---- neighbour tables of all rows on every rank (the union symmetrisation needs the in-edges of a rank's rows) ----
+    AS_TRY(gather_rows(ctx, comm, idx.p, idx_all.p, n, K * sizeof(uint64_t)));
+    AS_TRY(gather_rows(ctx, comm, dst.p, dst_all.p, n, K * sizeof(double)));
   }
-
-  // ---- neighbour tables of all rows on every rank (the union symmetrisation needs the in-edges of a rank's rows) ----
-  AS_TRY(idx_all.alloc(ctx, (size_t)n * K));
-  AS_TRY(dst_all.alloc(ctx, (size_t)n * K));
-  AS_TRY(gather_rows(ctx, comm, idx.p, idx_all.p, n, K * sizeof(uint64_t)));
-  AS_TRY(gather_rows(ctx, comm, dst.p, dst_all.p, n, K * sizeof(double)));
 
   // ---- this rank's row block of the Laplacian; nnz of the whole matrix ----
   DevBuf<uint64_t> nnz_d;
@@ -307,14 +546,133 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
     AS_TRY(as_laplacian_from_knn_rows(ctx, idx_all.p, dst_all.p, n, params, lo, rows_here, out_block));
     nnz = as_csr_nnz(*out_block);
   }
-  AS_HIP(ctx, copy_h2d(ctx, nnz_d.p, &nnz, sizeof(nnz)));
+  // (from here on a failure must not leave the block behind: a caller that treats rc != 0 as "no outputs" would leak it)
+  auto drop_block = [&](int rc) {
+    if (*out_block) as_csr_free(*out_block);
+    *out_block = nullptr;
+    return rc;
+  };
+  if (copy_h2d(ctx, nnz_d.p, &nnz, sizeof(nnz)) != hipSuccess) return drop_block(fail(ctx, AS_ERR_HIP, "sharded build: copy failed"));
   {
     const int rc = comm->ops.all_reduce_sum_u64(comm->ops.user, nnz_d.p, 1, ctx->stream);
-    if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-reduce failed");
+    if (rc != AS_OK) return drop_block(fail(ctx, rc, "sharded build: all-reduce failed"));
   }
-  AS_HIP(ctx, copy_d2h(ctx, &nnz, nnz_d.p, sizeof(nnz)));
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (copy_d2h(ctx, &nnz, nnz_d.p, sizeof(nnz)) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return drop_block(fail(ctx, AS_ERR_HIP, "sharded build: copy failed"));
   if (nnz_total) *nnz_total = nnz;
+  return AS_OK;
+}
+
+int as_lambda_stats_sharded(as_ctx *ctx, as_comm *comm, const double *lambdas_shard, uint64_t n_here, double *min_out, double *max_out,
+                            double *mean_out) {
+  if (!ctx) return AS_ERR_ARG;
+  if (!comm || (n_here && !lambdas_shard)) return fail(ctx, AS_ERR_ARG, "null argument");
+  AS_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = comm->world;
+  DevIn<double> L;
+  AS_TRY(L.bind(ctx, lambdas_shard, n_here));
+  const unsigned blocks = 256;
+  DevBuf<double> part, mine, all;
+  AS_TRY(part.alloc(ctx, (size_t)blocks * 3));
+  AS_TRY(mine.alloc(ctx, 4));
+  AS_TRY(all.alloc(ctx, (size_t)W * 4));
+  hipLaunchKernelGGL(lambda_stats_kernel, dim3(blocks), dim3(256), 0, ctx->stream, L.p, n_here, part.p);
+  AS_HIP(ctx, hipGetLastError());
+  std::vector<double> hp((size_t)blocks * 3);
+  AS_HIP(ctx, copy_d2h(ctx, hp.data(), part.p, hp.size() * sizeof(double)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double st[4] = {__builtin_inf(), -__builtin_inf(), 0.0, (double)n_here};
+  for (unsigned b = 0; b < blocks; ++b) {
+    st[0] = hp[b * 3] < st[0] ? hp[b * 3] : st[0];
+    st[1] = hp[b * 3 + 1] > st[1] ? hp[b * 3 + 1] : st[1];
+    st[2] += hp[b * 3 + 2];
+  }
+  AS_HIP(ctx, copy_h2d(ctx, mine.p, st, sizeof(st)));
+  std::vector<uint64_t> rb((size_t)W, sizeof(st)), ro((size_t)W);
+  for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * sizeof(st);
+  {
+    const int rc = comm->ops.all_gather_v(comm->ops.user, mine.p, sizeof(st), all.p, rb.data(), ro.data(), ctx->stream);
+    if (rc != AS_OK) return fail(ctx, rc, "sharded lambda statistics: all-gather failed");
+  }
+  std::vector<double> ha((size_t)W * 4);
+  AS_HIP(ctx, copy_d2h(ctx, ha.data(), all.p, ha.size() * sizeof(double)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double mn = __builtin_inf(), mx = -__builtin_inf(), sm = 0.0, cnt = 0.0;
+  for (int r = 0; r < W; ++r) {  // rank order: the same sum on every rank
+    mn = ha[(size_t)r * 4] < mn ? ha[(size_t)r * 4] : mn;
+    mx = ha[(size_t)r * 4 + 1] > mx ? ha[(size_t)r * 4 + 1] : mx;
+    sm += ha[(size_t)r * 4 + 2];
+    cnt += ha[(size_t)r * 4 + 3];
+  }
+  if (min_out) *min_out = mn;
+  if (max_out) *max_out = mx;
+  if (mean_out) *mean_out = cnt > 0.0 ? sm / cnt : 0.0;
+  return AS_OK;
+}
+
+int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *index_shard, const double *queries,
+                                   const double *q_lambdas, uint64_t nq, uint64_t k, double alpha, uint64_t id_offset,
+                                   uint64_t *idx_out, double *score_out) {
+  if (!ctx) return AS_ERR_ARG;
+  if (!comm || (nq && (!queries || !q_lambdas))) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (nq == 0 || k == 0) return AS_OK;
+  if (!idx_out || !score_out) return fail(ctx, AS_ERR_ARG, "null output");
+  if (k > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "k must be <= 4096");
+  AS_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = comm->world;
+  if (W > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "sharded search: more than 64 ranks");
+  const uint64_t per = nq * k;
+  DevBuf<uint64_t> li, gi;
+  DevBuf<double> ls, gs;
+  AS_TRY(li.alloc(ctx, (size_t)per));
+  AS_TRY(ls.alloc(ctx, (size_t)per));
+  AS_TRY(gi.alloc(ctx, (size_t)W * per));
+  AS_TRY(gs.alloc(ctx, (size_t)W * per));
+  // a local failure (zero query lambda, NaN score: the reference's panics) must not leave the peers waiting in the collective:
+  // the shard's lists are exchanged empty and the status is returned afterwards
+  int rc_local = AS_OK;
+  std::string err_local;
+  if (index_shard) {
+    const uint64_t ks = std::min<uint64_t>(k, as_index_nitems(index_shard));  // (a shard smaller than k returns what it has)
+    if (ks == k) {
+      rc_local = as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, k, alpha, id_offset, li.p, ls.p);
+    } else {
+      DevBuf<uint64_t> ti;
+      DevBuf<double> ts;
+      AS_TRY(ti.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
+      AS_TRY(ts.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
+      if (ks) rc_local = as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, ks, alpha, id_offset, ti.p, ts.p);
+      if (rc_local == AS_OK) {
+        hipLaunchKernelGGL(widen_topk_kernel, dim3(cdiv(per, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)ti.p, (const double *)ts.p, nq,
+                           (uint32_t)ks, (uint32_t)k, li.p, ls.p);
+        AS_HIP(ctx, hipGetLastError());
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
+    }
+    if (rc_local != AS_OK) err_local = ctx->err;
+  }
+  if (!index_shard || rc_local != AS_OK) {
+    hipLaunchKernelGGL(fill_empty_topk_kernel, dim3(cdiv(per, 256)), dim3(256), 0, ctx->stream, li.p, ls.p, per);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  std::vector<uint64_t> rb((size_t)W, per * 8), ro((size_t)W);
+  for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * per * 8;
+  {
+    int rc = comm->ops.all_gather_v(comm->ops.user, li.p, per * 8, gi.p, rb.data(), ro.data(), ctx->stream);
+    if (rc == AS_OK) rc = comm->ops.all_gather_v(comm->ops.user, ls.p, per * 8, gs.p, rb.data(), ro.data(), ctx->stream);
+    if (rc != AS_OK) return fail(ctx, rc, "sharded search: all-gather failed");
+  }
+  if (rc_local != AS_OK) return fail(ctx, rc_local, err_local);
+  DevOut<uint64_t> I;
+  DevOut<double> S;
+  AS_TRY(I.bind(ctx, idx_out, per));
+  AS_TRY(S.bind(ctx, score_out, per));
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(cdiv(nq, 128)), dim3(128), 0, ctx->stream, (const uint64_t *)gi.p, (const double *)gs.p, (uint32_t)W, nq,
+                     (uint32_t)k, I.p, S.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_TRY(I.finish(ctx));
+  AS_TRY(S.finish(ctx));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // li / ls / gi / gs go back to the workspace cache
   return AS_OK;
 }
 

@@ -15,13 +15,16 @@ Inputs are resident in HBM before the timed region.  `value` = N / build seconds
 all-gathers of the row blocks, the neighbour tables and the per-shard top-k.
 
 Beside the contract's fields the JSON line carries (all measured in this run, HIP events on the library's stream):
-  roofline          the dominant kernel (the symmetric join): SURVEY.md 8(d) algorithmic flops 2 n^2 d per launch
-                    over its average launch time against the dense 16-bit MFMA peak, with the MFMA flops it really
-                    executes next to it
+  roofline          the kernel with the most time per step: the work it EXECUTES per launch over its measured launch time against
+                    the peak of its own pipe (int8 / f16 MFMA, or HBM); roofline_kernels: the same for every long kernel
+  reference_equivalent  SURVEY.md 8(d)'s 2 n^2 d of the reference's all-pairs loop over the time of the launches that replace
+                    it: how much of that loop is never executed -- a separate figure, never a frac
   roofline_scan     the lambda-tau scan (K6/K7/K8): bytes n (8 D + 8) per launch against HBM
   roofline_search   the search scan at the benchmark batch (K9, MFMA-bound at nq = 10 k): 2 nq N D flops
-  roofline_search_hbm  the search at nq = 1 and nq = 32 (bandwidth-bound regime): bytes N (8 D + 8) per pass
+  roofline_search_hbm  the search at nq = 1 and nq = 32 with every item row streamed (bandwidth-bound regime): bytes N (8 D + 8) per
+                    pass; equivalent_filtered: the same batches on an index searched before (int8 filter: an equivalent, not a bandwidth)
   value_host_inputs the build with the item matrix starting in host memory (PCIe inclusive; never `value`)
+  value_hard_data   the item graph on a mixture the rotated first pass cannot exploit (which path ran; never `value`)
   cpu_baseline      the oracle on the host cores, bounded sample
 """
 import argparse
@@ -115,7 +118,7 @@ def recorded_traffic(kernel_substr, n, d):
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if not (name.startswith("r02") and name.endswith("_pmc_traffic.json")):
+        if not (name.startswith("r03") and name.endswith("_pmc_traffic.json")):
             continue
         try:
             with open(os.path.join(pdir, name)) as f:
@@ -162,7 +165,15 @@ def main():
     qidx = synth.query_indices(n, nq, seed=42)
     Q = torch.from_numpy(synth.mixture_at(qidx, d, seed=42) * 1.02).to(dev)
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
-    sas = D.ShardedArrowSpace(ops, Xd, n, gp, A.TauMode.Median)
+    # N > 1: the exchange steps of the build, the lambda statistics and the search run INSIDE the library over its own RCCL
+    # communicator (csrc/sharded.hip): the one-GPU algorithm sharded by image positions.  ARROWSPACE_TORCH_EXCHANGE=1 keeps
+    # the torch.distributed form (the join in the order of the caller's rows, no first pass).
+    libcomm = None
+    if use_dist and os.environ.get("ARROWSPACE_TORCH_EXCHANGE") != "1":
+        box = [D.LibComm.unique_id(ctx) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        libcomm = D.LibComm.rccl(ctx, box[0], rank, world)
+    sas = D.ShardedArrowSpace(ops, Xd, n, gp, A.TauMode.Median, libcomm=libcomm)
 
     def sync():
         torch.cuda.synchronize()
@@ -211,7 +222,8 @@ def main():
     stats = {k: ctx.stat(k) for k in ("knn_join", "knn_join_pipe", "knn_join_blocks", "knn_join_candidates", "knn_uncertified_rows",
                                       "knn_uncertified_rows_stage1a", "knn_join_delta_e9", "search_uncertified_rows", "search_scan",
                                       "knn_mfma_join_bf16_blocks_full", "knn_join_prefilter", "knn_join_prefilter_rotated",
-                                      "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged")}
+                                      "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged", "knn_rerank_scored",
+                                      "knn_join_row_order", "knn_join_theta_grouped")}
 
     # ---- untimed extra legs (rank 0, one GPU): small-batch search, host-resident inputs --------------------------------
     extra = {}
@@ -232,10 +244,39 @@ def main():
             bytes_pass = float(n) * (8.0 * d + 8.0)
             legs.append({"nq": b, "ms_per_batch": dt * 1e3, "qps": b / dt, "algorithmic_bytes_per_pass": bytes_pass,
                          "achieved": bytes_pass / dt / 1e9, "frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS})
-        best = max(legs, key=lambda leg: leg["frac"])
-        extra["roofline_search_hbm"] = {"bound": "hbm", "kernel": "search_lambda_aware at small batches (wall time per batch, host launch included)",
+        # the same batches with the int8 filter of an index searched before switched off: every batch STREAMS the N (8 D + 8)
+        # bytes of the items (what the first search of an index does): a bandwidth, where the filtered form above is an equivalent
+        streamed = []
+        ctx.set_option("search_stream_filter", 0)
+        try:
+            for b in (1, 32):
+                Qb = Q[:b].contiguous()
+                lqb = sas.prepare_queries(Qb)
+                for _ in range(2):
+                    sas.search(Qb, lqb, args.k, args.alpha)
+                torch.cuda.synchronize()
+                reps = 10
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    sas.search(Qb, lqb, args.k, args.alpha)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                bytes_pass = float(n) * (8.0 * d + 8.0)
+                streamed.append({"nq": b, "ms_per_batch": dt * 1e3, "qps": b / dt, "bytes_streamed_per_pass": bytes_pass,
+                                 "achieved": bytes_pass / dt / 1e9, "frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS,
+                                 "stream_scan_filter": ctx.stat("stream_scan_filter")})
+        finally:
+            ctx.set_option("search_stream_filter", 1)
+        best = max(streamed, key=lambda leg: leg["frac"])
+        extra["roofline_search_hbm"] = {"bound": "hbm", "kernel": "stream_scan_d128_kernel (search_lambda_aware at small batches, every item row "
+                                                                  "streamed once per batch; wall time per batch, three launches + host included)",
                                         "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"],
-                                        "traffic": None, "legs": legs}
+                                        "traffic": None, "legs": streamed,
+                                        "equivalent_filtered": {
+                                            "what": "EQUIVALENT, not a bandwidth: from the second search of an index on, a rotated int8 image "
+                                                    "(32 B per item) replaces the list pass, so ~100 MB are read instead of N (8 D + 8); the "
+                                                    "figures below divide the reference's bytes by the measured time",
+                                            "legs": [dict(leg, equivalent_GBs=leg.pop("achieved"), equivalent_frac=leg.pop("frac")) for leg in legs]}}
         # the reference's build() starts from host rows (Vec<Vec<f64>>): the same build with the item matrix in host memory
         X_host = Xd.cpu().numpy()
         A.build_laplacian_matrix(X_host[:4096], gp, ctx=ctx)  # staging buffers warm
@@ -248,93 +289,125 @@ def main():
                                       "note": "item matrix (%.2f GB) in pageable host memory at the start; the library stages it "
                                               "through pinned buffers for the graph and again for the lambda pass" % (n * d * 8 / 1e9)}
         del gl_h, asp_h, X_host
+        # ---- the hard case: data the rotated first pass cannot exploit (never in `value`) ------------------------------
+        # `value` is measured on SURVEY's rank-8 / 256-cluster mixture, whose energy sits in 31 directions.  Same size and graph
+        # parameters on a rank-64 / 4096-cluster mixture (244 rows per cluster; 31 directions hold about half of the energy, so
+        # the library falls back to the full-width int8 image or the dense f16 join by itself): same exact results, other path.
+        hard = {}
+        try:
+            Xh, _ = synth.mixture_device(n, d, dev, seed=43, n_clusters=4096, rank=64)
+            A.build_laplacian_matrix(Xh, gp, ctx=ctx)   # warm
+            ctx.synchronize()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                glh = A.build_laplacian_matrix(Xh, gp, ctx=ctx)
+            ctx.synchronize()
+            t_hard = (time.perf_counter() - t0) / reps
+            hard = {"value": n / t_hard, "unit": "items/s", "build_ms": t_hard * 1e3, "item_graph_nnz": int(glh.matrix.nnz()),
+                    "data": "rank-64 / 4096-cluster Gaussian mixture (seed 43), same n, d and graph parameters; item graph only "
+                            "(the lambda pass adds 0.4 ms)",
+                    "path": {k: ctx.stat(k) for k in ("knn_join", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
+                                                      "knn_join_theta_grouped", "knn_join_prefilter_tail_e6", "knn_uncertified_rows",
+                                                      "knn_uncertified_rows_stage1a")}}
+            if ctx.stat("knn_join_prefilter") == 1:
+                hard["path"]["blocks_passed_on_frac"] = ctx.stat("knn_join_prefilter_blocks_flagged") * 2.0 / max(1, ctx.stat("knn_join_prefilter_blocks"))
+            del Xh, glh
+        except Exception as e:  # noqa: BLE001 -- an extra leg must not take the bench line down
+            hard = {"error": repr(e)}
+        extra["value_hard_data"] = hard
 
     if rank == 0:
         steps = args.steps
         build_s = t_build / steps
         search_s = t_search / steps
         rows_here = hi - lo
-        flops_alg = 2.0 * rows_here * n * d  # SURVEY.md 8(d): 2 n^2 d over the rows this rank owns
-        roofline = None
+        # ---- every long kernel of the build against ITS OWN pipe: executed work / measured time / peak ----------------
+        # (HIP events on the library's stream around each launch group; `roofline` is the one with the most time.)
+        # The reference's all-pairs loop (2 n^2 d flop) is NOT what these kernels execute -- the first pass
+        # rules most of it out -- so that figure lives in `reference_equivalent`, never in a `frac`.
         names = {16: "knn_mfma_join_f16", 48: "knn_mfma_join_bf16", 32: "knn_mfma_join_f32"}
-        ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
-        ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
         pipe = stats["knn_join_pipe"]
-        msj, lj = prof.get(names.get(pipe, ""), (0.0, 0))
-        if stats["knn_join"] == 1 and lj:
-            avg_ms = msj / lj
-            d_pad = (d + 15) // 16 * 16
+        d_pad = (d + 15) // 16 * 16
+        kernels = []
+
+        def add(key, kernel, bound, work, peak, unit, what, extra_fields=None):
+            ms, launches = prof.get(key, (0.0, 0))
+            if not launches or ms <= 0.0:
+                return
+            avg_ms = ms / steps   # per step: a group may hold several launches of a step (prune + score, items + queries)
+            ach = work / (avg_ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+            e = {"bound": bound, "kernel": kernel, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                 "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches / steps, "work_per_launch": work,
+                 "work_is": what, "profile_group": key}
+            if extra_fields:
+                e.update(extra_fields)
+            if world == 1:
+                rec = recorded_traffic(kernel.split(" ")[0].split("<")[0], n, d)
+                if rec:   # PMC counters cannot be read from inside this process: the committed rocprofv3 --pmc passes of the
+                    e["traffic"] = rec["bytes_per_launch"]   # same command (scripts/profile_round.sh), per launch
+                    e["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
+            kernels.append(e)
+
+        if stats["knn_join"] == 1:
             blocks = stats["knn_join_blocks"]
-            if pipe == 16:
-                executed = 2.0 * 32 * 32 * d_pad * blocks
-                kern = ("pair_join_f16_kernel (v_mfma_f32_32x32x16_f16 on one f16 plane of the unit rows, f32 acc; symmetric threshold "
-                        "join: every unordered pair of 512-row super tiles once; exact f64 re-rank + certification follow)")
-                peak = MFMA16_PEAK_TFLOPS
-            elif pipe == 48:
-                executed = 2.0 * 32 * 32 * d_pad * (blocks + 2.0 * stats["knn_mfma_join_bf16_blocks_full"])
-                kern = "pair_join_bf16_kernel (split bf16, two-phase blocks)"
-                peak = MFMA16_PEAK_TFLOPS
-            else:
-                t2 = (n + 255) // 256
-                executed = 2.0 * (t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)) * 256 * 256 * d
-                kern = "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32)"
-                peak = F32_MFMA_PEAK_TFLOPS
-            msp, lp = prof.get("knn_join_prefilter", (0.0, 0))
-            if pipe == 16 and stats.get("knn_join_prefilter", 0) == 1 and lp:
-                # two launches make the join: the int8 first pass over all block pairs (the dominant kernel) and the f16 pass
-                # over the blocks it leaves.  8(d) prices the pair against the reference's 2 n^2 d; each kernel's own MFMA
-                # work against the peak of its pipe is reported next to it.
-                pre_ms = msp / lp
+            if stats.get("knn_join_prefilter", 0) == 1:
                 rotated = stats.get("knn_join_prefilter_rotated", 0) == 1
                 k8 = 32 if rotated else (d + 31) // 32 * 32
-                pre_exec = 2.0 * 32 * 32 * k8 * stats["knn_join_prefilter_blocks"]
-                kern = ("pair_prefilter_i8%s_kernel + pair_join_f16_kernel<masked> (v_mfma_i32_32x32x32_i8 first pass over every unordered "
-                        "pair of 512-row super tiles on %s, then v_mfma_f32_32x32x16_f16 on the %.1f %% of the 64 x 32 blocks it "
-                        "cannot rule out; exact f64 re-rank + certification follow)" % (
-                            "_narrow" if k8 <= 64 else "", "the rotated 32-wide int8 image (31 dominant directions + tail norm)"
-                            if rotated else "the int8 image of the unit rows",
-                            100.0 * stats["knn_join_prefilter_blocks_flagged"] * 2.0 / max(1, stats["knn_join_prefilter_blocks"])))
-                achieved = flops_alg / ((avg_ms + pre_ms) * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                            "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms + pre_ms, "launches": lj,
-                            "algorithmic_flops_per_launch": flops_alg,
-                            "first_pass": {"avg_launch_ms": pre_ms, "executed_ops_per_launch": pre_exec,
-                                           "executed_TOPs": pre_exec / (pre_ms * 1e-3) / 1e12, "peak_TOPs": INT8_PEAK_TOPS,
-                                           "executed_frac_of_peak": pre_exec / (pre_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS,
-                                           "bound_note": "16 outputs per lane and 32-wide MFMA: the v_max3 of the block test, not the "
-                                                         "matrix pipe, limits it (DESIGN.md section 4)"},
-                            "f16_pass": {"avg_launch_ms": avg_ms, "executed_flops_per_launch": executed,
-                                         "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
-                                         "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak},
-                            "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d over the measured time of the two "
-                                    "launches that replace its all-pairs loop. The first pass rules out most of the blocks on an 8-bit "
-                                    "upper bound of the cosine and every unordered pair is visited once, so frac is far above 1; the "
-                                    "pipe utilisation of each kernel is under first_pass / f16_pass"}
+                add("knn_join_prefilter",
+                    "pair_prefilter_i8%s_kernel (v_mfma_i32_32x32x32_i8 over every unordered pair of 512-row super tiles on %s; "
+                    "a bit per 64 x 32 block that can hold a pair)" % ("_narrow" if k8 <= 64 else "",
+                                                                          "the rotated 32-wide int8 image (31 directions + tail norm)"
+                                                                          if rotated else "the full-width int8 image of the unit rows"),
+                    "mfma", 2.0 * 32 * 32 * k8 * stats["knn_join_prefilter_blocks"], INT8_PEAK_TOPS, "TFLOP/s",
+                    "int8 multiply-adds x 2 the MFMAs execute (blocks visited x 32 x 32 x k); peak = dense int8 MFMA",
+                    {"blocks_passed_on_frac": stats["knn_join_prefilter_blocks_flagged"] * 2.0 / max(1, stats["knn_join_prefilter_blocks"])})
+            if pipe == 16:
+                add(names[16], "pair_join_f16_kernel (v_mfma_f32_32x32x16_f16 on one f16 plane of the unit rows; symmetric threshold join "
+                               "over the blocks the first pass leaves, listing (row, column, score))",
+                    "mfma", 2.0 * 32 * 32 * d_pad * blocks, MFMA16_PEAK_TFLOPS, "TFLOP/s", "f16 MFMA flops executed (blocks contracted x 32 x 32 x d)")
+            elif pipe == 48:
+                add(names[48], "pair_join_bf16_kernel (split bf16, two-phase blocks)", "mfma",
+                    2.0 * 32 * 32 * d_pad * (blocks + 2.0 * stats["knn_mfma_join_bf16_blocks_full"]), MFMA16_PEAK_TFLOPS, "TFLOP/s",
+                    "bf16 MFMA flops executed")
             else:
-              achieved = flops_alg / (avg_ms * 1e-3) / 1e12
-              roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms, "launches": lj,
-                          "algorithmic_flops_per_launch": flops_alg,
-                          "executed_flops_per_launch": executed, "executed_TFLOPs": executed / (avg_ms * 1e-3) / 1e12,
-                          "executed_frac_of_peak": executed / (avg_ms * 1e-3) / 1e12 / peak,
-                          "note": "achieved / frac follow SURVEY.md 8(d): the reference's 2 n^2 d per launch over the measured launch time. "
-                                  "cos(i,j) = cos(j,i), so the kernel contracts every unordered pair of row tiles once and EXECUTES half of "
-                                  "that (executed_*: the MFMA flops really issued = pipe utilisation); frac can therefore exceed "
-                                  "executed_frac_of_peak by up to 2x"}
-        elif l32 and ms32 >= ms64:
-            achieved = flops_alg / (ms32 / min(l32, steps) * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32; exact f64 re-rank + certification follow)",
-                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                        "traffic": None, "avg_launch_ms": ms32 / min(l32, steps), "launches": l32}
-        elif l64:
-            achieved = flops_alg / (ms64 / min(l64, steps) * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "pair_topk_mfma_kernel (v_mfma_f64_16x16x4_f64)", "achieved": achieved,
-                        "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "avg_launch_ms": ms64 / min(l64, steps), "launches": l64}
-        if roofline and world == 1:
-            rec = recorded_traffic(roofline["kernel"].split(" ")[0], n, d)
-            if rec:
-                roofline["traffic_recorded"] = rec
+                t2 = (n + 255) // 256
+                add(names[32], "pair_join_mfma32_kernel (v_mfma_f32_32x32x2_f32)", "mfma",
+                    2.0 * (t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)) * 256 * 256 * d, F32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+                    "f32 MFMA flops executed")
+            scored = stats["knn_rerank_scored"]
+            if scored > 0:
+                # exact re-rank: every surviving candidate row (8 d bytes) is fetched once, the row itself once, the lists are read
+                # (8 B per listed slot), a record of 1.5 KB per row written and read, the table written
+                rr_bytes = (scored + rows_here) * 8.0 * d + stats["knn_join_candidates"] * 8.0 + rows_here * (2 * 1536.0 + 17 * 12.0)
+                add("knn_rerank", "rerank_score_d128_kernel (+ rerank_prune_kernel: lists -> pruned records -> gathered 1 KB rows, sequential "
+                                  "f64 chains in the reference's order, ranking, certification)",
+                    "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes of the surviving candidates' rows + lists + records + table",
+                    {"scored_candidates_per_row": scored / max(1, rows_here)})
+        ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
+        ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
+        flops_alg = 2.0 * rows_here * n * d  # SURVEY.md 8(d): 2 n^2 d over the rows this rank owns
+        if stats["knn_join"] != 1 and l32 and ms32 >= ms64:
+            add("knn_mfma_candidates_f32", "pair_topk_mfma32_kernel (v_mfma_f32_32x32x2_f32; exact f64 re-rank + certification follow)", "mfma",
+                flops_alg, F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "2 n^2 d (the full square is contracted)")
+        elif stats["knn_join"] != 1 and l64:
+            add("knn_mfma_candidates", "pair_topk_mfma_kernel (v_mfma_f64_16x16x4_f64)", "mfma", flops_alg, F64_MFMA_PEAK_TFLOPS, "TFLOP/s",
+                "2 n^2 d (the full square is contracted)")
+        nnz = float(state.get("nnz", 0))
+        if nnz > 0 and world == 1:
+            add("graph_assembly", "graph assembly (degree_kernel, adjacency_kernel, fill_reverse_kernel, union_count_kernel, write_rows_kernel)",
+                "hbm", rows_here * 17 * 16.0 + nnz * 16.0 + (rows_here + 1) * 8.0, HBM_PEAK_GBS, "GB/s",
+                "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out")
+        roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
+        reference_equivalent = None
+        if stats["knn_join"] == 1:
+            join_ms = sum(e["avg_launch_ms"] for e in kernels if e["profile_group"] in ("knn_join_prefilter",) + tuple(names.values()))
+            if join_ms > 0:
+                reference_equivalent = {
+                    "what": "SURVEY.md 8(d) prices the neighbour search at the reference's all-pairs loop, 2 n^2 d flop; the launches that "
+                            "replace it (first pass + f16 pass) take join_ms. This is how much of that loop is never executed, NOT a "
+                            "utilisation: no frac is derived from it",
+                    "algorithmic_flops": flops_alg, "join_ms": join_ms, "equivalent_TFLOPs": flops_alg / (join_ms * 1e-3) / 1e12}
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))
         if lam_n:
             # two launches per step hit this group: the N items and the nq queries
@@ -346,7 +419,8 @@ def main():
             if world == 1:
                 rec = recorded_traffic("lambda_kernel", n, d)
                 if rec:
-                    extra["roofline_scan"]["traffic_recorded"] = rec
+                    extra["roofline_scan"]["traffic"] = rec["bytes_per_launch"]
+                    extra["roofline_scan"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
         ss_kernel = ("pair_join_f16_kernel<KS, 1> (threshold scan of the search: one-f16-plane products, coarse test on the cosine, "
                      "lambda term against per-query score guesses in the listing)")
         ss_ms, ss_n = prof.get("search_scan_f16", (0.0, 0))
@@ -385,6 +459,8 @@ def main():
             "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items())},
             "commit": git_head(),
             "roofline": roofline,
+            "roofline_kernels": kernels,
+            "reference_equivalent": reference_equivalent,
         }
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:

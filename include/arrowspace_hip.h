@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AS_ABI_VERSION 3
+#define AS_ABI_VERSION 4
 
 typedef enum {
   AS_OK = 0,
@@ -261,8 +261,11 @@ void as_csr_free(as_csr *m);
 
 /* ---- row-sharded build, one process per GPU: what replaces build_laplacian_matrix
  * (src/laplacian.rs:122-178) when the items are spread over several GPUs.  The library runs the whole exchange
- * sequence (all-gather of the row shards, all-gather of the join thresholds, all-to-all of the candidate lists in
- * compact form, all-gather of the neighbour tables, all-reduce of nnz) through a communicator:
+ * sequence through a communicator: all-gather of the row shards; then every rank prepares the SAME join (rotated
+ * coordinates, row order, f16 / int8 images, thresholds: functions of the rows alone, every sum in a fixed order), runs the
+ * int8 first pass and the masked f16 pass over the tile pairs of ITS range of image positions, and the candidate lists go to
+ * the owners of their positions in compact form (all-to-all: counts, sizes, slots); every rank finishes the rows of its
+ * positions exactly; all-gather of the neighbour tables (by position, put back in row order); all-reduce of nnz.
  *   - as_comm_create_rccl: RCCL over xGMI.  Rank 0 calls as_comm_unique_id and ships the 128 bytes to the other ranks
  *     by whatever means the host has; every rank then creates its communicator.  librccl is loaded at run time
  *     (AS_ERR_UNSUPPORTED when it is not there).  Collectives are issued on the context's stream.
@@ -296,6 +299,20 @@ int as_comm_world(const as_comm *comm);
 void as_shard_range(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi);
 int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_shard, uint64_t n_total, uint64_t dim,
                                const as_graph_params *params, as_csr **out_block, uint64_t *nnz_total);
+/* The logged lambda statistics of a sharded build (src/builder.rs:434-445: min, max and mean over ALL items' lambdas):
+ * lambdas_shard = this rank's n_here lambdas (host or device; n_here may be 0).  Every rank gets the same three values: the
+ * shards' (min, max, sum, count) are all-gathered and combined in rank order, every partial sum in a fixed order. */
+int as_lambda_stats_sharded(as_ctx *ctx, as_comm *comm, const double *lambdas_shard, uint64_t n_here, double *min_out,
+                            double *max_out, double *mean_out);
+/* ArrowSpace::search_lambda_aware (src/core.rs:760-798) over a row-sharded index: every rank searches its shard
+ * (as_search_lambda_aware with id_offset = its first global row; index_shard NULL on a rank without rows), the per-shard
+ * top-k lists are all-gathered and merged by (score desc, global index asc) -- what the reference's stable sort of all items
+ * gives.  queries / q_lambdas are replicated (the same on every rank); idx_out / score_out (nq x k, host or device) hold the
+ * same global result on every rank.  A rank whose local search fails (AS_ERR_ZERO_LAMBDA, AS_ERR_NAN_SCORE) still takes part
+ * in the exchange and returns its status afterwards. */
+int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *index_shard, const double *queries,
+                                   const double *q_lambdas, uint64_t nq, uint64_t k, double alpha, uint64_t id_offset,
+                                   uint64_t *idx_out, double *score_out);
 
 /* ---- lambda-tau: replaces TauMode::compute_taumode_lambdas_parallel, src/taumode.rs:174-312 */
 /* items: n_items x n_features.  tau is taken from each item's own values (select_tau,

@@ -30,13 +30,46 @@ def short(name):
     return name[:cut][:110]
 
 
+def demangle_one(m):
+    """Enough of the Itanium scheme for this library's kernels: _ZN <len><ident>... [I <integral template args> E] E ...
+    -> ident<args>.  (binutils' c++filt in the image gives up on _Float16 parameter types, DF16_.)"""
+    if not m.startswith("_ZN"):
+        return m
+    i, last = 3, None
+    while i < len(m) and m[i].isdigit():
+        j = i
+        while m[j].isdigit():
+            j += 1
+        ln = int(m[i:j])
+        last = m[j:j + ln]
+        i = j + ln
+    if last is None:
+        return m
+    args = []
+    if i < len(m) and m[i] == "I":
+        i += 1
+        while i < len(m) and m[i] == "L":
+            j = m.index("E", i)
+            kind, val = m[i + 1], m[i + 2:j]
+            val = ("-" + val[1:]) if val.startswith("n") else val
+            args.append(("true" if val == "1" else "false") if kind == "b" else val + ("u" if kind == "j" else ""))
+            i = j + 1
+        if not (i < len(m) and m[i] == "E"):
+            args = None   # a type argument: leave the argument list out
+    return last + ("<" + ", ".join(args) + ">" if args else "")
+
+
+def demangle(names):
+    return {n: demangle_one(n) for n in names if n.startswith("_Z")}
+
+
 def load(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for cf in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(cf)):
-            if r["Counter_Name"] != counter:
-                continue
-            k = short(r["Kernel_Name"])
+        rows = [r for r in csv.DictReader(open(cf)) if r["Counter_Name"] == counter]
+        plain = demangle({r["Kernel_Name"] for r in rows})
+        for r in rows:
+            k = short(plain.get(r["Kernel_Name"], r["Kernel_Name"]))
             acc[k][0] += 1
             acc[k][1] += float(r["Counter_Value"])
     return acc

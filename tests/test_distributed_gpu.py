@@ -215,15 +215,26 @@ def _lib_worker(rank, world, port, n, d, out_dir):
         assert (comm.rank(), comm.world()) == (rank, world)
         lo, hi = comm.shard_range(n)
         assert (lo, hi) == D.shard_range(n, rank, world)
-        X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
         gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
-        gl = comm.build_laplacian(torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp)
+        # the whole sharded path inside the library: build, lambda statistics, search + merge (no torch collective on the data path)
+        sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp, A.TauMode.Median, libcomm=comm)
+        gl = sas.build_item_graph()
+        join = ctx.stat("sharded_join")
         assert (gl.block is None) == (hi == lo)
         if gl.block is not None:
             assert gl.block.shape() == (hi - lo, n) and gl.block.row_begin() == lo
         csr = gl.to_host()
+        sas.build_lambdas(cent)
+        Q = torch.from_numpy(X[[1, n // 2, n - 1, 77]] * 1.02).cuda()
+        lq = sas.prepare_queries(Q)
+        idx, sc = sas.search(Q, lq, 10, 0.7)
+        idx_big, sc_big = sas.search(Q, lq, 600, 0.7)   # k beyond the smallest shard: short lists are padded before the merge
+        lam_all = D.all_gather_rows(sas.lambdas.reshape(-1, 1), sas.sizes).reshape(-1)
+        torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, "lib%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()),
-                 join=np.array(ctx.stat("sharded_join")))
+                 join=np.array(join), lam=lam_all.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
+                 idx_big=idx_big.cpu().numpy(), sc_big=sc_big.cpu().numpy(), stats=np.array(sas.lambda_stats))
         comm.close()
     finally:
         dist.destroy_process_group()
@@ -236,12 +247,25 @@ def test_library_sharded_build_matches_single_process(tmp_path, n, world, d):
     from oracle import oracle_ctypes as O
     from tests import synth
     mp.spawn(_lib_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
-    X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
-    csr = O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))
+    X, cent = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    gp = O.graph_params(0.5, 16, 16, 2.0, 0.25)
+    csr = O.build_laplacian(X, gp)
+    lam = O.taumode_lambdas(X, O.build_laplacian(np.ascontiguousarray(cent.T), gp), O.TAU_MEDIAN)
+    Q = X[[1, n // 2, n - 1, 77]] * 1.02
     for r in [np.load(tmp_path / ("lib%d.npz" % k)) for k in range(world)]:
         assert int(r["join"]) == 1 and int(r["nnz"]) == len(csr[1])
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
+        # as_lambda_stats_sharded (src/builder.rs:434-445) and as_search_lambda_aware_sharded (src/core.rs:778-798)
+        np.testing.assert_allclose(r["lam"], lam, rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(r["stats"], [r["lam"].min(), r["lam"].max(), r["lam"].mean()], rtol=1e-12)
+        for j in range(4):
+            oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
+            assert np.array_equal(r["idx"][j], oi.astype(np.int64))
+            assert np.array_equal(r["sc"][j], osc)
+            oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 600, 0.7)
+            assert np.array_equal(r["idx_big"][j], oi.astype(np.int64))
+            assert np.array_equal(r["sc_big"][j], osc)
 
 
 def test_library_sharded_build_one_rank_rccl():
@@ -306,3 +330,65 @@ def test_library_sharded_build_multi_rank_rccl(tmp_path, n):
         assert int(r["nnz"]) == len(csr[1])
         assert np.array_equal(r["indptr"], csr[0]) and np.array_equal(r["indices"], csr[1])
         np.testing.assert_allclose(r["data"], csr[2], rtol=1e-13)
+
+
+# ---- the sharded build with the one-GPU algorithm: row order + int8 first pass + masked f16 pass, sharded by image positions ----
+def _lib_positions_worker(rank, world, port, n, d, topk, out_dir):
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = A.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        comm = D.LibComm.torch_transport(ctx)
+        lo, hi = comm.shard_range(n)
+        X, _ = synth.mixture(n, d, seed=29, n_clusters=96, rank=6)
+        X[n // 3] = X[5]            # duplicates across shards: ties by row id must survive the trip through image positions
+        X[n - 7] = X[5]
+        X[n // 2] = 0.0
+        gp = A.GraphParams(0.5, 16, topk, 2.0, 0.25)
+        gl = comm.build_laplacian(torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp)
+        stats = {k: ctx.stat(k) for k in ("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated",
+                                          "knn_join_row_order", "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows")}
+        csr = gl.to_host()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "pos.npz"), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()))
+        np.save(os.path.join(out_dir, "pos_stats%d.npy" % rank), np.array([stats[k] for k in sorted(stats)]))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,d,topk", [(70_000, 3, 128, 16), (66_000, 2, 96, 16), (70_000, 2, 128, 38)])
+def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk):
+    """From 65 536 rows the sharded build runs the ONE-GPU algorithm (src/laplacian.rs:203-292 replaced by: rotated
+    coordinates -> row order -> int8 first pass -> masked f16 pass -> exact re-rank), every rank on its own range of IMAGE
+    positions, the lists exchanged by position and translated back to rows.  The stacked row blocks must be the Laplacian of
+    the one-GPU build (itself checked against the oracle at these sizes in test_gpu_stress / test_gpu_parity), bit for bit in
+    structure, with duplicates across shards and a zero row."""
+    import arrowspace_amd as A
+    from tests import synth
+    mp.spawn(_lib_positions_worker, args=(world, _free_port(), n, d, topk, str(tmp_path)), nprocs=world, join=True)
+    X, _ = synth.mixture(n, d, seed=29, n_clusters=96, rank=6)
+    X[n // 3] = X[5]
+    X[n - 7] = X[5]
+    X[n // 2] = 0.0
+    ctx = A.default_context()
+    gl = A.build_laplacian_matrix(X, A.GraphParams(0.5, 16, topk, 2.0, 0.25), ctx=ctx)
+    assert ctx.stat("knn_join") == 1
+    ip, ix, dv = gl.matrix.to_host()
+    r = np.load(tmp_path / "pos.npz")
+    assert int(r["nnz"]) == len(ix)
+    assert np.array_equal(r["indptr"], ip) and np.array_equal(r["indices"], ix)
+    assert np.array_equal(r["data"], dv)
+    keys = sorted(("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
+                   "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows"))
+    for k in range(world):
+        st = dict(zip(keys, np.load(tmp_path / ("pos_stats%d.npy" % k)).tolist()))
+        assert st["sharded_join"] == 1 and st["sharded_by_positions"] == 1, st
+        assert st["knn_join_prefilter"] == 1 and st["knn_join_row_order"] == 1, st
+        assert st["sharded_foreign_slots"] * 2 < st["sharded_listed_slots"], st   # most partners of a position live on its own rank
