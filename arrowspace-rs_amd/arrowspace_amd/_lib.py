@@ -28,6 +28,7 @@ EXPORTS = [
     "as_jl_original_dim", "as_jl_reduced_dim", "as_jl_matrix", "as_jl_project",
     "as_comm_unique_id", "as_comm_create_rccl", "as_comm_create_custom", "as_comm_destroy", "as_comm_rank", "as_comm_world",
     "as_shard_range", "as_build_laplacian_sharded", "as_lambda_stats_sharded", "as_search_lambda_aware_sharded",
+    "as_device_upload", "as_device_download", "as_device_free",
 ]
 
 # transport callbacks of as_comm_create_custom (device buffers; byte counts / offsets are arrays of `world` entries)
@@ -134,6 +135,9 @@ def load():
         "as_comm_world": (i32, [vp]),
         "as_shard_range": (None, [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]),
         "as_build_laplacian_sharded": (i32, [vp, vp, vp, u64, u64, C.POINTER(GraphParamsC), C.POINTER(vp), C.POINTER(u64)]),
+        "as_device_upload": (i32, [vp, vp, u64, C.POINTER(vp)]),
+        "as_device_download": (i32, [vp, vp, u64, vp]),
+        "as_device_free": (None, [vp, vp]),
         "as_lambda_stats_sharded": (i32, [vp, vp, vp, u64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
         "as_search_lambda_aware_sharded": (i32, [vp, vp, vp, vp, vp, u64, u64, dbl, u64, vp, vp]),
     }

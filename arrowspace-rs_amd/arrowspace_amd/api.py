@@ -73,6 +73,51 @@ class GraphParams:
                 (self.sigma is None or np.isclose(self.sigma, o.sigma)) and self.normalise == o.normalise)
 
 
+class DeviceArray:
+    """An HBM buffer owned through the C ABI (as_device_upload / as_device_free), with just enough of the tensor protocol
+    (shape, data_ptr, is_contiguous) for this package's marshalling."""
+    is_cuda = False   # (not a torch tensor: no torch stream to adopt)
+
+    def __init__(self, ctx, handle, shape, dtype):
+        self.ctx, self._h, self.shape, self.dtype = ctx, handle, tuple(int(x) for x in shape), np.dtype(dtype)
+
+    def data_ptr(self):
+        return self._h.value
+
+    def is_contiguous(self):
+        return True
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        """Row i of a matrix (or element i of a vector) as a host array: one small download."""
+        i = int(i)
+        if not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        row_shape = self.shape[1:]
+        out = np.empty(row_shape, dtype=self.dtype)
+        nb = int(np.prod(row_shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ctx.check(self.ctx.lib.as_device_download(self.ctx.h, C.c_void_p(self._h.value + i * nb), nb, out.ctypes.data))
+        return out
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx.check(self.ctx.lib.as_device_download(self.ctx.h, self._h, out.nbytes, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self._h is not None and self._h.value:
+            self.ctx.lib.as_device_free(self.ctx.h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class Context:
     """One as_ctx: device, stream and workspace.  Not re-entrant (one per host thread)."""
 
@@ -103,6 +148,14 @@ class Context:
 
     def stat(self, name):
         return int(self.lib.as_ctx_get_stat(self.h, name.encode()))
+
+    def upload(self, array):
+        """as_device_upload: a host matrix / vector -> HBM once; the DeviceArray that comes back is accepted wherever rows,
+        items, queries or lambdas are (the library uses device pointers in place)."""
+        a = np.ascontiguousarray(array)
+        h = C.c_void_p()
+        self.check(self.lib.as_device_upload(self.h, a.ctypes.data, a.nbytes, C.byref(h)))
+        return DeviceArray(self, h, a.shape, a.dtype)
 
     def profile(self, on=True):
         self.lib.as_profile_enable(self.h, int(on))
@@ -421,7 +474,7 @@ class ImplicitProjection:
             X = X.reshape(1, -1)
         n, d = _shape2(X)
         assert d == self.original_dim
-        if _lib.is_tensor(X):
+        if hasattr(X, "device"):
             import torch
             out = torch.empty((n, self.reduced_dim), dtype=torch.float64, device=X.device)
         else:
@@ -478,6 +531,9 @@ class ArrowSpace:
         self.ctx = ctx or default_context()
         self.data = _f64(data, self.ctx)
         self.nitems, self.nfeatures = _shape2(self.data)
+        self._resident = None  # HBM copy of host data (Context.upload), made at the first library call and kept: the
+        #                        reference keeps its items in host memory and walks them three times (src/builder.rs:249-304);
+        #                        here lambdas, queries' index and search all read the one device copy
         self.taumode = taumode
         self.lambdas_ = None
         self.signals = None  # F x F spectral Laplacian (src/core.rs:372), set by build_spectral_laplacian
@@ -490,24 +546,32 @@ class ArrowSpace:
     def lambdas(self):
         return self.lambdas_
 
+    def _items(self):
+        """The items as the library should see them: in place when they are in HBM already, else uploaded once."""
+        if _lib.is_tensor(self.data) or self.data.nbytes < (1 << 20):   # (torch tensor or DeviceArray: in HBM already)
+            return self.data
+        if self._resident is None:
+            self._resident = self.ctx.upload(self.data)
+        return self._resident
+
     def get_item(self, i):  # src/core.rs:586-594
         assert i < self.nitems, "item index out of bounds"
         row = self.data[i]
-        row = row.cpu().numpy() if _lib.is_tensor(row) else row
+        row = row.cpu().numpy() if hasattr(row, "cpu") else row
         return ArrowItem(np.array(row), float(self.lambdas_[i]))
 
     def compute_taumode(self, gl):
         """EigenMaps::compute_taumode (src/eigenmaps.rs:358-383) ->
         TauMode::compute_taumode_lambdas_parallel (src/taumode.rs:174-312)."""
         lib, ctx = self.ctx.lib, self.ctx
-        if _lib.is_tensor(self.data):
+        if hasattr(self.data, "device"):   # a torch tensor in HBM: the lambdas stay there too
             import torch
             out = torch.empty(self.nitems, dtype=torch.float64, device=self.data.device)
         else:
             out = np.empty(self.nitems, dtype=np.float64)
         # graph = aspace.signals if non-empty else gl.matrix (src/taumode.rs:195-200)
         graph = self.signals if self.signals is not None else gl.matrix
-        ctx.check(lib.as_compute_taumode(ctx.h, ptr(self.data), self.nitems, self.nfeatures, graph.h,
+        ctx.check(lib.as_compute_taumode(ctx.h, ptr(self._items()), self.nitems, self.nfeatures, graph.h,
                                          self.taumode.kind, self.taumode.arg, ptr(out)))
         self.update_lambdas(out)
 
@@ -527,7 +591,7 @@ class ArrowSpace:
         if f != self.nfeatures:  # src/core.rs:510-516
             raise ArrowSpaceError(_lib.AS_ERR_DIM, "Query dimension %d doesn't match index original dimension %d"
                                   % (f, self.nfeatures))
-        if _lib.is_tensor(Q):
+        if hasattr(Q, "device"):
             import torch
             out = torch.empty(nq, dtype=torch.float64, device=Q.device)
         else:
@@ -554,7 +618,7 @@ class ArrowSpace:
             h = C.c_void_p()
             lam = self.lambdas_ if _lib.is_tensor(self.lambdas_) else np.ascontiguousarray(self.lambdas_, np.float64)
             self._lam_keep = lam
-            self.ctx.check(self.ctx.lib.as_index_create(self.ctx.h, ptr(self.data), ptr(lam), self.nitems,
+            self.ctx.check(self.ctx.lib.as_index_create(self.ctx.h, ptr(self._items()), ptr(lam), self.nitems,
                                                         self.nfeatures, C.byref(h)))
             self._index = h
         return self._index
@@ -577,7 +641,7 @@ class ArrowSpace:
         assert f == self.nfeatures, "items should be of the same length"  # src/core.rs:157-161
         QL = _f64(q_lambdas, ctx)
         kk = min(int(k), self.nitems)
-        if _lib.is_tensor(Q):
+        if hasattr(Q, "device"):
             import torch
             idx = torch.empty((nq, kk), dtype=torch.int64, device=Q.device)
             sc = torch.empty((nq, kk), dtype=torch.float64, device=Q.device)
@@ -693,10 +757,10 @@ class ArrowSpaceBuilder:
         """EigenMaps::start_clustering (src/eigenmaps.rs:175-290): optimal K + radius, incremental clustering, optional
         JL projection of the centroids.  Returns the (possibly projected) centroids."""
         ctx = aspace.ctx
-        k_opt, radius, _ = compute_optimal_k(aspace.data, self.clustering_seed, ctx=ctx)
+        k_opt, radius, _ = compute_optimal_k(aspace._items(), self.clustering_seed, ctx=ctx)
         self.cluster_max_clusters, self.cluster_radius = k_opt, radius
         batch = 1 if self.deterministic_clustering else self.clustering_batch
-        cents, assign, sizes = incremental_clustering(aspace.data, k_opt, radius, batch, ctx=ctx)
+        cents, assign, sizes = incremental_clustering(aspace._items(), k_opt, radius, batch, ctx=ctx)
         aspace.n_clusters, aspace.cluster_assignments, aspace.cluster_sizes = len(cents), assign, sizes
         aspace.cluster_radius = radius
         return self._maybe_project(aspace, cents)

@@ -2,9 +2,99 @@
 #include <algorithm>
 #include <cmath>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "common.h"
 
 using namespace asx;
+
+// ---- host copy threads (staging of host inputs and outputs, common.h: copy_h2d / copy_d2h) --------------------------------
+// A handful of threads that split one memcpy between them.  Created at the first large transfer, kept for the process.
+namespace {
+struct CopyPool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  char *dst = nullptr;
+  const char *src = nullptr;
+  size_t bytes = 0;
+  uint64_t generation = 0;
+  int pending = 0, n_threads = 0;
+  bool stop = false;
+  void worker(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      char *d;
+      const char *s_;
+      size_t b;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+        d = dst;
+        s_ = src;
+        b = bytes;
+      }
+      const size_t parts = (size_t)n_threads + 1, per = (b / parts + 4095) & ~(size_t)4095;
+      const size_t lo = std::min(b, per * (size_t)(id + 1)), hi = std::min(b, lo + per);  // part 0 is the caller's
+      if (hi > lo) std::memcpy(d + lo, s_ + lo, hi - lo);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) cv_done.notify_one();
+      }
+    }
+  }
+  void start() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    n_threads = (int)std::max(1u, std::min(7u, hw > 2 ? hw / 2 - 1 : 1u));
+    for (int i = 0; i < n_threads; ++i) threads.emplace_back([this, i] { worker(i); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto &t : threads) t.join();
+  }
+};
+CopyPool *copy_pool() {
+  static CopyPool *pool = [] {
+    CopyPool *p = new CopyPool();  // (leaked on purpose at exit: joining threads from a static destructor can deadlock the unload)
+    p->start();
+    return p;
+  }();
+  return pool;
+}
+std::mutex g_copy_call;  // one transfer at a time through the pool (contexts of different host threads share it)
+}  // namespace
+
+namespace asx {
+void host_copy_parallel(void *dst, const void *src, size_t bytes) {
+  if (bytes < (1u << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  std::lock_guard<std::mutex> call(g_copy_call);
+  CopyPool *p = copy_pool();
+  const size_t parts = (size_t)p->n_threads + 1, per = (bytes / parts + 4095) & ~(size_t)4095;
+  {
+    std::lock_guard<std::mutex> lk(p->m);
+    p->dst = (char *)dst;
+    p->src = (const char *)src;
+    p->bytes = bytes;
+    p->pending = p->n_threads;
+    ++p->generation;
+  }
+  p->cv_work.notify_all();
+  std::memcpy(dst, src, std::min(bytes, per));  // the caller's own part
+  std::unique_lock<std::mutex> lk(p->m);
+  p->cv_done.wait(lk, [&] { return p->pending == 0; });
+}
+}  // namespace asx
 
 namespace {
 
@@ -283,6 +373,35 @@ int as_profile_names(as_ctx *ctx, char *buf, uint64_t cap) {
   std::strncpy(buf, s.c_str(), cap - 1);
   buf[cap - 1] = 0;
   return AS_OK;
+}
+
+int as_device_upload(as_ctx *ctx, const void *host, uint64_t bytes, void **dev_out) {
+  AS_TRY(check_ctx(ctx));
+  if (!dev_out || (bytes && !host)) return fail(ctx, AS_ERR_ARG, "null argument");
+  *dev_out = nullptr;
+  void *p = nullptr;
+  AS_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1));
+  const hipError_t e = is_device_ptr(host) ? hipMemcpyAsync(p, host, bytes, hipMemcpyDeviceToDevice, ctx->stream) : copy_h2d(ctx, p, host, bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(ctx, AS_ERR_HIP, std::string("as_device_upload: ") + hipGetErrorString(e));
+  }
+  *dev_out = p;
+  return AS_OK;
+}
+int as_device_download(as_ctx *ctx, const void *dev, uint64_t bytes, void *host_out) {
+  AS_TRY(check_ctx(ctx));
+  if (bytes && (!dev || !host_out)) return fail(ctx, AS_ERR_ARG, "null argument");
+  AS_HIP(ctx, copy_d2h(ctx, host_out, dev, bytes));
+  return AS_OK;
+}
+void as_device_free(as_ctx *ctx, void *dev) {
+  if (!dev) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(dev);
 }
 
 uint64_t as_define_result_k(uint64_t k, uint64_t topk) {

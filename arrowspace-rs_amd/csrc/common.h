@@ -204,24 +204,75 @@ inline hipError_t ensure_pinned(as_ctx *ctx) {
   if (ctx->pinned) return hipSuccess;
   return hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault);
 }
+// Large transfers (the item matrix of a host caller: 1 GB at 1 M x 128) are pipelined through the staging buffer cut into four
+// slots of 16 MB: a few host threads copy chunk c + 1 into its slot while the DMA of chunk c is in flight, an event per slot
+// says when it may be overwritten.  One thread and one slot (the form before) moved 1 GB in 52 ms: the host memcpy and the
+// DMA took turns.  (api.hip: the worker pool.)
+constexpr size_t kStageSlot = 16u << 20;
+constexpr int kStageSlots = 4;
+static_assert(kStageSlot * kStageSlots == kPinnedBytes, "the slots tile the staging buffer");
+void host_copy_parallel(void *dst, const void *src, size_t bytes);  // memcpy split over the library's copy threads
 inline hipError_t copy_h2d(as_ctx *ctx, void *dst, const void *src, size_t bytes) {
   hipError_t e = ensure_pinned(ctx);
-  for (size_t off = 0; e == hipSuccess && off < bytes; off += kPinnedBytes) {
-    const size_t n = std::min(kPinnedBytes, bytes - off);
-    std::memcpy(ctx->pinned, (const char *)src + off, n);
-    e = hipMemcpyAsync((char *)dst + off, ctx->pinned, n, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging buffer is reused
+  if (bytes <= kStageSlot) {
+    if (e == hipSuccess && bytes) {
+      std::memcpy(ctx->pinned, src, bytes);
+      e = hipMemcpyAsync(dst, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging buffer is reused
+    }
+    return e;
   }
+  hipEvent_t done[kStageSlots] = {};
+  for (int k = 0; k < kStageSlots && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+  size_t c = 0;
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += kStageSlot, ++c) {
+    const size_t n = std::min(kStageSlot, bytes - off);
+    const int k = (int)(c % kStageSlots);
+    char *slot = (char *)ctx->pinned + (size_t)k * kStageSlot;
+    if (c >= (size_t)kStageSlots) e = hipEventSynchronize(done[k]);  // the DMA that read this slot last
+    if (e != hipSuccess) break;
+    host_copy_parallel(slot, (const char *)src + off, n);
+    e = hipMemcpyAsync((char *)dst + off, slot, n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(done[k], ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  else (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < kStageSlots; ++k)
+    if (done[k]) (void)hipEventDestroy(done[k]);
   return e;
 }
 inline hipError_t copy_d2h(as_ctx *ctx, void *dst, const void *src, size_t bytes) {
   hipError_t e = ensure_pinned(ctx);
-  for (size_t off = 0; e == hipSuccess && off < bytes; off += kPinnedBytes) {
-    const size_t n = std::min(kPinnedBytes, bytes - off);
-    e = hipMemcpyAsync(ctx->pinned, (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) std::memcpy((char *)dst + off, ctx->pinned, n);
+  if (bytes <= kStageSlot) {
+    if (e == hipSuccess && bytes) {
+      e = hipMemcpyAsync(ctx->pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) std::memcpy(dst, ctx->pinned, bytes);
+    }
+    return e;
   }
+  // the same pipeline the other way: the DMA of chunk c + 1 .. c + 3 runs while chunk c leaves its slot
+  hipEvent_t done[kStageSlots] = {};
+  for (int k = 0; k < kStageSlots && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+  const size_t chunks = (bytes + kStageSlot - 1) / kStageSlot;
+  auto issue = [&](size_t c) -> hipError_t {
+    const size_t off = c * kStageSlot, n = std::min(kStageSlot, bytes - off);
+    const int k = (int)(c % kStageSlots);
+    hipError_t r = hipMemcpyAsync((char *)ctx->pinned + (size_t)k * kStageSlot, (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream);
+    return r == hipSuccess ? hipEventRecord(done[k], ctx->stream) : r;
+  };
+  for (size_t c = 0; c < std::min<size_t>(chunks, kStageSlots) && e == hipSuccess; ++c) e = issue(c);
+  for (size_t c = 0; c < chunks && e == hipSuccess; ++c) {
+    const size_t off = c * kStageSlot, n = std::min(kStageSlot, bytes - off);
+    const int k = (int)(c % kStageSlots);
+    e = hipEventSynchronize(done[k]);
+    if (e != hipSuccess) break;
+    host_copy_parallel((char *)dst + off, (const char *)ctx->pinned + (size_t)k * kStageSlot, n);
+    if (c + kStageSlots < chunks) e = issue(c + kStageSlots);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < kStageSlots; ++k)
+    if (done[k]) (void)hipEventDestroy(done[k]);
   return e;
 }
 

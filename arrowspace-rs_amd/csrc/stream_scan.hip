@@ -629,7 +629,13 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
                          (const uint32_t *)g_pairs.p, (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p,
                          lidx.p, lkey.p, err_flag);
     }
-    AS_SS(true, 256u)
+    {
+      // (its own group: the one launch of stream_scan_d128_kernel<..., LIST> that streams all of B -- the HBM-bound kernel bench.py
+      // prices against N (8 D + 8) bytes)
+      const std::string list_name = std::string(prof_name) + "_list";
+      ProfScope pl(ctx, list_name.c_str());
+      AS_SS(true, 256u)
+    }
     hipLaunchKernelGGL(stream_final_kernel, dim3(nA), dim3(256), 0, ctx->stream, cnt.p, lidx.p, lkey.p, cap, K, out_ld, 0u, out_key,
                        out_idx, over.p, guess.p, done.p);
     AS_HIP(ctx, hipGetLastError());

@@ -117,6 +117,17 @@ int as_profile_get(as_ctx *ctx, const char *name, double *ms_total, uint64_t *la
 /* writes up to cap names separated by '\n' */
 int as_profile_names(as_ctx *ctx, char *buf, uint64_t cap);
 
+/* ---- residency for a host caller -----------------------------------------------------------------------------------------
+ * The reference's build() walks host rows (Vec<Vec<f64>>, src/builder.rs:249-304 makes three host copies of them).  Here
+ * every data pointer may be an HBM pointer, so a host that builds the graph, the lambdas and the index from the same item
+ * matrix uploads it ONCE and passes the device pointer to every call.  as_device_upload allocates `bytes` of HBM and fills
+ * them from host memory (pipelined through the context's pinned staging buffer: several host threads copy chunk c + 1 while
+ * the DMA of chunk c is in flight); as_device_download copies back; as_device_free releases.  A host pointer passed straight
+ * to a call goes through the same pipeline once per call. */
+int as_device_upload(as_ctx *ctx, const void *host, uint64_t bytes, void **dev_out);
+int as_device_download(as_ctx *ctx, const void *dev, uint64_t bytes, void *host_out);
+void as_device_free(as_ctx *ctx, void *dev);
+
 /* ---- builder helper --------------------------------------------------------------------- */
 /* ArrowSpaceBuilder::define_result_k, src/builder.rs:225-233 */
 uint64_t as_define_result_k(uint64_t k, uint64_t topk);
