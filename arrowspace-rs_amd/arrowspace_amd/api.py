@@ -201,6 +201,11 @@ def _adopt_torch_stream(ctx):
         ctx._stream = st
 
 
+def _is_torch(x):
+    """A torch tensor (numpy >= 2 arrays have a .device too, and DeviceArray is tensor-like without being one)."""
+    return _lib.is_tensor(x) and not isinstance(x, DeviceArray)
+
+
 def _f64(a, ctx=None):
     if _lib.is_tensor(a):
         if a.is_cuda and ctx is not None:
@@ -474,7 +479,7 @@ class ImplicitProjection:
             X = X.reshape(1, -1)
         n, d = _shape2(X)
         assert d == self.original_dim
-        if hasattr(X, "device"):
+        if _is_torch(X):
             import torch
             out = torch.empty((n, self.reduced_dim), dtype=torch.float64, device=X.device)
         else:
@@ -564,7 +569,7 @@ class ArrowSpace:
         """EigenMaps::compute_taumode (src/eigenmaps.rs:358-383) ->
         TauMode::compute_taumode_lambdas_parallel (src/taumode.rs:174-312)."""
         lib, ctx = self.ctx.lib, self.ctx
-        if hasattr(self.data, "device"):   # a torch tensor in HBM: the lambdas stay there too
+        if _is_torch(self.data):   # a torch tensor in HBM: the lambdas stay there too
             import torch
             out = torch.empty(self.nitems, dtype=torch.float64, device=self.data.device)
         else:
@@ -591,7 +596,7 @@ class ArrowSpace:
         if f != self.nfeatures:  # src/core.rs:510-516
             raise ArrowSpaceError(_lib.AS_ERR_DIM, "Query dimension %d doesn't match index original dimension %d"
                                   % (f, self.nfeatures))
-        if hasattr(Q, "device"):
+        if _is_torch(Q):
             import torch
             out = torch.empty(nq, dtype=torch.float64, device=Q.device)
         else:
@@ -641,7 +646,7 @@ class ArrowSpace:
         assert f == self.nfeatures, "items should be of the same length"  # src/core.rs:157-161
         QL = _f64(q_lambdas, ctx)
         kk = min(int(k), self.nitems)
-        if hasattr(Q, "device"):
+        if _is_torch(Q):
             import torch
             idx = torch.empty((nq, kk), dtype=torch.int64, device=Q.device)
             sc = torch.empty((nq, kk), dtype=torch.float64, device=Q.device)

@@ -113,6 +113,14 @@ struct StreamOperands<SearchScorePolicy> {
     out = -sc;
     return true;
   }
+  // the same arithmetic without the error flag (a NaN key comes back as NaN): the filter below only decides who is looked at
+  __device__ __forceinline__ double key_quiet(const SearchScorePolicy &p, double dot, uint32_t, uint32_t, double xn, double xl) const {
+    const double denom = __dmul_rn(qn, xn);
+    const double c = denom > 0.0 ? __ddiv_rn(dot, denom) : 0.0;
+    const double diff = fabs(__dsub_rn(ql, xl));
+    const double lam = __dsub_rn(1.0, fmin(diff, 1.0));
+    return -__dadd_rn(__dmul_rn(p.alpha, c), __dmul_rn(__dsub_rn(1.0, p.alpha), lam));
+  }
 };
 template <>
 struct StreamOperands<GraphDistPolicy> {
@@ -134,7 +142,152 @@ struct StreamOperands<GraphDistPolicy> {
     out = __dsub_rn(1.0, c);
     return !(out != out);
   }
+  __device__ __forceinline__ double key_quiet(const GraphDistPolicy &p, double dot, uint32_t a, uint32_t j, double nj, double) const {
+    if (a == j) return __builtin_inf();  // (a row is not its own neighbour: never looked at)
+    const double denom = __dmul_rn(na, nj);
+    double c = denom > 1e-12 ? __ddiv_rn(dot, denom) : 0.0;
+    if (p.rectify) {
+      c = fmin(fmax(c, -1.0), 1.0);
+      c = fmax(c, 0.0);
+    }
+    return __dsub_rn(1.0, c);
+  }
 };
+
+// ---- the list pass at HBM speed for up to 8 A rows (the first search of an index, one query or a few) ------------------------
+// The exact chain of the reference (128 dependent multiply / add pairs per item, one lane per (item, query)) keeps 8 of a
+// wave's 64 lanes busy at one query and pulls every B row through LDS eight times wider than it is used: 0.28 ms per GB, LDS-
+// and latency-bound.  But the chain is only needed for the items that can reach the cut.  Here every lane takes 16 B of every
+// row straight from HBM (a wave reads 8 rows = 8 KB per trip with eight fully coalesced loads, two trips in flight: no LDS),
+// multiplies them with its 16 B of each query, and the partial products are added across the wave by a halving butterfly
+// (shuffles; a fixed order: the same sums in every run).  That dot product differs from the reference's sequential one by at
+// most 2 x 128 x 2^-53 x |x||q| (both are within 128 ulp-sized steps of the true sum), i.e. the cosine by < 3e-14 and the key
+// by less still, so every pair whose QUICK key is within `margin` = 1e-12 of the cut is queued for stream_pairs_kernel, which
+// runs the reference's chain for exactly those (~16 K per query) and lists the keys at or below the cut: the lists, and with
+// them the results, are those of the full exact pass.  Pairs with a non-finite quick key are queued too.
+template <int CUR, int LB>
+__device__ __forceinline__ void ssq_halve(double *v, int lane) {
+  constexpr int H = CUR / 2;
+  const bool up = ((lane >> LB) & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const double keep = up ? v[i + H] : v[i];
+    const double send = up ? v[i] : v[i + H];
+    v[i] = keep + __shfl_xor(send, 1 << LB, 64);
+  }
+}
+template <class Policy, int NQ>
+__global__ __launch_bounds__(256) void stream_filter_f64_kernel(const double *__restrict__ A, const uint32_t *__restrict__ a_ids, uint32_t a_begin,
+                                                               uint32_t nA, const double *__restrict__ B, uint32_t nB, Policy pol,
+                                                               const double *__restrict__ guess, double margin, uint32_t cap,
+                                                               uint32_t *__restrict__ count, uint32_t *__restrict__ pairs,
+                                                               int *__restrict__ overflow) {
+  static_assert(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 8, "queries per launch");
+  constexpr int QB = NQ == 1 ? 0 : (NQ == 2 ? 1 : (NQ == 4 ? 2 : 3));
+  const int lane = threadIdx.x & 63;
+  // the wave's finds go through an LDS queue and out with one reservation on the global counter per flush (stream_filter_i8_kernel)
+  constexpr uint32_t kQ = 1024;
+  __shared__ uint32_t s_q[4][kQ];
+  __shared__ uint32_t s_qn[4];
+  uint32_t *q = s_q[threadIdx.x >> 6];
+  uint32_t *qn_p = &s_qn[threadIdx.x >> 6];
+  if (lane == 0) *qn_p = 0;
+  ss_wave_sync();
+  auto flush = [&]() {
+    ss_wave_sync();
+    const uint32_t qn = *(volatile uint32_t *)qn_p;
+    if (qn != 0) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count, qn);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + qn > cap) {
+        if (lane == 0) *overflow = 1;
+      } else {
+        for (uint32_t e = lane; e < qn; e += 64) pairs[base + e] = q[e];
+      }
+    }
+    ss_wave_sync();
+    if (lane == 0) *qn_p = 0;
+    ss_wave_sync();
+  };
+  // this lane's 16 B of every query (elements 2 lane, 2 lane + 1); queries beyond the batch are zero
+  double2 qv[NQ];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a) {
+    qv[a] = double2{0.0, 0.0};
+    if ((uint32_t)a < nA) {
+      const uint32_t ga = a_ids ? a_ids[a] : a_begin + (uint32_t)a;
+      qv[a] = reinterpret_cast<const double2 *>(A + (uint64_t)ga * kSsD)[lane];
+    }
+  }
+  // the (row of the trip, query) this lane holds once the butterfly is through: row = lane >> 3, query = the top QB of its low
+  // three bits; the lanes whose other low bits are zero speak for the pair
+  const uint32_t row_sel = (uint32_t)lane >> 3;
+  const uint32_t a_fin = NQ == 1 ? 0u : ((uint32_t)lane & 7u) >> (3 - QB);
+  const bool speaker = (((uint32_t)lane & 7u) & ((8u >> QB) - 1u)) == 0u && a_fin < nA;
+  const uint32_t ga_fin = a_fin < nA ? (a_ids ? a_ids[a_fin] : a_begin + a_fin) : 0u;
+  StreamOperands<Policy> op;
+  op.load_a(pol, ga_fin);
+  const double cut = a_fin < nA ? guess[a_fin] + margin : -__builtin_inf();
+  const double *b_norms = StreamOperands<Policy>::b_norms(pol);
+  const double *b_lams = StreamOperands<Policy>::b_lambdas(pol);
+  const uint32_t n_tiles = (nB + kSsTile - 1) / kSsTile;
+  const uint32_t wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  auto load_tile = [&](uint32_t t, double2 (&x)[kSsTile], double &xn, double &xl) {
+    const uint32_t row0 = t * kSsTile;
+#pragma unroll
+    for (int r = 0; r < kSsTile; ++r) {
+      const uint32_t row = min(row0 + (uint32_t)r, nB - 1);
+      typedef double ssq_d2 __attribute__((ext_vector_type(2)));
+      const ssq_d2 w = __builtin_nontemporal_load(reinterpret_cast<const ssq_d2 *>(B + (uint64_t)row * kSsD) + lane);
+      x[r] = double2{w.x, w.y};
+    }
+    const uint32_t jr = min(row0 + row_sel, nB - 1);
+    xn = b_norms[jr];
+    xl = StreamOperands<Policy>::kLambda ? b_lams[jr] : 0.0;
+  };
+  double2 xa[kSsTile], xb[kSsTile];
+  double na = 0.0, la = 0.0, nb = 0.0, lb = 0.0;
+  uint32_t t = wave_id;
+  if (t < n_tiles) load_tile(t, xa, na, la);
+  auto consume = [&](uint32_t tt, const double2 (&x)[kSsTile], double xn, double xl) {
+    double v[kSsTile * NQ];  // index = row * NQ + query: the row bits on top
+#pragma unroll
+    for (int r = 0; r < kSsTile; ++r)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) v[r * NQ + a] = __builtin_fma(x[r].y, qv[a].y, x[r].x * qv[a].x);
+    ssq_halve<8 * NQ, 5>(v, lane);
+    ssq_halve<4 * NQ, 4>(v, lane);
+    ssq_halve<2 * NQ, 3>(v, lane);
+    if constexpr (NQ >= 2) ssq_halve<NQ, 2>(v, lane);
+    if constexpr (NQ >= 4) ssq_halve<NQ / 2, 1>(v, lane);
+    if constexpr (NQ >= 8) ssq_halve<NQ / 4, 0>(v, lane);
+    double dot = v[0];
+    if constexpr (NQ <= 4) dot += __shfl_xor(dot, 1, 64);
+    if constexpr (NQ <= 2) dot += __shfl_xor(dot, 2, 64);
+    if constexpr (NQ <= 1) dot += __shfl_xor(dot, 4, 64);
+    const uint32_t j = tt * kSsTile + row_sel;
+    bool take = false;
+    if (speaker && j < nB) {
+      const double key = op.key_quiet(pol, dot, ga_fin, j, xn, xl);
+      take = !(key > cut);  // (NaN included: the exact arithmetic has to see it)
+    }
+    if (__any(take)) {
+      ss_wave_sync();
+      if (*(volatile uint32_t *)qn_p + 64 > kQ) flush();
+      if (take) q[atomicAdd(qn_p, 1u)] = (a_fin << 27) | j;
+    }
+  };
+  for (; t < n_tiles; t += 2 * n_waves) {
+    const uint32_t t1 = t + n_waves, t2 = t + 2 * n_waves;
+    if (t1 < n_tiles) load_tile(t1, xb, nb, lb);
+    consume(t, xa, na, la);
+    if (t1 >= n_tiles) break;
+    if (t2 < n_tiles) load_tile(t2, xa, na, la);
+    consume(t1, xb, nb, lb);
+  }
+  flush();
+}
 
 constexpr int kSsTileBytes = kSsTile * kSsPitchB + 128;  // 8 rows + 8 norms + 8 lambdas
 constexpr int kSsPieces = kSsTile + 1;                   // DMA instructions per tile
@@ -585,9 +738,14 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   uint32_t *const g_count = reinterpret_cast<uint32_t *>(over.p + nA);
   int *const g_over = over.p + nA + 1;
   const uint32_t g_cap = 1u << 20;
+  // without that image (the first search of an index, leftover rows of a join without coordinates): up to 8 rows take the
+  // quick f64 pass over B (stream_filter_f64_kernel) in front of the exact chains of the pairs it leaves
+  const bool quick = !filter && nA <= 8 && nB < (1u << 27) && ctx->opt_search_stream_quick;
   if (filter) {
     AS_TRY(g_pairs.alloc(ctx, g_cap));
     AS_TRY(pq8.alloc(ctx, rotated_image_bytes(1)));
+  } else if (quick) {
+    AS_TRY(g_pairs.alloc(ctx, g_cap));
   }
   const int nbuf = nA <= 8 ? 3 : 2;  // a third tile in flight per wave while the A rows leave the LDS for it
   const size_t lds = (size_t)((nA + 7) / 8 * 8) * kSsPitchA + (size_t)kSsWaves * nbuf * kSsTileBytes;
@@ -601,7 +759,7 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
   hipLaunchKernelGGL((stream_scan_d128_kernel<Policy, LISTV, NB, GV>), dim3(GRID), dim3(kSsWaves * 64), lds, ctx->stream, A,   \
                      a_ids, a_begin, nA, B, nB, n_tiles, pol, smin.p, guess.p, cap, cnt.p, lidx.p, lkey.p, err_flag,       \
-                     (LISTV && filter && first_list) ? (const int *)g_over : (const int *)nullptr)
+                     (LISTV && (filter || quick) && first_list) ? (const int *)g_over : (const int *)nullptr)
 #define AS_SS(LISTV, GRID)                                                             \
   switch ((nA + 7) / 8) {                                                              \
     case 1: AS_SS1(LISTV, 3, 1, GRID); break;                                          \
@@ -629,10 +787,30 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
                          (const uint32_t *)g_pairs.p, (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p,
                          lidx.p, lkey.p, err_flag);
     }
-    {
-      // (its own group: the one launch of stream_scan_d128_kernel<..., LIST> that streams all of B -- the HBM-bound kernel bench.py
-      // prices against N (8 D + 8) bytes)
+    if (quick) {
+      // (its own group: the one launch that streams all of B -- the HBM-bound kernel bench.py prices against N (8 D + 8) bytes)
       const std::string list_name = std::string(prof_name) + "_list";
+      ProfScope pl(ctx, list_name.c_str());
+      const double margin = 1e-12;
+#define AS_QF(NQV)                                                                                                                  \
+  hipLaunchKernelGGL((stream_filter_f64_kernel<Policy, NQV>), dim3(NQV == 1 ? 1024 : (NQV == 2 ? 768 : (NQV == 4 ? 512 : 256))), dim3(256), 0,    \
+                     ctx->stream, A, a_ids, a_begin, nA, B, nB, pol,                                                                  \
+                     (const double *)guess.p, margin, g_cap, g_count, g_pairs.p, g_over)
+      if (nA == 1) AS_QF(1);
+      else if (nA == 2) AS_QF(2);
+      else if (nA <= 4) AS_QF(4);
+      else AS_QF(8);
+#undef AS_QF
+    }
+    if (quick) {
+      const size_t lds_p = (size_t)nA * 129 * sizeof(double);
+      hipLaunchKernelGGL(stream_pairs_kernel<Policy>, dim3(256), dim3(256), lds_p, ctx->stream, A, a_ids, nA, B, (const uint32_t *)nullptr, pol,
+                         (const uint32_t *)g_pairs.p, (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt.p,
+                         lidx.p, lkey.p, err_flag);
+    }
+    {
+      // (the exact list pass: everything when there is no filter in front, else only when a filter's pair list ran out of room)
+      const std::string list_name = std::string(prof_name) + (quick ? "_list_exact" : "_list");
       ProfScope pl(ctx, list_name.c_str());
       AS_SS(true, 256u)
     }
@@ -666,6 +844,7 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   for (uint32_t a = 0; a < nA; ++a)
     if (h[a]) redo_pos->push_back(a);
   ctx->stats["stream_scan_filter"] = filter ? 1 : 0;
+  ctx->stats["stream_scan_quick"] = quick ? 1 : 0;
   ctx->stats["stream_scan_filter_items"] = (int64_t)h_count;
   ctx->stats["stream_scan_filter_overflow"] = h_gover;
   ctx->stats["stream_scan_retries"] = retries;

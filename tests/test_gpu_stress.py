@@ -112,3 +112,44 @@ def test_build_is_the_same_from_run_to_run(ctx):
         ctx.set_option("join_prefilter_min_rows", 65536)
     assert seen[0][0] != 0
     assert seen[0] == seen[1] == seen[2], seen
+
+
+@pytest.fixture(scope="module")
+def index_rows():
+    n, d = 140_000, 128
+    X, _ = synth.mixture(n, d, seed=17, n_clusters=48, rank=6)
+    X[100] = X[7]
+    X[90_000] = X[7]
+    X[9] = 0.0
+    return X
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("alpha", [0.7, 1.0])
+def test_small_batch_search_quick_pass_is_exact(ctx, index_rows, nq, alpha):
+    """The first search of an index with up to 8 queries streams the items through stream_filter_f64_kernel (a dot product in
+    butterfly order, within 3e-14 of the reference's sequential one) and runs the reference's chain only for the pairs within
+    1e-12 of the cut: indices and scores must be those of the full exact pass (search_stream_quick = 0) and of the oracle
+    (src/core.rs:760-798), with duplicate items (ties by index) and a zero row in the index."""
+    X = index_rows
+    n = len(X)
+    rng = np.random.default_rng(nq)
+    lam = rng.random(n)
+    qi = np.concatenate([[7], rng.integers(0, n, nq)])[:nq]
+    Q = X[qi] * 1.02
+    lq = lam[qi] + 0.01
+    res = {}
+    for quick in (0, 1):
+        ctx.set_option("search_stream_quick", quick)
+        try:
+            asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+            asp.update_lambdas(lam)
+            res[quick] = asp.search_lambda_aware_batch(Q, lq, 12, alpha)
+            assert ctx.stat("search_stream_scan") == 1 and ctx.stat("stream_scan_quick") == quick
+        finally:
+            ctx.set_option("search_stream_quick", 1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for j in range(nq):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 12, alpha)
+        assert np.array_equal(res[1][0][j].astype(np.int64), oi.astype(np.int64)), j
+        assert np.array_equal(res[1][1][j], osc), j
