@@ -271,7 +271,7 @@ class CsrMatrix:
     def to_dense(self):
         indptr, indices, data = self.to_host()
         n = len(indptr) - 1
-        M = np.zeros((n, n))
+        M = np.zeros((n, self.shape()[1]))   # (a row block of a sharded build has global column ids: rows x n_nodes)
         for i in range(n):
             s, e = int(indptr[i]), int(indptr[i + 1])
             M[i, indices[s:e].astype(np.int64)] = data[s:e]
@@ -296,8 +296,8 @@ class GraphLaplacian:
 
     @staticmethod
     def sparsity(matrix):  # src/graph.rs:572-578
-        n = matrix.shape()[0]
-        return 1.0 - matrix.nnz() / float(n * n)
+        rows, cols = matrix.shape()            # (a row block: its own rows x all columns)
+        return 1.0 - matrix.nnz() / float(rows * cols)
 
 
 def build_laplacian_matrix(transposed, params, n_items=None, ctx=None):

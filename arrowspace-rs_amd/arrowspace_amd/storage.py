@@ -6,7 +6,10 @@ that a Rust host reads them with the crate's own loaders and vice versa:
   sparse matrix  `<name>.parquet`: name_id, n_rows, n_cols, nnz (u64), row, col (u64), value (f64): COO triplets in
                  CSR order                                                      src/storage/parquet.rs:354-460
   lambda vector  `<name>.parquet`: name_id, n_values, row_index (u64), lambda (f64)  src/storage/parquet.rs:664-760
-  metadata       `<name>_metadata.json` sidecar (name_id, dimensions, files, builder configuration)
+  metadata       `<name>_metadata.json` sidecar = serde_json of ArrowSpaceMetadata (src/storage/parquet.rs:29-54): name_id,
+                 timestamp (RFC 3339), n_rows, n_cols, builder_config (HashMap<String, ConfigValue>: an externally tagged
+                 enum, {"Usize": 3}, src/builder.rs:528-538), files (HashMap<String, FileInfo>; key "matrix" for the
+                 matrices, "lambda_vector" with file_type "lambda_vector" for the lambdas, :715-742)
 Snappy compression, one record batch, as the reference writes them.  Host-side I/O: nothing here touches the GPU
 except reading the CSR back from HBM (CsrMatrix.to_host).
 """
@@ -25,12 +28,59 @@ def _write(table, path, name_id):
     return fp
 
 
-def _metadata(path, name_id, file_type, rows, cols, nnz, fp, builder_config):
+# ConfigValue variants of the keys ArrowSpaceBuilder::builder_config_typed writes (src/builder.rs:580-634)
+_OPTION_KEYS = {"lambda_sigma": "OptionF64", "cluster_max_clusters": "OptionUsize", "clustering_seed": "OptionU64",
+                "sampling": "OptionSamplerType"}
+_TAGS = ("Bool", "Usize", "F64", "String", "OptionF64", "OptionUsize", "OptionU64", "TauMode", "OptionSamplerType")
+
+
+def _tau_json(t):
+    """serde's form of TauMode (src/taumode.rs:75-82): "Median" / "Mean" / {"Fixed": x} / {"Percentile": p}."""
+    kind, arg = getattr(t, "kind", None), getattr(t, "arg", 0.0)
+    return {0: {"Fixed": float(arg)}, 1: "Median", 2: "Mean", 3: {"Percentile": float(arg)}}[int(kind)]
+
+
+def config_value(key, v):
+    """One builder_config entry as serde_json writes ConfigValue (externally tagged: {"Variant": payload})."""
+    if isinstance(v, dict) and len(v) == 1 and next(iter(v)) in _TAGS:
+        return v                                   # already tagged
+    if key in _OPTION_KEYS:
+        return {_OPTION_KEYS[key]: v}
+    if hasattr(v, "kind") and hasattr(v, "arg"):
+        return {"TauMode": _tau_json(v)}
+    if isinstance(v, (bool, np.bool_)):
+        return {"Bool": bool(v)}
+    if isinstance(v, (int, np.integer)):
+        return {"Usize": int(v)}
+    if isinstance(v, (float, np.floating)):
+        return {"F64": float(v)}
+    if isinstance(v, str):
+        return {"String": v}
+    raise TypeError("builder_config[%r]: no ConfigValue variant for %r" % (key, type(v)))
+
+
+def builder_config_typed(builder):
+    """ArrowSpaceBuilder::builder_config_typed (src/builder.rs:580-634) for this package's builder mirror."""
+    g = lambda name, default=None: getattr(builder, name, default)  # noqa: E731
+    cfg = {"prebuilt_spectral": bool(g("prebuilt_spectral", False)), "lambda_eps": float(g("lambda_eps")),
+           "lambda_k": int(g("lambda_k")), "lambda_topk": int(g("lambda_topk")), "lambda_p": float(g("lambda_p")),
+           "lambda_sigma": g("lambda_sigma"), "normalise": bool(g("normalise", False)),
+           "sparsity_check": bool(g("sparsity_check", False)), "synthesis": g("synthesis"), "sampling": None,
+           "cluster_max_clusters": g("cluster_max_clusters"), "cluster_radius": float(g("cluster_radius", 1.0) or 0.0),
+           "clustering_seed": g("clustering_seed"), "deterministic_clustering": bool(g("deterministic_clustering", False)),
+           "use_dims_reduction": bool(g("use_dims_reduction", False)), "rp_eps": float(g("rp_eps", 0.3) or 0.0)}
+    return {k: config_value(k, v) for k, v in cfg.items()}
+
+
+def _metadata(path, name_id, file_type, rows, cols, nnz, fp, builder_config, key="matrix"):
     if builder_config is None:
         return
-    meta = {"name_id": name_id, "n_rows": int(rows), "n_cols": int(cols), "builder_config": builder_config,
-            "files": {"matrix": {"filename": os.path.basename(fp), "file_type": file_type, "rows": int(rows), "cols": int(cols),
-                                 "nnz": None if nnz is None else int(nnz), "size_bytes": os.path.getsize(fp)}}}
+    import datetime
+    meta = {"name_id": name_id, "timestamp": datetime.datetime.now(datetime.timezone.utc).isoformat(),  # chrono to_rfc3339
+            "n_rows": int(rows), "n_cols": int(cols),
+            "builder_config": {k: config_value(k, v) for k, v in builder_config.items()},
+            "files": {key: {"filename": os.path.basename(fp), "file_type": file_type, "rows": int(rows), "cols": int(cols),
+                            "nnz": None if nnz is None else int(nnz), "size_bytes": os.path.getsize(fp)}}}
     with open(os.path.join(path, "%s_metadata.json" % name_id), "w") as f:
         json.dump(meta, f, indent=1)
 
@@ -52,6 +102,9 @@ def save_dense_matrix(matrix, path, name_id, builder_config=None):
 def load_dense_matrix(file_path):
     """src/storage/parquet.rs:291-352"""
     t = pq.read_table(file_path)
+    cols = [c for c in t.column_names if c.startswith("col_")]
+    if t.num_rows == 0:   # (the shape columns repeat per record: an empty matrix carries its width only in the schema)
+        return np.zeros((0, len(cols)), dtype=np.float64)
     n_cols = int(t.column("n_cols")[0].as_py())
     return np.stack([t.column("col_%d" % c).to_numpy() for c in range(n_cols)], axis=1)
 
@@ -77,6 +130,8 @@ def save_sparse_matrix(csr, path, name_id, builder_config=None, shape=None):
 def load_sparse_matrix(file_path):
     """src/storage/parquet.rs:462-560: (indptr, indices, data), shape."""
     t = pq.read_table(file_path)
+    if t.num_rows == 0:   # nnz = 0: no record carries the shape (the reference's loader fails on such a file too)
+        raise ValueError("%s holds no entries: the COO layout keeps the shape in its records" % file_path)
     n_rows, n_cols = int(t.column("n_rows")[0].as_py()), int(t.column("n_cols")[0].as_py())
     row, col, val = (t.column(c).to_numpy() for c in ("row", "col", "value"))
     order = np.lexsort((col, row))
@@ -94,7 +149,7 @@ def save_lambda(lambdas, path, name_id, builder_config=None):
                       "n_values": pa.array(np.full(n, n, dtype=np.uint64)),
                       "row_index": pa.array(np.arange(n, dtype=np.uint64)), "lambda": pa.array(lam)})
     fp = _write(table, path, name_id)
-    _metadata(path, name_id, "lambda", n, 1, None, fp, builder_config)
+    _metadata(path, name_id, "lambda_vector", n, 1, None, fp, builder_config, key="lambda_vector")
     return fp
 
 

@@ -325,6 +325,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
   else if (n == "search_stream_filter") ctx->opt_search_stream_filter = value;
   else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
+  else if (n == "cluster_on_device") ctx->opt_cluster_on_device = value;
   else if (n == "search_stream_quick") ctx->opt_search_stream_quick = value;
   else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;

@@ -1814,7 +1814,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       }
       if (ix->weird_items == 0 && ix->rot_state == 0) {
         double tail = 1.0;
-        AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+        if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));  // (kept on failure: the next call reuses it)
         AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
         ix->rot_state = tail <= 0.10 ? 1 : -1;
       }
@@ -1932,7 +1932,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     if (scan_h && ix->scan_perm && ix->rot_state == 0 && ctx->opt_search_prefilter && d > 32) {
       const uint32_t tiles = packed_tiles_f16(n);
       double tail = 1.0;
-      AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+      if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
       AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
       ix->rot_state = tail <= 0.10 ? 1 : -1;
       if (ix->rot_state == 1) {

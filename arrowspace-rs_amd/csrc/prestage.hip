@@ -161,6 +161,62 @@ __global__ __launch_bounds__(256) void jl_project_kernel(const double *__restric
   }
 }
 
+// ---- incremental clustering once every centroid exists (src/clustering.rs:721-905 with the cluster cap reached) --------------
+// From then on a row's fate depends on its nearest centroid of the batch's snapshot alone: within `radius` it joins and moves
+// the running mean, within 1.5 radius it is counted, else it is dropped -- no new centroid can appear, so nothing of the batch
+// has to visit the host.  decide: one thread per row.  apply: one workgroup per centroid walks the batch IN ROW ORDER (the
+// reference's order of the running-mean updates of one centroid; different centroids do not interact) with a thread per
+// feature: c += (x - c) / k_new, the same two roundings as the host loop.
+__global__ void cluster_decide_kernel(const uint64_t *__restrict__ idx, const double *__restrict__ d2, uint64_t bn, double radius,
+                                      uint32_t *__restrict__ act /* 0 dropped, 1 counted, 2 joins */, long long *__restrict__ assign) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= bn) return;
+  const double bd = d2[r];
+  const uint32_t a = bd <= radius ? 2u : (bd <= radius * 1.5 ? 1u : 0u);
+  act[r] = a;
+  assign[r] = a ? (long long)idx[r] : -1ll;
+}
+__global__ __launch_bounds__(256) void cluster_apply_kernel(const double *__restrict__ rows, uint64_t bn, uint64_t f,
+                                                            const uint64_t *__restrict__ idx, const uint32_t *__restrict__ act,
+                                                            double *__restrict__ cents, unsigned long long *__restrict__ counts) {
+  const uint64_t c = blockIdx.x;
+  __shared__ uint32_t s_rows[256];
+  __shared__ uint32_t s_n;
+  unsigned long long cnt = counts[c];
+  for (uint64_t base = 0; base < bn; base += 256) {
+    // the rows of this chunk that belong to centroid c, in row order (a stable compaction by a block-wide prefix count)
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t r = base + threadIdx.x;
+    const uint32_t a = (r < bn && idx[r] == c) ? act[r] : 0u;
+    const unsigned long long m = __ballot(a != 0);
+    __shared__ uint32_t s_wave[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_wave[wv] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wv; ++w) before += s_wave[w];
+    if (a) s_rows[before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)threadIdx.x | (a << 16);
+    if (threadIdx.x == 0) s_n = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    const uint32_t nn = s_n;
+    for (uint32_t e = 0; e < nn; ++e) {
+      const uint32_t w = s_rows[e], rr = w & 0xFFFFu, aa = w >> 16;
+      if (aa == 2u) {
+        const double k_new = (double)cnt + 1.0;
+        const double *row = rows + (base + rr) * f;
+        for (uint64_t j = threadIdx.x; j < f; j += 256) {
+          const double cj = cents[c * f + j];
+          cents[c * f + j] = __dadd_rn(cj, __ddiv_rn(__dsub_rn(row[j], cj), k_new));
+        }
+      }
+      cnt += 1;
+    }
+  }
+  if (threadIdx.x == 0) counts[c] = cnt;
+}
+
 // rows [begin, begin + count) of a host- or device-resident matrix as a host pointer
 struct HostRows {
   std::vector<double> buf;
@@ -545,8 +601,36 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
   uint64_t nc = 0;
   for (uint64_t i = 0; i < n; ++i) assignments_out[i] = -1;
   HostRows H;
+  // device state of the phase in which every centroid exists (no row of it visits the host)
+  DevBuf<unsigned long long> counts_d;
+  DevBuf<long long> assign_d;
+  DevBuf<uint32_t> act_d;
+  bool on_device_phase = false;
+  ctx->stats["clustering_device_batches"] = 0;
+  ctx->stats["clustering_host_batches"] = 0;
   for (uint64_t b0 = 0; b0 < n; b0 += batch) {
     const uint64_t bn = std::min(batch, n - b0), nc_snap = nc;
+    if (nc == max_clusters && ctx->opt_cluster_on_device) {
+      if (!on_device_phase) {  // the state so far moves to the device once
+        AS_TRY(counts_d.alloc(ctx, max_clusters));
+        AS_TRY(assign_d.alloc(ctx, n));
+        AS_TRY(act_d.alloc(ctx, batch));
+        std::vector<unsigned long long> hc(max_clusters);
+        for (uint64_t c = 0; c < max_clusters; ++c) hc[c] = counts_out[c];
+        AS_HIP(ctx, copy_h2d(ctx, counts_d.p, hc.data(), sizeof(unsigned long long) * max_clusters));
+        AS_HIP(ctx, copy_h2d(ctx, cd.p, cents, sizeof(double) * max_clusters * f));
+        on_device_phase = true;
+      }
+      AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
+      hipLaunchKernelGGL(cluster_decide_kernel, dim3(cdiv(bn, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idxd.p, (const double *)d2d.p, bn,
+                         radius, act_d.p, assign_d.p + b0);
+      hipLaunchKernelGGL(cluster_apply_kernel, dim3((unsigned)nc), dim3(256), 0, ctx->stream, R.p + b0 * f, bn, f, (const uint64_t *)idxd.p,
+                         (const uint32_t *)act_d.p, cd.p, counts_d.p);
+      AS_HIP(ctx, hipGetLastError());
+      ctx->stats["clustering_device_batches"] += 1;
+      continue;
+    }
+    ctx->stats["clustering_host_batches"] += 1;
     if (nc_snap == 0) {
       std::fill(snap_d2.begin(), snap_d2.begin() + bn, INFINITY);
       std::fill(snap_i.begin(), snap_i.begin() + bn, 0);
@@ -591,6 +675,20 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
         assignments_out[b0 + r] = (int64_t)bi;
       }
     }
+  }
+  if (on_device_phase) {  // the device phase's centroids, counts and assignments come back once
+    std::vector<unsigned long long> hc(max_clusters);
+    AS_HIP(ctx, copy_d2h(ctx, cents, cd.p, sizeof(double) * max_clusters * f));
+    AS_HIP(ctx, copy_d2h(ctx, hc.data(), counts_d.p, sizeof(unsigned long long) * max_clusters));
+    for (uint64_t c = 0; c < max_clusters; ++c) counts_out[c] = hc[c];
+    // (assignments of the host phase are in assignments_out already: the device phase covers the batches from its first on)
+    uint64_t first = 0;
+    {
+      const uint64_t host_batches = (uint64_t)ctx->stats["clustering_host_batches"];
+      first = std::min(n, host_batches * batch);
+    }
+    if (first < n) AS_HIP(ctx, copy_d2h(ctx, assignments_out + first, assign_d.p + first, sizeof(long long) * (n - first)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   *n_clusters_out = nc;
   return AS_OK;

@@ -302,6 +302,33 @@ def main():
                                               "pipelined through pinned staging by several host threads), then the same build on the device "
                                               "copy; PCIe-inclusive" % (n * d * 8 / 1e9)}
         del gl_h, asp_h, X_host, X_up
+        # ---- the clustering pre-stage (the step in front of the hot path inside build()) ----------
+        # ArrowSpaceBuilder.build(rows) WITHOUT supplied centroids: Two-NN intrinsic dimension + optimal K + pilot radius
+        # (src/clustering.rs:36-164,384-492), then incremental clustering over all N rows (:547-910), then the same graph +
+        # lambda stages as the bench line.  Rows resident in HBM.  Never in `value` (the bench line supplies the centroids).
+        try:
+            import arrowspace_amd.api as API
+            t0 = time.perf_counter()
+            k_opt, radius, idim = API.compute_optimal_k(Xd, None, ctx=ctx)
+            ctx.synchronize()
+            t_k = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cents_p, assign_p, sizes_p = API.incremental_clustering(Xd, k_opt, radius, 4096, ctx=ctx)
+            ctx.synchronize()
+            t_inc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            asp_p, gl_p = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(Xd)
+            ctx.synchronize()
+            t_full = time.perf_counter() - t0
+            extra["prestage"] = {"optimal_k_ms": t_k * 1e3, "incremental_clustering_ms": t_inc * 1e3, "build_from_rows_ms": t_full * 1e3,
+                                 "k_optimal": int(k_opt), "intrinsic_dimension": int(idim), "radius": float(radius),
+                                 "clusters": int(len(cents_p)), "assigned": int((assign_p >= 0).sum()), "batch": 4096,
+                                 "items_per_s_build_from_rows": n / t_full,
+                                 "note": "build(rows) without supplied centroids: Two-NN + optimal K + pilot radius, incremental "
+                                         "clustering of all N rows (batch 4096), F x F graph, per-item lambdas"}
+            del asp_p, gl_p
+        except Exception as e:  # noqa: BLE001
+            extra["prestage"] = {"error": repr(e)}
         # ---- the hard case: data the rotated first pass cannot exploit (never in `value`) ------------------------------
         # `value` is measured on SURVEY's rank-8 / 256-cluster mixture, whose energy sits in 31 directions.  Same size and graph
         # parameters on a rank-64 / 4096-cluster mixture (244 rows per cluster; 31 directions hold about half of the energy, so

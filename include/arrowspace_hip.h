@@ -342,6 +342,9 @@ int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len
                   double tau_arg, double *taus_out);
 
 /* ---- search: replaces ArrowSpace::search_lambda_aware, src/core.rs:760-798 ---------------- */
+/* An index handle has ONE owner: searches keep lazily built state with it (ordered / rotated images from the second search
+ * on, a call counter), so two contexts or threads must not search the same handle at once -- create one index per searching
+ * thread (the items are borrowed when they are in HBM already, so that costs no second copy). */
 int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uint64_t n_items,
                     uint64_t n_features, as_index **out);
 void as_index_destroy(as_index *index);

@@ -1095,9 +1095,19 @@ def test_incremental_clustering_matches_oracle(ctx, batch):
     X[100:110] += 40.0                              # far outliers: new clusters until the cap, then dropped
     k, radius, _ = O.compute_optimal_k(X)
     cents, assign, sizes = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
+    # once the cap is reached the batches stay on the device (decisions from the snapshot's nearest centroid, running means
+    # applied per centroid in row order): the same centroids, bit for bit, as with every batch decided on the host
+    assert ctx.stat("clustering_device_batches") > 0 and ctx.stat("clustering_host_batches") > 0
     oc, oa, osz = O.incremental_clustering(X, k, radius, batch)
     assert np.array_equal(assign, oa) and np.array_equal(sizes, osz) and np.array_equal(cents, oc)
     assert (assign < 0).sum() == (oa < 0).sum()
+    ctx.set_option("cluster_on_device", 0)
+    try:
+        ch, ah, sh = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
+        assert ctx.stat("clustering_device_batches") == 0
+    finally:
+        ctx.set_option("cluster_on_device", 1)
+    assert np.array_equal(ah, oa) and np.array_equal(sh, osz) and np.array_equal(ch, oc)
     import torch
     c2, a2, s2 = A.incremental_clustering(torch.from_numpy(X).cuda(), k, radius, batch, ctx=ctx)
     assert np.array_equal(a2, oa) and np.array_equal(c2, oc)

@@ -469,3 +469,45 @@ def test_parquet_formats_round_trip(tmp_path):
     import json
     meta = json.load(open(tmp_path / "gl_metadata.json"))
     assert meta["files"]["matrix"]["file_type"] == "sparse" and meta["files"]["matrix"]["nnz"] == len(csr[1])
+
+
+def test_metadata_sidecar_is_the_reference_struct(tmp_path):
+    """`<name>_metadata.json` must deserialise as the reference's ArrowSpaceMetadata (src/storage/parquet.rs:29-54): the
+    fields of the struct and of FileInfo, the RFC 3339 timestamp, builder_config values as the externally tagged ConfigValue
+    enum serde writes (src/builder.rs:528-538, keys of builder_config_typed :580-634), and the lambda file under key and
+    file_type "lambda_vector" (:715-742).  Field lists below are read off the reference structs."""
+    import datetime
+    import json
+    import arrowspace_amd as A
+    from arrowspace_amd import storage as S
+    b = A.ArrowSpaceBuilder.new(None).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).with_synthesis(A.TauMode.Percentile(0.95))
+    cfg = S.builder_config_typed(b)
+    want_keys = {"prebuilt_spectral", "lambda_eps", "lambda_k", "lambda_topk", "lambda_p", "lambda_sigma", "normalise",
+                 "sparsity_check", "synthesis", "sampling", "cluster_max_clusters", "cluster_radius", "clustering_seed",
+                 "deterministic_clustering", "use_dims_reduction", "rp_eps"}
+    assert set(cfg) == want_keys
+    assert cfg["lambda_k"] == {"Usize": 16} and cfg["lambda_eps"] == {"F64": 0.5} and cfg["lambda_sigma"] == {"OptionF64": 0.25}
+    assert cfg["synthesis"] == {"TauMode": {"Percentile": 0.95}} and cfg["sampling"] == {"OptionSamplerType": None}
+    assert cfg["normalise"] == {"Bool": False}
+    assert S.config_value("synthesis", A.TauMode.Median) == {"TauMode": "Median"}
+    assert S.config_value("lambda_sigma", None) == {"OptionF64": None}
+    lam = np.linspace(0.0, 1.0, 7)
+    S.save_lambda(lam, str(tmp_path), "lam", cfg)
+    S.save_dense_matrix(np.zeros((3, 2)), str(tmp_path), "m", {"lambda_k": 4, "lambda_sigma": None})
+    for name, key, ftype, rows, cols in (("lam", "lambda_vector", "lambda_vector", 7, 1), ("m", "matrix", "dense", 3, 2)):
+        meta = json.load(open(tmp_path / ("%s_metadata.json" % name)))
+        assert list(meta) == ["name_id", "timestamp", "n_rows", "n_cols", "builder_config", "files"]   # ArrowSpaceMetadata
+        assert datetime.datetime.fromisoformat(meta["timestamp"]).tzinfo is not None                    # to_rfc3339()
+        assert (meta["n_rows"], meta["n_cols"]) == (rows, cols)
+        assert list(meta["files"]) == [key]
+        fi = meta["files"][key]
+        assert list(fi) == ["filename", "file_type", "rows", "cols", "nnz", "size_bytes"]               # FileInfo
+        assert fi["file_type"] == ftype and fi["filename"] == name + ".parquet" and fi["nnz"] is None
+        for v in meta["builder_config"].values():       # every value is one tagged variant
+            assert isinstance(v, dict) and len(v) == 1 and next(iter(v)) in S._TAGS
+    # empty tables: a dense matrix without rows loads as 0 x F; a sparse one without entries is refused with a message
+    fd = S.save_dense_matrix(np.zeros((0, 4)), str(tmp_path), "empty")
+    assert S.load_dense_matrix(fd).shape == (0, 4)
+    fs = S.save_sparse_matrix((np.zeros(4, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros(0)), str(tmp_path), "nil")
+    with pytest.raises(ValueError):
+        S.load_sparse_matrix(fs)
