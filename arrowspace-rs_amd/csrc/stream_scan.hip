@@ -398,6 +398,154 @@ __global__ __launch_bounds__(256) void stream_filter_i8_kernel(const ssf_i32x4 *
   flush();
 }
 
+// ---- the same quick pass for rows of 256 .. 1024 values (128 P), and as the SAMPLE pass of such rows -------------------------
+// A row arrives as P pieces of 1 KB (eight rows x one piece per trip: the same eight coalesced loads); the partial products of a
+// (row, query) pair add up over the pieces before the butterfly.  The queries live in LDS (P KB each), a lane re-reads its 16 B
+// of every query per piece.  SAMPLE: one tile in 16 (the hashed pick of the exact sample pass), the quick keys go to the share
+// minima stream_guess_kernel reads: guess = the K-th smallest SAMPLED quick key, so the K-th smallest exact key over all rows
+// is at most guess + margin, the list must hold every exact key <= guess + margin, and the filter lets every quick key
+// <= guess + 2 margin through.
+template <class Policy, int NQ, bool SAMPLE>
+__global__ __launch_bounds__(256) void stream_quick_wide_kernel(const double *__restrict__ A, const uint32_t *__restrict__ a_ids, uint32_t a_begin,
+                                                               uint32_t nA, const double *__restrict__ B, uint32_t nB, uint32_t P, Policy pol,
+                                                               const double *__restrict__ guess, double cut_margin,
+                                                               unsigned long long *__restrict__ sample_min, uint32_t cap,
+                                                               uint32_t *__restrict__ count, uint32_t *__restrict__ pairs,
+                                                               int *__restrict__ overflow) {
+  static_assert(NQ == 1 || NQ == 2 || NQ == 4, "queries per launch");
+  constexpr int QB = NQ == 1 ? 0 : (NQ == 2 ? 1 : 2);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2 *s_q = reinterpret_cast<double2 *>(smem);  // [NQ][P][64]
+  const int lane = threadIdx.x & 63;
+  const uint32_t D = 128u * P;
+  for (uint32_t e = threadIdx.x; e < (uint32_t)NQ * P * 64u; e += blockDim.x) {
+    const uint32_t a = e / (P * 64u), rest = e - a * (P * 64u);
+    double2 v{0.0, 0.0};
+    if (a < nA) {
+      const uint32_t ga = a_ids ? a_ids[a] : a_begin + a;
+      v = reinterpret_cast<const double2 *>(A + (uint64_t)ga * D)[rest];
+    }
+    s_q[e] = v;
+  }
+  constexpr uint32_t kQ = 512;
+  __shared__ uint32_t s_qq[4][kQ];
+  __shared__ uint32_t s_qn[4];
+  uint32_t *q = s_qq[threadIdx.x >> 6];
+  uint32_t *qn_p = &s_qn[threadIdx.x >> 6];
+  if (lane == 0) *qn_p = 0;
+  __syncthreads();
+  auto flush = [&]() {
+    ss_wave_sync();
+    const uint32_t qn = *(volatile uint32_t *)qn_p;
+    if (qn != 0) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count, qn);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + qn > cap) {
+        if (lane == 0) *overflow = 1;
+      } else {
+        for (uint32_t e = lane; e < qn; e += 64) pairs[base + e] = q[e];
+      }
+    }
+    ss_wave_sync();
+    if (lane == 0) *qn_p = 0;
+    ss_wave_sync();
+  };
+  const uint32_t row_sel = (uint32_t)lane >> 3;
+  const uint32_t a_fin = NQ == 1 ? 0u : ((uint32_t)lane & 7u) >> (3 - QB);
+  const bool speaker = (((uint32_t)lane & 7u) & ((8u >> QB) - 1u)) == 0u && a_fin < nA;
+  const uint32_t ga_fin = a_fin < nA ? (a_ids ? a_ids[a_fin] : a_begin + a_fin) : 0u;
+  StreamOperands<Policy> op;
+  op.load_a(pol, ga_fin);
+  const double cut = (!SAMPLE && a_fin < nA) ? guess[a_fin] + cut_margin : -__builtin_inf();
+  const double *b_norms = StreamOperands<Policy>::b_norms(pol);
+  const double *b_lams = StreamOperands<Policy>::b_lambdas(pol);
+  const uint32_t n_tiles = (nB + kSsTile - 1) / kSsTile;
+  const uint32_t n_my_all = SAMPLE ? (n_tiles + kSsSampleStride - 1) / kSsSampleStride : n_tiles;
+  const uint32_t wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  auto tile_of = [&](uint32_t t) -> uint32_t {
+    if (!SAMPLE) return t;
+    uint32_t h = t * 0x9E3779B9u;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    const uint32_t pick = t * kSsSampleStride + (h & (kSsSampleStride - 1));
+    return pick < n_tiles ? pick : t * kSsSampleStride;
+  };
+  // this wave's tiles: wave_id, wave_id + n_waves, ...; a unit = (tile ordinal i, piece p)
+  const uint32_t n_mine = wave_id < n_my_all ? (n_my_all - wave_id + n_waves - 1) / n_waves : 0u;
+  const uint32_t n_units = n_mine * P;
+  typedef double ssq_d2 __attribute__((ext_vector_type(2)));
+  auto load_unit = [&](uint32_t u, double2 (&x)[kSsTile]) {
+    const uint32_t i = u / P, p = u - i * P;
+    const uint32_t row0 = tile_of(wave_id + i * n_waves) * kSsTile;
+#pragma unroll
+    for (int r = 0; r < kSsTile; ++r) {
+      const uint32_t row = min(row0 + (uint32_t)r, nB - 1);
+      const ssq_d2 w = __builtin_nontemporal_load(reinterpret_cast<const ssq_d2 *>(B + (uint64_t)row * D + (uint64_t)p * 128u) + lane);
+      x[r] = double2{w.x, w.y};
+    }
+  };
+  double v[kSsTile * NQ];
+  auto consume = [&](uint32_t u, const double2 (&x)[kSsTile]) {
+    const uint32_t i = u / P, p = u - i * P;
+    double2 qv[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) qv[a] = s_q[((uint32_t)a * P + p) * 64u + (uint32_t)lane];
+    if (p == 0) {
+#pragma unroll
+      for (int e = 0; e < kSsTile * NQ; ++e) v[e] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < kSsTile; ++r)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) v[r * NQ + a] = __builtin_fma(x[r].y, qv[a].y, __builtin_fma(x[r].x, qv[a].x, v[r * NQ + a]));
+    if (p + 1 != P) return;
+    const uint32_t t_ord = wave_id + i * n_waves, tt = tile_of(t_ord);
+    const uint32_t jr = min(tt * kSsTile + row_sel, nB - 1);
+    const double xn = b_norms[jr];
+    const double xl = StreamOperands<Policy>::kLambda ? b_lams[jr] : 0.0;
+    ssq_halve<8 * NQ, 5>(v, lane);
+    ssq_halve<4 * NQ, 4>(v, lane);
+    ssq_halve<2 * NQ, 3>(v, lane);
+    if constexpr (NQ >= 2) ssq_halve<NQ, 2>(v, lane);
+    if constexpr (NQ >= 4) ssq_halve<NQ / 2, 1>(v, lane);
+    double dot = v[0];
+    if constexpr (NQ <= 4) dot += __shfl_xor(dot, 1, 64);
+    if constexpr (NQ <= 2) dot += __shfl_xor(dot, 2, 64);
+    if constexpr (NQ <= 1) dot += __shfl_xor(dot, 4, 64);
+    const uint32_t j = tt * kSsTile + row_sel;
+    if (SAMPLE) {
+      if (speaker && j < nB) {
+        const double key = op.key_quiet(pol, dot, ga_fin, j, xn, xl);
+        if (key == key && key < __builtin_inf())
+          atomicMin(sample_min + (size_t)a_fin * kSsShares + ((t_ord * kSsTile + row_sel) & (kSsShares - 1)), ss_orderable(key));
+      }
+    } else {
+      bool take = false;
+      if (speaker && j < nB) {
+        const double key = op.key_quiet(pol, dot, ga_fin, j, xn, xl);
+        take = !(key > cut);
+      }
+      if (__any(take)) {
+        ss_wave_sync();
+        if (*(volatile uint32_t *)qn_p + 64 > kQ) flush();
+        if (take) q[atomicAdd(qn_p, 1u)] = (a_fin << 27) | j;
+      }
+    }
+  };
+  double2 xa[kSsTile], xb[kSsTile];
+  if (n_units) load_unit(0, xa);
+  for (uint32_t u = 0; u < n_units; u += 2) {
+    if (u + 1 < n_units) load_unit(u + 1, xb);
+    consume(u, xa);
+    if (u + 1 >= n_units) break;
+    if (u + 2 < n_units) load_unit(u + 2, xa);
+    consume(u + 1, xb);
+  }
+  if (!SAMPLE) flush();
+}
+
 // The exact keys of the pairs the filter left: one lane per (query, item) pair, the reference's chain over k (multiply and add
 // rounded separately, k ascending: src/core.rs:185-197) with the query rows in LDS; keys at or below the query's cut are listed
 // for stream_final_kernel exactly as the list pass of the streaming scan lists them.
@@ -408,25 +556,27 @@ __global__ __launch_bounds__(256) void stream_pairs_kernel(const double *__restr
                                                           const uint32_t *__restrict__ count, const int *__restrict__ overflow,
                                                           const double *__restrict__ guess, uint32_t cap, uint32_t *__restrict__ cnt,
                                                           uint32_t *__restrict__ list_idx, double *__restrict__ list_key,
-                                                          int *__restrict__ err_flag) {
+                                                          int *__restrict__ err_flag, uint32_t d = kSsD, uint32_t a_begin = 0,
+                                                          double list_margin = 0.0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *sA = reinterpret_cast<double *>(smem);  // nA x 129 (the pad keeps the rows of different queries in different banks)
+  double *sA = reinterpret_cast<double *>(smem);  // nA x (d + 1) (the pad keeps the rows of different queries in different banks)
   if (*overflow) return;
-  for (uint32_t e = threadIdx.x; e < nA * kSsD; e += blockDim.x) {
-    const uint32_t a = e / kSsD, k = e % kSsD;
-    sA[a * 129 + k] = A[(uint64_t)(a_ids ? a_ids[a] : a) * kSsD + k];
+  const uint32_t pitch = d + 1;
+  for (uint32_t e = threadIdx.x; e < nA * d; e += blockDim.x) {
+    const uint32_t a = e / d, k = e % d;
+    sA[a * pitch + k] = A[(uint64_t)(a_ids ? a_ids[a] : a_begin + a) * d + k];
   }
   __syncthreads();
   const uint32_t n_pairs = *count;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
     const uint32_t w = pairs[p], a = w >> 27, jpos = w & 0x7FFFFFFu;
-    const uint32_t j = perm ? perm[jpos] : jpos, ga = a_ids ? a_ids[a] : a;  // (the filter's image may be in a permuted order)
-    const double *x = B + (uint64_t)j * kSsD, *qa = sA + a * 129;
+    const uint32_t j = perm ? perm[jpos] : jpos, ga = a_ids ? a_ids[a] : a_begin + a;  // (the filter's image may be in a permuted order)
+    const double *x = B + (uint64_t)j * d, *qa = sA + a * pitch;
     double acc = 0.0;
 #pragma unroll 8
-    for (uint32_t k = 0; k < kSsD; ++k) acc = __dadd_rn(acc, __dmul_rn(qa[k], x[k]));
+    for (uint32_t k = 0; k < d; ++k) acc = __dadd_rn(acc, __dmul_rn(qa[k], x[k]));
     double key;
-    if (pol.key(acc, ga, j, key, err_flag) && key <= guess[a]) {
+    if (pol.key(acc, ga, j, key, err_flag) && key <= guess[a] + list_margin) {
       const uint32_t pos = atomicAdd(cnt + a, 1u);
       if (pos < cap) {
         list_idx[(size_t)a * cap + pos] = j;
@@ -851,6 +1001,86 @@ static int stream_scan(as_ctx *ctx, const char *prof_name, const double *A, cons
   ctx->stats["stream_scan_rows"] = nA;
   ctx->stats["stream_scan_overflow_rows"] = (int64_t)redo_pos->size();
   return AS_OK;
+}
+
+// ---- rows of 256 .. 1024 values: sample, guess, list and final for up to 32 A rows, four at a time -------------------------------
+bool stream_quick_wide_applies(uint64_t nA, uint64_t nB, uint64_t d, uint32_t K) {
+  return nA >= 1 && nA <= kSsMaxA && d > kSsD && d <= 1024 && d % 128 == 0 && K >= 1 && K <= 64 && nB >= 65536 && nB < (1ull << 27);
+}
+template <class Policy>
+static int stream_quick_wide(as_ctx *ctx, const char *prof_name, const double *A, const uint32_t *a_ids, uint32_t nA, const double *B, uint32_t nB,
+                             uint32_t d, uint32_t K, Policy pol, double *out_key, uint32_t *out_idx, int *err_flag,
+                             std::vector<uint32_t> *redo_pos) {
+  const uint32_t P = d / 128, cap = kSsSortMax, g_cap = 1u << 20;
+  const double margin = 1e-12;
+  DevBuf<double> guess, lkey;
+  DevBuf<unsigned long long> smin;
+  DevBuf<uint32_t> lidx, small, g_pairs;
+  AS_TRY(smin.alloc(ctx, (size_t)4 * kSsShares));
+  AS_TRY(guess.alloc(ctx, 4));
+  AS_TRY(lidx.alloc(ctx, (size_t)4 * cap));
+  AS_TRY(lkey.alloc(ctx, (size_t)4 * cap));
+  AS_TRY(small.alloc(ctx, 16));  // cnt[4] | over[4] | done[4] | g_count | g_over
+  AS_TRY(g_pairs.alloc(ctx, g_cap));
+  redo_pos->clear();
+  ProfScope ps(ctx, prof_name);
+  for (uint32_t a0 = 0; a0 < nA; a0 += 4) {
+    const uint32_t na = std::min<uint32_t>(4, nA - a0);
+    const uint32_t *ids = a_ids ? a_ids + a0 : nullptr;
+    uint32_t *cnt = small.p;
+    int *over = reinterpret_cast<int *>(small.p + 4), *done = reinterpret_cast<int *>(small.p + 8);
+    uint32_t *g_count = small.p + 12;
+    int *g_over = reinterpret_cast<int *>(small.p + 13);
+    AS_HIP(ctx, hipMemsetAsync(small.p, 0, sizeof(uint32_t) * 16, ctx->stream));
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(cdiv((uint64_t)4 * kSsShares, 256)), dim3(256), 0, ctx->stream, smin.p, (uint64_t)4 * kSsShares,
+                       0xFFF0000000000000ull);
+#define AS_QW(NQV, SAMPLEV, GRID)                                                                                                         \
+  {                                                                                                                                        \
+    const size_t lds_q = (size_t)NQV * P * 1024;                                                                                           \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)stream_quick_wide_kernel<Policy, NQV, SAMPLEV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds_q));                                                                                          \
+    hipLaunchKernelGGL((stream_quick_wide_kernel<Policy, NQV, SAMPLEV>), dim3(GRID), dim3(256), lds_q, ctx->stream, A, ids, a0, na, B, nB, P, \
+                       pol, (const double *)guess.p, 2.0 * margin, smin.p, g_cap, g_count, g_pairs.p, g_over);                              \
+  }
+#define AS_QWN(SAMPLEV, GRID)              \
+  if (na == 1) AS_QW(1, SAMPLEV, GRID)     \
+  else if (na == 2) AS_QW(2, SAMPLEV, GRID) \
+  else AS_QW(4, SAMPLEV, GRID)
+    AS_QWN(true, 256u)
+    hipLaunchKernelGGL(stream_guess_kernel, dim3(na), dim3(256), 0, ctx->stream, smin.p, K, guess.p);
+    {
+      const std::string list_name = std::string(prof_name) + "_list";
+      ProfScope pl(ctx, list_name.c_str());
+      AS_QWN(false, 512u)
+    }
+#undef AS_QWN
+#undef AS_QW
+    const size_t lds_p = (size_t)na * (d + 1) * sizeof(double);
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)stream_pairs_kernel<Policy>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    hipLaunchKernelGGL(stream_pairs_kernel<Policy>, dim3(256), dim3(256), lds_p, ctx->stream, A, ids, na, B, (const uint32_t *)nullptr, pol,
+                       (const uint32_t *)g_pairs.p, (const uint32_t *)g_count, (const int *)g_over, (const double *)guess.p, cap, cnt, lidx.p,
+                       lkey.p, err_flag, d, a0, margin);
+    hipLaunchKernelGGL(stream_final_kernel, dim3(na), dim3(256), 0, ctx->stream, cnt, lidx.p, lkey.p, cap, K, K, 0u, out_key + (size_t)a0 * K,
+                       out_idx + (size_t)a0 * K, over, guess.p, done);
+    AS_HIP(ctx, hipGetLastError());
+    int h[16];
+    AS_HIP(ctx, copy_d2h(ctx, h, small.p, sizeof(h)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t a = 0; a < na; ++a)
+      if (h[4 + a] || h[13]) redo_pos->push_back(a0 + a);  // list ran over / the pair queue did: the caller's older path
+  }
+  ctx->stats["stream_scan_quick"] = 1;
+  ctx->stats["stream_scan_rows"] = nA;
+  ctx->stats["stream_scan_overflow_rows"] = (int64_t)redo_pos->size();
+  return AS_OK;
+}
+int stream_quick_wide_search(as_ctx *ctx, const double *queries, uint32_t nq, const double *items, uint32_t n, uint32_t d, uint32_t K,
+                             const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
+  return stream_quick_wide<SearchScorePolicy>(ctx, "search_stream_scan", queries, nullptr, nq, items, n, d, K, pol, out_key, out_idx, err_flag, redo);
+}
+int stream_quick_wide_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t d, uint32_t K,
+                            const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
+  return stream_quick_wide<GraphDistPolicy>(ctx, "knn_stream_scan", rows, row_ids, n_rows, rows, n, d, K, pol, out_key, out_idx, err_flag, redo);
 }
 
 int stream_scan_search(as_ctx *ctx, const double *queries, const uint32_t *q_ids, uint32_t nq, const double *items, uint32_t n, uint32_t K,

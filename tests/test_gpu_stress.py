@@ -153,3 +153,58 @@ def test_small_batch_search_quick_pass_is_exact(ctx, index_rows, nq, alpha):
         oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 12, alpha)
         assert np.array_equal(res[1][0][j].astype(np.int64), oi.astype(np.int64)), j
         assert np.array_equal(res[1][1][j], osc), j
+
+
+@pytest.mark.parametrize("d", [256, 768])
+@pytest.mark.parametrize("nq", [1, 3, 6])
+def test_small_batch_search_of_wide_items_quick_pass_is_exact(ctx, d, nq):
+    """Items of 256 .. 1024 values: the quick pass (stream_quick_wide_kernel: sample, guess, list) + the reference's chain for the
+    pairs it leaves must give the staged path's and the oracle's indices and scores (src/core.rs:760-798)."""
+    n = 70_000
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=32, rank=6)
+    X[100] = X[7]
+    X[60_000] = X[7]
+    X[9] = 0.0
+    rng = np.random.default_rng(nq + d)
+    lam = rng.random(n)
+    qi = np.concatenate([[7], rng.integers(0, n, nq)])[:nq]
+    Q = X[qi] * 1.02
+    lq = lam[qi] + 0.01
+    res = {}
+    for quick in (0, 1):
+        ctx.set_option("search_stream_quick", quick)
+        try:
+            asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+            asp.update_lambdas(lam)
+            res[quick] = asp.search_lambda_aware_batch(Q, lq, 12, 0.7)
+            assert ctx.stat("search_stream_scan") == quick
+        finally:
+            ctx.set_option("search_stream_quick", 1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for j in range(nq):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], 12, 0.7)
+        assert np.array_equal(res[1][0][j].astype(np.int64), oi.astype(np.int64)), j
+        assert np.array_equal(res[1][1][j], osc), j
+
+
+def test_wide_item_graph_leftover_rows_take_the_quick_pass(ctx):
+    """Rows wider than 128 that the join and its second pass leave open (here forced: thresholds far too tight, short lists) are
+    finished by the quick pass + exact chains instead of an f32 top-k sweep; the table is the default path's, and sampled rows
+    the oracle's (src/laplacian.rs:211-252)."""
+    n, d = 66_000, 256
+    X, _ = synth.mixture(n, d, seed=31, n_clusters=64, rank=6)
+    X[1000] = X[3]
+    X[200:203] *= 1e-9     # tiny norms: pairs among them fall under the |a||b| <= 1e-12 rule, so these rows are always re-done
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)  # exactly: they reach the stage behind the second pass whatever the thresholds
+    i0, d0 = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_stream_scan_rows") >= 3
+    ctx.set_option("search_stream_quick", 0)      # the same rows through the f32 / f64 top-k stages and the exact scan
+    try:
+        i1, d1 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_stream_scan_rows") <= 0
+    finally:
+        ctx.set_option("search_stream_quick", 1)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    sample_rows = np.sort(np.concatenate([[200, 201, 202, 1000, 3], np.random.default_rng(5).choice(n, size=19, replace=False)]))
+    oi, od = O.knn_cosine_rows(X, O.graph_params(0.5, 16, 16, 2.0, 0.25), sample_rows)
+    assert np.array_equal(i0[sample_rows], oi) and np.array_equal(d0[sample_rows], od)
