@@ -113,8 +113,15 @@ def git_head():
 
 
 def recorded_traffic(kernel_substr, n, d):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (PMC counters cannot be read from inside this
-    process): reported as `traffic_recorded` with its source, never as this run's `traffic`."""
+    """HBM bytes per step from the committed rocprofv3 --pmc passes of this same command (scripts/profile_round.sh; PMC
+    counters cannot be read from inside this process): `traffic`, with the file and commit it comes from beside it.
+    kernel_substr: one name or a tuple of names (a profile group of several kernels: their sum)."""
+    if isinstance(kernel_substr, (tuple, list)):
+        parts = [recorded_traffic(k, n, d) for k in kernel_substr]
+        parts = [p_ for p_ in parts if p_]
+        if not parts:
+            return None
+        return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"]}
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -127,8 +134,9 @@ def recorded_traffic(kernel_substr, n, d):
             continue
         for k in j.get("kernels", []):
             if kernel_substr in k.get("kernel", "") and j.get("n") == n and j.get("dim") == d:
-                best = {"bytes_per_launch": k.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
-                        "commit": j.get("commit")}
+                # (the PMC passes run ONE step, no warm-up: a kernel's total over the pass is its traffic per step)
+                best = {"bytes_per_launch": k.get("hbm_bytes_total"), "launches_per_step": k.get("launches"),
+                        "source": "profiles/" + name, "commit": j.get("commit")}
     return best
 
 
@@ -371,7 +379,7 @@ def main():
         d_pad = (d + 15) // 16 * 16
         kernels = []
 
-        def add(key, kernel, bound, work, peak, unit, what, extra_fields=None):
+        def add(key, kernel, bound, work, peak, unit, what, extra_fields=None, pmc=None):
             ms, launches = prof.get(key, (0.0, 0))
             if not launches or ms <= 0.0:
                 return
@@ -383,7 +391,7 @@ def main():
             if extra_fields:
                 e.update(extra_fields)
             if world == 1:
-                rec = recorded_traffic(kernel.split(" ")[0].split("<")[0], n, d)
+                rec = recorded_traffic(pmc or kernel.split(" ")[0].split("<")[0], n, d)
                 if rec:   # PMC counters cannot be read from inside this process: the committed rocprofv3 --pmc passes of the
                     e["traffic"] = rec["bytes_per_launch"]   # same command (scripts/profile_round.sh), per launch
                     e["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
@@ -405,7 +413,9 @@ def main():
             if pipe == 16:
                 add(names[16], "pair_join_f16_kernel (v_mfma_f32_32x32x16_f16 on one f16 plane of the unit rows; symmetric threshold join "
                                "over the blocks the first pass leaves, listing (row, column, score))",
-                    "mfma", 2.0 * 32 * 32 * d_pad * blocks, MFMA16_PEAK_TFLOPS, "TFLOP/s", "f16 MFMA flops executed (blocks contracted x 32 x 32 x d)")
+                    "mfma", 2.0 * 32 * 32 * d_pad * blocks, MFMA16_PEAK_TFLOPS, "TFLOP/s", "f16 MFMA flops executed (blocks contracted x 32 x 32 x d)",
+                    pmc="pair_join_f16_kernel<%d, 0, true>" % (d_pad // 16) if stats.get("knn_join_prefilter", 0) == 1
+                    else "pair_join_f16_kernel<%d, 0, false>" % (d_pad // 16))
             elif pipe == 48:
                 add(names[48], "pair_join_bf16_kernel (split bf16, two-phase blocks)", "mfma",
                     2.0 * 32 * 32 * d_pad * (blocks + 2.0 * stats["knn_mfma_join_bf16_blocks_full"]), MFMA16_PEAK_TFLOPS, "TFLOP/s",
@@ -423,7 +433,7 @@ def main():
                 add("knn_rerank", "rerank_score_d128_kernel (+ rerank_prune_kernel: lists -> pruned records -> gathered 1 KB rows, sequential "
                                   "f64 chains in the reference's order, ranking, certification)",
                     "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes of the surviving candidates' rows + lists + records + table",
-                    {"scored_candidates_per_row": scored / max(1, rows_here)})
+                    {"scored_candidates_per_row": scored / max(1, rows_here)}, pmc=("rerank_score_d128_kernel", "rerank_prune_kernel"))
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
         flops_alg = 2.0 * rows_here * n * d  # 2 n^2 d over the rows this rank owns
@@ -437,7 +447,8 @@ def main():
         if nnz > 0 and world == 1:
             add("graph_assembly", "graph assembly (degree_kernel, adjacency_kernel, fill_reverse_kernel, union_count_kernel, write_rows_kernel)",
                 "hbm", rows_here * 17 * 16.0 + nnz * 16.0 + (rows_here + 1) * 8.0, HBM_PEAK_GBS, "GB/s",
-                "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out")
+                "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out",
+                pmc=("degree_kernel", "adjacency_kernel", "fill_reverse_kernel", "union_count_kernel", "write_rows_kernel", "write_rows_big_kernel"))
         roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
         reference_equivalent = None
         if stats["knn_join"] == 1:
