@@ -3,6 +3,7 @@
 #include <cmath>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 
@@ -301,7 +302,18 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   if (n == "knn_mfma") ctx->opt_knn_mfma = value;
   else if (n == "search_mfma") ctx->opt_search_mfma = value;
   else if (n == "cand_slack") ctx->opt_cand_slack = std::max<int64_t>(0, value);
-  else if (n == "debug") ctx->opt_debug = value;
+  else if (n == "debug") {
+    // Diagnostics.  Bits 1 .. 128 (except 8 = cycle stamps, 16 / 32 / 64 = variants that keep the results) and 0xC000 are ABLATIONS
+    // for timing experiments: they switch parts of kernels off and leave the outputs UNDEFINED.  They are honoured only in a
+    // process that asked for them (ARROWSPACE_ALLOW_ABLATION=1: scripts/explore_*.py); anywhere else they are masked off, so no
+    // product call can come back with an undefined table because of a stray option.
+    static const bool allow = [] {
+      const char *e = std::getenv("ARROWSPACE_ALLOW_ABLATION");
+      return e && e[0] == '1';
+    }();
+    const int64_t ablation = 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64);
+    ctx->opt_debug = allow ? value : (value & ~ablation);
+  }
   else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;
   else if (n == "lambda_v3") ctx->opt_lambda_v3 = value;
   else if (n == "knn_join") ctx->opt_knn_join = value;
@@ -325,6 +337,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
   else if (n == "search_stream_filter") ctx->opt_search_stream_filter = value;
   else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
+  else if (n == "order_mfma") ctx->opt_order_mfma = value;
   else if (n == "cluster_on_device") ctx->opt_cluster_on_device = value;
   else if (n == "search_stream_quick") ctx->opt_search_stream_quick = value;
   else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;

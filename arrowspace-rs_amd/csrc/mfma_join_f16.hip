@@ -49,9 +49,11 @@ constexpr float kProductScale = 16384.f;   // ... so products (and thresholds in
 //   P[((T * KS + ks) * 4 + s) * 64 + l][j] = f16( 128 * unit(R)[128 T + 32 s + (l & 31)][16 ks + 8 (l >> 5) + j] )
 // = the A / B operand of v_mfma_f32_32x32x16_f16 as it stands.  Rows beyond n, columns beyond d and non-finite
 // quotients are 0 (a row with a non-finite norm is re-done exactly whatever its products say: flag_tiny_norm_rows_kernel).
+// err_part (optional, rows x 2 KS doubles): the squared error of the thread's 8 stored values, || stored / 128 - unit ||^2 over its
+// piece of the row, for f16_error_reduce_kernel: the plane error comes out of the packing pass instead of a second read of the rows.
 __global__ void pack_f16_kernel(const double *__restrict__ R, const double *__restrict__ norms,
                                 const uint32_t *__restrict__ row_ids, uint64_t row0, uint64_t n, uint32_t d, uint32_t KS,
-                                uint64_t total_frag_lanes, f16x8 *__restrict__ P) {
+                                uint64_t total_frag_lanes, f16x8 *__restrict__ P, double *__restrict__ err_part = nullptr) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total_frag_lanes) return;
   const uint32_t l = g & 63;
@@ -64,6 +66,7 @@ __global__ void pack_f16_kernel(const double *__restrict__ R, const double *__re
   f16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+  double e2 = 0.0;
   if (row < n && !(row_ids && row_ids[row] == 0xFFFFFFFFu)) {  // (an id of ~0: an empty slot, a zero row)
     const uint64_t src = row_ids ? row_ids[row] : row0 + row;
     const double nr = norms[src];
@@ -71,12 +74,115 @@ __global__ void pack_f16_kernel(const double *__restrict__ R, const double *__re
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (k0 + j < d) {
-          const float x = (float)(R[src * d + k0 + j] / nr) * kOperandScale;
+          const double u = R[src * d + k0 + j] / nr;
+          const float x = (float)u * kOperandScale;
           v[j] = (x == x && __builtin_fabsf(x) <= 2.f * kOperandScale) ? (_Float16)x : (_Float16)0.0f;
+          if (err_part && nr < __builtin_inf()) {  // (the measure f16_row_error_kernel takes: rows with a finite positive norm)
+            const double e = (double)(float)v[j] * (1.0 / kOperandScale) - u;
+            e2 += e * e;
+          }
         }
     }
   }
   P[g] = v;
+  if (err_part && row < n) err_part[row * (2ull * KS) + 2ull * ks + (l >> 5)] = e2;
+}
+// ---- rows of exactly 128 values: image and plane error in ONE coalesced pass over the rows (round 3) ---------------------------
+// The per-fragment-lane packer above reads a row in sixteen 64-byte pieces from sixteen different waves and ran at 0.6 TB/s
+// (1.66 ms per GB), the error kernel read the rows again (1.09 ms).  Here a workgroup owns a 128-row tile of the image: each of
+// its four waves reads 32 rows, a row per instruction (lane l takes values 2 l, 2 l + 1: 1 KB contiguous), divides by the norm,
+// rounds to f16, writes the two halves to their place in an LDS copy of the tile's fragment layout and keeps the squared error
+// of its two values; a halving butterfly adds those over the 64 lanes per row (a fixed order), and the 32 KB tile goes out
+// with 16-byte stores.  Same values as pack_f16_kernel stores, same error measure as f16_row_error_kernel.
+__global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__restrict__ R, const double *__restrict__ norms,
+                                                               const uint32_t *__restrict__ row_ids, uint64_t n, f16x8 *__restrict__ P,
+                                                               unsigned int *__restrict__ err_bits) {
+  constexpr int KS = 8;
+  __shared__ f16x8 s_tile[KS * 4 * 64];  // 32 KB: [ks][s][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t T = blockIdx.x;
+  typedef double pk_d2 __attribute__((ext_vector_type(2)));
+  // lane l holds values k = 2 l, 2 l + 1 of a row: k step l / 8, half (l % 8) / 4, elements 2 (l % 4) and + 1 of that vector
+  const int ks = lane >> 3, half = (lane >> 2) & 1, j2 = (lane & 3);
+  float worst = 0.f;
+  constexpr int kBatch = 8;
+  for (int r0 = 0; r0 < 32; r0 += kBatch) {
+    pk_d2 x[kBatch];
+    double nr[kBatch];
+    bool live[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const uint64_t pos = T * kTileRows + (uint64_t)wv * 32 + (uint64_t)(r0 + b);
+      live[b] = pos < n && !(row_ids && row_ids[pos] == 0xFFFFFFFFu);
+      const uint64_t src = live[b] ? (row_ids ? (uint64_t)row_ids[pos] : pos) : 0;
+      nr[b] = live[b] ? norms[src] : 0.0;
+      x[b] = reinterpret_cast<const pk_d2 *>(R + src * 128)[lane];
+    }
+    double e2[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      _Float16 h0 = (_Float16)0.0f, h1 = (_Float16)0.0f;
+      e2[b] = 0.0;
+      if (live[b] && nr[b] > 0.0) {
+        const double u0 = x[b].x / nr[b], u1 = x[b].y / nr[b];
+        const float f0 = (float)u0 * kOperandScale, f1 = (float)u1 * kOperandScale;
+        h0 = (f0 == f0 && __builtin_fabsf(f0) <= 2.f * kOperandScale) ? (_Float16)f0 : (_Float16)0.0f;
+        h1 = (f1 == f1 && __builtin_fabsf(f1) <= 2.f * kOperandScale) ? (_Float16)f1 : (_Float16)0.0f;
+        if (nr[b] < __builtin_inf()) {
+          const double d0 = (double)(float)h0 * (1.0 / kOperandScale) - u0, d1 = (double)(float)h1 * (1.0 / kOperandScale) - u1;
+          e2[b] = d0 * d0 + d1 * d1;
+        }
+      }
+      const int rr = r0 + b;  // row of the wave's 32: sub-tile s = wv, lane' = rr + 32 half
+      _Float16 *dst = reinterpret_cast<_Float16 *>(&s_tile[(ks * 4 + wv) * 64 + rr + 32 * half]) + 2 * j2;
+      dst[0] = h0;
+      dst[1] = h1;
+    }
+    // per-row sums over the 64 lanes: 8 values per lane -> halving butterfly (lane bits 5, 4, 3), then full adds (bits 2, 1, 0)
+    {
+      const bool up5 = (lane >> 5) & 1, up4 = (lane >> 4) & 1, up3 = (lane >> 3) & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double keep = up5 ? e2[i + 4] : e2[i], send = up5 ? e2[i] : e2[i + 4];
+        e2[i] = keep + __shfl_xor(send, 32, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double keep = up4 ? e2[i + 2] : e2[i], send = up4 ? e2[i] : e2[i + 2];
+        e2[i] = keep + __shfl_xor(send, 16, 64);
+      }
+      {
+        const double keep = up3 ? e2[1] : e2[0], send = up3 ? e2[0] : e2[1];
+        e2[0] = keep + __shfl_xor(send, 8, 64);
+      }
+      double t = e2[0];
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 1, 64);
+      const float e = (float)(__builtin_sqrt(t) * (1.0 + 1e-6));  // rounded up
+      if (e == e) worst = __builtin_fmaxf(worst, e);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) worst = __builtin_fmaxf(worst, __shfl_xor(worst, o, 64));
+  if (lane == 0) atomicMax(err_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+  __syncthreads();
+  f16x8 *out = P + T * (uint64_t)(KS * 4 * 64);
+#pragma unroll
+  for (int q = 0; q < KS * 4 * 64 / 256; ++q) out[q * 256 + tid] = s_tile[q * 256 + tid];
+}
+
+// E = max over the rows of sqrt(sum of the 2 KS partial sums, in index order) (1 + 1e-6): see f16_row_error_kernel
+__global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uint64_t n, uint32_t slots, unsigned int *__restrict__ out_bits) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float e = 0.f;
+  if (row < n) {
+    double e2 = 0.0;
+    for (uint32_t s_ = 0; s_ < slots; ++s_) e2 += err_part[row * slots + s_];
+    const float ev = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6));  // rounded up
+    if (ev == ev) e = ev;
+  }
+  for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(e));  // non-negative floats order like their bits
 }
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
@@ -670,12 +776,30 @@ __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__rest
 // (perm: image position -> row, or nullptr)
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
                  const uint32_t *perm) {
-  AS_TRY(pack_f16(ctx, R, norms, perm, 0, n, d, P, tiles));
   DevBuf<unsigned int> bits;
   AS_TRY(bits.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
-  hipLaunchKernelGGL(f16_row_error_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n, 4), 256 * 32)), dim3(256), 0, ctx->stream, R, norms,
-                     n, d, bits.p);
+  const uint32_t KS = f16_ksteps(d);
+  if (d == 128 && ((uintptr_t)R & 15) == 0) {
+    ProfScope ps(ctx, "pack_unit_rows");
+    hipLaunchKernelGGL(pack_f16_tile128_kernel, dim3(tiles), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p);
+  } else if (KS <= 8) {
+    // up to 128 columns: the plane error comes out of the packing pass (16 partial sums per row, 128 B against the 1 KB of a
+    // second read of the row: pack 1.66 + error 1.09 ms at 1 M x 128 before)
+    DevBuf<double> part;
+    AS_TRY(part.alloc(ctx, (size_t)n * 2 * KS));
+    const uint64_t total = packed_vecs_f16(tiles, d);
+    {
+      ProfScope ps(ctx, "pack_unit_rows");
+      hipLaunchKernelGGL(pack_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, perm, (uint64_t)0, n, d, KS, total,
+                         (f16x8 *)P, part.p);
+      hipLaunchKernelGGL(f16_error_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)part.p, n, 2 * KS, bits.p);
+    }
+  } else {
+    AS_TRY(pack_f16(ctx, R, norms, perm, 0, n, d, P, tiles));
+    hipLaunchKernelGGL(f16_row_error_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n, 4), 256 * 32)), dim3(256), 0, ctx->stream, R, norms,
+                       n, d, bits.p);
+  }
   AS_HIP(ctx, hipGetLastError());
   unsigned int h = 0;
   AS_HIP(ctx, copy_d2h(ctx, &h, bits.p, sizeof(h)));

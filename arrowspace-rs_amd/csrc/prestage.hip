@@ -234,14 +234,31 @@ struct HostRows {
   }
 };
 
+__global__ void gather_rows_kernel(const double *__restrict__ rows, const uint64_t *__restrict__ ids, uint64_t count, uint64_t f,
+                                   double *__restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count * f) out[t] = rows[ids[t / f] * f + t % f];
+}
+// the listed rows of a host- or device-resident matrix as one host block (device rows: one gather kernel and ONE copy back;
+// it used to be a copy per row: 1 000 round trips for the sample of compute_optimal_k)
 int gather_rows_host(as_ctx *ctx, const double *rows, bool on_device, const std::vector<uint64_t> &ids, uint64_t f,
                      std::vector<double> &out) {
   out.resize(ids.size() * f);
-  for (size_t s = 0; s < ids.size(); ++s) {
-    if (on_device) AS_HIP(ctx, copy_d2h(ctx, out.data() + s * f, rows + ids[s] * f, sizeof(double) * f));
-    else std::memcpy(out.data() + s * f, rows + ids[s] * f, sizeof(double) * f);
+  if (ids.empty()) return AS_OK;
+  if (!on_device) {
+    for (size_t s = 0; s < ids.size(); ++s) std::memcpy(out.data() + s * f, rows + ids[s] * f, sizeof(double) * f);
+    return AS_OK;
   }
-  if (on_device) AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  DevBuf<uint64_t> idd;
+  DevBuf<double> g;
+  AS_TRY(idd.alloc(ctx, ids.size()));
+  AS_TRY(g.alloc(ctx, ids.size() * f));
+  AS_HIP(ctx, copy_h2d(ctx, idd.p, ids.data(), sizeof(uint64_t) * ids.size()));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(ids.size() * f, 256)), dim3(256), 0, ctx->stream, rows, (const uint64_t *)idd.p,
+                     (uint64_t)ids.size(), f, g.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, copy_d2h(ctx, out.data(), g.p, sizeof(double) * ids.size() * f));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 

@@ -140,12 +140,24 @@ __global__ __launch_bounds__(256) void yacc_kernel(const double *__restrict__ R,
       if (k < d) Y[((size_t)blockIdx.x * kDirs + a) * pitch + k] = acc[a][c];
     }
 }
-__global__ void yreduce_kernel(const float *__restrict__ part, uint32_t blocks, uint32_t elems, float *__restrict__ Y) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+// (a fixed TREE: 16 threads per element add 1/16 of the blocks each, in block order, and one of them adds the 16 sums in
+// order -- the same sum in every run, 48 dependent additions instead of 512)
+__global__ __launch_bounds__(256) void yreduce_kernel(const float *__restrict__ part, uint32_t blocks, uint32_t elems, float *__restrict__ Y) {
+  __shared__ float s_p[16][17];
+  const uint32_t el = threadIdx.x & 15u, j = threadIdx.x >> 4;  // 16 elements x 16 slices per workgroup
+  const uint32_t e = blockIdx.x * 16u + el;
+  const uint32_t per = (blocks + 15u) / 16u;
   float s = 0.f;
-  for (uint32_t b = 0; b < blocks; ++b) s += part[(size_t)b * elems + e];
-  Y[e] = s;
+  if (e < elems)
+    for (uint32_t b = j * per; b < min(blocks, (j + 1) * per); ++b) s += part[(size_t)b * elems + e];
+  s_p[el][j] = s;
+  __syncthreads();
+  if (j == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_p[el][q];
+    Y[e] = t;
+  }
 }
 
 __global__ void znorm_kernel(const double *__restrict__ Z, uint32_t n, double *__restrict__ out) {
@@ -265,7 +277,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
                         pitch, Zs.p, (double *)nullptr));
     hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, rows, norms, stride, ns, d,
                        (const double *)Zs.p, pitch, Ypart.p);
-    hipLaunchKernelGGL(yreduce_kernel, dim3(cdiv((uint32_t)kDirs * pitch, 256)), dim3(256), 0, ctx->stream, (const float *)Ypart.p, y_blocks,
+    hipLaunchKernelGGL(yreduce_kernel, dim3(cdiv((uint32_t)kDirs * pitch, 16)), dim3(256), 0, ctx->stream, (const float *)Ypart.p, y_blocks,
                        (uint32_t)kDirs * pitch, Yd.p);
     AS_HIP(ctx, hipGetLastError());
     AS_HIP(ctx, copy_d2h(ctx, Yh.data(), Yd.p, Yh.size() * sizeof(float)));

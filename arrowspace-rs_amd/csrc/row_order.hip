@@ -67,6 +67,84 @@ __global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__rest
   if (row < n) assign[row] = arg;
 }
 
+// The same argmax for the 32 rotated coordinates on the matrix pipe (round 3): a 1 M x 32 . 32 x 1024 product is 6.6e10 flop, 1.5 ms
+// of f32 vector work above, and a rounding of the operands to f16 moves an assignment only between pivots whose products lie
+// within 1e-3 of each other -- any assignment gives a correct image order, and this one is as deterministic as the other.
+// A wave owns 32 rows (A fragments: 2 x 8 halves per lane, straight from the f64 coordinates), the np pivots sit in LDS as f16
+// B fragments, two v_mfma_f32_32x32x16_f16 per 32 pivots; every lane keeps the best (value, pivot) of its 16 rows over the
+// pivots of its column, in pivot order with a strict '>', and the 32 columns meet at the end (lower pivot on equal values).
+typedef float ro_v16f32 __attribute__((ext_vector_type(16)));
+typedef _Float16 ro_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *__restrict__ Z, uint32_t n, const float *__restrict__ piv,
+                                                                 uint32_t np, uint32_t *__restrict__ assign) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
+  ro_f16x8 *s_b = reinterpret_cast<ro_f16x8 *>(ro_smem);  // [np / 32 tiles][2 k steps][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, lc = lane & 31, lh = lane >> 5;
+  for (uint32_t e = tid; e < (np / 32) * 2 * 64; e += 256) {
+    const uint32_t l = e & 63, ks = (e >> 6) & 1, t = e >> 7;
+    const float *src = piv + (size_t)(t * 32 + (l & 31)) * 32 + 16 * ks + 8 * (l >> 5);
+    ro_f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)src[j];
+    s_b[e] = v;
+  }
+  __syncthreads();
+  const uint32_t row0 = (blockIdx.x * 4 + (tid >> 6)) * 32;
+  if (row0 >= n) return;
+  ro_f16x8 a[2];
+  {
+    const uint32_t row = min(row0 + (uint32_t)lc, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const double *src = Z + (size_t)row * 32 + 16 * ks + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = (float)src[j];
+        a[ks][j] = (_Float16)(x == x ? x : 0.f);
+      }
+    }
+  }
+  float best[16];
+  uint32_t arg[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    best[r] = -__builtin_inff();
+    arg[r] = 0;
+  }
+  ro_v16f32 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  for (uint32_t t = 0; t < np / 32; ++t) {
+    const ro_f16x8 b0 = s_b[(t * 2 + 0) * 64 + lane], b1 = s_b[(t * 2 + 1) * 64 + lane];
+    ro_v16f32 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b0, zero, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b1, x, 0, 0, 0);
+    const uint32_t p = t * 32 + (uint32_t)lc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (x[r] > best[r]) {
+        best[r] = x[r];
+        arg[r] = p;
+      }
+  }
+  // accumulator register r of lane (lh, lc) = row 4 lh + (r & 3) + 8 (r >> 2) of the tile, column lc: the columns meet here
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float bv = best[r];
+    uint32_t ba = arg[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const uint32_t oa = __shfl_xor(ba, o, 64);
+      if (ov > bv || (ov == bv && oa < ba)) {
+        bv = ov;
+        ba = oa;
+      }
+    }
+    const uint32_t row = row0 + 4 * lh + (r & 3) + 8 * (r >> 2);
+    if (lc == 0 && row < n) assign[row] = ba;
+  }
+}
+
 // stable counting sort by pivot, blocks of 256 rows: counts[c * n_blocks + b] -> (exclusive scan) -> positions
 __global__ __launch_bounds__(256) void order_count_kernel(const uint32_t *__restrict__ assign, uint32_t n, uint32_t n_blocks,
                                                           uint32_t *__restrict__ counts, int np) {
@@ -127,6 +205,10 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   AS_TRY(offsets.alloc(ctx, (size_t)np * n_blocks + 1));
 #define AS_ASSIGN(DPV)                                                                                                         \
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
+  const size_t lds_mfma = (size_t)(np / 32) * 2 * 64 * 16;
+  if (d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024 && ctx->opt_order_mfma) {  // the rotated coordinates: on the matrix pipe
+    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(cdiv(n, 128)), dim3(256), lds_mfma, ctx->stream, rows, n, piv, np, assign.p);
+  } else
   switch (dpv / 32) {
     case 1: AS_ASSIGN(32); break;
     case 2: AS_ASSIGN(64); break;
