@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -460,7 +461,8 @@ struct OwnJoin {
   const uint32_t *perm = nullptr;       // perm_own.p or nullptr
   const float *theta_image = nullptr;   // thresholds in the order of the image: theta_pos.p or theta_own.p
 };
-int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj);
+int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
+                     uint32_t pos_begin = 0, uint32_t pos_count = 0, const std::function<int(void *, size_t)> *gather = nullptr);
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
                    OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos);
 

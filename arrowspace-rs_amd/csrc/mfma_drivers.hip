@@ -776,7 +776,8 @@ int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, con
                          uint32_t *cnt, uint32_t *cand, const char *prof_name);
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out);
+                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin = 0,
+                                uint32_t pos_count = 0);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out);
@@ -1037,7 +1038,16 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
 // plain sample).  All of it is a function of the rows and the options alone and every sum on the way has a fixed order, so
 // every rank of a sharded build that holds all rows computes the SAME order, image and thresholds (csrc/sharded.hip calls
 // this on every rank and then contracts only the tile pairs of its own range of image positions).
-int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj) {
+// pos_begin / pos_count / gather (a sharded build): the thresholds -- the one step of the preparation that is a sweep of MFMAs
+// per row rather than a pass over the row -- are computed for that range of image positions (rows, when there is no order)
+// only, and gather(buffer of n elements, element bytes) completes the buffer on every rank (in place: the caller's own part
+// is where it belongs).  Everything else stays replicated.
+int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
+                     uint32_t pos_begin, uint32_t pos_count, const std::function<int(void *, size_t)> *gather) {
+  if (!gather) {
+    pos_begin = 0;
+    pos_count = n;
+  }
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   ctx->f16_err = -1.0;
@@ -1090,7 +1100,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
     AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
-                                       oj.theta_pos.p, m2, oj.theta2_pos.p));
+                                       oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count));
+    if (gather) {
+      AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
+      AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
+    }
     if (ctx->opt_debug & 65536) {  // diagnostic: a checksum of the thresholds (are they the same from run to run?)
       DevBuf<unsigned long long> cs;
       AS_TRY(cs.alloc(ctx, 1));
@@ -1132,13 +1146,28 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       oj.have_theta2 = true;
       oj.grouped_theta = true;
     } else {
-      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, oj.theta_pos.p, nullptr, oj.theta2_pos.p, &oj.have_theta2, oj.Phown.p));
+      if (pos_count)
+        AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_pos.p + pos_begin, nullptr, oj.theta2_pos.p + pos_begin,
+                                   &oj.have_theta2, oj.Phown.p));
+      else oj.have_theta2 = true;  // (a rank without positions: what the ranks with positions find, the 16-bit pass always has them)
+      if (gather) {
+        AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
+        AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
+      }
     }
     ctx->stats["knn_join_theta_grouped"] = oj.grouped_theta ? 1 : 0;
   } else {
     ctx->stats["knn_join_theta_grouped"] = 0;
-    AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, 0, n, reorder ? oj.theta_pos.p : oj.theta_own.p, nullptr,
-                               reorder ? oj.theta2_pos.p : oj.theta2_own.p, &oj.have_theta2, oj.Phown.p));
+    float *t1 = reorder ? oj.theta_pos.p : oj.theta_own.p, *t2 = reorder ? oj.theta2_pos.p : oj.theta2_own.p;
+    if (pos_count)
+      AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, t1 + pos_begin, nullptr, t2 + pos_begin, &oj.have_theta2, oj.Phown.p));
+    if (gather) {
+      // (whether the pass produced second thresholds depends on the options and the width alone: every rank agrees; a rank
+      // without positions takes the answer of the 16-bit passes, which always have them)
+      if (!pos_count) oj.have_theta2 = ctx->opt_join_bf16 != 0;
+      AS_TRY((*gather)(t1, sizeof(float)));
+      if (oj.have_theta2) AS_TRY((*gather)(t2, sizeof(float)));
+    }
   }
   if (reorder) {  // ... and go back to row order for everything behind the join
     AS_TRY(scatter_by_perm(ctx, oj.theta_pos.p, oj.perm_own.p, n, oj.theta_own.p));

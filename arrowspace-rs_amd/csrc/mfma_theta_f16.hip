@@ -374,13 +374,20 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
 // The same for ALL rows of an image ordered by pivot groups (perm: image position -> row; group_start: np + 1 positions; piv:
 // the np pivots, `piv_dim` coordinates of pitch `piv_pitch`): thresholds by image position against the sampled rows of the 16
 // groups nearest to a row's own.
+// pos_begin / pos_count (a multiple of 256 / any; 0 / 0 = all): only the thresholds of that range of image positions are computed
+// (theta_out / theta2_out stay indexed by position of the WHOLE image) -- a rank of a build sharded by positions computes its own.
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out) {
+                                uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin,
+                                uint32_t pos_count) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
   const uint32_t a_supers = (n + 255) / 256;
+  if (pos_count == 0 && pos_begin == 0) pos_count = n;
+  if (pos_count == 0) return AS_OK;  // (a rank without positions)
+  if (pos_begin % 256 != 0 || (uint64_t)pos_begin + pos_count > n) return fail(ctx, AS_ERR_ARG, "threshold pass: bad position range");
+  const uint32_t u_begin = pos_begin / 256, u_count = (pos_count + 255) / 256;
   DevBuf<unsigned char> PS;
   DevBuf<uint32_t> unitc, near, ids, ug;
   AS_TRY(PS.alloc(ctx, packed_vecs_f16(np * kGroupTiles, d) * 16));
@@ -397,12 +404,15 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
   const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
-  const unsigned grid = std::min<uint32_t>(a_supers, 512u);
+  const unsigned grid = std::min<uint32_t>(u_count, 512u);
+  const f16x8 *PA_r = (const f16x8 *)P_all + (size_t)(pos_begin / kTileRows) * KS * 4 * 64;
+  float *t1_r = theta_out + pos_begin, *t2_r = theta2_out ? theta2_out + pos_begin : nullptr;
+  const uint32_t *ug_r = ug.p + 2 * (size_t)u_begin;
 #define AS_THETA(K)                                                                                                          \
   case K:                                                                                                                    \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P_all, a_supers, n,    \
-                       (const f16x8 *)PS.p, kGroupTiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)ug.p);     \
+    hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA_r, u_count, pos_count,             \
+                       (const f16x8 *)PS.p, kGroupTiles, m, t1_r, m2, t2_r, unitc.p, ug_r);                                  \
     break;
   switch (KS) {
     AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)

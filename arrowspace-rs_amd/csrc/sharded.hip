@@ -77,6 +77,10 @@ int rccl_all_to_all_v(void *user, const void *send, const uint64_t *send_bytes, 
   if (r.GroupStart() != ncclSuccess) return AS_ERR_HIP;
   bool ok = true;
   for (int p = 0; p < c->world && ok; ++p) {
+    // (an in-place exchange: this rank's own part already sits where it belongs)
+    if (p == c->rank && send_bytes[p] == recv_bytes[p] &&
+        static_cast<const char *>(send) + send_offsets[p] == static_cast<const char *>(recv) + recv_offsets[p])
+      continue;
     if (send_bytes[p])
       ok = r.Send(static_cast<const char *>(send) + send_offsets[p], send_bytes[p], ncclInt8, p, c->nccl, (hipStream_t)stream) == ncclSuccess;
     if (ok && recv_bytes[p])
@@ -407,7 +411,12 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
     AS_TRY(norms.alloc(ctx, (size_t)n));
     AS_TRY(row_norms(ctx, X.p, n, dim, norms.p));
     OwnJoin oj;
-    AS_TRY(own_join_prepare(ctx, X.p, norms.p, n32, d32, K32, oj));
+    // (the thresholds, the one MFMA sweep of the preparation, are computed per rank for its own positions and all-gathered in
+    // place: 8 bytes per position)
+    const std::function<int(void *, size_t)> gather_positions = [&](void *all, size_t elem_bytes) -> int {
+      return gather_rows(ctx, comm, (const char *)all + lo * elem_bytes, all, n, elem_bytes);
+    };
+    AS_TRY(own_join_prepare(ctx, X.p, norms.p, n32, d32, K32, oj, lo32, here32, &gather_positions));
     if (oj.reorder) {
       AS_TRY(oj.inv_own.alloc(ctx, (size_t)n));
       hipLaunchKernelGGL(invert_perm_u32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n32, oj.inv_own.p);
