@@ -30,17 +30,33 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_sums(const uint32_t *__
   }
 }
 
-__global__ void scan_of_sums(uint64_t *bsum, uint64_t nb, uint64_t *total_out) {
-  // single thread; nb <= a few thousand
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    uint64_t run = 0;
-    for (uint64_t b = 0; b < nb; ++b) {
-      uint64_t t = bsum[b];
-      bsum[b] = run;
-      run += t;
+// exclusive scan of the block sums in place, one workgroup of 1024: chunks of 1024 sums, a wave-level inclusive scan and the
+// waves' totals through LDS, the running total carried from chunk to chunk.  (It was one thread walking the sums: a dependent
+// global load per block, 0.1 ms per thousand blocks, six scans per build.)
+__global__ __launch_bounds__(1024) void scan_of_sums(uint64_t *bsum, uint64_t nb, uint64_t *total_out) {
+  __shared__ uint64_t wsum[16];
+  __shared__ uint64_t s_run;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < nb; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const uint64_t v = i < nb ? bsum[i] : 0;
+    uint64_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
     }
-    *total_out = run;
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint64_t before = s_run;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (i < nb) bsum[i] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_run = before + inc;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *total_out = s_run;
 }
 
 __global__ __launch_bounds__(kScanBlock) void scan_finish(const uint32_t *__restrict__ in, uint64_t n,
@@ -71,7 +87,7 @@ int exclusive_scan_u32_u64(as_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t
     return AS_OK;
   }
   hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, bsum.p);
-  hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(64), 0, ctx->stream, bsum.p, nb, out + n);
+  hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(1024), 0, ctx->stream, bsum.p, nb, out + n);
   hipLaunchKernelGGL(scan_finish, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, bsum.p, out);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;

@@ -1132,6 +1132,61 @@ def test_build_without_centroids_runs_the_prestage(ctx):
     assert 2 <= asp2.n_clusters <= k and gl2.matrix.shape() == (24, 24)
 
 
+def _moons_hd(n, noise_xy, noise_hd, dims, seed):
+    """The shape of the reference's make_moons_hd fixture (src/tests/test_data.rs:6256-6303): two half circles in the
+    first two coordinates, uniform [0, noise) jitter everywhere.  numpy's generator, not the reference's Pcg64: the
+    acceptance below is statistical."""
+    rng = np.random.default_rng(seed)
+    n0 = n // 2
+    out = np.zeros((n, dims))
+    t = rng.random(n) * np.pi
+    out[:n0, 0], out[:n0, 1] = np.cos(t[:n0]), np.sin(t[:n0])
+    out[n0:, 0], out[n0:, 1] = 1.0 - np.cos(t[n0:]), -np.sin(t[n0:]) - 0.5
+    out[:, :2] += noise_xy * rng.random((n, 2))
+    out[:, 2:] = noise_hd * rng.random((n, dims - 2))
+    return out
+
+
+@pytest.mark.parametrize("n,dims,data_seed", [(80, 11, 789), (2000, 24, 17)])
+def test_prestage_statistical_acceptance_of_the_reference(ctx, n, dims, data_seed):
+    """src/tests/test_taumode.rs:328-428 (test_builder_lambdas_consistency_properties): the reference does not pin the
+    clustering's draws, it accepts a build whose lambdas are all finite and in [0, 1], vary, and whose mean stays within
+    2x between two builds.  Here the two builds are two clustering seeds plus the default batched schedule, on the
+    reference's fixture shape and parameters (with_lambda_graph(0.3, 5, 2, 2.0, None), Median); the oracle's pre-stage
+    is held to the same acceptance, and the cluster counts of library and oracle agree seed for seed."""
+    X = _moons_hd(n, 0.15, 0.4, dims, data_seed)
+
+    def stats(l):
+        return l.mean(), l.var(), l.min(), l.max()
+
+    builds = []
+    for seed in (128, 977, None):
+        b = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.3, 5, 2, 2.0, None).with_normalisation(False) \
+            .with_spectral(False).with_synthesis(A.TauMode.Median)
+        if seed is not None:
+            b = b.with_seed(seed)
+        asp, gl = b.build(X)
+        lam = np.asarray(asp.lambdas())
+        assert 0 < asp.n_clusters <= n and len(lam) == n          # one lambda per item, clusters <= items
+        assert gl.matrix.shape() == (dims, dims)
+        assert np.all(np.isfinite(lam)) and np.all((lam >= 0.0) & (lam <= 1.0))
+        mean, var, lo, hi = stats(lam)
+        assert hi > lo and var > 0.0
+        if seed is not None:                                      # the oracle's pre-stage at the same seed: same clusters
+            k, radius, _ = O.compute_optimal_k(X, seed)
+            oc, oa, osz = O.incremental_clustering(X, k, radius, 1)
+            assert asp.n_clusters == len(oc) and np.array_equal(asp.cluster_sizes, osz)
+            ocsr = O.build_laplacian(np.ascontiguousarray(oc.T), O.graph_params(0.3, 5, O.define_result_k(5, 2), 2.0, None))
+            olam = O.taumode_lambdas(X, ocsr, O.TAU_MEDIAN)
+            assert np.all(np.isfinite(olam)) and np.all((olam >= 0.0) & (olam <= 1.0)) and olam.var() > 0.0
+            np.testing.assert_allclose(lam, olam, rtol=LAMBDA_RTOL, atol=1e-300)
+        builds.append((asp.n_clusters, mean))
+    means = [m for _, m in builds]
+    assert max(means) / min(means) < 2.0, builds                  # the reference's tolerance between builds
+    counts = [c for c, _ in builds]
+    assert max(counts) <= 2 * min(counts) + 2, builds             # cluster counts in one range across seeds / schedules
+
+
 def test_jl_projection_matches_oracle(ctx):
     """ImplicitProjection (src/reduction.rs:166-203): the Gaussian matrix is the build's own seeded draw (moments
     checked), the projection arithmetic the reference's: equal to the oracle's on the same matrix, bit for bit, for
