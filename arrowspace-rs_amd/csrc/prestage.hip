@@ -217,6 +217,234 @@ __global__ __launch_bounds__(256) void cluster_apply_kernel(const double *__rest
   if (threadIdx.x == 0) counts[c] = cnt;
 }
 
+// ---- a batch in which centroids can still appear: sequential in its rows, parallel in the centroids ------------------------
+// (src/clustering.rs:596-905 for one batch.)  A row has to be measured against the centroids created earlier in its own batch
+// at their CURRENT values, and its own decision (new centroid / running-mean update) changes what the next row sees, so the rows
+// of such a batch form a chain.  One workgroup walks it: thread t owns the live centroids live_from + t, + 512, ... and runs
+// the reference's sum over the features for each (d2 += (a - b) * (a - b), two roundings, features ascending) from a
+// TRANSPOSED copy of the live centroids (lanes read neighbouring words); the minimum with the smallest index among equal
+// minima meets the snapshot's (idx, d2) of the row (strict '<': the snapshot wins ties, as in the host loop that starts from
+// it), every thread takes the same decision, and the threads of the first f lanes apply it to both copies.  live_from = the
+// snapshot's centroid count (batched mode) or 0 with no snapshot at all (batch = 1: the reference's sequential mode, where a
+// row sees every centroid as it stands).
+// What a row costs is latency, so: the centroid words come from L2 through a ring of four chunks of 16 (64 loads in flight
+// per lane before the first is needed); the NEXT row and its snapshot entry are fetched by the workgroup's upper half only
+// (memory operations retire in order per wave: a row fetch from HBM issued by a wave that also measures centroids would sit in
+// front of every wait of its chain), at the start of the row, and reach LDS before the row's last barrier.
+constexpr int kSeqThreads = 512, kSeqWaves = kSeqThreads / 64, kSeqChunk = 16, kSeqRing = 4, kSeqLoaders = 256;
+constexpr uint64_t kSeqMaxF = 1024;
+__global__ __launch_bounds__(kSeqThreads) void cluster_seq_kernel(const double *__restrict__ rows, uint64_t bn, uint32_t f,
+                                                                  const uint64_t *__restrict__ snap_idx,
+                                                                  const double *__restrict__ snap_d2, uint64_t live_from, double radius,
+                                                                  uint64_t max_clusters, double *cents, double *centsT,
+                                                                  unsigned long long *counts, long long *__restrict__ assign,
+                                                                  unsigned long long *nc_io, int stop_at_cap, unsigned long long *stamps) {
+  extern __shared__ double s_row[];  // two rows of f
+  __shared__ double s_wd[kSeqWaves];
+  __shared__ uint64_t s_wc[kSeqWaves];
+  __shared__ double s_sd[2];    // the snapshot's entry of the row, by row parity
+  __shared__ uint64_t s_si[2];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const bool loader = t >= (uint32_t)(kSeqThreads - kSeqLoaders);
+  const uint32_t lt = t - (uint32_t)(kSeqThreads - kSeqLoaders);
+  const uint64_t M = max_clusters;
+  // nc_io[0]: cluster count (in / out); nc_io[1]: rows of the batch consumed (out).  stop_at_cap: the batch ends with the row
+  // that creates the last centroid the cap allows (the rule of oracle/prestage.c: from there on no centroid can appear and the
+  // rows go through the parallel kernels with a snapshot of all of them)
+  uint64_t nc = nc_io[0];
+  const bool may_stop = stop_at_cap && nc < M;
+  uint64_t rows_done = bn;
+  for (uint32_t j = t; j < f; j += kSeqThreads) s_row[j] = rows[j];
+  if (t == 0) {
+    s_sd[0] = snap_d2 ? snap_d2[0] : __builtin_inf();
+    s_si[0] = snap_idx ? snap_idx[0] : 0;
+  }
+  __syncthreads();
+  const uint32_t nch = f / kSeqChunk;
+  for (uint64_t r = 0; r < bn; ++r) {
+    const double *cur = s_row + (r & 1) * f;
+    double *nxt = s_row + ((r + 1) & 1) * f;
+    double pre[kSeqMaxF / kSeqLoaders];
+    double p_bd = __builtin_inf();
+    uint64_t p_bi = 0;
+    const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    if (loader && r + 1 < bn) {
+#pragma unroll
+      for (uint32_t q = 0; q < kSeqMaxF / kSeqLoaders; ++q) {
+        const uint32_t j = lt + q * kSeqLoaders;
+        pre[q] = j < f ? rows[(r + 1) * f + j] : 0.0;
+      }
+      if (lt == 0) {
+        if (snap_d2) p_bd = snap_d2[r + 1];
+        if (snap_idx) p_bi = snap_idx[r + 1];
+      }
+    }
+    double best = __builtin_inf();
+    uint64_t bc = ~0ull;
+    for (uint64_t c = live_from + t; c < nc; c += kSeqThreads) {
+      // (row j of the transposed copy is a uniform base, the centroid a 32-bit lane offset)
+      const uint32_t co = (uint32_t)c;
+#define AS_CT(J) (centsT + (uint64_t)(J) * M)[co]
+      double acc = 0.0;
+      double v[kSeqRing][kSeqChunk];
+      // whole turns of the ring, branch-free (a conditional refill would make the compiler drain the ring at every join)
+      const uint32_t turns = nch / kSeqRing;
+      uint32_t j = 0;
+      if (turns) {
+#pragma unroll
+        for (int b = 0; b < kSeqRing; ++b) {
+#pragma unroll
+          for (int u = 0; u < kSeqChunk; ++u) v[b][u] = AS_CT(b * kSeqChunk + u);
+        }
+        // the row's words of a chunk are read from LDS one chunk ahead of their use (an LDS read takes longer than the three
+        // operations it feeds)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 *cur2 = reinterpret_cast<const d2 *>(cur);
+        d2 xa[kSeqChunk / 2], xb[kSeqChunk / 2];
+#pragma unroll
+        for (int u = 0; u < kSeqChunk / 2; ++u) xa[u] = cur2[u];
+#define AS_CHUNK(XA, XB, B, NEXT)                                                      \
+  {                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < kSeqChunk / 2; ++u) XB[u] = cur2[(NEXT) / 2 + u]; \
+    _Pragma("unroll") for (int u = 0; u < kSeqChunk / 2; ++u) {                        \
+      const double d0 = __dsub_rn(XA[u].x, v[B][2 * u]);                               \
+      acc = __dadd_rn(acc, __dmul_rn(d0, d0));                                         \
+      const double d1 = __dsub_rn(XA[u].y, v[B][2 * u + 1]);                           \
+      acc = __dadd_rn(acc, __dmul_rn(d1, d1));                                         \
+    }                                                                                  \
+  }
+        static_assert(kSeqRing == 4, "the chunks of a turn below");
+        const uint32_t last = turns * kSeqRing * kSeqChunk - kSeqChunk;  // the read-ahead of the last chunk stays inside the row
+        for (uint32_t tn = 0; tn + 1 < turns; ++tn) {
+          AS_CHUNK(xa, xb, 0, j + 1 * kSeqChunk)
+#pragma unroll
+          for (int u = 0; u < kSeqChunk; ++u) v[0][u] = AS_CT(j + (kSeqRing + 0) * kSeqChunk + u);
+          AS_CHUNK(xb, xa, 1, j + 2 * kSeqChunk)
+#pragma unroll
+          for (int u = 0; u < kSeqChunk; ++u) v[1][u] = AS_CT(j + (kSeqRing + 1) * kSeqChunk + u);
+          AS_CHUNK(xa, xb, 2, j + 3 * kSeqChunk)
+#pragma unroll
+          for (int u = 0; u < kSeqChunk; ++u) v[2][u] = AS_CT(j + (kSeqRing + 2) * kSeqChunk + u);
+          AS_CHUNK(xb, xa, 3, j + 4 * kSeqChunk)
+#pragma unroll
+          for (int u = 0; u < kSeqChunk; ++u) v[3][u] = AS_CT(j + (kSeqRing + 3) * kSeqChunk + u);
+          j += kSeqRing * kSeqChunk;
+        }
+        AS_CHUNK(xa, xb, 0, j + 1 * kSeqChunk)
+        AS_CHUNK(xb, xa, 1, j + 2 * kSeqChunk)
+        AS_CHUNK(xa, xb, 2, j + 3 * kSeqChunk)
+        AS_CHUNK(xb, xa, 3, (j + 4 * kSeqChunk <= last ? j + 4 * kSeqChunk : last))
+#undef AS_CHUNK
+        j += kSeqRing * kSeqChunk;
+      }
+      for (; j < f; ++j) {  // widths that are not a multiple of 64: the rest one word at a time
+        const double diff = __dsub_rn(cur[j], AS_CT(j));
+        acc = __dadd_rn(acc, __dmul_rn(diff, diff));
+      }
+#undef AS_CT
+      if (acc < best) {  // this thread's centroids come in index order: strict '<' keeps the first of equal minima
+        best = acc;
+        bc = c;
+      }
+    }
+    const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double od = __shfl_xor(best, o, 64);
+      const uint64_t oc = __shfl_xor((unsigned long long)bc, o, 64);
+      if (od < best || (od == best && oc < bc)) {
+        best = od;
+        bc = oc;
+      }
+    }
+    if (lane == 0) {
+      s_wd[wv] = best;
+      s_wc[wv] = bc;
+    }
+    __syncthreads();
+    double bd = s_sd[r & 1];
+    uint64_t bi = s_si[r & 1];
+    {
+      double ld = __builtin_inf();
+      uint64_t lc = ~0ull;
+#pragma unroll
+      for (int w = 0; w < kSeqWaves; ++w) {
+        const double od = s_wd[w];
+        const uint64_t oc = s_wc[w];
+        if (od < ld || (od == ld && oc < lc)) {
+          ld = od;
+          lc = oc;
+        }
+      }
+      if (lc != ~0ull && ld < bd) {
+        bd = ld;
+        bi = lc;
+      }
+    }
+    const unsigned long long t2 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    // the reference's decisions (src/clustering.rs:637-656, 670-713, 721-905), the same for every thread
+    if (nc == 0 || (nc < M && bd > radius * 0.5)) {
+      for (uint32_t j = t; j < f; j += kSeqThreads) {
+        const double vj = cur[j];
+        cents[nc * f + j] = vj;
+        centsT[(uint64_t)j * M + nc] = vj;
+      }
+      if (t == 0) {
+        counts[nc] = 1;
+        assign[r] = (long long)nc;
+      }
+      ++nc;
+    } else if (bd <= radius) {
+      const double k_new = (double)counts[bi] + 1.0;
+      for (uint32_t j = t; j < f; j += kSeqThreads) {
+        const double cj = cents[bi * f + j];
+        const double vj = __dadd_rn(cj, __ddiv_rn(__dsub_rn(cur[j], cj), k_new));
+        cents[bi * f + j] = vj;
+        centsT[(uint64_t)j * M + bi] = vj;
+      }
+      __syncthreads();  // every thread has read the count
+      if (t == 0) {
+        counts[bi] += 1;
+        assign[r] = (long long)bi;
+      }
+    } else if (t == 0) {
+      if (bd <= radius * 1.5) {
+        counts[bi] += 1;
+        assign[r] = (long long)bi;
+      } else {
+        assign[r] = -1;
+      }
+    }
+    const unsigned long long t3 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    if (loader && r + 1 < bn) {
+#pragma unroll
+      for (uint32_t q = 0; q < kSeqMaxF / kSeqLoaders; ++q) {
+        const uint32_t j = lt + q * kSeqLoaders;
+        if (j < f) nxt[j] = pre[q];
+      }
+      if (lt == 0) {
+        s_sd[(r + 1) & 1] = p_bd;
+        s_si[(r + 1) & 1] = p_bi;
+      }
+    }
+    __syncthreads();  // the centroids as the next row has to see them; the row buffers; s_wd / s_wc / the snapshot slots
+    if (may_stop && nc == M) {
+      rows_done = r + 1;
+      break;
+    }
+    if (stamps && lane == 0) {  // diagnostic build of a launch: cycles per phase, per wave
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      stamps[wv * 4 + 0] += t1 - t0;
+      stamps[wv * 4 + 1] += t2 - t1;
+      stamps[wv * 4 + 2] += t3 - t2;
+      stamps[wv * 4 + 3] += t4 - t3;
+    }
+  }
+  if (t == 0) {
+    nc_io[0] = nc;
+    nc_io[1] = rows_done;
+  }
+}
+
 // rows [begin, begin + count) of a host- or device-resident matrix as a host pointer
 struct HostRows {
   std::vector<double> buf;
@@ -623,10 +851,88 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
   DevBuf<long long> assign_d;
   DevBuf<uint32_t> act_d;
   bool on_device_phase = false;
+  uint64_t first_device_row = 0;
   ctx->stats["clustering_device_batches"] = 0;
   ctx->stats["clustering_host_batches"] = 0;
-  for (uint64_t b0 = 0; b0 < n; b0 += batch) {
+  ctx->stats["clustering_sequential_batches"] = 0;
+  if (ctx->opt_cluster_on_device && f <= kSeqMaxF) {
+    // No row visits the host.  Batches in which centroids can still appear: cluster_seq_kernel (a chain over the rows of the
+    // batch); once the cap is reached: decisions and running means per centroid in parallel.  batch = 1 (every row sees every
+    // centroid as it stands) is ONE chain over all rows with no snapshot, cut into launches of 65 536 rows.
+    DevBuf<double> cdT;
+    DevBuf<unsigned long long> nc_d;
+    AS_TRY(cdT.alloc(ctx, max_clusters * f));
+    AS_TRY(nc_d.alloc(ctx, 2));
+    AS_TRY(counts_d.alloc(ctx, max_clusters));
+    AS_TRY(assign_d.alloc(ctx, n));
+    AS_TRY(act_d.alloc(ctx, batch));
+    AS_HIP(ctx, hipMemsetAsync(counts_d.p, 0, sizeof(unsigned long long) * max_clusters, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(nc_d.p, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(cd.p, 0, sizeof(double) * max_clusters * f, ctx->stream));
+    const size_t lds = sizeof(double) * 2 * f;
+    DevBuf<unsigned long long> stamps_d;  // debug bit 0x100000: cycles per phase of the chain kernel (diagnostic only)
+    if (ctx->opt_debug & 0x100000) {
+      AS_TRY(stamps_d.alloc(ctx, kSeqWaves * 4));
+      AS_HIP(ctx, hipMemsetAsync(stamps_d.p, 0, sizeof(unsigned long long) * kSeqWaves * 4, ctx->stream));
+    }
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)cluster_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t step = batch == 1 ? 65536 : batch;
+    uint64_t done = 0;
+    for (uint64_t b0 = 0; b0 < n; b0 += done) {
+      const uint64_t bn = std::min(step, n - b0);
+      done = bn;
+      if (nc == max_clusters && batch != 1) {
+        AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
+        hipLaunchKernelGGL(cluster_decide_kernel, dim3(cdiv(bn, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idxd.p,
+                           (const double *)d2d.p, bn, radius, act_d.p, assign_d.p + b0);
+        hipLaunchKernelGGL(cluster_apply_kernel, dim3((unsigned)nc), dim3(256), 0, ctx->stream, R.p + b0 * f, bn, f,
+                           (const uint64_t *)idxd.p, (const uint32_t *)act_d.p, cd.p, counts_d.p);
+        AS_HIP(ctx, hipGetLastError());
+        ctx->stats["clustering_device_batches"] += 1;
+        continue;
+      }
+      const bool snap = batch != 1 && nc > 0;
+      if (snap) AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
+      {
+        ProfScope ps(ctx, "cluster_sequential");
+        hipLaunchKernelGGL(cluster_seq_kernel, dim3(1), dim3(kSeqThreads), lds, ctx->stream, R.p + b0 * f, bn, (uint32_t)f,
+                           snap ? (const uint64_t *)idxd.p : nullptr, snap ? (const double *)d2d.p : nullptr, batch == 1 ? 0 : nc, radius,
+                           max_clusters, cd.p, cdT.p, counts_d.p, assign_d.p + b0, nc_d.p, batch != 1 ? 1 : 0, stamps_d.p);
+      }
+      AS_HIP(ctx, hipGetLastError());
+      ctx->stats["clustering_sequential_batches"] += 1;
+      if (batch != 1 || b0 + step >= n) {  // the next batch's path and start depend on the cluster count and on where this one ended
+        unsigned long long h[2] = {0, 0};
+        AS_HIP(ctx, copy_d2h(ctx, h, nc_d.p, sizeof(h)));
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        nc = h[0];
+        if (batch != 1) done = h[1];
+        if (done == 0 || done > bn) return fail(ctx, AS_ERR_HIP, "clustering chain: row count");
+      }
+    }
+    if (stamps_d.p) {
+      unsigned long long hs[kSeqWaves * 4];
+      AS_HIP(ctx, copy_d2h(ctx, hs, stamps_d.p, sizeof(hs)));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (int w = 0; w < kSeqWaves; ++w)
+        for (int q = 0; q < 4; ++q) ctx->stats["clustering_chain_cycles_w" + std::to_string(w) + "_p" + std::to_string(q)] = (double)hs[w * 4 + q];
+    }
+    std::vector<unsigned long long> hc(nc);
+    if (nc) {
+      AS_HIP(ctx, copy_d2h(ctx, cents, cd.p, sizeof(double) * nc * f));
+      AS_HIP(ctx, copy_d2h(ctx, hc.data(), counts_d.p, sizeof(unsigned long long) * nc));
+    }
+    static_assert(sizeof(long long) == sizeof(int64_t), "assignments");
+    if (n) AS_HIP(ctx, copy_d2h(ctx, assignments_out, assign_d.p, sizeof(long long) * n));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t c = 0; c < nc; ++c) counts_out[c] = hc[c];
+    *n_clusters_out = nc;
+    return AS_OK;
+  }
+  uint64_t done_h = 0;
+  for (uint64_t b0 = 0; b0 < n; b0 += done_h) {
     const uint64_t bn = std::min(batch, n - b0), nc_snap = nc;
+    done_h = bn;
     if (nc == max_clusters && ctx->opt_cluster_on_device) {
       if (!on_device_phase) {  // the state so far moves to the device once
         AS_TRY(counts_d.alloc(ctx, max_clusters));
@@ -637,6 +943,7 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
         AS_HIP(ctx, copy_h2d(ctx, counts_d.p, hc.data(), sizeof(unsigned long long) * max_clusters));
         AS_HIP(ctx, copy_h2d(ctx, cd.p, cents, sizeof(double) * max_clusters * f));
         on_device_phase = true;
+        first_device_row = b0;
       }
       AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
       hipLaunchKernelGGL(cluster_decide_kernel, dim3(cdiv(bn, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idxd.p, (const double *)d2d.p, bn,
@@ -675,9 +982,7 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
         counts_out[0] = 1;
         assignments_out[b0 + r] = 0;
         nc = 1;
-        continue;
-      }
-      if (nc < max_clusters && bd > radius * 0.5) {
+      } else if (nc < max_clusters && bd > radius * 0.5) {
         std::memcpy(cents + nc * f, row, sizeof(double) * f);
         counts_out[nc] = 1;
         assignments_out[b0 + r] = (int64_t)nc;
@@ -691,6 +996,10 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
         counts_out[bi] += 1;
         assignments_out[b0 + r] = (int64_t)bi;
       }
+      if (nc_snap < max_clusters && nc == max_clusters) {  // the cap was reached inside this batch: it ends here
+        done_h = r + 1;
+        break;
+      }
     }
   }
   if (on_device_phase) {  // the device phase's centroids, counts and assignments come back once
@@ -699,11 +1008,7 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
     AS_HIP(ctx, copy_d2h(ctx, hc.data(), counts_d.p, sizeof(unsigned long long) * max_clusters));
     for (uint64_t c = 0; c < max_clusters; ++c) counts_out[c] = hc[c];
     // (assignments of the host phase are in assignments_out already: the device phase covers the batches from its first on)
-    uint64_t first = 0;
-    {
-      const uint64_t host_batches = (uint64_t)ctx->stats["clustering_host_batches"];
-      first = std::min(n, host_batches * batch);
-    }
+    const uint64_t first = first_device_row;
     if (first < n) AS_HIP(ctx, copy_d2h(ctx, assignments_out + first, assign_d.p + first, sizeof(long long) * (n - first)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }

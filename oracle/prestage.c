@@ -12,7 +12,9 @@
  *   - the ChaCha8 Gaussian stream of ImplicitProjection (src/reduction.rs:186-199)       -> the matrix is an input
  * The incremental clustering is restated for a batch size B: the snapshot of src/clustering.rs:571-594 is taken once
  * per batch of B rows (a legal schedule of the reference's parallel mode) and rows also see the centroids created
- * earlier in their own batch; B = 1 is the reference's sequential mode (`with_seed`, :900-901) exactly.
+ * earlier in their own batch; a batch ENDS EARLY with the row that creates the last centroid the cap allows (from then on
+ * no centroid can appear, a row's fate depends on the snapshot alone, and the next batch starts with a snapshot of them
+ * all); B = 1 is the reference's sequential mode (`with_seed`, :900-901) exactly.
  */
 #include "oracle.h"
 
@@ -356,9 +358,11 @@ int64_t aso_incremental_clustering(const double *rows, uint64_t n, uint64_t f, u
   double *snap_d2 = (double *)malloc(sizeof(double) * batch);
   uint64_t *snap_i = (uint64_t *)malloc(sizeof(uint64_t) * batch);
   for (uint64_t i = 0; i < n; ++i) assign[i] = -1;
-  for (uint64_t b0 = 0; b0 < n; b0 += batch) {
+  uint64_t done = 0;
+  for (uint64_t b0 = 0; b0 < n; b0 += done) {
     const uint64_t bn = n - b0 < batch ? n - b0 : batch;
     const uint64_t nc_snap = nc;
+    done = bn;
     /* phase 1 for the whole batch: nearest centroid of the snapshot (:571-594) */
     for (uint64_t r = 0; r < bn; ++r) {
       if (nc_snap == 0) {
@@ -385,9 +389,7 @@ int64_t aso_incremental_clustering(const double *rows, uint64_t n, uint64_t f, u
         counts[0] = 1;
         assign[b0 + r] = 0;
         nc = 1;
-        continue;
-      }
-      if (nc < max_clusters && bd > radius * 0.5) { /* new cluster (:670-713) */
+      } else if (nc < max_clusters && bd > radius * 0.5) { /* new cluster (:670-713) */
         memcpy(cents + nc * f, row, sizeof(double) * f);
         counts[nc] = 1;
         assign[b0 + r] = (int64_t)nc;
@@ -401,6 +403,10 @@ int64_t aso_incremental_clustering(const double *rows, uint64_t n, uint64_t f, u
         counts[bi] += 1;
         assign[b0 + r] = (int64_t)bi;
       } /* else dropped (:801-826) */
+      if (nc_snap < max_clusters && nc == max_clusters) { /* the cap was reached inside this batch: it ends here */
+        done = r + 1;
+        break;
+      }
     }
   }
   free(snap_d2);

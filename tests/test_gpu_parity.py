@@ -1095,22 +1095,47 @@ def test_incremental_clustering_matches_oracle(ctx, batch):
     X[100:110] += 40.0                              # far outliers: new clusters until the cap, then dropped
     k, radius, _ = O.compute_optimal_k(X)
     cents, assign, sizes = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
-    # once the cap is reached the batches stay on the device (decisions from the snapshot's nearest centroid, running means
-    # applied per centroid in row order): the same centroids, bit for bit, as with every batch decided on the host
-    assert ctx.stat("clustering_device_batches") > 0 and ctx.stat("clustering_host_batches") > 0
+    # no row visits the host: batches in which centroids can still appear run as one chain over their rows
+    # (cluster_seq_kernel; batch = 1 is a single chain with no snapshot), once the cap is reached the decisions come from the
+    # snapshot's nearest centroid and the running means are applied per centroid in row order: the same centroids, bit for
+    # bit, as with every batch decided on the host
+    assert ctx.stat("clustering_sequential_batches") > 0 and ctx.stat("clustering_host_batches") == 0
+    assert batch == 1 or ctx.stat("clustering_device_batches") > 0
     oc, oa, osz = O.incremental_clustering(X, k, radius, batch)
     assert np.array_equal(assign, oa) and np.array_equal(sizes, osz) and np.array_equal(cents, oc)
     assert (assign < 0).sum() == (oa < 0).sum()
     ctx.set_option("cluster_on_device", 0)
     try:
         ch, ah, sh = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
-        assert ctx.stat("clustering_device_batches") == 0
+        assert ctx.stat("clustering_device_batches") == 0 and ctx.stat("clustering_sequential_batches") == 0
     finally:
         ctx.set_option("cluster_on_device", 1)
     assert np.array_equal(ah, oa) and np.array_equal(sh, osz) and np.array_equal(ch, oc)
     import torch
     c2, a2, s2 = A.incremental_clustering(torch.from_numpy(X).cuda(), k, radius, batch, ctx=ctx)
     assert np.array_equal(a2, oa) and np.array_equal(c2, oc)
+
+
+@pytest.mark.parametrize("n,f,k,radius_scale,batch", [
+    (6000, 8, 1500, 0.02, 4096),     # more than 1024 centroids appear inside one batch: a thread owns several
+    (3000, 37, 200, 0.3, 1),         # ragged width, sequential mode
+    (2500, 130, 40, 0.5, 512),       # a width past two whole chunks of the chain
+    (900, 3, 5, 1.0, 64),            # cap reached at once; rows beyond 1.5 radius are dropped
+    (300, 16, 400, 0.1, 128),        # the cap is never reached
+])
+def test_incremental_clustering_chain_shapes(ctx, n, f, k, radius_scale, batch):
+    """cluster_seq_kernel against the oracle across widths, cluster counts above the workgroup size, caps that are reached
+    at once or never, NaN / duplicate rows (src/clustering.rs:596-905)."""
+    X = _blobs(n, f, max(2, min(k, 60)), seed=n * 7 + f, spread=0.5)
+    X[n // 2] = X[n // 3]                                      # a duplicate row: distance exactly 0
+    X[n // 5, f // 2] = np.nan                                  # never nearer than anything: dropped unless it creates
+    X[-7:] += 1e3                                               # far rows late in the order
+    radius = radius_scale * float(np.nanmedian(np.sum((X[:100] - X[100:200]) ** 2, axis=1)))
+    cents, assign, sizes = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
+    assert ctx.stat("clustering_host_batches") == 0 and ctx.stat("clustering_sequential_batches") > 0
+    oc, oa, osz = O.incremental_clustering(X, k, radius, batch)
+    assert len(cents) == len(oc)
+    assert np.array_equal(assign, oa) and np.array_equal(sizes, osz) and np.array_equal(cents, oc, equal_nan=True)
 
 
 def test_build_without_centroids_runs_the_prestage(ctx):
