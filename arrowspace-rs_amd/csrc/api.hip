@@ -339,6 +339,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
   else if (n == "order_mfma") ctx->opt_order_mfma = value;
   else if (n == "cluster_on_device") ctx->opt_cluster_on_device = value;
+  else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "search_stream_quick") ctx->opt_search_stream_quick = value;
   else if (n == "join_prefilter_min_rows") ctx->opt_join_prefilter_min_rows = value;
   else if (n == "search_scan_f16") ctx->opt_search_scan_f16 = value;
@@ -472,7 +473,14 @@ int as_nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n_rows, uint6
   DevOut<double> D;
   AS_TRY(I.bind(ctx, out_idx, n_rows));
   AS_TRY(D.bind(ctx, out_dist2, n_rows));
-  AS_TRY(nearest_centroids(ctx, R.p, n_rows, dim, Cn.p, n_centroids, I.p, D.p));
+  double qmax2 = 0.0;
+  if (ctx->opt_nearest_mfma == 2) {  // (tests: the candidate path behind this entry point too)
+    double a = 0.0, b = 0.0;
+    AS_TRY(max_row_sqnorm(ctx, R.p, n_rows, dim, &a));
+    AS_TRY(max_row_sqnorm(ctx, Cn.p, n_centroids, dim, &b));
+    qmax2 = std::max(a, b);
+  }
+  AS_TRY(nearest_centroids(ctx, R.p, n_rows, dim, Cn.p, n_centroids, I.p, D.p, qmax2));
   AS_TRY(I.finish(ctx));
   AS_TRY(D.finish(ctx));
   return AS_OK;

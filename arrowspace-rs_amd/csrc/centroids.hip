@@ -12,7 +12,10 @@
 // A batch of the incremental clustering is 4 096 rows = 64 row tiles: too few workgroups for 256 CUs.  Then the centroid
 // chunks are dealt to gridDim.y workgroups per row tile, each leaves its minimum per row, and nearest_merge_kernel takes the
 // minimum of those with the smallest index among equal minima -- the same (index, distance) as the single sweep.
+#include <cstring>
+
 #include "common.h"
+#include "mfma_common.h"
 
 namespace asx {
 
@@ -22,7 +25,11 @@ constexpr int kCtRows = 64, kCtCents = 64, kCtFeat = 32, kCtPitch = kCtFeat + 1;
 
 __global__ __launch_bounds__(256) void nearest_centroids_kernel(const double *__restrict__ rows, uint64_t n, uint64_t d,
                                                                 const double *__restrict__ cents, uint64_t n_cents,
-                                                                uint64_t *__restrict__ out_idx, double *__restrict__ out_d2) {
+                                                                uint64_t *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                                const uint32_t *__restrict__ row_list,
+                                                                const uint32_t *__restrict__ row_count) {
+  // row_list: the rows to do are row_list[0 .. *row_count) (the leftovers of the MFMA candidate path; results by row id)
+  if (row_list) n = *row_count;
   // gridDim.y > 1: this workgroup sweeps the centroid chunks blockIdx.y, + gridDim.y, ... and writes slice blockIdx.y of
   // out_idx / out_d2 (n entries each; index ~0 = no centroid of the slice was comparable)
   __shared__ double s_row[kCtRows * kCtPitch];
@@ -45,7 +52,8 @@ __global__ __launch_bounds__(256) void nearest_centroids_kernel(const double *__
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int e = q * 256 + tid, rr = e >> 5, kk = e & 31;
-          s_row[rr * kCtPitch + kk] = (row0 + rr < n && kk < feats) ? rows[(row0 + rr) * d + k0 + kk] : 0.0;
+          s_row[rr * kCtPitch + kk] =
+              (row0 + rr < n && kk < feats) ? rows[(row_list ? (uint64_t)row_list[row0 + rr] : row0 + rr) * d + k0 + kk] : 0.0;
           s_cen[rr * kCtPitch + kk] = (c0 + rr < n_cents && kk < feats) ? cents[(c0 + rr) * d + k0 + kk] : 0.0;
         }
         __syncthreads();
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void nearest_centroids_kernel(const double *__
           bi = vi;
         }
       }
-      const uint64_t at = (uint64_t)blockIdx.y * n + row0 + r;
+      const uint64_t at = row_list ? (uint64_t)row_list[row0 + r] : (uint64_t)blockIdx.y * n + row0 + r;
       out_idx[at] = (bi == ~0ull && gridDim.y == 1) ? 0 : bi;
       out_d2[at] = bi == ~0ull ? __builtin_inf() : b;
     }
@@ -110,18 +118,253 @@ __global__ void nearest_merge_kernel(const uint64_t *__restrict__ part_idx, cons
   out_d2[r] = bi == ~0ull ? __builtin_inf() : b;
 }
 
+
+// ---- keys on the matrix pipe, exact re-rank of the few centroids that can be the nearest ---------------
+// |q - p|^2 = |q|^2 + (|p|^2 - 2 q.p): euclid_keys_kernel writes the approximate key  |p|^2 - 2 q.p  of every (row, centroid)
+// of the batch from an f32 MFMA contraction of the raw rows rounded to f32 (the packed images of mfma_topk_f32.hip, norms ==
+// nullptr; one wave = 32 rows x 128 centroids, fragments straight from L2, no LDS).  With E bounding |approximate key - true
+// key| every centroid whose REFERENCE distance can be the smallest has its key within 2 E of the row's best key, so: a row with
+// at most kEuCap keys in that window is decided by summing those centroids' distances in the reference's arithmetic (d2 += (a -
+// b) * (a - b), features ascending, two roundings) -- the minimum, smallest index among equal minima, is exactly what the sweep
+// over all centroids returns.  Every other row (many centroids tied, non-finite values, keys that overflow f32) goes to the
+// exact kernel by a row list whose length stays on the device.
+//   E = ((2 d + 19) 2^-23 Qmax^2) 1.05:  operands rounded to f32 (2^-24 each), d products summed in f32 by the matrix pipe
+//   (2^-23 per addition covers a truncating adder), |p|^2 rounded to f32, the final fma; |q|, |p| <= Qmax (a centroid is a
+//   running mean of rows); the reference's own rounding ((d + 2) 2^-53 relative) is inside the factor 1.05.
+constexpr int kEuCap = 4;
+typedef float v16f32e __attribute__((ext_vector_type(16)));
+
+// The centroids as the B image of the contraction, P[((T KS2 + ks) 4 + s) 64 + l] = (float) c[128 T + 32 s + (l & 31)][(l >> 5) KS2 + ks]
+// (the tile shape of mfma_topk_f32.hip with the features dealt in two contiguous halves, so that the A side reads each row in
+// 16-byte pieces; zero beyond the last centroid and the last feature), their |c|^2 rounded to f32, and the reset of the
+// leftover-row counter: one wave per row of the padded image.
+__global__ __launch_bounds__(256) void euclid_pack_cents_kernel(const double *__restrict__ C, uint32_t n, uint32_t d, uint32_t KS2, uint32_t rows_padded,
+                                                                float *__restrict__ P, float *__restrict__ bsq, uint32_t *__restrict__ redo_count) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row == 0 && lane == 0) *redo_count = 0;
+  if (row >= rows_padded) return;
+  const uint32_t T = row >> 7, sg = (row & 127) >> 5, lc = row & 31;
+  float *dst = P + ((size_t)T * KS2 * 4 + sg) * 64 + lc;
+  double sq = 0.0;
+  for (uint32_t k = lane; k < 2 * KS2; k += 64) {
+    const double v = (row < n && k < d) ? C[(size_t)row * d + k] : 0.0;
+    sq = fma(v, v, sq);
+    dst[(size_t)(k % KS2) * 256 + 32 * (k / KS2)] = (float)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if (lane == 0 && row < n) bsq[row] = (float)sq;
+}
+
+// largest row norm (upper bound: fma sum, rounded up by a relative 1e-12 on the host); positive doubles order as integers
+__global__ __launch_bounds__(256) void max_sqnorm_kernel(const double *__restrict__ R, uint64_t n, uint32_t d, unsigned long long *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  double m = 0.0;
+  bool bad = false;
+  for (uint64_t r = wave; r < n; r += waves) {
+    double s = 0.0;
+    for (uint32_t k = lane; k < d; k += 64) s = fma(R[r * d + k], R[r * d + k], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (!(s <= 1.7e308)) bad = true;  // NaN or inf
+    m = fmax(m, s);
+  }
+  if (lane == 0) atomicMax(out, bad ? 0x7FF0000000000000ull : (unsigned long long)__double_as_longlong(m));
+}
+
+// keys[row * ldk + col]: one wave = the 32 rows of group g against the 32 centroids of column group cg; the rows are read as
+// they are (f64 -> f32 on the way: lane l holds row g 32 + (l & 31), features (l >> 5) KS2 + ks), the centroids from the packed
+// image; all fragments of the wave are requested before the first MFMA (KS2 <= 64: d <= 128) or in panels of 64 k steps.
+__global__ __launch_bounds__(64) void euclid_keys_kernel(const double *__restrict__ rows, const float *__restrict__ PB, const float *__restrict__ bsq,
+                                                         uint32_t col_groups, uint32_t KS2, uint32_t nA, uint32_t nB, uint32_t d, uint32_t ldk,
+                                                         float *__restrict__ keys) {
+  const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
+  const uint32_t g = blockIdx.x / col_groups, cg = blockIdx.x - g * col_groups;
+  const uint32_t J = cg >> 2, ng = cg & 3;
+  const uint32_t arow = g * 32 + lc;
+  const double *a_src = rows + (size_t)arow * d + (size_t)lh * KS2;
+  const bool pairs = (d & 1u) == 0;  // KS2 is a multiple of 16: every pair of features of a lane is 16-byte aligned then
+  typedef double d2e __attribute__((ext_vector_type(2)));
+  const float *b_src = PB + ((size_t)J * KS2 * 4 + ng) * 64 + lane;
+  v16f32e acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (uint32_t k0 = 0; k0 < KS2; k0 += 64) {
+    float a[64], b[64];
+#pragma unroll
+    for (int u = 0; u < 64; u += 2) {
+      const uint32_t ks = k0 + u, k = lh * KS2 + ks;
+      if (pairs) {
+        d2e v = {0.0, 0.0};
+        if (arow < nA && k < d) v = *reinterpret_cast<const d2e *>(a_src + ks);
+        a[u] = (float)v.x;
+        a[u + 1] = (float)v.y;
+      } else {
+        a[u] = (arow < nA && k < d) ? (float)a_src[ks] : 0.f;
+        a[u + 1] = (arow < nA && k + 1 < d) ? (float)a_src[ks + 1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 64; ++u) b[u] = k0 + u < KS2 ? b_src[(size_t)(k0 + u) * 256] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  const uint32_t col = cg * 32 + lc;
+  if (col < nB) {
+    const float nb = bsq[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t row = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < nA) keys[(size_t)row * ldk + col] = fmaf(-2.f, acc[r], nb);
+    }
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void euclid_rerank_kernel(const double *__restrict__ rows, uint64_t n, uint32_t d, const double *__restrict__ cents,
+                                                            uint32_t n_cents, const float *__restrict__ keys, uint32_t ldk, float two_e,
+                                                            uint64_t *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                            uint32_t *__restrict__ redo_rows, uint32_t *__restrict__ redo_count) {
+  __shared__ double s_t[4][kEuCap][128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + wv;
+  if (row >= n) return;
+  const float *kr = keys + row * ldk;
+  float k1 = __builtin_inff();
+  bool odd = false;  // a key that is NaN or -inf: the row is not decided here
+  for (uint32_t c = lane; c < n_cents; c += 64) {
+    const float k = kr[c];
+    odd = odd || !(k == k) || k < -3.0e38f;
+    k1 = fminf(k1, k);
+  }
+  for (int o = 32; o > 0; o >>= 1) k1 = fminf(k1, __shfl_xor(k1, o, 64));
+  // the window in f32: k <= k1 + 2E evaluated as k - k1 <= 2E (exact or rounded to nearest: two_e carries a relative 2^-20 for it)
+  uint32_t cnt = 0;
+  uint32_t ci[kEuCap];
+#pragma unroll
+  for (int c = 0; c < kEuCap; ++c) ci[c] = kNoIdx;
+  if (!__any(odd) && k1 < 3.0e38f) {
+    for (uint32_t c0 = 0; c0 < n_cents && cnt <= (uint32_t)kEuCap; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      const bool near = c < n_cents && (kr[c] - k1) <= two_e;
+      unsigned long long mask = __ballot(near);
+      while (mask && cnt <= (uint32_t)kEuCap) {  // (wave-uniform) centroids in index order
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (cnt < (uint32_t)kEuCap) {
+#pragma unroll
+          for (int q = 0; q < kEuCap; ++q)
+            if ((uint32_t)q == cnt) ci[q] = c0 + (uint32_t)l;
+        }
+        ++cnt;
+      }
+    }
+  }
+  if (cnt == 0 || cnt > (uint32_t)kEuCap) {
+    if (lane == 0) redo_rows[atomicAdd(redo_count, 1u)] = (uint32_t)row;
+    return;
+  }
+  double acc = 0.0;
+  for (uint32_t k0 = 0; k0 < d; k0 += 128) {
+    const uint32_t ka = k0 + 2 * lane, kb = ka + 1;
+    const double q0 = ka < d ? rows[row * d + ka] : 0.0, q1 = kb < d ? rows[row * d + kb] : 0.0;
+#pragma unroll
+    for (int c = 0; c < kEuCap; ++c) {
+      if ((uint32_t)c < cnt) {
+        const double p0 = ka < d ? cents[(uint64_t)ci[c] * d + ka] : 0.0, p1 = kb < d ? cents[(uint64_t)ci[c] * d + kb] : 0.0;
+        const double d0 = __dsub_rn(q0, p0), d1 = __dsub_rn(q1, p1);
+        s_t[wv][c][2 * lane] = __dmul_rn(d0, d0);
+        s_t[wv][c][2 * lane + 1] = __dmul_rn(d1, d1);
+      }
+    }
+    wave_sync();
+    if ((uint32_t)lane < cnt) {
+      const uint32_t m = d - k0 < 128u ? d - k0 : 128u;
+      for (uint32_t j = 0; j < m; ++j) acc = __dadd_rn(acc, s_t[wv][lane][j]);  // the reference's sequential sum
+    }
+    wave_sync();
+  }
+  // the candidates in index order with a strict '<' = smallest distance, smallest index among equal ones; NaN never wins
+  double best = __builtin_inf();
+  uint32_t bi = kNoIdx;
+  bool found = false;
+#pragma unroll
+  for (int c = 0; c < kEuCap; ++c) {
+    const double dc = __shfl(acc, c, 64);
+    if ((uint32_t)c < cnt && dc < best) {
+      best = dc;
+      bi = ci[c];
+      found = true;
+    }
+  }
+  if (lane == 0) {
+    out_idx[row] = found ? bi : 0;
+    out_d2[row] = found ? best : __builtin_inf();
+  }
+}
+
 }  // namespace
 
+int max_row_sqnorm(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out) {
+  DevBuf<unsigned long long> m;
+  AS_TRY(m.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(m.p, 0, sizeof(unsigned long long), ctx->stream));
+  if (n) hipLaunchKernelGGL(max_sqnorm_kernel, dim3(1024), dim3(256), 0, ctx->stream, rows, n, (uint32_t)d, m.p);
+  AS_HIP(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, m.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double v;
+  std::memcpy(&v, &h, sizeof(v));
+  *out = v * (1.0 + 1e-12);
+  return AS_OK;
+}
+
+// qmax2 > 0: an upper bound of |row|^2 and |centroid|^2 -> candidates from the f32 matrix pipe where the shape pays
 int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const double *cents, uint64_t n_cents,
-                      uint64_t *out_idx, double *out_d2) {
+                      uint64_t *out_idx, double *out_d2, double qmax2) {
   if (n == 0) return AS_OK;
+  const bool mfma = ctx->opt_nearest_mfma && qmax2 > 0.0 && qmax2 < 1e30 && n >= 1024 && n_cents >= 64 && n < (1ull << 31) &&
+                    n_cents <= 16384 && d >= 1 && d <= 1024;
+  if (mfma) {
+    ProfScope ps(ctx, "nearest_centroids_mfma");
+    const uint32_t a_tiles = (uint32_t)cdiv(n, (uint64_t)kTileRows), b_tiles = (uint32_t)cdiv(n_cents, (uint64_t)kTileRows);
+    const uint32_t KS2 = packed_units((uint32_t)d) * 16, ldk = b_tiles * kTileRows;
+    DevBuf<float> PB, bsq, keys;
+    DevBuf<uint32_t> redo;
+    AS_TRY(PB.alloc(ctx, packed_elems(b_tiles, (uint32_t)d)));
+    AS_TRY(bsq.alloc(ctx, n_cents));
+    AS_TRY(keys.alloc(ctx, (size_t)n * ldk));
+    AS_TRY(redo.alloc(ctx, n + 1));
+    hipLaunchKernelGGL(euclid_pack_cents_kernel, dim3(b_tiles * kTileRows / 4), dim3(256), 0, ctx->stream, cents, (uint32_t)n_cents, (uint32_t)d, KS2,
+                       b_tiles * kTileRows, PB.p, bsq.p, redo.p + n);
+    const uint32_t a_groups = a_tiles * 4, col_groups = (uint32_t)cdiv(n_cents, (uint64_t)32);
+    hipLaunchKernelGGL(euclid_keys_kernel, dim3(a_groups * col_groups), dim3(64), 0, ctx->stream, rows, (const float *)PB.p, (const float *)bsq.p,
+                       col_groups, KS2, (uint32_t)n, (uint32_t)n_cents, (uint32_t)d, ldk, keys.p);
+    const double two_e = (2.0 * 1.05 * (double)(2 * d + 19) * 0x1p-23 * qmax2 + 1e-30) * (1.0 + 0x1p-18);
+    const float two_e32 = std::nextafterf((float)two_e, INFINITY);
+    hipLaunchKernelGGL(euclid_rerank_kernel, dim3((unsigned)cdiv(n, (uint64_t)4)), dim3(256), 0, ctx->stream, rows, n, (uint32_t)d, cents,
+                       (uint32_t)n_cents, (const float *)keys.p, ldk, two_e32, out_idx, out_d2, redo.p, redo.p + n);
+    // the rows that were not decided there: the exact sweep over their list (its length never visits the host)
+    hipLaunchKernelGGL(nearest_centroids_kernel, dim3(64), dim3(256), 0, ctx->stream, rows, n, d, cents, n_cents, out_idx, out_d2,
+                       (const uint32_t *)redo.p, (const uint32_t *)(redo.p + n));
+    AS_HIP(ctx, hipGetLastError());
+    if (ctx->opt_debug & 0x200000) {  // diagnostic: how many rows took the exact sweep
+      uint32_t h = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h, redo.p + n, sizeof(h)));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->stats["nearest_mfma_leftover_rows"] += h;
+    }
+    ctx->stats["nearest_mfma_calls"] += 1;
+    return AS_OK;
+  }
   ProfScope ps(ctx, "nearest_centroids");
   const uint64_t tiles = cdiv(n, (uint64_t)kCtRows), chunks = cdiv(n_cents, (uint64_t)kCtCents);
   const unsigned grid = (unsigned)std::min<uint64_t>(tiles, 256 * 8);
   const uint32_t slices = tiles >= 1024 ? 1u : (uint32_t)std::min<uint64_t>(chunks, cdiv((uint64_t)1024, tiles));
   if (slices <= 1) {
     hipLaunchKernelGGL(nearest_centroids_kernel, dim3(grid), dim3(256), 0, ctx->stream, rows, n, d, cents, n_cents, out_idx,
-                       out_d2);
+                       out_d2, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     AS_HIP(ctx, hipGetLastError());
     return AS_OK;
   }
@@ -129,7 +372,8 @@ int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, c
   DevBuf<double> pd;
   AS_TRY(pi.alloc(ctx, (size_t)slices * n));
   AS_TRY(pd.alloc(ctx, (size_t)slices * n));
-  hipLaunchKernelGGL(nearest_centroids_kernel, dim3(grid, slices), dim3(256), 0, ctx->stream, rows, n, d, cents, n_cents, pi.p, pd.p);
+  hipLaunchKernelGGL(nearest_centroids_kernel, dim3(grid, slices), dim3(256), 0, ctx->stream, rows, n, d, cents, n_cents, pi.p, pd.p,
+                     (const uint32_t *)nullptr, (const uint32_t *)nullptr);
   hipLaunchKernelGGL(nearest_merge_kernel, dim3((unsigned)cdiv(n, (uint64_t)256)), dim3(256), 0, ctx->stream, (const uint64_t *)pi.p,
                      (const double *)pd.p, n, slices, out_idx, out_d2);
   AS_HIP(ctx, hipGetLastError());

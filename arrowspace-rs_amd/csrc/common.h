@@ -72,6 +72,7 @@ struct as_ctx {
                                       // 1 = from the second scan of an index on, 2 = at once, 0 = never
   int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
   int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
+  int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)
   int64_t opt_cluster_on_device = 1;     // incremental clustering: batches after the last centroid is created stay on the device
   int64_t opt_search_stream_quick = 1;   // up to 8 rows without an int8 image: quick f64 pass over the items + exact chains of what it leaves
   int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
@@ -506,7 +507,8 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded);
 bool knn_join_applies(const as_ctx *ctx, uint32_t n, uint32_t d);  // for shard starts on super-tile boundaries
 // batch nearest_centroid (src/clustering.rs:913-928), centroids.hip
 int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const double *cents, uint64_t n_cents,
-                      uint64_t *out_idx, double *out_d2);
+                      uint64_t *out_idx, double *out_d2, double qmax2 = 0.0);  // qmax2 > 0: bound of |row|^2, |centroid|^2 (MFMA candidates)
+int max_row_sqnorm(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out);  // upper bound; inf when a row is not finite
 
 // rows [row_begin, row_begin + row_count) of the n x n Laplacian (the whole matrix: 0, n)
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,

@@ -43,8 +43,12 @@ __global__ void pack_f32_kernel(const double *__restrict__ R, const double *__re
   float v = 0.f;
   if (row < n && k < d) {
     const uint64_t src = row_ids ? row_ids[row] : row0 + row;
-    const double nr = norms[src];
-    v = nr > 0.0 ? (float)(R[src * d + k] / nr) : 0.f;
+    if (norms) {
+      const double nr = norms[src];
+      v = nr > 0.0 ? (float)(R[src * d + k] / nr) : 0.f;
+    } else {  // the rows as they are (Euclidean candidates of the clustering pre-stage)
+      v = (float)R[src * d + k];
+    }
   }
   P[g] = v;
 }

@@ -855,6 +855,7 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
   ctx->stats["clustering_device_batches"] = 0;
   ctx->stats["clustering_host_batches"] = 0;
   ctx->stats["clustering_sequential_batches"] = 0;
+  ctx->stats["nearest_mfma_calls"] = 0;
   if (ctx->opt_cluster_on_device && f <= kSeqMaxF) {
     // No row visits the host.  Batches in which centroids can still appear: cluster_seq_kernel (a chain over the rows of the
     // batch); once the cap is reached: decisions and running means per centroid in parallel.  batch = 1 (every row sees every
@@ -876,13 +877,20 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
       AS_HIP(ctx, hipMemsetAsync(stamps_d.p, 0, sizeof(unsigned long long) * kSeqWaves * 4, ctx->stream));
     }
     AS_HIP(ctx, hipFuncSetAttribute((const void *)cluster_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the nearest-centroid searches of the batches take their candidates from the f32 matrix pipe (centroids.hip): one bound
+    // of |row|^2 for the whole run (a centroid is a running mean of rows: inside their hull up to rounding)
+    double qmax2 = 0.0;
+    if (ctx->opt_nearest_mfma && batch >= 1024 && n >= 1024) {
+      AS_TRY(max_row_sqnorm(ctx, R.p, n, f, &qmax2));
+      qmax2 *= 1.0 + 1e-6;
+    }
     const uint64_t step = batch == 1 ? 65536 : batch;
     uint64_t done = 0;
     for (uint64_t b0 = 0; b0 < n; b0 += done) {
       const uint64_t bn = std::min(step, n - b0);
       done = bn;
       if (nc == max_clusters && batch != 1) {
-        AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
+        AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p, qmax2));
         hipLaunchKernelGGL(cluster_decide_kernel, dim3(cdiv(bn, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idxd.p,
                            (const double *)d2d.p, bn, radius, act_d.p, assign_d.p + b0);
         hipLaunchKernelGGL(cluster_apply_kernel, dim3((unsigned)nc), dim3(256), 0, ctx->stream, R.p + b0 * f, bn, f,
@@ -892,7 +900,7 @@ int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n, uint6
         continue;
       }
       const bool snap = batch != 1 && nc > 0;
-      if (snap) AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p));
+      if (snap) AS_TRY(nearest_centroids(ctx, R.p + b0 * f, bn, f, cd.p, nc, idxd.p, d2d.p, qmax2));
       {
         ProfScope ps(ctx, "cluster_sequential");
         hipLaunchKernelGGL(cluster_seq_kernel, dim3(1), dim3(kSeqThreads), lds, ctx->stream, R.p + b0 * f, bn, (uint32_t)f,

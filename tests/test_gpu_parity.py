@@ -877,6 +877,59 @@ def test_nearest_centroids_match_oracle(ctx, n, d, nc):
         assert idx[7] == 0 and d2[7] == INF
 
 
+@pytest.mark.parametrize("case", ["blobs128", "narrow_many", "panels200", "near_ties", "offset", "odd_width"])
+def test_nearest_centroids_mfma_candidates_equal_the_exact_sweep(ctx, case):
+    """The candidate path of a clustering batch (csrc/centroids.hip: f32 matrix-pipe keys |p|^2 - 2 q.p, the entries within
+    2 E of the best re-ranked in the reference's arithmetic, everything undecided swept exactly) against the oracle:
+    index and squared distance bit for bit -- duplicated and nearly coincident centroids (first of equal minima; the window
+    holds more than the lists: exact sweep), rows that ARE centroids, a large common offset (a window as wide as the data),
+    widths across the packed shapes."""
+    rng = np.random.default_rng({"blobs128": 1, "narrow_many": 2, "panels200": 3, "near_ties": 4, "offset": 5, "odd_width": 6}[case])
+    if case == "blobs128":
+        n, d, nc = 5000, 128, 317
+        Cn = rng.normal(size=(nc, d)) * 2
+        X = Cn[rng.integers(0, nc, size=n)] + 0.4 * rng.normal(size=(n, d))
+    elif case == "narrow_many":
+        n, d, nc = 4096, 8, 1500
+        Cn = rng.normal(size=(nc, d))
+        X = rng.normal(size=(n, d))
+    elif case == "panels200":
+        n, d, nc = 2000, 200, 100
+        Cn = rng.normal(size=(nc, d))
+        X = Cn[rng.integers(0, nc, size=n)] + 0.1 * rng.normal(size=(n, d))
+    elif case == "odd_width":
+        n, d, nc = 1500, 37, 70
+        Cn = rng.normal(size=(nc, d))
+        X = rng.normal(size=(n, d))
+    elif case == "near_ties":
+        n, d, nc = 3000, 64, 200
+        base = rng.normal(size=(20, d))
+        Cn = np.repeat(base, 10, axis=0) + 1e-9 * rng.normal(size=(nc, d))   # ten centroids within 1e-9 of each other
+        Cn[7] = Cn[3]; Cn[150] = Cn[151]                                       # exact duplicates
+        X = base[rng.integers(0, 20, size=n)] + 0.3 * rng.normal(size=(n, d))
+    else:
+        n, d, nc = 2048, 32, 128
+        Cn = rng.normal(size=(nc, d)) + 1e4
+        X = rng.normal(size=(n, d)) + 1e4
+    X[5] = Cn[2]; X[6] = Cn[nc - 1]                                             # rows that are centroids: distance 0
+    oi, od = O.nearest_centroids(X, Cn)
+    ctx.set_option("nearest_mfma", 2)
+    ctx.set_option("debug", 0x200000)
+    try:
+        c0, l0 = ctx.stat("nearest_mfma_calls"), ctx.stat("nearest_mfma_leftover_rows")
+        idx, d2 = A.nearest_centroids(X, Cn, ctx=ctx)
+        calls, left = ctx.stat("nearest_mfma_calls") - max(c0, 0), ctx.stat("nearest_mfma_leftover_rows") - max(l0, 0)
+    finally:
+        ctx.set_option("nearest_mfma", 1)
+        ctx.set_option("debug", 0)
+    assert calls == 1
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    if case in ("near_ties", "offset"):
+        assert left > n // 2            # the window holds more than a list keeps: these rows took the exact sweep
+    if case == "blobs128":
+        assert left < n // 100          # separated centroids: one or two candidates per row
+
+
 def test_nearest_centroids_device_inputs(ctx):
     import torch
     rng = np.random.default_rng(3)
@@ -1122,13 +1175,16 @@ def test_incremental_clustering_matches_oracle(ctx, batch):
     (2500, 130, 40, 0.5, 512),       # a width past two whole chunks of the chain
     (900, 3, 5, 1.0, 64),            # cap reached at once; rows beyond 1.5 radius are dropped
     (300, 16, 400, 0.1, 128),        # the cap is never reached
+    (30000, 128, 150, 0.05, 4096),   # batches of 4 096 rows against >= 64 centroids: candidates from the matrix pipe
+    (20000, 24, 90, 0.05, 2048),     # narrow rows, rows beyond 1.5 radius dropped
 ])
 def test_incremental_clustering_chain_shapes(ctx, n, f, k, radius_scale, batch):
     """cluster_seq_kernel against the oracle across widths, cluster counts above the workgroup size, caps that are reached
     at once or never, NaN / duplicate rows (src/clustering.rs:596-905)."""
     X = _blobs(n, f, max(2, min(k, 60)), seed=n * 7 + f, spread=0.5)
     X[n // 2] = X[n // 3]                                      # a duplicate row: distance exactly 0
-    X[n // 5, f // 2] = np.nan                                  # never nearer than anything: dropped unless it creates
+    if n < 20000:
+        X[n // 5, f // 2] = np.nan                              # never nearer than anything: dropped unless it creates
     X[-7:] += 1e3                                               # far rows late in the order
     radius = radius_scale * float(np.nanmedian(np.sum((X[:100] - X[100:200]) ** 2, axis=1)))
     cents, assign, sizes = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
@@ -1136,6 +1192,8 @@ def test_incremental_clustering_chain_shapes(ctx, n, f, k, radius_scale, batch):
     oc, oa, osz = O.incremental_clustering(X, k, radius, batch)
     assert len(cents) == len(oc)
     assert np.array_equal(assign, oa) and np.array_equal(sizes, osz) and np.array_equal(cents, oc, equal_nan=True)
+    if n >= 20000:
+        assert ctx.stat("nearest_mfma_calls") > 0 and len(cents) >= 64
 
 
 def test_build_without_centroids_runs_the_prestage(ctx):
