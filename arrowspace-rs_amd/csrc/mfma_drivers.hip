@@ -1324,16 +1324,18 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
         AS_TRY(scored.alloc(ctx, 1));
         AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
+        // the rows in the order of the image (a list of image positions is in that order already): neighbours share candidates
+        const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n && ctx->opt_rerank_order) ? oj->perm_own.p : nullptr;
         hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
                            ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                           force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids);
+                           force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order);
         AS_HIP(ctx, hipGetLastError());
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
-    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(std::min<uint32_t>(row_count, 256 * 7 * 8)), dim3(64), \
+    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(row_count >= 256 * 7 * 8 ? 256 * 7 * 8 : row_count), dim3(64), \
                        rs_lds(PC == 1 ? 2 : 4), ctx->stream, \
                        rows, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, \
-                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u, a_ids);                                      \
+                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u, a_ids, score_order);                         \
     break;
         switch (d / 128) {
           AS_SCORE(1) AS_SCORE(2) AS_SCORE(3) AS_SCORE(4) AS_SCORE(5) AS_SCORE(6) AS_SCORE(7) AS_SCORE(8)

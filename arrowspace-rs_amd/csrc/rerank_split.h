@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            uint32_t *__restrict__ records, int slots,
                                                            const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv,
                                                            unsigned long long *__restrict__ scored_total,
-                                                           const uint32_t *__restrict__ a_ids) {
+                                                           const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order) {
+  // records are written by PLACE r of the visiting order: the rows of the range in their own order, or (order: place -> row of
+  // the whole matrix, row_begin = 0) in the order of the join's image, where the list of place r sits at position r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
@@ -46,10 +48,10 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
   unsigned long long scored = 0;  // candidates this wave hands to the scoring kernel (the rows it fetches: bench.py's algorithmic bytes)
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     // (a_ids: the rows of the range as a list -- a rank of a build sharded by image positions finishes the rows perm[pb .. pe))
-    const uint32_t a = a_ids ? a_ids[r] : row_begin + r;
+    const uint32_t a = order ? order[r] : (a_ids ? a_ids[r] : row_begin + r);
     // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
     // holds positions; what leaves this kernel is row ids again
-    const uint32_t lr = inv ? inv[a] : r;
+    const uint32_t lr = order ? r : (inv ? inv[a] : r);
     uint32_t C = 0;
     bool overflow = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
@@ -125,23 +127,26 @@ __device__ __forceinline__ double rs_readlane(double v, uint32_t l) {
 // the rows of a wave as a stream of steps: (row, batch in row, 128-wide piece of the rows); a row without survivors
 // still has one (empty) batch
 struct RsCursor {
-  uint32_t r, b, q, C, nb;
+  uint32_t p, r, b, q, C, nb;  // p: place in the visiting order; r: the row (index into records / outputs) found there
   bool done;
-  uint32_t words;  // of a record
-  __device__ __forceinline__ void enter(const uint32_t *__restrict__ records, uint32_t row, uint32_t row_count) {
-    r = row;
+  uint32_t words;   // of a record
+  uint32_t p_end;   // end of this wave's share of the places
+  const uint32_t *order;  // place -> row, or nullptr (the rows in their own order)
+  __device__ __forceinline__ void enter(const uint32_t *__restrict__ records, uint32_t place) {
+    p = place;
     b = 0;
     q = 0;
-    done = row >= row_count;
-    C = done ? 0u : (records[(size_t)row * words] & 0xFFu);
+    done = place >= p_end;
+    r = done ? 0u : (order ? order[place] : place);
+    C = done ? 0u : (records[(size_t)place * words] & 0xFFu);  // (records are kept by place)
     nb = C ? (C + kRsRows - 1) / kRsRows : 1u;
   }
   // next step: the next piece of the batch, the next batch, the wave's next row
-  __device__ __forceinline__ void advance(const uint32_t *__restrict__ records, uint32_t pieces, uint32_t stride, uint32_t row_count) {
+  __device__ __forceinline__ void advance(const uint32_t *__restrict__ records, uint32_t pieces, uint32_t stride) {
     if (done) return;
     if (++q < pieces) return;
     q = 0;
-    if (++b == nb) enter(records, r + stride, row_count);
+    if (++b == nb) enter(records, p + stride);
   }
 };
 
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
                                                                GraphBound bnd, double *__restrict__ out_key,
                                                                uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows,
                                                                uint32_t *__restrict__ fail_count, uint32_t dbg,
-                                                               const uint32_t *__restrict__ a_ids) {
+                                                               const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order) {
   constexpr uint32_t pieces = PIECES, d = 128u * PIECES;
   // row of the range at index r (wave-uniform: a_ids comes through the scalar cache)
   auto arow = [&](uint32_t r) __attribute__((always_inline)) { return a_ids ? a_ids[r] : row_begin + r; };
@@ -165,12 +170,24 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
   double *ek = reinterpret_cast<double *>(tile + kRsRows * kRsPitch);     // keys and ids of the scored candidates
   uint32_t *ei = reinterpret_cast<uint32_t *>(ek + 64 * SLOTS);
   const uint32_t lane_off = (uint32_t)lane * 16u;
-  const uint32_t stride = gridDim.x;
   const uint32_t chain_len = (dbg & 1) ? 16u : 128u;  // dbg: timing experiments only (outputs undefined)
 
+  // Which rows this wave scores.  `order` (the row order of the join's image: rows of one direction group side by side) makes
+  // the waves that run at the same time work on neighbouring rows, whose candidates are largely the SAME rows: they are then
+  // fetched from HBM once and found in L2 by the others.  L2 is per XCD and workgroups are dealt to the eight XCDs in turn, so
+  // XCD x = blockIdx.x % 8 takes the x-th eighth of the places and its waves walk it side by side.
+  uint32_t stride = gridDim.x, first = blockIdx.x, last = row_count;
+  if (gridDim.x % 8u == 0u) {
+    const uint32_t x = blockIdx.x & 7u, chunk = (row_count + 7u) / 8u;
+    stride = gridDim.x / 8u;
+    first = x * chunk + (blockIdx.x >> 3);
+    last = min((x + 1u) * chunk, row_count);
+  }
   RsCursor is, ps;  // issue side (two batches ahead), process side
   is.words = kRsWords;
-  is.enter(records, blockIdx.x, row_count);
+  is.p_end = last;
+  is.order = order;
+  is.enter(records, first);
   ps = is;
   if (ps.done) return;
 
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
   // (L2-hot), so that every batch is exactly kRsLoads loads and the waits can be counted
   auto batch_ids = [&](const RsCursor &cu, uint32_t (&ids)[kRsRows]) __attribute__((always_inline)) {
     const uint32_t row = cu.done ? 0u : cu.r;
-    const uint32_t *rec = records + (size_t)row * kRsWords + kRsIdsAt + (cu.done ? 0u : cu.b * kRsRows);
+    const uint32_t *rec = records + (size_t)(cu.done ? 0u : cu.p) * kRsWords + kRsIdsAt + (cu.done ? 0u : cu.b * kRsRows);
     const uint4 q0 = *reinterpret_cast<const uint4 *>(rec), q1 = *reinterpret_cast<const uint4 *>(rec + 4);
     const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8), q3 = *reinterpret_cast<const uint4 *>(rec + 12);
     const uint32_t raw[kRsRows] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     AS_GL(S, 8) AS_GL(S, 9) AS_GL(S, 10) AS_GL(S, 11) AS_GL(S, 12) AS_GL(S, 13) AS_GL(S, 14) AS_GL(S, 15)                   \
     rs_gload16(S.x, lane_off,                                                                                               \
                X + (uint64_t)__builtin_amdgcn_readfirstlane((int)arow(is.done ? 0u : is.r)) * d + is.q * 128u);              \
-    is.advance(records, pieces, stride, row_count);                                                                         \
+    is.advance(records, pieces, stride);                                                                                    \
   }
 
   bool p_overflow = false, p_force = false;  // header of the process side's row
@@ -216,12 +233,12 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     batch_ids(ps, ids);
     double nrm[kRsRows];  // norms of the batch's candidates (slots past the count: whatever follows, unused)
     {
-      const double *np = reinterpret_cast<const double *>(records + (size_t)ps.r * kRsWords + kRsNormsAt) + ps.b * kRsRows;
+      const double *np = reinterpret_cast<const double *>(records + (size_t)ps.p * kRsWords + kRsNormsAt) + ps.b * kRsRows;
 #pragma unroll
       for (int t = 0; t < kRsRows; ++t) nrm[t] = np[t];
     }
     if (ps.b == 0 && ps.q == 0) {  // row entry
-      const uint4 h = *reinterpret_cast<const uint4 *>(records + (size_t)ps.r * kRsWords);
+      const uint4 h = *reinterpret_cast<const uint4 *>(records + (size_t)ps.p * kRsWords);
       p_overflow = (h.x & 0x100u) != 0;
       p_force = (h.x & 0x200u) != 0;
       p_theta = __uint_as_float(h.y);
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     {
       const bool row_done = ps.q + 1 == pieces && ps.b + 1 == ps.nb;
       if (!row_done) {
-        ps.advance(records, pieces, stride, row_count);
+        ps.advance(records, pieces, stride);
         return;
       }
     }
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     const bool ok = !p_overflow && !p_force && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
     if (!ok && lane == 0 && !dbg) fail_rows[atomicAdd(fail_count, 1u)] = r;
     wave_sync();
-    ps.enter(records, ps.r + stride, row_count);
+    ps.enter(records, ps.p + stride);
   };
 
   RsSet sA, sB;
