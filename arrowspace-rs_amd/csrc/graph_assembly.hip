@@ -177,6 +177,111 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
   }
 }
 
+// ---- K3a / K3b with 32 lanes per row (K <= 32: every depth the reference's defaults reach) -----------------------------------
+// One thread per row reads its K entries 68 bytes apart from its neighbours' and keeps three K-element arrays in scratch for the
+// pruning's insertion sort; here lane s of a half wave holds entry s of the row: the table is read side by side, the stable
+// order by score (descending, equal scores in their original order -- what the insertion sort with a strict '<' leaves) is a
+// rank count over the half wave, and nothing leaves the registers.
+__device__ __forceinline__ uint32_t half_ballot(bool p, int half) { return (uint32_t)(__ballot(p) >> (32 * half)); }
+
+__global__ __launch_bounds__(256) void degree32_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
+                                                       double eps, uint32_t *__restrict__ deg, unsigned long long *__restrict__ deg_sum) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+  unsigned long long total = 0;  // (one atomic per wave at the end: the sum has a single address)
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; i < n; i += (gridDim.x * blockDim.x) >> 5) {
+    bool hit = false;
+    if ((uint32_t)s < K) {
+      const uint32_t j = nbr_idx[(uint64_t)i * K + s];
+      hit = j != kNoIdx && j != i && nbr_dist[(uint64_t)i * K + s] <= eps;
+    }
+    const uint32_t c = (uint32_t)__popc(half_ballot(hit, half));
+    if (s == 0) {
+      deg[i] = c;
+      total += c;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  if (lane == 0 && total) atomicAdd(deg_sum, total);
+}
+
+__global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
+                                                          double eps, double sigma, double p, const uint32_t *__restrict__ deg,
+                                                          const unsigned long long *__restrict__ deg_sum, uint32_t *__restrict__ adj_j,
+                                                          double *__restrict__ adj_w, uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in,
+                                                          uint32_t r0, uint32_t nr) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const bool sparsify = ((double)(*deg_sum) / (double)n) > 10.0;  // avg_degree > 10.0 (src/laplacian.rs:229-230)
+  uint32_t j = kNoIdx;
+  double w = 0.0, score = 0.0;
+  bool keep = false;
+  if (i < n && (uint32_t)s < K) {
+    j = nbr_idx[(uint64_t)i * K + s];
+    const double dist = nbr_dist[(uint64_t)i * K + s];
+    if (j != kNoIdx && j != i && dist <= eps) {
+      w = kernel_weight(dist, sigma, p);
+      keep = w > 1e-12;
+      if (keep) score = sparsify ? __dmul_rn(w, __dsqrt_rn((double)((uint64_t)deg[i] * (uint64_t)deg[j]))) : w;
+    }
+  }
+  const uint32_t km = half_ballot(keep, half);
+  uint32_t len = (uint32_t)__popc(km);
+  uint32_t pos = (uint32_t)__popc(km & ((1u << s) - 1u));  // place among the kept entries, in table order
+  if (sparsify && len > 2) {
+    // place in the stable descending order by score: kept entries with a larger score, or an equal one earlier in the table
+    uint32_t rank = 0;
+    for (int t = 0; t < 32; ++t) {
+      const double so = __shfl(score, t, 32);
+      const bool ko = (km >> t) & 1u;
+      rank += (ko && (so > score || (so == score && t < s))) ? 1u : 0u;
+    }
+    uint32_t keepn = len / 2;
+    if (keepn < 1) keepn = 1;
+    keep = keep && rank < keepn;
+    pos = rank;
+    len = keepn;
+  }
+  if (i < n) {
+    if (s == 0) adj_len[i] = len;
+    if (keep) {
+      adj_j[(uint64_t)i * K + pos] = j;
+      adj_w[(uint64_t)i * K + pos] = w;
+      if (j - r0 < nr) atomicAdd(&cnt_in[j - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
+    }
+  }
+}
+
+// union size of a row, 32 lanes per row: the out-neighbours sit one per lane, the in-edges pass by 32 at a time
+__global__ __launch_bounds__(256) void union_count32_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len, uint32_t nr, uint32_t K,
+                                                            const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src,
+                                                            uint32_t *__restrict__ ucnt, uint32_t r0) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+  const uint32_t li = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const bool live = li < nr;
+  const uint32_t i = r0 + (live ? li : 0u);
+  const uint32_t len = live ? adj_len[i] : 0u;
+  const uint32_t mine = (uint32_t)s < len ? adj_j[(uint64_t)i * K + s] : kNoIdx;
+  const uint64_t e0 = live ? rev_ptr[li] : 0, e1 = live ? rev_ptr[li + 1] : 0;
+  uint32_t c = len;
+  // (the two rows of a wave walk their in-edges together: the trip count is the longer of the two)
+  const uint64_t span = e1 - e0;
+  const uint64_t span_o = __shfl_xor((unsigned long long)span, 32, 64);
+  const uint64_t trips = ((span > span_o ? span : span_o) + 31) / 32;
+  const uint32_t len_o = __shfl_xor(len, 32, 64), len_m = len > len_o ? len : len_o;
+  for (uint64_t t = 0; t < trips; ++t) {
+    const uint64_t e = e0 + t * 32 + s;
+    const bool have = e < e1;
+    const uint32_t src = have ? rev_src[e] : kNoIdx;
+    bool found = false;
+    for (uint32_t q = 0; q < len_m; ++q) {
+      const uint32_t a = __shfl(mine, (int)q, 32);
+      found = found || (q < len && a == src);
+    }
+    c += (uint32_t)__popc(half_ballot(have && !found, half));
+  }
+  if (live && s == 0) ucnt[li] = c;
+}
+
 // ---- K4: reverse edges ------------------------------------------------------------------------
 __global__ void fill_reverse_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
                                     const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
@@ -503,8 +608,17 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   uint64_t n_edges_dir = 0, n_union = 0;
   {
     ProfScope ps(ctx, "graph_assembly");
-    hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
-    if (K <= 64)
+    const bool lanes32 = K <= 32 && ctx->opt_assembly_lanes;
+    const unsigned gb32 = (unsigned)cdiv((uint64_t)n * 32, (uint64_t)256), gr32 = (unsigned)std::max<uint64_t>(1, cdiv((uint64_t)nr * 32, (uint64_t)256));
+    if (lanes32) {
+      hipLaunchKernelGGL(degree32_kernel, dim3(std::min(gb32, 4096u)), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
+      hipLaunchKernelGGL(adjacency32_kernel, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
+                         adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
+    } else {
+      hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
+    }
+    if (lanes32) {
+    } else if (K <= 64)
       hipLaunchKernelGGL(adjacency_kernel<64>, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
                          gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
     else
@@ -517,8 +631,11 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
     AS_TRY(rev_w.alloc(ctx, n_edges_dir));
     hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
                        rev_ptr.p, cursor.p, rev_src.p, rev_w.p, r0, nr);
-    hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
-                       rev_src.p, ucnt.p, r0);
+    if (lanes32)
+      hipLaunchKernelGGL(union_count32_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev_src.p, ucnt.p, r0);
+    else
+      hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
+                         rev_src.p, ucnt.p, r0);
     AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, nr, eptr.p));
     AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + nr, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
