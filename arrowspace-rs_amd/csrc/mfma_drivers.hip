@@ -426,8 +426,34 @@ __device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, ui
     }
   }
   if (__ballot(has_nan)) return C;  // NaN scores: leave the list alone
-  uint32_t prefix = 0u;
-  for (int bit = 31; bit >= 0; --bit) {
+  // the scores of a list share their leading bits (cosines of one neighbourhood): the search starts below the common prefix
+  uint32_t kmax = 0u, kmin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q)
+    if ((uint32_t)q * 64u < C && (uint32_t)q * 64u + lane < C) {
+      kmax = max(kmax, key[q]);
+      kmin = min(kmin, key[q]);
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+  }
+  const uint32_t diff = kmax ^ kmin;
+  const int top = diff ? 31 - __builtin_clz(diff) : -1;   // highest bit in which two scores differ
+  uint32_t prefix = top >= 31 ? 0u : (kmax & ~((2u << (top < 0 ? 0 : top)) - 1u));
+  if (top < 0) prefix = kmax;
+  // ... and stops where a step is worth less than delta / 8: tau only has to be a LOWER bound of the K-th largest score (a
+  // smaller tau keeps more candidates, never fewer), and clearing the low bits of a key lowers its score by less than 2^stop
+  // units in the last place of the largest score
+  int stop = 0;
+  if (delta > 0.0) {
+    const float top_score = fabsf(__uint_as_float((kmax & 0x80000000u) ? (kmax & 0x7FFFFFFFu) : ~kmax));
+    int e = 0;
+    (void)frexpf(top_score, &e);                                  // top_score < 2^e: one unit in the last place <= 2^(e - 24)
+    stop = (int)floor(log2(delta / 8.0)) - (e - 24);
+    stop = stop < 0 ? 0 : stop;
+  }
+  for (int bit = top; bit >= stop; --bit) {
     const uint32_t trial = prefix | (1u << bit);
     uint32_t cnt = 0;
 #pragma unroll
