@@ -432,7 +432,8 @@ def main():
                 rr_bytes = (scored + rows_here) * 8.0 * d + stats["knn_join_candidates"] * 8.0 + rows_here * (2 * 1536.0 + 17 * 12.0)
                 add("knn_rerank", "rerank_score_d128_kernel (+ rerank_prune_kernel: lists -> pruned records -> gathered 1 KB rows, sequential "
                                   "f64 chains in the reference's order, ranking, certification)",
-                    "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes of the surviving candidates' rows + lists + records + table",
+                    "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes of the surviving candidates' rows + lists + records + table as REQUESTED "
+                    "(rows are visited in image order, so part of the candidate rows is found in L2: `traffic` is what came from HBM)",
                     {"scored_candidates_per_row": scored / max(1, rows_here)}, pmc=("rerank_score_d128_kernel", "rerank_prune_kernel"))
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
@@ -445,10 +446,11 @@ def main():
                 "2 n^2 d (the full square is contracted)")
         nnz = float(state.get("nnz", 0))
         if nnz > 0 and world == 1:
-            add("graph_assembly", "graph assembly (degree_kernel, adjacency_kernel, fill_reverse_kernel, union_count_kernel, write_rows_kernel)",
+            add("graph_assembly", "graph assembly (degree32_kernel, adjacency32_kernel, fill_reverse_kernel, union_count32_kernel, write_rows_kernel)",
                 "hbm", rows_here * 17 * 16.0 + nnz * 16.0 + (rows_here + 1) * 8.0, HBM_PEAK_GBS, "GB/s",
                 "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out",
-                pmc=("degree_kernel", "adjacency_kernel", "fill_reverse_kernel", "union_count_kernel", "write_rows_kernel", "write_rows_big_kernel"))
+                pmc=("degree_kernel", "degree32_kernel", "adjacency_kernel", "adjacency32_kernel", "fill_reverse_kernel", "union_count_kernel",
+                     "union_count32_kernel", "write_rows_kernel", "write_rows_big_kernel", "scan_block_sums", "scan_of_sums", "scan_finish"))
         roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
         reference_equivalent = None
         if stats["knn_join"] == 1:

@@ -105,6 +105,10 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               (and 2 = at the first search, for "search_scan_order")
  *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
  *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
+ *   "rerank_order" (1), "assembly_lanes" (1), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
+ *                               exact re-rank in the order of the join's image, graph assembly with 32 lanes per row,
+ *                               nearest-centroid keys of a clustering batch on the f32 matrix pipe, clustering batches
+ *                               on the device (0 = the older form of each, kept for comparison)
  *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);
@@ -179,7 +183,9 @@ int as_compute_optimal_k(as_ctx *ctx, const double *rows, uint64_t n_rows, uint6
                          double *radius_out, uint64_t *id_out);
 /* run_incremental_clustering_with_sampling without a sampler (:547-910).  batch = 1 is the reference's sequential mode
  * (with_seed) exactly; a larger batch takes the snapshot of :571-594 once per batch (a legal schedule of its parallel
- * mode) and lets a row also see the centroids created earlier in its batch.  centroids_out: max_clusters x n_features,
+ * mode) and lets a row also see the centroids created earlier in its batch; a batch ends with the row that creates the
+ * last centroid max_clusters allows (the next one starts with a snapshot of all of them).  No row visits the host for
+ * n_features <= 1024.  centroids_out: max_clusters x n_features (the first *n_clusters_out rows are written),
  * assignments_out[n_rows] (-1: dropped), counts_out[max_clusters]. */
 int as_incremental_clustering(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t n_features, uint64_t max_clusters,
                               double radius, uint64_t batch, double *centroids_out, uint64_t *n_clusters_out,
