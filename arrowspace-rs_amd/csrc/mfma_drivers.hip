@@ -800,6 +800,9 @@ int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_
 int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                          const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
                          uint32_t *cnt, uint32_t *cand, const char *prof_name);
+int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
+                                     const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out);
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin = 0,
@@ -1121,10 +1124,15 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   }
   // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
   // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
-  if (reorder_wide && d <= 128 && oj.order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 && !(ctx->opt_debug & 32) &&
-      ctx->opt_join_sample <= 0) {
+  const bool wide_grouped = d > 128 && join_on_f16(ctx, d) && pos_begin == 0 && (pos_count == 0 || pos_count == n) && !gather;  // (rows wider than 128: one GPU)
+  if (reorder_wide && (d <= 128 || wide_grouped) && oj.order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 &&
+      !(ctx->opt_debug & 32) && ctx->opt_join_sample <= 0) {
     const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
+    if (d > 128)
+      AS_TRY(join_thresholds_f16_wide_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32,
+                                              32, m, oj.theta_pos.p, m2, oj.theta2_pos.p));
+    else
     AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
                                        oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count));
     if (gather) {
@@ -1162,7 +1170,8 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_all, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n,
                        ns_all, chk_sid.p);  // (the same sampled positions, all of them: what differs is the restriction alone)
     AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
-    AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
+    if (d > 128) AS_TRY(join_thresholds_f16_wide(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
+    else AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
     hipLaunchKernelGGL(theta_check_count_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const float *)oj.theta_pos.p, stride,
                        (const float *)chk_t1.p, n_chk, 5e-3f, chk_bad.p);
     uint32_t h_bad = 0;

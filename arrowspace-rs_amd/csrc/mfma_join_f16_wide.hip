@@ -171,16 +171,24 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
   const uint32_t l_max = MODE == 0 ? 1 + n_norm + 1 : T2;
   const uint32_t n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8;
   const uint32_t xcd = blockIdx.x & 7u;
-  uint32_t t_row = 0xFFFFFFFFu, t_col = 0;  // MODE 2, thread 0: where the sweep stands
+  uint32_t t_row = 0xFFFFFFFFu, t_col = 0, t_end = 0;  // MODE 2, thread 0: where the sweep stands
   auto fetch_unit = [&]() {  // thread 0: the next valid pair into s_next
     if (kSweep) {
-      if (t_row == 0xFFFFFFFFu || ++t_col == I_count) {
+      // (MODE 2 with a_ids: the GROUPED sample -- a_ids[2 t], a_ids[2 t + 1] = the range of sample super tiles row super tile t
+      // sweeps: those of the pivot groups its rows belong to, join_thresholds_f16_wide_grouped)
+      if (t_row == 0xFFFFFFFFu || ++t_col == t_end) {
         const uint32_t v = atomicAdd(unit_counters, 1u);
         t_row = v < T2 ? v : 0xFFFFFFFFu;
         t_col = 0;
+        t_end = I_count;
         if (v >= T2) {
           s_next[0] = 0xFFFFFFFFu;
           return;
+        }
+        if (MODE == 2 && a_ids) {
+          t_col = a_ids[2 * v];
+          t_end = min(a_ids[2 * v + 1], I_count);
+          if (t_end <= t_col) t_end = t_col + 1;
         }
       }
       s_next[0] = I_begin + t_row;
@@ -661,6 +669,37 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
                      theta2_out);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  return AS_OK;
+}
+
+// The same thresholds from the GROUPED sample (mfma_theta_f16.hip: with the rows ordered by 1 024 pivots of their rotated
+// coordinates, a row super tile meets only the sampled rows of the groups nearest to its own: 2 - 4 sample super tiles instead of
+// n / 32 / 256 of them).  P_all: the image of all rows in that order; thresholds come out by image position.
+uint32_t grouped_sample_rows_per_group();
+int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges);
+int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
+                                     const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
+  const uint32_t per = grouped_sample_rows_per_group(), ns = np * per, row_supers = (n + kWS - 1) / kWS;
+  if (per % kWS != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: group sample size");
+  DevBuf<uint32_t> ids, ranges;
+  DevBuf<unsigned char> PS;
+  DevBuf<float> maxima;
+  AS_TRY(ids.alloc(ctx, ns));
+  AS_TRY(ranges.alloc(ctx, (size_t)2 * row_supers));
+  AS_TRY(grouped_sample_plan(ctx, perm, group_start, np, piv, piv_pitch, piv_dim, n, ids.p, ranges.p));
+  AS_TRY(PS.alloc(ctx, packed_vecs_f16(ns / kTileRows, d) * 16));
+  AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, ns, d, PS.p, ns / kTileRows));
+  AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));
+  AS_TRY(launch_wide<2>(ctx, "knn_join_thresholds", P_all, PS.p, ranges.p, KS, row_supers, 0, ns / kWS, n, ns, nullptr, 0, nullptr, nullptr,
+                        maxima.p));
+  hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, maxima.p, n, m, m2, theta_out, theta2_out);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 

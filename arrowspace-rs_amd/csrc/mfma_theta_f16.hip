@@ -376,6 +376,33 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
 // groups nearest to a row's own.
 // pos_begin / pos_count (a multiple of 256 / any; 0 / 0 = all): only the thresholds of that range of image positions are computed
 // (theta_out / theta2_out stay indexed by position of the WHOLE image) -- a rank of a build sharded by positions computes its own.
+// The plan of the grouped sample by itself (rows wider than 128 sweep it with the panelled kernel, mfma_join_f16_wide.hip):
+// ids[np x 512] = the sampled rows of the 16 groups nearest to each group (~0 beyond), unit_ranges[2 x units] = for every unit
+// of 256 image positions the range [lo, hi) of 256-row sample super tiles (two per group) of the groups it covers.
+uint32_t grouped_sample_rows_per_group() { return kGroupSlots; }
+namespace {
+__global__ void unit_ranges_kernel(const uint32_t *__restrict__ ug, uint32_t units, uint32_t *__restrict__ out) {
+  const uint32_t I = blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= units) return;
+  out[2 * I] = ug[2 * I] * (kGroupTiles / 2);
+  out[2 * I + 1] = (ug[2 * I + 1] + 1) * (kGroupTiles / 2);
+}
+}  // namespace
+int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
+                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges) {
+  static_assert(kGroupTiles % 2 == 0, "whole 256-row super tiles per group");
+  const uint32_t units = (n + 255) / 256;
+  DevBuf<uint32_t> near, ug;
+  AS_TRY(near.alloc(ctx, (size_t)np * kGroupNear));
+  AS_TRY(ug.alloc(ctx, (size_t)2 * units));
+  hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
+  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(cdiv(np, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm, ids);
+  hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, group_start, np, n, units, ug.p);
+  hipLaunchKernelGGL(unit_ranges_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ug.p, units, unit_ranges);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin,
