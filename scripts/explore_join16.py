@@ -40,7 +40,8 @@ for pipe in pipes:
         ctx.stat("knn_uncertified_rows_stage2"), ctx.stat("knn_join_blocks")),
         "grouped theta %d bad %d; prefilter %d blocks %d flagged %d delta %.5f rotated %d tail %.4f" % (ctx.stat("knn_join_theta_grouped"), ctx.stat("knn_join_theta_grouped_bad"), ctx.stat("knn_join_prefilter"), ctx.stat("knn_join_prefilter_blocks"),
             ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_join_prefilter_delta_e6") * 1e-6, ctx.stat("knn_join_prefilter_rotated"),
-            ctx.stat("knn_join_prefilter_tail_e6") * 1e-6), {k: round(v[0] / v[1], 2) for k, v in prof.items()}, flush=True)
+            ctx.stat("knn_join_prefilter_tail_e6") * 1e-6), {k: round(v[0] / v[1], 2) for k, v in prof.items()},
+        "TOTALS (ms, launches):", {k: (round(v[0], 2), v[1]) for k, v in prof.items()}, "sum %.1f" % sum(v[0] for v in prof.values()), flush=True)
 for dbg in [int(x) for x in os.environ.get("ABLATE", "").split(",") if x]:
     ctx.set_option("join_pipe", pipes[-1]); ctx.set_option("debug", dbg)
     for rep in range(2):
