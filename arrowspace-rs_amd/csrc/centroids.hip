@@ -12,7 +12,9 @@
 // A batch of the incremental clustering is 4 096 rows = 64 row tiles: too few workgroups for 256 CUs.  Then the centroid
 // chunks are dealt to gridDim.y workgroups per row tile, each leaves its minimum per row, and nearest_merge_kernel takes the
 // minimum of those with the smallest index among equal minima -- the same (index, distance) as the single sweep.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 #include "mfma_common.h"
@@ -156,6 +158,45 @@ __global__ __launch_bounds__(256) void euclid_pack_cents_kernel(const double *__
   if (lane == 0 && row < n) bsq[row] = (float)sq;
 }
 
+// The same image for MANY rows (Two-NN: every row of the matrix is a point): a workgroup per 128-row tile, panels of 64 k steps
+// through a padded LDS transpose, so that rows are read side by side (a row per wave instruction) and the image is written in
+// whole 1 KB lines (the wave-per-row form above scatters 4-byte words 1 KB apart: 1.4 ms per million rows against 0.4).
+__global__ __launch_bounds__(256) void euclid_pack_tile_kernel(const double *__restrict__ C, uint32_t n, uint32_t d, uint32_t KS2, float *__restrict__ P,
+                                                               float *__restrict__ bsq) {
+  __shared__ float s_t[64 * 257];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t T = blockIdx.x;
+  double sq[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) sq[r] = 0.0;
+  for (uint32_t p0 = 0; p0 < KS2; p0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const uint32_t row = T * 128 + (uint32_t)w * 32 + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t ks = p0 + lane, k = h * KS2 + ks;
+        const double v = (row < n && ks < KS2 && k < d) ? C[(size_t)row * d + k] : 0.0;
+        sq[r] = fma(v, v, sq[r]);
+        s_t[lane * 257 + w * 64 + r + 32 * h] = (float)v;
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < 64u * 256u; e += 256) {
+      const uint32_t ks = e >> 8, at = e & 255u;
+      if (p0 + ks < KS2) P[((size_t)T * KS2 + p0 + ks) * 256 + at] = s_t[ks * 257 + at];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    double v = sq[r];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const uint32_t row = T * 128 + (uint32_t)w * 32 + r;
+    if (lane == 0 && row < n) bsq[row] = (float)v;
+  }
+}
+
 // largest row norm (upper bound: fma sum, rounded up by a relative 1e-12 on the host); positive doubles order as integers
 __global__ __launch_bounds__(256) void max_sqnorm_kernel(const double *__restrict__ R, uint64_t n, uint32_t d, unsigned long long *__restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -176,48 +217,239 @@ __global__ __launch_bounds__(256) void max_sqnorm_kernel(const double *__restric
 // they are (f64 -> f32 on the way: lane l holds row g 32 + (l & 31), features (l >> 5) KS2 + ks), the centroids from the packed
 // image; all fragments of the wave are requested before the first MFMA (KS2 <= 64: d <= 128) or in panels of 64 k steps.
 __global__ __launch_bounds__(64) void euclid_keys_kernel(const double *__restrict__ rows, const float *__restrict__ PB, const float *__restrict__ bsq,
-                                                         uint32_t col_groups, uint32_t KS2, uint32_t nA, uint32_t nB, uint32_t d, uint32_t ldk,
-                                                         float *__restrict__ keys) {
+                                                         uint32_t col_groups, uint32_t g_splits, uint32_t a_groups, uint32_t KS2, uint32_t nA, uint32_t nB,
+                                                         uint32_t d, uint64_t ldk, float *__restrict__ keys, const float *__restrict__ PA) {
+  // blockIdx.x = split * col_groups + cg: the wave keeps the fragments of column group cg and meets the row groups
+  // split, split + g_splits, ... (a batch of the clustering: one row group per wave; Two-NN's 16 row groups against a million
+  // points: all of them per wave, so that the points are read once)
   const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
-  const uint32_t g = blockIdx.x / col_groups, cg = blockIdx.x - g * col_groups;
+  const uint32_t split = blockIdx.x / col_groups, cg = blockIdx.x - split * col_groups;
   const uint32_t J = cg >> 2, ng = cg & 3;
-  const uint32_t arow = g * 32 + lc;
-  const double *a_src = rows + (size_t)arow * d + (size_t)lh * KS2;
+  const float *b_src = PB + ((size_t)J * KS2 * 4 + ng) * 64 + lane;
   const bool pairs = (d & 1u) == 0;  // KS2 is a multiple of 16: every pair of features of a lane is 16-byte aligned then
   typedef double d2e __attribute__((ext_vector_type(2)));
-  const float *b_src = PB + ((size_t)J * KS2 * 4 + ng) * 64 + lane;
-  v16f32e acc;
+  const uint32_t col = cg * 32 + lc;
+  const float nb = col < nB ? bsq[col] : 0.f;
+  if (KS2 <= 64) {
+    float b[64];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (uint32_t k0 = 0; k0 < KS2; k0 += 64) {
-    float a[64], b[64];
+    for (int u = 0; u < 64; ++u) b[u] = (uint32_t)u < KS2 ? b_src[(size_t)u * 256] : 0.f;
+    for (uint32_t g = split; g < a_groups; g += g_splits) {
+      const uint32_t arow = g * 32 + lc;
+      const double *a_src = rows + (size_t)arow * d + (size_t)lh * KS2;
+      float a[64];
+      if (PA) {  // the rows as a packed f32 image as well (Two-NN's samples: read once per column group, 256 bytes per instruction)
+        const float *pa = PA + ((size_t)(g >> 2) * KS2 * 4 + (g & 3)) * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < 64; u += 2) {
-      const uint32_t ks = k0 + u, k = lh * KS2 + ks;
-      if (pairs) {
-        d2e v = {0.0, 0.0};
-        if (arow < nA && k < d) v = *reinterpret_cast<const d2e *>(a_src + ks);
-        a[u] = (float)v.x;
-        a[u + 1] = (float)v.y;
-      } else {
-        a[u] = (arow < nA && k < d) ? (float)a_src[ks] : 0.f;
-        a[u + 1] = (arow < nA && k + 1 < d) ? (float)a_src[ks + 1] : 0.f;
+        for (int u = 0; u < 64; ++u) a[u] = (uint32_t)u < KS2 ? pa[(size_t)u * 256] : 0.f;
+      } else
+#pragma unroll
+      for (int u = 0; u < 64; u += 2) {
+        const uint32_t k = lh * KS2 + u;
+        if (pairs) {
+          d2e v = {0.0, 0.0};
+          if (arow < nA && k < d) v = *reinterpret_cast<const d2e *>(a_src + u);
+          a[u] = (float)v.x;
+          a[u + 1] = (float)v.y;
+        } else {
+          a[u] = (arow < nA && k < d) ? (float)a_src[u] : 0.f;
+          a[u + 1] = (arow < nA && k + 1 < d) ? (float)a_src[u + 1] : 0.f;
+        }
+      }
+      v16f32e acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+      if (col < nB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t row = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < nA) keys[(size_t)row * ldk + col] = fmaf(-2.f, acc[r], nb);
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < 64; ++u) b[u] = k0 + u < KS2 ? b_src[(size_t)(k0 + u) * 256] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    return;
   }
-  const uint32_t col = cg * 32 + lc;
-  if (col < nB) {
-    const float nb = bsq[col];
+  for (uint32_t g = split; g < a_groups; g += g_splits) {  // rows wider than 128: panels of 64 k steps, both operands per panel
+    const uint32_t arow = g * 32 + lc;
+    const double *a_src = rows + (size_t)arow * d + (size_t)lh * KS2;
+    v16f32e acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t row = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < nA) keys[(size_t)row * ldk + col] = fmaf(-2.f, acc[r], nb);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (uint32_t k0 = 0; k0 < KS2; k0 += 64) {
+      float a[64], b[64];
+#pragma unroll
+      for (int u = 0; u < 64; u += 2) {
+        const uint32_t ks = k0 + u, k = lh * KS2 + ks;
+        if (pairs) {
+          d2e v = {0.0, 0.0};
+          if (arow < nA && k < d) v = *reinterpret_cast<const d2e *>(a_src + ks);
+          a[u] = (float)v.x;
+          a[u + 1] = (float)v.y;
+        } else {
+          a[u] = (arow < nA && k < d) ? (float)a_src[ks] : 0.f;
+          a[u + 1] = (arow < nA && k + 1 < d) ? (float)a_src[ks + 1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 64; ++u) b[u] = k0 + u < KS2 ? b_src[(size_t)(k0 + u) * 256] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (col < nB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < nA) keys[(size_t)row * ldk + col] = fmaf(-2.f, acc[r], nb);
+      }
     }
   }
+}
+
+// Two-NN (src/clustering.rs:117-147) from the same keys: per sampled row (one workgroup) the three smallest keys over all
+// points give the window k3 + 2 E that holds every point whose reference distance can be among the two smallest to OTHER
+// rows (the 2nd smallest key among the others is at most the 3rd overall); the points inside are measured in the reference's
+// arithmetic and the two smallest values kept.  A window with more than kTnList points (hundreds of duplicates of the
+// sampled row) raises `overflow`: the caller then runs the exact kernel for all samples.
+constexpr uint32_t kTnList = 512, kTnThreads = 1024;
+// per-point error of a key: c_dot |q| |p| (operands rounded to f32, d products summed by the matrix pipe) + c_sq |p|^2 (|p|^2
+// rounded to f32, the final fma); both factors carry the 1.05 of E above
+struct TnBound {
+  float c_dot, c_sq;
+};
+__global__ __launch_bounds__(kTnThreads) void two_nn_select_kernel(const double *__restrict__ rows, uint64_t n, uint32_t d, const double *__restrict__ samples,
+                                                                   const uint64_t *__restrict__ sample_ids, uint32_t ns, const float *__restrict__ keys,
+                                                                   const float *__restrict__ bsq, uint64_t ldk, TnBound bnd, double *__restrict__ out,
+                                                                   uint32_t *__restrict__ redo /* [0]: count, [1 ..]: samples */) {
+  __shared__ float s_k[kTnThreads][3];
+  __shared__ uint32_t s_list[kTnList];
+  __shared__ uint32_t s_cnt;
+  __shared__ double s_b[kTnThreads][2];
+  __shared__ float s_w, s_qn;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  if (s >= ns) return;
+  const float *kr = keys + (size_t)s * ldk;
+  const double *a = samples + (size_t)s * d;
+  if (tid < 64) {  // |q| rounded up
+    double q2 = 0.0;
+    for (uint32_t k = tid; k < d; k += 64) q2 = fma(a[k], a[k], q2);
+    for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+    if (tid == 0) s_qn = (float)(sqrt(q2) * (1.0 + 1e-6));
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const float qn = s_qn;
+  auto err = [&](float b2) -> float { return fmaf(bnd.c_dot * qn, sqrtf(b2) * 1.000001f, bnd.c_sq * b2); };
+  // the three smallest UPPER ends key + e over all points
+  float k1 = __builtin_inff(), k2 = k1, k3 = k1;
+  auto push = [&](float k) {
+    if (k < k3) {
+      if (k < k2) {
+        k3 = k2;
+        if (k < k1) {
+          k2 = k1;
+          k1 = k;
+        } else {
+          k2 = k;
+        }
+      } else {
+        k3 = k;
+      }
+    }
+  };
+  const uint64_t n4 = n & ~3ull;
+  for (uint64_t c = (uint64_t)tid * 4; c < n4; c += (uint64_t)kTnThreads * 4) {
+    const float4 kv = *reinterpret_cast<const float4 *>(kr + c), bv = *reinterpret_cast<const float4 *>(bsq + c);
+    push(kv.x + err(bv.x));
+    push(kv.y + err(bv.y));
+    push(kv.z + err(bv.z));
+    push(kv.w + err(bv.w));
+  }
+  for (uint64_t c = n4 + tid; c < n; c += kTnThreads) push(kr[c] + err(bsq[c]));
+  s_k[tid][0] = k1;
+  s_k[tid][1] = k2;
+  s_k[tid][2] = k3;
+  __syncthreads();
+  if (tid < 64) {  // 1024 triples -> 64 -> 1
+    k1 = k2 = k3 = __builtin_inff();
+    for (uint32_t t = tid; t < kTnThreads; t += 64)
+      for (int e = 0; e < 3; ++e) push(s_k[t][e]);
+    // (lane t reads and then overwrites only entries t, t + 64, ...: no other lane's input)
+    s_k[tid][0] = k1;
+    s_k[tid][1] = k2;
+    s_k[tid][2] = k3;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    k1 = k2 = k3 = __builtin_inff();
+    for (int t = 0; t < 64; ++t)
+      for (int e = 0; e < 3; ++e) push(s_k[t][e]);
+    s_w = k3;  // (+inf when fewer than three comparable keys: every point is inside)
+  }
+  __syncthreads();
+  const float w = s_w;
+  // every point whose LOWER end key - e reaches the window
+  for (uint64_t c0 = 0; c0 < n; c0 += kTnThreads) {
+    const uint64_t c = c0 + tid;
+    if (c < n) {
+      const float b2 = bsq[c];
+      if (kr[c] - err(b2) <= w) {
+        const uint32_t at = atomicAdd(&s_cnt, 1u);
+        if (at < kTnList) s_list[at] = (uint32_t)c;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  if (cnt > kTnList) {  // hundreds of points inside the window (duplicates of the sample, an outlier's loose bound): the exact kernel
+    if (tid == 0) redo[1 + atomicAdd(redo, 1u)] = s;
+    return;
+  }
+  const uint64_t my = sample_ids[s];
+  double b1 = __builtin_inf(), b2v = __builtin_inf();
+  for (uint32_t e = tid; e < cnt; e += kTnThreads) {
+    const uint64_t c = s_list[e];
+    if (c == my) continue;
+    const double *b = rows + c * d;
+    double v = 0.0;
+    for (uint32_t k = 0; k < d; ++k) {
+      const double diff = __dsub_rn(a[k], b[k]);
+      v = __dadd_rn(v, __dmul_rn(diff, diff));
+    }
+    if (v < b1) {
+      b2v = b1;
+      b1 = v;
+    } else if (v < b2v) {
+      b2v = v;
+    }
+  }
+  s_b[tid][0] = b1;
+  s_b[tid][1] = b2v;
+  __syncthreads();
+  if (tid == 0) {
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    const uint32_t lim = cnt < kTnThreads ? cnt : kTnThreads;
+    for (uint32_t t = 0; t < lim; ++t)
+      for (int e = 0; e < 2; ++e) {
+        const double v = s_b[t][e];
+        if (v < m1) {
+          m2 = m1;
+          m1 = v;
+        } else if (v < m2) {
+          m2 = v;
+        }
+      }
+    out[2 * (size_t)s] = m1;
+    out[2 * (size_t)s + 1] = m2;
+  }
+}
+
+__global__ void gather_sample_rows_kernel(const double *__restrict__ rows, const uint64_t *__restrict__ ids, uint32_t ns, uint32_t d,
+                                          double *__restrict__ out) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (uint64_t)ns * d) return;
+  out[e] = rows[ids[e / d] * d + e % d];
 }
 
 // one wave per row
@@ -305,6 +537,56 @@ __global__ __launch_bounds__(256) void euclid_rerank_kernel(const double *__rest
 
 }  // namespace
 
+// Two-NN on the matrix pipe: (b1, b2)[ns] = the two smallest squared distances of every sampled row to the other rows, the values
+// of the exact kernel bit for bit.  AS_ERR_UNSUPPORTED when the shape or the data do not allow it (the caller keeps the exact kernel).
+int two_nn_mfma(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const uint64_t *sample_ids_dev, uint64_t ns, double *out_dev,
+                std::vector<uint32_t> *redo_samples) {
+  redo_samples->clear();
+  if (!ctx->opt_nearest_mfma || n < 65536 || n >= (1ull << 31) || ns == 0 || ns > 4096 || d < 1 || d > 1024)
+    return AS_ERR_UNSUPPORTED;
+  double qmax2 = 0.0;
+  AS_TRY(max_row_sqnorm(ctx, rows, n, d, &qmax2));
+  if (!(qmax2 > 0.0 && qmax2 < 1e30)) return AS_ERR_UNSUPPORTED;  // (non-finite values, or keys that would leave f32)
+  ProfScope ps(ctx, "two_nn_mfma");
+  const uint32_t b_tiles = (uint32_t)cdiv(n, (uint64_t)kTileRows), KS2 = packed_units((uint32_t)d) * 16;
+  const uint64_t ldk = (uint64_t)b_tiles * kTileRows;
+  const uint32_t a_groups = (uint32_t)cdiv(ns, (uint64_t)32), col_groups = (uint32_t)cdiv(n, (uint64_t)32);
+  const uint32_t a_tiles = (a_groups + 3) / 4;
+  DevBuf<float> PB, PA, bsq, asq, keys;
+  DevBuf<double> S;
+  DevBuf<uint32_t> redo;
+  AS_TRY(PB.alloc(ctx, packed_elems(b_tiles, (uint32_t)d)));
+  AS_TRY(PA.alloc(ctx, packed_elems(a_tiles, (uint32_t)d)));
+  AS_TRY(bsq.alloc(ctx, ldk));
+  AS_TRY(asq.alloc(ctx, (size_t)a_tiles * kTileRows));
+  AS_TRY(keys.alloc(ctx, (size_t)ns * ldk));
+  AS_TRY(S.alloc(ctx, (size_t)a_tiles * kTileRows * d));
+  AS_TRY(redo.alloc(ctx, ns + 1));
+  AS_HIP(ctx, hipMemsetAsync(S.p, 0, sizeof(double) * (size_t)a_tiles * kTileRows * d, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(redo.p, 0, sizeof(uint32_t), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(bsq.p, 0, sizeof(float) * ldk, ctx->stream));
+  hipLaunchKernelGGL(gather_sample_rows_kernel, dim3((unsigned)cdiv(ns * d, (uint64_t)256)), dim3(256), 0, ctx->stream, rows, sample_ids_dev, (uint32_t)ns,
+                     (uint32_t)d, S.p);
+  hipLaunchKernelGGL(euclid_pack_tile_kernel, dim3(b_tiles), dim3(256), 0, ctx->stream, rows, (uint32_t)n, (uint32_t)d, KS2, PB.p, bsq.p);
+  hipLaunchKernelGGL(euclid_pack_tile_kernel, dim3(a_tiles), dim3(256), 0, ctx->stream, (const double *)S.p, (uint32_t)ns, (uint32_t)d, KS2, PA.p, asq.p);
+  hipLaunchKernelGGL(euclid_keys_kernel, dim3(col_groups), dim3(64), 0, ctx->stream, (const double *)S.p, (const float *)PB.p, (const float *)bsq.p,
+                     col_groups, 1u, a_groups, KS2, (uint32_t)ns, (uint32_t)n, (uint32_t)d, ldk, keys.p, KS2 <= 64 ? (const float *)PA.p : nullptr);
+  // |key - true key| <= c_dot |q| |p| + c_sq |p|^2 (see E above: (2 d + 2) 2^-23 for the products and their f32 sum, 2^-23 for |p|^2
+  // and the fma; the same 1.05, and the comparison itself in f32)
+  TnBound bnd{(float)(1.06 * (double)(2 * d + 4) * 0x1p-23), (float)(1.06 * 4.0 * 0x1p-23)};
+  hipLaunchKernelGGL(two_nn_select_kernel, dim3((unsigned)ns), dim3(kTnThreads), 0, ctx->stream, rows, n, (uint32_t)d, (const double *)S.p, sample_ids_dev,
+                     (uint32_t)ns, (const float *)keys.p, (const float *)bsq.p, ldk, bnd, out_dev, redo.p);
+  AS_HIP(ctx, hipGetLastError());
+  std::vector<uint32_t> h(ns + 1);
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), redo.p, sizeof(uint32_t) * (ns + 1)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  redo_samples->assign(h.begin() + 1, h.begin() + 1 + std::min<uint64_t>(h[0], ns));
+  std::sort(redo_samples->begin(), redo_samples->end());
+  ctx->stats["two_nn_mfma_overflow"] = (int64_t)redo_samples->size();
+  ctx->stats["two_nn_mfma"] = 1;
+  return AS_OK;
+}
+
 int max_row_sqnorm(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out) {
   DevBuf<unsigned long long> m;
   AS_TRY(m.alloc(ctx, 1));
@@ -340,7 +622,7 @@ int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, c
                        b_tiles * kTileRows, PB.p, bsq.p, redo.p + n);
     const uint32_t a_groups = a_tiles * 4, col_groups = (uint32_t)cdiv(n_cents, (uint64_t)32);
     hipLaunchKernelGGL(euclid_keys_kernel, dim3(a_groups * col_groups), dim3(64), 0, ctx->stream, rows, (const float *)PB.p, (const float *)bsq.p,
-                       col_groups, KS2, (uint32_t)n, (uint32_t)n_cents, (uint32_t)d, ldk, keys.p);
+                       col_groups, a_groups, a_groups, KS2, (uint32_t)n, (uint32_t)n_cents, (uint32_t)d, (uint64_t)ldk, keys.p, (const float *)nullptr);
     const double two_e = (2.0 * 1.05 * (double)(2 * d + 19) * 0x1p-23 * qmax2 + 1e-30) * (1.0 + 0x1p-18);
     const float two_e32 = std::nextafterf((float)two_e, INFINITY);
     hipLaunchKernelGGL(euclid_rerank_kernel, dim3((unsigned)cdiv(n, (uint64_t)4)), dim3(256), 0, ctx->stream, rows, n, (uint32_t)d, cents,

@@ -510,7 +510,9 @@ bool knn_join_applies(const as_ctx *ctx, uint32_t n, uint32_t d);  // for shard 
 // batch nearest_centroid (src/clustering.rs:913-928), centroids.hip
 int nearest_centroids(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const double *cents, uint64_t n_cents,
                       uint64_t *out_idx, double *out_d2, double qmax2 = 0.0);  // qmax2 > 0: bound of |row|^2, |centroid|^2 (MFMA candidates)
-int max_row_sqnorm(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out);  // upper bound; inf when a row is not finite
+int max_row_sqnorm(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *out);
+int two_nn_mfma(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const uint64_t *sample_ids_dev, uint64_t ns, double *out_dev,
+                std::vector<uint32_t> *redo_samples);  // AS_ERR_UNSUPPORTED: keep the exact kernel; redo_samples: those it must still do  // upper bound; inf when a row is not finite
 
 // rows [row_begin, row_begin + row_count) of the n x n Laplacian (the whole matrix: 0, n)
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,

@@ -505,6 +505,45 @@ int two_nn_ratios(as_ctx *ctx, const double *rows_dev, uint64_t n, uint64_t f, c
   AS_TRY(ids.alloc(ctx, ns));
   AS_TRY(part.alloc(ctx, n_chunks * ns * 2));
   AS_HIP(ctx, copy_h2d(ctx, ids.p, sample_ids_host, sizeof(uint64_t) * ns));
+  ctx->stats["two_nn_mfma"] = 0;
+  // keys on the f32 matrix pipe, exact distances of the points inside the error window (centroids.hip); the samples whose
+  // window holds too many points -- and every sample when the shape or the data rule the pass out -- take the exact kernel
+  std::vector<double> hb;
+  std::vector<uint32_t> redo;
+  bool have_mfma = false;
+  {
+    DevBuf<double> b12;
+    AS_TRY(b12.alloc(ctx, ns * 2));
+    const int rc = two_nn_mfma(ctx, rows_dev, n, f, ids.p, ns, b12.p, &redo);
+    if (rc == AS_OK) {
+      hb.resize(ns * 2);
+      AS_HIP(ctx, copy_d2h(ctx, hb.data(), b12.p, sizeof(double) * hb.size()));
+      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      have_mfma = true;
+    } else if (rc != AS_ERR_UNSUPPORTED) {
+      return rc;
+    }
+  }
+  auto ratio = [&](double b1, double b2) {
+    const double d1 = std::sqrt(b1), d2 = std::sqrt(b2);  // src/clustering.rs:135,141-147
+    return (n >= 3 && d1 > 1e-12) ? d2 / d1 : (double)NAN;
+  };
+  std::vector<uint64_t> ex_ids;       // samples of the exact pass and where their ratios go
+  std::vector<uint64_t> ex_slot;
+  if (have_mfma) {
+    for (uint64_t s = 0; s < ns; ++s) ratios_host[s] = ratio(hb[2 * s], hb[2 * s + 1]);
+    for (uint32_t s : redo) {
+      ex_ids.push_back(sample_ids_host[s]);
+      ex_slot.push_back(s);
+    }
+    if (ex_ids.empty()) return AS_OK;
+    AS_HIP(ctx, copy_h2d(ctx, ids.p, ex_ids.data(), sizeof(uint64_t) * ex_ids.size()));
+  } else {
+    for (uint64_t s = 0; s < ns; ++s) ex_slot.push_back(s);
+  }
+  const uint64_t ns_all = ns;
+  ns = ex_slot.size();
+  (void)ns_all;
   {
     ProfScope ps(ctx, "two_nn");
     hipLaunchKernelGGL(two_nn_kernel, dim3(cdiv(ns, kTnRows), (unsigned)n_chunks), dim3(256), 0, ctx->stream, rows_dev, n, f, ids.p, ns,
@@ -526,8 +565,7 @@ int two_nn_ratios(as_ctx *ctx, const double *rows_dev, uint64_t n, uint64_t f, c
           b2 = v;
         }
       }
-    const double d1 = std::sqrt(b1), d2 = std::sqrt(b2);  // src/clustering.rs:135,141-147
-    ratios_host[s] = (n >= 3 && d1 > 1e-12) ? d2 / d1 : NAN;
+    ratios_host[ex_slot[s]] = ratio(b1, b2);
   }
   return AS_OK;
 }

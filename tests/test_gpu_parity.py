@@ -1140,6 +1140,30 @@ def test_prestage_pieces_match_oracle(ctx, n, f):
     assert A.compute_optimal_k(torch.from_numpy(X).cuda(), ctx=ctx) == O.compute_optimal_k(X)   # device-resident rows
 
 
+@pytest.mark.parametrize("n,f", [(70000, 128), (66000, 40)])
+def test_two_nn_on_the_matrix_pipe_matches_oracle(ctx, n, f):
+    """From 65 536 rows on the two nearest distances of a sampled row come from f32 matrix-pipe keys with an exact re-measure of
+    the points inside the error window (csrc/centroids.hip: two_nn_mfma): the ratios are the oracle's bit for bit --
+    a sampled row with an exact duplicate elsewhere (d1 = 0: NaN ratio), near duplicates, a sampled row far from everything."""
+    X = _blobs(n, f, 40, seed=n + f, spread=0.6)
+    ids = O.pre_sample_indices(n, 500, 129)
+    X[int(ids[3])] = X[(int(ids[3]) + 17) % n]                      # the sampled row is a duplicate of another row
+    X[(int(ids[5]) + 1) % n] = X[int(ids[5])] * (1.0 + 1e-12)       # a near duplicate of a sampled row
+    X[int(ids[7])] += 500.0                                         # a sampled outlier
+    got = A.two_nn_ratios(X, ids, ctx=ctx)
+    assert ctx.stat("two_nn_mfma") == 1 and ctx.stat("two_nn_mfma_overflow") == 0
+    want = O.two_nn_ratios(X, ids)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(got[3])
+    ctx.set_option("nearest_mfma", 0)
+    try:
+        exact = A.two_nn_ratios(X, ids, ctx=ctx)
+        assert ctx.stat("two_nn_mfma") == 0
+    finally:
+        ctx.set_option("nearest_mfma", 1)
+    assert np.array_equal(exact, want, equal_nan=True)
+
+
 @pytest.mark.parametrize("batch", [1, 7, 256])
 def test_incremental_clustering_matches_oracle(ctx, batch):
     """src/clustering.rs:547-910 without a sampler: batch = 1 is the reference's sequential mode; larger batches take
