@@ -124,9 +124,8 @@ def recorded_traffic(kernel_substr, n, d):
         return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"]}
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if not (name.startswith("r03") and name.endswith("_pmc_traffic.json")):
-            continue
+    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x.startswith("r03") and x.endswith("_pmc_traffic.json"))
+    for name in files[-1:]:   # the newest pass only: a kernel that no longer exists must not bring an old file's bytes along
         try:
             with open(os.path.join(pdir, name)) as f:
                 j = json.load(f)
