@@ -544,6 +544,7 @@ int two_nn_mfma(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const u
   redo_samples->clear();
   if (!ctx->opt_nearest_mfma || n < 65536 || n >= (1ull << 31) || ns == 0 || ns > 4096 || d < 1 || d > 1024)
     return AS_ERR_UNSUPPORTED;
+  if ((double)ns * (double)n * 4.0 > 16e9) return AS_ERR_UNSUPPORTED;  // the key matrix (ns x n floats) is kept whole: 16 GB at most
   double qmax2 = 0.0;
   AS_TRY(max_row_sqnorm(ctx, rows, n, d, &qmax2));
   if (!(qmax2 > 0.0 && qmax2 < 1e30)) return AS_ERR_UNSUPPORTED;  // (non-finite values, or keys that would leave f32)
