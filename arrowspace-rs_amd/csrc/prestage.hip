@@ -1,15 +1,17 @@
 // prestage.hip -- the clustering pre-stage (src/clustering.rs) and the JL projection (src/reduction.rs) behind the
 // C ABI: what runs immediately before the hot path inside ArrowSpaceBuilder::build.
 //
-// Division of labour.  Everything that touches all N rows runs on the device in the reference's arithmetic:
+// Division of labour.  Everything that touches all N rows runs on the device, results in the reference's arithmetic:
 //   - Two-NN intrinsic dimension (src/clustering.rs:101-164): 500 sampled rows against all N rows, the two smallest
-//     Euclidean distances of each                                                              two_nn_kernel
+//     Euclidean distances of each                                    two_nn_mfma (centroids.hip) / two_nn_kernel
 //   - the nearest-centroid searches of the incremental clustering (:571-594) and of Lloyd's assignment step
-//                                                                                               nearest_centroids (centroids.hip)
+//                                                                     nearest_centroids (centroids.hip)
+//   - the decisions and running means of the incremental clustering (:596-905)
+//                                             cluster_seq_kernel, cluster_decide_kernel, cluster_apply_kernel
 //   - the JL projection of rows / queries (src/reduction.rs:180-203)                            jl_project_kernel
-// What works on the <= 1000-row sample or on one centroid at a time (Lloyd's update, the Calinski-Harabasz score,
-// the pilot threshold, the decisions and running means of the incremental clustering) is sequential bookkeeping on the
-// host, in the same order as the reference so that the oracle's restatement matches bit for bit.
+// What works on the <= 1000-row sample (Lloyd's update, the Calinski-Harabasz score, the pilot threshold) is sequential
+// bookkeeping on the host, in the same order as the reference so that the oracle's restatement matches bit for bit; so is
+// the incremental clustering of rows wider than 1024 or with cluster_on_device = 0 (the older form, kept for comparison).
 //
 // The reference's random draws (StdRng shuffles, smartcore's k-means, the ChaCha8 Gaussian stream) cannot be reproduced
 // without its Rust dependencies: the build's own seeded definitions replace them (same in oracle/prestage.c), so
