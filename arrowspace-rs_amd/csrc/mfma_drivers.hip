@@ -404,36 +404,28 @@ __global__ void join_count_stats_kernel(const uint32_t *__restrict__ cnt, uint32
 // exact cosine >= tau - delta, so a candidate below tau - 2 delta is strictly worse than K others and cannot be in
 // the top K (nor tie with it).  The survivors are compacted in place (order kept); returns their count.
 // rectify: distances of negative cosines all collapse to 1 and tie by index, so nothing is dropped at or below 0.
-__device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, uint32_t C, uint32_t K, double delta, int rectify,
-                                                     int lane) {
-  if (C <= K) return C;
-  // tau by bisection over the order-preserving integer image of the scores: the largest v with |{s >= v}| >= K.
-  // Counting is a compare + ballot + popcount per 64 scores and round (the scores stay in registers); ranking every
-  // score against every other one took 3 x C LDS round trips per row and made the pruning pass compute-bound.
-  constexpr int kSlots = 16;  // 64 x 16 = 1024 scores
-  if (C > 64u * kSlots) return C;
-  uint32_t key[kSlots];
+// tau for a list of at most 64 NS scores (NS = its number of 64-score slots: the loops below have exactly that length; with one
+// body for 16 slots and a test per slot, the tests were most of the pruning kernel's instructions for the usual 2 - 3 slots)
+template <int NS>
+__device__ __forceinline__ bool prune_tau(const float *es, uint32_t C, uint32_t K, double delta, int lane, float *tau_out) {
+  uint32_t key[NS];
   bool has_nan = false;
+  uint32_t kmax = 0u, kmin = 0xFFFFFFFFu;
 #pragma unroll
-  for (int q = 0; q < kSlots; ++q) {
+  for (int q = 0; q < NS; ++q) {
     const uint32_t c = (uint32_t)q * 64u + lane;
     key[q] = 0u;
-    if ((uint32_t)q * 64u < C && c < C) {  // (first test wave-uniform)
+    if (c < C) {
       const float sc = es[c];
       has_nan = has_nan || sc != sc;
       const uint32_t b = __float_as_uint(sc);
       key[q] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    }
-  }
-  if (__ballot(has_nan)) return C;  // NaN scores: leave the list alone
-  // the scores of a list share their leading bits (cosines of one neighbourhood): the search starts below the common prefix
-  uint32_t kmax = 0u, kmin = 0xFFFFFFFFu;
-#pragma unroll
-  for (int q = 0; q < kSlots; ++q)
-    if ((uint32_t)q * 64u < C && (uint32_t)q * 64u + lane < C) {
       kmax = max(kmax, key[q]);
       kmin = min(kmin, key[q]);
     }
+  }
+  if (__ballot(has_nan)) return false;  // NaN scores: leave the list alone
+  // the scores of a list share their leading bits (cosines of one neighbourhood): the search starts below the common prefix
   for (int o = 32; o > 0; o >>= 1) {
     kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
     kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
@@ -457,11 +449,29 @@ __device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, ui
     const uint32_t trial = prefix | (1u << bit);
     uint32_t cnt = 0;
 #pragma unroll
-    for (int q = 0; q < kSlots; ++q)
-      if ((uint32_t)q * 64u < C) cnt += (uint32_t)__builtin_popcountll(__ballot(key[q] >= trial));
+    for (int q = 0; q < NS; ++q) cnt += (uint32_t)__builtin_popcountll(__ballot(key[q] >= trial));  // (slots past C hold key 0 < trial)
     if (cnt >= K) prefix = trial;
   }
-  const float tau = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix);
+  *tau_out = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix);
+  return true;
+}
+
+__device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, uint32_t C, uint32_t K, double delta, int rectify,
+                                                     int lane) {
+  if (C <= K) return C;
+  // tau by bisection over the order-preserving integer image of the scores: the largest v with |{s >= v}| >= K.
+  // Counting is a compare + ballot + popcount per 64 scores and round (the scores stay in registers); ranking every
+  // score against every other one took 3 x C LDS round trips per row and made the pruning pass compute-bound.
+  if (C > 64u * 16u) return C;
+  float tau = 0.f;
+  bool ok;
+  const uint32_t ns = (C + 63u) / 64u;  // wave-uniform
+  if (ns <= 2) ok = prune_tau<2>(es, C, K, delta, lane, &tau);
+  else if (ns <= 3) ok = prune_tau<3>(es, C, K, delta, lane, &tau);
+  else if (ns <= 4) ok = prune_tau<4>(es, C, K, delta, lane, &tau);
+  else if (ns <= 8) ok = prune_tau<8>(es, C, K, delta, lane, &tau);
+  else ok = prune_tau<16>(es, C, K, delta, lane, &tau);
+  if (!ok) return C;
   const double thr = (double)tau - 2.0 * delta;
   if (rectify && thr <= 0.0) return C;
   uint32_t out = 0;
