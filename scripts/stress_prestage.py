@@ -22,13 +22,18 @@ for case in range(cases):
         while n * k * f > 3e9: n //= 2
         batch = int(rng.choice([1, 64, 1000, 4096]))
         nb = max(2, min(k, int(rng.integers(2, 80))))
+        many = case % 2 == 0   # every other clustering case: many clusters and large batches (the matrix-pipe nearest-centroid search)
+        if many:
+            k = int(rng.choice([80, 150, 317])); batch = int(rng.choice([2048, 4096])); nb = k + 20
+            n = max(n, 12 * batch)
+            while n * k * f > 6e9: f = max(2, f // 2)
         C0 = rng.normal(size=(nb, f)) * 3
         X = C0[rng.integers(0, nb, size=n)] + float(rng.choice([0.2, 0.5, 1.0])) * rng.normal(size=(n, f))
         if rng.random() < 0.5: X[n // 2] = X[n // 3]
         if rng.random() < 0.3: X[-5:] += 1e3
         if rng.random() < 0.2: X[n // 7, f // 2] = np.nan
         d2 = np.sum((X[:100] - X[100:200]) ** 2, axis=1)
-        radius = float(rng.choice([0.02, 0.1, 0.4, 1.0])) * float(np.nanmedian(d2))
+        radius = (float(rng.choice([0.01, 0.03])) if many else float(rng.choice([0.02, 0.1, 0.4, 1.0]))) * float(np.nanmedian(d2))
         t0 = time.time()
         c, a, s = A.incremental_clustering(X, k, radius, batch, ctx=ctx)
         t1 = time.time()
