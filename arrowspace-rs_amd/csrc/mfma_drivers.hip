@@ -1081,6 +1081,7 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
 // per row rather than a pass over the row -- are computed for that range of image positions (rows, when there is no order)
 // only, and gather(buffer of n elements, element bytes) completes the buffer on every rank (in place: the caller's own part
 // is where it belongs).  Everything else stays replicated.
+constexpr double kRotatedTailMax = 0.50;  // share of the rows' energy outside the 31 directions up to which the rotated first pass is taken
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
                      uint32_t pos_begin, uint32_t pos_count, const std::function<int(void *, size_t)> *gather) {
   if (!gather) {
@@ -1109,7 +1110,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     AS_TRY(oj.rot_norm.alloc(ctx, n));
     AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail));
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
-    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= 0.10;
+    // Measured at 1 M x 128 (scripts/time_hard.py, mixtures of rank 16 ... 128 with 1 024 ... 4 096 clusters): up to a tail of
+    // 0.44 the rotated 32-wide pass is never slower than the full-width one (within 2 %) and usually twice as fast (rank 64 / 2 048
+    // clusters, tail 0.28: 56 against 122 ms; rank 96 / 1 024 clusters, tail 0.37: 50 against 114) -- a loose tail term still
+    // separates clusters, and the pass costs a quarter of the full-width one.  (Until round 3 the cut was 0.10.)
+    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= kRotatedTailMax;
   }
   // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
   const bool reorder_wide = oj.wide_pre && ctx->opt_join_row_order && n >= 65536;

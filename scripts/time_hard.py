@@ -7,9 +7,12 @@ import arrowspace_amd as A
 from arrowspace_amd import synth
 n, d = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 128
 ctx = A.default_context()
+rank, clusters = 64, 4096
 for name, val in [a.split("=") for a in sys.argv[2:]]:
-    ctx.set_option(name, int(val))
-Xh, _ = synth.mixture_device(n, d, "cuda", seed=43, n_clusters=4096, rank=64)
+    if name == "rank": rank = int(val)
+    elif name == "clusters": clusters = int(val)
+    else: ctx.set_option(name, int(val))
+Xh, _ = synth.mixture_device(n, d, "cuda", seed=43, n_clusters=clusters, rank=rank)
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 A.build_laplacian_matrix(Xh, gp, ctx=ctx)
 for rep in range(2):
@@ -18,6 +21,6 @@ for rep in range(2):
     gl = A.build_laplacian_matrix(Xh, gp, ctx=ctx)
     ctx.synchronize(); dt = time.perf_counter() - t0
     pr = ctx.profile_all(); ctx.profile(False)
-    print("build %.1f ms nnz %d" % (dt * 1e3, gl.matrix.nnz()), {k: (round(v[0], 2), v[1]) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])},
+    print("rank %d clusters %d tail %.3f build %.1f ms nnz %d" % (rank, clusters, ctx.stat("knn_join_prefilter_tail_e6") * 1e-6, dt * 1e3, gl.matrix.nnz()), {k: (round(v[0], 2), v[1]) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])},
           {k: ctx.stat(k) for k in ("knn_join_prefilter_rotated", "knn_join_row_order", "knn_join_theta_grouped", "knn_uncertified_rows", "knn_join_candidates")}, flush=True)
     del gl
