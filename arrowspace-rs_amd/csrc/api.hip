@@ -436,6 +436,8 @@ int as_knn_cosine(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64_t di
   AS_TRY(validate_graph_args(ctx, rows, n_nodes, dim, params));
   if (!nbr_idx || !nbr_dist) return fail(ctx, AS_ERR_ARG, "null output");
   if (row_begin + row_count > n_nodes) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
+  ctx->stats["knn_join"] = 0;            // (statistics of THIS call: the paths that do not join leave them alone)
+  ctx->stats["knn_join_prefilter"] = 0;
   const uint32_t K = (uint32_t)params->topk + 1;
   DevIn<double> R;
   AS_TRY(R.bind(ctx, rows, n_nodes * dim));

@@ -1114,7 +1114,9 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     // 0.44 the rotated 32-wide pass is never slower than the full-width one (within 2 %) and usually twice as fast (rank 64 / 2 048
     // clusters, tail 0.28: 56 against 122 ms; rank 96 / 1 024 clusters, tail 0.37: 50 against 114) -- a loose tail term still
     // separates clusters, and the pass costs a quarter of the full-width one.  (Until round 3 the cut was 0.10.)
-    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= kRotatedTailMax;
+    // Rows wider than 128 have no full-width first pass to fall back to, only the dense panelled join, which costs d / 32 times
+    // the rotated pass: it is taken whatever it can rule out (400 k x 768, rank 64, tail 0.49: 68 against 170 ms).
+    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= (d > 128 ? 0.95 : kRotatedTailMax);
   }
   // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
   const bool reorder_wide = oj.wide_pre && ctx->opt_join_row_order && n >= 65536;
@@ -1318,6 +1320,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                         join_supported(ctx, n, d, 0);
   const bool use_join = js != nullptr || own_join;
   ctx->stats["knn_join"] = use_join ? 1 : 0;
+  if (!js) ctx->stats["knn_join_prefilter"] = 0;  // (not a leftover of the call before: only the 16-bit joins set it; with js the caller has just run the join)
   JoinSources local{};  // outlives the block below: the later stages still read js->packed
   // own join: the images, the order, the rotated coordinates and the thresholds (own_join_prepare) stay for the later stages;
   // a build sharded by image positions (csrc/sharded.hip) has prepared the same thing and hands it in with the lists

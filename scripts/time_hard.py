@@ -10,6 +10,7 @@ ctx = A.default_context()
 rank, clusters = 64, 4096
 for name, val in [a.split("=") for a in sys.argv[2:]]:
     if name == "rank": rank = int(val)
+    elif name == "d": d = int(val)
     elif name == "clusters": clusters = int(val)
     else: ctx.set_option(name, int(val))
 Xh, _ = synth.mixture_device(n, d, "cuda", seed=43, n_clusters=clusters, rank=rank)
