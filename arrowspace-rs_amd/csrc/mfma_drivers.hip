@@ -1081,7 +1081,7 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
 // per row rather than a pass over the row -- are computed for that range of image positions (rows, when there is no order)
 // only, and gather(buffer of n elements, element bytes) completes the buffer on every rank (in place: the caller's own part
 // is where it belongs).  Everything else stays replicated.
-constexpr double kRotatedTailMax = 0.50;  // share of the rows' energy outside the 31 directions up to which the rotated first pass is taken
+constexpr double kRotatedTailMax = 0.95;  // share of the rows' energy outside the 31 directions up to which the rotated first pass is taken
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
                      uint32_t pos_begin, uint32_t pos_count, const std::function<int(void *, size_t)> *gather) {
   if (!gather) {
@@ -1110,13 +1110,14 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     AS_TRY(oj.rot_norm.alloc(ctx, n));
     AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail));
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
-    // Measured at 1 M x 128 (scripts/time_hard.py, mixtures of rank 16 ... 128 with 1 024 ... 4 096 clusters): up to a tail of
-    // 0.44 the rotated 32-wide pass is never slower than the full-width one (within 2 %) and usually twice as fast (rank 64 / 2 048
-    // clusters, tail 0.28: 56 against 122 ms; rank 96 / 1 024 clusters, tail 0.37: 50 against 114) -- a loose tail term still
-    // separates clusters, and the pass costs a quarter of the full-width one.  (Until round 3 the cut was 0.10.)
-    // Rows wider than 128 have no full-width first pass to fall back to, only the dense panelled join, which costs d / 32 times
-    // the rotated pass: it is taken whatever it can rule out (400 k x 768, rank 64, tail 0.49: 68 against 170 ms).
-    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= (d > 128 ? 0.95 : kRotatedTailMax);
+    // Measured at 1 M x 128 (scripts/time_hard.py: mixtures of rank 16 ... 128 with 4 ... 50 000 clusters, duplicated rows, plain
+    // Gaussian rows): the rotated 32-wide pass was never slower than the full-width one (within 2 %) and usually twice as fast
+    // (rank 64 / 2 048 clusters, tail 0.28: 56 against 122 ms; rank 96 / 1 024 clusters, tail 0.37: 50 against 114) -- a loose
+    // tail term still separates clusters -- and where neither pass can rule anything out (Gaussian rows, tail 0.76: 204 against
+    // 248 ms) it simply costs a quarter of the other.  Rows wider than 128 have no full-width pass at all, only the dense
+    // panelled join, d / 32 times the cost of the pass (400 k x 768, rank 128, tail 0.69: 87 against 173 ms).  So the cut only
+    // keeps degenerate directions out.  (Until round 3 it was 0.10; join_prefilter = 2 still forces the full-width image.)
+    oj.wide_pre = ctx->opt_join_prefilter == 3 || tail <= kRotatedTailMax;
   }
   // (with the coordinates at hand the order is found on them: 32 columns instead of dim, a quarter of the pivot pass)
   const bool reorder_wide = oj.wide_pre && ctx->opt_join_row_order && n >= 65536;

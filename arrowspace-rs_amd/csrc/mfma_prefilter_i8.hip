@@ -1001,7 +1001,7 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
     double tail = 1.0;
     AS_TRY(rotated_basis(ctx, rows, norms, n, d, Qd.p, &tail));
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
-    rotated = ctx->opt_join_prefilter == 3 || tail <= 0.50;  // (as own_join_prepare: mfma_drivers.hip, kRotatedTailMax)
+    rotated = ctx->opt_join_prefilter == 3 || tail <= 0.95;  // (as own_join_prepare: mfma_drivers.hip, kRotatedTailMax)
   }
   ctx->stats["knn_join_prefilter_rotated"] = rotated ? 1 : 0;
   if (rotated) KS8 = 1;

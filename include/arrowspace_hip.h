@@ -97,9 +97,9 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "join_sample", "join_rank", "join_cap", "join_block"   threshold sample 1-in-N, order statistic,
  *                               list slots per row (0 = automatic: 32 / 4 / 512), column super tiles per work unit
  *   "join_prefilter"            int8 first pass in front of the f16 join (whole-matrix item graphs from
- *                               "join_prefilter_min_rows" = 65536 rows): 1 = on, on the rotated 32-wide image where its 31
- *                               directions carry at least half of the rows' energy (default), 2 = full-width image always,
- *                               3 = rotated always, 0 = off;
+ *                               "join_prefilter_min_rows" = 65536 rows): 1 = on, on the rotated 32-wide image (31 dominant
+ *                               directions + the tail norm; default), 2 = full-width image always, 3 = rotated always,
+ *                               0 = off;
  *                               "join_order_pivots" (1024), "join_theta_grouped" (1): the row order and the thresholds behind it
  *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
  *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never

@@ -7,14 +7,24 @@ import arrowspace_amd as A
 from arrowspace_amd import synth
 n, d = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 128
 ctx = A.default_context()
-rank, clusters = 64, 4096
+rank, clusters, kind, eps = 64, 4096, "mixture", 0.5
 for name, val in [a.split("=") for a in sys.argv[2:]]:
     if name == "rank": rank = int(val)
+    elif name == "kind": kind = val          # mixture | normal | dup (every row 16 times)
+    elif name == "eps": eps = float(val)
     elif name == "d": d = int(val)
     elif name == "clusters": clusters = int(val)
+    elif name in ("kind", "eps", "d"): pass
     else: ctx.set_option(name, int(val))
-Xh, _ = synth.mixture_device(n, d, "cuda", seed=43, n_clusters=clusters, rank=rank)
-gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+if kind == "normal":
+    Xh = torch.randn((n, d), dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+elif kind == "dup":
+    base, _ = synth.mixture_device(n // 16, d, "cuda", seed=43, n_clusters=clusters, rank=rank)
+    Xh = base.repeat_interleave(16, dim=0)[torch.randperm(n // 16 * 16, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))].contiguous()
+    n = Xh.shape[0]
+else:
+    Xh, _ = synth.mixture_device(n, d, "cuda", seed=43, n_clusters=clusters, rank=rank)
+gp = A.GraphParams(eps, 16, 16, 2.0, 0.25)
 A.build_laplacian_matrix(Xh, gp, ctx=ctx)
 for rep in range(2):
     ctx.profile(True)
