@@ -1943,7 +1943,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         double tail = 1.0;
         if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));  // (kept on failure: the next call reuses it)
         AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
-        ix->rot_state = tail <= 0.10 ? 1 : -1;
+        ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
       }
       if (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat) {
         const uint32_t tiles = packed_tiles_f16(n);
@@ -2077,7 +2077,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       double tail = 1.0;
       if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
       AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
-      ix->rot_state = tail <= 0.10 ? 1 : -1;
+      ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
       if (ix->rot_state == 1) {
         AS_HIP(ctx, hipMalloc(&ix->packed8, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, ix->scan_perm, n, d, ix->rot_q, ix->packed8, tiles, &ix->rot_err));

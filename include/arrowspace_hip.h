@@ -104,6 +104,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
  *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never
  *                               (and 2 = at the first search, for "search_scan_order")
+ *                               "search_rot_tail_e3" (100): the rotated images are kept when at most this share (x 1e-3) of the
+ *                               items' energy lies outside their 31 directions (measured on data of higher rank: no gain above)
  *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
  *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
  *   "rerank_order" (1), "assembly_lanes" (1), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
