@@ -341,6 +341,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "cluster_on_device") ctx->opt_cluster_on_device = value;
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "rerank_order") ctx->opt_rerank_order = value;
+  else if (n == "join_order_sub") ctx->opt_join_order_sub = value;
   else if (n == "search_rot_tail_e3") ctx->opt_search_rot_tail_e3 = value;
   else if (n == "assembly_lanes") ctx->opt_assembly_lanes = value;
   else if (n == "search_stream_quick") ctx->opt_search_stream_quick = value;

@@ -74,6 +74,7 @@ struct as_ctx {
   int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
   int64_t opt_assembly_lanes = 1;        // graph assembly: 32 lanes per row for degrees / weights + pruning / union sizes (K <= 32)
   int64_t opt_search_rot_tail_e3 = 100;  // a re-searched index keeps rotated int8 images when the tail of its items is at most this (x 1e-3)
+  int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_rerank_order = 1;          // exact re-rank of the join: rows visited in the order of the image (candidates shared through L2)
   int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)
   int64_t opt_cluster_on_device = 1;     // incremental clustering: batches after the last centroid is created stay on the device

@@ -771,7 +771,7 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
                   uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr);
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
-                    uint32_t *group_start = nullptr);
+                    uint32_t *group_start = nullptr, const float *piv_sub = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);

@@ -100,7 +100,9 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               "join_prefilter_min_rows" = 65536 rows): 1 = on, on the rotated 32-wide image (31 dominant
  *                               directions + the tail norm; default), 2 = full-width image always, 3 = rotated always,
  *                               0 = off;
- *                               "join_order_pivots" (1024), "join_theta_grouped" (1): the row order and the thresholds behind it
+ *                               "join_order_pivots" (1024), "join_theta_grouped" (1): the row order and the thresholds behind it;
+ *                               "join_order_sub" (4): inside a pivot's group the rows follow their nearest pivot of a second
+ *                               set of join_order_pivots / 4 pivots (0 = off)
  *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
  *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never
  *                               (and 2 = at the first search, for "search_scan_order")
