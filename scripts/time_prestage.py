@@ -15,7 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 ctx = A.default_context()
-Xd, _ = synth.mixture_device(n, d, torch.device("cuda:0"), seed=42)   # the bench's item matrix
+rank = int(os.environ.get("RANK_", "8")); clusters = int(os.environ.get("CLUSTERS_", "256"))
+Xd, _ = synth.mixture_device(n, d, torch.device("cuda:0"), seed=42, n_clusters=clusters, rank=rank)   # default: the bench's item matrix
 k_opt, radius, idim = API.compute_optimal_k(Xd, None, ctx=ctx)
 for rep in range(2):
     ctx.profile(True)
