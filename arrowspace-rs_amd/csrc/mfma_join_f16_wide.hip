@@ -675,7 +675,7 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
 // The same thresholds from the GROUPED sample (mfma_theta_f16.hip: with the rows ordered by 1 024 pivots of their rotated
 // coordinates, a row super tile meets only the sampled rows of the groups nearest to its own: 2 - 4 sample super tiles instead of
 // n / 32 / 256 of them).  P_all: the image of all rows in that order; thresholds come out by image position.
-uint32_t grouped_sample_rows_per_group();
+uint32_t grouped_sample_rows_per_group(uint32_t n, uint32_t np);
 int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                         uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges);
 int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
@@ -684,7 +684,7 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
-  const uint32_t per = grouped_sample_rows_per_group(), ns = np * per, row_supers = (n + kWS - 1) / kWS;
+  const uint32_t per = grouped_sample_rows_per_group(n, np), ns = np * per, row_supers = (n + kWS - 1) / kWS;
   if (per % kWS != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: group sample size");
   DevBuf<uint32_t> ids, ranges;
   DevBuf<unsigned char> PS;

@@ -242,8 +242,19 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
 // image ordered by 1024 pivots, restricting a row's sample to the sampled rows of the 16 pivot groups nearest to its own
 // moves the threshold of 0.5 % of the rows by more than 1e-3 and of none by 1e-2 (scripts/explore_theta_window.py) -- and
 // any threshold is correct -- for 1.7 % of the products.  So every group gets its own small sample image (the sampled rows
-// of its nearest groups, kGroupTiles tiles, zero rows beyond), and a unit sweeps the images of the groups it covers.
-constexpr uint32_t kGroupNear = 16, kGroupTiles = 4, kGroupSlots = kGroupTiles * 128;
+// of its nearest groups, group_tiles() tiles, zero rows beyond), and a unit sweeps the images of the groups it covers.
+constexpr uint32_t kGroupNear = 16;
+// sample rows kept per group: 128-row tiles, 4 of them where a group is ~1 000 rows (16 near groups x one position in 32 = 500
+// rows) and more for larger groups, up to 32 (4 M rows in 1 024 groups: 2 000 rows, half as many again for the groups larger
+// than the average -- with 4 tiles only the four nearest groups fitted, the check against the plain sample failed and the
+// plain pass cost 116 ms of a 574 ms table)
+static uint32_t group_tiles(uint32_t n, uint32_t np) {
+  const uint64_t near_rows = ((uint64_t)n / std::max(1u, np)) * kGroupNear / 32u;  // rows the near groups' samples hold
+  if (near_rows <= 512) return 4;
+  uint32_t t = (uint32_t)((near_rows * 3 / 2 + 127u) / 128u);
+  t = (t + 1u) & ~1u;  // whole 256-row super tiles
+  return std::min(32u, t);
+}
 
 // near[g][0 .. 16): the pivots most similar to pivot g (itself first).  piv: np x pitch floats.
 __global__ __launch_bounds__(256) void near_groups_kernel(const float *__restrict__ piv, uint32_t pitch, uint32_t dim, uint32_t np,
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256) void near_groups_kernel(const float *__restric
 
 // ids[g][slot]: the sampled rows (one image position in 32, hashed) of the groups near g, ~0 beyond; one thread per group
 __global__ void group_sample_ids_kernel(const uint32_t *__restrict__ near, const uint32_t *__restrict__ group_start, uint32_t np,
-                                        const uint32_t *__restrict__ perm, uint32_t *__restrict__ ids) {
+                                        const uint32_t *__restrict__ perm, uint32_t *__restrict__ ids, uint32_t kGroupSlots) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= np) return;
   uint32_t *out = ids + (size_t)g * kGroupSlots;
@@ -377,28 +388,30 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
 // pos_begin / pos_count (a multiple of 256 / any; 0 / 0 = all): only the thresholds of that range of image positions are computed
 // (theta_out / theta2_out stay indexed by position of the WHOLE image) -- a rank of a build sharded by positions computes its own.
 // The plan of the grouped sample by itself (rows wider than 128 sweep it with the panelled kernel, mfma_join_f16_wide.hip):
-// ids[np x 512] = the sampled rows of the 16 groups nearest to each group (~0 beyond), unit_ranges[2 x units] = for every unit
-// of 256 image positions the range [lo, hi) of 256-row sample super tiles (two per group) of the groups it covers.
-uint32_t grouped_sample_rows_per_group() { return kGroupSlots; }
+// ids[np x grouped_sample_rows_per_group()] = the sampled rows of the 16 groups nearest to each group (~0 beyond), unit_ranges[2 x units] = for every unit
+// of 256 image positions the range [lo, hi) of 256-row sample super tiles of the groups it covers.
+uint32_t grouped_sample_rows_per_group(uint32_t n, uint32_t np) { return group_tiles(n, np) * 128u; }
 namespace {
-__global__ void unit_ranges_kernel(const uint32_t *__restrict__ ug, uint32_t units, uint32_t *__restrict__ out) {
+__global__ void unit_ranges_kernel(const uint32_t *__restrict__ ug, uint32_t units, uint32_t *__restrict__ out, uint32_t supers_per_group) {
   const uint32_t I = blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= units) return;
-  out[2 * I] = ug[2 * I] * (kGroupTiles / 2);
-  out[2 * I + 1] = (ug[2 * I + 1] + 1) * (kGroupTiles / 2);
+  out[2 * I] = ug[2 * I] * supers_per_group;
+  out[2 * I + 1] = (ug[2 * I + 1] + 1) * supers_per_group;
 }
 }  // namespace
 int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                         uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges) {
-  static_assert(kGroupTiles % 2 == 0, "whole 256-row super tiles per group");
+  const uint32_t kGroupTiles = group_tiles(n, np), kGroupSlots = kGroupTiles * 128u;
   const uint32_t units = (n + 255) / 256;
   DevBuf<uint32_t> near, ug;
   AS_TRY(near.alloc(ctx, (size_t)np * kGroupNear));
   AS_TRY(ug.alloc(ctx, (size_t)2 * units));
   hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
-  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(cdiv(np, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm, ids);
+  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(cdiv(np, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm, ids,
+                     kGroupSlots);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, group_start, np, n, units, ug.p);
-  hipLaunchKernelGGL(unit_ranges_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ug.p, units, unit_ranges);
+  hipLaunchKernelGGL(unit_ranges_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ug.p, units, unit_ranges,
+                     kGroupTiles / 2);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
@@ -411,6 +424,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
   const uint32_t a_supers = (n + 255) / 256;
+  const uint32_t kGroupTiles = group_tiles(n, np), kGroupSlots = kGroupTiles * 128u;
   if (pos_count == 0 && pos_begin == 0) pos_count = n;
   if (pos_count == 0) return AS_OK;  // (a rank without positions)
   if (pos_begin % 256 != 0 || (uint64_t)pos_begin + pos_count > n) return fail(ctx, AS_ERR_ARG, "threshold pass: bad position range");
@@ -426,7 +440,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   ProfScope ps(ctx, "knn_join_thresholds");
   hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
   hipLaunchKernelGGL(group_sample_ids_kernel, dim3(cdiv(np, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm,
-                     ids.p);
+                     ids.p, kGroupSlots);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, group_start, np, n, a_supers, ug.p);
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
