@@ -409,11 +409,77 @@ __device__ void write_row_serial(uint32_t i, uint32_t li, const uint32_t *__rest
   }
 }
 
-// One WAVE per row: lane e holds one entry of the union (out-edges first, then the in-edges whose source is not an
-// out-neighbour), a 64-lane bitonic network orders them by column, the degree is the sequential sum in column order
-// (src/laplacian.rs:369), and the lanes write the finished row side by side.  Rows with more than 64 entries before
-// the duplicate check (hubs) take the serial form on one lane.  (One thread per row with its insertion sort on the
-// global scratch arrays was 7 of the 11 ms of the assembly at 1 M rows.)
+// W lanes per row (64, or 32 with two rows side by side in a wave): lane e of the row's lanes holds one entry of the union
+// (out-edges first, then the in-edges whose source is not an out-neighbour), a bitonic network over the W lanes orders them by
+// column, the degree is the sequential sum in column order (src/laplacian.rs:369), and the lanes write the finished row side
+// by side.  len / rs / nrev / li / i: per row, the same in all of its lanes.  (One thread per row with its insertion sort on
+// the global scratch arrays was 7 of the 11 ms of the assembly at 1 M rows.)
+template <int W>
+__device__ __forceinline__ void write_row_union(const int lane, const uint32_t li, const uint32_t i, const uint32_t len, const uint64_t rs,
+                                                const uint32_t nrev, const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+                                                const uint32_t K, const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
+                                                const uint64_t *__restrict__ eptr, uint64_t *__restrict__ indptr,
+                                                uint64_t *__restrict__ indices, double *__restrict__ data) {
+  const int l = lane & (W - 1), first = lane & ~(W - 1);  // lane within the row, the row's first lane
+  uint32_t col = 0xFFFFFFFFu;  // invalid entries sort to the end
+  double w = 0.0;
+  if ((uint32_t)l < len) {
+    col = adj_j[(uint64_t)i * K + l];
+    w = adj_w[(uint64_t)i * K + l];
+  } else if ((uint32_t)l < len + nrev) {
+    col = rev_src[rs + l - len];
+    w = rev_w[rs + l - len];
+  }
+  // in-edges whose source is already an out-neighbour are dropped (the out-edge carries the pair)
+  const uint32_t len_max = W == 64 ? len : max((uint32_t)__builtin_amdgcn_readlane((int)len, 0), (uint32_t)__builtin_amdgcn_readlane((int)len, 32));
+  bool dup = false;
+  for (uint32_t s = 0; s < len_max; ++s) {
+    const uint32_t a = __shfl(col, first + (int)s, 64);
+    dup = dup || (s < len && (uint32_t)l >= len && a == col);
+  }
+  if (dup) col = 0xFFFFFFFFu;
+  // bitonic sort of the W (col, w) pairs, ascending by column (columns of valid entries are distinct)
+#pragma unroll
+  for (int k = 2; k <= W; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t oc = __shfl_xor(col, j, 64);
+      const double ow = __shfl_xor(w, j, 64);
+      const bool up = (l & k) == 0;          // this lane's pair sorts ascending
+      const bool lower = (l & j) == 0;       // this lane keeps the smaller one when ascending
+      const bool take_min = up == lower;
+      const bool swap = take_min ? (oc < col) : (oc > col);
+      col = swap ? oc : col;
+      w = swap ? ow : w;
+    }
+  }
+  const unsigned long long row_lanes = W == 64 ? ~0ull : 0xFFFFFFFFull;
+  const unsigned long long valid = (__ballot(col != 0xFFFFFFFFu) >> first) & row_lanes;
+  const uint32_t L = (uint32_t)__builtin_popcountll(valid);  // = eptr[i + 1] - eptr[i]
+  const uint32_t L_max = W == 64 ? L : max((uint32_t)__builtin_amdgcn_readlane((int)L, 0), (uint32_t)__builtin_amdgcn_readlane((int)L, 32));
+  double degree = 0.0;
+  for (uint32_t s = 0; s < L_max; ++s) {
+    const double t = __shfl(w, first + (int)s, 64);
+    if (s < L) degree = __dadd_rn(degree, t);
+  }
+  const uint64_t o = eptr[li] + li;
+  const uint32_t below = (uint32_t)__builtin_popcountll((__ballot(col < i) >> first) & row_lanes);  // entries left of the diagonal
+  if (l == 0) {
+    indptr[li] = o;
+    indices[o + below] = i;
+    data[o + below] = degree;
+  }
+  if ((uint32_t)l < L) {
+    const uint64_t at = o + l + ((uint32_t)l >= below ? 1 : 0);
+    indices[at] = col;
+    data[at] = -w;
+  }
+}
+
+// A wave takes rows 2 w and 2 w + 1 of the range: side by side on its two halves when both unions have at most 32 entries
+// before the duplicate check (nearly all rows of a k-NN graph with k = 16: write_rows was 0.98 ms of the 2.9 ms assembly with
+// a wave per row), one after the other on all 64 lanes otherwise.  Rows with more than 64 entries (hubs) go to the list of
+// write_rows_big_kernel.
 __global__ __launch_bounds__(256) void write_rows_kernel(
     const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t n,
     uint32_t K, const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src, const double *__restrict__ rev_w,
@@ -422,66 +488,25 @@ __global__ __launch_bounds__(256) void write_rows_kernel(
     uint32_t *__restrict__ big_count, uint32_t r0) {
   // n = rows of the range [r0, r0 + n): li = position in it (eptr, rev_ptr, indptr), i = global row (adj_*, the diagonal)
   const int lane = threadIdx.x & 63;
-  const uint32_t li = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (li > n) return;
-  if (li == n) {
-    if (lane == 0) indptr[n] = eptr[n] + n;
-    return;
-  }
-  const uint32_t i = r0 + li;
-  const uint32_t len = adj_len[i];
-  const uint64_t rs = rev_ptr[li], re = rev_ptr[li + 1];
-  if (len + (re - rs) > 64) {  // hub rows (in-degree in the hundreds or thousands): one workgroup each, below
-    if (lane == 0) big_rows[atomicAdd(big_count, 1u)] = li;
-    return;
-  }
-  const uint32_t nrev = (uint32_t)(re - rs);
-  uint32_t col = 0xFFFFFFFFu;  // invalid entries sort to the end
-  double w = 0.0;
-  if ((uint32_t)lane < len) {
-    col = adj_j[(uint64_t)i * K + lane];
-    w = adj_w[(uint64_t)i * K + lane];
-  } else if ((uint32_t)lane < len + nrev) {
-    col = rev_src[rs + lane - len];
-    w = rev_w[rs + lane - len];
-  }
-  // in-edges whose source is already an out-neighbour are dropped (the out-edge carries the pair)
-  bool dup = false;
-  for (uint32_t s = 0; s < len; ++s) {
-    const uint32_t a = __shfl(col, (int)s, 64);
-    dup = dup || ((uint32_t)lane >= len && a == col);
-  }
-  if (dup) col = 0xFFFFFFFFu;
-  // bitonic sort of the 64 (col, w) pairs, ascending by column (columns of valid entries are distinct)
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t oc = __shfl_xor(col, j, 64);
-      const double ow = __shfl_xor(w, j, 64);
-      const bool up = (lane & k) == 0;          // this lane's pair sorts ascending
-      const bool lower = (lane & j) == 0;       // this lane keeps the smaller one when ascending
-      const bool take_min = up == lower;
-      const bool swap = take_min ? (oc < col) : (oc > col);
-      col = swap ? oc : col;
-      w = swap ? ow : w;
-    }
-  }
-  const unsigned long long valid = __ballot(col != 0xFFFFFFFFu);
-  const uint32_t L = (uint32_t)__builtin_popcountll(valid);  // = eptr[i + 1] - eptr[i]
-  double degree = 0.0;
-  for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, __shfl(w, (int)s, 64));
-  const uint64_t o = eptr[li] + li;
-  const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(col < i));  // entries left of the diagonal
-  if (lane == 0) {
-    indptr[li] = o;
-    indices[o + below] = i;
-    data[o + below] = degree;
-  }
-  if ((uint32_t)lane < L) {
-    const uint64_t at = o + lane + ((uint32_t)lane >= below ? 1 : 0);
-    indices[at] = col;
-    data[at] = -w;
+  const uint32_t liA = 2u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), liB = liA + 1;
+  if (liA > n) return;
+  if ((liA == n || liB == n) && lane == 0) indptr[n] = eptr[n] + n;
+  if (liA == n) return;
+  const bool haveB = liB < n;
+  const uint32_t lenA = adj_len[r0 + liA], lenB = haveB ? adj_len[r0 + liB] : 0u;
+  const uint64_t rsA = rev_ptr[liA], reA = rev_ptr[liA + 1], rsB = reA, reB = haveB ? rev_ptr[liB + 1] : reA;
+  const uint64_t cntA = lenA + (reA - rsA), cntB = lenB + (reB - rsB);
+  // hub rows (in-degree in the hundreds or thousands): one workgroup each, below
+  if (cntA > 64 && lane == 0) big_rows[atomicAdd(big_count, 1u)] = liA;
+  if (haveB && cntB > 64 && lane == 0) big_rows[atomicAdd(big_count, 1u)] = liB;
+  if (haveB && cntA <= 32 && cntB <= 32) {
+    const bool hb = lane >= 32;
+    write_row_union<32>(lane, hb ? liB : liA, r0 + (hb ? liB : liA), hb ? lenB : lenA, hb ? rsB : rsA, (uint32_t)(hb ? reB - rsB : reA - rsA), adj_j,
+                        adj_w, K, rev_src, rev_w, eptr, indptr, indices, data);
+  } else {
+    if (cntA <= 64) write_row_union<64>(lane, liA, r0 + liA, lenA, rsA, (uint32_t)(reA - rsA), adj_j, adj_w, K, rev_src, rev_w, eptr, indptr, indices, data);
+    if (haveB && cntB <= 64)
+      write_row_union<64>(lane, liB, r0 + liB, lenB, rsB, (uint32_t)(reB - rsB), adj_j, adj_w, K, rev_src, rev_w, eptr, indptr, indices, data);
   }
 }
 
@@ -658,7 +683,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   AS_HIP(ctx, hipMemsetAsync(big_count.p, 0, sizeof(uint32_t), st));
   {
     ProfScope ps(ctx, "graph_assembly");
-    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)nr + 1, 4)), dim3(256), 0, st, adj_j.p, adj_w.p,
+    hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)nr + 1, 8)), dim3(256), 0, st, adj_j.p, adj_w.p,
                        adj_len.p, nr, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,
                        m->indices, m->data, big_rows.p, big_count.p, r0);
     hipLaunchKernelGGL(write_rows_big_kernel, dim3(4096), dim3(256), 0, st, big_rows.p, big_count.p, adj_j.p, adj_w.p, adj_len.p,
