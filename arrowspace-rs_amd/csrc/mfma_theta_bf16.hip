@@ -107,7 +107,12 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
                                                             uint32_t row_count, const bf16x8 *__restrict__ PS,
                                                             uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
                                                             uint32_t m2, float *__restrict__ theta2_out,
-                                                            uint32_t *__restrict__ unit_counter, SearchTerm st) {
+                                                            uint32_t *__restrict__ unit_counter, SearchTerm st, uint32_t slices,
+                                                            float *__restrict__ part) {
+  // slices > 1: a unit is (super tile, slice of the sample) -- few rows against a long sample (a batch of queries: 40 super
+  // tiles on 256 CUs) -- and leaves its 64 sub-sample maxima per row in part[row][slice * 64 ..] for theta_select_kernel:
+  // more, smaller sub-samples, so the m-th largest of them is at least what one unit per super tile finds and never above
+  // the m-th best sampled value.
   constexpr int kPlaneVecs = KS * 4 * 64;   // 16-B vectors per plane of a 128-row tile
   constexpr int kTileVecs = 2 * kPlaneVecs;  // hi plane + lo plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,8 +137,10 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
     __syncthreads();
     if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
     __syncthreads();
-    const uint32_t I = s_unit;
-    if (I >= a_supers) break;
+    const uint32_t unit = s_unit;
+    if (unit >= a_supers * slices) break;
+    const uint32_t I = unit / slices, sl = unit - I * slices;
+    const uint32_t J_begin = (uint32_t)((uint64_t)(s_tiles / 2) * sl / slices) * 2, J_end = (uint32_t)((uint64_t)(s_tiles / 2) * (sl + 1) / slices) * 2;
 
     bf16x8 a_hi[KS], a_lo[KS];
     {
@@ -207,10 +214,10 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending
 
     __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring)
-    stage(0, 0, -1);
+    if (J_begin < J_end) stage(J_begin, 0, -1);
     __syncthreads();
     const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
-    for (uint32_t J = 0; J < s_tiles; J += 2) {
+    for (uint32_t J = J_begin; J < J_end; J += 2) {
 #define AS_IC(V) std::integral_constant<int, (V)>{}
 // block NN of the tile in buffer PAR (= its parity bin); PREV_PAR = bin of the block whose maxima are taken now
 #define AS_BLOCK(PAR, NN, NEXT, CUR, PREV, PREV_PAR, MORE, JN)      \
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
       }
       __syncthreads();  // tile J + 1 has landed; everyone is done with buffer 0
       {  // odd tile J + 1 (buffer 1, bin 1)
-        const bool more = J + 2 < s_tiles;
+        const bool more = J + 2 < J_end;
         const uint32_t b_addr = b_addr0 + kTileVecs * 16;
         float lx[4] = {0.f, 0.f, 0.f, 0.f};
         if (SEARCH) {
@@ -282,7 +289,9 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
       wm[((r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + 32 + lc] = rmax[1][r];
     }
     wave_sync();
-    if (lane < 32) {
+    if (slices > 1) {  // (wave-uniform) the maxima of this slice, 64 floats per row side by side
+      for (int r = 0; r < 32; ++r) part[((size_t)I * 256 + wv * 32 + r) * (64 * slices) + sl * 64 + lane] = wm[r * 65 + lane];
+    } else if (lane < 32) {
       const uint32_t row = I * 256 + wv * 32 + lane;
       float vals[64];
 #pragma unroll
@@ -311,6 +320,43 @@ __global__ __launch_bounds__(512, 2) void theta_bf16_kernel(const bf16x8 *__rest
   }
 }
 
+// theta[row] = the m-th largest (theta2: the max(m, m2)-th) of the `count` (a multiple of 64) sub-sample maxima of a row; a wave per row
+__global__ __launch_bounds__(256) void theta_select_kernel(const float *__restrict__ part, uint32_t count, uint32_t row_count, uint32_t m,
+                                                           float *__restrict__ theta_out, uint32_t m2, float *__restrict__ theta2_out) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= row_count) return;
+  constexpr int kMine = 8;  // count <= 512
+  float v[kMine];
+#pragma unroll
+  for (int j = 0; j < kMine; ++j) v[j] = (uint32_t)j * 64 + lane < count ? part[(size_t)row * count + (uint32_t)j * 64 + lane] : -__builtin_inff();
+  const uint32_t mm = theta2_out ? max(m, m2) : m;
+  float t = -__builtin_inff(), t1 = -__builtin_inff();
+  for (uint32_t k = 0; k < mm; ++k) {  // remove the current maximum (one instance of it) mm - 1 times
+    float best = v[0];
+    int at = 0;
+#pragma unroll
+    for (int j = 1; j < kMine; ++j) {
+      const bool gt = v[j] > best;
+      best = gt ? v[j] : best;
+      at = gt ? j : at;
+    }
+    float wbest = best;
+    for (int o = 32; o > 0; o >>= 1) wbest = __builtin_fmaxf(wbest, __shfl_xor(wbest, o, 64));
+    const unsigned long long holders = __ballot(best == wbest);
+    t = wbest;
+    if (k + 1 == m) t1 = wbest;
+    if (holders == 0) break;  // (NaN: cannot happen for finite images; leave the loop rather than spin)
+    if (lane == (uint32_t)__builtin_ctzll(holders)) {
+#pragma unroll
+      for (int j = 0; j < kMine; ++j) v[j] = j == at ? -__builtin_inff() : v[j];
+    }
+  }
+  if (lane == 0) {
+    if (theta2_out) theta2_out[row] = t;
+    theta_out[row] = t1;
+  }
+}
+
 }  // namespace
 
 // 16-B vectors of a split image (hi plane + lo plane per tile)
@@ -335,14 +381,19 @@ static int launch_theta(as_ctx *ctx, uint32_t KS, const void *PA, uint32_t a_sup
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   const size_t lds = std::max((size_t)2 * 2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
-  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
+  // few super tiles against a long sample: the sample is cut into slices, a unit per (super tile, slice)
+  uint32_t slices = 1;
+  if (st && a_supers < 128) slices = std::max(1u, std::min({8u, 256u / std::max(1u, a_supers), s_tiles / 16u}));
+  DevBuf<float> part;
+  if (slices > 1) AS_TRY(part.alloc(ctx, (size_t)a_supers * 256 * 64 * slices));
+  const unsigned grid = std::min<uint32_t>(a_supers * slices, 512u);
   const SearchTerm none{nullptr, nullptr, 0.f, 0.f};
   ProfScope ps(ctx, prof_name);
 #define AS_THETA1(K, S)                                                                                               \
   AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_bf16_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                   (int)lds));                                                                         \
   hipLaunchKernelGGL((theta_bf16_kernel<K, S>), dim3(grid), dim3(512), lds, ctx->stream, (const bf16x8 *)PA, a_supers, \
-                     row_count, (const bf16x8 *)PS, s_tiles, m, theta_out, m2, theta2_out, unitc.p, st ? *st : none)
+                     row_count, (const bf16x8 *)PS, s_tiles, m, theta_out, m2, theta2_out, unitc.p, st ? *st : none, slices, part.p)
 #define AS_THETA(K)                                                                                                    \
   case K:                                                                                                              \
     if (st) { AS_THETA1(K, true); } else { AS_THETA1(K, false); }                                                      \
@@ -353,6 +404,9 @@ static int launch_theta(as_ctx *ctx, uint32_t KS, const void *PA, uint32_t a_sup
   }
 #undef AS_THETA
 #undef AS_THETA1
+  if (slices > 1)
+    hipLaunchKernelGGL(theta_select_kernel, dim3(cdiv(row_count, 4)), dim3(256), 0, ctx->stream, (const float *)part.p, 64u * slices, row_count, m,
+                       theta_out, m2, theta2_out);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's images may go back to the workspace cache
   return AS_OK;
