@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libarrowspace_hip.so")
 
 (AS_OK, AS_ERR_SHAPE, AS_ERR_NONFINITE, AS_ERR_ZERO_LAMBDA, AS_ERR_NAN_SCORE, AS_ERR_DIM, AS_ERR_TOO_SPARSE,
- AS_ERR_ARG, AS_ERR_UNSUPPORTED, AS_ERR_HIP, AS_ERR_NO_DEVICE) = range(11)
+ AS_ERR_ARG, AS_ERR_UNSUPPORTED, AS_ERR_HIP, AS_ERR_NO_DEVICE, AS_ERR_PEER) = range(12)
 
 EXPORTS = [
     "as_abi_version", "as_ctx_create", "as_ctx_destroy", "as_last_error", "as_status_message", "as_ctx_set_stream",

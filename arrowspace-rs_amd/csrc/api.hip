@@ -238,6 +238,7 @@ const char *as_status_message(int status) {
     case AS_ERR_UNSUPPORTED: return "unsupported on the accelerated path";
     case AS_ERR_HIP: return "HIP runtime error";
     case AS_ERR_NO_DEVICE: return "no gfx950 device available (libarrowspace_hip has no CPU fallback)";
+    case AS_ERR_PEER: return "another rank of a sharded call failed";
     default: return "unknown status";
   }
 }
@@ -342,6 +343,9 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "rerank_order") ctx->opt_rerank_order = value;
   else if (n == "join_order_sub") ctx->opt_join_order_sub = value;
+  else if (n == "join_basis_iters") ctx->opt_join_basis_iters = value;
+  else if (n == "sharded_agreement") ctx->opt_sharded_agreement = value;
+  else if (n == "sharded_inject_failure") ctx->opt_sharded_inject_failure = value;
   else if (n == "search_rot_tail_e3") ctx->opt_search_rot_tail_e3 = value;
   else if (n == "assembly_lanes") ctx->opt_assembly_lanes = value;
   else if (n == "search_stream_quick") ctx->opt_search_stream_quick = value;

@@ -74,6 +74,9 @@ struct as_ctx {
   int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
   int64_t opt_assembly_lanes = 1;        // graph assembly: 32 lanes per row for degrees / weights + pruning / union sizes (K <= 32)
   int64_t opt_search_rot_tail_e3 = 100;  // a re-searched index keeps rotated int8 images when the tail of its items is at most this (x 1e-3)
+  int64_t opt_sharded_agreement = 1;     // sharded build: a one-word all-reduce of "has anyone failed" in front of every data collective (sharded.hip)
+  int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange) or 3 (before the nnz all-reduce)
+  int64_t opt_join_basis_iters = 4;      // rotated coordinates: rounds of subspace iteration on the 16 k-row sample (each 0.15 ms: three small kernels, two copies, a host Gram-Schmidt; hard mixture 98.2 / 94.7 / 93.2 / 93.9 ms at 2 / 3 / 4 / 5 rounds, the bench data indifferent from 3 on)
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_rerank_order = 1;          // exact re-rank of the join: rows visited in the order of the image (candidates shared through L2)
   int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)

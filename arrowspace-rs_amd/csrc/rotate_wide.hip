@@ -340,7 +340,8 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
       for (uint32_t k = 0; k < pitch; ++k) Q[(size_t)j * pitch + k] = k < d ? (float)V[(size_t)j * d + k] : 0.f;
   };
   orthonormalise();
-  for (int it = 0; it < 3; ++it) {  // Q <- orth(S^T S Q)
+  const int iters = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_basis_iters, 8));
+  for (int it = 0; it < iters; ++it) {  // Q <- orth(S^T S Q)
     AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(Ypart.p, 0, (size_t)y_blocks * kDirs * pitch * sizeof(float), ctx->stream));  // (columns d .. pitch stay 0)
     AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, rows, norms, (uint64_t)0, stride, ns, d, (const float *)Qd.p,

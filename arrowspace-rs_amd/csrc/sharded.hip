@@ -122,6 +122,44 @@ int gather_rows(as_ctx *ctx, as_comm *c, const void *mine, void *all, uint64_t n
   return rc == AS_OK ? AS_OK : fail(ctx, rc, "sharded build: all-gather failed");
 }
 
+// ---- every rank leaves a sharded build together ---------------------------------------------------------------------------------
+// A rank that fails locally (an allocation, a kernel, an unsupported shape found late) returns early -- and its peers would wait
+// for it in the next collective.  So every data collective of the build is preceded by a one-word all-reduce of "has anyone
+// failed": the ranks that are well add 0 and go on, a failing rank adds 1 ONCE on its way out, which is the agreement its peers
+// are about to enter, and they return AS_ERR_PEER.  (Option "sharded_agreement", default 1: ~10 all-reduces of 8 bytes per build.
+// A transport that fails inside a collective is not covered: that is the transport's own error path.)
+struct Agreement {
+  as_ctx *ctx;
+  as_comm *comm;
+  bool enabled;
+  bool settled = false;  // an agreement came back non-zero (or could not be run): every rank is leaving, nothing more to announce
+  DevBuf<uint64_t> word;
+  int run(uint64_t mine, uint64_t *sum) {
+    if (!word.p && word.alloc(ctx, 1) != AS_OK) return AS_ERR_HIP;
+    if (copy_h2d(ctx, word.p, &mine, sizeof(mine)) != hipSuccess) return AS_ERR_HIP;
+    if (comm->ops.all_reduce_sum_u64(comm->ops.user, word.p, 1, ctx->stream) != AS_OK) return AS_ERR_HIP;
+    if (copy_d2h(ctx, sum, word.p, sizeof(*sum)) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return AS_ERR_HIP;
+    return AS_OK;
+  }
+  int before_collective() {  // on a rank that is well
+    if (!enabled) return AS_OK;
+    uint64_t sum = 0;
+    if (run(0, &sum) != AS_OK) {
+      settled = true;
+      return fail(ctx, AS_ERR_HIP, "sharded build: the status agreement failed");
+    }
+    if (sum == 0) return AS_OK;
+    settled = true;
+    return fail(ctx, AS_ERR_PEER, "sharded build: " + std::to_string(sum) + " other rank(s) failed; this rank stops with them");
+  }
+  void announce_failure() {  // on a rank that failed locally, once
+    if (!enabled || settled) return;
+    settled = true;
+    uint64_t sum = 0;
+    (void)run(1, &sum);
+  }
+};
+
 // ---- lists of a build sharded by IMAGE POSITIONS ---------------------------------------------------------------------------
 // Every rank has prepared the same join (own_join_prepare: order, image, thresholds) and contracted the tile pairs of its own
 // range of positions; what it listed for positions of other ranks has crossed the links in compact form.  Here, per local
@@ -362,16 +400,37 @@ void as_comm_destroy(as_comm *c) {
 int as_comm_rank(const as_comm *c) { return c ? c->rank : -1; }
 int as_comm_world(const as_comm *c) { return c ? c->world : 0; }
 
+static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double *rows_shard, uint64_t n_total, uint64_t dim,
+                                        const as_graph_params *params, as_csr **out_block, uint64_t *nnz_total, asx::Agreement &ag);
+
 int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_shard, uint64_t n_total, uint64_t dim,
                                const as_graph_params *params, as_csr **out_block, uint64_t *nnz_total) {
   if (!ctx) return AS_ERR_ARG;
   if (!comm || !params || !out_block) return fail(ctx, AS_ERR_ARG, "null argument");
   *out_block = nullptr;
+  // (argument errors are the same on every rank: no agreement needed for them)
   if (n_total < 2 || dim < 2)
     return fail(ctx, AS_ERR_SHAPE, "items should be at least of shape (2,2): (" + std::to_string(n_total) + "," + std::to_string(dim) + ")");
   if (n_total >= 0xFFFFFFFFull || dim >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_nodes/dim must be < 2^32-1");
   AS_HIP(ctx, hipSetDevice(ctx->device));
+  asx::Agreement ag{ctx, comm, comm->world > 1 && ctx->opt_sharded_agreement != 0};
+  const int rc = build_laplacian_sharded_body(ctx, comm, rows_shard, n_total, dim, params, out_block, nnz_total, ag);
+  if (rc != AS_OK) {
+    const std::string msg = ctx->err;  // (the announcement must not replace what went wrong here)
+    ag.announce_failure();
+    ctx->err = msg;
+    if (*out_block) as_csr_free(*out_block);  // a caller that treats rc != 0 as "no outputs" must not leak the block
+    *out_block = nullptr;
+  }
+  return rc;
+}
+
+static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double *rows_shard, uint64_t n_total, uint64_t dim,
+                                        const as_graph_params *params, as_csr **out_block, uint64_t *nnz_total, asx::Agreement &ag) {
   const int W = comm->world, R = comm->rank;
+  auto inject = [&](int64_t at) -> int {  // test hook: this rank fails at checkpoint `at`
+    return ctx->opt_sharded_inject_failure == at ? fail(ctx, AS_ERR_ARG, "sharded build: injected failure (test hook)") : AS_OK;
+  };
   uint64_t lo, hi;
   shard_range(n_total, R, W, &lo, &hi);
   const uint64_t rows_here = hi - lo, K = params->topk + 1, n = n_total;
@@ -386,6 +445,8 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
   // ---- all rows on every rank (B side of the neighbour search, candidates' rows for the exact re-rank) ----
   DevBuf<double> X;
   AS_TRY(X.alloc(ctx, (size_t)n * dim));
+  AS_TRY(inject(1));
+  AS_TRY(ag.before_collective());
   AS_TRY(gather_rows(ctx, comm, rows_shard, X.p, n, dim * sizeof(double)));
 
   DevBuf<uint64_t> idx, idx_all;
@@ -414,6 +475,7 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
     // (the thresholds, the one MFMA sweep of the preparation, are computed per rank for its own positions and all-gathered in
     // place: 8 bytes per position)
     const std::function<int(void *, size_t)> gather_positions = [&](void *all, size_t elem_bytes) -> int {
+      AS_TRY(ag.before_collective());
       return gather_rows(ctx, comm, (const char *)all + lo * elem_bytes, all, n, elem_bytes);
     };
     AS_TRY(own_join_prepare(ctx, X.p, norms.p, n32, d32, K32, oj, lo32, here32, &gather_positions));
@@ -458,6 +520,8 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
                          (const uint32_t *)cnt.p, n, slots, (const uint64_t *)offsets.p, (const uint2 *)cand.p, (uint2 *)packed.p);
     AS_HIP(ctx, hipGetLastError());
     AS_TRY(cnt_src.alloc(ctx, (size_t)std::max<uint64_t>((uint64_t)W * rows_here, 1)));
+    AS_TRY(inject(2));
+    AS_TRY(ag.before_collective());  // (one agreement for the three exchanges of the lists: nothing that can fail locally sits between them but allocations sized by the peers)
     {
       const int rc = comm->ops.all_to_all_v(comm->ops.user, cnt.p, sb.data(), so.data(), cnt_src.p, rb.data(), ro.data(), ctx->stream);
       if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-to-all of the list counts failed");
@@ -524,6 +588,7 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
       DevBuf<double> dst_pos;
       AS_TRY(idx_pos.alloc(ctx, (size_t)n * K));
       AS_TRY(dst_pos.alloc(ctx, (size_t)n * K));
+      AS_TRY(ag.before_collective());
       AS_TRY(gather_rows(ctx, comm, idx.p, idx_pos.p, n, K * sizeof(uint64_t)));
       AS_TRY(gather_rows(ctx, comm, dst.p, dst_pos.p, n, K * sizeof(double)));
       hipLaunchKernelGGL(unpermute_table_kernel, dim3(cdiv(n * K, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)idx_pos.p,
@@ -531,6 +596,7 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
       AS_HIP(ctx, hipGetLastError());
       AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } else {
+      AS_TRY(ag.before_collective());
       AS_TRY(gather_rows(ctx, comm, idx.p, idx_all.p, n, K * sizeof(uint64_t)));
       AS_TRY(gather_rows(ctx, comm, dst.p, dst_all.p, n, K * sizeof(double)));
     }
@@ -543,6 +609,7 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
   } else {
     if (rows_here) AS_TRY(as_knn_cosine(ctx, X.p, n, dim, lo, rows_here, params, idx.p, dst.p));
     // ---- neighbour tables of all rows on every rank (the union symmetrisation needs the in-edges of a rank's rows) ----
+    AS_TRY(ag.before_collective());
     AS_TRY(gather_rows(ctx, comm, idx.p, idx_all.p, n, K * sizeof(uint64_t)));
     AS_TRY(gather_rows(ctx, comm, dst.p, dst_all.p, n, K * sizeof(double)));
   }
@@ -555,19 +622,16 @@ int as_build_laplacian_sharded(as_ctx *ctx, as_comm *comm, const double *rows_sh
     AS_TRY(as_laplacian_from_knn_rows(ctx, idx_all.p, dst_all.p, n, params, lo, rows_here, out_block));
     nnz = as_csr_nnz(*out_block);
   }
-  // (from here on a failure must not leave the block behind: a caller that treats rc != 0 as "no outputs" would leak it)
-  auto drop_block = [&](int rc) {
-    if (*out_block) as_csr_free(*out_block);
-    *out_block = nullptr;
-    return rc;
-  };
-  if (copy_h2d(ctx, nnz_d.p, &nnz, sizeof(nnz)) != hipSuccess) return drop_block(fail(ctx, AS_ERR_HIP, "sharded build: copy failed"));
+  AS_TRY(inject(3));
+  AS_TRY(ag.before_collective());
+  // (a failure from here on must not leave the block behind: the caller of this body frees it)
+  if (copy_h2d(ctx, nnz_d.p, &nnz, sizeof(nnz)) != hipSuccess) return fail(ctx, AS_ERR_HIP, "sharded build: copy failed");
   {
     const int rc = comm->ops.all_reduce_sum_u64(comm->ops.user, nnz_d.p, 1, ctx->stream);
-    if (rc != AS_OK) return drop_block(fail(ctx, rc, "sharded build: all-reduce failed"));
+    if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-reduce failed");
   }
   if (copy_d2h(ctx, &nnz, nnz_d.p, sizeof(nnz)) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-    return drop_block(fail(ctx, AS_ERR_HIP, "sharded build: copy failed"));
+    return fail(ctx, AS_ERR_HIP, "sharded build: copy failed");
   if (nnz_total) *nnz_total = nnz;
   return AS_OK;
 }

@@ -44,7 +44,8 @@ typedef enum {
   AS_ERR_ARG = 7,         /* null pointer / bad enum / unsupported size */
   AS_ERR_UNSUPPORTED = 8, /* outside the accelerated path (e.g. topk + 1 > 256, k > 4096) */
   AS_ERR_HIP = 9,         /* HIP runtime failure; text in as_last_error */
-  AS_ERR_NO_DEVICE = 10   /* no gfx950 device: there is no CPU fallback */
+  AS_ERR_NO_DEVICE = 10,  /* no gfx950 device: there is no CPU fallback */
+  AS_ERR_PEER = 11        /* as_build_laplacian_sharded: another rank failed locally; this rank stopped with it */
 } as_status;
 
 /* TauMode, src/taumode.rs:75-82 */
@@ -102,7 +103,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               0 = off;
  *                               "join_order_pivots" (1024), "join_theta_grouped" (1): the row order and the thresholds behind it;
  *                               "join_order_sub" (4): inside a pivot's group the rows follow their nearest pivot of a second
- *                               set of join_order_pivots / 4 pivots (0 = off)
+ *                               set of join_order_pivots / 4 pivots (0 = off);
+ *                               "join_basis_iters" (4): rounds of subspace iteration behind the 31 directions of the first pass
  *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
  *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never
  *                               (and 2 = at the first search, for "search_scan_order")
@@ -299,7 +301,10 @@ void as_csr_free(as_csr *m);
  * as_build_laplacian_sharded: rows_shard = this rank's rows ((hi - lo) x dim; host or device, a host shard is staged once); *out_block = its ROW
  * BLOCK of the Laplacian (see as_laplacian_from_knn_rows; NULL when the rank owns no rows), *nnz_total = nnz of the
  * whole matrix.  Stacking the blocks of ranks 0 .. world - 1 gives exactly the CSR of as_build_laplacian on all rows.
- * Every rank must make the call; a rank that fails locally returns early and leaves its peers waiting. */
+ * Every rank must make the call.  A rank that fails locally (an allocation, a kernel) returns its own status and its peers
+ * return AS_ERR_PEER instead of waiting for it: every data collective of the build is preceded by a one-word all-reduce
+ * of "has anyone failed" (option "sharded_agreement", default 1; 0 = none: a failing rank then leaves its peers waiting).
+ * A transport that fails INSIDE a collective is the transport's own error path.  No block is left behind on failure. */
 typedef struct as_comm as_comm;
 typedef struct as_comm_ops {
   void *user;

@@ -240,6 +240,60 @@ def _lib_worker(rank, world, port, n, d, out_dir):
         dist.destroy_process_group()
 
 
+def _lib_fail_worker(rank, world, port, n, d, stage, out_dir):
+    import arrowspace_amd as A
+    from arrowspace_amd import distributed as D
+    from tests import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = A.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx._stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_option("join_min_rows", 512)
+        comm = D.LibComm.torch_transport(ctx)
+        lo, hi = comm.shard_range(n)
+        X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+        gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+        sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp, A.TauMode.Median, libcomm=comm)
+        if rank == world - 1:
+            ctx.set_option("sharded_inject_failure", stage)  # this rank alone fails, at checkpoint `stage`
+        status, text = 0, ""
+        try:
+            sas.build_item_graph()
+        except A.ArrowSpaceError as e:
+            status, text = e.status, str(e)
+        ctx.set_option("sharded_inject_failure", 0)
+        gl = sas.build_item_graph()  # the communicator is in step again: the same call succeeds on every rank
+        np.savez(os.path.join(out_dir, "fail%d.npz" % rank), status=np.array(status), nnz=np.array(gl.nnz()), text=np.array(text))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,stage", [(2, 1), (2, 2), (3, 2), (2, 3)])
+def test_library_sharded_build_ranks_leave_together_when_one_fails(tmp_path, world, stage):
+    """One rank fails locally (test hook: before the row all-gather, before the list exchange, before the nnz all-reduce):
+    it returns its own status, its peers return AS_ERR_PEER instead of waiting in the collective it never reaches, no rank
+    hangs, and the next build on the same communicator succeeds."""
+    import arrowspace_amd as A
+    from arrowspace_amd import _lib
+    from oracle import oracle_ctypes as O
+    from tests import synth
+    n, d = 3000, 64
+    mp.spawn(_lib_fail_worker, args=(world, _free_port(), n, d, stage, str(tmp_path)), nprocs=world, join=True)
+    X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
+    nnz = len(O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))[1])
+    for k in range(world):
+        r = np.load(tmp_path / ("fail%d.npz" % k))
+        assert int(r["status"]) == (_lib.AS_ERR_ARG if k == world - 1 else _lib.AS_ERR_PEER), str(r["text"])
+        if k == world - 1:
+            assert "injected failure" in str(r["text"])
+        assert int(r["nnz"]) == nnz
+
+
 @pytest.mark.parametrize("n,world,d", [(3000, 2, 64), (1111, 2, 64), (3000, 3, 64), (1000, 3, 64), (3000, 2, 200)])
 def test_library_sharded_build_matches_single_process(tmp_path, n, world, d):
     """as_build_laplacian_sharded with 2 and 3 ranks on the one GPU (transport callbacks over gloo): the stacked row blocks
