@@ -57,7 +57,7 @@ struct as_ctx {
   int64_t opt_join_rank = 0;
   int64_t opt_join_cap = 0;
   int64_t opt_join_min_rows = 32768;
-  int64_t opt_join_block = 32;    // column super tiles per work unit of the bf16 join (1M x 128 on one device: 4 -> 304 ms, 8 .. 64 ->
+  int64_t opt_join_block = 64;    // column super tiles per work unit of the join passes, at most 64 (the masked pass lists a unit's <= 128 stages in LDS); 1 M x 128: 32 -> 45.0 ms, 64 -> 44.4, 16 -> 46.1, 8 -> 48.2 (r03n); the dense bf16 join of round 1: 4 -> 304 ms, 8 .. 64 ->
                                   // 291-293: longer units amortise the unit prologue; devices differ by more than that)
   int64_t opt_join_pipe = 16;     // contraction of the join: 16 = one f16 plane (dim <= 128; mfma_join_f16.hip), 48 = split bf16 in
                                   // two phases (dim <= 128; mfma_join_bf16.hip), 32 = f32 MFMA

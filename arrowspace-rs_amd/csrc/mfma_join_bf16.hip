@@ -437,7 +437,7 @@ static int join_bf16_launch(as_ctx *ctx, int mode, const JoinSearchTerm &st, con
 
   const bool rect = mode >= 1;
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
-  const uint32_t W = rect ? std::min(w_opt, T2) : std::max(1u, std::min(w_opt, T2 / 4));
+  const uint32_t W = rect ? std::min(std::min(w_opt, 32u), T2) : std::max(1u, std::min(w_opt, T2 / 4));  // (one-sided: few row super tiles, see join_f16_search)
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;

@@ -892,7 +892,10 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
   // (on an image ordered by direction, and all the more behind the first pass, a unit's work is what its blocks hold, not how
   // many columns it spans: small units balance it)
-  const uint32_t W = std::max(1u, std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_opt, 2u) : w_opt, std::max(1u, T2 / 4)));
+  // ... and the one-sided pass has few row super tiles (20 for 10 k queries, a dozen for the rows of a second pass): column blocks of at
+  // most 32 super tiles keep a thousand units for 256 CUs (64: search scan 4.3 -> 5.5 ms, second pass of the 4 M table 29 -> 42 ms)
+  const uint32_t w_one = std::min(w_opt, 32u);
+  const uint32_t W = std::max(1u, std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_one, 2u) : w_one, std::max(1u, T2 / 4)));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
