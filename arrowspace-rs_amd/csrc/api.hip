@@ -749,9 +749,13 @@ int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
 void as_csr_free(as_csr *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  (void)hipFree(m->indptr);
-  (void)hipFree(m->indices);
-  (void)hipFree(m->data);
+  if (m->slab) {
+    (void)hipFree(m->slab);
+  } else {
+    (void)hipFree(m->indptr);
+    (void)hipFree(m->indices);
+    (void)hipFree(m->data);
+  }
   if (m->packed) (void)hipFree(m->packed);
   if (m->packed_upper) (void)hipFree(m->packed_upper);
   if (m->v3_ent) (void)hipFree(m->v3_ent);

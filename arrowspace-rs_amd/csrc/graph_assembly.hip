@@ -672,9 +672,17 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   m->n_cols = n;
   m->row_begin = r0;
   m->nnz = nnz;
-  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * ((size_t)nr + 1)));
-  AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
-  AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
+  {  // one allocation for the three arrays (the handle outlives the call: not from the workspace cache)
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_ptr = up(sizeof(uint64_t) * ((size_t)nr + 1)), b_idx = up(sizeof(uint64_t) * (nnz ? nnz : 1)), b_val = up(sizeof(double) * (nnz ? nnz : 1));
+    if (hipMalloc(&m->slab, b_ptr + b_idx + b_val) != hipSuccess) {
+      delete m;
+      return fail(ctx, AS_ERR_HIP, "graph assembly: out of device memory for the CSR");
+    }
+    m->indptr = reinterpret_cast<uint64_t *>(m->slab);
+    m->indices = reinterpret_cast<uint64_t *>(static_cast<char *>(m->slab) + b_ptr);
+    m->data = reinterpret_cast<double *>(static_cast<char *>(m->slab) + b_ptr + b_idx);
+  }
   AS_TRY(ecol.alloc(ctx, n_union));
   AS_TRY(ew.alloc(ctx, n_union));
   DevBuf<uint32_t> big_rows, big_count;
