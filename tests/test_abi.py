@@ -40,6 +40,12 @@ def test_abi_version_and_messages():
         "Query item contains invalid values (NaN or infinity)")  # src/core.rs:534-537
     assert "too sparse" in lib.as_status_message(_lib.AS_ERR_TOO_SPARSE).decode()  # src/graph.rs:185-193
     assert "shape (2,2)" in lib.as_status_message(_lib.AS_ERR_SHAPE).decode()  # src/laplacian.rs:129-134
+    assert "another rank" in lib.as_status_message(_lib.AS_ERR_PEER).decode()  # the sharded build's status agreement
+    # the Python constants mirror the header's enum, one by one
+    import re
+    hdr = open(os.path.join(ROOT, "include", "arrowspace_hip.h")).read()
+    for name, value in re.findall(r"^\s*(AS_(?:OK|ERR_[A-Z_]+)) = (\d+)", hdr, flags=re.M):
+        assert getattr(_lib, name) == int(value), name
 
 
 def test_define_result_k_needs_no_device():
