@@ -303,7 +303,8 @@ void as_csr_free(as_csr *m);
  * whole matrix.  Stacking the blocks of ranks 0 .. world - 1 gives exactly the CSR of as_build_laplacian on all rows.
  * Every rank must make the call.  A rank that fails locally (an allocation, a kernel) returns its own status and its peers
  * return AS_ERR_PEER instead of waiting for it: every data collective of the build is preceded by a one-word all-reduce
- * of "has anyone failed" (option "sharded_agreement", default 1; 0 = none: a failing rank then leaves its peers waiting).
+ * of "has anyone failed" (option "sharded_agreement", default 1, the same value on every rank; 0 = none: a failing rank
+ * then leaves its peers waiting).
  * A transport that fails INSIDE a collective is the transport's own error path.  No block is left behind on failure. */
 typedef struct as_comm as_comm;
 typedef struct as_comm_ops {
