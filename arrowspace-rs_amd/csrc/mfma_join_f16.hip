@@ -910,13 +910,13 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
       hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
                          (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
-                         (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)mask, perm_a);       \
+                         (int)ctx->opt_debug, stamps.p, st, perm, (const unsigned long long *)mask, perm_a);       \
     } else {                                                                                                              \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, false>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
       hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,  \
                          (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
-                         (int)(ctx->opt_debug & ~8), stamps.p, st, perm, (const unsigned long long *)nullptr, perm_a);    \
+                         (int)ctx->opt_debug, stamps.p, st, perm, (const unsigned long long *)nullptr, perm_a);    \
     }                                                                                                                     \
     break;
   switch (KS) {
@@ -925,6 +925,17 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   }
 #undef AS_JOIN
   AS_HIP(ctx, hipGetLastError());
+  if (ctx->opt_debug & 8) {  // diagnostic: where a wave's cycles go (the stamps of the kernel; scripts/stamps_one_sided.py)
+    unsigned long long h[10];
+    AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double w = (double)std::max<unsigned long long>(1, h[4]);
+    std::fprintf(stderr,
+                 "[join_f16 one-sided stamps, %s, W %u, %llu units] per wave, Mcycles: unit prologue %.2f  blocks %.2f  dma wait %.2f  barrier %.2f; "
+                 "%llu blocks, %.3f through the walk; in the listing %.2f of which flushing %.2f\n",
+                 prof_name, W, (unsigned long long)units, h[0] / w / 1e6, h[1] / w / 1e6, h[2] / w / 1e6, h[3] / w / 1e6, h[5],
+                 h[5] ? (double)h[7] / h[5] : 0.0, h[6] / w / 1e6, h[8] / w / 1e6);
+  }
   return AS_OK;
 }
 
