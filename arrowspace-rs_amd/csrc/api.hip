@@ -344,6 +344,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "rerank_order") ctx->opt_rerank_order = value;
   else if (n == "join_order_sub") ctx->opt_join_order_sub = value;
   else if (n == "join_basis_iters") ctx->opt_join_basis_iters = value;
+  else if (n == "search_lambda_order") ctx->opt_search_lambda_order = value;
   else if (n == "sharded_agreement") ctx->opt_sharded_agreement = value;
   else if (n == "sharded_inject_failure") ctx->opt_sharded_inject_failure = value;
   else if (n == "search_rot_tail_e3") ctx->opt_search_rot_tail_e3 = value;

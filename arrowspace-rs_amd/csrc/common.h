@@ -70,6 +70,7 @@ struct as_ctx {
   int64_t opt_search_scan_f16 = 1; // threshold scan of the search (items up to 128 wide) on one f16 plane; 0: split bf16
   int64_t opt_search_scan_order = 1;  // search scan, dim <= 128: items (from 65,536) and large query batches grouped by direction:
                                       // 1 = from the second scan of an index on, 2 = at once, 0 = never
+  int64_t opt_search_lambda_order = 1;  // search scan on items in their own order: batches of 1024 queries or more go in the order of their lambdas
   int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
   int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
   int64_t opt_assembly_lanes = 1;        // graph assembly: 32 lanes per row for degrees / weights + pruning / union sizes (K <= 32)

@@ -770,6 +770,7 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
                   uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr);
+int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm);  // row_order.hip
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
                     uint32_t *group_start = nullptr, const float *piv_sub = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
@@ -2143,11 +2144,18 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     DevBuf<float> floor_pad, gmb_pad;
     // a large batch is put in the order of the items' image too (the same pivots): positions in the query image -> queries
     DevBuf<uint32_t> qperm;
-    const bool q_order = scan_h && ix->scan_perm && nq >= 2048;
+    // ... and on an index whose items are in their own order a batch goes in the order of its LAMBDAS: a row group of the scan
+    // then spans a narrow lambda range, and a lane can rule its column out by the lambda term from two scalars (the cosine alone
+    // reaching its floor sent half of all blocks of a 10 k-query batch through the walk; mfma_join_f16.hip)
+    const bool q_by_pivots = scan_h && ix->scan_perm && nq >= 2048;
+    const bool q_by_lambda = scan_h && !q_by_pivots && nq >= 1024 && ctx->opt_search_lambda_order && is_device_ptr(q_lambdas);
+    const bool q_order = q_by_pivots || q_by_lambda;
     if (q_order) {
       AS_TRY(qperm.alloc(ctx, nq));
-      AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
+      if (q_by_pivots) AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
+      else AS_TRY(order_by_value(ctx, q_lambdas, nq, qperm.p));
     }
+    ctx->stats["search_scan_lambda_order"] = q_by_lambda ? 1 : 0;
     if (scan_h) {
       AS_TRY(PQh.alloc(ctx, packed_vecs_f16(a_alloc, d) * 16));
       AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQh.p, a_alloc, q_order ? qperm.p : nullptr));
@@ -2202,7 +2210,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         AS_TRY(prefilter_i8_rect(ctx, ix->packed8, n, PQ8.p, a_supers, floor_pad.p, delta8, mask.p, "search_scan_prefilter"));
       }
       ctx->stats["search_scan_prefilter"] = pre ? 1 : 0;
-      ctx->stats["search_scan_order"] = q_order ? 1 : 0;
+      ctx->stats["search_scan_order"] = q_by_pivots ? 1 : 0;
       AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQh.p, nq, floor_pad.p, gmb_pad.p, q_order ? qlam_pos.p : qlam.p, x_lam_h,
                              (float)alpha, (float)beta, cap, cnt.p, cand.p, unitc.p, "search_scan_f16", ix->scan_perm,
                              q_order ? qperm.p : nullptr, pre ? mask.p : nullptr));

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     // max(acc + theta_row) >= theta_col); the few lanes that hold a pair (a block of clustered data typically has one)
     // put their 16 values into the wave's LDS slots, four lanes at a time, and the 64 lanes take one (slot, register)
     // entry each: one pass of ballots and queue writes instead of a 16-step walk over the accumulator registers.
+    float qlo0 = 0.f, qhi0 = 0.f, qlo1 = 0.f, qhi1 = 0.f;  // MODE 1: lambda range of the rows of the wave's two groups (set below, per unit)
     auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc) -> bool {
       if constexpr (MODE == 0 && MASKED) {
         // A block that gets here (the int8 first pass has removed the rest) holds ~9 pairs on average, dozens inside a cluster,
@@ -521,7 +522,20 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       v16f32 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
-      const bool hit = max16(acc) >= 0.f || (MODE == 0 && max16(v) >= tc);
+      bool hit = max16(acc) >= 0.f || (MODE == 0 && max16(v) >= tc);
+      if constexpr (MODE == 1) {
+        // The cosine alone reaching its floor says little where the lambda term matters: half of all blocks of a 10 k-query batch
+        // got here, 9 % hold a pair.  A pair passes the walk below when alpha * cos - pen >= g - beta with pen = min(|beta lq -
+        // beta lx|, beta), i.e. alpha * (cos - floor) >= pen, and pen >= min(beta * dist(lx, [lo, hi]), beta) for every row of the
+        // group: one more compare per lane, on the maximum it has already taken.  (4e-6 x magnitudes covers the roundings between
+        // this form and the walk's; the test only decides who is walked.)  It bites when the batch is in the order of its lambdas.
+        const bool g1 = ((row_group0 >> 5) & 1u) != 0;
+        const float lo = g1 ? qlo1 : qlo0, hi = g1 ? qhi1 : qhi0;
+        const float dist = __builtin_fmaxf(0.f, __builtin_fmaxf(lo - tc, tc - hi));
+        const float pen = __builtin_fminf(st.beta * dist, st.beta);
+        const float slack = 4e-6f * (1.f + st.beta * (__builtin_fabsf(tc) + __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi))));
+        hit = hit && (max16(acc) * (st.alpha * (1.f / kProductScale)) + slack >= pen);
+      }
       unsigned long long m = __ballot(hit);
       if (m == 0) return false;
       do {
@@ -590,6 +604,20 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     auto step_at = [&](uint32_t li) -> uint32_t { return MASKED ? __builtin_amdgcn_readfirstlane((uint32_t)s_step[li]) : li; };
     stage(tile_of(step_at(0)), 0, -1);
     __syncthreads();
+    if (MODE == 1) {  // the lambda range of the wave's two row groups (rows beyond the batch left out): what emit() bounds the lambda term by
+      const bool live = I * kSuperH + (uint32_t)wv * 64u + (uint32_t)lane < st.nq;
+      const float ql = s_qlam[wv * 64 + lane];
+      float lo = live ? ql : __builtin_inff(), hi = live ? ql : -__builtin_inff();
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        lo = __builtin_fminf(lo, __shfl_xor(lo, o, 64));
+        hi = __builtin_fmaxf(hi, __shfl_xor(hi, o, 64));
+      }
+      qlo0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 0));
+      qhi0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 0));
+      qlo1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 32));
+      qhi1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 32));
+    }
     if (stamp) {
       const unsigned long long t = now();
       t_unit += t - t_mark;

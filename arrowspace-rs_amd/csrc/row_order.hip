@@ -10,6 +10,8 @@
 // appends to the lists.  Nothing else sees the permutation: thresholds are scattered back to row order, the re-rank, its
 // tie-breaks by row id and every later stage work on the rows as given.  Any permutation is correct; this one is cheap
 // (about 2 ms at 1 M x 128) and needs no clustering from the caller.
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace asx {
@@ -355,6 +357,40 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out) {
   hipLaunchKernelGGL(scatter_f32_by_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, in, perm, n, out);
   AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// perm[p] = the index of the p-th smallest value (stable: equal values keep their order; NaNs last): the queries of a batch in
+// the order of their lambdas, so that the 32 rows of a row group of the search scan share a narrow lambda range (mfma_join_f16.hip)
+namespace {
+__global__ void value_keys_kernel(const double *__restrict__ v, uint32_t n, unsigned long long *__restrict__ keys, uint32_t *__restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = v[i];
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // order-preserving
+  if (x != x) b = ~0ull;
+  keys[i] = b;
+  ids[i] = i;
+}
+}  // namespace
+int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm) {
+  if (n == 0) return AS_OK;
+  DevBuf<unsigned long long> k_in, k_out;
+  DevBuf<uint32_t> ids;
+  DevBuf<unsigned char> tmp;
+  AS_TRY(k_in.alloc(ctx, n));
+  AS_TRY(k_out.alloc(ctx, n));
+  AS_TRY(ids.alloc(ctx, n));
+  hipLaunchKernelGGL(value_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, values, n, k_in.p, ids.p);
+  size_t bytes = 0;
+  AS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)k_in.p, k_out.p, (const uint32_t *)ids.p, perm, (int)n, 0, 64,
+                                                 ctx->stream));
+  AS_TRY(tmp.alloc(ctx, std::max<size_t>(bytes, 16)));
+  AS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, (const unsigned long long *)k_in.p, k_out.p, (const uint32_t *)ids.p, perm, (int)n, 0, 64,
+                                                 ctx->stream));
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the buffers go back to the workspace cache)
   return AS_OK;
 }
 

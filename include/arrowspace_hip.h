@@ -105,6 +105,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               "join_order_sub" (4): inside a pivot's group the rows follow their nearest pivot of a second
  *                               set of join_order_pivots / 4 pivots (0 = off);
  *                               "join_basis_iters" (4): rounds of subspace iteration behind the 31 directions of the first pass
+ *   "search_lambda_order" (1)   a batch of 1024 queries or more on an index whose items are in their own order is scanned in the
+ *                               order of its lambdas (a row group then spans a narrow lambda range: fewer blocks walked); 0 = as given
  *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
  *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never
  *                               (and 2 = at the first search, for "search_scan_order")

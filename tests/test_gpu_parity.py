@@ -1021,6 +1021,7 @@ def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
     asp.update_lambdas(lam)
     idx1, sc1 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
     assert ctx.stat("search_scan") == 1 and ctx.stat("search_scan_order") == 0 and ctx.stat("search_scan_prefilter") == 0
+    assert ctx.stat("search_scan_lambda_order") == 1  # items in their own order: the batch goes in the order of its lambdas
     idx2, sc2 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
     assert ctx.stat("search_scan_order") == 1 and ctx.stat("search_scan_prefilter") == 1
     assert 0 < ctx.stat("search_scan_prefilter_blocks_flagged") < ctx.stat("search_scan_prefilter_blocks") // 2
