@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
         const float dist = __builtin_fmaxf(0.f, __builtin_fmaxf(lo - tc, tc - hi));
         const float pen = __builtin_fminf(st.beta * dist, st.beta);
         const float slack = 4e-6f * (1.f + st.beta * (__builtin_fabsf(tc) + __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi))));
-        hit = hit && (max16(acc) * (st.alpha * (1.f / kProductScale)) + slack >= pen);
+        if (!(dbg & 0x400000)) hit = hit && (max16(acc) * (st.alpha * (1.f / kProductScale)) + slack >= pen);  // (debug bit 22: without the bound)
       }
       unsigned long long m = __ballot(hit);
       if (m == 0) return false;
@@ -605,9 +605,17 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     stage(tile_of(step_at(0)), 0, -1);
     __syncthreads();
     if (MODE == 1) {  // the lambda range of the wave's two row groups (rows beyond the batch left out): what emit() bounds the lambda term by
-      const bool live = I * kSuperH + (uint32_t)wv * 64u + (uint32_t)lane < st.nq;
+      const uint32_t my_row = I * kSuperH + (uint32_t)wv * 64u + (uint32_t)lane;
+      const bool live = my_row < st.nq;
       const float ql = s_qlam[wv * 64 + lane];
       float lo = live ? ql : __builtin_inff(), hi = live ? ql : -__builtin_inff();
+      // (a floor below -1.5 enters the accumulator clamped, thr_scaled: cos - floor is then not what the accumulator holds, and
+      // the bound does not apply to a group with such a row -- queries whose lambda term is at its floor for every item)
+      const unsigned long long clamped = __ballot(live && !(theta[my_row] >= -1.5f));
+      if (clamped & (lane < 32 ? 0xFFFFFFFFull : 0xFFFFFFFF00000000ull)) {
+        lo = -__builtin_inff();
+        hi = __builtin_inff();
+      }
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) {
         lo = __builtin_fminf(lo, __shfl_xor(lo, o, 64));

@@ -1003,6 +1003,39 @@ def test_search_scan_matches_oracle(ctx, scan_on, n, d, nq, k, alpha):
         assert np.array_equal(sc[j], osc), j
 
 
+@pytest.mark.parametrize("n,d,nq,k,alpha,spread", [(40_000, 128, 3000, 10, 0.7, 0.4), (36_000, 96, 1500, 7, 0.3, 5.0), (33_000, 128, 1100, 10, 0.9, 1e-6)])
+def test_search_scan_in_the_order_of_the_lambdas(ctx, n, d, nq, k, alpha, spread):
+    """A batch of 1024 queries or more on an index whose items are in their own order is scanned in the order of its
+    lambdas, a lane of the scan ruling its column out by the lambda range of the row group (csrc/mfma_join_f16.hip): the
+    oracle's results, the same with the order switched off; lambdas spread widely, narrowly, with duplicates, and queries
+    whose lambda lies outside the items' range (src/core.rs:229-239,760-798)."""
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=20, rank=5)
+    rng = np.random.default_rng(8)
+    lam = rng.random(n) * spread + 0.01
+    lam[::7] = lam[3]
+    qi = synth.query_indices(n, nq, seed=9)
+    Q = X[qi] * 0.97 + rng.normal(size=(nq, d)) * 0.01
+    lq = lam[qi] + rng.normal(size=nq) * 0.05 * spread
+    lq[:20] = lam.max() + 3.0 * spread + 2.0   # far outside: the lambda term is at its floor for every item
+    lq[20:40] = lq[41]
+    lq = np.abs(lq) + 1e-9
+    res = {}
+    try:
+        for order in (1, 0):
+            ctx.set_option("search_lambda_order", order)
+            asp = A.ArrowSpace(X, A.TauMode.Median, ctx)  # a fresh index: items in their own order
+            asp.update_lambdas(lam)
+            res[order] = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+            assert ctx.stat("search_scan") == 1 and ctx.stat("search_scan_lambda_order") == order
+    finally:
+        ctx.set_option("search_lambda_order", 1)
+    assert np.array_equal(np.asarray(res[0][0]), np.asarray(res[1][0])) and np.array_equal(np.asarray(res[0][1]), np.asarray(res[1][1]))
+    for j in list(range(0, 45)) + list(range(45, nq, max(1, nq // 40))):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], float(lq[j]), k, alpha)
+        assert np.array_equal(np.asarray(res[1][0])[j], oi.astype(np.int64))
+        assert np.array_equal(np.asarray(res[1][1])[j], osc)
+
+
 @pytest.mark.parametrize("n,d,nq,k,alpha", [(70_000, 128, 2500, 10, 0.7), (66_000, 64, 2100, 5, 1.0), (131_072, 100, 3000, 10, 0.4)])
 def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
     """An index of 65,536 items or more that is searched again keeps its f16 image grouped by direction, orders large query
