@@ -268,6 +268,15 @@ class CsrMatrix:
     def data(self):
         return self.to_host()[2]
 
+    def set_order(self, order):
+        """as_csr_set_order: order[position] = row, an order of the rows in which neighbours sit together (None removes it);
+        the item-graph lambda kernels visit the rows in it."""
+        if order is None:
+            self.ctx.check(self.ctx.lib.as_csr_set_order(self.ctx.h, self.h, None))
+            return
+        order = order if _lib.is_tensor(order) else np.ascontiguousarray(order, dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.as_csr_set_order(self.ctx.h, self.h, ptr(order)))
+
     def to_dense(self):
         indptr, indices, data = self.to_host()
         n = len(indptr) - 1
@@ -526,6 +535,24 @@ def compute_synthetic_lambda(x, matrix, tau, ctx=None):
     out = np.empty(1, dtype=np.float64)
     ctx.check(ctx.lib.as_compute_taumode(ctx.h, ptr(x), 1, x.shape[1], matrix.h, TauMode.FIXED, float(tau), ptr(out)))
     return float(out[0])
+
+
+def compute_taumode_signals(items, matrix, taumode=None, ctx=None):
+    """Lambdas of the feature COLUMNS of `items` (N x F) as signals over the item graph `matrix` (n x n, n <= N): for every
+    column f, compute_synthetic_lambda_csr(items[:, f], matrix, select_tau(items[:, f])) (src/taumode.rs:552-660, 87-127) --
+    TauMode::compute_taumode_lambdas_parallel on the transposed matrix, without the transpose.  Returns F values (a torch
+    tensor in HBM when the items are one)."""
+    ctx = ctx or matrix.ctx
+    taumode = taumode or TauMode.Median
+    X = _f64(items, ctx)
+    n, f = _shape2(X)
+    if _is_torch(X):
+        import torch
+        out = torch.empty(f, dtype=torch.float64, device=X.device)
+    else:
+        out = np.empty(f, dtype=np.float64)
+    ctx.check(ctx.lib.as_compute_taumode_signals(ctx.h, ptr(X), n, f, matrix.h, taumode.kind, taumode.arg, ptr(out)))
+    return out
 
 
 class ArrowSpace:

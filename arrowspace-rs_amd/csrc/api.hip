@@ -275,6 +275,7 @@ void as_ctx_destroy(as_ctx *ctx) {
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   join_session_close(ctx);
+  if (ctx->join_order) (void)hipFree(ctx->join_order);
   for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
   delete ctx;
 }
@@ -329,6 +330,11 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "stream_scan") ctx->opt_stream_scan = value;
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
+  else if (n == "signal_sym") ctx->opt_signal_sym = value;
+  else if (n == "signal_order") ctx->opt_signal_order = value;
+  else if (n == "signal_chunk_rows") ctx->opt_signal_chunk_rows = std::min<int64_t>(std::max<int64_t>(1, value), 1024);
+  else if (n == "signal_waves") ctx->opt_signal_waves = std::max<int64_t>(0, value);
+  else if (n == "signal_min_len") ctx->opt_signal_min_len = std::max<int64_t>(1, value);
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
@@ -696,8 +702,21 @@ int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
   AS_TRY(idx.alloc(ctx, n_nodes * K));
   AS_TRY(dist.alloc(ctx, n_nodes * K));
   AS_TRY(row_norms(ctx, R.p, n_nodes, dim, norms.p));
+  const uint64_t order_seq = ctx->join_order_seq;
   AS_TRY(knn_dispatch(ctx, R.p, norms.p, n_nodes, dim, 0, n_nodes, K, params, idx.p, dist.p));
   AS_TRY(laplacian_from_knn(ctx, idx.p, dist.p, n_nodes, K, params, out, 0, n_nodes));
+  if (ctx->join_order_seq != order_seq && ctx->join_order_n == n_nodes) {
+    // the neighbour search grouped the rows by direction: neighbours sit together in that order, which is what the item-graph
+    // lambda kernels want to visit the rows in (as_csr_set_order)
+    as_csr *m = *out;
+    if (hipMalloc((void **)&m->order, sizeof(uint32_t) * n_nodes) == hipSuccess) {
+      AS_HIP(ctx, hipMemcpyAsync(m->order, ctx->join_order, sizeof(uint32_t) * n_nodes, hipMemcpyDeviceToDevice, ctx->stream));
+      m->order_state = 1;
+    } else {
+      (void)hipGetLastError();
+      m->order = nullptr;
+    }
+  }
   return AS_OK;
 }
 
@@ -761,6 +780,8 @@ void as_csr_free(as_csr *m) {
   if (m->packed_upper) (void)hipFree(m->packed_upper);
   if (m->v3_ent) (void)hipFree(m->v3_ent);
   if (m->v3_diag) (void)hipFree(m->v3_diag);
+  signal_stream_release(m);
+  if (m->order) (void)hipFree(m->order);
   delete m;
 }
 
@@ -770,15 +791,54 @@ static int lambdas_common(as_ctx *ctx, const double *items, uint64_t n, uint64_t
                           double arg, bool check_finite, double *out) {
   AS_TRY(check_ctx(ctx));
   if (!items || !L || !out) return fail(ctx, AS_ERR_ARG, "null argument");
-  if ((L->n_cols && L->n_cols != L->n) || L->row_begin) return fail(ctx, AS_ERR_UNSUPPORTED, "a row block of a sharded graph is not a lambda graph");
+  if ((L->n_cols && L->n_cols != L->n) || L->row_begin) return fail(ctx, AS_ERR_UNSUPPORTED, "a row block of a sharded graph is not a lambda graph (as_compute_taumode_signals_sharded takes one)");
   if (F >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_UNSUPPORTED, "n_features too large");
+  if (L->n > F) return fail(ctx, AS_ERR_DIM, "graph has more nodes than the items have features");
+  if (mode < AS_TAU_FIXED || mode > AS_TAU_PERCENTILE) return fail(ctx, AS_ERR_ARG, "bad tau_mode");
   DevIn<double> X;
   AS_TRY(X.bind(ctx, items, n * F));
   DevOut<double> O;
   AS_TRY(O.bind(ctx, out, n));
-  AS_TRY(taumode_lambdas(ctx, X.p, n, F, const_cast<as_csr *>(L), mode, arg, check_finite, O.p));
+  if (F >= (uint64_t)ctx->opt_signal_min_len) {
+    // long signals (the rows-as-nodes graph of src/energymaps.rs:270): no per-item kernel holds one in LDS / registers; the
+    // signals become columns and the graph is streamed once for all of them (signal_lambda.hip)
+    if (check_finite) {
+      bool bad = false;
+      AS_TRY(any_nonfinite(ctx, X.p, n * F, &bad));
+      if (bad) return fail(ctx, AS_ERR_NONFINITE, as_status_message(AS_ERR_NONFINITE));
+    }
+    AS_TRY(signal_lambdas_rows(ctx, X.p, n, F, const_cast<as_csr *>(L), mode, arg, O.p));
+  } else {
+    AS_TRY(taumode_lambdas(ctx, X.p, n, F, const_cast<as_csr *>(L), mode, arg, check_finite, O.p));
+  }
   AS_TRY(O.finish(ctx));
   return AS_OK;
+}
+
+int as_compute_taumode_signals(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L, int tau_mode,
+                               double tau_arg, double *lambdas_out) {
+  AS_TRY(check_ctx(ctx));
+  if (!items || !L || !lambdas_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if ((L->n_cols && L->n_cols != L->n) || L->row_begin) return fail(ctx, AS_ERR_UNSUPPORTED, "a row block of a sharded graph: use as_compute_taumode_signals_sharded");
+  if (n_features == 0 || n_features >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad shape");
+  if (L->n > n_items) return fail(ctx, AS_ERR_DIM, "graph has more nodes than the signals have entries");
+  if (tau_mode < AS_TAU_FIXED || tau_mode > AS_TAU_PERCENTILE) return fail(ctx, AS_ERR_ARG, "bad tau_mode");
+  DevIn<double> X;
+  AS_TRY(X.bind(ctx, items, n_items * n_features));
+  DevOut<double> O;
+  AS_TRY(O.bind(ctx, lambdas_out, n_features));
+  AS_TRY(signal_lambdas(ctx, X.p, n_items, (uint32_t)n_features, const_cast<as_csr *>(L), tau_mode, tau_arg, O.p));
+  AS_TRY(O.finish(ctx));
+  return AS_OK;
+}
+
+int as_csr_set_order(as_ctx *ctx, as_csr *m, const uint32_t *order) {
+  AS_TRY(check_ctx(ctx));
+  if (!m) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (!order) return csr_set_order(ctx, m, nullptr);
+  DevIn<uint32_t> P;
+  AS_TRY(P.bind(ctx, order, m->n));
+  return csr_set_order(ctx, m, P.p);
 }
 
 int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L,
@@ -805,7 +865,8 @@ int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len
   AS_TRY(X.bind(ctx, rows, n_rows * len));
   DevOut<double> O;
   AS_TRY(O.bind(ctx, taus_out, n_rows));
-  AS_TRY(select_tau_rows(ctx, X.p, n_rows, len, tau_mode, tau_arg, O.p));
+  if (len >= (uint64_t)ctx->opt_signal_min_len) AS_TRY(signal_taus_rows(ctx, X.p, n_rows, len, tau_mode, tau_arg, O.p));  // an order statistic of a long slice: signal_lambda.hip
+  else AS_TRY(select_tau_rows(ctx, X.p, n_rows, len, tau_mode, tau_arg, O.p));
   AS_TRY(O.finish(ctx));
   return AS_OK;
 }

@@ -96,6 +96,11 @@ struct as_ctx {
   int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
   int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
+  int64_t opt_signal_sym = 1;            // item-graph lambda (signal_lambda.hip): a bitwise symmetric graph is streamed as its upper triangle
+  int64_t opt_signal_order = 1;          // ... in the order attached to the graph (as_csr_set_order / the join's own); 0: the rows as stored
+  int64_t opt_signal_chunk_rows = 16;    // ... consecutive rows a wave takes at a time
+  int64_t opt_signal_waves = 0;          // ... waves of the graph pass in all (0: one chunk per wave; else the waves of an XCD group interleave their chunks)
+  int64_t opt_signal_min_len = 9000;     // as_compute_taumode: signals this long or longer go through the item-graph kernels
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
   // Sharded join sequence (as_knn_join_thresholds -> _pairs -> _finish over the same `rows`): norms and the packed
@@ -113,6 +118,10 @@ struct as_ctx {
     size_t norms_cap = 0, packed_cap = 0, packed16_cap = 0, packedh_cap = 0, theta2_cap = 0;
   } join;
   double f16_err = -1.0;  // measured error of the f16 plane of the rows packed last (pack_f16_all), -1: none
+  // the row order the last whole-matrix join found (position -> row; row_order.hip): as_build_laplacian attaches a copy to the
+  // graph it returns, where the item-graph lambda kernels visit the rows in it (signal_lambda.hip)
+  uint32_t *join_order = nullptr;
+  uint64_t join_order_n = 0, join_order_cap = 0, join_order_seq = 0;
   // stats of the last call
   std::map<std::string, int64_t> stats;
   // profiling
@@ -140,6 +149,16 @@ struct as_csr {
   void *v3_ent = nullptr, *v3_diag = nullptr;
   uint32_t v3_steps = 0;
   double v3_scale = 1.0;
+  // record stream of the item-graph lambda kernels (signal_lambda.hip), built on first use
+  int sig_state = 0;            // 0: not prepared, 1: ready
+  void *sig_rec = nullptr;      // 16-byte records: per visited row a header and its kept off-diagonal entries
+  uint64_t *sig_off = nullptr;  // record offsets by stream slot (slots + 1)
+  uint64_t sig_nrec = 0;
+  uint32_t sig_ch = 0, sig_wx = 0, sig_k = 0, sig_c8 = 0;  // its geometry: rows per chunk, waves per XCD group, chunks per wave, chunks per group
+  int sig_sym = 0;              // the stream holds the upper triangle only (bitwise symmetric matrix)
+  int known_symmetric = 0;      // symmetric by construction (the library's own graphs and their row blocks)
+  uint32_t *order = nullptr;    // position -> row: an order of the rows in which neighbours sit together (device), or nullptr
+  int order_state = 0;          // 0: none, 1: given by the caller or the build
 };
 
 struct as_index {
@@ -531,6 +550,16 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
               double arg, bool check_finite, double *out, bool *handled);
 int select_tau_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode,
                     double arg, double *taus);
+// item-graph lambda (signal_lambda.hip): the S columns of X (n_len x S) against L; signals stored as rows; the pieces of the sharded form
+int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr *L, int mode, double arg, double *out);
+int signal_lambdas_rows(as_ctx *ctx, const double *items, uint64_t n_sig, uint64_t n_len, as_csr *L, int mode, double arg, double *out);
+int signal_sums(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr *L, uint64_t tail_begin, uint64_t tail_end, double *sums);
+int signal_taus(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau);
+int signal_taus_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode, double arg, double *taus);
+int signal_lambda_finish(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const double *tau, double *out);
+int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev);
+int any_nonfinite(as_ctx *ctx, const double *p, uint64_t count, bool *out);
+void signal_stream_release(as_csr *L);
 
 int search_exact(as_ctx *ctx, const as_index *ix, const double *queries, const double *q_norms,
                  const double *q_lambdas, const uint32_t *q_ids, uint64_t nq_sel, uint64_t nq,

@@ -666,17 +666,26 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
     AS_HIP(ctx, hipStreamSynchronize(st));
   }
   const uint64_t nnz = n_union + nr;
-  as_csr *m = new as_csr();
+  // the handle leaves through *out on success only: every early return below frees it and its slab
+  struct CsrHolder {
+    as_csr *p;
+    ~CsrHolder() {
+      if (p) as_csr_free(p);
+    }
+  } holder{new as_csr()};
+  as_csr *m = holder.p;
   m->device = ctx->device;
   m->n = nr;
   m->n_cols = n;
   m->row_begin = r0;
   m->nnz = nnz;
+  m->known_symmetric = 1;  // a union of pairs, one weight per pair (src/laplacian.rs:303-320): L_ij == L_ji bit for bit
   {  // one allocation for the three arrays (the handle outlives the call: not from the workspace cache)
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_ptr = up(sizeof(uint64_t) * ((size_t)nr + 1)), b_idx = up(sizeof(uint64_t) * (nnz ? nnz : 1)), b_val = up(sizeof(double) * (nnz ? nnz : 1));
     if (hipMalloc(&m->slab, b_ptr + b_idx + b_val) != hipSuccess) {
-      delete m;
+      (void)hipGetLastError();
+      m->slab = nullptr;
       return fail(ctx, AS_ERR_HIP, "graph assembly: out of device memory for the CSR");
     }
     m->indptr = reinterpret_cast<uint64_t *>(m->slab);
@@ -701,6 +710,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   ctx->stats["graph_directed_edges"] = (int64_t)n_edges_dir;
   ctx->stats["graph_nnz"] = (int64_t)nnz;
   *out = m;
+  holder.p = nullptr;
   return AS_OK;
 }
 

@@ -1336,6 +1336,20 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   if (use_join) {
     if (own_join) {
       AS_TRY(own_join_prepare(ctx, rows, norms, n, d, K, oj_local));
+      if (oj_local.reorder) {  // kept for the caller (as_build_laplacian hands it to the graph: common.h, join_order)
+        if (ctx->join_order_cap < n) {
+          if (ctx->join_order) (void)hipFree(ctx->join_order);
+          ctx->join_order = nullptr;
+          ctx->join_order_cap = 0;
+          if (hipMalloc((void **)&ctx->join_order, sizeof(uint32_t) * n) == hipSuccess) ctx->join_order_cap = n;
+          else (void)hipGetLastError();
+        }
+        if (ctx->join_order_cap >= n) {
+          AS_HIP(ctx, hipMemcpyAsync(ctx->join_order, oj_local.perm_own.p, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+          ctx->join_order_n = n;
+          ++ctx->join_order_seq;
+        }
+      }
       const uint32_t cap = oj_local.cap;
       AS_TRY(cnt_own.alloc(ctx, n));
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AS_ABI_VERSION 4
+#define AS_ABI_VERSION 5
 
 typedef enum {
   AS_OK = 0,
@@ -350,6 +350,25 @@ int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *i
  * Requires as_csr_n(L) <= n_features. */
 int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features,
                        const as_csr *L, int tau_mode, double tau_arg, double *lambdas_out);
+
+/* The same lambdas for SIGNALS OVER THE ITEM GRAPH (SURVEY.md section 8(a'), item-graph mapping): L is the n x n Laplacian of
+ * build_laplacian_matrix on the untransposed items (rows are nodes, src/energymaps.rs:270), a signal is a feature COLUMN of the
+ * n_items x n_features item matrix -- one value per node ("feature row over item nodes"), n <= n_items.  lambdas_out[f] =
+ * compute_synthetic_lambda_csr(column f, L, select_tau(column f)) (src/taumode.rs:552-660, 87-127): what
+ * as_compute_taumode returns for the transposed matrix (n_features items of n_items values each), without the transpose:
+ * the CSR is streamed once for all signals and each stored pair fetches the two item ROWS (algorithmic bytes nnz * 16 +
+ * n_items * n_features * 8).  as_compute_taumode itself takes this route for signals of "signal_min_len" (9000) values or more.
+ * Options: "signal_sym" (1: a bitwise symmetric L is streamed as its upper triangle), "signal_order" (1: rows visited in the
+ * order attached to L), "signal_chunk_rows" (16) / "signal_waves" (0 = one chunk per wave): the interleave of the graph pass; they take
+ * effect when the graph's record stream is next built (as_csr_set_order drops it). */
+int as_compute_taumode_signals(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L, int tau_mode,
+                               double tau_arg, double *lambdas_out);
+/* An order of the rows of L in which neighbours sit together (order[position] = row, a permutation of 0 .. n - 1, host or
+ * device; NULL removes it): the item-graph lambda kernels visit the rows in it so that the rows an entry fetches are still in
+ * cache.  Any permutation gives the same lambdas (to rounding of the sums); a host that knows its clustering (ArrowSpace's
+ * cluster_assignments, src/core.rs:373-377) passes the rows sorted by cluster.  Graphs built by as_build_laplacian carry the
+ * order their neighbour search found. */
+int as_csr_set_order(as_ctx *ctx, as_csr *m, const uint32_t *order);
 
 /* Batched ArrowSpace::prepare_query_item, src/core.rs:533-549 (projection off): fails with
  * AS_ERR_NONFINITE if any query value is NaN/inf. */

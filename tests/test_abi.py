@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_messages():
     lib = A.load()
-    assert lib.as_abi_version() == 4
+    assert lib.as_abi_version() == 5
     # the reference's panic texts travel through the boundary verbatim
     assert lib.as_status_message(_lib.AS_ERR_ZERO_LAMBDA).decode() == \
         "Lambda of the item is 0.0, prepare the item before searching"  # src/core.rs:773-776
