@@ -29,7 +29,7 @@ EXPORTS = [
     "as_comm_unique_id", "as_comm_create_rccl", "as_comm_create_custom", "as_comm_destroy", "as_comm_rank", "as_comm_world",
     "as_shard_range", "as_build_laplacian_sharded", "as_lambda_stats_sharded", "as_search_lambda_aware_sharded",
     "as_device_upload", "as_device_download", "as_device_free",
-    "as_compute_taumode_signals", "as_csr_set_order",
+    "as_compute_taumode_signals", "as_csr_set_order", "as_compute_taumode_signals_sharded",
 ]
 
 # transport callbacks of as_comm_create_custom (device buffers; byte counts / offsets are arrays of `world` entries)
@@ -108,6 +108,7 @@ def load():
         "as_prepare_query_items": (i32, [vp, vp, u64, u64, vp, i32, dbl, vp]),
         "as_compute_taumode_signals": (i32, [vp, vp, u64, u64, vp, i32, dbl, vp]),
         "as_csr_set_order": (i32, [vp, vp, vp]),
+        "as_compute_taumode_signals_sharded": (i32, [vp, vp, vp, u64, u64, vp, i32, dbl, vp]),
         "as_select_tau": (i32, [vp, vp, u64, u64, i32, dbl, vp]),
         "as_index_create": (i32, [vp, vp, vp, u64, u64, C.POINTER(vp)]),
         "as_index_destroy": (None, [vp]),

@@ -570,6 +570,24 @@ class LibComm:
                                                          ptr(idx), ptr(sc)))
         return idx, sc
 
+    def signal_lambdas(self, X_shard, n_total, block, taumode=None):
+        """as_compute_taumode_signals_sharded: the lambdas of the feature columns as signals over the row-sharded item graph
+        (block = this rank's CsrMatrix row block, None on a rank without rows).  The same F values on every rank."""
+        ctx = self.ctx
+        taumode = taumode or A.TauMode.Median
+        f = int(X_shard.shape[1])
+        lo, hi = self.shard_range(n_total)
+        if torch.is_tensor(X_shard):
+            Xs = X_shard.contiguous()
+            out = torch.empty(f, dtype=torch.float64, device=Xs.device)
+        else:
+            Xs = np.ascontiguousarray(X_shard, dtype=np.float64)
+            out = np.empty(f, dtype=np.float64)
+        A._adopt_torch_stream(ctx)
+        ctx.check(ctx.lib.as_compute_taumode_signals_sharded(ctx.h, self.h, ptr(Xs) if hi > lo else None, int(n_total), f,
+                                                             block.h if block is not None else None, taumode.kind, taumode.arg, ptr(out)))
+        return out
+
     def close(self):
         if self.h:
             self.ctx.lib.as_comm_destroy(self.h)

@@ -557,6 +557,11 @@ int signal_sums(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr
 int signal_taus(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau);
 int signal_taus_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode, double arg, double *taus);
 int signal_lambda_finish(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const double *tau, double *out);
+int signal_shares(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const int *need, double *g2);
+int signal_rank_sum(as_ctx *ctx, const double *all, uint32_t world, uint32_t count, double *out);
+uint32_t signal_pad(uint32_t S);
+int signal_need_pass2(as_ctx *ctx, const double *sums, uint32_t S, int *need_dev);
+int signal_lambda_from_sums(as_ctx *ctx, const double *sums, const double *g2, const int *need_dev, bool upper_only, uint32_t S, const double *tau, double *out);
 int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev);
 int any_nonfinite(as_ctx *ctx, const double *p, uint64_t count, bool *out);
 void signal_stream_release(as_csr *L);

@@ -636,31 +636,48 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
   return AS_OK;
 }
 
+// The collectives of the three calls below sit behind the same status agreement as the build's: every fallible local step
+// (workspace, staging of host inputs, kernels, the local search) runs FIRST, then one word says whether anyone failed; a rank
+// that failed returns its own status, its peers AS_ERR_PEER, and nobody is left waiting in an all-gather.
 int as_lambda_stats_sharded(as_ctx *ctx, as_comm *comm, const double *lambdas_shard, uint64_t n_here, double *min_out, double *max_out,
                             double *mean_out) {
   if (!ctx) return AS_ERR_ARG;
   if (!comm || (n_here && !lambdas_shard)) return fail(ctx, AS_ERR_ARG, "null argument");
   AS_HIP(ctx, hipSetDevice(ctx->device));
   const int W = comm->world;
-  DevIn<double> L;
-  AS_TRY(L.bind(ctx, lambdas_shard, n_here));
+  Agreement ag{ctx, comm, ctx->opt_sharded_agreement != 0};
   const unsigned blocks = 256;
   DevBuf<double> part, mine, all;
-  AS_TRY(part.alloc(ctx, (size_t)blocks * 3));
-  AS_TRY(mine.alloc(ctx, 4));
-  AS_TRY(all.alloc(ctx, (size_t)W * 4));
-  hipLaunchKernelGGL(lambda_stats_kernel, dim3(blocks), dim3(256), 0, ctx->stream, L.p, n_here, part.p);
-  AS_HIP(ctx, hipGetLastError());
-  std::vector<double> hp((size_t)blocks * 3);
-  AS_HIP(ctx, copy_d2h(ctx, hp.data(), part.p, hp.size() * sizeof(double)));
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double st[4] = {__builtin_inf(), -__builtin_inf(), 0.0, (double)n_here};
-  for (unsigned b = 0; b < blocks; ++b) {
-    st[0] = hp[b * 3] < st[0] ? hp[b * 3] : st[0];
-    st[1] = hp[b * 3 + 1] > st[1] ? hp[b * 3 + 1] : st[1];
-    st[2] += hp[b * 3 + 2];
+  auto local = [&]() -> int {
+    if (ctx->opt_sharded_inject_failure == 4) return fail(ctx, AS_ERR_HIP, "sharded lambda statistics: injected failure");
+    DevIn<double> L;
+    AS_TRY(L.bind(ctx, lambdas_shard, n_here));
+    AS_TRY(part.alloc(ctx, (size_t)blocks * 3));
+    AS_TRY(mine.alloc(ctx, 4));
+    AS_TRY(all.alloc(ctx, (size_t)W * 4));
+    hipLaunchKernelGGL(lambda_stats_kernel, dim3(blocks), dim3(256), 0, ctx->stream, L.p, n_here, part.p);
+    AS_HIP(ctx, hipGetLastError());
+    std::vector<double> hp((size_t)blocks * 3);
+    AS_HIP(ctx, copy_d2h(ctx, hp.data(), part.p, hp.size() * sizeof(double)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (unsigned b = 0; b < blocks; ++b) {
+      st[0] = hp[b * 3] < st[0] ? hp[b * 3] : st[0];
+      st[1] = hp[b * 3 + 1] > st[1] ? hp[b * 3 + 1] : st[1];
+      st[2] += hp[b * 3 + 2];
+    }
+    AS_HIP(ctx, copy_h2d(ctx, mine.p, st, sizeof(st)));
+    return AS_OK;
+  };
+  {
+    const int rc = local();
+    if (rc != AS_OK) {
+      const std::string err = ctx->err;
+      ag.announce_failure();
+      return fail(ctx, rc, err);
+    }
   }
-  AS_HIP(ctx, copy_h2d(ctx, mine.p, st, sizeof(st)));
+  AS_TRY(ag.before_collective());
   std::vector<uint64_t> rb((size_t)W, sizeof(st)), ro((size_t)W);
   for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * sizeof(st);
   {
@@ -695,38 +712,55 @@ int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *i
   const int W = comm->world;
   if (W > 64) return fail(ctx, AS_ERR_UNSUPPORTED, "sharded search: more than 64 ranks");
   const uint64_t per = nq * k;
+  Agreement ag{ctx, comm, ctx->opt_sharded_agreement != 0};
   DevBuf<uint64_t> li, gi;
   DevBuf<double> ls, gs;
-  AS_TRY(li.alloc(ctx, (size_t)per));
-  AS_TRY(ls.alloc(ctx, (size_t)per));
-  AS_TRY(gi.alloc(ctx, (size_t)W * per));
-  AS_TRY(gs.alloc(ctx, (size_t)W * per));
-  // a local failure (zero query lambda, NaN score: the reference's panics) must not leave the peers waiting in the collective:
-  // the shard's lists are exchanged empty and the status is returned afterwards
-  int rc_local = AS_OK;
-  std::string err_local;
-  if (index_shard) {
-    const uint64_t ks = std::min<uint64_t>(k, as_index_nitems(index_shard));  // (a shard smaller than k returns what it has)
-    if (ks == k) {
-      rc_local = as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, k, alpha, id_offset, li.p, ls.p);
-    } else {
-      DevBuf<uint64_t> ti;
-      DevBuf<double> ts;
-      AS_TRY(ti.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
-      AS_TRY(ts.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
-      if (ks) rc_local = as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, ks, alpha, id_offset, ti.p, ts.p);
-      if (rc_local == AS_OK) {
+  DevOut<uint64_t> I;
+  DevOut<double> S;
+  // The local stage: workspace, output staging and this shard's search.  A local failure -- an allocation, or the reference's
+  // panics (a zero query lambda: every rank sees it; a NaN score from a non-finite item: this shard alone) -- is announced in
+  // the agreement: this rank returns its status, the others AS_ERR_PEER, as the reference fails the whole query.
+  auto local = [&]() -> int {
+    if (ctx->opt_sharded_inject_failure == 5) return fail(ctx, AS_ERR_HIP, "sharded search: injected failure");
+    AS_TRY(li.alloc(ctx, (size_t)per));
+    AS_TRY(ls.alloc(ctx, (size_t)per));
+    AS_TRY(gi.alloc(ctx, (size_t)W * per));
+    AS_TRY(gs.alloc(ctx, (size_t)W * per));
+    AS_TRY(I.bind(ctx, idx_out, per));
+    AS_TRY(S.bind(ctx, score_out, per));
+    if (index_shard) {
+      const uint64_t ks = std::min<uint64_t>(k, as_index_nitems(index_shard));  // (a shard smaller than k returns what it has)
+      if (ks == k) {
+        AS_TRY(as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, k, alpha, id_offset, li.p, ls.p));
+      } else {
+        DevBuf<uint64_t> ti;
+        DevBuf<double> ts;
+        AS_TRY(ti.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
+        AS_TRY(ts.alloc(ctx, (size_t)std::max<uint64_t>(nq * ks, 1)));
+        if (ks) AS_TRY(as_search_lambda_aware(ctx, index_shard, queries, q_lambdas, nq, ks, alpha, id_offset, ti.p, ts.p));
         hipLaunchKernelGGL(widen_topk_kernel, dim3(cdiv(per, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)ti.p, (const double *)ts.p, nq,
                            (uint32_t)ks, (uint32_t)k, li.p, ls.p);
         AS_HIP(ctx, hipGetLastError());
         AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       }
+    } else {
+      hipLaunchKernelGGL(fill_empty_topk_kernel, dim3(cdiv(per, 256)), dim3(256), 0, ctx->stream, li.p, ls.p, per);
+      AS_HIP(ctx, hipGetLastError());
     }
-    if (rc_local != AS_OK) err_local = ctx->err;
+    return AS_OK;
+  };
+  int rc_local = local();
+  std::string err_local = rc_local != AS_OK ? ctx->err : std::string();
+  if (rc_local != AS_OK && ag.enabled) {
+    ag.announce_failure();
+    return fail(ctx, rc_local, err_local);
   }
-  if (!index_shard || rc_local != AS_OK) {
+  AS_TRY(ag.before_collective());
+  if (rc_local != AS_OK) {
+    // no agreement ("sharded_agreement" 0): the shard's lists are exchanged empty and the status is returned afterwards, so that
+    // the peers at least are not left waiting (they merge what the other shards found)
+    if (!li.p || !ls.p || !gi.p || !gs.p) return fail(ctx, rc_local, err_local);  // (without workspace there is nothing to exchange)
     hipLaunchKernelGGL(fill_empty_topk_kernel, dim3(cdiv(per, 256)), dim3(256), 0, ctx->stream, li.p, ls.p, per);
-    AS_HIP(ctx, hipGetLastError());
   }
   std::vector<uint64_t> rb((size_t)W, per * 8), ro((size_t)W);
   for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * per * 8;
@@ -736,16 +770,113 @@ int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *i
     if (rc != AS_OK) return fail(ctx, rc, "sharded search: all-gather failed");
   }
   if (rc_local != AS_OK) return fail(ctx, rc_local, err_local);
-  DevOut<uint64_t> I;
-  DevOut<double> S;
-  AS_TRY(I.bind(ctx, idx_out, per));
-  AS_TRY(S.bind(ctx, score_out, per));
   hipLaunchKernelGGL(merge_topk_kernel, dim3(cdiv(nq, 128)), dim3(128), 0, ctx->stream, (const uint64_t *)gi.p, (const double *)gs.p, (uint32_t)W, nq,
                      (uint32_t)k, I.p, S.p);
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(I.finish(ctx));
   AS_TRY(S.finish(ctx));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // li / ls / gi / gs go back to the workspace cache
+  return AS_OK;
+}
+
+// Item-graph lambda over a row-sharded graph (TauMode::compute_synthetic_lambda_csr,
+// src/taumode.rs:552-660, with the sums of :565-596 and :611-639 taken per row block): all-gather of the item shards (a stored
+// pair (i, j) reads row j wherever it lives), every rank sums (num, edge, sum t^2, den) over the rows of ITS block -- a pair
+// {i, j} is taken once, by the owner of min(i, j) -- all-gather of the 4 sums per signal, added in rank order; a second round of
+// one sum per signal only where the literal shares are needed (the same decision on every rank: it is a function of the totals).
+int as_compute_taumode_signals_sharded(as_ctx *ctx, as_comm *comm, const double *items_shard, uint64_t n_total, uint64_t n_features,
+                                       const as_csr *L_block, int tau_mode, double tau_arg, double *lambdas_out) {
+  if (!ctx) return AS_ERR_ARG;
+  if (!comm || !lambdas_out) return fail(ctx, AS_ERR_ARG, "null argument");
+  if (n_features == 0 || n_features >= 0xFFFFFFFFull || n_total == 0 || n_total >= 0x7FFFFFFFull) return fail(ctx, AS_ERR_ARG, "bad shape");
+  if (tau_mode < AS_TAU_FIXED || tau_mode > AS_TAU_PERCENTILE) return fail(ctx, AS_ERR_ARG, "bad tau_mode");
+  AS_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = comm->world;
+  const uint32_t S = (uint32_t)n_features, s_pad = signal_pad(S);
+  uint64_t lo, hi;
+  shard_range(n_total, comm->rank, W, &lo, &hi);
+  if ((hi > lo) && !items_shard) return fail(ctx, AS_ERR_ARG, "null shard");
+  as_csr *L = const_cast<as_csr *>(L_block);
+  if (L && (L->row_begin != lo || L->n != hi - lo || (L->n_cols ? L->n_cols : L->n) > n_total))
+    return fail(ctx, AS_ERR_ARG, "the row block does not belong to this rank's range of rows");
+  Agreement ag{ctx, comm, ctx->opt_sharded_agreement != 0};
+  auto leave = [&](int rc) -> int {  // a local failure: said once in the next agreement
+    const std::string err = ctx->err;
+    ag.announce_failure();
+    return fail(ctx, rc, err);
+  };
+#define AS_STAGE(expr)                  \
+  do {                                  \
+    const int _rc = (expr);             \
+    if (_rc != AS_OK) return leave(_rc); \
+  } while (0)
+  DevIn<double> mine;
+  DevBuf<double> all_rows, sums_mine, sums_all, sums, tau, g2_mine, g2_all, g2;
+  DevBuf<int> need;
+  DevOut<double> O;
+  auto stage1 = [&]() -> int {
+    if (ctx->opt_sharded_inject_failure == 6) return fail(ctx, AS_ERR_HIP, "sharded item-graph lambda: injected failure");
+    AS_TRY(mine.bind(ctx, items_shard, (hi - lo) * n_features));
+    AS_TRY(all_rows.alloc(ctx, (size_t)n_total * n_features));
+    AS_TRY(sums_mine.alloc(ctx, (size_t)4 * s_pad));
+    AS_TRY(sums_all.alloc(ctx, (size_t)W * 4 * s_pad));
+    AS_TRY(sums.alloc(ctx, (size_t)4 * s_pad));
+    AS_TRY(tau.alloc(ctx, S));
+    AS_TRY(g2_mine.alloc(ctx, s_pad));
+    AS_TRY(g2_all.alloc(ctx, (size_t)W * s_pad));
+    AS_TRY(g2.alloc(ctx, s_pad));
+    AS_TRY(need.alloc(ctx, 1));
+    AS_TRY(O.bind(ctx, lambdas_out, S));
+    return AS_OK;
+  };
+  AS_STAGE(stage1());
+  AS_TRY(ag.before_collective());
+  AS_TRY(gather_rows(ctx, comm, mine.p, all_rows.p, n_total, n_features * sizeof(double)));
+  const uint64_t graph_n = L ? (L->n_cols ? L->n_cols : L->n) : n_total;
+  auto stage2 = [&]() -> int {
+    AS_TRY(signal_taus(ctx, all_rows.p, n_total, S, tau_mode, tau_arg, tau.p));  // every rank has all rows: tau is not exchanged
+    if (L) {
+      // the rows past the graph (a signal longer than the graph has nodes) count for the denominator only: rank 0 takes them
+      const bool first = comm->rank == 0;
+      AS_TRY(signal_sums(ctx, all_rows.p, n_total, S, L, first ? graph_n : 0, first ? n_total : 0, sums_mine.p));
+    } else {
+      AS_HIP(ctx, hipMemsetAsync(sums_mine.p, 0, sizeof(double) * 4 * s_pad, ctx->stream));
+    }
+    return AS_OK;
+  };
+  AS_STAGE(stage2());
+  AS_TRY(ag.before_collective());
+  {
+    std::vector<uint64_t> rb((size_t)W, (uint64_t)4 * s_pad * 8), ro((size_t)W);
+    for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * 4 * s_pad * 8;
+    const int rc = comm->ops.all_gather_v(comm->ops.user, sums_mine.p, (uint64_t)4 * s_pad * 8, sums_all.p, rb.data(), ro.data(), ctx->stream);
+    if (rc != AS_OK) return fail(ctx, rc, "sharded item-graph lambda: all-gather failed");
+  }
+  int need_h = 0;
+  auto stage3 = [&]() -> int {
+    AS_TRY(signal_rank_sum(ctx, sums_all.p, (uint32_t)W, 4 * s_pad, sums.p));
+    AS_TRY(signal_need_pass2(ctx, sums.p, S, need.p));
+    AS_HIP(ctx, copy_d2h(ctx, &need_h, need.p, sizeof(int)));  // the same value on every rank: the totals are
+    if (need_h) {
+      if (L) AS_TRY(signal_shares(ctx, all_rows.p, S, L, sums.p, need.p, g2_mine.p));
+      else AS_HIP(ctx, hipMemsetAsync(g2_mine.p, 0, sizeof(double) * s_pad, ctx->stream));
+    }
+    return AS_OK;
+  };
+  AS_STAGE(stage3());
+  if (need_h) {
+    AS_TRY(ag.before_collective());
+    std::vector<uint64_t> rb((size_t)W, (uint64_t)s_pad * 8), ro((size_t)W);
+    for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * s_pad * 8;
+    const int rc = comm->ops.all_gather_v(comm->ops.user, g2_mine.p, (uint64_t)s_pad * 8, g2_all.p, rb.data(), ro.data(), ctx->stream);
+    if (rc != AS_OK) return fail(ctx, rc, "sharded item-graph lambda: all-gather failed");
+    AS_TRY(signal_rank_sum(ctx, g2_all.p, (uint32_t)W, s_pad, g2.p));
+  }
+#undef AS_STAGE
+  // every block of the library's graphs is symmetric by construction: a pair was taken once unless the option says otherwise
+  AS_TRY(signal_lambda_from_sums(ctx, sums.p, g2.p, need.p, ctx->opt_signal_sym != 0, S, tau.p, O.p));
+  AS_TRY(O.finish(ctx));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 

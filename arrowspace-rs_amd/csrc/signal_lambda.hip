@@ -1021,6 +1021,34 @@ int signal_taus(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, int mo
   return AS_OK;
 }
 
+// ---- pieces of the sharded form (sharded.hip): every rank sums over its row block, the sums meet in rank order ----------------
+__global__ void signal_rank_sum_kernel(const double *__restrict__ all, uint32_t world, uint32_t count, double *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (uint32_t r = 0; r < world; ++r) s = __dadd_rn(s, all[(uint64_t)r * count + i]);
+  out[i] = s;
+}
+int signal_rank_sum(as_ctx *ctx, const double *all, uint32_t world, uint32_t count, double *out) {
+  hipLaunchKernelGGL(signal_rank_sum_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, all, world, count, out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+uint32_t signal_pad(uint32_t S) { return (S + kSlab - 1) / kSlab * kSlab; }
+// *need_dev = 1 when some signal's G cannot be taken from the sums of squares (then the literal second pass runs)
+int signal_need_pass2(as_ctx *ctx, const double *sums, uint32_t S, int *need_dev) {
+  AS_HIP(ctx, hipMemsetAsync(need_dev, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(signal_need_pass2_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, sums, signal_pad(S), S, need_dev);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+int signal_lambda_from_sums(as_ctx *ctx, const double *sums, const double *g2, const int *need_dev, bool upper_only, uint32_t S, const double *tau,
+                            double *out) {
+  hipLaunchKernelGGL(signal_lambda_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, sums, g2, need_dev, upper_only ? 2.0 : 1.0, signal_pad(S), S, tau, out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 int signal_lambda_finish(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const double *tau, double *out) {
   const uint32_t s_pad = (S + kSlab - 1) / kSlab * kSlab;
   DevBuf<int> need;

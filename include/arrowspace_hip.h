@@ -270,7 +270,7 @@ int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nb
  * CSR rows (src/laplacian.rs:295-417) are done for the range only.  The handle that comes out is a ROW BLOCK:
  * as_csr_n = row_count rows, as_csr_cols = n_nodes, GLOBAL column ids, indptr starting at 0, as_csr_row_begin = its
  * first row.  Stacking the blocks of consecutive ranges gives exactly the CSR of as_laplacian_from_knn.  A row block is
- * not accepted as the graph of as_compute_taumode (AS_ERR_UNSUPPORTED). */
+ * not accepted as the graph of as_compute_taumode (AS_ERR_UNSUPPORTED); as_compute_taumode_signals_sharded takes one per rank. */
 int as_laplacian_from_knn_rows(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,
                                const as_graph_params *params, uint64_t row_begin, uint64_t row_count, as_csr **out);
 
@@ -338,11 +338,25 @@ int as_lambda_stats_sharded(as_ctx *ctx, as_comm *comm, const double *lambdas_sh
  * (as_search_lambda_aware with id_offset = its first global row; index_shard NULL on a rank without rows), the per-shard
  * top-k lists are all-gathered and merged by (score desc, global index asc) -- what the reference's stable sort of all items
  * gives.  queries / q_lambdas are replicated (the same on every rank); idx_out / score_out (nq x k, host or device) hold the
- * same global result on every rank.  A rank whose local search fails (AS_ERR_ZERO_LAMBDA, AS_ERR_NAN_SCORE) still takes part
- * in the exchange and returns its status afterwards. */
+ * same global result on every rank.  The reference panics for the whole query when one item's score is NaN or the query's
+ * lambda is 0; here a rank whose local stage fails (those two, or an allocation) returns its own status and every other rank
+ * returns AS_ERR_PEER -- the status agreement of the sharded build in front of the exchange ("sharded_agreement"; with 0 the
+ * failing shard's lists are exchanged empty and only that rank reports the error).  as_lambda_stats_sharded above and
+ * as_compute_taumode_signals_sharded below leave together in the same way. */
 int as_search_lambda_aware_sharded(as_ctx *ctx, as_comm *comm, const as_index *index_shard, const double *queries,
                                    const double *q_lambdas, uint64_t nq, uint64_t k, double alpha, uint64_t id_offset,
                                    uint64_t *idx_out, double *score_out);
+
+/* Item-graph lambdas over a row-sharded graph ("K7 item-graph signals"): items_shard = this rank's
+ * item rows ((hi - lo) x n_features, as_shard_range; host or device), L_block = its ROW BLOCK of the Laplacian
+ * (as_build_laplacian_sharded; NULL on a rank without rows).  The shards are all-gathered (a stored pair (i, j) reads row j
+ * wherever it lives), every rank sums x'Lx, the edge energy and the sum of squares over the rows of its block (a pair once, on
+ * the rank that owns its smaller row), the 4 partial sums per signal are all-gathered and added in rank order; a second round of
+ * one sum per signal runs only where G needs the literal shares (src/taumode.rs:611-639).  tau comes from the whole columns
+ * on every rank.  lambdas_out[n_features] (host or device): the same values on every rank, equal to as_compute_taumode_signals
+ * on one GPU up to the order of the sums.  Every rank must make the call. */
+int as_compute_taumode_signals_sharded(as_ctx *ctx, as_comm *comm, const double *items_shard, uint64_t n_total, uint64_t n_features,
+                                       const as_csr *L_block, int tau_mode, double tau_arg, double *lambdas_out);
 
 /* ---- lambda-tau: replaces TauMode::compute_taumode_lambdas_parallel, src/taumode.rs:174-312 */
 /* items: n_items x n_features.  tau is taken from each item's own values (select_tau,

@@ -231,8 +231,12 @@ def _lib_worker(rank, world, port, n, d, out_dir):
         idx, sc = sas.search(Q, lq, 10, 0.7)
         idx_big, sc_big = sas.search(Q, lq, 600, 0.7)   # k beyond the smallest shard: short lists are padded before the merge
         lam_all = D.all_gather_rows(sas.lambdas.reshape(-1, 1), sas.sizes).reshape(-1)
+        # item-graph lambdas over the row blocks (as_compute_taumode_signals_sharded): the feature columns as signals
+        lam_sig = comm.signal_lambdas(torch.from_numpy(X[lo:hi].copy()).cuda(), n, gl.block, A.TauMode.Median)
+        lam_sig_p = comm.signal_lambdas(X[lo:hi].copy(), n, gl.block, A.TauMode.Percentile(0.9))   # host shard, host output
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, "lib%d.npz" % rank), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()),
+                 lam_sig=lam_sig.cpu().numpy(), lam_sig_p=lam_sig_p,
                  join=np.array(join), lam=lam_all.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), lq=lq.cpu().numpy(),
                  idx_big=idx_big.cpu().numpy(), sc_big=sc_big.cpu().numpy(), stats=np.array(sas.lambda_stats))
         comm.close()
@@ -257,15 +261,33 @@ def _lib_fail_worker(rank, world, port, n, d, stage, out_dir):
         X, _ = synth.mixture(n, d, seed=13, n_clusters=16, rank=4)
         gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
         sas = D.ShardedArrowSpace(D.HipOps(ctx), torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp, A.TauMode.Median, libcomm=comm)
+        Xs = torch.from_numpy(X[lo:hi].copy()).cuda()
+        if stage >= 4:   # the calls behind the build: statistics (4), search (5), item-graph lambdas (6)
+            gl0 = sas.build_item_graph()
+            sas.build_lambdas(synth.mixture(n, d, seed=13, n_clusters=16, rank=4)[1])
+            Q = torch.from_numpy(X[[1, n // 2]] * 1.02).cuda()
+            lq = sas.prepare_queries(Q)
+
+            def call():
+                if stage == 4:
+                    comm.lambda_stats(sas.lambdas)
+                elif stage == 5:
+                    sas.search(Q, lq, 10, 0.7)
+                else:
+                    comm.signal_lambdas(Xs, n, gl0.block, A.TauMode.Median)
+        else:
+            def call():
+                sas.build_item_graph()
         if rank == world - 1:
             ctx.set_option("sharded_inject_failure", stage)  # this rank alone fails, at checkpoint `stage`
         status, text = 0, ""
         try:
-            sas.build_item_graph()
+            call()
         except A.ArrowSpaceError as e:
             status, text = e.status, str(e)
         ctx.set_option("sharded_inject_failure", 0)
-        gl = sas.build_item_graph()  # the communicator is in step again: the same call succeeds on every rank
+        call()  # the communicator is in step again: the same call succeeds on every rank
+        gl = sas.build_item_graph()
         np.savez(os.path.join(out_dir, "fail%d.npz" % rank), status=np.array(status), nnz=np.array(gl.nnz()), text=np.array(text))
         comm.close()
     finally:
@@ -273,11 +295,12 @@ def _lib_fail_worker(rank, world, port, n, d, stage, out_dir):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,stage", [(2, 1), (2, 2), (3, 2), (2, 3)])
+@pytest.mark.parametrize("world,stage", [(2, 1), (2, 2), (3, 2), (2, 3), (2, 4), (3, 5), (2, 5), (2, 6)])
 def test_library_sharded_build_ranks_leave_together_when_one_fails(tmp_path, world, stage):
-    """One rank fails locally (test hook: before the row all-gather, before the list exchange, before the nnz all-reduce):
-    it returns its own status, its peers return AS_ERR_PEER instead of waiting in the collective it never reaches, no rank
-    hangs, and the next build on the same communicator succeeds."""
+    """One rank fails locally (test hook: before the row all-gather, before the list exchange, before the nnz all-reduce; in
+    the lambda statistics, in the sharded search, in the item-graph lambdas): it returns its own status, its peers return
+    AS_ERR_PEER instead of waiting in the collective it never reaches (or merging a result that silently misses a shard), no
+    rank hangs, and the next call on the same communicator succeeds."""
     import arrowspace_amd as A
     from arrowspace_amd import _lib
     from oracle import oracle_ctypes as O
@@ -288,7 +311,7 @@ def test_library_sharded_build_ranks_leave_together_when_one_fails(tmp_path, wor
     nnz = len(O.build_laplacian(X, O.graph_params(0.5, 16, 16, 2.0, 0.25))[1])
     for k in range(world):
         r = np.load(tmp_path / ("fail%d.npz" % k))
-        assert int(r["status"]) == (_lib.AS_ERR_ARG if k == world - 1 else _lib.AS_ERR_PEER), str(r["text"])
+        assert int(r["status"]) == ((_lib.AS_ERR_ARG if stage < 4 else _lib.AS_ERR_HIP) if k == world - 1 else _lib.AS_ERR_PEER), str(r["text"])
         if k == world - 1:
             assert "injected failure" in str(r["text"])
         assert int(r["nnz"]) == nnz
@@ -313,6 +336,10 @@ def test_library_sharded_build_matches_single_process(tmp_path, n, world, d):
         # as_lambda_stats_sharded (src/builder.rs:434-445) and as_search_lambda_aware_sharded (src/core.rs:778-798)
         np.testing.assert_allclose(r["lam"], lam, rtol=1e-12, atol=1e-300)
         np.testing.assert_allclose(r["stats"], [r["lam"].min(), r["lam"].max(), r["lam"].mean()], rtol=1e-12)
+        # as_compute_taumode_signals_sharded: TauMode::compute_synthetic_lambda_csr (src/taumode.rs:552-660) of every feature
+        # column over the N x N graph, the sums taken per row block and added in rank order
+        np.testing.assert_allclose(r["lam_sig"], O.taumode_lambdas(np.ascontiguousarray(X.T), csr, O.TAU_MEDIAN), rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(r["lam_sig_p"], O.taumode_lambdas(np.ascontiguousarray(X.T), csr, O.TAU_PERCENTILE, 0.9), rtol=1e-12, atol=1e-300)
         for j in range(4):
             oi, osc = O.search_lambda_aware(X, r["lam"], Q[j], float(r["lq"][j]), 10, 0.7)
             assert np.array_equal(r["idx"][j], oi.astype(np.int64))

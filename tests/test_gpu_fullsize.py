@@ -8,7 +8,9 @@ The oracle cannot finish an n^2 graph at these sizes, so each config is checked 
   (c) for the row-sharded config, equality of one rank's output with the single-GPU output of the same rows.
 Tolerances follow src/tests/test_eigenmaps.rs:117-329 (indices exact, lambdas and scores 1e-6), asserted tighter.
 
-  configs[2]  1 M x 128, full lambda-tau build + 10 k-query search_lambda_aware(alpha = 0.7)
+  configs[1]  100 k x 128: the item graph (MFMA distance block) + Rayleigh kernel, the size the config names
+  configs[2]  1 M x 128, full lambda-tau build + 10 k-query search_lambda_aware(alpha = 0.7); and the item-graph lambdas of
+              the 128 feature columns over the 1 M x 1 M Laplacian that build returns (the "SpMV" of north_star)
   configs[3]  4 M x 128 row-sharded over 8 GPUs: here rank 3 of 8 through as_knn_join_thresholds / _pairs / _finish
               with the foreign ranks' lists produced by the same calls on this GPU
   configs[4]  1 M x 768, Percentile(0.95), 100 k batched prepare_query_item + search
@@ -128,6 +130,63 @@ def build_and_search(ctx, Xd, X, cent, gp, taumode, otau, oarg, nq, n_lambda_sam
     return asp, gl
 
 
+def item_graph_lambdas(ctx, Xd, X, gp, cols, taumode=A.TauMode.Median, otau=None, oarg=0.0):
+    """the Laplacian of the items, the lambdas of the feature columns over it; `cols` (or all) against the oracle, which walks
+    the same CSR once per signal (src/taumode.rs:552-660)"""
+    from arrowspace_amd.api import compute_taumode_signals
+    otau = O.TAU_MEDIAN if otau is None else otau
+    gl = A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+    lam = compute_taumode_signals(Xd, gl.matrix, taumode, ctx=ctx)
+    ctx.synchronize()
+    assert ctx.stat("signal_stream_sym") == 1 and ctx.stat("signal_stream_ordered") == 1   # upper triangle, in the join's order
+    lam = lam.cpu().numpy()
+    assert lam.shape == (X.shape[1],) and np.all(np.isfinite(lam)) and np.all(lam > 0)
+    cols = np.arange(X.shape[1]) if cols is None else np.asarray(cols)
+    want = O.taumode_lambdas(np.ascontiguousarray(X[:, cols].T), gl.matrix.to_host(), otau, oarg)
+    np.testing.assert_allclose(lam[cols], want, rtol=LAMBDA_RTOL, atol=1e-300)
+    # the rows as stored instead of the join's order: the same sums in another order
+    gl.matrix.set_order(None)
+    lam2 = compute_taumode_signals(Xd, gl.matrix, taumode, ctx=ctx).cpu().numpy()
+    np.testing.assert_allclose(lam2, lam, rtol=1e-12)
+    return gl
+
+
+def test_config1_100k_x_128_item_graph_and_rayleigh(ctx):
+    """configs[1] at its own size: the whole neighbour table against the plain dense join, sampled rows against the oracle,
+    the reference-mapping lambdas and search, and the item-graph lambdas of all 128 feature columns against the oracle."""
+    n, d = 100_000, 128
+    Xd, cent = synth.mixture_device(n, d, "cuda", seed=42)
+    X = Xd.cpu().numpy()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dst = knn_device(ctx, Xd, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 1
+    ctx.set_option("join_prefilter", 0)
+    try:
+        idx2, dst2 = knn_device(ctx, Xd, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 0
+    finally:
+        ctx.set_option("join_prefilter", 1)
+    assert torch.equal(idx, idx2) and torch.equal(dst, dst2)
+    del idx2, dst2
+    rng = np.random.default_rng(7)
+    assert_sampled_rows(X, gp, idx, dst, np.sort(rng.choice(n, size=96, replace=False)))
+    assert_table_invariants(idx, dst)
+    assert_csr_invariants(A.laplacian_from_knn(idx, dst, gp, ctx=ctx), n, gp.topk + 1)
+    del idx, dst
+    build_and_search(ctx, Xd, X, cent, gp, A.TauMode.Median, O.TAU_MEDIAN, 0.0, 1000, 500, 20)
+    item_graph_lambdas(ctx, Xd, X, gp, None)
+
+
+def test_item_graph_lambdas_200k_whole_result(ctx):
+    """200 k nodes x 128 signals: every lambda against aso_synthetic_lambda, Median and Percentile tau"""
+    n, d = 200_000, 128
+    Xd, _ = synth.mixture_device(n, d, "cuda", seed=42)
+    X = Xd.cpu().numpy()
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    item_graph_lambdas(ctx, Xd, X, gp, None)
+    item_graph_lambdas(ctx, Xd, X, gp, None, A.TauMode.Percentile(0.95), O.TAU_PERCENTILE, 0.95)
+
+
 def test_config2_1M_x_128_build_and_10k_query_search(ctx):
     """configs[2] with the library's default options: the item graph goes through the symmetric threshold join."""
     n, d, nq = 1_000_000, 128, 10_000
@@ -161,6 +220,8 @@ def test_config2_1M_x_128_build_and_10k_query_search(ctx):
     del idx, dst
     build_and_search(ctx, Xd, X, cent, gp, A.TauMode.Median, O.TAU_MEDIAN, 0.0, nq, 1000, 40)
     assert ctx.stat("search_scan") == 1                                       # the threshold scan of the search ran
+    # the 15 M-entry Laplacian of that build as the graph of the 128 feature columns: sampled signals against the oracle
+    item_graph_lambdas(ctx, Xd, X, gp, [0, 1, 17, 31, 64, 100, 126, 127])
 
 
 def test_config4_1M_x_768_percentile_100k_queries(ctx):
