@@ -20,6 +20,8 @@ Beside the contract's fields the JSON line carries (all measured in this run, HI
   reference_equivalent  SURVEY.md 8(d)'s 2 n^2 d of the reference's all-pairs loop over the time of the launches that replace
                     it: how much of that loop is never executed -- a separate figure, never a frac
   roofline_scan     the lambda-tau scan (K6/K7/K8): bytes n (8 D + 8) per launch against HBM
+  roofline_spmm     the item-graph lambda (the D feature columns as signals over the N x N Laplacian the build returns): bytes
+                    nnz 16 + N D 8 per launch against HBM, the gather rate and the f64 vector bound beside it
   roofline_search   the search scan at the benchmark batch (K9, MFMA-bound at nq = 10 k): 2 nq N D flops
   roofline_search_hbm  the search at nq = 1 and nq = 32 with every item row streamed (bandwidth-bound regime): bytes N (8 D + 8) per
                     pass; equivalent_filtered: the same batches on an index searched before (int8 filter: an equivalent, not a bandwidth)
@@ -62,6 +64,7 @@ def parse():
     p.add_argument("--alpha", type=float, default=0.7)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-legs", action="store_true", help="skip the host-input build and the small-batch search legs")
+    p.add_argument("--no-spmm-leg", action="store_true", help="skip the item-graph lambda leg (roofline_spmm)")
     p.add_argument("--cand-precision", type=int, default=32, choices=[32, 64],
                    help="first candidate stage: 32 = 16-bit / f32 MFMA then f64 MFMA then exact (default); 64 = f64 MFMA first")
     p.add_argument("--join-pipe", type=int, default=16, choices=[16, 48, 32],
@@ -124,7 +127,7 @@ def recorded_traffic(kernel_substr, n, d):
         return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"]}
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x.startswith("r03") and x.endswith("_pmc_traffic.json"))
+    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x[:3] in ("r03", "r04") and x.endswith("_pmc_traffic.json"))
     for name in files[-1:]:   # the newest pass only: a kernel that no longer exists must not bring an old file's bytes along
         try:
             with open(os.path.join(pdir, name)) as f:
@@ -146,10 +149,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ARROWSPACE_DIST_FORCE=1 under a one-rank torch.distributed.run: the RCCL path on a one-GPU box
     use_dist = world > 1 or (os.environ.get("ARROWSPACE_DIST_FORCE") == "1" and "RANK" in os.environ)
+    # ARROWSPACE_SHARED_GPU=1: every rank runs on GPU 0 (RCCL refuses two ranks on one device, so the library's exchange goes
+    # over its callback transport on gloo): the N > 1 bookkeeping of this script and the sharded path of the library on a one-GPU box
+    shared_gpu = os.environ.get("ARROWSPACE_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -176,10 +187,42 @@ def main():
     # communicator (csrc/sharded.hip): the one-GPU algorithm sharded by image positions.  ARROWSPACE_TORCH_EXCHANGE=1 keeps
     # the torch.distributed form (the join in the order of the caller's rows, no first pass).
     libcomm = None
-    if use_dist and os.environ.get("ARROWSPACE_TORCH_EXCHANGE") != "1":
+    transport = "none (one rank)"
+    if use_dist and os.environ.get("ARROWSPACE_TORCH_EXCHANGE") == "1":
+        transport = "torch.distributed (%s), stage-level entry points" % dist.get_backend()
+    elif use_dist and shared_gpu:
+        libcomm = D.LibComm.torch_transport(ctx)
+        transport = "library exchange over its callback transport on gloo (ranks share one GPU)"
+    elif use_dist:
+        # The library's own RCCL communicator.  Its bring-up (ncclCommInitRank over the bootstrap sockets) and its first
+        # collective run in a side thread under a deadline: a rank that cannot come up says so in an all-reduce on torch's
+        # process group, and then EVERY rank continues on the torch.distributed exchange instead (reported in `transport`);
+        # nothing is re-executed, and a hung bring-up cannot hang the job.
+        import threading
         box = [D.LibComm.unique_id(ctx) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        libcomm = D.LibComm.rccl(ctx, box[0], rank, world)
+        result = {}
+
+        def bring_up():
+            try:
+                c = D.LibComm.rccl(ctx, box[0], rank, world)
+                c.lambda_stats(torch.zeros(1, dtype=torch.float64, device=dev))   # first collective: a 32-byte all-gather
+                result["comm"] = c
+            except Exception as e:  # noqa: BLE001
+                result["error"] = repr(e)
+
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("ARROWSPACE_RCCL_TIMEOUT_S", "120")))
+        ok = torch.tensor([1 if "comm" in result else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 1:
+            libcomm = result["comm"]
+            transport = "library exchange over its own RCCL communicator"
+        else:
+            why = result.get("error", "timed out" if th.is_alive() else "a peer failed")
+            transport = "torch.distributed (nccl), stage-level entry points -- FALLBACK: the library's RCCL communicator did not come up (%s)" % why
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, transport))
     sas = D.ShardedArrowSpace(ops, Xd, n, gp, A.TauMode.Median, libcomm=libcomm)
 
     def sync():
@@ -220,7 +263,7 @@ def main():
         t_search += t2 - t1
     sync()
     t_all = time.perf_counter() - t_all0
-    times = torch.tensor([t_all, t_build, t_search], dtype=torch.float64, device=dev)
+    times = torch.tensor([t_all, t_build, t_search], dtype=torch.float64, device="cpu" if shared_gpu else dev)
     if use_dist:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     t_all, t_build, t_search = [float(x) for x in times]
@@ -363,6 +406,51 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra leg must not take the bench line down
             hard = {"error": repr(e)}
         extra["value_hard_data"] = hard
+    if rank == 0 and world == 1 and not args.no_spmm_leg:
+        # ---- the item-graph lambda: the feature columns as signals over the N x N Laplacian the build returns ------------
+        # (SURVEY.md 8(a') item-graph mapping, the "SpMV" of north_star; src/taumode.rs:552-660 per signal.)  Algorithmic bytes
+        # (SURVEY.md 8(d)): nnz * 16 for the CSR entries + N * D * 8 for the item rows read once; the gathers of the rows a
+        # stored pair names come on top and are served on-die where the row order keeps neighbours together.
+        try:
+            from arrowspace_amd.api import compute_taumode_signals
+            gl_sp = A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+            nnz_sp = gl_sp.matrix.nnz()
+            legs_sp = {}
+            for name, tm in (("fixed_tau", A.TauMode.Fixed(0.5)), ("median_tau", A.TauMode.Median)):
+                for it in range(5):
+                    if it == 1:
+                        ctx.profile(True)
+                    lam_sp = compute_taumode_signals(Xd, gl_sp.matrix, tm, ctx=ctx)
+                    ctx.synchronize()
+                pl = ctx.profile_all()
+                ctx.profile(False)
+                legs_sp[name] = {k.replace("signal_", "") + "_ms": v[0] / v[1] for k, v in pl.items() if k.startswith("signal_") and v[1]}
+            sums_ms = legs_sp["median_tau"]["sums_ms"]
+            alg_bytes = nnz_sp * 16.0 + float(n) * d * 8.0
+            records = ctx.stat("signal_stream_records")
+            valu_floor_ms = records * 7.0 * d / (16.0 * 4 * 256 * 2.4e9) * 1e3   # 16 f64 lanes per clock and SIMD, 1024 SIMDs, 2.4 GHz
+            extra["roofline_spmm"] = {
+                "bound": "hbm", "kernel": "signal_sums_kernel<false, true> (item-graph lambda: the upper triangle of the N x N Laplacian "
+                                          "streamed once for all D signals, each stored pair gathers the two 1 KB item rows; HIP events "
+                                          "around the launch)",
+                "achieved": alg_bytes / (sums_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (sums_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes": alg_bytes, "avg_launch_ms": sums_ms, "item_graph_nnz": int(nnz_sp), "stream_records": int(records),
+                "gathered_bytes": records * 8.0 * d, "gather_rate_GBs": records * 8.0 * d / (sums_ms * 1e-3) / 1e9,
+                "f64_valu_floor_ms": valu_floor_ms, "frac_of_f64_valu_bound": valu_floor_ms / sums_ms,
+                "row_order": "the join's own (attached to the graph by as_build_laplacian)" if ctx.stat("signal_stream_ordered") else "as stored",
+                "legs_ms": legs_sp, "lambda_min_max": [float(lam_sp.min()), float(lam_sp.max())],
+                "note": "frac divides the algorithmic bytes (each row once) by the launch time; the pass requests gathered_bytes from "
+                        "the caches (a pair's second row), which at this graph (neighbours random inside a 4 MB cluster, as large as "
+                        "an XCD's L2) come mostly from the Infinity Cache; median_tau adds the order statistic of every column "
+                        "(taus_ms: two histogram passes + one collecting pass over the N x D matrix)"}
+            rec = recorded_traffic("signal_sums_kernel", n, d)
+            if rec:
+                extra["roofline_spmm"]["traffic"] = rec["bytes_per_launch"]
+                extra["roofline_spmm"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
+            del gl_sp
+        except Exception as e:  # noqa: BLE001
+            extra["roofline_spmm"] = {"error": repr(e)}
 
     if rank == 0:
         steps = args.steps
@@ -501,7 +589,7 @@ def main():
                                    "with_lambda_graph(eps=0.5,k=16,topk=16,p=2,sigma=0.25) + per-item lambda-tau "
                                    "(Median) + %d-query prepare+search_lambda_aware(k=%d, alpha=%.1f)"
                                    % (n, d, nq, args.k, args.alpha),
-                       "n_items": n, "dim": d, "n_queries": nq, "sharding": "rows x %d" % world},
+                       "n_items": n, "dim": d, "n_queries": nq, "sharding": "rows x %d" % world, "transport": transport},
             "search_qps": nq / search_s, "build_ms": build_s * 1e3, "search_ms": search_s * 1e3,
             "item_graph_nnz": int(state.get("nnz", -1)),
             "knn_uncertified_rows": stats["knn_uncertified_rows"], "knn_uncertified_rows_after_second_pass": stats["knn_uncertified_rows_stage1a"],
