@@ -330,6 +330,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "stream_scan") ctx->opt_stream_scan = value;
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
+  else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;
   else if (n == "signal_sym") ctx->opt_signal_sym = value;
   else if (n == "signal_order") ctx->opt_signal_order = value;
   else if (n == "signal_chunk_rows") ctx->opt_signal_chunk_rows = std::min<int64_t>(std::max<int64_t>(1, value), 1024);

@@ -79,6 +79,8 @@ struct as_ctx {
   int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange) or 3 (before the nnz all-reduce)
   int64_t opt_join_basis_iters = 4;      // rotated coordinates: rounds of subspace iteration on the 16 k-row sample (each 0.15 ms: three small kernels, two copies, a host Gram-Schmidt; hard mixture 98.2 / 94.7 / 93.2 / 93.9 ms at 2 / 3 / 4 / 5 rounds, the bench data indifferent from 3 on)
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
+  int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
+                                         // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
   int64_t opt_rerank_order = 1;          // exact re-rank of the join: rows visited in the order of the image (candidates shared through L2)
   int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)
   int64_t opt_cluster_on_device = 1;     // incremental clustering: batches after the last centroid is created stay on the device
@@ -493,7 +495,7 @@ struct OwnJoin {
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
                      uint32_t pos_begin = 0, uint32_t pos_count = 0, const std::function<int(void *, size_t)> *gather = nullptr);
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
-                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos);
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io = nullptr);
 
 struct JoinSources {
   const float *packed;    // f32 image of all rows if the caller has one (else nullptr)
@@ -527,7 +529,8 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
                    const float *packed = nullptr, const void *packed16 = nullptr, const void *packedh = nullptr,
                    const uint32_t *perm = nullptr,         // image position -> row when packedh is packed in a permuted order
                    const uint32_t *image_perm = nullptr,   // ... when it is, but the lists are to be kept by image position
-                   const double *rot_z = nullptr);         // rows wider than 128: their rotated coordinates (n x 32), for the first pass
+                   const double *rot_z = nullptr,          // rows wider than 128: their rotated coordinates (n x 32), for the first pass
+                   bool *grouped_io = nullptr);            // in: lists per group of 32 positions are welcome; out: that is what was written
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

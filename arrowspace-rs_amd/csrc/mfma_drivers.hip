@@ -764,7 +764,7 @@ int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t 
               uint32_t d, void *P, uint32_t tiles);
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr,
-             const unsigned char *mask = nullptr);
+             const unsigned char *mask = nullptr, bool grouped = false);
 uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
@@ -925,7 +925,10 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
                    const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm,
-                   const double *rot_z) {
+                   const double *rot_z, bool *grouped_io) {
+  // grouped_io: in = the caller can take lists kept per group of 32 image positions (mfma_join_f16.hip, GROUPED); out = they are
+  const bool want_grouped = grouped_io && *grouped_io;
+  if (grouped_io) *grouped_io = false;
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
@@ -986,8 +989,11 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
         }
       }
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
+      const bool grouped = want_grouped && pre && !perm && (((uint64_t)T2 * super) >> 27) == 0 && ctx->opt_join_grouped_lists;
+      if (grouped_io) *grouped_io = grouped;
+      ctx->stats["knn_join_grouped_lists"] = grouped ? 1 : 0;
       AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm,
-                      pre ? mask.p : nullptr));
+                      pre ? mask.p : nullptr, grouped));
     } else {
       // rows wider than 128: the same first pass on the rotated coordinates the caller has (rotate_wide.hip), reduced to "which
       // pairs of 256-row super tiles hold anything" for the panelled kernel
@@ -1243,14 +1249,14 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
 // cnt (n) / cand (n x cap slots of two words): lists_by_pos = indexed by image position and holding positions, else indexed
 // by row and holding rows (the join kernel translates where it appends).
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
-                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos) {
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io) {
   // (the directions were tried above and do not carry the rows: the first pass, if any, takes the full-width image without
   // looking for them again)
   const int64_t saved_mode = ctx->opt_join_prefilter;
   if (oj.rot_z.p && !oj.wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
   const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_image, oj.cap, cnt, cand, nullptr, oj.P16own.p,
                                       oj.Phown.p, (oj.reorder && !lists_by_pos) ? oj.perm_own.p : nullptr,
-                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr);
+                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, grouped_io);
   ctx->opt_join_prefilter = saved_mode;
   return rc_pairs;
 }
@@ -1332,6 +1338,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   OwnJoin oj_local;
   const OwnJoin *oj = js ? js->oj : nullptr;
   bool lists_by_pos = false;            // the lists of the own join are indexed by (and hold) image positions
+  bool lists_grouped = false;           // ... and kept per group of 32 positions (mfma_join_f16.hip, GROUPED)
   DevBuf<uint32_t> cnt_own, cand_own;
   if (use_join) {
     if (own_join) {
@@ -1361,7 +1368,9 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(oj_local.inv_own.alloc(ctx, n));
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
-      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos));
+      // whole-matrix lists by image position feed the two-kernel re-rank alone: they may be kept per group of 32 positions
+      lists_grouped = lists_by_pos && ctx->opt_rerank_order && (ctx->opt_debug & ~(int64_t)8) == 0;
+      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos, &lists_grouped));
       if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, oj_local.theta_own.p, 1, cap, cnt_own.p, cand_own.p, oj_local.have_theta2 ? oj_local.theta2_own.p : nullptr,
                           oj_local.P16own.p, oj_local.Phown.p};
@@ -1398,9 +1407,17 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
         // the rows in the order of the image (a list of image positions is in that order already): neighbours share candidates
         const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n && ctx->opt_rerank_order) ? oj->perm_own.p : nullptr;
-        hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
-                           ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                           force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order);
+        if (lists_grouped) {
+          if (!score_order || js->n_src != 1) return fail(ctx, AS_ERR_HIP, "internal: lists by group need the re-rank in image order");
+          const size_t lds_g = (size_t)16 * js->cap * 8;
+          AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_prune_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+          hipLaunchKernelGGL(rerank_prune_grouped_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 32), 256 * 16)), dim3(256), lds_g, ctx->stream, row_count,
+                             js->theta, norms, js->cnt, js->cand, js->cap, K, force.p, prune_delta, rectify, records.p, slots, score_order, scored.p);
+        } else {
+          hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
+                             ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
+                             force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order);
+        }
         AS_HIP(ctx, hipGetLastError());
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
@@ -1443,8 +1460,11 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       DevBuf<unsigned long long> st;
       AS_TRY(st.alloc(ctx, 3));
       AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
-      hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
-                         js->cap, st.p);
+      if (lists_grouped)
+        hipLaunchKernelGGL(join_group_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, row_count, js->cap, st.p);
+      else
+        hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
+                           js->cap, st.p);
       unsigned long long h[3] = {0, 0, 0};
       AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
       ctx->stats["knn_join_cap"] = js->cap;

@@ -187,6 +187,16 @@ __global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uin
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
 
+// LDS traffic between the lanes of ONE wave (queues, listing slots).  The hardware keeps a wave's LDS operations in order, so all
+// that is needed is that they have been issued and completed (lgkmcnt) and that the compiler moves nothing across.  wave_sync()
+// (mfma_common.h) says the same with two wavefront-scope fences -- which hipcc lowers to s_waitcnt vmcnt(0) as well: every listed
+// block then waited for the stores and returning atomics of the flush before it and for the LDS-DMA of the next stage.
+__device__ __forceinline__ void lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // LDS fragment reads issued and waited for by hand (the compiler would wait each one out on the spot)
 template <int OFF>
 __device__ __forceinline__ void lds_read16(f16x8 &dst, uint32_t addr) {
@@ -252,7 +262,15 @@ struct F16SearchTerm {
 // MASKED (MODE 0): mask = what the int8 first pass found (mfma_prefilter_i8.hip): one byte per (row super tile, stage of 256
 // columns, wave), a bit per 32-column block that may hold a pair.  The unit visits only the stages with a bit set and a wave
 // contracts only its own blocks (the fragment ring then restarts at every block).
-template <int KS, int MODE, bool MASKED>
+// GROUPED (MODE 0, MASKED): the lists are kept per GROUP of 32 image positions instead of per row.  cnt[g] counts the entries of
+// group g, which owns the slots [g * 32 * cap, (g + 1) * 32 * cap) of cand; an entry is (other position | local row << 27, score).
+// What that buys: a wave's row-side pairs all go to the two groups of its 64 rows, so they are queued per group and leave with ONE
+// returning atomic per 96 entries and a contiguous write (whole 64-B segments); the column-side pairs of a block go to the block's
+// one column group -- a run in the column queue, one atomic per run, 64 runs per atomic instruction.  The per-row form took one
+// returning atomic and one scattered 8-byte store per entry (131 M of each at 1 M rows: two thirds of this kernel's time and
+// 4.4 bytes written per byte listed).  rerank_prune_grouped_kernel (rerank_split.h) bins a group's entries by row in LDS.
+constexpr uint32_t kRowQueue = 96, kColQueue = 120, kColRuns = 32, kGroupRows = 32, kGroupShift = 27;
+template <int KS, int MODE, bool MASKED, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
                                                                uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
                                                                const float *__restrict__ theta, uint32_t cap,
@@ -296,35 +314,108 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   auto flush_queue = [&]() {
     unsigned long long tf0 = 0;
     if (dbg & 8) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tf0)::"memory");
-    wave_sync();
+    lds_sync();
+    if constexpr (MODE == 0 && MASKED) {
+      // one entry per pair (row, column): bit 0 / 1 of the score = listed for the row / the column.  All the returning atomics of
+      // the queue's (up to four) rounds go out back to back and the stores follow: taken round by round (atomic, wait, store) a
+      // flush cost a wave four to eight exposed round trips (55 k cycles, stamps of round 3).
+      // (two rounds at a time: the four-round form needs 20 registers the kernel does not have)
+      constexpr int R = 2;
+      for (uint32_t k0 = 0; k0 * 64u < qn; k0 += R) {
+        uint32_t ta[R], tb[R], ts[R], pa[R], pb[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t e = (k0 + (uint32_t)k) * 64u + lane;
+          ts[k] = 0;
+          ta[k] = tb[k] = 0;
+          if (e < qn && !(dbg & 16384)) {
+            const uint2 v = queue[e];
+            if (v.x != v.y) {
+              ta[k] = perm ? perm[v.x] : v.x;
+              tb[k] = perm ? perm[v.y] : v.y;
+              ts[k] = __float_as_uint(queue_s[e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          pa[k] = pb[k] = 0;
+          if (ts[k] & 1u) pa[k] = atomicAdd(cnt + ta[k], 1u);
+          if (ts[k] & 2u) pb[k] = atomicAdd(cnt + tb[k], 1u);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t sc = ts[k] & ~3u;
+          if ((ts[k] & 1u) && pa[k] < cap) reinterpret_cast<uint2 *>(cand)[(size_t)ta[k] * cap + pa[k]] = make_uint2(tb[k], sc);
+          if ((ts[k] & 2u) && pb[k] < cap) reinterpret_cast<uint2 *>(cand)[(size_t)tb[k] * cap + pb[k]] = make_uint2(ta[k], sc);
+        }
+      }
+    } else {
     for (uint32_t base = 0; base < qn; base += 64) {
       const uint32_t e = base + lane;
       if (e < qn && !(dbg & 16384)) {
         // positions in the image -> row ids where the image is packed in a permuted order (row_order.hip); a list of the
         // search mode is owned by a query position, which stays
         const uint2 v = queue[e];
-        if constexpr (MODE == 0 && MASKED) {  // one entry per pair (row, column): bit 0 / 1 of the score = listed for the row / column
-          const uint32_t sb = __float_as_uint(queue_s[e]);
-          const float sc = __uint_as_float(sb & ~3u);
-          if (v.x != v.y) {
-            const uint32_t a = perm ? perm[v.x] : v.x, b = perm ? perm[v.y] : v.y;
-            if (sb & 1u) append16(cnt, cand, cap, a, b, sc);
-            if (sb & 2u) append16(cnt, cand, cap, b, a, sc);
-          }
-        } else {
+        {
           // (MODE 1: a list is owned by a query, perm_a: position in the query image -> query)
           const uint32_t owner = MODE == 0 ? (perm ? perm[v.x] : v.x) : (perm_a ? perm_a[v.x] : v.x), other = perm ? perm[v.y] : v.y;
           append16(cnt, cand, cap, owner, other, queue_s[e]);
         }
       }
     }
-    wave_sync();
+    }
+    lds_sync();
     qn = 0;
     if (dbg & 8) {
       unsigned long long tf1;
       asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tf1)::"memory");
       t_flush += tf1 - tf0;
     }
+  };
+  // GROUPED: the wave's 3 KB of queue space holds two row-group queues, the column queue, its runs (group, first entry, base
+  // slot) and the run of every column entry
+  // (the wave's queue space is two pieces: 2 KB of (owner, other) pairs and 1 KB of scores)
+  uint2 *rowq = queue;                                                   // [2][kRowQueue]
+  uint2 *colq = reinterpret_cast<uint2 *>(queue_s);                      // [kColQueue]
+  uint32_t *crun_g = reinterpret_cast<uint32_t *>(rowq + 2 * kRowQueue); // [kColRuns]
+  uint32_t *crun_s = crun_g + kColRuns;                                  // [kColRuns + 1]
+  uint32_t *crun_b = crun_s + kColRuns + 1;                              // [kColRuns]
+  unsigned char *crun_of = reinterpret_cast<unsigned char *>(crun_b + kColRuns);  // [kColQueue]
+  static_assert(!GROUPED || (2 * kRowQueue * 8 + (3 * kColRuns + 1) * 4 + kColQueue <= kQueueJoin * 8 && kColQueue * 8 <= kQueueJoin * 4),
+                "the grouped queues fit the two pieces of the queue space");
+  uint32_t rq_n0 = 0, rq_n1 = 0, cq_n = 0, cq_runs = 0, rq_g0 = 0;  // wave-uniform: entries queued per row group, column entries, runs; first row group
+  auto group_cap = [&](uint32_t g) -> uint32_t { return min((uint32_t)kGroupRows, n - min(n, g * kGroupRows)) * cap; };
+  auto flush_rows = [&](uint32_t which) {
+    const uint32_t cnt_r = which ? rq_n1 : rq_n0, g = rq_g0 + which;
+    if (cnt_r) {
+      lds_sync();
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cnt + g, cnt_r);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const uint32_t gc = group_cap(g);
+      uint2 *dst = reinterpret_cast<uint2 *>(cand) + (size_t)g * kGroupRows * cap;
+      for (uint32_t e = lane; e < cnt_r; e += 64)
+        if (base + e < gc) dst[base + e] = rowq[which * kRowQueue + e];
+      lds_sync();
+    }
+    if (which) rq_n1 = 0;
+    else rq_n0 = 0;
+  };
+  auto flush_cols = [&]() {
+    if (cq_n) {
+      if (lane == 0) crun_s[cq_runs] = cq_n;
+      lds_sync();
+      if ((uint32_t)lane < cq_runs) crun_b[lane] = atomicAdd(cnt + crun_g[lane], crun_s[lane + 1] - crun_s[lane]);  // one instruction: a run per lane
+      lds_sync();
+      for (uint32_t e = lane; e < cq_n; e += 64) {
+        const uint32_t k = crun_of[e], g = crun_g[k], slot = crun_b[k] + (e - crun_s[k]);
+        if (slot < group_cap(g)) reinterpret_cast<uint2 *>(cand)[(size_t)g * kGroupRows * cap + slot] = colq[e];
+      }
+      lds_sync();
+    }
+    cq_n = 0;
+    cq_runs = 0;
   };
   const uint32_t n_norm = (T2 - 1) / 2;
   const uint32_t n_cblocks = (T2 + W - 1) / W;
@@ -427,6 +518,11 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       }
     }
     const uint32_t row_base0 = I * kSuperH + wv * 64 + 4 * lh, row_base1 = row_base0 + 32;  // + (r & 3) + 8 * (r >> 2)
+    if constexpr (GROUPED) {  // the row queues of the unit before belong to other groups
+      flush_rows(0);
+      flush_rows(1);
+      rq_g0 = (I * kSuperH + wv * 64) >> 5;
+    }
     v16f32 nth0, nth1;              // minus the scaled row thresholds: the C operand of a block's first MFMA
     float tmax0 = -__builtin_inff(), tmax1 = -__builtin_inff();  // largest finite scaled threshold of each row group
 #pragma unroll
@@ -476,10 +572,124 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           return r;
         };
         {  // most blocks hold no pair at all: two maxima per lane settle that before the walk
+           // (a one-maximum test in front, max(acc) >= min(0, theta_col - largest row threshold), was tried: one more live value
+           // across the listing and the kernel, at 256 registers, spilled 115 of them -- 8.1 -> 14.1 ms)
           v16f32 v;
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
           if (!__any(max16(acc) >= z || max16(v) >= tc)) return false;
+        }
+        if constexpr (GROUPED) {
+          // one entry per listed side of a pair: the row side into the queue of the row's group (this wave's first or second),
+          // the column side into the column queue, where the block's entries form one run for the block's column group
+          const uint32_t rg0 = __builtin_amdgcn_readfirstlane(row_group0), cb0 = __builtin_amdgcn_readfirstlane(colbase);  // (uniform: say so)
+          const uint32_t which = (rg0 >> 5) & 1u;
+          const uint32_t rq_addr = lds_addr(rowq + which * kRowQueue), cq_addr = lds_addr(colq), of_addr = lds_addr(crun_of);
+          const bool diag_block = rg0 == cb0;  // only there can a pair be (i, i)
+          bool listed = false, run_open = false;
+          uint32_t run_k = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float vr = acc[r] - nth[r];
+            unsigned long long m1 = cmp_ge(acc[r], z), m2 = cmp_ge(vr, tc);
+            if ((m1 | m2) == 0) continue;
+            const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
+            if (diag_block) {
+              const unsigned long long ms = __ballot(row == col);
+              m1 &= ~ms;
+              m2 &= ~ms;
+              if ((m1 | m2) == 0) continue;
+            }
+            const uint32_t sbits = __float_as_uint(vr * (1.f / kProductScale));
+            if (m1) {
+              const uint32_t n1 = (uint32_t)__builtin_popcountll(m1);
+              if ((which ? rq_n1 : rq_n0) + n1 > kRowQueue) flush_rows(which);
+              const uint32_t o = (which ? rq_n1 : rq_n0) + lanes_below(m1);
+              const unsigned long long ent = ((unsigned long long)sbits << 32) | (col | ((row - rg0) << kGroupShift));
+              unsigned long long saved;
+              asm volatile(
+                  "s_and_saveexec_b64 %0, %1\n\t"
+                  "ds_write_b64 %2, %3\n\t"
+                  "s_mov_b64 exec, %0"
+                  : "=&s"(saved)
+                  : "s"(m1), "v"(rq_addr + 8u * o), "v"(ent)
+                  : "memory");
+              if (which) rq_n1 += n1;
+              else rq_n0 += n1;
+              listed = true;
+            }
+            if (m2) {
+              const uint32_t n2 = (uint32_t)__builtin_popcountll(m2);
+              if (cq_n + n2 > kColQueue || (!run_open && cq_runs == kColRuns)) {
+                flush_cols();
+                run_open = false;
+              }
+              if (!run_open) {  // the block's run: its 32 columns are one group
+                run_k = cq_runs;
+                if (lane == 0) {
+                  crun_g[run_k] = cb0 >> 5;
+                  crun_s[run_k] = cq_n;
+                }
+                cq_runs += 1;
+                run_open = true;
+              }
+              const uint32_t o = cq_n + lanes_below(m2);
+              const unsigned long long ent = ((unsigned long long)sbits << 32) | (row | ((uint32_t)lc << kGroupShift));
+              unsigned long long saved;
+              asm volatile(
+                  "s_and_saveexec_b64 %0, %1\n\t"
+                  "ds_write_b64 %2, %3\n\t"
+                  "ds_write_b8 %4, %5\n\t"
+                  "s_mov_b64 exec, %0"
+                  : "=&s"(saved)
+                  : "s"(m2), "v"(cq_addr + 8u * o), "v"(ent), "v"(of_addr + o), "v"(run_k)
+                  : "memory");
+              cq_n += n2;
+              listed = true;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          lds_sync();
+          return listed;
+        }
+        if (!(dbg & 0x800000)) {  // (debug bit 23: the register-by-register walk below, kept as the form for blocks too dense for the queue)
+          // Every lane looks at its own 16 products (one column, 16 rows): which reach the row's threshold, which the column's;
+          // a wave-wide prefix sum of the counts gives each lane its place in the queue, and it writes its pairs there one
+          // register at a time under its own predicate.  No scalar mask is formed per register: the walk that did (two compares
+          // into SGPR pairs, population counts, a branch and an exec-masked write per register) spent 9 k cycles per listed block
+          // on scalar round trips.
+          uint32_t b1 = 0, b2 = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float vr = acc[r] - nth[r];
+            b1 |= acc[r] >= z ? (1u << r) : 0u;
+            b2 |= vr >= tc ? (1u << r) : 0u;
+          }
+          const uint32_t bb = b1 | b2, c = (uint32_t)__builtin_popcount(bb);
+          uint32_t inc = c;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+          }
+          const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          if (tot == 0) return false;
+          if (tot <= kQueueH) {
+            if (qn + tot > kQueueH) flush_queue();
+            uint32_t o = qn + inc - c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if ((bb >> r) & 1u) {
+                const float vr = acc[r] - nth[r];
+                queue[o] = make_uint2(row0 + (r & 3) + 8 * (r >> 2), col);
+                queue_s[o] = __uint_as_float((__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | ((b1 >> r) & 1u) | (((b2 >> r) & 1u) << 1));
+                ++o;
+              }
+            }
+            qn += tot;
+            lds_sync();
+            return true;
+          }
         }
         uint32_t resume = 0;
         bool listed = false;
@@ -516,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           flush_queue();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wave_sync();
+        lds_sync();
         return listed;
       } else {
       v16f32 v;
@@ -550,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           sl[32] = __uint_as_float((uint32_t)lane);
           sl[33] = tc;
         }
-        wave_sync();
+        lds_sync();
         const uint32_t filled = min(4u, (uint32_t)__builtin_popcountll(m));
         const uint32_t slot = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
         const float *sl = ex + slot * kSlotFloats;
@@ -585,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           queue_s[qn + n1 + lanes_below(m2)] = sc;
         }
         qn += n1 + n2;
-        wave_sync();
+        lds_sync();
         m &= m - 1;  // the four lowest lanes are done
         m &= m - 1;
         m &= m - 1;
@@ -747,7 +957,13 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       }
     }
   }
-  flush_queue();
+  if constexpr (GROUPED) {
+    flush_rows(0);
+    flush_rows(1);
+    flush_cols();
+  } else {
+    flush_queue();
+  }
   if (lane == 0) {
     atomicAdd(stamps + 5, n_blk);
     atomicAdd(stamps + 7, n_pass);
@@ -857,7 +1073,9 @@ static size_t f16_join_lds(uint32_t KS, bool search) {
 // zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm,
-             const unsigned char *mask) {
+             const unsigned char *mask, bool grouped) {
+  if (grouped && (!mask || perm || ((uint64_t)((n + kSuperH - 1) / kSuperH) * kSuperH >> kGroupShift) != 0))
+    return fail(ctx, AS_ERR_ARG, "f16 join: lists by group need the first pass, an image in its own positions and fewer than 2^27 rows");
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
@@ -873,7 +1091,14 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
     ProfScope ps(ctx, prof_name);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    if (mask) {                                                                                                           \
+    if (mask && grouped) {                                                                                                \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true, true>,                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P, \
+                         (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
+                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
+                         (const uint32_t *)nullptr);                                                                      \
+    } else if (mask) {                                                                                                    \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true>,                                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
       hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \

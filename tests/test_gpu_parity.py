@@ -371,6 +371,33 @@ def test_item_graph_join_behind_the_int8_first_pass(ctx, join_on, n, d, mode, is
     assert np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("n,topk", [(70000, 16), (66001, 40), (131072, 5)])
+def test_item_graph_join_lists_by_group(ctx, join_on, n, topk):
+    """"join_grouped_lists" 1: the masked f16 pass keeps its candidates per group of 32 image positions (one returning atomic per
+    run of entries, contiguous writes) and the pruning kernel bins a group's entries by row in LDS.  Off by default (measured
+    slower end to end); the tables are those of the per-row lists and the oracle's.  Duplicates, a zero row, ragged tiles, a
+    table deeper than a record."""
+    X, _ = synth.mixture(n, 128, seed=29, n_clusters=9 if n < 10000 else 40, rank=4)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25)
+    ctx.set_option("join_prefilter_min_rows", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_grouped_lists") == 0
+        ctx.set_option("join_grouped_lists", 1)
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_grouped_lists") == 1
+    finally:
+        ctx.set_option("join_grouped_lists", 0)
+        ctx.set_option("join_prefilter_min_rows", 65536)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(n, size=min(n, 256), replace=False))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 def _stress_case(seed, index):
     """Case `index` of scripts/stress_first_pass.py for `seed` (the same draws in the same order)."""
     rng = np.random.default_rng(seed)
