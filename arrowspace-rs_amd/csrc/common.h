@@ -8,8 +8,11 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <functional>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -164,6 +167,11 @@ struct as_csr {
 };
 
 struct as_index {
+  // Concurrency (the reference's search takes &self, src/core.rs:760, and ArrowSpace is Sync): any number of contexts / threads may
+  // search one index at once.  A search holds `rw` shared while it reads the state below; whatever is built lazily (images,
+  // orders, samples) is built under `rw` held exclusively, by whichever search finds it missing, and the building stream is
+  // synchronised before the lock is released -- so a reader never sees a half-built image, and an image is never freed under one.
+  mutable std::shared_mutex rw;
   int device = 0;
   uint64_t n = 0, d = 0;
   const double *items = nullptr;    // n x d (device); owned iff own_items
@@ -191,7 +199,7 @@ struct as_index {
   float *rot_q = nullptr;           // its 31 directions (32 x 128)
   double rot_err = -1.0;            // its largest quantisation error norm
   int rot_state = 0;                // 0 not tried, 1 usable, -1 the directions do not carry the items
-  uint32_t scan_calls = 0;          // searches run on this index so far
+  std::atomic<uint32_t> scan_calls{0};  // searches run on this index so far
   uint32_t scan_ns = 0;
 };
 

@@ -1948,8 +1948,22 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     return search_exact(ctx, ix, queries, q_norms, q_lambdas, nullptr, nq, nq, k, alpha, out_idx, out_key);
   // an index that is searched again gets its items ordered by direction and a rotated int8 image (below); with those a small
   // batch reads 32 MB + the few blocks its queries can reach instead of streaming the 1 GB of rows
-  const uint32_t prior_calls = ix->scan_calls;
-  ix->scan_calls += 1;
+  const uint32_t prior_calls = ix->scan_calls.fetch_add(1);
+  // shared for the whole search; a lazy build drops it, takes the index exclusively, builds (re-checking), synchronises the stream
+  // and comes back (as_index, common.h).  Pointers of the index are read where they are used, after the builds.
+  std::shared_lock<std::shared_mutex> reading(ix->rw);
+#define AS_IX_BUILD(cond, ...)                                      \
+  if (cond) {                                                       \
+    reading.unlock();                                               \
+    {                                                               \
+      std::unique_lock<std::shared_mutex> building(ix->rw);         \
+      if (cond) {                                                   \
+        __VA_ARGS__                                                 \
+        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));             \
+      }                                                             \
+    }                                                               \
+    reading.lock();                                                 \
+  }
   const bool ordered_ok = !wide && n >= 65536 && ctx->opt_join_pipe == 16 && ctx->opt_search_scan_f16 && ctx->opt_search_scan &&
                           (ctx->opt_search_scan_order == 2 || (ctx->opt_search_scan_order == 1 && prior_calls >= 1));
   const bool prefer_staged = ordered_ok && ctx->opt_search_prefilter && d > 32 && ix->rot_state >= 0 && alpha > 0.0 && alpha <= 1.0 &&
@@ -1967,6 +1981,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     StreamFilter flt{};
     const StreamFilter *use_filter = nullptr;
     if (ctx->opt_search_stream_filter && prior_calls >= 1 && alpha > 0.0 && alpha <= 1.0 && ix->rot_state >= 0 && ix->weird_items != 1) {
+      AS_IX_BUILD(ix->weird_items < 0 || (ix->weird_items == 0 && ix->rot_state == 0) || (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat),
       if (ix->weird_items < 0) {  // (a non-finite norm or lambda must reach the exact arithmetic: no filter for such an index)
         DevBuf<int> wc;
         AS_TRY(wc.alloc(ctx, 1));
@@ -1988,6 +2003,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         AS_HIP(ctx, hipMalloc(&ix->packed8_nat, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, nullptr, n, d, ix->rot_q, ix->packed8_nat, tiles, &ix->rot_err_nat));
       }
+      )
       if (ix->weird_items == 0 && ix->rot_state == 1 && ix->packed8_nat) {
         flt = StreamFilter{ix->packed8_nat, (float)(ix->rot_err_nat * (1.0 + 1e-6)), ix->rot_q, q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
         use_filter = &flt;
@@ -2023,17 +2039,17 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   auto ensure64 = [&]() -> int {
-    if (!ix->packed) {
+    AS_IX_BUILD(!ix->packed,
       AS_HIP(ctx, hipMalloc((void **)&ix->packed, sizeof(double) * packed_elems(b_alloc, d)));
       AS_TRY(pack_f64(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed, b_alloc));
-    }
+    )
     return AS_OK;
   };
   auto ensure32 = [&]() -> int {
-    if (!ix->packed32) {
+    AS_IX_BUILD(!ix->packed32,
       AS_HIP(ctx, hipMalloc((void **)&ix->packed32, sizeof(float) * packed_elems(b_alloc, d)));
       AS_TRY(pack_f32(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed32, b_alloc));
-    }
+    )
     return AS_OK;
   };
 
@@ -2095,6 +2111,14 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // finding their directions and the second image cost ~5 ms at 1 M items, so an index gets them at its SECOND scan
     // (search_scan_order = 2: at the first): one-shot use pays nothing, a serving index pays once.
     const bool want_order = scan_h && ordered_ok;
+    const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
+    auto scan_state_missing = [&]() -> bool {
+      return (want_order && !ix->scan_perm && ix->packedh) || ((scan_wide || scan_h) && !ix->packedh) ||
+             (scan_h && ctx->opt_search_prefilter && d > 32 && (want_order || ix->scan_perm) && (ix->rot_state == 0 || (ix->rot_state == 1 && !ix->packed8))) ||
+             (!scan_wide && !scan_h && !ix->packed16) ||
+             !ix->lam32 || (scan_h && ix->scan_perm && !ix->lam32_pos) || !ix->scan_sample || ix->scan_ns != ns_want;
+    };
+    AS_IX_BUILD(scan_state_missing(),
     if (want_order && !ix->scan_perm && ix->packedh) {  // (the image of the first scan was in the order of the items)
       (void)hipFree(ix->packedh);
       ix->packedh = nullptr;
@@ -2110,13 +2134,18 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles, ix->scan_perm));
       ix->f16_err = ctx->f16_err;
     }
-    if (scan_h && ix->scan_perm && ix->rot_state == 0 && ctx->opt_search_prefilter && d > 32) {
+    if (scan_h && ix->scan_perm && ctx->opt_search_prefilter && d > 32) {
       const uint32_t tiles = packed_tiles_f16(n);
-      double tail = 1.0;
-      if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
-      AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
-      ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
-      if (ix->rot_state == 1) {
+      if (ix->rot_state == 0) {
+        double tail = 1.0;
+        if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+        AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
+        ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
+      }
+      // (the directions may have been found by a small batch before, for its own image in the order of the items: the image by
+      // position is this path's to build -- it used to be built only together with the directions, and a large batch that came
+      // after a small one then handed the first pass a null image)
+      if (ix->rot_state == 1 && !ix->packed8) {
         AS_HIP(ctx, hipMalloc(&ix->packed8, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, ix->scan_perm, n, d, ix->rot_q, ix->packed8, tiles, &ix->rot_err));
       }
@@ -2137,8 +2166,6 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream, ix->lambdas,
                          (const uint32_t *)ix->scan_perm, n, lpad, ix->lam32_pos);
     }
-    const float *x_lam_h = (scan_h && ix->scan_perm) ? ix->lam32_pos : ix->lam32;  // what the f16 scan of narrow items reads
-    const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
     if (ix->scan_sample && ix->scan_ns != ns_want) {  // the option changed since the sample was drawn
       (void)hipFree(ix->scan_sample);
       (void)hipFree(ix->scan_sample_lam);
@@ -2156,6 +2183,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_HIP(ctx, hipGetLastError());
       ix->scan_ns = ns;
     }
+    )
+    const float *x_lam_h = (scan_h && ix->scan_perm) ? ix->lam32_pos : ix->lam32;  // what the f16 scan of narrow items reads
     const uint32_t ns = ix->scan_ns;
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_search_scan_rank, 32));
     const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = scan_h ? (a_tiles + 3) & ~3u : (a_tiles + 1) & ~1u;
@@ -2478,5 +2507,6 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   }
   return AS_OK;
 }
+#undef AS_IX_BUILD
 
 }  // namespace asx

@@ -394,9 +394,11 @@ int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len
                   double tau_arg, double *taus_out);
 
 /* ---- search: replaces ArrowSpace::search_lambda_aware, src/core.rs:760-798 ---------------- */
-/* An index handle has ONE owner: searches keep lazily built state with it (ordered / rotated images from the second search
- * on, a call counter), so two contexts or threads must not search the same handle at once -- create one index per searching
- * thread (the items are borrowed when they are in HBM already, so that costs no second copy). */
+/* An index may be searched from several contexts / threads at once (the reference's search takes &self, src/core.rs:760, and
+ * ArrowSpace is Sync): every searching thread brings its own as_ctx (scratch and stream are the context's), the handle is
+ * shared.  What a search builds lazily and keeps with the index (ordered / rotated images from the second search on, samples)
+ * is built under a writer lock inside the handle, with the building stream synchronised before readers go on; a search holds
+ * the reader side.  as_index_destroy must not run while a search is in flight. */
 int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uint64_t n_items,
                     uint64_t n_features, as_index **out);
 void as_index_destroy(as_index *index);

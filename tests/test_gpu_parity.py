@@ -1668,3 +1668,74 @@ def test_streaming_lambda_query_nonfinite_is_an_error(ctx):
     lq = asp.prepare_query_items(Q, gl)
     want = np.array([O.prepare_query_item(q, gl.matrix.to_host(), O.TAU_MEDIAN, 0.0) for q in Q])
     np.testing.assert_allclose(lq, want, rtol=LAMBDA_RTOL)
+
+
+def test_concurrent_searches_on_one_index(ctx):
+    """The reference's search takes &self (src/core.rs:760) and ArrowSpace is Sync: several threads, each with its own context,
+    search ONE index at the same time -- from its very first search on, so that the lazily built state (images, orders,
+    samples: as_index in csrc/common.h) is built while others are reading.  Every result equals the oracle's."""
+    import ctypes as C
+    import threading
+    n, d, k, alpha = 70000, 128, 10, 0.7
+    X, cent = synth.mixture(n, d, seed=61, n_clusters=32, rank=6)
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(X, cent)
+    lam = np.asarray(asp.lambdas())
+    index = asp._ensure_index()
+    Xdev = asp._items()
+    rng = np.random.default_rng(8)
+    batches = {}
+    for t, nq in enumerate((1, 7, 1500, 1, 33, 2048)):   # small batches (streamed), large ones (threshold scan), twice each kind
+        qi = rng.choice(n, size=nq, replace=False)
+        Q = np.ascontiguousarray(X[qi] * 1.02)
+        batches[t] = (Q, np.asarray(asp.prepare_query_items(Q, gl)))
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            c = A.Context(0)          # a context per thread; the index is shared
+            Q, lq = batches[t]
+            nq = Q.shape[0]
+            for rep in range(3):      # the first call builds state, the later ones find it (or find it being rebuilt in order)
+                idx = np.empty((nq, k), dtype=np.uint64)
+                sc = np.empty((nq, k), dtype=np.float64)
+                c.check(c.lib.as_search_lambda_aware(c.h, index, _lib.ptr(Q), _lib.ptr(lq), nq, k, alpha, 0, _lib.ptr(idx), _lib.ptr(sc)))
+                results[(t, rep)] = (idx, sc)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in batches]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t, (Q, lq) in batches.items():
+        for j in np.linspace(0, Q.shape[0] - 1, min(Q.shape[0], 6)).astype(int):
+            oi, osc = O.search_lambda_aware(X, lam, Q[j], float(lq[j]), k, alpha)
+            for rep in range(3):
+                idx, sc = results[(t, rep)]
+                assert np.array_equal(idx[j], oi), (t, rep, j)
+                assert np.array_equal(sc[j], osc), (t, rep, j)
+        for rep in (1, 2):   # and the same batch gives the same table every time
+            assert np.array_equal(results[(t, rep)][0], results[(t, 0)][0]) and np.array_equal(results[(t, rep)][1], results[(t, 0)][1])
+
+
+def test_large_batch_after_a_small_one_on_the_same_index(ctx):
+    """An index's second search finds the items' directions for whichever path runs; the rotated image by position belongs to the
+    large-batch scan, the one in item order to the small-batch filter.  A small batch in between used to leave the scan's image
+    unbuilt (null first-pass operand).  Sequence: large, small, large, small -- every table the oracle's."""
+    n, d, k, alpha = 70000, 128, 10, 0.7
+    X, cent = synth.mixture(n, d, seed=62, n_clusters=32, rank=6)
+    asp, gl = A.ArrowSpaceBuilder.new(ctx).with_lambda_graph(0.5, 16, 16, 2.0, 0.25).build(X, cent)
+    lam = np.asarray(asp.lambdas())
+    rng = np.random.default_rng(9)
+    for nq in (1200, 3, 2100, 1, 2100):
+        qi = rng.choice(n, size=nq, replace=False)
+        Q = np.ascontiguousarray(X[qi] * 1.02)
+        lq = np.asarray(asp.prepare_query_items(Q, gl))
+        idx, sc = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+        for j in np.linspace(0, nq - 1, min(nq, 5)).astype(int):
+            oi, osc = O.search_lambda_aware(X, lam, Q[j], float(lq[j]), k, alpha)
+            assert np.array_equal(np.asarray(idx)[j], oi.astype(np.int64)) and np.array_equal(np.asarray(sc)[j], osc), (nq, j)
+    assert ctx.stat("search_scan_prefilter") == 1   # the last large batch ran behind the first pass
