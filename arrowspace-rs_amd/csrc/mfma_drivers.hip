@@ -916,7 +916,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
   hipLaunchKernelGGL(join_theta_kernel, dim3(cdiv(row_count, 256)), dim3(256), 0, ctx->stream, ckey.p, cidx.p, row_count,
                      KC0, m, row_count, theta_out);
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
 }
 
@@ -1026,7 +1026,6 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
     ctx->stats["knn_join_blocks"] = (int64_t)(I_end - I_begin) * 64;  // at least the diagonal super tiles
     ctx->stats["knn_join_pipe"] = 32;
   }
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;
 }
 
@@ -1545,7 +1544,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                              pb.splits, ckey.p, cidx.p, force.p, pol, bnd, out_dist, out_idx, fail1.p, fail_count.p,
                              err.p));
       }
-      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // candidate buffers go back to the workspace cache
+      // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
     }
     if (ctx->opt_debug) return AS_OK;
     pb.splits = splits_used;
@@ -1639,7 +1638,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                          0u, ids_out.p);
       hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_pos, failx.p, n_next,
                          0u, pos_out.p);
-      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // failx goes back to the workspace cache
+      // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
       cur_ids = ids_out.p;
       cur_pos = pos_out.p;
     }
@@ -1745,7 +1744,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                          ids_r.p);
       hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_next, 256)), dim3(256), 0, ctx->stream, cur_pos, failx.p, n_next, 0u,
                          pos_r.p);
-      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // failx goes back to the workspace cache
+      // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
       cur_ids = ids_r.p;
       cur_pos = pos_r.p;
     }

@@ -668,7 +668,7 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
   hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(row_count, 64)), dim3(64), 0, ctx->stream, maxima.p, row_count, m, m2, theta_out,
                      theta2_out);
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
 }
 

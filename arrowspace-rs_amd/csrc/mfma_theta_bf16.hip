@@ -408,7 +408,7 @@ static int launch_theta(as_ctx *ctx, uint32_t KS, const void *PA, uint32_t a_sup
     hipLaunchKernelGGL(theta_select_kernel, dim3(cdiv(row_count, 4)), dim3(256), 0, ctx->stream, (const float *)part.p, 64u * slices, row_count, m,
                        theta_out, m2, theta2_out);
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's images may go back to the workspace cache
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
 }
 

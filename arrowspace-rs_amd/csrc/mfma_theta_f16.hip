@@ -388,7 +388,7 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   }
 #undef AS_THETA
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sample image goes back to the workspace cache
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
 }
 

@@ -10,8 +10,6 @@
 // appends to the lists.  Nothing else sees the permutation: thresholds are scattered back to row order, the re-rank, its
 // tie-breaks by row id and every later stage work on the rows as given.  Any permutation is correct; this one is cheap
 // (about 2 ms at 1 M x 128) and needs no clustering from the caller.
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
 
 namespace asx {
@@ -309,7 +307,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   if (group_start)
     hipLaunchKernelGGL(order_group_starts_kernel, dim3(cdiv(np + 1, 256)), dim3(256), 0, ctx->stream, offsets.p, n_blocks, np, n, group_start);
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the buffers of this pass go back to the workspace cache
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
 }
 
@@ -362,36 +360,102 @@ int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t
 
 // perm[p] = the index of the p-th smallest value (stable: equal values keep their order; NaNs last): the queries of a batch in
 // the order of their lambdas, so that the 32 rows of a row group of the search scan share a narrow lambda range (mfma_join_f16.hip)
+//
+// A sort of (order-preserving 64-bit key, index) pairs, hand-written: chunks of 4096 pairs are sorted in LDS by one workgroup
+// each (bitonic network), then runs are merged pairwise, every element finding its place by a binary search in the partner run.
+// The pair (key, index) is a total order (indices are distinct), so the result is THE stable order whatever network sorts it.
+// 10 k queries: one chunk pass + two merge passes, three launches on the context's stream and no host round trip (a library
+// radix sort stood here through round 3: four launches of its own and a synchronisation to hand its buffers back).
 namespace {
-__global__ void value_keys_kernel(const double *__restrict__ v, uint32_t n, unsigned long long *__restrict__ keys, uint32_t *__restrict__ ids) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = v[i];
+constexpr uint32_t kSortChunk = 4096;
+struct KeyId {
+  unsigned long long k;
+  uint32_t i;
+};
+__device__ __forceinline__ bool keyid_less(unsigned long long ka, uint32_t ia, unsigned long long kb, uint32_t ib) { return ka < kb || (ka == kb && ia < ib); }
+__device__ __forceinline__ unsigned long long value_key(double x) {
   unsigned long long b = (unsigned long long)__double_as_longlong(x);
   b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // order-preserving
-  if (x != x) b = ~0ull;
-  keys[i] = b;
-  ids[i] = i;
+  return x != x ? ~0ull : b;
+}
+// one workgroup per chunk: keys from the values, bitonic sort of (key, index) in LDS, sorted chunk out
+__global__ __launch_bounds__(1024) void sort_chunks_kernel(const double *__restrict__ v, uint32_t n, unsigned long long *__restrict__ keys,
+                                                           uint32_t *__restrict__ ids) {
+  __shared__ unsigned long long s_k[kSortChunk];
+  __shared__ uint32_t s_i[kSortChunk];
+  const uint32_t base = blockIdx.x * kSortChunk;
+  for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+    const uint32_t g = base + t;
+    s_k[t] = g < n ? value_key(v[g]) : ~0ull;
+    s_i[t] = g < n ? g : 0xFFFFFFFFu;  // padding sorts behind everything (a NaN has key ~0 too, and a smaller index)
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= kSortChunk; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+        const uint32_t p = t ^ j;
+        if (p > t) {
+          const unsigned long long ka = s_k[t], kb = s_k[p];
+          const uint32_t ia = s_i[t], ib = s_i[p];
+          const bool up = (t & k) == 0;
+          if (keyid_less(kb, ib, ka, ia) == up) {
+            s_k[t] = kb, s_i[t] = ib;
+            s_k[p] = ka, s_i[p] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+    const uint32_t g = base + t;
+    if (g < n) {
+      keys[g] = s_k[t];
+      ids[g] = s_i[t];
+    }
+  }
+}
+// runs of `run` sorted pairs -> runs of 2 `run`: element e of a run goes to (its index in the run) + (elements of the partner run
+// that precede it)
+__global__ void merge_runs_kernel(const unsigned long long *__restrict__ k_in, const uint32_t *__restrict__ i_in, uint32_t n, uint32_t run,
+                                  unsigned long long *__restrict__ k_out, uint32_t *__restrict__ i_out) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const uint32_t r = e / run, pair0 = (r & ~1u) * run;
+  const uint32_t other0 = (r & 1u) ? pair0 : pair0 + run, other1 = min(other0 + run, n);
+  const unsigned long long k = k_in[e];
+  const uint32_t i = i_in[e];
+  uint32_t lo = min(other0, n), hi = other1;  // (a last run without a partner: nothing precedes)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keyid_less(k_in[mid], i_in[mid], k, i)) lo = mid + 1;
+    else hi = mid;
+  }
+  const uint32_t dst = pair0 + (e - r * run) + (lo - min(other0, n));
+  k_out[dst] = k;
+  i_out[dst] = i;
 }
 }  // namespace
 int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm) {
   if (n == 0) return AS_OK;
-  DevBuf<unsigned long long> k_in, k_out;
-  DevBuf<uint32_t> ids;
-  DevBuf<unsigned char> tmp;
-  AS_TRY(k_in.alloc(ctx, n));
-  AS_TRY(k_out.alloc(ctx, n));
-  AS_TRY(ids.alloc(ctx, n));
-  hipLaunchKernelGGL(value_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, values, n, k_in.p, ids.p);
-  size_t bytes = 0;
-  AS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)k_in.p, k_out.p, (const uint32_t *)ids.p, perm, (int)n, 0, 64,
-                                                 ctx->stream));
-  AS_TRY(tmp.alloc(ctx, std::max<size_t>(bytes, 16)));
-  AS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, (const unsigned long long *)k_in.p, k_out.p, (const uint32_t *)ids.p, perm, (int)n, 0, 64,
-                                                 ctx->stream));
+  DevBuf<unsigned long long> ka, kb;
+  DevBuf<uint32_t> ib;
+  AS_TRY(ka.alloc(ctx, n));
+  AS_TRY(kb.alloc(ctx, n));
+  AS_TRY(ib.alloc(ctx, n));
+  // the number of merge passes decides where the chunk pass writes, so that the last pass lands in `perm`
+  uint32_t passes = 0;
+  for (uint64_t run = kSortChunk; run < n; run <<= 1) ++passes;
+  unsigned long long *k_cur = ka.p, *k_nxt = kb.p;
+  uint32_t *i_cur = (passes & 1u) ? ib.p : perm, *i_nxt = (passes & 1u) ? perm : ib.p;
+  hipLaunchKernelGGL(sort_chunks_kernel, dim3(cdiv(n, kSortChunk)), dim3(1024), 0, ctx->stream, values, n, k_cur, i_cur);
+  for (uint64_t run = kSortChunk; run < n; run <<= 1) {
+    hipLaunchKernelGGL(merge_runs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)k_cur, (const uint32_t *)i_cur, n,
+                       (uint32_t)run, k_nxt, i_nxt);
+    std::swap(k_cur, k_nxt);
+    std::swap(i_cur, i_nxt);
+  }
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the buffers go back to the workspace cache)
-  return AS_OK;
+  return AS_OK;  // (the workspace blocks go back to the cache of the ONE stream every later user runs on: common.h, ws_alloc)
 }
 
 }  // namespace asx
