@@ -333,6 +333,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;
   else if (n == "signal_sym") ctx->opt_signal_sym = value;
   else if (n == "signal_order") ctx->opt_signal_order = value;
+  else if (n == "signal_order_refine") ctx->opt_signal_order_refine = value;
   else if (n == "signal_chunk_rows") ctx->opt_signal_chunk_rows = std::min<int64_t>(std::max<int64_t>(1, value), 1024);
   else if (n == "signal_waves") ctx->opt_signal_waves = std::max<int64_t>(0, value);
   else if (n == "signal_min_len") ctx->opt_signal_min_len = std::max<int64_t>(1, value);

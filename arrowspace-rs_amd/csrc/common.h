@@ -103,6 +103,8 @@ struct as_ctx {
   int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
   int64_t opt_signal_sym = 1;            // item-graph lambda (signal_lambda.hip): a bitwise symmetric graph is streamed as its upper triangle
   int64_t opt_signal_order = 1;          // ... in the order attached to the graph (as_csr_set_order / the join's own); 0: the rows as stored
+  int64_t opt_signal_order_refine = 0;   // ... the blocks of 1024 positions of that order chained by the entries between them (groups of one cluster end up side
+                                         // by side: the pass 0.86 -> 0.78 ms at 1 M x 128, but 3.2 ms more to prepare the stream (host chain): for graphs used many times)
   int64_t opt_signal_chunk_rows = 16;    // ... consecutive rows a wave takes at a time
   int64_t opt_signal_waves = 0;          // ... waves of the graph pass in all (0: one chunk per wave; else the waves of an XCD group interleave their chunks)
   int64_t opt_signal_min_len = 9000;     // as_compute_taumode: signals this long or longer go through the item-graph kernels

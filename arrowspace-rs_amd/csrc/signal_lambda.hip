@@ -200,6 +200,36 @@ __global__ void sig_pad_kernel(SigGeom g, uint64_t row_begin, const uint32_t *__
   cnt[last] += (uint32_t)((8 - total % 8) % 8);
 }
 
+// ---- refining a given order by the graph itself --------------------------------------------------------------------------------
+// The order a neighbour search leaves groups the rows by direction (nearest pivot), but lists the groups in no particular
+// order: the groups of one cluster sit far apart, and the rows a group gathers from its sister groups are evicted between
+// their visits.  So the positions are cut into blocks of 1024, the stored entries between blocks are counted (a small dense
+// matrix), and the blocks are chained greedily on the host: each next block is the unvisited one with the most entries towards
+// the last two placed.  Blocks that belong together then follow each other.  Any outcome is a permutation, hence correct.
+constexpr uint32_t kRefineBlock = 1024;
+__global__ void order_inverse_kernel(const uint32_t *__restrict__ order, uint64_t n, uint32_t *__restrict__ inv) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) inv[order[p]] = (uint32_t)p;
+}
+__global__ void block_edges_kernel(const uint64_t *__restrict__ indptr, const uint64_t *__restrict__ indices, uint64_t n,
+                                   const uint32_t *__restrict__ inv, uint32_t nb, uint32_t *__restrict__ counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t bi = inv[i] / kRefineBlock;
+  for (uint64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+    const uint64_t j = indices[e];
+    if (j >= n) continue;
+    const uint32_t bj = inv[j] / kRefineBlock;
+    if (bj != bi) atomicAdd(&counts[(size_t)bi * nb + bj], 1u);
+  }
+}
+__global__ void order_apply_blocks_kernel(const uint32_t *__restrict__ order, uint64_t n, const uint32_t *__restrict__ new_start,
+                                          uint32_t *__restrict__ out) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  out[new_start[p / kRefineBlock] + (uint32_t)(p % kRefineBlock)] = order[p];
+}
+
 __global__ void order_check_kernel(const uint32_t *__restrict__ order, uint64_t n, uint32_t *__restrict__ seen, int *__restrict__ bad) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
@@ -821,6 +851,61 @@ int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev) {
   return AS_OK;
 }
 
+// refined copy of L->order (see block_edges_kernel); out: a workspace buffer of n entries
+static int refine_order(as_ctx *ctx, as_csr *L, DevBuf<uint32_t> &out) {
+  const uint64_t n = L->n;
+  const uint32_t nb = (uint32_t)((n + kRefineBlock - 1) / kRefineBlock);
+  DevBuf<uint32_t> inv, counts, starts;
+  AS_TRY(inv.alloc(ctx, n));
+  AS_TRY(counts.alloc(ctx, (size_t)nb * nb));
+  AS_TRY(starts.alloc(ctx, nb));
+  AS_TRY(out.alloc(ctx, n));
+  AS_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(uint32_t) * (size_t)nb * nb, ctx->stream));
+  hipLaunchKernelGGL(order_inverse_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)L->order, n, inv.p);
+  hipLaunchKernelGGL(block_edges_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices, n, (const uint32_t *)inv.p, nb, counts.p);
+  AS_HIP(ctx, hipGetLastError());
+  std::vector<uint32_t> h((size_t)nb * nb);
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), counts.p, sizeof(uint32_t) * h.size()));
+  // greedy chain: ties and empty rows fall back to the lowest unvisited block (deterministic)
+  std::vector<uint32_t> seq;
+  std::vector<char> used(nb, 0);
+  seq.reserve(nb);
+  uint32_t next_free = 0;
+  while (seq.size() < nb) {
+    uint32_t pick = 0xFFFFFFFFu;
+    unsigned long long best = 0;
+    if (!seq.empty()) {
+      const uint32_t a = seq.back(), b = seq.size() > 1 ? seq[seq.size() - 2] : seq.back();
+      for (uint32_t c = 0; c < nb; ++c) {
+        if (used[c]) continue;
+        const unsigned long long w = 2ull * (h[(size_t)a * nb + c] + h[(size_t)c * nb + a]) + (h[(size_t)b * nb + c] + h[(size_t)c * nb + b]);
+        if (w > best) {
+          best = w;
+          pick = c;
+        }
+      }
+    }
+    if (pick == 0xFFFFFFFFu) {
+      while (used[next_free]) ++next_free;
+      pick = next_free;
+    }
+    used[pick] = 1;
+    seq.push_back(pick);
+  }
+  // where each old block starts in the new order (the last block of the old order may be short: it keeps its length)
+  std::vector<uint32_t> start(nb);
+  uint32_t at = 0;
+  for (uint32_t c : seq) {
+    start[c] = at;
+    at += (uint32_t)std::min<uint64_t>(kRefineBlock, n - (uint64_t)c * kRefineBlock);
+  }
+  AS_HIP(ctx, copy_h2d(ctx, starts.p, start.data(), sizeof(uint32_t) * nb));
+  hipLaunchKernelGGL(order_apply_blocks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)L->order, n, (const uint32_t *)starts.p,
+                     out.p);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 static SigGeom geom_of(const as_csr *L) {
   SigGeom g;
   g.n = (uint32_t)L->n, g.ch = L->sig_ch, g.wx = L->sig_wx, g.k = L->sig_k, g.c8 = L->sig_c8;
@@ -865,6 +950,13 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   const SigGeom g = geom_of(L);
   const uint64_t slots = sig_slots(g);
   const uint32_t *order = ctx->opt_signal_order ? L->order : nullptr;
+  DevBuf<uint32_t> refined;
+  const bool refine = order && !block && ctx->opt_signal_order_refine && L->n >= 16 * kRefineBlock && L->n / kRefineBlock <= 8192;
+  if (refine) {
+    AS_TRY(refine_order(ctx, L, refined));
+    order = refined.p;
+  }
+  ctx->stats["signal_stream_order_refined"] = refine ? 1 : 0;
   DevBuf<uint32_t> cnt;
   AS_TRY(cnt.alloc(ctx, slots + 1));
   hipLaunchKernelGGL(sig_count_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices, g, L->row_begin, order, sym, cnt.p);

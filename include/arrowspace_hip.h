@@ -373,7 +373,8 @@ int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint6
  * the CSR is streamed once for all signals and each stored pair fetches the two item ROWS (algorithmic bytes nnz * 16 +
  * n_items * n_features * 8).  as_compute_taumode itself takes this route for signals of "signal_min_len" (9000) values or more.
  * Options: "signal_sym" (1: a bitwise symmetric L is streamed as its upper triangle), "signal_order" (1: rows visited in the
- * order attached to L), "signal_chunk_rows" (16) / "signal_waves" (0 = one chunk per wave): the interleave of the graph pass; they take
+ * order attached to L; "signal_order_refine" 1: that order's blocks of 1024 positions chained by the entries between them, 3 ms
+ * once per graph for a tenth off every pass), "signal_chunk_rows" (16) / "signal_waves" (0 = one chunk per wave): the interleave of the graph pass; they take
  * effect when the graph's record stream is next built (as_csr_set_order drops it). */
 int as_compute_taumode_signals(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L, int tau_mode,
                                double tau_arg, double *lambdas_out);
