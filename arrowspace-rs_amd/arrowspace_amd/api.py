@@ -152,7 +152,10 @@ class Context:
     def upload(self, array):
         """as_device_upload: a host matrix / vector -> HBM once; the DeviceArray that comes back is accepted wherever rows,
         items, queries or lambdas are (the library uses device pointers in place)."""
-        a = np.ascontiguousarray(array)
+        a = np.asarray(array)
+        # every data pointer of the C ABI is f64 (u32 only for a row order): anything else is converted HERE, so that a
+        # float32 / integer matrix is never reinterpreted as doubles on the device
+        a = np.ascontiguousarray(a, dtype=np.uint32 if a.dtype == np.uint32 else np.float64)
         h = C.c_void_p()
         self.check(self.lib.as_device_upload(self.h, a.ctypes.data, a.nbytes, C.byref(h)))
         return DeviceArray(self, h, a.shape, a.dtype)
@@ -208,6 +211,10 @@ def _is_torch(x):
 
 def _f64(a, ctx=None):
     if _lib.is_tensor(a):
+        if isinstance(a, DeviceArray):
+            assert a.dtype == np.float64, "a DeviceArray handed to the library as rows / items / lambdas must hold float64"
+        elif str(getattr(a, "dtype", "")) not in ("torch.float64", ""):
+            raise TypeError("tensors handed to the library as rows / items / lambdas must be float64, got %s" % a.dtype)
         if a.is_cuda and ctx is not None:
             _adopt_torch_stream(ctx)
         return a
@@ -629,7 +636,7 @@ class ArrowSpace:
         else:
             out = np.empty(nq, dtype=np.float64)
         if self.projection_matrix is not None:  # src/core.rs:541-546: the query is projected first
-            if not np.all(np.isfinite(Q.cpu().numpy() if _lib.is_tensor(Q) else Q)):
+            if not np.all(np.isfinite(Q.numpy() if isinstance(Q, DeviceArray) else (Q.cpu().numpy() if _lib.is_tensor(Q) else Q))):
                 raise ArrowSpaceError(_lib.AS_ERR_NONFINITE, ctx.lib.as_status_message(_lib.AS_ERR_NONFINITE).decode())
             Q = self.project_query(Q)
             f = self.reduced_dim

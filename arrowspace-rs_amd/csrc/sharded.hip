@@ -521,7 +521,7 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
     AS_HIP(ctx, hipGetLastError());
     AS_TRY(cnt_src.alloc(ctx, (size_t)std::max<uint64_t>((uint64_t)W * rows_here, 1)));
     AS_TRY(inject(2));
-    AS_TRY(ag.before_collective());  // (one agreement for the three exchanges of the lists: nothing that can fail locally sits between them but allocations sized by the peers)
+    AS_TRY(ag.before_collective());  // (one agreement for the counts and the sizes; the slots have their own below, behind the allocation they need)
     {
       const int rc = comm->ops.all_to_all_v(comm->ops.user, cnt.p, sb.data(), so.data(), cnt_src.p, rb.data(), ro.data(), ctx->stream);
       if (rc != AS_OK) return fail(ctx, rc, "sharded build: all-to-all of the list counts failed");
@@ -546,7 +546,10 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
       recv_off[(size_t)g] = total;
       total += recv_bytes[(size_t)g];
     }
+    // (sized by what the peers send: an allocation that can fail between two collectives gets its own agreement, so that a
+    // rank that runs out of memory here meets its peers in a one-word all-reduce and not in their all-to-all)
     AS_TRY(recv.alloc(ctx, (size_t)std::max<uint64_t>(total / sizeof(uint32_t), 2)));
+    AS_TRY(ag.before_collective());
     {
       const int rc = comm->ops.all_to_all_v(comm->ops.user, packed.p, send_bytes.data(), send_off.data(), recv.p, recv_bytes.data(), recv_off.data(),
                                             ctx->stream);

@@ -115,11 +115,22 @@ pub(crate) fn laplacian_of(ctx: *mut AsCtx, nodes: *const f64, n_nodes: usize, d
 ///   stage 1  clustering: optimal K + radius, incremental clustering (src/eigenmaps.rs:175-290)
 ///   stage 2  F x F Laplacian over centroids^T (GraphFactory::build_laplacian_matrix_from_k_cluster, src/graph.rs:149-204)
 ///   stage 4  lambdas of all items (TauMode::compute_taumode_lambdas_parallel, src/taumode.rs:174-312)
-/// Returns what the reference returns; the index handle for the searches is created here once and kept with the space.
+/// The device copy of the feature graph, freed with its owner (prepare_query_item reads it for every query).
+pub struct DeviceGraph(pub *mut AsCsr);
+impl Drop for DeviceGraph {
+    fn drop(&mut self) {
+        if !self.0.is_null() {
+            unsafe { hip::as_csr_free(self.0) };
+        }
+    }
+}
+
+/// Returns what the reference returns, plus what the searches need on the device: the index handle (created here once), the
+/// device copy of the rows it borrows, and the device copy of the feature graph (search_on_device takes it for the query's lambda).
 pub fn build_on_device(
     builder: &mut crate::builder::ArrowSpaceBuilder,
     rows: Vec<Vec<f64>>,
-) -> (crate::core::ArrowSpace, crate::graph::GraphLaplacian, *mut AsIndex, DeviceRows) {
+) -> (crate::core::ArrowSpace, crate::graph::GraphLaplacian, *mut AsIndex, DeviceRows, DeviceGraph) {
     builder.define_result_k();
     let ctx = thread_ctx();
     let dev = DeviceRows::upload(&rows);
@@ -161,7 +172,7 @@ pub fn build_on_device(
     let (mode, arg) = tau_to_c(builder.synthesis);
     let mut lambdas = vec![0f64; n];
     check(ctx, unsafe { hip::as_compute_taumode(ctx, dev.ptr, n as u64, f as u64, lh, mode, arg, lambdas.as_mut_ptr()) });
-    unsafe { hip::as_csr_free(lh) };
+    let gl_dev = DeviceGraph(lh);   // kept: every prepared query reads it (search_on_device)
     let mut ix: *mut AsIndex = std::ptr::null_mut();
     check(ctx, unsafe { hip::as_index_create(ctx, dev.ptr, lambdas.as_ptr(), n as u64, f as u64, &mut ix) });
 
@@ -176,13 +187,14 @@ pub fn build_on_device(
         nnodes: n,
         graph_params: gp,
     };
-    (aspace, gl, ix, dev)
+    (aspace, gl, ix, dev, gl_dev)
 }
 
 /// EigenMaps::search, src/eigenmaps.rs:410-455: query lambda, then the lambda-aware top-k on the kept index handle.
-pub fn search_on_device(ix: *mut AsIndex, gl_dev: *const AsCsr, taumode: crate::taumode::TauMode, item: &[f64], k: usize, alpha: f64)
+pub fn search_on_device(ix: *mut AsIndex, gl_dev: &DeviceGraph, taumode: crate::taumode::TauMode, item: &[f64], k: usize, alpha: f64)
     -> Vec<(usize, f64)> {
     let ctx = thread_ctx();
+    let gl_dev = gl_dev.0 as *const AsCsr;
     let (mode, arg) = tau_to_c(taumode);
     let mut lq = 0f64;
     check(ctx, unsafe { hip::as_prepare_query_items(ctx, item.as_ptr(), 1, item.len() as u64, gl_dev, mode, arg, &mut lq) });
@@ -201,10 +213,17 @@ pub fn build_item_graph_sharded(id128: &[u8; 128], rank: i32, world: i32, rows_s
     let c = graph_params_to_c(p);
     let (mut block, mut nnz) = (std::ptr::null_mut(), 0u64);
     check(ctx, unsafe { hip::as_build_laplacian_sharded(ctx, comm, rows_shard.ptr, n_total as u64, rows_shard.d as u64, &c, &mut block, &mut nnz) });
-    let row_begin = unsafe { hip::as_csr_row_begin(block) };
-    let m = csr_to_sprs(ctx, block);   // rows [row_begin, row_begin + m.rows()) x n_total, global column ids
+    // a rank that owns no rows gets no block: an empty 0 x n_total matrix
+    let (m, row_begin) = if block.is_null() {
+        (sprs::CsMat::new((0, n_total), vec![0usize], Vec::new(), Vec::new()), 0u64)
+    } else {
+        let rb = unsafe { hip::as_csr_row_begin(block) };
+        (csr_to_sprs(ctx, block), rb)   // rows [row_begin, row_begin + m.rows()) x n_total, global column ids
+    };
     unsafe {
-        hip::as_csr_free(block);
+        if !block.is_null() {
+            hip::as_csr_free(block);
+        }
         hip::as_comm_destroy(comm);
     }
     (m, row_begin, nnz)
