@@ -292,3 +292,69 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo % 512 == 0 or lo == n for lo, _ in spans)
+
+
+# ---- the item-graph lambda over row blocks (csrc/sharded.hip, as_compute_taumode_signals_sharded), restated with numpy ----
+def _signal_partials(X, indptr, indices, data, lo, hi, n_graph, tail_owner):
+    """What one rank sums over ITS row block [lo, hi) of the Laplacian (rows as they are stored: global column ids): a stored
+    pair {i, j} once, on the rank that owns its smaller row, and doubled; the diagonal once; the denominator over its own rows
+    (and the rows past the graph on `tail_owner`).  Returns (num, edge, sum t^2, den), each one value per signal."""
+    S = X.shape[1]
+    num, edge, s2, den = np.zeros(S), np.zeros(S), np.zeros(S), np.zeros(S)
+    for i in range(lo, hi):
+        xi = X[i]
+        den += xi * xi
+        for e in range(int(indptr[i]), int(indptr[i + 1])):
+            j, v = int(indices[e]), data[e]
+            if j == i:
+                num += xi * v * xi
+            elif j > i:
+                xj = X[j]
+                num += 2.0 * (xi * v * xj)
+                w = max(-v, 0.0)
+                t = w * (xi - xj) ** 2
+                edge += 2.0 * t
+                s2 += 2.0 * t * t
+    if tail_owner:
+        den += (X[n_graph:] ** 2).sum(axis=0)
+    return np.stack([num, edge, s2, den])
+
+
+def _signal_worker(rank, world, port, n, d, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, _ = synth.mixture(n, d, seed=17, n_clusters=6, rank=3)
+        csr = O.build_laplacian(X[: n - 40], O.graph_params(0.5, 8, 8, 2.0, 0.25))   # a graph 40 nodes shorter than the signals
+        n_graph = n - 40
+        lo, hi = D.shard_range(n_graph, rank, world)
+        part = torch.from_numpy(_signal_partials(X, csr[0], csr[1], csr[2], lo, hi, n_graph, rank == 0))
+        parts = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(parts, part)                       # 4 sums per signal and rank
+        tot = parts[0].clone()
+        for p in parts[1:]:                                 # added in rank order: the same totals on every rank
+            tot += p
+        num, edge, s2, den = [t.numpy() for t in tot]
+        tau = np.array([O.select_tau(X[:, c], O.TAU_MEDIAN) for c in range(d)])   # every rank has the whole columns
+        e_raw = np.where(den > 1e-12, num / den, 0.0)
+        g = np.where(edge > 0, s2 / (edge * edge), 0.0).clip(0.0, 1.0)
+        lam = tau * (e_raw / (e_raw + tau)) + (1.0 - tau) * g
+        np.save(os.path.join(out_dir, "sig%d.npy" % rank), lam)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(1500, 2), (1200, 3)])
+def test_item_graph_lambda_sums_shard_by_row_blocks(tmp_path, n, world):
+    """SURVEY.md section 8(e), "K7 item-graph signals": partial (num, edge, den) per row block, one exchange of the partial sums,
+    the same lambdas as TauMode::compute_synthetic_lambda_csr on one process (src/taumode.rs:552-660) -- the decomposition the
+    library's sharded call uses, here on CPU over gloo (the library's own run: tests/test_distributed_gpu.py)."""
+    d = 12
+    mp.spawn(_signal_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    X, _ = synth.mixture(n, d, seed=17, n_clusters=6, rank=3)
+    csr = O.build_laplacian(X[: n - 40], O.graph_params(0.5, 8, 8, 2.0, 0.25))
+    want = O.taumode_lambdas(np.ascontiguousarray(X.T), csr, O.TAU_MEDIAN)
+    lams = [np.load(tmp_path / ("sig%d.npy" % r)) for r in range(world)]
+    for lam in lams:
+        np.testing.assert_allclose(lam, want, rtol=1e-12, atol=1e-300)
+        assert np.array_equal(lam, lams[0])   # bit-identical across the ranks
