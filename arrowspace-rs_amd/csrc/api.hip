@@ -336,6 +336,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "signal_order_refine") ctx->opt_signal_order_refine = value;
   else if (n == "signal_chunk_rows") ctx->opt_signal_chunk_rows = std::min<int64_t>(std::max<int64_t>(1, value), 1024);
   else if (n == "signal_waves") ctx->opt_signal_waves = std::max<int64_t>(0, value);
+  else if (n == "signal_half_slabs") ctx->opt_signal_half_slabs = value != 0;
   else if (n == "signal_min_len") ctx->opt_signal_min_len = std::max<int64_t>(1, value);
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "join_row_order") ctx->opt_join_row_order = value;

@@ -107,6 +107,7 @@ struct as_ctx {
                                          // by side: the pass 0.86 -> 0.78 ms at 1 M x 128, but 3.2 ms more to prepare the stream (host chain): for graphs used many times)
   int64_t opt_signal_chunk_rows = 16;    // ... consecutive rows a wave takes at a time
   int64_t opt_signal_waves = 0;          // ... waves of the graph pass in all (0: one chunk per wave; else the waves of an XCD group interleave their chunks)
+  int64_t opt_signal_half_slabs = 0;     // ... 1: a lane holds one column, a workgroup half a slab (512-byte gathers: half the neighbourhood against the L2)
   int64_t opt_signal_min_len = 9000;     // as_compute_taumode: signals this long or longer go through the item-graph kernels
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only

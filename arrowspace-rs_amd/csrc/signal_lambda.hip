@@ -251,23 +251,28 @@ constexpr int kNQ = 4;  // partial sums per column: 0 num, 1 edge, 2 sum t^2 (ea
 
 // One record against the current row: the same arithmetic for an entry (x = x_j) and for a header, which is the diagonal entry
 // with x_j = x_i (so d = 0 and no edge term) after the gathered row has become x_i.  PASS2: squared shares only.
-template <bool PASS2>
+template <bool PASS2, bool TWO>
 __device__ __forceinline__ void sig_term(const Acc2 &xi, const Acc2 &x, double v, double w, const Acc2 &tot_e, Acc2 &num, Acc2 &edge, Acc2 &s2) {
   if (!PASS2) {
     num.x = fma(__dmul_rn(xi.x, v), x.x, num.x);  // xi * lij * xj
-    num.y = fma(__dmul_rn(xi.y, v), x.y, num.y);
+    if (TWO) num.y = fma(__dmul_rn(xi.y, v), x.y, num.y);
   }
-  const double dx = __dsub_rn(xi.x, x.x), dy = __dsub_rn(xi.y, x.y);
-  const double tx = __dmul_rn(__dmul_rn(w, dx), dx), ty = __dmul_rn(__dmul_rn(w, dy), dy);  // w * d * d
+  const double dx = __dsub_rn(xi.x, x.x), dy = TWO ? __dsub_rn(xi.y, x.y) : 0.0;
+  const double tx = __dmul_rn(__dmul_rn(w, dx), dx), ty = TWO ? __dmul_rn(__dmul_rn(w, dy), dy) : 0.0;  // w * d * d
   if (PASS2) {
-    const double sx = __ddiv_rn(tx, tot_e.x), sy = __ddiv_rn(ty, tot_e.y);  // share = contrib / edge_energy_sum
+    const double sx = __ddiv_rn(tx, tot_e.x);  // share = contrib / edge_energy_sum
     s2.x = fma(sx, sx, s2.x);
-    s2.y = fma(sy, sy, s2.y);
+    if (TWO) {
+      const double sy = __ddiv_rn(ty, tot_e.y);
+      s2.y = fma(sy, sy, s2.y);
+    }
   } else {
     edge.x = __dadd_rn(edge.x, tx);
-    edge.y = __dadd_rn(edge.y, ty);
     s2.x = fma(tx, tx, s2.x);
-    s2.y = fma(ty, ty, s2.y);
+    if (TWO) {
+      edge.y = __dadd_rn(edge.y, ty);
+      s2.y = fma(ty, ty, s2.y);
+    }
   }
 }
 
@@ -280,7 +285,11 @@ __device__ __forceinline__ void sig_term(const Acc2 &xi, const Acc2 &x, double v
 // of them (lgkmcnt(0)), and the address arithmetic of a record would be five scalar instructions instead of one vector
 // instruction per 64 records.  The loop has no bounds checks: the stream pads every wave's records to whole batches with
 // entries of value 0 against the wave's last row (they add exactly 0).
-template <bool PASS2, bool VEC>
+// W: how a lane reads its columns.  2: two neighbouring columns in one 16-byte load (every row slice 16-byte aligned: even S,
+// aligned base); 0: the same two columns in two 8-byte loads; 1: ONE column per lane, blockIdx.y = 2 * slab + half -- the rows a
+// workgroup gathers are 512 bytes, so the neighbourhood an XCD works in is half as large against its L2 (the partials keep
+// their layout: a block writes its half of the 128 columns).
+template <bool PASS2, int W>
 __global__ __launch_bounds__(256) void signal_sums_kernel(const double *__restrict__ X, uint64_t ldx, uint32_t S,
                                                              const SigRec *__restrict__ rec, const uint64_t *__restrict__ off,
                                                              uint32_t slots_per_wave, uint32_t waves_per_group,
@@ -288,28 +297,30 @@ __global__ __launch_bounds__(256) void signal_sums_kernel(const double *__restri
                                                              double *__restrict__ part) {
   if (PASS2 && *need_pass2 == 0) return;
   constexpr uint32_t NQ = PASS2 ? 1 : kNQ;
+  constexpr bool TWO = W != 1;
   __shared__ double s_red[kWavesPerBlock][kNQ][kSlab];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = uni(threadIdx.x >> 6);
-  const uint32_t slab = blockIdx.y;
+  const uint32_t slab = TWO ? blockIdx.y : blockIdx.y / 2, half = TWO ? 0 : blockIdx.y % 2;
   const uint32_t widx = (blockIdx.x % 8) * waves_per_group + (blockIdx.x / 8) * kWavesPerBlock + wv;
   // Lanes past the last column read a valid one (their sums land in the padding of the partials, which nobody reads): no
-  // predicate in the loop.  VEC: every row slice is 16-byte aligned (even S, aligned base) -- one dwordx4 per lane and row.
-  const uint32_t col = slab * kSlab + 2 * lane;
-  const bool on0 = col < S, on1 = col + 1 < S;
-  const uint32_t c_lo = VEC ? min(col, S - 2) : min(col, S - 1), c_hi = min(col + 1, S - 1);
+  // predicate in the loop.
+  const uint32_t cc0 = TWO ? 2 * lane : half * 64 + lane;  // this lane's (first) column inside the slab
+  const uint32_t col = slab * kSlab + cc0;
+  const bool on0 = col < S, on1 = TWO && col + 1 < S;
+  const uint32_t c_lo = W == 2 ? min(col, S - 2) : min(col, S - 1), c_hi = min(col + 1, S - 1);
   const uint32_t off_lo = c_lo * 8u, off_hi = c_hi * 8u;  // byte offsets of this lane's columns inside a row
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   auto load_row = [&](uint32_t olo, uint32_t ohi) -> Acc2 {  // the row's byte offset in X (wave-uniform; bit 0 is the header flag)
     Acc2 r;
     const char *src = reinterpret_cast<const char *>(X) + (((uint64_t)ohi << 32) | (olo & ~3u));
-    if (VEC) {
+    if (W == 2) {
       const dbl2 t = *reinterpret_cast<const dbl2 *>(src + off_lo);
       r.x = t.x;
       r.y = t.y;
     } else {
       r.x = *reinterpret_cast<const double *>(src + off_lo);
-      r.y = *reinterpret_cast<const double *>(src + off_hi);
+      r.y = TWO ? *reinterpret_cast<const double *>(src + off_hi) : 0.0;
     }
     return r;
   };
@@ -359,10 +370,10 @@ __global__ __launch_bounds__(256) void signal_sums_kernel(const double *__restri
         xi = x;
         if (!PASS2) {
           den.x = fma(x.x, x.x, den.x);
-          den.y = fma(x.y, x.y, den.y);
+          if (TWO) den.y = fma(x.y, x.y, den.y);
         }
       }
-      sig_term<PASS2>(xi, x, r.v, r.w, tot_e, num, edge, s2);
+      sig_term<PASS2, TWO>(xi, x, r.v, r.w, tot_e, num, edge, s2);
     };
     Block cur = load_block(0), nxt = load_block(1);
     Rec ra0 = read_rec(cur, 0), ra1 = read_rec(cur, 1), ra2 = read_rec(cur, 2), ra3 = read_rec(cur, 3), rb0, rb1, rb2, rb3;
@@ -386,14 +397,19 @@ __global__ __launch_bounds__(256) void signal_sums_kernel(const double *__restri
   }
   // waves of the block in index order
   double *mine = &s_red[wv][0][0];
-  mine[0 * kSlab + 2 * lane] = num.x, mine[0 * kSlab + 2 * lane + 1] = num.y;
-  mine[1 * kSlab + 2 * lane] = edge.x, mine[1 * kSlab + 2 * lane + 1] = edge.y;
-  mine[2 * kSlab + 2 * lane] = s2.x, mine[2 * kSlab + 2 * lane + 1] = s2.y;
-  mine[3 * kSlab + 2 * lane] = den.x, mine[3 * kSlab + 2 * lane + 1] = den.y;
+  if (TWO) {
+    mine[0 * kSlab + cc0] = num.x, mine[0 * kSlab + cc0 + 1] = num.y;
+    mine[1 * kSlab + cc0] = edge.x, mine[1 * kSlab + cc0 + 1] = edge.y;
+    mine[2 * kSlab + cc0] = s2.x, mine[2 * kSlab + cc0 + 1] = s2.y;
+    mine[3 * kSlab + cc0] = den.x, mine[3 * kSlab + cc0 + 1] = den.y;
+  } else {
+    mine[0 * kSlab + cc0] = num.x, mine[1 * kSlab + cc0] = edge.x, mine[2 * kSlab + cc0] = s2.x, mine[3 * kSlab + cc0] = den.x;
+  }
   __syncthreads();
   const uint32_t nb = gridDim.x + (PASS2 ? 0 : 1);
-  for (uint32_t t = threadIdx.x; t < kNQ * kSlab; t += 256) {
-    const uint32_t qn = t / kSlab, cc = t % kSlab;
+  constexpr uint32_t kMine = TWO ? kSlab : kSlab / 2;  // columns this block holds
+  for (uint32_t t = threadIdx.x; t < kNQ * kMine; t += 256) {
+    const uint32_t qn = t / kMine, cc = half * 64 + t % kMine;
     if (PASS2 && qn != 2) continue;
     double s = s_red[0][qn][cc];
 #pragma unroll
@@ -931,7 +947,7 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   if (ctx->opt_signal_sym == 0) sym = 0;
   // geometry: as many waves per XCD group as are resident together (the window of the interleave is what they cover at one time)
   int blocks_per_cu = 0;
-  AS_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)signal_sums_kernel<false, true>, 256, 0));
+  AS_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)signal_sums_kernel<false, 2>, 256, 0));
   hipDeviceProp_t prop;
   AS_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
   const uint32_t cus = (uint32_t)std::max(8, prop.multiProcessorCount);
@@ -982,6 +998,21 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   return AS_OK;
 }
 
+template <bool PASS2>
+static void launch_sums(as_ctx *ctx, bool vec, uint32_t nbk, uint32_t n_slabs, const double *X, uint32_t S, const as_csr *L, uint32_t spw,
+                        const double *edge_tot, const int *need, double *part) {
+#define AS_SIG_LAUNCH(W, GY)                                                                                                          \
+  hipLaunchKernelGGL((signal_sums_kernel<PASS2, W>), dim3(nbk, GY), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec, \
+                     (const uint64_t *)L->sig_off, spw, L->sig_wx, edge_tot, need, part)
+  if (ctx->opt_signal_half_slabs)
+    AS_SIG_LAUNCH(1, 2 * n_slabs);
+  else if (vec)
+    AS_SIG_LAUNCH(2, n_slabs);
+  else
+    AS_SIG_LAUNCH(0, n_slabs);
+#undef AS_SIG_LAUNCH
+}
+
 // (num, edge, sum t^2, den) of every signal over the rows of L: sums[4][s_pad], s_pad = 128 * ceil(S / 128).  X: n_len x S row-major
 // (ldx = S); the graph's rows are rows [L->row_begin, L->row_begin + L->n) of X; den also covers rows [tail_begin, tail_end) of X.
 int signal_sums(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr *L, uint64_t tail_begin, uint64_t tail_end, double *sums) {
@@ -999,12 +1030,7 @@ int signal_sums(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr
   {
     ProfScope ps(ctx, "signal_sums");
     hipLaunchKernelGGL(signal_tail_den_kernel, dim3(n_slabs), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, tail_begin, std::max(tail_begin, tail_end), nb, part.p);
-    if (vec)
-      hipLaunchKernelGGL((signal_sums_kernel<false, true>), dim3(nbk, n_slabs), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec,
-                         (const uint64_t *)L->sig_off, spw, L->sig_wx, (const double *)nullptr, (const int *)nullptr, part.p);
-    else
-      hipLaunchKernelGGL((signal_sums_kernel<false, false>), dim3(nbk, n_slabs), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec,
-                         (const uint64_t *)L->sig_off, spw, L->sig_wx, (const double *)nullptr, (const int *)nullptr, part.p);
+    launch_sums<false>(ctx, vec, nbk, n_slabs, X, S, L, spw, nullptr, nullptr, part.p);
     AS_HIP(ctx, hipGetLastError());
   }
   {
@@ -1038,12 +1064,7 @@ int signal_shares(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const dou
   const bool vec = S >= 2 && (S & 1) == 0 && (((uintptr_t)X) & 15) == 0;
   ProfScope ps(ctx, "signal_shares");
   // a skipped pass leaves g2 unwritten: the lambda kernel reads it only where *need is set
-  if (vec)
-    hipLaunchKernelGGL((signal_sums_kernel<true, true>), dim3(nbk, n_slabs), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec,
-                       (const uint64_t *)L->sig_off, spw, L->sig_wx, sums + s_pad, need, part.p);
-  else
-    hipLaunchKernelGGL((signal_sums_kernel<true, false>), dim3(nbk, n_slabs), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec,
-                       (const uint64_t *)L->sig_off, spw, L->sig_wx, sums + s_pad, need, part.p);
+  launch_sums<true>(ctx, vec, nbk, n_slabs, X, S, L, spw, sums + s_pad, need, part.p);
   const double *src = part.p;
   uint32_t count = nbk;
   if (ng_mid) {

@@ -138,6 +138,7 @@ def recorded_traffic(kernel_substr, n, d):
             if kernel_substr in k.get("kernel", "") and j.get("n") == n and j.get("dim") == d:
                 # (the PMC passes run ONE step, no warm-up: a kernel's total over the pass is its traffic per step)
                 best = {"bytes_per_launch": k.get("hbm_bytes_total"), "launches_per_step": k.get("launches"),
+                        "bytes_per_single_launch": k.get("hbm_bytes_per_launch"),
                         "source": "profiles/" + name, "commit": j.get("commit")}
     return best
 
@@ -430,7 +431,7 @@ def main():
             records = ctx.stat("signal_stream_records")
             valu_floor_ms = records * 7.0 * d / (16.0 * 4 * 256 * 2.4e9) * 1e3   # 16 f64 lanes per clock and SIMD, 1024 SIMDs, 2.4 GHz
             extra["roofline_spmm"] = {
-                "bound": "hbm", "kernel": "signal_sums_kernel<false, true> (item-graph lambda: the upper triangle of the N x N Laplacian "
+                "bound": "hbm", "kernel": "signal_sums_kernel<false, 2> (item-graph lambda: the upper triangle of the N x N Laplacian "
                                           "streamed once for all D signals, each stored pair gathers the two 1 KB item rows; HIP events "
                                           "around the launch)",
                 "achieved": alg_bytes / (sums_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -446,8 +447,11 @@ def main():
                         "(taus_ms: two histogram passes + one collecting pass over the N x D matrix)"}
             rec = recorded_traffic("signal_sums_kernel", n, d)
             if rec:
-                extra["roofline_spmm"]["traffic"] = rec["bytes_per_launch"]
-                extra["roofline_spmm"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
+                # (this leg launches the kernel several times in the profiled pass: bytes per single launch)
+                extra["roofline_spmm"]["traffic"] = rec["bytes_per_single_launch"]
+                extra["roofline_spmm"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"],
+                                                            "what": "bytes that left the L2s (TCC fabric reads x the guide's factor 2, + writes): "
+                                                                    "the gathers the L2 misses, most of them served by the Infinity Cache, not HBM"}
             del gl_sp
         except Exception as e:  # noqa: BLE001
             extra["roofline_spmm"] = {"error": repr(e)}

@@ -174,6 +174,26 @@ def test_order_refined_by_the_graph(ctx):
     assert_lambdas(got, want)
 
 
+@pytest.mark.parametrize("S", [1, 63, 64, 65, 128, 200])
+def test_half_slabs_give_the_same_bits(ctx, S):
+    """"signal_half_slabs": one column per lane and 512-byte gathers (a measured alternative, off by default) -- the same sums in
+    the same order, both rounds"""
+    rng = np.random.default_rng(40 + S)
+    csr = random_csr(rng, 3000, 7, True)
+    X = rng.standard_normal((3000, S))
+    if S > 4:
+        X[:, :2] *= 1e90   # these columns take the second round
+    m = A.CsrMatrix.from_host(ctx, *csr)
+    whole = compute_taumode_signals(X, m, T.Fixed(0.4), ctx=ctx)
+    ctx.set_option("signal_half_slabs", 1)
+    try:
+        half = compute_taumode_signals(X, m, T.Fixed(0.4), ctx=ctx)
+    finally:
+        ctx.set_option("signal_half_slabs", 0)
+    assert np.array_equal(whole, half)
+    assert_lambdas(half, oracle_signals(X, csr, O.TAU_FIXED, 0.4))
+
+
 def test_extreme_magnitudes_take_the_literal_second_pass(ctx):
     """sum t^2 overflows although every share t / edge is fine: the reference's own second pass (taumode.rs:611-639)"""
     rng = np.random.default_rng(21)
