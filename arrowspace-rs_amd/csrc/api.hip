@@ -331,6 +331,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;
+  else if (n == "sharded_own_rows") ctx->opt_sharded_own_rows = value != 0;
   else if (n == "signal_sym") ctx->opt_signal_sym = value;
   else if (n == "signal_order") ctx->opt_signal_order = value;
   else if (n == "signal_order_refine") ctx->opt_signal_order_refine = value;

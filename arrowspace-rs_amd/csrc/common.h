@@ -101,6 +101,7 @@ struct as_ctx {
   int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
   int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
+  int64_t opt_sharded_own_rows = 1;      // build sharded by rows: the join is prepared from the ranks' own rows and the all-gather of the f64 rows runs under it (0: rows first)
   int64_t opt_signal_sym = 1;            // item-graph lambda (signal_lambda.hip): a bitwise symmetric graph is streamed as its upper triangle
   int64_t opt_signal_order = 1;          // ... in the order attached to the graph (as_csr_set_order / the join's own); 0: the rows as stored
   int64_t opt_signal_order_refine = 0;   // ... the blocks of 1024 positions of that order chained by the entries between them (groups of one cluster end up side
@@ -490,6 +491,8 @@ int apply_self_in_results(as_ctx *ctx, const double *rows, const double *norms, 
 // the same object on every rank.
 struct OwnJoin {
   DevBuf<unsigned char> P16own, Phown;                        // split-bf16 / f16 image of all rows (Phown in the order `perm`)
+  DevBuf<unsigned char> Prow;                                 // sharded by rows with an order: the f16 image of all rows in ROW order (the all-gathered one)
+  bool sharded_rows = false;                                  // the preparation ran on the ranks' own rows (ShardedRows below)
   DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos; // thresholds (and the looser second ones) by row / by image position
   DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
@@ -503,8 +506,24 @@ struct OwnJoin {
   const uint32_t *perm = nullptr;       // perm_own.p or nullptr
   const float *theta_image = nullptr;   // thresholds in the order of the image: theta_pos.p or theta_own.p
 };
+// A build sharded by rows (csrc/sharded.hip): what the preparation of the join is handed instead of all rows.  Every rank holds
+// the rows [lo, lo + count) (`own`; shard starts are multiples of 512) and the norms of ALL rows; per-row products of the
+// preparation (coordinates, f16 image) are made from the own rows and completed by the gathers below, so the f64 rows themselves
+// are not needed before the exact re-rank: their all-gather is issued behind the preparation (rows_begin) and awaited where they
+// are first read (rows_all) -- under the first pass and the f16 pass instead of in front of everything.
+struct ShardedRows {
+  const double *own = nullptr;
+  uint32_t lo = 0, count = 0;
+  int rank = 0, world = 1;
+  std::vector<uint64_t> row_lo, row_hi;                        // the row range of every rank
+  std::function<int(void *all, size_t elem_bytes)> gather;     // a buffer of n elements by row (or by image position): completed in place
+  // pieces of any size: rank r contributes bytes[r] at offsets[r] of `all` (its own piece is in place already)
+  std::function<int(void *all, const uint64_t *bytes, const uint64_t *offsets)> gather_v;
+  std::function<int()> rows_begin;                             // start the all-gather of the f64 rows (once; returns at once)
+  std::function<int(const double **rows)> rows_all;            // all rows, complete on the context's stream (starts the gather if nobody has)
+};
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
-                     uint32_t pos_begin = 0, uint32_t pos_count = 0, const std::function<int(void *, size_t)> *gather = nullptr);
+                     uint32_t pos_begin = 0, uint32_t pos_count = 0, const ShardedRows *sr = nullptr);
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
                    OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io = nullptr);
 

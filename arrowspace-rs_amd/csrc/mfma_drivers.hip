@@ -788,7 +788,7 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
                        const uint32_t *perm = nullptr);
 bool rotated_wide_supported(uint32_t d);
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out);
+                      double *tail_out, const ShardedRows *sr = nullptr);
 int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
 int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
                          unsigned char *mask);
@@ -817,10 +817,12 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin = 0,
-                                uint32_t pos_count = 0);
+                                uint32_t pos_count = 0, const void *row_image = nullptr);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
-                        float *theta2_out);
+                        float *theta2_out, const void *row_image = nullptr, uint64_t n_image = 0);
+int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
+int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of
 // the two where the bf16 pipe may have been used: every rank of a sharded build derives the same value)
@@ -1089,11 +1091,20 @@ uint32_t knn_join_cap(const as_ctx *ctx, uint32_t K, bool sharded) {
 // is where it belongs).  Everything else stays replicated.
 constexpr double kRotatedTailMax = 0.95;  // share of the rows' energy outside the 31 directions up to which the rotated first pass is taken
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
-                     uint32_t pos_begin, uint32_t pos_count, const std::function<int(void *, size_t)> *gather) {
+                     uint32_t pos_begin, uint32_t pos_count, const ShardedRows *sr) {
+  const std::function<int(void *, size_t)> *gather = sr ? &sr->gather : nullptr;
   if (!gather) {
     pos_begin = 0;
     pos_count = n;
   }
+  // sr (ShardedRows, common.h): `rows` is null until somebody needs the f64 rows of OTHER ranks (need_rows: the steps that have no
+  // form on the rank's own rows -- the plain row order, the plain thresholds, widths the sharded packing does not cover); on the
+  // path the benchmark shapes take nothing in here does, and the caller starts their all-gather behind this function
+  auto need_rows = [&]() -> int {
+    if (!rows) AS_TRY(sr->rows_all(&rows));
+    return AS_OK;
+  };
+  if (!sr) oj.sharded_rows = false;
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows;
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   ctx->f16_err = -1.0;
@@ -1114,7 +1125,8 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     double tail = 1.0;
     AS_TRY(oj.rot_z.alloc(ctx, (size_t)n * 32));
     AS_TRY(oj.rot_norm.alloc(ctx, n));
-    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail));
+    if (sr && d > 128) AS_TRY(need_rows());
+    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail, rows ? nullptr : sr));
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
     // Measured at 1 M x 128 (scripts/time_hard.py: mixtures of rank 16 ... 128 with 4 ... 50 000 clusters, duplicated rows, plain
     // Gaussian rows): the rotated 32-wide pass was never slower than the full-width one (within 2 %) and usually twice as fast
@@ -1129,8 +1141,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   const bool reorder_wide = oj.wide_pre && ctx->opt_join_row_order && n >= 65536;
   if (reorder || reorder_wide) {
     AS_TRY(oj.perm_own.alloc(ctx, n));
-    if (!reorder_wide) AS_TRY(cluster_order(ctx, rows, norms, n, d, oj.perm_own.p));
-    else {
+    if (!reorder_wide) {
+      AS_TRY(need_rows());
+      AS_TRY(cluster_order(ctx, rows, norms, n, d, oj.perm_own.p));
+    } else {
       AS_TRY(oj.order_piv.alloc(ctx, (size_t)1024 * 128));
       AS_TRY(oj.order_starts.alloc(ctx, 1025));
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
@@ -1144,8 +1158,24 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
     const uint32_t tiles = packed_tiles_f16(n);
     AS_TRY(oj.Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
-    AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr));
+    if (sr && !rows && d <= 128) {
+      // sharded by rows: every rank packs its own rows, the image of all rows in ROW order is all-gathered (256 B per row at 128
+      // columns), and the image in the order of the join is that one re-arranged -- the same bytes pack_f16_all stores
+      if (reorder) {
+        AS_TRY(oj.Prow.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
+        AS_TRY(pack_f16_rows_sharded(ctx, *sr, norms, n, d, oj.Prow.p, tiles));
+        AS_TRY(pack_f16_from_image(ctx, oj.Prow.p, n, oj.perm_own.p, n, d, oj.Phown.p, tiles));
+      } else {
+        AS_TRY(pack_f16_rows_sharded(ctx, *sr, norms, n, d, oj.Phown.p, tiles));
+      }
+      oj.sharded_rows = true;
+    } else {
+      if (sr) AS_TRY(need_rows());
+      AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr));
+    }
   }
+  ctx->stats["sharded_prepare_by_rows"] = oj.sharded_rows ? 1 : 0;
+  const void *row_image = oj.sharded_rows ? (reorder ? oj.Prow.p : oj.Phown.p) : nullptr;  // the f16 form of any row by id (sharded by rows)
   // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
   // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
   const bool wide_grouped = d > 128 && join_on_f16(ctx, d) && pos_begin == 0 && (pos_count == 0 || pos_count == n) && !gather;  // (rows wider than 128: one GPU)
@@ -1158,7 +1188,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
                                               32, m, oj.theta_pos.p, m2, oj.theta2_pos.p));
     else
     AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
-                                       oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count));
+                                       oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count, row_image));
     if (gather) {
       AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
       AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
@@ -1193,9 +1223,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
                        n_chk, chk_ids.p);
     hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_all, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n,
                        ns_all, chk_sid.p);  // (the same sampled positions, all of them: what differs is the restriction alone)
-    AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
+    if (row_image) AS_TRY(pack_f16_from_image(ctx, row_image, n, chk_ids.p, n_chk, d, chk_img.p, n_chk / kTileRows));
+    else AS_TRY(pack_f16(ctx, rows, norms, chk_ids.p, 0, n_chk, d, chk_img.p, n_chk / kTileRows));
     if (d > 128) AS_TRY(join_thresholds_f16_wide(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
-    else AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p));
+    else AS_TRY(join_thresholds_f16(ctx, rows, norms, d, chk_img.p, 0, n_chk, chk_sid.p, ns_all, m, chk_t1.p, m2, chk_t2.p, row_image, n));
     hipLaunchKernelGGL(theta_check_count_kernel, dim3(cdiv(n_chk, 256)), dim3(256), 0, ctx->stream, (const float *)oj.theta_pos.p, stride,
                        (const float *)chk_t1.p, n_chk, 5e-3f, chk_bad.p);
     uint32_t h_bad = 0;
@@ -1208,6 +1239,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       oj.have_theta2 = true;
       oj.grouped_theta = true;
     } else {
+      if (sr) AS_TRY(need_rows());  // (every rank takes this branch together: the check reads the same thresholds everywhere)
       if (pos_count)
         AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_pos.p + pos_begin, nullptr, oj.theta2_pos.p + pos_begin,
                                    &oj.have_theta2, oj.Phown.p));
@@ -1221,6 +1253,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   } else {
     ctx->stats["knn_join_theta_grouped"] = 0;
     float *t1 = reorder ? oj.theta_pos.p : oj.theta_own.p, *t2 = reorder ? oj.theta2_pos.p : oj.theta2_own.p;
+    if (sr) AS_TRY(need_rows());
     if (pos_count)
       AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, t1 + pos_begin, nullptr, t2 + pos_begin, &oj.have_theta2, oj.Phown.p));
     if (gather) {
@@ -1236,6 +1269,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     if (oj.have_theta2) AS_TRY(scatter_by_perm(ctx, oj.theta2_pos.p, oj.perm_own.p, n, oj.theta2_own.p));
   }
   if (join_on_bf16(ctx, d)) {
+    if (sr) AS_TRY(need_rows());
     AS_TRY(oj.P16own.alloc(ctx, packed_vecs_bf16(b_alloc, d) * 16));
     AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, oj.P16own.p, b_alloc));
   }

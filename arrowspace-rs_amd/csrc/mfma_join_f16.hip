@@ -87,6 +87,31 @@ __global__ void pack_f16_kernel(const double *__restrict__ R, const double *__re
   P[g] = v;
   if (err_part && row < n) err_part[row * (2ull * KS) + 2ull * ks + (l >> 5)] = e2;
 }
+// The same image from an f16 image of ALL rows in ROW order (`src`: the layout above with row = row id, n_src rows) instead of the
+// f64 rows: position p of P takes the 2 KS vectors of row ids[p] (ids null: row p; an id of ~0 or a position beyond `count`: zeros).
+// Pure data movement, so P holds exactly what pack_f16_kernel stores for the same ids.  A build sharded by rows (csrc/sharded.hip)
+// packs its own rows once, all-gathers that image (256 B per row at 128 columns instead of the 1 KB of the row) and takes every
+// image of the preparation -- the one in the order of the join, the samples of the thresholds -- from it.
+__global__ void f16_image_gather_kernel(const f16x8 *__restrict__ src, uint64_t n_src, const uint32_t *__restrict__ ids, uint64_t count, uint32_t KS,
+                                        uint64_t total_frag_lanes, f16x8 *__restrict__ P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_frag_lanes) return;
+  const uint32_t l = g & 63;
+  const uint32_t s = (g >> 6) & 3;
+  const uint64_t tk = g >> 8;
+  const uint32_t ks = (uint32_t)(tk % KS);
+  const uint64_t T = tk / KS;
+  const uint64_t pos = T * kTileRows + s * 32 + (l & 31);
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+  if (pos < count) {
+    const uint64_t id = ids ? (uint64_t)ids[pos] : pos;
+    if (!(ids && ids[pos] == 0xFFFFFFFFu) && id < n_src)
+      v = src[(((id / kTileRows) * KS + ks) * 4 + ((id % kTileRows) >> 5)) * 64 + (id & 31) + (l & 32)];
+  }
+  P[g] = v;
+}
 // ---- rows of exactly 128 values: image and plane error in ONE coalesced pass over the rows (round 3) ---------------------------
 // The per-fragment-lane packer above reads a row in sixteen 64-byte pieces from sixteen different waves and ran at 0.6 TB/s
 // (1.66 ms per GB), the error kernel read the rows again (1.09 ms).  Here a workgroup owns a 128-row tile of the image: each of
@@ -1059,6 +1084,52 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
   float e;
   std::memcpy(&e, &h, sizeof(e));
   ctx->f16_err = (double)e;
+  return AS_OK;
+}
+
+int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles) {
+  const uint32_t KS = f16_ksteps(d);
+  const uint64_t total = packed_vecs_f16(tiles, d);
+  ProfScope ps(ctx, "pack_unit_rows");
+  hipLaunchKernelGGL(f16_image_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, (const f16x8 *)row_image, n_src, row_ids, n, KS, total,
+                     (f16x8 *)P);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// The f16 image of ALL rows in row order on every rank of a build sharded by rows: each rank packs its own rows (pack_f16_all:
+// the same stored values and the same plane error as on one GPU), the pieces are all-gathered in place (shard starts are multiples
+// of 512 rows, so a rank's rows are whole tiles), and ctx->f16_err becomes the largest plane error over all ranks.
+int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles) {
+  const uint32_t KS = f16_ksteps(d);
+  const uint64_t tile_bytes = (uint64_t)KS * 4 * 64 * 16;
+  const uint64_t used_tiles = (n + kTileRows - 1) / kTileRows;
+  if (tiles > used_tiles)  // (the padding of the last super tile: rows of zeros)
+    AS_HIP(ctx, hipMemsetAsync((char *)Prow + used_tiles * tile_bytes, 0, (tiles - used_tiles) * tile_bytes, ctx->stream));
+  double own_err = 0.0;
+  if (sr.count) {
+    const uint32_t own_tiles = (sr.count + kTileRows - 1) / kTileRows;
+    AS_TRY(pack_f16_all(ctx, sr.own, norms_all + sr.lo, sr.count, d, (char *)Prow + (uint64_t)(sr.lo / kTileRows) * tile_bytes, own_tiles, nullptr));
+    own_err = ctx->f16_err;
+  }
+  std::vector<uint64_t> bytes((size_t)sr.world), offs((size_t)sr.world), eight((size_t)sr.world, 8), at8((size_t)sr.world);
+  for (int r = 0; r < sr.world; ++r) {
+    const uint64_t t0 = sr.row_lo[(size_t)r] / kTileRows, t1 = (sr.row_hi[(size_t)r] + kTileRows - 1) / kTileRows;
+    bytes[(size_t)r] = sr.row_hi[(size_t)r] > sr.row_lo[(size_t)r] ? (t1 - t0) * tile_bytes : 0;
+    offs[(size_t)r] = t0 * tile_bytes;
+    at8[(size_t)r] = (uint64_t)r * 8;
+  }
+  AS_TRY(sr.gather_v(Prow, bytes.data(), offs.data()));
+  DevBuf<double> errs;
+  AS_TRY(errs.alloc(ctx, (size_t)sr.world));
+  AS_HIP(ctx, copy_h2d(ctx, errs.p + sr.rank, &own_err, sizeof(double)));
+  AS_TRY(sr.gather_v(errs.p, eight.data(), at8.data()));
+  std::vector<double> h((size_t)sr.world);
+  AS_HIP(ctx, copy_d2h(ctx, h.data(), errs.p, sizeof(double) * sr.world));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double e = 0.0;
+  for (double v : h) e = std::max(e, v);
+  ctx->f16_err = e;
   return AS_OK;
 }
 

@@ -353,13 +353,14 @@ __global__ void unit_groups_kernel(const uint32_t *__restrict__ group_start, uin
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
+int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
 
 // theta_out[r], r < row_count, for rows [row_begin, row_begin + row_count) (row_begin a multiple of 256) against the
 // sample `sample_ids` (ns global row ids, ns a multiple of 256).  P_all: the f16 image of ALL rows (whole 512-row super
 // tiles: pack_f16_all).  dim <= 128; AS_ERR_UNSUPPORTED beyond.
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
-                        float *theta2_out) {
+                        float *theta2_out, const void *row_image, uint64_t n_image) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || ns < 256 || ns % 256 != 0 || row_begin % 256 != 0)
@@ -369,7 +370,9 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   DevBuf<unsigned char> PS;
   DevBuf<uint32_t> unitc;
   AS_TRY(PS.alloc(ctx, packed_vecs_f16(s_tiles, d) * 16));
-  AS_TRY(pack_f16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
+  // (row_image: the f16 image of all n_image rows in row order, a build sharded by rows -- the sample's rows are copied from it)
+  if (row_image) AS_TRY(pack_f16_from_image(ctx, row_image, n_image, sample_ids, ns, d, PS.p, s_tiles));
+  else AS_TRY(pack_f16(ctx, rows, norms, sample_ids, 0, ns, d, PS.p, s_tiles));
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   const f16x8 *PA = (const f16x8 *)P_all + (size_t)(row_begin / kTileRows) * KS * 4 * 64;
@@ -429,7 +432,7 @@ int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin,
-                                uint32_t pos_count) {
+                                uint32_t pos_count, const void *row_image) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
@@ -453,7 +456,8 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
                      ids.p, kGroupSlots);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, group_start, np, n, a_supers, ug.p);
   AS_HIP(ctx, hipGetLastError());
-  AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
+  if (row_image) AS_TRY(pack_f16_from_image(ctx, row_image, n, ids.p, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
+  else AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
   const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
   const unsigned grid = std::min<uint32_t>(u_count, 512u);
   const f16x8 *PA_r = (const f16x8 *)P_all + (size_t)(pos_begin / kTileRows) * KS * 4 * 64;

@@ -230,6 +230,29 @@ __global__ void znorm_kernel(const double *__restrict__ Z, uint32_t n, double *_
   out[i] = __builtin_sqrt(s);
 }
 
+// ---- a build sharded by rows (ShardedRows, common.h) --------------------------------------------------------------------------
+// the rank's share of the strided sample, side by side: S[i] = row i * stride for the sample indices [i0, i1) whose rows it holds
+__global__ void copy_sample_rows_kernel(const double *__restrict__ own, uint64_t lo, uint64_t stride, uint64_t i0, uint64_t i1, uint32_t d,
+                                        double *__restrict__ S) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (i1 - i0) * d) return;
+  const uint64_t i = i0 + e / d, k = e % d;
+  S[i * d + k] = own[(i * stride - lo) * d + k];
+}
+__global__ void sample_norms_kernel(const double *__restrict__ norms, uint64_t stride, uint32_t ns, double *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) out[i] = norms[(uint64_t)i * stride];
+}
+// the coordinates are f32 values kept in doubles (zproj_*_kernel): they cross the links as f32, exactly
+__global__ void z_to_f32_kernel(const double *__restrict__ Z, uint64_t count, float *__restrict__ out) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) out[e] = (float)Z[e];
+}
+__global__ void z_from_f32_kernel(const float *__restrict__ in, uint64_t count, double *__restrict__ Z) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) Z[e] = (double)in[e];
+}
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // the int8 image (one k step: mfma_prefilter_i8.hip) of image position p = row perm[p] (or p) from the kept coordinates:
@@ -284,9 +307,13 @@ bool rotated_wide_supported(uint32_t d) { return d > 32 && d <= kMaxWide; }  // 
 
 // Z: n x 32 doubles (device), znorm: n doubles (their norms, ~1): the rotated coordinates of all rows.  tail_out: the share of
 // the sample's energy outside the 31 directions (the caller decides whether the bound is worth using).
+// sr (a build sharded by rows; `rows` is not read, `norms` are those of ALL rows; rows up to 128 wide): the directions come from
+// the same strided sample -- every rank contributes the sample rows it holds, 16 MB in all -- each rank projects its OWN rows, and
+// the coordinates (128 B per row) and the per-block tail sums are all-gathered: the same Z, norms and tail as on one GPU.
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out) {
+                      double *tail_out, const ShardedRows *sr) {
   if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
+  if (sr && d > 128) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates of a sharded build: rows up to 128 wide");
   const uint32_t pitch = (d + 63) / 64 * 64;
   uint32_t nv = pitch / 64;  // round up to an instantiated width
   for (uint32_t c : {1u, 2u, 3u, 4u, 6u, 8u, 12u, 16u})
@@ -306,6 +333,29 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   AS_TRY(Ypart.alloc(ctx, (size_t)y_blocks * kDirs * pitch));
   AS_TRY(Zs.alloc(ctx, (size_t)ns * 32));
   AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
+  // the sample the directions are found on: rows 0, stride, 2 stride, ... of the matrix, or (sharded) the same rows side by side
+  const double *s_rows = rows, *s_norms = norms;
+  uint64_t s_stride = stride;
+  DevBuf<double> S, Sn;
+  if (sr) {
+    AS_TRY(S.alloc(ctx, (size_t)ns * d));
+    AS_TRY(Sn.alloc(ctx, ns));
+    std::vector<uint64_t> bytes((size_t)sr->world), offs((size_t)sr->world);
+    for (int r = 0; r < sr->world; ++r) {
+      const uint64_t i0 = (sr->row_lo[(size_t)r] + stride - 1) / stride, i1 = (sr->row_hi[(size_t)r] + stride - 1) / stride;
+      bytes[(size_t)r] = (i1 - i0) * d * sizeof(double);
+      offs[(size_t)r] = i0 * d * sizeof(double);
+    }
+    const uint64_t i0 = ((uint64_t)sr->lo + stride - 1) / stride, i1 = ((uint64_t)sr->lo + sr->count + stride - 1) / stride;
+    if (i1 > i0)
+      hipLaunchKernelGGL(copy_sample_rows_kernel, dim3(cdiv((i1 - i0) * d, 256)), dim3(256), 0, ctx->stream, sr->own, (uint64_t)sr->lo, stride, i0, i1, d, S.p);
+    hipLaunchKernelGGL(sample_norms_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, norms, stride, ns, Sn.p);
+    AS_HIP(ctx, hipGetLastError());
+    AS_TRY(sr->gather_v(S.p, bytes.data(), offs.data()));
+    s_rows = S.p;
+    s_norms = Sn.p;
+    s_stride = 1;
+  }
   std::vector<float> Q((size_t)kDirs * pitch, 0.f), Yh((size_t)kDirs * pitch);
   std::vector<double> V((size_t)kDirs * d);
   uint64_t seed = 0x9E3779B97F4A7C15ull;
@@ -344,9 +394,9 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   for (int it = 0; it < iters; ++it) {  // Q <- orth(S^T S Q)
     AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(Ypart.p, 0, (size_t)y_blocks * kDirs * pitch * sizeof(float), ctx->stream));  // (columns d .. pitch stay 0)
-    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, rows, norms, (uint64_t)0, stride, ns, d, (const float *)Qd.p,
+    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, s_rows, s_norms, (uint64_t)0, s_stride, ns, d, (const float *)Qd.p,
                         pitch, Zs.p, (double *)nullptr));
-    hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, rows, norms, stride, ns, d,
+    hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, s_rows, s_norms, s_stride, ns, d,
                        (const double *)Zs.p, pitch, Ypart.p);
     hipLaunchKernelGGL(yreduce_kernel, dim3(cdiv((uint32_t)kDirs * pitch, 16)), dim3(256), 0, ctx->stream, (const float *)Ypart.p, y_blocks,
                        (uint32_t)kDirs * pitch, Yd.p);
@@ -359,14 +409,36 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   }
   AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (d <= 128) {
-#define AS_ZT(DPV) hipLaunchKernelGGL(zproj_tile_kernel<DPV>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, rows, norms, n, d, (const float *)Qd.p, pitch, Z, tpart.p)
-    switch ((d + 31) / 32) {
+    // (sharded: the rank's own rows into their place in Z and in the per-block tail sums -- shard starts are multiples of 512, so
+    // its blocks of 256 rows are blocks of the whole matrix)
+    const double *p_rows = sr ? sr->own : rows, *p_norms = sr ? norms + sr->lo : norms;
+    const uint32_t p_n = sr ? sr->count : n;
+    double *p_z = sr ? Z + (size_t)sr->lo * 32 : Z, *p_t = sr ? tpart.p + (size_t)(sr->lo / 256) * 4 : tpart.p;
+#define AS_ZT(DPV) hipLaunchKernelGGL(zproj_tile_kernel<DPV>, dim3(cdiv(p_n, 256)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, d, (const float *)Qd.p, pitch, p_z, p_t)
+    if (p_n) switch ((d + 31) / 32) {
       case 2: AS_ZT(64); break;
       case 3: AS_ZT(96); break;
       default: AS_ZT(128); break;
     }
 #undef AS_ZT
     AS_HIP(ctx, hipGetLastError());
+    if (sr) {
+      DevBuf<float> zf;
+      AS_TRY(zf.alloc(ctx, (size_t)n * 32));
+      if (p_n)
+        hipLaunchKernelGGL(z_to_f32_kernel, dim3(cdiv((uint64_t)p_n * 32, 256)), dim3(256), 0, ctx->stream, (const double *)p_z, (uint64_t)p_n * 32,
+                           zf.p + (size_t)sr->lo * 32);
+      AS_TRY(sr->gather(zf.p, 32 * sizeof(float)));
+      hipLaunchKernelGGL(z_from_f32_kernel, dim3(cdiv((uint64_t)n * 32, 256)), dim3(256), 0, ctx->stream, (const float *)zf.p, (uint64_t)n * 32, Z);
+      AS_HIP(ctx, hipGetLastError());
+      std::vector<uint64_t> bytes((size_t)sr->world), offs((size_t)sr->world);
+      for (int r = 0; r < sr->world; ++r) {
+        const uint64_t b0 = sr->row_lo[(size_t)r] / 256, b1 = (sr->row_hi[(size_t)r] + 255) / 256;
+        bytes[(size_t)r] = sr->row_hi[(size_t)r] > sr->row_lo[(size_t)r] ? (b1 - b0) * 4 * sizeof(double) : 0;
+        offs[(size_t)r] = b0 * 4 * sizeof(double);
+      }
+      AS_TRY(sr->gather_v(tpart.p, bytes.data(), offs.data()));
+    }
   } else {
     AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p, pitch, Z, tpart.p));
   }

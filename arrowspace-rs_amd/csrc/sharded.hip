@@ -108,7 +108,7 @@ void shard_range(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi) {
 }
 
 // all-gather of row blocks: rank r contributes rows [lo_r, hi_r) x row_bytes, every rank ends with all n rows
-int gather_rows(as_ctx *ctx, as_comm *c, const void *mine, void *all, uint64_t n, uint64_t row_bytes) {
+int gather_rows(as_ctx *ctx, as_comm *c, const void *mine, void *all, uint64_t n, uint64_t row_bytes, hipStream_t stream = nullptr) {
   std::vector<uint64_t> rb((size_t)c->world), ro((size_t)c->world);
   uint64_t my = 0;
   for (int r = 0; r < c->world; ++r) {
@@ -118,7 +118,7 @@ int gather_rows(as_ctx *ctx, as_comm *c, const void *mine, void *all, uint64_t n
     ro[(size_t)r] = lo * row_bytes;
     if (r == c->rank) my = rb[(size_t)r];
   }
-  const int rc = c->ops.all_gather_v(c->ops.user, mine, my, all, rb.data(), ro.data(), ctx->stream);
+  const int rc = c->ops.all_gather_v(c->ops.user, mine, my, all, rb.data(), ro.data(), stream ? stream : ctx->stream);
   return rc == AS_OK ? AS_OK : fail(ctx, rc, "sharded build: all-gather failed");
 }
 
@@ -442,12 +442,54 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
     rows_shard = staged.p;
   }
 
-  // ---- all rows on every rank (B side of the neighbour search, candidates' rows for the exact re-rank) ----
+  // ---- all rows on every rank (candidates' rows for the exact re-rank, the exact scans) -------------------------------------
+  // The join itself works on images the ranks make of their OWN rows (own_join_prepare with ShardedRows: 392 B per row cross the
+  // links instead of the 1 KB of a 128-wide f64 row), so the all-gather of the f64 rows is issued on a second stream behind the
+  // preparation and awaited in front of the re-rank: it runs under the first pass and the f16 pass.  Everything that is not the
+  // join (small tables, sharded_own_rows = 0) gathers them first, as every build did until round 4.
   DevBuf<double> X;
   AS_TRY(X.alloc(ctx, (size_t)n * dim));
-  AS_TRY(inject(1));
-  AS_TRY(ag.before_collective());
-  AS_TRY(gather_rows(ctx, comm, rows_shard, X.p, n, dim * sizeof(double)));
+  const bool join = W > 1 && as_knn_join_applies(ctx, n, dim, params);
+  const bool rows_late = join && ctx->opt_sharded_own_rows != 0 && dim <= 128;
+  struct SideStream {  // the stream of the late all-gather and its two events; drained before it goes
+    hipStream_t s = nullptr;
+    hipEvent_t start = nullptr, done = nullptr;
+    ~SideStream() {
+      if (s) (void)hipStreamSynchronize(s);
+      if (start) (void)hipEventDestroy(start);
+      if (done) (void)hipEventDestroy(done);
+      if (s) (void)hipStreamDestroy(s);
+    }
+  } side;
+  bool rows_started = false, rows_awaited = false;
+  auto rows_begin = [&]() -> int {
+    if (rows_started) return AS_OK;
+    AS_TRY(inject(1));
+    AS_TRY(ag.before_collective());
+    if (rows_late) {  // (the side stream starts where this one stands: X may be a recycled block, the shard may have just been staged)
+      AS_HIP(ctx, hipEventRecord(side.start, ctx->stream));
+      AS_HIP(ctx, hipStreamWaitEvent(side.s, side.start, 0));
+    }
+    AS_TRY(gather_rows(ctx, comm, rows_shard, X.p, n, dim * sizeof(double), rows_late ? side.s : nullptr));
+    if (rows_late) AS_HIP(ctx, hipEventRecord(side.done, side.s));
+    rows_started = true;
+    return AS_OK;
+  };
+  auto rows_all = [&](const double **out) -> int {
+    AS_TRY(rows_begin());
+    if (rows_late && !rows_awaited) AS_HIP(ctx, hipStreamWaitEvent(ctx->stream, side.done, 0));
+    rows_awaited = true;
+    if (out) *out = X.p;
+    return AS_OK;
+  };
+  if (rows_late) {
+    AS_HIP(ctx, hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+    AS_HIP(ctx, hipEventCreateWithFlags(&side.start, hipEventDisableTiming));
+    AS_HIP(ctx, hipEventCreateWithFlags(&side.done, hipEventDisableTiming));
+  } else {
+    AS_TRY(rows_all(nullptr));
+  }
+  ctx->stats["sharded_rows_late"] = rows_late ? 1 : 0;
 
   DevBuf<uint64_t> idx, idx_all;
   DevBuf<double> dst, dst_all;
@@ -455,7 +497,6 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
   AS_TRY(dst.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1) * K));
   AS_TRY(idx_all.alloc(ctx, (size_t)n * K));
   AS_TRY(dst_all.alloc(ctx, (size_t)n * K));
-  const bool join = W > 1 && as_knn_join_applies(ctx, n, dim, params);
   ctx->stats["sharded_join"] = join ? 1 : 0;
   ctx->stats["sharded_by_positions"] = 0;
   if (join) {
@@ -470,15 +511,41 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
     const uint32_t n32 = (uint32_t)n, d32 = (uint32_t)dim, K32 = (uint32_t)K, lo32 = (uint32_t)lo, here32 = (uint32_t)rows_here;
     DevBuf<double> norms;
     AS_TRY(norms.alloc(ctx, (size_t)n));
-    AS_TRY(row_norms(ctx, X.p, n, dim, norms.p));
     OwnJoin oj;
     // (the thresholds, the one MFMA sweep of the preparation, are computed per rank for its own positions and all-gathered in
-    // place: 8 bytes per position)
-    const std::function<int(void *, size_t)> gather_positions = [&](void *all, size_t elem_bytes) -> int {
+    // place: 8 bytes per position; with the rows late so are the norms, the coordinates and the f16 image, by row)
+    ShardedRows sr;
+    sr.own = rows_shard;
+    sr.lo = lo32;
+    sr.count = here32;
+    sr.rank = R;
+    sr.world = W;
+    sr.row_lo.resize((size_t)W);
+    sr.row_hi.resize((size_t)W);
+    for (int g = 0; g < W; ++g) shard_range(n, g, W, &sr.row_lo[(size_t)g], &sr.row_hi[(size_t)g]);
+    sr.gather = [&](void *all, size_t elem_bytes) -> int {
       AS_TRY(ag.before_collective());
       return gather_rows(ctx, comm, (const char *)all + lo * elem_bytes, all, n, elem_bytes);
     };
-    AS_TRY(own_join_prepare(ctx, X.p, norms.p, n32, d32, K32, oj, lo32, here32, &gather_positions));
+    sr.gather_v = [&](void *all, const uint64_t *bytes, const uint64_t *offsets) -> int {
+      AS_TRY(ag.before_collective());
+      const int rc = comm->ops.all_gather_v(comm->ops.user, (const char *)all + offsets[(size_t)R], bytes[(size_t)R], all, bytes, offsets, ctx->stream);
+      return rc == AS_OK ? AS_OK : fail(ctx, rc, "sharded build: all-gather failed");
+    };
+    sr.rows_begin = rows_begin;
+    sr.rows_all = rows_all;
+    if (rows_late) {
+      if (rows_here) AS_TRY(row_norms(ctx, rows_shard, rows_here, dim, norms.p + lo));
+      AS_TRY(sr.gather(norms.p, sizeof(double)));
+    } else {
+      AS_TRY(row_norms(ctx, X.p, n, dim, norms.p));
+    }
+    AS_TRY(own_join_prepare(ctx, rows_late ? nullptr : X.p, norms.p, n32, d32, K32, oj, lo32, here32, &sr));
+    // the f64 rows from here on: started now (nothing in front of the re-rank reads them on the rotated first pass -- they cross
+    // the links under it), awaited at once where the join still wants them
+    AS_TRY(rows_begin());
+    const bool pairs_need_rows = !(oj.sharded_rows && oj.wide_pre);
+    if (pairs_need_rows) AS_TRY(rows_all(nullptr));
     if (oj.reorder) {
       AS_TRY(oj.inv_own.alloc(ctx, (size_t)n));
       hipLaunchKernelGGL(invert_perm_u32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n32, oj.inv_own.p);
@@ -491,7 +558,7 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
     AS_TRY(offsets.alloc(ctx, (size_t)n + 1));
     if (rows_here) {
       AS_TRY(cand.alloc(ctx, (size_t)n * slots * 2));
-      AS_TRY(own_join_pairs(ctx, X.p, norms.p, n32, d32, lo32, here32, oj, cnt.p, cand.p, /*lists by position*/ true));
+      AS_TRY(own_join_pairs(ctx, pairs_need_rows ? X.p : nullptr, norms.p, n32, d32, lo32, here32, oj, cnt.p, cand.p, /*lists by position*/ true));
     } else {  // nothing contracted here: empty lists for every position
       AS_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * n, ctx->stream));
     }
@@ -557,6 +624,7 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
     }
     cand.release();  // (the dense lists are done with: 4 KB per position of the whole image; stream-ordered reuse)
     packed.release();
+    AS_TRY(rows_all(nullptr));  // the exact stages read the f64 rows of every rank
     if (rows_here) {
       // own pairs -> list 0, all foreign sources -> list 1, positions -> rows
       AS_TRY(used.alloc(ctx, (size_t)W * rows_here));

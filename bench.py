@@ -600,6 +600,11 @@ def main():
             "knn_join": stats["knn_join"], "knn_join_pipe": pipe, "knn_join_delta": stats["knn_join_delta_e9"] * 1e-9,
             "knn_join_candidates_per_row": stats["knn_join_candidates"] / max(1, rows_here),
             "search_uncertified_rows": stats["search_uncertified_rows"],
+            **({"sharded": {"join_sharded_by_positions": ctx.stat("sharded_by_positions"),
+                            "prepared_from_own_rows": ctx.stat("sharded_prepare_by_rows"),
+                            "f64_rows_gathered_under_the_join": ctx.stat("sharded_rows_late"),
+                            "foreign_share_of_listed_slots": ctx.stat("sharded_foreign_slots") / max(1, ctx.stat("sharded_listed_slots"))}}
+               if world > 1 else {}),
             "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items())},
             "commit": git_head(),
             "roofline": roofline,

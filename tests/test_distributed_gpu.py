@@ -414,7 +414,11 @@ def test_library_sharded_build_multi_rank_rccl(tmp_path, n):
 
 
 # ---- the sharded build with the one-GPU algorithm: row order + int8 first pass + masked f16 pass, sharded by image positions ----
-def _lib_positions_worker(rank, world, port, n, d, topk, out_dir):
+_POS_STATS = ("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
+              "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows", "sharded_rows_late", "sharded_prepare_by_rows")
+
+
+def _lib_positions_worker(rank, world, port, n, d, topk, own_rows, out_dir):
     import arrowspace_amd as A
     from arrowspace_amd import distributed as D
     from tests import synth
@@ -426,6 +430,7 @@ def _lib_positions_worker(rank, world, port, n, d, topk, out_dir):
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx._stream = torch.cuda.current_stream().cuda_stream
         comm = D.LibComm.torch_transport(ctx)
+        ctx.set_option("sharded_own_rows", own_rows)
         lo, hi = comm.shard_range(n)
         X, _ = synth.mixture(n, d, seed=29, n_clusters=96, rank=6)
         X[n // 3] = X[5]            # duplicates across shards: ties by row id must survive the trip through image positions
@@ -433,8 +438,7 @@ def _lib_positions_worker(rank, world, port, n, d, topk, out_dir):
         X[n // 2] = 0.0
         gp = A.GraphParams(0.5, 16, topk, 2.0, 0.25)
         gl = comm.build_laplacian(torch.from_numpy(X[lo:hi].copy()).cuda(), n, gp)
-        stats = {k: ctx.stat(k) for k in ("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated",
-                                          "knn_join_row_order", "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows")}
+        stats = {k: ctx.stat(k) for k in _POS_STATS}
         csr = gl.to_host()
         if rank == 0:
             np.savez(os.path.join(out_dir, "pos.npz"), indptr=csr[0], indices=csr[1], data=csr[2], nnz=np.array(gl.nnz()))
@@ -444,16 +448,20 @@ def _lib_positions_worker(rank, world, port, n, d, topk, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world,d,topk", [(70_000, 3, 128, 16), (66_000, 2, 96, 16), (70_000, 2, 128, 38)])
-def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk):
+@pytest.mark.parametrize("n,world,d,topk,own_rows", [(70_000, 3, 128, 16, 1), (70_000, 3, 128, 16, 0), (66_000, 2, 96, 16, 1), (70_000, 2, 128, 38, 1),
+                                                      (66_048, 4, 128, 16, 1)])
+def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk, own_rows):
     """From 65 536 rows the sharded build runs the ONE-GPU algorithm (src/laplacian.rs:203-292 replaced by: rotated
     coordinates -> row order -> int8 first pass -> masked f16 pass -> exact re-rank), every rank on its own range of IMAGE
     positions, the lists exchanged by position and translated back to rows.  The stacked row blocks must be the Laplacian of
     the one-GPU build (itself checked against the oracle at these sizes in test_gpu_stress / test_gpu_parity), bit for bit in
-    structure, with duplicates across shards and a zero row."""
+    structure, with duplicates across shards and a zero row.
+    own_rows = 1 (the default since round 4): the join is prepared from the ranks' OWN rows -- norms, rotated coordinates and the f16
+    image are made per rank and all-gathered (392 B per row at 128 columns), the row order comes from the gathered coordinates --
+    and the all-gather of the f64 rows runs on a second stream under the first pass and the f16 pass; 0: rows first, as in round 3."""
     import arrowspace_amd as A
     from tests import synth
-    mp.spawn(_lib_positions_worker, args=(world, _free_port(), n, d, topk, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_lib_positions_worker, args=(world, _free_port(), n, d, topk, own_rows, str(tmp_path)), nprocs=world, join=True)
     X, _ = synth.mixture(n, d, seed=29, n_clusters=96, rank=6)
     X[n // 3] = X[5]
     X[n - 7] = X[5]
@@ -466,10 +474,10 @@ def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk):
     assert int(r["nnz"]) == len(ix)
     assert np.array_equal(r["indptr"], ip) and np.array_equal(r["indices"], ix)
     assert np.array_equal(r["data"], dv)
-    keys = sorted(("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
-                   "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows"))
+    keys = sorted(_POS_STATS)
     for k in range(world):
         st = dict(zip(keys, np.load(tmp_path / ("pos_stats%d.npy" % k)).tolist()))
         assert st["sharded_join"] == 1 and st["sharded_by_positions"] == 1, st
+        assert st["sharded_rows_late"] == own_rows and st["sharded_prepare_by_rows"] == own_rows, st
         assert st["knn_join_prefilter"] == 1 and st["knn_join_row_order"] == 1, st
         assert st["sharded_foreign_slots"] * 2 < st["sharded_listed_slots"], st   # most partners of a position live on its own rank
