@@ -295,12 +295,14 @@ struct F16SearchTerm {
 // returning atomic and one scattered 8-byte store per entry (131 M of each at 1 M rows: two thirds of this kernel's time and
 // 4.4 bytes written per byte listed).  rerank_prune_grouped_kernel (rerank_split.h) bins a group's entries by row in LDS.
 constexpr uint32_t kRowQueue = 96, kColQueue = 120, kColRuns = 32, kGroupRows = 32, kGroupShift = 27;
-template <int KS, int MODE, bool MASKED, bool GROUPED = false>
+// DIAG = false: the diagnostics (debug bits, cycle stamps) compiled out -- the form the build launches when no debug bit is set
+// (128 columns behind the first pass: the scalar registers and branches they cost sit in the listing, which has none to spare).
+template <int KS, int MODE, bool MASKED, bool GROUPED = false, bool DIAG = true>
 __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
                                                                uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
                                                                const float *__restrict__ theta, uint32_t cap,
                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
-                                                               uint32_t *__restrict__ unit_counter, int dbg,
+                                                               uint32_t *__restrict__ unit_counter, int dbg_in,
                                                                unsigned long long *__restrict__ stamps, F16SearchTerm st,
                                                                const uint32_t *__restrict__ perm,
                                                                const unsigned long long *__restrict__ mask,
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   constexpr int kTileVecs = KS * 4 * 64;     // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 2 * kTileVecs;  // a stage = 256 columns
   constexpr int kBlocks = 8;                 // 32-column blocks per stage
+  const int dbg = DIAG ? dbg_in : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [2 stages of B][2 x 256 column thresholds][8 queues of (owner, other)][8 queues of scores][8 x 4 listing slots]
   f16x8 *bufB = reinterpret_cast<f16x8 *>(smem);
@@ -559,8 +562,22 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       if (t0 < __builtin_inff()) tmax0 = __builtin_fmaxf(tmax0, t0);
       if (t1 < __builtin_inff()) tmax1 = __builtin_fmaxf(tmax1, t1);
     }
+    // (the compiler must not see that nth is minus something it has: it then keeps the thresholds themselves and rebuilds nth with
+    // 16 v_xor in front of every block's first MFMA -- as the C operand nth can be read where it sits)
+    if constexpr (MASKED && MODE == 0) asm volatile("" : "+v"(nth0), "+v"(nth1));
     tmax0 = __builtin_fmaxf(tmax0, __shfl_xor(tmax0, 32, 64));
     tmax1 = __builtin_fmaxf(tmax1, __shfl_xor(tmax1, 32, 64));
+    // (the same in every lane of a group of 32 ... and, as the larger of the two, in the wave: one scalar register)
+    tmax0 = tmax1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_fmaxf(tmax0, tmax1))));
+    // does the wave hold rows that never list (theta = +inf)?  wave-uniform: the listing masks them by hand (emit)
+    bool dead0 = false;
+    {
+      bool d0 = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d0 = d0 || nth0[r] == -__builtin_inff() || nth1[r] == -__builtin_inff();
+      dead0 = __any(d0);
+    }
+    const bool dead1 = dead0;
 
     auto tile_of = [&](uint32_t step) -> uint32_t {  // first packed tile of a stage
       uint32_t S = (MODE == 1 ? 0u : I) + p_lo + (step >> 1);
@@ -573,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     // put their 16 values into the wave's LDS slots, four lanes at a time, and the 64 lanes take one (slot, register)
     // entry each: one pass of ballots and queue writes instead of a 16-step walk over the accumulator registers.
     float qlo0 = 0.f, qhi0 = 0.f, qlo1 = 0.f, qhi1 = 0.f;  // MODE 1: lambda range of the rows of the wave's two groups (set below, per unit)
-    auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc) -> bool {
+    auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, uint32_t colbase, float tc, float tmax, bool dead) -> bool {
       if constexpr (MODE == 0 && MASKED) {
         // A block that gets here (the int8 first pass has removed the rest) holds ~9 pairs on average, dozens inside a cluster,
         // and the listing is written for instruction count.  Per accumulator register: two compares into scalar masks, nothing
@@ -596,9 +613,15 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           asm("v_cndmask_b32 %0, 0, %2, %1" : "=v"(r) : "s"(m), "v"(v));
           return r;
         };
-        {  // most blocks hold no pair at all: two maxima per lane settle that before the walk
-           // (a one-maximum test in front, max(acc) >= min(0, theta_col - largest row threshold), was tried: one more live value
-           // across the listing and the kernel, at 256 registers, spilled 115 of them -- 8.1 -> 14.1 ms)
+        if constexpr (!GROUPED) {
+          // Most blocks hold no pair at all, and ONE maximum per lane settles most of those: a product that reaches its row's
+          // threshold has acc >= 0, one that reaches its column's has acc = vr - t_row >= theta_col - t_row >= theta_col - (the
+          // largest finite threshold of the group's rows).
+          if (!(dbg & 0x800000)) {
+            if (!__any(max16(acc) >= __builtin_fminf(0.f, tc - tmax))) return false;
+          }
+        }
+        if constexpr (GROUPED) {  // (the grouped form keeps the exact pretest of round 3)
           v16f32 v;
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
@@ -678,37 +701,57 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           return listed;
         }
         if (!(dbg & 0x800000)) {  // (debug bit 23: the register-by-register walk below, kept as the form for blocks too dense for the queue)
-          // Every lane looks at its own 16 products (one column, 16 rows): which reach the row's threshold, which the column's;
-          // a wave-wide prefix sum of the counts gives each lane its place in the queue, and it writes its pairs there one
-          // register at a time under its own predicate.  No scalar mask is formed per register: the walk that did (two compares
-          // into SGPR pairs, population counts, a branch and an exec-masked write per register) spent 9 k cycles per listed block
-          // on scalar round trips.
-          uint32_t b1 = 0, b2 = 0;
+          // Every lane looks at its own 16 products (one column, 16 rows).  Which of them pass is read off SIGN bits: acc[r] < 0 fails
+          // the row's threshold, (acc[r] - nth[r]) - theta_col < 0 the column's, and v_alignbit shifts a sign into a word in one
+          // instruction -- two bits per product, 64 instructions for the block where compares, selects and ors took 112.  A wave-wide
+          // prefix sum (six DPP adds, no LDS round trip) gives each lane its place in the queue, and it writes its pairs there one
+          // register at a time under its own predicate.  (No scalar mask is formed per register: the walk that did -- two compares
+          // into SGPR pairs, population counts, a branch and an exec-masked write per register -- spent 9 k cycles per listed
+          // block on scalar round trips.)
+          uint32_t w = 0;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float vr = acc[r] - nth[r];
-            b1 |= acc[r] >= z ? (1u << r) : 0u;
-            b2 |= vr >= tc ? (1u << r) : 0u;
+            const float d2 = (acc[r] - nth[r]) - tc;
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(d2), 31);      // ... so register r ends at bits 2 (15 - r) + 1: the column's test,
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(acc[r]), 31);  //     2 (15 - r): the row's
           }
-          const uint32_t bb = b1 | b2, c = (uint32_t)__builtin_popcount(bb);
-          uint32_t inc = c;
+          uint32_t pass = col < n ? ~w : 0u;  // (a column beyond n: theta_col = +inf has failed its side already, the row side must not list it)
+          if (dead) {  // rows that never list (theta = +inf: padding) hold acc = -inf and acc - nth = NaN, whose sign says nothing
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
+            for (int r = 0; r < 16; ++r)
+              if (nth[r] == -__builtin_inff()) pass &= ~(3u << (2 * (15 - r)));
           }
+          if (!__any(pass != 0u)) return false;
+          const uint32_t c = (uint32_t)__builtin_popcount((pass | (pass >> 1)) & 0x55555555u);
+          uint32_t inc = c;  // inclusive prefix sum over the wave: inside rows of 16 lanes, then across them
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);  // row_shr:1
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);  // row_shr:2
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);  // row_shr:4
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);  // row_shr:8
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
           const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-          if (tot == 0) return false;
           if (tot <= kQueueH) {
             if (qn + tot > kQueueH) flush_queue();
-            uint32_t o = qn + inc - c;
+            // (the two LDS writes of an entry are issued by hand: in front of a write of its own the compiler waits for every
+            // pending vector memory operation -- vmcnt(0): the scattered stores of the flush before, the LDS-DMA of the next stage)
+            const uint32_t o = qn + inc - c;
+            uint32_t qa = q_addr + 8u * o, sa = s_addr + 4u * o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              if ((bb >> r) & 1u) {
+              const uint32_t f = (pass >> (2 * (15 - r))) & 3u;  // bit 0: listed for the row, bit 1: for the column (what the flush reads)
+              if (f) {
                 const float vr = acc[r] - nth[r];
-                queue[o] = make_uint2(row0 + (r & 3) + 8 * (r >> 2), col);
-                queue_s[o] = __uint_as_float((__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | ((b1 >> r) & 1u) | (((b2 >> r) & 1u) << 1));
-                ++o;
+                const uint32_t sc = (__float_as_uint(vr * (1.f / kProductScale)) & ~3u) | f;
+                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
+                asm volatile(
+                    "ds_write2_b32 %0, %2, %3 offset1:1\n\t"
+                    "ds_write_b32 %1, %4\n\t"
+                    "v_add_u32 %0, 8, %0\n\t"
+                    "v_add_u32 %1, 4, %1"
+                    : "+v"(qa), "+v"(sa)
+                    : "v"(row), "v"(col), "v"(sc)
+                    : "memory");
               }
             }
             qn += tot;
@@ -905,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
             const uint32_t colbase = tile0 * kTileRows + nn * 32;
             const float tc = MODE == 1 ? tcol[nn * 32] /* lambda of the lane's column */
                                        : ((diag || colbase + lc >= n) ? __builtin_inff() : thr_scaled(tcol[nn * 32]));
-            auto half = [&](const f16x8(&a)[KS], const v16f32 &nth, float tmax, uint32_t row_base) {
+            auto half = [&](const f16x8(&a)[KS], const v16f32 &nth, float tmax, uint32_t row_base, bool dead) {
               lds_read16<0>(fa[0], blk);
               if constexpr (KS > 1) lds_read16<1 * 4 * 64 * 16>(fa[1], blk);
               if constexpr (KS > 2) lds_read16<2 * 4 * 64 * 16>(fa[2], blk);
@@ -921,12 +964,12 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
               n_blk += 1;
               if (!(dbg & 128) && !(dbg & 2)) {  // (no coarse test: the first pass was one)
                 const unsigned long long te0 = stamp ? now() : 0;
-                n_pass += emit(x, nth, row_base - 4 * lh, colbase, tc) ? 1 : 0;
+                n_pass += emit(x, nth, row_base - 4 * lh, colbase, tc, tmax, dead) ? 1 : 0;
                 if (stamp) t_emit += now() - te0;
               }
             };
-            half(a0, nth0, tmax0, row_base0);
-            half(a1, nth1, tmax1, row_base1);
+            half(a0, nth0, tmax0, row_base0, dead0);
+            half(a1, nth1, tmax1, row_base1, dead1);
           }
           blk = nxt;
           continue;
@@ -958,8 +1001,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           const bool h0 = MODE == 1 ? max16(x0) >= 0.f : max16(x0) >= __builtin_fminf(0.f, tc - tmax0);
           const bool h1 = MODE == 1 ? max16(x1) >= 0.f : max16(x1) >= __builtin_fminf(0.f, tc - tmax1);
           if (__any(h0 || h1) && !(dbg & 2)) {
-            if (__any(h0)) n_pass += emit(x0, nth0, row_base0 - 4 * lh, colbase, tc) ? 1 : 0;
-            if (__any(h1)) n_pass += emit(x1, nth1, row_base1 - 4 * lh, colbase, tc) ? 1 : 0;
+            if (__any(h0)) n_pass += emit(x0, nth0, row_base0 - 4 * lh, colbase, tc, tmax0, dead0) ? 1 : 0;
+            if (__any(h1)) n_pass += emit(x1, nth1, row_base1 - 4 * lh, colbase, tc, tmax1, dead1) ? 1 : 0;
           }
         }
         blk = nxt;
@@ -1169,10 +1212,17 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
                          (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
                          (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
                          (const uint32_t *)nullptr);                                                                      \
-    } else if (mask) {                                                                                                    \
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true>,                                     \
+    } else if (mask && (K != 8 || ctx->opt_debug == 0)) { /* (the diagnostics of this form exist at 8 k steps only) */    \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true, false, false>,                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true, false, false>), dim3(grid), dim3(512), lds, ctx->stream,       \
+                         (const f16x8 *)P, (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand,     \
+                         unit_counter, 0, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,              \
+                         (const uint32_t *)nullptr);                                                                      \
+    } else if (mask) {                                                                                                    \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<8, 0, true>,                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+      hipLaunchKernelGGL((pair_join_f16_kernel<8, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
                          (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
                          (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
                          (const uint32_t *)nullptr);                                                                      \
