@@ -294,6 +294,7 @@ struct F16SearchTerm {
 // one column group -- a run in the column queue, one atomic per run, 64 runs per atomic instruction.  The per-row form took one
 // returning atomic and one scattered 8-byte store per entry (131 M of each at 1 M rows: two thirds of this kernel's time and
 // 4.4 bytes written per byte listed).  rerank_prune_grouped_kernel (rerank_split.h) bins a group's entries by row in LDS.
+constexpr int kFlushRounds = 3;  // rounds of 64 queue entries whose returning atomics go out together (each costs five registers)
 constexpr uint32_t kRowQueue = 96, kColQueue = 120, kColRuns = 32, kGroupRows = 32, kGroupShift = 27;
 // DIAG = false: the diagnostics (debug bits, cycle stamps) compiled out -- the form the build launches when no debug bit is set
 // (128 columns behind the first pass: the scalar registers and branches they cost sit in the listing, which has none to spare).
@@ -347,8 +348,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       // one entry per pair (row, column): bit 0 / 1 of the score = listed for the row / the column.  All the returning atomics of
       // the queue's (up to four) rounds go out back to back and the stores follow: taken round by round (atomic, wait, store) a
       // flush cost a wave four to eight exposed round trips (55 k cycles, stamps of round 3).
-      // (two rounds at a time: the four-round form needs 20 registers the kernel does not have)
-      constexpr int R = 2;
+      // (kFlushRounds at a time: five registers per round; four rounds spill)
+      constexpr int R = kFlushRounds;
+      const uint32_t fq_addr = lds_addr(queue) + 8u * (uint32_t)lane, fs_addr = lds_addr(queue_s) + 4u * (uint32_t)lane;
       for (uint32_t k0 = 0; k0 * 64u < qn; k0 += R) {
         uint32_t ta[R], tb[R], ts[R], pa[R], pb[R];
 #pragma unroll
@@ -357,11 +359,21 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           ts[k] = 0;
           ta[k] = tb[k] = 0;
           if (e < qn && !(dbg & 16384)) {
-            const uint2 v = queue[e];
-            if (v.x != v.y) {
-              ta[k] = perm ? perm[v.x] : v.x;
-              tb[k] = perm ? perm[v.y] : v.y;
-              ts[k] = __float_as_uint(queue_s[e]);
+            // (read by hand: in front of an LDS read of its own the compiler waits for the stores of the rounds before -- vmcnt(0))
+            unsigned long long vxy;
+            uint32_t vs;
+            asm volatile(
+                "ds_read_b64 %0, %2\n\t"
+                "ds_read_b32 %1, %3\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(vxy), "=&v"(vs)
+                : "v"(fq_addr + (k0 + (uint32_t)k) * 512u), "v"(fs_addr + (k0 + (uint32_t)k) * 256u)
+                : "memory");
+            const uint32_t vx = (uint32_t)vxy, vy = (uint32_t)(vxy >> 32);
+            if (vx != vy) {
+              ta[k] = perm ? perm[vx] : vx;
+              tb[k] = perm ? perm[vy] : vy;
+              ts[k] = vs;
             }
           }
         }
@@ -732,7 +744,9 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
           const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
           if (tot <= kQueueH) {
-            if (qn + tot > kQueueH) flush_queue();
+            // (flushed while the queue still fits ONE batch of the flush's rounds -- one exposed round trip of returning atomics per
+            // flush instead of two; only a block with more pairs than that fills the queue beyond)
+            if (qn && qn + tot > 64u * (uint32_t)kFlushRounds) flush_queue();
             // (the two LDS writes of an entry are issued by hand: in front of a write of its own the compiler waits for every
             // pending vector memory operation -- vmcnt(0): the scattered stores of the flush before, the LDS-DMA of the next stage)
             const uint32_t o = qn + inc - c;
