@@ -325,15 +325,19 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   const int lh = lane >> 5, lc = lane & 31;
   // passing pairs go to a per-wave LDS queue as (list owner, other row, score) and are appended 64 at a time: an append is
   // a returning atomic (~2 us before its store can go out) and, taken one by one, makes its wave late at the barrier
-  constexpr size_t kQueueBase = (size_t)2 * kStageVecs * 16 + 2 * 256 * sizeof(float);
+  // (a variable of its own, not a piece of the dynamic array the LDS-DMA writes: in front of every LDS access that may alias a
+  // pending DMA the compiler waits for vmcnt(0) -- the pieces of the next stage in flight, the stores of the flush before)
   constexpr uint32_t kQueueH = MODE == 1 ? kQueueSearch : kQueueJoin;
-  uint2 *queue = reinterpret_cast<uint2 *>(smem + kQueueBase) + (size_t)wv * kQueueH;
-  float *queue_s = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * sizeof(uint2)) + (size_t)wv * kQueueH;
-  // listing scratch of the wave: 4 slots of (16 acc, 16 acc + theta_row, lane, theta_col, 2 unused) floats
   constexpr int kSlotFloats = 36;
-  float *ex = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + (size_t)wv * 4 * kSlotFloats;
+  constexpr size_t kSideBytes = (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float)) + (size_t)8 * 4 * kSlotFloats * sizeof(float) +
+                                (MODE == 1 ? (size_t)2 * kSuperH * sizeof(float) : 0);
+  __shared__ __attribute__((aligned(16))) unsigned char s_side[kSideBytes];
+  uint2 *queue = reinterpret_cast<uint2 *>(s_side) + (size_t)wv * kQueueH;
+  float *queue_s = reinterpret_cast<float *>(s_side + (size_t)8 * kQueueH * sizeof(uint2)) + (size_t)wv * kQueueH;
+  // listing scratch of the wave: 4 slots of (16 acc, 16 acc + theta_row, lane, theta_col, 2 unused) floats
+  float *ex = reinterpret_cast<float *>(s_side + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + (size_t)wv * 4 * kSlotFloats;
   // MODE 1: lambda and g - beta of the unit's 512 queries
-  float *s_qlam = reinterpret_cast<float *>(smem + kQueueBase + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + 8 * 4 * kSlotFloats;
+  float *s_qlam = reinterpret_cast<float *>(s_side + (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float))) + 8 * 4 * kSlotFloats;
   float *s_qg = s_qlam + kSuperH;
   uint32_t qn = 0;  // wave-uniform
   auto lanes_below = [&](unsigned long long m) -> uint32_t {
@@ -1190,10 +1194,9 @@ int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norm
   return AS_OK;
 }
 
-static size_t f16_join_lds(uint32_t KS, bool search) {
-  return (size_t)2 * 2 * KS * 4 * 64 * 16 + 2 * 256 * sizeof(float) +
-         (size_t)8 * (search ? kQueueSearch : kQueueJoin) * (sizeof(uint2) + sizeof(float)) + (size_t)8 * 4 * 36 * sizeof(float) +
-         (search ? (size_t)2 * kSuperH * sizeof(float) : 0);
+static size_t f16_join_lds(uint32_t KS, bool search) {  // the dynamic part: two stages of B + the column thresholds (the queues are static)
+  (void)search;
+  return (size_t)2 * 2 * KS * 4 * 64 * 16 + 2 * 256 * sizeof(float);
 }
 
 // Threshold join over super tiles [I_begin, I_begin + I_count) of the T2 = ceil(n / 512) super tiles of the f16 image P
