@@ -127,7 +127,9 @@ def recorded_traffic(kernel_substr, n, d):
         return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"]}
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x[:3] in ("r03", "r04") and x.endswith("_pmc_traffic.json"))
+    # (the item-graph lambda has a pass of its own: scripts/profile_round.sh)
+    suffix = "_pmc_traffic_spmm.json" if kernel_substr == "signal_sums_kernel" else "_pmc_traffic.json"
+    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x[:3] in ("r03", "r04") and x.endswith(suffix))
     for name in files[-1:]:   # the newest pass only: a kernel that no longer exists must not bring an old file's bytes along
         try:
             with open(os.path.join(pdir, name)) as f:
@@ -505,8 +507,8 @@ def main():
                 add(names[16], "pair_join_f16_kernel (v_mfma_f32_32x32x16_f16 on one f16 plane of the unit rows; symmetric threshold join "
                                "over the blocks the first pass leaves, listing (row, column, score))",
                     "mfma", 2.0 * 32 * 32 * d_pad * blocks, MFMA16_PEAK_TFLOPS, "TFLOP/s", "f16 MFMA flops executed (blocks contracted x 32 x 32 x d)",
-                    pmc="pair_join_f16_kernel<%d, 0, true>" % (d_pad // 16) if stats.get("knn_join_prefilter", 0) == 1
-                    else "pair_join_f16_kernel<%d, 0, false>" % (d_pad // 16))
+                    pmc="pair_join_f16_kernel<%d, 0, true," % (d_pad // 16) if stats.get("knn_join_prefilter", 0) == 1
+                    else "pair_join_f16_kernel<%d, 0, false," % (d_pad // 16))
             elif pipe == 48:
                 add(names[48], "pair_join_bf16_kernel (split bf16, two-phase blocks)", "mfma",
                     2.0 * 32 * 32 * d_pad * (blocks + 2.0 * stats["knn_mfma_join_bf16_blocks_full"]), MFMA16_PEAK_TFLOPS, "TFLOP/s",
