@@ -84,6 +84,7 @@ struct as_ctx {
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
                                          // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
+  int64_t opt_rerank_grid = 0;           // scoring kernel of the re-rank: workgroups launched (0: the default)
   int64_t opt_rerank_order = 1;          // exact re-rank of the join: rows visited in the order of the image (candidates shared through L2)
   int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)
   int64_t opt_cluster_on_device = 1;     // incremental clustering: batches after the last centroid is created stay on the device

@@ -1000,18 +1000,19 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
       // rows wider than 128: the same first pass on the rotated coordinates the caller has (rotate_wide.hip), reduced to "which
       // pairs of 256-row super tiles hold anything" for the panelled kernel
       DevBuf<unsigned char> mask, P8;
-      const bool pre = rot_z && I_begin == 0 && (uint64_t)I_end * 512 >= n;
+      // (on any range of row super tiles: a rank of a sharded build sweeps its own positions against every column)
+      const bool pre = rot_z != nullptr && I_end > I_begin;
       if (pre) {
         const uint32_t tiles = packed_tiles_f16(n);
         double err = 0.0;
         AS_TRY(P8.alloc(ctx, (size_t)tiles * 4 * 64 * 16));
-        AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end)));
-        AS_HIP(ctx, hipMemsetAsync(mask.p, 0, prefilter_mask_bytes(n, I_end), ctx->stream));  // (both orientations of a pair are looked up)
+        AS_TRY(mask.alloc(ctx, prefilter_mask_bytes(n, I_end - I_begin)));
+        AS_HIP(ctx, hipMemsetAsync(mask.p, 0, prefilter_mask_bytes(n, I_end - I_begin), ctx->stream));  // (both orientations of a pair are looked up)
         {
           ProfScope ps(ctx, "knn_join_prefilter_pack");
           AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
         }
-        AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, 0, I_end, theta.p, mask.p));
+        AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p));
       }
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
       AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16", perm,
@@ -1452,9 +1453,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                              force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order);
         }
         AS_HIP(ctx, hipGetLastError());
+        const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each) of the scoring kernel
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
-    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(row_count >= 256 * 7 * 8 ? 256 * 7 * 8 : row_count), dim3(64), \
+    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(row_count >= rs_grid ? rs_grid : row_count), dim3(64), \
                        rs_lds(PC == 1 ? 2 : 4), ctx->stream, \
                        rows, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, \
                        (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u, a_ids, score_order);                         \

@@ -216,10 +216,28 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
       if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) continue;
       uint32_t J = I + off;
       J = J >= T2 ? J - T2 : J;
-      if (MODE == 0 && mask) {  // (rows of I against columns of J, or the other way round: the first pass saw one of the two)
-        const unsigned long long a = mask[(size_t)(I >> 1) * mask_pitch + J] >> (32u * (I & 1u));
-        const unsigned long long b = mask[(size_t)(J >> 1) * mask_pitch + I] >> (32u * (J & 1u));
-        if ((uint32_t)(a | b) == 0u) continue;
+      if (MODE == 0 && mask) {
+        // The first pass swept every unordered pair of 512-row super tiles ONCE, from the side its cyclic half pattern names
+        // (looked): rows of A against columns of B, or the other way round.  The mask holds the row super tiles of THIS call's
+        // range [A0, A1) (a rank of a sharded build: its own positions) against every column; a pair the first pass saw from a
+        // row super tile outside the range (a few pairs near the antipodal offset) is unknown here and contracted.
+        const uint32_t A = I >> 1, B = J >> 1, T5 = T2 >> 1, nn5 = (T5 - 1) / 2;
+        const uint32_t A0 = I_begin >> 1, A1 = (I_begin + I_count + 1) >> 1;
+        auto looked = [&](uint32_t from, uint32_t to) -> bool {
+          const uint32_t dl = to >= from ? to - from : to + T5 - from;
+          return dl <= nn5 || ((T5 % 2 == 0) && T5 > 1 && from < T5 / 2 && dl == nn5 + 1);
+        };
+        bool known = false;
+        unsigned long long bits = 0;
+        if (looked(A, B)) {
+          known = true;
+          bits |= mask[(size_t)(A - A0) * mask_pitch + J] >> (32u * (I & 1u));
+        }
+        if (looked(B, A) && B >= A0 && B < A1) {
+          known = true;
+          bits |= mask[(size_t)(B - A0) * mask_pitch + I] >> (32u * (J & 1u));
+        }
+        if (known && (uint32_t)bits == 0u) continue;
       }
       s_next[0] = I;
       s_next[1] = J;
@@ -628,7 +646,6 @@ int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
   const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;  // 256-row super tiles of the image (whole 512-row ones)
-  if (mask && I_begin != 0) return fail(ctx, AS_ERR_ARG, "wide f16 join: a mask covers the whole matrix");
   return launch_wide<0>(ctx, prof_name, P, nullptr, nullptr, KS, T2, 2 * I_begin, std::min(2 * I_count, T2 - 2 * I_begin), n, n, theta,
                         cap, cnt, cand, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, perm, mask, T2);
 }

@@ -449,7 +449,7 @@ def _lib_positions_worker(rank, world, port, n, d, topk, own_rows, out_dir):
 
 
 @pytest.mark.parametrize("n,world,d,topk,own_rows", [(70_000, 3, 128, 16, 1), (70_000, 3, 128, 16, 0), (66_000, 2, 96, 16, 1), (70_000, 2, 128, 38, 1),
-                                                      (66_048, 4, 128, 16, 1)])
+                                                      (66_048, 4, 128, 16, 1), (66_560, 2, 256, 16, 1)])
 def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk, own_rows):
     """From 65 536 rows the sharded build runs the ONE-GPU algorithm (src/laplacian.rs:203-292 replaced by: rotated
     coordinates -> row order -> int8 first pass -> masked f16 pass -> exact re-rank), every rank on its own range of IMAGE
@@ -478,6 +478,7 @@ def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk, o
     for k in range(world):
         st = dict(zip(keys, np.load(tmp_path / ("pos_stats%d.npy" % k)).tolist()))
         assert st["sharded_join"] == 1 and st["sharded_by_positions"] == 1, st
-        assert st["sharded_rows_late"] == own_rows and st["sharded_prepare_by_rows"] == own_rows, st
+        late = own_rows if d <= 128 else 0   # (rows wider than 128: the f64 rows first; their first pass runs on the rank's own positions)
+        assert st["sharded_rows_late"] == late and st["sharded_prepare_by_rows"] == late, st
         assert st["knn_join_prefilter"] == 1 and st["knn_join_row_order"] == 1, st
         assert st["sharded_foreign_slots"] * 2 < st["sharded_listed_slots"], st   # most partners of a position live on its own rank
