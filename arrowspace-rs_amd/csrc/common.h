@@ -82,6 +82,8 @@ struct as_ctx {
   int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange) or 3 (before the nnz all-reduce)
   int64_t opt_join_basis_iters = 4;      // rotated coordinates: rounds of subspace iteration on the 16 k-row sample (each 0.15 ms: three small kernels, two copies, a host Gram-Schmidt; hard mixture 98.2 / 94.7 / 93.2 / 93.9 ms at 2 / 3 / 4 / 5 rounds, the bench data indifferent from 3 on)
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
+  int64_t opt_join_cone_tiles = 1;       // rotated first pass on an ordered image: behind a cone bound on pairs of 128-position tiles (cone_tiles.hip)
+  int64_t opt_join_cone_tiles_max_e3 = 600;  // ... taken while it keeps at most this share (x 1e-3) of the tile pairs; beyond, the pass sweeps everything
   int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
                                          // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
   int64_t opt_rerank_grid = 0;           // scoring kernel of the re-rank: workgroups launched (0: the default)

@@ -1,0 +1,289 @@
+// cone_tiles.hip -- in front of the int8 first pass of the item graph's join (mfma_prefilter_i8.hip): which PAIRS OF 128-POSITION
+// TILES of the ordered image can hold a pair of rows whose cosine reaches a threshold at all (replaces nothing of the reference
+// by itself: part of what stands in for the all-pairs loop of src/laplacian.rs:203-252).
+//
+// The first pass sweeps every pair of rows with a 32-wide product that bounds their cosine from above, cos(i, j) <= z_i . z_j
+// (z: the 31 rotated coordinates and the tail norm, rotate_wide.hip).  On an image ordered by direction 97 % of the pairs of 512-row
+// super tiles hold no pair at its threshold (scripts/explore_super_level.py) -- but a bound on a pair of GROUPS from centre and
+// radius is useless (it flags 79 %): the slack of both radii floods the gap between thresholds and inter-cluster products.  The
+// bound here is one-sided: the rows of tile I sit in a cone of half angle a_I around their mean direction u_I, and the EXACT
+// largest product of the rows of tile J with u_I is computed (an n x n/128 product on the matrix pipe: 1/128 of the pass).  On the
+// unit sphere angle(i, j) >= angle(u_I, j) - angle(u_I, i), so for every i in I, j in J
+//     z_i . z_j <= |z_i| |z_j| cos(max(0, acos(M_JI) - a_I)),   M_JI = max_j  z_j / |z_j| . u_I,
+// and the same with the roles swapped; a tile pair is kept iff BOTH bounds reach min(theta) of its rows.  Bench mixture (1 M x
+// 128): 6.3 % of the tile pairs are kept (1.3 % hold a pair); rank 64 / 4 096 clusters: 85 % -- how sharp it is depends on the data,
+// never whether it holds.  Rounding: unit directions and rows enter the MFMA as f16 (error norm <= 2^-11 each: 1.5e-3 on M covers
+// both, their product and the f32 accumulation), cos a_I is lowered by 1e-5, the thresholds by 2e-4 (what the f32 projection
+// and the basis contribute, as in the first pass's own delta), |z| enters as the largest norm of any row.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "mfma_common.h"
+
+namespace asx {
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kCK = 32;   // coordinates (two k steps of the f16 MFMA)
+constexpr float kEpsM = 1.5e-3f, kEpsCone = 1e-5f, kEpsTheta = 2e-4f;
+
+// One workgroup of 128 threads per tile: thread t is position T * 128 + t (row perm[position], or the position itself).
+// rows_img: the unit directions of the rows in the operand layout of v_mfma_f32_32x32x16_f16 with KS = 2
+//   rows_img[((T * 2 + ks) * 4 + s) * 64 + l][j] = f16(dir(128 T + 32 s + (l & 31))[16 ks + 8 (l >> 5) + j]);
+// dirs_img: the same layout with "row" = tile index (the mean directions, 128 of them per image tile).
+__global__ __launch_bounds__(128) void cone_tile_kernel(const double *__restrict__ Z, const uint32_t *__restrict__ perm, uint32_t n,
+                                                        const float *__restrict__ theta, f16x8 *__restrict__ rows_img,
+                                                        f16x8 *__restrict__ dirs_img, float *__restrict__ cos_a, float *__restrict__ sin_a,
+                                                        float *__restrict__ theta_min, unsigned int *__restrict__ nmax_bits) {
+  __shared__ float s_u[128][kCK + 1];
+  __shared__ float s_m[kCK];
+  __shared__ float s_red[128];
+  const uint32_t T = blockIdx.x, t = threadIdx.x, pos = T * 128u + t;
+  float u[kCK];
+  float nrm = 0.f;
+  bool live = false;
+  if (pos < n) {
+    const double *z = Z + (size_t)(perm ? perm[pos] : pos) * kCK;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) {
+      const double v = z[k];
+      u[k] = (float)v;
+      s += v * v;
+    }
+    const double r = __builtin_sqrt(s);
+    nrm = (float)(r * (1.0 + 1e-6));  // rounded up
+    live = r > 0.0 && r < __builtin_inf();
+    const float inv = live ? (float)(1.0 / r) : 0.f;
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) u[k] = live ? u[k] * inv : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) u[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) s_u[t][k] = u[k];
+  // largest |z| of any row
+  {
+    float m = live ? nrm : 0.f;
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((t & 63) == 0 && m > 0.f) atomicMax(nmax_bits, __float_as_uint(m));  // non-negative floats order like their bits
+  }
+  __syncthreads();
+  // mean direction: coordinate k summed over the 128 rows in index order (the same sum in every run)
+  if (t < kCK) {
+    float s = 0.f;
+    for (int r = 0; r < 128; ++r) s += s_u[r][t];
+    s_m[t] = s;
+  }
+  __syncthreads();
+  float mm = 0.f;
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) mm = __builtin_fmaf(s_m[k], s_m[k], mm);
+  const float minv = mm > 0.f ? 1.f / __builtin_sqrtf(mm) : 0.f;  // (no direction: a cone of half angle pi below)
+  float dotm = 0.f;
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) dotm = __builtin_fmaf(u[k], s_m[k] * minv, dotm);
+  // cos of the cone's half angle = the smallest product of a live row with the mean direction; smallest finite threshold
+  s_red[t] = live ? dotm : 2.f;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < (uint32_t)o) s_red[t] = __builtin_fminf(s_red[t], s_red[t + o]);
+    __syncthreads();
+  }
+  const float ca_raw = s_red[0];
+  __syncthreads();
+  const float th = theta[pos];  // (padded to whole super tiles with +inf)
+  s_red[t] = (pos < n && th < __builtin_inff()) ? th : __builtin_inff();
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < (uint32_t)o) s_red[t] = __builtin_fminf(s_red[t], s_red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    float ca = (minv > 0.f && ca_raw <= 1.5f) ? __builtin_fminf(__builtin_fmaxf(ca_raw - kEpsCone, -1.f), 1.f) : -1.f;
+    if (ca_raw > 1.5f) ca = 1.f;  // no live row: nothing to bound (its thresholds are +inf as well)
+    cos_a[T] = ca;
+    sin_a[T] = __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - ca * ca)) + 1e-6f;
+    theta_min[T] = s_red[0];
+  }
+  // the rows' directions in operand order: thread t = row 32 s + r of the tile
+  {
+    const uint32_t s = t >> 5, r = t & 31u;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)u[16 * ks + 8 * h + j];
+        rows_img[(((size_t)T * 2 + ks) * 4 + s) * 64 + r + 32 * h] = v;
+      }
+  }
+  // the tile's mean direction as "row" T of the direction image
+  if (t < 4) {
+    const uint32_t ks = t >> 1, h = t & 1u, Td = T >> 7, s = (T & 127u) >> 5, r = T & 31u;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)(s_m[16 * ks + 8 * h + j] * minv);
+    dirs_img[(((size_t)Td * 2 + ks) * 4 + s) * 64 + r + 32 * h] = v;
+  }
+}
+
+__device__ __forceinline__ float max16f(const v16f32 &a) {
+  float m = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[3]), a[4]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[5]), a[6]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[7]), a[8]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[9]), a[10]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[11]), a[12]);
+  m = __builtin_fmaxf(__builtin_fmaxf(m, a[13]), a[14]);
+  return __builtin_fmaxf(m, a[15]);
+}
+
+// bit1[J * words + g], bit b: can a row of tile J and a row of tile I = 32 g + b reach a threshold, by the cone of I and the
+// exact products of J's rows with I's direction?  One wave per row tile J of [jt_begin, jt_begin + jt_count), sweeping the
+// direction groups [dg_begin, dg_begin + dg_count).
+__global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img,
+                                                       uint32_t jt_begin, uint32_t jt_count, uint32_t dg_begin, uint32_t dg_count,
+                                                       uint32_t ntiles, const float *__restrict__ cos_a, const float *__restrict__ sin_a,
+                                                       const float *__restrict__ theta_min, const unsigned int *__restrict__ nmax_bits,
+                                                       uint32_t words, uint32_t *__restrict__ bit1) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t wid = blockIdx.x * 4u + (uint32_t)wv;
+  if (wid >= jt_count) return;
+  const uint32_t J = jt_begin + wid;
+  const int lc = lane & 31;
+  f16x8 a[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[s][ks] = rows_img[(((size_t)J * 2 + ks) * 4 + s) * 64 + lane];
+  const float thJ = theta_min[J];
+  const float nmax = __uint_as_float(*nmax_bits);
+  const float inv_n2 = nmax > 0.f ? 1.f / (nmax * nmax) : 1.f;
+  v16f32 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  for (uint32_t g = dg_begin; g < dg_begin + dg_count; ++g) {
+    const f16x8 b0 = dirs_img[(((size_t)(g >> 2) * 2 + 0) * 4 + (g & 3u)) * 64 + lane];
+    const f16x8 b1 = dirs_img[(((size_t)(g >> 2) * 2 + 1) * 4 + (g & 3u)) * 64 + lane];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      v16f32 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b0, zero, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b1, acc, 0, 0, 0);
+      m = __builtin_fmaxf(m, max16f(acc));
+    }
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+    const uint32_t I = g * 32u + (uint32_t)lc;
+    bool flag = false;
+    if (I < ntiles) {
+      const float t = __builtin_fminf(theta_min[I], thJ);
+      if (t < __builtin_inff()) {
+        const float tpp = (t - kEpsTheta) * inv_n2;
+        if (t <= 1e-3f) {
+          flag = true;  // (thresholds at or below zero: rows of norm zero count, no bound on directions says anything)
+        } else if (tpp <= 1.f) {
+          const float ca = cos_a[I], sa = sin_a[I];
+          if (tpp <= -ca) flag = true;  // the cone and the threshold's angle together span the half circle
+          else flag = m + kEpsM >= ca * tpp - sa * __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - tpp * tpp)) - 1e-5f;
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(flag && lane < 32);
+    if (lane == 0) bit1[(size_t)J * words + g] = (uint32_t)bal;
+  }
+}
+
+// tile_mask[(I - it_begin) * words + w], bit b: the pair (I, J = 32 w + b) is kept iff both orientations keep it
+__global__ void cone_and_kernel(const uint32_t *__restrict__ bit1, uint32_t it_begin, uint32_t it_count, uint32_t ntiles, uint32_t words,
+                                uint32_t *__restrict__ tile_mask, unsigned long long *__restrict__ kept) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t out = 0;
+  if (e < (uint64_t)it_count * words) {
+    const uint32_t ii = (uint32_t)(e / words), w = (uint32_t)(e % words), I = it_begin + ii;
+    const uint32_t a = bit1[(size_t)I * words + w];
+    uint32_t b = 0;
+    for (uint32_t bb = 0; bb < 32; ++bb) {
+      const uint32_t J = 32u * w + bb;
+      if (J < ntiles) b |= ((bit1[(size_t)J * words + (I >> 5)] >> (I & 31u)) & 1u) << bb;
+    }
+    out = a & b;
+    tile_mask[e] = out;
+  }
+  uint32_t c = (uint32_t)__builtin_popcount(out);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept, (unsigned long long)c);
+}
+
+}  // namespace
+
+uint32_t cone_tile_words(uint32_t n) { return (((n + 127u) / 128u) + 31u) / 32u; }
+
+// tile_mask: (tiles of [pos_begin, pos_begin + pos_count)) x cone_tile_words(n) words; bit J of row I - first tile: the pair of
+// 128-position tiles (I, J) may hold a pair of rows at a threshold.  Z: n x 32 rotated coordinates by ROW, perm: position -> row
+// (or null), theta: thresholds by position padded to whole 512-position super tiles (+inf beyond n).  pos_begin a multiple of 512.
+int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin,
+                   uint32_t pos_count, uint32_t *tile_mask, double *kept_share) {
+  const uint32_t ntiles = (n + 127u) / 128u, words = cone_tile_words(n);
+  const uint32_t dir_tiles = (ntiles + 127u) / 128u;  // image tiles of the direction image
+  const uint32_t it_begin = pos_begin / 128u, it_count = std::min(ntiles - std::min(ntiles, it_begin), (pos_count + 127u) / 128u);
+  ProfScope ps(ctx, "knn_join_cone_tiles");
+  DevBuf<unsigned char> rows_img, dirs_img;
+  DevBuf<float> ca, sa, tmin;
+  DevBuf<unsigned int> nmax;
+  DevBuf<uint32_t> bit1;
+  DevBuf<unsigned long long> kept;
+  AS_TRY(rows_img.alloc(ctx, (size_t)ntiles * 2 * 4 * 64 * 16));
+  AS_TRY(dirs_img.alloc(ctx, (size_t)dir_tiles * 2 * 4 * 64 * 16));
+  AS_TRY(ca.alloc(ctx, ntiles));
+  AS_TRY(sa.alloc(ctx, ntiles));
+  AS_TRY(tmin.alloc(ctx, ntiles));
+  AS_TRY(nmax.alloc(ctx, 1));
+  AS_TRY(bit1.alloc(ctx, (size_t)ntiles * words));
+  AS_TRY(kept.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(dirs_img.p, 0, (size_t)dir_tiles * 2 * 4 * 64 * 16, ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(nmax.p, 0, sizeof(unsigned int), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(kept.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(cone_tile_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, Z, perm, n, theta, (f16x8 *)rows_img.p, (f16x8 *)dirs_img.p, ca.p,
+                     sa.p, tmin.p, nmax.p);
+  const uint32_t all_groups = words;
+  if (it_begin == 0 && it_count == ntiles) {
+    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
+                       ntiles, 0u, all_groups, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
+                       (const unsigned int *)nmax.p, words, bit1.p);
+  } else if (it_count) {
+    // a range of row tiles (a rank of a sharded build): its rows against every direction, and every tile's rows against its directions
+    AS_HIP(ctx, hipMemsetAsync(bit1.p, 0, sizeof(uint32_t) * (size_t)ntiles * words, ctx->stream));
+    const uint32_t g0 = it_begin / 32u, g1 = (it_begin + it_count + 31u) / 32u;
+    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
+                       ntiles, g0, g1 - g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
+                       (const unsigned int *)nmax.p, words, bit1.p);
+    // (the rows of the range against the directions outside it; the groups [g0, g1) were written above, by the same rule)
+    if (g0 > 0)
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
+                         it_begin, it_count, 0u, g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
+                         (const unsigned int *)nmax.p, words, bit1.p);
+    if (g1 < all_groups)
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
+                         it_begin, it_count, g1, all_groups - g1, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
+                         (const unsigned int *)nmax.p, words, bit1.p);
+  }
+  if (it_count)
+    hipLaunchKernelGGL(cone_and_kernel, dim3(cdiv((uint64_t)it_count * words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)bit1.p, it_begin,
+                       it_count, ntiles, words, tile_mask, kept.p);
+  AS_HIP(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, &h, kept.p, sizeof(h)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double share = it_count ? (double)h / ((double)it_count * (double)ntiles) : 0.0;
+  ctx->stats["knn_join_cone_tiles_kept_e6"] = (int64_t)(share * 1e6);
+  if (kept_share) *kept_share = share;
+  return AS_OK;
+}
+
+}  // namespace asx

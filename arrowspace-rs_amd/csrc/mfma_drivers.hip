@@ -791,7 +791,10 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
                       double *tail_out, const ShardedRows *sr = nullptr);
 int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
 int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
-                         unsigned char *mask);
+                         unsigned char *mask, const uint32_t *tile_mask = nullptr, uint32_t tm_words = 0);
+uint32_t cone_tile_words(uint32_t n);
+int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin, uint32_t pos_count,
+                   uint32_t *tile_mask, double *kept_share);
 int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                              uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                              float *theta2_out);
@@ -985,7 +988,20 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
             ProfScope ps(ctx, "knn_join_prefilter_pack");
             AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
           }
-          AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p));
+          // in front of it, on an image ordered by direction: which pairs of 128-position tiles can hold a pair at all (a cone
+          // around each tile's direction against the exact products of the other tile's rows with it: cone_tiles.hip).  Where the
+          // bound keeps most pairs (data without directions to tell apart) the pass sweeps everything as before.
+          DevBuf<uint32_t> tile_mask;
+          const uint32_t tm_words = cone_tile_words(n);
+          bool tiled = ctx->opt_join_cone_tiles != 0 && (perm || image_perm) && n >= 65536 && !(ctx->opt_debug & 2048);
+          if (tiled) {
+            double kept = 1.0;
+            AS_TRY(tile_mask.alloc(ctx, (size_t)(I_end - I_begin) * 4 * tm_words));
+            AS_TRY(cone_tile_mask(ctx, rot_z, image_perm ? image_perm : perm, n, theta.p, I_begin * 512u, (I_end - I_begin) * 512u, tile_mask.p, &kept));
+            tiled = kept <= (double)ctx->opt_join_cone_tiles_max_e3 * 1e-3;
+          }
+          ctx->stats["knn_join_cone_tiles"] = tiled ? 1 : 0;
+          AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p, tiled ? tile_mask.p : nullptr, tm_words));
         } else {
           AS_TRY(prefilter_i8(ctx, packedh, rows, norms, n, d, I_begin, I_end - I_begin, theta.p, mask.p, image_perm ? image_perm : perm));
         }

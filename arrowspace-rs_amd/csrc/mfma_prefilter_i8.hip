@@ -558,14 +558,21 @@ __global__ __launch_bounds__(512, 2) void pair_prefilter_i8_kernel(const i32x4 *
 // it, thresholds thr_a by their position), every one of which meets every column super tile of P8; no column side.
 // OCC4: one accumulator set (the test of a block right behind its MFMAs) in 128 registers, so that two workgroups share a CU:
 // four waves per SIMD instead of two interleave by themselves and cover each other's barriers.
-template <int KS8, bool RECT, bool OCC4 = false>
+// TILED (OCC4, not RECT): tile_mask (cone_tiles.hip) says which pairs of 128-position tiles can hold a pair at all -- row tile
+// 4 (I - I_begin) + a of the call against column tile 4 S + c, a bit each, tm_words words per row tile.  A unit then visits only
+// the column super tiles with a bit set for any of its four row tiles (their list is made in LDS, as the masked f16 pass lists
+// its stages), and a wave contracts only the 128-column trips its own row tile needs; the ring of fragment registers restarts
+// at every trip.  The output mask of what is not visited must be zero (the launcher clears it).
+template <int KS8, bool RECT, bool OCC4 = false, bool TILED = false>
 __global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_kernel(const i32x4 *__restrict__ P8, const i32x4 *__restrict__ PA,
                                                                           const int *__restrict__ thr_a, uint32_t T2, uint32_t I_begin,
                                                                           uint32_t I_count, uint32_t W, uint32_t n,
                                                                           const int *__restrict__ thr, const int *__restrict__ thr_min,
                                                                           unsigned char *__restrict__ mask,
                                                                           uint32_t *__restrict__ unit_counter, int dbg,
-                                                                          unsigned long long *__restrict__ stamps) {
+                                                                          unsigned long long *__restrict__ stamps,
+                                                                          const uint32_t *__restrict__ tile_mask = nullptr, uint32_t tm_words = 0) {
+  static_assert(!TILED || (OCC4 && !RECT && KS8 == 1), "the tiled form exists for the rotated image at four waves per SIMD");
   static_assert(KS8 == 1 || KS8 == 2, "one or two k steps");
   constexpr int kTileVecs = KS8 * 4 * 64;    // 16-B vectors of a 128-row tile
   constexpr int kStageVecs = 4 * kTileVecs;  // a stage = 512 columns = one column super tile
@@ -574,6 +581,8 @@ __global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_ke
   int *colthr = reinterpret_cast<int *>(smem + (size_t)2 * kStageVecs * 16);  // 2 x 512, then the block minima (2 x 64 slots),
   int *colmin = colthr + 2 * 512;                                             // then 8 KB nobody owns: the ring reads ahead
   __shared__ uint32_t s_unit;
+  __shared__ uint32_t s_st[64];  // TILED: the unit's column super tiles with anything to do: step | 16 tile bits << 8
+  __shared__ uint32_t s_nl;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
@@ -630,6 +639,26 @@ __global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_ke
       if (p_hi <= p_lo) continue;
     }
     const uint32_t steps = p_hi - p_lo;  // column super tiles to visit
+    uint32_t n_list = steps;             // ... of which (TILED) those with a tile pair to look at
+    if constexpr (TILED) {
+      if (tid < 64) {  // (steps <= W <= 64: one lane of wave 0 per column super tile)
+        uint32_t bits16 = 0;
+        if ((uint32_t)tid < steps) {
+          uint32_t S = I + p_lo + (uint32_t)tid;
+          S = S >= T2 ? S - T2 : S;
+          const uint32_t ct = 4u * S;  // its four column tiles: one nibble of a word
+#pragma unroll
+          for (uint32_t a = 0; a < 4; ++a)
+            bits16 |= ((tile_mask[(size_t)(4u * (I - I_begin) + a) * tm_words + (ct >> 5)] >> (ct & 31u)) & 0xFu) << (4u * a);
+        }
+        const unsigned long long have = __ballot(bits16 != 0);
+        if (bits16) s_st[__builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0u))] = (uint32_t)tid | (bits16 << 8);
+        if (tid == 0) s_nl = (uint32_t)__builtin_popcountll(have);
+      }
+      __syncthreads();
+      n_list = s_nl;
+      if (n_list == 0) continue;
+    }
 
     i32x4 a0[KS8], a1[KS8];
     {
@@ -663,19 +692,23 @@ __global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_ke
     };
 
     i32x4 fa[4];
+    auto step_at = [&](uint32_t li) -> uint32_t { return TILED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_st[li] & 0xFFu)) : li; };
     __syncthreads();
-    stage(super_of(0), 0);
+    stage(super_of(step_at(0)), 0);
     __syncthreads();
     if (stamp) {
       const unsigned long long t = now();
       t_unit += t - t_mark;
       t_mark = t;
     }
-    for (uint32_t step = 0; step < steps; ++step) {
+    for (uint32_t li = 0; li < n_list; ++li) {
+      const uint32_t step = step_at(li);
+      // TILED: the 128-column trips of this stage that the wave's own row tile (two waves each) needs
+      const uint32_t my_trips = TILED ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)(s_st[li] >> 8)) >> (4u * ((uint32_t)wv >> 1))) & 0xFu : 0xFu;
       const uint32_t S = super_of(step);
-      const int pbuf = (int)(step & 1u);
+      const int pbuf = (int)(li & 1u);
       const bool diag = RECT || (p_lo + step) == 0;  // no column side
-      if (step + 1 < steps) stage(super_of(step + 1), pbuf ^ 1);  // (buffer pbuf ^ 1 was let go at the barrier)
+      if (li + 1 < n_list) stage(super_of(step_at(li + 1)), pbuf ^ 1);  // (buffer pbuf ^ 1 was let go at the barrier)
       const uint32_t b_addr = lds_addr(bufB + (size_t)pbuf * kStageVecs) + (uint32_t)lane * 16u;
       const uint32_t t_addr = lds_addr(colthr + pbuf * 512) + (uint32_t)lc * 4u;
       uint32_t bits = 0;  // wave-uniform: blocks of this stage that may hold a pair
@@ -726,20 +759,33 @@ __global__ __launch_bounds__(512, OCC4 ? 4 : 2) void pair_prefilter_i8_narrow_ke
           }
         }
       };
-      lds_read16<frag_off(0)>(fa[0], b_addr);
-      lds_read16<frag_off(1)>(fa[1], b_addr);
-      lds_read16<frag_off(2)>(fa[2], b_addr);
+      if constexpr (!TILED) {
+        lds_read16<frag_off(0)>(fa[0], b_addr);
+        lds_read16<frag_off(1)>(fa[1], b_addr);
+        lds_read16<frag_off(2)>(fa[2], b_addr);
+      }
       v16i32 xa0, xa1, xb0, xb1;
 #pragma nounroll
       for (int trip = 0; trip < 4; ++trip) {
         const uint32_t base = b_addr + (uint32_t)(trip * kTileVecs * 16);
+        if constexpr (TILED) {
+          if (!((my_trips >> trip) & 1u)) continue;
+          lds_read16<frag_off(0)>(fa[0], base);
+          lds_read16<frag_off(1)>(fa[1], base);
+          lds_read16<frag_off(2)>(fa[2], base);
+        }
         static_for<0, 4>([&](auto b_c) {
           constexpr int b = decltype(b_c)::value;
           static_for<0, KS8>([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value;
             constexpr int f = b * KS8 + ks;
+            if constexpr (TILED) {  // the look-ahead ends with the trip: 3, 2, 1, 0 reads behind the fragment waited for
+              if constexpr (f + 3 < 4 * KS8) lds_read16<frag_off(f + 3)>(fa[(f + 3) & 3], base);
+              lds_wait1<(4 * KS8 - 1 - f) < 3 ? (4 * KS8 - 1 - f) : 3>(fa[f & 3]);
+            } else {
             lds_read16<frag_off(f + 3)>(fa[(f + 3) & 3], base);
             lds_wait1<3>(fa[f & 3]);
+            }
             if constexpr (OCC4 || (b & 1) == 0) {
               xa0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[ks], fa[f & 3], ks == 0 ? nth0 : xa0, 0, 0, 0);
               xa1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[ks], fa[f & 3], ks == 0 ? nth1 : xa1, 0, 0, 0);
@@ -975,14 +1021,14 @@ uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count) { return (uint64_t)I
 // largest quantisation error over them is taken); theta: T2 * 512 thresholds by image position (+inf on padding), as join_f16
 // takes them.  mask: prefilter_mask_bytes(n, I_count) bytes, every byte the f16 pass reads is written.  dim <= 128.
 int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, double inv_step2, uint32_t n, uint32_t I_begin,
-                     uint32_t I_count, const float *theta, unsigned char *mask);
+                     uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *tile_mask = nullptr, uint32_t tm_words = 0);
 
 // The pass on a rotated image the caller has (rows wider than 128: rotate_wide.hip): err = its largest quantisation error norm.
 int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
-                         unsigned char *mask) {
+                         unsigned char *mask, const uint32_t *tile_mask, uint32_t tm_words) {
   const double delta8 = (2.0 * err + err * err) * (1.0 + 1e-6) + 1e-4;
   ctx->stats["knn_join_prefilter_rotated"] = 1;
-  return prefilter_launch(ctx, P8, 1, delta8, 127.0 * 127.0, n, I_begin, I_count, theta, mask);
+  return prefilter_launch(ctx, P8, 1, delta8, 127.0 * 127.0, n, I_begin, I_count, theta, mask, tile_mask, tm_words);
 }
 
 // perm: image position -> row of Ph (nullptr: the rows as given).
@@ -1045,7 +1091,7 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
 
 // the pass itself on a finished int8 image of KS8 k steps: s8 >= T  <=>  s8 / inv_step2 >= theta - delta8
 int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, double inv_step2, uint32_t n, uint32_t I_begin,
-                     uint32_t I_count, const float *theta, unsigned char *mask) {
+                     uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *tile_mask, uint32_t tm_words) {
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
   struct { const void *p; } P8{P8v};
   DevBuf<int> thr;
@@ -1081,7 +1127,15 @@ int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, 
 #define AS_PRE_NARROW(K)                                                                                                     \
   case K: {                                                                                                                  \
     const size_t lds_n = (size_t)2 * 4 * K * 4 * 64 * 16 + 2 * 512 * sizeof(int) + 2 * 64 * sizeof(int) + 8192;              \
-    if (!(ctx->opt_debug & 2048)) {  /* (debug bit 2048: the two-set form at one workgroup per CU) */                       \
+    if (tile_mask && K == 1 && !(ctx->opt_debug & 2048)) { /* behind the cone bound on tile pairs (cone_tiles.hip) */      \
+      AS_HIP(ctx, hipMemsetAsync(mask, 0, prefilter_mask_bytes(n, I_count), ctx->stream)); /* (what is not visited) */    \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<1, false, true, true>,                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                              \
+      hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<1, false, true, true>), dim3((unsigned)std::min<uint64_t>(units, 512u)), \
+                         dim3(512), lds_n, ctx->stream, (const i32x4 *)P8.p, (const i32x4 *)nullptr, (const int *)nullptr,   \
+                         T2, I_begin, I_count, W, n, thr.p, thr_min.p, mask, unitc.p, (int)ctx->opt_debug, stamps.p,         \
+                         tile_mask, tm_words);                                                                               \
+    } else if (!(ctx->opt_debug & 2048)) {  /* (debug bit 2048: the two-set form at one workgroup per CU) */                \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_prefilter_i8_narrow_kernel<K, false, true>,                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                              \
       hipLaunchKernelGGL((pair_prefilter_i8_narrow_kernel<K, false, true>), dim3((unsigned)std::min<uint64_t>(units, 512u)), \

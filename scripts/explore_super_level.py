@@ -53,3 +53,22 @@ for G in (512, 128):
         flagged += int((bound >= torch.minimum(tg, tg[I])).sum())
         total += ng
     print("groups of %d rows: %.4f of the group pairs hold a pair at its threshold; a centre + radius bound flags %.4f" % (G, true_any / total, flagged / total), flush=True)
+    # one-sided angular bound: the group's rows sit in a cone of half angle a_I around its mean direction u_I (32 coordinates,
+    # unit vectors), and the EXACT largest product of the other group's rows with u_I is known (an n x groups product, 1 / G of
+    # the pass): cos(i, j) <= cos(max(0, angle(u_I, z_j) - a_I)); both orientations, the smaller bound counts
+    Zu = Zg / Zg.norm(dim=2, keepdim=True).clamp_min(1e-30)
+    u = Zu.mean(dim=1); u = u / u.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    cosa = (Zu * u[:, None, :]).sum(dim=2).clamp(-1, 1).min(dim=1).values        # cos of the cone's half angle
+    aI = torch.acos(cosa)
+    flagged2 = 0; total2 = 0
+    for I in pick.tolist():
+        # M1[J] = max_j z_j . u_I (rows of J against I's direction), M2[J] = max_i z_i . u_J (rows of I against J's direction)
+        M1 = (Zu.view(ng * G, 32) @ u[I]).view(ng, G).max(dim=1).values.clamp(-1, 1)
+        M2 = (Zu[I] @ u.T).max(dim=0).values.clamp(-1, 1)
+        b1 = torch.cos((torch.acos(M1) - aI[I]).clamp_min(0))
+        b2 = torch.cos((torch.acos(M2) - aI).clamp_min(0))
+        bound = torch.minimum(b1, b2)
+        # (the rows are not exactly unit in the 32 coordinates after quantisation; here they are: the bound is on z_i . z_j itself)
+        flagged2 += int((bound >= torch.minimum(tg, tg[I])).sum()); total2 += ng
+    print("    one-sided cone bound (exact far side): flags %.4f; cone half angle: median %.3f rad, 90 %% %.3f" % (
+        flagged2 / total2, float(aI.median()), float(aI.quantile(0.9))), flush=True)
