@@ -145,8 +145,9 @@ __device__ __forceinline__ float max16f(const v16f32 &a) {
 }
 
 // bit1[J * words + g], bit b: can a row of tile J and a row of tile I = 32 g + b reach a threshold, by the cone of I and the
-// exact products of J's rows with I's direction?  One wave per row tile J of [jt_begin, jt_begin + jt_count), sweeping the
-// direction groups [dg_begin, dg_begin + dg_count).
+// exact products of J's rows with I's direction?  One wave per PAIR of row tiles of [jt_begin, jt_begin + jt_count) (the direction
+// fragments serve both), sweeping the direction groups [dg_begin, dg_begin + dg_count); the fragments of the next group are
+// requested before the products of this one.
 __global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img,
                                                        uint32_t jt_begin, uint32_t jt_count, uint32_t dg_begin, uint32_t dg_count,
                                                        uint32_t ntiles, const float *__restrict__ cos_a, const float *__restrict__ sin_a,
@@ -154,70 +155,90 @@ __global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__
                                                        uint32_t words, uint32_t *__restrict__ bit1) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t wid = blockIdx.x * 4u + (uint32_t)wv;
-  if (wid >= jt_count) return;
-  const uint32_t J = jt_begin + wid;
+  if (2u * wid >= jt_count) return;
+  const uint32_t J0 = jt_begin + 2u * wid;
+  const bool two = 2u * wid + 1u < jt_count;
+  const uint32_t J1 = two ? J0 + 1u : J0;
   const int lc = lane & 31;
-  f16x8 a[4][2];
+  f16x8 a[2][4][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a[s][ks] = rows_img[(((size_t)J * 2 + ks) * 4 + s) * 64 + lane];
-  const float thJ = theta_min[J];
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[q][s][ks] = rows_img[(((size_t)(q ? J1 : J0) * 2 + ks) * 4 + s) * 64 + lane];
+  const float thJ[2] = {theta_min[J0], theta_min[J1]};
   const float nmax = __uint_as_float(*nmax_bits);
   const float inv_n2 = nmax > 0.f ? 1.f / (nmax * nmax) : 1.f;
   v16f32 zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-  for (uint32_t g = dg_begin; g < dg_begin + dg_count; ++g) {
-    const f16x8 b0 = dirs_img[(((size_t)(g >> 2) * 2 + 0) * 4 + (g & 3u)) * 64 + lane];
-    const f16x8 b1 = dirs_img[(((size_t)(g >> 2) * 2 + 1) * 4 + (g & 3u)) * 64 + lane];
-    float m = -__builtin_inff();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      v16f32 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b0, zero, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b1, acc, 0, 0, 0);
-      m = __builtin_fmaxf(m, max16f(acc));
-    }
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+  auto dir_frag = [&](uint32_t g, int ks) -> f16x8 { return dirs_img[(((size_t)(g >> 2) * 2 + ks) * 4 + (g & 3u)) * 64 + lane]; };
+  const uint32_t g_end = dg_begin + dg_count;
+  if (dg_count == 0) return;
+  f16x8 b0 = dir_frag(dg_begin, 0), b1 = dir_frag(dg_begin, 1);
+  for (uint32_t g = dg_begin; g < g_end; ++g) {
+    const uint32_t gn = g + 1 < g_end ? g + 1 : g;
+    const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
     const uint32_t I = g * 32u + (uint32_t)lc;
-    bool flag = false;
-    if (I < ntiles) {
-      const float t = __builtin_fminf(theta_min[I], thJ);
-      if (t < __builtin_inff()) {
+    const bool in = I < ntiles;
+    const float thI = in ? theta_min[I] : __builtin_inff(), ca = in ? cos_a[I] : 1.f, sa = in ? sin_a[I] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        v16f32 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][s][0], b0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][s][1], b1, acc, 0, 0, 0);
+        m = __builtin_fmaxf(m, max16f(acc));
+      }
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+      bool flag = false;
+      const float t = __builtin_fminf(thI, thJ[q]);
+      if (in && t < __builtin_inff()) {
         const float tpp = (t - kEpsTheta) * inv_n2;
         if (t <= 1e-3f) {
           flag = true;  // (thresholds at or below zero: rows of norm zero count, no bound on directions says anything)
         } else if (tpp <= 1.f) {
-          const float ca = cos_a[I], sa = sin_a[I];
           if (tpp <= -ca) flag = true;  // the cone and the threshold's angle together span the half circle
           else flag = m + kEpsM >= ca * tpp - sa * __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - tpp * tpp)) - 1e-5f;
         }
       }
+      const unsigned long long bal = __ballot(flag && lane < 32);
+      if (lane == 0 && (q == 0 || two)) bit1[(size_t)(q ? J1 : J0) * words + g] = (uint32_t)bal;
     }
-    const unsigned long long bal = __ballot(flag && lane < 32);
-    if (lane == 0) bit1[(size_t)J * words + g] = (uint32_t)bal;
+    b0 = n0;
+    b1 = n1;
   }
 }
 
-// tile_mask[(I - it_begin) * words + w], bit b: the pair (I, J = 32 w + b) is kept iff both orientations keep it
-__global__ void cone_and_kernel(const uint32_t *__restrict__ bit1, uint32_t it_begin, uint32_t it_count, uint32_t ntiles, uint32_t words,
-                                uint32_t *__restrict__ tile_mask, unsigned long long *__restrict__ kept) {
-  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// tile_mask[(I - it_begin) * words + w], bit b: the pair (I, J = 32 w + b) is kept iff both orientations keep it:
+// bit1[I][w] bit b AND bit1[J][I / 32] bit I % 32 -- the second is a 32 x 32 bit transpose: a wave takes the block (rows 32 w ..
+// 32 w + 31 of bit1, word ig), lane l its row's word, and ballot c of "bit c of my word" is the transposed word of I = 32 ig + c.
+__global__ __launch_bounds__(256) void cone_and_kernel(const uint32_t *__restrict__ bit1, uint32_t it_begin, uint32_t it_count, uint32_t ntiles,
+                                                       uint32_t words, uint32_t ig_begin, uint32_t ig_count, uint32_t *__restrict__ tile_mask,
+                                                       unsigned long long *__restrict__ kept) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (uint64_t)ig_count * words) return;
+  const uint32_t ig = ig_begin + (uint32_t)(wid / words), w = (uint32_t)(wid % words);
+  const uint32_t J = 32u * w + (uint32_t)lane;
+  const uint32_t x = (lane < 32 && J < ntiles) ? bit1[(size_t)J * words + ig] : 0u;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const uint32_t t = (uint32_t)__ballot((x >> c) & 1u);
+    mine = lane == c ? t : mine;
+  }
+  const uint32_t I = 32u * ig + (uint32_t)lane;
   uint32_t out = 0;
-  if (e < (uint64_t)it_count * words) {
-    const uint32_t ii = (uint32_t)(e / words), w = (uint32_t)(e % words), I = it_begin + ii;
-    const uint32_t a = bit1[(size_t)I * words + w];
-    uint32_t b = 0;
-    for (uint32_t bb = 0; bb < 32; ++bb) {
-      const uint32_t J = 32u * w + bb;
-      if (J < ntiles) b |= ((bit1[(size_t)J * words + (I >> 5)] >> (I & 31u)) & 1u) << bb;
-    }
-    out = a & b;
-    tile_mask[e] = out;
+  if (lane < 32 && I >= it_begin && I < it_begin + it_count) {
+    out = bit1[(size_t)I * words + w] & mine;
+    tile_mask[(size_t)(I - it_begin) * words + w] = out;
   }
   uint32_t c = (uint32_t)__builtin_popcount(out);
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept, (unsigned long long)c);
+  if (lane == 0 && c) atomicAdd(kept + (blockIdx.x & 255u), (unsigned long long)c);  // (256 counters: one word takes ~90 adds per microsecond)
 }
 
 }  // namespace
@@ -245,41 +266,44 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   AS_TRY(tmin.alloc(ctx, ntiles));
   AS_TRY(nmax.alloc(ctx, 1));
   AS_TRY(bit1.alloc(ctx, (size_t)ntiles * words));
-  AS_TRY(kept.alloc(ctx, 1));
+  AS_TRY(kept.alloc(ctx, 256));
   AS_HIP(ctx, hipMemsetAsync(dirs_img.p, 0, (size_t)dir_tiles * 2 * 4 * 64 * 16, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(nmax.p, 0, sizeof(unsigned int), ctx->stream));
-  AS_HIP(ctx, hipMemsetAsync(kept.p, 0, sizeof(unsigned long long), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(cone_tile_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, Z, perm, n, theta, (f16x8 *)rows_img.p, (f16x8 *)dirs_img.p, ca.p,
                      sa.p, tmin.p, nmax.p);
   const uint32_t all_groups = words;
   if (it_begin == 0 && it_count == ntiles) {
-    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
+    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, 0u, all_groups, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                        (const unsigned int *)nmax.p, words, bit1.p);
   } else if (it_count) {
     // a range of row tiles (a rank of a sharded build): its rows against every direction, and every tile's rows against its directions
     AS_HIP(ctx, hipMemsetAsync(bit1.p, 0, sizeof(uint32_t) * (size_t)ntiles * words, ctx->stream));
     const uint32_t g0 = it_begin / 32u, g1 = (it_begin + it_count + 31u) / 32u;
-    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
+    hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, g0, g1 - g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                        (const unsigned int *)nmax.p, words, bit1.p);
     // (the rows of the range against the directions outside it; the groups [g0, g1) were written above, by the same rule)
     if (g0 > 0)
-      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, 0u, g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                          (const unsigned int *)nmax.p, words, bit1.p);
     if (g1 < all_groups)
-      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, g1, all_groups - g1, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                          (const unsigned int *)nmax.p, words, bit1.p);
   }
-  if (it_count)
-    hipLaunchKernelGGL(cone_and_kernel, dim3(cdiv((uint64_t)it_count * words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)bit1.p, it_begin,
-                       it_count, ntiles, words, tile_mask, kept.p);
+  if (it_count) {
+    const uint32_t ig0 = it_begin / 32u, ig1 = (it_begin + it_count + 31u) / 32u;
+    hipLaunchKernelGGL(cone_and_kernel, dim3(cdiv((uint64_t)(ig1 - ig0) * words, 4)), dim3(256), 0, ctx->stream, (const uint32_t *)bit1.p, it_begin,
+                       it_count, ntiles, words, ig0, ig1 - ig0, tile_mask, kept.p);
+  }
   AS_HIP(ctx, hipGetLastError());
-  unsigned long long h = 0;
-  AS_HIP(ctx, copy_d2h(ctx, &h, kept.p, sizeof(h)));
+  unsigned long long hk[256], h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, hk, kept.p, sizeof(hk)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (unsigned long long v : hk) h += v;
   const double share = it_count ? (double)h / ((double)it_count * (double)ntiles) : 0.0;
   ctx->stats["knn_join_cone_tiles_kept_e6"] = (int64_t)(share * 1e6);
   if (kept_share) *kept_share = share;
