@@ -276,7 +276,7 @@ def main():
                                       "knn_uncertified_rows_stage1a", "knn_join_delta_e9", "search_uncertified_rows", "search_scan",
                                       "knn_mfma_join_bf16_blocks_full", "knn_join_prefilter", "knn_join_prefilter_rotated",
                                       "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged", "knn_rerank_scored",
-                                      "knn_join_row_order", "knn_join_theta_grouped")}
+                                      "knn_join_row_order", "knn_join_theta_grouped", "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6")}
 
     # ---- untimed extra legs (rank 0, one GPU): small-batch search, host-resident inputs --------------------------------
     extra = {}
@@ -401,7 +401,7 @@ def main():
                     "data": "rank-64 / 4096-cluster Gaussian mixture (seed 43), same n, d and graph parameters; item graph only "
                             "(the lambda pass adds 0.4 ms)",
                     "path": {k: ctx.stat(k) for k in ("knn_join", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
-                                                      "knn_join_theta_grouped", "knn_join_prefilter_tail_e6", "knn_uncertified_rows",
+                                                      "knn_join_theta_grouped", "knn_join_prefilter_tail_e6", "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6", "knn_uncertified_rows",
                                                       "knn_uncertified_rows_stage1a")}}
             if ctx.stat("knn_join_prefilter") == 1:
                 hard["path"]["blocks_passed_on_frac"] = ctx.stat("knn_join_prefilter_blocks_flagged") * 2.0 / max(1, ctx.stat("knn_join_prefilter_blocks"))
@@ -495,9 +495,20 @@ def main():
             if stats.get("knn_join_prefilter", 0) == 1:
                 rotated = stats.get("knn_join_prefilter_rotated", 0) == 1
                 k8 = 32 if rotated else (d + 31) // 32 * 32
+                cone = stats.get("knn_join_cone_tiles", 0) == 1
+                if prof.get("knn_join_cone_tiles", (0.0, 0))[1]:
+                    nt = (n + 127) // 128
+                    add("knn_join_cone_tiles",
+                        "cone_max_kernel (+ cone_tile_kernel, cone_and_kernel: v_mfma_f32_32x32x16_f16, the rows of every 128-position tile "
+                        "against the mean direction of every tile; a bit per pair of tiles that can hold a pair of rows at a threshold)",
+                        "mfma", 2.0 * n * nt * 32, MFMA16_PEAK_TFLOPS, "TFLOP/s",
+                        "f16 MFMA flops executed (n rows x n/128 directions x 32 coordinates)",
+                        {"tile_pairs_kept_frac": stats.get("knn_join_cone_tiles_kept_e6", 0) * 1e-6, "first_pass_behind_it": bool(cone)})
                 add("knn_join_prefilter",
-                    "pair_prefilter_i8%s_kernel (v_mfma_i32_32x32x32_i8 over every unordered pair of 512-row super tiles on %s; "
+                    "pair_prefilter_i8%s_kernel (v_mfma_i32_32x32x32_i8 over %s on %s; "
                     "a bit per 64 x 32 block that can hold a pair)" % ("_narrow" if k8 <= 64 else "",
+                                                                          "the pairs of 128-position tiles the cone bound keeps" if cone
+                                                                          else "every unordered pair of 512-row super tiles",
                                                                           "the rotated 32-wide int8 image (31 directions + tail norm)"
                                                                           if rotated else "the full-width int8 image of the unit rows"),
                     "mfma", 2.0 * 32 * 32 * k8 * stats["knn_join_prefilter_blocks"], INT8_PEAK_TOPS, "TFLOP/s",
@@ -547,11 +558,11 @@ def main():
         roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
         reference_equivalent = None
         if stats["knn_join"] == 1:
-            join_ms = sum(e["avg_launch_ms"] for e in kernels if e["profile_group"] in ("knn_join_prefilter",) + tuple(names.values()))
+            join_ms = sum(e["avg_launch_ms"] for e in kernels if e["profile_group"] in ("knn_join_prefilter", "knn_join_cone_tiles") + tuple(names.values()))
             if join_ms > 0:
                 reference_equivalent = {
                     "what": "SURVEY.md 8(d) prices the neighbour search at the reference's all-pairs loop, 2 n^2 d flop; the launches that "
-                            "replace it (first pass + f16 pass) take join_ms. This is how much of that loop is never executed, NOT a "
+                            "replace it (cone bound on tile pairs + int8 first pass + f16 pass) take join_ms. This is how much of that loop is never executed, NOT a "
                             "utilisation: no frac is derived from it",
                     "algorithmic_flops": flops_alg, "join_ms": join_ms, "equivalent_TFLOPs": flops_alg / (join_ms * 1e-3) / 1e12}
         lam_ms, lam_n = prof.get("taumode_lambda", (0.0, 0))

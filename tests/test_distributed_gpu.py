@@ -415,7 +415,8 @@ def test_library_sharded_build_multi_rank_rccl(tmp_path, n):
 
 # ---- the sharded build with the one-GPU algorithm: row order + int8 first pass + masked f16 pass, sharded by image positions ----
 _POS_STATS = ("sharded_join", "sharded_by_positions", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order",
-              "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows", "sharded_rows_late", "sharded_prepare_by_rows")
+              "sharded_listed_slots", "sharded_foreign_slots", "knn_uncertified_rows", "sharded_rows_late", "sharded_prepare_by_rows",
+              "knn_join_cone_tiles")
 
 
 def _lib_positions_worker(rank, world, port, n, d, topk, own_rows, out_dir):
@@ -431,6 +432,7 @@ def _lib_positions_worker(rank, world, port, n, d, topk, own_rows, out_dir):
         ctx._stream = torch.cuda.current_stream().cuda_stream
         comm = D.LibComm.torch_transport(ctx)
         ctx.set_option("sharded_own_rows", own_rows)
+        ctx.set_option("join_cone_tiles_max_e3", 1000)   # (the tiled first pass whatever share of the tile pairs the bound keeps on this data)
         lo, hi = comm.shard_range(n)
         X, _ = synth.mixture(n, d, seed=29, n_clusters=96, rank=6)
         X[n // 3] = X[5]            # duplicates across shards: ties by row id must survive the trip through image positions
@@ -480,5 +482,7 @@ def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk, o
         assert st["sharded_join"] == 1 and st["sharded_by_positions"] == 1, st
         late = own_rows if d <= 128 else 0   # (rows wider than 128: the f64 rows first; their first pass runs on the rank's own positions)
         assert st["sharded_rows_late"] == late and st["sharded_prepare_by_rows"] == late, st
+        if d <= 128:   # the cone bound on tile pairs in front of the first pass, on the rank's own range of row tiles
+            assert st["knn_join_cone_tiles"] == 1, st
         assert st["knn_join_prefilter"] == 1 and st["knn_join_row_order"] == 1, st
         assert st["sharded_foreign_slots"] * 2 < st["sharded_listed_slots"], st   # most partners of a position live on its own rank

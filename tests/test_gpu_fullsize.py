@@ -200,15 +200,21 @@ def test_config2_1M_x_128_build_and_10k_query_search(ctx):
     # bench line times is the path this test checks
     assert ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_prefilter_rotated") == 1
     assert ctx.stat("knn_join_row_order") == 1 and ctx.stat("knn_join_theta_grouped") == 1
-    # the WHOLE table against two independent forms of the join (src/laplacian.rs:211-252 is what all of them replace):
-    # the plain dense f16 join (no row order used by a first pass, no mask), and the join on the f32 pipe (another
-    # contraction, another rounding bound, no f16 image at all)
-    for opt, val, restore in (("join_prefilter", 0, 1), ("join_pipe", 32, 16)):
+    # ... and the first pass itself behind the cone bound on pairs of 128-position tiles (round 4, cone_tiles.hip): taken, and it
+    # rules most of the tile pairs out on this data
+    assert ctx.stat("knn_join_cone_tiles") == 1 and 0 < ctx.stat("knn_join_cone_tiles_kept_e6") < 200_000
+    # the WHOLE table against three independent forms of the join (src/laplacian.rs:211-252 is what all of them replace):
+    # the first pass sweeping every tile pair (no cone bound), the plain dense f16 join (no row order used by a first pass, no
+    # mask), and the join on the f32 pipe (another contraction, another rounding bound, no f16 image at all)
+    for opt, val, restore in (("join_cone_tiles", 0, 1), ("join_prefilter", 0, 1), ("join_pipe", 32, 16)):
         ctx.set_option(opt, val)
         try:
             idx2, dst2 = knn_device(ctx, Xd, gp)
             assert ctx.stat("knn_join") == 1
-            assert ctx.stat("knn_join_prefilter") == 0 and ctx.stat("knn_join_pipe") == (32 if opt == "join_pipe" else 16)
+            if opt == "join_cone_tiles":
+                assert ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_cone_tiles") == 0
+            else:
+                assert ctx.stat("knn_join_prefilter") == 0 and ctx.stat("knn_join_pipe") == (32 if opt == "join_pipe" else 16)
         finally:
             ctx.set_option(opt, restore)
         assert torch.equal(idx, idx2) and torch.equal(dst, dst2), opt
