@@ -148,7 +148,7 @@ __device__ __forceinline__ float max16f(const v16f32 &a) {
 // exact products of J's rows with I's direction?  One wave per PAIR of row tiles of [jt_begin, jt_begin + jt_count) (the direction
 // fragments serve both), sweeping the direction groups [dg_begin, dg_begin + dg_count); the fragments of the next group are
 // requested before the products of this one.
-__global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img,
+__global__ __launch_bounds__(256, 4) void cone_max_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img,
                                                        uint32_t jt_begin, uint32_t jt_count, uint32_t dg_begin, uint32_t dg_count,
                                                        uint32_t ntiles, const float *__restrict__ cos_a, const float *__restrict__ sin_a,
                                                        const float *__restrict__ theta_min, const unsigned int *__restrict__ nmax_bits,
@@ -176,13 +176,24 @@ __global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__
   auto dir_frag = [&](uint32_t g, int ks) -> f16x8 { return dirs_img[(((size_t)(g >> 2) * 2 + ks) * 4 + (g & 3u)) * 64 + lane]; };
   const uint32_t g_end = dg_begin + dg_count;
   if (dg_count == 0) return;
+  // (the cone of direction 32 g + lane is requested a group ahead, with the fragments: a load in the loop that is used in the
+  // same trip makes the compiler wait for everything requested before it -- the prefetched fragments too)
+  auto dir_cone = [&](uint32_t g, float &th, float &c, float &sn) {
+    const uint32_t I = min(g * 32u + (uint32_t)lc, ntiles - 1u);
+    th = theta_min[I];
+    c = cos_a[I];
+    sn = sin_a[I];
+  };
   f16x8 b0 = dir_frag(dg_begin, 0), b1 = dir_frag(dg_begin, 1);
+  float thI, ca, sa;
+  dir_cone(dg_begin, thI, ca, sa);
   for (uint32_t g = dg_begin; g < g_end; ++g) {
     const uint32_t gn = g + 1 < g_end ? g + 1 : g;
     const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
+    float thN, caN, saN;
+    dir_cone(gn, thN, caN, saN);
     const uint32_t I = g * 32u + (uint32_t)lc;
     const bool in = I < ntiles;
-    const float thI = in ? theta_min[I] : __builtin_inff(), ca = in ? cos_a[I] : 1.f, sa = in ? sin_a[I] : 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float m = -__builtin_inff();
@@ -209,6 +220,9 @@ __global__ __launch_bounds__(256) void cone_max_kernel(const f16x8 *__restrict__
     }
     b0 = n0;
     b1 = n1;
+    thI = thN;
+    ca = caN;
+    sa = saN;
   }
 }
 

@@ -1028,7 +1028,18 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
           ProfScope ps(ctx, "knn_join_prefilter_pack");
           AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
         }
-        AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p));
+        // (behind the same cone bound on tile pairs as the narrow rows' pass)
+        DevBuf<uint32_t> tile_mask;
+        const uint32_t tm_words = cone_tile_words(n);
+        bool tiled = ctx->opt_join_cone_tiles != 0 && (perm || image_perm) && n >= 65536 && !(ctx->opt_debug & 2048);
+        if (tiled) {
+          double kept = 1.0;
+          AS_TRY(tile_mask.alloc(ctx, (size_t)(I_end - I_begin) * 4 * tm_words));
+          AS_TRY(cone_tile_mask(ctx, rot_z, image_perm ? image_perm : perm, n, theta.p, I_begin * 512u, (I_end - I_begin) * 512u, tile_mask.p, &kept));
+          tiled = kept <= (double)ctx->opt_join_cone_tiles_max_e3 * 1e-3;
+        }
+        ctx->stats["knn_join_cone_tiles"] = tiled ? 1 : 0;
+        AS_TRY(prefilter_i8_rotated(ctx, P8.p, err, n, I_begin, I_end - I_begin, theta.p, mask.p, tiled ? tile_mask.p : nullptr, tm_words));
       }
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
       AS_TRY(join_f16_wide(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, "knn_mfma_join_f16", perm,
