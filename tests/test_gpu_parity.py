@@ -398,6 +398,39 @@ def test_item_graph_join_lists_by_group(ctx, join_on, n, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,topk", [(70000, 128, 16), (66001, 64, 40), (131072 + 300, 128, 5), (70144, 256, 16)])
+def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
+    """"join_cone_tiles" (round 4, cone_tiles.hip): the int8 first pass sweeps only the pairs of 128-position tiles a one-sided cone
+    bound keeps.  The bound is rigorous, so the first pass behind it must find what it found sweeping everything -- the same
+    blocks up to the few int8 false positives that lay in tile pairs the bound rules out -- the lists must leave the same rows
+    open, and the tables are the same and the oracle's.  Ragged tiles, an odd and an even count of super tiles, duplicates, a
+    zero row, rows wider than 128 (their first pass runs on the same kernel)."""
+    X, _ = synth.mixture(n, d, seed=31, n_clusters=48, rank=5)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25)
+    ctx.set_option("join_cone_tiles_max_e3", 1000)   # (taken whatever share of the tile pairs the bound keeps)
+    try:
+        ctx.set_option("join_cone_tiles", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_cone_tiles") == 0
+        flagged0, open0, cand0 = ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")
+        ctx.set_option("join_cone_tiles", 1)
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_cone_tiles") == 1 and 0 < ctx.stat("knn_join_cone_tiles_kept_e6") <= 1_000_000
+        flagged1, open1, cand1 = ctx.stat("knn_join_prefilter_blocks_flagged"), ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")
+    finally:
+        ctx.set_option("join_cone_tiles", 1)
+        ctx.set_option("join_cone_tiles_max_e3", 600)
+    assert flagged1 <= flagged0 and flagged0 - flagged1 <= max(8, flagged0 // 500), (flagged0, flagged1)
+    assert open1 <= open0 + max(2, open0 // 100) and abs(cand1 - cand0) <= max(16, cand0 // 1000), (open0, open1, cand0, cand1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(n, size=128, replace=False))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 def _stress_case(seed, index):
     """Case `index` of scripts/stress_first_pass.py for `seed` (the same draws in the same order)."""
     rng = np.random.default_rng(seed)
