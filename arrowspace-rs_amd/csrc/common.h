@@ -84,6 +84,7 @@ struct as_ctx {
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_join_cone_tiles = 1;       // rotated first pass on an ordered image: behind a cone bound on pairs of 128-position tiles (cone_tiles.hip)
   int64_t opt_join_cone_tiles_max_e3 = 600;  // ... taken while it keeps at most this share (x 1e-3) of the tile pairs; beyond, the pass sweeps everything
+  int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
   int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
                                          // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
   int64_t opt_rerank_grid = 0;           // scoring kernel of the re-rank: workgroups launched (0: the default)
@@ -492,10 +493,20 @@ int apply_self_in_results(as_ctx *ctx, const double *rows, const double *norms, 
 // The join on an image in the library's own row order, prepared (own_join_prepare, mfma_drivers.hip): what the contraction
 // of the tile pairs and every stage behind it need.  One per build; a build sharded by image positions (sharded.hip) prepares
 // the same object on every rank.
+// What the cone bound on tile pairs (cone_tiles.hip) keeps of the image's tiles for later one-sided uses (the second pass): the mean
+// direction of every 128-position tile as an MFMA operand, the cosine and sine of its cone's half angle, the largest norm of a row.
+struct ConeDirs {
+  DevBuf<unsigned char> dirs_img;
+  DevBuf<float> cos_a, sin_a;
+  DevBuf<unsigned int> nmax;
+  uint32_t ntiles = 0;
+  bool valid = false;
+};
 struct OwnJoin {
   DevBuf<unsigned char> P16own, Phown;                        // split-bf16 / f16 image of all rows (Phown in the order `perm`)
   DevBuf<unsigned char> Prow;                                 // sharded by rows with an order: the f16 image of all rows in ROW order (the all-gathered one)
   bool sharded_rows = false;                                  // the preparation ran on the ranks' own rows (ShardedRows below)
+  ConeDirs cone;                                              // the tiles' cones, when the first pass ran behind the cone bound
   DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos; // thresholds (and the looser second ones) by row / by image position
   DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
@@ -529,6 +540,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
                      uint32_t pos_begin = 0, uint32_t pos_count = 0, const ShardedRows *sr = nullptr);
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
                    OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io = nullptr);
+uint32_t cone_tile_words(uint32_t n);
+int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin, uint32_t pos_count,
+                   uint32_t *tile_mask, double *kept_share, ConeDirs *keep = nullptr);
+int cone_rect_mask(as_ctx *ctx, const double *Z, const uint32_t *ids, uint32_t nf, const float *theta_a, uint32_t pad, const ConeDirs &cone,
+                   uint32_t n, unsigned char *mask, double *kept_share);
 
 struct JoinSources {
   const float *packed;    // f32 image of all rows if the caller has one (else nullptr)
@@ -563,7 +579,7 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
                    const uint32_t *perm = nullptr,         // image position -> row when packedh is packed in a permuted order
                    const uint32_t *image_perm = nullptr,   // ... when it is, but the lists are to be kept by image position
                    const double *rot_z = nullptr,          // rows wider than 128: their rotated coordinates (n x 32), for the first pass
-                   bool *grouped_io = nullptr);            // in: lists per group of 32 positions are welcome; out: that is what was written
+                   bool *grouped_io = nullptr, ConeDirs *cone_keep = nullptr);            // in: lists per group of 32 positions are welcome; out: that is what was written
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

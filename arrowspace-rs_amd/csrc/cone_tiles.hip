@@ -263,14 +263,20 @@ uint32_t cone_tile_words(uint32_t n) { return (((n + 127u) / 128u) + 31u) / 32u;
 // 128-position tiles (I, J) may hold a pair of rows at a threshold.  Z: n x 32 rotated coordinates by ROW, perm: position -> row
 // (or null), theta: thresholds by position padded to whole 512-position super tiles (+inf beyond n).  pos_begin a multiple of 512.
 int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin,
-                   uint32_t pos_count, uint32_t *tile_mask, double *kept_share) {
+                   uint32_t pos_count, uint32_t *tile_mask, double *kept_share, ConeDirs *keep) {
   const uint32_t ntiles = (n + 127u) / 128u, words = cone_tile_words(n);
   const uint32_t dir_tiles = (ntiles + 127u) / 128u;  // image tiles of the direction image
   const uint32_t it_begin = pos_begin / 128u, it_count = std::min(ntiles - std::min(ntiles, it_begin), (pos_count + 127u) / 128u);
   ProfScope ps(ctx, "knn_join_cone_tiles");
-  DevBuf<unsigned char> rows_img, dirs_img;
-  DevBuf<float> ca, sa, tmin;
-  DevBuf<unsigned int> nmax;
+  // (keep: the directions, the cones and the largest norm stay with the caller, for the one-sided bound of the second pass)
+  ConeDirs local;
+  ConeDirs &cd = keep ? *keep : local;
+  cd.valid = false;
+  DevBuf<unsigned char> rows_img;
+  DevBuf<unsigned char> &dirs_img = cd.dirs_img;
+  DevBuf<float> &ca = cd.cos_a, &sa = cd.sin_a;
+  DevBuf<float> tmin;
+  DevBuf<unsigned int> &nmax = cd.nmax;
   DevBuf<uint32_t> bit1;
   DevBuf<unsigned long long> kept;
   AS_TRY(rows_img.alloc(ctx, (size_t)ntiles * 2 * 4 * 64 * 16));
@@ -320,6 +326,148 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   for (unsigned long long v : hk) h += v;
   const double share = it_count ? (double)h / ((double)it_count * (double)ntiles) : 0.0;
   ctx->stats["knn_join_cone_tiles_kept_e6"] = (int64_t)(share * 1e6);
+  if (kept_share) *kept_share = share;
+  cd.ntiles = ntiles;
+  cd.valid = true;
+  return AS_OK;
+}
+
+// ---- one-sided: gathered rows against the tiles of the image (the second pass of the join) --------------------------------------
+// The rows `ids` (nf of them, any rows; theta_a: their thresholds by place in the list, +inf beyond nf, `pad` entries: whole 512-row
+// super tiles) are swept against ALL rows by the one-sided form of the f16 kernel, 64 of them per wave.  For a wave's 64 rows and a
+// column tile J with direction u_J and cone a_J:  cos(i, j) <= |z_i||z_j| cos(max(0, acos(max_i z_i / |z_i| . u_J) - a_J)): when
+// that stays below the smallest threshold of the 64 rows, the wave has nothing to list in J's 128 columns.  mask: what the kernel
+// reads (mfma_join_f16.hip, MODE 1, MASKED): a byte per (super tile of 512 listed rows, stage of 256 columns, wave), a bit per
+// 32-column block -- here a nibble per tile.  It pays when the listed rows are in the order of the image (neighbours in a wave).
+namespace {
+__global__ __launch_bounds__(256, 4) void cone_rect_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img, uint32_t gt_count,
+                                                           uint32_t ntiles, uint32_t words, const float *__restrict__ cos_a,
+                                                           const float *__restrict__ sin_a, const float *__restrict__ theta_a,
+                                                           const unsigned int *__restrict__ nmax_a, const unsigned int *__restrict__ nmax_b,
+                                                           uint32_t *__restrict__ bits) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t g = blockIdx.x * 4u + (uint32_t)wv;
+  if (g >= gt_count) return;
+  const int lc = lane & 31;
+  f16x8 a[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[s][ks] = rows_img[(((size_t)g * 2 + ks) * 4 + s) * 64 + lane];
+  float th[2];  // the smallest threshold of each half of the tile (64 rows = a wave of the f16 kernel)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float t = theta_a[(size_t)g * 128 + 64 * h + lane];
+    t = t < __builtin_inff() ? t : __builtin_inff();
+    for (int o = 32; o > 0; o >>= 1) t = __builtin_fminf(t, __shfl_xor(t, o, 64));
+    th[h] = t;
+  }
+  const float nmax = __builtin_fmaxf(__uint_as_float(*nmax_a), __uint_as_float(*nmax_b));
+  const float inv_n2 = nmax > 0.f ? 1.f / (nmax * nmax) : 1.f;
+  v16f32 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  auto dir_frag = [&](uint32_t gq, int ks) -> f16x8 { return dirs_img[(((size_t)(gq >> 2) * 2 + ks) * 4 + (gq & 3u)) * 64 + lane]; };
+  auto dir_cone = [&](uint32_t gq, float &c, float &sn) {
+    const uint32_t J = min(gq * 32u + (uint32_t)lc, ntiles - 1u);
+    c = cos_a[J];
+    sn = sin_a[J];
+  };
+  f16x8 b0 = dir_frag(0, 0), b1 = dir_frag(0, 1);
+  float ca, sa;
+  dir_cone(0, ca, sa);
+  for (uint32_t gq = 0; gq < words; ++gq) {
+    const uint32_t gn = gq + 1 < words ? gq + 1 : gq;
+    const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
+    float caN, saN;
+    dir_cone(gn, caN, saN);
+    const bool in = gq * 32u + (uint32_t)lc < ntiles;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int s = 2 * h; s < 2 * h + 2; ++s) {
+        v16f32 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b1, acc, 0, 0, 0);
+        m = __builtin_fmaxf(m, max16f(acc));
+      }
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+      bool flag = false;
+      const float t = th[h];
+      if (in && t < __builtin_inff()) {
+        const float tpp = (t - kEpsTheta) * inv_n2;
+        if (t <= 1e-3f) flag = true;
+        else if (tpp <= 1.f) {
+          if (tpp <= -ca) flag = true;
+          else flag = m + kEpsM >= ca * tpp - sa * __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - tpp * tpp)) - 1e-5f;
+        }
+      }
+      const unsigned long long bal = __ballot(flag && lane < 32);
+      if (lane == 0) bits[((size_t)2 * g + h) * words + gq] = (uint32_t)bal;
+    }
+    b0 = n0;
+    b1 = n1;
+    ca = caN;
+    sa = saN;
+  }
+}
+
+// the byte mask of the one-sided f16 kernel from the bits per (64 listed rows, column tile)
+__global__ void cone_rect_expand_kernel(const uint32_t *__restrict__ bits, uint32_t halves, uint32_t ntiles, uint32_t words, uint32_t a_supers,
+                                        uint32_t stages, unsigned char *__restrict__ mask, unsigned long long *__restrict__ kept) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  if (e < (uint64_t)a_supers * stages * 8) {
+    const uint32_t w = (uint32_t)(e & 7u), st = (uint32_t)((e >> 3) % stages), Ia = (uint32_t)((e >> 3) / stages);
+    const uint32_t hh = 8u * Ia + w;
+    unsigned char b = 0;
+    if (hh < halves) {
+      const uint32_t J0 = 2u * st, J1 = J0 + 1u;
+      if (J0 < ntiles && ((bits[(size_t)hh * words + (J0 >> 5)] >> (J0 & 31u)) & 1u)) b |= 0x0F, ++c;
+      if (J1 < ntiles && ((bits[(size_t)hh * words + (J1 >> 5)] >> (J1 & 31u)) & 1u)) b |= 0xF0, ++c;
+    }
+    mask[e] = b;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept + (blockIdx.x & 255u), (unsigned long long)c);
+}
+}  // namespace
+
+int cone_rect_mask(as_ctx *ctx, const double *Z, const uint32_t *ids, uint32_t nf, const float *theta_a, uint32_t pad, const ConeDirs &cone,
+                   uint32_t n, unsigned char *mask, double *kept_share) {
+  if (!cone.valid || cone.ntiles != (n + 127u) / 128u) return fail(ctx, AS_ERR_ARG, "cone bound of the second pass: no cones of this image");
+  const uint32_t ntiles = cone.ntiles, words = cone_tile_words(n);
+  const uint32_t gt = (nf + 127u) / 128u, a_supers = pad / 512u, stages = 2u * ((n + 511u) / 512u);
+  ProfScope ps(ctx, "knn_join_cone_second");
+  DevBuf<unsigned char> rows_img, dirs_g;
+  DevBuf<float> ca_g, sa_g, tmin_g;
+  DevBuf<unsigned int> nmax_g;
+  DevBuf<uint32_t> bits;
+  DevBuf<unsigned long long> kept;
+  AS_TRY(rows_img.alloc(ctx, (size_t)gt * 2 * 4 * 64 * 16));
+  AS_TRY(dirs_g.alloc(ctx, (size_t)((gt + 127u) / 128u) * 2 * 4 * 64 * 16));
+  AS_TRY(ca_g.alloc(ctx, gt));
+  AS_TRY(sa_g.alloc(ctx, gt));
+  AS_TRY(tmin_g.alloc(ctx, gt));
+  AS_TRY(nmax_g.alloc(ctx, 1));
+  AS_TRY(bits.alloc(ctx, (size_t)2 * gt * words));
+  AS_TRY(kept.alloc(ctx, 256));
+  AS_HIP(ctx, hipMemsetAsync(nmax_g.p, 0, sizeof(unsigned int), ctx->stream));
+  AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(cone_tile_kernel, dim3(gt), dim3(128), 0, ctx->stream, Z, ids, nf, theta_a, (f16x8 *)rows_img.p, (f16x8 *)dirs_g.p, ca_g.p,
+                     sa_g.p, tmin_g.p, nmax_g.p);
+  hipLaunchKernelGGL(cone_rect_kernel, dim3(cdiv(gt, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)cone.dirs_img.p, gt,
+                     ntiles, words, (const float *)cone.cos_a.p, (const float *)cone.sin_a.p, theta_a, (const unsigned int *)cone.nmax.p,
+                     (const unsigned int *)nmax_g.p, bits.p);
+  hipLaunchKernelGGL(cone_rect_expand_kernel, dim3(cdiv((uint64_t)a_supers * stages * 8, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)bits.p,
+                     2u * gt, ntiles, words, a_supers, stages, mask, kept.p);
+  AS_HIP(ctx, hipGetLastError());
+  unsigned long long hk[256], h = 0;
+  AS_HIP(ctx, copy_d2h(ctx, hk, kept.p, sizeof(hk)));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (unsigned long long v : hk) h += v;
+  const double share = gt ? (double)h / ((double)2 * gt * ntiles) : 0.0;
+  ctx->stats["knn_join_cone_second_kept_e6"] = (int64_t)(share * 1e6);
   if (kept_share) *kept_share = share;
   return AS_OK;
 }

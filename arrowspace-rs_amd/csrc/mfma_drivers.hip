@@ -169,6 +169,12 @@ __global__ void gather_u32_kernel(const uint32_t *__restrict__ table, const uint
   if (t < count) out[t] = (table ? table[pos[t]] : pos[t]) + add;
 }
 
+// key of a listed row for the order of the image: its position there
+__global__ void position_keys_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ inv, uint32_t count, double *__restrict__ keys) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) keys[t] = (double)inv[ids[t]];
+}
+
 static uint32_t pick_splits(uint32_t a_items, uint32_t b_tiles) {
   // keep >= ~4 work items per CU when the A side is short (query batches, small graphs, fall-back lists)
   uint32_t s = 1;
@@ -792,9 +798,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
 int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
 int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
                          unsigned char *mask, const uint32_t *tile_mask = nullptr, uint32_t tm_words = 0);
-uint32_t cone_tile_words(uint32_t n);
-int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin, uint32_t pos_count,
-                   uint32_t *tile_mask, double *kept_share);
+
 int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                              uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                              float *theta2_out);
@@ -930,7 +934,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
                    const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm,
-                   const double *rot_z, bool *grouped_io) {
+                   const double *rot_z, bool *grouped_io, ConeDirs *cone_keep) {
   // grouped_io: in = the caller can take lists kept per group of 32 image positions (mfma_join_f16.hip, GROUPED); out = they are
   const bool want_grouped = grouped_io && *grouped_io;
   if (grouped_io) *grouped_io = false;
@@ -997,7 +1001,8 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
           if (tiled) {
             double kept = 1.0;
             AS_TRY(tile_mask.alloc(ctx, (size_t)(I_end - I_begin) * 4 * tm_words));
-            AS_TRY(cone_tile_mask(ctx, rot_z, image_perm ? image_perm : perm, n, theta.p, I_begin * 512u, (I_end - I_begin) * 512u, tile_mask.p, &kept));
+            AS_TRY(cone_tile_mask(ctx, rot_z, image_perm ? image_perm : perm, n, theta.p, I_begin * 512u, (I_end - I_begin) * 512u, tile_mask.p, &kept,
+                                  cone_keep));
             tiled = kept <= (double)ctx->opt_join_cone_tiles_max_e3 * 1e-3;
           }
           ctx->stats["knn_join_cone_tiles"] = tiled ? 1 : 0;
@@ -1317,7 +1322,7 @@ int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   if (oj.rot_z.p && !oj.wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
   const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_image, oj.cap, cnt, cand, nullptr, oj.P16own.p,
                                       oj.Phown.p, (oj.reorder && !lists_by_pos) ? oj.perm_own.p : nullptr,
-                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, grouped_io);
+                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, grouped_io, &oj.cone);
   ctx->opt_join_prefilter = saved_mode;
   return rc_pairs;
 }
@@ -1733,6 +1738,27 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       split_image = P16late.p;
     }
     const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = second_h ? (bt + 3) & ~3u : (bt + 1) & ~1u, pad = b_al * kTileRows;
+    // The f16 pass behind a ONE-SIDED cone bound (cone_tiles.hip: the cones of the image's tiles are kept from the first pass): the
+    // open rows are put in the order of the image first -- a wave's 64 rows are then neighbours, and most column tiles lie outside
+    // what any of them can reach.
+    DevBuf<uint32_t> ids_s, pos_s;
+    const bool cone_second = second_h && oj && oj->cone.valid && oj->rot_z.p && oj->inv_own.p && ctx->opt_join_cone_second && nf >= 512 &&
+                             !(ctx->opt_debug & 2048);
+    if (cone_second) {
+      DevBuf<double> keys;
+      DevBuf<uint32_t> ord;
+      AS_TRY(keys.alloc(ctx, nf));
+      AS_TRY(ord.alloc(ctx, nf));
+      AS_TRY(ids_s.alloc(ctx, nf));
+      AS_TRY(pos_s.alloc(ctx, nf));
+      hipLaunchKernelGGL(position_keys_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, ctx->stream, cur_ids, (const uint32_t *)oj->inv_own.p, nf, keys.p);
+      AS_TRY(order_by_value(ctx, keys.p, nf, ord.p));
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, ctx->stream, cur_ids, (const uint32_t *)ord.p, nf, 0u, ids_s.p);
+      hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, ctx->stream, cur_pos, (const uint32_t *)ord.p, nf, 0u, pos_s.p);
+      AS_HIP(ctx, hipGetLastError());
+      cur_ids = ids_s.p;
+      cur_pos = pos_s.p;
+    }
     DevBuf<unsigned char> PA;
     DevBuf<float> theta_a, zeros;
     DevBuf<uint32_t> cnt_b, cand_b, unitc, oi, failx;
@@ -1774,8 +1800,17 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const size_t zn = std::max<size_t>(((size_t)n + 511) / 512 * 512, pad);
       AS_TRY(zeros.alloc(ctx, zn));
       AS_HIP(ctx, hipMemsetAsync(zeros.p, 0, sizeof(float) * zn, ctx->stream));
+      DevBuf<unsigned char> mask2;
+      bool masked = false;
+      if (cone_second) {
+        double kept = 1.0;
+        AS_TRY(mask2.alloc(ctx, (size_t)(pad / 512u) * 2 * ((n + 511) / 512) * 8));
+        AS_TRY(cone_rect_mask(ctx, oj->rot_z.p, cur_ids, nf, theta_a.p, pad, oj->cone, n, mask2.p, &kept));
+        masked = kept <= (double)ctx->opt_join_cone_tiles_max_e3 * 1e-3;
+      }
+      ctx->stats["knn_join_cone_second"] = masked ? 1 : 0;
       AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
-                             unitc.p, "knn_mfma_join_f16_second", perm_used, nullptr, nullptr, cur_ids));
+                             unitc.p, "knn_mfma_join_f16_second", perm_used, nullptr, masked ? mask2.p : nullptr, cur_ids));
     } else if (second_wide)
       AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second",
                                 perm_used));
