@@ -331,6 +331,11 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "join_cone_tiles") ctx->opt_join_cone_tiles = value != 0;
+  else if (n == "join_theta_rate") {
+    int64_t r = 32;
+    while (r > 2 && r > value) r >>= 1;
+    ctx->opt_join_theta_rate = r;
+  }
   else if (n == "join_cone_second") ctx->opt_join_cone_second = value != 0;
   else if (n == "join_cone_tiles_max_e3") ctx->opt_join_cone_tiles_max_e3 = std::max<int64_t>(0, value);
   else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;

@@ -248,12 +248,12 @@ constexpr uint32_t kGroupNear = 16;
 // rows) and more for larger groups, up to 32 (4 M rows in 1 024 groups: 2 000 rows, half as many again for the groups larger
 // than the average -- with 4 tiles only the four nearest groups fitted, the check against the plain sample failed and the
 // plain pass cost 116 ms of a 574 ms table)
-static uint32_t group_tiles(uint32_t n, uint32_t np) {
-  const uint64_t near_rows = ((uint64_t)n / std::max(1u, np)) * kGroupNear / 32u;  // rows the near groups' samples hold
+static uint32_t group_tiles(uint32_t n, uint32_t np, uint32_t rate = 32) {
+  const uint64_t near_rows = ((uint64_t)n / std::max(1u, np)) * kGroupNear / rate;  // rows the near groups' samples hold
   if (near_rows <= 512) return 4;
   uint32_t t = (uint32_t)((near_rows * 3 / 2 + 127u) / 128u);
   t = (t + 1u) & ~1u;  // whole 256-row super tiles
-  return std::min(32u, t);
+  return std::min(rate >= 32 ? 32u : 128u, t);
 }
 
 // near[g][0 .. 16): the pivots most similar to pivot g (itself first).  piv: np x pitch floats.
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void near_groups_kernel(const float *__restric
 // slots in the order of the positions (a thread per group walking them alone was 0.55 ms of the 2.1 ms of the thresholds)
 __global__ __launch_bounds__(64) void group_sample_ids_kernel(const uint32_t *__restrict__ near, const uint32_t *__restrict__ group_start,
                                                               uint32_t np, const uint32_t *__restrict__ perm, uint32_t *__restrict__ ids,
-                                                              uint32_t slots) {
+                                                              uint32_t slots, uint32_t rate = 32) {
   const uint32_t g = blockIdx.x, lane = threadIdx.x;
   uint32_t *out = ids + (size_t)g * slots;
   uint32_t at = 0;  // (wave-uniform)
@@ -308,16 +308,16 @@ __global__ __launch_bounds__(64) void group_sample_ids_kernel(const uint32_t *__
     const uint32_t h = near[(size_t)g * kGroupNear + k];
     if (h >= np) continue;
     const uint32_t lo = group_start[h], hi = group_start[h + 1];
-    for (uint32_t j0 = lo / 32; (uint64_t)j0 * 32 < hi && at < slots; j0 += 64) {
+    for (uint32_t j0 = lo / rate; (uint64_t)j0 * rate < hi && at < slots; j0 += 64) {
       const uint32_t j = j0 + lane;
       bool ok = false;
       uint32_t p = 0;
-      if ((uint64_t)j * 32 < hi) {
+      if ((uint64_t)j * rate < hi) {
         uint32_t x = j * 0x9E3779B9u;
         x ^= x >> 15;
         x *= 0x85EBCA6Bu;
         x ^= x >> 13;
-        p = j * 32 + (x & 31u);
+        p = j * rate + (x & (rate - 1u));  // (rate: a power of two)
         ok = p >= lo && p < hi;
       }
       const unsigned long long m = __ballot(ok);
@@ -437,7 +437,8 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
   const uint32_t a_supers = (n + 255) / 256;
-  const uint32_t kGroupTiles = group_tiles(n, np), kGroupSlots = kGroupTiles * 128u;
+  const uint32_t rate = (uint32_t)std::max<int64_t>(2, std::min<int64_t>(ctx->opt_join_theta_rate, 32));  // (a power of two: api.hip)
+  const uint32_t kGroupTiles = group_tiles(n, np, rate), kGroupSlots = kGroupTiles * 128u;
   if (pos_count == 0 && pos_begin == 0) pos_count = n;
   if (pos_count == 0) return AS_OK;  // (a rank without positions)
   if (pos_begin % 256 != 0 || (uint64_t)pos_begin + pos_count > n) return fail(ctx, AS_ERR_ARG, "threshold pass: bad position range");
@@ -453,7 +454,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   ProfScope ps(ctx, "knn_join_thresholds");
   hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
   hipLaunchKernelGGL(group_sample_ids_kernel, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm,
-                     ids.p, kGroupSlots);
+                     ids.p, kGroupSlots, rate);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, group_start, np, n, a_supers, ug.p);
   AS_HIP(ctx, hipGetLastError());
   if (row_image) AS_TRY(pack_f16_from_image(ctx, row_image, n, ids.p, (uint64_t)np * kGroupSlots, d, PS.p, np * kGroupTiles));
