@@ -34,6 +34,41 @@ __global__ __launch_bounds__(kNormRows) void row_norms_kernel(const double *__re
   if (row0 + tid < n) norms[row0 + tid] = __dsqrt_rn(s);
 }
 
+// Rows of exactly 128 values, 16-byte aligned: a workgroup stages 64 WHOLE rows (64 KB: sixteen 16-byte loads per thread, every
+// one of them a full 1-KB row per wave instruction, all in flight together), then one thread per row walks its row in LDS in
+// index order -- the same sum.  The chunked form above moves a GB in 0.74 ms (eight rounds of loads and two barriers each per
+// block); this one runs at the speed of the loads.
+constexpr int kNorm128Rows = 64, kNorm128Pitch = 129;
+__global__ __launch_bounds__(256) void row_norms_d128_kernel(const double *__restrict__ rows, uint64_t n, double *__restrict__ norms) {
+  extern __shared__ __attribute__((aligned(16))) double tile128[];  // 64 x 129
+  const uint64_t row0 = (uint64_t)blockIdx.x * kNorm128Rows;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {  // wave wv takes rows wv, wv + 4, ...: lane l the values 2 l, 2 l + 1
+    const uint64_t r = row0 + (uint64_t)(4 * q + wv);
+    v[q] = r < n ? reinterpret_cast<const d2 *>(rows + r * 128)[lane] : d2{0.0, 0.0};
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    double *dst = tile128 + (size_t)(4 * q + wv) * kNorm128Pitch + 2 * lane;
+    dst[0] = v[q].x;
+    dst[1] = v[q].y;
+  }
+  __syncthreads();
+  if (tid < kNorm128Rows && row0 + tid < n) {
+    const double *src = tile128 + (size_t)tid * kNorm128Pitch;
+    double s = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < 128; ++c) {
+      const double x = src[c];
+      s = __dadd_rn(s, __dmul_rn(x, x));
+    }
+    norms[row0 + tid] = __dsqrt_rn(s);
+  }
+}
+
 // StandardScaler (src/laplacian.rs:146-151): per-column z-score.  smartcore's source is absent;
 // the oracle's convention is used (population variance, zero std -> 1; PARITY UNPINNED).  One thread
 // per column walks the rows in order (the sums are sequential, as the oracle's), lanes read
@@ -79,6 +114,11 @@ int standardise_rows(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, do
 int row_norms(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, double *norms) {
   if (n == 0) return AS_OK;
   ProfScope ps(ctx, "row_norms");
+  if (d == 128 && ((uintptr_t)rows & 15) == 0 && n >= 4096) {
+    const size_t lds = (size_t)kNorm128Rows * kNorm128Pitch * sizeof(double);
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)row_norms_d128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(row_norms_d128_kernel, dim3(cdiv(n, kNorm128Rows)), dim3(256), lds, ctx->stream, rows, n, norms);
+  } else
   hipLaunchKernelGGL(row_norms_kernel, dim3(cdiv(n, kNormRows)), dim3(kNormRows), 0, ctx->stream, rows, n, d, norms);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;

@@ -163,6 +163,89 @@ __global__ __launch_bounds__(256) void zproj_tile_kernel(const double *__restric
   if (tail_part && (tid & 63) == 0) tail_part[blockIdx.x * 4 + (tid >> 6)] = tails;
 }
 
+// Rows of exactly 128 values, 16-byte aligned: the same coordinates again (the same four chains per direction, the same divisions),
+// with a workgroup staging 64 WHOLE rows -- every wave instruction a full 1-KB row, sixteen of them in flight per wave, divided
+// by the norm and kept in LDS as f32 -- and four threads per row taking eight directions each.  The chunked form above moves the
+// GB of a million rows in 0.8 ms; this one runs at the speed of the loads.  tail_part: [block][4 waves], blocks of 64 rows.
+__global__ __launch_bounds__(256) void zproj_rows128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
+                                                            const float *__restrict__ Q, uint32_t pitch, double *__restrict__ out,
+                                                            double *__restrict__ tail_part) {
+  // (a direction per 132 floats: the four threads of a row read four neighbouring directions at once -- 528 bytes apart, four
+  // different groups of banks; 8 directions apart they sat 4 KB apart, on the same banks, and the kernel was no faster than the old)
+  constexpr int kQS = 132;
+  __shared__ __attribute__((aligned(16))) float s_q[kDirs * kQS];
+  __shared__ float xf[64 * 129];
+  __shared__ float zs[64 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int e = tid; e < kDirs * 128; e += 256) s_q[(e >> 7) * kQS + (e & 127)] = Q[(size_t)(e >> 7) * pitch + (e & 127)];
+  const uint32_t row0 = blockIdx.x * 64u;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {  // wave wv takes rows wv, wv + 4, ...: lane l the values 2 l, 2 l + 1
+    const uint32_t r = row0 + (uint32_t)(4 * q + wv);
+    v[q] = r < n ? reinterpret_cast<const d2 *>(R + (uint64_t)r * 128)[lane] : d2{0.0, 0.0};
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const uint32_t r = row0 + (uint32_t)(4 * q + wv);
+    const double nr = r < n ? norms[r] : 0.0;
+    const bool live = r < n && nr > 0.0 && nr < __builtin_inf();
+    const float f0 = live ? (float)(v[q].x / nr) : 0.f, f1 = live ? (float)(v[q].y / nr) : 0.f;
+    float *dst = xf + (size_t)(4 * q + wv) * 129 + 2 * lane;
+    dst[0] = f0 == f0 ? f0 : 0.f;
+    dst[1] = f1 == f1 ? f1 : 0.f;
+  }
+  __syncthreads();
+  const int rr = tid >> 2, part = tid & 3;
+  {
+    float acc[8][4];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[jj][c] = 0.f;
+    const float *xr = xf + (size_t)rr * 129;
+#pragma unroll 4
+    for (int k0 = 0; k0 < 128; k0 += 4) {
+      const float x0 = xr[k0], x1 = xr[k0 + 1], x2 = xr[k0 + 2], x3 = xr[k0 + 3];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int j = min(4 * jj + part, kDirs - 1);  // (direction 31 does not exist: the last thread of a row repeats 30 and drops it)
+        const float4 q = *reinterpret_cast<const float4 *>(&s_q[j * kQS + k0]);
+        acc[jj][0] = __builtin_fmaf(x0, q.x, acc[jj][0]);
+        acc[jj][1] = __builtin_fmaf(x1, q.y, acc[jj][1]);
+        acc[jj][2] = __builtin_fmaf(x2, q.z, acc[jj][2]);
+        acc[jj][3] = __builtin_fmaf(x3, q.w, acc[jj][3]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      if (4 * jj + part < kDirs) zs[rr * 33 + 4 * jj + part] = (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+  }
+  __syncthreads();
+  const uint32_t row = row0 + (uint32_t)rr;
+  double tails = 0.0;
+  if (row < n) {
+    double *o = out + (size_t)row * 32;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      if (8 * part + jj < kDirs) o[8 * part + jj] = (double)zs[rr * 33 + 8 * part + jj];  // (each thread a contiguous 64 bytes of the row)
+    if (part == 0) {
+      const double nr = norms[row];
+      const bool live = nr > 0.0 && nr < __builtin_inf();
+      float zz = 0.f;
+      for (int j = 0; j < kDirs; ++j) {
+        const float z = zs[rr * 33 + j];
+        zz = __builtin_fmaf(z, z, zz);
+      }
+      o[kDirs] = live ? (double)__builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.0;
+      if (live) tails = (double)__builtin_fmaxf(1.f - zz, 0.f);
+    }
+  }
+  for (int o2 = 32; o2 > 0; o2 >>= 1) tails += __shfl_xor(tails, o2, 64);
+  if (tail_part && lane == 0) tail_part[blockIdx.x * 4 + wv] = tails;
+}
+
 // Y[block][dir][k] = sum over the sample rows of the block (i = block, block + grid, ...: a fixed order) of z[row][dir] * u[row][k];
 // yreduce_kernel adds the blocks' parts in block order.  (Was a float atomicAdd into one Y: the directions differed in their last
 // bits from run to run, and with them the row order and the routing of rows through the stages.)
@@ -327,7 +410,10 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   DevBuf<float> Qd, Yd, Ypart;
   DevBuf<double> Zs, tpart;
   const uint32_t y_blocks = std::min<uint32_t>(ns, 512);
-  const uint32_t z_grid = d <= 128 ? (uint32_t)cdiv(n, 256) : std::min<uint32_t>((uint32_t)cdiv(n, 4), 256 * 8);
+  // (128 aligned columns: zproj_rows128_kernel, blocks of 64 rows; other widths up to 128: blocks of 256)
+  const bool rows128 = d == 128 && (((uintptr_t)(sr ? sr->own : rows)) & 15) == 0 && !(ctx->opt_debug & 2048);
+  const uint32_t z_rows = rows128 ? 64u : 256u;
+  const uint32_t z_grid = d <= 128 ? (uint32_t)cdiv(n, z_rows) : std::min<uint32_t>((uint32_t)cdiv(n, 4), 256 * 8);
   AS_TRY(Qd.alloc(ctx, (size_t)kDirs * pitch));
   AS_TRY(Yd.alloc(ctx, (size_t)kDirs * pitch));
   AS_TRY(Ypart.alloc(ctx, (size_t)y_blocks * kDirs * pitch));
@@ -413,9 +499,11 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
     // its blocks of 256 rows are blocks of the whole matrix)
     const double *p_rows = sr ? sr->own : rows, *p_norms = sr ? norms + sr->lo : norms;
     const uint32_t p_n = sr ? sr->count : n;
-    double *p_z = sr ? Z + (size_t)sr->lo * 32 : Z, *p_t = sr ? tpart.p + (size_t)(sr->lo / 256) * 4 : tpart.p;
+    double *p_z = sr ? Z + (size_t)sr->lo * 32 : Z, *p_t = sr ? tpart.p + (size_t)(sr->lo / z_rows) * 4 : tpart.p;
 #define AS_ZT(DPV) hipLaunchKernelGGL(zproj_tile_kernel<DPV>, dim3(cdiv(p_n, 256)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, d, (const float *)Qd.p, pitch, p_z, p_t)
-    if (p_n) switch ((d + 31) / 32) {
+    if (p_n && rows128)
+      hipLaunchKernelGGL(zproj_rows128_kernel, dim3(cdiv(p_n, 64)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, (const float *)Qd.p, pitch, p_z, p_t);
+    else if (p_n) switch ((d + 31) / 32) {
       case 2: AS_ZT(64); break;
       case 3: AS_ZT(96); break;
       default: AS_ZT(128); break;
@@ -433,7 +521,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
       AS_HIP(ctx, hipGetLastError());
       std::vector<uint64_t> bytes((size_t)sr->world), offs((size_t)sr->world);
       for (int r = 0; r < sr->world; ++r) {
-        const uint64_t b0 = sr->row_lo[(size_t)r] / 256, b1 = (sr->row_hi[(size_t)r] + 255) / 256;
+        const uint64_t b0 = sr->row_lo[(size_t)r] / z_rows, b1 = (sr->row_hi[(size_t)r] + z_rows - 1) / z_rows;
         bytes[(size_t)r] = sr->row_hi[(size_t)r] > sr->row_lo[(size_t)r] ? (b1 - b0) * 4 * sizeof(double) : 0;
         offs[(size_t)r] = b0 * 4 * sizeof(double);
       }
