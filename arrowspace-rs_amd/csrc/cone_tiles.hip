@@ -226,6 +226,14 @@ __global__ __launch_bounds__(256, 4) void cone_max_kernel(const f16x8 *__restric
   }
 }
 
+// how many tiles have a cone wider than `cos_limit` allows (the bound says nothing about them: a quick way to see that it will not pay)
+__global__ void cone_wide_count_kernel(const float *__restrict__ cos_a, uint32_t ntiles, float cos_limit, unsigned int *__restrict__ count) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool wide = t < ntiles && cos_a[t] < cos_limit;
+  const unsigned long long m = __ballot(wide);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned int)__builtin_popcountll(m));
+}
+
 // tile_mask[(I - it_begin) * words + w], bit b: the pair (I, J = 32 w + b) is kept iff both orientations keep it:
 // bit1[I][w] bit b AND bit1[J][I / 32] bit I % 32 -- the second is a 32 x 32 bit transpose: a wave takes the block (rows 32 w ..
 // 32 w + 31 of bit1, word ig), lane l its row's word, and ballot c of "bit c of my word" is the transposed word of I = 32 ig + c.
@@ -292,6 +300,26 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(cone_tile_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, Z, perm, n, theta, (f16x8 *)rows_img.p, (f16x8 *)dirs_img.p, ca.p,
                      sa.p, tmin.p, nmax.p);
+  {
+    // Data whose tiles are not cones (rows of many clusters in one tile, no directions to tell apart): more than half of the tiles
+    // wider than 0.8 rad -- the bound would keep nearly every pair (rank 64 / 4 096 clusters: 93 %), so its n^2 pass is not run and
+    // the caller sweeps everything.  (The widths are functions of the gathered coordinates: every rank of a sharded build agrees.)
+    DevBuf<unsigned int> wide;
+    AS_TRY(wide.alloc(ctx, 1));
+    AS_HIP(ctx, hipMemsetAsync(wide.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(cone_wide_count_kernel, dim3(cdiv(ntiles, 256)), dim3(256), 0, ctx->stream, (const float *)ca.p, ntiles, 0.6967f, wide.p);
+    unsigned int hw = 0;
+    AS_HIP(ctx, copy_d2h(ctx, &hw, wide.p, sizeof(hw)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats["knn_join_cone_tiles_wide_e6"] = (int64_t)((double)hw / std::max(1u, ntiles) * 1e6);
+    if ((uint64_t)hw * 2 > ntiles) {
+      ctx->stats["knn_join_cone_tiles_kept_e6"] = 1000000;
+      if (kept_share) *kept_share = 1.0;
+      // (every pair kept: whoever reads the mask all the same sweeps everything)
+      AS_HIP(ctx, hipMemsetAsync(tile_mask, 0xFF, sizeof(uint32_t) * (size_t)it_count * words, ctx->stream));
+      return AS_OK;  // (cd.valid stays false: no one-sided bound for the second pass either)
+    }
+  }
   const uint32_t all_groups = words;
   if (it_begin == 0 && it_count == ntiles) {
     hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
