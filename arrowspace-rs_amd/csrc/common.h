@@ -95,6 +95,7 @@ struct as_ctx {
   int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
+  int64_t opt_join_theta_band = 2;       // thresholds also from a row's own neighbourhood in the image: this many 512-position super tiles on either side (0: off)
   int64_t opt_join_theta_rate = 32;      // grouped thresholds: one image position in this many is sampled (a power of two, 2 .. 32)
   int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
                                          // groups (8.2 -> 1.7 ms at 1 M x 128), checked against the whole sample on 4096 rows

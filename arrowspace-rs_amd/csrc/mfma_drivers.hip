@@ -170,6 +170,14 @@ __global__ void gather_u32_kernel(const uint32_t *__restrict__ table, const uint
 }
 
 // key of a listed row for the order of the image: its position there
+// t[p] = max(t[p], band[p] - by): the thresholds of the own neighbourhood where they are the higher ones (+inf stays +inf)
+__global__ void theta_band_merge_kernel(float *__restrict__ t, const float *__restrict__ band, uint32_t n, float by) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && t[p] < __builtin_inff()) {
+    const float b = band[p] - by;
+    if (b > t[p]) t[p] = b;
+  }
+}
 __global__ void position_keys_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ inv, uint32_t count, double *__restrict__ keys) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < count) keys[t] = (double)inv[ids[t]];
@@ -828,6 +836,8 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out, const void *row_image = nullptr, uint64_t n_image = 0);
+int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out,
+                             uint32_t pos_begin = 0, uint32_t pos_count = 0);
 int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
 int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles);
 
@@ -1296,6 +1306,22 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       AS_TRY((*gather)(t1, sizeof(float)));
       if (oj.have_theta2) AS_TRY((*gather)(t2, sizeof(float)));
     }
+  }
+  // Whatever pass the thresholds came from (grouped sample, plain sample), in the order of the image they are raised to what the
+  // row's own neighbourhood certifies:
+  // ... and, where that is higher, from the row's own neighbourhood in the image: K other rows of its super tile and the ones
+  // beside it reach it, so the row is certified by construction and its list is cut near its K-th best cosine instead of its
+  // 128th (mfma_theta_f16.hip, join_thresholds_f16_band); the sampled threshold stays for rows whose neighbours live elsewhere
+  if (reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && d <= 128 && K + 1 <= 32) {
+    DevBuf<float> tband;
+    AS_TRY(tband.alloc(ctx, n));
+    AS_HIP(ctx, hipMemsetAsync(tband.p, 0xFF, sizeof(float) * n, ctx->stream));  // (NaN where not computed: never the larger one)
+    AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
+    if (pos_count)
+      hipLaunchKernelGGL(theta_band_merge_kernel, dim3(cdiv(pos_count, 256)), dim3(256), 0, ctx->stream, oj.theta_pos.p + pos_begin,
+                         (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6));
+    AS_HIP(ctx, hipGetLastError());
+    if (gather) AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));  // (a rank raised the thresholds of its own positions)
   }
   if (reorder) {  // ... and go back to row order for everything behind the join
     AS_TRY(scatter_by_perm(ctx, oj.theta_pos.p, oj.perm_own.p, n, oj.theta_own.p));

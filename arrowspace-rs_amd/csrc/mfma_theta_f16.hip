@@ -480,4 +480,54 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   return AS_OK;
 }
 
+// Thresholds from a row's OWN NEIGHBOURHOOD in the ordered image, not from a sample: theta_out[p] = a value that at least m
+// products of row p reach among ALL rows of its own 512-position super tile and the `band` super tiles on either side (the m-th
+// largest of 64 bin maxima, as everywhere in this file).  With m = K + 1 (the row meets itself) that is a certificate: K other rows
+// have an f16 product >= theta_out[p], so a list cut at theta_out[p] - 2 delta holds K rows whose exact cosines are above the cut
+// + delta -- the row is certified whatever the rest of the matrix holds, and the cut sits near the K-th best cosine itself instead
+// of near the 128th (the 4th best of a 1-in-32 sample).  The kernel sweeps the image in place: the "sample of group g" is super
+// tile g of P_all (4 tiles), a unit's groups the super tiles around its own.  1 M x 128, band 1: 1 536 columns per row, 0.4 TFLOP.
+__global__ void band_groups_kernel(uint32_t units, uint32_t T5, uint32_t band, uint32_t *__restrict__ ug) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const uint32_t I5 = u >> 1;  // the unit's 512-position super tile (a unit = 256 positions)
+  ug[2 * u] = I5 > band ? I5 - band : 0u;
+  ug[2 * u + 1] = min(T5 - 1u, I5 + band);
+}
+int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out,
+                             uint32_t pos_begin, uint32_t pos_count) {
+  const uint32_t KS = (d + 15) / 16;
+  if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
+  if (pos_count == 0 && pos_begin == 0) pos_count = n;
+  if (pos_count == 0) return AS_OK;
+  if (pos_begin % 256 != 0 || (uint64_t)pos_begin + pos_count > n) return fail(ctx, AS_ERR_ARG, "threshold pass: bad position range");
+  const uint32_t a_supers = (n + 255) / 256, T5 = (n + 511) / 512;
+  const uint32_t u_begin = pos_begin / 256, u_count = (pos_count + 255) / 256;
+  DevBuf<uint32_t> ug, unitc;
+  AS_TRY(ug.alloc(ctx, (size_t)2 * a_supers));
+  AS_TRY(unitc.alloc(ctx, 1));
+  AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
+  ProfScope ps(ctx, "knn_join_thresholds_band");
+  hipLaunchKernelGGL(band_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, a_supers, T5, band, ug.p);
+  const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
+  const unsigned grid = std::min<uint32_t>(u_count, 512u);
+  const f16x8 *PA_r = (const f16x8 *)P_all + (size_t)(pos_begin / kTileRows) * KS * 4 * 64;
+  float *t1_r = theta_out + pos_begin;
+  const uint32_t *ug_r = ug.p + 2 * (size_t)u_begin;
+#define AS_THETA(K)                                                                                                          \
+  case K:                                                                                                                    \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA_r, u_count, pos_count,             \
+                       (const f16x8 *)P_all, 4u, m, t1_r, 0u, (float *)nullptr, unitc.p, ug_r);                              \
+    break;
+  switch (KS) {
+    AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
+    default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
+  }
+#undef AS_THETA
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 }  // namespace asx

@@ -431,6 +431,34 @@ def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,topk", [(70000, 128, 16), (66001, 64, 30), (131072 + 300, 128, 5)])
+def test_item_graph_thresholds_from_the_own_neighbourhood(ctx, n, d, topk):
+    """"join_theta_band" (round 4): a row's threshold is raised to what its own neighbourhood in the ordered image certifies -- the
+    (K+1)-th largest of the bin maxima of its products with ALL rows of its super tile and the ones beside it, lowered by twice the
+    f16 bound: K other rows are then in its list with exact cosines above the cut + delta.  Fewer candidates, no more open rows than
+    with the sampled thresholds alone, the same tables, the oracle's rows.  topk = 30: K + 1 = 32, the deepest the pass takes."""
+    X, _ = synth.mixture(n, d, seed=37, n_clusters=40, rank=5)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25)
+    try:
+        ctx.set_option("join_theta_band", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_row_order") == 1
+        open0, cand0 = ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")
+        ctx.set_option("join_theta_band", 2)
+        idx, dist = A.knn_cosine(X, gp)
+        open1, cand1 = ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")
+    finally:
+        ctx.set_option("join_theta_band", 2)
+    assert cand1 < cand0 and open1 <= open0 + max(2, open0 // 50), (cand0, cand1, open0, open1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    rng = np.random.default_rng(6)
+    sample = np.sort(rng.choice(n, size=128, replace=False))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 def _stress_case(seed, index):
     """Case `index` of scripts/stress_first_pass.py for `seed` (the same draws in the same order)."""
     rng = np.random.default_rng(seed)
