@@ -318,7 +318,7 @@ __global__ void join_theta_kernel(const double *__restrict__ ckey, const uint32_
 __global__ void second_theta_kernel(const float *__restrict__ theta, const float *__restrict__ theta2,
                                     const uint32_t *__restrict__ cnt, uint32_t n_src, uint32_t t2_base, uint32_t list_base, uint32_t row_count,
                                     uint32_t cap, const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded,
-                                    float *__restrict__ out, const uint32_t *__restrict__ inv) {
+                                    float *__restrict__ out, const uint32_t *__restrict__ inv, const float *__restrict__ band, float band_by) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
@@ -328,6 +328,8 @@ __global__ void second_theta_kernel(const float *__restrict__ theta, const float
     bool over = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) over = over || cnt[(size_t)sidx * row_count + lr] > cap;
     t = over ? theta[g] : theta2[r];
+    // never below what the row's own neighbourhood certifies (K rows reach it: mfma_theta_f16.hip, join_thresholds_f16_band)
+    if (band && band[g] - band_by > t) t = band[g] - band_by;
   }
   out[i] = t;
 }
@@ -337,7 +339,7 @@ __global__ void second_theta_fresh_kernel(const float *__restrict__ t1, const fl
                                           const uint32_t *__restrict__ cnt,
                                           uint32_t n_src, uint32_t list_base, uint32_t row_count, uint32_t cap,
                                           const uint32_t *__restrict__ ids, uint32_t count, uint32_t padded, float *__restrict__ out,
-                                          const uint32_t *__restrict__ inv) {
+                                          const uint32_t *__restrict__ inv, const float *__restrict__ band, float band_by) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   float t = __builtin_inff();
@@ -349,6 +351,7 @@ __global__ void second_theta_fresh_kernel(const float *__restrict__ t1, const fl
     // a list that ran over although the first threshold was the right one is a dense neighbourhood: the tight threshold and
     // twice the room; one that ran over because the first threshold was far too low is an ordinary row: the looser threshold
     t = (over && !(t1[i] - theta_first[g] > 1e-3f)) ? t1[i] : t2[i];
+    if (band && band[g] - band_by > t) t = band[g] - band_by;  // (as in second_theta_kernel)
   }
   out[i] = t;
 }
@@ -1322,6 +1325,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
                          (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6));
     AS_HIP(ctx, hipGetLastError());
     if (gather) AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));  // (a rank raised the thresholds of its own positions)
+    // kept by row for the second pass: a row the sampled threshold left open has K rows above this one by construction
+    AS_TRY(oj.theta_band_own.alloc(ctx, n));
+    AS_TRY(scatter_by_perm(ctx, tband.p, oj.perm_own.p, n, oj.theta_band_own.p));
+  } else {
+    oj.theta_band_own.release();
   }
   if (reorder) {  // ... and go back to row order for everything behind the join
     AS_TRY(scatter_by_perm(ctx, oj.theta_pos.p, oj.perm_own.p, n, oj.theta_own.p));
@@ -1799,6 +1807,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(failx.alloc(ctx, nf));
     if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
+    const float *band_own = (second_h && oj && oj->theta_band_own.p && ctx->opt_join_theta_band_second) ? oj->theta_band_own.p : nullptr;
+    const float band_by = (float)(2.0 * join_delta(ctx, d) + 2e-6);
     if (grouped_theta && second_h && !(ctx->opt_debug & 131072)) {  // (debug bit 131072: the first pass's own second thresholds)
       // the thresholds of the first pass came from the sampled rows of the nearest pivot groups only; a row that is open after it
       // may be one whose neighbours live elsewhere (a cluster without a pivot of its own), so the second pass takes thresholds
@@ -1814,10 +1824,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, n / ns, sample_half_bits(ns), sid.p);
       AS_TRY(join_thresholds_f16(ctx, rows, norms, d, PA.p, 0, nf, sid.p, ns, m, t1.p, m2, t2.p));
       hipLaunchKernelGGL(second_theta_fresh_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, (const float *)t1.p, (const float *)t2.p,
-                         js->theta, js->cnt, js->n_src, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv);
+                         js->theta, js->cnt, js->n_src, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv, band_own, band_by);
     } else {
       hipLaunchKernelGGL(second_theta_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, ctx->stream, js->theta, js->theta2, js->cnt,
-                         js->n_src, t2_base, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv);
+                         js->n_src, t2_base, list_base, row_count, js->cap, cur_ids, nf, pad, theta_a.p, lists_inv, band_own, band_by);
     }
     AS_HIP(ctx, hipMemsetAsync(cnt_b.p, 0, sizeof(uint32_t) * pad, ctx->stream));
     AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));

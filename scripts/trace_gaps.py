@@ -6,8 +6,8 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-# the last build starts at the last row_norms_kernel
-starts = [i for i, r in enumerate(rows) if "row_norms_kernel" in r[2]]
+# the last build starts at the last row-norms kernel
+starts = [i for i, r in enumerate(rows) if "row_norms" in r[2]]
 i0 = starts[-1]
 seg = rows[i0:]
 t0 = seg[0][0]; t1 = max(r[1] for r in seg)
