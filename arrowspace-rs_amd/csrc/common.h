@@ -95,6 +95,7 @@ struct as_ctx {
   int64_t opt_search_stream_filter = 1;  // small batches on an index searched before: int8 filter in front of the streaming scan
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
+  int64_t opt_rerank_pair_bound = 1;       // the pruning in front of the exact re-rank bounds each pair by its two rows' own plane errors
   int64_t opt_join_theta_band_second = 1;  // the second pass never cuts below what the band certified
   int64_t opt_join_theta_band = 2;       // thresholds also from a row's own neighbourhood in the image: this many 512-position super tiles on either side (0: off)
   int64_t opt_join_theta_rate = 32;      // grouped thresholds: one image position in this many is sampled (a power of two, 2 .. 32)
@@ -511,6 +512,7 @@ struct OwnJoin {
   bool sharded_rows = false;                                  // the preparation ran on the ranks' own rows (ShardedRows below)
   ConeDirs cone;                                              // the tiles' cones, when the first pass ran behind the cone bound
   DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos; // thresholds (and the looser second ones) by row / by image position
+  DevBuf<float> f16_err_pos;            // plane error of every row of the f16 image by image position (the pruning's bound per pair)
   DevBuf<float> theta_band_own;         // by row: what the row's own neighbourhood certifies, less twice the bound (NaN: not computed); the second pass's floor
   DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms

@@ -505,6 +505,46 @@ __device__ __forceinline__ uint32_t prune_candidates(uint32_t *ei, float *es, ui
   return out;
 }
 
+// The same pruning with a bound PER PAIR: the f16 product of rows i and j differs from their exact cosine by at most
+// E_i + E_j + E_i E_j (their measured plane errors, Cauchy-Schwarz per pair) + the accumulation term, where the one bound for all
+// pairs has twice the LARGEST plane error of the matrix (a third more at 1 M x 128: 28.8 -> 25 rows fetched per row).  err: the
+// plane errors by the ids the list holds (image positions), e_self: the row's own; ed: the bounds d_c of the pairs.  lo_c = s_c - d_c
+// replaces the score (tau = a lower bound of the K-th largest lo), a candidate stays when s_c + d_c >= tau: K candidates have an
+// exact cosine >= tau, which a dropped one cannot reach.
+// pair_bound: (rounded up: the three roundings of the sum and of the subtraction from the score are covered by the 4e-7)
+__device__ __forceinline__ float pair_bound(float e_self, float ej, float accum, float floor_delta) {
+  return __builtin_fmaxf((e_self + ej + e_self * ej) * (1.f + 1e-6f) + accum + 4e-7f, floor_delta);
+}
+// es[c] = s_c - d_c and ed[c] = d_c on entry (the kernel computes them as it copies the lists)
+__device__ __forceinline__ uint32_t prune_candidates_pairwise(uint32_t *ei, float *es, const float *ed, uint32_t C, uint32_t K, float step_f, int rectify,
+                                                              int lane) {
+  if (C <= K) return C;
+  if (C > 64u * 16u) return C;
+  float tau = 0.f;
+  bool ok;
+  const uint32_t ns = (C + 63u) / 64u;  // wave-uniform
+  const double step = (double)step_f;  // (the bisection stops an eighth of this below the K-th largest lo: a lower bound)
+  if (ns <= 2) ok = prune_tau<2>(es, C, K, step, lane, &tau);
+  else if (ns <= 3) ok = prune_tau<3>(es, C, K, step, lane, &tau);
+  else if (ns <= 4) ok = prune_tau<4>(es, C, K, step, lane, &tau);
+  else if (ns <= 8) ok = prune_tau<8>(es, C, K, step, lane, &tau);
+  else ok = prune_tau<16>(es, C, K, step, lane, &tau);
+  if (!ok) return C;
+  if (rectify && !(tau > 0.f)) return C;  // (cosines rectified to 0 tie: a dropped candidate could still rank by its id)
+  uint32_t out = 0;
+  for (uint32_t base = 0; base < C; base += 64) {
+    const uint32_t c = base + lane;
+    const bool keep = c < C && !((double)es[c] + 2.0 * (double)ed[c] < (double)tau);
+    const uint32_t id = c < C ? ei[c] : 0u;
+    const unsigned long long m = __ballot(keep);
+    wave_sync();
+    if (keep) ei[out + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = id;
+    out += (uint32_t)__builtin_popcountll(m);
+  }
+  wave_sync();
+  return out;
+}
+
 }  // namespace asx
 #include "rerank_split.h"
 namespace asx {
@@ -796,7 +836,7 @@ uint32_t packed_tiles_f16(uint64_t n);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
-                 const uint32_t *perm = nullptr);
+                 const uint32_t *perm = nullptr, float *err_rows = nullptr);
 int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
                   uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm = nullptr,
                   const unsigned char *mask = nullptr);
@@ -1201,6 +1241,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     reorder = true;
   }
   ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
+  if (!join_on_f16(ctx, d)) oj.f16_err_pos.release();
   if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
     const uint32_t tiles = packed_tiles_f16(n);
     AS_TRY(oj.Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
@@ -1215,9 +1256,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
         AS_TRY(pack_f16_rows_sharded(ctx, *sr, norms, n, d, oj.Phown.p, tiles));
       }
       oj.sharded_rows = true;
+      oj.f16_err_pos.release();  // (the ranks exchange the largest plane error only: one bound for all pairs)
     } else {
       if (sr) AS_TRY(need_rows());
-      AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr));
+      AS_TRY(oj.f16_err_pos.alloc(ctx, n));  // the rows' plane errors by image position: the pruning's bound per pair
+      AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr, oj.f16_err_pos.p));
     }
   }
   ctx->stats["sharded_prepare_by_rows"] = oj.sharded_rows ? 1 : 0;
@@ -1498,7 +1541,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t kmax = pruning ? std::min<uint32_t>(cmax, std::max<uint32_t>(128, 2 * K)) : cmax;
       const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + rr_key_bytes(cmax, kmax) + (size_t)cmax * 4);
       DevBuf<uint32_t> records;
-      if (d % 128 == 0 && d <= 1024 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 8 <= 64 * 1024 &&
+      if (d % 128 == 0 && d <= 1024 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 12 <= 64 * 1024 &&
           ctx->opt_debug != 5 && ctx->opt_rerank_split) {
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
         const int slots = d == 128 ? 2 : 4;  // 124 / 252 survivors per record
@@ -1514,9 +1557,13 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
           hipLaunchKernelGGL(rerank_prune_grouped_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 32), 256 * 16)), dim3(256), lds_g, ctx->stream, row_count,
                              js->theta, norms, js->cnt, js->cand, js->cap, K, force.p, prune_delta, rectify, records.p, slots, score_order, scored.p);
         } else {
-          hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 8,
+          // the bound per pair from the rows' own plane errors, where the lists hold image positions and the image was packed here
+          const float *err_pos = (lists_by_pos && ent_perm && join_on_f16(ctx, d) && oj->f16_err_pos.p && ctx->opt_rerank_pair_bound) ? oj->f16_err_pos.p : nullptr;
+          ctx->stats["knn_rerank_pair_bound"] = err_pos ? 1 : 0;
+          hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
                              ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
-                             force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order);
+                             force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order, err_pos,
+                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)));
         }
         AS_HIP(ctx, hipGetLastError());
         const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each) of the scoring kernel

@@ -121,7 +121,7 @@ __global__ void f16_image_gather_kernel(const f16x8 *__restrict__ src, uint64_t 
 // with 16-byte stores.  Same values as pack_f16_kernel stores, same error measure as f16_row_error_kernel.
 __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__restrict__ R, const double *__restrict__ norms,
                                                                const uint32_t *__restrict__ row_ids, uint64_t n, f16x8 *__restrict__ P,
-                                                               unsigned int *__restrict__ err_bits) {
+                                                               unsigned int *__restrict__ err_bits, float *__restrict__ err_rows) {
   constexpr int KS = 8;
   __shared__ f16x8 s_tile[KS * 4 * 64];  // 32 KB: [ks][s][lane]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -186,6 +186,12 @@ __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__r
       t += __shfl_xor(t, 1, 64);
       const float e = (float)(__builtin_sqrt(t) * (1.0 + 1e-6));  // rounded up
       if (e == e) worst = __builtin_fmaxf(worst, e);
+      // (the eight lanes of group (bits 5, 4, 3) hold the sum of row 4 b5 + 2 b4 + b3 of the batch) -- the plane error of each
+      // row by image position, for the per-pair bound of the pruning (rerank_split.h); NaN -> +inf: such a row prunes nothing
+      if (err_rows && (lane & 7) == 0) {
+        const uint64_t pos = T * kTileRows + (uint64_t)wv * 32 + (uint64_t)(r0 + 4 * (int)up5 + 2 * (int)up4 + (int)up3);
+        if (pos < n) err_rows[pos] = e == e ? e : __builtin_inff();
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) worst = __builtin_fmaxf(worst, __shfl_xor(worst, o, 64));
@@ -1112,15 +1118,21 @@ __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__rest
 
 // packs ALL n rows and leaves the measured plane error in ctx->f16_err (what join_delta certifies against)
 // (perm: image position -> row, or nullptr)
+// (err_rows: the plane error of every row by image position, or nullptr; paths that do not measure it per row fill in the largest)
+__global__ void fill_f32_kernel(float *__restrict__ p, uint64_t n, float v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, uint32_t d, void *P, uint32_t tiles,
-                 const uint32_t *perm) {
+                 const uint32_t *perm, float *err_rows) {
   DevBuf<unsigned int> bits;
   AS_TRY(bits.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
   const uint32_t KS = f16_ksteps(d);
   if (d == 128 && ((uintptr_t)R & 15) == 0) {
     ProfScope ps(ctx, "pack_unit_rows");
-    hipLaunchKernelGGL(pack_f16_tile128_kernel, dim3(tiles), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p);
+    hipLaunchKernelGGL(pack_f16_tile128_kernel, dim3(tiles), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p, err_rows);
+    err_rows = nullptr;  // (written)
   } else if (KS <= 8) {
     // up to 128 columns: the plane error comes out of the packing pass (16 partial sums per row, 128 B against the 1 KB of a
     // second read of the row: pack 1.66 + error 1.09 ms at 1 M x 128 before)
@@ -1145,6 +1157,10 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
   float e;
   std::memcpy(&e, &h, sizeof(e));
   ctx->f16_err = (double)e;
+  if (err_rows) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, err_rows, n, e);
+    AS_HIP(ctx, hipGetLastError());
+  }
   return AS_OK;
 }
 
@@ -1170,7 +1186,7 @@ int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norm
   double own_err = 0.0;
   if (sr.count) {
     const uint32_t own_tiles = (sr.count + kTileRows - 1) / kTileRows;
-    AS_TRY(pack_f16_all(ctx, sr.own, norms_all + sr.lo, sr.count, d, (char *)Prow + (uint64_t)(sr.lo / kTileRows) * tile_bytes, own_tiles, nullptr));
+    AS_TRY(pack_f16_all(ctx, sr.own, norms_all + sr.lo, sr.count, d, (char *)Prow + (uint64_t)(sr.lo / kTileRows) * tile_bytes, own_tiles, nullptr, nullptr));
     own_err = ctx->f16_err;
   }
   std::vector<uint64_t> bytes((size_t)sr.world), offs((size_t)sr.world), eight((size_t)sr.world, 8), at8((size_t)sr.world);

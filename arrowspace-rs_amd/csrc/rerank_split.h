@@ -37,14 +37,16 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            uint32_t *__restrict__ records, int slots,
                                                            const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv,
                                                            unsigned long long *__restrict__ scored_total,
-                                                           const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order) {
+                                                           const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
+                                                           const float *__restrict__ err_pos, float accum_delta, float floor_delta) {
   // records are written by PLACE r of the visiting order: the rows of the range in their own order, or (order: place -> row of
   // the whole matrix, row_begin = 0) in the order of the join's image, where the list of place r sits at position r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
-  float *es = reinterpret_cast<float *>(smem) + (size_t)wv * 2 * cmax;
+  float *es = reinterpret_cast<float *>(smem) + (size_t)wv * 3 * cmax;
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
+  float *ed = es + 2 * cmax;  // the bound of each pair (err_pos: the rows' plane errors by image position = what the lists hold)
   unsigned long long scored = 0;  // candidates this wave hands to the scoring kernel (the rows it fetches: bench.py's algorithmic bytes)
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     // (a_ids: the rows of the range as a list -- a rank of a build sharded by image positions finishes the rows perm[pb .. pe))
@@ -63,15 +65,27 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
         take = cmax - C;
       }
       const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + lr) * cap;
-      for (uint32_t c = lane; c < take; c += 64) {
-        const uint2 e = src[c];
-        ei[C + c] = e.x;
-        es[C + c] = __uint_as_float(e.y);
+      if (err_pos) {  // the bound of each pair as its entry passes by (prune_candidates_pairwise: es = the LOWER end of the pair's cosine)
+        const float e_self = err_pos[lr];
+        for (uint32_t c = lane; c < take; c += 64) {
+          const uint2 e = src[c];
+          const float dc = pair_bound(e_self, err_pos[e.x], accum_delta, floor_delta);
+          ei[C + c] = e.x;
+          ed[C + c] = dc;
+          es[C + c] = __uint_as_float(e.y) - dc;
+        }
+      } else {
+        for (uint32_t c = lane; c < take; c += 64) {
+          const uint2 e = src[c];
+          ei[C + c] = e.x;
+          es[C + c] = __uint_as_float(e.y);
+        }
       }
       C += take;
     }
     wave_sync();
-    C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
+    if (err_pos) C = prune_candidates_pairwise(ei, es, ed, C, K, accum_delta + err_pos[lr], prune_rectify, lane);
+    else C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
     if (C > kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
       overflow = true;
       C = kRsMaxIds;
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
 #pragma unroll
     for (int t = 0; t < kRsRows; ++t) ids[t] = (!cu.done && cu.b * kRsRows + t < cu.C) ? raw[t] : self;
   };
+  // (slots past the count fetch the row itself; all lanes taking the SAME 16 bytes of it instead was measured: +0.3 ms)
 #define AS_GL(S, T) rs_gload16(S.v[T], lane_off, X + (uint64_t)__builtin_amdgcn_readfirstlane((int)ids_[T]) * d + is.q * 128u);
 #define AS_ISSUE(S)                                                                                                         \
   {                                                                                                                         \

@@ -694,6 +694,7 @@ int lambda_v3(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as
   int nw = (int)std::min<size_t>(kWaves, (kLdsBudget - fixed) / kTileB);
   if (nw < 1) return AS_OK;
   const size_t lds = (size_t)nw * kTileB + fixed;
+  ctx->stats["taumode_v3_steps"] = (int64_t)L->v3_steps;  // edge steps per lane and item (four entries each): bench.py's f64 operation count
   const uint64_t n_tiles = (n_items + kRows - 1) / kRows;
   const unsigned blocks = (unsigned)std::min<uint64_t>((n_tiles + nw - 1) / nw, 256);
 
