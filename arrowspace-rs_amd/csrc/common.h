@@ -76,7 +76,7 @@ struct as_ctx {
   int64_t opt_search_lambda_order = 1;  // search scan on items in their own order: batches of 1024 queries or more go in the order of their lambdas
   int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
   int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
-  int64_t opt_assembly_lanes = 1;        // graph assembly: 32 lanes per row for degrees / weights + pruning / union sizes (K <= 32)
+  int64_t opt_assembly_lanes = 2;        // graph assembly (K <= 32): 2 = the round-4 kernels (graph_assembly.hip), 1 = 32 lanes per row throughout, 0 = a thread per row
   int64_t opt_search_rot_tail_e3 = 100;  // a re-searched index keeps rotated int8 images when the tail of its items is at most this (x 1e-3)
   int64_t opt_sharded_agreement = 1;     // sharded build: a one-word all-reduce of "has anyone failed" in front of every data collective (sharded.hip)
   int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange) or 3 (before the nnz all-reduce)

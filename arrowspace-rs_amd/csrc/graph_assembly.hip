@@ -204,51 +204,202 @@ __global__ __launch_bounds__(256) void degree32_kernel(const uint32_t *__restric
   if (lane == 0 && total) atomicAdd(deg_sum, total);
 }
 
+// R rows per half wave with their loads issued together (measured at 1 M rows: R = 1 0.41 ms, R = 2 0.47 ms -- the kernel is bound
+// by its f64 divisions, the square root and the shuffles of the ranking, not by the round trips: R = 1 is what runs).
+template <int R>
 __global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
                                                           double eps, double sigma, double p, const uint32_t *__restrict__ deg,
                                                           const unsigned long long *__restrict__ deg_sum, uint32_t *__restrict__ adj_j,
                                                           double *__restrict__ adj_w, uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in,
-                                                          uint32_t r0, uint32_t nr) {
+                                                          uint32_t r0, uint32_t nr, uint32_t *__restrict__ adj_slot) {
+  // adj_slot (or nullptr): the place of each kept edge among the in-edges of its target, as the counting atomic returns it -- the
+  // scatter of the reverse edges then needs no second round of atomics (fill_reverse32_kernel)
   const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
-  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const uint32_t i0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 5) * R;
   const bool sparsify = ((double)(*deg_sum) / (double)n) > 10.0;  // avg_degree > 10.0 (src/laplacian.rs:229-230)
-  uint32_t j = kNoIdx;
-  double w = 0.0, score = 0.0;
-  bool keep = false;
-  if (i < n && (uint32_t)s < K) {
-    j = nbr_idx[(uint64_t)i * K + s];
-    const double dist = nbr_dist[(uint64_t)i * K + s];
-    if (j != kNoIdx && j != i && dist <= eps) {
-      w = kernel_weight(dist, sigma, p);
-      keep = w > 1e-12;
-      if (keep) score = sparsify ? __dmul_rn(w, __dsqrt_rn((double)((uint64_t)deg[i] * (uint64_t)deg[j]))) : w;
+  uint32_t j[R], di[R], dj[R], pos[R], len[R];
+  double dist[R], w[R];
+  bool live[R], keep[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = i0 + r;
+    live[r] = i < n && (uint32_t)s < K;
+    const uint64_t at = live[r] ? (uint64_t)i * K + s : 0;
+    j[r] = nbr_idx[at];
+    dist[r] = nbr_dist[at];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = i0 + r;
+    keep[r] = live[r] && j[r] != kNoIdx && j[r] != i && dist[r] <= eps;
+    di[r] = dj[r] = 0;
+    if (sparsify) {
+      di[r] = deg[i < n ? i : 0];
+      dj[r] = deg[keep[r] ? j[r] : 0];
     }
   }
-  const uint32_t km = half_ballot(keep, half);
-  uint32_t len = (uint32_t)__popc(km);
-  uint32_t pos = (uint32_t)__popc(km & ((1u << s) - 1u));  // place among the kept entries, in table order
-  if (sparsify && len > 2) {
-    // place in the stable descending order by score: kept entries with a larger score, or an equal one earlier in the table
-    uint32_t rank = 0;
-    for (int t = 0; t < 32; ++t) {
-      const double so = __shfl(score, t, 32);
-      const bool ko = (km >> t) & 1u;
-      rank += (ko && (so > score || (so == score && t < s))) ? 1u : 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double score = 0.0;
+    w[r] = 0.0;
+    if (keep[r]) {
+      w[r] = kernel_weight(dist[r], sigma, p);
+      keep[r] = w[r] > 1e-12;
+      if (keep[r]) score = sparsify ? __dmul_rn(w[r], __dsqrt_rn((double)((uint64_t)di[r] * (uint64_t)dj[r]))) : w[r];
     }
-    uint32_t keepn = len / 2;
-    if (keepn < 1) keepn = 1;
-    keep = keep && rank < keepn;
-    pos = rank;
-    len = keepn;
-  }
-  if (i < n) {
-    if (s == 0) adj_len[i] = len;
-    if (keep) {
-      adj_j[(uint64_t)i * K + pos] = j;
-      adj_w[(uint64_t)i * K + pos] = w;
-      if (j - r0 < nr) atomicAdd(&cnt_in[j - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
+    const uint32_t km = half_ballot(keep[r], half);
+    len[r] = (uint32_t)__popc(km);
+    pos[r] = (uint32_t)__popc(km & ((1u << s) - 1u));  // place among the kept entries, in table order
+    if (sparsify && len[r] > 2) {
+      // place in the stable descending order by score: kept entries with a larger score, or an equal one earlier in the table
+      uint32_t rank = 0;
+      for (int t = 0; t < (int)K; ++t) {  // (entries past K are never kept)
+        const double so = __shfl(score, t, 32);
+        const bool ko = (km >> t) & 1u;
+        rank += (ko && (so > score || (so == score && t < s))) ? 1u : 0u;
+      }
+      uint32_t keepn = len[r] / 2;
+      if (keepn < 1) keepn = 1;
+      keep[r] = keep[r] && rank < keepn;
+      pos[r] = rank;
+      len[r] = keepn;
     }
   }
+  uint32_t slot[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    slot[r] = 0;
+    if (keep[r] && j[r] - r0 < nr) slot[r] = atomicAdd(&cnt_in[j[r] - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = i0 + r;
+    if (i < n) {
+      if (s == 0) adj_len[i] = len[r];
+      if (keep[r]) {
+        adj_j[(uint64_t)i * K + pos[r]] = j[r];
+        adj_w[(uint64_t)i * K + pos[r]] = w[r];
+        if (adj_slot && j[r] - r0 < nr) adj_slot[(uint64_t)i * K + pos[r]] = slot[r];
+      }
+    }
+  }
+}
+
+// ---- the round-4 form of the stages around it (K <= 32, "assembly_lanes" 2) -----------------------------------------------------
+// Degrees: a wave takes 64 rows = 64 K consecutive entries of the table and reads them side by side (the 32-lanes-per-row form
+// leaves 15 of 32 lanes idle at K = 17 and moved 0.8 TB/s); the hit bits of the K loads go through LDS as K ballots, lane r counts
+// the K bits of row r.
+// (LDS traffic between the lanes of one wave: the hardware keeps a wave's LDS operations in order, the compiler is told not to move
+// memory operations across this point)
+__device__ __forceinline__ void lanes_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void degree_rows64_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
+                                                            double eps, uint32_t *__restrict__ deg, unsigned long long *__restrict__ deg_sum) {
+  __shared__ unsigned long long s_bits[4][34];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long total = 0;
+  for (uint64_t row0 = ((uint64_t)blockIdx.x * 4 + wv) * 64; row0 < n; row0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t e0 = row0 * K, e_end = min((uint64_t)n, row0 + 64) * K;
+    for (uint32_t t = 0; t < K; ++t) {
+      const uint64_t e = e0 + (uint64_t)t * 64 + lane;
+      bool hit = false;
+      if (e < e_end) {
+        const uint32_t j = nbr_idx[e];
+        const uint32_t i = (uint32_t)row0 + (t * 64u + (uint32_t)lane) / K;
+        hit = j != kNoIdx && j != i && nbr_dist[e] <= eps;
+      }
+      const unsigned long long b = __ballot(hit);
+      if (lane == 0) s_bits[wv][t] = b;
+    }
+    if (lane == 0) s_bits[wv][K] = 0;
+    lanes_sync();
+    const uint32_t p = (uint32_t)lane * K, w0 = p >> 6, sh = p & 63u;
+    unsigned long long v = s_bits[wv][w0] >> sh;
+    if (sh) v |= s_bits[wv][w0 + 1] << (64u - sh);
+    const uint32_t c = (uint32_t)__builtin_popcountll(v & ((1ull << K) - 1ull));
+    if (row0 + lane < n) deg[row0 + lane] = c;
+    total += c;
+    lanes_sync();
+  }
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  if (lane == 0 && total) atomicAdd(deg_sum, total);
+}
+
+// a reverse edge as the scatter stores it: one 16-byte write instead of a 4-byte and an 8-byte one in two arrays
+struct __align__(16) RevEdge {
+  uint32_t src, pad;
+  double w;
+};
+
+// Reverse edges, 32 lanes per row: the kept edges of a row are read side by side, an edge goes to the place the counting atomic of
+// adjacency32_kernel gave it (no cursor atomics; one thread per row with a returning atomic per edge took 0.61 ms at 1 M rows)
+template <int R>
+__global__ __launch_bounds__(256) void fill_reverse32_kernel(const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w,
+                                                             const uint32_t *__restrict__ adj_slot, const uint32_t *__restrict__ adj_len, uint32_t n,
+                                                             uint32_t K, const uint64_t *__restrict__ rev_ptr, RevEdge *__restrict__ rev, uint32_t r0,
+                                                             uint32_t nr) {
+  // (R rows per half wave, each round of loads issued for all of them: three dependent round trips per edge)
+  const uint32_t s = threadIdx.x & 31u;
+  const uint32_t i0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 5) * R;
+  uint32_t len[R], j[R], slot[R];
+  double w[R];
+  uint64_t base[R];
+  bool on[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) len[r] = i0 + r < n ? adj_len[i0 + r] : 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    on[r] = s < len[r];
+    const uint64_t at = on[r] ? (uint64_t)(i0 + r) * K + s : 0;
+    j[r] = adj_j[at] - r0;
+    slot[r] = adj_slot[at];
+    w[r] = adj_w[at];
+    on[r] = on[r] && j[r] < nr;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) base[r] = rev_ptr[on[r] ? j[r] : 0];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (on[r]) {
+      RevEdge e;
+      e.src = i0 + r;
+      e.pad = 0;
+      e.w = w[r];
+      rev[base[r] + slot[r]] = e;
+    }
+}
+
+// union size of a row over the packed reverse edges (union_count32_kernel's walk)
+__global__ __launch_bounds__(256) void union_count32r_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len, uint32_t nr, uint32_t K,
+                                                             const uint64_t *__restrict__ rev_ptr, const RevEdge *__restrict__ rev,
+                                                             uint32_t *__restrict__ ucnt, uint32_t r0) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+  const uint32_t li = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const bool live = li < nr;
+  const uint32_t i = r0 + (live ? li : 0u);
+  const uint32_t len = live ? adj_len[i] : 0u;
+  const uint32_t mine = (uint32_t)s < len ? adj_j[(uint64_t)i * K + s] : kNoIdx;
+  const uint64_t e0 = live ? rev_ptr[li] : 0, e1 = live ? rev_ptr[li + 1] : 0;
+  uint32_t c = len;
+  const uint64_t span = e1 - e0;
+  const uint64_t span_o = __shfl_xor((unsigned long long)span, 32, 64);
+  const uint64_t trips = ((span > span_o ? span : span_o) + 31) / 32;
+  const uint32_t len_o = __shfl_xor(len, 32, 64), len_m = len > len_o ? len : len_o;
+  for (uint64_t t = 0; t < trips; ++t) {
+    const uint64_t e = e0 + t * 32 + s;
+    const bool have = e < e1;
+    const uint32_t src = have ? rev[e].src : kNoIdx;
+    bool found = false;
+    for (uint32_t q = 0; q < len_m; ++q) {
+      const uint32_t a = __shfl(mine, (int)q, 32);
+      found = found || (q < len && a == src);
+    }
+    c += (uint32_t)__popc(half_ballot(have && !found, half));
+  }
+  if (live && s == 0) ucnt[li] = c;
 }
 
 // union size of a row, 32 lanes per row: the out-neighbours sit one per lane, the in-edges pass by 32 at a time
@@ -597,6 +748,387 @@ __global__ __launch_bounds__(256) void write_rows_big_kernel(
   }
 }
 
+// ---- K5, round-4 form: the union ordered by RANK COUNTING ----------------------------------------------------------------------
+// W lanes per row as above, but instead of a bitonic network over the lanes (15 stages of three shuffles at W = 32) every lane
+// counts the entries with a smaller column -- the rows of a k-NN graph hold ~14 entries, so that is ~14 shuffles --, the entries
+// move to their rank with three ds_permute, and everything behind (degree in column order, diagonal, the writes) is as before.
+template <int W>
+__device__ __forceinline__ void row_entry_load(const int lane, const uint32_t i, const uint32_t len, const uint64_t rs, const uint32_t nrev,
+                                               const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w, const uint32_t K,
+                                               const RevEdge *__restrict__ rev, uint32_t &col, double &w) {
+  const int l = lane & (W - 1);
+  col = 0xFFFFFFFFu;  // invalid entries sort to the end
+  w = 0.0;
+  if ((uint32_t)l < len) {
+    col = adj_j[(uint64_t)i * K + l];
+    w = adj_w[(uint64_t)i * K + l];
+  } else if ((uint32_t)l < len + nrev) {
+    const RevEdge e = rev[rs + l - len];
+    col = e.src;
+    w = e.w;
+  }
+}
+// (o: where the row starts in the CSR = eptr[li] + li)
+template <int W>
+__device__ __forceinline__ void row_finish_ranked(const int lane, const uint32_t li, const uint32_t i, const uint32_t len, const uint32_t nrev,
+                                                  const uint64_t o, uint32_t col, double w, uint64_t *__restrict__ indptr,
+                                                  uint64_t *__restrict__ indices, double *__restrict__ data) {
+  const int l = lane & (W - 1), first = lane & ~(W - 1);
+  const uint32_t len_max = W == 64 ? len : max((uint32_t)__builtin_amdgcn_readlane((int)len, 0), (uint32_t)__builtin_amdgcn_readlane((int)len, 32));
+  bool dup = false;  // in-edges whose source is already an out-neighbour are dropped (the out-edge carries the pair)
+  for (uint32_t s = 0; s < len_max; ++s) {
+    const uint32_t a = __shfl(col, first + (int)s, 64);
+    dup = dup || (s < len && (uint32_t)l >= len && a == col);
+  }
+  if (dup) col = 0xFFFFFFFFu;
+  const uint32_t tot = len + nrev;
+  const uint32_t tot_max = W == 64 ? tot : max((uint32_t)__builtin_amdgcn_readlane((int)tot, 0), (uint32_t)__builtin_amdgcn_readlane((int)tot, 32));
+  uint32_t rank = 0;  // valid entries with a smaller column (the columns of valid entries are distinct)
+  for (uint32_t s = 0; s < tot_max; ++s) {
+    const uint32_t a = __shfl(col, first + (int)s, 64);
+    rank += (s < tot && a < col) ? 1u : 0u;
+  }
+  const unsigned long long row_lanes = W == 64 ? ~0ull : 0xFFFFFFFFull;
+  const bool valid = col != 0xFFFFFFFFu;
+  const unsigned long long vm = (__ballot(valid) >> first) & row_lanes;
+  const uint32_t L = (uint32_t)__builtin_popcountll(vm);  // = eptr[li + 1] - eptr[li]
+  // the invalid lanes take the places behind the valid ones, in lane order: the ranks are a permutation of the row's lanes
+  if (!valid) rank = L + (uint32_t)__builtin_popcountll(~vm & row_lanes & ((1ull << l) - 1ull));
+  const int dest = (first + (int)rank) * 4;
+  col = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)col);
+  {
+    const int lo = __builtin_amdgcn_ds_permute(dest, __double2loint(w)), hi = __builtin_amdgcn_ds_permute(dest, __double2hiint(w));
+    w = __hiloint2double(hi, lo);
+  }
+  const uint32_t L_max = W == 64 ? L : max((uint32_t)__builtin_amdgcn_readlane((int)L, 0), (uint32_t)__builtin_amdgcn_readlane((int)L, 32));
+  double degree = 0.0;  // sequential sum in column order (src/laplacian.rs:369)
+  for (uint32_t s = 0; s < L_max; ++s) {
+    const double t = __shfl(w, first + (int)s, 64);
+    if (s < L) degree = __dadd_rn(degree, t);
+  }
+  const uint32_t below = (uint32_t)__builtin_popcountll((__ballot(col < i) >> first) & row_lanes);  // entries left of the diagonal
+  if (l == 0) {
+    indptr[li] = o;
+    indices[o + below] = i;
+    data[o + below] = degree;
+  }
+  if ((uint32_t)l < L) {
+    const uint64_t at = o + l + ((uint32_t)l >= below ? 1 : 0);
+    indices[at] = col;
+    data[at] = -w;
+  }
+}
+
+constexpr uint32_t kMidMax = 512, kMidPer = kMidMax / 64;  // rows a wave orders by itself (write_rows_mid_kernel)
+// A wave takes R pairs of rows (2 w R .. 2 w R + 2 R - 1), their loads issued round by round for all of them (a pair alone: two
+// dependent round trips and ~14 shuffles of work -- at 1 M rows the 32 waves of a CU mostly waited: 0.46 ms).  A pair sits side
+// by side on the wave's halves when both unions have at most 32 entries before the duplicate check (nearly all rows of a k-NN
+// graph with k = 16); otherwise its rows take all 64 lanes one after the other; rows of more than 64 entries go to the lists of
+// the two kernels below.
+template <int R>
+__global__ __launch_bounds__(256) void write_rows_ranked_kernel(
+    const uint32_t *__restrict__ adj_j, const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t n,
+    uint32_t K, const uint64_t *__restrict__ rev_ptr, const RevEdge *__restrict__ rev, const uint64_t *__restrict__ eptr,
+    uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices, double *__restrict__ data, uint32_t *__restrict__ mid_rows,
+    uint32_t *__restrict__ big_rows, uint32_t *__restrict__ counts, uint32_t r0) {
+  // n = rows of the range [r0, r0 + n): li = position in it (eptr, rev_ptr, indptr), i = global row (adj_*, the diagonal)
+  const int lane = threadIdx.x & 63;
+  const bool hb = lane >= 32;
+  if (blockIdx.x == 0 && threadIdx.x == 0) indptr[n] = eptr[n] + n;
+  if (n == 0) return;
+  const uint32_t p0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * R;
+  uint32_t liA[R], lenA[R], lenB[R];
+  uint64_t rp0[R], rp1[R], rp2[R], eA[R], eB[R];
+  bool haveA[R], haveB[R], fast[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    liA[r] = 2u * (p0 + r);
+    haveA[r] = liA[r] < n;
+    haveB[r] = liA[r] + 1 < n;
+    const uint32_t a = haveA[r] ? liA[r] : 0u, b = haveB[r] ? liA[r] + 1 : a;
+    lenA[r] = adj_len[r0 + a];
+    lenB[r] = adj_len[r0 + b];
+    rp0[r] = rev_ptr[a];
+    rp1[r] = rev_ptr[a + 1];
+    rp2[r] = rev_ptr[b + 1];
+    eA[r] = eptr[a];
+    eB[r] = eptr[b];
+  }
+  uint32_t col[R];
+  double w[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t cntA = lenA[r] + (rp1[r] - rp0[r]), cntB = lenB[r] + (rp2[r] - rp1[r]);
+    if (lane == 0) {
+      if (haveA[r] && cntA > 64) {
+        if (cntA <= kMidMax) mid_rows[atomicAdd(counts, 1u)] = liA[r];
+        else big_rows[atomicAdd(counts + 1, 1u)] = liA[r];
+      }
+      if (haveB[r] && cntB > 64) {
+        if (cntB <= kMidMax) mid_rows[atomicAdd(counts, 1u)] = liA[r] + 1;
+        else big_rows[atomicAdd(counts + 1, 1u)] = liA[r] + 1;
+      }
+    }
+    fast[r] = haveB[r] && cntA <= 32 && cntB <= 32;
+    col[r] = 0xFFFFFFFFu;
+    w[r] = 0.0;
+    if (fast[r])
+      row_entry_load<32>(lane, r0 + liA[r] + (hb ? 1u : 0u), hb ? lenB[r] : lenA[r], hb ? rp1[r] : rp0[r],
+                         (uint32_t)(hb ? rp2[r] - rp1[r] : rp1[r] - rp0[r]), adj_j, adj_w, K, rev, col[r], w[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!haveA[r]) continue;
+    if (fast[r]) {
+      const uint32_t li = liA[r] + (hb ? 1u : 0u);
+      row_finish_ranked<32>(lane, li, r0 + li, hb ? lenB[r] : lenA[r], (uint32_t)(hb ? rp2[r] - rp1[r] : rp1[r] - rp0[r]), (hb ? eB[r] : eA[r]) + li,
+                            col[r], w[r], indptr, indices, data);
+    } else {
+      const uint64_t cntA = lenA[r] + (rp1[r] - rp0[r]), cntB = lenB[r] + (rp2[r] - rp1[r]);
+      if (cntA <= 64) {
+        uint32_t c;
+        double v;
+        row_entry_load<64>(lane, r0 + liA[r], lenA[r], rp0[r], (uint32_t)(rp1[r] - rp0[r]), adj_j, adj_w, K, rev, c, v);
+        row_finish_ranked<64>(lane, liA[r], r0 + liA[r], lenA[r], (uint32_t)(rp1[r] - rp0[r]), eA[r] + liA[r], c, v, indptr, indices, data);
+      }
+      if (haveB[r] && cntB <= 64) {
+        uint32_t c;
+        double v;
+        row_entry_load<64>(lane, r0 + liA[r] + 1, lenB[r], rp1[r], (uint32_t)(rp2[r] - rp1[r]), adj_j, adj_w, K, rev, c, v);
+        row_finish_ranked<64>(lane, liA[r] + 1, r0 + liA[r] + 1, lenB[r], (uint32_t)(rp2[r] - rp1[r]), eB[r] + liA[r] + 1, c, v, indptr, indices, data);
+      }
+    }
+  }
+}
+
+// Hub rows of 65 .. kMidMax entries: one WAVE per row (four per workgroup), the union in the wave's LDS, ordered by rank counting
+// like the short rows: a lane holds up to kMidMax / 64 entries in registers, counts for each the entries with a smaller column
+// (broadcast reads of the LDS copy), and the entries go back to LDS at their ranks; the degree is the sequential sum in column
+// order (src/laplacian.rs:369) over values passed from lane to lane (a workgroup per row with a bitonic network and a barrier per
+// stage was 0.42 ms at 1 M rows; a wave per row with the same network 0.36 ms: ~30 dependent passes over LDS per row).
+__global__ __launch_bounds__(256) void write_rows_mid_kernel(
+    const uint32_t *__restrict__ rows_list, const uint32_t *__restrict__ rows_count, const uint32_t *__restrict__ adj_j,
+    const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+    const RevEdge *__restrict__ rev, const uint64_t *__restrict__ eptr, uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
+    double *__restrict__ data, uint32_t r0) {
+  __shared__ uint32_t s_col_all[4 * kMidMax];
+  __shared__ double s_w_all[4 * kMidMax];
+  const uint32_t unit = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  uint32_t *s_col = s_col_all + unit * kMidMax;
+  double *s_w = s_w_all + unit * kMidMax;
+  const uint32_t count = *rows_count;
+  for (uint32_t b = blockIdx.x * 4 + unit; b < count; b += gridDim.x * 4) {
+    const uint32_t li = rows_list[b], i = r0 + li;
+    const uint32_t len = adj_len[i];
+    const uint64_t rs = rev_ptr[li], o = eptr[li] + li;
+    const uint32_t nrev = (uint32_t)(rev_ptr[li + 1] - rs), total = len + nrev;  // 64 < total <= kMidMax
+    const uint32_t mine = lane < len ? adj_j[(uint64_t)i * K + lane] : 0xFFFFFFFFu;  // (K <= 32: the out-neighbours sit one per lane)
+    uint32_t col[kMidPer], rank[kMidPer];
+    double w[kMidPer];
+    lanes_sync();  // the row before is done with the arrays
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m) {
+      const uint32_t e = m * 64 + lane;
+      col[m] = 0xFFFFFFFFu;
+      w[m] = 0.0;
+      if (e < len) {
+        col[m] = adj_j[(uint64_t)i * K + e];
+        w[m] = adj_w[(uint64_t)i * K + e];
+      } else if (e < total) {
+        const RevEdge r = rev[rs + e - len];
+        col[m] = r.src;
+        w[m] = r.w;
+      }
+    }
+    // in-edges whose source is an out-neighbour are dropped (the out-edge carries the pair)
+    for (uint32_t q = 0; q < len; ++q) {
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)q);
+#pragma unroll
+      for (uint32_t m = 0; m < kMidPer; ++m)
+        if (m * 64 + lane >= len && col[m] == a) col[m] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m) {
+      if (m * 64 < total) s_col[m * 64 + lane] = col[m];
+      rank[m] = 0;
+    }
+    lanes_sync();
+    for (uint32_t s_ = 0; s_ < total; ++s_) {
+      const uint32_t a = s_col[s_];  // (one address for the wave: a broadcast)
+#pragma unroll
+      for (uint32_t m = 0; m < kMidPer; ++m) rank[m] += a < col[m] ? 1u : 0u;
+    }
+    lanes_sync();  // every lane has read the unordered copy
+    uint32_t below = 0;
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m)
+      if (col[m] != 0xFFFFFFFFu) {  // (valid columns are distinct: the ranks of the valid entries are 0 .. L - 1)
+        s_col[rank[m]] = col[m];
+        s_w[rank[m]] = w[m];
+        below += col[m] < i ? 1u : 0u;
+      }
+    for (int o_ = 32; o_ > 0; o_ >>= 1) below += __shfl_xor(below, o_, 64);
+    lanes_sync();
+    const uint32_t L = (uint32_t)(eptr[li + 1] - eptr[li]);  // valid entries
+    double ws[kMidPer];
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m) ws[m] = m * 64 + lane < L ? s_w[m * 64 + lane] : 0.0;
+    double degree = 0.0;
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m) {
+      if (m * 64 >= L) break;
+      const uint32_t upto = min(64u, L - m * 64);
+      for (uint32_t t = 0; t < upto; ++t) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(ws[m]), (int)t), hi = __builtin_amdgcn_readlane(__double2hiint(ws[m]), (int)t);
+        degree = __dadd_rn(degree, __hiloint2double(hi, lo));
+      }
+    }
+    if (lane == 0) {
+      indptr[li] = o;
+      indices[o + below] = i;
+      data[o + below] = degree;
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < kMidPer; ++m) {
+      const uint32_t e = m * 64 + lane;
+      if (e < L) {
+        const uint64_t at = o + e + (e >= below ? 1 : 0);
+        indices[at] = s_col[e];
+        data[at] = -ws[m];
+      }
+    }
+  }
+}
+
+// Rows of kMidMax + 1 .. kBigMax entries: one workgroup per row, a bitonic network over LDS with a barrier per stage.
+__global__ __launch_bounds__(256) void write_rows_hub_kernel(
+    const uint32_t *__restrict__ rows_list, const uint32_t *__restrict__ rows_count, const uint32_t *__restrict__ adj_j,
+    const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t K, const uint64_t *__restrict__ rev_ptr,
+    const RevEdge *__restrict__ rev, const uint64_t *__restrict__ eptr, uint64_t *__restrict__ indptr, uint64_t *__restrict__ indices,
+    double *__restrict__ data, uint32_t r0) {
+  __shared__ uint32_t s_col[kBigMax];
+  __shared__ double s_w[kBigMax];
+  __shared__ double s_degree;
+  __shared__ uint32_t s_below;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t count = *rows_count;
+  for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
+    const uint32_t li = rows_list[b], i = r0 + li;
+    const uint32_t len = adj_len[i];
+    const uint64_t rs = rev_ptr[li];
+    const uint32_t nrev = (uint32_t)(rev_ptr[li + 1] - rs), total = len + nrev;
+    if (total > kBigMax) continue;  // (write_rows_serial_kernel)
+    uint32_t P = 64;
+    while (P < total) P <<= 1;
+    __syncthreads();  // the row before is done with the arrays
+    if (tid == 0) s_below = 0;
+    for (uint32_t e = tid; e < P; e += blockDim.x) {
+      uint32_t c = 0xFFFFFFFFu;
+      double v = 0.0;
+      if (e < len) {
+        c = adj_j[(uint64_t)i * K + e];
+        v = adj_w[(uint64_t)i * K + e];
+      } else if (e < total) {
+        const RevEdge r = rev[rs + e - len];
+        c = r.src;
+        v = r.w;
+        if (in_adj(adj_j + (uint64_t)i * K, len, c)) c = 0xFFFFFFFFu;  // the out-edge carries the pair
+      }
+      s_col[e] = c;
+      s_w[e] = v;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t e = tid; e < P; e += blockDim.x) {
+          const uint32_t partner = e ^ j;
+          if (partner > e) {
+            const bool up = (e & k) == 0;
+            const uint32_t a = s_col[e], c2 = s_col[partner];
+            if (up ? (a > c2) : (a < c2)) {
+              s_col[e] = c2;
+              s_col[partner] = a;
+              const double t = s_w[e];
+              s_w[e] = s_w[partner];
+              s_w[partner] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    const uint32_t L = (uint32_t)(eptr[li + 1] - eptr[li]);  // valid entries (the invalid ones sorted behind them)
+    uint32_t below = 0;
+    for (uint32_t e = tid; e < L; e += blockDim.x) below += s_col[e] < i ? 1u : 0u;
+    if (below) atomicAdd(&s_below, below);
+    if (tid == 0) {
+      double degree = 0.0;  // sequential sum in column order (src/laplacian.rs:369)
+      for (uint32_t e = 0; e < L; ++e) degree = __dadd_rn(degree, s_w[e]);
+      s_degree = degree;
+    }
+    __syncthreads();
+    const uint64_t o = eptr[li] + li;
+    const uint32_t nb = s_below;
+    if (tid == 0) {
+      indptr[li] = o;
+      indices[o + nb] = i;
+      data[o + nb] = s_degree;
+    }
+    for (uint32_t e = tid; e < L; e += blockDim.x) {
+      const uint64_t at = o + e + (e >= nb ? 1 : 0);
+      indices[at] = s_col[e];
+      data[at] = -s_w[e];
+    }
+  }
+}
+
+// rows past kBigMax entries: the serial form on the packed reverse edges (one thread per row; ecol / ew: scratch of the union's size)
+__global__ void write_rows_serial_kernel(const uint32_t *__restrict__ rows_list, const uint32_t *__restrict__ rows_count, const uint32_t *__restrict__ adj_j,
+                                         const double *__restrict__ adj_w, const uint32_t *__restrict__ adj_len, uint32_t K,
+                                         const uint64_t *__restrict__ rev_ptr, const RevEdge *__restrict__ rev, const uint64_t *__restrict__ eptr,
+                                         uint32_t *__restrict__ ecol, double *__restrict__ ew, uint64_t *__restrict__ indptr,
+                                         uint64_t *__restrict__ indices, double *__restrict__ data, uint32_t r0) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= *rows_count) return;
+  const uint32_t li = rows_list[b], i = r0 + li;
+  const uint32_t len = adj_len[i];
+  if (len + (rev_ptr[li + 1] - rev_ptr[li]) <= kBigMax) return;
+  const uint32_t *aj = adj_j + (uint64_t)i * K;
+  const double *aw = adj_w + (uint64_t)i * K;
+  uint32_t *col = ecol + eptr[li];
+  double *w = ew + eptr[li];
+  uint32_t L = 0;
+  for (uint32_t s = 0; s < len; ++s) {
+    col[L] = aj[s];
+    w[L++] = aw[s];
+  }
+  for (uint64_t e = rev_ptr[li]; e < rev_ptr[li + 1]; ++e) {
+    const uint32_t src = rev[e].src;
+    if (!in_adj(aj, len, src)) {
+      col[L] = src;
+      w[L++] = rev[e].w;
+    }
+  }
+  sort_row(col, w, L);
+  double degree = 0.0;
+  for (uint32_t s = 0; s < L; ++s) degree = __dadd_rn(degree, w[s]);
+  uint64_t o = eptr[li] + li;
+  indptr[li] = o;
+  bool diag_done = false;
+  for (uint32_t s = 0; s < L; ++s) {
+    if (!diag_done && col[s] > i) {
+      indices[o] = i;
+      data[o++] = degree;
+      diag_done = true;
+    }
+    indices[o] = col[s];
+    data[o++] = -w[s];
+  }
+  if (!diag_done) {
+    indices[o] = i;
+    data[o] = degree;
+  }
+}
+
 // Rows [row_begin, row_begin + row_count) of the Laplacian of the n-node graph whose complete neighbour table is given
 // (row-sharded builds: every rank holds the all-gathered table and assembles its own row block; the whole matrix is the
 // range [0, n)).  Weights and the pruning need the degrees of ALL rows (two passes over the table, replicated: they are
@@ -612,33 +1144,47 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   const unsigned gb = cdiv(n, 256), gr = std::max(1u, cdiv(nr, 256));
   hipStream_t st = ctx->stream;
 
-  DevBuf<uint32_t> deg, adj_j, adj_len, cnt_in, cursor, rev_src, ucnt, ecol;
+  DevBuf<uint32_t> deg, adj_j, adj_len, cnt_in, cursor, rev_src, ucnt, ecol, adj_slot;
   DevBuf<double> adj_w, rev_w, ew;
+  DevBuf<RevEdge> rev;
   DevBuf<unsigned long long> deg_sum;
   DevBuf<uint64_t> rev_ptr, eptr;
+  // "assembly_lanes" 2 (K <= 32): the round-4 kernels -- degrees 64 rows per wave, the reverse edges placed by the counting atomic's
+  // return value into one array of 16-byte records sized by its bound n K (no read-back of their number), unions ordered by rank
+  // counting, hub rows a wave each.  1: the 32-lanes-per-row kernels of round 3; 0 / K > 32: one thread per row.
+  const bool lanes32 = K <= 32 && ctx->opt_assembly_lanes;
+  const bool ranked = lanes32 && ctx->opt_assembly_lanes >= 2;
   AS_TRY(deg.alloc(ctx, n));
   AS_TRY(deg_sum.alloc(ctx, 1));
   AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
   AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
   AS_TRY(adj_len.alloc(ctx, n));
   AS_TRY(cnt_in.alloc(ctx, (size_t)nr + 1));
-  AS_TRY(cursor.alloc(ctx, (size_t)nr + 1));
+  if (!ranked) AS_TRY(cursor.alloc(ctx, (size_t)nr + 1));
   AS_TRY(rev_ptr.alloc(ctx, (size_t)nr + 1));
   AS_TRY(ucnt.alloc(ctx, (size_t)nr + 1));
   AS_TRY(eptr.alloc(ctx, (size_t)nr + 1));
+  if (ranked) {
+    AS_TRY(adj_slot.alloc(ctx, (size_t)n * K));
+    AS_TRY(rev.alloc(ctx, (size_t)n * K));  // (every kept edge could point into the range)
+  }
   AS_HIP(ctx, hipMemsetAsync(deg_sum.p, 0, sizeof(unsigned long long), st));
   AS_HIP(ctx, hipMemsetAsync(cnt_in.p, 0, sizeof(uint32_t) * ((size_t)nr + 1), st));
-  AS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * ((size_t)nr + 1), st));
+  if (!ranked) AS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * ((size_t)nr + 1), st));
 
   uint64_t n_edges_dir = 0, n_union = 0;
   {
     ProfScope ps(ctx, "graph_assembly");
-    const bool lanes32 = K <= 32 && ctx->opt_assembly_lanes;
     const unsigned gb32 = (unsigned)cdiv((uint64_t)n * 32, (uint64_t)256), gr32 = (unsigned)std::max<uint64_t>(1, cdiv((uint64_t)nr * 32, (uint64_t)256));
-    if (lanes32) {
+    if (ranked) {
+      hipLaunchKernelGGL(degree_rows64_kernel, dim3((unsigned)std::min<uint64_t>(cdiv((uint64_t)n, (uint64_t)256), 256 * 8)), dim3(256), 0, st, nbr_idx,
+                         nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
+      hipLaunchKernelGGL(adjacency32_kernel<1>, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
+                         adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr, adj_slot.p);
+    } else if (lanes32) {
       hipLaunchKernelGGL(degree32_kernel, dim3(std::min(gb32, 4096u)), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
-      hipLaunchKernelGGL(adjacency32_kernel, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
-                         adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
+      hipLaunchKernelGGL(adjacency32_kernel<1>, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
+                         adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr, (uint32_t *)nullptr);
     } else {
       hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
     }
@@ -650,18 +1196,24 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
       hipLaunchKernelGGL(adjacency_kernel<kMaxK>, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
                          gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
     AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, nr, rev_ptr.p));
-    AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));
-    AS_HIP(ctx, hipStreamSynchronize(st));
-    AS_TRY(rev_src.alloc(ctx, n_edges_dir));
-    AS_TRY(rev_w.alloc(ctx, n_edges_dir));
-    hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
-                       rev_ptr.p, cursor.p, rev_src.p, rev_w.p, r0, nr);
-    if (lanes32)
-      hipLaunchKernelGGL(union_count32_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev_src.p, ucnt.p, r0);
-    else
-      hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
-                         rev_src.p, ucnt.p, r0);
+    if (ranked) {
+      hipLaunchKernelGGL(fill_reverse32_kernel<2>, dim3((unsigned)cdiv((uint64_t)cdiv((uint64_t)n, (uint64_t)2) * 32, (uint64_t)256)), dim3(256), 0, st, adj_j.p, adj_w.p, adj_slot.p, adj_len.p, n, K, rev_ptr.p, rev.p, r0, nr);
+      hipLaunchKernelGGL(union_count32r_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev.p, ucnt.p, r0);
+    } else {
+      AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));
+      AS_HIP(ctx, hipStreamSynchronize(st));
+      AS_TRY(rev_src.alloc(ctx, n_edges_dir));
+      AS_TRY(rev_w.alloc(ctx, n_edges_dir));
+      hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
+                         rev_ptr.p, cursor.p, rev_src.p, rev_w.p, r0, nr);
+      if (lanes32)
+        hipLaunchKernelGGL(union_count32_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev_src.p, ucnt.p, r0);
+      else
+        hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
+                           rev_src.p, ucnt.p, r0);
+    }
     AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, nr, eptr.p));
+    if (ranked) AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));  // (a statistic here: one read-back for both)
     AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + nr, sizeof(uint64_t)));
     AS_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -694,11 +1246,22 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   }
   AS_TRY(ecol.alloc(ctx, n_union));
   AS_TRY(ew.alloc(ctx, n_union));
-  DevBuf<uint32_t> big_rows, big_count;
+  DevBuf<uint32_t> big_rows, big_count, mid_rows;
   AS_TRY(big_rows.alloc(ctx, (size_t)nr + 1));
-  AS_TRY(big_count.alloc(ctx, 1));
-  AS_HIP(ctx, hipMemsetAsync(big_count.p, 0, sizeof(uint32_t), st));
-  {
+  AS_TRY(big_count.alloc(ctx, 2));
+  AS_HIP(ctx, hipMemsetAsync(big_count.p, 0, 2 * sizeof(uint32_t), st));
+  if (ranked) {
+    AS_TRY(mid_rows.alloc(ctx, (size_t)nr + 1));
+    ProfScope ps(ctx, "graph_assembly");
+    hipLaunchKernelGGL(write_rows_ranked_kernel<2>, dim3(cdiv((uint64_t)nr + 1, 16)), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, nr, K, rev_ptr.p, rev.p,
+                       eptr.p, m->indptr, m->indices, m->data, mid_rows.p, big_rows.p, big_count.p, r0);
+    hipLaunchKernelGGL(write_rows_mid_kernel, dim3(2048), dim3(256), 0, st, mid_rows.p, big_count.p, adj_j.p, adj_w.p, adj_len.p, K, rev_ptr.p, rev.p,
+                       eptr.p, m->indptr, m->indices, m->data, r0);
+    hipLaunchKernelGGL(write_rows_hub_kernel, dim3(512), dim3(256), 0, st, big_rows.p, big_count.p + 1, adj_j.p, adj_w.p, adj_len.p, K, rev_ptr.p,
+                       rev.p, eptr.p, m->indptr, m->indices, m->data, r0);
+    hipLaunchKernelGGL(write_rows_serial_kernel, dim3(cdiv((uint64_t)nr + 1, 256)), dim3(256), 0, st, big_rows.p, big_count.p + 1, adj_j.p, adj_w.p, adj_len.p,
+                       K, rev_ptr.p, rev.p, eptr.p, ecol.p, ew.p, m->indptr, m->indices, m->data, r0);
+  } else {
     ProfScope ps(ctx, "graph_assembly");
     hipLaunchKernelGGL(write_rows_kernel, dim3(cdiv((uint64_t)nr + 1, 8)), dim3(256), 0, st, adj_j.p, adj_w.p,
                        adj_len.p, nr, K, rev_ptr.p, rev_src.p, rev_w.p, eptr.p, ecol.p, ew.p, m->indptr,

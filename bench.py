@@ -573,6 +573,24 @@ def main():
             extra["roofline_scan"] = {"bound": "hbm", "kernel": "lambda_kernel_v3 (tau select + Rayleigh/dispersion, items + queries)",
                                       "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                                       "traffic": None, "avg_step_ms": lam_ms / steps, "algorithmic_bytes_per_step": bytes_per_step}
+            v3_steps = ctx.stat("taumode_v3_steps")
+            if v3_steps > 0 and d == 128:
+                # The kernel's other two limits (SURVEY.md 7 asks for the fraction against each).  Per item and Median: the four
+                # lanes of an item walk v3_steps edge steps of 7 f64 operations each, 3 x 128 for the diagonal term and the
+                # denominator, 4 x 638 min/max for the order statistic (32-sorter 191 compare-exchanges, the two merges, the
+                # median's half-cleaner), ~30 to finish; f64 vector peak = CUs x 4 SIMDs x 16 lanes x clock (an FMA counts once).
+                # LDS: every edge step reads a 16 B entry and two 8 B values per lane, the row is written once by the DMA and read
+                # once into registers; peak 128 B per clock and CU.
+                clock_hz, cus = 2.4e9, 256
+                ops_item = 28.0 * v3_steps + 384.0 + 2552.0 + 30.0
+                lds_item = 4.0 * v3_steps * 32.0 + 2.0 * 8.0 * d
+                items_s = (rows_here + nq) * steps / (lam_ms * 1e-3)
+                valu_peak, lds_peak = cus * 4 * 16 * clock_hz, cus * 128.0 * clock_hz
+                extra["roofline_scan"]["edge_steps_per_lane"] = v3_steps
+                extra["roofline_scan"]["f64_valu"] = {"ops_per_item": ops_item, "achieved_Tops": items_s * ops_item / 1e12, "peak_Tops": valu_peak / 1e12,
+                                                      "frac": items_s * ops_item / valu_peak}
+                extra["roofline_scan"]["lds"] = {"bytes_per_item": lds_item, "achieved_TBs": items_s * lds_item / 1e12, "peak_TBs": lds_peak / 1e12,
+                                                 "frac": items_s * lds_item / lds_peak}
             if world == 1:
                 rec = recorded_traffic("lambda_kernel", n, d)
                 if rec:

@@ -896,6 +896,62 @@ def test_hybrid_search_beyond_64(ctx):
         assert np.array_equal([g[1] for g in got], osc), (j, k)
 
 
+def test_graph_assembly_hub_rows_on_every_path(ctx):
+    """A neighbour table with hubs of every size class of the assembly (graph_assembly.hip): two nodes that ~12 000 rows point to
+    (the serial form past 4 096 entries), ten with ~1 200 in-edges (a workgroup per row), fifty with ~240 (a wave per row), the
+    rest short rows side by side.  The round-4 kernels ("assembly_lanes" 2), the 32-lanes-per-row ones (1) and the
+    thread-per-row form (0: its own sort and union code) must give the same CSR bit for bit, as whole matrix and as row blocks,
+    and the CSR keeps the reference's invariants (src/tests/test_laplacian.rs:51-152)."""
+    n, K = 12_000, 12
+    rng = np.random.default_rng(5)
+    idx = np.empty((n, K), dtype=np.uint64)
+    rows = np.arange(n)
+    idx[:, 0], idx[:, 1] = 0, 1
+    idx[:, 2] = 2 + rows % 50
+    idx[:, 3] = 100 + rows % 10
+    for i in range(n):
+        idx[i, 4:] = 200 + rng.choice(n - 200, size=K - 4, replace=False)
+    # a distance per unordered pair, as a cosine distance is (the union keeps one weight per pair: src/laplacian.rs:303-320)
+    pair = np.minimum(rows[:, None], idx.astype(np.int64)) * n + np.maximum(rows[:, None], idx.astype(np.int64))
+    dist = 0.01 + 0.44 * ((pair * 2654435761) % (1 << 32)) / float(1 << 32)
+    gp = A.GraphParams(0.5, 16, K - 1, 2.0, 0.25)
+    got = {}
+    for lanes in (2, 1, 0):
+        ctx.set_option("assembly_lanes", lanes)
+        try:
+            got[lanes] = A.laplacian_from_knn(idx, dist, gp, ctx=ctx).to_host()
+            if lanes == 2:
+                blocks = [A.laplacian_from_knn(idx, dist, gp, row_begin=a, row_count=b - a, ctx=ctx).to_host() for a, b in ((0, 5000), (5000, n))]
+        finally:
+            ctx.set_option("assembly_lanes", 2)
+    for lanes in (1, 0):
+        for a, b in zip(got[2], got[lanes]):
+            assert np.array_equal(a, b), lanes
+    indptr, indices, data = got[2]
+    assert np.array_equal(np.concatenate([blocks[0][0], blocks[1][0][1:] + blocks[0][0][-1]]), indptr)
+    assert np.array_equal(np.concatenate([blocks[0][1], blocks[1][1]]), indices) and np.array_equal(np.concatenate([blocks[0][2], blocks[1][2]]), data)
+    counts = np.diff(indptr.astype(np.int64))
+    assert counts[0] > 4096 and counts[1] > 4096 and 512 < counts[100] <= 4096 and 64 < counts[2] <= 512
+    rows_of = np.repeat(np.arange(n), counts)
+    cols = indices.astype(np.int64)
+    assert np.all((np.diff(cols) > 0) | (np.diff(rows_of) > 0))          # sorted, unique per row
+    diag = cols == rows_of
+    assert diag.sum() == n and np.all(data[~diag] <= 0) and np.all(data[diag] >= 0)
+    off = ~diag
+    key = np.minimum(rows_of[off], cols[off]) * n + np.maximum(rows_of[off], cols[off])
+    order = np.argsort(key, kind="stable")
+    k_sorted, v_sorted = key[order], data[off][order]
+    assert len(k_sorted) % 2 == 0 and np.array_equal(k_sorted[0::2], k_sorted[1::2]) and np.array_equal(v_sorted[0::2], v_sorted[1::2])
+    # the degree of a row is the sequential sum of its weights in column order (src/laplacian.rs:369)
+    for r in (0, 100, 2, 7000):
+        seg = slice(int(indptr[r]), int(indptr[r + 1]))
+        acc = 0.0
+        for c, v in zip(cols[seg], data[seg]):
+            if c != r:
+                acc = acc + (-v)
+        assert data[seg][cols[seg] == r][0] == acc
+
+
 def test_laplacian_row_blocks_stack_to_the_whole_matrix(ctx):
     """as_laplacian_from_knn_rows (the sharded assembly: every rank its own row block from the gathered table): blocks
     of consecutive ranges, hub rows and an empty range included, stacked = the CSR of as_laplacian_from_knn."""
