@@ -7,6 +7,10 @@
 #include <mutex>
 #include <thread>
 
+#include <unordered_map>
+#include <map>
+#include <deque>
+#include <vector>
 #include "common.h"
 
 using namespace asx;
@@ -74,6 +78,134 @@ std::mutex g_copy_call;  // one transfer at a time through the pool (contexts of
 }  // namespace
 
 namespace asx {
+
+// ---- handle memory cache (common.h) ---------------------------------------------------------------------------------------------
+namespace {
+struct HandleCache {
+  std::mutex mu;
+  std::unordered_map<void *, std::pair<int, size_t>> live;           // blocks handed out: device, bytes
+  std::multimap<std::pair<int, size_t>, void *> idle;                // blocks given back, by (device, bytes)
+  std::deque<std::pair<void *, std::pair<int, size_t>>> idle_order;  // ... oldest first, for eviction
+  size_t idle_bytes = 0;
+  size_t cap = [] {
+    const char *e = std::getenv("ARROWSPACE_HANDLE_CACHE_MB");
+    const long long mb = e ? std::atoll(e) : 4096;
+    return (size_t)(mb > 0 ? mb : 0) << 20;
+  }();
+  // evicts until at most `limit` idle bytes remain; returns the blocks to hipFree (outside the lock)
+  std::vector<void *> shrink(size_t limit) {
+    std::vector<void *> out;
+    while (idle_bytes > limit && !idle_order.empty()) {
+      auto v = idle_order.front();
+      idle_order.pop_front();
+      auto range = idle.equal_range(v.second);
+      for (auto it = range.first; it != range.second; ++it)
+        if (it->second == v.first) {
+          idle.erase(it);
+          idle_bytes -= v.second.second;
+          out.push_back(v.first);
+          break;
+        }
+    }
+    return out;
+  }
+};
+HandleCache &handle_cache() {
+  static HandleCache *c = new HandleCache();  // (never destroyed: handles may be freed during process exit)
+  return *c;
+}
+}  // namespace
+
+hipError_t handle_malloc(void **p, size_t bytes) {
+  HandleCache &c = handle_cache();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bytes = bytes ? bytes : 1;
+  void *hit = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.idle.find({dev, bytes});
+    if (it != c.idle.end()) {
+      hit = it->second;
+      c.idle.erase(it);
+      c.idle_bytes -= bytes;
+      for (auto o = c.idle_order.begin(); o != c.idle_order.end(); ++o)
+        if (o->first == hit) {
+          c.idle_order.erase(o);
+          break;
+        }
+    }
+  }
+  if (hit) {
+    // whatever still reads or writes the block on any stream of the device finishes first (what hipFree did for its last owner)
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    *p = hit;
+  } else {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // out of memory: give the idle blocks back and try once more
+      (void)hipGetLastError();
+      std::vector<void *> drop;
+      {
+        std::lock_guard<std::mutex> g(c.mu);
+        drop = c.shrink(0);
+      }
+      for (void *q : drop) (void)hipFree(q);
+      e = hipMalloc(p, bytes);
+      if (e != hipSuccess) return e;
+    }
+  }
+  std::lock_guard<std::mutex> g(c.mu);
+  c.live[*p] = {dev, bytes};
+  return hipSuccess;
+}
+
+hipError_t handle_free(void *p) {
+  if (!p) return hipSuccess;
+  HandleCache &c = handle_cache();
+  std::vector<void *> drop;
+  bool keep = false;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      const auto key = it->second;
+      c.live.erase(it);
+      if (c.cap > 0 && key.second <= c.cap) {
+        c.idle.insert({key, p});
+        c.idle_order.push_back({p, key});
+        c.idle_bytes += key.second;
+        keep = true;
+        drop = c.shrink(c.cap);
+      }
+    }
+  }
+  hipError_t e = hipSuccess;
+  for (void *q : drop) (void)hipFree(q);
+  if (!keep) e = hipFree(p);
+  return e;
+}
+
+void handle_cache_release() {
+  HandleCache &c = handle_cache();
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    drop = c.shrink(0);
+  }
+  for (void *q : drop) (void)hipFree(q);
+}
+
+void handle_cache_limit(int64_t mb) {
+  HandleCache &c = handle_cache();
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    c.cap = (size_t)(mb > 0 ? mb : 0) << 20;
+    drop = c.shrink(c.cap);
+  }
+  for (void *q : drop) (void)hipFree(q);
+}
 void host_copy_parallel(void *dst, const void *src, size_t bytes) {
   if (bytes < (1u << 20)) {
     std::memcpy(dst, src, bytes);
@@ -331,6 +463,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "join_cone_tiles") ctx->opt_join_cone_tiles = value != 0;
+  else if (n == "handle_cache_mb") handle_cache_limit(value);
   else if (n == "rerank_pair_bound") ctx->opt_rerank_pair_bound = value != 0;
   else if (n == "join_theta_band_second") ctx->opt_join_theta_band_second = value != 0;
   else if (n == "join_theta_band") ctx->opt_join_theta_band = std::min<int64_t>(std::max<int64_t>(0, value), 8);
@@ -354,6 +487,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
   else if (n == "join_order_pivots") ctx->opt_join_order_pivots = value;
+  else if (n == "join_theta_grouped_bad_e3") ctx->opt_join_theta_grouped_bad_e3 = value;
   else if (n == "join_theta_grouped") ctx->opt_join_theta_grouped = value;
   else if (n == "search_scan_order") ctx->opt_search_scan_order = value;
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
@@ -427,10 +561,10 @@ int as_device_upload(as_ctx *ctx, const void *host, uint64_t bytes, void **dev_o
   if (!dev_out || (bytes && !host)) return fail(ctx, AS_ERR_ARG, "null argument");
   *dev_out = nullptr;
   void *p = nullptr;
-  AS_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1));
+  AS_HIP(ctx, handle_malloc(&p, bytes ? bytes : 1));
   const hipError_t e = is_device_ptr(host) ? hipMemcpyAsync(p, host, bytes, hipMemcpyDeviceToDevice, ctx->stream) : copy_h2d(ctx, p, host, bytes);
   if (e != hipSuccess) {
-    (void)hipFree(p);
+    (void)handle_free(p);
     return fail(ctx, AS_ERR_HIP, std::string("as_device_upload: ") + hipGetErrorString(e));
   }
   *dev_out = p;
@@ -448,7 +582,7 @@ void as_device_free(as_ctx *ctx, void *dev) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)hipFree(dev);
+  (void)handle_free(dev);
 }
 
 uint64_t as_define_result_k(uint64_t k, uint64_t topk) {
@@ -725,7 +859,7 @@ int as_build_laplacian(as_ctx *ctx, const double *rows, uint64_t n_nodes, uint64
     // the neighbour search grouped the rows by direction: neighbours sit together in that order, which is what the item-graph
     // lambda kernels want to visit the rows in (as_csr_set_order)
     as_csr *m = *out;
-    if (hipMalloc((void **)&m->order, sizeof(uint32_t) * n_nodes) == hipSuccess) {
+    if (handle_malloc((void **)&m->order, sizeof(uint32_t) * n_nodes) == hipSuccess) {
       AS_HIP(ctx, hipMemcpyAsync(m->order, ctx->join_order, sizeof(uint32_t) * n_nodes, hipMemcpyDeviceToDevice, ctx->stream));
       m->order_state = 1;
     } else {
@@ -765,9 +899,9 @@ int as_csr_import(as_ctx *ctx, uint64_t n, uint64_t nnz, const uint64_t *indptr,
   m->n = n;
   m->n_cols = n;
   m->nnz = nnz;
-  AS_HIP(ctx, hipMalloc((void **)&m->indptr, sizeof(uint64_t) * (n + 1)));
-  AS_HIP(ctx, hipMalloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
-  AS_HIP(ctx, hipMalloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
+  AS_HIP(ctx, handle_malloc((void **)&m->indptr, sizeof(uint64_t) * (n + 1)));
+  AS_HIP(ctx, handle_malloc((void **)&m->indices, sizeof(uint64_t) * (nnz ? nnz : 1)));
+  AS_HIP(ctx, handle_malloc((void **)&m->data, sizeof(double) * (nnz ? nnz : 1)));
   auto put = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
     if (is_device_ptr(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
     return copy_h2d(ctx, dst, src, bytes);
@@ -786,18 +920,18 @@ void as_csr_free(as_csr *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->slab) {
-    (void)hipFree(m->slab);
+    (void)handle_free(m->slab);
   } else {
-    (void)hipFree(m->indptr);
-    (void)hipFree(m->indices);
-    (void)hipFree(m->data);
+    (void)handle_free(m->indptr);
+    (void)handle_free(m->indices);
+    (void)handle_free(m->data);
   }
-  if (m->packed) (void)hipFree(m->packed);
-  if (m->packed_upper) (void)hipFree(m->packed_upper);
-  if (m->v3_ent) (void)hipFree(m->v3_ent);
-  if (m->v3_diag) (void)hipFree(m->v3_diag);
+  if (m->packed) (void)handle_free(m->packed);
+  if (m->packed_upper) (void)handle_free(m->packed_upper);
+  if (m->v3_ent) (void)handle_free(m->v3_ent);
+  if (m->v3_diag) (void)handle_free(m->v3_diag);
   signal_stream_release(m);
-  if (m->order) (void)hipFree(m->order);
+  if (m->order) (void)handle_free(m->order);
   delete m;
 }
 
@@ -902,7 +1036,7 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
     ix->items = items;  // borrowed: the caller keeps it alive (ArrowSpace.data)
   } else {
     double *p;
-    AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items * n_features));
+    AS_HIP(ctx, handle_malloc((void **)&p, sizeof(double) * n_items * n_features));
     AS_HIP(ctx, copy_h2d(ctx, p, items, sizeof(double) * n_items * n_features));
     ix->items = p;
     ix->own_items = true;
@@ -911,12 +1045,12 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
     ix->lambdas = lambdas;
   } else {
     double *p;
-    AS_HIP(ctx, hipMalloc((void **)&p, sizeof(double) * n_items));
+    AS_HIP(ctx, handle_malloc((void **)&p, sizeof(double) * n_items));
     AS_HIP(ctx, copy_h2d(ctx, p, lambdas, sizeof(double) * n_items));
     ix->lambdas = p;
     ix->own_lambdas = true;
   }
-  AS_HIP(ctx, hipMalloc((void **)&ix->norms, sizeof(double) * n_items));
+  AS_HIP(ctx, handle_malloc((void **)&ix->norms, sizeof(double) * n_items));
   AS_TRY(row_norms(ctx, ix->items, n_items, n_features, ix->norms));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = ix;
@@ -926,22 +1060,22 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
 void as_index_destroy(as_index *ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
-  if (ix->own_items) (void)hipFree((void *)ix->items);
-  if (ix->own_lambdas) (void)hipFree((void *)ix->lambdas);
-  (void)hipFree(ix->norms);
-  if (ix->packed) (void)hipFree(ix->packed);
-  if (ix->packed32) (void)hipFree(ix->packed32);
-  if (ix->packed16) (void)hipFree(ix->packed16);
-  if (ix->scan_sample) (void)hipFree(ix->scan_sample);
-  if (ix->scan_sample_lam) (void)hipFree(ix->scan_sample_lam);
-  if (ix->lam32) (void)hipFree(ix->lam32);
-  if (ix->packedh) (void)hipFree(ix->packedh);
-  if (ix->scan_perm) (void)hipFree(ix->scan_perm);
-  if (ix->lam32_pos) (void)hipFree(ix->lam32_pos);
-  if (ix->scan_piv) (void)hipFree(ix->scan_piv);
-  if (ix->packed8) (void)hipFree(ix->packed8);
-  if (ix->packed8_nat) (void)hipFree(ix->packed8_nat);
-  if (ix->rot_q) (void)hipFree(ix->rot_q);
+  if (ix->own_items) (void)handle_free((void *)ix->items);
+  if (ix->own_lambdas) (void)handle_free((void *)ix->lambdas);
+  (void)handle_free(ix->norms);
+  if (ix->packed) (void)handle_free(ix->packed);
+  if (ix->packed32) (void)handle_free(ix->packed32);
+  if (ix->packed16) (void)handle_free(ix->packed16);
+  if (ix->scan_sample) (void)handle_free(ix->scan_sample);
+  if (ix->scan_sample_lam) (void)handle_free(ix->scan_sample_lam);
+  if (ix->lam32) (void)handle_free(ix->lam32);
+  if (ix->packedh) (void)handle_free(ix->packedh);
+  if (ix->scan_perm) (void)handle_free(ix->scan_perm);
+  if (ix->lam32_pos) (void)handle_free(ix->lam32_pos);
+  if (ix->scan_piv) (void)handle_free(ix->scan_piv);
+  if (ix->packed8) (void)handle_free(ix->packed8);
+  if (ix->packed8_nat) (void)handle_free(ix->packed8_nat);
+  if (ix->rot_q) (void)handle_free(ix->rot_q);
   delete ix;
 }
 

@@ -99,6 +99,7 @@ struct as_ctx {
   int64_t opt_join_theta_band_second = 1;  // the second pass never cuts below what the band certified
   int64_t opt_join_theta_band = 2;       // thresholds also from a row's own neighbourhood in the image: this many 512-position super tiles on either side (0: off)
   int64_t opt_join_theta_rate = 32;      // grouped thresholds: one image position in this many is sampled (a power of two, 2 .. 32)
+  int64_t opt_join_theta_grouped_bad_e3 = 6;  // ... kept while at most this share (x 1e-3, times min(4, n / 1 M)) of 4 096 checked rows sit 5e-3 below the plain sample's
   int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
                                          // groups (8.2 -> 1.7 ms at 1 M x 128), checked against the whole sample on 4096 rows
   int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 1024)
@@ -337,6 +338,7 @@ inline hipError_t copy_d2h(as_ctx *ctx, void *dst, const void *src, size_t bytes
 // the same stream, i.e. after those kernels.  (The runtime's stream-ordered pool, hipMallocAsync,
 // was dropped: mixed with the blocking hipMalloc/hipFree of the long-lived handles it produced
 // intermittent stale reads on this stack.)
+void handle_cache_release();  // (below: the cache of handle memory) every idle block back to the device
 inline int ws_alloc(as_ctx *ctx, size_t bytes, void **out, size_t *cap) {
   if (bytes == 0) bytes = 1;
   bytes = (bytes + 255) & ~(size_t)255;
@@ -352,6 +354,7 @@ inline int ws_alloc(as_ctx *ctx, size_t bytes, void **out, size_t *cap) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     ctx->free_blocks.clear();
+    handle_cache_release();  // ... and the blocks destroyed handles left behind
     e = hipMalloc(out, bytes);
   }
   if (e != hipSuccess) {
@@ -506,6 +509,18 @@ struct ConeDirs {
   uint32_t ntiles = 0;
   bool valid = false;
 };
+// Memory owned by handles (as_csr, as_index, as_jl, uploads): a block a destroyed handle gives back is kept (up to a cap) and handed
+// to the next allocation of exactly its size on the same device, after a device synchronisation -- hipFree costs ~150 us whatever
+// the size (it synchronises and unmaps), and a loop that rebuilds a graph or an index asks for the same sizes again.  The cap:
+// environment ARROWSPACE_HANDLE_CACHE_MB or option "handle_cache_mb" (default 4096; 0 = off, and what is cached is released).
+hipError_t handle_malloc(void **p, size_t bytes);
+hipError_t handle_free(void *p);
+void handle_cache_limit(int64_t mb);
+template <class T>
+inline hipError_t handle_malloc(T **p, size_t bytes) {
+  return handle_malloc(reinterpret_cast<void **>(p), bytes);
+}
+
 struct OwnJoin {
   DevBuf<unsigned char> P16own, Phown;                        // split-bf16 / f16 image of all rows (Phown in the order `perm`)
   DevBuf<unsigned char> Prow;                                 // sharded by rows with an order: the f16 image of all rows in ROW order (the all-gathered one)

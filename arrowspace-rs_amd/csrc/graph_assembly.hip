@@ -1235,7 +1235,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   {  // one allocation for the three arrays (the handle outlives the call: not from the workspace cache)
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_ptr = up(sizeof(uint64_t) * ((size_t)nr + 1)), b_idx = up(sizeof(uint64_t) * (nnz ? nnz : 1)), b_val = up(sizeof(double) * (nnz ? nnz : 1));
-    if (hipMalloc(&m->slab, b_ptr + b_idx + b_val) != hipSuccess) {
+    if (handle_malloc(&m->slab, b_ptr + b_idx + b_val) != hipSuccess) {
       (void)hipGetLastError();
       m->slab = nullptr;
       return fail(ctx, AS_ERR_HIP, "graph assembly: out of device memory for the CSR");

@@ -1268,6 +1268,25 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
   // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
   const bool wide_grouped = d > 128 && join_on_f16(ctx, d) && pos_begin == 0 && (pos_count == 0 || pos_count == n) && !gather;  // (rows wider than 128: one GPU)
+  // Whatever pass the sampled thresholds come from (grouped sample, plain sample), in the order of the image they are raised to what
+  // the row's own neighbourhood certifies: K other rows of its super tile and the ones beside it reach it, so the row is certified
+  // by construction and its list is cut near its K-th best cosine instead of its 128th (mfma_theta_f16.hip,
+  // join_thresholds_f16_band); the sampled threshold stays for rows whose neighbours live elsewhere.  Computed first: the check of
+  // the grouped thresholds below looks at the thresholds the join will use.
+  const bool have_band = reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && d <= 128 && K + 1 <= 32;
+  DevBuf<float> tband;
+  if (have_band) {
+    AS_TRY(tband.alloc(ctx, n));
+    AS_HIP(ctx, hipMemsetAsync(tband.p, 0xFF, sizeof(float) * n, ctx->stream));  // (NaN where not computed: never the larger one)
+    AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
+  }
+  auto merge_band = [&]() -> int {  // (own positions; the callers gather afterwards)
+    if (have_band && pos_count)
+      hipLaunchKernelGGL(theta_band_merge_kernel, dim3(cdiv(pos_count, 256)), dim3(256), 0, ctx->stream, oj.theta_pos.p + pos_begin,
+                         (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6));
+    AS_HIP(ctx, hipGetLastError());
+    return AS_OK;
+  };
   if (reorder_wide && (d <= 128 || wide_grouped) && oj.order_np >= 256 && ctx->opt_join_theta_grouped && ctx->opt_join_bf16 &&
       !(ctx->opt_debug & 32) && ctx->opt_join_sample <= 0) {
     const int64_t rank_opt = ctx->opt_join_rank > 0 ? ctx->opt_join_rank : 4;
@@ -1278,6 +1297,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     else
     AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
                                        oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count, row_image));
+    AS_TRY(merge_band());
     if (gather) {
       AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
       AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
@@ -1323,7 +1343,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     ctx->stats["knn_join_theta_grouped_bad"] = h_bad;
     // (the plain pass grows with the square of the table and what the rows below it add with the table: the share allowed grows
     // with it -- 4 M rows: 0.66 % of the checked rows below, the plain pass 116 ms of 530)
-    const uint32_t bad_per_mille = 6u * std::min(4u, std::max(1u, n / 1000000u));
+    const uint32_t bad_per_mille = (uint32_t)std::max<int64_t>(0, ctx->opt_join_theta_grouped_bad_e3) * std::min(4u, std::max(1u, n / 1000000u));
     if (h_bad * 1000u <= bad_per_mille * n_chk) {
       oj.have_theta2 = true;
       oj.grouped_theta = true;
@@ -1333,6 +1353,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
         AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_pos.p + pos_begin, nullptr, oj.theta2_pos.p + pos_begin,
                                    &oj.have_theta2, oj.Phown.p));
       else oj.have_theta2 = true;  // (a rank without positions: what the ranks with positions find, the 16-bit pass always has them)
+      AS_TRY(merge_band());
       if (gather) {
         AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
         AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
@@ -1345,6 +1366,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     if (sr) AS_TRY(need_rows());
     if (pos_count)
       AS_TRY(knn_join_thresholds(ctx, rows, norms, n, d, pos_begin, pos_count, t1 + pos_begin, nullptr, t2 + pos_begin, &oj.have_theta2, oj.Phown.p));
+    AS_TRY(merge_band());  // (have_band implies reorder: t1 is theta_pos)
     if (gather) {
       // (whether the pass produced second thresholds depends on the options and the width alone: every rank agrees; a rank
       // without positions takes the answer of the 16-bit passes, which always have them)
@@ -1353,21 +1375,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       if (oj.have_theta2) AS_TRY((*gather)(t2, sizeof(float)));
     }
   }
-  // Whatever pass the thresholds came from (grouped sample, plain sample), in the order of the image they are raised to what the
-  // row's own neighbourhood certifies:
-  // ... and, where that is higher, from the row's own neighbourhood in the image: K other rows of its super tile and the ones
-  // beside it reach it, so the row is certified by construction and its list is cut near its K-th best cosine instead of its
-  // 128th (mfma_theta_f16.hip, join_thresholds_f16_band); the sampled threshold stays for rows whose neighbours live elsewhere
-  if (reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && d <= 128 && K + 1 <= 32) {
-    DevBuf<float> tband;
-    AS_TRY(tband.alloc(ctx, n));
-    AS_HIP(ctx, hipMemsetAsync(tband.p, 0xFF, sizeof(float) * n, ctx->stream));  // (NaN where not computed: never the larger one)
-    AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
-    if (pos_count)
-      hipLaunchKernelGGL(theta_band_merge_kernel, dim3(cdiv(pos_count, 256)), dim3(256), 0, ctx->stream, oj.theta_pos.p + pos_begin,
-                         (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6));
-    AS_HIP(ctx, hipGetLastError());
-    if (gather) AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));  // (a rank raised the thresholds of its own positions)
+  if (have_band) {
     // kept by row for the second pass: a row the sampled threshold left open has K rows above this one by construction
     AS_TRY(oj.theta_band_own.alloc(ctx, n));
     AS_TRY(scatter_by_perm(ctx, tband.p, oj.perm_own.p, n, oj.theta_band_own.p));
@@ -2174,13 +2182,13 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       }
       if (ix->weird_items == 0 && ix->rot_state == 0) {
         double tail = 1.0;
-        if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));  // (kept on failure: the next call reuses it)
+        if (!ix->rot_q) AS_HIP(ctx, handle_malloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));  // (kept on failure: the next call reuses it)
         AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
         ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
       }
       if (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat) {
         const uint32_t tiles = packed_tiles_f16(n);
-        AS_HIP(ctx, hipMalloc(&ix->packed8_nat, rotated_image_bytes(tiles)));
+        AS_HIP(ctx, handle_malloc(&ix->packed8_nat, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, nullptr, n, d, ix->rot_q, ix->packed8_nat, tiles, &ix->rot_err_nat));
       }
       )
@@ -2220,14 +2228,14 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   const uint32_t b_alloc = (b_tiles + 1) & ~1u;
   auto ensure64 = [&]() -> int {
     AS_IX_BUILD(!ix->packed,
-      AS_HIP(ctx, hipMalloc((void **)&ix->packed, sizeof(double) * packed_elems(b_alloc, d)));
+      AS_HIP(ctx, handle_malloc((void **)&ix->packed, sizeof(double) * packed_elems(b_alloc, d)));
       AS_TRY(pack_f64(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed, b_alloc));
     )
     return AS_OK;
   };
   auto ensure32 = [&]() -> int {
     AS_IX_BUILD(!ix->packed32,
-      AS_HIP(ctx, hipMalloc((void **)&ix->packed32, sizeof(float) * packed_elems(b_alloc, d)));
+      AS_HIP(ctx, handle_malloc((void **)&ix->packed32, sizeof(float) * packed_elems(b_alloc, d)));
       AS_TRY(pack_f32(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed32, b_alloc));
     )
     return AS_OK;
@@ -2300,17 +2308,17 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     };
     AS_IX_BUILD(scan_state_missing(),
     if (want_order && !ix->scan_perm && ix->packedh) {  // (the image of the first scan was in the order of the items)
-      (void)hipFree(ix->packedh);
+      (void)handle_free(ix->packedh);
       ix->packedh = nullptr;
     }
     if ((scan_wide || scan_h) && !ix->packedh) {
       const uint32_t tiles = packed_tiles_f16(n);
       if (want_order) {
-        AS_HIP(ctx, hipMalloc((void **)&ix->scan_perm, sizeof(uint32_t) * (size_t)n));
-        AS_HIP(ctx, hipMalloc((void **)&ix->scan_piv, sizeof(float) * 256 * 128));
+        AS_HIP(ctx, handle_malloc((void **)&ix->scan_perm, sizeof(uint32_t) * (size_t)n));
+        AS_HIP(ctx, handle_malloc((void **)&ix->scan_piv, sizeof(float) * 256 * 128));
         AS_TRY(cluster_order(ctx, ix->items, ix->norms, n, d, ix->scan_perm, ix->scan_piv));
       }
-      AS_HIP(ctx, hipMalloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
+      AS_HIP(ctx, handle_malloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
       AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles, ix->scan_perm));
       ix->f16_err = ctx->f16_err;
     }
@@ -2318,7 +2326,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       const uint32_t tiles = packed_tiles_f16(n);
       if (ix->rot_state == 0) {
         double tail = 1.0;
-        if (!ix->rot_q) AS_HIP(ctx, hipMalloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
+        if (!ix->rot_q) AS_HIP(ctx, handle_malloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));
         AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
         ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
       }
@@ -2326,36 +2334,36 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       // position is this path's to build -- it used to be built only together with the directions, and a large batch that came
       // after a small one then handed the first pass a null image)
       if (ix->rot_state == 1 && !ix->packed8) {
-        AS_HIP(ctx, hipMalloc(&ix->packed8, rotated_image_bytes(tiles)));
+        AS_HIP(ctx, handle_malloc(&ix->packed8, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, ix->scan_perm, n, d, ix->rot_q, ix->packed8, tiles, &ix->rot_err));
       }
     }
     if (!scan_wide && !scan_h && !ix->packed16) {
-      AS_HIP(ctx, hipMalloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
+      AS_HIP(ctx, handle_malloc(&ix->packed16, packed_vecs_bf16(b_alloc, d) * 16));
       AS_TRY(pack_bf16(ctx, ix->items, ix->norms, nullptr, 0, n, d, ix->packed16, b_alloc));
     }
     if (!ix->lam32) {  // padded to whole 512-row super tiles (the images of both forms of the scan end there)
       const uint32_t lpad = (n + 511) / 512 * 512;
-      AS_HIP(ctx, hipMalloc((void **)&ix->lam32, sizeof(float) * (size_t)lpad));
+      AS_HIP(ctx, handle_malloc((void **)&ix->lam32, sizeof(float) * (size_t)lpad));
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream,
                          ix->lambdas, (const uint32_t *)nullptr, n, lpad, ix->lam32);
     }
     if (scan_h && ix->scan_perm && !ix->lam32_pos) {  // ... and by position in the ordered image
       const uint32_t lpad = (n + 511) / 512 * 512;
-      AS_HIP(ctx, hipMalloc((void **)&ix->lam32_pos, sizeof(float) * (size_t)lpad));
+      AS_HIP(ctx, handle_malloc((void **)&ix->lam32_pos, sizeof(float) * (size_t)lpad));
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream, ix->lambdas,
                          (const uint32_t *)ix->scan_perm, n, lpad, ix->lam32_pos);
     }
     if (ix->scan_sample && ix->scan_ns != ns_want) {  // the option changed since the sample was drawn
-      (void)hipFree(ix->scan_sample);
-      (void)hipFree(ix->scan_sample_lam);
+      (void)handle_free(ix->scan_sample);
+      (void)handle_free(ix->scan_sample_lam);
       ix->scan_sample = nullptr;
       ix->scan_sample_lam = nullptr;
     }
     if (!ix->scan_sample) {
       const uint32_t ns = ns_want;
-      AS_HIP(ctx, hipMalloc((void **)&ix->scan_sample, sizeof(uint32_t) * ns));
-      AS_HIP(ctx, hipMalloc((void **)&ix->scan_sample_lam, sizeof(float) * ns));
+      AS_HIP(ctx, handle_malloc((void **)&ix->scan_sample, sizeof(uint32_t) * ns));
+      AS_HIP(ctx, handle_malloc((void **)&ix->scan_sample_lam, sizeof(float) * ns));
       hipLaunchKernelGGL(sample_ids_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ns, n / ns, sample_half_bits(ns),
                          ix->scan_sample);
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ctx->stream, ix->lambdas,

@@ -1080,7 +1080,7 @@ int as_jl_create(as_ctx *ctx, uint64_t original_dim, uint64_t reduced_dim, uint6
   j->original_dim = original_dim;
   j->reduced_dim = reduced_dim;
   j->seed = seed;
-  AS_HIP(ctx, hipMalloc((void **)&j->G, sizeof(double) * original_dim * reduced_dim));
+  AS_HIP(ctx, handle_malloc((void **)&j->G, sizeof(double) * original_dim * reduced_dim));
   const uint64_t total = original_dim * reduced_dim;
   hipLaunchKernelGGL(jl_gaussian_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, seed, total, j->G);
   AS_HIP(ctx, hipGetLastError());
@@ -1092,7 +1092,7 @@ int as_jl_create(as_ctx *ctx, uint64_t original_dim, uint64_t reduced_dim, uint6
 void as_jl_destroy(as_jl *jl) {
   if (!jl) return;
   (void)hipSetDevice(jl->device);
-  (void)hipFree(jl->G);
+  (void)handle_free(jl->G);
   delete jl;
 }
 

@@ -835,8 +835,8 @@ int any_nonfinite(as_ctx *ctx, const double *p, uint64_t count, bool *out) {
 // ---- host side --------------------------------------------------------------------------------------------------------------
 
 void signal_stream_release(as_csr *L) {
-  if (L->sig_rec) (void)hipFree(L->sig_rec);
-  if (L->sig_off) (void)hipFree(L->sig_off);
+  if (L->sig_rec) (void)handle_free(L->sig_rec);
+  if (L->sig_off) (void)handle_free(L->sig_off);
   L->sig_rec = nullptr;
   L->sig_off = nullptr;
   L->sig_state = 0;
@@ -845,7 +845,7 @@ void signal_stream_release(as_csr *L) {
 // position -> row order of the rows of L, copied into the handle (any permutation gives the same lambdas up to rounding)
 int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev) {
   signal_stream_release(L);
-  if (L->order) (void)hipFree(L->order);
+  if (L->order) (void)handle_free(L->order);
   L->order = nullptr;
   L->order_state = 0;
   if (!order_dev) return AS_OK;
@@ -860,7 +860,7 @@ int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev) {
   int h = 0;
   AS_HIP(ctx, copy_d2h(ctx, &h, bad.p, sizeof(int)));
   if (h) return fail(ctx, AS_ERR_ARG, "the order is not a permutation of the rows");
-  AS_HIP(ctx, hipMalloc((void **)&L->order, sizeof(uint32_t) * (L->n ? L->n : 1)));
+  AS_HIP(ctx, handle_malloc((void **)&L->order, sizeof(uint32_t) * (L->n ? L->n : 1)));
   AS_HIP(ctx, hipMemcpyAsync(L->order, order_dev, sizeof(uint32_t) * L->n, hipMemcpyDeviceToDevice, ctx->stream));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   L->order_state = 1;
@@ -980,11 +980,11 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   AS_TRY(pad_row.alloc(ctx, 8 * wx));
   hipLaunchKernelGGL(sig_pad_kernel, dim3(cdiv(8 * wx, 64)), dim3(64), 0, ctx->stream, g, L->row_begin, order, cnt.p, pad_row.p);
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipMalloc((void **)&L->sig_off, sizeof(uint64_t) * (slots + 1)));
+  AS_HIP(ctx, handle_malloc((void **)&L->sig_off, sizeof(uint64_t) * (slots + 1)));
   AS_TRY(exclusive_scan_u32_u64(ctx, cnt.p, slots, L->sig_off));
   uint64_t n_rec = 0;
   AS_HIP(ctx, copy_d2h(ctx, &n_rec, L->sig_off + slots, sizeof(uint64_t)));
-  AS_HIP(ctx, hipMalloc(&L->sig_rec, sizeof(SigRec) * (n_rec ? n_rec : 1)));
+  AS_HIP(ctx, handle_malloc(&L->sig_rec, sizeof(SigRec) * (n_rec ? n_rec : 1)));
   hipLaunchKernelGGL(sig_fill_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices, L->data, g, L->row_begin, order, sym,
                      L->sig_off, (const uint32_t *)pad_row.p, (SigRec *)L->sig_rec);
   AS_HIP(ctx, hipGetLastError());

@@ -86,7 +86,7 @@ __global__ void pack_upper_kernel(const uint64_t *__restrict__ indptr, const uin
 
 static int ensure_packed(as_ctx *ctx, as_csr *L) {
   if (L->packed || L->nnz == 0) return AS_OK;
-  AS_HIP(ctx, hipMalloc(&L->packed, sizeof(PackedEntry) * L->nnz));
+  AS_HIP(ctx, handle_malloc(&L->packed, sizeof(PackedEntry) * L->nnz));
   hipLaunchKernelGGL(pack_csr_kernel, dim3(cdiv(L->n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices,
                      L->data, L->n, (PackedEntry *)L->packed);
   AS_HIP(ctx, hipGetLastError());
@@ -107,7 +107,7 @@ static int ensure_packed(as_ctx *ctx, as_csr *L) {
   AS_HIP(ctx, copy_d2h(ctx, &n_upper, uptr.p + L->n, sizeof(uint64_t)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h == 0 && n_upper > 0) {
-    AS_HIP(ctx, hipMalloc(&L->packed_upper, sizeof(PackedEntry) * n_upper));
+    AS_HIP(ctx, handle_malloc(&L->packed_upper, sizeof(PackedEntry) * n_upper));
     hipLaunchKernelGGL(pack_upper_kernel, dim3(cdiv(L->n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices,
                        L->data, L->n, uptr.p, (PackedEntry *)L->packed_upper);
     AS_HIP(ctx, hipGetLastError());

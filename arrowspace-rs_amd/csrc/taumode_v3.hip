@@ -670,8 +670,8 @@ static int prepare_v3(as_ctx *ctx, as_csr *L) {
   w.swap(sched_w);
   const size_t fixed = n_slots * sizeof(V3Entry) + 128 * sizeof(double) + 16;
   if (fixed + kTileB > kLdsBudget) return AS_OK;  // entry table too large for LDS
-  AS_HIP(ctx, hipMalloc(&L->v3_ent, n_slots * sizeof(V3Entry)));
-  AS_HIP(ctx, hipMalloc(&L->v3_diag, 128 * sizeof(double)));
+  AS_HIP(ctx, handle_malloc(&L->v3_ent, n_slots * sizeof(V3Entry)));
+  AS_HIP(ctx, handle_malloc(&L->v3_diag, 128 * sizeof(double)));
   AS_HIP(ctx, copy_h2d(ctx, L->v3_ent, ent.data(), n_slots * sizeof(V3Entry)));
   AS_HIP(ctx, copy_h2d(ctx, L->v3_diag, diag.data(), 128 * sizeof(double)));
   L->v3_steps = n_steps;

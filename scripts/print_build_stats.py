@@ -18,5 +18,5 @@ for kv in sys.argv[4:]:
 A.build_laplacian_matrix(Xd, gp, ctx=ctx); ctx.synchronize()
 for k in ("knn_join_cap", "knn_join_candidates", "knn_join_max_per_row", "knn_join_overflow_rows", "knn_rerank_scored", "knn_uncertified_rows",
           "knn_uncertified_rows_stage1a", "knn_join_cone_tiles_kept_e6", "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged",
-          "knn_join_cone_second", "knn_join_cone_second_kept_e6"):
+          "knn_join_cone_second", "knn_join_cone_second_kept_e6", "knn_join_theta_grouped", "knn_join_theta_grouped_bad", "knn_join_row_order"):
     print(k, ctx.stat(k))
