@@ -550,11 +550,13 @@ def main():
                 "2 n^2 d (the full square is contracted)")
         nnz = float(state.get("nnz", 0))
         if nnz > 0 and world == 1:
-            add("graph_assembly", "graph assembly (degree32_kernel, adjacency32_kernel, fill_reverse_kernel, union_count32_kernel, write_rows_kernel)",
+            add("graph_assembly", "graph assembly (degree_rows64_kernel, adjacency32_kernel, fill_reverse32_kernel, union_count32r_kernel, write_rows_ranked_kernel, write_rows_mid / _hub_kernel)",
                 "hbm", rows_here * 17 * 16.0 + nnz * 16.0 + (rows_here + 1) * 8.0, HBM_PEAK_GBS, "GB/s",
                 "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out",
-                pmc=("degree_kernel", "degree32_kernel", "adjacency_kernel", "adjacency32_kernel", "fill_reverse_kernel", "union_count_kernel",
-                     "union_count32_kernel", "write_rows_kernel", "write_rows_big_kernel", "scan_block_sums", "scan_of_sums", "scan_finish"))
+                pmc=("degree_kernel", "degree32_kernel", "degree_rows64_kernel", "adjacency_kernel", "adjacency32_kernel", "fill_reverse_kernel",
+                     "fill_reverse32_kernel", "union_count_kernel", "union_count32_kernel", "union_count32r_kernel", "write_rows_kernel",
+                     "write_rows_big_kernel", "write_rows_ranked_kernel", "write_rows_mid_kernel", "write_rows_hub_kernel", "write_rows_serial_kernel",
+                     "scan_block_sums", "scan_of_sums", "scan_finish"))
         roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
         reference_equivalent = None
         if stats["knn_join"] == 1:

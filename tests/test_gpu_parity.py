@@ -896,6 +896,30 @@ def test_hybrid_search_beyond_64(ctx):
         assert np.array_equal([g[1] for g in got], osc), (j, k)
 
 
+def test_handle_memory_cache_on_and_off(ctx):
+    """Handle memory (CSR slabs, index images) goes through a cache of the blocks destroyed handles leave ("handle_cache_mb", api.hip):
+    graphs and searches built on re-used blocks are the ones built on fresh memory."""
+    import gc
+    X, cent = synth.mixture(70_000, 128, seed=42)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    ref = None
+    try:
+        for mb in (4096, 4096, 0, 4096):
+            ctx.set_option("handle_cache_mb", mb)
+            gl = A.build_laplacian_matrix(X, gp, ctx=ctx)
+            got = gl.matrix.to_host()
+            asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+            asp.update_lambdas(np.linspace(0.05, 0.9, len(X)))
+            hits = asp.search_lambda_aware(A.ArrowItem(X[11] * 1.01, 0.4), 10, 0.7)
+            if ref is None:
+                ref = (got, hits)
+            assert all(np.array_equal(a, b) for a, b in zip(ref[0], got)) and hits == ref[1]
+            del gl, asp
+            gc.collect()
+    finally:
+        ctx.set_option("handle_cache_mb", 4096)
+
+
 def test_graph_assembly_hub_rows_on_every_path(ctx):
     """A neighbour table with hubs of every size class of the assembly (graph_assembly.hip): two nodes that ~12 000 rows point to
     (the serial form past 4 096 entries), ten with ~1 200 in-edges (a workgroup per row), fifty with ~240 (a wave per row), the
