@@ -1318,26 +1318,30 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq, self_ids};
   ProfScope ps(ctx, prof_name);
-#define AS_JOIN(K)                                                                                                        \
-  case K:                                                                                                                 \
-    if (mask) {                                                                                                           \
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, true>,                                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-      hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
-                         (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
-                         (int)ctx->opt_debug, stamps.p, st, perm, (const unsigned long long *)mask, perm_a);       \
-    } else {                                                                                                              \
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, false>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-      hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, false>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,  \
-                         (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand, unit_counter,              \
-                         (int)ctx->opt_debug, stamps.p, st, perm, (const unsigned long long *)nullptr, perm_a);    \
-    }                                                                                                                     \
+  // (diagnostics compiled out unless a debug bit asks for them: the product instantiation, as in the build's first pass)
+  const bool diag = ctx->opt_debug != 0;
+#define AS_LAUNCH(K, M, DG)                                                                                               \
+  {                                                                                                                       \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, M, false, DG>,                               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, M, false, DG>), dim3(grid), dim3(512), lds, ctx->stream,               \
+                       (const f16x8 *)P, (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand,            \
+                       unit_counter, (int)ctx->opt_debug, stamps.p, st, perm,                                             \
+                       (const unsigned long long *)(M ? mask : nullptr), perm_a);                                         \
+  }
+#define AS_JOIN(K)                                       \
+  case K:                                                \
+    if (K == 8 && !diag) {                               \
+      if (mask) AS_LAUNCH(K, true, false)                \
+      else AS_LAUNCH(K, false, false)                    \
+    } else if (mask) AS_LAUNCH(K, true, true)            \
+    else AS_LAUNCH(K, false, true)                       \
     break;
   switch (KS) {
     AS_JOIN(1) AS_JOIN(2) AS_JOIN(3) AS_JOIN(4) AS_JOIN(5) AS_JOIN(6) AS_JOIN(7) AS_JOIN(8)
     default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 search scan: dim not covered");
   }
+#undef AS_LAUNCH
 #undef AS_JOIN
   AS_HIP(ctx, hipGetLastError());
   if (ctx->opt_debug & 8) {  // diagnostic: where a wave's cycles go (the stamps of the kernel; scripts/stamps_one_sided.py)

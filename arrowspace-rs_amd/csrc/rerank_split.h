@@ -225,6 +225,18 @@ __global__ void join_group_stats_kernel(const uint32_t *__restrict__ gcnt, uint3
   }
 }
 
+// A failed row's slot in the list: the returning atomic and its wait by hand, INSIDE the branch.  Left to the compiler the wait for
+// the returned value (s_waitcnt vmcnt(0)) lands behind the branch's join, on the path of every row, and drains the two batches of
+// row gathers in flight at every row end.
+__device__ __forceinline__ uint32_t rs_take_fail_slot(uint32_t *fail_count) {
+  uint32_t slot;
+  const uint32_t zero = 0u, one = 1u;
+  // (s_nop: the pointer may have just come back from a spill lane by v_readlane -- a VALU write of an SGPR that a VMEM instruction
+  // reads needs five wait states, and the compiler does not look inside the statement)
+  asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(zero), "v"(one), "s"(fail_count) : "memory");
+  return slot;
+}
+
 typedef double rs_d2 __attribute__((ext_vector_type(2)));  // (a native vector: asm operands of struct type go through memory)
 struct RsSet {
   rs_d2 v[kRsRows];  // this lane's 16 B of each candidate row of a batch
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
     }
     // every pair that is not in the lists has an approximate cosine below theta
     const bool ok = !p_overflow && !p_force && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
-    if (!ok && lane == 0 && !dbg) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    if (!ok && lane == 0 && !dbg) fail_rows[rs_take_fail_slot(fail_count)] = r;
     wave_sync();
     ps.enter(records, ps.p + stride);
   };
@@ -527,5 +539,6 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
 #undef AS_ST
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batches issued past the end
 }
+
 
 }  // namespace asx
