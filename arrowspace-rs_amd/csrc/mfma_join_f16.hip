@@ -1310,7 +1310,11 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   // ... and the one-sided pass has few row super tiles (20 for 10 k queries, a dozen for the rows of a second pass): column blocks of at
   // most 32 super tiles keep a thousand units for 256 CUs (64: search scan 4.3 -> 5.5 ms, second pass of the 4 M table 29 -> 42 ms)
   const uint32_t w_one = std::min(w_opt, 32u);
-  const uint32_t W = std::max(1u, std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_one, 2u) : w_one, std::max(1u, T2 / 4)));
+  // ... and a short batch (the few hundred queries a second guess re-scans: ONE row super tile) takes narrower blocks still, so that
+  // there are about a thousand units whatever the batch (62 units of 32 column super tiles left three quarters of the CUs idle:
+  // 0.6 ms for 5 % of the scan's work)
+  const uint32_t w_fill = (uint32_t)std::max<uint64_t>(1, (uint64_t)T2 * a_supers / 1024);
+  const uint32_t W = std::max(1u, std::min(std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_one, 2u) : w_one, w_fill), std::max(1u, T2 / 4)));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
