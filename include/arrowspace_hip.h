@@ -114,10 +114,19 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               items' energy lies outside their 31 directions (measured on data of higher rank: no gain above)
  *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
  *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
- *   "rerank_order" (1), "assembly_lanes" (1), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
- *                               exact re-rank in the order of the join's image, graph assembly with 32 lanes per row,
- *                               nearest-centroid keys of a clustering batch on the f32 matrix pipe, clustering batches
- *                               on the device (0 = the older form of each, kept for comparison)
+ *                               "join_cone_tiles" (1), "join_cone_second" (1): the cone bound on pairs of 128-position tiles in
+ *                               front of the first pass / its one-sided form in front of the second pass;
+ *                               "join_theta_band" (2): thresholds raised to what a row's own neighbourhood in the ordered image
+ *                               certifies (super tiles on either side; 0 = off), "join_theta_band_second" (1): the second pass
+ *                               never cuts below them; "rerank_pair_bound" (1): the pruning in front of the exact re-rank bounds
+ *                               each pair by its two rows' own f16 plane errors
+ *   "rerank_order" (1), "assembly_lanes" (2), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
+ *                               exact re-rank in the order of the join's image, graph assembly (2 = the round-4 kernels, 1 = 32
+ *                               lanes per row throughout, 0 = a thread per row), nearest-centroid keys of a clustering batch on
+ *                               the f32 matrix pipe, clustering batches on the device (0 = the older form of each, for comparison)
+ *   "handle_cache_mb" (4096)    memory of destroyed handles (CSR slabs, index images, uploads) kept for the next allocation of the
+ *                               same size instead of hipFree + hipMalloc (process-wide; environment ARROWSPACE_HANDLE_CACHE_MB;
+ *                               0 = off and released)
  *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);

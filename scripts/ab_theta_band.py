@@ -15,7 +15,7 @@ Xd, cent = synth.mixture_device(n, 128, "cuda", seed=seed, n_clusters=clusters, 
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 A.build_laplacian_matrix(Xd, gp, ctx=ctx); ctx.synchronize()
 ref = None
-for band in (0, 1, 2, 3, 0):
+for band in [int(b) for b in os.environ.get("BANDS", "0,1,2,3,0").split(",")]:
     ctx.set_option("join_theta_band", band)
     for it in range(2):
         ctx.profile(True)
