@@ -54,7 +54,13 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
                                                            uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
                                                            uint32_t m2, float *__restrict__ theta2_out,
                                                            uint32_t *__restrict__ unit_counter,
-                                                           const uint32_t *__restrict__ unit_groups) {
+                                                           const uint32_t *__restrict__ unit_groups, uint32_t parts = 1,
+                                                           float *__restrict__ bins_out = nullptr) {
+  // parts > 1 (plain sample only, bins_out given): a unit is (256 rows, one of `parts` even ranges of the sample's tiles) and
+  // leaves its 64 sub-sample maxima per row in bins_out[(row * parts + part) * 64 ..] instead of selecting -- the maxima of the
+  // whole sample are the maxima over the parts bin by bin (a tile keeps its parity), so theta_bins_select_kernel returns the very
+  // thresholds of one sweep.  For the calls with few rows (the check of the grouped thresholds, the second pass): 16 or 24 units
+  // sweeping the whole sample each left most of the chip idle for 0.37 ms.
   // unit_groups (2 per unit: first and last pivot group of its 256 image positions): the sample is not one image for all rows
   // but s_tiles tiles per GROUP (the sampled rows of the groups nearest to it: join_thresholds_f16_grouped), and a unit sweeps
   // those of the groups it covers.
@@ -85,8 +91,12 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
     __syncthreads();
     if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
     __syncthreads();
-    const uint32_t I = s_unit;
-    if (I >= a_supers) break;
+    const uint32_t U = s_unit;
+    if (U >= a_supers * parts) break;
+    const uint32_t I = U / parts, part = U % parts;
+    // this unit's tiles of the sample (whole pairs of tiles; all of them when parts == 1)
+    const uint32_t per = ((s_tiles / 2 + parts - 1) / parts) * 2, t_lo = min(s_tiles, part * per), t_hi = min(s_tiles, t_lo + per);
+    const uint32_t st = unit_groups ? s_tiles : t_hi - t_lo;
 
     f16x8 a_hi[KS];
     {
@@ -142,13 +152,13 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = -__builtin_inff();  // nothing pending
 
     const uint32_t g_lo = unit_groups ? unit_groups[2 * I] : 0u, g_hi = unit_groups ? unit_groups[2 * I + 1] : 0u;
-    for (uint32_t g = g_lo; g <= g_hi; ++g) {
-    if (unit_groups) PSc = PS + (size_t)g * s_tiles * kTileVecs;
+    for (uint32_t g = g_lo; g <= g_hi && st > 0; ++g) {
+    PSc = unit_groups ? PS + (size_t)g * s_tiles * kTileVecs : PS + (size_t)t_lo * kTileVecs;
     __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring); the sweep before with its buffers
     stage(0, 0, -1);
     __syncthreads();
     const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
-    for (uint32_t J = 0; J < s_tiles; J += 2) {
+    for (uint32_t J = 0; J < st; J += 2) {
 #define AS_IC(V) std::integral_constant<int, (V)>{}
 // block NN of the tile in buffer PAR (= its parity bin); PREV_PAR = bin of the block whose maxima are taken now
 #define AS_BLOCK(PAR, NN, NEXT, CUR, PREV, PREV_PAR, MORE, JN)      \
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
       }
       __syncthreads();  // tile J + 1 has landed; everyone is done with buffer 0
       {  // odd tile J + 1 (buffer 1, bin 1)
-        const bool more = J + 2 < s_tiles;
+        const bool more = J + 2 < st;
         const uint32_t b_addr = b_addr0 + kTileVecs * 16;
         AS_READ(0, 0, 0)
         AS_BLOCK(1, 0, 1, accA, accB, 0, more, J + 2)
@@ -212,6 +222,13 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
       float vals[64];
 #pragma unroll
       for (int c = 0; c < 64; ++c) vals[c] = wm[lane * 65 + c];
+      if (bins_out) {  // (one part of the sample: the selection follows in theta_bins_select_kernel)
+        if (row < row_count) {
+          float *dst = bins_out + ((size_t)row * parts + part) * 64;
+#pragma unroll
+          for (int c = 0; c < 64; ++c) dst[c] = vals[c];
+        }
+      } else {
       float t = -__builtin_inff(), t1 = -__builtin_inff();
       const uint32_t mm = theta2_out ? max(m, m2) : m;  // theta2_out: a second, looser order statistic (m2 >= m)
       for (uint32_t k = 0; k < mm; ++k) {  // remove the current maximum mm - 1 times
@@ -232,9 +249,43 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
       if (row < row_count && theta2_out) theta2_out[row] = t * (1.f / 16384.f);
       t = t1;
       if (row < row_count) theta_out[row] = t * (1.f / 16384.f);
+      }
     }
     wave_sync();
   }
+}
+
+// the thresholds from the bins the parts of the sample left: maxima over the parts, then the selection of theta_f16_kernel
+__global__ __launch_bounds__(64) void theta_bins_select_kernel(const float *__restrict__ bins, uint32_t row_count, uint32_t parts, uint32_t m,
+                                                               float *__restrict__ theta_out, uint32_t m2, float *__restrict__ theta2_out) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= row_count) return;
+  float vals[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) vals[c] = -__builtin_inff();
+  for (uint32_t p = 0; p < parts; ++p) {
+    const float *src = bins + ((size_t)row * parts + p) * 64;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) vals[c] = __builtin_fmaxf(vals[c], src[c]);
+  }
+  float t = -__builtin_inff(), t1 = -__builtin_inff();
+  const uint32_t mm = theta2_out ? max(m, m2) : m;
+  for (uint32_t k = 0; k < mm; ++k) {
+    float best = -__builtin_inff();
+    int at = 0;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      const bool gt = vals[c] > best;
+      best = gt ? vals[c] : best;
+      at = gt ? c : at;
+    }
+    t = best;
+    if (k + 1 == m) t1 = best;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
+  }
+  if (theta2_out) theta2_out[row] = t * (1.f / 16384.f);
+  theta_out[row] = t1 * (1.f / 16384.f);
 }
 
 // ---- the sample by pivot group (own join with the row order found on the rotated coordinates, row_order.hip) -------------------
@@ -377,19 +428,28 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   const f16x8 *PA = (const f16x8 *)P_all + (size_t)(row_begin / kTileRows) * KS * 4 * 64;
   const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
-  const unsigned grid = std::min<uint32_t>(a_supers, 256u);
+  // few rows (the check of the grouped thresholds, the open rows of the second pass): the sample split over several units per
+  // 256 rows, so that there are a few hundred units
+  const uint32_t parts = a_supers >= 64 ? 1u : std::max(1u, std::min(std::min(16u, s_tiles / 2), 256u / std::max(1u, a_supers)));
+  DevBuf<float> bins;
+  if (parts > 1) AS_TRY(bins.alloc(ctx, (size_t)a_supers * 256 * parts * 64));
+  const unsigned grid = std::min<uint32_t>(a_supers * parts, 256u);
   ProfScope ps(ctx, "knn_join_thresholds");
 #define AS_THETA(K)                                                                                                          \
   case K:                                                                                                                    \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA, a_supers, row_count,              \
-                       (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)nullptr);      \
+                       (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)nullptr,       \
+                       parts, parts > 1 ? bins.p : (float *)nullptr);                                                        \
     break;
   switch (KS) {
     AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)
     default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   }
 #undef AS_THETA
+  if (parts > 1)
+    hipLaunchKernelGGL(theta_bins_select_kernel, dim3(cdiv(row_count, 64)), dim3(64), 0, ctx->stream, (const float *)bins.p, row_count, parts, m,
+                       theta_out, m2, theta2_out);
   AS_HIP(ctx, hipGetLastError());
   // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
   return AS_OK;
