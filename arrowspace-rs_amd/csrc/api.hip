@@ -472,6 +472,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
     while (r > 2 && r > value) r >>= 1;
     ctx->opt_join_theta_rate = r;
   }
+  else if (n == "join_unit_list") ctx->opt_join_unit_list = value != 0;
   else if (n == "join_cone_second") ctx->opt_join_cone_second = value != 0;
   else if (n == "join_cone_tiles_max_e3") ctx->opt_join_cone_tiles_max_e3 = std::max<int64_t>(0, value);
   else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;

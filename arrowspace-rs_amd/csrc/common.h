@@ -84,6 +84,7 @@ struct as_ctx {
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_join_cone_tiles = 1;       // rotated first pass on an ordered image: behind a cone bound on pairs of 128-position tiles (cone_tiles.hip)
   int64_t opt_join_cone_tiles_max_e3 = 600;  // ... taken while it keeps at most this share (x 1e-3) of the tile pairs; beyond, the pass sweeps everything
+  int64_t opt_join_unit_list = 1;        // masked f16 pass: the units that hold a flagged stage listed first (0: every unit drawn and looked at)
   int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
   int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
                                          // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
