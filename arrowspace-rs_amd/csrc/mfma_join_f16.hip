@@ -1310,7 +1310,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
       hipLaunchKernelGGL((pair_join_f16_kernel<8, 0, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P,   \
                          (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
                          (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
-                         (const uint32_t *)nullptr);                                                                      \
+                         (const uint32_t *)nullptr, (const uint32_t *)unit_list.p);                                       \
     } else {                                                                                                              \
       AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, false>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
