@@ -401,11 +401,15 @@ __global__ __launch_bounds__(256, 4) void cone_rect_kernel(const f16x8 *__restri
     c = cos_a[J];
     sn = sin_a[J];
   };
-  f16x8 b0 = dir_frag(0, 0), b1 = dir_frag(0, 1);
+  // (blockIdx.y: a share of the direction groups -- a few thousand open rows are a dozen workgroups, each walking all of them alone
+  // took 0.14 ms)
+  const uint32_t per = (words + gridDim.y - 1) / gridDim.y, w_lo = min(words, blockIdx.y * per), w_hi = min(words, w_lo + per);
+  if (w_lo >= w_hi) return;
+  f16x8 b0 = dir_frag(w_lo, 0), b1 = dir_frag(w_lo, 1);
   float ca, sa;
-  dir_cone(0, ca, sa);
-  for (uint32_t gq = 0; gq < words; ++gq) {
-    const uint32_t gn = gq + 1 < words ? gq + 1 : gq;
+  dir_cone(w_lo, ca, sa);
+  for (uint32_t gq = w_lo; gq < w_hi; ++gq) {
+    const uint32_t gn = gq + 1 < w_hi ? gq + 1 : gq;
     const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
     float caN, saN;
     dir_cone(gn, caN, saN);
@@ -484,7 +488,7 @@ int cone_rect_mask(as_ctx *ctx, const double *Z, const uint32_t *ids, uint32_t n
   AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(cone_tile_kernel, dim3(gt), dim3(128), 0, ctx->stream, Z, ids, nf, theta_a, (f16x8 *)rows_img.p, (f16x8 *)dirs_g.p, ca_g.p,
                      sa_g.p, tmin_g.p, nmax_g.p);
-  hipLaunchKernelGGL(cone_rect_kernel, dim3(cdiv(gt, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)cone.dirs_img.p, gt,
+  hipLaunchKernelGGL(cone_rect_kernel, dim3(cdiv(gt, 4), std::max(1u, std::min(16u, 512u / std::max(1u, cdiv(gt, 4u))))), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)cone.dirs_img.p, gt,
                      ntiles, words, (const float *)cone.cos_a.p, (const float *)cone.sin_a.p, theta_a, (const unsigned int *)cone.nmax.p,
                      (const unsigned int *)nmax_g.p, bits.p);
   hipLaunchKernelGGL(cone_rect_expand_kernel, dim3(cdiv((uint64_t)a_supers * stages * 8, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)bits.p,
