@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__r
 }
 
 // E = max over the rows of sqrt(sum of the 2 KS partial sums, in index order) (1 + 1e-6): see f16_row_error_kernel
-__global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uint64_t n, uint32_t slots, unsigned int *__restrict__ out_bits) {
+__global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uint64_t n, uint32_t slots, unsigned int *__restrict__ out_bits,
+                                        float *__restrict__ err_rows) {
   const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float e = 0.f;
   if (row < n) {
@@ -211,6 +212,7 @@ __global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uin
     for (uint32_t s_ = 0; s_ < slots; ++s_) e2 += err_part[row * slots + s_];
     const float ev = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6));  // rounded up
     if (ev == ev) e = ev;
+    if (err_rows) err_rows[row] = ev == ev ? ev : __builtin_inff();  // (by image position: the pruning's bound per pair)
   }
   for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(e));  // non-negative floats order like their bits
@@ -1138,10 +1140,13 @@ int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *
 // |stored product - cos| = |a.eb + ea.b + ea.eb| <= 2 E + E^2 (Cauchy-Schwarz), about half the worst case of 2^-11 per
 // element that cos_delta_f16 assumes: rounding errors of 128 elements do not all sit at the edge of their binade.
 __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t n,
-                                                            uint32_t d, unsigned int *__restrict__ out_bits) {
+                                                            uint32_t d, unsigned int *__restrict__ out_bits, const uint32_t *__restrict__ perm,
+                                                            float *__restrict__ err_rows) {
+  // (perm / err_rows: the error of the row at image position p = perm[p] goes to err_rows[p])
   const int lane = threadIdx.x & 63;
   float worst = 0.f;
-  for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (uint64_t)gridDim.x * 4) {
+  for (uint64_t pos = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pos < n; pos += (uint64_t)gridDim.x * 4) {
+    const uint64_t row = perm ? (uint64_t)perm[pos] : pos;
     const double nr = norms[row];
     double e2 = 0.0;
     if (nr > 0.0 && nr < __builtin_inf()) {
@@ -1156,6 +1161,7 @@ __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__rest
     for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
     const float e = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6)) ;  // rounded up
     if (e == e) worst = __builtin_fmaxf(worst, e);
+    if (err_rows && lane == 0) err_rows[pos] = e == e ? e : __builtin_inff();
   }
   if (lane == 0) atomicMax(out_bits, __float_as_uint(worst));  // non-negative floats order like their bits
 }
@@ -1187,12 +1193,14 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
       ProfScope ps(ctx, "pack_unit_rows");
       hipLaunchKernelGGL(pack_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, R, norms, perm, (uint64_t)0, n, d, KS, total,
                          (f16x8 *)P, part.p);
-      hipLaunchKernelGGL(f16_error_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)part.p, n, 2 * KS, bits.p);
+      hipLaunchKernelGGL(f16_error_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)part.p, n, 2 * KS, bits.p, err_rows);
+      err_rows = nullptr;  // (written)
     }
   } else {
     AS_TRY(pack_f16(ctx, R, norms, perm, 0, n, d, P, tiles));
     hipLaunchKernelGGL(f16_row_error_kernel, dim3((unsigned)std::min<uint64_t>(cdiv(n, 4), 256 * 32)), dim3(256), 0, ctx->stream, R, norms,
-                       n, d, bits.p);
+                       n, d, bits.p, perm, err_rows);
+    err_rows = nullptr;  // (written)
   }
   AS_HIP(ctx, hipGetLastError());
   unsigned int h = 0;
