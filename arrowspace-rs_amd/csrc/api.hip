@@ -465,6 +465,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_cone_tiles") ctx->opt_join_cone_tiles = value != 0;
   else if (n == "handle_cache_mb") handle_cache_limit(value);
   else if (n == "rerank_pair_bound") ctx->opt_rerank_pair_bound = value != 0;
+  else if (n == "join_theta_parts") ctx->opt_join_theta_parts = value != 0;
   else if (n == "join_theta_band_second") ctx->opt_join_theta_band_second = value != 0;
   else if (n == "join_theta_band") ctx->opt_join_theta_band = std::min<int64_t>(std::max<int64_t>(0, value), 8);
   else if (n == "join_theta_rate") {

@@ -97,6 +97,7 @@ struct as_ctx {
   int64_t opt_search_staged_min_batch = 1 << 30;  // batches from this size take the scan with the first pass instead of streaming all
                                                   // rows (measured: 1.5 ms of fixed cost against 0.46 - 1.0 ms of streaming: off)
   int64_t opt_rerank_pair_bound = 1;       // the pruning in front of the exact re-rank bounds each pair by its two rows' own plane errors
+  int64_t opt_join_theta_parts = 1;        // threshold passes with few rows split the sample over several units (0: one sweep per 256 rows)
   int64_t opt_join_theta_band_second = 1;  // the second pass never cuts below what the band certified
   int64_t opt_join_theta_band = 2;       // thresholds also from a row's own neighbourhood in the image: this many 512-position super tiles on either side (0: off)
   int64_t opt_join_theta_rate = 32;      // grouped thresholds: one image position in this many is sampled (a power of two, 2 .. 32)

@@ -430,7 +430,7 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   const size_t lds = std::max((size_t)2 * KS * 4 * 64 * 16, (size_t)8 * 32 * 65 * sizeof(float));
   // few rows (the check of the grouped thresholds, the open rows of the second pass): the sample split over several units per
   // 256 rows, so that there are a few hundred units
-  const uint32_t parts = a_supers >= 64 ? 1u : std::max(1u, std::min(std::min(16u, s_tiles / 2), 256u / std::max(1u, a_supers)));
+  const uint32_t parts = (a_supers >= 64 || !ctx->opt_join_theta_parts) ? 1u : std::max(1u, std::min(std::min(16u, s_tiles / 2), 256u / std::max(1u, a_supers)));
   DevBuf<float> bins;
   if (parts > 1) AS_TRY(bins.alloc(ctx, (size_t)a_supers * 256 * parts * 64));
   const unsigned grid = std::min<uint32_t>(a_supers * parts, 256u);

@@ -459,6 +459,26 @@ def test_item_graph_thresholds_from_the_own_neighbourhood(ctx, n, d, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+def test_thresholds_of_few_rows_from_a_split_sample(ctx):
+    """The threshold passes with few rows (the check of the grouped thresholds: 4 096 rows; the open rows of the second pass) split the
+    sample over several units per 256 rows and take the order statistic of the bin-wise maxima ("join_theta_parts", mfma_theta_f16.hip):
+    the very thresholds of one sweep -- the same candidate count, the same open rows at every stage, the same tables."""
+    X, _ = synth.mixture(150_000, 128, seed=42)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    seen = []
+    try:
+        for parts in (1, 0):
+            ctx.set_option("join_theta_parts", parts)
+            idx, dist = A.knn_cosine(X, gp)
+            seen.append((idx, dist, ctx.stat("knn_join_candidates"), ctx.stat("knn_uncertified_rows"), ctx.stat("knn_uncertified_rows_stage1a"),
+                         ctx.stat("knn_join_theta_grouped"), ctx.stat("knn_join_theta_grouped_bad")))
+    finally:
+        ctx.set_option("join_theta_parts", 1)
+    assert seen[0][2:] == seen[1][2:], (seen[0][2:], seen[1][2:])
+    assert seen[0][3] > 0  # (rows were left open: the second pass, and with it the fresh thresholds of a few rows, ran)
+    assert np.array_equal(seen[0][0], seen[1][0]) and np.array_equal(seen[0][1], seen[1][1])
+
+
 def _stress_case(seed, index):
     """Case `index` of scripts/stress_first_pass.py for `seed` (the same draws in the same order)."""
     rng = np.random.default_rng(seed)
