@@ -479,6 +479,21 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
           iv[q] = ei[64 * q + lane];
         }
       }
+      if (C <= 64u) {
+        // (nearly every row: one candidate per lane, and the keys compare as integers -- the order-preserving image of a double: sign
+        // bit set for non-negative values, all bits flipped for negative ones (a cosine a rounding above 1 gives a distance just below
+        // 0 where nothing is rectified); -0 and NaN do not occur: 1 - c is +0 at c = 1, NaN keys were replaced by +inf.  The general form
+        // below spends as much again on the empty second slot: ranking was 1.3 of the kernel's 6 ms)
+        const unsigned long long kraw = (unsigned long long)__double_as_longlong(kv[0]);
+        const unsigned long long kb = (kraw >> 63) ? ~kraw : (kraw | 0x8000000000000000ull);
+        for (uint32_t c2 = 0; c2 < C; ++c2) {
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, (int)c2);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), (int)c2);
+          const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)iv[0], (int)c2);
+          const unsigned long long kc = ((unsigned long long)hi << 32) | lo;
+          rank[0] += (kc < kb || (kc == kb && ic < iv[0])) ? 1u : 0u;
+        }
+      } else {
 #pragma unroll
       for (int q2 = 0; q2 < SLOTS; ++q2) {
         const uint32_t c_hi = C < 64u * (q2 + 1) ? C : 64u * (q2 + 1);
@@ -488,6 +503,7 @@ __global__ __launch_bounds__(64) void rerank_score_d128_kernel(const double *__r
 #pragma unroll
           for (int q = 0; q < SLOTS; ++q) rank[q] += lex_less(kc, ic, kv[q], iv[q]) ? 1u : 0u;
         }
+      }
       }
 #pragma unroll
       for (int q = 0; q < SLOTS; ++q)
