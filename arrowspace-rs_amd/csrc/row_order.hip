@@ -89,8 +89,11 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
     s_b[e] = v;
   }
   __syncthreads();
-  const uint32_t row0 = (blockIdx.x * 4 + (tid >> 6)) * 32;
-  if (row0 >= n) return;
+  // (a workgroup walks chunks of 128 rows: the 64 KB of pivot fragments above are built once per workgroup, not once per 128 rows
+  // -- with a workgroup per chunk the setup was most of the 0.32 ms this took at 1 M rows)
+  for (uint32_t chunk = blockIdx.x; chunk * 128u < n; chunk += gridDim.x) {
+  const uint32_t row0 = (chunk * 4 + (tid >> 6)) * 32;
+  if (row0 >= n) continue;
   ro_f16x8 a[2];
   {
     const uint32_t row = min(row0 + (uint32_t)lc, n - 1);
@@ -104,13 +107,13 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
       }
     }
   }
-  float best[16];
-  uint32_t arg[16];
+  // best (value, pivot) as ONE integer: the product's bits with the low ten replaced by 1023 - pivot (np <= 1024).  Integer order is
+  // float order for positive values, a larger key wins, an equal value goes to the lower pivot; the ten bits given up (1.2e-4
+  // relative) are below what the f16 operands resolve, and a row whose products are all negative gets SOME pivot -- any assignment
+  // gives a correct order.  Two instructions per product instead of a compare and two selects (the loop was bound by them).
+  int best[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    best[r] = -__builtin_inff();
-    arg[r] = 0;
-  }
+  for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000u;
   ro_v16f32 zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -118,30 +121,20 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
     const ro_f16x8 b0 = s_b[(t * 2 + 0) * 64 + lane], b1 = s_b[(t * 2 + 1) * 64 + lane];
     ro_v16f32 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b0, zero, 0, 0, 0);
     x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b1, x, 0, 0, 0);
-    const uint32_t p = t * 32 + (uint32_t)lc;
+    const uint32_t inv = 1023u - (t * 32 + (uint32_t)lc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (x[r] > best[r]) {
-        best[r] = x[r];
-        arg[r] = p;
-      }
+    for (int r = 0; r < 16; ++r) best[r] = max(best[r], (int)((__float_as_uint(x[r]) & 0xFFFFFC00u) | inv));
   }
   // accumulator register r of lane (lh, lc) = row 4 lh + (r & 3) + 8 (r >> 2) of the tile, column lc: the columns meet here
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float bv = best[r];
-    uint32_t ba = arg[r];
+    int bv = best[r];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const uint32_t oa = __shfl_xor(ba, o, 64);
-      if (ov > bv || (ov == bv && oa < ba)) {
-        bv = ov;
-        ba = oa;
-      }
-    }
+    for (int o = 16; o > 0; o >>= 1) bv = max(bv, __shfl_xor(bv, o, 64));
+    const uint32_t ba = 1023u - ((uint32_t)bv & 1023u);
     const uint32_t row = row0 + 4 * lh + (r & 3) + 8 * (r >> 2);
     if (lc == 0 && row < n) assign[row] = ba;
+  }
   }
 }
 
@@ -272,7 +265,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
   const size_t lds_mfma = (size_t)(np / 32) * 2 * 64 * 16;
   if (d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024 && ctx->opt_order_mfma) {  // the rotated coordinates: on the matrix pipe
-    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(cdiv(n, 128)), dim3(256), lds_mfma, ctx->stream, rows, n, piv, np, assign.p);
+    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), lds_mfma, ctx->stream, rows, n, piv, np, assign.p);
   } else
   switch (dpv / 32) {
     case 1: AS_ASSIGN(32); break;
@@ -299,7 +292,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
     }
     // (opt_join_order_sub = the divisor of the second set's size: 1 = as many pivots as the first, 2 = half, ...)
     const uint32_t np_sub = std::max<uint32_t>(32u, np / (uint32_t)std::max<int64_t>(1, ctx->opt_join_order_sub) / 32u * 32u);
-    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(cdiv(n, 128)), dim3(256), (size_t)(np_sub / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv_sub,
+    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 1024u)), dim3(256), (size_t)(np_sub / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv_sub,
                        np_sub, assign_sub.p);
     hipLaunchKernelGGL(order_group_starts_kernel, dim3(cdiv(np + 1, 256)), dim3(256), 0, ctx->stream, offsets.p, n_blocks, np, n, gs);
     hipLaunchKernelGGL(order_sub_kernel, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)gs, (const uint32_t *)assign_sub.p, (int)np, perm);
