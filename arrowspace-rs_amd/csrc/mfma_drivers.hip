@@ -1312,7 +1312,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       ctx->stats["knn_join_theta_checksum"] = (int64_t)(h & 0x7FFFFFFFFFFFFFFFull);
     }
     // How good they are depends on the data (do the pivots cover its clusters?), so they are CHECKED: 4096 rows spread over
-    // the image get their threshold against the whole sample as well (0.1 ms), and if more than 0.6 % of them sit more than
+    // the image get their threshold against the whole sample as well (0.1 ms), and if more than 1.0 % of them (0.6 % until round 4) sit more than
     // 5e-3 below it (rows whose neighbours live in groups the sample of their own group does not reach: every one of them
     // lists thousands of pairs) the grouped thresholds are dropped for the plain pass.  (1 M x 128 bench mixture, 1024
     // pivots: 0.24 %; 700 k rows: 0.27 %; 400 k rows, 768 pivots: 2.9 %; 200 k rows: 4.1 %.)

@@ -442,6 +442,9 @@ def test_item_graph_thresholds_from_the_own_neighbourhood(ctx, n, d, topk):
     X[11] = 0.0
     gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25)
     try:
+        # (the sampled thresholds from the plain sample in both runs: whether the grouped ones are kept is decided on the thresholds
+        # the join will use, band included, and the two runs must differ in the band alone)
+        ctx.set_option("join_theta_grouped", 0)
         ctx.set_option("join_theta_band", 0)
         idx0, dist0 = A.knn_cosine(X, gp)
         assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_row_order") == 1
@@ -449,8 +452,12 @@ def test_item_graph_thresholds_from_the_own_neighbourhood(ctx, n, d, topk):
         ctx.set_option("join_theta_band", 2)
         idx, dist = A.knn_cosine(X, gp)
         open1, cand1 = ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_candidates")
+        ctx.set_option("join_theta_grouped", 1)
+        idx2, dist2 = A.knn_cosine(X, gp)
+        assert np.array_equal(idx2, idx0) and np.array_equal(dist2, dist0)
     finally:
         ctx.set_option("join_theta_band", 2)
+        ctx.set_option("join_theta_grouped", 1)
     assert cand1 < cand0 and open1 <= open0 + max(2, open0 // 50), (cand0, cand1, open0, open1)
     assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
     rng = np.random.default_rng(6)
