@@ -119,7 +119,10 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               "join_theta_band" (2): thresholds raised to what a row's own neighbourhood in the ordered image
  *                               certifies (super tiles on either side; 0 = off), "join_theta_band_second" (1): the second pass
  *                               never cuts below them; "rerank_pair_bound" (1): the pruning in front of the exact re-rank bounds
- *                               each pair by its two rows' own f16 plane errors
+ *                               each pair by its two rows' own f16 plane errors; "join_theta_grouped_bad_e3" (10): the grouped
+ *                               thresholds are kept while at most this share (x 1e-3) of 4 096 checked rows sit far below the plain
+ *                               sample's; "join_theta_parts" (1), "join_unit_list" (1): threshold passes with few rows split the
+ *                               sample over several units / the masked f16 pass walks a list of the units that hold something
  *   "rerank_order" (1), "assembly_lanes" (2), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
  *                               exact re-rank in the order of the join's image, graph assembly (2 = the round-4 kernels, 1 = 32
  *                               lanes per row throughout, 0 = a thread per row), nearest-centroid keys of a clustering batch on
