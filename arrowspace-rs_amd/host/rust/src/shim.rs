@@ -24,7 +24,7 @@ use std::os::raw::c_void;
 pub(crate) fn thread_ctx() -> *mut AsCtx {
     thread_local! {
         static CTX: *mut AsCtx = {
-            assert_eq!(unsafe { hip::as_abi_version() }, 4, "libarrowspace_hip ABI mismatch");
+            assert_eq!(unsafe { hip::as_abi_version() }, hip::AS_ABI_VERSION, "libarrowspace_hip ABI mismatch");
             let mut c = std::ptr::null_mut();
             let rc = unsafe { hip::as_ctx_create(0, &mut c) };
             assert_eq!(rc, 0, "as_ctx_create failed: no gfx950 device (there is no CPU fallback in the library)");

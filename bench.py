@@ -32,6 +32,7 @@ Beside the contract's fields the JSON line carries (all measured in this run, HI
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -39,6 +40,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -50,6 +53,10 @@ MFMA16_PEAK_TFLOPS = 2500.0   # dense bf16 / f16 (v_mfma_f32_32x32x16_{bf16,f16}
 INT8_PEAK_TOPS = 5000.0       # dense int8 (v_mfma_i32_32x32x32_i8: twice the 16-bit rate, MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
+
+from source_sha import source_sha16  # noqa: E402
+
+SOURCE_SHA16 = source_sha16(ROOT)
 
 
 def parse():
@@ -124,24 +131,42 @@ def recorded_traffic(kernel_substr, n, d):
         parts = [p_ for p_ in parts if p_]
         if not parts:
             return None
-        return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"]}
+        return {"bytes_per_launch": sum(p_["bytes_per_launch"] for p_ in parts), "source": parts[0]["source"], "commit": parts[0]["commit"],
+                "stale": parts[0]["stale"], "source_sha16": parts[0]["source_sha16"]}
     best = None
     pdir = os.path.join(ROOT, "profiles")
     # (the item-graph lambda has a pass of its own: scripts/profile_round.sh)
     suffix = "_pmc_traffic_spmm.json" if kernel_substr == "signal_sums_kernel" else "_pmc_traffic.json"
-    files = sorted(x for x in (os.listdir(pdir) if os.path.isdir(pdir) else []) if x[:3] in ("r03", "r04") and x.endswith(suffix))
-    for name in files[-1:]:   # the newest pass only: a kernel that no longer exists must not bring an old file's bytes along
+    # Which pass: the one RECORDED last (`recorded_unix`, written by scripts/pmc_traffic.py), never the one whose file name sorts
+    # last (round 4 quoted r04zzzz, 25 commits old, over r04y).  Passes older than that field are eligible only when no newer one
+    # exists, ordered by the commit time noted in profiles/pmc_passes.json.  `stale` says whether the pass was taken on the very
+    # sources this process runs from (sha over csrc/ + include/: works on the GPU box, which has no .git).
+    passes = []
+    try:
+        with open(os.path.join(pdir, "pmc_passes.json")) as f:
+            legacy_time = json.load(f)
+    except (OSError, ValueError):
+        legacy_time = {}
+    for name in (os.listdir(pdir) if os.path.isdir(pdir) else []):
+        if not (re.match(r"r\d\d", name) and name.endswith(suffix)):
+            continue
         try:
             with open(os.path.join(pdir, name)) as f:
                 j = json.load(f)
         except (OSError, ValueError):
             continue
+        if j.get("n") != n or j.get("dim") != d:
+            continue
+        passes.append((j.get("recorded_unix") or legacy_time.get(name, 0), name, j))
+    passes.sort(key=lambda t: (t[0], t[1]))
+    for when, name, j in passes[-1:]:   # the newest pass only: a kernel that no longer exists must not bring an old file's bytes along
         for k in j.get("kernels", []):
-            if kernel_substr in k.get("kernel", "") and j.get("n") == n and j.get("dim") == d:
+            if kernel_substr in k.get("kernel", ""):
                 # (the PMC passes run ONE step, no warm-up: a kernel's total over the pass is its traffic per step)
                 best = {"bytes_per_launch": k.get("hbm_bytes_total"), "launches_per_step": k.get("launches"),
                         "bytes_per_single_launch": k.get("hbm_bytes_per_launch"),
-                        "source": "profiles/" + name, "commit": j.get("commit")}
+                        "source": "profiles/" + name, "commit": j.get("commit"),
+                        "stale": j.get("source_sha16") != SOURCE_SHA16, "source_sha16": j.get("source_sha16")}
     return best
 
 
@@ -451,7 +476,8 @@ def main():
             if rec:
                 # (this leg launches the kernel several times in the profiled pass: bytes per single launch)
                 extra["roofline_spmm"]["traffic"] = rec["bytes_per_single_launch"]
-                extra["roofline_spmm"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"],
+                extra["roofline_spmm"]["traffic_stale"] = rec["stale"]
+                extra["roofline_spmm"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"], "source_sha16": rec["source_sha16"],
                                                             "what": "bytes that left the L2s (TCC fabric reads x the guide's factor 2, + writes): "
                                                                     "the gathers the L2 misses, most of them served by the Infinity Cache, not HBM"}
             del gl_sp
@@ -487,7 +513,8 @@ def main():
                 rec = recorded_traffic(pmc or kernel.split(" ")[0].split("<")[0], n, d)
                 if rec:   # PMC counters cannot be read from inside this process: the committed rocprofv3 --pmc passes of the
                     e["traffic"] = rec["bytes_per_launch"]   # same command (scripts/profile_round.sh), per launch
-                    e["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
+                    e["traffic_source"] = {"file": rec["source"], "commit": rec["commit"], "source_sha16": rec["source_sha16"]}
+                    e["traffic_stale"] = rec["stale"]
             kernels.append(e)
 
         if stats["knn_join"] == 1:
@@ -597,7 +624,8 @@ def main():
                 rec = recorded_traffic("lambda_kernel", n, d)
                 if rec:
                     extra["roofline_scan"]["traffic"] = rec["bytes_per_launch"]
-                    extra["roofline_scan"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"]}
+                    extra["roofline_scan"]["traffic_source"] = {"file": rec["source"], "commit": rec["commit"], "source_sha16": rec["source_sha16"]}
+                    extra["roofline_scan"]["traffic_stale"] = rec["stale"]
         ss_kernel = ("pair_join_f16_kernel<KS, 1> (threshold scan of the search: one-f16-plane products, coarse test on the cosine, "
                      "lambda term against per-query score guesses in the listing)")
         ss_ms, ss_n = prof.get("search_scan_f16", (0.0, 0))

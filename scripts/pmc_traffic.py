@@ -8,8 +8,13 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_sha import source_sha16  # noqa: E402
 
 
 def short(name):
@@ -90,4 +95,5 @@ print(json.dumps({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, se
                              "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs",
                   "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950: FETCH_SIZE counts half of wide streaming reads), "
                                 "WRITE_SIZE x 1024 exact", "n": int(sys.argv[3]), "dim": int(sys.argv[4]), "commit": sys.argv[5],
+                  "recorded_unix": int(time.time()), "source_sha16": source_sha16(),
                   "kernels": kernels}, indent=1))

@@ -98,3 +98,46 @@ def test_rust_extern_block_lists_every_export():
     c_fields = re.findall(r"\b(\w+);", body)
     rs_fields = re.findall(r"pub (\w+):", re.search(r"pub struct AsGraphParams \{(.*?)\n\}", rs, flags=re.S).group(1))
     assert c_fields == rs_fields == [f[0] for f in _lib.GraphParamsC._fields_]
+
+
+def _header_abi_version():
+    hdr = open(os.path.join(ROOT, "include", "arrowspace_hip.h")).read()
+    return int(re.search(r"#define\s+AS_ABI_VERSION\s+(\d+)", hdr).group(1))
+
+
+def test_rust_shim_and_integration_doc_follow_the_header():
+    """The hand-written Rust side (host/rust/src/shim.rs, uncompiled: no rustc in the image) and INTEGRATION.md must not drift
+    from the header: the expected ABI version comes from ONE generated constant (hip.rs: AS_ABI_VERSION), every `hip::as_*` the
+    shim calls and every `as_*(` the document names is an export of the header, and the counts the document quotes are the
+    header's.  (Round 4 shipped a shim that asserted version 4 against a version-5 library: src/eigenmaps.rs:93-172 seam.)"""
+    want = _header_abi_version()
+    syms = set(_header_symbols())
+    rsdir = os.path.join(ROOT, "arrowspace-rs_amd", "host", "rust", "src")
+    hip_rs = open(os.path.join(rsdir, "hip.rs")).read()
+    assert int(re.search(r"pub const AS_ABI_VERSION: c_int = (\d+);", hip_rs).group(1)) == want
+    shim = open(os.path.join(rsdir, "shim.rs")).read()
+    code = "\n".join(line.split("//")[0] for line in shim.splitlines())
+    # the version check reads the generated constant, never a literal
+    m = re.search(r"assert_eq!\(\s*unsafe \{ hip::as_abi_version\(\) \}\s*,\s*([^,]+),", code)
+    assert m and m.group(1).strip() == "hip::AS_ABI_VERSION", m and m.group(1)
+    used = set(re.findall(r"\bhip::(as_[a-z0-9_]+)\s*\(", code))
+    assert used and used <= syms, sorted(used - syms)
+    # every hip:: item that is not a function is a type or constant hip.rs defines
+    for item in set(re.findall(r"\bhip::([A-Z][A-Za-z0-9_]*)", code)):
+        assert re.search(r"pub (?:struct|const|type) %s\b" % item, hip_rs), item
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", doc)) | set(re.findall(r"`(as_[a-z0-9_]+)`", doc))
+    named = {s_ for s_ in named if not s_.endswith("_")}   # `as_jl_*`-style families are prefixes, checked below
+    named -= {"as_ptr", "as_mut_ptr"}   # Rust slice methods in the excerpts, not exports
+    assert named <= syms | {"as_graph_params", "as_ctx", "as_csr", "as_index", "as_comm", "as_comm_ops", "as_jl", "as_clustering"}, \
+        sorted(named - syms)
+    for prefix in re.findall(r"`(as_[a-z0-9_]+_)\*`", doc):
+        assert any(s_.startswith(prefix) for s_ in syms), prefix
+    for v in re.findall(r"ABI version (\d+)", doc) + re.findall(r"AS_ABI_VERSION: c_int = (\d+)", doc) + \
+            re.findall(r"as_abi_version\(\)[^\n]*?==\s*(\d+)", doc):
+        assert int(v) == want, "INTEGRATION.md names ABI %s, the header %d" % (v, want)
+    for cnt in re.findall(r"\((\d+), ABI version", doc):
+        assert int(cnt) == len(syms)
+    m = re.search(r"// \.\.\. (\d+) more: see host/rust/src/hip.rs", doc)
+    shown = len(set(re.findall(r"pub fn (as_[a-z0-9_]+)\(", doc.split("// ...")[0].split("```rust")[-1])))
+    assert m and int(m.group(1)) + shown == len(syms), (m and m.group(1), shown, len(syms))
