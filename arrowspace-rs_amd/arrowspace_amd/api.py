@@ -153,9 +153,15 @@ class Context:
         """as_device_upload: a host matrix / vector -> HBM once; the DeviceArray that comes back is accepted wherever rows,
         items, queries or lambdas are (the library uses device pointers in place)."""
         a = np.asarray(array)
-        # every data pointer of the C ABI is f64 (u32 only for a row order): anything else is converted HERE, so that a
-        # float32 / integer matrix is never reinterpreted as doubles on the device
-        a = np.ascontiguousarray(a, dtype=np.uint32 if a.dtype == np.uint32 else np.float64)
+        # every data pointer of the C ABI is f64 (u32 only for a row order).  Floating-point input is widened HERE, so that a
+        # float32 matrix is never reinterpreted as doubles on the device; integers other than uint32 are refused (an int64
+        # permutation silently turned into doubles is a wrong order, not a conversion)
+        if a.dtype == np.uint32:
+            a = np.ascontiguousarray(a)
+        elif a.dtype.kind == "f":
+            a = np.ascontiguousarray(a, dtype=np.float64)
+        else:
+            raise TypeError("upload takes floating-point data (widened to float64) or a uint32 row order, got %s" % a.dtype)
         h = C.c_void_p()
         self.check(self.lib.as_device_upload(self.h, a.ctypes.data, a.nbytes, C.byref(h)))
         return DeviceArray(self, h, a.shape, a.dtype)
@@ -212,7 +218,8 @@ def _is_torch(x):
 def _f64(a, ctx=None):
     if _lib.is_tensor(a):
         if isinstance(a, DeviceArray):
-            assert a.dtype == np.float64, "a DeviceArray handed to the library as rows / items / lambdas must hold float64"
+            if a.dtype != np.float64:   # (not an assert: python -O strips those)
+                raise TypeError("a DeviceArray handed to the library as rows / items / lambdas must hold float64, got %s" % a.dtype)
         elif str(getattr(a, "dtype", "")) not in ("torch.float64", ""):
             raise TypeError("tensors handed to the library as rows / items / lambdas must be float64, got %s" % a.dtype)
         if a.is_cuda and ctx is not None:
@@ -281,7 +288,19 @@ class CsrMatrix:
         if order is None:
             self.ctx.check(self.ctx.lib.as_csr_set_order(self.ctx.h, self.h, None))
             return
-        order = order if _lib.is_tensor(order) else np.ascontiguousarray(order, dtype=np.uint32)
+        if _lib.is_tensor(order):
+            dt = str(getattr(order, "dtype", ""))
+            if isinstance(order, DeviceArray):
+                if order.dtype != np.uint32:
+                    raise TypeError("a row order on the device must hold uint32, got %s" % order.dtype)
+            elif dt in ("torch.int64", "torch.int16", "torch.uint8", "torch.int8"):   # e.g. torch.argsort's int64
+                import torch
+                order = order.to(torch.int32).contiguous()
+            elif dt not in ("torch.int32", "torch.uint32"):
+                raise TypeError("a row order must be an integer tensor, got %s" % dt)
+            self._order_keepalive = order
+        else:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
         self.ctx.check(self.ctx.lib.as_csr_set_order(self.ctx.h, self.h, ptr(order)))
 
     def to_dense(self):

@@ -577,11 +577,11 @@ class LibComm:
         taumode = taumode or A.TauMode.Median
         f = int(X_shard.shape[1])
         lo, hi = self.shard_range(n_total)
-        if torch.is_tensor(X_shard):
-            Xs = X_shard.contiguous()
+        Xs = A._f64(X_shard, ctx)   # float64 or TypeError: a float32 shard must not be read as doubles
+        if torch.is_tensor(Xs):
+            Xs = Xs.contiguous()
             out = torch.empty(f, dtype=torch.float64, device=Xs.device)
         else:
-            Xs = np.ascontiguousarray(X_shard, dtype=np.float64)
             out = np.empty(f, dtype=np.float64)
         A._adopt_torch_stream(ctx)
         ctx.check(ctx.lib.as_compute_taumode_signals_sharded(ctx.h, self.h, ptr(Xs) if hi > lo else None, int(n_total), f,

@@ -9,6 +9,7 @@
 
 #include <unordered_map>
 #include <map>
+#include <set>
 #include <deque>
 #include <vector>
 #include "common.h"
@@ -83,13 +84,20 @@ namespace asx {
 namespace {
 struct HandleCache {
   std::mutex mu;
+  // Streams the library's contexts run on (their own, or the caller's: as_ctx_set_stream), per device.  A block given back is
+  // stamped with one event per such stream, recorded at that moment; its next owner waits for THOSE events on the host, i.e. for
+  // the work queued before the free on the streams that can have touched the block -- not for the whole device, which stalled
+  // every other context, torch's streams and concurrent searches of a shared index (hipDeviceSynchronize, until round 5).
+  std::multiset<std::pair<int, hipStream_t>> streams;
+  std::unordered_map<void *, std::vector<hipEvent_t>> stamps;  // idle block -> events to wait for
+  std::vector<hipEvent_t> event_pool;
   std::unordered_map<void *, std::pair<int, size_t>> live;           // blocks handed out: device, bytes
   std::multimap<std::pair<int, size_t>, void *> idle;                // blocks given back, by (device, bytes)
   std::deque<std::pair<void *, std::pair<int, size_t>>> idle_order;  // ... oldest first, for eviction
   size_t idle_bytes = 0;
   size_t cap = [] {
     const char *e = std::getenv("ARROWSPACE_HANDLE_CACHE_MB");
-    const long long mb = e ? std::atoll(e) : 4096;
+    const long long mb = e ? std::atoll(e) : 2048;
     return (size_t)(mb > 0 ? mb : 0) << 20;
   }();
   // evicts until at most `limit` idle bytes remain; returns the blocks to hipFree (outside the lock)
@@ -104,6 +112,11 @@ struct HandleCache {
           idle.erase(it);
           idle_bytes -= v.second.second;
           out.push_back(v.first);
+          auto st = stamps.find(v.first);
+          if (st != stamps.end()) {  // (the hipFree that follows waits for the device by itself)
+            event_pool.insert(event_pool.end(), st->second.begin(), st->second.end());
+            stamps.erase(st);
+          }
           break;
         }
     }
@@ -122,6 +135,8 @@ hipError_t handle_malloc(void **p, size_t bytes) {
   (void)hipGetDevice(&dev);
   bytes = bytes ? bytes : 1;
   void *hit = nullptr;
+  std::vector<hipEvent_t> wait;
+  bool stamped = false;
   {
     std::lock_guard<std::mutex> g(c.mu);
     auto it = c.idle.find({dev, bytes});
@@ -134,11 +149,27 @@ hipError_t handle_malloc(void **p, size_t bytes) {
           c.idle_order.erase(o);
           break;
         }
+      auto st = c.stamps.find(hit);
+      if (st != c.stamps.end()) {
+        wait = std::move(st->second);
+        c.stamps.erase(st);
+        stamped = true;
+      }
     }
   }
   if (hit) {
-    // whatever still reads or writes the block on any stream of the device finishes first (what hipFree did for its last owner)
-    const hipError_t e = hipDeviceSynchronize();
+    // whatever still reads or writes the block finishes first (what hipFree did for its last owner): the events recorded when it
+    // was given back, one per stream the library runs on; a block without a stamp (no event to be had) waits for the device
+    hipError_t e = hipSuccess;
+    if (!stamped) e = hipDeviceSynchronize();
+    for (hipEvent_t ev : wait) {
+      const hipError_t e1 = hipEventSynchronize(ev);
+      if (e1 != hipSuccess) e = e1;
+    }
+    {
+      std::lock_guard<std::mutex> g(c.mu);
+      c.event_pool.insert(c.event_pool.end(), wait.begin(), wait.end());
+    }
     if (e != hipSuccess) return e;
     *p = hit;
   } else {
@@ -172,6 +203,33 @@ hipError_t handle_free(void *p) {
       const auto key = it->second;
       c.live.erase(it);
       if (c.cap > 0 && key.second <= c.cap) {
+        // stamp: an event on every registered stream of the block's device (recorded under the lock: a handful of microseconds)
+        std::vector<hipEvent_t> evs;
+        bool ok = true;
+        hipStream_t last = (hipStream_t)-1;
+        for (auto sit = c.streams.lower_bound({key.first, (hipStream_t)0}); ok && sit != c.streams.end() && sit->first == key.first; ++sit) {
+          if (sit->second == last) continue;  // (a stream several contexts share)
+          last = sit->second;
+          hipEvent_t ev = nullptr;
+          if (!c.event_pool.empty()) {
+            ev = c.event_pool.back();
+            c.event_pool.pop_back();
+          } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+            break;
+          }
+          evs.push_back(ev);
+          if (hipEventRecord(ev, sit->second) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+          }
+        }
+        if (ok) {
+          c.stamps[p] = std::move(evs);
+        } else {  // no stamp: the next owner synchronises the device
+          c.event_pool.insert(c.event_pool.end(), evs.begin(), evs.end());
+        }
         c.idle.insert({key, p});
         c.idle_order.push_back({p, key});
         c.idle_bytes += key.second;
@@ -184,6 +242,17 @@ hipError_t handle_free(void *p) {
   for (void *q : drop) (void)hipFree(q);
   if (!keep) e = hipFree(p);
   return e;
+}
+
+void handle_cache_stream(int device, hipStream_t s, bool add) {
+  HandleCache &c = handle_cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  if (add) {
+    c.streams.insert({device, s});
+  } else {
+    auto it = c.streams.find({device, s});
+    if (it != c.streams.end()) c.streams.erase(it);
+  }
 }
 
 void handle_cache_release() {
@@ -395,6 +464,7 @@ int as_ctx_create(int device, as_ctx **out) {
     return AS_ERR_HIP;
   }
   c->own_stream = true;
+  handle_cache_stream(device, c->stream, true);
   *out = c;
   return AS_OK;
 }
@@ -404,6 +474,7 @@ void as_ctx_destroy(as_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   prof_resolve(ctx);
+  handle_cache_stream(ctx->device, ctx->stream, false);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   join_session_close(ctx);
@@ -418,9 +489,11 @@ int as_ctx_set_stream(as_ctx *ctx, void *hip_stream) {
   AS_TRY(check_ctx(ctx));
   (void)hipStreamSynchronize(ctx->stream);
   prof_resolve(ctx);
+  handle_cache_stream(ctx->device, ctx->stream, false);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   ctx->own_stream = false;
   ctx->stream = (hipStream_t)hip_stream;  // NULL = HIP's default (null) stream
+  handle_cache_stream(ctx->device, ctx->stream, true);
   return AS_OK;
 }
 
@@ -825,7 +898,13 @@ int as_laplacian_from_knn_rows(as_ctx *ctx, const uint64_t *nbr_idx, const doubl
   AS_TRY(idx32.alloc(ctx, n_nodes * K));
   hipLaunchKernelGGL(narrow_idx_kernel, dim3(cdiv(n_nodes * K, 256)), dim3(256), 0, ctx->stream, I.p, n_nodes * K,
                      idx32.p);
-  return laplacian_from_knn(ctx, idx32.p, D.p, n_nodes, K, params, out, row_begin, row_count);
+  AS_TRY(laplacian_from_knn(ctx, idx32.p, D.p, n_nodes, K, params, out, row_begin, row_count));
+  // A caller's table may hold dist(i, j) != dist(j, i): a mutual pair then keeps each row's OWN weight and L is not bitwise
+  // symmetric.  Only graphs whose distances the library computed itself are symmetric by construction (as_build_laplacian, the
+  // sharded build: they set the flag again); here the one-pass bitwise check of the item-graph lambda decides (a row block
+  // streams all of its entries).
+  (*out)->known_symmetric = 0;
+  return AS_OK;
 }
 
 int as_laplacian_from_knn(as_ctx *ctx, const uint64_t *nbr_idx, const double *nbr_dist, uint64_t n_nodes,

@@ -79,7 +79,7 @@ struct as_ctx {
   int64_t opt_assembly_lanes = 2;        // graph assembly (K <= 32): 2 = the round-4 kernels (graph_assembly.hip), 1 = 32 lanes per row throughout, 0 = a thread per row
   int64_t opt_search_rot_tail_e3 = 100;  // a re-searched index keeps rotated int8 images when the tail of its items is at most this (x 1e-3)
   int64_t opt_sharded_agreement = 1;     // sharded build: a one-word all-reduce of "has anyone failed" in front of every data collective (sharded.hip)
-  int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange) or 3 (before the nnz all-reduce)
+  int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange), 3 (before the nnz all-reduce); 4 statistics, 5 search; item-graph lambda: 6 (first stage), 7 (after the sums exchange), 8 (its rank-local argument checks)
   int64_t opt_join_basis_iters = 4;      // rotated coordinates: rounds of subspace iteration on the 16 k-row sample (each 0.15 ms: three small kernels, two copies, a host Gram-Schmidt; hard mixture 98.2 / 94.7 / 93.2 / 93.9 ms at 2 / 3 / 4 / 5 rounds, the bench data indifferent from 3 on)
   int64_t opt_join_order_sub = 4;        // row order of the join: inside a pivot's group, by the nearest pivot of a second set of np / this pivots (0 = off; 0.45 ms per million rows; pays wherever a group holds several clusters)
   int64_t opt_join_cone_tiles = 1;       // rotated first pass on an ordered image: behind a cone bound on pairs of 128-position tiles (cone_tiles.hip)
@@ -513,9 +513,11 @@ struct ConeDirs {
   bool valid = false;
 };
 // Memory owned by handles (as_csr, as_index, as_jl, uploads): a block a destroyed handle gives back is kept (up to a cap) and handed
-// to the next allocation of exactly its size on the same device, after a device synchronisation -- hipFree costs ~150 us whatever
+// to the next allocation of exactly its size on the same device, after the work queued on the library's streams when it was given back -- hipFree costs ~150 us whatever
 // the size (it synchronises and unmaps), and a loop that rebuilds a graph or an index asks for the same sizes again.  The cap:
-// environment ARROWSPACE_HANDLE_CACHE_MB or option "handle_cache_mb" (default 4096; 0 = off, and what is cached is released).
+// environment ARROWSPACE_HANDLE_CACHE_MB or option "handle_cache_mb" (default 2048; 0 = off, and what is cached is released).
+// Reuse waits for events recorded at the free on the streams the library's contexts run on (handle_cache_stream), not for the device.
+void handle_cache_stream(int device, hipStream_t s, bool add);
 hipError_t handle_malloc(void **p, size_t bytes);
 hipError_t handle_free(void *p);
 void handle_cache_limit(int64_t mb);

@@ -168,6 +168,11 @@ struct Agreement {
 // list ran over, or a merged list longer than `slots`, is reported as slots + 1 entries: the re-rank takes that as an overflow
 // and the row goes on to the second pass.
 // cnt_src: W x rows (raw counts); recv: the used slots, source-major; off: exclusive scan of min(cnt, slots) in that order.
+__global__ void scale_f64_kernel(double *__restrict__ p, uint64_t n, double f) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = __dmul_rn(p[i], f);
+}
+
 __global__ __launch_bounds__(256) void merge_lists_kernel(const uint32_t *__restrict__ cnt_src, const uint2 *__restrict__ recv,
                                                           const uint64_t *__restrict__ off, uint32_t W, uint32_t me, uint32_t rows,
                                                           uint32_t slots, const uint32_t *__restrict__ perm, uint32_t *__restrict__ cnt2,
@@ -691,6 +696,7 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
   uint64_t nnz = 0;
   if (rows_here) {
     AS_TRY(as_laplacian_from_knn_rows(ctx, idx_all.p, dst_all.p, n, params, lo, rows_here, out_block));
+    (*out_block)->known_symmetric = 1;  // the table is the library's own: one distance per pair
     nnz = as_csr_nnz(*out_block);
   }
   AS_TRY(inject(3));
@@ -866,16 +872,18 @@ int as_compute_taumode_signals_sharded(as_ctx *ctx, as_comm *comm, const double 
   const uint32_t S = (uint32_t)n_features, s_pad = signal_pad(S);
   uint64_t lo, hi;
   shard_range(n_total, comm->rank, W, &lo, &hi);
-  if ((hi > lo) && !items_shard) return fail(ctx, AS_ERR_ARG, "null shard");
   as_csr *L = const_cast<as_csr *>(L_block);
-  if (L && (L->row_begin != lo || L->n != hi - lo || (L->n_cols ? L->n_cols : L->n) > n_total))
-    return fail(ctx, AS_ERR_ARG, "the row block does not belong to this rank's range of rows");
   Agreement ag{ctx, comm, ctx->opt_sharded_agreement != 0};
   auto leave = [&](int rc) -> int {  // a local failure: said once in the next agreement
     const std::string err = ctx->err;
     ag.announce_failure();
     return fail(ctx, rc, err);
   };
+  // rank-local argument checks: a rank that fails them says so in the first agreement instead of leaving its peers in it
+  if (ctx->opt_sharded_inject_failure == 8) return leave(fail(ctx, AS_ERR_HIP, "sharded item-graph lambda: injected failure"));
+  if ((hi > lo) && !items_shard) return leave(fail(ctx, AS_ERR_ARG, "null shard"));
+  if (L && (L->row_begin != lo || L->n != hi - lo || (L->n_cols ? L->n_cols : L->n) > n_total))
+    return leave(fail(ctx, AS_ERR_ARG, "the row block does not belong to this rank's range of rows"));
 #define AS_STAGE(expr)                  \
   do {                                  \
     const int _rc = (expr);             \
@@ -923,19 +931,35 @@ int as_compute_taumode_signals_sharded(as_ctx *ctx, as_comm *comm, const double 
     const int rc = comm->ops.all_gather_v(comm->ops.user, sums_mine.p, (uint64_t)4 * s_pad * 8, sums_all.p, rb.data(), ro.data(), ctx->stream);
     if (rc != AS_OK) return fail(ctx, rc, "sharded item-graph lambda: all-gather failed");
   }
+  // Stage 3 ends in an agreement of its own, whether a second round follows or not: a rank that fails here while its peers
+  // need no second round would otherwise announce into a collective nobody else enters (and poison the NEXT sharded call).
   int need_h = 0;
   auto stage3 = [&]() -> int {
+    if (ctx->opt_sharded_inject_failure == 7) return fail(ctx, AS_ERR_HIP, "sharded item-graph lambda: injected failure");
     AS_TRY(signal_rank_sum(ctx, sums_all.p, (uint32_t)W, 4 * s_pad, sums.p));
     AS_TRY(signal_need_pass2(ctx, sums.p, S, need.p));
     AS_HIP(ctx, copy_d2h(ctx, &need_h, need.p, sizeof(int)));  // the same value on every rank: the totals are
-    if (need_h) {
-      if (L) AS_TRY(signal_shares(ctx, all_rows.p, S, L, sums.p, need.p, g2_mine.p));
-      else AS_HIP(ctx, hipMemsetAsync(g2_mine.p, 0, sizeof(double) * s_pad, ctx->stream));
-    }
     return AS_OK;
   };
   AS_STAGE(stage3());
+  AS_TRY(ag.before_collective());
   if (need_h) {
+    auto stage4 = [&]() -> int {
+      if (L) {
+        AS_TRY(signal_shares(ctx, all_rows.p, S, L, sums.p, need.p, g2_mine.p));
+        // A block streamed as its upper triangle saw every pair once: its shares count twice.  The factor belongs to the
+        // block's cached record stream (L->sig_sym), not to the option's value at this call, and blocks may differ -- so every
+        // rank applies its own before the exchange (a doubling is exact: the rank-ordered sum is the same bit for bit).
+        if (L->sig_sym) {
+          hipLaunchKernelGGL(scale_f64_kernel, dim3(cdiv(s_pad, 256)), dim3(256), 0, ctx->stream, g2_mine.p, (uint64_t)s_pad, 2.0);
+          AS_HIP(ctx, hipGetLastError());
+        }
+      } else {
+        AS_HIP(ctx, hipMemsetAsync(g2_mine.p, 0, sizeof(double) * s_pad, ctx->stream));
+      }
+      return AS_OK;
+    };
+    AS_STAGE(stage4());
     AS_TRY(ag.before_collective());
     std::vector<uint64_t> rb((size_t)W, (uint64_t)s_pad * 8), ro((size_t)W);
     for (int r = 0; r < W; ++r) ro[(size_t)r] = (uint64_t)r * s_pad * 8;
@@ -944,8 +968,7 @@ int as_compute_taumode_signals_sharded(as_ctx *ctx, as_comm *comm, const double 
     AS_TRY(signal_rank_sum(ctx, g2_all.p, (uint32_t)W, s_pad, g2.p));
   }
 #undef AS_STAGE
-  // every block of the library's graphs is symmetric by construction: a pair was taken once unless the option says otherwise
-  AS_TRY(signal_lambda_from_sums(ctx, sums.p, g2.p, need.p, ctx->opt_signal_sym != 0, S, tau.p, O.p));
+  AS_TRY(signal_lambda_from_sums(ctx, sums.p, g2.p, need.p, /*upper_only=*/false, S, tau.p, O.p));
   AS_TRY(O.finish(ctx));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AS_OK;

@@ -197,13 +197,15 @@ def main():
     from arrowspace_amd import distributed as D
     from arrowspace_amd import synth
 
-    ctx = A.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx._stream = torch.cuda.current_stream().cuda_stream
-    ctx.set_option("cand_precision", args.cand_precision)
-    ctx.set_option("join_pipe", args.join_pipe)
-    ops = D.HipOps(ctx)
+    def make_ctx():
+        c = A.Context(local_rank)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c._stream = torch.cuda.current_stream().cuda_stream
+        c.set_option("cand_precision", args.cand_precision)
+        c.set_option("join_pipe", args.join_pipe)
+        return c
 
+    ctx = make_ctx()
     n, d, nq = args.n, args.dim, args.nq
     lo, hi = D.shard_range(n, rank, world)
     # seeded mixture rows, generated on the device (the numpy form of the same generator takes 35 s per 1 M x 128)
@@ -226,31 +228,41 @@ def main():
         # collective run in a side thread under a deadline: a rank that cannot come up says so in an all-reduce on torch's
         # process group, and then EVERY rank continues on the torch.distributed exchange instead (reported in `transport`);
         # nothing is re-executed, and a hung bring-up cannot hang the job.
+        # The bring-up thread owns a context and a communicator of its OWN (a context is one per thread and not re-entrant,
+        # INTEGRATION.md): on success the whole run adopts that pair; on a timeout the main thread never touches either again
+        # (a late success inside the abandoned thread then meets no peer and no shared state), and the vote below runs on a
+        # gloo group, so it cannot queue behind hung device work.
         import threading
+        vote_group = dist.new_group(backend="gloo")
         box = [D.LibComm.unique_id(ctx) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         result = {}
 
         def bring_up():
             try:
-                c = D.LibComm.rccl(ctx, box[0], rank, world)
+                torch.cuda.set_device(dev)
+                cb = make_ctx()
+                c = D.LibComm.rccl(cb, box[0], rank, world)
                 c.lambda_stats(torch.zeros(1, dtype=torch.float64, device=dev))   # first collective: a 32-byte all-gather
-                result["comm"] = c
+                cb.synchronize()
+                result["ctx"], result["comm"] = cb, c
             except Exception as e:  # noqa: BLE001
                 result["error"] = repr(e)
 
         th = threading.Thread(target=bring_up, daemon=True)
         th.start()
         th.join(float(os.environ.get("ARROWSPACE_RCCL_TIMEOUT_S", "120")))
-        ok = torch.tensor([1 if "comm" in result else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        came_up = (not th.is_alive()) and "comm" in result
+        ok = torch.tensor([1 if came_up else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=vote_group)
         if int(ok) == 1:
-            libcomm = result["comm"]
+            ctx, libcomm = result["ctx"], result["comm"]
             transport = "library exchange over its own RCCL communicator"
         else:
             why = result.get("error", "timed out" if th.is_alive() else "a peer failed")
             transport = "torch.distributed (nccl), stage-level entry points -- FALLBACK: the library's RCCL communicator did not come up (%s)" % why
             sys.stderr.write("bench.py rank %d: %s\n" % (rank, transport))
+    ops = D.HipOps(ctx)
     sas = D.ShardedArrowSpace(ops, Xd, n, gp, A.TauMode.Median, libcomm=libcomm)
 
     def sync():

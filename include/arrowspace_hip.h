@@ -127,7 +127,7 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               exact re-rank in the order of the join's image, graph assembly (2 = the round-4 kernels, 1 = 32
  *                               lanes per row throughout, 0 = a thread per row), nearest-centroid keys of a clustering batch on
  *                               the f32 matrix pipe, clustering batches on the device (0 = the older form of each, for comparison)
- *   "handle_cache_mb" (4096)    memory of destroyed handles (CSR slabs, index images, uploads) kept for the next allocation of the
+ *   "handle_cache_mb" (2048)    memory of destroyed handles (CSR slabs, index images, uploads) kept for the next allocation of the
  *                               same size instead of hipFree + hipMalloc (process-wide; environment ARROWSPACE_HANDLE_CACHE_MB;
  *                               0 = off and released)
  *   "debug"                     diagnostics only (outputs may be undefined) */
