@@ -457,9 +457,14 @@ __device__ __forceinline__ bool prune_tau(const float *es, uint32_t C, uint32_t 
   int stop = 0;
   if (delta > 0.0) {
     const float top_score = fabsf(__uint_as_float((kmax & 0x80000000u) ? (kmax & 0x7FFFFFFFu) : ~kmax));
-    int e = 0;
-    (void)frexpf(top_score, &e);                                  // top_score < 2^e: one unit in the last place <= 2^(e - 24)
-    stop = (int)floor(log2(delta / 8.0)) - (e - 24);
+    // top_score < 2^e: one unit in the last place <= 2^(e - 24).  Exponents read off the bits (frexpf and floor(log2()) in f64
+    // were a tenth of the pruning kernel's instructions): for a normal x, floor(log2 x) is its unbiased exponent and frexp's e is
+    // that + 1; a zero score takes e = 0 as with frexpf (a subnormal one too: any stop is valid, it only moves how tight tau is)
+    const uint32_t tb = __float_as_uint(top_score) >> 23;
+    const int e = tb ? (int)tb - 126 : 0;
+    const unsigned long long db = (unsigned long long)__double_as_longlong(delta / 8.0) >> 52;
+    const int lg = db ? (int)(db & 0x7FFu) - 1023 : -1023;
+    stop = lg - (e - 24);
     stop = stop < 0 ? 0 : stop;
   }
   for (int bit = top; bit >= stop; --bit) {
@@ -547,7 +552,118 @@ __device__ __forceinline__ uint32_t prune_candidates_pairwise(uint32_t *ei, floa
 
 }  // namespace asx
 #include "rerank_split.h"
+#include "rerank_pairs.h"
 namespace asx {
+
+// records (rerank_prune_kernel) -> every pair scored once -> the K best of every row + the rows that could not be certified
+// (rerank_pairs.h).  records are by place p: row = order ? order[p] : p, its id a_ids ? a_ids[row] : row_begin + row;
+// row2rec: row id -> record of the whole-matrix image order (the inverse of `order`), or nullptr (built here).
+__global__ void gather_f64_kernel(const double *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, double *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+struct RerankPairsState {  // what outlives rerank_pairs_launch until the caller's next read-back
+  DevBuf<uint32_t> map, s_ids, meta, rowpos, seg_batches;
+  DevBuf<uint64_t> seg_off;
+  DevBuf<rp_u4> s_desc;
+  DevBuf<unsigned long long> counters;
+  uint32_t cap_batches = 0;
+};
+template <int SLOTS>
+static int rerank_pairs_launch(as_ctx *ctx, RerankPairsState &st, uint64_t cap_batches, const double *rows, uint32_t d, uint64_t n_total,
+                               uint32_t row_begin, uint32_t row_count, uint32_t *records, uint32_t K, int rectify, GraphBound bnd, double *out_dist,
+                               uint32_t *out_idx, uint32_t *fail_rows, uint32_t *fail_count, const uint32_t *a_ids, const uint32_t *order,
+                               const uint32_t *row2rec) {
+  constexpr uint32_t S = 64u * SLOTS;
+  const uint32_t n_seg = (row_count + kRpSeg - 1) / kRpSeg;
+  const int share = ctx->opt_rerank_share && row_count < kRpShareMax;
+  if (share && !row2rec) {
+    if (!st.map.p) {
+      AS_TRY(st.map.alloc(ctx, n_total));
+      AS_HIP(ctx, hipMemsetAsync(st.map.p, 0xFF, sizeof(uint32_t) * n_total, ctx->stream));
+      hipLaunchKernelGGL(rerank_row2rec_kernel, dim3(cdiv(row_count, 256)), dim3(256), 0, ctx->stream, row_begin, row_count, a_ids, order, st.map.p);
+    }
+    row2rec = st.map.p;
+  }
+  if (cap_batches >= 0xFFFFFFF0ull / 16) return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: too many pairs for one call");
+  st.cap_batches = (uint32_t)cap_batches;
+  AS_TRY(st.s_ids.alloc(ctx, (size_t)cap_batches * 16));
+  AS_TRY(st.s_desc.alloc(ctx, (size_t)cap_batches * 16));
+  if (!st.counters.p) AS_TRY(st.counters.alloc(ctx, kRpCounters));
+  AS_HIP(ctx, hipMemsetAsync(st.counters.p, 0, sizeof(unsigned long long) * kRpCounters, ctx->stream));
+  AS_TRY(st.meta.alloc(ctx, (size_t)row_count * S));
+  AS_TRY(st.rowpos.alloc(ctx, row_count));
+  AS_TRY(st.seg_batches.alloc(ctx, n_seg));
+  AS_TRY(st.seg_off.alloc(ctx, (size_t)n_seg + 1));
+  {
+    ProfScope ps(ctx, "knn_rerank_link");
+    hipLaunchKernelGGL((rerank_link_kernel<SLOTS>), dim3(std::min<uint32_t>(n_seg, 256u * 32u)), dim3(256), 0, ctx->stream, row_begin, row_count,
+                       records, a_ids, order, row2rec, share, st.meta.p, st.rowpos.p, st.seg_batches.p, st.counters.p);
+    AS_HIP(ctx, hipGetLastError());
+    AS_TRY(exclusive_scan_u32_u64(ctx, st.seg_batches.p, n_seg, st.seg_off.p));
+  }
+  {
+    ProfScope ps(ctx, "knn_rerank_fill");
+    hipLaunchKernelGGL((rerank_fill_kernel<SLOTS>), dim3(std::min<uint32_t>(n_seg, 256u * 32u)), dim3(256), 0, ctx->stream, row_begin, row_count,
+                       (const uint32_t *)records, a_ids, order, (const uint32_t *)st.meta.p, (const uint32_t *)st.rowpos.p,
+                       (const uint32_t *)st.seg_batches.p, (const uint64_t *)st.seg_off.p, st.s_ids.p, reinterpret_cast<uint4 *>(st.s_desc.p),
+                       st.cap_batches, st.counters.p);
+    AS_HIP(ctx, hipGetLastError());
+  }
+  {
+    ProfScope ps(ctx, "knn_rerank_score");
+    const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each)
+    // (the stream's length is known on the device only: a grid sized for the chip; waves past the stream's end leave at once)
+    const uint32_t grid = std::min<uint64_t>(rs_grid, std::max<uint64_t>(8, cap_batches / 8 * 8));
+    const uint32_t dbg = (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u;
+    const size_t lds = (size_t)kRsRows * kRsPitch;
+#define AS_SCORE(PC)                                                                                                                              \
+  case PC:                                                                                                                                        \
+    hipLaunchKernelGGL((rerank_pairs_score_kernel<PC, SLOTS>), dim3(grid), dim3(64), lds, ctx->stream, rows, (const uint32_t *)st.s_ids.p,         \
+                       (const rp_u4 *)st.s_desc.p, (const unsigned long long *)st.counters.p, rectify, records, dbg);                             \
+    break;
+    switch (d / 128) {
+      AS_SCORE(1) AS_SCORE(2) AS_SCORE(3) AS_SCORE(4) AS_SCORE(5) AS_SCORE(6) AS_SCORE(7) AS_SCORE(8)
+      default: return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: row width not covered");
+    }
+#undef AS_SCORE
+    AS_HIP(ctx, hipGetLastError());
+  }
+  ProfScope ps(ctx, "knn_rerank_rank");
+  hipLaunchKernelGGL((rerank_rank_kernel<SLOTS>), dim3(std::min<uint64_t>(cdiv(row_count, 8), 256 * 32)), dim3(256), 0, ctx->stream, row_begin, row_count,
+                     (const uint32_t *)records, K, bnd, out_dist, out_idx, fail_rows, fail_count, a_ids, order);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
+// records (rerank_prune_kernel) -> every pair scored once -> the K best of every row + the rows that could not be certified
+// (rerank_pairs.h).  records are by place p: row = order ? order[p] : p, its id a_ids ? a_ids[row] : row_begin + row;
+// row2rec: row id -> record of the whole-matrix image order (the inverse of `order`), or nullptr (built here).
+// No read-back in between: the slot stream gets room for 3 batches per row (half of that is used on the bench data); a call that
+// needs more finds out at the caller's read-back of fail_count (*n_fail) and is repeated here with the size the device counted.
+template <int SLOTS>
+static int rerank_pairs_run(as_ctx *ctx, const double *rows, uint32_t d, uint64_t n_total, uint32_t row_begin, uint32_t row_count, uint32_t *records,
+                            uint32_t K, int rectify, GraphBound bnd, double *out_dist, uint32_t *out_idx, uint32_t *fail_rows, uint32_t *fail_count,
+                            const uint32_t *a_ids, const uint32_t *order, const uint32_t *row2rec) {
+  RerankPairsState st;
+  uint64_t cap = (uint64_t)row_count * std::max<uint64_t>(3, (3 * (uint64_t)K + 15) / 16) + 64;
+  if (ctx->opt_debug == 77) cap = 8;  // (test hook: the first attempt runs out of room)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    AS_TRY(rerank_pairs_launch<SLOTS>(ctx, st, cap, rows, d, n_total, row_begin, row_count, records, K, rectify, bnd, out_dist, out_idx, fail_rows,
+                                      fail_count, a_ids, order, row2rec));
+    unsigned long long h[kRpCounters] = {0, 0, 0, 0};
+    AS_HIP(ctx, copy_d2h(ctx, h, st.counters.p, sizeof(h)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats["knn_rerank_batches"] = (int64_t)h[0];
+    ctx->stats["knn_rerank_pairs_scored"] = (int64_t)h[1];
+    ctx->stats["knn_rerank_stream_retries"] = attempt;
+    if (h[2] == 0) return AS_OK;
+    cap = h[0] + 64;
+    AS_HIP(ctx, hipMemsetAsync(fail_count, 0, sizeof(uint32_t), ctx->stream));  // (the ranking ran on keys nobody wrote)
+  }
+  return fail(ctx, AS_ERR_HIP, "re-rank: the slot stream overflowed twice");
+}
 
 // Exact re-rank of the joined candidates of rows [row_begin, row_begin + row_count) (one wave per row),
 // certification against theta.  The candidates of a row come from n_src lists (one per rank that contracted
@@ -1549,6 +1665,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       const uint32_t kmax = pruning ? std::min<uint32_t>(cmax, std::max<uint32_t>(128, 2 * K)) : cmax;
       const size_t lds128 = (size_t)4 * (1024 + (size_t)rr_nbuf * rr_rows * kRrPitch + rr_key_bytes(cmax, kmax) + (size_t)cmax * 4);
       DevBuf<uint32_t> records;
+      DevBuf<double> norms_pos;
       if (d % 128 == 0 && d <= 1024 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 12 <= 64 * 1024 &&
           ctx->opt_debug != 5 && ctx->opt_rerank_split) {
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
@@ -1568,12 +1685,22 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
           // the bound per pair from the rows' own plane errors, where the lists hold image positions and the image was packed here
           const float *err_pos = (lists_by_pos && ent_perm && join_on_f16(ctx, d) && oj->f16_err_pos.p && ctx->opt_rerank_pair_bound) ? oj->f16_err_pos.p : nullptr;
           ctx->stats["knn_rerank_pair_bound"] = err_pos ? 1 : 0;
+          if (ent_perm) {  // the norms by image position: a survivor's norm is asked for together with its row id
+            AS_TRY(norms_pos.alloc(ctx, n));
+            hipLaunchKernelGGL(gather_f64_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, ent_perm, n, norms_pos.p);
+          }
           hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
                              ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
                              force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order, err_pos,
-                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)));
+                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)), (const double *)norms_pos.p);
         }
         AS_HIP(ctx, hipGetLastError());
+        if (ctx->opt_rerank_pairs) {
+          // every unordered pair scored once, the ranking in a kernel of its own (rerank_pairs.h)
+          const uint32_t *row2rec = score_order ? list_inv : nullptr;
+          if (d == 128) AS_TRY(rerank_pairs_run<2>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
+          else AS_TRY(rerank_pairs_run<4>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
+        } else {
         const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each) of the scoring kernel
 #define AS_SCORE(PC)                                                                                                             \
   case PC:                                                                                                                       \
@@ -1587,6 +1714,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
           default: return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: row width not covered");
         }
 #undef AS_SCORE
+        }
       } else if (lists_by_pos) {
         return fail(ctx, AS_ERR_HIP, "internal: lists by image position need the two-kernel re-rank");
       } else if (d == 128 && lds128 <= 160 * 1024 && ((uintptr_t)rows & 15) == 0 && ctx->opt_debug != 5) {

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            const uint32_t *__restrict__ perm, const uint32_t *__restrict__ inv,
                                                            unsigned long long *__restrict__ scored_total,
                                                            const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
-                                                           const float *__restrict__ err_pos, float accum_delta, float floor_delta) {
+                                                           const float *__restrict__ err_pos, float accum_delta, float floor_delta,
+                                                           const double *__restrict__ norms_pos) {
   // records are written by PLACE r of the visiting order: the rows of the range in their own order, or (order: place -> row of
   // the whole matrix, row_begin = 0) in the order of the join's image, where the list of place r sits at position r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
     // holds positions; what leaves this kernel is row ids again
     const uint32_t lr = order ? r : (inv ? inv[a] : r);
+    // what the record's header needs, and the row's own error: asked for now, used at the end of the row
+    const float th_a = theta[a];
+    const double nrm_a = norms[a];
+    const bool force = force_exact && force_exact[a];
+    const float e_self = err_pos ? err_pos[lr] : 0.f;
     uint32_t C = 0;
     bool overflow = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
@@ -66,13 +72,30 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
       }
       const uint2 *src = reinterpret_cast<const uint2 *>(cand_src) + ((size_t)sidx * row_count + lr) * cap;
       if (err_pos) {  // the bound of each pair as its entry passes by (prune_candidates_pairwise: es = the LOWER end of the pair's cosine)
-        const float e_self = err_pos[lr];
-        for (uint32_t c = lane; c < take; c += 64) {
-          const uint2 e = src[c];
-          const float dc = pair_bound(e_self, err_pos[e.x], accum_delta, floor_delta);
-          ei[C + c] = e.x;
-          ed[C + c] = dc;
-          es[C + c] = __uint_as_float(e.y) - dc;
+        // (four entries per lane in flight, then their four gathered errors: two dependent levels per 256 entries, not eight)
+        for (uint32_t c0 = 0; c0 < take; c0 += 256) {
+          uint2 e[4];
+          float ej[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * 64u + (uint32_t)lane;
+            e[u] = c < take ? src[c] : make_uint2(0u, 0u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * 64u + (uint32_t)lane;
+            ej[u] = c < take ? err_pos[e[u].x] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * 64u + (uint32_t)lane;
+            if (c < take) {
+              const float dc = pair_bound(e_self, ej[u], accum_delta, floor_delta);
+              ei[C + c] = e[u].x;
+              ed[C + c] = dc;
+              es[C + c] = __uint_as_float(e[u].y) - dc;
+            }
+          }
         }
       } else {
         for (uint32_t c = lane; c < take; c += 64) {
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
       C += take;
     }
     wave_sync();
-    if (err_pos) C = prune_candidates_pairwise(ei, es, ed, C, K, accum_delta + err_pos[lr], prune_rectify, lane);
+    if (err_pos) C = prune_candidates_pairwise(ei, es, ed, C, K, accum_delta + e_self, prune_rectify, lane);
     else C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
     if (C > kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
       overflow = true;
@@ -93,15 +116,16 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     scored += C;
     uint32_t *rec = records + (size_t)r * kRsWords;
     for (uint32_t c = lane; c < C; c += 64) {
-      const uint32_t j = perm ? perm[ei[c]] : ei[c];
+      const uint32_t pj = ei[c];
+      const uint32_t j = perm ? perm[pj] : pj;
       rec[kRsIdsAt + c] = j;
-      reinterpret_cast<double *>(rec + kRsNormsAt)[c] = norms[j];
+      // (norms_pos: the norms by image position, so that the norm does not wait for the row id)
+      reinterpret_cast<double *>(rec + kRsNormsAt)[c] = (perm && norms_pos) ? norms_pos[pj] : norms[j];
     }
     if (lane == 0) {
-      const bool force = force_exact && force_exact[a];
       rec[0] = C | (overflow ? 0x100u : 0u) | (force ? 0x200u : 0u);
-      rec[1] = __float_as_uint(theta[a]);
-      const unsigned long long nb = (unsigned long long)__double_as_longlong(norms[a]);
+      rec[1] = __float_as_uint(th_a);
+      const unsigned long long nb = (unsigned long long)__double_as_longlong(nrm_a);
       rec[2] = (uint32_t)nb;
       rec[3] = (uint32_t)(nb >> 32);
     }

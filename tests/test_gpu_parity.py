@@ -431,6 +431,46 @@ def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,topk,rectify", [(70000, 128, 16, 0), (66001, 128, 40, 1), (70144, 256, 16, 0), (40000, 128, 5, 0)])
+def test_item_graph_rerank_scores_every_pair_once(ctx, n, d, topk, rectify):
+    """The exact re-rank of the joined lists (round 5, rerank_pairs.h): a pair two rows both keep is fetched and chained ONCE and
+    its key handed to both (x_i . x_j in the reference's order, src/core.rs:204-210, and the product of the two norms are the
+    same bits from either side); batches are packed across rows; the ranking runs in a kernel of its own.  The tables must be
+    what every row scoring all of its own survivors gives ("rerank_share" 0), what a slot stream that ran out of room and was
+    laid out again gives (debug 77), and the oracle's rows (src/laplacian.rs:243-252).  Duplicates (tie-break by index), a zero
+    row, deep lists (topk 40: records of more than 32 slots take the full-wave ranking), rows of two 128-wide pieces, the
+    rectified variant."""
+    X, _ = synth.mixture(n, d, seed=41, n_clusters=40, rank=5)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25, rectify=bool(rectify))
+    try:
+        ctx.set_option("join_min_rows", 512)
+        ctx.set_option("rerank_share", 1)
+        idx1, dist1 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_rerank_batches") > 0
+        scored, pairs, open1 = ctx.stat("knn_rerank_scored"), ctx.stat("knn_rerank_pairs_scored"), ctx.stat("knn_uncertified_rows")
+        assert 0 < pairs < scored and ctx.stat("knn_rerank_stream_retries") == 0   # some pairs are mutual: fewer rows fetched than survivors
+        ctx.set_option("rerank_share", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        # (a row is among its own candidates and is never scored: one survivor per row is no pair)
+        assert ctx.stat("knn_rerank_pairs_scored") >= ctx.stat("knn_rerank_scored") - n and ctx.stat("knn_uncertified_rows") == open1
+        ctx.set_option("rerank_share", 1)
+        ctx.set_option("debug", 77)
+        idx2, dist2 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_rerank_stream_retries") == 1
+    finally:
+        ctx.set_option("debug", 0)
+        ctx.set_option("rerank_share", 1)
+        ctx.set_option("join_min_rows", 32768)
+    assert np.array_equal(idx1, idx0) and np.array_equal(dist1, dist0)
+    assert np.array_equal(idx2, idx0) and np.array_equal(dist2, dist0)
+    rng = np.random.default_rng(6)
+    sample = np.sort(np.concatenate([rng.choice(n, size=120, replace=False), np.arange(40, 48)]))
+    oi, od = O.knn_cosine_rows(X, O.graph_params(gp.eps, gp.k, gp.topk, gp.p, gp.sigma, rectify=gp.rectify), sample)
+    assert np.array_equal(idx1[sample], oi) and np.array_equal(dist1[sample], od)
+
+
 @pytest.mark.parametrize("n,d,topk", [(70000, 128, 16), (66001, 64, 30), (131072 + 300, 128, 5)])
 def test_item_graph_thresholds_from_the_own_neighbourhood(ctx, n, d, topk):
     """"join_theta_band" (round 4): a row's threshold is raised to what its own neighbourhood in the ordered image certifies -- the
