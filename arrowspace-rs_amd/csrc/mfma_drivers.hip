@@ -648,7 +648,7 @@ static int rerank_pairs_run(as_ctx *ctx, const double *rows, uint32_t d, uint64_
                             const uint32_t *a_ids, const uint32_t *order, const uint32_t *row2rec) {
   RerankPairsState st;
   uint64_t cap = (uint64_t)row_count * std::max<uint64_t>(3, (3 * (uint64_t)K + 15) / 16) + 64;
-  if (ctx->opt_debug == 77) cap = 8;  // (test hook: the first attempt runs out of room)
+  if (ctx->opt_rerank_stream_cap > 0) cap = (uint64_t)ctx->opt_rerank_stream_cap;  // (test hook: a first attempt that runs out of room)
   for (int attempt = 0; attempt < 2; ++attempt) {
     AS_TRY(rerank_pairs_launch<SLOTS>(ctx, st, cap, rows, d, n_total, row_begin, row_count, records, K, rectify, bnd, out_dist, out_idx, fail_rows,
                                       fail_count, a_ids, order, row2rec));
@@ -1695,25 +1695,11 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
                              (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)), (const double *)norms_pos.p);
         }
         AS_HIP(ctx, hipGetLastError());
-        if (ctx->opt_rerank_pairs) {
+        {
           // every unordered pair scored once, the ranking in a kernel of its own (rerank_pairs.h)
           const uint32_t *row2rec = score_order ? list_inv : nullptr;
           if (d == 128) AS_TRY(rerank_pairs_run<2>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
           else AS_TRY(rerank_pairs_run<4>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
-        } else {
-        const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each) of the scoring kernel
-#define AS_SCORE(PC)                                                                                                             \
-  case PC:                                                                                                                       \
-    hipLaunchKernelGGL((rerank_score_d128_kernel<PC, (PC == 1 ? 2 : 4)>), dim3(row_count >= rs_grid ? rs_grid : row_count), dim3(64), \
-                       rs_lds(PC == 1 ? 2 : 4), ctx->stream, \
-                       rows, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, \
-                       (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u, a_ids, score_order);                         \
-    break;
-        switch (d / 128) {
-          AS_SCORE(1) AS_SCORE(2) AS_SCORE(3) AS_SCORE(4) AS_SCORE(5) AS_SCORE(6) AS_SCORE(7) AS_SCORE(8)
-          default: return fail(ctx, AS_ERR_UNSUPPORTED, "re-rank: row width not covered");
-        }
-#undef AS_SCORE
         }
       } else if (lists_by_pos) {
         return fail(ctx, AS_ERR_HIP, "internal: lists by image position need the two-kernel re-rank");

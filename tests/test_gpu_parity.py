@@ -437,7 +437,7 @@ def test_item_graph_rerank_scores_every_pair_once(ctx, n, d, topk, rectify):
     its key handed to both (x_i . x_j in the reference's order, src/core.rs:204-210, and the product of the two norms are the
     same bits from either side); batches are packed across rows; the ranking runs in a kernel of its own.  The tables must be
     what every row scoring all of its own survivors gives ("rerank_share" 0), what a slot stream that ran out of room and was
-    laid out again gives (debug 77), and the oracle's rows (src/laplacian.rs:243-252).  Duplicates (tie-break by index), a zero
+    laid out again gives ("rerank_stream_cap" 8), and the oracle's rows (src/laplacian.rs:243-252).  Duplicates (tie-break by index), a zero
     row, deep lists (topk 40: records of more than 32 slots take the full-wave ranking), rows of two 128-wide pieces, the
     rectified variant."""
     X, _ = synth.mixture(n, d, seed=41, n_clusters=40, rank=5)
@@ -456,11 +456,11 @@ def test_item_graph_rerank_scores_every_pair_once(ctx, n, d, topk, rectify):
         # (a row is among its own candidates and is never scored: one survivor per row is no pair)
         assert ctx.stat("knn_rerank_pairs_scored") >= ctx.stat("knn_rerank_scored") - n and ctx.stat("knn_uncertified_rows") == open1
         ctx.set_option("rerank_share", 1)
-        ctx.set_option("debug", 77)
+        ctx.set_option("rerank_stream_cap", 8)
         idx2, dist2 = A.knn_cosine(X, gp)
         assert ctx.stat("knn_rerank_stream_retries") == 1
     finally:
-        ctx.set_option("debug", 0)
+        ctx.set_option("rerank_stream_cap", 0)
         ctx.set_option("rerank_share", 1)
         ctx.set_option("join_min_rows", 32768)
     assert np.array_equal(idx1, idx0) and np.array_equal(dist1, dist0)
