@@ -27,6 +27,10 @@ Beside the contract's fields the JSON line carries (all measured in this run, HI
                     pass; equivalent_filtered: the same batches on an index searched before (int8 filter: an equivalent, not a bandwidth)
   value_host_inputs the build with the item matrix starting in host memory (PCIe inclusive; never `value`)
   value_hard_data   the item graph on a mixture the rotated first pass cannot exploit (which path ran; never `value`)
+  value_cfg1 / value_cfg3_one_gpu / value_wide   the other BASELINE.json configs on this one GPU (100 k x 128; 4 M x 128, which the
+                    baseline shards over 8 GPUs; 1 M x 768 with Percentile(0.95) tau and a 100 k-query batch): build ms, the path taken,
+                    the kernel with the most time; geometry_sweep: the 1 M x 128 item graph on mixtures of rank 8 ... 128 with the
+                    bounds that stayed on.  Never `value`
   cpu_baseline      the oracle on the host cores, bounded sample
 """
 import argparse
@@ -72,6 +76,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-legs", action="store_true", help="skip the host-input build and the small-batch search legs")
     p.add_argument("--no-spmm-leg", action="store_true", help="skip the item-graph lambda leg (roofline_spmm)")
+    p.add_argument("--no-config-legs", action="store_true", help="skip the other BASELINE configs (value_cfg1, value_cfg3_one_gpu, value_wide) "
+                                                                 "and the geometry sweep")
     p.add_argument("--cand-precision", type=int, default=32, choices=[32, 64],
                    help="first candidate stage: 32 = 16-bit / f32 MFMA then f64 MFMA then exact (default); 64 = f64 MFMA first")
     p.add_argument("--join-pipe", type=int, default=16, choices=[16, 48, 32],
@@ -168,6 +174,67 @@ def recorded_traffic(kernel_substr, n, d):
                         "source": "profiles/" + name, "commit": j.get("commit"),
                         "stale": j.get("source_sha16") != SOURCE_SHA16, "source_sha16": j.get("source_sha16")}
     return best
+
+
+def config_leg(A, D, synth, ctx, dev, n, d, nq, taumode, k, alpha, rank=8, clusters=256, reps=2, seed=42, search=True, lambdas=True):
+    """One BASELINE config (or one geometry of the sweep) on this GPU through the same calls as the timed region: item graph,
+    reference-mapping lambdas, a query batch.  Wall times of `reps` repetitions behind one warm-up; the profile of the last one."""
+    ops = D.HipOps(ctx)
+    X, cent = synth.mixture_device(n, d, dev, seed=seed, n_clusters=clusters, rank=rank)
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    sas = D.ShardedArrowSpace(ops, X, n, gp, taumode)
+    Q = None
+    if search and nq:
+        qidx = synth.query_indices(n, nq, seed=seed)
+        Q = X[torch.from_numpy(qidx.astype(np.int64)).to(dev)] * 1.02
+
+    path_keys = ("knn_join", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order", "knn_join_theta_grouped",
+                 "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6", "knn_join_prefilter_tail_e6", "knn_uncertified_rows",
+                 "knn_uncertified_rows_stage1a", "knn_join_candidates", "knn_rerank_pairs_scored")
+    path = {}
+
+    def step():
+        t0 = time.perf_counter()
+        gl = sas.build_item_graph()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        path.update({kk: ctx.stat(kk) for kk in path_keys})   # (read here: the search behind it runs passes that count in the same names)
+        if lambdas:
+            sas.build_lambdas(cent)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if Q is not None:
+            lq = sas.prepare_queries(Q)
+            sas.search(Q, lq, k, alpha)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        return gl, t1 - t0, t2 - t1, t3 - t2
+
+    step()
+    ctx.profile(True)
+    tg = tl = ts = 0.0
+    for _ in range(reps):
+        gl, a, b, c = step()
+        tg, tl, ts = tg + a, tl + b, ts + c
+    prof = ctx.profile_all()
+    ctx.profile(False)
+    tg, tl, ts = tg / reps, tl / reps, ts / reps
+    stages = {kk: v[0] / reps for kk, v in prof.items() if v[1]}
+    inner = ("knn_rerank_link", "knn_rerank_fill", "knn_rerank_score", "knn_rerank_rank")   # (inside knn_rerank)
+    top = sorted(((v, kk) for kk, v in stages.items() if kk not in inner), reverse=True)[:4]
+    leg = {"n_items": n, "dim": d, "mixture": {"rank": rank, "clusters": clusters, "seed": seed},
+           "value": n / (tg + tl), "unit": "items/s", "build_ms": (tg + tl) * 1e3, "item_graph_ms": tg * 1e3, "lambda_ms": tl * 1e3,
+           "item_graph_nnz": int(gl.matrix.nnz() if hasattr(gl, "matrix") else gl.nnz()),
+           "dominant_stage": {"name": top[0][1], "ms": top[0][0]} if top else None,
+           "top_stages_ms": {kk: v for v, kk in top},
+           "path": {kk: path[kk] for kk in path_keys[:10]},
+           "candidates_per_row": path["knn_join_candidates"] / max(1, n),
+           "rows_fetched_per_row": path["knn_rerank_pairs_scored"] / max(1, n)}
+    if Q is not None:
+        leg.update({"n_queries": nq, "search_ms": ts * 1e3, "search_qps": nq / ts if ts > 0 else None})
+    del sas, X, Q, gl
+    torch.cuda.empty_cache()
+    return leg
 
 
 def main():
@@ -446,6 +513,36 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra leg must not take the bench line down
             hard = {"error": repr(e)}
         extra["value_hard_data"] = hard
+    if rank == 0 and world == 1 and not args.no_config_legs and n == 1_000_000 and d == 128:
+        # ---- the other BASELINE.json configs and the geometry sweep (never in `value`: that stays configs[2]) --------------
+        # configs[1] 100 k x 128 (MFMA distance block + Rayleigh kernel); configs[3] 4 M x 128 as ONE GPU runs it (the baseline shards
+        # it over 8: that line is `--gpus 8`); configs[4] 1 M x 768, Percentile(0.95) tau, 100 k batched prepare + search.
+        if True:
+            for name, kw in (("value_cfg1", dict(n=100_000, d=128, nq=10_000, taumode=A.TauMode.Median, reps=3)),
+                             ("value_cfg3_one_gpu", dict(n=4_000_000, d=128, nq=10_000, taumode=A.TauMode.Median, reps=2)),
+                             ("value_wide", dict(n=1_000_000, d=768, nq=100_000, taumode=A.TauMode.Percentile(0.95), reps=2))):
+                try:
+                    extra[name] = config_leg(A, D, synth, ctx, dev, k=args.k, alpha=args.alpha, **kw)
+                except Exception as e:  # noqa: BLE001 -- an extra leg must not take the bench line down
+                    extra[name] = {"error": repr(e)}
+            sweep = []
+            for rk, cl in ((8, 256), (16, 1024), (32, 2048), (64, 4096), (128, 4096)):
+                try:
+                    leg = config_leg(A, D, synth, ctx, dev, n=n, d=d, nq=0, taumode=A.TauMode.Median, k=args.k, alpha=args.alpha, rank=rk, clusters=cl,
+                                     reps=2, seed=43 if rk > 8 else 42, search=False, lambdas=False)
+                    sweep.append({"rank": rk, "clusters": cl, "item_graph_ms": leg["item_graph_ms"], "items_per_s": n / (leg["item_graph_ms"] * 1e-3),
+                                  "dominant_stage": leg["dominant_stage"], "candidates_per_row": leg["candidates_per_row"],
+                                  "rows_fetched_per_row": leg["rows_fetched_per_row"],
+                                  "bounds_on": {"cone_bound_on_tile_pairs": leg["path"]["knn_join_cone_tiles"],
+                                                "tile_pairs_kept": leg["path"]["knn_join_cone_tiles_kept_e6"] * 1e-6,
+                                                "grouped_thresholds": leg["path"]["knn_join_theta_grouped"],
+                                                "rotated_first_pass": leg["path"]["knn_join_prefilter_rotated"],
+                                                "energy_outside_the_31_directions": leg["path"]["knn_join_prefilter_tail_e6"] * 1e-6}})
+                except Exception as e:  # noqa: BLE001
+                    sweep.append({"rank": rk, "clusters": cl, "error": repr(e)})
+            extra["geometry_sweep"] = {"what": "item graph of 1 M x 128 mixtures (noise 0.3 sqrt(rank) per coordinate) of growing rank: where the "
+                                               "cone bound and the grouped thresholds switch themselves off, and what the build costs then",
+                                       "legs": sweep}
     if rank == 0 and world == 1 and not args.no_spmm_leg:
         # ---- the item-graph lambda: the feature columns as signals over the N x N Laplacian the build returns ------------
         # (SURVEY.md 8(a') item-graph mapping, the "SpMV" of north_star; src/taumode.rs:552-660 per signal.)  Algorithmic bytes

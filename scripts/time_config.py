@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Item graph of one configuration: wall time and every profiled stage.  usage: time_config.py n d [reps] [rank] [clusters] [opt=value ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+import torch  # noqa: E402
+
+import arrowspace_amd as A  # noqa: E402
+from arrowspace_amd import synth  # noqa: E402
+
+n, d = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rank = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+clusters = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+ctx = A.default_context()
+for kv in sys.argv[6:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
+gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+Xd, cent = synth.mixture_device(n, d, "cuda", seed=42, n_clusters=clusters, rank=rank)
+A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+ctx.synchronize()
+ctx.profile(True)
+t0 = time.perf_counter()
+for _ in range(reps):
+    gl = A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+ctx.synchronize()
+dt = (time.perf_counter() - t0) / reps
+prof = ctx.profile_all()
+ctx.profile(False)
+print("%d x %d rank %d clusters %d: build %.2f ms, nnz %d" % (n, d, rank, clusters, dt * 1e3, gl.matrix.nnz()))
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+    if v[1]:
+        print("  %-36s %8.3f ms" % (k, v[0] / reps))
+print("  stats:", {k: ctx.stat(k) for k in ("knn_join", "knn_join_prefilter", "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6", "knn_join_theta_grouped",
+                                            "knn_join_candidates", "knn_rerank_scored", "knn_rerank_pairs_scored", "knn_rerank_batches",
+                                            "knn_uncertified_rows", "knn_uncertified_rows_stage1a", "knn_join_blocks")})
