@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
                                                            uint32_t m2, float *__restrict__ theta2_out,
                                                            uint32_t *__restrict__ unit_counter,
                                                            const uint32_t *__restrict__ unit_groups, uint32_t parts = 1,
-                                                           float *__restrict__ bins_out = nullptr) {
+                                                           float *__restrict__ bins_out = nullptr,
+                                                           const uint32_t *__restrict__ group_start = nullptr) {
   // parts > 1 (plain sample only, bins_out given): a unit is (256 rows, one of `parts` even ranges of the sample's tiles) and
   // leaves its 64 sub-sample maxima per row in bins_out[(row * parts + part) * 64 ..] instead of selecting -- the maxima of the
   // whole sample are the maxima over the parts bin by bin (a tile keeps its parity), so theta_bins_select_kernel returns the very
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
   // sweeping the whole sample each left most of the chip idle for 0.37 ms.
   // unit_groups (2 per unit: first and last pivot group of its 256 image positions): the sample is not one image for all rows
   // but s_tiles tiles per GROUP (the sampled rows of the groups nearest to it: join_thresholds_f16_grouped), and a unit sweeps
-  // those of the groups it covers.
+  // those of the groups it covers.  group_start (the groups' first positions): a row takes the maxima of ITS group's sample alone.
+  // Where the groups are laid out along a chain of similar pivots (row_order.hip, round 5) two neighbouring groups' samples hold
+  // largely the SAME rows at different slots, i.e. in different bins: the union counted a row's best partners twice and the m-th
+  // largest bin maximum came out too high for the rows of every unit that straddles a boundary (3.4 % of all rows left open
+  // instead of 0.6 %).
   constexpr bool SEARCH = false;
   constexpr int kTileVecs = KS * 4 * 64;  // 16-B vectors of a 128-row tile (one plane)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -112,7 +117,10 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
     float rmax[2][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rmax[0][r] = rmax[1][r] = -__builtin_inff();
-    auto value = [&](float sdot, int) -> float { return sdot; };
+    bool in_group[16];  // does accumulator row r of this lane belong to the group whose sample is being swept?
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in_group[r] = true;
+    auto value = [&](float sdot, int r) -> float { return in_group[r] ? sdot : -__builtin_inff(); };
 
     f16x8 b_hi[2];
 #define AS_READ(SET, KSTEP, NN) lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);
@@ -154,6 +162,14 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
     const uint32_t g_lo = unit_groups ? unit_groups[2 * I] : 0u, g_hi = unit_groups ? unit_groups[2 * I + 1] : 0u;
     for (uint32_t g = g_lo; g <= g_hi && st > 0; ++g) {
     PSc = unit_groups ? PS + (size_t)g * s_tiles * kTileVecs : PS + (size_t)t_lo * kTileVecs;
+    if (group_start && g_lo != g_hi) {
+      const uint32_t p_lo = group_start[g], p_hi = group_start[g + 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t pos = I * 256u + (uint32_t)wv * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * lh);
+        in_group[r] = pos >= p_lo && pos < p_hi;
+      }
+    }
     __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring); the sweep before with its buffers
     stage(0, 0, -1);
     __syncthreads();
@@ -533,7 +549,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   case K:                                                                                                                    \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA_r, u_count, pos_count,             \
-                       (const f16x8 *)PS.p, kGroupTiles, m, t1_r, m2, t2_r, unitc.p, ug_r);                                  \
+                       (const f16x8 *)PS.p, kGroupTiles, m, t1_r, m2, t2_r, unitc.p, ug_r, 1u, (float *)nullptr, group_start); \
     break;
   switch (KS) {
     AS_THETA(1) AS_THETA(2) AS_THETA(3) AS_THETA(4) AS_THETA(5) AS_THETA(6) AS_THETA(7) AS_THETA(8)

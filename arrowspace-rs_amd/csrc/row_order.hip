@@ -233,6 +233,94 @@ __global__ void shift_ids_kernel(uint32_t *__restrict__ ids, uint32_t np, uint32
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) ids[p] += by;
 }
+// The pivots in the order of a greedy chain (round 5): from pivot 0, always on to the most similar pivot not yet taken (ties: the lower
+// index).  The groups of the image are laid out in the order of their pivots, and the sampled pivots come in the order of the rows
+// they were drawn from -- so the four groups a cluster of the bench mixture falls into sat anywhere in the image, and with them the
+// rows' neighbours: tile pairs that hold a pair lay all over the square.  Along the chain the groups of one cluster are adjacent and
+// similar clusters follow each other: the band thresholds see more of a row's true neighbourhood, the tile pairs the cone bound keeps
+// sit near the diagonal, and what the exact re-rank and the item-graph lambda gather is closer in the caches.  Any order is correct;
+// this one is a function of the pivots alone (the same on every rank).
+// Two kernels: the 32 most similar pivots of every pivot (a workgroup each), then ONE wave walks the chain through those lists held in
+// LDS -- a step is a list read, a look at the taken flags and a ballot (~0.1 us; the whole-set argmax per step it replaces took 2 us
+// of one workgroup's vector issue, 2.3 ms for 1 024 pivots).  Where all 32 of a pivot's list are taken the chain goes on at the
+// lowest pivot not yet taken: late in the walk, and any order is correct.
+constexpr uint32_t kChainList = 32;
+__global__ __launch_bounds__(256) void pivot_near_lists_kernel(const float *__restrict__ piv, uint32_t dpv, uint32_t np, uint16_t *__restrict__ lists) {
+  __shared__ float s_sim[1024];
+  __shared__ float s_best[256];
+  __shared__ uint32_t s_at[256];
+  const uint32_t g = blockIdx.x;
+  for (uint32_t h = threadIdx.x; h < np; h += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (uint32_t k = 0; k < 32; ++k) a = __builtin_fmaf(piv[(size_t)g * dpv + k], piv[(size_t)h * dpv + k], a);
+    s_sim[h] = (h == g || !(a == a)) ? -__builtin_inff() : a;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < kChainList; ++k) {
+    float best = -__builtin_inff();
+    uint32_t at = 0xFFFFFFFFu;
+    for (uint32_t h = threadIdx.x; h < np; h += 256)
+      if (s_sim[h] > best) {
+        best = s_sim[h];
+        at = h;
+      }
+    s_best[threadIdx.x] = best;
+    s_at[threadIdx.x] = at;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o && (s_best[threadIdx.x + o] > s_best[threadIdx.x] ||
+                                   (s_best[threadIdx.x + o] == s_best[threadIdx.x] && s_at[threadIdx.x + o] < s_at[threadIdx.x]))) {
+        s_best[threadIdx.x] = s_best[threadIdx.x + o];
+        s_at[threadIdx.x] = s_at[threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      lists[(size_t)g * kChainList + k] = s_at[0] == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)s_at[0];
+      if (s_at[0] != 0xFFFFFFFFu) s_sim[s_at[0]] = -__builtin_inff();
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void pivot_chain_kernel(const uint16_t *__restrict__ lists, uint32_t np, uint32_t *__restrict__ order) {
+  extern __shared__ unsigned char smem[];
+  uint16_t *s_list = reinterpret_cast<uint16_t *>(smem);                       // np x 32
+  unsigned char *s_taken = smem + (size_t)np * kChainList * sizeof(uint16_t);  // np
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = lane; i < np * kChainList; i += 64) s_list[i] = lists[i];
+  for (uint32_t i = lane; i < np; i += 64) s_taken[i] = i == 0 ? 1 : 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint32_t cur = 0, low = 1;  // low: every pivot below it is taken
+  if (lane == 0) order[0] = 0;
+  for (uint32_t step = 1; step < np; ++step) {
+    const uint32_t c = lane < kChainList ? s_list[cur * kChainList + lane] : 0xFFFFu;
+    const bool ok = c < np && s_taken[c] == 0;
+    const unsigned long long m = __ballot(ok);
+    uint32_t nxt;
+    if (m) {
+      nxt = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(m));
+    } else {
+      while (low < np && s_taken[low]) ++low;  // (wave-uniform: every lane reads the same flag)
+      nxt = low < np ? low : 0u;
+    }
+    if (lane == 0) {
+      s_taken[nxt] = 1;
+      order[step] = nxt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    cur = nxt;
+  }
+}
+__global__ void pivot_permute_kernel(const float *__restrict__ piv, const uint32_t *__restrict__ order, uint32_t dpv, float *__restrict__ out) {
+  const uint32_t p = blockIdx.x;
+  for (uint32_t k = threadIdx.x; k < dpv; k += blockDim.x) out[(size_t)p * dpv + k] = piv[(size_t)order[p] * dpv + k];
+}
+
 __global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids, uint32_t np) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) ids[p] = (uint32_t)(((uint64_t)p * n) / np + (((uint64_t)p * 2654435761ull) % (n / np)));
@@ -304,6 +392,25 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   return AS_OK;
 }
 
+// piv (np x dpv, 32 coordinates used) -> the same pivots in the order of the greedy chain
+static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
+  if (np > 1024 || np < 2) return AS_OK;
+  DevBuf<uint32_t> order;
+  DevBuf<uint16_t> lists;
+  DevBuf<float> tmp;
+  AS_TRY(order.alloc(ctx, np));
+  AS_TRY(lists.alloc(ctx, (size_t)np * kChainList));
+  AS_TRY(tmp.alloc(ctx, (size_t)np * dpv));
+  const size_t lds = (size_t)np * kChainList * sizeof(uint16_t) + np;
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)pivot_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pivot_near_lists_kernel, dim3(np), dim3(256), 0, ctx->stream, (const float *)piv, dpv, np, lists.p);
+  hipLaunchKernelGGL(pivot_chain_kernel, dim3(1), dim3(64), lds, ctx->stream, (const uint16_t *)lists.p, np, order.p);
+  hipLaunchKernelGGL(pivot_permute_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float *)piv, (const uint32_t *)order.p, dpv, tmp.p);
+  AS_HIP(ctx, hipGetLastError());
+  AS_HIP(ctx, hipMemcpyAsync(piv, tmp.p, sizeof(float) * (size_t)np * dpv, hipMemcpyDeviceToDevice, ctx->stream));
+  return AS_OK;
+}
+
 // perm[pos] = row: the rows grouped by their nearest pivot (device array of n), the pivots being 256 of the rows themselves.
 // dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
 // n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 512 rows or more, 256 at least).  piv_out: n_pivots x 128.
@@ -330,6 +437,9 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
   AS_HIP(ctx, hipGetLastError());
   if (np_out) *np_out = np;
+  const bool chain = d == 32 && ctx->opt_join_order_chain;
+  if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
+  ctx->stats["knn_join_order_chain"] = chain ? 1 : 0;
   DevBuf<float> piv_sub;
   if (d == 32 && ctx->opt_join_order_sub) {  // a second set of pivots (other rows), for the order inside the groups
     DevBuf<uint32_t> ids2;
@@ -339,6 +449,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     hipLaunchKernelGGL(shift_ids_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ctx->stream, ids2.p, np, n / (2 * np));
     hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids2.p, d, dpv, piv_sub.p);
     AS_HIP(ctx, hipGetLastError());
+    if (chain && ctx->opt_join_order_chain > 1) AS_TRY(chain_pivots(ctx, piv_sub.p, np, dpv));  // (the order inside the groups too)
     return order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, piv_sub.p);
   }
   return order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, nullptr);
