@@ -1689,6 +1689,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
             AS_TRY(norms_pos.alloc(ctx, n));
             hipLaunchKernelGGL(gather_f64_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, ent_perm, n, norms_pos.p);
           }
+          ProfScope ps_prune(ctx, "knn_rerank_prune");
           hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
                              ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
                              force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order, err_pos,

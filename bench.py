@@ -380,7 +380,8 @@ def main():
                                       "knn_uncertified_rows_stage1a", "knn_join_delta_e9", "search_uncertified_rows", "search_scan",
                                       "knn_mfma_join_bf16_blocks_full", "knn_join_prefilter", "knn_join_prefilter_rotated",
                                       "knn_join_prefilter_blocks", "knn_join_prefilter_blocks_flagged", "knn_rerank_scored",
-                                      "knn_join_row_order", "knn_join_theta_grouped", "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6")}
+                                      "knn_join_row_order", "knn_join_theta_grouped", "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6",
+                                      "knn_rerank_batches", "knn_rerank_pairs_scored", "knn_join_order_chain")}
 
     # ---- untimed extra legs (rank 0, one GPU): small-batch search, host-resident inputs --------------------------------
     extra = {}
@@ -666,15 +667,29 @@ def main():
                     2.0 * (t2 * ((t2 - 1) // 2) + t2 + (t2 // 2 if t2 % 2 == 0 else 0)) * 256 * 256 * d, F32_MFMA_PEAK_TFLOPS, "TFLOP/s",
                     "f32 MFMA flops executed")
             scored = stats["knn_rerank_scored"]
-            if scored > 0:
-                # exact re-rank: every surviving candidate row (8 d bytes) is fetched once, the row itself once, the lists are read
-                # (8 B per listed slot), a record of 1.5 KB per row written and read, the table written
-                rr_bytes = (scored + rows_here) * 8.0 * d + stats["knn_join_candidates"] * 8.0 + rows_here * (2 * 1536.0 + 17 * 12.0)
-                add("knn_rerank", "rerank_score_d128_kernel (+ rerank_prune_kernel: lists -> pruned records -> gathered 1 KB rows, sequential "
-                                  "f64 chains in the reference's order, ranking, certification)",
-                    "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes of the surviving candidates' rows + lists + records + table as REQUESTED "
-                    "(rows are visited in image order, so part of the candidate rows is found in L2: `traffic` is what came from HBM)",
-                    {"scored_candidates_per_row": scored / max(1, rows_here)}, pmc=("rerank_score_d128_kernel", "rerank_prune_kernel"))
+            batches = stats.get("knn_rerank_batches", 0)
+            if scored > 0 and batches > 0:
+                # exact re-rank (rerank_split.h, rerank_pairs.h).  Its kernels one by one, then the whole stage as a group:
+                #   scoring  every slot of the stream is a 1 KB row fetched (16 per batch, own rows and padding included) + 20 B of
+                #            descriptor per slot + one 8 B key written per pair and side
+                #   pruning  the lists read (8 B per listed slot), the records written (12 B per survivor + header)
+                pairs = stats.get("knn_rerank_pairs_scored", 0)
+                score_bytes = batches * 16.0 * (8.0 * d + 20.0) + pairs * 16.0
+                add("knn_rerank_score", "rerank_pairs_score_kernel (the slot stream: batches of 16 rows packed across rows, every unordered pair once; "
+                                        "counted vector loads only, products in registers, 16 sequential f64 chains per batch)",
+                    "hbm", score_bytes, HBM_PEAK_GBS, "GB/s", "bytes REQUESTED: 16 rows of 8 d bytes per batch + descriptors + keys (rows of one neighbourhood are "
+                    "visited side by side on an L2, so part is served on-die: `traffic` is what left the L2s)",
+                    {"rows_fetched_per_row": batches * 16.0 / max(1, rows_here), "pairs_scored_per_row": pairs / max(1, rows_here),
+                     "survivors_per_row": scored / max(1, rows_here), "batches": batches}, pmc="rerank_pairs_score_kernel")
+                add("knn_rerank_prune", "rerank_prune_kernel (lists -> per-pair bounds -> survivors: a record per row)", "hbm",
+                    stats["knn_join_candidates"] * 12.0 + scored * 12.0 + rows_here * 16.0, HBM_PEAK_GBS, "GB/s",
+                    "lists (8 B per listed slot + a 4 B plane error gathered) read, records (ids + norms) written; instruction-bound (bisection "
+                    "for the K-th lower bound, compaction)", pmc="rerank_prune_kernel")
+                rr_bytes = score_bytes + stats["knn_join_candidates"] * 12.0 + scored * 12.0 + rows_here * (16.0 + 17 * 12.0) + scored * 40.0
+                add("knn_rerank", "exact re-rank, all five kernels (rerank_prune_kernel, rerank_link_kernel, rerank_fill_kernel, rerank_pairs_score_kernel, "
+                                  "rerank_rank_kernel)",
+                    "hbm", rr_bytes, HBM_PEAK_GBS, "GB/s", "bytes requested by the five kernels together", {"group": True},
+                    pmc=("rerank_pairs_score_kernel", "rerank_prune_kernel", "rerank_link_kernel", "rerank_fill_kernel", "rerank_rank_kernel"))
         ms32, l32 = prof.get("knn_mfma_candidates_f32", (0.0, 0))
         ms64, l64 = prof.get("knn_mfma_candidates", (0.0, 0))
         flops_alg = 2.0 * rows_here * n * d  # 2 n^2 d over the rows this rank owns
@@ -688,12 +703,15 @@ def main():
         if nnz > 0 and world == 1:
             add("graph_assembly", "graph assembly (degree_rows64_kernel, adjacency32_kernel, fill_reverse32_kernel, union_count32r_kernel, write_rows_ranked_kernel, write_rows_mid / _hub_kernel)",
                 "hbm", rows_here * 17 * 16.0 + nnz * 16.0 + (rows_here + 1) * 8.0, HBM_PEAK_GBS, "GB/s",
-                "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out",
+                "SURVEY.md 8(d): n (t+1) 16 B in + nnz 16 B + (n+1) 8 B out", {"group": True},
                 pmc=("degree_kernel", "degree32_kernel", "degree_rows64_kernel", "adjacency_kernel", "adjacency32_kernel", "fill_reverse_kernel",
                      "fill_reverse32_kernel", "union_count_kernel", "union_count32_kernel", "union_count32r_kernel", "write_rows_kernel",
                      "write_rows_big_kernel", "write_rows_ranked_kernel", "write_rows_mid_kernel", "write_rows_hub_kernel", "write_rows_serial_kernel",
                      "scan_block_sums", "scan_of_sums", "scan_finish"))
-        roofline = max(kernels, key=lambda e: e["avg_launch_ms"]) if kernels else None
+        # `roofline`: the single kernel with the most time (groups of kernels -- the re-rank as a whole, the graph assembly -- are listed in
+        # roofline_kernels but do not stand for "the dominant kernel")
+        singles = [e for e in kernels if not e.get("group")]
+        roofline = max(singles, key=lambda e: e["avg_launch_ms"]) if singles else None
         reference_equivalent = None
         if stats["knn_join"] == 1:
             join_ms = sum(e["avg_launch_ms"] for e in kernels if e["profile_group"] in ("knn_join_prefilter", "knn_join_cone_tiles") + tuple(names.values()))
@@ -729,6 +747,13 @@ def main():
                                                       "frac": items_s * ops_item / valu_peak}
                 extra["roofline_scan"]["lds"] = {"bytes_per_item": lds_item, "achieved_TBs": items_s * lds_item / 1e12, "peak_TBs": lds_peak / 1e12,
                                                  "frac": items_s * lds_item / lds_peak}
+                # the limit that binds is the one the kernel is nearest to: its floor (time at that limit's peak) over the measured time
+                limits = {"hbm": extra["roofline_scan"]["frac"], "lds": extra["roofline_scan"]["lds"]["frac"],
+                          "f64_valu": extra["roofline_scan"]["f64_valu"]["frac"]}
+                binding = max(limits, key=limits.get)
+                extra["roofline_scan"]["binding_limit"] = binding
+                extra["roofline_scan"]["frac_of_binding_limit"] = limits[binding]
+                extra["roofline_scan"]["hbm_frac_at_the_binding_limits_peak"] = extra["roofline_scan"]["frac"] / limits[binding]
             if world == 1:
                 rec = recorded_traffic("lambda_kernel", n, d)
                 if rec:
