@@ -88,6 +88,7 @@ struct as_ctx {
   int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
   int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
                                          // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
+  int64_t opt_join_theta_band_slack = 4; // thresholds of the own neighbourhood: taken instead of a sampled threshold that is higher by at most this many deltas (certified by construction)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)

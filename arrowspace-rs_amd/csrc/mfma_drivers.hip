@@ -171,11 +171,15 @@ __global__ void gather_u32_kernel(const uint32_t *__restrict__ table, const uint
 
 // key of a listed row for the order of the image: its position there
 // t[p] = max(t[p], band[p] - by): the thresholds of the own neighbourhood where they are the higher ones (+inf stays +inf)
-__global__ void theta_band_merge_kernel(float *__restrict__ t, const float *__restrict__ band, uint32_t n, float by) {
+// ... and where the sampled threshold is the higher one by no more than `slack`, the certified cut is taken all the same (round 5): a
+// row cut at band - by is certified by construction, a row cut at a sampled value that sits within a few deltas of its K-th best
+// cosine is a coin toss -- rows of 768 columns have the cosines of a whole cluster within a few deltas of each other, and 2 % of them
+// (19.6 k of 1 M) went on to a 36 ms second pass for lists a handful of entries shorter
+__global__ void theta_band_merge_kernel(float *__restrict__ t, const float *__restrict__ band, uint32_t n, float by, float slack) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n && t[p] < __builtin_inff()) {
     const float b = band[p] - by;
-    if (b > t[p]) t[p] = b;
+    if (b > t[p] || (b == b && t[p] - b <= slack)) t[p] = b;
   }
 }
 __global__ void position_keys_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ inv, uint32_t count, double *__restrict__ keys) {
@@ -632,7 +636,7 @@ static int rerank_pairs_launch(as_ctx *ctx, RerankPairsState &st, uint64_t cap_b
   }
   ProfScope ps(ctx, "knn_rerank_rank");
   hipLaunchKernelGGL((rerank_rank_kernel<SLOTS>), dim3(std::min<uint64_t>(cdiv(row_count, 8), 256 * 32)), dim3(256), 0, ctx->stream, row_begin, row_count,
-                     (const uint32_t *)records, K, bnd, out_dist, out_idx, fail_rows, fail_count, a_ids, order);
+                     (const uint32_t *)records, K, bnd, out_dist, out_idx, fail_rows, fail_count, a_ids, order, st.counters.p);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
@@ -652,12 +656,17 @@ static int rerank_pairs_run(as_ctx *ctx, const double *rows, uint32_t d, uint64_
   for (int attempt = 0; attempt < 2; ++attempt) {
     AS_TRY(rerank_pairs_launch<SLOTS>(ctx, st, cap, rows, d, n_total, row_begin, row_count, records, K, rectify, bnd, out_dist, out_idx, fail_rows,
                                       fail_count, a_ids, order, row2rec));
-    unsigned long long h[kRpCounters] = {0, 0, 0, 0};
+    unsigned long long h[kRpCounters] = {};
     AS_HIP(ctx, copy_d2h(ctx, h, st.counters.p, sizeof(h)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats["knn_rerank_batches"] = (int64_t)h[0];
     ctx->stats["knn_rerank_pairs_scored"] = (int64_t)h[1];
     ctx->stats["knn_rerank_stream_retries"] = attempt;
+    ctx->stats["knn_rerank_open_list_ran_over"] = (int64_t)h[4];
+    ctx->stats["knn_rerank_open_forced"] = (int64_t)h[5];
+    ctx->stats["knn_rerank_open_undelivered"] = (int64_t)h[6];
+    ctx->stats["knn_rerank_open_too_few"] = (int64_t)h[7];
+    ctx->stats["knn_rerank_open_kth_not_clear"] = (int64_t)h[8];
     if (h[2] == 0) return AS_OK;
     cap = h[0] + 64;
     AS_HIP(ctx, hipMemsetAsync(fail_count, 0, sizeof(uint32_t), ctx->stream));  // (the ranking ran on keys nobody wrote)
@@ -995,6 +1004,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out, const void *row_image = nullptr, uint64_t n_image = 0);
+int join_thresholds_f16_wide_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out);
 int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out,
                              uint32_t pos_begin = 0, uint32_t pos_count = 0);
 int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
@@ -1389,17 +1399,19 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   // by construction and its list is cut near its K-th best cosine instead of its 128th (mfma_theta_f16.hip,
   // join_thresholds_f16_band); the sampled threshold stays for rows whose neighbours live elsewhere.  Computed first: the check of
   // the grouped thresholds below looks at the thresholds the join will use.
-  const bool have_band = reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && d <= 128 && K + 1 <= 32;
+  const bool have_band = reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && (d <= 128 || wide_grouped) && K + 1 <= 32;
   DevBuf<float> tband;
   if (have_band) {
     AS_TRY(tband.alloc(ctx, n));
     AS_HIP(ctx, hipMemsetAsync(tband.p, 0xFF, sizeof(float) * n, ctx->stream));  // (NaN where not computed: never the larger one)
-    AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
+    if (d > 128) AS_TRY(join_thresholds_f16_wide_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p));
+    else AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
   }
   auto merge_band = [&]() -> int {  // (own positions; the callers gather afterwards)
     if (have_band && pos_count)
       hipLaunchKernelGGL(theta_band_merge_kernel, dim3(cdiv(pos_count, 256)), dim3(256), 0, ctx->stream, oj.theta_pos.p + pos_begin,
-                         (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6));
+                         (const float *)tband.p + pos_begin, pos_count, (float)(2.0 * join_delta(ctx, d) + 2e-6),
+                         (float)((double)std::max<int64_t>(0, ctx->opt_join_theta_band_slack) * join_delta(ctx, d)));
     AS_HIP(ctx, hipGetLastError());
     return AS_OK;
   };
@@ -1684,6 +1696,18 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         } else {
           // the bound per pair from the rows' own plane errors, where the lists hold image positions and the image was packed here
           const float *err_pos = (lists_by_pos && ent_perm && join_on_f16(ctx, d) && oj->f16_err_pos.p && ctx->opt_rerank_pair_bound) ? oj->f16_err_pos.p : nullptr;
+          // lists that hold ROW ids (rows wider than 128 columns, images in row order): the same bound from the errors by row
+          DevBuf<float> err_row;
+          if (!err_pos && !lists_by_pos && oj && own_join && oj->f16_err_pos.p && join_on_f16(ctx, d) && ctx->opt_rerank_pair_bound && !a_ids &&
+              js->n_src == 1) {
+            if (oj->reorder) {
+              AS_TRY(err_row.alloc(ctx, n));
+              AS_TRY(scatter_by_perm(ctx, oj->f16_err_pos.p, oj->perm_own.p, n, err_row.p));
+              err_pos = err_row.p;
+            } else {
+              err_pos = oj->f16_err_pos.p;
+            }
+          }
           ctx->stats["knn_rerank_pair_bound"] = err_pos ? 1 : 0;
           if (ent_perm) {  // the norms by image position: a survivor's norm is asked for together with its row id
             AS_TRY(norms_pos.alloc(ctx, n));
@@ -1977,7 +2001,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     AS_TRY(failx.alloc(ctx, nf));
     if (second_wide || second_h) AS_TRY(pack_f16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
     else AS_TRY(pack_bf16(ctx, rows, norms, cur_ids, 0, nf, d, PA.p, b_al));
-    const float *band_own = (second_h && oj && oj->theta_band_own.p && ctx->opt_join_theta_band_second) ? oj->theta_band_own.p : nullptr;
+    const float *band_own = ((second_h || second_wide) && oj && oj->theta_band_own.p && ctx->opt_join_theta_band_second) ? oj->theta_band_own.p : nullptr;
     const float band_by = (float)(2.0 * join_delta(ctx, d) + 2e-6);
     if (grouped_theta && second_h && !(ctx->opt_debug & 131072)) {  // (debug bit 131072: the first pass's own second thresholds)
       // the thresholds of the first pass came from the sampled rows of the nearest pivot groups only; a row that is open after it

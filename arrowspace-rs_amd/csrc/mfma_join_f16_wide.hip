@@ -103,6 +103,67 @@ __device__ __forceinline__ void append_w(uint32_t *__restrict__ cnt, uint32_t *_
   if (pos < cap) reinterpret_cast<uint2 *>(cand)[(size_t)target * cap + pos] = make_uint2(other, __float_as_uint(score));
 }
 
+// MODE 0 behind the first pass: is the w-th pair of rectangle `sb` (4 row super tiles x 8 column offsets) a pair of the pattern that
+// the first pass flagged (or did not look at)?  The first pass swept every unordered pair of 512-row super tiles ONCE, from the side
+// its cyclic half pattern names (looked): rows of A against columns of B, or the other way round.  The mask holds the row super
+// tiles of THIS call's range [A0, A1) (a rank of a sharded build: its own positions) against every column; a pair the first pass
+// saw from a row super tile outside the range (a few pairs near the antipodal offset) is unknown here and contracted.
+__device__ __forceinline__ bool wide_pair_wanted(uint32_t sb, uint32_t w, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_ob,
+                                                 const unsigned long long *__restrict__ mask, uint32_t mask_pitch, uint32_t *I_out, uint32_t *J_out) {
+  const uint32_t n_norm = (T2 - 1) / 2;
+  const uint32_t ib = sb / n_ob, ob = sb - ib * n_ob;
+  const uint32_t di = w & 3u, off = ob * 8u + (w >> 2);
+  if (ib * 4u + di >= I_count) return false;
+  const uint32_t I = I_begin + ib * 4u + di;
+  const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
+  if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) return false;
+  uint32_t J = I + off;
+  J = J >= T2 ? J - T2 : J;
+  *I_out = I;
+  *J_out = J;
+  if (!mask) return true;
+  const uint32_t A = I >> 1, B = J >> 1, T5 = T2 >> 1, nn5 = (T5 - 1) / 2;
+  const uint32_t A0 = I_begin >> 1, A1 = (I_begin + I_count + 1) >> 1;
+  auto looked = [&](uint32_t from, uint32_t to) -> bool {
+    const uint32_t dl = to >= from ? to - from : to + T5 - from;
+    return dl <= nn5 || ((T5 % 2 == 0) && T5 > 1 && from < T5 / 2 && dl == nn5 + 1);
+  };
+  bool known = false;
+  unsigned long long bits = 0;
+  if (looked(A, B)) {
+    known = true;
+    bits |= mask[(size_t)(A - A0) * mask_pitch + J] >> (32u * (I & 1u));
+  }
+  if (looked(B, A) && B >= A0 && B < A1) {
+    known = true;
+    bits |= mask[(size_t)(B - A0) * mask_pitch + I] >> (32u * (J & 1u));
+  }
+  return !(known && (uint32_t)bits == 0u);
+}
+// The wanted pairs as a list (round 5): rectangle by rectangle in the order of the walk, so that consecutive entries share super
+// tiles.  Until then thread 0 of every workgroup looked for its next pair by drawing candidates from its XCD's counter one returning
+// atomic and one mask read at a time: at 1 M x 768 that search -- 7.6 M candidates for 0.4 M wanted pairs, 30 k serial round trips per
+// workgroup -- took the same 89 ms whether the first pass left 0.62 M pairs or 0.44 M: it, not the contraction, set the pass's time.
+__global__ __launch_bounds__(256) void wide_unit_list_kernel(uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_sb, uint32_t n_ob,
+                                                             const unsigned long long *__restrict__ mask, uint32_t mask_pitch,
+                                                             uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
+                                                             uint2 *__restrict__ list) {
+  // counts given (offsets null): the number of wanted pairs of every rectangle; offsets given: the pairs themselves
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t sb0 = (blockIdx.x * 4 + wv) * 2; sb0 < n_sb; sb0 += gridDim.x * 8) {
+    const uint32_t sb = sb0 + (lane >> 5), w = lane & 31;  // two rectangles per wave
+    uint32_t I = 0, J = 0;
+    const bool want = sb < n_sb && wide_pair_wanted(sb, w, T2, I_begin, I_count, n_ob, mask, mask_pitch, &I, &J);
+    const unsigned long long bal = __ballot(want);
+    const uint32_t half = (uint32_t)((lane >> 5) ? (bal >> 32) : bal);
+    if (offsets) {
+      if (want) list[offsets[sb] + (uint32_t)__builtin_popcount(half & ((1u << w) - 1u))] = make_uint2(I, J);
+    } else if (w == 0 && sb < n_sb) {
+      counts[sb] = (uint32_t)__builtin_popcount(half);
+    }
+  }
+}
+
 // P: f16 image of ALL rows with KS = a multiple of kPK k steps per row (zero padded), T2 super tiles of 256 rows (the image
 // is padded to whole 512-row super tiles: an even number of them).
 // MODE 0: the symmetric join.  theta: T2 * 256 thresholds, +inf on padding rows.  Super tile I meets the column super
@@ -131,7 +192,9 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
                                                                     const float *__restrict__ col_lam, const float *__restrict__ row_lam,
                                                                     const float *__restrict__ row_g, float alpha, float beta,
                                                                     const uint32_t *__restrict__ perm,
-                                                                    const unsigned long long *__restrict__ mask, uint32_t mask_pitch) {
+                                                                    const unsigned long long *__restrict__ mask, uint32_t mask_pitch,
+                                                                    const uint32_t *__restrict__ grp_start = nullptr, uint32_t grp_supers = 0,
+                                                                    const uint2 *__restrict__ unit_list = nullptr, uint32_t n_list = 0) {
   // perm (MODE 0 / 1): P is packed in a permuted order (image position -> row): list entries are translated where they are
   // appended.  mask (MODE 0): what the int8 first pass found (mfma_prefilter_i8.hip; zeroed where it did not look): a word per
   // (512-row super tile, 256-column stage), a byte per 64-row wave; a pair of 256-row super tiles none of whose bits is set in
@@ -198,6 +261,18 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
     for (;;) {
       const uint32_t v = atomicAdd(unit_counters + xcd, 1u);
       const uint32_t sb = xcd + 8u * (v >> 5), w = v & 31u;
+      if (MODE == 0 && unit_list) {  // the wanted pairs are listed: XCD x takes the x-th of every eight runs of 32 entries
+        const uint32_t e = sb * 32u + w;
+        if (sb * 32u >= n_list) {
+          s_next[0] = 0xFFFFFFFFu;
+          return;
+        }
+        if (e >= n_list) continue;
+        const uint2 pr = unit_list[e];
+        s_next[0] = pr.x;
+        s_next[1] = pr.y;
+        return;
+      }
       if (sb >= n_ib * n_ob) {
         s_next[0] = 0xFFFFFFFFu;
         return;
@@ -212,33 +287,8 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
         s_next[1] = off;
         return;
       }
-      const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
-      if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) continue;
-      uint32_t J = I + off;
-      J = J >= T2 ? J - T2 : J;
-      if (MODE == 0 && mask) {
-        // The first pass swept every unordered pair of 512-row super tiles ONCE, from the side its cyclic half pattern names
-        // (looked): rows of A against columns of B, or the other way round.  The mask holds the row super tiles of THIS call's
-        // range [A0, A1) (a rank of a sharded build: its own positions) against every column; a pair the first pass saw from a
-        // row super tile outside the range (a few pairs near the antipodal offset) is unknown here and contracted.
-        const uint32_t A = I >> 1, B = J >> 1, T5 = T2 >> 1, nn5 = (T5 - 1) / 2;
-        const uint32_t A0 = I_begin >> 1, A1 = (I_begin + I_count + 1) >> 1;
-        auto looked = [&](uint32_t from, uint32_t to) -> bool {
-          const uint32_t dl = to >= from ? to - from : to + T5 - from;
-          return dl <= nn5 || ((T5 % 2 == 0) && T5 > 1 && from < T5 / 2 && dl == nn5 + 1);
-        };
-        bool known = false;
-        unsigned long long bits = 0;
-        if (looked(A, B)) {
-          known = true;
-          bits |= mask[(size_t)(A - A0) * mask_pitch + J] >> (32u * (I & 1u));
-        }
-        if (looked(B, A) && B >= A0 && B < A1) {
-          known = true;
-          bits |= mask[(size_t)(B - A0) * mask_pitch + I] >> (32u * (J & 1u));
-        }
-        if (known && (uint32_t)bits == 0u) continue;
-      }
+      uint32_t J = 0, I2 = 0;
+      if (!wide_pair_wanted(sb, w, T2, I_begin, I_count, n_ob, MODE == 0 ? mask : nullptr, mask_pitch, &I2, &J)) continue;
       s_next[0] = I;
       s_next[1] = J;
       return;
@@ -379,6 +429,15 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
     // ---- the pair is contracted: coarse test per 32 x 32 block, element-wise test and listing for the few that pass ----
     n_blk += 16;
     if (kSweep) {
+      // MODE 2 with the grouped sample (grp_start: first image position of every pivot group; grp_supers: sample super tiles per
+      // group): a row takes the maxima of ITS group's sample alone -- the samples of neighbouring groups hold largely the same rows at
+      // other slots (other bins) where the groups lie along a chain of similar pivots, and the union counted them twice
+      uint32_t g_lo_pos = 0u, g_hi_pos = 0xFFFFFFFFu;
+      if (MODE == 2 && grp_start && grp_supers) {
+        const uint32_t g = J / grp_supers;
+        g_lo_pos = grp_start[g];
+        g_hi_pos = grp_start[g + 1];
+      }
       float lx[4] = {0.f, 0.f, 0.f, 0.f};  // MODE 3: lambdas of the lane's columns
       const uint32_t la = lds_addr_w(smem + kThrAt + (size_t)slot * kSlotBytes + 2048) + (uint32_t)(wr * 128 + 4 * lh) * 4u;
       if (MODE == 3) {
@@ -410,6 +469,10 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
             if (MODE == 3) {  // the approximate score: alpha s + beta (1 - min(|lambda_q - lambda_x|, 1))
               const float tt = __builtin_fminf(__builtin_fabsf(lq[r] - lx[sb]), 1.f);
               val = __builtin_fmaf(-beta, tt, __builtin_fmaf(alpha * (1.f / kProductScaleW), val, beta));
+            }
+            if (MODE == 2) {
+              const uint32_t pos = I * (uint32_t)kWS + (uint32_t)(wr * 128 + sa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+              val = (pos >= g_lo_pos && pos < g_hi_pos) ? val : -__builtin_inff();
             }
             rmax[kSweep ? sa : 0][r] = __builtin_fmaxf(rmax[kSweep ? sa : 0][r], val);
           }
@@ -615,13 +678,40 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
                        uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_rows, uint32_t n, const float *theta,
                        uint32_t cap, uint32_t *cnt, uint32_t *cand, float *maxima, const float *col_lam = nullptr,
                        const float *row_lam = nullptr, const float *row_g = nullptr, float alpha = 0.f, float beta = 0.f,
-                       const uint32_t *perm = nullptr, const unsigned char *mask = nullptr, uint32_t mask_pitch = 0) {
+                       const uint32_t *perm = nullptr, const unsigned char *mask = nullptr, uint32_t mask_pitch = 0,
+                       const uint32_t *grp_start = nullptr, uint32_t grp_supers = 0) {
   DevBuf<unsigned long long> stamps;
   DevBuf<uint32_t> counters;
   AS_TRY(stamps.alloc(ctx, 8));
   AS_TRY(counters.alloc(ctx, 8));
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(counters.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+  DevBuf<uint2> unit_list;
+  uint32_t n_list = 0;
+  if (MODE == 0 && mask && ctx->opt_join_unit_list) {  // the wanted pairs, listed (wide_unit_list_kernel)
+    const uint32_t n_norm = (T2 - 1) / 2, l_max = 1 + n_norm + 1, n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8, n_sb = n_ib * n_ob;
+    DevBuf<uint32_t> counts;
+    DevBuf<uint64_t> offsets;
+    AS_TRY(counts.alloc(ctx, n_sb));
+    AS_TRY(offsets.alloc(ctx, (size_t)n_sb + 1));
+    const unsigned grid = std::min<uint32_t>(cdiv(n_sb, 8), 256u * 8u);
+    hipLaunchKernelGGL(wide_unit_list_kernel, dim3(grid), dim3(256), 0, ctx->stream, T2, I_begin, I_count, n_sb, n_ob, (const unsigned long long *)mask,
+                       mask_pitch, counts.p, (const uint64_t *)nullptr, (uint2 *)nullptr);
+    AS_HIP(ctx, hipGetLastError());
+    AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, n_sb, offsets.p));
+    uint64_t total = 0;
+    AS_HIP(ctx, copy_d2h(ctx, &total, offsets.p + n_sb, sizeof(total)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (total && total < 0xFFFFFFFFull) {
+      AS_TRY(unit_list.alloc(ctx, total));
+      hipLaunchKernelGGL(wide_unit_list_kernel, dim3(grid), dim3(256), 0, ctx->stream, T2, I_begin, I_count, n_sb, n_ob, (const unsigned long long *)mask,
+                         mask_pitch, (uint32_t *)nullptr, (const uint64_t *)offsets.p, unit_list.p);
+      AS_HIP(ctx, hipGetLastError());
+      n_list = (uint32_t)total;
+    }
+    ctx->stats[std::string(prof_name) + "_pairs_listed"] = (int64_t)total;
+    if (total == 0) return AS_OK;  // (nothing the first pass left: no pair to contract)
+  }
   {
     ProfScope ps(ctx, prof_name);
     AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -629,7 +719,7 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
     hipLaunchKernelGGL((pair_join_f16_wide_kernel<MODE>), dim3(256), dim3(256), kWideLds, ctx->stream, (const f16x8 *)P,
                        (const f16x8 *)PA, a_ids, KS, T2, I_begin, I_count, n_rows, n, theta, cap, cnt, cand, maxima, counters.p,
                        (int)ctx->opt_debug, stamps.p, col_lam, row_lam, row_g, alpha, beta, perm, (const unsigned long long *)mask,
-                       mask_pitch);
+                       mask_pitch, grp_start, grp_supers, (const uint2 *)unit_list.p, n_list);
     AS_HIP(ctx, hipGetLastError());
   }
   unsigned long long h[8];
@@ -713,10 +803,39 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
   AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, ns, d, PS.p, ns / kTileRows));
   AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));
   AS_TRY(launch_wide<2>(ctx, "knn_join_thresholds", P_all, PS.p, ranges.p, KS, row_supers, 0, ns / kWS, n, ns, nullptr, 0, nullptr, nullptr,
-                        maxima.p));
+                        maxima.p, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, 0, group_start, per / kWS));
   hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, maxima.p, n, m, m2, theta_out, theta2_out);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AS_OK;
+}
+
+// Thresholds from a row's OWN NEIGHBOURHOOD in the ordered image for rows wider than 128 (mfma_theta_f16.hip,
+// join_thresholds_f16_band: what the value certifies): the sweep kernel with the image as its own sample, every row super tile
+// against the 512-position super tiles `band` on either side of its own.  theta_out[p] = the m-th largest of the row's 64 bin maxima.
+namespace {
+__global__ void band_ranges_wide_kernel(uint32_t row_supers, uint32_t t_img, uint32_t band, uint32_t *__restrict__ ranges) {
+  const uint32_t I = blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= row_supers) return;
+  const uint32_t I5 = I >> 1;
+  ranges[2 * I] = 2u * (I5 > band ? I5 - band : 0u);
+  ranges[2 * I + 1] = min(t_img, 2u * (I5 + band) + 2u);
+}
+}  // namespace
+int join_thresholds_f16_wide_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out) {
+  const uint32_t KS = f16_ksteps(d);
+  if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
+  if (m < 1 || m > 32) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
+  const uint32_t row_supers = (n + kWS - 1) / kWS, t_img = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
+  DevBuf<uint32_t> ranges;
+  DevBuf<float> maxima;
+  AS_TRY(ranges.alloc(ctx, (size_t)2 * row_supers));
+  AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));
+  hipLaunchKernelGGL(band_ranges_wide_kernel, dim3(cdiv(row_supers, 256)), dim3(256), 0, ctx->stream, row_supers, t_img, band, ranges.p);
+  AS_TRY(launch_wide<2>(ctx, "knn_join_thresholds_band", P_all, P_all, ranges.p, KS, row_supers, 0, t_img, n, n, nullptr, 0, nullptr, nullptr,
+                        maxima.p));
+  hipLaunchKernelGGL(theta_select_wide_kernel, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, maxima.p, n, m, 0u, theta_out, (float *)nullptr);
+  AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 

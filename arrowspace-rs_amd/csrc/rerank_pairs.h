@@ -55,7 +55,7 @@ struct RpLayout {
 
 // counters of a call (device): [0] batches of the slot stream (allocated by the segments' atomics), [1] pairs scored, [2] set when the
 // stream ran out of room (nothing of it is then valid: the scoring kernel does not run and the host repeats the call with [0] batches)
-constexpr int kRpCounters = 4;
+constexpr int kRpCounters = 12;  // ([4 .. 8]: why rows were left open, rerank_rank_kernel)
 
 // Link + layout (rerank_link_kernel), then -- behind an exclusive scan of the segments' batch counts, so that the stream is in the
 // order of the records whatever the order the workgroups run in: the scoring kernel's waves work side by side on one L2 -- the
@@ -438,7 +438,7 @@ template <int SLOTS>
 __device__ __forceinline__ void rp_rank_full(uint32_t p, uint32_t row_begin, const uint32_t *__restrict__ records, uint32_t K, const GraphBound &bnd,
                                              double *__restrict__ out_key, uint32_t *__restrict__ out_idx, uint32_t *__restrict__ fail_rows,
                                              uint32_t *__restrict__ fail_count, const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
-                                             int lane) {
+                                             int lane, unsigned long long *__restrict__ why) {
   constexpr uint32_t W = (uint32_t)rs_words(SLOTS), NA = (uint32_t)rs_norms_at(SLOTS);
   const uint32_t *rec = records + (size_t)p * W;
   const uint4 h = *reinterpret_cast<const uint4 *>(rec);
@@ -498,15 +498,21 @@ __device__ __forceinline__ void rp_rank_full(uint32_t p, uint32_t row_begin, con
   }
   // every pair that is not in the lists has an approximate cosine below theta; a slot nobody wrote (never expected: the
   // link rule is symmetric) sends the row to the next stage like any other uncertified row
-  const bool ok = !p_overflow && !p_force && __ballot(undelivered) == 0ull && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
-  if (!ok && lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+  const bool und = __ballot(undelivered) != 0ull;
+  const bool ok = !p_overflow && !p_force && !und && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
+  if (!ok && lane == 0) {
+    fail_rows[atomicAdd(fail_count, 1u)] = r;
+    // why (counters 4 ..: list ran over, forced, a slot nobody wrote, fewer than K candidates, K-th not clear of the threshold)
+    atomicAdd(&why[p_overflow ? 4 : (p_force ? 5 : (und ? 6 : (n_valid < K ? 7 : 8)))], 1ull);
+  }
 }
 
 template <int SLOTS>
 __global__ __launch_bounds__(256) void rerank_rank_kernel(uint32_t row_begin, uint32_t row_count, const uint32_t *__restrict__ records, uint32_t K,
                                                           GraphBound bnd, double *__restrict__ out_key, uint32_t *__restrict__ out_idx,
                                                           uint32_t *__restrict__ fail_rows, uint32_t *__restrict__ fail_count,
-                                                          const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order) {
+                                                          const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
+                                                          unsigned long long *__restrict__ why) {
   constexpr uint32_t W = (uint32_t)rs_words(SLOTS), NA = (uint32_t)rs_norms_at(SLOTS);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int half = lane >> 5, hl = lane & 31;
@@ -514,8 +520,8 @@ __global__ __launch_bounds__(256) void rerank_rank_kernel(uint32_t row_begin, ui
     const uint32_t C0 = records[(size_t)p0 * W] & 0xFFu;
     const uint32_t C1 = p0 + 1 < row_count ? (records[(size_t)(p0 + 1) * W] & 0xFFu) : 0u;
     if (C0 > 32u || C1 > 32u || p0 + 1 >= row_count) {
-      rp_rank_full<SLOTS>(p0, row_begin, records, K, bnd, out_key, out_idx, fail_rows, fail_count, a_ids, order, lane);
-      if (p0 + 1 < row_count) rp_rank_full<SLOTS>(p0 + 1, row_begin, records, K, bnd, out_key, out_idx, fail_rows, fail_count, a_ids, order, lane);
+      rp_rank_full<SLOTS>(p0, row_begin, records, K, bnd, out_key, out_idx, fail_rows, fail_count, a_ids, order, lane, why);
+      if (p0 + 1 < row_count) rp_rank_full<SLOTS>(p0 + 1, row_begin, records, K, bnd, out_key, out_idx, fail_rows, fail_count, a_ids, order, lane, why);
       continue;
     }
     // each half of the wave one record: lane hl of the half holds slot hl.  Keys compare as integers -- the order-preserving image of a
@@ -577,7 +583,10 @@ __global__ __launch_bounds__(256) void rerank_rank_kernel(uint32_t row_begin, ui
     const unsigned long long und = __ballot(undelivered);
     const bool und_half = ((half ? (und >> 32) : und) & 0xFFFFFFFFull) != 0ull;
     const bool ok = !p_overflow && !p_force && !und_half && n_valid >= K && kth < bnd.lower_bound(-(double)p_theta);
-    if (!ok && hl == 0) fail_rows[atomicAdd(fail_count, 1u)] = r;
+    if (!ok && hl == 0) {
+      fail_rows[atomicAdd(fail_count, 1u)] = r;
+      atomicAdd(&why[p_overflow ? 4 : (p_force ? 5 : (und_half ? 6 : (n_valid < K ? 7 : 8)))], 1ull);
+    }
   }
 }
 
