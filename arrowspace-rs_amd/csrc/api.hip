@@ -533,7 +533,6 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_block") ctx->opt_join_block = value;
   else if (n == "search_scan") ctx->opt_search_scan = value;
   else if (n == "stream_scan") ctx->opt_stream_scan = value;
-  else if (n == "rerank_split") ctx->opt_rerank_split = value;
   else if (n == "lambda_wide") ctx->opt_lambda_wide = value;
   else if (n == "join_cone_tiles") ctx->opt_join_cone_tiles = value != 0;
   else if (n == "handle_cache_mb") handle_cache_limit(value);
@@ -549,14 +548,9 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_unit_list") ctx->opt_join_unit_list = value != 0;
   else if (n == "join_cone_second") ctx->opt_join_cone_second = value != 0;
   else if (n == "join_cone_tiles_max_e3") ctx->opt_join_cone_tiles_max_e3 = std::max<int64_t>(0, value);
-  else if (n == "join_grouped_lists") ctx->opt_join_grouped_lists = value;
   else if (n == "sharded_own_rows") ctx->opt_sharded_own_rows = value != 0;
   else if (n == "signal_sym") ctx->opt_signal_sym = value;
   else if (n == "signal_order") ctx->opt_signal_order = value;
-  else if (n == "signal_order_refine") ctx->opt_signal_order_refine = value;
-  else if (n == "signal_chunk_rows") ctx->opt_signal_chunk_rows = std::min<int64_t>(std::max<int64_t>(1, value), 1024);
-  else if (n == "signal_waves") ctx->opt_signal_waves = std::max<int64_t>(0, value);
-  else if (n == "signal_half_slabs") ctx->opt_signal_half_slabs = value != 0;
   else if (n == "signal_min_len") ctx->opt_signal_min_len = std::max<int64_t>(1, value);
   else if (n == "second_pass_f16") ctx->opt_second_pass_f16 = value;
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
@@ -568,15 +562,12 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_prefilter") ctx->opt_search_prefilter = value;
   else if (n == "search_stream_filter") ctx->opt_search_stream_filter = value;
   else if (n == "search_staged_min_batch") ctx->opt_search_staged_min_batch = value;
-  else if (n == "order_mfma") ctx->opt_order_mfma = value;
   else if (n == "cluster_on_device") ctx->opt_cluster_on_device = value;
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
-  else if (n == "rerank_order") ctx->opt_rerank_order = value;
   else if (n == "rerank_share") ctx->opt_rerank_share = value != 0;
   else if (n == "join_order_chain") ctx->opt_join_order_chain = value;
   else if (n == "join_theta_band_slack") ctx->opt_join_theta_band_slack = value;
   else if (n == "rerank_stream_cap") ctx->opt_rerank_stream_cap = std::max<int64_t>(0, value);
-  else if (n == "rerank_grid") ctx->opt_rerank_grid = std::max<int64_t>(0, value);
   else if (n == "join_order_sub") ctx->opt_join_order_sub = value;
   else if (n == "join_basis_iters") ctx->opt_join_basis_iters = value;
   else if (n == "search_lambda_order") ctx->opt_search_lambda_order = value;
@@ -590,7 +581,6 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "search_scan_sample") ctx->opt_search_scan_sample = value;
   else if (n == "search_scan_rank") ctx->opt_search_scan_rank = value;
   else if (n == "search_scan_cap") ctx->opt_search_scan_cap = value;
-  else if (n == "waves_per_simd") ctx->opt_waves_per_simd = value == 1 ? 1 : 2;
   else if (n == "cand_precision") ctx->opt_cand_precision = value == 64 ? 64 : 32;
   else return fail(ctx, AS_ERR_ARG, "unknown option " + n);
   return AS_OK;

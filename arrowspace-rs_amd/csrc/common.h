@@ -42,11 +42,15 @@ struct as_ctx {
   std::string err;
   void *pinned = nullptr;  // staging buffer for host <-> device transfers
   std::multimap<size_t, void *> free_blocks;  // workspace cache (capacity -> block)
-  // options
+  // Options (as_ctx_set_option).  include/arrowspace_hip.h documents the 33 SUPPORTED ones; the others here are switches for the tests
+  // (forms of one stage that must agree bit for bit: lambda_v2 / lambda_v3 / lambda_wide, join_bf16, second_pass_f16, search_scan_f16,
+  // assembly_lanes, nearest_mfma, cluster_on_device, join_theta_parts, join_unit_list, sharded_own_rows, search_stream_quick), failure
+  // injection and capacity hooks (sharded_inject_failure, rerank_stream_cap), and sizes kept adjustable for measurements (cand_slack,
+  // join_block, join_basis_iters, join_theta_rate, join_theta_grouped_bad_e3, join_cone_tiles_max_e3, join_theta_band_second,
+  // search_scan_sample / _rank / _cap, search_rot_tail_e3, search_staged_min_batch, signal_min_len): accepted, but no interface.
   int64_t opt_knn_mfma = 1;       // 1: MFMA candidates + exact re-rank, 0: exact scan only
   int64_t opt_search_mfma = 1;    // same for the search scan
   int64_t opt_cand_slack = 8;     // extra candidates kept by the MFMA pass beyond topk+1
-  int64_t opt_waves_per_simd = 2; // f32 candidate pass: 2 = 8 waves x 32 rows, 1 = 4 waves x 64 rows
   int64_t opt_lambda_v2 = 1;      // 1: register sorting-network tau + 2-wave tile kernel when n_features <= 128
   int64_t opt_lambda_v3 = 1;      // 1: streaming 2-lanes-per-item kernel when n_features == 128 (taumode_v3.hip)
   int64_t opt_knn_join = 1;       // item graph over the whole matrix: symmetric threshold join (mfma_join_f32.hip)
@@ -75,8 +79,7 @@ struct as_ctx {
                                       // 1 = from the second scan of an index on, 2 = at once, 0 = never
   int64_t opt_search_lambda_order = 1;  // search scan on items in their own order: batches of 1024 queries or more go in the order of their lambdas
   int64_t opt_search_prefilter = 1;   // ... and the int8 first pass in front of the scan
-  int64_t opt_order_mfma = 1;            // row order on the rotated coordinates: nearest pivot on the matrix pipe (f16 operands); 0: f32 vector form
-  int64_t opt_assembly_lanes = 2;        // graph assembly (K <= 32): 2 = the round-4 kernels (graph_assembly.hip), 1 = 32 lanes per row throughout, 0 = a thread per row
+  int64_t opt_assembly_lanes = 2;        // graph assembly (K <= 32): the lane-parallel kernels (graph_assembly.hip); 0 = a thread per row (what deeper tables take)
   int64_t opt_search_rot_tail_e3 = 100;  // a re-searched index keeps rotated int8 images when the tail of its items is at most this (x 1e-3)
   int64_t opt_sharded_agreement = 1;     // sharded build: a one-word all-reduce of "has anyone failed" in front of every data collective (sharded.hip)
   int64_t opt_sharded_inject_failure = 0;  // test hook: this rank fails at checkpoint 1 (before the row all-gather), 2 (before the list exchange), 3 (before the nnz all-reduce); 4 statistics, 5 search; item-graph lambda: 6 (first stage), 7 (after the sums exchange), 8 (its rank-local argument checks)
@@ -86,14 +89,10 @@ struct as_ctx {
   int64_t opt_join_cone_tiles_max_e3 = 600;  // ... taken while it keeps at most this share (x 1e-3) of the tile pairs; beyond, the pass sweeps everything
   int64_t opt_join_unit_list = 1;        // masked f16 pass: the units that hold a flagged stage listed first (0: every unit drawn and looked at)
   int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
-  int64_t opt_join_grouped_lists = 0;    // own join behind the first pass, 128 columns: candidate lists kept per group of 32 image positions (one atomic per run of
-                                         // entries, contiguous writes; measured slower end to end at 1 M x 128 -- 11.2 + 10.2 ms against 8.1 + 8.1 for join + re-rank: off)
   int64_t opt_join_theta_band_slack = 4; // thresholds of the own neighbourhood: taken instead of a sampled threshold that is higher by at most this many deltas (certified by construction)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)
-  int64_t opt_rerank_grid = 0;           // scoring kernel of the re-rank: workgroups launched (0: the default)
-  int64_t opt_rerank_order = 1;          // exact re-rank of the join: rows visited in the order of the image (candidates shared through L2)
   int64_t opt_nearest_mfma = 1;          // nearest-centroid search of a batch: candidates from the f32 matrix pipe + exact re-rank (2: also behind as_nearest_centroids)
   int64_t opt_cluster_on_device = 1;     // incremental clustering: batches after the last centroid is created stay on the device
   int64_t opt_search_stream_quick = 1;   // up to 8 rows without an int8 image: quick f64 pass over the items + exact chains of what it leaves
@@ -116,15 +115,9 @@ struct as_ctx {
   int64_t opt_join_row_order = 1;  // own join, dim <= 128: operand image packed with the rows grouped by direction (row_order.hip)
   int64_t opt_second_pass_f16 = 1; // second pass over the rows the f16 join leaves open on the f16 plane too; 0: split bf16
   int64_t opt_lambda_wide = 1;    // lambda-tau for items wider than 128 features: one wave per item (taumode_wide.hip); 0: the generic kernel
-  int64_t opt_rerank_split = 1;   // re-rank of joined lists as prune + streamed scoring kernels (rerank_split.h); 0: the one-kernel form
   int64_t opt_sharded_own_rows = 1;      // build sharded by rows: the join is prepared from the ranks' own rows and the all-gather of the f64 rows runs under it (0: rows first)
   int64_t opt_signal_sym = 1;            // item-graph lambda (signal_lambda.hip): a bitwise symmetric graph is streamed as its upper triangle
   int64_t opt_signal_order = 1;          // ... in the order attached to the graph (as_csr_set_order / the join's own); 0: the rows as stored
-  int64_t opt_signal_order_refine = 0;   // ... the blocks of 1024 positions of that order chained by the entries between them (groups of one cluster end up side
-                                         // by side: the pass 0.86 -> 0.78 ms at 1 M x 128, but 3.2 ms more to prepare the stream (host chain): for graphs used many times)
-  int64_t opt_signal_chunk_rows = 16;    // ... consecutive rows a wave takes at a time
-  int64_t opt_signal_waves = 0;          // ... waves of the graph pass in all (0: one chunk per wave; else the waves of an XCD group interleave their chunks)
-  int64_t opt_signal_half_slabs = 0;     // ... 1: a lane holds one column, a workgroup half a slab (512-byte gathers: half the neighbourhood against the L2)
   int64_t opt_signal_min_len = 9000;     // as_compute_taumode: signals this long or longer go through the item-graph kernels
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
@@ -569,7 +562,7 @@ struct ShardedRows {
 int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t K, OwnJoin &oj,
                      uint32_t pos_begin = 0, uint32_t pos_count = 0, const ShardedRows *sr = nullptr);
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
-                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io = nullptr);
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos);
 uint32_t cone_tile_words(uint32_t n);
 int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, const float *theta, uint32_t pos_begin, uint32_t pos_count,
                    uint32_t *tile_mask, double *kept_share, ConeDirs *keep = nullptr);
@@ -609,7 +602,7 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
                    const uint32_t *perm = nullptr,         // image position -> row when packedh is packed in a permuted order
                    const uint32_t *image_perm = nullptr,   // ... when it is, but the lists are to be kept by image position
                    const double *rot_z = nullptr,          // rows wider than 128: their rotated coordinates (n x 32), for the first pass
-                   bool *grouped_io = nullptr, ConeDirs *cone_keep = nullptr);            // in: lists per group of 32 positions are welcome; out: that is what was written
+                   ConeDirs *cone_keep = nullptr);
 int join_session_open(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);   // (re)builds norms + image
 bool join_session_matches(const as_ctx *ctx, const double *rows, uint64_t n, uint64_t d);
 void join_session_close(as_ctx *ctx);

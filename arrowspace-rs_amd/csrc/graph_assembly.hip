@@ -184,26 +184,6 @@ __global__ void adjacency_kernel(const uint32_t *__restrict__ nbr_idx, const dou
 // rank count over the half wave, and nothing leaves the registers.
 __device__ __forceinline__ uint32_t half_ballot(bool p, int half) { return (uint32_t)(__ballot(p) >> (32 * half)); }
 
-__global__ __launch_bounds__(256) void degree32_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
-                                                       double eps, uint32_t *__restrict__ deg, unsigned long long *__restrict__ deg_sum) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
-  unsigned long long total = 0;  // (one atomic per wave at the end: the sum has a single address)
-  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; i < n; i += (gridDim.x * blockDim.x) >> 5) {
-    bool hit = false;
-    if ((uint32_t)s < K) {
-      const uint32_t j = nbr_idx[(uint64_t)i * K + s];
-      hit = j != kNoIdx && j != i && nbr_dist[(uint64_t)i * K + s] <= eps;
-    }
-    const uint32_t c = (uint32_t)__popc(half_ballot(hit, half));
-    if (s == 0) {
-      deg[i] = c;
-      total += c;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-  if (lane == 0 && total) atomicAdd(deg_sum, total);
-}
-
 // R rows per half wave with their loads issued together (measured at 1 M rows: R = 1 0.41 ms, R = 2 0.47 ms -- the kernel is bound
 // by its f64 divisions, the square root and the shuffles of the ranking, not by the round trips: R = 1 is what runs).
 template <int R>
@@ -392,37 +372,6 @@ __global__ __launch_bounds__(256) void union_count32r_kernel(const uint32_t *__r
     const uint64_t e = e0 + t * 32 + s;
     const bool have = e < e1;
     const uint32_t src = have ? rev[e].src : kNoIdx;
-    bool found = false;
-    for (uint32_t q = 0; q < len_m; ++q) {
-      const uint32_t a = __shfl(mine, (int)q, 32);
-      found = found || (q < len && a == src);
-    }
-    c += (uint32_t)__popc(half_ballot(have && !found, half));
-  }
-  if (live && s == 0) ucnt[li] = c;
-}
-
-// union size of a row, 32 lanes per row: the out-neighbours sit one per lane, the in-edges pass by 32 at a time
-__global__ __launch_bounds__(256) void union_count32_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len, uint32_t nr, uint32_t K,
-                                                            const uint64_t *__restrict__ rev_ptr, const uint32_t *__restrict__ rev_src,
-                                                            uint32_t *__restrict__ ucnt, uint32_t r0) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
-  const uint32_t li = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  const bool live = li < nr;
-  const uint32_t i = r0 + (live ? li : 0u);
-  const uint32_t len = live ? adj_len[i] : 0u;
-  const uint32_t mine = (uint32_t)s < len ? adj_j[(uint64_t)i * K + s] : kNoIdx;
-  const uint64_t e0 = live ? rev_ptr[li] : 0, e1 = live ? rev_ptr[li + 1] : 0;
-  uint32_t c = len;
-  // (the two rows of a wave walk their in-edges together: the trip count is the longer of the two)
-  const uint64_t span = e1 - e0;
-  const uint64_t span_o = __shfl_xor((unsigned long long)span, 32, 64);
-  const uint64_t trips = ((span > span_o ? span : span_o) + 31) / 32;
-  const uint32_t len_o = __shfl_xor(len, 32, 64), len_m = len > len_o ? len : len_o;
-  for (uint64_t t = 0; t < trips; ++t) {
-    const uint64_t e = e0 + t * 32 + s;
-    const bool have = e < e1;
-    const uint32_t src = have ? rev_src[e] : kNoIdx;
     bool found = false;
     for (uint32_t q = 0; q < len_m; ++q) {
       const uint32_t a = __shfl(mine, (int)q, 32);
@@ -1149,11 +1098,10 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   DevBuf<RevEdge> rev;
   DevBuf<unsigned long long> deg_sum;
   DevBuf<uint64_t> rev_ptr, eptr;
-  // "assembly_lanes" 2 (K <= 32): the round-4 kernels -- degrees 64 rows per wave, the reverse edges placed by the counting atomic's
-  // return value into one array of 16-byte records sized by its bound n K (no read-back of their number), unions ordered by rank
-  // counting, hub rows a wave each.  1: the 32-lanes-per-row kernels of round 3; 0 / K > 32: one thread per row.
-  const bool lanes32 = K <= 32 && ctx->opt_assembly_lanes;
-  const bool ranked = lanes32 && ctx->opt_assembly_lanes >= 2;
+  // K <= 32: degrees 64 rows per wave, the reverse edges placed by the counting atomic's return value into one array of 16-byte
+  // records sized by its bound n K (no read-back of their number), unions ordered by rank counting, hub rows a wave each.
+  // K > 32 (or "assembly_lanes" 0, the independent form the tests compare with): one thread per row.
+  const bool ranked = K <= 32 && ctx->opt_assembly_lanes != 0;
   AS_TRY(deg.alloc(ctx, n));
   AS_TRY(deg_sum.alloc(ctx, 1));
   AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
@@ -1181,14 +1129,10 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
                          nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
       hipLaunchKernelGGL(adjacency32_kernel<1>, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
                          adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr, adj_slot.p);
-    } else if (lanes32) {
-      hipLaunchKernelGGL(degree32_kernel, dim3(std::min(gb32, 4096u)), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
-      hipLaunchKernelGGL(adjacency32_kernel<1>, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
-                         adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr, (uint32_t *)nullptr);
     } else {
       hipLaunchKernelGGL(degree_kernel, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
     }
-    if (lanes32) {
+    if (ranked) {
     } else if (K <= 64)
       hipLaunchKernelGGL(adjacency_kernel<64>, dim3(gb), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma,
                          gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
@@ -1206,10 +1150,7 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
       AS_TRY(rev_w.alloc(ctx, n_edges_dir));
       hipLaunchKernelGGL(fill_reverse_kernel, dim3(gb), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, n, K,
                          rev_ptr.p, cursor.p, rev_src.p, rev_w.p, r0, nr);
-      if (lanes32)
-        hipLaunchKernelGGL(union_count32_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev_src.p, ucnt.p, r0);
-      else
-        hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
+      hipLaunchKernelGGL(union_count_kernel, dim3(gr), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p,
                            rev_src.p, ucnt.p, r0);
     }
     AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, nr, eptr.p));

@@ -617,7 +617,7 @@ static int rerank_pairs_launch(as_ctx *ctx, RerankPairsState &st, uint64_t cap_b
   }
   {
     ProfScope ps(ctx, "knn_rerank_score");
-    const uint32_t rs_grid = ctx->opt_rerank_grid > 0 ? (uint32_t)ctx->opt_rerank_grid : 256u * 7u * 8u;  // workgroups (one wave each)
+    const uint32_t rs_grid = 256u * 7u * 8u;  // workgroups (one wave each)
     // (the stream's length is known on the device only: a grid sized for the chip; waves past the stream's end leave at once)
     const uint32_t grid = std::min<uint64_t>(rs_grid, std::max<uint64_t>(8, cap_batches / 8 * 8));
     const uint32_t dbg = (ctx->opt_debug & 64) ? (uint32_t)(ctx->opt_debug >> 8) : 0u;
@@ -946,7 +946,7 @@ int pack_bf16(as_ctx *ctx, const double *R, const double *norms, const uint32_t 
               uint32_t d, void *P, uint32_t tiles);
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm = nullptr,
-             const unsigned char *mask = nullptr, bool grouped = false);
+             const unsigned char *mask = nullptr);
 uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
@@ -1113,10 +1113,7 @@ int knn_join_thresholds(as_ctx *ctx, const double *rows, const double *norms, ui
 int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t row_begin,
                    uint32_t row_count, const float *theta_all, uint32_t cap, uint32_t *cnt, uint32_t *cand,
                    const float *packed, const void *packed16, const void *packedh, const uint32_t *perm, const uint32_t *image_perm,
-                   const double *rot_z, bool *grouped_io, ConeDirs *cone_keep) {
-  // grouped_io: in = the caller can take lists kept per group of 32 image positions (mfma_join_f16.hip, GROUPED); out = they are
-  const bool want_grouped = grouped_io && *grouped_io;
-  if (grouped_io) *grouped_io = false;
+                   const double *rot_z, ConeDirs *cone_keep) {
   if (!join_supported(ctx, n, d, row_begin)) return fail(ctx, AS_ERR_UNSUPPORTED, "threshold join not applicable");
   const uint32_t b_tiles = (n + kTileRows - 1) / kTileRows, b_alloc = (b_tiles + 1) & ~1u;
   const bool f16 = join_on_f16(ctx, d), bf16 = join_on_bf16(ctx, d);
@@ -1191,11 +1188,8 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
         }
       }
       ctx->stats["knn_join_prefilter"] = pre ? 1 : 0;
-      const bool grouped = want_grouped && pre && !perm && (((uint64_t)T2 * super) >> 27) == 0 && ctx->opt_join_grouped_lists;
-      if (grouped_io) *grouped_io = grouped;
-      ctx->stats["knn_join_grouped_lists"] = grouped ? 1 : 0;
       AS_TRY(join_f16(ctx, packedh, n, d, I_begin, I_end - I_begin, theta.p, cap, cnt, cand, unitc.p, "knn_mfma_join_f16", perm,
-                      pre ? mask.p : nullptr, grouped));
+                      pre ? mask.p : nullptr));
     } else {
       // rows wider than 128: the same first pass on the rotated coordinates the caller has (rotate_wide.hip), reduced to "which
       // pairs of 256-row super tiles hold anything" for the panelled kernel
@@ -1528,14 +1522,14 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
 // cnt (n) / cand (n x cap slots of two words): lists_by_pos = indexed by image position and holding positions, else indexed
 // by row and holding rows (the join kernel translates where it appends).
 int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t pos_begin, uint32_t pos_count,
-                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos, bool *grouped_io) {
+                   OwnJoin &oj, uint32_t *cnt, uint32_t *cand, bool lists_by_pos) {
   // (the directions were tried above and do not carry the rows: the first pass, if any, takes the full-width image without
   // looking for them again)
   const int64_t saved_mode = ctx->opt_join_prefilter;
   if (oj.rot_z.p && !oj.wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
   const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_image, oj.cap, cnt, cand, nullptr, oj.P16own.p,
                                       oj.Phown.p, (oj.reorder && !lists_by_pos) ? oj.perm_own.p : nullptr,
-                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, grouped_io, &oj.cone);
+                                      oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, &oj.cone);
   ctx->opt_join_prefilter = saved_mode;
   return rc_pairs;
 }
@@ -1617,7 +1611,6 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   OwnJoin oj_local;
   const OwnJoin *oj = js ? js->oj : nullptr;
   bool lists_by_pos = false;            // the lists of the own join are indexed by (and hold) image positions
-  bool lists_grouped = false;           // ... and kept per group of 32 positions (mfma_join_f16.hip, GROUPED)
   DevBuf<uint32_t> cnt_own, cand_own;
   if (use_join) {
     if (own_join) {
@@ -1641,15 +1634,13 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(cand_own.alloc(ctx, (size_t)n * cap * 2));  // two words per slot: row id, approximate cosine
       // 128 columns: the lists stay in image positions and the pruning kernel of the re-rank translates the ~30 survivors of
       // a row (rerank_split.h); other widths: the join kernel translates every entry where it appends it
-      lists_by_pos = oj_local.reorder && d == 128 && ctx->opt_rerank_split && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
+      lists_by_pos = oj_local.reorder && d == 128 && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
                      ctx->opt_debug != 5;
       if (lists_by_pos) {
         AS_TRY(oj_local.inv_own.alloc(ctx, n));
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
-      // whole-matrix lists by image position feed the two-kernel re-rank alone: they may be kept per group of 32 positions
-      lists_grouped = lists_by_pos && ctx->opt_rerank_order && (ctx->opt_debug & ~(int64_t)8) == 0;
-      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos, &lists_grouped));
+      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos));
       if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, oj_local.theta_own.p, 1, cap, cnt_own.p, cand_own.p, oj_local.have_theta2 ? oj_local.theta2_own.p : nullptr,
                           oj_local.P16own.p, oj_local.Phown.p};
@@ -1679,21 +1670,15 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       DevBuf<uint32_t> records;
       DevBuf<double> norms_pos;
       if (d % 128 == 0 && d <= 1024 && pruning && ((uintptr_t)rows & 15) == 0 && (size_t)4 * cmax * 12 <= 64 * 1024 &&
-          ctx->opt_debug != 5 && ctx->opt_rerank_split) {
+          ctx->opt_debug != 5) {
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
         const int slots = d == 128 ? 2 : 4;  // 124 / 252 survivors per record
         AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
         AS_TRY(scored.alloc(ctx, 1));
         AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
         // the rows in the order of the image (a list of image positions is in that order already): neighbours share candidates
-        const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n && ctx->opt_rerank_order) ? oj->perm_own.p : nullptr;
-        if (lists_grouped) {
-          if (!score_order || js->n_src != 1) return fail(ctx, AS_ERR_HIP, "internal: lists by group need the re-rank in image order");
-          const size_t lds_g = (size_t)16 * js->cap * 8;
-          AS_HIP(ctx, hipFuncSetAttribute((const void *)rerank_prune_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-          hipLaunchKernelGGL(rerank_prune_grouped_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 32), 256 * 16)), dim3(256), lds_g, ctx->stream, row_count,
-                             js->theta, norms, js->cnt, js->cand, js->cap, K, force.p, prune_delta, rectify, records.p, slots, score_order, scored.p);
-        } else {
+        const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n) ? oj->perm_own.p : nullptr;
+        {
           // the bound per pair from the rows' own plane errors, where the lists hold image positions and the image was packed here
           const float *err_pos = (lists_by_pos && ent_perm && join_on_f16(ctx, d) && oj->f16_err_pos.p && ctx->opt_rerank_pair_bound) ? oj->f16_err_pos.p : nullptr;
           // lists that hold ROW ids (rows wider than 128 columns, images in row order): the same bound from the errors by row
@@ -1755,10 +1740,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       DevBuf<unsigned long long> st;
       AS_TRY(st.alloc(ctx, 3));
       AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
-      if (lists_grouped)
-        hipLaunchKernelGGL(join_group_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, row_count, js->cap, st.p);
-      else
-        hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
+      hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
                            js->cap, st.p);
       unsigned long long h[3] = {0, 0, 0};
       AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));

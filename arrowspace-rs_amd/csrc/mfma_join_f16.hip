@@ -332,18 +332,10 @@ struct F16SearchTerm {
 // MASKED (MODE 0): mask = what the int8 first pass found (mfma_prefilter_i8.hip): one byte per (row super tile, stage of 256
 // columns, wave), a bit per 32-column block that may hold a pair.  The unit visits only the stages with a bit set and a wave
 // contracts only its own blocks (the fragment ring then restarts at every block).
-// GROUPED (MODE 0, MASKED): the lists are kept per GROUP of 32 image positions instead of per row.  cnt[g] counts the entries of
-// group g, which owns the slots [g * 32 * cap, (g + 1) * 32 * cap) of cand; an entry is (other position | local row << 27, score).
-// What that buys: a wave's row-side pairs all go to the two groups of its 64 rows, so they are queued per group and leave with ONE
-// returning atomic per 96 entries and a contiguous write (whole 64-B segments); the column-side pairs of a block go to the block's
-// one column group -- a run in the column queue, one atomic per run, 64 runs per atomic instruction.  The per-row form took one
-// returning atomic and one scattered 8-byte store per entry (131 M of each at 1 M rows: two thirds of this kernel's time and
-// 4.4 bytes written per byte listed).  rerank_prune_grouped_kernel (rerank_split.h) bins a group's entries by row in LDS.
 constexpr int kFlushRounds = 3;  // rounds of 64 queue entries whose returning atomics go out together (each costs five registers)
-constexpr uint32_t kRowQueue = 96, kColQueue = 120, kColRuns = 32, kGroupRows = 32, kGroupShift = 27;
 // DIAG = false: the diagnostics (debug bits, cycle stamps) compiled out -- the form the build launches when no debug bit is set
 // (128 columns behind the first pass: the scalar registers and branches they cost sit in the listing, which has none to spare).
-template <int KS, int MODE, bool MASKED, bool GROUPED = false, bool DIAG = true>
+template <int KS, int MODE, bool MASKED, bool DIAG = true>
 __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
                                                                uint32_t I_begin, uint32_t I_count, uint32_t W, uint32_t n,
                                                                const float *__restrict__ theta, uint32_t cap,
@@ -466,50 +458,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       t_flush += tf1 - tf0;
     }
   };
-  // GROUPED: the wave's 3 KB of queue space holds two row-group queues, the column queue, its runs (group, first entry, base
-  // slot) and the run of every column entry
-  // (the wave's queue space is two pieces: 2 KB of (owner, other) pairs and 1 KB of scores)
-  uint2 *rowq = queue;                                                   // [2][kRowQueue]
-  uint2 *colq = reinterpret_cast<uint2 *>(queue_s);                      // [kColQueue]
-  uint32_t *crun_g = reinterpret_cast<uint32_t *>(rowq + 2 * kRowQueue); // [kColRuns]
-  uint32_t *crun_s = crun_g + kColRuns;                                  // [kColRuns + 1]
-  uint32_t *crun_b = crun_s + kColRuns + 1;                              // [kColRuns]
-  unsigned char *crun_of = reinterpret_cast<unsigned char *>(crun_b + kColRuns);  // [kColQueue]
-  static_assert(!GROUPED || (2 * kRowQueue * 8 + (3 * kColRuns + 1) * 4 + kColQueue <= kQueueJoin * 8 && kColQueue * 8 <= kQueueJoin * 4),
-                "the grouped queues fit the two pieces of the queue space");
-  uint32_t rq_n0 = 0, rq_n1 = 0, cq_n = 0, cq_runs = 0, rq_g0 = 0;  // wave-uniform: entries queued per row group, column entries, runs; first row group
-  auto group_cap = [&](uint32_t g) -> uint32_t { return min((uint32_t)kGroupRows, n - min(n, g * kGroupRows)) * cap; };
-  auto flush_rows = [&](uint32_t which) {
-    const uint32_t cnt_r = which ? rq_n1 : rq_n0, g = rq_g0 + which;
-    if (cnt_r) {
-      lds_sync();
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(cnt + g, cnt_r);
-      base = __builtin_amdgcn_readfirstlane(base);
-      const uint32_t gc = group_cap(g);
-      uint2 *dst = reinterpret_cast<uint2 *>(cand) + (size_t)g * kGroupRows * cap;
-      for (uint32_t e = lane; e < cnt_r; e += 64)
-        if (base + e < gc) dst[base + e] = rowq[which * kRowQueue + e];
-      lds_sync();
-    }
-    if (which) rq_n1 = 0;
-    else rq_n0 = 0;
-  };
-  auto flush_cols = [&]() {
-    if (cq_n) {
-      if (lane == 0) crun_s[cq_runs] = cq_n;
-      lds_sync();
-      if ((uint32_t)lane < cq_runs) crun_b[lane] = atomicAdd(cnt + crun_g[lane], crun_s[lane + 1] - crun_s[lane]);  // one instruction: a run per lane
-      lds_sync();
-      for (uint32_t e = lane; e < cq_n; e += 64) {
-        const uint32_t k = crun_of[e], g = crun_g[k], slot = crun_b[k] + (e - crun_s[k]);
-        if (slot < group_cap(g)) reinterpret_cast<uint2 *>(cand)[(size_t)g * kGroupRows * cap + slot] = colq[e];
-      }
-      lds_sync();
-    }
-    cq_n = 0;
-    cq_runs = 0;
-  };
   const uint32_t n_norm = (T2 - 1) / 2;
   const uint32_t n_cblocks = (T2 + W - 1) / W;
   const uint32_t total_units = n_cblocks * I_count;
@@ -614,11 +562,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       }
     }
     const uint32_t row_base0 = I * kSuperH + wv * 64 + 4 * lh, row_base1 = row_base0 + 32;  // + (r & 3) + 8 * (r >> 2)
-    if constexpr (GROUPED) {  // the row queues of the unit before belong to other groups
-      flush_rows(0);
-      flush_rows(1);
-      rq_g0 = (I * kSuperH + wv * 64) >> 5;
-    }
     v16f32 nth0, nth1;              // minus the scaled row thresholds: the C operand of a block's first MFMA
     float tmax0 = -__builtin_inff(), tmax1 = -__builtin_inff();  // largest finite scaled threshold of each row group
 #pragma unroll
@@ -681,92 +624,11 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
           asm("v_cndmask_b32 %0, 0, %2, %1" : "=v"(r) : "s"(m), "v"(v));
           return r;
         };
-        if constexpr (!GROUPED) {
-          // Most blocks hold no pair at all, and ONE maximum per lane settles most of those: a product that reaches its row's
-          // threshold has acc >= 0, one that reaches its column's has acc = vr - t_row >= theta_col - t_row >= theta_col - (the
-          // largest finite threshold of the group's rows).
-          if (!(dbg & 0x800000)) {
-            if (!__any(max16(acc) >= __builtin_fminf(0.f, tc - tmax))) return false;
-          }
-        }
-        if constexpr (GROUPED) {  // (the grouped form keeps the exact pretest of round 3)
-          v16f32 v;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
-          if (!__any(max16(acc) >= z || max16(v) >= tc)) return false;
-        }
-        if constexpr (GROUPED) {
-          // one entry per listed side of a pair: the row side into the queue of the row's group (this wave's first or second),
-          // the column side into the column queue, where the block's entries form one run for the block's column group
-          const uint32_t rg0 = __builtin_amdgcn_readfirstlane(row_group0), cb0 = __builtin_amdgcn_readfirstlane(colbase);  // (uniform: say so)
-          const uint32_t which = (rg0 >> 5) & 1u;
-          const uint32_t rq_addr = lds_addr(rowq + which * kRowQueue), cq_addr = lds_addr(colq), of_addr = lds_addr(crun_of);
-          const bool diag_block = rg0 == cb0;  // only there can a pair be (i, i)
-          bool listed = false, run_open = false;
-          uint32_t run_k = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float vr = acc[r] - nth[r];
-            unsigned long long m1 = cmp_ge(acc[r], z), m2 = cmp_ge(vr, tc);
-            if ((m1 | m2) == 0) continue;
-            const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
-            if (diag_block) {
-              const unsigned long long ms = __ballot(row == col);
-              m1 &= ~ms;
-              m2 &= ~ms;
-              if ((m1 | m2) == 0) continue;
-            }
-            const uint32_t sbits = __float_as_uint(vr * (1.f / kProductScale));
-            if (m1) {
-              const uint32_t n1 = (uint32_t)__builtin_popcountll(m1);
-              if ((which ? rq_n1 : rq_n0) + n1 > kRowQueue) flush_rows(which);
-              const uint32_t o = (which ? rq_n1 : rq_n0) + lanes_below(m1);
-              const unsigned long long ent = ((unsigned long long)sbits << 32) | (col | ((row - rg0) << kGroupShift));
-              unsigned long long saved;
-              asm volatile(
-                  "s_and_saveexec_b64 %0, %1\n\t"
-                  "ds_write_b64 %2, %3\n\t"
-                  "s_mov_b64 exec, %0"
-                  : "=&s"(saved)
-                  : "s"(m1), "v"(rq_addr + 8u * o), "v"(ent)
-                  : "memory");
-              if (which) rq_n1 += n1;
-              else rq_n0 += n1;
-              listed = true;
-            }
-            if (m2) {
-              const uint32_t n2 = (uint32_t)__builtin_popcountll(m2);
-              if (cq_n + n2 > kColQueue || (!run_open && cq_runs == kColRuns)) {
-                flush_cols();
-                run_open = false;
-              }
-              if (!run_open) {  // the block's run: its 32 columns are one group
-                run_k = cq_runs;
-                if (lane == 0) {
-                  crun_g[run_k] = cb0 >> 5;
-                  crun_s[run_k] = cq_n;
-                }
-                cq_runs += 1;
-                run_open = true;
-              }
-              const uint32_t o = cq_n + lanes_below(m2);
-              const unsigned long long ent = ((unsigned long long)sbits << 32) | (row | ((uint32_t)lc << kGroupShift));
-              unsigned long long saved;
-              asm volatile(
-                  "s_and_saveexec_b64 %0, %1\n\t"
-                  "ds_write_b64 %2, %3\n\t"
-                  "ds_write_b8 %4, %5\n\t"
-                  "s_mov_b64 exec, %0"
-                  : "=&s"(saved)
-                  : "s"(m2), "v"(cq_addr + 8u * o), "v"(ent), "v"(of_addr + o), "v"(run_k)
-                  : "memory");
-              cq_n += n2;
-              listed = true;
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          lds_sync();
-          return listed;
+        // Most blocks hold no pair at all, and ONE maximum per lane settles most of those: a product that reaches its row's
+        // threshold has acc >= 0, one that reaches its column's has acc = vr - t_row >= theta_col - t_row >= theta_col - (the
+        // largest finite threshold of the group's rows).
+        if (!(dbg & 0x800000)) {
+          if (!__any(max16(acc) >= __builtin_fminf(0.f, tc - tmax))) return false;
         }
         if (!(dbg & 0x800000)) {  // (debug bit 23: the register-by-register walk below, kept as the form for blocks too dense for the queue)
           // Every lane looks at its own 16 products (one column, 16 rows).  Which of them pass is read off SIGN bits: acc[r] < 0 fails
@@ -1095,13 +957,7 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
       }
     }
   }
-  if constexpr (GROUPED) {
-    flush_rows(0);
-    flush_rows(1);
-    flush_cols();
-  } else {
-    flush_queue();
-  }
+  flush_queue();
   if (lane == 0) {
     atomicAdd(stamps + 5, n_blk);
     atomicAdd(stamps + 7, n_pass);
@@ -1272,9 +1128,7 @@ static size_t f16_join_lds(uint32_t KS, bool search) {  // the dynamic part: two
 // zeroed by the caller, unit_counter too.  dim <= 128; AS_ERR_UNSUPPORTED beyond.
 int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begin, uint32_t I_count, const float *theta,
              uint32_t cap, uint32_t *cnt, uint32_t *cand, uint32_t *unit_counter, const char *prof_name, const uint32_t *perm,
-             const unsigned char *mask, bool grouped) {
-  if (grouped && (!mask || perm || ((uint64_t)((n + kSuperH - 1) / kSuperH) * kSuperH >> kGroupShift) != 0))
-    return fail(ctx, AS_ERR_ARG, "f16 join: lists by group need the first pass, an image in its own positions and fewer than 2^27 rows");
+             const unsigned char *mask) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
@@ -1287,7 +1141,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   AS_TRY(stamps.alloc(ctx, 10));
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   DevBuf<uint32_t> unit_list;  // behind the first pass: the units that hold anything (the kernel walks these alone)
-  if (mask && !grouped && ctx->opt_join_unit_list && units < (1ull << 31)) {
+  if (mask && ctx->opt_join_unit_list && units < (1ull << 31)) {
     AS_TRY(unit_list.alloc(ctx, units + 1));
     AS_HIP(ctx, hipMemsetAsync(unit_list.p, 0, sizeof(uint32_t), ctx->stream));
   }
@@ -1298,17 +1152,10 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
                          I_begin, I_count, W, unit_list.p);
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
-    if (mask && grouped) {                                                                                                \
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true, true>,                               \
+    if (mask && (K != 8 || ctx->opt_debug == 0)) { /* (the diagnostics of this form exist at 8 k steps only) */    \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true, false>,                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true, true>), dim3(grid), dim3(512), lds, ctx->stream, (const f16x8 *)P, \
-                         (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand, unit_counter,         \
-                         (int)ctx->opt_debug, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,          \
-                         (const uint32_t *)nullptr);                                                                      \
-    } else if (mask && (K != 8 || ctx->opt_debug == 0)) { /* (the diagnostics of this form exist at 8 k steps only) */    \
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 0, true, false, false>,                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true, false, false>), dim3(grid), dim3(512), lds, ctx->stream,       \
+      hipLaunchKernelGGL((pair_join_f16_kernel<K, 0, true, false>), dim3(grid), dim3(512), lds, ctx->stream,       \
                          (const f16x8 *)P, (const f16x8 *)nullptr, T2, I_begin, I_count, W, n, theta, cap, cnt, cand,     \
                          unit_counter, 0, stamps.p, F16SearchTerm{}, perm, (const unsigned long long *)mask,              \
                          (const uint32_t *)nullptr, (const uint32_t *)unit_list.p);                                       \
@@ -1386,9 +1233,9 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   const bool diag = ctx->opt_debug != 0;
 #define AS_LAUNCH(K, M, DG)                                                                                               \
   {                                                                                                                       \
-    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, M, false, DG>,                               \
+    AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_kernel<K, 1, M, DG>,                               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, M, false, DG>), dim3(grid), dim3(512), lds, ctx->stream,               \
+    hipLaunchKernelGGL((pair_join_f16_kernel<K, 1, M, DG>), dim3(grid), dim3(512), lds, ctx->stream,               \
                        (const f16x8 *)P, (const f16x8 *)PQ, T2, 0u, a_supers, W, n, cos_floor, cap, cnt, cand,            \
                        unit_counter, (int)ctx->opt_debug, stamps.p, st, perm,                                             \
                        (const unsigned long long *)(M ? mask : nullptr), perm_a);                                         \

@@ -415,7 +415,7 @@ static int launch_f32(as_ctx *ctx, int NC, const float *PA, uint32_t a_items, co
   const size_t lds = lds_bytes_f32(KC, CPB);
   if (lds > 160 * 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "candidate capacity too large for the f32 MFMA pass");
   const unsigned grid = std::min<uint32_t>(a_items * splits, 256u);
-  const int MW = ctx->opt_waves_per_simd == 1 ? 2 : 1;
+  const int MW = 1;  // (8 waves x 32 rows; the 4 x 64 form was never faster)
   ProfScope ps(ctx, prof_name);
 #define AS_CAND(N, C)                                                                                                \
   do {                                                                                                               \

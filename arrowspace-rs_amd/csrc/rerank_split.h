@@ -122,121 +122,6 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
   if (scored_total && lane == 0 && scored) atomicAdd(scored_total, scored);
 }
 
-// The same pruning from lists kept per GROUP of 32 image positions (mfma_join_f16.hip, GROUPED): cnt[g] entries in the slots
-// [g * 32 * cap, ..) of cand, an entry = (other position | local row << 27, score).  A workgroup takes a group: per half of 16
-// rows it counts the half's entries per row, lays them out densely in LDS (a row keeps at most `cap`, what it kept in the per-row
-// form; 16 * cap entries always fit), and each wave then prunes four rows exactly as above.  The group's entries are read four
-// times, from L2 after the first.  Records go out by place = image position (`order`: position -> row).
-constexpr uint32_t kGrpRows = 32, kGrpShift = 27, kGrpHalf = 16;
-__global__ __launch_bounds__(256) void rerank_prune_grouped_kernel(uint32_t n, const float *__restrict__ theta, const double *__restrict__ norms,
-                                                                   const uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ cand, uint32_t cap,
-                                                                   uint32_t K, const uint8_t *__restrict__ force_exact, double prune_delta,
-                                                                   int prune_rectify, uint32_t *__restrict__ records, int slots,
-                                                                   const uint32_t *__restrict__ order, unsigned long long *__restrict__ scored_total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_cnt[kGrpHalf], s_off[kGrpHalf + 1], s_fill[kGrpHalf];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t kRsMaxIds = (uint32_t)rs_max_ids(slots), kRsWords = (uint32_t)rs_words(slots), kRsNormsAt = (uint32_t)rs_norms_at(slots);
-  float *es_all = reinterpret_cast<float *>(smem);                                   // [16 * cap]
-  uint32_t *ei_all = reinterpret_cast<uint32_t *>(smem) + (size_t)kGrpHalf * cap;    // [16 * cap]
-  const uint32_t n_groups = (n + kGrpRows - 1) / kGrpRows;
-  unsigned long long scored = 0;
-  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const uint32_t rows_in = min(kGrpRows, n - g * kGrpRows), gcap = rows_in * cap;
-    const uint32_t total = gcnt[g], E = min(total, gcap);
-    const bool group_overflow = total > gcap;  // entries were dropped: no row of the group can be certified from its list
-    const uint2 *src = reinterpret_cast<const uint2 *>(cand) + (size_t)g * kGrpRows * cap;
-    for (uint32_t h = 0; h < kGrpRows / kGrpHalf; ++h) {
-      if (h * kGrpHalf >= rows_in) break;
-      __syncthreads();
-      if (threadIdx.x < kGrpHalf) {
-        s_cnt[threadIdx.x] = 0;
-        s_fill[threadIdx.x] = 0;
-      }
-      __syncthreads();
-      for (uint32_t e = threadIdx.x; e < E; e += 256) {
-        const uint32_t l = src[e].x >> kGrpShift;
-        if ((l / kGrpHalf) == h) atomicAdd(&s_cnt[l % kGrpHalf], 1u);
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t l = 0; l < kGrpHalf; ++l) {
-          s_off[l] = run;
-          run += min(s_cnt[l], cap);
-        }
-        s_off[kGrpHalf] = run;
-      }
-      __syncthreads();
-      for (uint32_t e = threadIdx.x; e < E; e += 256) {
-        const uint2 v = src[e];
-        const uint32_t l = v.x >> kGrpShift;
-        if ((l / kGrpHalf) == h) {
-          const uint32_t slot = atomicAdd(&s_fill[l % kGrpHalf], 1u);
-          if (slot < cap) {
-            ei_all[s_off[l % kGrpHalf] + slot] = v.x & ((1u << kGrpShift) - 1u);
-            es_all[s_off[l % kGrpHalf] + slot] = __uint_as_float(v.y);
-          }
-        }
-      }
-      __syncthreads();
-      for (uint32_t l = wv; l < kGrpHalf; l += 4) {
-        const uint32_t r = g * kGrpRows + h * kGrpHalf + l;  // place = image position
-        if (r >= n) break;
-        const uint32_t a = order[r];
-        uint32_t *ei = ei_all + s_off[l];
-        float *es = es_all + s_off[l];
-        uint32_t C = min(s_cnt[l], cap);
-        bool overflow = group_overflow || s_cnt[l] > cap;
-        C = prune_candidates(ei, es, C, K, prune_delta, prune_rectify, lane);
-        if (C > kRsMaxIds) {  // more survivors than a record holds: the row goes on to the next stage
-          overflow = true;
-          C = kRsMaxIds;
-        }
-        scored += C;
-        uint32_t *rec = records + (size_t)r * kRsWords;
-        for (uint32_t c = lane; c < C; c += 64) {
-          const uint32_t j = order[ei[c]];
-          rec[kRsIdsAt + c] = j;
-          reinterpret_cast<double *>(rec + kRsNormsAt)[c] = norms[j];
-        }
-        if (lane == 0) {
-          const bool force = force_exact && force_exact[a];
-          rec[0] = C | (overflow ? 0x100u : 0u) | (force ? 0x200u : 0u);
-          rec[1] = __float_as_uint(theta[a]);
-          const unsigned long long nb = (unsigned long long)__double_as_longlong(norms[a]);
-          rec[2] = (uint32_t)nb;
-          rec[3] = (uint32_t)(nb >> 32);
-        }
-        wave_sync();
-      }
-    }
-  }
-  if (scored_total && lane == 0 && scored) atomicAdd(scored_total, scored);
-}
-
-// candidates listed in all / groups that ran over, for the statistics of a build with lists by group
-__global__ void join_group_stats_kernel(const uint32_t *__restrict__ gcnt, uint32_t n, uint32_t cap, unsigned long long *__restrict__ st) {
-  const uint32_t n_groups = (n + kGrpRows - 1) / kGrpRows;
-  unsigned long long sum = 0, over = 0, mx = 0;
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-    const uint32_t gcap = min(kGrpRows, n - g * kGrpRows) * cap, c = gcnt[g];
-    sum += min(c, gcap);
-    over += c > gcap ? min(kGrpRows, n - g * kGrpRows) : 0u;
-    mx = max(mx, (unsigned long long)c);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    sum += __shfl_xor(sum, o, 64);
-    over += __shfl_xor(over, o, 64);
-    mx = max(mx, (unsigned long long)__shfl_xor(mx, o, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(st, sum);
-    atomicMax(st + 1, mx);
-    atomicAdd(st + 2, over);
-  }
-}
-
 typedef double rs_d2 __attribute__((ext_vector_type(2)));  // (a native vector: asm operands of struct type go through memory)
 // row j of X -> one register per lane (lane l: bytes [16 l, 16 l + 16) of the row).  NOT valid before the set has landed (rerank_pairs.h).
 __device__ __forceinline__ void rs_gload16(rs_d2 &dst, uint32_t lane_off, const double *row) {

@@ -352,7 +352,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 #define AS_ASSIGN(DPV)                                                                                                         \
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
   const size_t lds_mfma = (size_t)(np / 32) * 2 * 64 * 16;
-  if (d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024 && ctx->opt_order_mfma) {  // the rotated coordinates: on the matrix pipe
+  if (d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024) {  // the rotated coordinates: on the matrix pipe
     hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), lds_mfma, ctx->stream, rows, n, piv, np, assign.p);
   } else
   switch (dpv / 32) {
@@ -371,7 +371,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   // of them, not a mix (1 M x 128, 4 096 clusters of 244 rows: the masked f16 pass 84 -> 50 ms).  (The second nearest pivot of
   // the FIRST set, kept by the same pass, was tried as the key: the top-2 bookkeeping made the assignment 2 ms slower.)
   DevBuf<uint32_t> assign_sub, starts_own;
-  if (piv_sub && d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024 && ctx->opt_order_mfma) {
+  if (piv_sub && d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024) {
     AS_TRY(assign_sub.alloc(ctx, n));
     uint32_t *gs = group_start;
     if (!gs) {

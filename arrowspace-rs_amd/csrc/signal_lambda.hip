@@ -200,36 +200,6 @@ __global__ void sig_pad_kernel(SigGeom g, uint64_t row_begin, const uint32_t *__
   cnt[last] += (uint32_t)((8 - total % 8) % 8);
 }
 
-// ---- refining a given order by the graph itself --------------------------------------------------------------------------------
-// The order a neighbour search leaves groups the rows by direction (nearest pivot), but lists the groups in no particular
-// order: the groups of one cluster sit far apart, and the rows a group gathers from its sister groups are evicted between
-// their visits.  So the positions are cut into blocks of 1024, the stored entries between blocks are counted (a small dense
-// matrix), and the blocks are chained greedily on the host: each next block is the unvisited one with the most entries towards
-// the last two placed.  Blocks that belong together then follow each other.  Any outcome is a permutation, hence correct.
-constexpr uint32_t kRefineBlock = 1024;
-__global__ void order_inverse_kernel(const uint32_t *__restrict__ order, uint64_t n, uint32_t *__restrict__ inv) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) inv[order[p]] = (uint32_t)p;
-}
-__global__ void block_edges_kernel(const uint64_t *__restrict__ indptr, const uint64_t *__restrict__ indices, uint64_t n,
-                                   const uint32_t *__restrict__ inv, uint32_t nb, uint32_t *__restrict__ counts) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t bi = inv[i] / kRefineBlock;
-  for (uint64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-    const uint64_t j = indices[e];
-    if (j >= n) continue;
-    const uint32_t bj = inv[j] / kRefineBlock;
-    if (bj != bi) atomicAdd(&counts[(size_t)bi * nb + bj], 1u);
-  }
-}
-__global__ void order_apply_blocks_kernel(const uint32_t *__restrict__ order, uint64_t n, const uint32_t *__restrict__ new_start,
-                                          uint32_t *__restrict__ out) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  out[new_start[p / kRefineBlock] + (uint32_t)(p % kRefineBlock)] = order[p];
-}
-
 __global__ void order_check_kernel(const uint32_t *__restrict__ order, uint64_t n, uint32_t *__restrict__ seen, int *__restrict__ bad) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
@@ -866,62 +836,6 @@ int csr_set_order(as_ctx *ctx, as_csr *L, const uint32_t *order_dev) {
   L->order_state = 1;
   return AS_OK;
 }
-
-// refined copy of L->order (see block_edges_kernel); out: a workspace buffer of n entries
-static int refine_order(as_ctx *ctx, as_csr *L, DevBuf<uint32_t> &out) {
-  const uint64_t n = L->n;
-  const uint32_t nb = (uint32_t)((n + kRefineBlock - 1) / kRefineBlock);
-  DevBuf<uint32_t> inv, counts, starts;
-  AS_TRY(inv.alloc(ctx, n));
-  AS_TRY(counts.alloc(ctx, (size_t)nb * nb));
-  AS_TRY(starts.alloc(ctx, nb));
-  AS_TRY(out.alloc(ctx, n));
-  AS_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(uint32_t) * (size_t)nb * nb, ctx->stream));
-  hipLaunchKernelGGL(order_inverse_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)L->order, n, inv.p);
-  hipLaunchKernelGGL(block_edges_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices, n, (const uint32_t *)inv.p, nb, counts.p);
-  AS_HIP(ctx, hipGetLastError());
-  std::vector<uint32_t> h((size_t)nb * nb);
-  AS_HIP(ctx, copy_d2h(ctx, h.data(), counts.p, sizeof(uint32_t) * h.size()));
-  // greedy chain: ties and empty rows fall back to the lowest unvisited block (deterministic)
-  std::vector<uint32_t> seq;
-  std::vector<char> used(nb, 0);
-  seq.reserve(nb);
-  uint32_t next_free = 0;
-  while (seq.size() < nb) {
-    uint32_t pick = 0xFFFFFFFFu;
-    unsigned long long best = 0;
-    if (!seq.empty()) {
-      const uint32_t a = seq.back(), b = seq.size() > 1 ? seq[seq.size() - 2] : seq.back();
-      for (uint32_t c = 0; c < nb; ++c) {
-        if (used[c]) continue;
-        const unsigned long long w = 2ull * (h[(size_t)a * nb + c] + h[(size_t)c * nb + a]) + (h[(size_t)b * nb + c] + h[(size_t)c * nb + b]);
-        if (w > best) {
-          best = w;
-          pick = c;
-        }
-      }
-    }
-    if (pick == 0xFFFFFFFFu) {
-      while (used[next_free]) ++next_free;
-      pick = next_free;
-    }
-    used[pick] = 1;
-    seq.push_back(pick);
-  }
-  // where each old block starts in the new order (the last block of the old order may be short: it keeps its length)
-  std::vector<uint32_t> start(nb);
-  uint32_t at = 0;
-  for (uint32_t c : seq) {
-    start[c] = at;
-    at += (uint32_t)std::min<uint64_t>(kRefineBlock, n - (uint64_t)c * kRefineBlock);
-  }
-  AS_HIP(ctx, copy_h2d(ctx, starts.p, start.data(), sizeof(uint32_t) * nb));
-  hipLaunchKernelGGL(order_apply_blocks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)L->order, n, (const uint32_t *)starts.p,
-                     out.p);
-  AS_HIP(ctx, hipGetLastError());
-  return AS_OK;
-}
-
 static SigGeom geom_of(const as_csr *L) {
   SigGeom g;
   g.n = (uint32_t)L->n, g.ch = L->sig_ch, g.wx = L->sig_wx, g.k = L->sig_k, g.c8 = L->sig_c8;
@@ -957,8 +871,7 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   // fixes the wave count instead (then a wave owns several chunks, cut as described above).
   uint32_t wx_max = 0x7FFFFFF0u / 8;
   (void)blocks_per_cu, (void)cus;
-  if (ctx->opt_signal_waves > 0) wx_max = (uint32_t)std::max<int64_t>(kWavesPerBlock, ctx->opt_signal_waves / 8 / kWavesPerBlock * kWavesPerBlock);
-  const uint32_t ch = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_signal_chunk_rows), 1024);
+  const uint32_t ch = 16;  // consecutive rows a wave takes at a time (8 / 32 measured: no better)
   const uint64_t n_chunks = std::max<uint64_t>(1, (L->n + ch - 1) / ch);
   const uint32_t c8 = (uint32_t)((n_chunks + 7) / 8);
   uint32_t wx = std::min<uint32_t>(wx_max, (c8 + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock);
@@ -966,13 +879,6 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   const SigGeom g = geom_of(L);
   const uint64_t slots = sig_slots(g);
   const uint32_t *order = ctx->opt_signal_order ? L->order : nullptr;
-  DevBuf<uint32_t> refined;
-  const bool refine = order && !block && ctx->opt_signal_order_refine && L->n >= 16 * kRefineBlock && L->n / kRefineBlock <= 8192;
-  if (refine) {
-    AS_TRY(refine_order(ctx, L, refined));
-    order = refined.p;
-  }
-  ctx->stats["signal_stream_order_refined"] = refine ? 1 : 0;
   DevBuf<uint32_t> cnt;
   AS_TRY(cnt.alloc(ctx, slots + 1));
   hipLaunchKernelGGL(sig_count_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, ctx->stream, L->indptr, L->indices, g, L->row_begin, order, sym, cnt.p);
@@ -1004,9 +910,7 @@ static void launch_sums(as_ctx *ctx, bool vec, uint32_t nbk, uint32_t n_slabs, c
 #define AS_SIG_LAUNCH(W, GY)                                                                                                          \
   hipLaunchKernelGGL((signal_sums_kernel<PASS2, W>), dim3(nbk, GY), dim3(256), 0, ctx->stream, X, (uint64_t)S, S, (const SigRec *)L->sig_rec, \
                      (const uint64_t *)L->sig_off, spw, L->sig_wx, edge_tot, need, part)
-  if (ctx->opt_signal_half_slabs)
-    AS_SIG_LAUNCH(1, 2 * n_slabs);
-  else if (vec)
+  if (vec)
     AS_SIG_LAUNCH(2, n_slabs);
   else
     AS_SIG_LAUNCH(0, n_slabs);

@@ -623,6 +623,13 @@ def main():
                 rec = recorded_traffic(pmc or kernel.split(" ")[0].split("<")[0], n, d)
                 if rec:   # PMC counters cannot be read from inside this process: the committed rocprofv3 --pmc passes of the
                     e["traffic"] = rec["bytes_per_launch"]   # same command (scripts/profile_round.sh), per launch
+                    if e.get("gather") and rec["bytes_per_launch"]:
+                        # a gather kernel whose rows are shared through the L2s REQUESTS more than the memory system can deliver from
+                        # HBM (frac of the requested bytes above 1 is no utilisation): its rate is what left the L2s over its time
+                        e["requested_GBs"] = ach
+                        e["achieved"] = rec["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+                        e["frac"] = e["achieved"] / peak
+                        e["achieved_is"] = "counter bytes (L2 <-> fabric, profiles/) over the launch time measured here"
                     e["traffic_source"] = {"file": rec["source"], "commit": rec["commit"], "source_sha16": rec["source_sha16"]}
                     e["traffic_stale"] = rec["stale"]
             kernels.append(e)
@@ -680,7 +687,9 @@ def main():
                     "hbm", score_bytes, HBM_PEAK_GBS, "GB/s", "bytes REQUESTED: 16 rows of 8 d bytes per batch + descriptors + keys (rows of one neighbourhood are "
                     "visited side by side on an L2, so part is served on-die: `traffic` is what left the L2s)",
                     {"rows_fetched_per_row": batches * 16.0 / max(1, rows_here), "pairs_scored_per_row": pairs / max(1, rows_here),
-                     "survivors_per_row": scored / max(1, rows_here), "batches": batches}, pmc="rerank_pairs_score_kernel")
+                     "survivors_per_row": scored / max(1, rows_here), "batches": batches, "gather": True,
+                     "achieved_is": "REQUESTED bytes over the launch time (no counter pass of this binary at hand): rows shared through the "
+                                    "L2s make this exceed what HBM delivers"}, pmc="rerank_pairs_score_kernel")
                 add("knn_rerank_prune", "rerank_prune_kernel (lists -> per-pair bounds -> survivors: a record per row)", "hbm",
                     stats["knn_join_candidates"] * 12.0 + scored * 12.0 + rows_here * 16.0, HBM_PEAK_GBS, "GB/s",
                     "lists (8 B per listed slot + a 4 B plane error gathered) read, records (ids + norms) written; instruction-bound (bisection "

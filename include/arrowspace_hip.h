@@ -87,49 +87,43 @@ const char *as_status_message(int status); /* the reference's panic text for a s
  * sync); host outputs are always complete on return. */
 int as_ctx_set_stream(as_ctx *ctx, void *hip_stream);
 int as_ctx_synchronize(as_ctx *ctx);
-/* Tuning knobs (none of them changes a result, only which stage produces it; defaults in
- * csrc/common.h).  The ones a caller may want:
- *   "knn_mfma" / "search_mfma"  0 = exact brute-force scan only, 1 = MFMA candidate passes + exact
- *                               re-rank + certification (default)
- *   "cand_precision"            32 (default) or 64: first MFMA candidate pass on the f32 / f64 pipe
- *   "knn_join"                  symmetric threshold join for whole-matrix item graphs (default 1)
- *   "join_pipe"                 16 = one f16 plane (dim <= 128, default), 48 = split bf16 in two phases, 32 = f32 MFMA
- *   "join_min_rows"             smallest n for the join and for the search scan (default 32768)
- *   "join_sample", "join_rank", "join_cap", "join_block"   threshold sample 1-in-N, order statistic,
- *                               list slots per row (0 = automatic: 32 / 4 / 512), column super tiles per work unit
- *   "join_prefilter"            int8 first pass in front of the f16 join (whole-matrix item graphs from
- *                               "join_prefilter_min_rows" = 65536 rows): 1 = on, on the rotated 32-wide image (31 dominant
- *                               directions + the tail norm; default), 2 = full-width image always, 3 = rotated always,
- *                               0 = off;
- *                               "join_order_pivots" (1024), "join_theta_grouped" (1): the row order and the thresholds behind it;
- *                               "join_order_sub" (4): inside a pivot's group the rows follow their nearest pivot of a second
- *                               set of join_order_pivots / 4 pivots (0 = off);
- *                               "join_basis_iters" (4): rounds of subspace iteration behind the 31 directions of the first pass
- *   "search_lambda_order" (1)   a batch of 1024 queries or more on an index whose items are in their own order is scanned in the
- *                               order of its lambdas (a row group then spans a narrow lambda range: fewer blocks walked); 0 = as given
- *   "search_scan_order", "search_prefilter", "search_stream_filter"   an index of 65536 items or more that is searched
- *                               again keeps ordered / rotated images: 1 = from the second search on (default), 0 = never
- *                               (and 2 = at the first search, for "search_scan_order")
- *                               "search_rot_tail_e3" (100): the rotated images are kept when at most this share (x 1e-3) of the
- *                               items' energy lies outside their 31 directions (measured on data of higher rank: no gain above)
- *   "search_scan"               threshold scan of the search on the bf16 pipe (default 1; applies for
- *                               0 < alpha <= 1, dim <= 128), "search_scan_sample" / "_rank" / "_cap"
- *                               "join_cone_tiles" (1), "join_cone_second" (1): the cone bound on pairs of 128-position tiles in
- *                               front of the first pass / its one-sided form in front of the second pass;
- *                               "join_theta_band" (2): thresholds raised to what a row's own neighbourhood in the ordered image
- *                               certifies (super tiles on either side; 0 = off), "join_theta_band_second" (1): the second pass
- *                               never cuts below them; "rerank_pair_bound" (1): the pruning in front of the exact re-rank bounds
- *                               each pair by its two rows' own f16 plane errors; "join_theta_grouped_bad_e3" (10): the grouped
- *                               thresholds are kept while at most this share (x 1e-3) of 4 096 checked rows sit far below the plain
- *                               sample's; "join_theta_parts" (1), "join_unit_list" (1): threshold passes with few rows split the
- *                               sample over several units / the masked f16 pass walks a list of the units that hold something
- *   "rerank_order" (1), "assembly_lanes" (2), "nearest_mfma" (1), "cluster_on_device" (1)   forms of the same results:
- *                               exact re-rank in the order of the join's image, graph assembly (2 = the round-4 kernels, 1 = 32
- *                               lanes per row throughout, 0 = a thread per row), nearest-centroid keys of a clustering batch on
- *                               the f32 matrix pipe, clustering batches on the device (0 = the older form of each, for comparison)
- *   "handle_cache_mb" (2048)    memory of destroyed handles (CSR slabs, index images, uploads) kept for the next allocation of the
- *                               same size instead of hipFree + hipMalloc (process-wide; environment ARROWSPACE_HANDLE_CACHE_MB;
- *                               0 = off and released)
+/* Options.  None of them changes a result -- only which stage produces it; defaults in parentheses.  The 33 below are the supported
+ * ones; csrc/common.h (struct as_ctx) lists, next to these, the switches that exist for the tests and for measurements only (forms
+ * of one stage that must agree bit for bit, failure injection, sample sizes): they are accepted here too but are no interface.
+ *  stages
+ *   "knn_mfma" (1), "search_mfma" (1)   MFMA candidate passes + exact re-rank + certification; 0 = the exact brute-force scan only
+ *   "cand_precision" (32)       first candidate pass of the non-join path on the f32 pipe, or 64: on the f64 pipe
+ *   "knn_join" (1)              symmetric threshold join for whole-matrix item graphs of "join_min_rows" (32768) rows or more
+ *   "join_pipe" (16)            its contraction: 16 = one f16 plane, 48 = split bf16 in two phases (dim <= 128), 32 = f32 MFMA
+ *   "join_sample", "join_rank", "join_cap" (0 = automatic: 32 / 4 / 512)   threshold sample 1-in-N, its order statistic, list slots per row
+ *   "stream_scan" (1)           streaming exact scans for the rows / queries the candidate stages leave open
+ *  the join's preparation
+ *   "join_prefilter" (1)        int8 first pass in front of the f16 join, from "join_prefilter_min_rows" (65536) rows: 1 = on the rotated
+ *                               32-wide image (31 dominant directions + the tail norm), 2 = full-width image always, 3 = rotated always, 0 = off
+ *   "join_row_order" (1)        rows grouped by direction in the operand image: "join_order_pivots" (1024) pivots on the rotated coordinates,
+ *                               "join_order_sub" (4): inside a group by a second set of pivots / 4, "join_order_chain" (1): the groups laid
+ *                               out along a greedy chain of similar pivots (neighbours of a row end up near it in the image)
+ *   "join_theta_grouped" (1)    thresholds against the sampled rows of the 16 pivot groups nearest to a row's own (checked against the plain sample)
+ *   "join_theta_band" (2)       thresholds raised to what a row's own neighbourhood in the ordered image certifies (512-position super tiles
+ *                               on either side; 0 = off); "join_theta_band_slack" (4): the certified cut is also taken where the sampled
+ *                               threshold is higher by at most this many rounding bounds
+ *   "join_cone_tiles" (1), "join_cone_second" (1)   cone bound on pairs of 128-position tiles in front of the first pass / its one-sided
+ *                               form in front of the second pass
+ *  the exact re-rank
+ *   "rerank_pair_bound" (1)     the pruning bounds each pair by its two rows' own f16 plane errors
+ *   "rerank_share" (1)          a pair two rows both keep is fetched and scored once, its key handed to both (0: every row scores all its own)
+ *  search
+ *   "search_scan" (1)           threshold scan of a query batch on the 16-bit pipe (0 < alpha <= 1)
+ *   "search_scan_order", "search_prefilter", "search_stream_filter" (1)   an index of 65536 items or more that is searched again keeps
+ *                               ordered / rotated images: 1 = from the second search on, 0 = never (2 = at the first, for "search_scan_order")
+ *   "search_lambda_order" (1)   a batch of 1024 queries or more is scanned in the order of its lambdas
+ *  item-graph lambda
+ *   "signal_sym" (1)            a bitwise symmetric graph is streamed as its upper triangle
+ *   "signal_order" (1)          rows visited in the order attached to the graph (as_csr_set_order; as_build_laplacian attaches the join's)
+ *  resources
+ *   "handle_cache_mb" (2048)    memory of destroyed handles kept for the next allocation of the same size (process-wide; environment
+ *                               ARROWSPACE_HANDLE_CACHE_MB; 0 = off and released)
+ *   "sharded_agreement" (1)     every collective of a sharded call behind a one-word status agreement (as_*_sharded)
  *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);

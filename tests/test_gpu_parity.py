@@ -371,33 +371,6 @@ def test_item_graph_join_behind_the_int8_first_pass(ctx, join_on, n, d, mode, is
     assert np.array_equal(dist, od)
 
 
-@pytest.mark.parametrize("n,topk", [(70000, 16), (66001, 40), (131072, 5)])
-def test_item_graph_join_lists_by_group(ctx, join_on, n, topk):
-    """"join_grouped_lists" 1: the masked f16 pass keeps its candidates per group of 32 image positions (one returning atomic per
-    run of entries, contiguous writes) and the pruning kernel bins a group's entries by row in LDS.  Off by default (measured
-    slower end to end); the tables are those of the per-row lists and the oracle's.  Duplicates, a zero row, ragged tiles, a
-    table deeper than a record."""
-    X, _ = synth.mixture(n, 128, seed=29, n_clusters=9 if n < 10000 else 40, rank=4)
-    X[40:48] = X[3]
-    X[11] = 0.0
-    gp = A.GraphParams(0.6, 16, topk, 2.0, 0.25)
-    ctx.set_option("join_prefilter_min_rows", 0)
-    try:
-        idx0, dist0 = A.knn_cosine(X, gp)
-        assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_prefilter") == 1 and ctx.stat("knn_join_grouped_lists") == 0
-        ctx.set_option("join_grouped_lists", 1)
-        idx, dist = A.knn_cosine(X, gp)
-        assert ctx.stat("knn_join_grouped_lists") == 1
-    finally:
-        ctx.set_option("join_grouped_lists", 0)
-        ctx.set_option("join_prefilter_min_rows", 65536)
-    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
-    rng = np.random.default_rng(4)
-    sample = np.sort(rng.choice(n, size=min(n, 256), replace=False))
-    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
-    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
-
-
 @pytest.mark.parametrize("n,d,topk", [(70000, 128, 16), (66001, 64, 40), (131072 + 300, 128, 5), (70144, 256, 16)])
 def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
     """"join_cone_tiles" (round 4, cone_tiles.hip): the int8 first pass sweeps only the pairs of 128-position tiles a one-sided cone
@@ -990,8 +963,8 @@ def test_handle_memory_cache_on_and_off(ctx):
 def test_graph_assembly_hub_rows_on_every_path(ctx):
     """A neighbour table with hubs of every size class of the assembly (graph_assembly.hip): two nodes that ~12 000 rows point to
     (the serial form past 4 096 entries), ten with ~1 200 in-edges (a workgroup per row), fifty with ~240 (a wave per row), the
-    rest short rows side by side.  The round-4 kernels ("assembly_lanes" 2), the 32-lanes-per-row ones (1) and the
-    thread-per-row form (0: its own sort and union code) must give the same CSR bit for bit, as whole matrix and as row blocks,
+    rest short rows side by side.  The lane-parallel kernels (K <= 32) and the thread-per-row form ("assembly_lanes" 0: its own sort and
+    union code, what tables deeper than 32 take) must give the same CSR bit for bit, as whole matrix and as row blocks,
     and the CSR keeps the reference's invariants (src/tests/test_laplacian.rs:51-152)."""
     n, K = 12_000, 12
     rng = np.random.default_rng(5)
@@ -1007,7 +980,7 @@ def test_graph_assembly_hub_rows_on_every_path(ctx):
     dist = 0.01 + 0.44 * ((pair * 2654435761) % (1 << 32)) / float(1 << 32)
     gp = A.GraphParams(0.5, 16, K - 1, 2.0, 0.25)
     got = {}
-    for lanes in (2, 1, 0):
+    for lanes in (2, 0):
         ctx.set_option("assembly_lanes", lanes)
         try:
             got[lanes] = A.laplacian_from_knn(idx, dist, gp, ctx=ctx).to_host()
@@ -1015,7 +988,7 @@ def test_graph_assembly_hub_rows_on_every_path(ctx):
                 blocks = [A.laplacian_from_knn(idx, dist, gp, row_begin=a, row_count=b - a, ctx=ctx).to_host() for a, b in ((0, 5000), (5000, n))]
         finally:
             ctx.set_option("assembly_lanes", 2)
-    for lanes in (1, 0):
+    for lanes in (0,):
         for a, b in zip(got[2], got[lanes]):
             assert np.array_equal(a, b), lanes
     indptr, indices, data = got[2]

@@ -157,43 +157,6 @@ def test_any_order_gives_the_same_lambdas(ctx):
         assert e.value.status == _lib.AS_ERR_ARG
 
 
-def test_order_refined_by_the_graph(ctx):
-    """"signal_order_refine": the blocks of the attached order chained by the stored entries between them -- another permutation,
-    the same lambdas"""
-    X, _ = synth.mixture(40000, 64, seed=19, n_clusters=24, rank=6)
-    gl = A.build_laplacian_matrix(X, A.GraphParams(0.5, 16, 16, 2.0, 0.25), ctx=ctx)
-    want = oracle_signals(X, gl.matrix.to_host(), O.TAU_MEAN, 0.0)
-    rng = np.random.default_rng(2)
-    gl.matrix.set_order(rng.permutation(40000))
-    ctx.set_option("signal_order_refine", 1)
-    try:
-        got = compute_taumode_signals(X, gl.matrix, T.Mean, ctx=ctx)
-        assert ctx.stat("signal_stream_order_refined") == 1
-    finally:
-        ctx.set_option("signal_order_refine", 0)
-    assert_lambdas(got, want)
-
-
-@pytest.mark.parametrize("S", [1, 63, 64, 65, 128, 200])
-def test_half_slabs_give_the_same_bits(ctx, S):
-    """"signal_half_slabs": one column per lane and 512-byte gathers (a measured alternative, off by default) -- the same sums in
-    the same order, both rounds"""
-    rng = np.random.default_rng(40 + S)
-    csr = random_csr(rng, 3000, 7, True)
-    X = rng.standard_normal((3000, S))
-    if S > 4:
-        X[:, :2] *= 1e90   # these columns take the second round
-    m = A.CsrMatrix.from_host(ctx, *csr)
-    whole = compute_taumode_signals(X, m, T.Fixed(0.4), ctx=ctx)
-    ctx.set_option("signal_half_slabs", 1)
-    try:
-        half = compute_taumode_signals(X, m, T.Fixed(0.4), ctx=ctx)
-    finally:
-        ctx.set_option("signal_half_slabs", 0)
-    assert np.array_equal(whole, half)
-    assert_lambdas(half, oracle_signals(X, csr, O.TAU_FIXED, 0.4))
-
-
 def test_extreme_magnitudes_take_the_literal_second_pass(ctx):
     """sum t^2 overflows although every share t / edge is fine: the reference's own second pass (taumode.rs:611-639)"""
     rng = np.random.default_rng(21)
