@@ -11,14 +11,23 @@ for r in rows:
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
     if "Start_Timestamp" in r:
         acc[key]["_wall_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+# per kernel name: launches, mean wall time, clock and matrix-pipe busy fraction over its launches (kernels of 0.2 ms or more on average;
+# until round 5 only launches of 5 ms or more were listed one by one -- at 1 M x 128 no launch is that long any more)
+per = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 for (did, name), c in acc.items():
     wall = c.get("_wall_ns", 0.0)
-    if wall < 5e6:
+    if wall <= 0:
         continue
-    clk = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / wall  # GHz
-    out = "%-90s wall %8.2f ms clock %.3f GHz" % (name, wall / 1e6, clk)
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and clk > 0:
-        out += "  mfma busy %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * clk * wall))
-    if "SQ_BUSY_CU_CYCLES" in c and clk > 0:
-        out += "  cu busy raw %.3e" % c["SQ_BUSY_CU_CYCLES"]
+    p = per[name]
+    p[0] += 1
+    p[1] += wall
+    p[2] += c.get("GRBM_GUI_ACTIVE", 0.0)
+    p[3] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+for name, (cnt, wall, gui, busy) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+    if wall / cnt < 2e5:
+        continue
+    clk = gui / 8.0 / wall  # GHz
+    out = "%-90s launches %3d  mean wall %7.3f ms  clock %.3f GHz" % (name, cnt, wall / cnt / 1e6, clk)
+    if busy and clk > 0:
+        out += "  mfma busy %.3f" % (busy / (1024.0 * clk * wall))
     print(out)
