@@ -1151,6 +1151,7 @@ void as_index_destroy(as_index *ix) {
   if (ix->packed8) (void)handle_free(ix->packed8);
   if (ix->packed8_nat) (void)handle_free(ix->packed8_nat);
   if (ix->rot_q) (void)handle_free(ix->rot_q);
+  if (ix->rot_qw) (void)handle_free(ix->rot_qw);
   delete ix;
 }
 

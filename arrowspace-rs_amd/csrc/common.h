@@ -210,6 +210,8 @@ struct as_index {
   float *scan_piv = nullptr;        // 256 x 128 pivots
   void *packed8 = nullptr;          // rotated int8 image, by image position
   float *rot_q = nullptr;           // its 31 directions (32 x 128)
+  float *rot_qw = nullptr;          // items wider than 128: the 31 directions of rotate_wide.hip (31 x rotated_wide_pitch(d)), kept to
+                                    // project a batch of queries the same way (the ordered images of wide items, round 5)
   double rot_err = -1.0;            // its largest quantisation error norm
   int rot_state = 0;                // 0 not tried, 1 usable, -1 the directions do not carry the items
   std::atomic<uint32_t> scan_calls{0};  // searches run on this index so far

@@ -970,7 +970,9 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
                        const uint32_t *perm = nullptr);
 bool rotated_wide_supported(uint32_t d);
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out, const ShardedRows *sr = nullptr);
+                      double *tail_out, const ShardedRows *sr = nullptr, float *Q_out = nullptr);
+uint32_t rotated_wide_pitch(uint32_t d);
+int rotated_project_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const float *Q, double *Z, double *znorm);
 int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
 int prefilter_i8_rotated(as_ctx *ctx, const void *P8, double err, uint32_t n, uint32_t I_begin, uint32_t I_count, const float *theta,
                          unsigned char *mask, const uint32_t *tile_mask = nullptr, uint32_t tm_words = 0);
@@ -993,7 +995,8 @@ int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_
                                float beta, float *score_out, uint32_t m2, float *score2_out);
 int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                          const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                         uint32_t *cnt, uint32_t *cand, const char *prof_name);
+                         uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm = nullptr, const uint32_t *q_perm = nullptr,
+                         const unsigned char *mask = nullptr);
 int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                      const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                      uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out);
@@ -2275,6 +2278,13 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   }
   const bool ordered_ok = !wide && n >= 65536 && ctx->opt_join_pipe == 16 && ctx->opt_search_scan_f16 && ctx->opt_search_scan &&
                           (ctx->opt_search_scan_order == 2 || (ctx->opt_search_scan_order == 1 && prior_calls >= 1));
+  // items wider than 128 (round 5): the same two things -- an image in an order that groups the items by direction, found on their
+  // rotated coordinates (rotate_wide.hip), and the rotated int8 image for a rectangular first pass in front of the panelled scan
+  const bool ordered_ok_w = wide && n >= 65536 && rotated_wide_supported((uint32_t)d) && ctx->opt_join_pipe == 16 && ctx->opt_search_scan &&
+                            ctx->opt_search_prefilter &&
+                            // (a batch of 8 192 queries or more pays for the images -- ~30 ms per million items of 768 columns -- within
+                            // its own scan, 1.5 ms per thousand queries there: such a batch gets them at the first search already)
+                            (ctx->opt_search_scan_order == 2 || (ctx->opt_search_scan_order == 1 && (prior_calls >= 1 || nq >= 8192)));
   const bool prefer_staged = ordered_ok && ctx->opt_search_prefilter && d > 32 && ix->rot_state >= 0 && alpha > 0.0 && alpha <= 1.0 &&
                              nq >= (uint32_t)std::max<int64_t>(1, ctx->opt_search_staged_min_batch);
   // one query or a small batch: the bandwidth-bound regime.  One exact pass over the items (stream_scan.hip), no
@@ -2421,8 +2431,10 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // (search_scan_order = 2: at the first): one-shot use pays nothing, a serving index pays once.
     const bool want_order = scan_h && ordered_ok;
     const uint32_t ns_want = std::max(256u, (n / (uint32_t)std::max<int64_t>(2, ctx->opt_search_scan_sample)) & ~255u);
+    const bool want_order_w = scan_wide && ordered_ok_w && ix->rot_state >= 0;
     auto scan_state_missing = [&]() -> bool {
       return (want_order && !ix->scan_perm && ix->packedh) || ((scan_wide || scan_h) && !ix->packedh) ||
+             (want_order_w && ix->rot_state == 0) || (want_order_w && ix->rot_state == 1 && (!ix->scan_perm || !ix->packed8 || !ix->lam32_pos)) ||
              (scan_h && ctx->opt_search_prefilter && d > 32 && (want_order || ix->scan_perm) && (ix->rot_state == 0 || (ix->rot_state == 1 && !ix->packed8))) ||
              (!scan_wide && !scan_h && !ix->packed16) ||
              !ix->lam32 || (scan_h && ix->scan_perm && !ix->lam32_pos) || !ix->scan_sample || ix->scan_ns != ns_want;
@@ -2431,6 +2443,34 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     if (want_order && !ix->scan_perm && ix->packedh) {  // (the image of the first scan was in the order of the items)
       (void)handle_free(ix->packedh);
       ix->packedh = nullptr;
+    }
+    if (want_order_w && (ix->rot_state == 0 || (ix->rot_state == 1 && (!ix->scan_perm || !ix->packed8)))) {
+      // wide items: rotated coordinates -> order, ordered f16 image, rotated int8 image by position; the directions stay with the index
+      const uint32_t tiles = packed_tiles_f16(n);
+      DevBuf<double> Zi, zn;
+      double tail = 1.0;
+      AS_TRY(Zi.alloc(ctx, (size_t)n * 32));
+      AS_TRY(zn.alloc(ctx, n));
+      if (!ix->rot_qw) AS_HIP(ctx, handle_malloc((void **)&ix->rot_qw, sizeof(float) * 31 * (size_t)rotated_wide_pitch(d)));
+      AS_TRY(rotated_rows_wide(ctx, ix->items, ix->norms, n, d, Zi.p, zn.p, &tail, nullptr, ix->rot_qw));
+      // (the cut of the narrow items -- a tenth of the energy outside the directions -- weighs a 32-wide pass against a 128-wide scan;
+      // here the scan is d / 32 times the pass, as for the join of wide rows: the images are kept unless the directions carry nothing)
+      ix->rot_state = tail <= std::max(0.5, (double)ctx->opt_search_rot_tail_e3 * 1e-3) ? 1 : -1;
+      ctx->stats["search_rot_tail_e6"] = (int64_t)(tail * 1e6);
+      if (ix->rot_state == 1) {
+        if (ix->packedh) {  // (the image of the first scan was in the order of the items)
+          (void)handle_free(ix->packedh);
+          ix->packedh = nullptr;
+        }
+        if (!ix->scan_perm) AS_HIP(ctx, handle_malloc((void **)&ix->scan_perm, sizeof(uint32_t) * (size_t)n));
+        if (!ix->scan_piv) AS_HIP(ctx, handle_malloc((void **)&ix->scan_piv, sizeof(float) * 256 * 128));
+        AS_TRY(cluster_order(ctx, Zi.p, zn.p, n, 32, ix->scan_perm, ix->scan_piv));
+        AS_HIP(ctx, handle_malloc(&ix->packedh, packed_vecs_f16(tiles, d) * 16));
+        AS_TRY(pack_f16_all(ctx, ix->items, ix->norms, n, d, ix->packedh, tiles, ix->scan_perm));
+        ix->f16_err = ctx->f16_err;
+        if (!ix->packed8) AS_HIP(ctx, handle_malloc(&ix->packed8, rotated_image_bytes(tiles)));
+        AS_TRY(pack_rotated_from_z(ctx, Zi.p, ix->scan_perm, n, tiles, ix->packed8, &ix->rot_err));
+      }
     }
     if ((scan_wide || scan_h) && !ix->packedh) {
       const uint32_t tiles = packed_tiles_f16(n);
@@ -2469,7 +2509,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream,
                          ix->lambdas, (const uint32_t *)nullptr, n, lpad, ix->lam32);
     }
-    if (scan_h && ix->scan_perm && !ix->lam32_pos) {  // ... and by position in the ordered image
+    if ((scan_h || scan_wide) && ix->scan_perm && !ix->lam32_pos) {  // ... and by position in the ordered image
       const uint32_t lpad = (n + 511) / 512 * 512;
       AS_HIP(ctx, handle_malloc((void **)&ix->lam32_pos, sizeof(float) * (size_t)lpad));
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv((uint64_t)lpad, 256)), dim3(256), 0, ctx->stream, ix->lambdas,
@@ -2493,7 +2533,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       ix->scan_ns = ns;
     }
     )
-    const float *x_lam_h = (scan_h && ix->scan_perm) ? ix->lam32_pos : ix->lam32;  // what the f16 scan of narrow items reads
+    const float *x_lam_h = ((scan_h || scan_wide) && ix->scan_perm) ? ix->lam32_pos : ix->lam32;  // what the f16 scan reads: by image position
     const uint32_t ns = ix->scan_ns;
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_search_scan_rank, 32));
     const uint32_t a_tiles = (nq + kTileRows - 1) / kTileRows, a_alloc = scan_h ? (a_tiles + 3) & ~3u : (a_tiles + 1) & ~1u;
@@ -2519,12 +2559,20 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // ... and on an index whose items are in their own order a batch goes in the order of its LAMBDAS: a row group of the scan
     // then spans a narrow lambda range, and a lane can rule its column out by the lambda term from two scalars (the cosine alone
     // reaching its floor sent half of all blocks of a 10 k-query batch through the walk; mfma_join_f16.hip)
-    const bool q_by_pivots = scan_h && ix->scan_perm && nq >= 2048;
+    const bool wide_pre = scan_wide && ix->scan_perm && ix->rot_state == 1 && ix->packed8 && ix->rot_qw && ctx->opt_search_prefilter;
+    DevBuf<double> Zq, zqn;  // wide items behind the first pass: the batch's rotated coordinates
+    if (wide_pre) {
+      AS_TRY(Zq.alloc(ctx, (size_t)nq * 32));
+      AS_TRY(zqn.alloc(ctx, nq));
+      AS_TRY(rotated_project_wide(ctx, queries, q_norms, nq, d, ix->rot_qw, Zq.p, zqn.p));
+    }
+    const bool q_by_pivots = (scan_h && ix->scan_perm && nq >= 2048) || (wide_pre && nq >= 2048);
     const bool q_by_lambda = scan_h && !q_by_pivots && nq >= 1024 && ctx->opt_search_lambda_order && is_device_ptr(q_lambdas);
     const bool q_order = q_by_pivots || q_by_lambda;
     if (q_order) {
       AS_TRY(qperm.alloc(ctx, nq));
-      if (q_by_pivots) AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
+      if (q_by_pivots && wide_pre) AS_TRY(order_by_pivots(ctx, Zq.p, nq, 32, ix->scan_piv, qperm.p));
+      else if (q_by_pivots) AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
       else AS_TRY(order_by_value(ctx, q_lambdas, nq, qperm.p));
     }
     ctx->stats["search_scan_lambda_order"] = q_by_lambda ? 1 : 0;
@@ -2538,7 +2586,7 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(gmb_pad.alloc(ctx, padded));
     }
     if (scan_wide) {  // one f16 plane: the measured plane errors of the two images (mfma_join_f16.hip)
-      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQ.p, a_alloc));
+      AS_TRY(pack_f16_all(ctx, queries, q_norms, nq, d, PQ.p, a_alloc, q_order ? qperm.p : nullptr));
       const double e = std::max(ctx->f16_err, ix->f16_err);
       cos_delta = (ctx->f16_err >= 0.0 && ix->f16_err >= 0.0) ? std::min(cos_delta_f16(d), 2.0 * e + e * e + cos_delta_f16_accum(d))
                                                                 : cos_delta_f16(d);
@@ -2555,7 +2603,15 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       hipLaunchKernelGGL(gather_lambda_f32_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, q_lambdas,
                          (const uint32_t *)qperm.p, nq, padded, qlam_pos.p);
     }
-    if (scan_wide)
+    if (scan_wide && q_order) {  // (the image is in the batch's own order: the guesses come out by position and go back to the queries)
+      DevBuf<float> g1, g2;
+      AS_TRY(g1.alloc(ctx, padded));
+      AS_TRY(g2.alloc(ctx, padded));
+      AS_TRY(search_thresholds_f16_wide(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam_pos.p, ix->scan_sample_lam,
+                                        (float)alpha, (float)beta, g1.p, m2, g2.p));
+      AS_TRY(scatter_by_perm(ctx, g1.p, qperm.p, nq, guess.p));
+      AS_TRY(scatter_by_perm(ctx, g2.p, qperm.p, nq, guess2.p));
+    } else if (scan_wide)
       AS_TRY(search_thresholds_f16_wide(ctx, PQ.p, nq, d, ix->items, ix->norms, ix->scan_sample, ns, m, qlam.p, ix->scan_sample_lam,
                                         (float)alpha, (float)beta, guess.p, m2, guess2.p));
     else
@@ -2587,10 +2643,28 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
                              (float)alpha, (float)beta, cap, cnt.p, cand.p, unitc.p, "search_scan_f16", ix->scan_perm,
                              q_order ? qperm.p : nullptr, pre ? mask.p : nullptr));
     } else if (scan_wide) {
-      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded, 256)), dim3(256), 0, ctx->stream, guess.p, (const uint32_t *)nullptr,
-                         nq, padded, (float)alpha, (float)beta, floor_pad.p, gmb_pad.p);
-      AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQ.p, nq, floor_pad.p, gmb_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta,
-                                  cap, cnt.p, cand.p, "search_scan_f16"));
+      // (floor / g - beta by position of the query image; padded to whole 512-position super tiles of the first pass: +inf beyond nq)
+      const uint32_t a_alloc4 = (a_alloc + 3) & ~3u, padded4 = a_alloc4 * kTileRows;
+      DevBuf<float> floor4, gmb4;
+      AS_TRY(floor4.alloc(ctx, padded4));
+      AS_TRY(gmb4.alloc(ctx, padded4));
+      hipLaunchKernelGGL(scan_guess_wide_kernel, dim3(cdiv(padded4, 256)), dim3(256), 0, ctx->stream, guess.p,
+                         (const uint32_t *)(q_order ? qperm.p : nullptr), nq, padded4, (float)alpha, (float)beta, floor4.p, gmb4.p);
+      DevBuf<unsigned char> PQ8, mask;
+      if (wide_pre) {
+        double eq = 0.0;
+        AS_TRY(PQ8.alloc(ctx, rotated_image_bytes(a_alloc4)));
+        AS_TRY(pack_rotated_from_z(ctx, Zq.p, q_order ? qperm.p : nullptr, nq, a_alloc4, PQ8.p, &eq));
+        const double E = std::max(eq, ix->rot_err), delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + 1e-4;
+        const uint32_t T2i = (n + 511) / 512, a_supers = a_alloc4 / 4;
+        AS_TRY(mask.alloc(ctx, (size_t)a_supers * 2 * T2i * 8));
+        AS_TRY(prefilter_i8_rect(ctx, ix->packed8, n, PQ8.p, a_supers, floor4.p, delta8, mask.p, "search_scan_prefilter"));
+      }
+      ctx->stats["search_scan_prefilter"] = wide_pre ? 1 : 0;
+      ctx->stats["search_scan_order"] = (q_by_pivots && wide_pre) ? 1 : 0;
+      AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQ.p, nq, floor4.p, gmb4.p, q_order ? qlam_pos.p : qlam.p, x_lam_h, (float)alpha,
+                                  (float)beta, cap, cnt.p, cand.p, "search_scan_f16", ix->scan_perm, q_order ? qperm.p : nullptr,
+                                  wide_pre ? mask.p : nullptr));
     } else {
       AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQ.p, nq, guess_pad.p, qlam.p, ix->lam32, (float)alpha, (float)beta, cap,
                               cnt.p, cand.p, unitc.p, "search_scan_bf16"));
@@ -2676,8 +2750,8 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
           AS_TRY(join_f16_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, x_lam_h, (float)alpha, (float)beta, cap2,
                                  cnt_b.p, cand_b.p, unitc.p, "search_scan_f16", ix->scan_perm));
         else
-          AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta,
-                                    cap2, cnt_b.p, cand_b.p, "search_scan_f16"));
+          AS_TRY(join_f16_wide_search(ctx, ix->packedh, n, d, PQb.p, nf, floor_b.p, gmb_b.p, qlam_b.p, x_lam_h, (float)alpha, (float)beta,
+                                    cap2, cnt_b.p, cand_b.p, "search_scan_f16", ix->scan_perm));
       } else {
         AS_TRY(join_bf16_search(ctx, ix->packed16, n, d, PQb.p, nf, guess_b.p, qlam_b.p, ix->lam32, (float)alpha, (float)beta, cap2,
                                 cnt_b.p, cand_b.p, unitc.p, "search_scan_bf16"));

@@ -109,12 +109,19 @@ __device__ __forceinline__ void append_w(uint32_t *__restrict__ cnt, uint32_t *_
 // tiles of THIS call's range [A0, A1) (a rank of a sharded build: its own positions) against every column; a pair the first pass
 // saw from a row super tile outside the range (a few pairs near the antipodal offset) is unknown here and contracted.
 __device__ __forceinline__ bool wide_pair_wanted(uint32_t sb, uint32_t w, uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_ob,
-                                                 const unsigned long long *__restrict__ mask, uint32_t mask_pitch, uint32_t *I_out, uint32_t *J_out) {
+                                                 const unsigned long long *__restrict__ mask, uint32_t mask_pitch, uint32_t *I_out, uint32_t *J_out,
+                                                 bool one_sided = false) {
   const uint32_t n_norm = (T2 - 1) / 2;
   const uint32_t ib = sb / n_ob, ob = sb - ib * n_ob;
   const uint32_t di = w & 3u, off = ob * 8u + (w >> 2);
   if (ib * 4u + di >= I_count) return false;
   const uint32_t I = I_begin + ib * 4u + di;
+  if (one_sided) {  // MODE 4 behind the rectangular first pass (prefilter_i8_rect): row super tile I of the batch against column super tile `off`
+    if (off >= T2) return false;
+    *I_out = I;
+    *J_out = off;
+    return !mask || (uint32_t)(mask[(size_t)(I >> 1) * mask_pitch + off] >> (32u * (I & 1u))) != 0u;
+  }
   const bool antipodal = (T2 % 2 == 0) && (I < T2 / 2) && T2 > 1;
   if (off >= 1 + n_norm + (antipodal ? 1u : 0u)) return false;
   uint32_t J = I + off;
@@ -147,13 +154,13 @@ __device__ __forceinline__ bool wide_pair_wanted(uint32_t sb, uint32_t w, uint32
 __global__ __launch_bounds__(256) void wide_unit_list_kernel(uint32_t T2, uint32_t I_begin, uint32_t I_count, uint32_t n_sb, uint32_t n_ob,
                                                              const unsigned long long *__restrict__ mask, uint32_t mask_pitch,
                                                              uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
-                                                             uint2 *__restrict__ list) {
+                                                             uint2 *__restrict__ list, int one_sided) {
   // counts given (offsets null): the number of wanted pairs of every rectangle; offsets given: the pairs themselves
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t sb0 = (blockIdx.x * 4 + wv) * 2; sb0 < n_sb; sb0 += gridDim.x * 8) {
     const uint32_t sb = sb0 + (lane >> 5), w = lane & 31;  // two rectangles per wave
     uint32_t I = 0, J = 0;
-    const bool want = sb < n_sb && wide_pair_wanted(sb, w, T2, I_begin, I_count, n_ob, mask, mask_pitch, &I, &J);
+    const bool want = sb < n_sb && wide_pair_wanted(sb, w, T2, I_begin, I_count, n_ob, mask, mask_pitch, &I, &J, one_sided != 0);
     const unsigned long long bal = __ballot(want);
     const uint32_t half = (uint32_t)((lane >> 5) ? (bal >> 32) : bal);
     if (offsets) {
@@ -219,6 +226,8 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
         const uint2 v = queue[e];
         if (perm && MODE == 0) append_w(cnt, cand, cap, perm[v.x], perm[v.y], queue_s[e]);
         else if (perm && MODE == 1) append_w(cnt, cand, cap, v.x, perm[v.y], queue_s[e]);
+        // (MODE 4: both images may be in an order of their own -- a_ids: position in the query image -> query, perm: item position -> item)
+        else if (MODE == 4) append_w(cnt, cand, cap, a_ids ? a_ids[v.x] : v.x, perm ? perm[v.y] : v.y, queue_s[e]);
         else append_w(cnt, cand, cap, v.x, v.y, queue_s[e]);
       }
     }
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
     for (;;) {
       const uint32_t v = atomicAdd(unit_counters + xcd, 1u);
       const uint32_t sb = xcd + 8u * (v >> 5), w = v & 31u;
-      if (MODE == 0 && unit_list) {  // the wanted pairs are listed: XCD x takes the x-th of every eight runs of 32 entries
+      if ((MODE == 0 || MODE == 4) && unit_list) {  // the wanted pairs are listed: XCD x takes the x-th of every eight runs of 32 entries
         const uint32_t e = sb * 32u + w;
         if (sb * 32u >= n_list) {
           s_next[0] = 0xFFFFFFFFu;
@@ -688,15 +697,16 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
   AS_HIP(ctx, hipMemsetAsync(counters.p, 0, 8 * sizeof(uint32_t), ctx->stream));
   DevBuf<uint2> unit_list;
   uint32_t n_list = 0;
-  if (MODE == 0 && mask && ctx->opt_join_unit_list) {  // the wanted pairs, listed (wide_unit_list_kernel)
-    const uint32_t n_norm = (T2 - 1) / 2, l_max = 1 + n_norm + 1, n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8, n_sb = n_ib * n_ob;
+  if ((MODE == 0 || MODE == 4) && mask && ctx->opt_join_unit_list) {  // the wanted pairs, listed (wide_unit_list_kernel)
+    const int one_sided = MODE == 4;
+    const uint32_t n_norm = (T2 - 1) / 2, l_max = one_sided ? T2 : 1 + n_norm + 1, n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8, n_sb = n_ib * n_ob;
     DevBuf<uint32_t> counts;
     DevBuf<uint64_t> offsets;
     AS_TRY(counts.alloc(ctx, n_sb));
     AS_TRY(offsets.alloc(ctx, (size_t)n_sb + 1));
     const unsigned grid = std::min<uint32_t>(cdiv(n_sb, 8), 256u * 8u);
     hipLaunchKernelGGL(wide_unit_list_kernel, dim3(grid), dim3(256), 0, ctx->stream, T2, I_begin, I_count, n_sb, n_ob, (const unsigned long long *)mask,
-                       mask_pitch, counts.p, (const uint64_t *)nullptr, (uint2 *)nullptr);
+                       mask_pitch, counts.p, (const uint64_t *)nullptr, (uint2 *)nullptr, one_sided);
     AS_HIP(ctx, hipGetLastError());
     AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, n_sb, offsets.p));
     uint64_t total = 0;
@@ -705,7 +715,7 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
     if (total && total < 0xFFFFFFFFull) {
       AS_TRY(unit_list.alloc(ctx, total));
       hipLaunchKernelGGL(wide_unit_list_kernel, dim3(grid), dim3(256), 0, ctx->stream, T2, I_begin, I_count, n_sb, n_ob, (const unsigned long long *)mask,
-                         mask_pitch, (uint32_t *)nullptr, (const uint64_t *)offsets.p, unit_list.p);
+                         mask_pitch, (uint32_t *)nullptr, (const uint64_t *)offsets.p, unit_list.p, one_sided);
       AS_HIP(ctx, hipGetLastError());
       n_list = (uint32_t)total;
     }
@@ -866,14 +876,18 @@ int search_thresholds_f16_wide(as_ctx *ctx, const void *PQ, uint32_t nq, uint32_
 // Lists, per query (position), every item whose approximate score reaches its guess.  P: f16 image of the n items; PQ: of
 // the nq queries; cos_floor = (g_q - beta) / alpha and g_minus_beta = g_q - beta by position (padded to the image: +inf);
 // q_lam / x_lam: f32 lambdas of the queries / the items (padded).  The contract of join_bf16_search (mfma_join_bf16.hip).
+// perm (item image position -> item), q_perm (query image position -> query): the images' orders, where they have one (lists come out
+// by query and hold items); mask: what prefilter_i8_rect found (a word per 512-query super tile and 256-item stage), the pairs of
+// super tiles none of whose bits is set are not contracted.
 int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PQ, uint32_t nq, const float *cos_floor,
                          const float *g_minus_beta, const float *q_lam, const float *x_lam, float alpha, float beta, uint32_t cap,
-                         uint32_t *cnt, uint32_t *cand, const char *prof_name) {
+                         uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm, const uint32_t *q_perm,
+                         const unsigned char *mask) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 search: dim not covered");
   const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
-  return launch_wide<4>(ctx, prof_name, P, PQ, nullptr, KS, T2, 0, (nq + kWS - 1) / kWS, nq, n, cos_floor, cap, cnt, cand, nullptr, x_lam,
-                        q_lam, g_minus_beta, alpha, beta);
+  return launch_wide<4>(ctx, prof_name, P, PQ, q_perm, KS, T2, 0, (nq + kWS - 1) / kWS, nq, n, cos_floor, cap, cnt, cand, nullptr, x_lam,
+                        q_lam, g_minus_beta, alpha, beta, perm, mask, T2);
 }
 
 }  // namespace asx

@@ -393,8 +393,16 @@ bool rotated_wide_supported(uint32_t d) { return d > 32 && d <= kMaxWide; }  // 
 // sr (a build sharded by rows; `rows` is not read, `norms` are those of ALL rows; rows up to 128 wide): the directions come from
 // the same strided sample -- every rank contributes the sample rows it holds, 16 MB in all -- each rank projects its OWN rows, and
 // the coordinates (128 B per row) and the per-block tail sums are all-gathered: the same Z, norms and tail as on one GPU.
+// Q_out (optional, device, 31 x rotated_wide_pitch(d) floats): the directions themselves, for rotated_project_wide on other rows.
+uint32_t rotated_wide_pitch(uint32_t d) { return (d + 63) / 64 * 64; }
+static uint32_t zproj_width(uint32_t pitch) {
+  uint32_t nv = pitch / 64;  // round up to an instantiated width
+  for (uint32_t c : {1u, 2u, 3u, 4u, 6u, 8u, 12u, 16u})
+    if (nv <= c) return c;
+  return nv;
+}
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out, const ShardedRows *sr) {
+                      double *tail_out, const ShardedRows *sr, float *Q_out) {
   if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
   if (sr && d > 128) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates of a sharded build: rows up to 128 wide");
   const uint32_t pitch = (d + 63) / 64 * 64;
@@ -532,12 +540,29 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   }
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
+  if (Q_out) AS_HIP(ctx, hipMemcpyAsync(Q_out, Qd.p, sizeof(float) * (size_t)kDirs * pitch, hipMemcpyDeviceToDevice, ctx->stream));
   std::vector<double> tp((size_t)z_grid * 4);
   AS_HIP(ctx, copy_d2h(ctx, tp.data(), tpart.p, tp.size() * sizeof(double)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
   double ts = 0.0;
   for (double v : tp) ts += v;
   *tail_out = ts / std::max<double>(1.0, (double)n);
+  return AS_OK;
+}
+
+// The rotated coordinates of OTHER rows (the queries of a search batch) in directions found before (Q: 31 x rotated_wide_pitch(d)
+// floats, rotated_rows_wide's Q_out): Z (n x 32: 31 coordinates and the norm of what they leave out of the unit row), znorm.
+int rotated_project_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const float *Q, double *Z, double *znorm) {
+  if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
+  if (n == 0) return AS_OK;
+  const uint32_t pitch = rotated_wide_pitch(d), nv = zproj_width(pitch);
+  const size_t lds = (size_t)kDirs * pitch * sizeof(float);
+  const uint32_t z_grid = std::min<uint32_t>((uint32_t)cdiv(n, 4), 256 * 8);
+  DevBuf<double> tpart;
+  AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
+  AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, Q, pitch, Z, tpart.p));
+  hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
+  AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 

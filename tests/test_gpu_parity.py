@@ -1306,6 +1306,50 @@ def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
         assert np.array_equal(sc1[j], osc), j
 
 
+@pytest.mark.parametrize("n,d,nq,k,alpha", [(70_000, 256, 2600, 10, 0.7), (66_000, 384, 2100, 5, 1.0), (70_000, 192, 300, 10, 0.4)])
+def test_search_scan_of_wide_items_on_an_ordered_index(ctx, n, d, nq, k, alpha):
+    """Items wider than 128 (round 5; src/core.rs:760-798 over configs[4]'s shape): an index that is searched again keeps an f16
+    image in an order found on the items' rotated coordinates (rotate_wide.hip), projects a batch of queries on the same 31
+    directions, orders a large batch the same way and runs the rectangular int8 first pass in front of the panelled scan, which
+    then contracts only the pairs of 256-row super tiles the first pass leaves (listed, mfma_join_f16_wide.hip).  First scan in the
+    order of the items, second and third with everything on, a batch too small to be ordered, the first pass switched off: the
+    same indices and scores bit for bit, and the oracle's."""
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=30, rank=5)
+    rng = np.random.default_rng(8)
+    lam = rng.random(n) * 0.4
+    lam[::5] = lam[2] + np.arange(len(lam[::5])) * 1e-9
+    qi = synth.query_indices(n, nq, seed=6)
+    Q = X[qi] * 1.03 + rng.normal(size=(nq, d)) * 0.01
+    lq = lam[qi] + rng.normal(size=nq) * 0.02
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    idx1, sc1 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan") == 1 and ctx.stat("search_scan_order") == 0 and ctx.stat("search_scan_prefilter") == 0
+    pairs_all = ((nq + 255) // 256) * (((n + 511) // 512) * 2)   # pairs of 256-row super tiles (queries x items) the scan would contract
+    idx2, sc2 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+    assert ctx.stat("search_scan_prefilter") == 1 and ctx.stat("search_scan_order") == (1 if nq >= 2048 else 0)
+    assert 0 < ctx.stat("search_scan_prefilter_blocks_flagged") < ctx.stat("search_scan_prefilter_blocks")
+    if nq >= 2048:
+        assert 0 < ctx.stat("search_scan_f16_pairs_listed") < pairs_all // 2   # most pairs of super tiles are never contracted
+    idx3, sc3 = asp.search_lambda_aware_batch(Q[::-1].copy(), lq[::-1].copy(), k, alpha)
+    assert np.array_equal(idx1, idx2) and np.array_equal(sc1, sc2)
+    assert np.array_equal(idx1, idx3[::-1]) and np.array_equal(sc1, sc3[::-1])
+    idx4, sc4 = asp.search_lambda_aware_batch(Q[:300], lq[:300], k, alpha)   # items ordered, queries as given
+    assert ctx.stat("search_scan_prefilter") == 1 and ctx.stat("search_scan_order") == 0
+    assert np.array_equal(idx1[:300], idx4) and np.array_equal(sc1[:300], sc4)
+    ctx.set_option("search_prefilter", 0)
+    try:
+        idx5, sc5 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+        assert ctx.stat("search_scan_prefilter") == 0
+    finally:
+        ctx.set_option("search_prefilter", 1)
+    assert np.array_equal(idx1, idx5) and np.array_equal(sc1, sc5)
+    for j in range(0, nq, max(1, nq // 20)):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], k, alpha)
+        assert np.array_equal(idx1[j], oi), j
+        assert np.array_equal(sc1[j], osc), j
+
+
 @pytest.mark.parametrize("rate,rank,cap", [(2, 1, 16), (1000, 1, 512), (32, 32, 64), (8, 2, 1024)])
 def test_search_scan_any_guess_is_exact(ctx, scan_on, rate, rank, cap):
     """The score guess only decides how many items are listed and how many queries fall through: guesses far too
