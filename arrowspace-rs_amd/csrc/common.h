@@ -90,6 +90,7 @@ struct as_ctx {
   int64_t opt_join_unit_list = 1;        // masked f16 pass: the units that hold a flagged stage listed first (0: every unit drawn and looked at)
   int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
   int64_t opt_join_theta_band_slack = 4; // thresholds of the own neighbourhood: taken instead of a sampled threshold that is higher by at most this many deltas (certified by construction)
+  int64_t opt_join_order_cover = 150;    // row order of the join: where more than this many per mille of the rows lie far from their pivot (cosine below 0.8 of the 90 % point), further pivots are drawn from those rows, 1 024 a round up to 4 096 (0 = never; row_order.hip)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)
@@ -108,7 +109,7 @@ struct as_ctx {
                                               // (measured at 1 M x 128: 0.7 % -> 5.5 ms better than the plain pass, 2.9 % -> 7 ms worse; break-even ~1.4 %)
   int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
                                          // groups (8.2 -> 1.7 ms at 1 M x 128), checked against the whole sample on 4096 rows
-  int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 1024)
+  int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 4096; beyond 1024 a pivot may stand for 240 rows)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
                                    // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off
   int64_t opt_join_prefilter_min_rows = 65536;

@@ -439,10 +439,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       AS_TRY(need_rows());
       AS_TRY(cluster_order(ctx, rows, norms, n, d, oj.perm_own.p));
     } else {
-      AS_TRY(oj.order_piv.alloc(ctx, (size_t)1024 * 128));
-      AS_TRY(oj.order_starts.alloc(ctx, 1025));
+      AS_TRY(oj.order_piv.alloc(ctx, (size_t)4096 * 128));
+      AS_TRY(oj.order_starts.alloc(ctx, 4097));
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
-                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np));
+                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np, 4096));
     }
     AS_TRY(oj.theta_pos.alloc(ctx, n));
     AS_TRY(oj.theta2_pos.alloc(ctx, n));

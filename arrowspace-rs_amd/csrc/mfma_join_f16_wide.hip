@@ -800,7 +800,7 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
                                      uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
-  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
+  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
   const uint32_t per = grouped_sample_rows_per_group(n, np), ns = np * per, row_supers = (n + kWS - 1) / kWS;
   if (per % kWS != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: group sample size");
   DevBuf<uint32_t> ids, ranges;

@@ -317,6 +317,7 @@ constexpr uint32_t kGroupNear = 16;
 // plain pass cost 116 ms of a 574 ms table)
 static uint32_t group_tiles(uint32_t n, uint32_t np, uint32_t rate = 32) {
   const uint64_t near_rows = ((uint64_t)n / std::max(1u, np)) * kGroupNear / rate;  // rows the near groups' samples hold
+  if (near_rows <= 192) return 2;  // (groups of fewer than 384 rows: more than 1 024 pivots, row_order.hip)
   if (near_rows <= 512) return 4;
   uint32_t t = (uint32_t)((near_rows * 3 / 2 + 127u) / 128u);
   t = (t + 1u) & ~1u;  // whole 256-row super tiles
@@ -326,7 +327,7 @@ static uint32_t group_tiles(uint32_t n, uint32_t np, uint32_t rate = 32) {
 // near[g][0 .. 16): the pivots most similar to pivot g (itself first).  piv: np x pitch floats.
 __global__ __launch_bounds__(256) void near_groups_kernel(const float *__restrict__ piv, uint32_t pitch, uint32_t dim, uint32_t np,
                                                           uint32_t *__restrict__ near) {
-  __shared__ float s_sim[1024];
+  __shared__ float s_sim[4096];
   __shared__ float s_best[256];
   __shared__ uint32_t s_at[256];
   const uint32_t g = blockIdx.x;
@@ -511,7 +512,7 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
                                 uint32_t pos_count, const void *row_image) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
-  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 1024) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
+  if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
   const uint32_t a_supers = (n + 255) / 256;
   const uint32_t rate = (uint32_t)std::max<int64_t>(2, std::min<int64_t>(ctx->opt_join_theta_rate, 32));  // (a power of two: api.hip)
   const uint32_t kGroupTiles = group_tiles(n, np, rate), kGroupSlots = kGroupTiles * 128u;

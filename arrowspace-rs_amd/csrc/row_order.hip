@@ -17,8 +17,10 @@ namespace asx {
 namespace {
 
 constexpr int kPivots = 256;      // pivots of an order found on the rows themselves
-constexpr int kPivotsMax = 1024;  // ... on 32 rotated coordinates (a quarter of the arithmetic per pivot: csrc/rotate_wide.hip), where
-                                  // 1024 instead of 256 pivots leave the f16 pass of the join half the blocks
+constexpr int kPivotsMax = 4096;  // ... on 32 rotated coordinates (a quarter of the arithmetic per pivot: csrc/rotate_wide.hip), where
+                                  // 1024 instead of 256 pivots leave the f16 pass of the join half the blocks; beyond 1024 (the
+                                  // assignment then runs in passes of 1024 pivots) where the data has more clusters than that
+constexpr int kPivotsPass = 1024;  // pivots of one pass of the assignment (64 KB of fragments in LDS) = the most of a second set
 constexpr int kPivotChunk = 32;  // pivots per LDS pass
 
 // unit pivots, f32, P x dp (dp = d rounded up to 4, zero padded)
@@ -75,8 +77,12 @@ __global__ __launch_bounds__(256) void assign_pivots_kernel(const double *__rest
 // pivots of its column, in pivot order with a strict '>', and the 32 columns meet at the end (lower pivot on equal values).
 typedef float ro_v16f32 __attribute__((ext_vector_type(16)));
 typedef _Float16 ro_f16x8 __attribute__((ext_vector_type(8)));
+// More than 1024 pivots: passes of up to 1024 (piv = the pass's first pivot, p_base its index), the best key of the passes so far
+// carried in key_io (flags: 1 = read it, 2 = write it, 4 = this pass is the last and writes the assignment); `bits` low bits of the
+// key hold the pivot (10 up to 1024 pivots -- the assignment round 4 measured with -- 12 beyond).
 __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *__restrict__ Z, uint32_t n, const float *__restrict__ piv,
-                                                                 uint32_t np, uint32_t *__restrict__ assign) {
+                                                                 uint32_t np, uint32_t *__restrict__ assign, uint32_t p_base = 0,
+                                                                 uint32_t bits = 10, int *__restrict__ key_io = nullptr, uint32_t flags = 4) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
   ro_f16x8 *s_b = reinterpret_cast<ro_f16x8 *>(ro_smem);  // [np / 32 tiles][2 k steps][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, lc = lane & 31, lh = lane >> 5;
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
   int best[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000u;
+  const uint32_t inv_max = (1u << bits) - 1u;
   ro_v16f32 zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -121,9 +128,9 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
     const ro_f16x8 b0 = s_b[(t * 2 + 0) * 64 + lane], b1 = s_b[(t * 2 + 1) * 64 + lane];
     ro_v16f32 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b0, zero, 0, 0, 0);
     x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b1, x, 0, 0, 0);
-    const uint32_t inv = 1023u - (t * 32 + (uint32_t)lc);
+    const uint32_t inv = inv_max - (p_base + t * 32 + (uint32_t)lc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) best[r] = max(best[r], (int)((__float_as_uint(x[r]) & 0xFFFFFC00u) | inv));
+    for (int r = 0; r < 16; ++r) best[r] = max(best[r], (int)((__float_as_uint(x[r]) & ~inv_max) | inv));
   }
   // accumulator register r of lane (lh, lc) = row 4 lh + (r & 3) + 8 (r >> 2) of the tile, column lc: the columns meet here
 #pragma unroll
@@ -131,9 +138,12 @@ __global__ __launch_bounds__(256) void assign_pivots_mfma_kernel(const double *_
     int bv = best[r];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) bv = max(bv, __shfl_xor(bv, o, 64));
-    const uint32_t ba = 1023u - ((uint32_t)bv & 1023u);
     const uint32_t row = row0 + 4 * lh + (r & 3) + 8 * (r >> 2);
-    if (lc == 0 && row < n) assign[row] = ba;
+    if (lc == 0 && row < n) {
+      if (flags & 1u) bv = max(bv, key_io[row]);
+      if (flags & 2u) key_io[row] = bv;
+      if (flags & 4u) assign[row] = inv_max - ((uint32_t)bv & inv_max);
+    }
   }
   }
 }
@@ -175,7 +185,7 @@ __global__ void scatter_f32_by_perm_kernel(const float *__restrict__ in, const u
 constexpr uint32_t kSubMax = 12288;
 __global__ __launch_bounds__(256) void order_sub_kernel(const uint32_t *__restrict__ group_start, const uint32_t *__restrict__ key_of_row, int np,
                                                         uint32_t *__restrict__ perm) {
-  __shared__ uint32_t s_cur[kPivotsMax];
+  __shared__ uint32_t s_cur[kPivotsPass];
   __shared__ uint32_t s_rows[kSubMax];
   __shared__ uint32_t s_key[256];
   __shared__ uint32_t s_scan[256];
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256) void order_sub_kernel(const uint32_t *__restri
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < len; i += 256) atomicAdd(&s_cur[key_of_row[perm[lo + i]]], 1u);  // (a sum: any order)
   __syncthreads();
-  // exclusive scan of the np counts (np <= 1024: four per thread)
+  // exclusive scan of the np counts (np <= kPivotsPass: four per thread)
   uint32_t mine[4], tot = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -244,9 +254,10 @@ __global__ void shift_ids_kernel(uint32_t *__restrict__ ids, uint32_t np, uint32
 // LDS -- a step is a list read, a look at the taken flags and a ballot (~0.1 us; the whole-set argmax per step it replaces took 2 us
 // of one workgroup's vector issue, 2.3 ms for 1 024 pivots).  Where all 32 of a pivot's list are taken the chain goes on at the
 // lowest pivot not yet taken: late in the walk, and any order is correct.
-constexpr uint32_t kChainList = 32;
-__global__ __launch_bounds__(256) void pivot_near_lists_kernel(const float *__restrict__ piv, uint32_t dpv, uint32_t np, uint16_t *__restrict__ lists) {
-  __shared__ float s_sim[1024];
+constexpr uint32_t kChainList = 32;  // (16 beyond 2 048 pivots: the lists of the walk stay in 128 KB of LDS)
+__global__ __launch_bounds__(256) void pivot_near_lists_kernel(const float *__restrict__ piv, uint32_t dpv, uint32_t np, uint16_t *__restrict__ lists,
+                                                               uint32_t list_len) {
+  __shared__ float s_sim[kPivotsMax];
   __shared__ float s_best[256];
   __shared__ uint32_t s_at[256];
   const uint32_t g = blockIdx.x;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void pivot_near_lists_kernel(const float *__re
     s_sim[h] = (h == g || !(a == a)) ? -__builtin_inff() : a;
   }
   __syncthreads();
-  for (uint32_t k = 0; k < kChainList; ++k) {
+  for (uint32_t k = 0; k < list_len; ++k) {
     float best = -__builtin_inff();
     uint32_t at = 0xFFFFFFFFu;
     for (uint32_t h = threadIdx.x; h < np; h += 256)
@@ -277,18 +288,19 @@ __global__ __launch_bounds__(256) void pivot_near_lists_kernel(const float *__re
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      lists[(size_t)g * kChainList + k] = s_at[0] == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)s_at[0];
+      lists[(size_t)g * list_len + k] = s_at[0] == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)s_at[0];
       if (s_at[0] != 0xFFFFFFFFu) s_sim[s_at[0]] = -__builtin_inff();
     }
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(64) void pivot_chain_kernel(const uint16_t *__restrict__ lists, uint32_t np, uint32_t *__restrict__ order) {
+__global__ __launch_bounds__(64) void pivot_chain_kernel(const uint16_t *__restrict__ lists, uint32_t np, uint32_t *__restrict__ order,
+                                                         uint32_t list_len) {
   extern __shared__ unsigned char smem[];
-  uint16_t *s_list = reinterpret_cast<uint16_t *>(smem);                       // np x 32
-  unsigned char *s_taken = smem + (size_t)np * kChainList * sizeof(uint16_t);  // np
+  uint16_t *s_list = reinterpret_cast<uint16_t *>(smem);                     // np x list_len
+  unsigned char *s_taken = smem + (size_t)np * list_len * sizeof(uint16_t);  // np
   const uint32_t lane = threadIdx.x;
-  for (uint32_t i = lane; i < np * kChainList; i += 64) s_list[i] = lists[i];
+  for (uint32_t i = lane; i < np * list_len; i += 64) s_list[i] = lists[i];
   for (uint32_t i = lane; i < np; i += 64) s_taken[i] = i == 0 ? 1 : 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(64) void pivot_chain_kernel(const uint16_t *__restr
   uint32_t cur = 0, low = 1;  // low: every pivot below it is taken
   if (lane == 0) order[0] = 0;
   for (uint32_t step = 1; step < np; ++step) {
-    const uint32_t c = lane < kChainList ? s_list[cur * kChainList + lane] : 0xFFFFu;
+    const uint32_t c = lane < list_len ? s_list[cur * list_len + lane] : 0xFFFFu;
     const bool ok = c < np && s_taken[c] == 0;
     const unsigned long long m = __ballot(ok);
     uint32_t nxt;
@@ -323,10 +335,92 @@ __global__ void pivot_permute_kernel(const float *__restrict__ piv, const uint32
 
 __global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids, uint32_t np) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < np) ids[p] = (uint32_t)(((uint64_t)p * n) / np + (((uint64_t)p * 2654435761ull) % (n / np)));
+  if (p >= np) return;
+  uint64_t off = (uint64_t)p * 2654435761ull;
+  if (np > (uint32_t)kPivotsPass) {  // (the multiplier alone walks n / np in a short cycle: with rows dealt round-robin over C clusters,
+    uint32_t x = p * 0x9E3779B9u;    // 4 096 pivots fell into a third of 2 048 clusters.  Up to 1 024 pivots it stays as measured.)
+    x ^= x >> 15;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    off = x;
+  }
+  ids[p] = (uint32_t)(((uint64_t)p * n) / np + off % (n / np));
 }
 
 }  // namespace
+
+// diagnostic (debug 524288): rows whose pivot on the matrix pipe lies more than 4e-3 (of the row's norm) below the f32 argmax
+__global__ void assign_check_kernel(const double *__restrict__ Z, uint32_t n, const float *__restrict__ piv, const uint32_t *__restrict__ a,
+                                    const uint32_t *__restrict__ b, uint32_t *__restrict__ bad) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  float sa = 0.f, sb = 0.f, nn = 0.f;
+  for (int k = 0; k < 32; ++k) {
+    const float x = (float)Z[(size_t)r * 32 + k];
+    sa = __builtin_fmaf(x, piv[(size_t)a[r] * 32 + k], sa);
+    sb = __builtin_fmaf(x, piv[(size_t)b[r] * 32 + k], sb);
+    nn = __builtin_fmaf(x, x, nn);
+  }
+  if (fabsf(sa - sb) > 4e-3f * sqrtf(nn)) atomicAdd(bad, 1u);
+}
+// ---- do the pivots cover the data? (round 5) ---------------------------------------------------------------------------------
+// A pivot is a sampled row; where the data has more clusters than pivots, the rows of a cluster without one go to whichever pivots of
+// OTHER clusters lie nearest -- a few of them, far from each other -- and the image no longer holds a row's neighbours together: the
+// grouped thresholds fail their check, the cone bound keeps every tile pair, and a 1 M x 128 table takes 40 ms instead of 17 (rank-32
+// mixture of 2 048 clusters under 1 024 pivots).  The assignment already knows: such a row's cosine with its pivot is far below that
+// of a row whose cluster has one.  So the cosines are binned, rows below 0.8 of the 90 % point count as not covered, and where they
+// are many the next 1 024 pivots are drawn FROM them (every round covers 1 - exp(-pivots / clusters left) of what is left, where
+// pivots drawn from all rows waste most of theirs on clusters that have one), up to 4 096 pivots or 240 rows per pivot.  Any set of
+// pivots gives a correct order; this one is a function of the rows alone.
+__device__ __forceinline__ float cover_cosine(const int *__restrict__ ka, uint32_t mask_a, const int *__restrict__ kb, uint32_t mask_b,
+                                              const double *__restrict__ norms, uint32_t r, bool *usable) {
+  const double nr = norms[r];
+  *usable = nr > 0.0 && nr < __builtin_inf();
+  float v = __uint_as_float((uint32_t)ka[r] & mask_a);
+  if (kb) v = fmaxf(v, __uint_as_float((uint32_t)kb[r] & mask_b));
+  return *usable ? v / (float)nr : 0.f;
+}
+// hist[256]: the cosine of every row with its pivot in steps of 1 / 256 (negative ones in bin 0); hist[256]: rows without a direction
+__global__ __launch_bounds__(256) void cover_hist_kernel(const int *__restrict__ ka, uint32_t mask_a, const int *__restrict__ kb, uint32_t mask_b,
+                                                         const double *__restrict__ norms, uint32_t n, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_h[257];
+  s_h[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_h[256] = 0;
+  __syncthreads();
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    bool usable;
+    const float c = cover_cosine(ka, mask_a, kb, mask_b, norms, r, &usable);
+    atomicAdd(&s_h[usable ? (uint32_t)fminf(255.f, fmaxf(0.f, c * 256.f)) : 256u], 1u);
+  }
+  __syncthreads();
+  if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+  if (threadIdx.x == 0 && s_h[256]) atomicAdd(&hist[256], s_h[256]);
+}
+__global__ void cover_flag_kernel(const int *__restrict__ ka, uint32_t mask_a, const int *__restrict__ kb, uint32_t mask_b,
+                                  const double *__restrict__ norms, uint32_t n, uint32_t below_bin, uint32_t *__restrict__ flag) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  bool usable;
+  const float c = cover_cosine(ka, mask_a, kb, mask_b, norms, r, &usable);
+  flag[r] = (usable && (uint32_t)fminf(255.f, fmaxf(0.f, c * 256.f)) < below_bin) ? 1u : 0u;
+}
+// ids[j], j < m: one of the rows not covered out of each of m even strata of their ranks (rank[n] = how many there are, >= m)
+__global__ void cover_draw_kernel(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint32_t n, uint32_t m,
+                                  uint32_t *__restrict__ ids) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || !flag[r]) return;
+  const uint64_t U = rank[n], k = rank[r], per = U / m;
+  const uint64_t j = min((uint64_t)m - 1, k / per);
+  uint32_t x = (uint32_t)j * 0x9E3779B9u;
+  x ^= x >> 15;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  if (k == j * per + x % per) ids[j] = r;
+}
 
 // perm[pos] = row: the rows grouped by the nearest (by cosine) of 256 GIVEN unit pivots (piv: 256 rows of pitch = dim rounded up
 // to 32, f32, device), stable within a pivot.  Any n >= 1, dim <= 128.
@@ -338,8 +432,10 @@ __global__ void order_group_starts_kernel(const uint64_t *__restrict__ offsets, 
 }
 
 // group_start (optional, np + 1 values, device): where the rows of every pivot begin in the order
+// keys_out (optional, n values; rotated coordinates only): every row's best (product, pivot) key of the assignment, key_value_bits()
+// of it being the product
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np,
-                    uint32_t *group_start, const float *piv_sub) {
+                    uint32_t *group_start, const float *piv_sub, int *keys_out) {
   if (d > 128 || n == 0 || np == 0 || np > (uint32_t)kPivotsMax || np % kPivotChunk != 0)
     return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
@@ -351,15 +447,36 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   AS_TRY(offsets.alloc(ctx, (size_t)np * n_blocks + 1));
 #define AS_ASSIGN(DPV)                                                                                                         \
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
-  const size_t lds_mfma = (size_t)(np / 32) * 2 * 64 * 16;
-  if (d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024) {  // the rotated coordinates: on the matrix pipe
-    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), lds_mfma, ctx->stream, rows, n, piv, np, assign.p);
+  const bool on_mfma = d == 32 && np % 32 == 0;
+  if (on_mfma && np <= (uint32_t)kPivotsPass) {  // the rotated coordinates: on the matrix pipe
+    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(np / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv, np,
+                       assign.p, 0u, 10u, keys_out, keys_out ? 6u : 4u);
+  } else if (on_mfma) {  // ... in passes of 1024 pivots, the best key so far carried from pass to pass
+    DevBuf<int> keys;
+    if (!keys_out) AS_TRY(keys.alloc(ctx, n));
+    for (uint32_t p0 = 0; p0 < np; p0 += kPivotsPass) {
+      const uint32_t pc = std::min<uint32_t>(kPivotsPass, np - p0);
+      const uint32_t flags = (p0 ? 1u : 0u) | (p0 + pc < np ? 2u : (keys_out ? 6u : 4u));
+      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(pc / 32) * 2 * 64 * 16, ctx->stream, rows, n,
+                         piv + (size_t)p0 * 32, pc, assign.p, p0, 12u, keys_out ? keys_out : keys.p, flags);
+    }
   } else
   switch (dpv / 32) {
     case 1: AS_ASSIGN(32); break;
     case 2: AS_ASSIGN(64); break;
     case 3: AS_ASSIGN(96); break;
     default: AS_ASSIGN(128); break;
+  }
+  if (on_mfma && (ctx->opt_debug & 524288)) {
+    DevBuf<uint32_t> ref, bad;
+    AS_TRY(ref.alloc(ctx, n));
+    AS_TRY(bad.alloc(ctx, 1));
+    AS_HIP(ctx, hipMemsetAsync(bad.p, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(assign_pivots_kernel<32>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, ref.p, (int)np);
+    hipLaunchKernelGGL(assign_check_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, piv, (const uint32_t *)assign.p, (const uint32_t *)ref.p, bad.p);
+    uint32_t h = 0;
+    AS_HIP(ctx, copy_d2h(ctx, &h, bad.p, sizeof(h)));
+    ctx->stats["knn_join_order_assign_off"] = h;
   }
 #undef AS_ASSIGN
   hipLaunchKernelGGL(order_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, counts.p, (int)np);
@@ -371,7 +488,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
   // of them, not a mix (1 M x 128, 4 096 clusters of 244 rows: the masked f16 pass 84 -> 50 ms).  (The second nearest pivot of
   // the FIRST set, kept by the same pass, was tried as the key: the top-2 bookkeeping made the assignment 2 ms slower.)
   DevBuf<uint32_t> assign_sub, starts_own;
-  if (piv_sub && d == 32 && np % 32 == 0 && lds_mfma <= 64 * 1024) {
+  if (piv_sub && on_mfma) {
     AS_TRY(assign_sub.alloc(ctx, n));
     uint32_t *gs = group_start;
     if (!gs) {
@@ -379,7 +496,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
       gs = starts_own.p;
     }
     // (opt_join_order_sub = the divisor of the second set's size: 1 = as many pivots as the first, 2 = half, ...)
-    const uint32_t np_sub = std::max<uint32_t>(32u, np / (uint32_t)std::max<int64_t>(1, ctx->opt_join_order_sub) / 32u * 32u);
+    const uint32_t np_sub = std::min<uint32_t>(kPivotsPass, std::max<uint32_t>(32u, np / (uint32_t)std::max<int64_t>(1, ctx->opt_join_order_sub) / 32u * 32u));
     hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 1024u)), dim3(256), (size_t)(np_sub / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv_sub,
                        np_sub, assign_sub.p);
     hipLaunchKernelGGL(order_group_starts_kernel, dim3(cdiv(np + 1, 256)), dim3(256), 0, ctx->stream, offsets.p, n_blocks, np, n, gs);
@@ -394,17 +511,18 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 
 // piv (np x dpv, 32 coordinates used) -> the same pivots in the order of the greedy chain
 static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
-  if (np > 1024 || np < 2) return AS_OK;
+  if (np > (uint32_t)kPivotsMax || np < 2) return AS_OK;
+  const uint32_t list_len = np > 2048 ? kChainList / 2 : kChainList;
   DevBuf<uint32_t> order;
   DevBuf<uint16_t> lists;
   DevBuf<float> tmp;
   AS_TRY(order.alloc(ctx, np));
-  AS_TRY(lists.alloc(ctx, (size_t)np * kChainList));
+  AS_TRY(lists.alloc(ctx, (size_t)np * list_len));
   AS_TRY(tmp.alloc(ctx, (size_t)np * dpv));
-  const size_t lds = (size_t)np * kChainList * sizeof(uint16_t) + np;
+  const size_t lds = (size_t)np * list_len * sizeof(uint16_t) + np;
   AS_HIP(ctx, hipFuncSetAttribute((const void *)pivot_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(pivot_near_lists_kernel, dim3(np), dim3(256), 0, ctx->stream, (const float *)piv, dpv, np, lists.p);
-  hipLaunchKernelGGL(pivot_chain_kernel, dim3(1), dim3(64), lds, ctx->stream, (const uint16_t *)lists.p, np, order.p);
+  hipLaunchKernelGGL(pivot_near_lists_kernel, dim3(np), dim3(256), 0, ctx->stream, (const float *)piv, dpv, np, lists.p, list_len);
+  hipLaunchKernelGGL(pivot_chain_kernel, dim3(1), dim3(64), lds, ctx->stream, (const uint16_t *)lists.p, np, order.p, list_len);
   hipLaunchKernelGGL(pivot_permute_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float *)piv, (const uint32_t *)order.p, dpv, tmp.p);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipMemcpyAsync(piv, tmp.p, sizeof(float) * (size_t)np * dpv, hipMemcpyDeviceToDevice, ctx->stream));
@@ -416,17 +534,22 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
 // n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 512 rows or more, 256 at least).  piv_out: n_pivots x 128.
 // group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
-                  uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out) {
+                  uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots) {
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   // (more than 256 only where a pivot still stands for 512 rows or more: the thresholds of the own join are taken against the
   // sampled rows -- one in 32 -- of a few groups)
-  const uint32_t np = std::min<uint32_t>(std::max<uint32_t>(n_pivots ? n_pivots : (uint32_t)kPivots, 32u) / 32u * 32u,
-                                         std::min<uint32_t>((uint32_t)kPivotsMax, std::max<uint32_t>((uint32_t)kPivots, n / 512u / 32u * 32u)));
+  // (beyond 1 024 -- asked for, or grown below where the data has more clusters than that -- a pivot may stand for 240 rows)
+  const uint32_t per_pivot = n_pivots > (uint32_t)kPivotsPass ? 240u : 512u;
+  uint32_t np = std::min<uint32_t>(std::max<uint32_t>(n_pivots ? n_pivots : (uint32_t)kPivots, 32u) / 32u * 32u,
+                                   std::min<uint32_t>((uint32_t)kPivotsMax, std::max<uint32_t>((uint32_t)kPivots, n / per_pivot / 32u * 32u)));
   ProfScope ps(ctx, "knn_join_row_order");
   const uint32_t dp = (d + 3) / 4 * 4;
+  // max_pivots: room in piv_out / group_start for a set grown where the first one does not cover the data (rotated coordinates only)
+  const uint32_t np_room = std::min<uint32_t>(std::min<uint32_t>(max_pivots, (uint32_t)kPivotsMax), n / 240u / 32u * 32u);
+  const bool may_grow = d == 32 && piv_out && np_room > np && np % 32 == 0 && ctx->opt_join_order_cover > 0;
   DevBuf<uint32_t> ids;
   DevBuf<float> piv_own;
-  AS_TRY(ids.alloc(ctx, np));
+  AS_TRY(ids.alloc(ctx, std::max(np, may_grow ? np_room : 0u)));
   float *piv = piv_out;
   if (!piv) {
     AS_TRY(piv_own.alloc(ctx, (size_t)np * 128));
@@ -436,12 +559,12 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   const uint32_t dpv = (dp + 31) / 32 * 32;
   hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
   AS_HIP(ctx, hipGetLastError());
-  if (np_out) *np_out = np;
   const bool chain = d == 32 && ctx->opt_join_order_chain;
   if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
   ctx->stats["knn_join_order_chain"] = chain ? 1 : 0;
   DevBuf<float> piv_sub;
-  if (d == 32 && ctx->opt_join_order_sub) {  // a second set of pivots (other rows), for the order inside the groups
+  const bool with_sub = d == 32 && ctx->opt_join_order_sub;
+  if (with_sub) {  // a second set of pivots (other rows), for the order inside the groups
     DevBuf<uint32_t> ids2;
     AS_TRY(ids2.alloc(ctx, np));
     AS_TRY(piv_sub.alloc(ctx, (size_t)np * 128));
@@ -450,9 +573,72 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids2.p, d, dpv, piv_sub.p);
     AS_HIP(ctx, hipGetLastError());
     if (chain && ctx->opt_join_order_chain > 1) AS_TRY(chain_pivots(ctx, piv_sub.p, np, dpv));  // (the order inside the groups too)
-    return order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, piv_sub.p);
   }
-  return order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, nullptr);
+  DevBuf<int> keys;
+  if (may_grow) AS_TRY(keys.alloc(ctx, n));
+  AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr));
+  ctx->stats["knn_join_order_pivots"] = np;
+  if (may_grow) {
+    // the first set's assignment is the one round 4 measured; what follows runs only where it leaves many rows far from their pivot
+    const uint32_t np_first = np, mask_a = np_first > (uint32_t)kPivotsPass ? ~4095u : ~1023u;
+    DevBuf<int> keys_new;
+    DevBuf<uint32_t> hist, flag;
+    DevBuf<uint64_t> rank;
+    AS_TRY(hist.alloc(ctx, 257));
+    uint32_t rounds = 0;
+    for (;;) {
+      AS_HIP(ctx, hipMemsetAsync(hist.p, 0, 257 * sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(cover_hist_kernel, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, (const int *)keys.p, mask_a,
+                         (const int *)(rounds ? keys_new.p : nullptr), ~4095u, norms, n, hist.p);
+      uint32_t hh[257];
+      AS_HIP(ctx, copy_d2h(ctx, hh, hist.p, sizeof(hh)));
+      const uint64_t usable = (uint64_t)n - hh[256];
+      uint64_t run = 0;
+      int q90 = 255;
+      for (int i = 0; i < 256; ++i) {
+        run += hh[i];
+        if (run * 10 >= usable * 9) {
+          q90 = i;
+          break;
+        }
+      }
+      const uint32_t below = (uint32_t)(q90 * 8 / 10);
+      uint64_t low = 0;
+      for (uint32_t i = 0; i < below; ++i) low += hh[i];
+      if (rounds == 0) ctx->stats["knn_join_order_cover_low_e3"] = (int64_t)(low * 1000 / std::max<uint64_t>(1, usable));
+      ctx->stats["knn_join_order_cover_left_e3"] = (int64_t)(low * 1000 / std::max<uint64_t>(1, usable));
+      // (the first round where a seventh of the rows lie far from their pivot, later ones down to 3 %)
+      const uint64_t trigger_e3 = rounds == 0 ? (uint64_t)ctx->opt_join_order_cover : 30u;
+      const uint32_t m = std::min<uint32_t>(kPivotsPass, np_room - np);
+      if (m == 0 || low * 1000 < trigger_e3 * usable || low < (uint64_t)m * 8) break;
+      if (rounds == 0) {
+        AS_TRY(keys_new.alloc(ctx, n));
+        AS_TRY(flag.alloc(ctx, n));
+        AS_TRY(rank.alloc(ctx, (size_t)n + 1));
+      }
+      hipLaunchKernelGGL(cover_flag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, mask_a,
+                         (const int *)(rounds ? keys_new.p : nullptr), ~4095u, norms, n, below, flag.p);
+      AS_TRY(exclusive_scan_u32_u64(ctx, flag.p, n, rank.p));
+      hipLaunchKernelGGL(cover_draw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)flag.p, (const uint64_t *)rank.p, n, m,
+                         ids.p + np);
+      hipLaunchKernelGGL(gather_pivots_kernel, dim3(m), dim3(128), 0, ctx->stream, rows, norms, (const uint32_t *)(ids.p + np), d, dpv,
+                         piv + (size_t)np * dpv);
+      // the new pivots against every row: the best of the drawn sets so far in keys_new (12 pivot bits; only its product is read)
+      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(m / 32) * 2 * 64 * 16, ctx->stream, rows, n,
+                         (const float *)(piv + (size_t)np * dpv), m, (uint32_t *)nullptr, np, 12u, keys_new.p, (rounds ? 1u : 0u) | 2u);
+      AS_HIP(ctx, hipGetLastError());
+      np += m;
+      ++rounds;
+    }
+    ctx->stats["knn_join_order_cover_rounds"] = rounds;
+    if (rounds) {  // the whole set along one chain, and the rows assigned again
+      if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr));
+      ctx->stats["knn_join_order_pivots"] = np;
+    }
+  }
+  if (np_out) *np_out = np;
+  return AS_OK;
 }
 
 // out[perm[i]] = in[i], i < n

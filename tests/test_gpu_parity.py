@@ -404,6 +404,38 @@ def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,clusters,rank", [(131072 + 300, 128, 700, 24), (300_000, 64, 1500, 32), (70144, 256, 420, 24)])
+def test_item_graph_row_order_draws_more_pivots_where_the_first_set_covers_too_little(ctx, n, d, clusters, rank):
+    """"join_order_cover" (round 5, row_order.hip): where many rows lie far from their pivot -- data with more clusters than the
+    first set has pivots -- further pivots are drawn from those rows (1 024 a round; beyond 1 024 pivots the assignment runs in
+    passes, the second case).  Any set of pivots gives a correct image order: the tables with and without the growth are the same
+    and the oracle's; the statistics say the growth ran, and that it left fewer rows uncovered.  Rows wider than 128 order their
+    image by the same code (third case)."""
+    X, _ = synth.mixture(n, d, seed=37, n_clusters=clusters, rank=rank)
+    X[40:48] = X[3]
+    X[11] = 0.0
+    gp = A.GraphParams(0.6, 16, 16, 2.0, 0.25)
+    try:
+        ctx.set_option("join_order_cover", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1
+        first = ctx.stat("knn_join_order_pivots")
+        ctx.set_option("join_order_cover", 150)
+        idx, dist = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join") == 1
+        rounds, grown = ctx.stat("knn_join_order_cover_rounds"), ctx.stat("knn_join_order_pivots")
+        low, left = ctx.stat("knn_join_order_cover_low_e3"), ctx.stat("knn_join_order_cover_left_e3")
+    finally:
+        ctx.set_option("join_order_cover", 150)
+    assert rounds >= 1 and grown > first and grown % 32 == 0 and grown <= n // 240, (first, grown, rounds)
+    assert low >= 150 and left < low, (low, left)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(n, size=96, replace=False))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n,d,topk,rectify", [(70000, 128, 16, 0), (66001, 128, 40, 1), (70144, 256, 16, 0), (40000, 128, 5, 0)])
 def test_item_graph_rerank_scores_every_pair_once(ctx, n, d, topk, rectify):
     """The exact re-rank of the joined lists (round 5, rerank_pairs.h): a pair two rows both keep is fetched and chained ONCE and
