@@ -566,6 +566,8 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "rerank_share") ctx->opt_rerank_share = value != 0;
   else if (n == "join_order_chain") ctx->opt_join_order_chain = value;
+  else if (n == "join_theta_far") ctx->opt_join_theta_far = value;
+  else if (n == "join_theta_dip_e3") ctx->opt_join_theta_dip_e3 = value;
   else if (n == "join_order_cover") ctx->opt_join_order_cover = value;
   else if (n == "join_theta_band_slack") ctx->opt_join_theta_band_slack = value;
   else if (n == "rerank_stream_cap") ctx->opt_rerank_stream_cap = std::max<int64_t>(0, value);

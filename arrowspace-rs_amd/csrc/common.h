@@ -91,6 +91,8 @@ struct as_ctx {
   int64_t opt_join_cone_second = 1;      // second pass of the join (f16 plane, 128 columns): behind the one-sided cone bound, the open rows in image order
   int64_t opt_join_theta_band_slack = 4; // thresholds of the own neighbourhood: taken instead of a sampled threshold that is higher by at most this many deltas (certified by construction)
   int64_t opt_join_order_cover = 150;    // row order of the join: where more than this many per mille of the rows lie far from their pivot (cosine below 0.8 of the 90 % point), further pivots are drawn from those rows, 1 024 a round up to 4 096 (0 = never; row_order.hip)
+  int64_t opt_join_theta_dip_e3 = 50;    // ... and of the rows whose threshold lies this far (per mille) below the median of their 64-position block (0 = off)
+  int64_t opt_join_theta_far = 1;        // thresholds of the rows far from their pivot (row_order.hip) from the whole sample, not their group's (0 = off)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)
@@ -538,6 +540,8 @@ struct OwnJoin {
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
   DevBuf<float> order_piv;                                    // the pivots of the order found on them (np x 32), where the rows of each begin
   DevBuf<uint32_t> order_starts;
+  DevBuf<uint32_t> far_pos;                                   // image positions of the rows far from their pivot (row_order.hip), whole 512s, ~0 beyond far_count
+  uint32_t far_count = 0;
   uint32_t order_np = 0, cap = 0;                             // pivots used; list slots per row
   bool wide_pre = false;       // the coordinates are in use (their directions carry the rows)
   bool reorder = false;        // the image is packed in the order perm_own (else: the rows as given)

@@ -442,7 +442,8 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       AS_TRY(oj.order_piv.alloc(ctx, (size_t)4096 * 128));
       AS_TRY(oj.order_starts.alloc(ctx, 4097));
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
-                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np, 4096));
+                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np, 4096,
+                           &oj.far_pos, &oj.far_count));
     }
     AS_TRY(oj.theta_pos.alloc(ctx, n));
     AS_TRY(oj.theta2_pos.alloc(ctx, n));
@@ -511,6 +512,64 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     if (gather) {
       AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));
       AS_TRY((*gather)(oj.theta2_pos.p, sizeof(float)));
+    }
+    // Rows far from their pivot (row_order.hip: rows of a cluster that got no pivot, scattered over the groups of other clusters):
+    // neither their group's sample nor their band holds their neighbours, their grouped threshold is that of a far cluster and each
+    // of them lists thousands of pairs (rank-128 mixture of 4 096 clusters: 0.4 % of the rows, and the f16 pass of the join visits
+    // five times the blocks).  They take the larger of it and the threshold against the WHOLE sample, like the rows of the check below.
+    // pos: image positions, whole 512s, ~0 where unused.
+    auto raise_from_whole_sample = [&](const uint32_t *pos, uint32_t room) -> int {
+      const uint32_t ns_far = std::max(256u, (n / 32u) & ~255u);
+      DevBuf<uint32_t> far_ids, far_sid;
+      DevBuf<float> far_t1, far_t2;
+      DevBuf<unsigned char> far_img;
+      AS_TRY(far_ids.alloc(ctx, room));
+      AS_TRY(far_sid.alloc(ctx, ns_far));
+      AS_TRY(far_t1.alloc(ctx, room));
+      AS_TRY(far_t2.alloc(ctx, room));
+      AS_TRY(far_img.alloc(ctx, packed_vecs_f16(room / kTileRows, d) * 16));
+      hipLaunchKernelGGL(rows_of_positions_kernel, dim3(cdiv(room, 256)), dim3(256), 0, ctx->stream, pos, (const uint32_t *)oj.perm_own.p, room, far_ids.p);
+      hipLaunchKernelGGL(theta_check_sample_kernel, dim3(cdiv(ns_far, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)oj.perm_own.p, n, ns_far, far_sid.p);
+      if (row_image) AS_TRY(pack_f16_from_image(ctx, row_image, n, far_ids.p, room, d, far_img.p, room / kTileRows));
+      else AS_TRY(pack_f16(ctx, rows, norms, far_ids.p, 0, room, d, far_img.p, room / kTileRows));
+      if (d > 128) AS_TRY(join_thresholds_f16_wide(ctx, rows, norms, d, far_img.p, 0, room, far_sid.p, ns_far, m, far_t1.p, m2, far_t2.p));
+      else AS_TRY(join_thresholds_f16(ctx, rows, norms, d, far_img.p, 0, room, far_sid.p, ns_far, m, far_t1.p, m2, far_t2.p, row_image, n));
+      hipLaunchKernelGGL(theta_raise_kernel, dim3(cdiv(room, 256)), dim3(256), 0, ctx->stream, oj.theta_pos.p, pos, (const float *)far_t1.p, room);
+      hipLaunchKernelGGL(theta_raise_kernel, dim3(cdiv(room, 256)), dim3(256), 0, ctx->stream, oj.theta2_pos.p, pos, (const float *)far_t2.p, room);
+      AS_HIP(ctx, hipGetLastError());
+      return AS_OK;
+    };
+    if (oj.far_count && ctx->opt_join_theta_far) {
+      AS_TRY(raise_from_whole_sample(oj.far_pos.p, (oj.far_count + 511u) / 512u * 512u));
+      ctx->stats["knn_join_theta_far_rows"] = oj.far_count;
+    } else {
+      ctx->stats["knn_join_theta_far_rows"] = 0;
+    }
+    // ... and so do the rows whose threshold lies far below those around them: in an image ordered by direction the 64 positions of
+    // a block are rows of one neighbourhood with thresholds alike, and one that sits "join_theta_dip_e3" (50: 0.05) below the
+    // block's median is a row whose neighbours the sample of its group missed -- whatever the reason.  A row flagged without need
+    // costs its share of one more pass and keeps its threshold.
+    ctx->stats["knn_join_theta_dip_rows"] = 0;
+    // (rows of 128 columns or fewer: the panelled pass of wider rows takes 3 ms for the 700 rows this finds at 1 M x 768 and the lists
+    // of those rows stay as long)
+    if (ctx->opt_join_theta_dip_e3 > 0 && ctx->opt_join_theta_far && d <= 128) {
+      DevBuf<uint32_t> dflag, dpos;
+      DevBuf<uint64_t> drank;
+      AS_TRY(dflag.alloc(ctx, n));
+      AS_TRY(drank.alloc(ctx, (size_t)n + 1));
+      hipLaunchKernelGGL(theta_dip_flag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const float *)oj.theta_pos.p, n,
+                         (float)ctx->opt_join_theta_dip_e3 * 1e-3f, dflag.p);
+      AS_TRY(exclusive_scan_u32_u64(ctx, dflag.p, n, drank.p));
+      uint64_t h_dip = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h_dip, drank.p + n, sizeof(h_dip)));
+      ctx->stats["knn_join_theta_dip_rows"] = (int64_t)h_dip;
+      if (h_dip > 0 && h_dip * 100 <= (uint64_t)n * 8) {
+        const uint32_t room = (uint32_t)((h_dip + 511) / 512 * 512);
+        AS_TRY(dpos.alloc(ctx, room));
+        AS_HIP(ctx, hipMemsetAsync(dpos.p, 0xFF, sizeof(uint32_t) * room, ctx->stream));
+        hipLaunchKernelGGL(list_flagged_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)dflag.p, (const uint64_t *)drank.p, n, room, dpos.p);
+        AS_TRY(raise_from_whole_sample(dpos.p, room));
+      }
     }
     if (ctx->opt_debug & 65536) {  // diagnostic: a checksum of the thresholds (are they the same from run to run?)
       DevBuf<unsigned long long> cs;

@@ -389,6 +389,35 @@ static __global__ void theta_check_count_kernel(const float *__restrict__ theta_
   if (i < count && theta_pos[(size_t)i * stride] < t_full[i] - slack) atomicAdd(bad, 1u);
 }
 
+// ids[i] = perm[pos[i]] (~0 stays ~0); then theta_pos[pos[i]] = max(theta_pos[pos[i]], t[i])
+static __global__ void rows_of_positions_kernel(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ perm, uint32_t count, uint32_t *__restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) ids[i] = pos[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : perm[pos[i]];
+}
+static __global__ void theta_raise_kernel(float *__restrict__ theta_pos, const uint32_t *__restrict__ pos, const float *__restrict__ t, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count && pos[i] != 0xFFFFFFFFu && t[i] > theta_pos[pos[i]] && t[i] < __builtin_inff()) theta_pos[pos[i]] = t[i];
+}
+// flag[p] = 1 where theta[p] lies more than `dip` below the median of the 64 positions of its block (one wave a block)
+static __global__ __launch_bounds__(256) void theta_dip_flag_kernel(const float *__restrict__ theta, uint32_t n, float dip, uint32_t *__restrict__ flag) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const float t = p < n ? theta[p] : __builtin_inff();
+  uint32_t below = 0;  // values of the block below mine (ties by lane): my rank
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t l = 0; l < 64; ++l) {
+    const float o = __shfl(t, (int)l, 64);
+    below += (o < t || (o == t && l < lane)) ? 1u : 0u;
+  }
+  // the value of rank 31 among the finite ones is close enough to a median; infinite thresholds (rows without a direction) rank last
+  const unsigned long long at = __ballot(below == 31u);
+  const float med = __shfl(t, at ? (int)__builtin_ctzll(at) : 0, 64);
+  if (p < n) flag[p] = (t == t && med < __builtin_inff() && t < med - dip) ? 1u : 0u;
+}
+static __global__ void list_flagged_kernel(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint32_t n, uint32_t room,
+                                           uint32_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && flag[p] && rank[p] < room) out[rank[p]] = p;
+}
 static __global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) inv[perm[i]] = i;
@@ -831,7 +860,8 @@ uint64_t prefilter_mask_bytes(uint32_t n, uint32_t I_count);
 int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t I_begin,
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
-                  uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr, uint32_t max_pivots = 0);
+                  uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr, uint32_t max_pivots = 0,
+                  DevBuf<uint32_t> *far_pos = nullptr, uint32_t *far_count = nullptr);
 int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm);  // row_order.hip
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
                     uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr);

@@ -351,6 +351,64 @@ __global__ void order_pivot_ids_kernel(uint32_t n, uint32_t *__restrict__ ids, u
 
 }  // namespace
 
+// Of the rows drawn in a round (unit vectors, c x pitch), those that lie within `cut` of an EARLIER one are dropped -- two rows of one
+// cluster would spend two pivots on it -- and the first `want` of the others (their count rounded down to whole 32s) are kept, in
+// the order they were drawn.  Twice as many rows are drawn as pivots are wanted: 1 024 draws into 3 000 clusters hit 870 different
+// ones, 2 048 draws give the 1 024.  keep[j] then out[..] / n_out.
+__global__ __launch_bounds__(256) void cover_distinct_kernel(const float *__restrict__ cand, uint32_t pitch, uint32_t c, float cut,
+                                                             uint32_t *__restrict__ keep) {
+  __shared__ int s_near;
+  const uint32_t j = blockIdx.x;
+  if (threadIdx.x == 0) s_near = 0;
+  __syncthreads();
+  float x[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) x[k] = cand[(size_t)j * pitch + k];
+  bool near = false;
+  for (uint32_t i = threadIdx.x; i < j && i < c; i += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a = __builtin_fmaf(x[k], cand[(size_t)i * pitch + k], a);
+    near |= a > cut;
+  }
+  if (near) s_near = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) keep[j] = s_near ? 0u : 1u;
+}
+__global__ __launch_bounds__(1024) void cover_keep_kernel(const float *__restrict__ cand, uint32_t pitch, uint32_t c, const uint32_t *__restrict__ keep,
+                                                          uint32_t want, float *__restrict__ out, uint32_t *__restrict__ n_out) {
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  uint32_t total = 0;
+  for (uint32_t j0 = 0; j0 < c; j0 += 1024) {  // first the count, so that the number kept is whole 32s
+    const uint32_t j = j0 + threadIdx.x;
+    const uint32_t k = j < c ? keep[j] : 0u;
+    total += __syncthreads_count(k != 0);
+  }
+  const uint32_t take = min(want, total) / 32u * 32u;
+  for (uint32_t j0 = 0; j0 < c; j0 += 1024) {
+    const uint32_t j = j0 + threadIdx.x;
+    const uint32_t k = j < c ? keep[j] : 0u;
+    s_scan[threadIdx.x] = k;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const uint32_t v = threadIdx.x >= (uint32_t)o ? s_scan[threadIdx.x - o] : 0u;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const uint32_t at = s_base + s_scan[threadIdx.x] - k;
+    if (k && at < take)
+      for (uint32_t q = 0; q < pitch; ++q) out[(size_t)at * pitch + q] = cand[(size_t)j * pitch + q];
+    __syncthreads();
+    if (threadIdx.x == 1023) s_base += s_scan[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = take;
+}
+
 // diagnostic (debug 524288): rows whose pivot on the matrix pipe lies more than 4e-3 (of the row's norm) below the f32 argmax
 __global__ void assign_check_kernel(const double *__restrict__ Z, uint32_t n, const float *__restrict__ piv, const uint32_t *__restrict__ a,
                                     const uint32_t *__restrict__ b, uint32_t *__restrict__ bad) {
@@ -405,6 +463,20 @@ __global__ void cover_flag_kernel(const int *__restrict__ ka, uint32_t mask_a, c
   bool usable;
   const float c = cover_cosine(ka, mask_a, kb, mask_b, norms, r, &usable);
   flag[r] = (usable && (uint32_t)fminf(255.f, fmaxf(0.f, c * 256.f)) < below_bin) ? 1u : 0u;
+}
+// the same by image position (perm[p] = row): flag[p]; then the flagged positions in ascending order
+__global__ void cover_flag_pos_kernel(const int *__restrict__ ka, uint32_t mask_a, const double *__restrict__ norms, const uint32_t *__restrict__ perm,
+                                      uint32_t n, uint32_t below_bin, uint32_t *__restrict__ flag) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  bool usable;
+  const float c = cover_cosine(ka, mask_a, nullptr, 0u, norms, perm[p], &usable);
+  flag[p] = (usable && (uint32_t)fminf(255.f, fmaxf(0.f, c * 256.f)) < below_bin) ? 1u : 0u;
+}
+__global__ void cover_list_pos_kernel(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint32_t n, uint32_t room,
+                                      uint32_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && flag[p] && rank[p] < room) out[rank[p]] = p;
 }
 // ids[j], j < m: one of the rows not covered out of each of m even strata of their ranks (rank[n] = how many there are, >= m)
 __global__ void cover_draw_kernel(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint32_t n, uint32_t m,
@@ -534,7 +606,9 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
 // n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 512 rows or more, 256 at least).  piv_out: n_pivots x 128.
 // group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
-                  uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots) {
+                  uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots, DevBuf<uint32_t> *far_pos,
+                  uint32_t *far_count) {
+  if (far_count) *far_count = 0;
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   // (more than 256 only where a pivot still stands for 512 rows or more: the thresholds of the own join are taken against the
   // sampled rows -- one in 32 -- of a few groups)
@@ -549,7 +623,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   const bool may_grow = d == 32 && piv_out && np_room > np && np % 32 == 0 && ctx->opt_join_order_cover > 0;
   DevBuf<uint32_t> ids;
   DevBuf<float> piv_own;
-  AS_TRY(ids.alloc(ctx, std::max(np, may_grow ? np_room : 0u)));
+  AS_TRY(ids.alloc(ctx, np));
   float *piv = piv_out;
   if (!piv) {
     AS_TRY(piv_own.alloc(ctx, (size_t)np * 128));
@@ -582,10 +656,11 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     // the first set's assignment is the one round 4 measured; what follows runs only where it leaves many rows far from their pivot
     const uint32_t np_first = np, mask_a = np_first > (uint32_t)kPivotsPass ? ~4095u : ~1023u;
     DevBuf<int> keys_new;
-    DevBuf<uint32_t> hist, flag;
+    DevBuf<uint32_t> hist, flag, cand_ids, keep;
     DevBuf<uint64_t> rank;
+    DevBuf<float> cand;
     AS_TRY(hist.alloc(ctx, 257));
-    uint32_t rounds = 0;
+    uint32_t rounds = 0, last_below = 0;
     for (;;) {
       AS_HIP(ctx, hipMemsetAsync(hist.p, 0, 257 * sizeof(uint32_t), ctx->stream));
       hipLaunchKernelGGL(cover_hist_kernel, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, (const int *)keys.p, mask_a,
@@ -605,24 +680,35 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
       const uint32_t below = (uint32_t)(q90 * 8 / 10);
       uint64_t low = 0;
       for (uint32_t i = 0; i < below; ++i) low += hh[i];
+      last_below = low ? below : 0u;
       if (rounds == 0) ctx->stats["knn_join_order_cover_low_e3"] = (int64_t)(low * 1000 / std::max<uint64_t>(1, usable));
       ctx->stats["knn_join_order_cover_left_e3"] = (int64_t)(low * 1000 / std::max<uint64_t>(1, usable));
       // (the first round where a seventh of the rows lie far from their pivot, later ones down to 3 %)
       const uint64_t trigger_e3 = rounds == 0 ? (uint64_t)ctx->opt_join_order_cover : 30u;
-      const uint32_t m = std::min<uint32_t>(kPivotsPass, np_room - np);
-      if (m == 0 || low * 1000 < trigger_e3 * usable || low < (uint64_t)m * 8) break;
+      const uint32_t want = std::min<uint32_t>(kPivotsPass, np_room - np);
+      // (twice as many rows drawn as pivots wanted, fewer where few rows are left: 8 rows or more per draw)
+      const uint32_t draws = (uint32_t)std::min<uint64_t>(2 * (uint64_t)want, low / 8);
+      if (want == 0 || low * 1000 < trigger_e3 * usable || draws < 32) break;
       if (rounds == 0) {
         AS_TRY(keys_new.alloc(ctx, n));
         AS_TRY(flag.alloc(ctx, n));
         AS_TRY(rank.alloc(ctx, (size_t)n + 1));
+        AS_TRY(cand.alloc(ctx, (size_t)2 * kPivotsPass * dpv));
+        AS_TRY(cand_ids.alloc(ctx, 2 * kPivotsPass));
+        AS_TRY(keep.alloc(ctx, 2 * kPivotsPass + 1));
       }
       hipLaunchKernelGGL(cover_flag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, mask_a,
                          (const int *)(rounds ? keys_new.p : nullptr), ~4095u, norms, n, below, flag.p);
       AS_TRY(exclusive_scan_u32_u64(ctx, flag.p, n, rank.p));
-      hipLaunchKernelGGL(cover_draw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)flag.p, (const uint64_t *)rank.p, n, m,
-                         ids.p + np);
-      hipLaunchKernelGGL(gather_pivots_kernel, dim3(m), dim3(128), 0, ctx->stream, rows, norms, (const uint32_t *)(ids.p + np), d, dpv,
-                         piv + (size_t)np * dpv);
+      hipLaunchKernelGGL(cover_draw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)flag.p, (const uint64_t *)rank.p, n, draws,
+                         cand_ids.p);
+      hipLaunchKernelGGL(gather_pivots_kernel, dim3(draws), dim3(128), 0, ctx->stream, rows, norms, (const uint32_t *)cand_ids.p, d, dpv, cand.p);
+      hipLaunchKernelGGL(cover_distinct_kernel, dim3(draws), dim3(256), 0, ctx->stream, (const float *)cand.p, dpv, draws, (float)below * (1.f / 256.f), keep.p);
+      hipLaunchKernelGGL(cover_keep_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float *)cand.p, dpv, draws, (const uint32_t *)keep.p, want,
+                         piv + (size_t)np * dpv, keep.p + 2 * kPivotsPass);
+      uint32_t m = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &m, keep.p + 2 * kPivotsPass, sizeof(m)));
+      if (m == 0) break;
       // the new pivots against every row: the best of the drawn sets so far in keys_new (12 pivot bits; only its product is read)
       hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(m / 32) * 2 * 64 * 16, ctx->stream, rows, n,
                          (const float *)(piv + (size_t)np * dpv), m, (uint32_t *)nullptr, np, 12u, keys_new.p, (rounds ? 1u : 0u) | 2u);
@@ -633,8 +719,30 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     ctx->stats["knn_join_order_cover_rounds"] = rounds;
     if (rounds) {  // the whole set along one chain, and the rows assigned again
       if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
-      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr));
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p));
       ctx->stats["knn_join_order_pivots"] = np;
+    }
+    // The rows still far from their pivot, by image position: their neighbours are not where the image order puts a row's
+    // neighbours, so the caller takes their thresholds from the whole sample (own_join_prepare).  (The cut of the last count.)
+    if (far_pos && far_count && last_below > 0) {
+      const uint32_t mask_f = np > (uint32_t)kPivotsPass ? ~4095u : ~1023u;
+      if (!flag.p) AS_TRY(flag.alloc(ctx, n));
+      if (!rank.p) AS_TRY(rank.alloc(ctx, (size_t)n + 1));
+      hipLaunchKernelGGL(cover_flag_pos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, mask_f, norms, (const uint32_t *)perm, n,
+                         last_below, flag.p);
+      AS_TRY(exclusive_scan_u32_u64(ctx, flag.p, n, rank.p));
+      uint64_t h_far = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h_far, rank.p + n, sizeof(h_far)));
+      ctx->stats["knn_join_order_far_rows"] = (int64_t)h_far;
+      if (h_far > 0 && h_far * 100 <= (uint64_t)n * 8) {  // (more than 8 %: the check of the thresholds decides for all rows)
+        const uint32_t room = (uint32_t)((h_far + 511) / 512 * 512);
+        AS_TRY(far_pos->alloc(ctx, room));
+        AS_HIP(ctx, hipMemsetAsync(far_pos->p, 0xFF, sizeof(uint32_t) * room, ctx->stream));
+        hipLaunchKernelGGL(cover_list_pos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)flag.p, (const uint64_t *)rank.p, n, room,
+                           far_pos->p);
+        AS_HIP(ctx, hipGetLastError());
+        *far_count = (uint32_t)h_far;
+      }
     }
   }
   if (np_out) *np_out = np;
