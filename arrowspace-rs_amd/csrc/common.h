@@ -42,7 +42,7 @@ struct as_ctx {
   std::string err;
   void *pinned = nullptr;  // staging buffer for host <-> device transfers
   std::multimap<size_t, void *> free_blocks;  // workspace cache (capacity -> block)
-  // Options (as_ctx_set_option).  include/arrowspace_hip.h documents the 33 SUPPORTED ones; the others here are switches for the tests
+  // Options (as_ctx_set_option).  include/arrowspace_hip.h documents the 35 SUPPORTED ones; the others here are switches for the tests
   // (forms of one stage that must agree bit for bit: lambda_v2 / lambda_v3 / lambda_wide, join_bf16, second_pass_f16, search_scan_f16,
   // assembly_lanes, nearest_mfma, cluster_on_device, join_theta_parts, join_unit_list, sharded_own_rows, search_stream_quick), failure
   // injection and capacity hooks (sharded_inject_failure, rerank_stream_cap), and sizes kept adjustable for measurements (cand_slack,

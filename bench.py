@@ -190,7 +190,8 @@ def config_leg(A, D, synth, ctx, dev, n, d, nq, taumode, k, alpha, rank=8, clust
 
     path_keys = ("knn_join", "knn_join_prefilter", "knn_join_prefilter_rotated", "knn_join_row_order", "knn_join_theta_grouped",
                  "knn_join_cone_tiles", "knn_join_cone_tiles_kept_e6", "knn_join_prefilter_tail_e6", "knn_uncertified_rows",
-                 "knn_uncertified_rows_stage1a", "knn_join_candidates", "knn_rerank_pairs_scored")
+                 "knn_uncertified_rows_stage1a", "knn_join_order_pivots", "knn_join_order_cover_rounds", "knn_join_order_cover_low_e3",
+                 "knn_join_theta_far_rows", "knn_join_theta_dip_rows", "knn_join_candidates", "knn_rerank_pairs_scored")
     path = {}
 
     def step():
@@ -227,7 +228,7 @@ def config_leg(A, D, synth, ctx, dev, n, d, nq, taumode, k, alpha, rank=8, clust
            "item_graph_nnz": int(gl.matrix.nnz() if hasattr(gl, "matrix") else gl.nnz()),
            "dominant_stage": {"name": top[0][1], "ms": top[0][0]} if top else None,
            "top_stages_ms": {kk: v for v, kk in top},
-           "path": {kk: path[kk] for kk in path_keys[:10]},
+           "path": {kk: path[kk] for kk in path_keys[:15]},
            "candidates_per_row": path["knn_join_candidates"] / max(1, n),
            "rows_fetched_per_row": path["knn_rerank_pairs_scored"] / max(1, n)}
     if Q is not None:
@@ -538,11 +539,17 @@ def main():
                                                 "tile_pairs_kept": leg["path"]["knn_join_cone_tiles_kept_e6"] * 1e-6,
                                                 "grouped_thresholds": leg["path"]["knn_join_theta_grouped"],
                                                 "rotated_first_pass": leg["path"]["knn_join_prefilter_rotated"],
-                                                "energy_outside_the_31_directions": leg["path"]["knn_join_prefilter_tail_e6"] * 1e-6}})
+                                                "energy_outside_the_31_directions": leg["path"]["knn_join_prefilter_tail_e6"] * 1e-6,
+                                                "pivots_of_the_row_order": leg["path"]["knn_join_order_pivots"],
+                                                "rounds_of_further_pivots": leg["path"]["knn_join_order_cover_rounds"],
+                                                "rows_far_from_the_first_pivots": leg["path"]["knn_join_order_cover_low_e3"] * 1e-3,
+                                                "rows_given_whole_sample_thresholds": leg["path"]["knn_join_theta_far_rows"]
+                                                + leg["path"]["knn_join_theta_dip_rows"]}})
                 except Exception as e:  # noqa: BLE001
                     sweep.append({"rank": rk, "clusters": cl, "error": repr(e)})
-            extra["geometry_sweep"] = {"what": "item graph of 1 M x 128 mixtures (noise 0.3 sqrt(rank) per coordinate) of growing rank: where the "
-                                               "cone bound and the grouped thresholds switch themselves off, and what the build costs then",
+            extra["geometry_sweep"] = {"what": "item graph of 1 M x 128 mixtures (noise 0.3 sqrt(rank) per coordinate) of growing rank and cluster count: "
+                                               "which bounds stay on, how many pivots the row order ends up with (it draws more where the first "
+                                               "1 024 leave rows far from any), and what the build costs",
                                        "legs": sweep}
     if rank == 0 and world == 1 and not args.no_spmm_leg:
         # ---- the item-graph lambda: the feature columns as signals over the N x N Laplacian the build returns ------------

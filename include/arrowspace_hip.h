@@ -87,7 +87,7 @@ const char *as_status_message(int status); /* the reference's panic text for a s
  * sync); host outputs are always complete on return. */
 int as_ctx_set_stream(as_ctx *ctx, void *hip_stream);
 int as_ctx_synchronize(as_ctx *ctx);
-/* Options.  None of them changes a result -- only which stage produces it; defaults in parentheses.  The 33 below are the supported
+/* Options.  None of them changes a result -- only which stage produces it; defaults in parentheses.  The 35 below are the supported
  * ones; csrc/common.h (struct as_ctx) lists, next to these, the switches that exist for the tests and for measurements only (forms
  * of one stage that must agree bit for bit, failure injection, sample sizes): they are accepted here too but are no interface.
  *  stages
@@ -102,11 +102,15 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               32-wide image (31 dominant directions + the tail norm), 2 = full-width image always, 3 = rotated always, 0 = off
  *   "join_row_order" (1)        rows grouped by direction in the operand image: "join_order_pivots" (1024) pivots on the rotated coordinates,
  *                               "join_order_sub" (4): inside a group by a second set of pivots / 4, "join_order_chain" (1): the groups laid
- *                               out along a greedy chain of similar pivots (neighbours of a row end up near it in the image)
+ *                               out along a greedy chain of similar pivots (neighbours of a row end up near it in the image);
+ *                               "join_order_cover" (150): where more than this many per mille of the rows lie far from their pivot (data
+ *                               with more clusters than pivots) further pivots are drawn from those rows, up to 4096 (0 = never)
  *   "join_theta_grouped" (1)    thresholds against the sampled rows of the 16 pivot groups nearest to a row's own (checked against the plain sample)
  *   "join_theta_band" (2)       thresholds raised to what a row's own neighbourhood in the ordered image certifies (512-position super tiles
  *                               on either side; 0 = off); "join_theta_band_slack" (4): the certified cut is also taken where the sampled
  *                               threshold is higher by at most this many rounding bounds
+ *   "join_theta_far" (1)        rows far from their pivot, and rows whose threshold lies 0.05 below the median of their 64-position block,
+ *                               take the larger of it and the threshold against the whole sample
  *   "join_cone_tiles" (1), "join_cone_second" (1)   cone bound on pairs of 128-position tiles in front of the first pass / its one-sided
  *                               form in front of the second pass
  *  the exact re-rank
@@ -379,9 +383,7 @@ int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint6
  * the CSR is streamed once for all signals and each stored pair fetches the two item ROWS (algorithmic bytes nnz * 16 +
  * n_items * n_features * 8).  as_compute_taumode itself takes this route for signals of "signal_min_len" (9000) values or more.
  * Options: "signal_sym" (1: a bitwise symmetric L is streamed as its upper triangle), "signal_order" (1: rows visited in the
- * order attached to L; "signal_order_refine" 1: that order's blocks of 1024 positions chained by the entries between them, 3 ms
- * once per graph for a tenth off every pass), "signal_chunk_rows" (16) / "signal_waves" (0 = one chunk per wave): the interleave of the graph pass; they take
- * effect when the graph's record stream is next built (as_csr_set_order drops it). */
+ * order attached to L); they take effect when the graph's record stream is next built (as_csr_set_order drops it). */
 int as_compute_taumode_signals(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L, int tau_mode,
                                double tau_arg, double *lambdas_out);
 /* An order of the rows of L in which neighbours sit together (order[position] = row, a permutation of 0 .. n - 1, host or
