@@ -296,6 +296,15 @@ void host_copy_parallel(void *dst, const void *src, size_t bytes) {
   std::unique_lock<std::mutex> lk(p->m);
   p->cv_done.wait(lk, [&] { return p->pending == 0; });
 }
+int ctx_side_stream(as_ctx *ctx) {
+  if (ctx->side && ctx->side_word) return AS_OK;
+  if (!ctx->side) AS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  if (!ctx->side_start) AS_HIP(ctx, hipEventCreateWithFlags(&ctx->side_start, hipEventDisableTiming));
+  if (!ctx->side_done) AS_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
+  if (!ctx->side_word) AS_HIP(ctx, hipHostMalloc((void **)&ctx->side_word, 64, hipHostMallocDefault));  // (the side stream's own read-back word)
+  return AS_OK;
+}
+
 }  // namespace asx
 
 namespace {
@@ -473,6 +482,13 @@ void as_ctx_destroy(as_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+  }
+  if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
+  if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
+  if (ctx->side_word) (void)hipHostFree(ctx->side_word);
   prof_resolve(ctx);
   handle_cache_stream(ctx->device, ctx->stream, false);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -566,6 +582,8 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "rerank_share") ctx->opt_rerank_share = value != 0;
   else if (n == "join_order_chain") ctx->opt_join_order_chain = value;
+  else if (n == "signal_tau_bracket") ctx->opt_signal_tau_bracket = value;
+  else if (n == "signal_tau_overlap") ctx->opt_signal_tau_overlap = value;
   else if (n == "join_theta_far") ctx->opt_join_theta_far = value;
   else if (n == "join_theta_dip_e3") ctx->opt_join_theta_dip_e3 = value;
   else if (n == "join_order_cover") ctx->opt_join_order_cover = value;

@@ -38,6 +38,9 @@ struct PendingEvent {
 struct as_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;             // a second stream for work that runs under a pass of the main one (ctx_side_stream)
+  hipEvent_t side_start = nullptr, side_done = nullptr;
+  int *side_word = nullptr;               // pinned: what the side stream reads back
   bool own_stream = false;
   std::string err;
   void *pinned = nullptr;  // staging buffer for host <-> device transfers
@@ -121,6 +124,8 @@ struct as_ctx {
   int64_t opt_sharded_own_rows = 1;      // build sharded by rows: the join is prepared from the ranks' own rows and the all-gather of the f64 rows runs under it (0: rows first)
   int64_t opt_signal_sym = 1;            // item-graph lambda (signal_lambda.hip): a bitwise symmetric graph is streamed as its upper triangle
   int64_t opt_signal_order = 1;          // ... in the order attached to the graph (as_csr_set_order / the join's own); 0: the rows as stored
+  int64_t opt_signal_tau_bracket = 1;    // Median / Percentile tau of columns of 131 072 values or more from a sampled bracket and ONE pass over the column (0: the digit passes, three reads)
+  int64_t opt_signal_tau_overlap = 1;    // ... on a side stream under the sums pass of the item-graph lambda (0: in front of it)
   int64_t opt_signal_min_len = 9000;     // as_compute_taumode: signals this long or longer go through the item-graph kernels
   int64_t opt_debug = 0;          // diagnostics only (timing experiments); 0 in production
   int64_t opt_cand_precision = 32;  // first candidate stage: 32 = f32 MFMA (then f64), 64 = f64 MFMA only
@@ -637,6 +642,7 @@ int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_
 int signal_lambdas_rows(as_ctx *ctx, const double *items, uint64_t n_sig, uint64_t n_len, as_csr *L, int mode, double arg, double *out);
 int signal_sums(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr *L, uint64_t tail_begin, uint64_t tail_end, double *sums);
 int signal_taus(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau);
+int ctx_side_stream(as_ctx *ctx);  // api.hip: creates ctx->side and its two events on first use
 int signal_taus_rows(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len, int mode, double arg, double *taus);
 int signal_lambda_finish(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const double *tau, double *out);
 int signal_shares(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, const double *sums, const int *need, double *g2);

@@ -562,15 +562,21 @@ def main():
             nnz_sp = gl_sp.matrix.nnz()
             legs_sp = {}
             for name, tm in (("fixed_tau", A.TauMode.Fixed(0.5)), ("median_tau", A.TauMode.Median)):
+                t_call = 0.0
                 for it in range(5):
                     if it == 1:
                         ctx.profile(True)
+                    t0c = time.perf_counter()
                     lam_sp = compute_taumode_signals(Xd, gl_sp.matrix, tm, ctx=ctx)
                     ctx.synchronize()
+                    t_call += (time.perf_counter() - t0c) if it >= 1 else 0.0
                 pl = ctx.profile_all()
                 ctx.profile(False)
                 legs_sp[name] = {k.replace("signal_", "") + "_ms": v[0] / v[1] for k, v in pl.items() if k.startswith("signal_") and v[1]}
-            sums_ms = legs_sp["median_tau"]["sums_ms"]
+                legs_sp[name]["call_ms"] = t_call / 4 * 1e3   # wall time of the whole call (with Median the order statistics run under the sums pass)
+                legs_sp[name]["tau_under_the_sums_pass"] = ctx.stat("signal_tau_overlapped")
+            # (the sums kernel by itself: in the Median leg the bracket pass of the order statistics shares the memory system with it)
+            sums_ms = legs_sp["fixed_tau"]["sums_ms"]
             alg_bytes = nnz_sp * 16.0 + float(n) * d * 8.0
             records = ctx.stat("signal_stream_records")
             valu_floor_ms = records * 7.0 * d / (16.0 * 4 * 256 * 2.4e9) * 1e3   # 16 f64 lanes per clock and SIMD, 1024 SIMDs, 2.4 GHz
@@ -587,8 +593,9 @@ def main():
                 "legs_ms": legs_sp, "lambda_min_max": [float(lam_sp.min()), float(lam_sp.max())],
                 "note": "frac divides the algorithmic bytes (each row once) by the launch time; the pass requests gathered_bytes from "
                         "the caches (a pair's second row), which at this graph (neighbours random inside a 4 MB cluster, as large as "
-                        "an XCD's L2) come mostly from the Infinity Cache; median_tau adds the order statistic of every column "
-                        "(taus_ms: two histogram passes + one collecting pass over the N x D matrix)"}
+                        "an XCD's L2) come mostly from the Infinity Cache; median_tau adds the order statistic of every column: "
+                        "8 192 sampled values bracket it, one pass over the N x D matrix counts below the bracket and lists what is inside, "
+                        "on a side stream under the sums pass (legs_ms.median_tau.call_ms against legs_ms.fixed_tau.call_ms is what it costs)"}
             rec = recorded_traffic("signal_sums_kernel", n, d)
             if rec:
                 # (this leg launches the kernel several times in the profiled pass: bytes per single launch)

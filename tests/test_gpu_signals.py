@@ -137,6 +137,49 @@ def test_order_statistics_of_long_columns(ctx):
                 assert np.array_equal(got, want), (tm, got, want)
 
 
+@pytest.mark.parametrize("n_len", [200_000, 200_001, 131_072])
+def test_order_statistics_of_very_long_columns_from_a_sampled_bracket(ctx, n_len):
+    """"signal_tau_bracket" (round 5): columns of 131 072 values or more get their order statistic from 8 192 sampled values that
+    bracket it and ONE pass that counts below the bracket and lists what lies inside.  Same value bit for bit as the oracle's
+    select_tau and as the digit passes; smooth columns of any scale, heavy tails, non-finite entries, even and odd counts take it
+    (no column falls back), columns of few distinct values run their lists over and hand ALL columns to the digit passes."""
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((n_len, 10))
+    X[:, 1] = np.exp(4.0 * X[:, 1])                      # eight decades
+    X[:, 2] = rng.standard_cauchy(n_len)                 # heavy tails
+    X[:, 3] = np.abs(X[:, 3]) * 1e-300                   # subnormal range
+    X[::7, 4] = np.nan
+    X[::5, 5] = np.inf
+    X[::3, 5] = -np.inf
+    X[:, 6] = -np.abs(X[:, 6])                           # all negative: tau floors
+    X[:, 7] = np.arange(n_len)[::-1] * 0.5               # sorted, every value once
+    X[:, 8] = np.round(X[:, 8], 4)                       # a few hundred copies of each value near the median
+    modes = [(T.Median, O.TAU_MEDIAN, 0.0), (T.Percentile(0.95), O.TAU_PERCENTILE, 0.95), (T.Percentile(0.0), O.TAU_PERCENTILE, 0.0),
+             (T.Percentile(1.0), O.TAU_PERCENTILE, 1.0), (T.Percentile(0.5), O.TAU_PERCENTILE, 0.5)]
+    Xt = np.ascontiguousarray(X.T)
+    for tm, omode, oarg in modes:
+        want = np.array([O.select_tau(X[:, c], omode, oarg) for c in range(X.shape[1])])
+        got = A.select_tau(Xt, tm, ctx=ctx)
+        assert ctx.stat("signal_tau_bracket_fallback_columns") == 0, tm
+        assert np.array_equal(got, want), (tm, got, want)
+        ctx.set_option("signal_tau_bracket", 0)
+        try:
+            assert np.array_equal(A.select_tau(Xt, tm, ctx=ctx), want)
+        finally:
+            ctx.set_option("signal_tau_bracket", 1)
+    Y = X.copy()
+    Y[:, 0] = 3.25                                        # constant
+    Y[:, 1] = rng.integers(0, 3, size=n_len)              # three distinct values
+    Y[:, 2] = np.nan                                      # no finite value (the floor; no fallback needed for it)
+    Y[:, 9] = np.where(rng.random(n_len) < 0.5, 1.0, 2.0)
+    Yt = np.ascontiguousarray(Y.T)
+    for tm, omode, oarg in modes[:2]:
+        want = np.array([O.select_tau(Y[:, c], omode, oarg) for c in range(Y.shape[1])])
+        got = A.select_tau(Yt, tm, ctx=ctx)
+        assert ctx.stat("signal_tau_bracket_fallback_columns") >= 3, tm
+        assert np.array_equal(got, want), (tm, got, want)
+
+
 def test_any_order_gives_the_same_lambdas(ctx):
     X, _ = synth.mixture(5000, 64, seed=9, n_clusters=16, rank=6)
     gl = A.build_laplacian_matrix(X, A.GraphParams(0.5, 16, 16, 2.0, 0.25), ctx=ctx)
