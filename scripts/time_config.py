@@ -17,19 +17,28 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rank = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 clusters = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 ctx = A.default_context()
+seed = 42
 for kv in sys.argv[6:]:
     k, v = kv.split("=")
-    ctx.set_option(k, int(v))
+    if k == "seed":
+        seed = int(v)
+    else:
+        ctx.set_option(k, int(v))
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
-Xd, cent = synth.mixture_device(n, d, "cuda", seed=42, n_clusters=clusters, rank=rank)
+Xd, cent = synth.mixture_device(n, d, "cuda", seed=seed, n_clusters=clusters, rank=rank)
 A.build_laplacian_matrix(Xd, gp, ctx=ctx)
 ctx.synchronize()
 ctx.profile(True)
 t0 = time.perf_counter()
+each = []
 for _ in range(reps):
+    t1 = time.perf_counter()
     gl = A.build_laplacian_matrix(Xd, gp, ctx=ctx)
-ctx.synchronize()
+    ctx.synchronize()
+    each.append((round((time.perf_counter() - t1) * 1e3, 2), ctx.stat("knn_join_theta_grouped"), ctx.stat("knn_join_theta_grouped_bad"), ctx.stat("knn_join_order_pivots"),
+                 ctx.stat("knn_join_theta_far_rows"), ctx.stat("knn_join_theta_dip_rows"), ctx.stat("knn_join_candidates")))
 dt = (time.perf_counter() - t0) / reps
+print("each call (ms, grouped, bad, pivots, far, dip, candidates):", each)
 prof = ctx.profile_all()
 ctx.profile(False)
 print("%d x %d rank %d clusters %d: build %.2f ms, nnz %d" % (n, d, rank, clusters, dt * 1e3, gl.matrix.nnz()))
