@@ -10,6 +10,7 @@
 #include <cstring>
 #include <atomic>
 #include <functional>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -45,6 +46,7 @@ struct as_ctx {
   std::string err;
   void *pinned = nullptr;  // staging buffer for host <-> device transfers
   std::multimap<size_t, void *> free_blocks;  // workspace cache (capacity -> block)
+  uint64_t ws_malloc_us = 0, ws_mallocs = 0;  // time this context spent in hipMalloc for workspace blocks (statistics)
   // Options (as_ctx_set_option).  include/arrowspace_hip.h documents the 35 SUPPORTED ones; the others here are switches for the tests
   // (forms of one stage that must agree bit for bit: lambda_v2 / lambda_v3 / lambda_wide, join_bf16, second_pass_f16, search_scan_f16,
   // assembly_lanes, nearest_mfma, cluster_on_device, join_theta_parts, join_unit_list, sharded_own_rows, search_stream_quick), failure
@@ -359,7 +361,10 @@ inline int ws_alloc(as_ctx *ctx, size_t bytes, void **out, size_t *cap) {
     ctx->free_blocks.erase(it);
     return AS_OK;
   }
+  const auto t0_ws = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
+  ctx->ws_malloc_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0_ws).count();
+  ++ctx->ws_mallocs;
   if (e != hipSuccess) {  // drop the cache and retry once
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);

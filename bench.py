@@ -708,6 +708,11 @@ def main():
                     "visited side by side on an L2, so part is served on-die: `traffic` is what left the L2s)",
                     {"rows_fetched_per_row": batches * 16.0 / max(1, rows_here), "pairs_scored_per_row": pairs / max(1, rows_here),
                      "survivors_per_row": scored / max(1, rows_here), "batches": batches, "gather": True,
+                     # per batch 128 sequential v_add_f64 on 16 lanes (the reference's summation order) + 2048 products on 64 lanes;
+                     # a wave-wide f64 instruction occupies its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+                     "f64_issue_ms": batches * (128.0 + 2048.0 / 64.0) * 4.0 / (1024.0 * 2.4e9) * 1e3,
+                     "f64_issue_is": "time the f64 instructions of the chains and products occupy the SIMDs (divide by avg_launch_ms for the "
+                                     "issue fraction: the kernel is bound by the gather, not by the chains)",
                      "achieved_is": "REQUESTED bytes over the launch time (no counter pass of this binary at hand): rows shared through the "
                                     "L2s make this exceed what HBM delivers"}, pmc="rerank_pairs_score_kernel")
                 add("knn_rerank_prune", "rerank_prune_kernel (lists -> per-pair bounds -> survivors: a record per row)", "hbm",

@@ -988,6 +988,18 @@ def test_handle_memory_cache_on_and_off(ctx):
             assert all(np.array_equal(a, b) for a, b in zip(ref[0], got)) and hits == ref[1]
             del gl, asp
             gc.collect()
+        # a handle takes the smallest idle block that holds it and is at most a quarter larger: graphs of other data (another
+        # number of entries) re-use the blocks too, and what is built in a larger block is what is built in a fresh one
+        X2, _ = synth.mixture(70_000, 128, seed=44, n_clusters=200)
+        ctx.set_option("handle_cache_mb", 0)
+        fresh2 = A.build_laplacian_matrix(X2, gp, ctx=ctx).matrix.to_host()
+        ctx.set_option("handle_cache_mb", 4096)
+        for Xa, want in ((X, ref[0]), (X2, fresh2), (X, ref[0]), (X2, fresh2)):
+            gl = A.build_laplacian_matrix(Xa, gp, ctx=ctx)
+            got = gl.matrix.to_host()
+            assert all(np.array_equal(a, b) for a, b in zip(want, got))
+            del gl
+            gc.collect()
     finally:
         ctx.set_option("handle_cache_mb", 4096)
 
