@@ -379,6 +379,14 @@ def main():
     if use_dist:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     t_all, t_build, t_search = [float(x) for x in times]
+    # device memory in use on every rank's GPU right after the timed steps (hipMemGetInfo: torch's blocks, the library's handles and
+    # its workspace cache, i.e. the high-water mark of the step -- the cache keeps what a step took).  Ranks sharing a GPU see the sum.
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    mem = torch.tensor([float(total_b - free_b)], dtype=torch.float64, device="cpu" if shared_gpu else dev)
+    mem_all = [mem.clone() for _ in range(world)] if use_dist else [mem]
+    if use_dist:
+        dist.all_gather(mem_all, mem)
+    device_memory_used_gb = [round(float(m) / 1e9, 3) for m in mem_all]
     prof = ctx.profile_all()
     ctx.profile(False)
     stats = {k: ctx.stat(k) for k in ("knn_join", "knn_join_pipe", "knn_join_blocks", "knn_join_candidates", "knn_uncertified_rows",
@@ -825,6 +833,7 @@ def main():
                        "n_items": n, "dim": d, "n_queries": nq, "sharding": "rows x %d" % world, "transport": transport},
             "search_qps": nq / search_s, "build_ms": build_s * 1e3, "search_ms": search_s * 1e3,
             "item_graph_nnz": int(state.get("nnz", -1)),
+            "device_memory_used_GB_per_rank": device_memory_used_gb,
             "knn_uncertified_rows": stats["knn_uncertified_rows"], "knn_uncertified_rows_after_second_pass": stats["knn_uncertified_rows_stage1a"],
             "knn_join": stats["knn_join"], "knn_join_pipe": pipe, "knn_join_delta": stats["knn_join_delta_e9"] * 1e-9,
             "knn_join_candidates_per_row": stats["knn_join_candidates"] / max(1, rows_here),
