@@ -1273,6 +1273,20 @@ struct TauBracket {
   DevBuf<unsigned long long> lists;
   DevBuf<int> n_fb;  // columns it could not serve (read back by the caller)
 };
+// Mean: its two launches on a stream (the partial sums live until the stream has run them)
+struct TauMean {
+  DevBuf<double> psum;
+  DevBuf<unsigned long long> pcnt;
+};
+static int tau_mean_launch(as_ctx *ctx, hipStream_t st, const double *X, uint64_t n_len, uint32_t S, double *tau, TauMean &tm) {
+  const uint32_t col_groups = (S + kSelCols - 1) / kSelCols;
+  AS_TRY(tm.psum.alloc(ctx, (size_t)kSelRowGroups * S));
+  AS_TRY(tm.pcnt.alloc(ctx, (size_t)kSelRowGroups * S));
+  hipLaunchKernelGGL(col_mean_part_kernel, dim3(kSelRowGroups, col_groups), dim3(1024), 0, st, X, (uint64_t)S, n_len, S, tm.psum.p, tm.pcnt.p);
+  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, st, (const double *)tm.psum.p, (const unsigned long long *)tm.pcnt.p, S, tau);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
 static bool tau_bracket_applies(const as_ctx *ctx, uint64_t n_len, int mode) {
   return (mode == AS_TAU_MEDIAN || mode == AS_TAU_PERCENTILE) && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_bracket;
 }
@@ -1308,14 +1322,8 @@ static int signal_taus_impl(as_ctx *ctx, const double *X, uint64_t n_len, uint32
   }
   const uint32_t col_groups = (S + kSelCols - 1) / kSelCols;
   if (mode == AS_TAU_MEAN) {
-    DevBuf<double> psum;
-    DevBuf<unsigned long long> pcnt;
-    AS_TRY(psum.alloc(ctx, (size_t)kSelRowGroups * S));
-    AS_TRY(pcnt.alloc(ctx, (size_t)kSelRowGroups * S));
-    hipLaunchKernelGGL(col_mean_part_kernel, dim3(kSelRowGroups, col_groups), dim3(1024), 0, ctx->stream, X, (uint64_t)S, n_len, S, psum.p, pcnt.p);
-    hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, (const double *)psum.p, (const unsigned long long *)pcnt.p, S, tau);
-    AS_HIP(ctx, hipGetLastError());
-    return AS_OK;
+    TauMean tm;
+    return tau_mean_launch(ctx, ctx->stream, X, n_len, S, tau, tm);
   }
   if (!digits_only && tau_bracket_applies(ctx, n_len, mode)) {  // long columns: a sampled bracket and one pass
     TauBracket tb;
@@ -1434,6 +1442,21 @@ int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_
     ctx->stats["signal_tau_bracket_fallback_columns"] = h_fb;
     ctx->stats["signal_tau_overlapped"] = 1;
     if (h_fb) AS_TRY(signal_taus_impl(ctx, X, n_len, S, mode, arg, tau.p, true));
+    AS_TRY(signal_lambda_finish(ctx, X, S, L, sums.p, tau.p, out));
+    return AS_OK;
+  }
+  if (mode == AS_TAU_MEAN && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_overlap) {  // the column means likewise (no read-back)
+    AS_TRY(ctx_side_stream(ctx));
+    TauMean tm;
+    AS_HIP(ctx, hipEventRecord(ctx->side_start, ctx->stream));
+    AS_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->side_start, 0));
+    AS_TRY(tau_mean_launch(ctx, ctx->side, X, n_len, S, tau.p, tm));
+    AS_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side));
+    const int rc_sums = signal_sums(ctx, X, n_len, S, L, L->n, n_len, sums.p);
+    AS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
+    // (tm's blocks go back to the cache of the main stream, which has just been told to wait for their last use)
+    AS_TRY(rc_sums);
+    ctx->stats["signal_tau_overlapped"] = 1;
     AS_TRY(signal_lambda_finish(ctx, X, S, L, sums.p, tau.p, out));
     return AS_OK;
   }

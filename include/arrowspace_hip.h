@@ -383,7 +383,10 @@ int as_compute_taumode(as_ctx *ctx, const double *items, uint64_t n_items, uint6
  * the CSR is streamed once for all signals and each stored pair fetches the two item ROWS (algorithmic bytes nnz * 16 +
  * n_items * n_features * 8).  as_compute_taumode itself takes this route for signals of "signal_min_len" (9000) values or more.
  * Options: "signal_sym" (1: a bitwise symmetric L is streamed as its upper triangle), "signal_order" (1: rows visited in the
- * order attached to L); they take effect when the graph's record stream is next built (as_csr_set_order drops it). */
+ * order attached to L); they take effect when the graph's record stream is next built (as_csr_set_order drops it).
+ * Median / Percentile tau of signals of 131072 values or more: the order statistics come from a sampled bracket and one pass over
+ * the columns, on a second stream of the context under the graph pass; the call reads one word back (did every bracket hold?), i.e.
+ * it waits for the work queued before it on the context's stream. */
 int as_compute_taumode_signals(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t n_features, const as_csr *L, int tau_mode,
                                double tau_arg, double *lambdas_out);
 /* An order of the rows of L in which neighbours sit together (order[position] = row, a permutation of 0 .. n - 1, host or
