@@ -66,8 +66,8 @@ SOURCE_SHA16 = source_sha16(ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--nq", type=int, default=10_000)
