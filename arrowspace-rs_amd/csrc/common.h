@@ -550,6 +550,7 @@ struct OwnJoin {
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
   DevBuf<float> order_piv;                                    // the pivots of the order found on them (np x 32), where the rows of each begin
   DevBuf<uint32_t> order_starts;
+  DevBuf<uint32_t> order_near;                                // the 16 nearest pivot groups of every group (np x 16), where the chain of the order has them
   DevBuf<uint32_t> far_pos;                                   // image positions of the rows far from their pivot (row_order.hip), whole 512s, ~0 beyond far_count
   uint32_t far_count = 0;
   uint32_t order_np = 0, cap = 0;                             // pivots used; list slots per row

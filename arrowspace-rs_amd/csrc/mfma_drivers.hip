@@ -443,7 +443,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       AS_TRY(oj.order_starts.alloc(ctx, 4097));
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
                            (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np, 4096,
-                           &oj.far_pos, &oj.far_count));
+                           &oj.far_pos, &oj.far_count, &oj.order_near));
     }
     AS_TRY(oj.theta_pos.alloc(ctx, n));
     AS_TRY(oj.theta2_pos.alloc(ctx, n));
@@ -504,10 +504,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     const uint32_t m = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(rank_opt, 32)), m2 = std::min<uint32_t>(48, 2 * m + 6);
     if (d > 128)
       AS_TRY(join_thresholds_f16_wide_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32,
-                                              32, m, oj.theta_pos.p, m2, oj.theta2_pos.p));
+                                              32, m, oj.theta_pos.p, m2, oj.theta2_pos.p, oj.order_near.p));
     else
     AS_TRY(join_thresholds_f16_grouped(ctx, rows, norms, n, d, oj.Phown.p, oj.perm_own.p, oj.order_starts.p, oj.order_np, oj.order_piv.p, 32, 32, m,
-                                       oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count, row_image));
+                                       oj.theta_pos.p, m2, oj.theta2_pos.p, pos_begin, pos_count, row_image, oj.order_near.p));
     AS_TRY(merge_band());
     if (gather) {
       AS_TRY((*gather)(oj.theta_pos.p, sizeof(float)));

@@ -794,10 +794,10 @@ int join_thresholds_f16_wide(as_ctx *ctx, const double *rows, const double *norm
 // n / 32 / 256 of them).  P_all: the image of all rows in that order; thresholds come out by image position.
 uint32_t grouped_sample_rows_per_group(uint32_t n, uint32_t np);
 int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges);
+                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges, const uint32_t *near_pre);
 int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                      const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out) {
+                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, const uint32_t *near_pre) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 threshold pass: parameters not covered");
@@ -808,7 +808,7 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
   DevBuf<float> maxima;
   AS_TRY(ids.alloc(ctx, ns));
   AS_TRY(ranges.alloc(ctx, (size_t)2 * row_supers));
-  AS_TRY(grouped_sample_plan(ctx, perm, group_start, np, piv, piv_pitch, piv_dim, n, ids.p, ranges.p));
+  AS_TRY(grouped_sample_plan(ctx, perm, group_start, np, piv, piv_pitch, piv_dim, n, ids.p, ranges.p, near_pre));
   AS_TRY(PS.alloc(ctx, packed_vecs_f16(ns / kTileRows, d) * 16));
   AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, ns, d, PS.p, ns / kTileRows));
   AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));

@@ -861,10 +861,10 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
                   uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr, uint32_t max_pivots = 0,
-                  DevBuf<uint32_t> *far_pos = nullptr, uint32_t *far_count = nullptr);
+                  DevBuf<uint32_t> *far_pos = nullptr, uint32_t *far_count = nullptr, DevBuf<uint32_t> *near_out = nullptr);
 int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm);  // row_order.hip
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
-                    uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr);
+                    uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr, const uint32_t *assign_pre = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
@@ -909,11 +909,11 @@ int join_f16_wide_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, con
                          const unsigned char *mask = nullptr);
 int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                      const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out);
+                                     uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, const uint32_t *near_pre = nullptr);
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin = 0,
-                                uint32_t pos_count = 0, const void *row_image = nullptr);
+                                uint32_t pos_count = 0, const void *row_image = nullptr, const uint32_t *near_pre = nullptr);
 int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, uint32_t d, const void *P_all, uint32_t row_begin,
                         uint32_t row_count, const uint32_t *sample_ids, uint32_t ns, uint32_t m, float *theta_out, uint32_t m2,
                         float *theta2_out, const void *row_image = nullptr, uint64_t n_image = 0);

@@ -489,15 +489,17 @@ __global__ void unit_ranges_kernel(const uint32_t *__restrict__ ug, uint32_t uni
   out[2 * I + 1] = (ug[2 * I + 1] + 1) * supers_per_group;
 }
 }  // namespace
+// near_pre (optional): the 16 nearest groups of every group, itself first -- what the chain of the row order has found already
+// (row_order.hip: at 4 096 pivots the search by itself takes 1.3 ms)
 int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
-                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges) {
+                        uint32_t piv_dim, uint32_t n, uint32_t *ids, uint32_t *unit_ranges, const uint32_t *near_pre) {
   const uint32_t kGroupTiles = group_tiles(n, np), kGroupSlots = kGroupTiles * 128u;
   const uint32_t units = (n + 255) / 256;
   DevBuf<uint32_t> near, ug;
   AS_TRY(near.alloc(ctx, (size_t)np * kGroupNear));
   AS_TRY(ug.alloc(ctx, (size_t)2 * units));
-  hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
-  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np, perm, ids,
+  if (!near_pre) hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
+  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(np), dim3(64), 0, ctx->stream, near_pre ? near_pre : (const uint32_t *)near.p, group_start, np, perm, ids,
                      kGroupSlots);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, group_start, np, n, units, ug.p);
   hipLaunchKernelGGL(unit_ranges_kernel, dim3(cdiv(units, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ug.p, units, unit_ranges,
@@ -509,7 +511,7 @@ int grouped_sample_plan(as_ctx *ctx, const uint32_t *perm, const uint32_t *group
 int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const void *P_all,
                                 const uint32_t *perm, const uint32_t *group_start, uint32_t np, const float *piv, uint32_t piv_pitch,
                                 uint32_t piv_dim, uint32_t m, float *theta_out, uint32_t m2, float *theta2_out, uint32_t pos_begin,
-                                uint32_t pos_count, const void *row_image) {
+                                uint32_t pos_count, const void *row_image, const uint32_t *near_pre) {
   const uint32_t KS = (d + 15) / 16;
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: dim not covered");
   if (m < 1 || m > 32 || m2 > 48 || np == 0 || np > 4096) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 threshold pass: parameters not covered");
@@ -529,12 +531,12 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   AS_TRY(unitc.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(unitc.p, 0, sizeof(uint32_t), ctx->stream));
   ProfScope ps(ctx, "knn_join_thresholds");
-  hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
+  if (!near_pre) hipLaunchKernelGGL(near_groups_kernel, dim3(np), dim3(256), 0, ctx->stream, piv, piv_pitch, piv_dim, np, near.p);
   // the sampled rows are gathered from an f16 image (256 B a row at 128 columns; from the f64 rows: 1 KB and the conversion again,
   // 0.22 ms of the 0.8 at 1 M rows): the image by row id where the caller has one (sharded by rows), else P_all itself -- it is in
   // the order of the positions, which is what the sample is drawn in (the ids are then positions: perm is not applied)
   const bool by_position = !row_image && perm && KS <= 8;
-  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)near.p, group_start, np,
+  hipLaunchKernelGGL(group_sample_ids_kernel, dim3(np), dim3(64), 0, ctx->stream, near_pre ? near_pre : (const uint32_t *)near.p, group_start, np,
                      by_position ? (const uint32_t *)nullptr : perm, ids.p, kGroupSlots, rate);
   hipLaunchKernelGGL(unit_groups_kernel, dim3(cdiv(a_supers, 256)), dim3(256), 0, ctx->stream, group_start, np, n, a_supers, ug.p);
   AS_HIP(ctx, hipGetLastError());

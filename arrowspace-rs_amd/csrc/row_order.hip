@@ -328,6 +328,41 @@ __global__ __launch_bounds__(64) void pivot_chain_kernel(const uint16_t *__restr
     cur = nxt;
   }
 }
+// inv[order[p]] = p; near16[p][0] = p, near16[p][k] = inv[lists[order[p]][k - 1]]: the 16 nearest groups of every group in the
+// order of the chain (what the grouped thresholds ask for: mfma_theta_f16.hip, near_groups_kernel), from the chain's own lists
+__global__ void chain_inverse_kernel(const uint32_t *__restrict__ order, uint32_t np, uint32_t *__restrict__ inv) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < np) inv[order[p]] = p;
+}
+__global__ void chain_near16_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ inv, const uint16_t *__restrict__ lists,
+                                    uint32_t list_len, uint32_t np, uint32_t *__restrict__ near16) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np * 16u) return;
+  const uint32_t p = t >> 4, k = t & 15u;
+  uint32_t v = p;
+  if (k) {
+    const uint32_t o = lists[(size_t)order[p] * list_len + (k - 1u)];
+    v = o < np ? inv[o] : 0xFFFFFFFFu;
+  }
+  near16[t] = v;
+}
+// The assignment behind rounds of further pivots without another pass over the pivots: a row's pivot is the better of its best
+// of the first set (key_a, `bits_a` pivot bits) and its best of the drawn ones (key_b, 12 pivot bits), both numbered as the pivots
+// lay BEFORE the last chain; inv: where each went.  key_out: the same as ONE key with `bits_out` pivot bits (the product's low bits
+// are the pivot's: a tie of the two within them goes to the first set -- any assignment gives a correct order).
+__global__ void assign_remap_kernel(const int *__restrict__ key_a, uint32_t bits_a, const int *__restrict__ key_b, const uint32_t *__restrict__ inv,
+                                    uint32_t n, uint32_t bits_out, uint32_t *__restrict__ assign, int *__restrict__ key_out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t ma = (1u << bits_a) - 1u, mb = 4095u, mo = (1u << bits_out) - 1u;
+  const int ka = key_a[r], kb = key_b[r];
+  const int va = (int)((uint32_t)ka & ~ma), vb = (int)((uint32_t)kb & ~mb);  // (integer order is float order for the positive products)
+  const bool second = vb > va;
+  const uint32_t old = second ? mb - ((uint32_t)kb & mb) : ma - ((uint32_t)ka & ma);
+  const uint32_t now = inv[old];
+  assign[r] = now;
+  key_out[r] = (int)(((uint32_t)(second ? vb : va) & ~mo) | (mo - now));
+}
 __global__ void pivot_permute_kernel(const float *__restrict__ piv, const uint32_t *__restrict__ order, uint32_t dpv, float *__restrict__ out) {
   const uint32_t p = blockIdx.x;
   for (uint32_t k = threadIdx.x; k < dpv; k += blockDim.x) out[(size_t)p * dpv + k] = piv[(size_t)order[p] * dpv + k];
@@ -507,20 +542,31 @@ __global__ void order_group_starts_kernel(const uint64_t *__restrict__ offsets, 
 // keys_out (optional, n values; rotated coordinates only): every row's best (product, pivot) key of the assignment, key_value_bits()
 // of it being the product
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np,
-                    uint32_t *group_start, const float *piv_sub, int *keys_out) {
+                    uint32_t *group_start, const float *piv_sub, int *keys_out, const uint32_t *assign_pre) {
   if (d > 128 || n == 0 || np == 0 || np > (uint32_t)kPivotsMax || np % kPivotChunk != 0)
     return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
   const uint32_t dpv = (dp + 31) / 32 * 32;  // pitch of the pivots = the kernel's register count
-  DevBuf<uint32_t> assign, counts;
+  // (assign_pre: the pivot of every row is known already -- cluster_order behind its rounds of further pivots)
+  struct {
+    DevBuf<uint32_t> own;
+    uint32_t *p = nullptr;
+  } assign;
+  DevBuf<uint32_t> counts;
   DevBuf<uint64_t> offsets;
-  AS_TRY(assign.alloc(ctx, n));
+  if (assign_pre) {
+    assign.p = const_cast<uint32_t *>(assign_pre);
+  } else {
+    AS_TRY(assign.own.alloc(ctx, n));
+    assign.p = assign.own.p;
+  }
   AS_TRY(counts.alloc(ctx, (size_t)np * n_blocks));
   AS_TRY(offsets.alloc(ctx, (size_t)np * n_blocks + 1));
 #define AS_ASSIGN(DPV)                                                                                                         \
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
   const bool on_mfma = d == 32 && np % 32 == 0;
-  if (on_mfma && np <= (uint32_t)kPivotsPass) {  // the rotated coordinates: on the matrix pipe
+  if (assign_pre) {
+  } else if (on_mfma && np <= (uint32_t)kPivotsPass) {  // the rotated coordinates: on the matrix pipe
     hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(np / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv, np,
                        assign.p, 0u, 10u, keys_out, keys_out ? 6u : 4u);
   } else if (on_mfma) {  // ... in passes of 1024 pivots, the best key so far carried from pass to pass
@@ -539,7 +585,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
     case 3: AS_ASSIGN(96); break;
     default: AS_ASSIGN(128); break;
   }
-  if (on_mfma && (ctx->opt_debug & 524288)) {
+  if (on_mfma && !assign_pre && (ctx->opt_debug & 524288)) {
     DevBuf<uint32_t> ref, bad;
     AS_TRY(ref.alloc(ctx, n));
     AS_TRY(bad.alloc(ctx, 1));
@@ -582,10 +628,12 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 }
 
 // piv (np x dpv, 32 coordinates used) -> the same pivots in the order of the greedy chain
-static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
-  if (np > (uint32_t)kPivotsMax || np < 2) return AS_OK;
+// inv_out (optional, np): where each pivot went; near_out (optional): np x 16, the nearest groups of every group in the new order
+static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint32_t *inv_out = nullptr, DevBuf<uint32_t> *near_out = nullptr) {
+  if (near_out) near_out->release();
+  if (np > (uint32_t)kPivotsMax || np < 2) return inv_out ? fail(ctx, AS_ERR_UNSUPPORTED, "row order: chain of this many pivots") : AS_OK;
   const uint32_t list_len = np > 2048 ? kChainList / 2 : kChainList;
-  DevBuf<uint32_t> order;
+  DevBuf<uint32_t> order, inv_own;
   DevBuf<uint16_t> lists;
   DevBuf<float> tmp;
   AS_TRY(order.alloc(ctx, np));
@@ -598,6 +646,20 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
   hipLaunchKernelGGL(pivot_permute_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float *)piv, (const uint32_t *)order.p, dpv, tmp.p);
   AS_HIP(ctx, hipGetLastError());
   AS_HIP(ctx, hipMemcpyAsync(piv, tmp.p, sizeof(float) * (size_t)np * dpv, hipMemcpyDeviceToDevice, ctx->stream));
+  if (inv_out || near_out) {
+    uint32_t *inv = inv_out;
+    if (!inv) {
+      AS_TRY(inv_own.alloc(ctx, np));
+      inv = inv_own.p;
+    }
+    hipLaunchKernelGGL(chain_inverse_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)order.p, np, inv);
+    if (near_out) {
+      AS_TRY(near_out->alloc(ctx, (size_t)np * 16));
+      hipLaunchKernelGGL(chain_near16_kernel, dim3(cdiv(np * 16, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)order.p, (const uint32_t *)inv,
+                         (const uint16_t *)lists.p, list_len, np, near_out->p);
+    }
+    AS_HIP(ctx, hipGetLastError());
+  }
   return AS_OK;
 }
 
@@ -607,7 +669,7 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv) {
 // group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
                   uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots, DevBuf<uint32_t> *far_pos,
-                  uint32_t *far_count) {
+                  uint32_t *far_count, DevBuf<uint32_t> *near_out) {
   if (far_count) *far_count = 0;
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   // (more than 256 only where a pivot still stands for 512 rows or more: the thresholds of the own join are taken against the
@@ -634,7 +696,8 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   hipLaunchKernelGGL(gather_pivots_kernel, dim3(np), dim3(128), 0, ctx->stream, rows, norms, ids.p, d, dpv, piv);
   AS_HIP(ctx, hipGetLastError());
   const bool chain = d == 32 && ctx->opt_join_order_chain;
-  if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
+  if (near_out) near_out->release();
+  if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv, nullptr, near_out));
   ctx->stats["knn_join_order_chain"] = chain ? 1 : 0;
   DevBuf<float> piv_sub;
   const bool with_sub = d == 32 && ctx->opt_join_order_sub;
@@ -650,7 +713,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   }
   DevBuf<int> keys;
   if (may_grow) AS_TRY(keys.alloc(ctx, n));
-  AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr));
+  AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr, nullptr));
   ctx->stats["knn_join_order_pivots"] = np;
   if (may_grow) {
     // the first set's assignment is the one round 4 measured; what follows runs only where it leaves many rows far from their pivot
@@ -717,9 +780,21 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
       ++rounds;
     }
     ctx->stats["knn_join_order_cover_rounds"] = rounds;
-    if (rounds) {  // the whole set along one chain, and the rows assigned again
-      if (chain) AS_TRY(chain_pivots(ctx, piv, np, dpv));
-      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p));
+    if (rounds && chain) {
+      // the whole set along one chain; every row's pivot is the better of its two bests so far, renumbered (no pass over 4 096
+      // pivots again: 1.2 ms)
+      DevBuf<uint32_t> inv, assign;
+      AS_TRY(inv.alloc(ctx, np));
+      AS_TRY(assign.alloc(ctx, n));
+      AS_TRY(chain_pivots(ctx, piv, np, dpv, inv.p, near_out));
+      hipLaunchKernelGGL(assign_remap_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, np_first > (uint32_t)kPivotsPass ? 12u : 10u,
+                         (const int *)keys_new.p, (const uint32_t *)inv.p, n, np > (uint32_t)kPivotsPass ? 12u : 10u, assign.p, keys.p);
+      AS_HIP(ctx, hipGetLastError());
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr, assign.p));
+      ctx->stats["knn_join_order_pivots"] = np;
+    } else if (rounds) {  // (no chain: the pivots stay where they are, the rows are assigned again)
+      if (near_out) near_out->release();
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p, nullptr));
       ctx->stats["knn_join_order_pivots"] = np;
     }
     // The rows still far from their pivot, by image position: their neighbours are not where the image order puts a row's
