@@ -513,24 +513,6 @@ __global__ void cover_list_pos_kernel(const uint32_t *__restrict__ flag, const u
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n && flag[p] && rank[p] < room) out[rank[p]] = p;
 }
-// Rows far from their pivot leave its group: they go to one of `zones` groups BEHIND the last pivot's (by the position of the pivot
-// they had, so that rows that shared a foreign pivot stay together), where the order inside a group sorts them by the second set of
-// pivots.  A tile of the image then holds rows of a pivot's own cluster or far rows, not both: one far row in a 128-row tile opens
-// its cone to 90 degrees, and with 3 % of the rows far 98 % of the tiles held one (rank 64 - 128 / 4 096 clusters: the cone bound
-// kept 14 - 34 % of the tile pairs).
-__global__ void assign_far_zone_kernel(const int *__restrict__ key, uint32_t mask, const double *__restrict__ norms, uint32_t n, uint32_t below_bin,
-                                       uint32_t np, uint32_t zones, uint32_t *__restrict__ assign) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  bool usable;
-  const float c = cover_cosine(key, mask, nullptr, 0u, norms, r, &usable);
-  if (usable && (uint32_t)fminf(255.f, fmaxf(0.f, c * 256.f)) < below_bin) assign[r] = np + min(zones - 1u, (uint32_t)(((uint64_t)assign[r] * zones) / np));
-}
-__global__ void near16_tail_kernel(uint32_t np, uint32_t extra, uint32_t *__restrict__ near16) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= extra * 16u) return;
-  near16[(size_t)np * 16 + t] = (t & 15u) ? 0xFFFFFFFFu : np + (t >> 4);  // (a zone's sample is its own)
-}
 // ids[j], j < m: one of the rows not covered out of each of m even strata of their ranks (rank[n] = how many there are, >= m)
 __global__ void cover_draw_kernel(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint32_t n, uint32_t m,
                                   uint32_t *__restrict__ ids) {
@@ -647,9 +629,7 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 
 // piv (np x dpv, 32 coordinates used) -> the same pivots in the order of the greedy chain
 // inv_out (optional, np): where each pivot went; near_out (optional): np x 16, the nearest groups of every group in the new order
-// (extra: rows of the near table behind the np pivots' -- the far zones of cluster_order -- that name themselves only)
-static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint32_t *inv_out = nullptr, DevBuf<uint32_t> *near_out = nullptr,
-                        uint32_t extra = 0) {
+static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint32_t *inv_out = nullptr, DevBuf<uint32_t> *near_out = nullptr) {
   if (near_out) near_out->release();
   if (np > (uint32_t)kPivotsMax || np < 2) return inv_out ? fail(ctx, AS_ERR_UNSUPPORTED, "row order: chain of this many pivots") : AS_OK;
   const uint32_t list_len = np > 2048 ? kChainList / 2 : kChainList;
@@ -674,10 +654,9 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint
     }
     hipLaunchKernelGGL(chain_inverse_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)order.p, np, inv);
     if (near_out) {
-      AS_TRY(near_out->alloc(ctx, (size_t)(np + extra) * 16));
+      AS_TRY(near_out->alloc(ctx, (size_t)np * 16));
       hipLaunchKernelGGL(chain_near16_kernel, dim3(cdiv(np * 16, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)order.p, (const uint32_t *)inv,
                          (const uint16_t *)lists.p, list_len, np, near_out->p);
-      if (extra) hipLaunchKernelGGL(near16_tail_kernel, dim3(cdiv(extra * 16, 256)), dim3(256), 0, ctx->stream, np, extra, near_out->p);
     }
     AS_HIP(ctx, hipGetLastError());
   }
@@ -702,9 +681,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   ProfScope ps(ctx, "knn_join_row_order");
   const uint32_t dp = (d + 3) / 4 * 4;
   // max_pivots: room in piv_out / group_start for a set grown where the first one does not cover the data (rotated coordinates only)
-  constexpr uint32_t kFarZones = 32;  // groups behind the pivots' for the rows far from every pivot (below)
-  const uint32_t np_room = std::min<uint32_t>(std::min<uint32_t>(max_pivots, (uint32_t)kPivotsMax) - std::min<uint32_t>(max_pivots, kFarZones),
-                                              n / 240u / 32u * 32u);
+  const uint32_t np_room = std::min<uint32_t>(std::min<uint32_t>(max_pivots, (uint32_t)kPivotsMax), n / 240u / 32u * 32u);
   const bool may_grow = d == 32 && piv_out && np_room > np && np % 32 == 0 && ctx->opt_join_order_cover > 0;
   DevBuf<uint32_t> ids;
   DevBuf<float> piv_own;
@@ -735,7 +712,6 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     if (chain && ctx->opt_join_order_chain > 1) AS_TRY(chain_pivots(ctx, piv_sub.p, np, dpv));  // (the order inside the groups too)
   }
   DevBuf<int> keys;
-  uint32_t np_groups = 0;
   if (may_grow) AS_TRY(keys.alloc(ctx, n));
   AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr, nullptr));
   ctx->stats["knn_join_order_pivots"] = np;
@@ -804,27 +780,18 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
       ++rounds;
     }
     ctx->stats["knn_join_order_cover_rounds"] = rounds;
-    ctx->stats["knn_join_order_far_zones"] = 0;
     if (rounds && chain) {
       // the whole set along one chain; every row's pivot is the better of its two bests so far, renumbered (no pass over 4 096
       // pivots again: 1.2 ms)
       DevBuf<uint32_t> inv, assign;
       AS_TRY(inv.alloc(ctx, np));
       AS_TRY(assign.alloc(ctx, n));
-      const bool zones = last_below > 0 && ctx->opt_join_order_far_zones != 0;
-      AS_TRY(chain_pivots(ctx, piv, np, dpv, inv.p, near_out, zones ? kFarZones : 0u));
+      AS_TRY(chain_pivots(ctx, piv, np, dpv, inv.p, near_out));
       hipLaunchKernelGGL(assign_remap_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, np_first > (uint32_t)kPivotsPass ? 12u : 10u,
                          (const int *)keys_new.p, (const uint32_t *)inv.p, n, np > (uint32_t)kPivotsPass ? 12u : 10u, assign.p, keys.p);
-      if (zones) {  // (zero vectors stand for the zones' pivots: nobody is assigned to them by a product)
-        hipLaunchKernelGGL(assign_far_zone_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p,
-                           np > (uint32_t)kPivotsPass ? ~4095u : ~1023u, norms, n, last_below, np, kFarZones, assign.p);
-        AS_HIP(ctx, hipMemsetAsync(piv + (size_t)np * dpv, 0, sizeof(float) * (size_t)kFarZones * dpv, ctx->stream));
-      }
       AS_HIP(ctx, hipGetLastError());
-      np_groups = np + (zones ? kFarZones : 0u);
-      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np_groups, group_start, with_sub ? piv_sub.p : nullptr, nullptr, assign.p));
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr, assign.p));
       ctx->stats["knn_join_order_pivots"] = np;
-      ctx->stats["knn_join_order_far_zones"] = zones ? kFarZones : 0;
     } else if (rounds) {  // (no chain: the pivots stay where they are, the rows are assigned again)
       if (near_out) near_out->release();
       AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p, nullptr));
@@ -853,7 +820,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
       }
     }
   }
-  if (np_out) *np_out = np_groups ? np_groups : np;  // (groups of the image: the pivots' and the far zones behind them)
+  if (np_out) *np_out = np;
   return AS_OK;
 }
 
