@@ -98,6 +98,7 @@ struct as_ctx {
   int64_t opt_join_order_cover = 150;    // row order of the join: where more than this many per mille of the rows lie far from their pivot (cosine below 0.8 of the 90 % point), further pivots are drawn from those rows, 1 024 a round up to 4 096 (0 = never; row_order.hip)
   int64_t opt_join_theta_dip_e3 = 50;    // ... and of the rows whose threshold lies this far (per mille) below the median of their 64-position block (0 = off)
   int64_t opt_join_theta_far = 1;        // thresholds of the rows far from their pivot (row_order.hip) from the whole sample, not their group's (0 = off)
+  int64_t opt_debug_label_mod = 0;       // diagnostic: rows carry the label (row mod this); statistics of the labels per image tile (row_order.hip)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)

@@ -10,6 +10,9 @@
 // appends to the lists.  Nothing else sees the permutation: thresholds are scattered back to row order, the re-rank, its
 // tie-breaks by row id and every later stage work on the rows as given.  Any permutation is correct; this one is cheap
 // (about 2 ms at 1 M x 128) and needs no clustering from the caller.
+#include <vector>
+#include <algorithm>
+
 #include "common.h"
 
 namespace asx {
@@ -667,6 +670,7 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint
 // dim <= 128, n >= 256 * 256.  piv_out (optional, 256 x 128 floats, device): the pivots, for order_by_pivots on other rows.
 // n_pivots: 0 = 256; up to 1024 (a multiple of 32; clamped so that a pivot stands for 512 rows or more, 256 at least).  piv_out: n_pivots x 128.
 // group_start / np_out (optional): order_by_pivots' group starts (room for 1025 values) and the number of pivots used.
+int order_label_stats(as_ctx *ctx, const uint32_t *perm, uint32_t n, uint32_t C);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
                   uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots, DevBuf<uint32_t> *far_pos,
                   uint32_t *far_count, DevBuf<uint32_t> *near_out) {
@@ -821,6 +825,53 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
     }
   }
   if (np_out) *np_out = np;
+  if (ctx->opt_debug_label_mod > 0) AS_TRY(order_label_stats(ctx, perm, n, (uint32_t)ctx->opt_debug_label_mod));
+  return AS_OK;
+}
+
+// diagnostic ("debug_label_mod" = C: row r carries label r mod C, as the bench mixtures deal their clusters): how many different
+// labels the 128 positions of a tile hold, and how many of its rows carry the tile's most frequent label
+namespace {
+__global__ __launch_bounds__(128) void tile_labels_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t C, uint32_t *__restrict__ distinct,
+                                                          uint32_t *__restrict__ major) {
+  __shared__ uint32_t s_l[128];
+  const uint32_t T = blockIdx.x, t = threadIdx.x, pos = T * 128u + t;
+  s_l[t] = pos < n ? perm[pos] % C : 0xFFFFFFFFu;
+  __syncthreads();
+  const uint32_t mine = s_l[t];
+  uint32_t same = 0, first = 1;
+  for (uint32_t k = 0; k < 128; ++k) {
+    same += s_l[k] == mine ? 1u : 0u;
+    if (k < t && s_l[k] == mine) first = 0;
+  }
+  __shared__ uint32_t s_d, s_m;
+  if (t == 0) s_d = 0, s_m = 0;
+  __syncthreads();
+  if (mine != 0xFFFFFFFFu) {
+    if (first) atomicAdd(&s_d, 1u);
+    atomicMax(&s_m, same);
+  }
+  __syncthreads();
+  if (t == 0) distinct[T] = s_d, major[T] = s_m;
+}
+}  // namespace
+int order_label_stats(as_ctx *ctx, const uint32_t *perm, uint32_t n, uint32_t C) {
+  const uint32_t ntiles = (n + 127u) / 128u;
+  DevBuf<uint32_t> dd, mm;
+  AS_TRY(dd.alloc(ctx, ntiles));
+  AS_TRY(mm.alloc(ctx, ntiles));
+  hipLaunchKernelGGL(tile_labels_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, perm, n, C, dd.p, mm.p);
+  std::vector<uint32_t> hd(ntiles), hm(ntiles);
+  AS_HIP(ctx, copy_d2h(ctx, hd.data(), dd.p, sizeof(uint32_t) * ntiles));
+  AS_HIP(ctx, copy_d2h(ctx, hm.data(), mm.p, sizeof(uint32_t) * ntiles));
+  std::sort(hd.begin(), hd.end());
+  std::sort(hm.begin(), hm.end());
+  uint64_t sum_m = 0;
+  for (uint32_t v : hm) sum_m += v;
+  ctx->stats["order_tile_labels_q10"] = hd[ntiles / 10];
+  ctx->stats["order_tile_labels_q50"] = hd[ntiles / 2];
+  ctx->stats["order_tile_labels_q90"] = hd[(size_t)ntiles * 9 / 10];
+  ctx->stats["order_tile_major_share_e3"] = (int64_t)(sum_m * 1000 / std::max<uint64_t>(1, n));
   return AS_OK;
 }
 
