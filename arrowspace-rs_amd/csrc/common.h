@@ -99,6 +99,7 @@ struct as_ctx {
   int64_t opt_join_theta_dip_e3 = 50;    // ... and of the rows whose threshold lies this far (per mille) below the median of their 64-position block (0 = off)
   int64_t opt_join_theta_far = 1;        // thresholds of the rows far from their pivot (row_order.hip) from the whole sample, not their group's (0 = off)
   int64_t opt_debug_label_mod = 0;       // diagnostic: rows carry the label (row mod this); statistics of the labels per image tile (row_order.hip)
+  int64_t opt_join_cone_split_above_e3 = 80;  // cone bound on tile pairs: where it keeps more than this many per mille it is taken again with two cones per tile, split where a pivot group ends (cone_tiles.hip; -1 = never)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)
@@ -524,6 +525,8 @@ struct ConeDirs {
   DevBuf<unsigned int> nmax;
   uint32_t ntiles = 0;
   bool valid = false;
+  const uint32_t *group_start = nullptr;  // (set by the caller: where the pivot groups of the image begin, `groups` + 1 positions --
+  uint32_t groups = 0;                    //  the tiles may be split there, cone_tiles.hip)
 };
 // Memory owned by handles (as_csr, as_index, as_jl, uploads): a block a destroyed handle gives back is kept (up to a cap) and handed
 // to the next allocation of exactly its size on the same device, after the work queued on the library's streams when it was given back -- hipFree costs ~150 us whatever

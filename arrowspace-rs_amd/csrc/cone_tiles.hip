@@ -226,6 +226,217 @@ __global__ __launch_bounds__(256, 4) void cone_max_kernel(const f16x8 *__restric
   }
 }
 
+// ---- the same with TWO cones per tile, split where a pivot group ends (round 5) -----------------------------------------------------
+// Where a cluster is a few hundred rows (4 096 clusters in 1 M rows: 244) half of the 128-position tiles straddle two clusters.  Under
+// this bound two unrelated rows still have z_i . z_j = t_i t_j (0.26 - 0.42 at rank 64 - 128), so the two clusters of such a tile stand
+// at 65 - 75 degrees, its cone opens to 40 degrees, and against the rows of another such tile that leaves cos(10 .. 25 degrees) >= the
+// thresholds: kept in both orientations -- 0.52^2 of all pairs, the 14 - 34 % measured.  Split at the boundary of the pivot groups inside
+// it, a straddling tile is two narrow cones; a pair of tiles is kept iff one of its four pairs of SEGMENTS is.  (Fixed halves do not
+// do it: a tile has a straddling half exactly when it straddles.)  Twice the directions against the same rows' image: it runs where
+// the bound above keeps more than "join_cone_split_above_e3" (80) per mille.
+// split[T] in [1, 127]: the first position of tile T's second segment -- the group boundary inside the tile nearest its middle, 64
+// where there is none.
+__global__ void cone_split_kernel(const uint32_t *__restrict__ group_start, uint32_t groups, uint32_t n, uint32_t ntiles, uint32_t *__restrict__ split) {
+  const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+  if (T >= ntiles) return;
+  const uint32_t p0 = T * 128u;
+  uint32_t lo = 0, hi = groups;  // the first group that starts behind p0
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (group_start[mid] <= p0) lo = mid + 1;
+    else hi = mid;
+  }
+  uint32_t best = 64, dist = 0xFFFFFFFFu;
+  for (uint32_t g = lo; g < groups && group_start[g] < p0 + 128u; ++g) {
+    const uint32_t b = group_start[g] - p0;  // 1 .. 127
+    const uint32_t dd = b > 64u ? b - 64u : 64u - b;
+    if (b >= 1u && b <= 127u && dd < dist) best = b, dist = dd;
+  }
+  split[T] = best;
+}
+// One workgroup of 128 threads per segment H = 2 T + a (a = 0: positions [128 T, 128 T + split), 1: the rest): its mean direction as
+// "row" H of the direction image, its cone and its smallest threshold.
+__global__ __launch_bounds__(128) void cone_segment_kernel(const double *__restrict__ Z, const uint32_t *__restrict__ perm, uint32_t n,
+                                                          const float *__restrict__ theta, const uint32_t *__restrict__ split,
+                                                          f16x8 *__restrict__ dirs_img, float *__restrict__ cos_a, float *__restrict__ sin_a,
+                                                          float *__restrict__ theta_min) {
+  __shared__ float s_u[128][kCK + 1];
+  __shared__ float s_m[kCK];
+  __shared__ float s_red[128];
+  const uint32_t H = blockIdx.x, T = H >> 1, a = H & 1u, t = threadIdx.x, pos = T * 128u + t;
+  const uint32_t b = split[T];
+  const bool mine = a ? t >= b : t < b;
+  float u[kCK];
+  bool live = false;
+  if (pos < n && mine) {
+    const double *z = Z + (size_t)(perm ? perm[pos] : pos) * kCK;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) {
+      const double v = z[k];
+      u[k] = (float)v;
+      s += v * v;
+    }
+    const double r = __builtin_sqrt(s);
+    live = r > 0.0 && r < __builtin_inf();
+    const float inv = live ? (float)(1.0 / r) : 0.f;
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) u[k] = live ? u[k] * inv : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) u[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) s_u[t][k] = u[k];
+  __syncthreads();
+  if (t < kCK) {
+    float s = 0.f;
+    for (int r = 0; r < 128; ++r) s += s_u[r][t];  // (index order: the same sum in every run; rows outside the segment are zero)
+    s_m[t] = s;
+  }
+  __syncthreads();
+  float mm = 0.f;
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) mm = __builtin_fmaf(s_m[k], s_m[k], mm);
+  const float minv = mm > 0.f ? 1.f / __builtin_sqrtf(mm) : 0.f;
+  float dotm = 0.f;
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) dotm = __builtin_fmaf(u[k], s_m[k] * minv, dotm);
+  s_red[t] = live ? dotm : 2.f;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < (uint32_t)o) s_red[t] = __builtin_fminf(s_red[t], s_red[t + o]);
+    __syncthreads();
+  }
+  const float ca_raw = s_red[0];
+  __syncthreads();
+  const float th = theta[pos];  // (padded to whole super tiles with +inf)
+  s_red[t] = (pos < n && mine && th < __builtin_inff()) ? th : __builtin_inff();
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < (uint32_t)o) s_red[t] = __builtin_fminf(s_red[t], s_red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    float ca = (minv > 0.f && ca_raw <= 1.5f) ? __builtin_fminf(__builtin_fmaxf(ca_raw - kEpsCone, -1.f), 1.f) : -1.f;
+    if (ca_raw > 1.5f) ca = 1.f;  // no live row: nothing to bound (its thresholds are +inf as well)
+    cos_a[H] = ca;
+    sin_a[H] = __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - ca * ca)) + 1e-6f;
+    theta_min[H] = s_red[0];
+  }
+  if (t < 4) {
+    const uint32_t ks = t >> 1, h = t & 1u, Td = H >> 7, s = (H & 127u) >> 5, r = H & 31u;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)(s_m[16 * ks + 8 * h + j] * minv);
+    dirs_img[(((size_t)Td * 2 + ks) * 4 + s) * 64 + r + 32 * h] = v;
+  }
+}
+// bit1[H * words + g], bit b: can a row of SEGMENT H and a row of segment 32 g + b reach a threshold, by the cone of the latter and
+// the exact products of H's rows with its direction?  One wave per 128-row tile J: the largest product of each of its four 32-row
+// blocks with a direction; segment 2 J takes the blocks that hold one of its rows, segment 2 J + 1 likewise (the block the split
+// falls into counts for both: a larger maximum only keeps more).
+__global__ __launch_bounds__(256, 4) void cone_max_segment_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img, uint32_t ntiles,
+                                                                const uint32_t *__restrict__ split, const float *__restrict__ cos_a,
+                                                                const float *__restrict__ sin_a, const float *__restrict__ theta_min,
+                                                                const unsigned int *__restrict__ nmax_bits, uint32_t words,
+                                                                uint32_t *__restrict__ bit1) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t J = blockIdx.x * 4u + (uint32_t)wv;
+  if (J >= ntiles) return;
+  const uint32_t nseg = 2u * ntiles;
+  const int lc = lane & 31;
+  f16x8 a[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[s][ks] = rows_img[(((size_t)J * 2 + ks) * 4 + s) * 64 + lane];
+  const uint32_t b = split[J];
+  const int s_last0 = (int)((b - 1u) >> 5), s_first1 = (int)(b >> 5);  // blocks of the first / the second segment
+  const float thJ[2] = {theta_min[2u * J], theta_min[2u * J + 1u]};
+  const float nmax = __uint_as_float(*nmax_bits);
+  const float inv_n2 = nmax > 0.f ? 1.f / (nmax * nmax) : 1.f;
+  v16f32 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  auto dir_frag = [&](uint32_t g, int ks) -> f16x8 { return dirs_img[(((size_t)(g >> 2) * 2 + ks) * 4 + (g & 3u)) * 64 + lane]; };
+  auto dir_cone = [&](uint32_t g, float &th, float &c, float &sn) {
+    const uint32_t I = min(g * 32u + (uint32_t)lc, nseg - 1u);
+    th = theta_min[I];
+    c = cos_a[I];
+    sn = sin_a[I];
+  };
+  f16x8 b0 = dir_frag(0, 0), b1 = dir_frag(0, 1);
+  float thI, ca, sa;
+  dir_cone(0, thI, ca, sa);
+  for (uint32_t g = 0; g < words; ++g) {
+    const uint32_t gn = g + 1 < words ? g + 1 : g;
+    const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
+    float thN, caN, saN;
+    dir_cone(gn, thN, caN, saN);
+    const uint32_t I = g * 32u + (uint32_t)lc;
+    const bool in = I < nseg;
+    float ms[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      v16f32 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b0, zero, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b1, acc, 0, 0, 0);
+      const float m = max16f(acc);
+      ms[s] = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (q == 0 ? s <= s_last0 : s >= s_first1) m = __builtin_fmaxf(m, ms[s]);
+      bool flag = false;
+      const float t = __builtin_fminf(thI, thJ[q]);
+      if (in && t < __builtin_inff()) {
+        const float tpp = (t - kEpsTheta) * inv_n2;
+        if (t <= 1e-3f) {
+          flag = true;
+        } else if (tpp <= 1.f) {
+          if (tpp <= -ca) flag = true;
+          else flag = m + kEpsM >= ca * tpp - sa * __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - tpp * tpp)) - 1e-5f;
+        }
+      }
+      const unsigned long long bal = __ballot(flag && lane < 32);
+      if (lane == 0) bit1[(size_t)(2u * J + (uint32_t)q) * words + g] = (uint32_t)bal;
+    }
+    b0 = n0;
+    b1 = n1;
+    thI = thN;
+    ca = caN;
+    sa = saN;
+  }
+}
+// tile_mask[I * words + w], bit b (pair of 128-position tiles I, J = 32 w + b) from the mask of the segments (rows 2 I, 2 I + 1;
+// bits 2 J, 2 J + 1): kept iff one of the four pairs of segments is
+__global__ void cone_segments_to_tiles_kernel(const uint32_t *__restrict__ seg_mask, uint32_t ntiles, uint32_t words_s, uint32_t words,
+                                              uint32_t *__restrict__ tile_mask, unsigned long long *__restrict__ kept) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t out = 0;
+  if (t < (uint64_t)ntiles * words) {
+    const uint32_t I = (uint32_t)(t / words), w = (uint32_t)(t % words);
+    unsigned long long x = 0;
+    for (uint32_t a = 0; a < 2; ++a) {
+      const uint32_t H = 2u * I + a;
+      const uint32_t lo = 2u * w < words_s ? seg_mask[(size_t)H * words_s + 2u * w] : 0u;
+      const uint32_t hi = 2u * w + 1u < words_s ? seg_mask[(size_t)H * words_s + 2u * w + 1u] : 0u;
+      x |= ((unsigned long long)hi << 32) | lo;
+    }
+    const unsigned long long y = (x | (x >> 1)) & 0x5555555555555555ull;  // bit 2 b of y: segment pair (., 2 J) or (., 2 J + 1)
+    for (uint32_t bb = 0; bb < 32; ++bb) out |= (uint32_t)((y >> (2u * bb)) & 1ull) << bb;
+    if (32u * w >= ntiles) out = 0;
+    else if (ntiles - 32u * w < 32u) out &= (1u << (ntiles - 32u * w)) - 1u;
+    tile_mask[t] = out;
+  }
+  uint32_t c = (uint32_t)__builtin_popcount(out);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept + (blockIdx.x & 255u), (unsigned long long)c);
+}
+
 // how many tiles have a cone wider than `cos_limit` allows (the bound says nothing about them: a quick way to see that it will not pay)
 __global__ void cone_wide_count_kernel(const float *__restrict__ cos_a, uint32_t ntiles, float cos_limit, unsigned int *__restrict__ count) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,7 +511,11 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(cone_tile_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, Z, perm, n, theta, (f16x8 *)rows_img.p, (f16x8 *)dirs_img.p, ca.p,
                      sa.p, tmin.p, nmax.p);
-  {
+  // Pivot groups of fewer than 400 rows (the row order drew further pivots: clusters of a few hundred rows): most tiles straddle two
+  // of them, the bound on whole tiles is known to keep a tenth of the pairs or more -- the split form below is taken at once.
+  const bool can_split = cd.group_start && cd.groups && it_begin == 0 && it_count == ntiles && ctx->opt_join_cone_split_above_e3 >= 0 && ntiles >= 64;
+  const bool split_first = can_split && (uint64_t)n < 400ull * cd.groups;
+  if (!split_first) {
     // Data whose tiles are not cones (rows of many clusters in one tile, no directions to tell apart): more than half of the tiles
     // wider than 0.8 rad -- the bound would keep nearly every pair (rank 64 / 4 096 clusters: 93 %), so its n^2 pass is not run and
     // the caller sweeps everything.  (The widths are functions of the gathered coordinates: every rank of a sharded build agrees.)
@@ -321,7 +536,8 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
     }
   }
   const uint32_t all_groups = words;
-  if (it_begin == 0 && it_count == ntiles) {
+  if (split_first) {
+  } else if (it_begin == 0 && it_count == ntiles) {
     hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, 0u, all_groups, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                        (const unsigned int *)nmax.p, words, bit1.p);
@@ -342,17 +558,57 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
                          it_begin, it_count, g1, all_groups - g1, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
                          (const unsigned int *)nmax.p, words, bit1.p);
   }
-  if (it_count) {
+  if (it_count && !split_first) {
     const uint32_t ig0 = it_begin / 32u, ig1 = (it_begin + it_count + 31u) / 32u;
     hipLaunchKernelGGL(cone_and_kernel, dim3(cdiv((uint64_t)(ig1 - ig0) * words, 4)), dim3(256), 0, ctx->stream, (const uint32_t *)bit1.p, it_begin,
                        it_count, ntiles, words, ig0, ig1 - ig0, tile_mask, kept.p);
   }
   AS_HIP(ctx, hipGetLastError());
   unsigned long long hk[256], h = 0;
-  AS_HIP(ctx, copy_d2h(ctx, hk, kept.p, sizeof(hk)));
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (unsigned long long v : hk) h += v;
-  const double share = it_count ? (double)h / ((double)it_count * (double)ntiles) : 0.0;
+  if (!split_first) {
+    AS_HIP(ctx, copy_d2h(ctx, hk, kept.p, sizeof(hk)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (unsigned long long v : hk) h += v;
+  }
+  double share = it_count ? (double)h / ((double)it_count * (double)ntiles) : 0.0;
+  ctx->stats["knn_join_cone_split"] = 0;
+  if (split_first || (can_split && share * 1000.0 > (double)ctx->opt_join_cone_split_above_e3)) {
+    // two cones per tile, split where a pivot group ends (cone_segment_kernel)
+    const uint32_t nseg = 2u * ntiles, words_s = (nseg + 31u) / 32u, dir_tiles_s = (nseg + 127u) / 128u;
+    DevBuf<unsigned char> dirs_s;
+    DevBuf<float> ca_s, sa_s, tmin_s;
+    DevBuf<uint32_t> bit_s, mask_s, split;
+    DevBuf<unsigned long long> kept_s;  // (the pairs of segments kept: not reported)
+    AS_TRY(dirs_s.alloc(ctx, (size_t)dir_tiles_s * 2 * 4 * 64 * 16));
+    AS_TRY(ca_s.alloc(ctx, nseg));
+    AS_TRY(sa_s.alloc(ctx, nseg));
+    AS_TRY(tmin_s.alloc(ctx, nseg));
+    AS_TRY(bit_s.alloc(ctx, (size_t)nseg * words_s));
+    AS_TRY(mask_s.alloc(ctx, (size_t)nseg * words_s));
+    AS_TRY(split.alloc(ctx, ntiles));
+    AS_TRY(kept_s.alloc(ctx, 256));
+    AS_HIP(ctx, hipMemsetAsync(dirs_s.p, 0, (size_t)dir_tiles_s * 2 * 4 * 64 * 16, ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    AS_HIP(ctx, hipMemsetAsync(kept_s.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(cone_split_kernel, dim3(cdiv(ntiles, 256)), dim3(256), 0, ctx->stream, cd.group_start, cd.groups, n, ntiles, split.p);
+    hipLaunchKernelGGL(cone_segment_kernel, dim3(nseg), dim3(128), 0, ctx->stream, Z, perm, n, theta, (const uint32_t *)split.p, (f16x8 *)dirs_s.p, ca_s.p,
+                       sa_s.p, tmin_s.p);
+    hipLaunchKernelGGL(cone_max_segment_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_s.p, ntiles,
+                       (const uint32_t *)split.p, (const float *)ca_s.p, (const float *)sa_s.p, (const float *)tmin_s.p, (const unsigned int *)nmax.p,
+                       words_s, bit_s.p);
+    hipLaunchKernelGGL(cone_and_kernel, dim3(cdiv((uint64_t)words_s * words_s, 4)), dim3(256), 0, ctx->stream, (const uint32_t *)bit_s.p, 0u, nseg, nseg,
+                       words_s, 0u, words_s, mask_s.p, kept_s.p);
+    hipLaunchKernelGGL(cone_segments_to_tiles_kernel, dim3(cdiv((uint64_t)ntiles * words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)mask_s.p, ntiles,
+                       words_s, words, tile_mask, kept.p);
+    AS_HIP(ctx, hipGetLastError());
+    AS_HIP(ctx, copy_d2h(ctx, hk, kept.p, sizeof(hk)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h = 0;
+    for (unsigned long long v : hk) h += v;
+    ctx->stats["knn_join_cone_tiles_kept_whole_e6"] = split_first ? -1 : (int64_t)(share * 1e6);
+    share = (double)h / ((double)ntiles * (double)ntiles);
+    ctx->stats["knn_join_cone_split"] = 1;
+  }
   ctx->stats["knn_join_cone_tiles_kept_e6"] = (int64_t)(share * 1e6);
   if (kept_share) *kept_share = share;
   cd.ntiles = ntiles;

@@ -674,6 +674,9 @@ int own_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
   // looking for them again)
   const int64_t saved_mode = ctx->opt_join_prefilter;
   if (oj.rot_z.p && !oj.wide_pre && saved_mode == 1) ctx->opt_join_prefilter = 2;
+  // (where the pivot groups of the image begin: the cone bound may split its tiles there)
+  oj.cone.group_start = (oj.reorder && oj.order_np && oj.order_starts.p) ? oj.order_starts.p : nullptr;
+  oj.cone.groups = oj.cone.group_start ? oj.order_np : 0;
   const int rc_pairs = knn_join_pairs(ctx, rows, norms, n, d, pos_begin, pos_count, oj.theta_image, oj.cap, cnt, cand, nullptr, oj.P16own.p,
                                       oj.Phown.p, (oj.reorder && !lists_by_pos) ? oj.perm_own.p : nullptr,
                                       oj.reorder ? oj.perm_own.p : nullptr, oj.wide_pre ? oj.rot_z.p : nullptr, &oj.cone);

@@ -425,8 +425,19 @@ def test_item_graph_row_order_draws_more_pivots_where_the_first_set_covers_too_l
         assert ctx.stat("knn_join") == 1
         rounds, grown = ctx.stat("knn_join_order_cover_rounds"), ctx.stat("knn_join_order_pivots")
         low, left = ctx.stat("knn_join_order_cover_low_e3"), ctx.stat("knn_join_order_cover_left_e3")
+        # pivot groups of fewer than 400 rows: the cone bound on tile pairs takes two cones per tile, split where a group ends
+        # ("join_cone_split_above_e3"; cone_tiles.hip) -- the same table with and without, and fewer tile pairs kept with
+        split, kept_split = ctx.stat("knn_join_cone_split"), ctx.stat("knn_join_cone_tiles_kept_e6")
+        ctx.set_option("join_cone_split_above_e3", -1)
+        idx1, dist1 = A.knn_cosine(X, gp)
+        kept_whole = ctx.stat("knn_join_cone_tiles_kept_e6")
+        assert ctx.stat("knn_join_cone_split") == 0
     finally:
         ctx.set_option("join_order_cover", 150)
+        ctx.set_option("join_cone_split_above_e3", 80)
+    if d <= 128 and ctx.stat("knn_join_cone_tiles") == 1 and n < 400 * grown:
+        assert split == 1 and kept_split <= kept_whole, (split, kept_split, kept_whole)
+    assert np.array_equal(idx, idx1) and np.array_equal(dist, dist1)
     assert rounds >= 1 and grown > first and grown % 32 == 0 and grown <= n // 240, (first, grown, rounds)
     assert low >= 150 and left < low, (low, left)
     assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
