@@ -487,6 +487,7 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   const uint32_t dir_tiles = (ntiles + 127u) / 128u;  // image tiles of the direction image
   const uint32_t it_begin = pos_begin / 128u, it_count = std::min(ntiles - std::min(ntiles, it_begin), (pos_count + 127u) / 128u);
   ProfScope ps(ctx, "knn_join_cone_tiles");
+  ctx->stats["knn_join_cone_split"] = 0;
   // (keep: the directions, the cones and the largest norm stay with the caller, for the one-sided bound of the second pass)
   ConeDirs local;
   ConeDirs &cd = keep ? *keep : local;
