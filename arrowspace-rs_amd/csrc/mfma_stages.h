@@ -831,7 +831,7 @@ int stream_scan_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, 
                       const StreamFilter *filter = nullptr);
 bool stream_quick_wide_applies(uint64_t nA, uint64_t nB, uint64_t d, uint32_t K);
 int stream_quick_wide_search(as_ctx *ctx, const double *queries, uint32_t nq, const double *items, uint32_t n, uint32_t d, uint32_t K,
-                             const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
+                             const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo, const uint32_t *q_ids = nullptr);
 int stream_quick_wide_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t d, uint32_t K,
                             const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo);
 constexpr uint32_t kStreamRowsMax = 128;  // leftover rows up to this many take the streaming exact scan, 32 per pass

@@ -695,6 +695,44 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
   AS_HIP(ctx, copy_d2h(ctx, &h_err, err.p, sizeof(int)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h_err) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
+  // Items of 256 .. 1024 values and a handful of queries left open: the quick pass over the items (stream_scan.hip, what a small
+  // batch takes from the start), 32 queries at a time -- search_exact puts ONE wave on a query's 6 GB: 0.9 s a query at 1 M x 768,
+  // and two queries left of 100 000 made a 41 ms batch take 1.8 s (a draw of lambdas in 15: scripts/time_search.py, round 5).
+  ctx->stats["search_leftover_stream_scan"] = 0;
+  // (up to 4 096 of them: a pass of 32 queries streams the items once, ~1 ms per 6 GB, where search_exact's waves each take a second)
+  if (n_exact && wide && n_exact <= 4096u && K == k && ctx->opt_stream_scan && ctx->opt_search_stream_quick &&
+      stream_quick_wide_applies(std::min<uint32_t>(n_exact, 32), n, d, K)) {
+    DevBuf<double> fk;
+    DevBuf<uint32_t> fi, redo_d;
+    AS_TRY(fk.alloc(ctx, (size_t)n_exact * K));
+    AS_TRY(fi.alloc(ctx, (size_t)n_exact * K));
+    AS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+    std::vector<uint32_t> redo_all;
+    for (uint32_t c0 = 0; c0 < n_exact; c0 += 32) {
+      const uint32_t cn = std::min<uint32_t>(32, n_exact - c0);
+      std::vector<uint32_t> redo;
+      AS_TRY(stream_quick_wide_search(ctx, queries, cn, ix->items, n, d, K, pol, fk.p + (size_t)c0 * K, fi.p + (size_t)c0 * K, err.p, &redo, exact_ids + c0));
+      for (uint32_t r : redo) redo_all.push_back(c0 + r);
+    }
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((uint64_t)n_exact * K, 256)), dim3(256), 0, ctx->stream, exact_ids, n_exact, K, fk.p, fi.p, out_key,
+                       out_idx);
+    AS_HIP(ctx, hipGetLastError());
+    int h_err1 = 0;
+    AS_HIP(ctx, copy_d2h(ctx, &h_err1, err.p, sizeof(int)));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err1) return fail(ctx, AS_ERR_NAN_SCORE, as_status_message(AS_ERR_NAN_SCORE));
+    ctx->stats["search_leftover_stream_scan"] = n_exact;
+    if (redo_all.empty()) return AS_OK;
+    // (a query whose list ran over in the quick pass: the exact scan for those)
+    const uint32_t nr = (uint32_t)redo_all.size();
+    AS_TRY(redo_d.alloc(ctx, nr));
+    AS_HIP(ctx, copy_h2d(ctx, redo_d.p, redo_all.data(), sizeof(uint32_t) * nr));
+    AS_TRY(ids2.alloc(ctx, nr));
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(nr, 256)), dim3(256), 0, ctx->stream, exact_ids, redo_d.p, nr, 0u, ids2.p);
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    exact_ids = ids2.p;
+    n_exact = nr;
+  }
   if (n_exact) {
     DevBuf<double> fk;
     DevBuf<uint32_t> fi;

@@ -1075,8 +1075,10 @@ static int stream_quick_wide(as_ctx *ctx, const char *prof_name, const double *A
   return AS_OK;
 }
 int stream_quick_wide_search(as_ctx *ctx, const double *queries, uint32_t nq, const double *items, uint32_t n, uint32_t d, uint32_t K,
-                             const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {
-  return stream_quick_wide<SearchScorePolicy>(ctx, "search_stream_scan", queries, nullptr, nq, items, n, d, K, pol, out_key, out_idx, err_flag, redo);
+                             const SearchScorePolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo,
+                             const uint32_t *q_ids) {
+  // (q_ids: the listed queries of a batch -- what a large batch's threshold scan left open -- results in list order)
+  return stream_quick_wide<SearchScorePolicy>(ctx, "search_stream_scan", queries, q_ids, nq, items, n, d, K, pol, out_key, out_idx, err_flag, redo);
 }
 int stream_quick_wide_graph(as_ctx *ctx, const double *rows, const uint32_t *row_ids, uint32_t n_rows, uint32_t n, uint32_t d, uint32_t K,
                             const GraphDistPolicy &pol, double *out_key, uint32_t *out_idx, int *err_flag, std::vector<uint32_t> *redo) {

@@ -21,6 +21,7 @@ for kv in sys.argv[4:]:
 X, cent = synth.mixture_device(n, d, "cuda", seed=42)
 qidx = synth.query_indices(n, nq, seed=42)
 Q = X[torch.from_numpy(qidx.astype(np.int64)).cuda()] * 1.02
+torch.manual_seed(42)  # (the same lambdas in every run: scripts/scan_search_seeds.py varies them)
 lam = torch.rand(n, dtype=torch.float64, device="cuda") * 0.4 + 0.01
 lq = lam[torch.from_numpy(qidx.astype(np.int64)).cuda()] + 0.01
 asp = A.ArrowSpace(X, A.TauMode.Median, ctx)

@@ -1399,6 +1399,23 @@ def test_search_scan_of_wide_items_on_an_ordered_index(ctx, n, d, nq, k, alpha):
     finally:
         ctx.set_option("search_prefilter", 1)
     assert np.array_equal(idx1, idx5) and np.array_equal(sc1, sc5)
+    # queries the scan leaves open (forced: 64 candidate slots instead of 512) take the quick streaming pass over the items, 32 at a
+    # time, where the items have 256 .. 1024 values (the one-wave-per-query exact scan took 0.9 s a query at 1 M x 768: two open
+    # queries of 100 000 made a 41 ms batch take 1.8 s); with the pass switched off they take that exact scan: the same results
+    if d >= 256 and nq >= 2048:
+        ctx.set_option("search_scan_cap", 64)
+        try:
+            idx6, sc6 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+            left = ctx.stat("search_uncertified_rows")
+            assert 0 < left <= 4096 and ctx.stat("search_leftover_stream_scan") == left, (left, ctx.stat("search_leftover_stream_scan"))
+            ctx.set_option("search_stream_quick", 0)
+            idx7, sc7 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+            assert ctx.stat("search_leftover_stream_scan") == 0
+        finally:
+            ctx.set_option("search_scan_cap", 512)
+            ctx.set_option("search_stream_quick", 1)
+        assert np.array_equal(idx1, idx6) and np.array_equal(sc1, sc6)
+        assert np.array_equal(idx1, idx7) and np.array_equal(sc1, sc7)
     for j in range(0, nq, max(1, nq // 20)):
         oi, osc = O.search_lambda_aware(X, lam, Q[j], lq[j], k, alpha)
         assert np.array_equal(idx1[j], oi), j
