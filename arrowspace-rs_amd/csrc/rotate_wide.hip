@@ -368,6 +368,96 @@ __global__ __launch_bounds__(256) void pack_from_z_kernel(const double *__restri
   if ((threadIdx.x & 63) == 0) atomicMax(err_bits, __float_as_uint(e));
 }
 
+// The same coordinates on the matrix pipe, for rows of 256 .. 1024 columns (a multiple of 32): Z = X Q is a GEMM of 2 n d 32 flop
+// behind n d 8 bytes, but zproj_kernel above gives a row to a wave and ends each of its 31 products in a wave-wide reduction: 14 ms
+// for 1 M x 768, ten times the time of its bytes (round 5: the largest stage of the wide build's preparation).  Here a wave owns 32
+// rows; a lane (row r = lane & 31, half h = lane >> 5) loads the 16 consecutive columns 32 c + 16 h .. of its row -- whole 64-byte
+// sectors -- and step s of v_mfma_f32_32x32x2_f32 takes each lane's s-th value: the k index of the instruction's two slices is then
+// 32 c + 16 h + s on both operands (the order in which k is summed is free), the directions coming from LDS in [k][32] form.  f32
+// products and sums as before (the unit row is formed in f64 first); the epilogue is the other kernel's: t = sqrt(max(0, 1 - |z|^2)
+// + 2e-5), rows without a direction all zero, the wave's sum of 1 - |z|^2 in a fixed order.
+typedef float zp_v16f32 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512) void zproj_mfma_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n, uint32_t d,
+                                                         const float *__restrict__ Q, uint32_t pitch, double *__restrict__ out,
+                                                         double *__restrict__ tail_part) {
+  extern __shared__ float zp_smem[];
+  float *s_q = zp_smem;                       // [d][33]: s_q[k * 33 + dir], dir 31 = 0
+  float *s_z = zp_smem + (size_t)d * 33;      // [8 waves][32 rows][33]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, r = lane & 31u, h = lane >> 5;
+  for (uint32_t e = tid; e < d * 32u; e += 512) {
+    const uint32_t k = e >> 5, dir = e & 31u;
+    s_q[k * 33 + dir] = dir < (uint32_t)kDirs ? Q[(size_t)dir * pitch + k] : 0.f;
+  }
+  __syncthreads();
+  const uint32_t row0 = (blockIdx.x * 8u + wv) * 32u;
+  double tails = 0.0;
+  if (row0 < n) {
+    const uint32_t row = min(row0 + r, n - 1u);
+    const double nr = norms[row];
+    const bool live = nr > 0.0 && nr < __builtin_inf() && row0 + r < n;
+    const double inv = live ? 1.0 / nr : 0.0;
+    const double *src = R + (size_t)row * d + 16u * h;
+    zp_v16f32 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (uint32_t c = 0; c < d / 32u; ++c) {
+      double x[16];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + 32u * c + 2 * q);
+        x[2 * q] = v.x, x[2 * q + 1] = v.y;
+      }
+      const float *bq = s_q + (size_t)(32u * c + 16u * h) * 33 + r;
+#pragma unroll
+      for (int sidx = 0; sidx < 16; ++sidx) {
+        const float a = live ? (float)(x[sidx] * inv) : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a == a ? a : 0.f, bq[sidx * 33], acc, 0, 0, 0);
+      }
+    }
+    // accumulator register i of lane (h, r): row 8 (i >> 2) + (i & 3) + 4 h of the wave's 32, direction r
+    float *zt = s_z + (size_t)wv * 32 * 33;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zt[(8 * (i >> 2) + (i & 3) + 4 * (int)h) * 33 + r] = acc[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (h == 0) {
+      const uint32_t mine = row0 + r;
+      const double nm = mine < n ? norms[mine] : 0.0;
+      const bool lv = mine < n && nm > 0.0 && nm < __builtin_inf();
+      float zz = 0.f;
+      float z[32];
+#pragma unroll
+      for (int k = 0; k < kDirs; ++k) {
+        z[k] = lv ? zt[r * 33 + k] : 0.f;
+        zz = __builtin_fmaf(z[k], z[k], zz);
+      }
+      z[kDirs] = lv ? __builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.f;
+      if (mine < n) {
+        double *o = out + (size_t)mine * 32;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) o[k] = (double)z[k];
+      }
+      if (lv) tails = (double)__builtin_fmaxf(1.f - zz, 0.f);
+    }
+  }
+  if (tail_part) {  // lanes 0 .. 31 of the wave, added in lane order (a fixed order: the same tail in every run)
+    double tsum = 0.0;
+    for (int l = 0; l < 32; ++l) tsum += __shfl(tails, l, 64);
+    if (lane == 0) tail_part[blockIdx.x * 8u + wv] = tsum;
+  }
+}
+static bool zproj_mfma_applies(uint32_t d) { return d >= 256 && d <= 960 && d % 32 == 0; }  // (the directions of 960 columns and the eight waves' tiles fill the 160 KB of LDS)
+static uint32_t zproj_mfma_parts(uint32_t n) { return cdiv(n, 256) * 8u; }  // entries of tail_part
+static int launch_zproj_mfma(as_ctx *ctx, const double *R, const double *norms, uint32_t n, uint32_t d, const float *Q, uint32_t pitch, double *out,
+                             double *tail_part) {
+  const size_t lds = ((size_t)d * 33 + (size_t)8 * 32 * 33) * sizeof(float);
+  AS_HIP(ctx, hipFuncSetAttribute((const void *)zproj_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(zproj_mfma_kernel, dim3(cdiv(n, 256)), dim3(512), lds, ctx->stream, R, norms, n, d, Q, pitch, out, tail_part);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 template <class... A>
 int launch_zproj(as_ctx *ctx, uint32_t nv, unsigned grid, size_t lds, A... a) {
 #define AS_Z(NV)                                                                                                              \
@@ -427,6 +517,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   AS_TRY(Ypart.alloc(ctx, (size_t)y_blocks * kDirs * pitch));
   AS_TRY(Zs.alloc(ctx, (size_t)ns * 32));
   AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
+  uint32_t tail_parts = 0;  // (entries of tpart where the projection of all rows has a grid of its own)
   // the sample the directions are found on: rows 0, stride, 2 stride, ... of the matrix, or (sharded) the same rows side by side
   const double *s_rows = rows, *s_norms = norms;
   uint64_t s_stride = stride;
@@ -535,13 +626,17 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
       }
       AS_TRY(sr->gather_v(tpart.p, bytes.data(), offs.data()));
     }
+  } else if (zproj_mfma_applies(d) && ((uintptr_t)rows & 15) == 0 && ctx->opt_join_zproj_mfma) {
+    AS_TRY(tpart.alloc(ctx, zproj_mfma_parts(n)));  // (a tail sum per wave of THIS kernel's grid)
+    tail_parts = zproj_mfma_parts(n);
+    AS_TRY(launch_zproj_mfma(ctx, rows, norms, n, d, (const float *)Qd.p, pitch, Z, tpart.p));
   } else {
     AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, (const float *)Qd.p, pitch, Z, tpart.p));
   }
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
   if (Q_out) AS_HIP(ctx, hipMemcpyAsync(Q_out, Qd.p, sizeof(float) * (size_t)kDirs * pitch, hipMemcpyDeviceToDevice, ctx->stream));
-  std::vector<double> tp((size_t)z_grid * 4);
+  std::vector<double> tp(tail_parts ? (size_t)tail_parts : (size_t)z_grid * 4);
   AS_HIP(ctx, copy_d2h(ctx, tp.data(), tpart.p, tp.size() * sizeof(double)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
   double ts = 0.0;
@@ -559,8 +654,12 @@ int rotated_project_wide(as_ctx *ctx, const double *rows, const double *norms, u
   const size_t lds = (size_t)kDirs * pitch * sizeof(float);
   const uint32_t z_grid = std::min<uint32_t>((uint32_t)cdiv(n, 4), 256 * 8);
   DevBuf<double> tpart;
-  AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
-  AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, Q, pitch, Z, tpart.p));
+  if (zproj_mfma_applies(d) && ((uintptr_t)rows & 15) == 0 && ctx->opt_join_zproj_mfma && n >= 4096) {
+    AS_TRY(launch_zproj_mfma(ctx, rows, norms, n, d, Q, pitch, Z, nullptr));
+  } else {
+    AS_TRY(tpart.alloc(ctx, (size_t)z_grid * 4));
+    AS_TRY(launch_zproj(ctx, nv, z_grid, lds, rows, norms, (uint64_t)0, (uint64_t)1, n, d, Q, pitch, Z, tpart.p));
+  }
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
