@@ -1097,7 +1097,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       AS_TRY(pack_bf16(ctx, rows, norms, nullptr, 0, n, d, P16late.p, b_alloc));
       split_image = P16late.p;
     }
-    const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = second_h ? (bt + 3) & ~3u : (bt + 1) & ~1u, pad = b_al * kTileRows;
+    const uint32_t bt = (nf + kTileRows - 1) / kTileRows, b_al = (second_h || second_wide) ? (bt + 3) & ~3u : (bt + 1) & ~1u, pad = b_al * kTileRows;
     // The f16 pass behind a ONE-SIDED cone bound (cone_tiles.hip: the cones of the image's tiles are kept from the first pass): the
     // open rows are put in the order of the image first -- a wave's 64 rows are then neighbours, and most column tiles lie outside
     // what any of them can reach.
@@ -1173,9 +1173,29 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       ctx->stats["knn_join_cone_second"] = masked ? 1 : 0;
       AS_TRY(join_f16_search(ctx, split_image, n, d, PA.p, nf, theta_a.p, theta_a.p, zeros.p, zeros.p, 1.f, 0.f, cap2, cnt_b.p, cand_b.p,
                              unitc.p, "knn_mfma_join_f16_second", perm_used, nullptr, masked ? mask2.p : nullptr, cur_ids));
-    } else if (second_wide)
+    } else if (second_wide) {
+      // rows wider than 128: the rectangular int8 first pass of the search (prefilter_i8_rect: the open rows' rotated image against
+      // the rotated image of all rows) in front of the panelled one-sided pass, which then contracts only the pairs of super tiles
+      // it leaves -- 6 k open rows against 1 M x 768 were 11.7 ms of dense products
+      DevBuf<unsigned char> P8all, PA8, mask2;
+      bool masked = false;
+      if (oj && oj->wide_pre && oj->rot_z.p && ctx->opt_join_second_prefilter && pad % 512u == 0) {
+        const uint32_t tiles_all = packed_tiles_f16(n), a_tiles = pad / 128u;
+        double e_all = 0.0, e_a = 0.0;
+        AS_TRY(P8all.alloc(ctx, (size_t)tiles_all * 4 * 64 * 16));
+        AS_TRY(PA8.alloc(ctx, (size_t)a_tiles * 4 * 64 * 16));
+        AS_TRY(pack_rotated_from_z(ctx, oj->rot_z.p, perm_used, n, tiles_all, P8all.p, &e_all));
+        AS_TRY(pack_rotated_from_z(ctx, oj->rot_z.p, cur_ids, nf, a_tiles, PA8.p, &e_a));
+        const double E = std::max(e_all, e_a), delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + 1e-4;
+        const uint32_t T2i = (n + 511u) / 512u, a_supers = pad / 512u;
+        AS_TRY(mask2.alloc(ctx, (size_t)a_supers * 2 * T2i * 8));
+        AS_TRY(prefilter_i8_rect(ctx, P8all.p, n, PA8.p, a_supers, theta_a.p, delta8, mask2.p, "knn_join_second_prefilter"));
+        masked = true;
+      }
+      ctx->stats["knn_join_second_prefilter"] = masked ? 1 : 0;
       AS_TRY(join_f16_wide_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, "knn_mfma_join_f16_second",
-                                perm_used));
+                                perm_used, masked ? mask2.p : nullptr));
+    }
     else
       AS_TRY(join_bf16_rect(ctx, split_image, n, d, PA.p, nf, cur_ids, theta_a.p, cap2, cnt_b.p, cand_b.p, unitc.p,
                             "knn_mfma_join_bf16_second"));

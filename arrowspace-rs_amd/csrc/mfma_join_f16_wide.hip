@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void pair_join_f16_wide_kernel(const f16x8 
     for (;;) {
       const uint32_t v = atomicAdd(unit_counters + xcd, 1u);
       const uint32_t sb = xcd + 8u * (v >> 5), w = v & 31u;
-      if ((MODE == 0 || MODE == 4) && unit_list) {  // the wanted pairs are listed: XCD x takes the x-th of every eight runs of 32 entries
+      if ((MODE == 0 || MODE == 4 || MODE == 1) && unit_list) {  // the wanted pairs are listed: XCD x takes the x-th of every eight runs of 32 entries
         const uint32_t e = sb * 32u + w;
         if (sb * 32u >= n_list) {
           s_next[0] = 0xFFFFFFFFu;
@@ -697,8 +697,8 @@ static int launch_wide(as_ctx *ctx, const char *prof_name, const void *P, const 
   AS_HIP(ctx, hipMemsetAsync(counters.p, 0, 8 * sizeof(uint32_t), ctx->stream));
   DevBuf<uint2> unit_list;
   uint32_t n_list = 0;
-  if ((MODE == 0 || MODE == 4) && mask && ctx->opt_join_unit_list) {  // the wanted pairs, listed (wide_unit_list_kernel)
-    const int one_sided = MODE == 4;
+  if ((MODE == 0 || MODE == 4 || MODE == 1) && mask && ctx->opt_join_unit_list) {  // the wanted pairs, listed (wide_unit_list_kernel)
+    const int one_sided = MODE != 0;
     const uint32_t n_norm = (T2 - 1) / 2, l_max = one_sided ? T2 : 1 + n_norm + 1, n_ib = (I_count + 3) / 4, n_ob = (l_max + 7) / 8, n_sb = n_ib * n_ob;
     DevBuf<uint32_t> counts;
     DevBuf<uint64_t> offsets;
@@ -752,13 +752,15 @@ int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I
 
 // One-sided pass: the nA gathered rows (image PA: whole 256-row super tiles, zero padded; a_ids their global ids; theta_a
 // their thresholds by position, +inf on padding) against all n rows of P.  cnt / cand (by position; cnt zeroed by the caller).
+// mask (optional): what prefilter_i8_rect found for these rows (a word per 512-row super tile of the list and 256-column stage).
 int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
-                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm) {
+                       const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name, const uint32_t *perm,
+                       const unsigned char *mask) {
   const uint32_t KS = f16_ksteps(d);
   if (KS <= 8 || KS % kPK != 0) return fail(ctx, AS_ERR_UNSUPPORTED, "wide f16 join: dim not covered");
   const uint32_t T2 = (uint32_t)(((uint64_t)n + 511) / 512) * 2;
   return launch_wide<1>(ctx, prof_name, P, PA, a_ids, KS, T2, 0, (nA + kWS - 1) / kWS, nA, n, theta_a, cap, cnt, cand, nullptr, nullptr,
-                        nullptr, nullptr, 0.f, 0.f, perm);
+                        nullptr, nullptr, 0.f, 0.f, perm, mask, T2);
 }
 
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,

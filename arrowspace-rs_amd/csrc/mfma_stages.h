@@ -877,7 +877,7 @@ int join_f16_wide(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I
                   const unsigned char *mask = nullptr);
 int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const void *PA, uint32_t nA, const uint32_t *a_ids,
                        const float *theta_a, uint32_t cap, uint32_t *cnt, uint32_t *cand, const char *prof_name,
-                       const uint32_t *perm = nullptr);
+                       const uint32_t *perm = nullptr, const unsigned char *mask = nullptr);
 bool rotated_wide_supported(uint32_t d);
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
                       double *tail_out, const ShardedRows *sr = nullptr, float *Q_out = nullptr);
