@@ -766,6 +766,7 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
              void *P, uint32_t tiles);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
+int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
 
 // Thresholds of rows [row_begin, row_begin + row_count) (row_begin a multiple of 256) against the sample (ns ids, ns a
 // multiple of 256) for rows wider than 128: the contract of join_thresholds_f16 (mfma_theta_f16.hip).
@@ -810,9 +811,12 @@ int join_thresholds_f16_wide_grouped(as_ctx *ctx, const double *rows, const doub
   DevBuf<float> maxima;
   AS_TRY(ids.alloc(ctx, ns));
   AS_TRY(ranges.alloc(ctx, (size_t)2 * row_supers));
-  AS_TRY(grouped_sample_plan(ctx, perm, group_start, np, piv, piv_pitch, piv_dim, n, ids.p, ranges.p, near_pre));
+  // (the sampled rows as image POSITIONS, gathered from P_all itself -- 2 d bytes a row and no conversion, where the f64 rows were
+  // 8 d bytes and the division again: half a million sampled rows of 768 columns, 3 GB, at 1 M x 768; mfma_theta_f16.hip does the same)
+  AS_TRY(grouped_sample_plan(ctx, perm ? nullptr : perm, group_start, np, piv, piv_pitch, piv_dim, n, ids.p, ranges.p, near_pre));
   AS_TRY(PS.alloc(ctx, packed_vecs_f16(ns / kTileRows, d) * 16));
-  AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, ns, d, PS.p, ns / kTileRows));
+  if (perm) AS_TRY(pack_f16_from_image(ctx, P_all, n, ids.p, ns, d, PS.p, ns / kTileRows));
+  else AS_TRY(pack_f16(ctx, rows, norms, ids.p, 0, ns, d, PS.p, ns / kTileRows));
   AS_TRY(maxima.alloc(ctx, (size_t)row_supers * kWS * 64));
   AS_TRY(launch_wide<2>(ctx, "knn_join_thresholds", P_all, PS.p, ranges.p, KS, row_supers, 0, ns / kWS, n, ns, nullptr, 0, nullptr, nullptr,
                         maxima.p, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, 0, group_start, per / kWS));
