@@ -101,21 +101,24 @@ __global__ __launch_bounds__(256) void rerank_link_kernel(uint32_t row_begin, ui
             const uint32_t q = row2rec[j];
             if (q < row_count && q != r) {
               // the partner's header and its first 28 ids in one go (a record's ids start 16 bytes in); longer lists go on from there
+              // (records of wide rows -- SLOTS 4, 52 survivors a row at 768 columns -- : header + 60 ids at once: the loads that went
+              // on from 28 were a chain of six dependent round trips per lookup)
+              constexpr int kPre = SLOTS >= 4 ? 16 : 8;
               const uint4 *bq = reinterpret_cast<const uint4 *>(records + (size_t)q * W);
-              uint4 v[8];
+              uint4 v[kPre];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) v[u] = bq[u];
+              for (int u = 0; u < kPre; ++u) v[u] = bq[u];
               const uint32_t Cq = v[0].x & 0xFFu;
               uint32_t t = kNoIdx;
 #pragma unroll
-              for (int u = 1; u < 8; ++u) {
+              for (int u = 1; u < kPre; ++u) {
                 const uint32_t t0 = (uint32_t)(u - 1) * 4u;
                 if (t0 < Cq && v[u].x == a) t = t0;
                 if (t0 + 1 < Cq && v[u].y == a) t = t0 + 1;
                 if (t0 + 2 < Cq && v[u].z == a) t = t0 + 2;
                 if (t0 + 3 < Cq && v[u].w == a) t = t0 + 3;
               }
-              for (uint32_t t0 = 28; t0 < Cq; t0 += 4) {
+              for (uint32_t t0 = (uint32_t)(kPre - 1) * 4u; t0 < Cq; t0 += 4) {
                 const uint4 x = bq[1 + t0 / 4];
                 if (x.x == a) t = t0;
                 if (t0 + 1 < Cq && x.y == a) t = t0 + 1;
