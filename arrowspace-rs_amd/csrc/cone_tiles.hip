@@ -514,7 +514,9 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
                      sa.p, tmin.p, nmax.p);
   // Pivot groups of fewer than 400 rows (the row order drew further pivots: clusters of a few hundred rows): most tiles straddle two
   // of them, the bound on whole tiles is known to keep a tenth of the pairs or more -- the split form below is taken at once.
-  const bool can_split = cd.group_start && cd.groups && it_begin == 0 && it_count == ntiles && ctx->opt_join_cone_split_above_e3 >= 0 && ntiles >= 64;
+  // (its two bit matrices are four times the whole-tile one each: up to 2 GB apiece, i.e. up to ~8 M rows)
+  const bool can_split = cd.group_start && cd.groups && it_begin == 0 && it_count == ntiles && ctx->opt_join_cone_split_above_e3 >= 0 && ntiles >= 64 &&
+                         (uint64_t)(2u * ntiles) * ((2u * ntiles + 31u) / 32u) * sizeof(uint32_t) <= (2ull << 30);
   const bool split_first = can_split && (uint64_t)n < 400ull * cd.groups;
   if (!split_first) {
     // Data whose tiles are not cones (rows of many clusters in one tile, no directions to tell apart): more than half of the tiles

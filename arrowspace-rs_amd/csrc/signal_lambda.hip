@@ -1287,14 +1287,19 @@ static int tau_mean_launch(as_ctx *ctx, hipStream_t st, const double *X, uint64_
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
-static bool tau_bracket_applies(const as_ctx *ctx, uint64_t n_len, int mode) {
-  return (mode == AS_TAU_MEDIAN || mode == AS_TAU_PERCENTILE) && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_bracket;
+static uint32_t tau_bracket_cap(uint64_t n_len) {
+  const uint64_t rows_per = (n_len + kSelRowGroups - 1) / kSelRowGroups;
+  // (the bracket holds (2 w + 2) / 8192 of the ranks, w = 2.25 sqrt(8192) + 2: 5.1 %; room for 2.5 times that per row group)
+  return (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1024, (uint64_t)((double)rows_per * 0.051 * 2.5)));
+}
+// (S columns: the lists take S x 32 x cap keys -- 13 % of the matrix; beyond 4 GB of them the digit passes, which need none)
+static bool tau_bracket_applies(const as_ctx *ctx, uint64_t n_len, int mode, uint32_t S) {
+  return (mode == AS_TAU_MEDIAN || mode == AS_TAU_PERCENTILE) && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_bracket &&
+         (uint64_t)S * kSelRowGroups * tau_bracket_cap(n_len) * sizeof(unsigned long long) <= (4ull << 30);
 }
 static int tau_bracket_launch(as_ctx *ctx, hipStream_t st, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau, TauBracket &tb) {
   const uint32_t col_groups = (S + kSelCols - 1) / kSelCols;
-  const uint64_t rows_per = (n_len + kSelRowGroups - 1) / kSelRowGroups;
-  // (the bracket holds (2 w + 2) / 8192 of the ranks, w = 2.25 sqrt(8192) + 2: 5.1 %; room for 2.5 times that per row group)
-  const uint32_t cap = (uint32_t)std::max<uint64_t>(1024, (uint64_t)((double)rows_per * 0.051 * 2.5));
+  const uint32_t cap = tau_bracket_cap(n_len);
   AS_TRY(tb.br.alloc(ctx, S));
   AS_TRY(tb.part.alloc(ctx, (size_t)S * kSelRowGroups * 4));
   AS_TRY(tb.lists.alloc(ctx, (size_t)S * kSelRowGroups * cap));
@@ -1325,7 +1330,7 @@ static int signal_taus_impl(as_ctx *ctx, const double *X, uint64_t n_len, uint32
     TauMean tm;
     return tau_mean_launch(ctx, ctx->stream, X, n_len, S, tau, tm);
   }
-  if (!digits_only && tau_bracket_applies(ctx, n_len, mode)) {  // long columns: a sampled bracket and one pass
+  if (!digits_only && tau_bracket_applies(ctx, n_len, mode, S)) {  // long columns: a sampled bracket and one pass
     TauBracket tb;
     AS_TRY(tau_bracket_launch(ctx, ctx->stream, X, n_len, S, mode, arg, tau, tb));
     int h_fb = 0;
@@ -1425,7 +1430,7 @@ int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_
   AS_TRY(tau.alloc(ctx, S));
   // The order statistics need nothing of the graph and the sums nothing of tau: the bracket form runs on the context's side stream
   // UNDER the sums pass (0.45 ms of sampling, one pass over the columns and the pick, hidden behind 0.66 ms of sums at 1 M x 128).
-  if (tau_bracket_applies(ctx, n_len, mode) && ctx->opt_signal_tau_overlap) {
+  if (tau_bracket_applies(ctx, n_len, mode, S) && ctx->opt_signal_tau_overlap) {
     AS_TRY(ctx_side_stream(ctx));
     TauBracket tb;
     AS_HIP(ctx, hipEventRecord(ctx->side_start, ctx->stream));  // (X, tau may be blocks the main stream has just written or recycled)
