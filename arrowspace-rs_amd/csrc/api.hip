@@ -602,6 +602,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "nearest_mfma") ctx->opt_nearest_mfma = value;
   else if (n == "rerank_share") ctx->opt_rerank_share = value != 0;
   else if (n == "join_order_chain") ctx->opt_join_order_chain = value;
+  else if (n == "join_theta_band_auto") ctx->opt_join_theta_band_auto = value;
   else if (n == "join_second_prefilter") ctx->opt_join_second_prefilter = value;
   else if (n == "join_zproj_mfma") ctx->opt_join_zproj_mfma = value;
   else if (n == "join_cone_split_above_e3") ctx->opt_join_cone_split_above_e3 = value;

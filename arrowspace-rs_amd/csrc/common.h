@@ -102,6 +102,7 @@ struct as_ctx {
   int64_t opt_join_cone_split_above_e3 = 80;  // cone bound on tile pairs: where it keeps more than this many per mille it is taken again with two cones per tile, split where a pivot group ends (cone_tiles.hip; -1 = never)
   int64_t opt_join_zproj_mfma = 1;       // rotated coordinates of rows of 256 .. 1024 columns on the matrix pipe (rotate_wide.hip; 0: a wave per row, shuffle reductions)
   int64_t opt_join_second_prefilter = 1; // rows wider than 128: the rectangular int8 first pass in front of the one-sided second pass of the join (0 = off)
+  int64_t opt_join_theta_band_auto = 1;  // a band of 2 (the default) grows to 3 or 4 super tiles on either side where the clusters found by the row order hold more rows than it covers (0: as set)
   int64_t opt_join_order_chain = 1;      // row order of the join: the pivot groups laid out along a greedy chain of their pivots (1), the second pivot set too (2); 0: in the order the pivots were drawn
   int64_t opt_rerank_share = 1;          // exact re-rank of the join (rerank_pairs.h): a pair two rows both keep is scored once; 0: every row scores all of its survivors
   int64_t opt_rerank_stream_cap = 0;     // ... test hook: batches the slot stream gets room for at the first attempt (0: three per row)

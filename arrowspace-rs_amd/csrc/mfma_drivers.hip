@@ -482,13 +482,24 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   // by construction and its list is cut near its K-th best cosine instead of its 128th (mfma_theta_f16.hip,
   // join_thresholds_f16_band); the sampled threshold stays for rows whose neighbours live elsewhere.  Computed first: the check of
   // the grouped thresholds below looks at the thresholds the join will use.
-  const bool have_band = reorder && oj.Phown.p && ctx->opt_join_theta_band > 0 && (d <= 128 || wide_grouped) && K + 1 <= 32;
+  // ("join_theta_band" 2, the default, also means: 3 or 4 where the clusters the row order found hold more rows than 2 super tiles
+  // on either side cover -- row_order.hip, knn_join_order_cluster_rows)
+  uint32_t band_tiles = (uint32_t)std::max<int64_t>(0, ctx->opt_join_theta_band);
+  if (band_tiles == 2 && ctx->opt_join_theta_band_auto && reorder_wide) {
+    const int64_t cr = ctx->stats.count("knn_join_order_cluster_rows") ? ctx->stats["knn_join_order_cluster_rows"] : 0;
+    // (the estimate runs similar clusters together along the chain: 8.8 k for the bench mixture's 3.9 k-row clusters, 38 k for 15.6 k.
+    // Measured optima: 2 below ~4 k estimated rows -- 400 k x 384, the mixtures of 1 024 clusters and more --, 3 at 9 k -- 1 M x 128
+    // and x 768 --, 4 at 17 k and beyond -- 2 M and 4 M x 128.)
+    band_tiles = cr >= 16000 ? 4u : (cr >= 6000 ? 3u : 2u);
+  }
+  ctx->stats["knn_join_theta_band_tiles"] = band_tiles;
+  const bool have_band = reorder && oj.Phown.p && band_tiles > 0 && (d <= 128 || wide_grouped) && K + 1 <= 32;
   DevBuf<float> tband;
   if (have_band) {
     AS_TRY(tband.alloc(ctx, n));
     AS_HIP(ctx, hipMemsetAsync(tband.p, 0xFF, sizeof(float) * n, ctx->stream));  // (NaN where not computed: never the larger one)
-    if (d > 128) AS_TRY(join_thresholds_f16_wide_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p));
-    else AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, (uint32_t)ctx->opt_join_theta_band, K + 1, tband.p, pos_begin, pos_count));
+    if (d > 128) AS_TRY(join_thresholds_f16_wide_band(ctx, n, d, oj.Phown.p, band_tiles, K + 1, tband.p));
+    else AS_TRY(join_thresholds_f16_band(ctx, n, d, oj.Phown.p, band_tiles, K + 1, tband.p, pos_begin, pos_count));
   }
   auto merge_band = [&]() -> int {  // (own positions; the callers gather afterwards)
     if (have_band && pos_count)

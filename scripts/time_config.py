@@ -50,4 +50,4 @@ print("  stats:", {k: ctx.stat(k) for k in ("knn_join", "knn_join_prefilter", "k
                                             "knn_uncertified_rows", "knn_uncertified_rows_stage1a", "knn_join_blocks", "knn_join_overflow_rows", "knn_join_max_per_row",
                                             "knn_join_theta_grouped_bad", "knn_join_order_chain", "knn_rerank_open_list_ran_over", "knn_rerank_open_forced",
                                             "knn_rerank_open_undelivered", "knn_rerank_open_too_few", "knn_rerank_open_kth_not_clear", "knn_join_order_assign_off",
-                                            "knn_join_order_pivots", "knn_join_order_cover_rounds", "knn_join_order_cover_low_e3", "knn_join_order_cover_left_e3", "knn_join_order_far_rows", "knn_join_theta_far_rows", "knn_join_theta_dip_rows", "knn_join_cone_split", "knn_join_cone_tiles_kept_whole_e6", "order_tile_labels_q10", "order_tile_labels_q50", "order_tile_labels_q90", "order_tile_major_share_e3")})
+                                            "knn_join_order_pivots", "knn_join_order_cover_rounds", "knn_join_order_cover_low_e3", "knn_join_order_cover_left_e3", "knn_join_order_far_rows", "knn_join_theta_far_rows", "knn_join_theta_dip_rows", "knn_join_cone_split", "knn_join_cone_tiles_kept_whole_e6", "knn_join_order_cluster_rows", "knn_join_theta_band_tiles", "order_tile_labels_q10", "order_tile_labels_q50", "order_tile_labels_q90", "order_tile_major_share_e3")})
