@@ -24,6 +24,32 @@ namespace asx {
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
 constexpr double kTauFloor = 1e-10;  // src/taumode.rs:84
 
+// ---- one word of device memory that many waves update ------------------------------------------------------------------------
+// Read-modify-writes on ONE address are carried out at the memory side one after the other: ~90 per microsecond (measured, cone
+// bound of round 4), whatever the rest of the kernel does -- 32 768 waves adding to one counter cost the pruning kernel 0.36 ms
+// at any n, one atomicMax per wave of a packing pass 0.17 ms per million rows.
+// A maximum only grows, so a wave LOOKS first (a coherent load; loads do not queue behind each other) and sends its value only
+// where it would raise the word: a stale look costs one atomic, never a result.
+__device__ __forceinline__ void raise_max_u32(unsigned int *word, unsigned int v) {
+  if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(word, v);
+}
+__device__ __forceinline__ void raise_max_u64(unsigned long long *word, unsigned long long v) {
+  if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(word, v);
+}
+__device__ __forceinline__ void lower_min_u64(unsigned long long *word, unsigned long long v) {
+  if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > v) atomicMin(word, v);
+}
+// A sum has no such shortcut: the waves of a block add up in LDS first (every thread of the block must call this, once, at the
+// end of the kernel), and the blocks spread over `slots` words (a power of two; 1: one word) that the reader adds up.
+__device__ __forceinline__ void block_add_u64(unsigned long long *words, unsigned int slots, unsigned long long wave_total) {
+  __shared__ unsigned long long s_block_total;
+  if (threadIdx.x == 0) s_block_total = 0ull;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && wave_total) atomicAdd(&s_block_total, wave_total);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_block_total) atomicAdd(words + (blockIdx.x & (slots - 1u)), s_block_total);
+}
+
 struct ProfEntry {
   double ms = 0.0;
   uint64_t launches = 0;
@@ -38,6 +64,7 @@ struct PendingEvent {
 
 struct as_ctx {
   int device = 0;
+  const char *cur_scope = nullptr;  // innermost open ProfScope (profile on)
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;             // a second stream for work that runs under a pass of the main one (ctx_side_stream)
   hipEvent_t side_start = nullptr, side_done = nullptr;
@@ -100,6 +127,7 @@ struct as_ctx {
   int64_t opt_join_theta_far = 1;        // thresholds of the rows far from their pivot (row_order.hip) from the whole sample, not their group's (0 = off)
   int64_t opt_debug_label_mod = 0;       // diagnostic: rows carry the label (row mod this); statistics of the labels per image tile (row_order.hip)
   int64_t opt_join_cone_split_above_e3 = 80;  // cone bound on tile pairs: where it keeps more than this many per mille it is taken again with two cones per tile, split where a pivot group ends (cone_tiles.hip; -1 = never)
+  int64_t opt_join_pack_wide_tiles = 1;  // f16 image of rows of a multiple of 128 columns in one coalesced pass (mfma_join_f16.hip; 0: per fragment lane + a second read for the error)
   int64_t opt_join_zproj_mfma = 1;       // rotated coordinates of rows of 256 .. 1024 columns on the matrix pipe (rotate_wide.hip; 0: a wave per row, shuffle reductions)
   int64_t opt_join_second_prefilter = 1; // rows wider than 128: the rectangular int8 first pass in front of the one-sided second pass of the join (0 = off)
   int64_t opt_join_theta_band_auto = 1;  // a band of 2 (the default) grows to 3 or 4 super tiles on either side where the clusters found by the row order hold more rows than it covers (0: as set)
@@ -315,6 +343,8 @@ inline hipError_t copy_h2d(as_ctx *ctx, void *dst, const void *src, size_t bytes
   return e;
 }
 inline hipError_t copy_d2h(as_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  // (with the profile on: how many times the host waited for the stream to read something back, by the stage it was in)
+  if (ctx->prof_on) ++ctx->stats[std::string("host_reads_in_") + (ctx->cur_scope ? ctx->cur_scope : "no_stage")];
   hipError_t e = ensure_pinned(ctx);
   if (bytes <= kStageSlot) {
     if (e == hipSuccess && bytes) {
@@ -463,9 +493,12 @@ struct ProfScope {
   as_ctx *ctx;
   PendingEvent ev;
   bool active;
+  const char *outer = nullptr;
   ProfScope(as_ctx *c, const char *name) : ctx(c), active(c->prof_on) {
     if (!active) return;
     ev.name = name;
+    outer = ctx->cur_scope;
+    ctx->cur_scope = name;
     if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
       active = false;
       return;
@@ -474,6 +507,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (!active) return;
+    ctx->cur_scope = outer;
     (void)hipEventRecord(ev.stop, ctx->stream);
     ctx->pending.push_back(ev);
   }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(128) void cone_tile_kernel(const double *__restrict
   {
     float m = live ? nrm : 0.f;
     for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if ((t & 63) == 0 && m > 0.f) atomicMax(nmax_bits, __float_as_uint(m));  // non-negative floats order like their bits
+    if ((t & 63) == 0 && m > 0.f) raise_max_u32(nmax_bits, __float_as_uint(m));  // non-negative floats order like their bits
   }
   __syncthreads();
   // mean direction: coordinate k summed over the 128 rows in index order (the same sum in every run)

@@ -108,7 +108,7 @@ __global__ void degree_kernel(const uint32_t *__restrict__ nbr_idx, const double
   }
   unsigned long long v = c;
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(deg_sum, v);
+  block_add_u64(deg_sum, 1u, v);  // (one add per block: common.h)
 }
 
 // ---- K3b: weights + optional pruning (src/laplacian.rs:243-288) ------------------------------
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void degree_rows64_kernel(const uint32_t *__re
     lanes_sync();
   }
   for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-  if (lane == 0 && total) atomicAdd(deg_sum, total);
+  block_add_u64(deg_sum, 1u, total);  // (one add per block: common.h)
 }
 
 // a reverse edge as the scatter stores it: one 16-byte write instead of a 4-byte and an 8-byte one in two arrays

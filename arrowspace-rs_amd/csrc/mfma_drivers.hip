@@ -107,6 +107,7 @@ static int rerank_pairs_run(as_ctx *ctx, const double *rows, uint32_t d, uint64_
     AS_HIP(ctx, copy_d2h(ctx, h, st.counters.p, sizeof(h)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats["knn_rerank_batches"] = (int64_t)h[0];
+    for (int s = 0; s < kRpPairSlots; ++s) h[1] += h[kRpPairsAt + s];
     ctx->stats["knn_rerank_pairs_scored"] = (int64_t)h[1];
     ctx->stats["knn_rerank_stream_retries"] = attempt;
     ctx->stats["knn_rerank_open_list_ran_over"] = (int64_t)h[4];
@@ -835,8 +836,8 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         // two kernels (rerank_split.h): lists -> pruned records, then one stream of row batches per wave
         const int slots = d == 128 ? 2 : 4;  // 124 / 252 survivors per record
         AS_TRY(records.alloc(ctx, (size_t)row_count * rs_words(slots) + kRsRows));
-        AS_TRY(scored.alloc(ctx, 1));
-        AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long), ctx->stream));
+        AS_TRY(scored.alloc(ctx, kRsScoredSlots));
+        AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long) * kRsScoredSlots, ctx->stream));
         // the rows in the order of the image (a list of image positions is in that order already): neighbours share candidates
         const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n) ? oj->perm_own.p : nullptr;
         {
@@ -897,26 +898,24 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       }
       AS_HIP(ctx, hipGetLastError());
     }
-    {  // statistics: candidates per row over all sources
+    {  // statistics: candidates per row over all sources -- and, in the same read-back (each one is a wait for the stream), the
+      // survivors of the pruning and the number of rows left open
       DevBuf<unsigned long long> st;
-      AS_TRY(st.alloc(ctx, 3));
-      AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+      AS_TRY(st.alloc(ctx, 5));
+      AS_HIP(ctx, hipMemsetAsync(st.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
       hipLaunchKernelGGL(join_count_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, js->cnt, js->n_src * row_count,
                            js->cap, st.p);
-      unsigned long long h[3] = {0, 0, 0};
+      hipLaunchKernelGGL(join_tail_words_kernel, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)scored.p, kRsScoredSlots,
+                         (const uint32_t *)fail_count.p, st.p + 3);
+      unsigned long long h[5] = {0, 0, 0, 0, 0};
       AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
       ctx->stats["knn_join_cap"] = js->cap;
       ctx->stats["knn_join_candidates"] = (int64_t)h[0];
       ctx->stats["knn_join_max_per_row"] = (int64_t)h[1];
       ctx->stats["knn_join_overflow_rows"] = (int64_t)h[2];
-      if (scored.p) {  // candidates that survived the pruning: the rows the scoring kernel fetched
-        unsigned long long hs = 0;
-        AS_HIP(ctx, copy_d2h(ctx, &hs, scored.p, sizeof(hs)));
-        AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->stats["knn_rerank_scored"] = (int64_t)hs;
-      }
+      if (scored.p) ctx->stats["knn_rerank_scored"] = (int64_t)h[3];  // candidates that survived the pruning: the rows the scoring kernel fetched
+      n_fail = (uint32_t)h[4];
     }
-    AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
   } else {
     const uint32_t item_rows = use_f32 ? 2 * kTileRows : kTileRows;  // A rows per work item
     const uint32_t a_tiles_all = (row_count + kTileRows - 1) / kTileRows;

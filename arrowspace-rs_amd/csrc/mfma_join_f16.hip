@@ -119,13 +119,22 @@ __global__ void f16_image_gather_kernel(const f16x8 *__restrict__ src, uint64_t 
 // rounds to f16, writes the two halves to their place in an LDS copy of the tile's fragment layout and keeps the squared error
 // of its two values; a halving butterfly adds those over the 64 lanes per row (a fixed order), and the 32 KB tile goes out
 // with 16-byte stores.  Same values as pack_f16_kernel stores, same error measure as f16_row_error_kernel.
+// WIDE (rows of a multiple of 128 values, round 5): block (T, c) does the same for columns [128 c, 128 c + 128) of the tile's rows --
+// k steps [8 c, 8 c + 8) of the image, 32 KB that lie together -- and leaves the squared error of each row's piece in
+// part[position * chunks + c]; f16_error_reduce_kernel adds a row's pieces in index order.  (Before: the per-fragment-lane packer
+// + a second read of the rows for the error, 5.6 ms for 1 M x 768 = 2.2 TB/s over two reads.)
+template <bool WIDE>
 __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__restrict__ R, const double *__restrict__ norms,
                                                                const uint32_t *__restrict__ row_ids, uint64_t n, f16x8 *__restrict__ P,
-                                                               unsigned int *__restrict__ err_bits, float *__restrict__ err_rows) {
+                                                               unsigned int *__restrict__ err_bits, float *__restrict__ err_rows,
+                                                               uint32_t d, double *__restrict__ part) {
   constexpr int KS = 8;
   __shared__ f16x8 s_tile[KS * 4 * 64];  // 32 KB: [ks][s][lane]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t T = blockIdx.x;
+  // (WIDE: the blocks of a tile follow each other, so the pieces of a row are asked for close in time)
+  const uint32_t chunks = WIDE ? d / 128u : 1u, chunk = WIDE ? blockIdx.x % chunks : 0u;
+  const uint64_t T = WIDE ? blockIdx.x / chunks : blockIdx.x;
+  const uint64_t pitch = WIDE ? (uint64_t)d : 128u;
   typedef double pk_d2 __attribute__((ext_vector_type(2)));
   // lane l holds values k = 2 l, 2 l + 1 of a row: k step l / 8, half (l % 8) / 4, elements 2 (l % 4) and + 1 of that vector
   const int ks = lane >> 3, half = (lane >> 2) & 1, j2 = (lane & 3);
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__r
       live[b] = pos < n && !(row_ids && row_ids[pos] == 0xFFFFFFFFu);
       const uint64_t src = live[b] ? (row_ids ? (uint64_t)row_ids[pos] : pos) : 0;
       nr[b] = live[b] ? norms[src] : 0.0;
-      x[b] = reinterpret_cast<const pk_d2 *>(R + src * 128)[lane];
+      x[b] = reinterpret_cast<const pk_d2 *>(R + src * pitch + (uint64_t)chunk * 128u)[lane];
     }
     double e2[kBatch];
 #pragma unroll
@@ -184,20 +193,25 @@ __global__ __launch_bounds__(256) void pack_f16_tile128_kernel(const double *__r
       t += __shfl_xor(t, 4, 64);
       t += __shfl_xor(t, 2, 64);
       t += __shfl_xor(t, 1, 64);
-      const float e = (float)(__builtin_sqrt(t) * (1.0 + 1e-6));  // rounded up
-      if (e == e) worst = __builtin_fmaxf(worst, e);
-      // (the eight lanes of group (bits 5, 4, 3) hold the sum of row 4 b5 + 2 b4 + b3 of the batch) -- the plane error of each
-      // row by image position, for the per-pair bound of the pruning (rerank_split.h); NaN -> +inf: such a row prunes nothing
-      if (err_rows && (lane & 7) == 0) {
-        const uint64_t pos = T * kTileRows + (uint64_t)wv * 32 + (uint64_t)(r0 + 4 * (int)up5 + 2 * (int)up4 + (int)up3);
-        if (pos < n) err_rows[pos] = e == e ? e : __builtin_inff();
+      // (the eight lanes of group (bits 5, 4, 3) hold the sum of row 4 b5 + 2 b4 + b3 of the batch)
+      const uint64_t pos = T * kTileRows + (uint64_t)wv * 32 + (uint64_t)(r0 + 4 * (int)up5 + 2 * (int)up4 + (int)up3);
+      if (WIDE) {
+        if ((lane & 7) == 0 && pos < n) part[pos * chunks + chunk] = t;
+      } else {
+        const float e = (float)(__builtin_sqrt(t) * (1.0 + 1e-6));  // rounded up
+        if (e == e) worst = __builtin_fmaxf(worst, e);
+        // the plane error of each row by image position, for the per-pair bound of the pruning (rerank_split.h); NaN -> +inf: such
+        // a row prunes nothing
+        if (err_rows && (lane & 7) == 0 && pos < n) err_rows[pos] = e == e ? e : __builtin_inff();
       }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) worst = __builtin_fmaxf(worst, __shfl_xor(worst, o, 64));
-  if (lane == 0) atomicMax(err_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+  if (!WIDE) {
+    for (int o = 32; o > 0; o >>= 1) worst = __builtin_fmaxf(worst, __shfl_xor(worst, o, 64));
+    if (lane == 0) raise_max_u32(err_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+  }
   __syncthreads();
-  f16x8 *out = P + T * (uint64_t)(KS * 4 * 64);
+  f16x8 *out = P + (T * (uint64_t)chunks + chunk) * (uint64_t)(KS * 4 * 64);
 #pragma unroll
   for (int q = 0; q < KS * 4 * 64 / 256; ++q) out[q * 256 + tid] = s_tile[q * 256 + tid];
 }
@@ -215,7 +229,7 @@ __global__ void f16_error_reduce_kernel(const double *__restrict__ err_part, uin
     if (err_rows) err_rows[row] = ev == ev ? ev : __builtin_inff();  // (by image position: the pruning's bound per pair)
   }
   for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(e));  // non-negative floats order like their bits
+  if ((threadIdx.x & 63) == 0) raise_max_u32(out_bits, __float_as_uint(e));  // non-negative floats order like their bits
 }
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(lds_void *)p; }
@@ -1019,7 +1033,7 @@ __global__ __launch_bounds__(256) void f16_row_error_kernel(const double *__rest
     if (e == e) worst = __builtin_fmaxf(worst, e);
     if (err_rows && lane == 0) err_rows[pos] = e == e ? e : __builtin_inff();
   }
-  if (lane == 0) atomicMax(out_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+  if (lane == 0) raise_max_u32(out_bits, __float_as_uint(worst));  // non-negative floats order like their bits
 }
 
 // packs ALL n rows and leaves the measured plane error in ctx->f16_err (what join_delta certifies against)
@@ -1035,9 +1049,22 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
   AS_TRY(bits.alloc(ctx, 1));
   AS_HIP(ctx, hipMemsetAsync(bits.p, 0, sizeof(unsigned int), ctx->stream));
   const uint32_t KS = f16_ksteps(d);
+  ctx->stats["knn_join_pack_wide_tiles"] = 0;
   if (d == 128 && ((uintptr_t)R & 15) == 0) {
     ProfScope ps(ctx, "pack_unit_rows");
-    hipLaunchKernelGGL(pack_f16_tile128_kernel, dim3(tiles), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p, err_rows);
+    hipLaunchKernelGGL(pack_f16_tile128_kernel<false>, dim3(tiles), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p, err_rows,
+                       d, (double *)nullptr);
+    err_rows = nullptr;  // (written)
+  } else if (d % 128 == 0 && (uint64_t)tiles * (d / 128) < 0x7FFFFFFFull && ((uintptr_t)R & 15) == 0 && ctx->opt_join_pack_wide_tiles) {
+    // a multiple of 128 columns: the same pass, a block per (tile, 128 columns)
+    DevBuf<double> part;
+    const uint32_t chunks = d / 128;
+    ctx->stats["knn_join_pack_wide_tiles"] = 1;
+    AS_TRY(part.alloc(ctx, (size_t)n * chunks));
+    ProfScope ps(ctx, "pack_unit_rows");
+    hipLaunchKernelGGL(pack_f16_tile128_kernel<true>, dim3(tiles * chunks), dim3(256), 0, ctx->stream, R, norms, perm, n, (f16x8 *)P, bits.p,
+                       (float *)nullptr, d, part.p);
+    hipLaunchKernelGGL(f16_error_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)part.p, n, chunks, bits.p, err_rows);
     err_rows = nullptr;  // (written)
   } else if (KS <= 8) {
     // up to 128 columns: the plane error comes out of the packing pass (16 partial sums per row, 128 B against the 1 KB of a

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void image_absmax_kernel(const f16x8 *__restri
     for (int j = 0; j < 8; ++j) m = __builtin_fmaxf(m, __builtin_fabsf((float)v[j]));
   }
   for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) raise_max_u32(out_bits, __float_as_uint(m));
 }
 
 // int8 image from the f16 image (same tiles of 128 rows, same order of the rows):
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void i8_row_error_kernel(const double *__restr
     const float e = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6));
     if (e == e) worst = __builtin_fmaxf(worst, e);
   }
-  if (lane == 0) atomicMax(out_bits, __float_as_uint(worst));
+  if (lane == 0) raise_max_u32(out_bits, __float_as_uint(worst));
 }
 
 // integer thresholds: s8 >= T  <=>  s8 / (128 c)^2 >= theta - delta8  (kNever where the f16 kernel never lists: thr_scaled)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void rotate_pack_i8_kernel(const double *__res
   }
   float e = __builtin_sqrtf(e2) * (1.f + 1e-6f);
   for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(err_bits, __float_as_uint(e));
+  if ((threadIdx.x & 63) == 0) raise_max_u32(err_bits, __float_as_uint(e));
 }
 
 // smallest threshold of every 32 consecutive positions (the scalar side of the narrow kernel's block test)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void rotate_pack_i8_few_kernel(const double *__
     const size_t v = ((size_t)(p >> 7) * 4 + ((p >> 5) & 3)) * 64 + (p & 31);
     P8[v] = i32x4{(int)w0, (int)w1, (int)w2, (int)w3};
     P8[v + 32] = i32x4{(int)w4, (int)w5, (int)w6, (int)w7};
-    atomicMax(err_bits, __float_as_uint(__builtin_sqrtf(e2) * (1.f + 1e-6f)));
+    raise_max_u32(err_bits, __float_as_uint(__builtin_sqrtf(e2) * (1.f + 1e-6f)));
   }
 }
 

@@ -149,7 +149,7 @@ static __global__ void min_norm_kernel(const double *__restrict__ norms, uint32_
     if (x > 0.0 && x < v) v = x;  // smallest POSITIVE norm
   }
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMin(out, (unsigned long long)__double_as_longlong(v));
+  if ((threadIdx.x & 63) == 0) lower_min_u64(out, (unsigned long long)__double_as_longlong(v));
 }
 
 static __global__ void scatter_rows_kernel(const uint32_t *__restrict__ rows, uint32_t count, uint32_t K,
@@ -421,6 +421,20 @@ static __global__ void list_flagged_kernel(const uint32_t *__restrict__ flag, co
 static __global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) inv[perm[i]] = i;
+}
+
+// the words the host reads after the re-rank, next to each other: the survivors of the pruning (spread over `slots` words by
+// rerank_prune_kernel; parts == nullptr: no pruning ran) and the number of rows left open
+static __global__ void join_tail_words_kernel(const unsigned long long *__restrict__ parts, uint32_t slots, const uint32_t *__restrict__ fail_count,
+                                              unsigned long long *__restrict__ out) {
+  unsigned long long s = 0;
+  if (parts)
+    for (uint32_t i = threadIdx.x; i < slots; i += 64) s += parts[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    out[1] = *fail_count;
+  }
 }
 
 static __global__ void pad_theta_kernel(const float *__restrict__ theta, uint32_t n, uint32_t n_pad, float *__restrict__ out) {

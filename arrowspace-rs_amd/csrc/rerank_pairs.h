@@ -55,7 +55,9 @@ struct RpLayout {
 
 // counters of a call (device): [0] batches of the slot stream (allocated by the segments' atomics), [1] pairs scored, [2] set when the
 // stream ran out of room (nothing of it is then valid: the scoring kernel does not run and the host repeats the call with [0] batches)
-constexpr int kRpCounters = 12;  // ([4 .. 8]: why rows were left open, rerank_rank_kernel)
+constexpr int kRpPairSlots = 64;  // words the count of scored pairs is spread over (one word: ~90 adds per microsecond, common.h)
+constexpr int kRpPairsAt = 16;
+constexpr int kRpCounters = kRpPairsAt + kRpPairSlots;  // ([4 .. 8]: why rows were left open, rerank_rank_kernel; [16 .. 80): pairs scored, by block)
 
 // Link + layout (rerank_link_kernel), then -- behind an exclusive scan of the segments' batch counts, so that the stream is in the
 // order of the records whatever the order the workgroups run in: the scoring kernel's waves work side by side on one L2 -- the
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void rerank_link_kernel(uint32_t row_begin, ui
     __syncthreads();
   }
   for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-  if (lane == 0 && total) atomicAdd(&counters[1], total);
+  block_add_u64(counters + kRpPairsAt, (unsigned int)kRpPairSlots, total);
 }
 
 // seg_off: exclusive scan of seg_batches (seg_off[n_seg] = the stream's length, which the scoring kernel reads from there)

@@ -14,6 +14,7 @@ constexpr int kRsIdsAt = 4;            // word 0: count | overflow << 8 | force 
 __host__ __device__ constexpr int rs_max_ids(int slots) { return 64 * slots - kRsIdsAt; }  // survivor ids behind the header
 __host__ __device__ constexpr int rs_norms_at(int slots) { return 64 * slots; }            // their norms (f64): what GraphDistPolicy::key reads per pair
 __host__ __device__ constexpr int rs_words(int slots) { return 192 * slots; }              // 1.5 KB / 3 KB per row
+constexpr unsigned int kRsScoredSlots = 256;  // words the pruning kernel's count of survivors is spread over
 constexpr int kRsRows = 16;            // candidate rows per batch
 constexpr int kRsPitch = 1040;         // LDS pitch of a staged row (bytes)
 
@@ -37,6 +38,9 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
   uint32_t *ei = reinterpret_cast<uint32_t *>(es + cmax);
   float *ed = es + 2 * cmax;  // the bound of each pair (err_pos: the rows' plane errors by image position = what the lists hold)
   unsigned long long scored = 0;  // candidates this wave hands to the scoring kernel (the rows it fetches: bench.py's algorithmic bytes)
+  // (Tried in round 5: asking for the NEXT row's count and first 64 entries while this row is pruned -- two of the four dependent
+  // round trips of a row a row ahead.  1 M rows: 0.96 -> 1.18 ms: the 64 entries read whatever the count are a third more bytes
+  // than the lists hold and the registers they wait in cost occupancy.  Not kept.)
   for (uint32_t r = blockIdx.x * 4 + wv; r < row_count; r += gridDim.x * 4) {
     // (a_ids: the rows of the range as a list -- a rank of a build sharded by image positions finishes the rows perm[pb .. pe))
     const uint32_t a = order ? order[r] : (a_ids ? a_ids[r] : row_begin + r);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     }
     wave_sync();
   }
-  if (scored_total && lane == 0 && scored) atomicAdd(scored_total, scored);
+  if (scored_total) block_add_u64(scored_total, kRsScoredSlots, scored);  // (one word took 0.36 ms of adds: common.h)
 }
 
 typedef double rs_d2 __attribute__((ext_vector_type(2)));  // (a native vector: asm operands of struct type go through memory)

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void pack_from_z_kernel(const double *__restri
   }
   float e = __builtin_sqrtf(e2) * (1.f + 1e-6f);
   for (int o = 32; o > 0; o >>= 1) e = __builtin_fmaxf(e, __shfl_xor(e, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(err_bits, __float_as_uint(e));
+  if ((threadIdx.x & 63) == 0) raise_max_u32(err_bits, __float_as_uint(e));
 }
 
 // The same coordinates on the matrix pipe, for rows of 256 .. 1024 columns (a multiple of 32): Z = X Q is a GEMM of 2 n d 32 flop

@@ -16,7 +16,7 @@ __global__ void absmax_kernel(const double *__restrict__ v, uint64_t n, unsigned
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0) raise_max_u64(out, (unsigned long long)__double_as_longlong(m));
 }
 
 // ---- threshold scan of the search (stage 0 of K9) --------------------------------------------------

@@ -51,3 +51,6 @@ print("  stats:", {k: ctx.stat(k) for k in ("knn_join", "knn_join_prefilter", "k
                                             "knn_join_theta_grouped_bad", "knn_join_order_chain", "knn_rerank_open_list_ran_over", "knn_rerank_open_forced",
                                             "knn_rerank_open_undelivered", "knn_rerank_open_too_few", "knn_rerank_open_kth_not_clear", "knn_join_order_assign_off",
                                             "knn_join_order_pivots", "knn_join_order_cover_rounds", "knn_join_order_cover_low_e3", "knn_join_order_cover_left_e3", "knn_join_order_far_rows", "knn_join_theta_far_rows", "knn_join_theta_dip_rows", "knn_join_cone_split", "knn_join_cone_tiles_kept_whole_e6", "knn_join_order_cluster_rows", "knn_join_theta_band_tiles", "order_tile_labels_q10", "order_tile_labels_q50", "order_tile_labels_q90", "order_tile_major_share_e3")})
+# how many times the host waited for the stream to read something back, by stage (counted over the profiled calls, per call here)
+reads = {k: ctx.stat("host_reads_in_" + k) for k in list(prof.keys()) + ["no_stage"]}
+print("  host read-backs per call:", {k: round(v / reps, 1) for k, v in sorted(reads.items(), key=lambda kv: -kv[1]) if v > 0})

@@ -295,6 +295,33 @@ def test_item_graph_join_wide_rows_on_either_pipe(ctx, join_on, n, d, pipe):
     assert np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("n,d", [(1300, 256), (70_000, 384), (900, 1024)])
+def test_item_graph_image_of_wide_rows_in_one_pass(ctx, join_on, n, d):
+    """Rows of a multiple of 128 columns: the f16 image and the plane error of every row come out of ONE pass over the rows, a
+    workgroup per (128-row tile, 128 columns) ("join_pack_wide_tiles", round 5, mfma_join_f16.hip) -- the same stored values as the
+    per-fragment-lane packer, the same error measure summed in another order.  The tables are those of the older pair of passes
+    and the oracle's; zero rows, a tiny row and a row count that is no multiple of the tile included, and (70,000 rows) the image in
+    the library's own row order."""
+    X, _ = synth.mixture(n, d, seed=23, n_clusters=12, rank=4)
+    X[5] = 0.0
+    X[40] *= 1e-8
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_pack_wide_tiles") == 1
+    delta = ctx.stat("knn_join_delta_e9")
+    ctx.set_option("join_pack_wide_tiles", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_pack_wide_tiles") == 0
+        assert abs(ctx.stat("knn_join_delta_e9") - delta) <= 2  # the same measure (units of 1e-9), another order of the sum
+    finally:
+        ctx.set_option("join_pack_wide_tiles", 1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.unique(np.concatenate([[5, 40, n - 1], np.random.default_rng(4).choice(n, size=min(n, 60), replace=False)]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n,d", [(70_000, 128), (66_000, 64), (131_072, 100)])
 def test_item_graph_join_on_a_reordered_image(ctx, n, d):
     """From 65,536 rows on, the operand image of the join is packed with the rows grouped by direction (row_order.hip): at 128
