@@ -49,7 +49,10 @@ static int rerank_pairs_launch(as_ctx *ctx, RerankPairsState &st, uint64_t cap_b
   AS_TRY(st.seg_off.alloc(ctx, (size_t)n_seg + 1));
   {
     ProfScope ps(ctx, "knn_rerank_link");
-    hipLaunchKernelGGL((rerank_link_kernel<SLOTS>), dim3(std::min<uint32_t>(n_seg, 256u * 32u)), dim3(256), 0, ctx->stream, row_begin, row_count,
+    // (a workgroup per segment, a multiple of 8 of them: the kernel deals the segments by XCD; opt_rerank_link_xcd 0: the round
+    // robin over a capped grid that stood here)
+    const uint32_t link_grid = ctx->opt_rerank_link_xcd ? (n_seg + 7u) / 8u * 8u : std::min<uint32_t>(n_seg, 256u * 32u) | 1u;
+    hipLaunchKernelGGL((rerank_link_kernel<SLOTS>), dim3(link_grid), dim3(256), 0, ctx->stream, row_begin, row_count,
                        records, a_ids, order, row2rec, share, st.meta.p, st.rowpos.p, st.seg_batches.p, st.counters.p);
     AS_HIP(ctx, hipGetLastError());
     AS_TRY(exclusive_scan_u32_u64(ctx, st.seg_batches.p, n_seg, st.seg_off.p));
@@ -773,6 +776,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   OwnJoin oj_local;
   const OwnJoin *oj = js ? js->oj : nullptr;
   bool lists_by_pos = false;            // the lists of the own join are indexed by (and hold) image positions
+  bool rerank_order_rows = false;       // lists by row id, but the re-rank visits the rows in the order of the image (wide rows)
   DevBuf<uint32_t> cnt_own, cand_own;
   if (use_join) {
     if (own_join) {
@@ -798,7 +802,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
       // a row (rerank_split.h); other widths: the join kernel translates every entry where it appends it
       lists_by_pos = oj_local.reorder && d == 128 && !(ctx->opt_debug & 16) && ((uintptr_t)rows & 15) == 0 &&
                      ctx->opt_debug != 5;
-      if (lists_by_pos) {
+      // other widths with the image in the library's own order: the lists hold row ids, but the re-rank still visits the rows in the
+      // order of the image (rerank_order_rows below), for which it needs row -> place as well
+      rerank_order_rows = oj_local.reorder && !lists_by_pos && d != 128 && ctx->opt_rerank_image_order && !(ctx->opt_debug & 16) && ctx->opt_debug != 5;
+      if (lists_by_pos || rerank_order_rows) {
         AS_TRY(oj_local.inv_own.alloc(ctx, n));
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
@@ -839,7 +846,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(scored.alloc(ctx, kRsScoredSlots));
         AS_HIP(ctx, hipMemsetAsync(scored.p, 0, sizeof(unsigned long long) * kRsScoredSlots, ctx->stream));
         // the rows in the order of the image (a list of image positions is in that order already): neighbours share candidates
-        const uint32_t *score_order = (lists_by_pos && !a_ids && row_begin == 0 && row_count == n) ? oj->perm_own.p : nullptr;
+        // (rows wider than 128, round 5: the records used to lie in ROW order -- a row's partners anywhere among them: every lookup of
+        // the link kernel missed the L2, 106 M lines for 52 M lookups at 1 M x 768, and the scoring kernel's waves shared no rows)
+        const uint32_t *score_order = ((lists_by_pos || rerank_order_rows) && !a_ids && row_begin == 0 && row_count == n) ? oj->perm_own.p : nullptr;
+        if (score_order || !a_ids) ctx->stats["knn_rerank_image_order"] = score_order ? 1 : 0;  // (the re-rank of a list of open rows says nothing)
         {
           // the bound per pair from the rows' own plane errors, where the lists hold image positions and the image was packed here
           const float *err_pos = (lists_by_pos && ent_perm && join_on_f16(ctx, d) && oj->f16_err_pos.p && ctx->opt_rerank_pair_bound) ? oj->f16_err_pos.p : nullptr;
@@ -869,7 +879,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_HIP(ctx, hipGetLastError());
         {
           // every unordered pair scored once, the ranking in a kernel of its own (rerank_pairs.h)
-          const uint32_t *row2rec = score_order ? list_inv : nullptr;
+          const uint32_t *row2rec = score_order ? (const uint32_t *)oj->inv_own.p : nullptr;
           if (d == 128) AS_TRY(rerank_pairs_run<2>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
           else AS_TRY(rerank_pairs_run<4>(ctx, rows, d, n, (uint32_t)row_begin, row_count, records.p, K, rectify, bnd, out_dist, out_idx, fail1.p, fail_count.p, a_ids, score_order, row2rec));
         }

@@ -81,7 +81,19 @@ __global__ __launch_bounds__(256) void rerank_link_kernel(uint32_t row_begin, ui
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
   const uint32_t n_seg = (row_count + kRpSeg - 1) / kRpSeg;
   unsigned long long total = 0;
-  for (uint32_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+  // Which segments this workgroup takes: XCD x = blockIdx.x % 8 walks the x-th eighth of the records with its workgroups side by
+  // side (as the scoring kernel does with the stream), so that the workgroups that run at the same time on one L2 look up partners
+  // among the same few thousand records -- the records are in the order of the image, a row's partners its neighbours there.
+  // With the segments dealt round robin over the whole grid every lookup missed the L2 (1 M x 768: 106 M missed lines for 52 M
+  // lookups of two lines, 8.0 ms).
+  uint32_t seg_first = blockIdx.x, seg_last = n_seg, seg_stride = gridDim.x;
+  if (gridDim.x % 8u == 0u) {
+    const uint32_t x = blockIdx.x & 7u, chunk = (n_seg + 7u) / 8u;
+    seg_stride = gridDim.x / 8u;
+    seg_first = x * chunk + (blockIdx.x >> 3);
+    seg_last = min((x + 1u) * chunk, n_seg);
+  }
+  for (uint32_t seg = seg_first; seg < seg_last; seg += seg_stride) {
 #pragma unroll 1
     for (uint32_t i = 0; i < kRowsPerWave / 2; ++i) {
       const uint32_t l = (uint32_t)wv * kRowsPerWave + 2u * i + (uint32_t)half, r = seg * kRpSeg + l;

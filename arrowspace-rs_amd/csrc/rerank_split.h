@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     const uint32_t a = order ? order[r] : (a_ids ? a_ids[r] : row_begin + r);
     // lists kept by image POSITION (the own join on a permuted image, row_order.hip): row a's list sits at inv[a] and
     // holds positions; what leaves this kernel is row ids again
-    const uint32_t lr = order ? r : (inv ? inv[a] : r);
+    // (order without inv: the rows in the order of the image, the lists by ROW -- rows wider than 128)
+    const uint32_t lr = order ? (inv ? r : a - row_begin) : (inv ? inv[a] : r);
     // what the record's header needs, and the row's own error: asked for now, used at the end of the row
     const float th_a = theta[a];
     const double nrm_a = norms[a];

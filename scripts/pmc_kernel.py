@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""Mean of every counter of one kernel over its dispatches, from rocprofv3 --pmc csv output dirs.
-usage: pmc_kernel.py <kernel substring> <dir> [<dir> ...]"""
-import csv, glob, sys, collections
-pat = sys.argv[1]
-acc = collections.defaultdict(list)
-for d in sys.argv[2:]:
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        per = collections.defaultdict(float)
-        for row in csv.DictReader(open(f)):
-            if pat in row["Kernel_Name"]:
-                per[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
-        for (disp, name), v in per.items():
-            acc[name].append(v)
-for name, vals in sorted(acc.items()):
-    print("%-32s mean %.6g over %d dispatches (min %.6g max %.6g)" % (name, sum(vals) / len(vals), len(vals), min(vals), max(vals)))
+"""Sums the PMC counters of the kernels whose name contains `pattern` in a rocprofv3 --pmc output directory.
+usage: pmc_kernel.py <dir> <pattern>"""
+import csv
+import glob
+import sys
+
+d, pat = sys.argv[1], sys.argv[2]
+tot, n = {}, {}
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            k = r["Counter_Name"]
+            tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
+            n[k] = n.get(k, 0) + 1
+for k in sorted(tot):
+    print("%-28s %16.0f  over %d launches" % (k, tot[k], n[k]))
