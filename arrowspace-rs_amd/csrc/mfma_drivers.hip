@@ -1032,6 +1032,33 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   const uint32_t *cur_ids = gids.p;
   const uint32_t *cur_pos = fail1.p;
   uint32_t cur_n = n_fail;
+  // The open rows in the order of the join's image (round 5).  The ranking kernel appends them as its waves finish; in the order
+  // of the image the open rows of one neighbourhood follow each other, and the waves of the later stages that run side by side
+  // fetch the same candidate rows (1 M x 768: the second re-rank moves 4.8 M pairs x 6 KB).  Flags by position, a scan, the
+  // flagged positions in order: the same list whatever order the rows were appended in.
+  DevBuf<uint32_t> ord_flag, ord_pos, ord_ids, ord_rows;
+  DevBuf<uint64_t> ord_rank;
+  if (ctx->opt_join_open_order && oj && oj->reorder && oj->inv_own.p && oj->perm_own.p && !(js && js->a_ids) && row_begin == 0 && row_count == n &&
+      n_fail > 64) {
+    AS_TRY(ord_flag.alloc(ctx, n));
+    AS_TRY(ord_rank.alloc(ctx, (size_t)n + 1));
+    AS_TRY(ord_pos.alloc(ctx, n_fail));
+    AS_TRY(ord_ids.alloc(ctx, n_fail));
+    AS_HIP(ctx, hipMemsetAsync(ord_flag.p, 0, sizeof(uint32_t) * n, ctx->stream));
+    hipLaunchKernelGGL(flag_positions_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)gids.p, (const uint32_t *)oj->inv_own.p,
+                       n_fail, ord_flag.p);
+    AS_TRY(exclusive_scan_u32_u64(ctx, ord_flag.p, n, ord_rank.p));
+    hipLaunchKernelGGL(list_flagged_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ord_flag.p, (const uint64_t *)ord_rank.p, n,
+                       n_fail, ord_pos.p);
+    hipLaunchKernelGGL(rows_of_positions_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ord_pos.p,
+                       (const uint32_t *)oj->perm_own.p, n_fail, ord_ids.p);
+    AS_HIP(ctx, hipGetLastError());
+    cur_ids = ord_ids.p;  // (the whole matrix from row 0: a row's place in the output is its id)
+    cur_pos = ord_ids.p;
+    ctx->stats["knn_join_open_order"] = 1;
+  } else {
+    ctx->stats["knn_join_open_order"] = 0;
+  }
   DevBuf<uint32_t> ids_a, pos_a, ids_b, pos_b;
 
   auto mfma_stage = [&](bool f32, DevBuf<uint32_t> &ids_out, DevBuf<uint32_t> &pos_out, const char *stat) -> int {

@@ -34,6 +34,9 @@ __device__ __forceinline__ double exact_dot_seq(const double *__restrict__ x_lds
   if (((uintptr_t)b & 31) == 0) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     const d4 *b4 = reinterpret_cast<const d4 *>(b);
+    // (Tried in round 5: eight loads in flight per lane, then the 32 steps of their part of the chain.  No gain for the second
+    // re-rank of 1 M x 768 (8.9 ms for 4 840 open rows) and the search's re-rank of wide items went 7.9 -> 9.7 ms: the registers
+    // of the waiting loads cost more than the round trips they overlap.  Not kept.)
     for (; k + 4 <= d; k += 4) {
       const d4 v = __builtin_nontemporal_load(b4 + (k >> 2));
       acc = __dadd_rn(acc, __dmul_rn(x_lds[k], v.x));
@@ -417,6 +420,11 @@ static __global__ void list_flagged_kernel(const uint32_t *__restrict__ flag, co
                                            uint32_t *__restrict__ out) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n && flag[p] && rank[p] < room) out[rank[p]] = p;
+}
+// flag[inv[ids[i]]] = 1: the image positions of a list of rows (distinct rows: no two writes meet)
+static __global__ void flag_positions_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ inv, uint32_t count, uint32_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) flag[inv[ids[i]]] = 1u;
 }
 static __global__ void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
