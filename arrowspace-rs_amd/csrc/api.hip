@@ -592,6 +592,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_row_order") ctx->opt_join_row_order = value;
   else if (n == "join_prefilter") ctx->opt_join_prefilter = value;
   else if (n == "join_order_pivots") ctx->opt_join_order_pivots = value;
+  else if (n == "join_order_pivots_auto") ctx->opt_join_order_pivots_auto = value;
   else if (n == "join_theta_grouped_bad_e3") ctx->opt_join_theta_grouped_bad_e3 = value;
   else if (n == "join_theta_grouped") ctx->opt_join_theta_grouped = value;
   else if (n == "search_scan_order") ctx->opt_search_scan_order = value;
@@ -606,7 +607,6 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_second_prefilter") ctx->opt_join_second_prefilter = value;
   else if (n == "join_zproj_mfma") ctx->opt_join_zproj_mfma = value;
   else if (n == "join_pack_wide_tiles") ctx->opt_join_pack_wide_tiles = value;
-  else if (n == "rerank_link_xcd") ctx->opt_rerank_link_xcd = value;
   else if (n == "rerank_image_order") ctx->opt_rerank_image_order = value;
   else if (n == "join_open_order") ctx->opt_join_open_order = value;
   else if (n == "join_cone_split_above_e3") ctx->opt_join_cone_split_above_e3 = value;

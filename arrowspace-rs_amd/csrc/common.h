@@ -129,7 +129,6 @@ struct as_ctx {
   int64_t opt_join_cone_split_above_e3 = 80;  // cone bound on tile pairs: where it keeps more than this many per mille it is taken again with two cones per tile, split where a pivot group ends (cone_tiles.hip; -1 = never)
   int64_t opt_join_open_order = 1;       // the rows the first re-rank leaves open go on in the order of the join's image (0: as they were appended)
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
-  int64_t opt_rerank_link_xcd = 1;       // re-rank, link kernel: segments dealt by XCD, neighbours on one L2 (0: round robin over the grid)
   int64_t opt_join_pack_wide_tiles = 1;  // f16 image of rows of a multiple of 128 columns in one coalesced pass (mfma_join_f16.hip; 0: per fragment lane + a second read for the error)
   int64_t opt_join_zproj_mfma = 1;       // rotated coordinates of rows of 256 .. 1024 columns on the matrix pipe (rotate_wide.hip; 0: a wave per row, shuffle reductions)
   int64_t opt_join_second_prefilter = 1; // rows wider than 128: the rectangular int8 first pass in front of the one-sided second pass of the join (0 = off)
@@ -152,6 +151,7 @@ struct as_ctx {
                                               // (measured at 1 M x 128: 0.7 % -> 5.5 ms better than the plain pass, 2.9 % -> 7 ms worse; break-even ~1.4 %)
   int64_t opt_join_theta_grouped = 1;    // own join ordered by pivots of the rotated coordinates: thresholds against the sample of the nearest
                                          // groups (8.2 -> 1.7 ms at 1 M x 128), checked against the whole sample on 4096 rows
+  int64_t opt_join_order_pivots_auto = 1;  // ... 2048 where the default of 1024 stands and the matrix has more than 3 M rows (0: as set)
   int64_t opt_join_order_pivots = 1024;  // pivots of the row order found on the rotated coordinates (256 .. 4096; beyond 1024 a pivot may stand for 240 rows)
   int64_t opt_join_prefilter = 1;  // int8 first pass in front of the f16 join (dim <= 128; mfma_prefilter_i8.hip): 1 = on, the
                                    // rotated 32-wide image where it pays, 2 = full width always, 3 = rotated always, 0 = off

@@ -1154,9 +1154,17 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
                            rev_src.p, ucnt.p, r0);
     }
     AS_TRY(exclusive_scan_u32_u64(ctx, ucnt.p, nr, eptr.p));
-    if (ranked) AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));  // (a statistic here: one read-back for both)
-    AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + nr, sizeof(uint64_t)));
-    AS_HIP(ctx, hipStreamSynchronize(st));
+    if (ranked) {  // (the directed count is a statistic here: both words behind ONE wait for the stream)
+      AS_HIP(ctx, ensure_pinned(ctx));
+      uint64_t *two = reinterpret_cast<uint64_t *>(ctx->pinned);
+      AS_HIP(ctx, hipMemcpyAsync(two, rev_ptr.p + nr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      AS_HIP(ctx, hipMemcpyAsync(two + 1, eptr.p + nr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      AS_HIP(ctx, hipStreamSynchronize(st));
+      n_edges_dir = two[0];
+      n_union = two[1];
+    } else {
+      AS_HIP(ctx, copy_d2h(ctx, &n_union, eptr.p + nr, sizeof(uint64_t)));
+    }
   }
   const uint64_t nnz = n_union + nr;
   // the handle leaves through *out on success only: every early return below frees it and its slab

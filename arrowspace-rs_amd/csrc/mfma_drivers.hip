@@ -49,9 +49,8 @@ static int rerank_pairs_launch(as_ctx *ctx, RerankPairsState &st, uint64_t cap_b
   AS_TRY(st.seg_off.alloc(ctx, (size_t)n_seg + 1));
   {
     ProfScope ps(ctx, "knn_rerank_link");
-    // (a workgroup per segment, a multiple of 8 of them: the kernel deals the segments by XCD; opt_rerank_link_xcd 0: the round
-    // robin over a capped grid that stood here)
-    const uint32_t link_grid = ctx->opt_rerank_link_xcd ? (n_seg + 7u) / 8u * 8u : std::min<uint32_t>(n_seg, 256u * 32u) | 1u;
+    // (a workgroup per segment, a multiple of 8 of them: the kernel deals the segments by XCD)
+    const uint32_t link_grid = (n_seg + 7u) / 8u * 8u;
     hipLaunchKernelGGL((rerank_link_kernel<SLOTS>), dim3(link_grid), dim3(256), 0, ctx->stream, row_begin, row_count,
                        records, a_ids, order, row2rec, share, st.meta.p, st.rowpos.p, st.seg_batches.p, st.counters.p);
     AS_HIP(ctx, hipGetLastError());
@@ -445,8 +444,14 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     } else {
       AS_TRY(oj.order_piv.alloc(ctx, (size_t)4096 * 128));
       AS_TRY(oj.order_starts.alloc(ctx, 4097));
+      // The first pivots: 1 024, twice that beyond 3 M rows ("join_order_pivots_auto").  A pivot group of 4 k rows is 30 tiles of the
+      // image: at 4 M x 128 (256 clusters) 2 048 pivots leave the cone bound 2.7 % of the tile pairs instead of 3.4 %, no far rows
+      // (34 k), a quarter of the rows whose lists run over, and the grouped sample is half as large per row: 131.9 -> 118.6 ms
+      // (1 536: 118.8, 3 072: 120.6, 4 096: 130.9); at 1 M and 2 M rows 1 024 is the faster (18.4 / 19.2 ms, 42.7 / 44.0 ms).
+      uint32_t first_pivots = (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots);
+      if (ctx->opt_join_order_pivots_auto && first_pivots == 1024 && n > 3000000u) first_pivots = 2048;
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
-                           (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots), oj.order_starts.p, &oj.order_np, 4096,
+                           first_pivots, oj.order_starts.p, &oj.order_np, 4096,
                            &oj.far_pos, &oj.far_count, &oj.order_near));
     }
     AS_TRY(oj.theta_pos.alloc(ctx, n));

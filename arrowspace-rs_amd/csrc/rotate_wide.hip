@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void zproj_tile_kernel(const double *__restric
 // Rows of exactly 128 values, 16-byte aligned: the same coordinates again (the same four chains per direction, the same divisions),
 // with a workgroup staging 64 WHOLE rows -- every wave instruction a full 1-KB row, sixteen of them in flight per wave, divided
 // by the norm and kept in LDS as f32 -- and four threads per row taking eight directions each.  The chunked form above moves the
-// GB of a million rows in 0.8 ms; this one runs at the speed of the loads.  tail_part: [block][4 waves], blocks of 64 rows.
+// GB of a million rows in 0.8 ms; this one in 0.5 ms (its LDS reads: 144 bytes per 32 multiply-adds).  The matrix-pipe form of
+// the wider rows (zproj_mfma_kernel) was measured here in round 5: 0.74 ms.  tail_part: [block][4 waves], blocks of 64 rows.
 __global__ __launch_bounds__(256) void zproj_rows128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
                                                             const float *__restrict__ Q, uint32_t pitch, double *__restrict__ out,
                                                             double *__restrict__ tail_part) {

@@ -100,7 +100,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *  the join's preparation
  *   "join_prefilter" (1)        int8 first pass in front of the f16 join, from "join_prefilter_min_rows" (65536) rows: 1 = on the rotated
  *                               32-wide image (31 dominant directions + the tail norm), 2 = full-width image always, 3 = rotated always, 0 = off
- *   "join_row_order" (1)        rows grouped by direction in the operand image: "join_order_pivots" (1024) pivots on the rotated coordinates,
+ *   "join_row_order" (1)        rows grouped by direction in the operand image: "join_order_pivots" (1024; 2048 beyond 3 M rows while the
+ *                               default stands) pivots on the rotated coordinates,
  *                               "join_order_sub" (4): inside a group by a second set of pivots / 4, "join_order_chain" (1): the groups laid
  *                               out along a greedy chain of similar pivots (neighbours of a row end up near it in the image);
  *                               "join_order_cover" (150): where more than this many per mille of the rows lie far from their pivot (data

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs on the MI355X box (gpurun): the default bench line, the rocprofv3 kernel stats of the same command and the PMC
-# passes behind `traffic` / the clock table.  usage: scripts/profile_round.sh <tag, e.g. r03a> <commit>
+# Runs on the MI355X box (gpurun): the rocprofv3 kernel stats of the bench command, the PMC passes behind `traffic` / the clock
+# table, and then the default bench line (which quotes those passes).  usage: scripts/profile_round.sh <tag, e.g. r03a> <commit>
 # Every pass is checked: a failed rocprofv3 run stops the script instead of leaving empty or stale artefacts behind.
 set -eu -o pipefail
 TAG=$1; COMMIT=${2:-unknown}
@@ -8,8 +8,6 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 need() { [ -s "$1" ] || { echo "profile_round: $1 is missing or empty" >&2; exit 1; }; }
 first() { local f; f=$(find "$1" -name "$2" | head -1); [ -n "$f" ] || { echo "profile_round: no $2 under $1" >&2; exit 1; }; echo "$f"; }
-python3 bench.py > $OUT/${TAG}_bench_1M_default.json 2> $OUT/bench_default.err || { tail -c 2000 $OUT/bench_default.err; exit 1; }
-need $OUT/${TAG}_bench_1M_default.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-config-legs > $OUT/${TAG}_bench_1M_under_rocprof.json 2> $OUT/rocprof_stats.err
 cp "$(first $OUT/stats '*kernel_stats.csv')" $OUT/${TAG}_bench_1M_kernel_stats.csv
 # (ONE build in these passes -- a kernel's total over the pass is its traffic per step: the item-graph lambda leg, which builds a
@@ -28,4 +26,9 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output
 python3 scripts/pmc_clock.py $OUT/pmc_clock > $OUT/${TAG}_pmc_clock.txt 2>&1
 need $OUT/${TAG}_pmc_clock.txt
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_s $OUT/pmc_write_s $OUT/pmc_clock
+# the default bench line LAST, with this round's PMC passes in place (profiles/ of this box's copy of the repository): its
+# `traffic` then comes from the sources it runs from and `traffic_stale` is false
+cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic_spmm.json profiles/
+python3 bench.py > $OUT/${TAG}_bench_1M_default.json 2> $OUT/bench_default.err || { tail -c 2000 $OUT/bench_default.err; exit 1; }
+need $OUT/${TAG}_bench_1M_default.json
 head -c 1500 $OUT/${TAG}_bench_1M_default.json; echo; head -12 $OUT/${TAG}_bench_1M_kernel_stats.csv | cut -c1-160; cat $OUT/${TAG}_pmc_clock.txt | cut -c1-200 | head

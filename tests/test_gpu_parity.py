@@ -334,13 +334,16 @@ def test_item_graph_rerank_of_wide_rows_in_the_order_of_the_image(ctx, join_on, 
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
     idx, dist = A.knn_cosine(X, gp)
     assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_row_order") == 1 and ctx.stat("knn_rerank_image_order") == 1
-    ctx.set_option("rerank_image_order", 0)
-    try:
-        idx0, dist0 = A.knn_cosine(X, gp)
-        assert ctx.stat("knn_rerank_image_order") == 0
-    finally:
-        ctx.set_option("rerank_image_order", 1)
-    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    open_rows, open_ordered = ctx.stat("knn_uncertified_rows"), ctx.stat("knn_join_open_order")
+    assert open_ordered == (1 if open_rows > 64 else 0)  # ("join_open_order": the rows left open go on in the order of the image too)
+    for option, stat in (("rerank_image_order", "knn_rerank_image_order"), ("join_open_order", "knn_join_open_order")):
+        ctx.set_option(option, 0)
+        try:
+            idx0, dist0 = A.knn_cosine(X, gp)
+            assert ctx.stat(stat) == 0
+        finally:
+            ctx.set_option(option, 1)
+        assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
     sample = np.concatenate([[9, 91, 6000, 6029], np.sort(np.random.default_rng(5).choice(n, size=40, replace=False))])
     oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
