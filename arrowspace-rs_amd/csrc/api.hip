@@ -609,6 +609,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_pack_wide_tiles") ctx->opt_join_pack_wide_tiles = value;
   else if (n == "rerank_image_order") ctx->opt_rerank_image_order = value;
   else if (n == "join_open_order") ctx->opt_join_open_order = value;
+  else if (n == "join_cone_groups") ctx->opt_join_cone_groups = value;
   else if (n == "join_cone_split_above_e3") ctx->opt_join_cone_split_above_e3 = value;
   else if (n == "debug_label_mod") ctx->opt_debug_label_mod = value;
   else if (n == "signal_tau_bracket") ctx->opt_signal_tau_bracket = value;

@@ -127,6 +127,7 @@ struct as_ctx {
   int64_t opt_join_theta_far = 1;        // thresholds of the rows far from their pivot (row_order.hip) from the whole sample, not their group's (0 = off)
   int64_t opt_debug_label_mod = 0;       // diagnostic: rows carry the label (row mod this); statistics of the labels per image tile (row_order.hip)
   int64_t opt_join_cone_split_above_e3 = 80;  // cone bound on tile pairs: where it keeps more than this many per mille it is taken again with two cones per tile, split where a pivot group ends (cone_tiles.hip; -1 = never)
+  int64_t opt_join_cone_groups = 1;      // cone bound on tile pairs: a coarse level first, every tile's rows against the cones around 32 tiles (from 2048 tiles on; 0: one level)
   int64_t opt_join_open_order = 1;       // the rows the first re-rank leaves open go on in the order of the join's image (0: as they were appended)
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_join_pack_wide_tiles = 1;  // f16 image of rows of a multiple of 128 columns in one coalesced pass (mfma_join_f16.hip; 0: per fragment lane + a second read for the error)

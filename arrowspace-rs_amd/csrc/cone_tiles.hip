@@ -37,7 +37,8 @@ constexpr float kEpsM = 1.5e-3f, kEpsCone = 1e-5f, kEpsTheta = 2e-4f;
 __global__ __launch_bounds__(128) void cone_tile_kernel(const double *__restrict__ Z, const uint32_t *__restrict__ perm, uint32_t n,
                                                         const float *__restrict__ theta, f16x8 *__restrict__ rows_img,
                                                         f16x8 *__restrict__ dirs_img, float *__restrict__ cos_a, float *__restrict__ sin_a,
-                                                        float *__restrict__ theta_min, unsigned int *__restrict__ nmax_bits) {
+                                                        float *__restrict__ theta_min, unsigned int *__restrict__ nmax_bits,
+                                                        float *__restrict__ mean_out = nullptr) {
   __shared__ float s_u[128][kCK + 1];
   __shared__ float s_m[kCK];
   __shared__ float s_red[128];
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(128) void cone_tile_kernel(const double *__restrict
     if (t < (uint32_t)o) s_red[t] = __builtin_fminf(s_red[t], s_red[t + o]);
     __syncthreads();
   }
+  if (mean_out && t < kCK) mean_out[(size_t)T * kCK + t] = s_m[t] * minv;  // (the unit mean direction, or zeros: cone_group_kernel)
   if (t == 0) {
     float ca = (minv > 0.f && ca_raw <= 1.5f) ? __builtin_fminf(__builtin_fmaxf(ca_raw - kEpsCone, -1.f), 1.f) : -1.f;
     if (ca_raw > 1.5f) ca = 1.f;  // no live row: nothing to bound (its thresholds are +inf as well)
@@ -144,15 +146,84 @@ __device__ __forceinline__ float max16f(const v16f32 &a) {
   return __builtin_fmaxf(m, a[15]);
 }
 
+// ---- a cone around 32 tiles (round 5): the coarse level of the n^2 pass ----------------------------------------------------------
+// The pass below meets every tile's rows with every tile's direction: 8 MFMAs per pair of tiles, 9.4 ms at 4 M rows where it
+// keeps 2.7 % of the pairs.  The 32 tiles of a direction group (4 096 positions of the ordered image: a cluster or two) lie in a
+// cone of their own: direction M = the normalised sum of their mean directions, half angle = the largest (angle(M, m_T) + a_T)
+// over its tiles (the triangle inequality on the sphere: every row of tile T lies within a_T of m_T).  cone_max_kernel runs once
+// against these directions (1/32 of the products) and then skips, tile by tile, the groups whose cone cannot reach the tile's rows --
+// a bound on a superset of the rows bounds each of them, so the bits it leaves out are bits the fine test could only have set for
+// pairs that cannot reach a threshold either.  One workgroup of 64 threads per group; lane l < 32 = tile 32 G + l.
+__global__ __launch_bounds__(64) void cone_group_kernel(const float *__restrict__ mean, const float *__restrict__ cos_a, const float *__restrict__ sin_a,
+                                                        const float *__restrict__ theta_min, uint32_t ntiles, f16x8 *__restrict__ dirs_img,
+                                                        float *__restrict__ cos_g, float *__restrict__ sin_g, float *__restrict__ theta_g) {
+  __shared__ float s_mean[32][kCK + 1];
+  __shared__ float s_M[kCK];
+  const uint32_t G = blockIdx.x, l = threadIdx.x, T = G * 32u + (l & 31u);
+  const bool tile = l < 32u && T < ntiles;
+  float m[kCK];
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) m[k] = tile ? mean[(size_t)T * kCK + k] : 0.f;
+  if (l < 32u) {
+#pragma unroll
+    for (int k = 0; k < kCK; ++k) s_mean[l][k] = m[k];
+  }
+  __syncthreads();
+  if (l < (uint32_t)kCK) {  // coordinate l summed over the tiles in index order (the same sum in every run)
+    float sum = 0.f;
+    for (int t = 0; t < 32; ++t) sum += s_mean[t][l];
+    s_M[l] = sum;
+  }
+  __syncthreads();
+  float mm = 0.f;
+#pragma unroll
+  for (int k = 0; k < kCK; ++k) mm = __builtin_fmaf(s_M[k], s_M[k], mm);
+  const float minv = mm > 0.f ? 1.f / __builtin_sqrtf(mm) : 0.f;
+  float c = 2.f, th = __builtin_inff();  // (2: a tile that does not exist or has no threshold says nothing)
+  if (tile) {
+    th = theta_min[T];
+    const float ca = cos_a[T], sa = sin_a[T];
+    if (th < __builtin_inff()) {
+      float cb = 0.f;
+#pragma unroll
+      for (int k = 0; k < kCK; ++k) cb = __builtin_fmaf(m[k], s_M[k] * minv, cb);
+      cb = __builtin_fminf(__builtin_fmaxf(cb - kEpsCone, -1.f), 1.f);  // angle(M, m_T), rounded up
+      const float sb = __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - cb * cb)) + 1e-6f;
+      // cos(angle(M, m_T) + a_T), rounded down; -1 where the two angles add up to pi or more, where the tile has no direction
+      // (ca = -1) or the group has none
+      c = (minv > 0.f && ca > -1.f && cb > -ca) ? __builtin_fmaxf(cb * ca - sb * sa - kEpsCone, -1.f) : -1.f;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    c = __builtin_fminf(c, __shfl_xor(c, o, 64));
+    th = __builtin_fminf(th, __shfl_xor(th, o, 64));
+  }
+  if (l == 0) {
+    const float cg = c > 1.5f ? 1.f : c;  // (no tile with a threshold: nothing to bound, theta_g = +inf says so as well)
+    cos_g[G] = cg;
+    sin_g[G] = __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - cg * cg)) + 1e-6f;
+    theta_g[G] = th;
+  }
+  if (l < 4u) {  // the group's direction as "row" G of a direction image (the layout cone_tile_kernel writes)
+    const uint32_t ks = l >> 1, h = l & 1u, Gd = G >> 7, sdx = (G & 127u) >> 5, r = G & 31u;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)(s_M[16 * ks + 8 * h + j] * minv);
+    dirs_img[(((size_t)Gd * 2 + ks) * 4 + sdx) * 64 + r + 32 * h] = v;
+  }
+}
+
 // bit1[J * words + g], bit b: can a row of tile J and a row of tile I = 32 g + b reach a threshold, by the cone of I and the
-// exact products of J's rows with I's direction?  One wave per PAIR of row tiles of [jt_begin, jt_begin + jt_count) (the direction
+// exact products of J's rows with I's direction?  (theta_dir: the smallest thresholds of the directions' tiles -- theta_min itself,
+// or those of the groups when the directions are cone_group_kernel's; coarse: that pass's bits, groups it excluded are skipped.)  One wave per PAIR of row tiles of [jt_begin, jt_begin + jt_count) (the direction
 // fragments serve both), sweeping the direction groups [dg_begin, dg_begin + dg_count); the fragments of the next group are
 // requested before the products of this one.
 __global__ __launch_bounds__(256, 4) void cone_max_kernel(const f16x8 *__restrict__ rows_img, const f16x8 *__restrict__ dirs_img,
                                                        uint32_t jt_begin, uint32_t jt_count, uint32_t dg_begin, uint32_t dg_count,
                                                        uint32_t ntiles, const float *__restrict__ cos_a, const float *__restrict__ sin_a,
                                                        const float *__restrict__ theta_min, const unsigned int *__restrict__ nmax_bits,
-                                                       uint32_t words, uint32_t *__restrict__ bit1) {
+                                                       uint32_t words, uint32_t *__restrict__ bit1, const float *__restrict__ theta_dir,
+                                                       const uint32_t *__restrict__ coarse, uint32_t words_c, uint32_t groups_c) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t wid = blockIdx.x * 4u + (uint32_t)wv;
   if (2u * wid >= jt_count) return;
@@ -180,14 +251,34 @@ __global__ __launch_bounds__(256, 4) void cone_max_kernel(const f16x8 *__restric
   // same trip makes the compiler wait for everything requested before it -- the prefetched fragments too)
   auto dir_cone = [&](uint32_t g, float &th, float &c, float &sn) {
     const uint32_t I = min(g * 32u + (uint32_t)lc, ntiles - 1u);
-    th = theta_min[I];
+    th = theta_dir[I];
     c = cos_a[I];
     sn = sin_a[I];
   };
   f16x8 b0 = dir_frag(dg_begin, 0), b1 = dir_frag(dg_begin, 1);
   float thI, ca, sa;
   dir_cone(dg_begin, thI, ca, sa);
+  bool have = true;           // b0 / b1 / the cones hold group g's
+  uint32_t cw = 0xFFFFFFFFu;  // the coarse pass's bits of these two tiles for the groups 32 (g >> 5) ..
   for (uint32_t g = dg_begin; g < g_end; ++g) {
+    if (coarse && ((g & 31u) == 0u || g == dg_begin)) {
+      const uint32_t w = g >> 5;
+      cw = w < words_c ? (coarse[(size_t)J0 * words_c + w] | coarse[(size_t)J1 * words_c + w]) : 0xFFFFFFFFu;
+    }
+    if (coarse && g < groups_c && !((cw >> (g & 31u)) & 1u)) {  // no row of either tile reaches the cone around the group's 32 tiles
+      if (lane == 0) {
+        bit1[(size_t)J0 * words + g] = 0u;
+        if (two) bit1[(size_t)J1 * words + g] = 0u;
+      }
+      have = false;  // (what was requested ahead was this group's: the next group that is not skipped asks for its own)
+      continue;
+    }
+    if (!have) {
+      b0 = dir_frag(g, 0);
+      b1 = dir_frag(g, 1);
+      dir_cone(g, thI, ca, sa);
+      have = true;
+    }
     const uint32_t gn = g + 1 < g_end ? g + 1 : g;
     const f16x8 n0 = dir_frag(gn, 0), n1 = dir_frag(gn, 1);
     float thN, caN, saN;
@@ -488,6 +579,7 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   const uint32_t it_begin = pos_begin / 128u, it_count = std::min(ntiles - std::min(ntiles, it_begin), (pos_count + 127u) / 128u);
   ProfScope ps(ctx, "knn_join_cone_tiles");
   ctx->stats["knn_join_cone_split"] = 0;
+  ctx->stats["knn_join_cone_groups"] = 0;
   // (keep: the directions, the cones and the largest norm stay with the caller, for the one-sided bound of the second pass)
   ConeDirs local;
   ConeDirs &cd = keep ? *keep : local;
@@ -510,8 +602,10 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   AS_HIP(ctx, hipMemsetAsync(dirs_img.p, 0, (size_t)dir_tiles * 2 * 4 * 64 * 16, ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(nmax.p, 0, sizeof(unsigned int), ctx->stream));
   AS_HIP(ctx, hipMemsetAsync(kept.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
+  DevBuf<float> mean;  // the tiles' unit mean directions (the coarse level of the pass: cone_group_kernel)
+  if (ctx->opt_join_cone_groups && ntiles >= 2048u) AS_TRY(mean.alloc(ctx, (size_t)ntiles * kCK));
   hipLaunchKernelGGL(cone_tile_kernel, dim3(ntiles), dim3(128), 0, ctx->stream, Z, perm, n, theta, (f16x8 *)rows_img.p, (f16x8 *)dirs_img.p, ca.p,
-                     sa.p, tmin.p, nmax.p);
+                     sa.p, tmin.p, nmax.p, mean.p);
   // Pivot groups of fewer than 400 rows (the row order drew further pivots: clusters of a few hundred rows): most tiles straddle two
   // of them, the bound on whole tiles is known to keep a tenth of the pairs or more -- the split form below is taken at once.
   // (its two bit matrices are four times the whole-tile one each: up to 2 GB apiece, i.e. up to ~8 M rows)
@@ -541,25 +635,47 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
   const uint32_t all_groups = words;
   if (split_first) {
   } else if (it_begin == 0 && it_count == ntiles) {
+    // two levels from 2 048 tiles on: every tile's rows against the cones around 32 tiles first (cone_group_kernel)
+    const uint32_t n_groups = (ntiles + 31u) / 32u, words_c = (n_groups + 31u) / 32u;
+    const bool two_level = ctx->opt_join_cone_groups && ntiles >= 2048u && mean.p;
+    DevBuf<unsigned char> dirs_g;
+    DevBuf<float> ca_g, sa_g, tmin_g;
+    DevBuf<uint32_t> bit_g;
+    if (two_level) {
+      const size_t dir_bytes = (size_t)((n_groups + 127u) / 128u) * 2 * 4 * 64 * 16;
+      AS_TRY(dirs_g.alloc(ctx, dir_bytes));
+      AS_TRY(ca_g.alloc(ctx, n_groups));
+      AS_TRY(sa_g.alloc(ctx, n_groups));
+      AS_TRY(tmin_g.alloc(ctx, n_groups));
+      AS_TRY(bit_g.alloc(ctx, (size_t)ntiles * words_c));
+      AS_HIP(ctx, hipMemsetAsync(dirs_g.p, 0, dir_bytes, ctx->stream));
+      hipLaunchKernelGGL(cone_group_kernel, dim3(n_groups), dim3(64), 0, ctx->stream, (const float *)mean.p, (const float *)ca.p, (const float *)sa.p,
+                         (const float *)tmin.p, ntiles, (f16x8 *)dirs_g.p, ca_g.p, sa_g.p, tmin_g.p);
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_g.p, 0u,
+                         ntiles, 0u, words_c, n_groups, (const float *)ca_g.p, (const float *)sa_g.p, (const float *)tmin.p,
+                         (const unsigned int *)nmax.p, words_c, bit_g.p, (const float *)tmin_g.p, (const uint32_t *)nullptr, 0u, 0u);
+    }
+    ctx->stats["knn_join_cone_groups"] = two_level ? 1 : 0;
     hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, 0u, all_groups, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                       (const unsigned int *)nmax.p, words, bit1.p);
+                       (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)(two_level ? bit_g.p : nullptr),
+                       words_c, n_groups);
   } else if (it_count) {
     // a range of row tiles (a rank of a sharded build): its rows against every direction, and every tile's rows against its directions
     AS_HIP(ctx, hipMemsetAsync(bit1.p, 0, sizeof(uint32_t) * (size_t)ntiles * words, ctx->stream));
     const uint32_t g0 = it_begin / 32u, g1 = (it_begin + it_count + 31u) / 32u;
     hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, g0, g1 - g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                       (const unsigned int *)nmax.p, words, bit1.p);
+                       (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
     // (the rows of the range against the directions outside it; the groups [g0, g1) were written above, by the same rule)
     if (g0 > 0)
       hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, 0u, g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                         (const unsigned int *)nmax.p, words, bit1.p);
+                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
     if (g1 < all_groups)
       hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, g1, all_groups - g1, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                         (const unsigned int *)nmax.p, words, bit1.p);
+                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
   }
   if (it_count && !split_first) {
     const uint32_t ig0 = it_begin / 32u, ig1 = (it_begin + it_count + 31u) / 32u;

@@ -458,6 +458,40 @@ def test_item_graph_first_pass_behind_the_cone_bound(ctx, n, d, topk):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d,clusters,rank", [(262144 + 4500, 64, 60, 5), (300_000, 96, 900, 16)])
+def test_item_graph_cone_bound_with_a_coarse_level(ctx, n, d, clusters, rank):
+    """"join_cone_groups" (round 5, cone_tiles.hip): from 2 048 tiles on, the n^2 pass of the cone bound first meets every tile's rows
+    with the cones around 32 tiles (direction: the normalised sum of the tiles' mean directions, half angle: the largest angle to
+    a tile's mean plus that tile's own) and skips the groups such a cone excludes (4 M x 128: 9.7 -> 3.6 ms).  A bound on a superset
+    of the rows: the pairs it keeps are at most those of the one-level pass, the lists leave no more rows open than a few, and the
+    tables are the same and the oracle's.  A ragged last group of tiles, duplicates, a zero row."""
+    X, _ = synth.mixture(n, d, seed=41, n_clusters=clusters, rank=rank)
+    X[50:58] = X[7]
+    X[13] = 0.0
+    gp = A.GraphParams(0.6, 16, 16, 2.0, 0.25)
+    ctx.set_option("join_cone_tiles_max_e3", 1000)   # (taken whatever share of the tile pairs the bound keeps)
+    try:
+        ctx.set_option("join_cone_groups", 0)
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_cone_tiles") == 1 and ctx.stat("knn_join_cone_groups") == 0
+        kept0, split0, open0 = ctx.stat("knn_join_cone_tiles_kept_e6"), ctx.stat("knn_join_cone_split"), ctx.stat("knn_uncertified_rows")
+        ctx.set_option("join_cone_groups", 1)
+        idx, dist = A.knn_cosine(X, gp)
+        kept1, split1, open1 = ctx.stat("knn_join_cone_tiles_kept_e6"), ctx.stat("knn_join_cone_split"), ctx.stat("knn_uncertified_rows")
+        assert ctx.stat("knn_join_cone_tiles") == 1
+    finally:
+        ctx.set_option("join_cone_groups", 1)
+        ctx.set_option("join_cone_tiles_max_e3", 600)
+    assert split0 == split1
+    if not split1:  # (where the split form ran at once the whole-tile pass, and with it the coarse level, did not)
+        assert ctx.stat("knn_join_cone_groups") == 1 and 0 < kept1 <= kept0, (kept0, kept1)
+    assert open1 <= open0 + max(2, open0 // 100), (open0, open1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.unique(np.concatenate([[7, 13, 50, 57, n - 1], np.random.default_rng(6).choice(n, size=60, replace=False)]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n,d,clusters,rank", [(131072 + 300, 128, 700, 24), (300_000, 64, 1500, 32), (70144, 256, 420, 24)])
 def test_item_graph_row_order_draws_more_pivots_where_the_first_set_covers_too_little(ctx, n, d, clusters, rank):
     """"join_order_cover" (round 5, row_order.hip): where many rows lie far from their pivot -- data with more clusters than the
