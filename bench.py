@@ -59,6 +59,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
 
 from source_sha import source_sha16  # noqa: E402
+import bench_line  # noqa: E402
 
 SOURCE_SHA16 = source_sha16(ROOT)
 
@@ -852,7 +853,12 @@ def main():
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, lambda a, b: Xd[a:b].cpu().numpy(), cent, n)
-        print(json.dumps(out))
+        # The full record goes to bench_detail.json; stdout carries ONE small line (bench_line.py: below 6 KB, strict JSON) -- round 5's
+        # 23 KB line could not be parsed by the driver.
+        out["detail_file"] = "bench_detail.json"
+        bench_line.write_detail(out, ROOT)
+        sys.stdout.flush()
+        print(bench_line.compact_line(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
