@@ -4,7 +4,7 @@
 //
 // The first pass sweeps every pair of rows with a 32-wide product that bounds their cosine from above, cos(i, j) <= z_i . z_j
 // (z: the 31 rotated coordinates and the tail norm, rotate_wide.hip).  On an image ordered by direction 97 % of the pairs of 512-row
-// super tiles hold no pair at its threshold (scripts/explore_super_level.py) -- but a bound on a pair of GROUPS from centre and
+// super tiles hold no pair at its threshold (scripts/attic/explore_super_level.py) -- but a bound on a pair of GROUPS from centre and
 // radius is useless (it flags 79 %): the slack of both radii floods the gap between thresholds and inter-cluster products.  The
 // bound here is one-sided: the rows of tile I sit in a cone of half angle a_I around their mean direction u_I, and the EXACT
 // largest product of the rows of tile J with u_I is computed (an n x n/128 product on the matrix pipe: 1/128 of the pass).  On the
@@ -179,11 +179,15 @@ __global__ __launch_bounds__(64) void cone_group_kernel(const float *__restrict_
 #pragma unroll
   for (int k = 0; k < kCK; ++k) mm = __builtin_fmaf(s_M[k], s_M[k], mm);
   const float minv = mm > 0.f ? 1.f / __builtin_sqrtf(mm) : 0.f;
-  float c = 2.f, th = __builtin_inff();  // (2: a tile that does not exist or has no threshold says nothing)
+  float c = 2.f, th = __builtin_inff();  // (2: a tile that does not exist or has no live row says nothing)
   if (tile) {
     th = theta_min[T];
     const float ca = cos_a[T], sa = sin_a[T];
-    if (th < __builtin_inff()) {
+    // every tile with a live row widens the group's cone, whatever its thresholds: cone_max_kernel's fine test bounds a pair with
+    // min(theta_I, theta_J), so a tile whose own thresholds are all +inf can still be matched through its partner's finite one,
+    // and a group cone that left its rows out would let the coarse level clear that pair's bit.  (ca = 1 exactly is cone_tile_kernel's
+    // mark for "no live row": a live row gives ca <= 1 - kEpsCone.)  th only feeds theta_g.
+    if (ca < 1.f) {
       float cb = 0.f;
 #pragma unroll
       for (int k = 0; k < kCK; ++k) cb = __builtin_fmaf(m[k], s_M[k] * minv, cb);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(64) void cone_group_kernel(const float *__restrict_
     th = __builtin_fminf(th, __shfl_xor(th, o, 64));
   }
   if (l == 0) {
-    const float cg = c > 1.5f ? 1.f : c;  // (no tile with a threshold: nothing to bound, theta_g = +inf says so as well)
+    const float cg = c > 1.5f ? 1.f : c;  // (no tile with a live row: nothing to bound, theta_g = +inf says so as well)
     cos_g[G] = cg;
     sin_g[G] = __builtin_sqrtf(__builtin_fmaxf(0.f, 1.f - cg * cg)) + 1e-6f;
     theta_g[G] = th;

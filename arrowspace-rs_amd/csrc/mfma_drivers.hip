@@ -394,6 +394,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     pos_begin = 0;
     pos_count = n;
   }
+  // the figures of stages that may not run in this call: a call that skips a stage must not report the call before's
+  for (const char *k : {"knn_join_order_cover_rounds", "knn_join_order_pivots", "knn_join_order_cover_low_e3", "knn_join_order_chain",
+                        "knn_join_theta_far_rows", "knn_join_theta_dip_rows"})
+    ctx->stats[k] = 0;
   // sr (ShardedRows, common.h): `rows` is null until somebody needs the f64 rows of OTHER ranks (need_rows: the steps that have no
   // form on the rank's own rows -- the plain row order, the plain thresholds, widths the sharded packing does not cover); on the
   // path the benchmark shapes take nothing in here does, and the caller starts their all-gather behind this function

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void theta_bins_select_kernel(const float *__re
 // ---- the sample by pivot group (own join with the row order found on the rotated coordinates, row_order.hip) -------------------
 // The 4th best product of a row against a 1-in-32 sample of all rows is a product with a row of its own cluster: with the
 // image ordered by 1024 pivots, restricting a row's sample to the sampled rows of the 16 pivot groups nearest to its own
-// moves the threshold of 0.5 % of the rows by more than 1e-3 and of none by 1e-2 (scripts/explore_theta_window.py) -- and
+// moves the threshold of 0.5 % of the rows by more than 1e-3 and of none by 1e-2 (scripts/attic/explore_theta_window.py) -- and
 // any threshold is correct -- for 1.7 % of the products.  So every group gets its own small sample image (the sampled rows
 // of its nearest groups, group_tiles() tiles, zero rows beyond), and a unit sweeps the images of the groups it covers.
 constexpr uint32_t kGroupNear = 16;

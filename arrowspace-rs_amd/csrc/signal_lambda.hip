@@ -1151,8 +1151,8 @@ static int signal_stream_prepare(as_ctx *ctx, as_csr *L) {
   const uint32_t cus = (uint32_t)std::max(8, prop.multiProcessorCount);
   // Default: ONE chunk per wave, so the dispatcher hands the chunks out in order as waves retire and the window of rows in
   // flight on an XCD stays compact whatever the pace of its CUs (measured at 1 M x 128, rows by cluster: 0.67 ms against 0.97 ms
-  // for waves that are all resident and interleave their chunks statically -- their window drifts apart).  "signal_waves" > 0
-  // fixes the wave count instead (then a wave owns several chunks, cut as described above).
+  // for waves that are all resident and interleave their chunks statically -- their window drifts apart; the option that fixed the
+  // wave count instead was removed in round 5).
   uint32_t wx_max = 0x7FFFFFF0u / 8;
   (void)blocks_per_cu, (void)cus;
   const uint32_t ch = 16;  // consecutive rows a wave takes at a time (8 / 32 measured: no better)
@@ -1297,13 +1297,19 @@ static bool tau_bracket_applies(const as_ctx *ctx, uint64_t n_len, int mode, uin
   return (mode == AS_TAU_MEDIAN || mode == AS_TAU_PERCENTILE) && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_bracket &&
          (uint64_t)S * kSelRowGroups * tau_bracket_cap(n_len) * sizeof(unsigned long long) <= (4ull << 30);
 }
-static int tau_bracket_launch(as_ctx *ctx, hipStream_t st, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau, TauBracket &tb) {
-  const uint32_t col_groups = (S + kSelCols - 1) / kSelCols;
+// the buffers first, apart from the launches: a caller that cannot have the lists (hipMalloc fails: up to 4 GB of them) takes the digit
+// passes, which need none, instead of failing -- and nothing has been queued on any stream by then
+static int tau_bracket_alloc(as_ctx *ctx, uint64_t n_len, uint32_t S, TauBracket &tb) {
   const uint32_t cap = tau_bracket_cap(n_len);
   AS_TRY(tb.br.alloc(ctx, S));
   AS_TRY(tb.part.alloc(ctx, (size_t)S * kSelRowGroups * 4));
   AS_TRY(tb.lists.alloc(ctx, (size_t)S * kSelRowGroups * cap));
   AS_TRY(tb.n_fb.alloc(ctx, 1));
+  return AS_OK;
+}
+static int tau_bracket_launch(as_ctx *ctx, hipStream_t st, const double *X, uint64_t n_len, uint32_t S, int mode, double arg, double *tau, TauBracket &tb) {
+  const uint32_t col_groups = (S + kSelCols - 1) / kSelCols;
+  const uint32_t cap = tau_bracket_cap(n_len);
   AS_HIP(ctx, hipMemsetAsync(tb.n_fb.p, 0, sizeof(int), st));
   AS_HIP(ctx, hipFuncSetAttribute((const void *)sel_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kBrSample * sizeof(unsigned long long))));
   hipLaunchKernelGGL(sel_sample_kernel, dim3(S), dim3(1024), 2 * kBrSample * sizeof(unsigned long long), st, X, (uint64_t)S, n_len, mode, arg, tb.br.p);
@@ -1332,12 +1338,16 @@ static int signal_taus_impl(as_ctx *ctx, const double *X, uint64_t n_len, uint32
   }
   if (!digits_only && tau_bracket_applies(ctx, n_len, mode, S)) {  // long columns: a sampled bracket and one pass
     TauBracket tb;
-    AS_TRY(tau_bracket_launch(ctx, ctx->stream, X, n_len, S, mode, arg, tau, tb));
-    int h_fb = 0;
-    AS_HIP(ctx, copy_d2h(ctx, &h_fb, tb.n_fb.p, sizeof(int)));
-    ctx->stats["signal_tau_bracket_fallback_columns"] = h_fb;
-    if (h_fb == 0) return AS_OK;
-    // (some column's bracket missed or its list ran over: the digit passes for all of them)
+    // (the only thing that can fail in there is hipMalloc: no room for the lists -> the digit passes, which need none)
+    const int rc_alloc = tau_bracket_alloc(ctx, n_len, S, tb);
+    if (rc_alloc == AS_OK) {
+      AS_TRY(tau_bracket_launch(ctx, ctx->stream, X, n_len, S, mode, arg, tau, tb));
+      int h_fb = 0;
+      AS_HIP(ctx, copy_d2h(ctx, &h_fb, tb.n_fb.p, sizeof(int)));
+      ctx->stats["signal_tau_bracket_fallback_columns"] = h_fb;
+      if (h_fb == 0) return AS_OK;
+    }
+    // (some column's bracket missed or its list ran over, or there was no room for the lists: the digit passes for all of them)
   }
   DevBuf<SelState> st;
   DevBuf<uint32_t> hist;
@@ -1420,6 +1430,16 @@ int signal_lambda_finish(as_ctx *ctx, const double *X, uint32_t S, as_csr *L, co
   return AS_OK;
 }
 
+// Once anything has been queued on the context's side stream no exit may hand the buffers it uses back to the workspace cache (which
+// orders blocks against the MAIN stream only) before the side stream has run: declared behind those buffers, drained in front of them.
+struct SideDrain {
+  as_ctx *ctx;
+  bool armed = false;
+  ~SideDrain() {
+    if (armed) (void)hipStreamSynchronize(ctx->side);
+  }
+};
+
 // lambdas of the S columns of X (n_len x S) against L (n <= n_len), one GPU
 int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_csr *L, int mode, double arg, double *out) {
   if (S == 0) return AS_OK;
@@ -1430,17 +1450,29 @@ int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_
   AS_TRY(tau.alloc(ctx, S));
   // The order statistics need nothing of the graph and the sums nothing of tau: the bracket form runs on the context's side stream
   // UNDER the sums pass (0.45 ms of sampling, one pass over the columns and the pick, hidden behind 0.66 ms of sums at 1 M x 128).
-  if (tau_bracket_applies(ctx, n_len, mode, S) && ctx->opt_signal_tau_overlap) {
+  TauBracket tb;  // (declared in front of the guard: the guard drains the side stream BEFORE these blocks go back to the cache)
+  bool bracket = tau_bracket_applies(ctx, n_len, mode, S) && ctx->opt_signal_tau_overlap;
+  if (bracket) {
+    // (the only thing that can fail in there is hipMalloc) no room for the lists: the digit passes on the main stream (below)
+    if (tau_bracket_alloc(ctx, n_len, S, tb) != AS_OK) {
+      bracket = false;
+      tb.br.release(), tb.part.release(), tb.lists.release(), tb.n_fb.release();
+    }
+  }
+  const bool digits_only = tau_bracket_applies(ctx, n_len, mode, S) && ctx->opt_signal_tau_overlap && !bracket;
+  if (bracket) {
     AS_TRY(ctx_side_stream(ctx));
-    TauBracket tb;
+    SideDrain drain{ctx};
     AS_HIP(ctx, hipEventRecord(ctx->side_start, ctx->stream));  // (X, tau may be blocks the main stream has just written or recycled)
     AS_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->side_start, 0));
+    drain.armed = true;  // from here on every exit waits for the side stream before tb's blocks are released
     AS_TRY(tau_bracket_launch(ctx, ctx->side, X, n_len, S, mode, arg, tau.p, tb));
     AS_HIP(ctx, hipMemcpyAsync(ctx->side_word, tb.n_fb.p, sizeof(int), hipMemcpyDeviceToHost, ctx->side));
     AS_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side));
     const int rc_sums = signal_sums(ctx, X, n_len, S, L, L->n, n_len, sums.p);
     // (the side stream is drained before anything of it goes out of scope, whatever the sums pass returned)
     AS_HIP(ctx, hipStreamSynchronize(ctx->side));
+    drain.armed = false;
     const int h_fb = *ctx->side_word;
     AS_TRY(rc_sums);
     AS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
@@ -1453,20 +1485,23 @@ int signal_lambdas(as_ctx *ctx, const double *X, uint64_t n_len, uint32_t S, as_
   if (mode == AS_TAU_MEAN && n_len >= (uint64_t)kBrMinLen && ctx->opt_signal_tau_overlap) {  // the column means likewise (no read-back)
     AS_TRY(ctx_side_stream(ctx));
     TauMean tm;
+    SideDrain drain{ctx};
     AS_HIP(ctx, hipEventRecord(ctx->side_start, ctx->stream));
     AS_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->side_start, 0));
+    drain.armed = true;
     AS_TRY(tau_mean_launch(ctx, ctx->side, X, n_len, S, tau.p, tm));
     AS_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side));
     const int rc_sums = signal_sums(ctx, X, n_len, S, L, L->n, n_len, sums.p);
     AS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     // (tm's blocks go back to the cache of the main stream, which has just been told to wait for their last use)
+    drain.armed = false;
     AS_TRY(rc_sums);
     ctx->stats["signal_tau_overlapped"] = 1;
     AS_TRY(signal_lambda_finish(ctx, X, S, L, sums.p, tau.p, out));
     return AS_OK;
   }
   ctx->stats["signal_tau_overlapped"] = 0;
-  AS_TRY(signal_taus(ctx, X, n_len, S, mode, arg, tau.p));
+  AS_TRY(signal_taus_impl(ctx, X, n_len, S, mode, arg, tau.p, digits_only));
   AS_TRY(signal_sums(ctx, X, n_len, S, L, L->n, n_len, sums.p));
   AS_TRY(signal_lambda_finish(ctx, X, S, L, sums.p, tau.p, out));
   return AS_OK;

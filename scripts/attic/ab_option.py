@@ -1,0 +1,25 @@
+"""A / B of one context option on the item graph of the bench (1 M x 128): wall time of build_laplacian_matrix and the
+profile groups, the two settings interleaved on the same box.  usage: python scripts/ab_option.py <option> <a> <b> [n]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
+import torch
+import arrowspace_amd as A
+from arrowspace_amd import synth
+opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+n, d = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000, 128
+ctx = A.default_context()
+Xd, _ = synth.mixture_device(n, d, "cuda", seed=42)
+gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+for rep in range(3):
+    for v in (va, vb):
+        ctx.set_option(opt, v)
+        ctx.profile(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        gl = A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+        ctx.synchronize(); dt = time.perf_counter() - t0
+        pr = ctx.profile_all(); ctx.profile(False)
+        top = sorted(pr.items(), key=lambda kv: -kv[1][0])[:7]
+        print("%s=%d  build %.2f ms  nnz %d  " % (opt, v, dt * 1e3, gl.matrix.nnz()) + "  ".join("%s %.2f" % (k.replace("knn_", ""), ms) for k, (ms, _) in top), flush=True)
+        del gl
