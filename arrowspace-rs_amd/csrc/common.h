@@ -130,6 +130,7 @@ struct as_ctx {
   int64_t opt_join_cone_groups = 1;      // cone bound on tile pairs: a coarse level first, every tile's rows against the cones around 32 tiles (from 2048 tiles on; 0: one level)
   int64_t opt_join_open_order = 1;       // the rows the first re-rank leaves open go on in the order of the join's image (0: as they were appended)
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
+  int64_t opt_join_fused_rows_pass = 1;  // rows of exactly 128 values: rotated coordinates and f16 image from ONE pass over the rows (rotate_wide.hip; 0: two passes)
   int64_t opt_join_pack_wide_tiles = 1;  // f16 image of rows of a multiple of 128 columns in one coalesced pass (mfma_join_f16.hip; 0: per fragment lane + a second read for the error)
   int64_t opt_join_zproj_mfma = 1;       // rotated coordinates of rows of 256 .. 1024 columns on the matrix pipe (rotate_wide.hip; 0: a wave per row, shuffle reductions)
   int64_t opt_join_second_prefilter = 1; // rows wider than 128: the rectangular int8 first pass in front of the one-sided second pass of the join (0 = off)
@@ -589,6 +590,8 @@ struct OwnJoin {
   bool sharded_rows = false;                                  // the preparation ran on the ranks' own rows (ShardedRows below)
   ConeDirs cone;                                              // the tiles' cones, when the first pass ran behind the cone bound
   DevBuf<float> theta_own, theta2_own, theta_pos, theta2_pos; // thresholds (and the looser second ones) by row / by image position
+  DevBuf<unsigned char> Hrow;           // one GPU, 128 columns: the rows' f16 form row-major in ROW order (rotate_wide.hip's fused pass), until the order is known
+  DevBuf<float> err_by_row;             // ... and their plane errors by row
   DevBuf<float> f16_err_pos;            // plane error of every row of the f16 image by image position (the pruning's bound per pair)
   DevBuf<float> theta_band_own;         // by row: what the row's own neighbourhood certifies, less twice the bound (NaN: not computed); the second pass's floor
   DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
@@ -611,6 +614,16 @@ struct OwnJoin {
 // preparation (coordinates, f16 image) are made from the own rows and completed by the gathers below, so the f64 rows themselves
 // are not needed before the exact re-rank: their all-gather is issued behind the preparation (rows_begin) and awaited where they
 // are first read (rows_all) -- under the first pass and the f16 pass instead of in front of everything.
+// What the pass over all rows that computes the rotated coordinates may leave beside them (rotate_wide.hip: rotated_rows_wide,
+// rows of exactly 128 values): the f16 form of the rows (the values the join's image stores) ROW-MAJOR in row order (n x 128 halves),
+// the plane error of every row by row, the largest of them.  The caller provides the buffers; `done` says whether they were filled.
+struct RotatedPacked {
+  void *Hrow = nullptr;
+  float *err_rows = nullptr;
+  double f16_err = -1.0;
+  bool done = false;
+};
+
 struct ShardedRows {
   const double *own = nullptr;
   uint32_t lo = 0, count = 0;

@@ -420,6 +420,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   // rows wider than 128 (up to 1024): their rotated coordinates (31 dominant directions + tail norm, rotate_wide.hip) serve
   // the int8 first pass and, being 32 wide, the row order as well
   oj.wide_pre = false;
+  RotatedPacked rp;
   if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
       n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
     ProfScope ps(ctx, "knn_join_prefilter_basis");
@@ -427,7 +428,17 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     AS_TRY(oj.rot_z.alloc(ctx, (size_t)n * 32));
     AS_TRY(oj.rot_norm.alloc(ctx, n));
     if (sr && d > 128) AS_TRY(need_rows());
-    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail, rows ? nullptr : sr));
+    // rows of exactly 128 values on one GPU: the same pass leaves the f16 form of the rows row-major in ROW order and every row's plane
+    // error (one read of the rows instead of two; the image in the order of the join is re-arranged from it below) -- "join_fused_rows_pass" (1)
+    if (!sr && rows && d == 128 && ((uintptr_t)rows & 15) == 0 && ctx->opt_join_fused_rows_pass && join_on_f16(ctx, d) && ctx->opt_join_row_order &&
+        n >= 65536 && !(ctx->opt_debug & 2048)) {
+      AS_TRY(oj.Hrow.alloc(ctx, (size_t)n * 128 * 2));
+      AS_TRY(oj.err_by_row.alloc(ctx, n));
+      rp.Hrow = oj.Hrow.p;
+      rp.err_rows = oj.err_by_row.p;
+    }
+    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail, rows ? nullptr : sr, nullptr, &rp));
+    if (!rp.done) oj.Hrow.release(), oj.err_by_row.release();
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
     // Measured at 1 M x 128 (scripts/time_hard.py: mixtures of rank 16 ... 128 with 4 ... 50 000 clusters, duplicated rows, plain
     // Gaussian rows): the rotated 32-wide pass was never slower than the full-width one (within 2 %) and usually twice as fast
@@ -464,6 +475,7 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   }
   ctx->stats["knn_join_row_order"] = reorder ? 1 : 0;
   if (!join_on_f16(ctx, d)) oj.f16_err_pos.release();
+  bool rows_packed_once = false;
   if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
     const uint32_t tiles = packed_tiles_f16(n);
     AS_TRY(oj.Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
@@ -479,12 +491,23 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       }
       oj.sharded_rows = true;
       oj.f16_err_pos.release();  // (the ranks exchange the largest plane error only: one bound for all pairs)
+    } else if (rp.done && reorder) {
+      // the rows were packed in ROW order by the pass that computed their coordinates: the image in the order of the join is that
+      // one re-arranged (the bytes pack_f16_all stores), the plane errors follow the same permutation
+      AS_TRY(oj.f16_err_pos.alloc(ctx, n));
+      AS_TRY(pack_f16_from_rows(ctx, oj.Hrow.p, n, oj.perm_own.p, oj.Phown.p, tiles));
+      AS_TRY(gather_f32_by_ids(ctx, oj.err_by_row.p, oj.perm_own.p, n, oj.f16_err_pos.p));
+      ctx->f16_err = rp.f16_err;
+      oj.err_by_row.release(), oj.Hrow.release();
+      rows_packed_once = true;
     } else {
       if (sr) AS_TRY(need_rows());
+      oj.Hrow.release(), oj.err_by_row.release();
       AS_TRY(oj.f16_err_pos.alloc(ctx, n));  // the rows' plane errors by image position: the pruning's bound per pair
       AS_TRY(pack_f16_all(ctx, rows, norms, n, d, oj.Phown.p, tiles, reorder ? oj.perm_own.p : nullptr, oj.f16_err_pos.p));
     }
   }
+  ctx->stats["knn_join_fused_rows_pass"] = rows_packed_once ? 1 : 0;
   ctx->stats["sharded_prepare_by_rows"] = oj.sharded_rows ? 1 : 0;
   const void *row_image = oj.sharded_rows ? (reorder ? oj.Prow.p : oj.Phown.p) : nullptr;  // the f16 form of any row by id (sharded by rows)
   // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's

@@ -112,6 +112,33 @@ __global__ void f16_image_gather_kernel(const f16x8 *__restrict__ src, uint64_t 
   }
   P[g] = v;
 }
+// The same image (rows of exactly 128 values) from the rows' f16 form ROW-MAJOR in row order (H: n x 128 halves, what
+// rotate_wide.hip's fused pass leaves): the 128 positions of tile T take the 256 bytes of rows ids[128 T ..] (ids null: row p; an id
+// of ~0 or a position beyond n: zeros) -- sixteen lanes a row, each one 16-byte fragment vector -- through an LDS copy of the tile.
+__global__ __launch_bounds__(256) void f16_image_from_rows_kernel(const f16x8 *__restrict__ H, const uint32_t *__restrict__ ids, uint64_t n,
+                                                                   f16x8 *__restrict__ P) {
+  constexpr int KS = 8;
+  __shared__ f16x8 s_tile[KS * 4 * 64];  // 32 KB: [ks][s][lane]
+  const int tid = threadIdx.x, sub = tid & 15;  // sub: values 8 sub .. 8 sub + 7 of a row = k step sub / 2, half sub % 2
+  const uint64_t T = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 16 * i + (tid >> 4);  // position in the tile
+    const uint64_t pos = T * kTileRows + (uint64_t)q;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+    if (pos < n) {
+      const uint32_t id = ids ? ids[pos] : (uint32_t)pos;
+      if (id != 0xFFFFFFFFu && (uint64_t)id < n) v = H[(uint64_t)id * 16 + sub];
+    }
+    s_tile[((sub >> 1) * 4 + (q >> 5)) * 64 + (q & 31) + 32 * (sub & 1)] = v;
+  }
+  __syncthreads();
+  f16x8 *out = P + T * (uint64_t)(KS * 4 * 64);
+#pragma unroll
+  for (int q = 0; q < KS * 4 * 64 / 256; ++q) out[q * 256 + tid] = s_tile[q * 256 + tid];
+}
 // ---- rows of exactly 128 values: image and plane error in ONE coalesced pass over the rows (round 3) ---------------------------
 // The per-fragment-lane packer above reads a row in sixteen 64-byte pieces from sixteen different waves and ran at 0.6 TB/s
 // (1.66 ms per GB), the error kernel read the rows again (1.09 ms).  Here a workgroup owns a 128-row tile of the image: each of
@@ -1096,6 +1123,13 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
     hipLaunchKernelGGL(fill_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, err_rows, n, e);
     AS_HIP(ctx, hipGetLastError());
   }
+  return AS_OK;
+}
+
+int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n, const uint32_t *row_ids, void *P, uint32_t tiles) {
+  ProfScope ps(ctx, "pack_unit_rows");
+  hipLaunchKernelGGL(f16_image_from_rows_kernel, dim3(tiles), dim3(256), 0, ctx->stream, (const f16x8 *)Hrow, row_ids, n, (f16x8 *)P);
+  AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 

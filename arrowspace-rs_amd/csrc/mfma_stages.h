@@ -888,6 +888,7 @@ int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
                     uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr, const uint32_t *assign_pre = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
+int gather_f32_by_ids(as_ctx *ctx, const float *in, const uint32_t *ids, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);
 uint32_t packed_tiles_f16(uint64_t n);
 int pack_f16(as_ctx *ctx, const double *R, const double *norms, const uint32_t *row_ids, uint64_t row0, uint64_t n, uint32_t d,
@@ -902,7 +903,7 @@ int join_f16_wide_rect(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const
                        const uint32_t *perm = nullptr, const unsigned char *mask = nullptr);
 bool rotated_wide_supported(uint32_t d);
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out, const ShardedRows *sr = nullptr, float *Q_out = nullptr);
+                      double *tail_out, const ShardedRows *sr = nullptr, float *Q_out = nullptr, RotatedPacked *packed = nullptr);
 uint32_t rotated_wide_pitch(uint32_t d);
 int rotated_project_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, const float *Q, double *Z, double *znorm);
 int pack_rotated_from_z(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t n, uint32_t tiles, void *P8, double *err_out);
@@ -943,6 +944,7 @@ int join_thresholds_f16_wide_band(as_ctx *ctx, uint32_t n, uint32_t d, const voi
 int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out,
                              uint32_t pos_begin = 0, uint32_t pos_count = 0);
 int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
+int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n, const uint32_t *row_ids, void *P, uint32_t tiles);
 int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of

@@ -247,6 +247,150 @@ __global__ __launch_bounds__(256) void zproj_rows128_kernel(const double *__rest
   if (tail_part && lane == 0) tail_part[blockIdx.x * 4 + wv] = tails;
 }
 
+// ---- one pass over rows of exactly 128 values (round 6): the rotated coordinates AND the f16 form of the rows ---------------------
+// zproj_rows128_kernel above and pack_f16_tile128_kernel (mfma_join_f16.hip) each read the GB of a million rows, divide every value by
+// its row's norm and round it -- 0.49 + 0.37 ms, the second one in the order of the join, which is only known once the coordinates
+// are.  Here a workgroup stages 64 whole rows once and leaves both:
+//  * the rows' f16 form exactly as the packer stores it (the same quotient, the same rounding, the same squared-error butterfly per
+//    row), ROW-MAJOR and in row order (Hrow: n x 128 halves, 256 B a row -- lane l writes its two values, a row per wave
+//    instruction); the image in the order of the join is that one re-arranged once the order is known (f16_image_from_rows_kernel:
+//    256 B per row instead of 1 KB);
+//  * the coordinates on the matrix pipe: Z = U Q is 2 n 128 32 flop behind n KB, but four threads per row each walking eight
+//    directions through LDS made zproj_rows128_kernel LDS-bound at 2 TB/s.  v_mfma_f32_32x32x2_f32 keeps f32 products and f32
+//    accumulation (the tail term's 2e-5 allows for f32 and a basis orthonormal to 1e-6: unchanged); wave (g, h) takes rows
+//    32 g .. 32 g + 31 and the k range [64 h, 64 h + 64) -- lane (lh, lc) supplies u[row lc][64 h + 32 lh + t] and
+//    q[dir lc][the same k] at step t (the order in which k is summed is free; this one reads LDS without bank conflicts and keeps
+//    the wave's 32 values of Q in registers) -- and the two halves meet in LDS in a fixed order.
+// err_rows: the plane error of each row BY ROW; err_bits: the largest.  Grid: ceil(n / 64) blocks.
+typedef float zp_v16f32 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void zproj_pack_rows128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
+                                                                 const float *__restrict__ Q, uint32_t pitch, double *__restrict__ out,
+                                                                 double *__restrict__ tail_part, _Float16 *__restrict__ Hrow,
+                                                                 float *__restrict__ err_rows, unsigned int *__restrict__ err_bits) {
+  constexpr float kScale = 128.f;  // (kOperandScale of mfma_join_f16.hip: unit rows are stored times 2^7)
+  __shared__ float xf[64 * 129];
+  __shared__ float zs[64 * 33];
+  __shared__ float zp[64 * 33];   // the partial products of the upper k half
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lh = lane >> 5, lc = lane & 31;
+  const uint32_t row0 = blockIdx.x * 64u;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {  // wave wv takes rows wv, wv + 4, ...: lane l the values 2 l, 2 l + 1
+    const uint32_t r = row0 + (uint32_t)(4 * q + wv);
+    v[q] = r < n ? reinterpret_cast<const d2 *>(R + (uint64_t)r * 128)[lane] : d2{0.0, 0.0};
+  }
+  // the wave's 32 values of Q for the matrix pipe (direction lc -- 31 does not exist: zeros --, k = 64 h + 32 lh + t)
+  const int g = wv & 1, h = wv >> 1;
+  float qreg[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) qreg[t] = lc < kDirs ? Q[(size_t)lc * pitch + 64 * h + 32 * lh + t] : 0.f;
+  float worst = 0.f;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {  // two batches of eight rows: the packer's butterfly adds a row's 64 partial errors in ITS order
+    double e2[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int q = 8 * qb + b, lr = 4 * q + wv;
+      const uint32_t r = row0 + (uint32_t)lr;
+      const double nr = r < n ? norms[r] : 0.0;
+      // the coordinates' operand (zproj_rows128_kernel: rows with a zero or non-finite norm are all zero)
+      const bool live_z = r < n && nr > 0.0 && nr < __builtin_inf();
+      const double u0 = v[q].x / nr, u1 = v[q].y / nr;
+      const float f0 = live_z ? (float)u0 : 0.f, f1 = live_z ? (float)u1 : 0.f;
+      float *dst = xf + (size_t)lr * 129 + 2 * lane;
+      dst[0] = f0 == f0 ? f0 : 0.f;
+      dst[1] = f1 == f1 ? f1 : 0.f;
+      // the image's operand (pack_f16_tile128_kernel: any positive norm, the quotient times 2^7, out of range or NaN -> 0)
+      _Float16 h0 = (_Float16)0.0f, h1 = (_Float16)0.0f;
+      e2[b] = 0.0;
+      if (r < n && nr > 0.0) {
+        const float g0 = (float)u0 * kScale, g1 = (float)u1 * kScale;
+        h0 = (g0 == g0 && __builtin_fabsf(g0) <= 2.f * kScale) ? (_Float16)g0 : (_Float16)0.0f;
+        h1 = (g1 == g1 && __builtin_fabsf(g1) <= 2.f * kScale) ? (_Float16)g1 : (_Float16)0.0f;
+        if (nr < __builtin_inf()) {
+          const double d0 = (double)(float)h0 * (1.0 / kScale) - u0, d1 = (double)(float)h1 * (1.0 / kScale) - u1;
+          e2[b] = d0 * d0 + d1 * d1;
+        }
+      }
+      if (r < n) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        reinterpret_cast<h2 *>(Hrow + (uint64_t)r * 128)[lane] = h2{h0, h1};
+      }
+    }
+    // per-row sums over the 64 lanes: 8 values per lane -> halving butterfly (lane bits 5, 4, 3), then full adds (bits 2, 1, 0)
+    const bool up5 = (lane >> 5) & 1, up4 = (lane >> 4) & 1, up3 = (lane >> 3) & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double keep = up5 ? e2[i + 4] : e2[i], send = up5 ? e2[i] : e2[i + 4];
+      e2[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double keep = up4 ? e2[i + 2] : e2[i], send = up4 ? e2[i] : e2[i + 2];
+      e2[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    {
+      const double keep = up3 ? e2[1] : e2[0], send = up3 ? e2[0] : e2[1];
+      e2[0] = keep + __shfl_xor(send, 8, 64);
+    }
+    double t = e2[0];
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 1, 64);
+    // (the eight lanes of group (bits 5, 4, 3) hold the sum of row 4 b5 + 2 b4 + b3 of the batch)
+    const uint32_t r = row0 + (uint32_t)(4 * (8 * qb + 4 * (int)up5 + 2 * (int)up4 + (int)up3) + wv);
+    const float e = (float)(__builtin_sqrt(t) * (1.0 + 1e-6));  // rounded up
+    if (e == e) worst = __builtin_fmaxf(worst, e);
+    if ((lane & 7) == 0 && r < n) err_rows[r] = e == e ? e : __builtin_inff();  // NaN -> +inf: such a row prunes nothing
+  }
+  for (int o = 32; o > 0; o >>= 1) worst = __builtin_fmaxf(worst, __shfl_xor(worst, o, 64));
+  if (lane == 0) raise_max_u32(err_bits, __float_as_uint(worst));  // non-negative floats order like their bits
+  __syncthreads();
+  {
+    zp_v16f32 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *xa = xf + (size_t)(32 * g + lc) * 129 + 64 * h + 32 * lh;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t], qreg[t], acc, 0, 0, 0);
+    // acc[r] of lane (lh, lc) = the product of row 32 g + 4 lh + (r & 3) + 8 (r >> 2) with direction lc over the wave's k half
+    float *dstz = h ? zp : zs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dstz[(32 * g + 4 * lh + (r & 3) + 8 * (r >> 2)) * 33 + lc] = acc[r];
+  }
+  __syncthreads();
+  const int rr = tid >> 2, part = tid & 3;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {  // the two k halves in a fixed order
+    const int j = 8 * part + jj;
+    zs[rr * 33 + j] = zs[rr * 33 + j] + zp[rr * 33 + j];
+  }
+  __syncthreads();
+  const uint32_t row = row0 + (uint32_t)rr;
+  double tails = 0.0;
+  if (row < n) {
+    double *o = out + (size_t)row * 32;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      if (8 * part + jj < kDirs) o[8 * part + jj] = (double)zs[rr * 33 + 8 * part + jj];  // (each thread a contiguous 64 bytes of the row)
+    if (part == 0) {
+      const double nr = norms[row];
+      const bool live = nr > 0.0 && nr < __builtin_inf();
+      float zz = 0.f;
+      for (int j = 0; j < kDirs; ++j) {
+        const float z = zs[rr * 33 + j];
+        zz = __builtin_fmaf(z, z, zz);
+      }
+      o[kDirs] = live ? (double)__builtin_sqrtf(__builtin_fmaxf(1.f - zz, 0.f) + 2e-5f) : 0.0;
+      if (live) tails = (double)__builtin_fmaxf(1.f - zz, 0.f);
+    }
+  }
+  for (int o2 = 32; o2 > 0; o2 >>= 1) tails += __shfl_xor(tails, o2, 64);
+  if (tail_part && lane == 0) tail_part[blockIdx.x * 4 + wv] = tails;
+}
+
 // Y[block][dir][k] = sum over the sample rows of the block (i = block, block + grid, ...: a fixed order) of z[row][dir] * u[row][k];
 // yreduce_kernel adds the blocks' parts in block order.  (Was a float atomicAdd into one Y: the directions differed in their last
 // bits from run to run, and with them the row order and the routing of rows through the stages.)
@@ -306,6 +450,24 @@ __global__ __launch_bounds__(256) void yreduce_kernel(const float *__restrict__ 
   }
 }
 
+// out[0] = the sum of `count` partial tail sums (thread t adds parts t, t + 1024, ... in that order, then a fixed tree over the
+// threads); out[1] = the float whose bits err_bits holds (the largest plane error of a packing pass), or 0
+__global__ __launch_bounds__(1024) void tail_reduce_kernel(const double *__restrict__ parts, uint32_t count, const unsigned int *__restrict__ err_bits,
+                                                           double *__restrict__ out) {
+  __shared__ double s_t[1024];
+  double s = 0.0;
+  for (uint32_t i = threadIdx.x; i < count; i += 1024) s += parts[i];
+  s_t[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_t[threadIdx.x] += s_t[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = s_t[0];
+    out[1] = err_bits ? (double)__uint_as_float(*err_bits) : 0.0;
+  }
+}
 __global__ void znorm_kernel(const double *__restrict__ Z, uint32_t n, double *__restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -492,8 +654,12 @@ static uint32_t zproj_width(uint32_t pitch) {
     if (nv <= c) return c;
   return nv;
 }
+// packed (or null): where the rows are exactly 128 values wide and the build is not sharded, the pass over all rows also leaves
+// their f16 form row-major in ROW order (packed->Hrow, n x 128 halves), every row's plane error (packed->err_rows, by row) and the
+// largest of them (packed->f16_err), and sets packed->done -- zproj_pack_rows128_kernel: one read of the rows instead of two.
 int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, double *Z, double *znorm,
-                      double *tail_out, const ShardedRows *sr, float *Q_out) {
+                      double *tail_out, const ShardedRows *sr, float *Q_out, RotatedPacked *packed) {
+  if (packed) packed->done = false;
   if (!rotated_wide_supported(d)) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates: width not covered");
   if (sr && d > 128) return fail(ctx, AS_ERR_UNSUPPORTED, "rotated coordinates of a sharded build: rows up to 128 wide");
   const uint32_t pitch = (d + 63) / 64 * 64;
@@ -508,6 +674,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   const uint32_t ns = (uint32_t)((n + stride - 1) / stride);
   DevBuf<float> Qd, Yd, Ypart;
   DevBuf<double> Zs, tpart;
+  DevBuf<unsigned int> err_bits;
   const uint32_t y_blocks = std::min<uint32_t>(ns, 512);
   // (128 aligned columns: zproj_rows128_kernel, blocks of 64 rows; other widths up to 128: blocks of 256)
   const bool rows128 = d == 128 && (((uintptr_t)(sr ? sr->own : rows)) & 15) == 0 && !(ctx->opt_debug & 2048);
@@ -601,7 +768,14 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
     const uint32_t p_n = sr ? sr->count : n;
     double *p_z = sr ? Z + (size_t)sr->lo * 32 : Z, *p_t = sr ? tpart.p + (size_t)(sr->lo / z_rows) * 4 : tpart.p;
 #define AS_ZT(DPV) hipLaunchKernelGGL(zproj_tile_kernel<DPV>, dim3(cdiv(p_n, 256)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, d, (const float *)Qd.p, pitch, p_z, p_t)
-    if (p_n && rows128)
+    if (p_n && rows128 && packed && packed->Hrow && packed->err_rows && !sr) {
+      AS_TRY(err_bits.alloc(ctx, 1));
+      AS_HIP(ctx, hipMemsetAsync(err_bits.p, 0, sizeof(unsigned int), ctx->stream));
+      ProfScope ps(ctx, "pack_unit_rows");  // (the packing's share cannot be told apart: the whole pass is booked here, under the basis stage)
+      hipLaunchKernelGGL(zproj_pack_rows128_kernel, dim3(cdiv(p_n, 64)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, (const float *)Qd.p, pitch, p_z, p_t,
+                         (_Float16 *)packed->Hrow, packed->err_rows, err_bits.p);
+      packed->done = true;
+    } else if (p_n && rows128)
       hipLaunchKernelGGL(zproj_rows128_kernel, dim3(cdiv(p_n, 64)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, (const float *)Qd.p, pitch, p_z, p_t);
     else if (p_n) switch ((d + 31) / 32) {
       case 2: AS_ZT(64); break;
@@ -637,12 +811,19 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   hipLaunchKernelGGL(znorm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const double *)Z, n, znorm);
   AS_HIP(ctx, hipGetLastError());
   if (Q_out) AS_HIP(ctx, hipMemcpyAsync(Q_out, Qd.p, sizeof(float) * (size_t)kDirs * pitch, hipMemcpyDeviceToDevice, ctx->stream));
-  std::vector<double> tp(tail_parts ? (size_t)tail_parts : (size_t)z_grid * 4);
-  AS_HIP(ctx, copy_d2h(ctx, tp.data(), tpart.p, tp.size() * sizeof(double)));
+  // the tail sums added up on the device (a fixed tree: the same value in every run and on every rank) and read back as ONE word --
+  // the half megabyte of per-wave parts used to cross to the host and be added there, 0.14 ms with the GPU idle -- together with
+  // the largest plane error when the pass packed the rows
+  const uint32_t n_parts = tail_parts ? tail_parts : z_grid * 4;
+  DevBuf<double> tsum;
+  AS_TRY(tsum.alloc(ctx, 2));
+  hipLaunchKernelGGL(tail_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)tpart.p, n_parts, (const unsigned int *)err_bits.p, tsum.p);
+  AS_HIP(ctx, hipGetLastError());
+  double h[2] = {0.0, 0.0};
+  AS_HIP(ctx, copy_d2h(ctx, h, tsum.p, sizeof(h)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
-  double ts = 0.0;
-  for (double v : tp) ts += v;
-  *tail_out = ts / std::max<double>(1.0, (double)n);
+  *tail_out = h[0] / std::max<double>(1.0, (double)n);
+  if (packed && packed->done) packed->f16_err = h[1];
   return AS_OK;
 }
 

@@ -903,6 +903,17 @@ int order_label_stats(as_ctx *ctx, const uint32_t *perm, uint32_t n, uint32_t C)
   return AS_OK;
 }
 
+// out[i] = in[ids[i]], i < n (an id of ~0: 0)
+__global__ void gather_f32_by_ids_kernel(const float *__restrict__ in, const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ids[i] == 0xFFFFFFFFu ? 0.f : in[ids[i]];
+}
+int gather_f32_by_ids(as_ctx *ctx, const float *in, const uint32_t *ids, uint32_t n, float *out) {
+  hipLaunchKernelGGL(gather_f32_by_ids_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, in, ids, n, out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+
 // out[perm[i]] = in[i], i < n
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out) {
   hipLaunchKernelGGL(scatter_f32_by_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, in, perm, n, out);

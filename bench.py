@@ -670,6 +670,11 @@ def main():
                     "value": n / t_off, "unit": "items/s", "build_ms": t_off * 1e3, "item_graph_nnz": int(gl_off.matrix.nnz()),
                     "join_f16_ms": join_ms, "join_blocks": ctx.stat("knn_join_blocks"),
                     "join_TFLOPs": 2.0 * 32 * 32 * 128 * ctx.stat("knn_join_blocks") / max(join_ms, 1e-9) / 1e9,
+                    "roofline": {"bound": "mfma", "kernel": "pair_join_f16_kernel<8, 0, false> (the dense form: every unordered pair of 512-row super tiles, "
+                                                            "2 n^2 d / 2 flop + the diagonal, listing included)",
+                                 "achieved": 2.0 * 32 * 32 * 128 * ctx.stat("knn_join_blocks") / max(join_ms, 1e-9) / 1e9, "peak": MFMA16_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": 2.0 * 32 * 32 * 128 * ctx.stat("knn_join_blocks") / max(join_ms, 1e-9) / 1e9 / MFMA16_PEAK_TFLOPS,
+                                 "traffic": None, "avg_launch_ms": join_ms},
                     "candidates_per_row": ctx.stat("knn_join_candidates") / max(1, n),
                     "what": "row order, cone bound, int8 first pass and band thresholds off: the f16 join contracts every unordered pair of "
                             "512-row super tiles (item graph only; the same table)"}

@@ -115,6 +115,8 @@ def compact_line(full):
     line["roofline_search_frac"] = _frac(full, "roofline_search")          # search threshold scan against the f16 MFMA peak
     line["roofline_search_hbm_frac"] = _frac(full, "roofline_search_hbm")  # small-batch search against HBM
     line["roofline_spmm_frac"] = _frac(full, "roofline_spmm")              # item-graph lambda against HBM
+    dense = (full.get("value_all_bounds_off") or {}).get("roofline") if isinstance(full.get("value_all_bounds_off"), dict) else None
+    line["roofline_dense_join_frac"] = _num(dense.get("frac"), 4) if isinstance(dense, dict) else None   # all-pairs f16 join, no bound on
     others = {}
     for key, fields in (("value_cfg1", ("build_ms", "search_ms")), ("value_cfg3_one_gpu", ("build_ms", "search_ms")),
                         ("value_wide", ("build_ms", "search_ms")), ("value_cfg3_rank_of_8", ("rank_ms", "one_gpu_ms")),

@@ -1,7 +1,7 @@
 """A / B of one context option on the item graph of the bench (1 M x 128): wall time of build_laplacian_matrix and the
 profile groups, the two settings interleaved on the same box.  usage: python scripts/ab_option.py <option> <a> <b> [n]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arrowspace-rs_amd"))
 import torch
 import arrowspace_amd as A
@@ -21,5 +21,8 @@ for rep in range(3):
         ctx.synchronize(); dt = time.perf_counter() - t0
         pr = ctx.profile_all(); ctx.profile(False)
         top = sorted(pr.items(), key=lambda kv: -kv[1][0])[:7]
-        print("%s=%d  build %.2f ms  nnz %d  " % (opt, v, dt * 1e3, gl.matrix.nnz()) + "  ".join("%s %.2f" % (k.replace("knn_", ""), ms) for k, (ms, _) in top), flush=True)
+        ip, ix, dv = gl.matrix.to_host()
+        import hashlib
+        sig = hashlib.sha1(ip.tobytes() + ix.tobytes() + dv.tobytes()).hexdigest()[:10]
+        print("%s=%d  build %.2f ms  nnz %d csr %s  " % (opt, v, dt * 1e3, gl.matrix.nnz(), sig) + "  ".join("%s %.2f" % (k.replace("knn_", ""), ms) for k, (ms, _) in top) + "  | basis %.2f pack %.2f" % (pr.get("knn_join_prefilter_basis", (0, 0))[0], pr.get("pack_unit_rows", (0, 0))[0]), flush=True)
         del gl

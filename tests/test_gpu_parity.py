@@ -322,6 +322,34 @@ def test_item_graph_image_of_wide_rows_in_one_pass(ctx, join_on, n, d):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n", [70_000, 131_075])
+def test_item_graph_coordinates_and_image_from_one_pass_over_the_rows(ctx, join_on, n):
+    """Rows of exactly 128 values: the rotated coordinates (on the matrix pipe) and the f16 form of the rows come out of ONE pass
+    over the rows ("join_fused_rows_pass", round 6, rotate_wide.hip: zproj_pack_rows128_kernel); the image in the order of the join
+    is re-arranged from the row-major f16 rows once the order is known.  The same stored values and the same plane errors as the
+    packer's own pass: the tables are those of the two passes and the oracle's, zero rows, a tiny row, duplicates and a row count
+    that is no multiple of 64 included."""
+    X, _ = synth.mixture(n, 128, seed=29, n_clusters=40, rank=6)
+    X[5] = 0.0
+    X[40] *= 1e-8
+    X[7000:7020] = X[77]
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_join_row_order") == 1 and ctx.stat("knn_join_fused_rows_pass") == 1
+    delta = ctx.stat("knn_join_delta_e9")
+    ctx.set_option("join_fused_rows_pass", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_fused_rows_pass") == 0
+        assert ctx.stat("knn_join_delta_e9") == delta   # the same measure, added up in the same order
+    finally:
+        ctx.set_option("join_fused_rows_pass", 1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.unique(np.concatenate([[5, 40, 77, 7000, 7019, n - 1], np.random.default_rng(4).choice(n, size=80, replace=False)]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n,d", [(70_000, 256), (66_000, 384)])
 def test_item_graph_rerank_of_wide_rows_in_the_order_of_the_image(ctx, join_on, n, d):
     """Rows of a multiple of 128 columns (the re-rank on records) on a reordered image: the lists hold row ids, but the re-rank lays
