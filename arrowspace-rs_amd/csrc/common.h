@@ -130,6 +130,7 @@ struct as_ctx {
   int64_t opt_join_cone_groups = 1;      // cone bound on tile pairs: a coarse level first, every tile's rows against the cones around 32 tiles (from 2048 tiles on; 0: one level)
   int64_t opt_join_open_order = 1;       // the rows the first re-rank leaves open go on in the order of the join's image (0: as they were appended)
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
+  int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
   int64_t opt_join_fused_rows_pass = 1;  // rows of exactly 128 values: rotated coordinates and f16 image from ONE pass over the rows (rotate_wide.hip; 0: two passes)
   int64_t opt_join_pack_wide_tiles = 1;  // f16 image of rows of a multiple of 128 columns in one coalesced pass (mfma_join_f16.hip; 0: per fragment lane + a second read for the error)
   int64_t opt_join_zproj_mfma = 1;       // rotated coordinates of rows of 256 .. 1024 columns on the matrix pipe (rotate_wide.hip; 0: a wave per row, shuffle reductions)

@@ -1061,6 +1061,17 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
     hipLaunchKernelGGL(gather_u32_kernel, dim3(cdiv(n_fail, 256)), dim3(256), 0, ctx->stream, a_ids_f, fail1.p, n_fail,
                        a_ids_f ? 0u : (uint32_t)row_begin, gids.p);
   }
+  ctx->stats["knn_open_rows_kept"] = 0;
+  if (ctx->opt_keep_open_rows) {
+    // diagnostic ("keep_open_rows"): the ids of the rows the first re-rank left open -- every row that goes through the second pass,
+    // the f32 / f64 top-k passes or an exact scan is one of them -- readable as the stats "knn_open_row_<i>", so that a test can
+    // put exactly these rows in front of the oracle (tests/test_gpu_fullsize.py)
+    std::vector<uint32_t> h(n_fail);
+    AS_HIP(ctx, copy_d2h(ctx, h.data(), gids.p, sizeof(uint32_t) * n_fail));
+    AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n_fail; ++i) ctx->stats["knn_open_row_" + std::to_string(i)] = (int64_t)h[i];
+    ctx->stats["knn_open_rows_kept"] = n_fail;
+  }
   const uint32_t *cur_ids = gids.p;
   const uint32_t *cur_pos = fail1.p;
   uint32_t cur_n = n_fail;

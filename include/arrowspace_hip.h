@@ -136,6 +136,9 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "handle_cache_mb" (2048)    memory of destroyed handles kept for the next allocation of the same size (process-wide; environment
  *                               ARROWSPACE_HANDLE_CACHE_MB; 0 = off and released)
  *   "sharded_agreement" (1)     every collective of a sharded call behind a one-word status agreement (as_*_sharded)
+ *   "keep_open_rows" (0)        diagnostic: 1 = the ids of the rows the first exact re-rank of an item graph leaves open (the rows that
+ *                               go on to the second pass, the top-k passes or an exact scan) are kept and read back as the stats
+ *                               "knn_open_rows_kept" (how many) and "knn_open_row_<i>"
  *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);
