@@ -185,6 +185,7 @@ struct as_ctx {
     size_t norms_cap = 0, packed_cap = 0, packed16_cap = 0, packedh_cap = 0, theta2_cap = 0;
   } join;
   double f16_err = -1.0;  // measured error of the f16 plane of the rows packed last (pack_f16_all), -1: none
+  const void *rowmajor_image = nullptr;  // while own_join_prepare runs: the buffer that holds the rows' f16 form ROW-MAJOR (pack_f16_from_image reads it as such)
   // the row order the last whole-matrix join found (position -> row; row_order.hip): as_build_laplacian attaches a copy to the
   // graph it returns, where the item-graph lambda kernels visit the rows in it (signal_lambda.hip)
   uint32_t *join_order = nullptr;

@@ -637,14 +637,16 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
     }
   }
   const uint32_t all_groups = words;
+  // two levels from 2 048 tiles on: every tile's rows against the cones around 32 tiles first (cone_group_kernel) -- for the whole
+  // range and, since round 6, for a range of row tiles as well (a rank of a sharded build swept its 2 / world of the fine pass
+  // without the coarse level: 3.9 ms of a rank's 40 at 4 M rows on 8 ranks, more than the whole pass costs one GPU)
+  const uint32_t n_groups = (ntiles + 31u) / 32u, words_c = (n_groups + 31u) / 32u;
+  const bool two_level = !split_first && it_count && ctx->opt_join_cone_groups && ntiles >= 2048u && mean.p;
+  DevBuf<unsigned char> dirs_g;
+  DevBuf<float> ca_g, sa_g, tmin_g;
+  DevBuf<uint32_t> bit_g;
   if (split_first) {
   } else if (it_begin == 0 && it_count == ntiles) {
-    // two levels from 2 048 tiles on: every tile's rows against the cones around 32 tiles first (cone_group_kernel)
-    const uint32_t n_groups = (ntiles + 31u) / 32u, words_c = (n_groups + 31u) / 32u;
-    const bool two_level = ctx->opt_join_cone_groups && ntiles >= 2048u && mean.p;
-    DevBuf<unsigned char> dirs_g;
-    DevBuf<float> ca_g, sa_g, tmin_g;
-    DevBuf<uint32_t> bit_g;
     if (two_level) {
       const size_t dir_bytes = (size_t)((n_groups + 127u) / 128u) * 2 * 4 * 64 * 16;
       AS_TRY(dirs_g.alloc(ctx, dir_bytes));
@@ -668,18 +670,34 @@ int cone_tile_mask(as_ctx *ctx, const double *Z, const uint32_t *perm, uint32_t 
     // a range of row tiles (a rank of a sharded build): its rows against every direction, and every tile's rows against its directions
     AS_HIP(ctx, hipMemsetAsync(bit1.p, 0, sizeof(uint32_t) * (size_t)ntiles * words, ctx->stream));
     const uint32_t g0 = it_begin / 32u, g1 = (it_begin + it_count + 31u) / 32u;
+    if (two_level) {  // (the coarse level for every tile's rows: the first fine pass below sweeps them all; the same bits on every rank)
+      const size_t dir_bytes = (size_t)((n_groups + 127u) / 128u) * 2 * 4 * 64 * 16;
+      AS_TRY(dirs_g.alloc(ctx, dir_bytes));
+      AS_TRY(ca_g.alloc(ctx, n_groups));
+      AS_TRY(sa_g.alloc(ctx, n_groups));
+      AS_TRY(tmin_g.alloc(ctx, n_groups));
+      AS_TRY(bit_g.alloc(ctx, (size_t)ntiles * words_c));
+      AS_HIP(ctx, hipMemsetAsync(dirs_g.p, 0, dir_bytes, ctx->stream));
+      hipLaunchKernelGGL(cone_group_kernel, dim3(n_groups), dim3(64), 0, ctx->stream, (const float *)mean.p, (const float *)ca.p, (const float *)sa.p,
+                         (const float *)tmin.p, ntiles, (f16x8 *)dirs_g.p, ca_g.p, sa_g.p, tmin_g.p);
+      hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_g.p, 0u,
+                         ntiles, 0u, words_c, n_groups, (const float *)ca_g.p, (const float *)sa_g.p, (const float *)tmin.p,
+                         (const unsigned int *)nmax.p, words_c, bit_g.p, (const float *)tmin_g.p, (const uint32_t *)nullptr, 0u, 0u);
+    }
+    ctx->stats["knn_join_cone_groups"] = two_level ? 1 : 0;
+    const uint32_t *coarse = two_level ? bit_g.p : nullptr;
     hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(ntiles, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p, 0u,
                        ntiles, g0, g1 - g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                       (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
+                       (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, coarse, words_c, n_groups);
     // (the rows of the range against the directions outside it; the groups [g0, g1) were written above, by the same rule)
     if (g0 > 0)
       hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, 0u, g0, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
+                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, coarse, words_c, n_groups);
     if (g1 < all_groups)
       hipLaunchKernelGGL(cone_max_kernel, dim3(cdiv(it_count, 8)), dim3(256), 0, ctx->stream, (const f16x8 *)rows_img.p, (const f16x8 *)dirs_img.p,
                          it_begin, it_count, g1, all_groups - g1, ntiles, (const float *)ca.p, (const float *)sa.p, (const float *)tmin.p,
-                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, (const uint32_t *)nullptr, 0u, 0u);
+                         (const unsigned int *)nmax.p, words, bit1.p, (const float *)tmin.p, coarse, words_c, n_groups);
   }
   if (it_count && !split_first) {
     const uint32_t ig0 = it_begin / 32u, ig1 = (it_begin + it_count + 31u) / 32u;

@@ -421,6 +421,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   // the int8 first pass and, being 32 wide, the row order as well
   oj.wide_pre = false;
   RotatedPacked rp;
+  struct RowMajorScope {  // (ctx->rowmajor_image lives as long as this function, whatever way it is left: its buffer belongs to oj)
+    as_ctx *c;
+    ~RowMajorScope() { c->rowmajor_image = nullptr; }
+  } rowmajor_scope{ctx};
+  ctx->rowmajor_image = nullptr;
   if (join_on_f16(ctx, d) && rotated_wide_supported(d) && ctx->opt_join_prefilter && ctx->opt_join_prefilter != 2 &&
       n >= (uint64_t)std::max<int64_t>(0, ctx->opt_join_prefilter_min_rows) && ctx->opt_join_bf16 && !(ctx->opt_debug & 32)) {
     ProfScope ps(ctx, "knn_join_prefilter_basis");
@@ -430,8 +435,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
     if (sr && d > 128) AS_TRY(need_rows());
     // rows of exactly 128 values on one GPU: the same pass leaves the f16 form of the rows row-major in ROW order and every row's plane
     // error (one read of the rows instead of two; the image in the order of the join is re-arranged from it below) -- "join_fused_rows_pass" (1)
-    if (!sr && rows && d == 128 && ((uintptr_t)rows & 15) == 0 && ctx->opt_join_fused_rows_pass && join_on_f16(ctx, d) && ctx->opt_join_row_order &&
-        n >= 65536 && !(ctx->opt_debug & 2048)) {
+    // ... and on every rank of a build sharded by rows: its own rows into their place, the rest arrives with an all-gather of 256 B a
+    // row (what the fragment image of the own rows used to be gathered as), and the re-arrangement reads whole rows
+    const double *pass_rows = (sr && !rows) ? sr->own : rows;
+    if (pass_rows && (!sr || !rows) && d == 128 && ((uintptr_t)pass_rows & 15) == 0 && ctx->opt_join_fused_rows_pass && join_on_f16(ctx, d) &&
+        ctx->opt_join_row_order && n >= 65536 && !(ctx->opt_debug & 2048)) {
       AS_TRY(oj.Hrow.alloc(ctx, (size_t)n * 128 * 2));
       AS_TRY(oj.err_by_row.alloc(ctx, n));
       rp.Hrow = oj.Hrow.p;
@@ -479,9 +487,21 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   if (join_on_f16(ctx, d)) {  // the f16 image serves the thresholds and the join
     const uint32_t tiles = packed_tiles_f16(n);
     AS_TRY(oj.Phown.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
-    if (sr && !rows && d <= 128) {
+    if (sr && !rows && d <= 128 && rp.done) {
+      // sharded by rows, the own rows packed row-major by the pass that computed their coordinates: all-gather 256 B a row, the
+      // largest plane error over the ranks, and the image in the order of the join re-arranged from whole rows
+      AS_TRY(sr->gather(oj.Hrow.p, (size_t)128 * 2));
+      AS_TRY(sharded_max_plane_error(ctx, *sr, rp.f16_err));
+      ctx->rowmajor_image = oj.Hrow.p;
+      AS_TRY(pack_f16_from_rows(ctx, oj.Hrow.p, n, reorder ? oj.perm_own.p : nullptr, n, oj.Phown.p, tiles));
+      oj.err_by_row.release();
+      oj.sharded_rows = true;
+      oj.f16_err_pos.release();  // (the ranks exchange the largest plane error only: one bound for all pairs)
+      rows_packed_once = true;
+    } else if (sr && !rows && d <= 128) {
       // sharded by rows: every rank packs its own rows, the image of all rows in ROW order is all-gathered (256 B per row at 128
       // columns), and the image in the order of the join is that one re-arranged -- the same bytes pack_f16_all stores
+      oj.Hrow.release(), oj.err_by_row.release();
       if (reorder) {
         AS_TRY(oj.Prow.alloc(ctx, packed_vecs_f16(tiles, d) * 16));
         AS_TRY(pack_f16_rows_sharded(ctx, *sr, norms, n, d, oj.Prow.p, tiles));
@@ -495,10 +515,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       // the rows were packed in ROW order by the pass that computed their coordinates: the image in the order of the join is that
       // one re-arranged (the bytes pack_f16_all stores), the plane errors follow the same permutation
       AS_TRY(oj.f16_err_pos.alloc(ctx, n));
-      AS_TRY(pack_f16_from_rows(ctx, oj.Hrow.p, n, oj.perm_own.p, oj.Phown.p, tiles));
+      AS_TRY(pack_f16_from_rows(ctx, oj.Hrow.p, n, oj.perm_own.p, n, oj.Phown.p, tiles));
       AS_TRY(gather_f32_by_ids(ctx, oj.err_by_row.p, oj.perm_own.p, n, oj.f16_err_pos.p));
       ctx->f16_err = rp.f16_err;
-      oj.err_by_row.release(), oj.Hrow.release();
+      oj.err_by_row.release();
+      ctx->rowmajor_image = oj.Hrow.p;  // (the samples of the thresholds below are copied from it: 256 B a row instead of 1 KB)
       rows_packed_once = true;
     } else {
       if (sr) AS_TRY(need_rows());
@@ -509,7 +530,10 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
   }
   ctx->stats["knn_join_fused_rows_pass"] = rows_packed_once ? 1 : 0;
   ctx->stats["sharded_prepare_by_rows"] = oj.sharded_rows ? 1 : 0;
-  const void *row_image = oj.sharded_rows ? (reorder ? oj.Prow.p : oj.Phown.p) : nullptr;  // the f16 form of any row by id (sharded by rows)
+  // the f16 form of any row by id: the rows row-major (the fused pass; pack_f16_from_image knows by ctx->rowmajor_image), or the
+  // all-gathered fragment image of a build sharded by rows
+  const void *row_image = ctx->rowmajor_image ? ctx->rowmajor_image : (oj.sharded_rows ? (reorder ? oj.Prow.p : oj.Phown.p) : nullptr);
+
   // thresholds: with the order by 1024 pivots of the coordinates, against the sampled rows of the 16 groups nearest to a row's
   // own (1.7 % of the products of the plain sample, the same thresholds for 99.5 % of the rows; mfma_theta_f16.hip)
   const bool wide_grouped = d > 128 && join_on_f16(ctx, d) && pos_begin == 0 && (pos_count == 0 || pos_count == n) && !gather;  // (rows wider than 128: one GPU)

@@ -112,11 +112,11 @@ __global__ void f16_image_gather_kernel(const f16x8 *__restrict__ src, uint64_t 
   }
   P[g] = v;
 }
-// The same image (rows of exactly 128 values) from the rows' f16 form ROW-MAJOR in row order (H: n x 128 halves, what
+// The same image (rows of exactly 128 values) from the rows' f16 form ROW-MAJOR in row order (H: n_src x 128 halves, what
 // rotate_wide.hip's fused pass leaves): the 128 positions of tile T take the 256 bytes of rows ids[128 T ..] (ids null: row p; an id
-// of ~0 or a position beyond n: zeros) -- sixteen lanes a row, each one 16-byte fragment vector -- through an LDS copy of the tile.
-__global__ __launch_bounds__(256) void f16_image_from_rows_kernel(const f16x8 *__restrict__ H, const uint32_t *__restrict__ ids, uint64_t n,
-                                                                   f16x8 *__restrict__ P) {
+// of ~0 or beyond n_src, or a position beyond n: zeros) -- sixteen lanes a row, each one 16-byte fragment vector -- through an LDS copy of the tile.
+__global__ __launch_bounds__(256) void f16_image_from_rows_kernel(const f16x8 *__restrict__ H, uint64_t n_src, const uint32_t *__restrict__ ids,
+                                                                   uint64_t n, f16x8 *__restrict__ P) {
   constexpr int KS = 8;
   __shared__ f16x8 s_tile[KS * 4 * 64];  // 32 KB: [ks][s][lane]
   const int tid = threadIdx.x, sub = tid & 15;  // sub: values 8 sub .. 8 sub + 7 of a row = k step sub / 2, half sub % 2
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void f16_image_from_rows_kernel(const f16x8 *_
     for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
     if (pos < n) {
       const uint32_t id = ids ? ids[pos] : (uint32_t)pos;
-      if (id != 0xFFFFFFFFu && (uint64_t)id < n) v = H[(uint64_t)id * 16 + sub];
+      if (id != 0xFFFFFFFFu && (uint64_t)id < n_src) v = H[(uint64_t)id * 16 + sub];
     }
     s_tile[((sub >> 1) * 4 + (q >> 5)) * 64 + (q & 31) + 32 * (sub & 1)] = v;
   }
@@ -1126,14 +1126,16 @@ int pack_f16_all(as_ctx *ctx, const double *R, const double *norms, uint64_t n, 
   return AS_OK;
 }
 
-int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n, const uint32_t *row_ids, void *P, uint32_t tiles) {
+int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n_src, const uint32_t *row_ids, uint64_t n, void *P, uint32_t tiles) {
   ProfScope ps(ctx, "pack_unit_rows");
-  hipLaunchKernelGGL(f16_image_from_rows_kernel, dim3(tiles), dim3(256), 0, ctx->stream, (const f16x8 *)Hrow, row_ids, n, (f16x8 *)P);
+  hipLaunchKernelGGL(f16_image_from_rows_kernel, dim3(tiles), dim3(256), 0, ctx->stream, (const f16x8 *)Hrow, n_src, row_ids, n, (f16x8 *)P);
   AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 
 int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles) {
+  // (ctx->rowmajor_image: the source is the rows' f16 form ROW-MAJOR, not an image in fragment layout -- own_join_prepare says so)
+  if (row_image && row_image == ctx->rowmajor_image && d == 128) return pack_f16_from_rows(ctx, row_image, n_src, row_ids, n, P, tiles);
   const uint32_t KS = f16_ksteps(d);
   const uint64_t total = packed_vecs_f16(tiles, d);
   ProfScope ps(ctx, "pack_unit_rows");
@@ -1146,6 +1148,7 @@ int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, cons
 // The f16 image of ALL rows in row order on every rank of a build sharded by rows: each rank packs its own rows (pack_f16_all:
 // the same stored values and the same plane error as on one GPU), the pieces are all-gathered in place (shard starts are multiples
 // of 512 rows, so a rank's rows are whole tiles), and ctx->f16_err becomes the largest plane error over all ranks.
+int sharded_max_plane_error(as_ctx *ctx, const ShardedRows &sr, double own_err);
 int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles) {
   const uint32_t KS = f16_ksteps(d);
   const uint64_t tile_bytes = (uint64_t)KS * 4 * 64 * 16;
@@ -1166,6 +1169,14 @@ int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norm
     at8[(size_t)r] = (uint64_t)r * 8;
   }
   AS_TRY(sr.gather_v(Prow, bytes.data(), offs.data()));
+  (void)eight, (void)at8;
+  return sharded_max_plane_error(ctx, sr, own_err);
+}
+
+// ctx->f16_err = the largest plane error over all ranks (every rank contributes the one of its own rows)
+int sharded_max_plane_error(as_ctx *ctx, const ShardedRows &sr, double own_err) {
+  std::vector<uint64_t> eight((size_t)sr.world, 8), at8((size_t)sr.world);
+  for (int r = 0; r < sr.world; ++r) at8[(size_t)r] = (uint64_t)r * 8;
   DevBuf<double> errs;
   AS_TRY(errs.alloc(ctx, (size_t)sr.world));
   AS_HIP(ctx, copy_h2d(ctx, errs.p + sr.rank, &own_err, sizeof(double)));

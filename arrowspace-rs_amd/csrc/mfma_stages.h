@@ -944,7 +944,8 @@ int join_thresholds_f16_wide_band(as_ctx *ctx, uint32_t n, uint32_t d, const voi
 int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_all, uint32_t band, uint32_t m, float *theta_out,
                              uint32_t pos_begin = 0, uint32_t pos_count = 0);
 int pack_f16_from_image(as_ctx *ctx, const void *row_image, uint64_t n_src, const uint32_t *row_ids, uint64_t n, uint32_t d, void *P, uint32_t tiles);
-int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n, const uint32_t *row_ids, void *P, uint32_t tiles);
+int pack_f16_from_rows(as_ctx *ctx, const void *Hrow, uint64_t n_src, const uint32_t *row_ids, uint64_t n, void *P, uint32_t tiles);
+int sharded_max_plane_error(as_ctx *ctx, const ShardedRows &sr, double own_err);
 int pack_f16_rows_sharded(as_ctx *ctx, const ShardedRows &sr, const double *norms_all, uint64_t n, uint32_t d, void *Prow, uint32_t tiles);
 
 // which pipe contracts the join, and the rounding bound its candidate lists are certified against (the wider of

@@ -768,13 +768,15 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
     const uint32_t p_n = sr ? sr->count : n;
     double *p_z = sr ? Z + (size_t)sr->lo * 32 : Z, *p_t = sr ? tpart.p + (size_t)(sr->lo / z_rows) * 4 : tpart.p;
 #define AS_ZT(DPV) hipLaunchKernelGGL(zproj_tile_kernel<DPV>, dim3(cdiv(p_n, 256)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, d, (const float *)Qd.p, pitch, p_z, p_t)
-    if (p_n && rows128 && packed && packed->Hrow && packed->err_rows && !sr) {
+    if (p_n && rows128 && packed && packed->Hrow && packed->err_rows) {  // (sharded: the rank's own rows into their place, as Z below)
       AS_TRY(err_bits.alloc(ctx, 1));
       AS_HIP(ctx, hipMemsetAsync(err_bits.p, 0, sizeof(unsigned int), ctx->stream));
       ProfScope ps(ctx, "pack_unit_rows");  // (the packing's share cannot be told apart: the whole pass is booked here, under the basis stage)
       hipLaunchKernelGGL(zproj_pack_rows128_kernel, dim3(cdiv(p_n, 64)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, (const float *)Qd.p, pitch, p_z, p_t,
-                         (_Float16 *)packed->Hrow, packed->err_rows, err_bits.p);
+                         (_Float16 *)packed->Hrow + (sr ? (size_t)sr->lo * 128 : 0), packed->err_rows + (sr ? sr->lo : 0), err_bits.p);
       packed->done = true;
+    } else if (!p_n && rows128 && packed && packed->Hrow && packed->err_rows && sr) {
+      packed->done = true;  // (a rank without rows: nothing of its own to pack, the others' rows arrive with the gather)
     } else if (p_n && rows128)
       hipLaunchKernelGGL(zproj_rows128_kernel, dim3(cdiv(p_n, 64)), dim3(256), 0, ctx->stream, p_rows, p_norms, p_n, (const float *)Qd.p, pitch, p_z, p_t);
     else if (p_n) switch ((d + 31) / 32) {
@@ -823,7 +825,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   AS_HIP(ctx, copy_d2h(ctx, h, tsum.p, sizeof(h)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (Q and the locals are done with)
   *tail_out = h[0] / std::max<double>(1.0, (double)n);
-  if (packed && packed->done) packed->f16_err = h[1];
+  if (packed && packed->done) packed->f16_err = err_bits.p ? h[1] : 0.0;
   return AS_OK;
 }
 

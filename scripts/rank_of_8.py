@@ -3,11 +3,11 @@
 No 8-GPU node has been available to this project, so the 8-rank figure of DESIGN.md section 6 was a model put together from
 one-GPU kernel times.  This script measures the compute of a rank instead:
 
-  record   `python -m torch.distributed.run --nproc-per-node W scripts/rank_of_8.py record --n N [--rank R]`
+  record   `python -m torch.distributed.run --nproc-per-node W scripts/rank_of_8.py record --rows N [--rank R]`
            W processes share GPU 0 (gloo for the barriers) and run as_build_laplacian_sharded over a transport that moves every
            collective through files in /dev/shm (one collective at a time, so the host never holds more than one of them).  Rank R
            keeps what it RECEIVED in every collective -- the sequence of (operation, offsets, bytes) -- under --dir.
-  replay   `python scripts/rank_of_8.py replay --n N [--rank R]`
+  replay   `python scripts/rank_of_8.py replay --rows N [--rank R]`
            one process is rank R of W: the same call on the same shard, over a transport that answers every collective with the
            recorded bytes, already resident in HBM, by device-to-device copies ON THE STREAM the library hands it (so the gather of
            the f64 rows still runs on its side stream under the join, as RCCL's would).  Nothing is sent: the wall time of the call
@@ -36,7 +36,7 @@ import torch.distributed as dist  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("mode", choices=["record", "replay"])
-    p.add_argument("--n", type=int, default=4_000_000)
+    p.add_argument("--rows", dest="n", type=int, default=4_000_000)
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--world", type=int, default=8)
     p.add_argument("--rank", type=int, default=3, help="the rank whose receptions are recorded / replayed")
