@@ -609,6 +609,11 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_pack_wide_tiles") ctx->opt_join_pack_wide_tiles = value;
   else if (n == "join_fused_rows_pass") ctx->opt_join_fused_rows_pass = value;
   else if (n == "keep_open_rows") ctx->opt_keep_open_rows = value;
+  else if (n == "release_workspace") {  // an action, not a setting: the context's cached workspace blocks go back to the device now
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+    ctx->free_blocks.clear();
+  }
   else if (n == "rerank_image_order") ctx->opt_rerank_image_order = value;
   else if (n == "join_open_order") ctx->opt_join_open_order = value;
   else if (n == "join_cone_groups") ctx->opt_join_cone_groups = value;

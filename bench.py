@@ -77,6 +77,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-legs", action="store_true", help="skip the host-input build and the small-batch search legs")
     p.add_argument("--no-spmm-leg", action="store_true", help="skip the item-graph lambda leg (roofline_spmm)")
+    p.add_argument("--rank-of-8-leg", action="store_true", help="add value_cfg3_rank_of_8 (scripts/rank_of_8.py: 8 recording processes on this GPU, "
+                                                              "then the replay of rank 3 of 8 at 4 M x 128).  Off by default: half a minute on a "
+                                                              "warm box, but eight fresh processes importing torch took 4.7 minutes on a fresh one "
+                                                              "-- not inside the driver's timed command; profiles/r06*_rank3_of_8_4M.json holds the result")
     p.add_argument("--no-config-legs", action="store_true", help="skip the other BASELINE configs (value_cfg1, value_cfg3_one_gpu, value_wide) "
                                                                  "and the geometry sweep")
     p.add_argument("--cand-precision", type=int, default=32, choices=[32, 64],
@@ -684,6 +688,49 @@ def main():
                     ctx.set_option(opt, dflt)
         except Exception as e:  # noqa: BLE001
             extra["value_all_bounds_off"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.rank_of_8_leg and n == 1_000_000 and d == 128:
+        # ---- what ONE rank of configs[3] (4 M x 128 row-sharded over 8 GPUs) executes, measured on this GPU ----------------------
+        # scripts/rank_of_8.py: eight processes share this GPU and run as_build_laplacian_sharded over a file transport while rank 3
+        # records what it receives; then one process replays rank 3 with every collective answered from HBM on the library's stream.
+        # Child processes (never an exec from this one); the line must survive their failure.
+        try:
+            # (the eight recording processes need ~15 GB each: what this process cached during the legs above goes back to the device first)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            ctx.set_option("release_workspace", 1)
+            ctx.set_option("handle_cache_mb", 0)
+            ctx.set_option("handle_cache_mb", 2048)
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            xdir = "/dev/shm/as_rank_of_8_%d" % os.getpid()
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+                env.pop(k, None)
+            script = os.path.join(ROOT, "scripts", "rank_of_8.py")
+            t0 = time.perf_counter()
+            rec = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(29600 + os.getpid() % 300), script, "record", "--rows", "4000000", "--dir", xdir],
+                                 env=env, capture_output=True, text=True, timeout=600)
+            t_rec = time.perf_counter() - t0
+            if rec.returncode != 0:
+                tb = [ln for ln in rec.stderr.splitlines() if "Error" in ln or "error" in ln or "File \"" in ln]
+                raise RuntimeError("record: " + " | ".join(tb[:12])[:1500])
+            outp = os.path.join(xdir, "replay.json")
+            rep = subprocess.run([sys.executable, script, "replay", "--rows", "4000000", "--dir", xdir, "--reps", "5", "--out", outp],
+                                 env=env, capture_output=True, text=True, timeout=600)
+            if rep.returncode != 0:
+                raise RuntimeError("replay: " + rep.stderr[-400:])
+            with open(outp) as f:
+                leg = json.load(f)
+            leg["leg_wall_s"] = time.perf_counter() - t0
+            leg["record_wall_s"] = t_rec
+            leg["record_says"] = [ln for ln in rec.stdout.splitlines() if ln.startswith("recorded")][:1]
+            leg["device_memory_free_GB_before_the_leg"] = round(free_b / 1e9, 1)
+            extra["value_cfg3_rank_of_8"] = leg
+        except Exception as e:  # noqa: BLE001
+            extra["value_cfg3_rank_of_8"] = {"error": repr(e)[:2000]}
+        finally:
+            import shutil
+            shutil.rmtree(xdir, ignore_errors=True)
     if rank == 0 and world == 1 and not args.no_spmm_leg:
         # ---- the item-graph lambda: the feature columns as signals over the N x N Laplacian the build returns ------------
         # (SURVEY.md 8(a') item-graph mapping, the "SpMV" of north_star; src/taumode.rs:552-660 per signal.)  Algorithmic bytes

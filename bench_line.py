@@ -119,7 +119,7 @@ def compact_line(full):
     line["roofline_dense_join_frac"] = _num(dense.get("frac"), 4) if isinstance(dense, dict) else None   # all-pairs f16 join, no bound on
     others = {}
     for key, fields in (("value_cfg1", ("build_ms", "search_ms")), ("value_cfg3_one_gpu", ("build_ms", "search_ms")),
-                        ("value_wide", ("build_ms", "search_ms")), ("value_cfg3_rank_of_8", ("rank_ms", "one_gpu_ms")),
+                        ("value_wide", ("build_ms", "search_ms")), ("value_cfg3_rank_of_8", ("rank_ms", "one_gpu_ms", "one_gpu_over_rank", "received_bytes_from_peers")),
                         ("value_hard_data", ("build_ms",)), ("value_host_inputs", ("build_ms",)),
                         ("value_all_bounds_off", ("build_ms",))):
         leg = _leg(full, key, fields)

@@ -135,6 +135,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *  resources
  *   "handle_cache_mb" (2048)    memory of destroyed handles kept for the next allocation of the same size (process-wide; environment
  *                               ARROWSPACE_HANDLE_CACHE_MB; 0 = off and released)
+ *   "release_workspace"         (an action: any value) the context's cached workspace blocks -- a call keeps what it took for the next
+ *                               one -- are returned to the device now
  *   "sharded_agreement" (1)     every collective of a sharded call behind a one-word status agreement (as_*_sharded)
  *   "keep_open_rows" (0)        diagnostic: 1 = the ids of the rows the first exact re-rank of an item graph leaves open (the rows that
  *                               go on to the second pass, the top-k passes or an exact scan) are kept and read back as the stats
