@@ -29,6 +29,7 @@ rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_s $OUT/pmc_write_
 # the default bench line LAST, with this round's PMC passes in place (profiles/ of this box's copy of the repository): its
 # `traffic` then comes from the sources it runs from and `traffic_stale` is false
 cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic_spmm.json profiles/
-python3 bench.py > $OUT/${TAG}_bench_1M_default.json 2> $OUT/bench_default.err || { tail -c 2000 $OUT/bench_default.err; exit 1; }
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_1M_default.json 2> $OUT/bench_default.err || { tail -c 2000 $OUT/bench_default.err; exit 1; }
 need $OUT/${TAG}_bench_1M_default.json
+cp bench_detail.json $OUT/${TAG}_bench_1M_detail.json
 head -c 1500 $OUT/${TAG}_bench_1M_default.json; echo; head -12 $OUT/${TAG}_bench_1M_kernel_stats.csv | cut -c1-160; cat $OUT/${TAG}_pmc_clock.txt | cut -c1-200 | head
