@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "mfma_common.h"
+#include "sortnet.h"
 
 namespace asx {
 
@@ -29,6 +30,17 @@ __device__ __forceinline__ void lds_read16(f16x8 &dst, uint32_t addr) {
 template <int PENDING>
 __device__ __forceinline__ void lds_wait(f16x8 &x) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(PENDING));
+}
+
+// vals sorted DESCENDING in place by Batcher's 64-network (543 compare-exchanges of two instructions each; sortnet.h)
+template <size_t... Is>
+__device__ __forceinline__ void sort64_desc(float (&v)[64], std::index_sequence<Is...>) {
+  auto ce = [&](int a, int b) {
+    const float hi = __builtin_fmaxf(v[a], v[b]), lo = __builtin_fminf(v[a], v[b]);
+    v[a] = hi;
+    v[b] = lo;
+  };
+  (ce(SortNet<64>::kA[Is], SortNet<64>::kB[Is]), ...);
 }
 
 __device__ __forceinline__ void pin16(float (&x)[16]) {
@@ -271,6 +283,234 @@ __global__ __launch_bounds__(512, 2) void theta_f16_kernel(const f16x8 *__restri
   }
 }
 
+// ---- the same sweep with TWO row groups per wave (round 6) -----------------------------------------------------------------------
+// The kernel above gives a wave 32 rows: every 1 KB fragment it reads from LDS feeds ONE MFMA, and the eight waves of a workgroup
+// each read the whole 32 KB stage -- 256 B per clock and CU at the MFMA peak, which is all the LDS array delivers: the sweep was
+// bound by its fragment reads (matrix pipe busy 0.25).  Here a workgroup is FOUR waves of 64 rows (the same 256-row unit, the
+// same thresholds bit for bit: a maximum does not depend on the order it is taken in): a fragment feeds two MFMAs, the stage is
+// read four times instead of eight, and two workgroups share a CU (2 x 66.5 KB of LDS, 2 waves per SIMD as before) so that one's
+// barrier is the other's time.  Same arguments, same unit geometry (unit_groups, parts, bins_out, group_start) as theta_f16_kernel.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void theta_f16x2_kernel(const f16x8 *__restrict__ PA, uint32_t a_supers,
+                                                             uint32_t row_count, const f16x8 *__restrict__ PS,
+                                                             uint32_t s_tiles, uint32_t m, float *__restrict__ theta_out,
+                                                             uint32_t m2, float *__restrict__ theta2_out,
+                                                             uint32_t *__restrict__ unit_counter,
+                                                             const uint32_t *__restrict__ unit_groups, uint32_t parts = 1,
+                                                             float *__restrict__ bins_out = nullptr,
+                                                             const uint32_t *__restrict__ group_start = nullptr) {
+  constexpr int kTileVecs = KS * 4 * 64;  // 16-B vectors of a 128-row tile (one plane)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f16x8 *bufB = reinterpret_cast<f16x8 *>(smem);   // 2 x tile
+  float *s_max = reinterpret_cast<float *>(bufB);  // [4 waves][64 rows][65], aliases the ring once the sweep is over
+  __shared__ uint32_t s_unit;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5, lc = lane & 31;
+
+  // 128-row sample tile J -> LDS: 4 KS pieces of 1 KB, piece p by wave p mod 4 (KS pieces a wave); part < 0: all of a wave's
+  // pieces, else those that go with block `part` of the tile before
+  const f16x8 *PSc = PS;  // the sample image of the current sweep
+  auto stage = [&](uint32_t J, int buf, int part) {
+    const f16x8 *src = PSc + (size_t)J * kTileVecs;
+    f16x8 *dst = bufB + (size_t)buf * kTileVecs;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int p = wv + 4 * i;
+      if (part < 0 || (i & 3) == part)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + p * 64 + lane), (lds_void *)(dst + p * 64), 16, 0, 0);
+    }
+  };
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_unit = atomicAdd(unit_counter, 1u);
+    __syncthreads();
+    const uint32_t U = s_unit;
+    if (U >= a_supers * parts) break;
+    const uint32_t I = U / parts, part = U % parts;
+    const uint32_t per = ((s_tiles / 2 + parts - 1) / parts) * 2, t_lo = min(s_tiles, part * per), t_hi = min(s_tiles, t_lo + per);
+    const uint32_t st = unit_groups ? s_tiles : t_hi - t_lo;
+
+    // the wave's 64 rows: two groups of 32 (sub-tiles 2 (wv & 1) and + 1 of tile 2 I + wv / 2), A fragments in registers
+    f16x8 a0[KS], a1[KS];
+    {
+      const size_t T = (size_t)2 * I + (wv >> 1);
+      const int s0 = 2 * (wv & 1);
+      const f16x8 *a_src = PA + T * kTileVecs + (size_t)s0 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a0[ks] = a_src[(size_t)ks * 256];
+        a1[ks] = a_src[(size_t)ks * 256 + 64];
+      }
+    }
+    float rmax0[2][16], rmax1[2][16];  // [parity bin][accumulator row] of the two row groups
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax0[0][r] = rmax0[1][r] = rmax1[0][r] = rmax1[1][r] = -__builtin_inff();
+    uint32_t in0 = 0xFFFFu, in1 = 0xFFFFu;  // bit r: does accumulator row r of the group belong to the pivot group whose sample is swept?
+    auto value0 = [&](float sdot, int r) -> float { return ((in0 >> r) & 1u) ? sdot : -__builtin_inff(); };
+    auto value1 = [&](float sdot, int r) -> float { return ((in1 >> r) & 1u) ? sdot : -__builtin_inff(); };
+
+    f16x8 b_hi[2];
+#define AS_READ(SET, KSTEP, NN) lds_read16<((KSTEP)*4 + (NN)) * 1024>(b_hi[SET], b_addr);
+    auto contract = [&](uint32_t b_addr, auto nn_c, auto next_c, auto k0_c, auto k1_c, v16f32 &acc0, v16f32 &acc1) {
+      constexpr int nn = decltype(nn_c)::value, next_nn = decltype(next_c)::value;
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+      constexpr int s0 = (nn * KS) & 1;  // set holding ks = 0 of this block
+      v16f32 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+      for (int ks = K0; ks < K1; ++ks) {
+        const int cur = (s0 + ks) & 1, nxt = cur ^ 1;
+        bool more = true;
+        if (ks + 1 < KS) {
+          switch (ks + 1) {  // compile-time offsets
+#define AS_CASE(K) case K: if (nxt) AS_READ(1, K, nn) else AS_READ(0, K, nn) break;
+            AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
+#undef AS_CASE
+          }
+        } else if (next_nn >= 0) {
+          if (nxt) AS_READ(1, 0, (next_nn < 0 ? 0 : next_nn)) else AS_READ(0, 0, (next_nn < 0 ? 0 : next_nn))
+        } else {
+          more = false;
+        }
+        if (more) {
+          if (cur) lds_wait<1>(b_hi[1]); else lds_wait<1>(b_hi[0]);
+        } else {
+          if (cur) lds_wait<0>(b_hi[1]); else lds_wait<0>(b_hi[0]);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks], b_hi[cur], ks == 0 ? z : acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], b_hi[cur], ks == 0 ? z : acc1, 0, 0, 0);
+      }
+    };
+
+    v16f32 accA0, accA1, accB0, accB1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = -__builtin_inff();  // nothing pending
+
+    const uint32_t g_lo = unit_groups ? unit_groups[2 * I] : 0u, g_hi = unit_groups ? unit_groups[2 * I + 1] : 0u;
+    // groups that every row of the unit sweeps alike (no group_start: the band of a row's own neighbourhood) lie side by side in
+    // the image: ONE sweep over all their tiles instead of a prologue (two barriers and an exposed stage load) per group -- a group
+    // is an even number of tiles, so every tile keeps its parity bin
+    const bool merged = unit_groups && !group_start && (s_tiles & 1u) == 0u;
+    const uint32_t g_last = merged ? g_lo : g_hi;
+    const uint32_t st_g = merged ? (g_hi - g_lo + 1u) * s_tiles : st;
+    for (uint32_t g = g_lo; g <= g_last && st_g > 0; ++g) {
+    PSc = unit_groups ? PS + (size_t)g * s_tiles * kTileVecs : PS + (size_t)t_lo * kTileVecs;
+    if (group_start && g_lo != g_hi) {
+      const uint32_t p_lo = group_start[g], p_hi = group_start[g + 1];
+      in0 = in1 = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t pos = I * 256u + (uint32_t)wv * 64u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * lh);
+        in0 |= (pos >= p_lo && pos < p_hi) ? (1u << r) : 0u;
+        in1 |= (pos + 32u >= p_lo && pos + 32u < p_hi) ? (1u << r) : 0u;
+      }
+    }
+    __syncthreads();  // the selection of the unit before is done with s_max (it aliases the ring); the sweep before with its buffers
+    stage(0, 0, -1);
+    __syncthreads();
+    const uint32_t b_addr0 = lds_addr(bufB) + (uint32_t)lane * 16u;
+    for (uint32_t J = 0; J < st_g; J += 2) {
+#define AS_IC(V) std::integral_constant<int, (V)>{}
+// block NN of the tile in buffer PAR (= its parity bin); PREV_PAR = bin of the block whose maxima are taken now
+#define AS_BLOCK(PAR, NN, NEXT, CUR0, CUR1, PREV0, PREV1, PREV_PAR, MORE, JN)  \
+  {                                                                 \
+    constexpr int KH = (KS + 1) / 2;                                \
+    const uint32_t b_addr = b_addr0 + (PAR) * kTileVecs * 16;       \
+    if ((MORE) && wv < 2) stage(JN, (PAR) ^ 1, NN);                 \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(0), AS_IC(KH), CUR0, CUR1); \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                \
+      rmax0[PREV_PAR][r] = __builtin_fmaxf(rmax0[PREV_PAR][r], value0(PREV0[r], r)); \
+      rmax1[PREV_PAR][r] = __builtin_fmaxf(rmax1[PREV_PAR][r], value1(PREV1[r], r)); \
+    }                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2 * KH; ++i) {            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);            \
+    }                                                               \
+    if ((MORE) && wv >= 2) stage(JN, (PAR) ^ 1, NN);                \
+    contract(b_addr, AS_IC(NN), AS_IC(NEXT), AS_IC(KH), AS_IC(KS), CUR0, CUR1); \
+    pin16(rmax0[PREV_PAR]);  /* the maxima are taken by here: PREV's registers are free for the next block */ \
+    pin16(rmax1[PREV_PAR]);                                         \
+  }
+      {  // even tile J (buffer 0, bin 0); tile J + 1 always exists
+        const uint32_t b_addr = b_addr0;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(0, 0, 1, accA0, accA1, accB0, accB1, 1, true, J + 1)
+        AS_BLOCK(0, 1, 2, accB0, accB1, accA0, accA1, 0, true, J + 1)
+        AS_BLOCK(0, 2, 3, accA0, accA1, accB0, accB1, 0, true, J + 1)
+        AS_BLOCK(0, 3, -1, accB0, accB1, accA0, accA1, 0, true, J + 1)
+      }
+      __syncthreads();  // tile J + 1 has landed; everyone is done with buffer 0
+      {  // odd tile J + 1 (buffer 1, bin 1)
+        const bool more = J + 2 < st_g;
+        const uint32_t b_addr = b_addr0 + kTileVecs * 16;
+        AS_READ(0, 0, 0)
+        AS_BLOCK(1, 0, 1, accA0, accA1, accB0, accB1, 0, more, J + 2)
+        AS_BLOCK(1, 1, 2, accB0, accB1, accA0, accA1, 1, more, J + 2)
+        AS_BLOCK(1, 2, 3, accA0, accA1, accB0, accB1, 1, more, J + 2)
+        AS_BLOCK(1, 3, -1, accB0, accB1, accA0, accA1, 1, more, J + 2)
+      }
+#undef AS_BLOCK
+#undef AS_IC
+      __syncthreads();
+    }
+#undef AS_READ
+    // the last block of the sweep (bin 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      rmax0[1][r] = __builtin_fmaxf(rmax0[1][r], value0(accB0[r], r));
+      rmax1[1][r] = __builtin_fmaxf(rmax1[1][r], value1(accB1[r], r));
+      accA0[r] = accA1[r] = accB0[r] = accB1[r] = -__builtin_inff();  // nothing pending for the next sweep
+    }
+    }
+
+    // 64 sub-sample maxima per row -> m-th largest.  s_max[wave][row of the wave's 64][parity * 32 + lane column]
+    float *wm = s_max + (size_t)wv * 64 * 65;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      wm[ro * 65 + lc] = rmax0[0][r];
+      wm[ro * 65 + 32 + lc] = rmax0[1][r];
+      wm[(32 + ro) * 65 + lc] = rmax1[0][r];
+      wm[(32 + ro) * 65 + 32 + lc] = rmax1[1][r];
+    }
+    wave_sync();
+    {
+      const uint32_t row = I * 256 + wv * 64 + lane;
+      float vals[64];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) vals[c] = wm[lane * 65 + c];
+      if (bins_out) {  // (one part of the sample: the selection follows in theta_bins_select_kernel)
+        if (row < row_count) {
+          float *dst = bins_out + ((size_t)row * parts + part) * 64;
+#pragma unroll
+          for (int c = 0; c < 64; ++c) dst[c] = vals[c];
+        }
+      } else {
+        // The m-th (and mm-th) largest of the 64: theta_f16_kernel removes the maximum mm times (64 compares and 64 selects a
+        // round: 18 rounds for the band's K + 1 were a third of a unit's time); a sorting network does it in 543 compare-exchanges
+        // whatever m.  The same value: the m-th largest of a multiset does not depend on how it is found (the maxima hold no NaN:
+        // they start at -inf and only take v_max of products).
+        float t = -__builtin_inff(), t1 = -__builtin_inff();
+        const uint32_t mm = theta2_out ? max(m, m2) : m;  // theta2_out: a second, looser order statistic (m2 >= m)
+        sort64_desc(vals, std::make_index_sequence<SortNet<64>::kCount>{});
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          t1 = (uint32_t)c + 1u == m ? vals[c] : t1;
+          t = (uint32_t)c + 1u == mm ? vals[c] : t;
+        }
+        // the image carries 2^7 per operand: products are 2^14 times the cosines
+        if (row < row_count && theta2_out) theta2_out[row] = t * (1.f / 16384.f);
+        t = t1;
+        if (row < row_count) theta_out[row] = t * (1.f / 16384.f);
+      }
+    }
+    wave_sync();
+  }
+}
+
+
 // the thresholds from the bins the parts of the sample left: maxima over the parts, then the selection of theta_f16_kernel
 __global__ __launch_bounds__(64) void theta_bins_select_kernel(const float *__restrict__ bins, uint32_t row_count, uint32_t parts, uint32_t m,
                                                                float *__restrict__ theta_out, uint32_t m2, float *__restrict__ theta2_out) {
@@ -454,6 +694,13 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   ProfScope ps(ctx, "knn_join_thresholds");
 #define AS_THETA(K)                                                                                                          \
   case K:                                                                                                                    \
+    if (ctx->opt_join_theta_rows64) {                                                                                        \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16x2_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((theta_f16x2_kernel<K>), dim3(std::min<uint32_t>(a_supers * parts, 512u)), dim3(256), lds, ctx->stream, PA, a_supers, row_count, \
+                         (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)nullptr,     \
+                         parts, parts > 1 ? bins.p : (float *)nullptr);                                                      \
+      break;                                                                                                                 \
+    }                                                                                                                        \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA, a_supers, row_count,              \
                        (const f16x8 *)PS.p, s_tiles, m, theta_out, m2, theta2_out, unitc.p, (const uint32_t *)nullptr,       \
@@ -550,6 +797,12 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   const uint32_t *ug_r = ug.p + 2 * (size_t)u_begin;
 #define AS_THETA(K)                                                                                                          \
   case K:                                                                                                                    \
+    if (ctx->opt_join_theta_rows64) {                                                                                        \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16x2_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((theta_f16x2_kernel<K>), dim3(grid), dim3(256), lds, ctx->stream, PA_r, u_count, pos_count,         \
+                         (const f16x8 *)PS.p, kGroupTiles, m, t1_r, m2, t2_r, unitc.p, ug_r, 1u, (float *)nullptr, group_start); \
+      break;                                                                                                                 \
+    }                                                                                                                        \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA_r, u_count, pos_count,             \
                        (const f16x8 *)PS.p, kGroupTiles, m, t1_r, m2, t2_r, unitc.p, ug_r, 1u, (float *)nullptr, group_start); \
@@ -601,6 +854,12 @@ int join_thresholds_f16_band(as_ctx *ctx, uint32_t n, uint32_t d, const void *P_
   const uint32_t *ug_r = ug.p + 2 * (size_t)u_begin;
 #define AS_THETA(K)                                                                                                          \
   case K:                                                                                                                    \
+    if (ctx->opt_join_theta_rows64) {                                                                                        \
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16x2_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((theta_f16x2_kernel<K>), dim3(grid), dim3(256), lds, ctx->stream, PA_r, u_count, pos_count,         \
+                         (const f16x8 *)P_all, 4u, m, t1_r, 0u, (float *)nullptr, unitc.p, ug_r);                            \
+      break;                                                                                                                 \
+    }                                                                                                                        \
     AS_HIP(ctx, hipFuncSetAttribute((const void *)theta_f16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((theta_f16_kernel<K>), dim3(grid), dim3(512), lds, ctx->stream, PA_r, u_count, pos_count,             \
                        (const f16x8 *)P_all, 4u, m, t1_r, 0u, (float *)nullptr, unitc.p, ug_r);                              \

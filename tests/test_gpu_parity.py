@@ -322,6 +322,32 @@ def test_item_graph_image_of_wide_rows_in_one_pass(ctx, join_on, n, d):
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,d", [(70_000, 128), (131_075, 128), (70_000, 72), (66_000, 40)])
+def test_item_graph_threshold_sweeps_with_two_row_groups_per_wave(ctx, join_on, n, d):
+    """The threshold sweeps (grouped sample, own neighbourhood, checks, second pass) on four waves of 64 rows per 256-row unit --
+    every fragment read feeds two MFMAs, the m-th largest bin maximum comes from a sorting network ("join_theta_rows64", round 6,
+    mfma_theta_f16.hip: theta_f16x2_kernel) -- give the thresholds of the eight-waves-of-32 form bit for bit: the same candidate
+    count, the same rows left open, the same tables, the oracle's rows.  Odd and even numbers of k steps, a row count that is no
+    multiple of 256."""
+    X, _ = synth.mixture(n, d, seed=31, n_clusters=48, rank=6)
+    X[11] = 0.0
+    X[9000:9012] = X[123]
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1
+    cand, open_rows = ctx.stat("knn_join_candidates"), ctx.stat("knn_uncertified_rows")
+    ctx.set_option("join_theta_rows64", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_join_candidates") == cand and ctx.stat("knn_uncertified_rows") == open_rows
+    finally:
+        ctx.set_option("join_theta_rows64", 1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.unique(np.concatenate([[11, 123, 9000, 9011, n - 1], np.random.default_rng(6).choice(n, size=80, replace=False)]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n", [70_000, 131_075])
 def test_item_graph_coordinates_and_image_from_one_pass_over_the_rows(ctx, join_on, n):
     """Rows of exactly 128 values: the rotated coordinates (on the matrix pipe) and the f16 form of the rows come out of ONE pass
