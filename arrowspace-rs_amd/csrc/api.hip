@@ -515,6 +515,7 @@ void as_ctx_destroy(as_ctx *ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   join_session_close(ctx);
   if (ctx->join_order) (void)hipFree(ctx->join_order);
+  ctx->deferred.clear();  // (their blocks go to the cache that is freed next)
   for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
   delete ctx;
 }
@@ -647,6 +648,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
 
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name) {
   if (!ctx || !name) return -1;
+  if (!ctx->deferred.empty()) (void)asx::deferred_stats_flush(const_cast<as_ctx *>(ctx));  // counters parked by the last call (common.h)
   if (std::strncmp(name, "handle_cache_", 13) == 0) {  // process-wide: time spent in the device allocator on behalf of handles
     HandleCache &c = handle_cache();
     const std::string n(name + 13);

@@ -12,6 +12,7 @@
 #include <functional>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -62,6 +63,9 @@ struct PendingEvent {
 
 }  // namespace asx
 
+namespace asx {
+struct DeferredStat;  // (below DevBuf)
+}
 struct as_ctx {
   int device = 0;
   const char *cur_scope = nullptr;  // innermost open ProfScope (profile on)
@@ -193,6 +197,9 @@ struct as_ctx {
   uint64_t join_order_n = 0, join_order_cap = 0, join_order_seq = 0;
   // stats of the last call
   std::map<std::string, int64_t> stats;
+  // counters of kernels that nobody decides anything by (blocks contracted / flagged / listed): read back with the NEXT read-back
+  // that has to wait for the stream anyway instead of a round trip of their own (deferred_stats_*, below DevBuf)
+  std::vector<std::unique_ptr<asx::DeferredStat>> deferred;
   // profiling
   bool prof_on = false;
   std::map<std::string, asx::ProfEntry> prof;
@@ -447,6 +454,33 @@ struct DevBuf {
     p = nullptr;
   }
 };
+
+// ---- statistics read back later (round 6) ------------------------------------------------------------------------------------------
+// A kernel's counters that are statistics only used to cost a copy and a stream synchronisation of their own (~25 us with the GPU
+// idle, 22 of them in a build).  The buffer is parked here with the stats it feeds; whoever next has to wait for the stream
+// (read_u32 in the drivers, as_ctx_get_stat) issues the copies in front of its own wait and applies them behind it.
+struct DeferredStat {
+  DevBuf<unsigned long long> buf;
+  std::vector<unsigned long long> host;
+  std::vector<std::pair<std::string, int>> keys;  // stats[name] = host[index]
+};
+inline int deferred_stats_issue(as_ctx *ctx) {
+  for (auto &d : ctx->deferred)
+    if (hipMemcpyAsync(d->host.data(), d->buf.p, d->host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return AS_ERR_HIP;
+  return AS_OK;
+}
+inline void deferred_stats_apply(as_ctx *ctx) {  // (behind a synchronisation of the stream that followed deferred_stats_issue)
+  for (auto &d : ctx->deferred)
+    for (auto &k : d->keys) ctx->stats[k.first] = (int64_t)d->host[(size_t)k.second];
+  ctx->deferred.clear();
+}
+inline int deferred_stats_flush(as_ctx *ctx) {
+  if (ctx->deferred.empty()) return AS_OK;
+  AS_TRY(deferred_stats_issue(ctx));
+  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  deferred_stats_apply(ctx);
+  return AS_OK;
+}
 
 // Input that may live on the host: staged to HBM when needed.
 template <typename T>

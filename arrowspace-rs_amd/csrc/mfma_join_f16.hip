@@ -1209,7 +1209,8 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   const uint32_t W = std::max(1u, std::min(w_opt, T2 / 4));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
-  DevBuf<unsigned long long> stamps;
+  auto parked = std::make_unique<DeferredStat>();  // the kernel's counters: statistics, read back with the next wait for the stream
+  DevBuf<unsigned long long> &stamps = parked->buf;
   AS_TRY(stamps.alloc(ctx, 10));
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   DevBuf<uint32_t> unit_list;  // behind the first pass: the units that hold anything (the kernel walks these alone)
@@ -1254,7 +1255,12 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
 #undef AS_JOIN
     AS_HIP(ctx, hipGetLastError());
   }
-  {
+  if (!(ctx->opt_debug & 8)) {
+    parked->host.resize(10);
+    parked->keys = {{std::string(prof_name) + "_blocks", 5}, {std::string(prof_name) + "_blocks_listed", 7}};
+    if (std::string(prof_name) == "knn_mfma_join_f16") parked->keys.push_back({"knn_join_blocks", 5});  // (mfma_drivers.hip copies it at once)
+    ctx->deferred.push_back(std::move(parked));
+  } else {
     unsigned long long h[10];
     AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));
     AS_HIP(ctx, hipStreamSynchronize(ctx->stream));

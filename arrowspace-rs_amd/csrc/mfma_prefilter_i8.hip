@@ -1096,7 +1096,8 @@ int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, 
   struct { const void *p; } P8{P8v};
   DevBuf<int> thr;
   DevBuf<uint32_t> unitc;
-  DevBuf<unsigned long long> stamps;
+  auto parked = std::make_unique<DeferredStat>();
+  DevBuf<unsigned long long> &stamps = parked->buf;
   AS_TRY(thr.alloc(ctx, (size_t)T2 * kSuperH));
   AS_TRY(unitc.alloc(ctx, 1));
   AS_TRY(stamps.alloc(ctx, 8));
@@ -1156,6 +1157,12 @@ int prefilter_launch(as_ctx *ctx, const void *P8v, uint32_t KS8, double delta8, 
 #undef AS_PRE_NARROW
 #undef AS_PRE
     AS_HIP(ctx, hipGetLastError());
+  }
+  if (!(ctx->opt_debug & 8)) {  // statistics only: read back with the next wait for the stream (common.h: DeferredStat)
+    parked->host.resize(8);
+    parked->keys = {{"knn_join_prefilter_blocks", 0}, {"knn_join_prefilter_blocks_flagged", 1}};
+    ctx->deferred.push_back(std::move(parked));
+    return AS_OK;
   }
   unsigned long long h[8];
   AS_HIP(ctx, copy_d2h(ctx, h, stamps.p, sizeof(h)));

@@ -263,8 +263,10 @@ static int launch_rerank(as_ctx *ctx, const char *name, const double *A, const d
 }
 
 static int read_u32(as_ctx *ctx, const uint32_t *dev, uint32_t *host) {
+  AS_TRY(deferred_stats_issue(ctx));  // (parked counters ride along with this wait: common.h)
   AS_HIP(ctx, copy_d2h(ctx, host, dev, sizeof(uint32_t)));
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  deferred_stats_apply(ctx);
   return AS_OK;
 }
 

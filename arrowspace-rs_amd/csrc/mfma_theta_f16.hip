@@ -813,7 +813,8 @@ int join_thresholds_f16_grouped(as_ctx *ctx, const double *rows, const double *n
   }
 #undef AS_THETA
   AS_HIP(ctx, hipGetLastError());
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only;
+  // the one that stood here cost 28 us of idle GPU per build)
   return AS_OK;
 }
 
