@@ -784,12 +784,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
   AS_TRY(force.alloc(ctx, n));
   hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, ctx->stream, minb.p, 0x7FF0000000000000ull);  // +inf
   hipLaunchKernelGGL(min_norm_kernel, dim3(256), dim3(256), 0, ctx->stream, norms, n, minb.p);
-  unsigned long long mb = 0;
-  AS_HIP(ctx, copy_d2h(ctx, &mb, minb.p, sizeof(mb)));
-  AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double min_norm;
-  std::memcpy(&min_norm, &mb, sizeof(double));
-  hipLaunchKernelGGL(flag_tiny_norm_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, n, min_norm,
+  hipLaunchKernelGGL(flag_tiny_norm_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, n, (const unsigned long long *)minb.p,
                      force.p);
 
   DevBuf<uint32_t> fail1, fail_count;

@@ -133,9 +133,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(const double *__restrict__ 
 // Pairs with 0 < |a||b| <= 1e-12 get cos := 0 in the exact rule but a genuine cosine from the unit
 // rows; a row that can form such a pair is always re-done exactly.  (Exactly-zero rows are
 // consistent: their unit row is 0, so the product is 0 as well.)
-static __global__ void flag_tiny_norm_rows_kernel(const double *__restrict__ norms, uint32_t n, double min_pos_norm,
+// (min_bits: the bits of the smallest positive norm, as min_norm_kernel leaves them ON THE DEVICE -- read here instead of on the host:
+// the read-back in between was a stream synchronisation of every build for one kernel argument)
+static __global__ void flag_tiny_norm_rows_kernel(const double *__restrict__ norms, uint32_t n, const unsigned long long *__restrict__ min_bits,
                                            uint8_t *__restrict__ flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double min_pos_norm = __longlong_as_double((long long)*min_bits);
   if (i < n) {
     const double x = norms[i];
     // non-finite norms as well: an infinite norm meets a NaN norm as cos := 0 under the exact rule (the product of
