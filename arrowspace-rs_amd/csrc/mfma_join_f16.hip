@@ -1299,7 +1299,8 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   // there are about a thousand units whatever the batch (62 units of 32 column super tiles left three quarters of the CUs idle:
   // 0.6 ms for 5 % of the scan's work)
   const uint32_t w_fill = (uint32_t)std::max<uint64_t>(1, (uint64_t)T2 * a_supers / 1024);
-  const uint32_t W = std::max(1u, std::min(std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_one, 2u) : w_one, w_fill), std::max(1u, T2 / 4)));
+  const uint32_t w_masked = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_one_sided_block, 32));
+  const uint32_t W = std::max(1u, std::min(std::min((mask || (perm && !(ctx->opt_debug & 262144))) ? std::min(w_one, w_masked) : w_one, w_fill), std::max(1u, T2 / 4)));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * a_supers;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);
   DevBuf<unsigned long long> stamps;
