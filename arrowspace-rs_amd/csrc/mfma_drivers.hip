@@ -494,9 +494,13 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       AS_TRY(sharded_max_plane_error(ctx, *sr, rp.f16_err));
       ctx->rowmajor_image = oj.Hrow.p;
       AS_TRY(pack_f16_from_rows(ctx, oj.Hrow.p, n, reorder ? oj.perm_own.p : nullptr, n, oj.Phown.p, tiles));
-      oj.err_by_row.release();
+      // every row's own plane error crosses the links too (4 B a row): the pruning of the re-rank bounds each pair by its two rows'
+      // errors as the one-GPU build does (until round 6 the ranks exchanged the largest error only -- one bound for all pairs, a
+      // third more survivors and six times the rows left open)
+      // (kept BY ROW: the lists of a sharded build hold row ids, and the pruning kernel reads a row's own error by its id)
+      AS_TRY(sr->gather(oj.err_by_row.p, sizeof(float)));
+      oj.f16_err_pos.release();
       oj.sharded_rows = true;
-      oj.f16_err_pos.release();  // (the ranks exchange the largest plane error only: one bound for all pairs)
       rows_packed_once = true;
     } else if (sr && !rows && d <= 128) {
       // sharded by rows: every rank packs its own rows, the image of all rows in ROW order is all-gathered (256 B per row at 128
@@ -916,6 +920,10 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
               err_pos = oj->f16_err_pos.p;
             }
           }
+          // a build sharded by rows: the lists hold row ids, the rows are a list (a_ids), the errors were all-gathered by row
+          const float *err_self = nullptr;
+          if (!err_pos && !lists_by_pos && a_ids && oj && oj->err_by_row.p && join_on_f16(ctx, d) && ctx->opt_rerank_pair_bound)
+            err_pos = err_self = oj->err_by_row.p;
           ctx->stats["knn_rerank_pair_bound"] = err_pos ? 1 : 0;
           if (ent_perm) {  // the norms by image position: a survivor's norm is asked for together with its row id
             AS_TRY(norms_pos.alloc(ctx, n));
@@ -925,7 +933,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
           hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
                              ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
                              force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order, err_pos,
-                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)), (const double *)norms_pos.p);
+                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)), (const double *)norms_pos.p, err_self);
         }
         AS_HIP(ctx, hipGetLastError());
         {

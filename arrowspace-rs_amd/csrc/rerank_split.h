@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
                                                            unsigned long long *__restrict__ scored_total,
                                                            const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
                                                            const float *__restrict__ err_pos, float accum_delta, float floor_delta,
-                                                           const double *__restrict__ norms_pos) {
+                                                           const double *__restrict__ norms_pos, const float *__restrict__ err_self = nullptr) {
+  // err_self (or null): the rows' own errors BY ROW ID, where the lists hold row ids and the rows are a list (a build sharded by rows)
   // records are written by PLACE r of the visiting order: the rows of the range in their own order, or (order: place -> row of
   // the whole matrix, row_begin = 0) in the order of the join's image, where the list of place r sits at position r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void rerank_prune_kernel(uint32_t row_begin, u
     const float th_a = theta[a];
     const double nrm_a = norms[a];
     const bool force = force_exact && force_exact[a];
-    const float e_self = err_pos ? err_pos[lr] : 0.f;
+    const float e_self = err_self ? err_self[a] : (err_pos ? err_pos[lr] : 0.f);
     uint32_t C = 0;
     bool overflow = false;
     for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
