@@ -473,9 +473,11 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       // (1 536: 118.8, 3 072: 120.6, 4 096: 130.9); at 1 M and 2 M rows 1 024 is the faster (18.4 / 19.2 ms, 42.7 / 44.0 ms).
       uint32_t first_pivots = (uint32_t)std::max<int64_t>(32, ctx->opt_join_order_pivots);
       if (ctx->opt_join_order_pivots_auto && first_pivots == 1024 && n > 3000000u) first_pivots = 2048;
+      // (a build sharded by rows: every rank holds all coordinates by now; the pivots of its own rows are found here and the
+      // assignments exchanged -- "sharded_order_assign", row_order.hip)
       AS_TRY(cluster_order(ctx, oj.rot_z.p, oj.rot_norm.p, n, 32, oj.perm_own.p, oj.order_piv.p,
                            first_pivots, oj.order_starts.p, &oj.order_np, 4096,
-                           &oj.far_pos, &oj.far_count, &oj.order_near));
+                           &oj.far_pos, &oj.far_count, &oj.order_near, (sr && !rows && ctx->opt_sharded_order_assign) ? sr : nullptr));
     }
     AS_TRY(oj.theta_pos.alloc(ctx, n));
     AS_TRY(oj.theta2_pos.alloc(ctx, n));

@@ -888,10 +888,12 @@ int prefilter_i8(as_ctx *ctx, const void *Ph, const double *rows, const double *
                  uint32_t I_count, const float *theta, unsigned char *mask, const uint32_t *perm);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out = nullptr,
                   uint32_t n_pivots = 0, uint32_t *group_start = nullptr, uint32_t *np_out = nullptr, uint32_t max_pivots = 0,
-                  DevBuf<uint32_t> *far_pos = nullptr, uint32_t *far_count = nullptr, DevBuf<uint32_t> *near_out = nullptr);
+                  DevBuf<uint32_t> *far_pos = nullptr, uint32_t *far_count = nullptr, DevBuf<uint32_t> *near_out = nullptr,
+                  const ShardedRows *own = nullptr);
 int order_by_value(as_ctx *ctx, const double *values, uint32_t n, uint32_t *perm);  // row_order.hip
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np = 256,
-                    uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr, const uint32_t *assign_pre = nullptr);
+                    uint32_t *group_start = nullptr, const float *piv_sub = nullptr, int *keys_out = nullptr, const uint32_t *assign_pre = nullptr,
+                    const ShardedRows *own = nullptr);
 int scatter_by_perm(as_ctx *ctx, const float *in, const uint32_t *perm, uint32_t n, float *out);
 int gather_f32_by_ids(as_ctx *ctx, const float *in, const uint32_t *ids, uint32_t n, float *out);
 uint64_t packed_vecs_f16(uint32_t tiles, uint32_t d);

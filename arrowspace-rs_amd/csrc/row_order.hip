@@ -556,8 +556,11 @@ __global__ void order_group_starts_kernel(const uint64_t *__restrict__ offsets, 
 // group_start (optional, np + 1 values, device): where the rows of every pivot begin in the order
 // keys_out (optional, n values; rotated coordinates only): every row's best (product, pivot) key of the assignment, key_value_bits()
 // of it being the product
+// own (a build sharded by rows that holds every row's coordinates): the pivots of a rank's OWN rows are found here and the
+// assignments (and keys) all-gathered -- 4 B a row instead of every rank sweeping all rows against all pivots; a row's pivot is a
+// function of the row and the pivots alone, so every rank ends with the same order
 int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, const float *piv, uint32_t *perm, uint32_t np,
-                    uint32_t *group_start, const float *piv_sub, int *keys_out, const uint32_t *assign_pre) {
+                    uint32_t *group_start, const float *piv_sub, int *keys_out, const uint32_t *assign_pre, const ShardedRows *own) {
   if (d > 128 || n == 0 || np == 0 || np > (uint32_t)kPivotsMax || np % kPivotChunk != 0)
     return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   const uint32_t dp = (d + 3) / 4 * 4, n_blocks = (n + 255) / 256;
@@ -580,18 +583,24 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
 #define AS_ASSIGN(DPV)                                                                                                         \
   hipLaunchKernelGGL(assign_pivots_kernel<DPV>, dim3(n_blocks), dim3(256), 0, ctx->stream, rows, n, d, piv, assign.p, (int)np)
   const bool on_mfma = d == 32 && np % 32 == 0;
+  // the rows this call sweeps: all of them, or (own) the rank's own range, in place
+  const bool sharded = own && on_mfma && !assign_pre && (uint64_t)own->lo + own->count <= n;
+  const uint32_t r_lo = sharded ? (uint32_t)own->lo : 0u, r_n = sharded ? (uint32_t)own->count : n;
+  const double *r_rows = rows + (size_t)r_lo * d;
+  ctx->stats["knn_join_order_assign_sharded"] = sharded ? 1 : 0;
   if (assign_pre) {
   } else if (on_mfma && np <= (uint32_t)kPivotsPass) {  // the rotated coordinates: on the matrix pipe
-    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(np / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv, np,
-                       assign.p, 0u, 10u, keys_out, keys_out ? 6u : 4u);
+    if (r_n)
+      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(r_n, 128), 512u)), dim3(256), (size_t)(np / 32) * 2 * 64 * 16, ctx->stream, r_rows, r_n,
+                         piv, np, assign.p + r_lo, 0u, 10u, keys_out ? keys_out + r_lo : nullptr, keys_out ? 6u : 4u);
   } else if (on_mfma) {  // ... in passes of 1024 pivots, the best key so far carried from pass to pass
     DevBuf<int> keys;
     if (!keys_out) AS_TRY(keys.alloc(ctx, n));
-    for (uint32_t p0 = 0; p0 < np; p0 += kPivotsPass) {
+    for (uint32_t p0 = 0; p0 < np && r_n; p0 += kPivotsPass) {
       const uint32_t pc = std::min<uint32_t>(kPivotsPass, np - p0);
       const uint32_t flags = (p0 ? 1u : 0u) | (p0 + pc < np ? 2u : (keys_out ? 6u : 4u));
-      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 512u)), dim3(256), (size_t)(pc / 32) * 2 * 64 * 16, ctx->stream, rows, n,
-                         piv + (size_t)p0 * 32, pc, assign.p, p0, 12u, keys_out ? keys_out : keys.p, flags);
+      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(r_n, 128), 512u)), dim3(256), (size_t)(pc / 32) * 2 * 64 * 16, ctx->stream, r_rows, r_n,
+                         piv + (size_t)p0 * 32, pc, assign.p + r_lo, p0, 12u, (keys_out ? keys_out : keys.p) + r_lo, flags);
     }
   } else
   switch (dpv / 32) {
@@ -612,6 +621,11 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
     ctx->stats["knn_join_order_assign_off"] = h;
   }
 #undef AS_ASSIGN
+  if (sharded) {
+    AS_HIP(ctx, hipGetLastError());
+    AS_TRY(own->gather(assign.p, sizeof(uint32_t)));
+    if (keys_out) AS_TRY(own->gather(keys_out, sizeof(int)));
+  }
   hipLaunchKernelGGL(order_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, assign.p, n, n_blocks, counts.p, (int)np);
   AS_HIP(ctx, hipGetLastError());
   AS_TRY(exclusive_scan_u32_u64(ctx, counts.p, (uint64_t)np * n_blocks, offsets.p));
@@ -630,8 +644,13 @@ int order_by_pivots(as_ctx *ctx, const double *rows, uint32_t n, uint32_t d, con
     }
     // (opt_join_order_sub = the divisor of the second set's size: 1 = as many pivots as the first, 2 = half, ...)
     const uint32_t np_sub = std::min<uint32_t>(kPivotsPass, std::max<uint32_t>(32u, np / (uint32_t)std::max<int64_t>(1, ctx->opt_join_order_sub) / 32u * 32u));
-    hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(n, 128), 1024u)), dim3(256), (size_t)(np_sub / 32) * 2 * 64 * 16, ctx->stream, rows, n, piv_sub,
-                       np_sub, assign_sub.p);
+    if (r_n)
+      hipLaunchKernelGGL(assign_pivots_mfma_kernel, dim3(std::min(cdiv(r_n, 128), 1024u)), dim3(256), (size_t)(np_sub / 32) * 2 * 64 * 16, ctx->stream, r_rows, r_n,
+                         piv_sub, np_sub, assign_sub.p + r_lo);
+    if (sharded) {
+      AS_HIP(ctx, hipGetLastError());
+      AS_TRY(own->gather(assign_sub.p, sizeof(uint32_t)));
+    }
     hipLaunchKernelGGL(order_group_starts_kernel, dim3(cdiv(np + 1, 256)), dim3(256), 0, ctx->stream, offsets.p, n_blocks, np, n, gs);
     hipLaunchKernelGGL(order_sub_kernel, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)gs, (const uint32_t *)assign_sub.p, (int)np, perm);
   }
@@ -685,7 +704,7 @@ static int chain_pivots(as_ctx *ctx, float *piv, uint32_t np, uint32_t dpv, uint
 int order_label_stats(as_ctx *ctx, const uint32_t *perm, uint32_t n, uint32_t C);
 int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t n, uint32_t d, uint32_t *perm, float *piv_out,
                   uint32_t n_pivots, uint32_t *group_start, uint32_t *np_out, uint32_t max_pivots, DevBuf<uint32_t> *far_pos,
-                  uint32_t *far_count, DevBuf<uint32_t> *near_out) {
+                  uint32_t *far_count, DevBuf<uint32_t> *near_out, const ShardedRows *own) {
   if (far_count) *far_count = 0;
   if (d > 128 || n < (uint32_t)kPivots * 256u) return fail(ctx, AS_ERR_UNSUPPORTED, "row order: shape not covered");
   // (more than 256 only where a pivot still stands for 512 rows or more: the thresholds of the own join are taken against the
@@ -730,7 +749,7 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
   DevBuf<int> keys;
   float cluster_cut = 0.75f;  // (where the coverage was not measured: what 0.8 of a typical 90 % point is)
   if (may_grow) AS_TRY(keys.alloc(ctx, n));
-  AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr, nullptr));
+  AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, may_grow ? keys.p : nullptr, nullptr, own));
   ctx->stats["knn_join_order_pivots"] = np;
   if (may_grow) {
     // the first set's assignment is the one round 4 measured; what follows runs only where it leaves many rows far from their pivot
@@ -808,11 +827,11 @@ int cluster_order(as_ctx *ctx, const double *rows, const double *norms, uint32_t
       hipLaunchKernelGGL(assign_remap_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const int *)keys.p, np_first > (uint32_t)kPivotsPass ? 12u : 10u,
                          (const int *)keys_new.p, (const uint32_t *)inv.p, n, np > (uint32_t)kPivotsPass ? 12u : 10u, assign.p, keys.p);
       AS_HIP(ctx, hipGetLastError());
-      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr, assign.p));
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, nullptr, assign.p, nullptr));
       ctx->stats["knn_join_order_pivots"] = np;
     } else if (rounds) {  // (no chain: the pivots stay where they are, the rows are assigned again)
       if (near_out) near_out->release();
-      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p, nullptr));
+      AS_TRY(order_by_pivots(ctx, rows, n, d, piv, perm, np, group_start, with_sub ? piv_sub.p : nullptr, keys.p, nullptr, nullptr));
       ctx->stats["knn_join_order_pivots"] = np;
     }
     // The rows still far from their pivot, by image position: their neighbours are not where the image order puts a row's
