@@ -139,9 +139,34 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "release_workspace"         (an action: any value) the context's cached workspace blocks -- a call keeps what it took for the next
  *                               one -- are returned to the device now
  *   "sharded_agreement" (1)     every collective of a sharded call behind a one-word status agreement (as_*_sharded)
+ *  tuning constants and test hooks (every setting gives the same results; kept as options so that the tests and the measurement
+ *  scripts can take the other branch; defaults in parentheses)
+ *   "cand_slack" (8) candidates kept beyond topk + 1 by the top-k passes; "join_bf16" (1) thresholds of the bf16 / f32 joins from bf16
+ *   products; "join_block" (64) column super tiles per unit of the join passes; "join_one_sided_block" (2) the same for the one-sided
+ *   f16 pass behind a mask or on an ordered image; "join_unit_list" (1) the masked f16 pass walks a list of the units that hold
+ *   anything; "join_basis_iters" (4) rounds of subspace iteration behind the rotated coordinates; "join_zproj_mfma" (1) those
+ *   coordinates of 256 .. 1024-wide rows on the matrix pipe; "join_theta_rate" (32) the grouped thresholds' sample, one position
+ *   in N; "join_theta_parts" (1) threshold passes with few rows split the sample over several units; "join_theta_grouped_bad_e3" (10)
+ *   per mille of checked rows that may sit below the plain sample's thresholds before the grouped ones are dropped;
+ *   "join_theta_dip_e3" (50) how far (per mille) below its block's median a threshold sends a row to the whole sample;
+ *   "join_theta_band_auto" (1) the band grows with the clusters the row order found; "join_theta_band_second" (1) the second pass
+ *   never cuts below what the band certified; "join_cone_tiles_max_e3" (600) / "join_cone_split_above_e3" (80) per mille of tile
+ *   pairs kept beyond which the cone bound is dropped / taken again with two cones per tile; "join_second_prefilter" (1) wide rows:
+ *   an int8 first pass in front of the second pass; "second_pass_f16" (1) the second pass on the f16 plane (0: split bf16);
+ *   "rerank_stream_cap" (0) test hook: batches the re-rank's slot stream gets room for at first; "assembly_lanes" (2) graph assembly
+ *   with 32 lanes a row (0: a thread a row); "lambda_v2" (1), "lambda_v3" (1), "lambda_wide" (1) which lambda-tau kernel a width
+ *   takes; "nearest_mfma" (1), "cluster_on_device" (1) the pre-stage's nearest-centroid search on the matrix pipe / its batches on
+ *   the device; "search_scan_f16" (1), "search_scan_sample" (32), "search_scan_rank" (3), "search_scan_cap" (512),
+ *   "search_rot_tail_e3" (100), "search_staged_min_batch" (2^30), "search_stream_quick" (1) the search scan's plane, its guess
+ *   (the m-th best of a 1-in-N sample), list slots per query, when a re-searched index keeps rotated images, batch sizes of the
+ *   staged and the quick streaming form; "signal_min_len" (9000), "signal_tau_bracket" (1), "signal_tau_overlap" (1) item-graph
+ *   lambda: from which signal length as_compute_taumode takes it, the order statistics from a sampled bracket, on a side stream;
+ *   "sharded_own_rows" (1) a sharded build prepares the join from the ranks' own rows; "sharded_order_assign" (1) ... and finds
+ *   the pivots of own rows only (assignments all-gathered); "sharded_inject_failure" (0) test hook: this rank fails at checkpoint N;
+ *   "debug_label_mod" (0) diagnostic: label statistics per image tile
  *   "keep_open_rows" (0)        diagnostic: 1 = the ids of the rows the first exact re-rank of an item graph leaves open (the rows that
  *                               go on to the second pass, the top-k passes or an exact scan) are kept and read back as the stats
- *                               "knn_open_rows_kept" (how many) and "knn_open_row_<i>"
+ *                               knn_open_rows_kept (how many) and knn_open_row_<i>
  *   "debug"                     diagnostics only (outputs may be undefined) */
 int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value);
 int64_t as_ctx_get_stat(const as_ctx *ctx, const char *name);

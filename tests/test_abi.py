@@ -141,3 +141,21 @@ def test_rust_shim_and_integration_doc_follow_the_header():
     m = re.search(r"// \.\.\. (\d+) more: see host/rust/src/hip.rs", doc)
     shown = len(set(re.findall(r"pub fn (as_[a-z0-9_]+)\(", doc.split("// ...")[0].split("```rust")[-1])))
     assert m and int(m.group(1)) + shown == len(syms), (m and m.group(1), shown, len(syms))
+
+
+def test_every_option_the_library_accepts_is_documented_in_the_header():
+    """as_ctx_set_option's names (csrc/api.hip) and the option block of include/arrowspace_hip.h are the same set: round 5's review
+    found A/B switches that existed only in the source."""
+    with open(os.path.join(ROOT, "include", "arrowspace_hip.h")) as f:
+        hdr = f.read()
+    end = hdr.index("int as_ctx_set_option")
+    block = hdr[hdr.rindex("/*", 0, end):end]
+    documented = set(re.findall(r'"([a-z0-9_]+)"', block))
+    with open(os.path.join(ROOT, "arrowspace-rs_amd", "csrc", "api.hip")) as f:
+        api = f.read()
+    start = api.index("int as_ctx_set_option")
+    body = api[start:api.index("\n}\n", start)]
+    accepted = set(re.findall(r'n == "([a-z0-9_]+)"', body))
+    assert len(accepted) > 60
+    assert accepted - documented == set(), sorted(accepted - documented)
+    assert documented - accepted == set(), sorted(documented - accepted)
