@@ -555,7 +555,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
       const char *e = std::getenv("ARROWSPACE_ALLOW_ABLATION");
       return e && e[0] == '1';
     }();
-    const int64_t ablation = 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64);
+    const int64_t ablation = (0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) | 0xE000000;  // (0xE000000: stages of the masked join's listing, mfma_join_f16.hip)
     ctx->opt_debug = allow ? value : (value & ~ablation);
   }
   else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;

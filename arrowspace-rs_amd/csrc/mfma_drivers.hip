@@ -867,7 +867,7 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
       AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos));
-      if (ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
+      if ((ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) || (ctx->opt_debug & 0xE000000)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, oj_local.theta_own.p, 1, cap, cnt_own.p, cand_own.p, oj_local.have_theta2 ? oj_local.theta2_own.p : nullptr,
                           oj_local.P16own.p, oj_local.Phown.p};
       js = &local;

@@ -1,5 +1,6 @@
 """Where the masked f16 join's time goes at n x 128: the product kernel, the diagnostic instantiation with no bit that changes
-anything (bit 30), without the flush's atomics and stores (16384), without the listing at all (2), and the cycle stamps (8).
+anything (bit 30), without the flush's atomics and stores (16384), with the listing cut short behind its prefix sums (0x8000000), behind the sign-bit
+word (0x4000000), behind the pretest (0x2000000), without the listing at all (2).
 usage: join_phases.py [n]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 Xd, cent = synth.mixture_device(n, 128, "cuda", seed=42)
 gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
 A.build_laplacian_matrix(Xd, gp, ctx=ctx); ctx.synchronize()
-for dbg in (0, 1 << 30, 16384, 2, 8, 0):
+for dbg in (0, 1 << 30, 16384, 0x8000000, 0x4000000, 0x2000000, 2, 0):
     ctx.set_option("debug", dbg)
     ts = []
     for it in range(3):
