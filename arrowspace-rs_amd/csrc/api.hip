@@ -555,7 +555,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
       const char *e = std::getenv("ARROWSPACE_ALLOW_ABLATION");
       return e && e[0] == '1';
     }();
-    const int64_t ablation = (0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) | 0xE000000;  // (0xE000000: stages of the masked join's listing, mfma_join_f16.hip)
+    const int64_t ablation = (0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) | 0xE000000;  // (bit 4 also: the lister form's "tiles not listed")  // (0xE000000: stages of the masked join's listing, mfma_join_f16.hip)
     ctx->opt_debug = allow ? value : (value & ~ablation);
   }
   else if (n == "lambda_v2") ctx->opt_lambda_v2 = value;
@@ -612,6 +612,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_theta_rows64") ctx->opt_join_theta_rows64 = value;
   else if (n == "join_one_sided_block") ctx->opt_join_one_sided_block = value;
   else if (n == "sharded_order_assign") ctx->opt_sharded_order_assign = value;
+  else if (n == "join_lister") ctx->opt_join_lister = value;
   else if (n == "keep_open_rows") ctx->opt_keep_open_rows = value;
   else if (n == "release_workspace") {  // an action, not a setting: the context's cached workspace blocks go back to the device now
     (void)hipStreamSynchronize(ctx->stream);

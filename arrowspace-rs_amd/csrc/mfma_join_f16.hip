@@ -1086,6 +1086,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   }
 }
 
+#include "mfma_join_f16_lister.h"
+
 }  // namespace
 
 // 16-B vectors of an f16 image with `tiles` 128-row tiles
@@ -1295,6 +1297,14 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
     if (unit_list.p)
       hipLaunchKernelGGL(join_unit_list_kernel, dim3((unsigned)cdiv(units, (uint64_t)256)), dim3(256), 0, ctx->stream, (const unsigned long long *)mask, T2,
                          I_begin, I_count, W, unit_list.p);
+    // rows of 128 values behind the first pass: the form with lister waves ("join_lister", mfma_join_f16_lister.h)
+    if (mask && KS == 8 && (ctx->opt_debug & ~(int64_t)6) == 0 && ctx->opt_join_lister) {
+      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_lister_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLsBytes));
+      hipLaunchKernelGGL(pair_join_f16_lister_kernel, dim3(grid), dim3(512), kLsBytes, ctx->stream, (const f16x8 *)P, T2, I_begin, I_count, W, n, theta, cap, cnt,
+                         cand, unit_counter, stamps.p, perm, (const unsigned long long *)mask, (const uint32_t *)unit_list.p, (int)ctx->opt_debug);
+      ctx->stats["knn_join_lister"] = 1;
+    } else {
+    ctx->stats["knn_join_lister"] = 0;
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
     if (mask && (K != 8 || ctx->opt_debug == 0)) { /* (the diagnostics of this form exist at 8 k steps only) */    \
@@ -1325,6 +1335,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
       default: return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
     }
 #undef AS_JOIN
+    }
     AS_HIP(ctx, hipGetLastError());
   }
   if (!(ctx->opt_debug & 8)) {
