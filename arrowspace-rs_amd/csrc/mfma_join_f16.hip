@@ -409,11 +409,8 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   // a returning atomic (~2 us before its store can go out) and, taken one by one, makes its wave late at the barrier
   // (a variable of its own, not a piece of the dynamic array the LDS-DMA writes: in front of every LDS access that may alias a
   // pending DMA the compiler waits for vmcnt(0) -- the pieces of the next stage in flight, the stores of the flush before)
-  // (the masked join, round 6: its listing dumps the accumulators of the lanes that hold a pair -- 16 lanes x 64 B per wave, where the
-  // other forms keep four listing slots -- and gives the 3.5 KB back from its queue: 216 entries, still three rounds of the flush)
-  constexpr bool kSparse = MODE == 0 && MASKED;
-  constexpr uint32_t kQueueH = MODE == 1 ? kQueueSearch : (kSparse ? 216u : kQueueJoin);
-  constexpr int kSlotFloats = kSparse ? 64 : 36;
+  constexpr uint32_t kQueueH = MODE == 1 ? kQueueSearch : kQueueJoin;
+  constexpr int kSlotFloats = 36;
   constexpr size_t kSideBytes = (size_t)8 * kQueueH * (sizeof(uint2) + sizeof(float)) + (size_t)8 * 4 * kSlotFloats * sizeof(float) +
                                 (MODE == 1 ? (size_t)2 * kSuperH * sizeof(float) : 0);
   __shared__ __attribute__((aligned(16))) unsigned char s_side[kSideBytes];
@@ -537,7 +534,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   };
   unsigned long long t_unit = 0, t_blocks = 0, t_dma = 0, t_bar = 0, t_mark = 0;
   unsigned long long n_blk = 0, n_pass = 0;  // 32x32 blocks contracted / blocks that went through the element-wise test
-  unsigned long long n_sparse = 0;           // ... of which listed through the dump (the sparse form)
   unsigned long long n_pre = 0;              // blocks whose one-maximum pretest passed (the sign-bit word is formed for these)
   const bool stamp = (dbg & 8) != 0;
   if (stamp) t_mark = now();
@@ -719,67 +715,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
             // pending vector memory operation -- vmcnt(0): the scattered stores of the flush before, the LDS-DMA of the next stage)
             const uint32_t o = qn + inc - c;
             uint32_t qa = q_addr + 8u * o, sa = s_addr + 4u * o;
-            // Sparse blocks (round 6).  The walk below visits all 16 accumulator registers -- 11 instructions each, under a branch --
-            // whatever the block holds; a typical listed block holds ~15 pairs in a dozen of its 64 lanes, at most four in any one
-            // of them.  Where that is so (at most 16 lanes with a pair, at most 4 pairs a lane: wave-uniform tests) those lanes DUMP
-            // their 16 products to the wave's 1 KB of LDS, every lane reads its (up to four) hits back by address -- the register
-            // number is the position of a set bit, and an LDS address may depend on it where a register name cannot -- and writes
-            // them to the queue: four steps instead of sixteen.
-            if constexpr (kSparse) {
-              const unsigned long long hm = __ballot(c != 0u);
-              if ((uint32_t)__builtin_popcountll(hm) <= 16u && !__any(c > 4u)) {
-                const uint32_t dump = lds_addr(ex) + 64u * lanes_below(hm);  // (this lane's 64 bytes, if it holds a pair)
-                if (c != 0u) {
-                  v16f32 vr;
-#pragma unroll
-                  for (int r = 0; r < 16; ++r) vr[r] = acc[r] - nth[r];
-                  asm volatile(
-                      "ds_write_b128 %0, %1\n\t"
-                      "ds_write_b128 %0, %2 offset:16\n\t"
-                      "ds_write_b128 %0, %3 offset:32\n\t"
-                      "ds_write_b128 %0, %4 offset:48"
-                      :
-                      : "v"(dump), "v"(__builtin_shufflevector(vr, vr, 0, 1, 2, 3)), "v"(__builtin_shufflevector(vr, vr, 4, 5, 6, 7)),
-                        "v"(__builtin_shufflevector(vr, vr, 8, 9, 10, 11)), "v"(__builtin_shufflevector(vr, vr, 12, 13, 14, 15))
-                      : "memory");
-                }
-                // register r sits at bits 2 (15 - r) and + 1 of `pass`: the lowest set pair first
-                uint32_t pp = (pass | (pass >> 1)) & 0x55555555u;
-                uint32_t rk[4], fk[4];
-                float vk[4];
-                bool hk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  hk[k] = pp != 0u;
-                  const uint32_t b = hk[k] ? (uint32_t)__builtin_ctz(pp) : 0u;
-                  pp &= pp - 1u;
-                  rk[k] = 15u - (b >> 1);
-                  fk[k] = (pass >> b) & 3u;
-                  // (a lane without a k-th hit reads a word of the dump area: harmless, its value is not used)
-                  asm volatile("ds_read_b32 %0, %1" : "=v"(vk[k]) : "v"(dump + 4u * rk[k]) : "memory");
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vk[0]), "+v"(vk[1]), "+v"(vk[2]), "+v"(vk[3])::"memory");
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  if (hk[k]) {
-                    const uint32_t sc = (__float_as_uint(vk[k] * (1.f / kProductScale)) & ~3u) | fk[k];
-                    const uint32_t row = row0 + (rk[k] & 3u) + 8u * (rk[k] >> 2);
-                    asm volatile(
-                        "ds_write2_b32 %0, %2, %3 offset1:1\n\t"
-                        "ds_write_b32 %1, %4\n\t"
-                        "v_add_u32 %0, 8, %0\n\t"
-                        "v_add_u32 %1, 4, %1"
-                        : "+v"(qa), "+v"(sa)
-                        : "v"(row), "v"(col), "v"(sc)
-                        : "memory");
-                  }
-                }
-                qn += tot;
-                n_sparse += 1;
-                lds_sync();
-                return true;
-              }
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const uint32_t f = (pass >> (2 * (15 - r))) & 3u;  // bit 0: listed for the row, bit 1: for the column (what the flush reads)
@@ -1072,7 +1007,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   if (lane == 0) {
     atomicAdd(stamps + 5, n_blk);
     atomicAdd(stamps + 7, n_pass);
-    if (n_sparse) atomicAdd(stamps + 9, n_sparse);
     if (!stamp && n_pre) atomicAdd(stamps + 1, n_pre);
   }
   if (stamp && lane == 0) {
@@ -1085,8 +1019,6 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
     atomicAdd(stamps + 8, t_flush);
   }
 }
-
-#include "mfma_join_f16_lister.h"
 
 }  // namespace
 
@@ -1298,13 +1230,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
       hipLaunchKernelGGL(join_unit_list_kernel, dim3((unsigned)cdiv(units, (uint64_t)256)), dim3(256), 0, ctx->stream, (const unsigned long long *)mask, T2,
                          I_begin, I_count, W, unit_list.p);
     // rows of 128 values behind the first pass: the form with lister waves ("join_lister", mfma_join_f16_lister.h)
-    if (mask && KS == 8 && (ctx->opt_debug & ~(int64_t)6) == 0 && ctx->opt_join_lister) {
-      AS_HIP(ctx, hipFuncSetAttribute((const void *)pair_join_f16_lister_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLsBytes));
-      hipLaunchKernelGGL(pair_join_f16_lister_kernel, dim3(grid), dim3(512), kLsBytes, ctx->stream, (const f16x8 *)P, T2, I_begin, I_count, W, n, theta, cap, cnt,
-                         cand, unit_counter, stamps.p, perm, (const unsigned long long *)mask, (const uint32_t *)unit_list.p, (int)ctx->opt_debug);
-      ctx->stats["knn_join_lister"] = 1;
-    } else {
-    ctx->stats["knn_join_lister"] = 0;
+    {
 #define AS_JOIN(K)                                                                                                        \
   case K:                                                                                                                 \
     if (mask && (K != 8 || ctx->opt_debug == 0)) { /* (the diagnostics of this form exist at 8 k steps only) */    \
@@ -1340,7 +1266,7 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   }
   if (!(ctx->opt_debug & 8)) {
     parked->host.resize(10);
-    parked->keys = {{std::string(prof_name) + "_blocks", 5}, {std::string(prof_name) + "_blocks_listed", 7}, {std::string(prof_name) + "_blocks_sparse", 9}, {std::string(prof_name) + "_blocks_pretest", 1}};
+    parked->keys = {{std::string(prof_name) + "_blocks", 5}, {std::string(prof_name) + "_blocks_listed", 7}, {std::string(prof_name) + "_blocks_pretest", 1}};
     if (std::string(prof_name) == "knn_mfma_join_f16") parked->keys.push_back({"knn_join_blocks", 5});  // (mfma_drivers.hip copies it at once)
     ctx->deferred.push_back(std::move(parked));
   } else {

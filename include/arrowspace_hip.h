@@ -116,13 +116,11 @@ int as_ctx_synchronize(as_ctx *ctx);
  *                               form in front of the second pass
  *   "join_cone_groups" (1)      the cone bound in two levels from 2048 tiles on: cones around 32 tiles first (0 = the fine level alone)
  *   "join_order_pivots_auto" (1) the first pivots follow the row count (see "join_order_pivots"; 0 = the number given, always)
- *   "join_lister" (1)           the masked f16 join of 128-wide rows with lister waves: four waves contract and dump the blocks that
- *                               can hold a pair into an LDS ring, four list them (0 = every wave lists its own blocks)
  *   "join_theta_rows64" (1)     the threshold sweeps give a wave 64 rows (two MFMAs per fragment read, two workgroups per CU; 0 = 32 rows)
  *   "join_fused_rows_pass" (1)  rows of exactly 128 values: the rotated coordinates and the f16 image from one pass over the rows (0 = two)
  *   "join_pack_wide_tiles" (1)  the f16 image of rows of a multiple of 128 columns in one coalesced pass (0 = the per-fragment packer)
  *   "join_open_order" (1)       the rows the first re-rank leaves open go on in the order of the image (0 = in the order they were flagged)
- *  (the last seven exist so that the tests can build the same table both ways; every setting gives the same result)
+ *  (the last six exist so that the tests can build the same table both ways; every setting gives the same result)
  *  the exact re-rank
  *   "rerank_pair_bound" (1)     the pruning bounds each pair by its two rows' own f16 plane errors
  *   "rerank_share" (1)          a pair two rows both keep is fetched and scored once, its key handed to both (0: every row scores all its own)
