@@ -487,3 +487,33 @@ def test_library_sharded_build_by_image_positions(tmp_path, n, world, d, topk, o
             assert st["knn_join_cone_tiles"] == 1, st
         assert st["knn_join_prefilter"] == 1 and st["knn_join_row_order"] == 1, st
         assert st["sharded_foreign_slots"] * 2 < st["sharded_listed_slots"], st   # most partners of a position live on its own rank
+
+
+def test_one_rank_of_a_sharded_build_replayed_alone(tmp_path):
+    """scripts/rank_of_8.py, the tool behind DESIGN.md section 6's measurement: three processes share the GPU and run
+    as_build_laplacian_sharded over a file transport while rank 1 records what it receives; one process then replays rank 1 with every
+    collective answered from HBM on the library's own stream (nothing is sent).  The replayed block has the recorded entry counts and
+    is, bit for bit, rows [lo, hi) of the one-GPU build of all rows (--check)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "rank_of_8.py")
+    xdir = str(tmp_path / "exchange")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--rows", "200000", "--world", "3", "--rank", "1", "--dir", xdir]
+    rec = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), script, "record"] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert rec.returncode == 0, rec.stderr[-2000:]
+    assert "recorded" in rec.stdout
+    out = str(tmp_path / "replay.json")
+    rep = subprocess.run([sys.executable, script, "replay", "--check", "--reps", "2", "--out", out] + common, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert rep.returncode == 0, rep.stderr[-2000:]
+    with open(out) as f:
+        leg = json.load(f)
+    assert leg["block_equals_rows_of_the_one_gpu_build"] is True
+    assert leg["world"] == 3 and leg["rank"] == 1 and leg["rank_ms"] > 0 and leg["received_bytes_from_peers"] > 0
+    assert leg["stats"]["sharded_by_positions"] == 1 and leg["collectives"] >= 10
