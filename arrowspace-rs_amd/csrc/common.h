@@ -135,6 +135,7 @@ struct as_ctx {
   int64_t opt_join_open_order = 1;       // the rows the first re-rank leaves open go on in the order of the join's image (0: as they were appended)
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
+  int64_t opt_join_basis_sample = 16384; // rotated coordinates: rows of the strided sample the directions are found on
   int64_t opt_sharded_order_assign = 1;  // a build sharded by rows: the row order's pivot assignment on a rank's own rows, the assignments all-gathered (0: every rank sweeps all rows)
   int64_t opt_join_one_sided_block = 2;  // column super tiles per unit of the one-sided f16 pass behind a mask or on an ordered image (second pass, search scan)
   int64_t opt_join_theta_rows64 = 1;     // threshold sweeps: four waves of 64 rows per 256-row unit (two MFMAs per fragment read; mfma_theta_f16.hip), 0: eight waves of 32

@@ -672,7 +672,7 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
       break;
     }
   const size_t lds = (size_t)kDirs * pitch * sizeof(float);
-  const uint64_t stride = std::max<uint64_t>(1, n / 16384);
+  const uint64_t stride = std::max<uint64_t>(1, n / (uint64_t)std::max<int64_t>(1024, std::min<int64_t>(ctx->opt_join_basis_sample, 65536)));
   const uint32_t ns = (uint32_t)((n + stride - 1) / stride);
   DevBuf<float> Qd, Yd, Ypart;
   DevBuf<double> Zs, tpart;

@@ -144,7 +144,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "cand_slack" (8) candidates kept beyond topk + 1 by the top-k passes; "join_bf16" (1) thresholds of the bf16 / f32 joins from bf16
  *   products; "join_block" (64) column super tiles per unit of the join passes; "join_one_sided_block" (2) the same for the one-sided
  *   f16 pass behind a mask or on an ordered image; "join_unit_list" (1) the masked f16 pass walks a list of the units that hold
- *   anything; "join_basis_iters" (4) rounds of subspace iteration behind the rotated coordinates; "join_zproj_mfma" (1) those
+ *   anything; "join_basis_iters" (4) rounds of subspace iteration behind the rotated coordinates, "join_basis_sample" (16384) rows of
+ *   the strided sample they run on (8192: 0.1 - 0.4 ms less per build up to rank 64, 0.8 ms more at rank 128); "join_zproj_mfma" (1) those
  *   coordinates of 256 .. 1024-wide rows on the matrix pipe; "join_theta_rate" (32) the grouped thresholds' sample, one position
  *   in N; "join_theta_parts" (1) threshold passes with few rows split the sample over several units; "join_theta_grouped_bad_e3" (10)
  *   per mille of checked rows that may sit below the plain sample's thresholds before the grouped ones are dropped;
