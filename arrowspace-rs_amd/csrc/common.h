@@ -136,6 +136,7 @@ struct as_ctx {
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
   int64_t opt_join_basis_sample = 16384; // rotated coordinates: rows of the strided sample the directions are found on
+  int64_t opt_sharded_split_assembly = 1;  // a build sharded by rows: degrees, weights and the pruning of a row on its owner, the adjacency exchanged (0: the tables exchanged, every rank ranks all rows)
   int64_t opt_sharded_order_assign = 1;  // a build sharded by rows: the row order's pivot assignment on a rank's own rows, the assignments all-gathered (0: every rank sweeps all rows)
   int64_t opt_join_one_sided_block = 2;  // column super tiles per unit of the one-sided f16 pass behind a mask or on an ordered image (second pass, search scan)
   int64_t opt_join_theta_rows64 = 1;     // threshold sweeps: four waves of 64 rows per 256-row unit (two MFMAs per fragment read; mfma_theta_f16.hip), 0: eight waves of 32
@@ -734,6 +735,23 @@ int two_nn_mfma(as_ctx *ctx, const double *rows, uint64_t n, uint64_t d, const u
 // rows [row_begin, row_begin + row_count) of the n x n Laplacian (the whole matrix: 0, n)
 int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n,
                        uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count);
+// the two halves of it apart (the row-sharded build: each rank ranks and prunes the edges of its own rows, the ranks exchange that
+// adjacency, each assembles its row block from the adjacency of all nodes); K <= 32 only
+struct GraphAdjacency {
+  const uint32_t *adj_j;    // n x K kept neighbours of each node, in rank order
+  const double *adj_w;      // n x K their weights
+  const uint32_t *adj_len;  // n     how many
+};
+int graph_degrees_of_rows(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, const uint32_t *row_ids, uint64_t n_rows, uint32_t K,
+                          const as_graph_params *gp, uint32_t *deg_out);
+int graph_degrees_to_nodes(as_ctx *ctx, const uint32_t *deg_pos, const uint32_t *perm, uint64_t n, uint32_t *deg, unsigned long long *deg_sum);
+int graph_adjacency_of_rows(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, const uint32_t *row_ids, uint64_t n_rows, uint64_t n_nodes,
+                            uint32_t K, const as_graph_params *gp, const uint32_t *deg, const unsigned long long *deg_sum, uint32_t *adj_j, double *adj_w,
+                            uint32_t *adj_len);
+int graph_adjacency_to_nodes(as_ctx *ctx, const uint32_t *pj, const double *pw, const uint32_t *plen, const uint32_t *perm, uint64_t n, uint32_t K,
+                             uint32_t *adj_j, double *adj_w, uint32_t *adj_len);
+int laplacian_from_adjacency(as_ctx *ctx, const GraphAdjacency *adj, uint64_t n, uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin,
+                             uint64_t row_count);
 
 int taumode_lambdas(as_ctx *ctx, const double *items, uint64_t n_items, uint64_t F, as_csr *L,
                     int mode, double arg, bool check_finite, double *lambdas_out);

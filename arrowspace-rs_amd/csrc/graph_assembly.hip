@@ -186,18 +186,21 @@ __device__ __forceinline__ uint32_t half_ballot(bool p, int half) { return (uint
 
 // R rows per half wave with their loads issued together (measured at 1 M rows: R = 1 0.41 ms, R = 2 0.47 ms -- the kernel is bound
 // by its f64 divisions, the square root and the shuffles of the ranking, not by the round trips: R = 1 is what runs).
-template <int R>
+// BY_ID (the row-sharded build): the table holds the n rows of ONE rank, row t of it is node row_ids[t] of the n_nodes of the graph;
+// deg is by node, the outputs stay by row of the table (no in-edge counting here: the ranks exchange the adjacency first).
+template <int R, bool BY_ID = false>
 __global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, uint32_t n, uint32_t K,
                                                           double eps, double sigma, double p, const uint32_t *__restrict__ deg,
                                                           const unsigned long long *__restrict__ deg_sum, uint32_t *__restrict__ adj_j,
                                                           double *__restrict__ adj_w, uint32_t *__restrict__ adj_len, uint32_t *__restrict__ cnt_in,
-                                                          uint32_t r0, uint32_t nr, uint32_t *__restrict__ adj_slot) {
+                                                          uint32_t r0, uint32_t nr, uint32_t *__restrict__ adj_slot,
+                                                          const uint32_t *__restrict__ row_ids = nullptr, uint32_t n_nodes = 0) {
   // adj_slot (or nullptr): the place of each kept edge among the in-edges of its target, as the counting atomic returns it -- the
   // scatter of the reverse edges then needs no second round of atomics (fill_reverse32_kernel)
   const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
   const uint32_t i0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 5) * R;
-  const bool sparsify = ((double)(*deg_sum) / (double)n) > 10.0;  // avg_degree > 10.0 (src/laplacian.rs:229-230)
-  uint32_t j[R], di[R], dj[R], pos[R], len[R];
+  const bool sparsify = ((double)(*deg_sum) / (double)(BY_ID ? n_nodes : n)) > 10.0;  // avg_degree > 10.0 (src/laplacian.rs:229-230)
+  uint32_t j[R], di[R], dj[R], pos[R], len[R], node[R];
   double dist[R], w[R];
   bool live[R], keep[R];
 #pragma unroll
@@ -207,14 +210,15 @@ __global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__rest
     const uint64_t at = live[r] ? (uint64_t)i * K + s : 0;
     j[r] = nbr_idx[at];
     dist[r] = nbr_dist[at];
+    node[r] = BY_ID ? row_ids[i < n ? i : 0] : i;
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t i = i0 + r;
-    keep[r] = live[r] && j[r] != kNoIdx && j[r] != i && dist[r] <= eps;
+    keep[r] = live[r] && j[r] != kNoIdx && j[r] != node[r] && dist[r] <= eps;
     di[r] = dj[r] = 0;
     if (sparsify) {
-      di[r] = deg[i < n ? i : 0];
+      di[r] = deg[i < n ? node[r] : 0];
       dj[r] = deg[keep[r] ? j[r] : 0];
     }
   }
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__rest
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     slot[r] = 0;
-    if (keep[r] && j[r] - r0 < nr) slot[r] = atomicAdd(&cnt_in[j[r] - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
+    if (!BY_ID && keep[r] && j[r] - r0 < nr) slot[r] = atomicAdd(&cnt_in[j[r] - r0], 1u);  // in-edges of the rows [r0, r0 + nr) only
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void adjacency32_kernel(const uint32_t *__rest
       if (keep[r]) {
         adj_j[(uint64_t)i * K + pos[r]] = j[r];
         adj_w[(uint64_t)i * K + pos[r]] = w[r];
-        if (adj_slot && j[r] - r0 < nr) adj_slot[(uint64_t)i * K + pos[r]] = slot[r];
+        if (!BY_ID && adj_slot && j[r] - r0 < nr) adj_slot[(uint64_t)i * K + pos[r]] = slot[r];
       }
     }
   }
@@ -380,6 +384,54 @@ __global__ __launch_bounds__(256) void union_count32r_kernel(const uint32_t *__r
     c += (uint32_t)__popc(half_ballot(have && !found, half));
   }
   if (live && s == 0) ucnt[li] = c;
+}
+
+// ---- the row-sharded form of the first half (sharded.hip): a rank ranks and prunes the edges of ITS rows only ------------------
+// degrees of the rows of one rank's table (row t is node row_ids[t])
+__global__ void degree_by_ids_kernel(const uint32_t *__restrict__ nbr_idx, const double *__restrict__ nbr_dist, const uint32_t *__restrict__ row_ids,
+                                     uint32_t n, uint32_t K, double eps, uint32_t *__restrict__ deg) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t i = row_ids[t];
+  uint32_t c = 0;
+  for (uint32_t s = 0; s < K; ++s) {
+    const uint32_t j = nbr_idx[(uint64_t)t * K + s];
+    if (j != kNoIdx && j != i && nbr_dist[(uint64_t)t * K + s] <= eps) ++c;
+  }
+  deg[t] = c;
+}
+// degrees by position of the image order -> by node, and their sum
+__global__ void degree_to_nodes_kernel(const uint32_t *__restrict__ deg_pos, const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ deg,
+                                       unsigned long long *__restrict__ deg_sum) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (p < n) {
+    v = deg_pos[p];
+    deg[perm[p]] = (uint32_t)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  block_add_u64(deg_sum, 1u, v);
+}
+// adjacency by position -> by node (32 lanes per row)
+__global__ __launch_bounds__(256) void adjacency_to_nodes_kernel(const uint32_t *__restrict__ pj, const double *__restrict__ pw, const uint32_t *__restrict__ plen,
+                                                                 const uint32_t *__restrict__ perm, uint32_t n, uint32_t K, uint32_t *__restrict__ adj_j,
+                                                                 double *__restrict__ adj_w, uint32_t *__restrict__ adj_len) {
+  const uint32_t s = threadIdx.x & 31u, p = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (p >= n) return;
+  const uint32_t i = perm[p], len = plen[p];
+  if (s == 0) adj_len[i] = len;
+  if (s < len) {
+    adj_j[(uint64_t)i * K + s] = pj[(uint64_t)p * K + s];
+    adj_w[(uint64_t)i * K + s] = pw[(uint64_t)p * K + s];
+  }
+}
+// in-edges of the rows [r0, r0 + nr) counted over the adjacency of all nodes; an edge keeps the place the atomic returned
+__global__ __launch_bounds__(256) void count_in_edges32_kernel(const uint32_t *__restrict__ adj_j, const uint32_t *__restrict__ adj_len, uint32_t n, uint32_t K,
+                                                               uint32_t r0, uint32_t nr, uint32_t *__restrict__ cnt_in, uint32_t *__restrict__ adj_slot) {
+  const uint32_t s = threadIdx.x & 31u, i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (i >= n || s >= adj_len[i]) return;
+  const uint32_t j = adj_j[(uint64_t)i * K + s] - r0;
+  if (j < nr) adj_slot[(uint64_t)i * K + s] = atomicAdd(&cnt_in[j], 1u);
 }
 
 // ---- K4: reverse edges ------------------------------------------------------------------------
@@ -1083,8 +1135,10 @@ __global__ void write_rows_serial_kernel(const uint32_t *__restrict__ rows_list,
 // range [0, n)).  Weights and the pruning need the degrees of ALL rows (two passes over the table, replicated: they are
 // the cheap part); the reverse-edge scatter, the unions, the sorts and the CSR rows are done for the range only.
 // The CSR that comes out has row_count rows, GLOBAL column ids, indptr starting at 0.
-int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n64,
-                       uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count) {
+// given != nullptr: the ranked and pruned adjacency of ALL nodes is there already (the row-sharded build ranks each rank's rows on
+// their owner and exchanges the result: graph_adjacency_of_rows below); the table arguments are not read.
+static int assemble_rows(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, const GraphAdjacency *given, uint64_t n64,
+                         uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin, uint64_t row_count) {
   if (K > kMaxK) return fail(ctx, AS_ERR_UNSUPPORTED, "topk + 1 must be <= 256");
   const uint32_t n = (uint32_t)n64;
   if (row_begin + row_count > n64) return fail(ctx, AS_ERR_ARG, "row range out of bounds");
@@ -1102,11 +1156,16 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   // records sized by its bound n K (no read-back of their number), unions ordered by rank counting, hub rows a wave each.
   // K > 32 (or "assembly_lanes" 0, the independent form the tests compare with): one thread per row.
   const bool ranked = K <= 32 && ctx->opt_assembly_lanes != 0;
-  AS_TRY(deg.alloc(ctx, n));
+  if (given && !ranked) return fail(ctx, AS_ERR_ARG, "graph assembly: a given adjacency needs the ranked form");
+  if (!given) {
+    AS_TRY(deg.alloc(ctx, n));
+    AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
+    AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
+    AS_TRY(adj_len.alloc(ctx, n));
+  }
   AS_TRY(deg_sum.alloc(ctx, 1));
-  AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
-  AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
-  AS_TRY(adj_len.alloc(ctx, n));
+  const uint32_t *aj = given ? given->adj_j : adj_j.p, *alen = given ? given->adj_len : adj_len.p;
+  const double *aw = given ? given->adj_w : adj_w.p;
   AS_TRY(cnt_in.alloc(ctx, (size_t)nr + 1));
   if (!ranked) AS_TRY(cursor.alloc(ctx, (size_t)nr + 1));
   AS_TRY(rev_ptr.alloc(ctx, (size_t)nr + 1));
@@ -1124,7 +1183,9 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   {
     ProfScope ps(ctx, "graph_assembly");
     const unsigned gb32 = (unsigned)cdiv((uint64_t)n * 32, (uint64_t)256), gr32 = (unsigned)std::max<uint64_t>(1, cdiv((uint64_t)nr * 32, (uint64_t)256));
-    if (ranked) {
+    if (given) {
+      hipLaunchKernelGGL(count_in_edges32_kernel, dim3(gb32), dim3(256), 0, st, aj, alen, n, K, r0, nr, cnt_in.p, adj_slot.p);
+    } else if (ranked) {
       hipLaunchKernelGGL(degree_rows64_kernel, dim3((unsigned)std::min<uint64_t>(cdiv((uint64_t)n, (uint64_t)256), 256 * 8)), dim3(256), 0, st, nbr_idx,
                          nbr_dist, n, K, gp->eps, deg.p, deg_sum.p);
       hipLaunchKernelGGL(adjacency32_kernel<1>, dim3(gb32), dim3(256), 0, st, nbr_idx, nbr_dist, n, K, gp->eps, sigma, gp->p, deg.p, deg_sum.p,
@@ -1141,8 +1202,8 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
                          gp->p, deg.p, deg_sum.p, adj_j.p, adj_w.p, adj_len.p, cnt_in.p, r0, nr);
     AS_TRY(exclusive_scan_u32_u64(ctx, cnt_in.p, nr, rev_ptr.p));
     if (ranked) {
-      hipLaunchKernelGGL(fill_reverse32_kernel<2>, dim3((unsigned)cdiv((uint64_t)cdiv((uint64_t)n, (uint64_t)2) * 32, (uint64_t)256)), dim3(256), 0, st, adj_j.p, adj_w.p, adj_slot.p, adj_len.p, n, K, rev_ptr.p, rev.p, r0, nr);
-      hipLaunchKernelGGL(union_count32r_kernel, dim3(gr32), dim3(256), 0, st, adj_j.p, adj_len.p, nr, K, rev_ptr.p, rev.p, ucnt.p, r0);
+      hipLaunchKernelGGL(fill_reverse32_kernel<2>, dim3((unsigned)cdiv((uint64_t)cdiv((uint64_t)n, (uint64_t)2) * 32, (uint64_t)256)), dim3(256), 0, st, aj, aw, adj_slot.p, alen, n, K, rev_ptr.p, rev.p, r0, nr);
+      hipLaunchKernelGGL(union_count32r_kernel, dim3(gr32), dim3(256), 0, st, aj, alen, nr, K, rev_ptr.p, rev.p, ucnt.p, r0);
     } else {
       AS_HIP(ctx, copy_d2h(ctx, &n_edges_dir, rev_ptr.p + nr, sizeof(uint64_t)));
       AS_HIP(ctx, hipStreamSynchronize(st));
@@ -1202,13 +1263,13 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   if (ranked) {
     AS_TRY(mid_rows.alloc(ctx, (size_t)nr + 1));
     ProfScope ps(ctx, "graph_assembly");
-    hipLaunchKernelGGL(write_rows_ranked_kernel<2>, dim3(cdiv((uint64_t)nr + 1, 16)), dim3(256), 0, st, adj_j.p, adj_w.p, adj_len.p, nr, K, rev_ptr.p, rev.p,
+    hipLaunchKernelGGL(write_rows_ranked_kernel<2>, dim3(cdiv((uint64_t)nr + 1, 16)), dim3(256), 0, st, aj, aw, alen, nr, K, rev_ptr.p, rev.p,
                        eptr.p, m->indptr, m->indices, m->data, mid_rows.p, big_rows.p, big_count.p, r0);
-    hipLaunchKernelGGL(write_rows_mid_kernel, dim3(2048), dim3(256), 0, st, mid_rows.p, big_count.p, adj_j.p, adj_w.p, adj_len.p, K, rev_ptr.p, rev.p,
+    hipLaunchKernelGGL(write_rows_mid_kernel, dim3(2048), dim3(256), 0, st, mid_rows.p, big_count.p, aj, aw, alen, K, rev_ptr.p, rev.p,
                        eptr.p, m->indptr, m->indices, m->data, r0);
-    hipLaunchKernelGGL(write_rows_hub_kernel, dim3(512), dim3(256), 0, st, big_rows.p, big_count.p + 1, adj_j.p, adj_w.p, adj_len.p, K, rev_ptr.p,
+    hipLaunchKernelGGL(write_rows_hub_kernel, dim3(512), dim3(256), 0, st, big_rows.p, big_count.p + 1, aj, aw, alen, K, rev_ptr.p,
                        rev.p, eptr.p, m->indptr, m->indices, m->data, r0);
-    hipLaunchKernelGGL(write_rows_serial_kernel, dim3(cdiv((uint64_t)nr + 1, 256)), dim3(256), 0, st, big_rows.p, big_count.p + 1, adj_j.p, adj_w.p, adj_len.p,
+    hipLaunchKernelGGL(write_rows_serial_kernel, dim3(cdiv((uint64_t)nr + 1, 256)), dim3(256), 0, st, big_rows.p, big_count.p + 1, aj, aw, alen,
                        K, rev_ptr.p, rev.p, eptr.p, ecol.p, ew.p, m->indptr, m->indices, m->data, r0);
   } else {
     ProfScope ps(ctx, "graph_assembly");
@@ -1223,6 +1284,49 @@ int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_d
   ctx->stats["graph_nnz"] = (int64_t)nnz;
   *out = m;
   holder.p = nullptr;
+  return AS_OK;
+}
+
+int laplacian_from_knn(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, uint64_t n, uint32_t K, const as_graph_params *gp, as_csr **out,
+                       uint64_t row_begin, uint64_t row_count) {
+  return assemble_rows(ctx, nbr_idx, nbr_dist, nullptr, n, K, gp, out, row_begin, row_count);
+}
+int laplacian_from_adjacency(as_ctx *ctx, const GraphAdjacency *adj, uint64_t n, uint32_t K, const as_graph_params *gp, as_csr **out, uint64_t row_begin,
+                             uint64_t row_count) {
+  return assemble_rows(ctx, nullptr, nullptr, adj, n, K, gp, out, row_begin, row_count);
+}
+
+// ---- the first half for the rows of one rank (row t of the table is node row_ids[t]) ---------------------------------------------
+int graph_degrees_of_rows(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, const uint32_t *row_ids, uint64_t n_rows, uint32_t K,
+                          const as_graph_params *gp, uint32_t *deg_out) {
+  if (!n_rows) return AS_OK;
+  hipLaunchKernelGGL(degree_by_ids_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, ctx->stream, nbr_idx, nbr_dist, row_ids, (uint32_t)n_rows, K, gp->eps, deg_out);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+int graph_degrees_to_nodes(as_ctx *ctx, const uint32_t *deg_pos, const uint32_t *perm, uint64_t n, uint32_t *deg, unsigned long long *deg_sum) {
+  AS_HIP(ctx, hipMemsetAsync(deg_sum, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(degree_to_nodes_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, deg_pos, perm, (uint32_t)n, deg, deg_sum);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+int graph_adjacency_of_rows(as_ctx *ctx, const uint32_t *nbr_idx, const double *nbr_dist, const uint32_t *row_ids, uint64_t n_rows, uint64_t n_nodes,
+                            uint32_t K, const as_graph_params *gp, const uint32_t *deg, const unsigned long long *deg_sum, uint32_t *adj_j, double *adj_w,
+                            uint32_t *adj_len) {
+  if (K > 32) return fail(ctx, AS_ERR_ARG, "graph_adjacency_of_rows: topk + 1 must be <= 32");
+  if (!n_rows) return AS_OK;
+  const double sigma = gp->has_sigma ? gp->sigma : 1.0;
+  hipLaunchKernelGGL((adjacency32_kernel<1, true>), dim3((unsigned)cdiv(n_rows * 32, (uint64_t)256)), dim3(256), 0, ctx->stream, nbr_idx, nbr_dist,
+                     (uint32_t)n_rows, K, gp->eps, sigma, gp->p, deg, deg_sum, adj_j, adj_w, adj_len, (uint32_t *)nullptr, 0u, 0u, (uint32_t *)nullptr, row_ids,
+                     (uint32_t)n_nodes);
+  AS_HIP(ctx, hipGetLastError());
+  return AS_OK;
+}
+int graph_adjacency_to_nodes(as_ctx *ctx, const uint32_t *pj, const double *pw, const uint32_t *plen, const uint32_t *perm, uint64_t n, uint32_t K,
+                             uint32_t *adj_j, double *adj_w, uint32_t *adj_len) {
+  hipLaunchKernelGGL(adjacency_to_nodes_kernel, dim3((unsigned)cdiv(n * 32, (uint64_t)256)), dim3(256), 0, ctx->stream, pj, pw, plen, perm, (uint32_t)n, K,
+                     adj_j, adj_w, adj_len);
+  AS_HIP(ctx, hipGetLastError());
   return AS_OK;
 }
 

@@ -510,6 +510,10 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
 
   DevBuf<uint64_t> idx, idx_all;
   DevBuf<double> dst, dst_all;
+  // (the assembly split between the owner of a row and the owner of a row block: see "tables of all positions" below)
+  DevBuf<uint32_t> deg_pos, deg_node, pj, plen, adj_j, adj_len;
+  DevBuf<double> pw, adj_w;
+  DevBuf<unsigned long long> deg_sum;
   AS_TRY(idx.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1) * K));
   AS_TRY(dst.alloc(ctx, (size_t)std::max<uint64_t>(rows_here, 1) * K));
   AS_TRY(idx_all.alloc(ctx, (size_t)n * K));
@@ -671,7 +675,43 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
       AS_HIP(ctx, hipGetLastError());
     }
     // ---- tables of all positions on every rank, then back to row order ----
-    if (oj.reorder) {
+    const bool split_assembly = ctx->opt_sharded_split_assembly && K <= 32 && ctx->opt_assembly_lanes != 0 && !params->self_in_results;
+    ctx->stats["sharded_split_assembly"] = oj.reorder && split_assembly ? 1 : 0;
+    if (oj.reorder && split_assembly) {
+      // The first half of the assembly on the owner of each row: a rank counts the degrees of its rows, the degrees of all nodes are
+      // exchanged (4 bytes a node), it ranks and prunes the edges of its rows, and the ADJACENCY crosses the links in place of the
+      // table (the same 12 bytes an entry + 4 a row) -- the weights and the ranking of 1/W of the rows instead of all of them.
+      AS_TRY(deg_pos.alloc(ctx, n));
+      AS_TRY(deg_node.alloc(ctx, n));
+      AS_TRY(deg_sum.alloc(ctx, 1));
+      AS_TRY(pj.alloc(ctx, (size_t)n * K));
+      AS_TRY(pw.alloc(ctx, (size_t)n * K));
+      AS_TRY(plen.alloc(ctx, n));
+      AS_TRY(adj_j.alloc(ctx, (size_t)n * K));
+      AS_TRY(adj_w.alloc(ctx, (size_t)n * K));
+      AS_TRY(adj_len.alloc(ctx, n));
+      {
+        ProfScope ps(ctx, "graph_assembly");
+        if (rows_here) AS_TRY(graph_degrees_of_rows(ctx, idx32.p, dst.p, oj.perm_own.p + lo, rows_here, K32, params, deg_pos.p + lo));
+      }
+      AS_TRY(ag.before_collective());
+      AS_TRY(gather_rows(ctx, comm, deg_pos.p + lo, deg_pos.p, n, sizeof(uint32_t)));
+      {
+        ProfScope ps(ctx, "graph_assembly");
+        AS_TRY(graph_degrees_to_nodes(ctx, deg_pos.p, oj.perm_own.p, n, deg_node.p, deg_sum.p));
+        if (rows_here)
+          AS_TRY(graph_adjacency_of_rows(ctx, idx32.p, dst.p, oj.perm_own.p + lo, rows_here, n, K32, params, deg_node.p, deg_sum.p, pj.p + lo * K,
+                                         pw.p + lo * K, plen.p + lo));
+      }
+      AS_TRY(ag.before_collective());
+      AS_TRY(gather_rows(ctx, comm, pj.p + lo * K, pj.p, n, K * sizeof(uint32_t)));
+      AS_TRY(gather_rows(ctx, comm, pw.p + lo * K, pw.p, n, K * sizeof(double)));
+      AS_TRY(gather_rows(ctx, comm, plen.p + lo, plen.p, n, sizeof(uint32_t)));
+      {
+        ProfScope ps(ctx, "graph_assembly");
+        AS_TRY(graph_adjacency_to_nodes(ctx, pj.p, pw.p, plen.p, oj.perm_own.p, n, K32, adj_j.p, adj_w.p, adj_len.p));
+      }
+    } else if (oj.reorder) {
       // (the indices cross the links as 32-bit values: 12 instead of 16 bytes per table entry, 0.8 GB instead of 1.1 at 4 M x 17)
       DevBuf<uint32_t> idx_pos;
       DevBuf<double> dst_pos;
@@ -708,7 +748,11 @@ static int build_laplacian_sharded_body(as_ctx *ctx, as_comm *comm, const double
   DevBuf<uint64_t> nnz_d;
   AS_TRY(nnz_d.alloc(ctx, 1));
   uint64_t nnz = 0;
-  if (rows_here) {
+  if (rows_here && adj_j.p) {
+    const GraphAdjacency given{adj_j.p, adj_w.p, adj_len.p};
+    AS_TRY(laplacian_from_adjacency(ctx, &given, n, (uint32_t)K, params, out_block, lo, rows_here));
+    nnz = as_csr_nnz(*out_block);
+  } else if (rows_here) {
     AS_TRY(as_laplacian_from_knn_rows(ctx, idx_all.p, dst_all.p, n, params, lo, rows_here, out_block));
     (*out_block)->known_symmetric = 1;  // the table is the library's own: one distance per pair
     nnz = as_csr_nnz(*out_block);
