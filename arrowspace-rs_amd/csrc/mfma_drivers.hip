@@ -931,11 +931,33 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
             AS_TRY(norms_pos.alloc(ctx, n));
             hipLaunchKernelGGL(gather_f64_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, norms, ent_perm, n, norms_pos.p);
           }
+          // one list of candidates with a bound per pair (every item graph of 128-wide rows): a row per half wave with the list in
+          // registers, the lists longer than 128 entries left to the LDS form (rerank_split.h)
+          const bool halves = js->n_src == 1 && err_pos && ctx->opt_rerank_prune_halves;
+          DevBuf<uint32_t> long_rows;
+          auto parked = std::make_unique<DeferredStat>();
+          if (halves) {
+            AS_TRY(long_rows.alloc(ctx, (size_t)row_count));
+            AS_TRY(parked->buf.alloc(ctx, 1));
+            AS_HIP(ctx, hipMemsetAsync(parked->buf.p, 0, sizeof(unsigned long long), ctx->stream));
+          }
+          const float accum_f = (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), floor_f = (float)(rect_delta(d) * (1.0 + 1e-6));
           ProfScope ps_prune(ctx, "knn_rerank_prune");
-          hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
+          if (halves)
+            hipLaunchKernelGGL(rerank_prune_halves_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 8), 256 * 32)), dim3(256), 0, ctx->stream,
+                               (uint32_t)row_begin, row_count, js->theta, norms, js->cnt, js->cand, js->cap, K, force.p, rectify, records.p, slots, ent_perm,
+                               list_inv, scored.p, a_ids, score_order, err_pos, accum_f, floor_f, (const double *)norms_pos.p, err_self, long_rows.p,
+                               reinterpret_cast<uint32_t *>(parked->buf.p));
+          hipLaunchKernelGGL(rerank_prune_kernel, dim3(std::min<uint64_t>(cdiv(row_count, 4), halves ? 1024 : 256 * 32)), dim3(256), (size_t)4 * cmax * 12,
                              ctx->stream, (uint32_t)row_begin, row_count, js->theta, norms, js->n_src, js->cnt, js->cand, js->cap, cmax, K,
                              force.p, prune_delta, rectify, records.p, slots, ent_perm, list_inv, scored.p, a_ids, score_order, err_pos,
-                             (float)(cos_delta_f16_accum(d) * (1.0 + 1e-6)), (float)(rect_delta(d) * (1.0 + 1e-6)), (const double *)norms_pos.p, err_self);
+                             accum_f, floor_f, (const double *)norms_pos.p, err_self, halves ? (const uint32_t *)long_rows.p : nullptr,
+                             halves ? reinterpret_cast<const uint32_t *>(parked->buf.p) : nullptr);
+          if (halves && !a_ids) {  // (statistics: read back with the next wait for the stream)
+            parked->host.resize(1);
+            parked->keys = {{"knn_rerank_long_lists", 0}};
+            ctx->deferred.push_back(std::move(parked));
+          }
         }
         AS_HIP(ctx, hipGetLastError());
         {

@@ -25,4 +25,5 @@ for rep in range(3):
         import hashlib
         sig = hashlib.sha1(ip.tobytes() + ix.tobytes() + dv.tobytes()).hexdigest()[:10]
         print("%s=%d  build %.2f ms  nnz %d csr %s  " % (opt, v, dt * 1e3, gl.matrix.nnz(), sig) + "  ".join("%s %.2f" % (k.replace("knn_", ""), ms) for k, (ms, _) in top) + "  | basis %.2f pack %.2f thr %.2f band %.2f join %.2f pre %.2f cand %d open %d second %.2f listed %d pretest %d of %d" % (pr.get("knn_join_prefilter_basis", (0, 0))[0], pr.get("pack_unit_rows", (0, 0))[0], pr.get("knn_join_thresholds", (0, 0))[0], pr.get("knn_join_thresholds_band", (0, 0))[0], pr.get("knn_mfma_join_f16", (0, 0))[0], pr.get("knn_join_prefilter", (0, 0))[0], ctx.stat("knn_join_candidates"), ctx.stat("knn_uncertified_rows"), pr.get("knn_mfma_join_f16_second", (0, 0))[0], ctx.stat("knn_mfma_join_f16_blocks_listed"), ctx.stat("knn_mfma_join_f16_blocks_pretest"), ctx.stat("knn_mfma_join_f16_blocks")), flush=True)
+        print("      rerank: prune %.3f link %.3f fill %.3f score %.3f rank %.3f  assembly %.3f  long lists %d" % tuple([pr.get("knn_rerank_" + k, (0, 0))[0] for k in ("prune", "link", "fill", "score", "rank")] + [pr.get("graph_assembly", (0, 0))[0], ctx.stat("knn_rerank_long_lists")]), flush=True)
         del gl

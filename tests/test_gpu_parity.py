@@ -348,6 +348,32 @@ def test_item_graph_threshold_sweeps_with_two_row_groups_per_wave(ctx, join_on, 
     assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
 
 
+@pytest.mark.parametrize("n,clusters", [(70_001, 40), (90_000, 3)])
+def test_item_graph_pruning_with_a_row_per_half_wave(ctx, join_on, n, clusters):
+    """The pruning of the re-rank with a row per half wave and the list in registers ("rerank_prune_halves", round 6,
+    rerank_split.h: rerank_prune_halves_kernel; lists longer than 128 entries go on to the LDS form) leaves the records of the
+    one-row-per-wave form: the same rows open, the same tables, the oracle's rows.  An odd row count (a half without a row), few
+    wide clusters (long lists), zero rows and duplicates."""
+    X, _ = synth.mixture(n, 128, seed=37, n_clusters=clusters, rank=6)
+    X[11] = 0.0
+    X[5000:5040] = X[123]
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    idx, dist = A.knn_cosine(X, gp)
+    assert ctx.stat("knn_join") == 1 and ctx.stat("knn_rerank_pair_bound") == 1
+    open_rows, long_lists = ctx.stat("knn_uncertified_rows"), ctx.stat("knn_rerank_long_lists")
+    assert long_lists >= (1 if clusters == 3 else 0)
+    ctx.set_option("rerank_prune_halves", 0)
+    try:
+        idx0, dist0 = A.knn_cosine(X, gp)
+        assert ctx.stat("knn_uncertified_rows") == open_rows
+    finally:
+        ctx.set_option("rerank_prune_halves", 1)
+    assert np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+    sample = np.unique(np.concatenate([[11, 123, 5000, 5039, n - 1], np.random.default_rng(8).choice(n, size=80, replace=False)]))
+    oi, od = O.knn_cosine_rows(X, ogp(gp), sample)
+    assert np.array_equal(idx[sample], oi) and np.array_equal(dist[sample], od)
+
+
 @pytest.mark.parametrize("n", [70_000, 131_075])
 def test_item_graph_coordinates_and_image_from_one_pass_over_the_rows(ctx, join_on, n):
     """Rows of exactly 128 values: the rotated coordinates (on the matrix pipe) and the f16 form of the rows come out of ONE pass
