@@ -1211,7 +1211,13 @@ int join_f16(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, uint32_t I_begi
   if (!(KS >= 1 && KS <= 8)) return fail(ctx, AS_ERR_UNSUPPORTED, "f16 join: dim not covered");
   const uint32_t T2 = (n + kSuperH - 1) / kSuperH;
   const size_t lds = f16_join_lds(KS, false);
-  const uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  uint32_t w_opt = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_block, 64));
+  // The masked pass over a SHORT range of row super tiles (a rank of a sharded build): nearly all flagged stages of a row super tile
+  // sit around the diagonal, in one or two units of 64 column super tiles -- 244 row super tiles (1 M rows, 8 ranks) leave some 400
+  // heavy units for 256 workgroups, and the longest of them is the pass: 1.68 ms for a sixth of the one-GPU pass's blocks, 1.04 with
+  // units of one column super tile (977 row super tiles -- 4 M rows, 8 ranks --: 64 and 8 within 3 %, 2 a sixth slower).
+  if (mask && ctx->opt_join_masked_block > 0) w_opt = (uint32_t)std::min<int64_t>(ctx->opt_join_masked_block, 64);
+  else if (mask && I_count < 512) w_opt = std::min(w_opt, std::max(1u, I_count / 128));
   const uint32_t W = std::max(1u, std::min(w_opt, T2 / 4));
   const uint64_t units = (uint64_t)((T2 + W - 1) / W) * I_count;
   const unsigned grid = (unsigned)std::min<uint64_t>(units, 256u);

@@ -42,7 +42,9 @@ def parse():
     p.add_argument("--rank", type=int, default=3, help="the rank whose receptions are recorded / replayed")
     p.add_argument("--dir", default="/dev/shm/as_rank_of_8")
     p.add_argument("--reps", type=int, default=5)
+    p.add_argument("--opt", action="append", default=[], help="replay: context option name=value (repeatable)")
     p.add_argument("--check", action="store_true", help="replay: compare the block with rows [lo, hi) of the one-GPU build")
+    p.add_argument("--rank-only", action="store_true", help="replay: no one-GPU build beside the rank's (a kernel trace then ends with the rank's build)")
     p.add_argument("--out", default=None)
     return p.parse_args()
 
@@ -278,6 +280,8 @@ def main():
         parts = [(off, np.fromfile(os.path.join(args.dir, "rec_%d_%d.bin" % (i, j)), dtype=np.uint8)) for j, (off, size) in enumerate(rec["parts"])]
         records.append({"op": rec["op"], "parts": parts})
     ctx = A.Context(0)
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     rp = Replay(records, dev)
     del records
     comm = D.LibComm(ctx, rp.make(ctx, L, rank, world))
@@ -303,7 +307,9 @@ def main():
             ctx.profile(False)
         block = sc.block
     stats = {k: ctx.stat(k) for k in ("sharded_by_positions", "sharded_prepare_by_rows", "sharded_rows_late", "sharded_foreign_slots",
-                                      "sharded_listed_slots", "knn_join_candidates", "knn_uncertified_rows")}
+                                      "sharded_listed_slots", "knn_join_candidates", "knn_uncertified_rows", "knn_mfma_join_f16_blocks",
+                                      "knn_mfma_join_f16_blocks_listed", "knn_mfma_join_f16_blocks_pretest", "knn_join_prefilter_blocks",
+                                      "knn_join_prefilter_blocks_flagged", "knn_join_cone_tiles_kept_e6")}
     by_op = {}
     for rec in meta["records"]:
         e = by_op.setdefault(rec["op"], {"calls": 0, "bytes": 0})
@@ -320,7 +326,7 @@ def main():
            "largest_collectives": [{"call": i, "op": op, "bytes": b} for b, i, op in largest],
            "xgmi_floor_ms_at_7x153GBs": (rp.total_bytes - own) / (7 * 153e9) * 1e3,
            "block_nnz": meta["block_nnz"], "nnz_total": meta["nnz_total"], "stats": stats, "stage_ms": prof}
-    if args.check or True:
+    if not args.rank_only:
         # the one-GPU build of all N rows beside it (time, and with --check the block's bytes)
         Xall, _ = synth.mixture_device(n, d, dev, seed=42)
         A.build_laplacian_matrix(Xall, gp, ctx=ctx)
