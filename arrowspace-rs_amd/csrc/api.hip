@@ -612,6 +612,8 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_theta_rows64") ctx->opt_join_theta_rows64 = value;
   else if (n == "join_one_sided_block") ctx->opt_join_one_sided_block = value;
   else if (n == "sharded_order_assign") ctx->opt_sharded_order_assign = value;
+  else if (n == "search_scan_run") ctx->opt_search_scan_run = value;
+  else if (n == "search_scan_slices") ctx->opt_search_scan_slices = value;
   else if (n == "join_masked_block") ctx->opt_join_masked_block = value;
   else if (n == "rerank_prune_halves") ctx->opt_rerank_prune_halves = value;
   else if (n == "sharded_split_assembly") ctx->opt_sharded_split_assembly = value;

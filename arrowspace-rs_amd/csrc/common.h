@@ -136,6 +136,8 @@ struct as_ctx {
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
   int64_t opt_join_basis_sample = 16384; // rotated coordinates: rows of the strided sample the directions are found on
+  int64_t opt_search_scan_run = 1;     // ... units a wave draws at a time (consecutive ones: of one slice)
+  int64_t opt_search_scan_slices = 2;  // the one-sided f16 scan behind a first pass: a wave per (64 queries, this many stages of 256 columns), nothing shared (0: a workgroup per 512 queries, stages through LDS)
   int64_t opt_join_masked_block = 0;  // column super tiles per work unit of the masked f16 pass alone (0: "join_block")
   int64_t opt_rerank_prune_halves = 1;  // the re-rank's pruning: a row per half wave with its list in registers where the list has at most 128 entries (0: every row through LDS, a wave each)
   int64_t opt_sharded_split_assembly = 1;  // a build sharded by rows: degrees, weights and the pruning of a row on its owner, the adjacency exchanged (0: the tables exchanged, every rank ranks all rows)

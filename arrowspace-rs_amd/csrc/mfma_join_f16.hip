@@ -1020,6 +1020,277 @@ __global__ __launch_bounds__(512, 2) void pair_join_f16_kernel(const f16x8 *__re
   }
 }
 
+
+// ---- the one-sided masked scan, a wave on its own (round 6) -------------------------------------------------------------------------
+// MODE 1 of pair_join_f16_kernel behind the rectangular first pass shares a stage of 256 columns among the eight waves of a workgroup
+// (64 queries each) through LDS, a barrier a stage.  With the batch in the order of the items' image the eight slices of a super tile
+// look at DIFFERENT columns: in a stage one or two waves hold flagged blocks and the others wait -- cycle stamps of a 10 000-query
+// batch at 1 M items: 1.1 M cycles in the blocks, 3.8 M at the barriers.  Here nothing is shared: a work unit is (a slice of 64
+// queries, G stages of 256 columns), drawn by ONE wave from the list of the units that hold a flagged block (scan_slice_units_kernel);
+// the wave keeps its queries' fragments in registers, asks for the eight k-step fragments of a flagged block straight from the image
+// (1 KB a fragment, contiguous; the next block's are on their way while this one is contracted) and lists through its own queue.
+// No barrier, no LDS staging; the image is read through the L2 once per slice that needs a block instead of once per super tile.
+__global__ __launch_bounds__(256) void scan_slice_flags_kernel(const unsigned long long *__restrict__ mask, uint32_t T2, uint32_t a_supers, uint32_t G,
+                                                               uint32_t *__restrict__ flags) {
+  // G: stages of 256 columns per unit.  flags[u] = 1 where unit u = slice * n_cblocks + c holds a flagged block
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_cblocks = (2 * T2 + G - 1) / G, total = n_cblocks * a_supers * 8u;
+  if (u >= total) return;
+  const uint32_t slice = u / n_cblocks, c = u - slice * n_cblocks, I = slice >> 3, w = slice & 7u;
+  const uint32_t s0 = c * G, s1 = min(2 * T2, s0 + G);
+  bool keep = false;
+  for (uint32_t t = s0; t < s1 && !keep; ++t) keep = ((mask[(size_t)I * 2 * T2 + t] >> (8 * w)) & 0xFFull) != 0;
+  flags[u] = keep ? 1u : 0u;
+}
+// ... and the list of them IN ORDER (list[0] = how many): consecutive entries are neighbours of one slice, which is what lets a wave
+// draw a run of units and keep its queries' fragments (off: the exclusive scan of flags, off[total] = the count)
+__global__ __launch_bounds__(256) void scan_slice_list_kernel(const uint32_t *__restrict__ flags, const uint64_t *__restrict__ off, uint32_t total,
+                                                              uint32_t *__restrict__ list) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0) list[0] = (uint32_t)off[total];
+  if (u < total && flags[u]) list[1 + off[u]] = u;
+}
+
+constexpr int kSliceWaves = 4;  // waves of a workgroup of the scan below (they share nothing but the workgroup)
+template <int KS>
+__global__ __launch_bounds__(64 * kSliceWaves, 2) void scan_slices_f16_kernel(const f16x8 *__restrict__ P, const f16x8 *__restrict__ PA, uint32_t T2,
+                                                                              uint32_t a_supers, uint32_t G, uint32_t n, const float *__restrict__ theta,
+                                                                              uint32_t cap, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cand,
+                                                                              uint32_t *__restrict__ unit_counter, F16SearchTerm st,
+                                                                              const uint32_t *__restrict__ perm, const unsigned long long *__restrict__ mask,
+                                                                              const uint32_t *__restrict__ perm_a, const uint32_t *__restrict__ unit_list,
+                                                                              unsigned long long *__restrict__ stamps, int dbg, uint32_t run_max) {
+  constexpr int kTileVecs = KS * 4 * 64;
+  constexpr int kSlotFloats = 36;
+  __shared__ uint2 s_queue[kSliceWaves][kQueueSearch];
+  __shared__ float s_score[kSliceWaves][kQueueSearch];
+  __shared__ __attribute__((aligned(16))) float s_ex[kSliceWaves][4 * kSlotFloats];
+  __shared__ float s_qlam[kSliceWaves][64], s_qg[kSliceWaves][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lh = lane >> 5, lc = lane & 31;
+  uint2 *queue = s_queue[wv];
+  float *queue_s = s_score[wv], *ex = s_ex[wv], *qlam = s_qlam[wv], *qg = s_qg[wv];
+  uint32_t qn = 0;  // wave-uniform
+  auto lanes_below = [&](unsigned long long m) -> uint32_t {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
+  auto flush_queue = [&]() {
+    lds_sync();
+    for (uint32_t base = 0; base < qn; base += 64) {
+      const uint32_t e = base + lane;
+      if (e < qn) {
+        const uint2 v = queue[e];
+        append16(cnt, cand, cap, perm_a ? perm_a[v.x] : v.x, perm ? perm[v.y] : v.y, queue_s[e]);
+      }
+    }
+    lds_sync();
+    qn = 0;
+  };
+  const uint32_t n_cblocks = (2 * T2 + G - 1) / G;
+  const uint32_t n_units = unit_list[0];
+  unsigned long long n_blk = 0, n_pass = 0;
+  uint32_t cur_slice = 0xFFFFFFFFu;
+  f16x8 a0[KS], a1[KS];
+  v16f32 nth0, nth1;
+  float qlo0 = 0.f, qhi0 = 0.f, qlo1 = 0.f, qhi1 = 0.f;
+  uint32_t row0 = 0;  // first query position of the slice
+
+  // the listing of pair_join_f16_kernel's search mode (the same tests, the same scores), the slice's lambdas from the wave's own arrays
+  auto emit = [&](const v16f32 &acc, const v16f32 &nth, uint32_t row_group0, bool g1, uint32_t colbase, float tc) -> bool {
+    v16f32 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] - nth[r];
+    const float top = max16(acc);
+    bool hit = top >= 0.f;
+    {
+      const float lo = g1 ? qlo1 : qlo0, hi = g1 ? qhi1 : qhi0;
+      const float dist = __builtin_fmaxf(0.f, __builtin_fmaxf(lo - tc, tc - hi));
+      const float pen = __builtin_fminf(st.beta * dist, st.beta);
+      const float slack = 4e-6f * (1.f + st.beta * (__builtin_fabsf(tc) + __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi))));
+      hit = hit && (top * (st.alpha * (1.f / kProductScale)) + slack >= pen);
+    }
+    unsigned long long m = __ballot(hit);
+    if (m == 0) return false;
+    do {
+      const uint32_t rank = lanes_below(m);
+      if (hit && ((m >> lane) & 1ull) && rank < 4) {
+        float *sl = ex + rank * kSlotFloats;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          reinterpret_cast<float4 *>(sl)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          reinterpret_cast<float4 *>(sl)[4 + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+        sl[32] = __uint_as_float((uint32_t)lane);
+        sl[33] = tc;
+      }
+      lds_sync();
+      const uint32_t filled = min(4u, (uint32_t)__builtin_popcountll(m));
+      const uint32_t slot = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
+      const float *sl = ex + slot * kSlotFloats;
+      const bool valid = slot < filled;
+      const float ap = sl[r], vv = sl[16 + r], tcs = sl[33];
+      const uint32_t src = __float_as_uint(sl[32]);
+      const uint32_t row = row_group0 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2), col = colbase + (src & 31);
+      bool inside = valid && col < n && row < st.nq;
+      if (st.self_ids && inside) inside = st.self_ids[row] != (perm ? perm[col] : col);
+      const uint32_t rl = (row - row0) & 63u;
+      float sc = vv * (1.f / kProductScale);
+      sc = __builtin_fmaf(st.alpha, sc, -__builtin_fminf(__builtin_fabsf(__builtin_fmaf(st.beta, qlam[rl], -st.beta * tcs)), st.beta));
+      const bool w1 = inside && ap >= 0.f && sc >= qg[rl];
+      const unsigned long long m1 = __ballot(w1);
+      const uint32_t n1 = (uint32_t)__builtin_popcountll(m1);
+      if (qn + n1 > kQueueSearch) flush_queue();
+      if (w1) {
+        queue[qn + lanes_below(m1)] = make_uint2(row, col);
+        queue_s[qn + lanes_below(m1)] = sc;
+      }
+      qn += n1;
+      lds_sync();
+      m &= m - 1;  // the four lowest lanes are done
+      m &= m - 1;
+      m &= m - 1;
+      m &= m - 1;
+    } while (m);
+    return true;
+  };
+
+  // a run of units per draw: one returning atomic, one read of the list and one of the mask for all of them (three dependent round
+  // trips a run instead of a unit -- most units hold one or two blocks), and a run is nearly always of one slice
+  const uint32_t run = min(run_max, 64u / G);
+  // (drawn in the order of the list from ONE counter.  Measured at 10 000 queries x 1 M items, 41 600 units: 1.04 ms; dealt round
+  // robin without a counter 1.27 -- units differ by a factor of thirty in what they hold --, drawn from 16 counters over interleaved
+  // parts of the list 1.27 as well; runs of 2 / 4 / 8 units a draw 1.16 / 1.46 / 2.13: the heavy units of a slice sit side by side)
+  for (;;) {
+    uint32_t u0 = 0;
+    if (lane == 0) u0 = atomicAdd(unit_counter, run);
+    u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u0);
+    if (u0 >= n_units) break;
+    const uint32_t n_here = min(run, n_units - u0);
+    const uint32_t k_l = (uint32_t)lane / G, t_l = (uint32_t)lane - k_l * G;  // lane -> (unit of the run, stage of the unit)
+    uint32_t unit_l = 0, bits_l = 0;
+    if (k_l < n_here) {
+      unit_l = unit_list[1 + u0 + k_l];
+      const uint32_t slice_l = unit_l / n_cblocks, c_l = unit_l - slice_l * n_cblocks, sg = c_l * G + t_l;
+      if (sg < 2 * T2) bits_l = (uint32_t)(mask[(size_t)(slice_l >> 3) * 2 * T2 + sg] >> (8 * (slice_l & 7u))) & 0xFFu;
+    }
+    const unsigned long long have_all = __ballot(bits_l != 0);
+   for (uint32_t k = 0; k < n_here; ++k) {
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readlane((int)unit_l, (int)(k * G));
+    const uint32_t slice = unit / n_cblocks, c = unit - slice * n_cblocks, I = slice >> 3, w = slice & 7u;
+    const uint32_t s0 = c * G;
+    unsigned long long have = (have_all >> (k * G)) & ((G >= 64u) ? ~0ull : ((1ull << G) - 1ull));
+    const uint32_t my_bits = bits_l;  // (stage t of the unit sits in lane k G + t)
+    const uint32_t lane0 = k * G;
+    if (have == 0) continue;
+    if (slice != cur_slice) {  // the slice's 64 queries: fragments, thresholds, lambdas
+      cur_slice = slice;
+      row0 = I * kSuperH + w * 64u;
+      const size_t T = (size_t)4 * I + (w >> 1);
+      const f16x8 *a_src = PA + T * kTileVecs + (size_t)(2 * (w & 1u)) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a0[ks] = a_src[(size_t)ks * 256];
+        a1[ks] = a_src[(size_t)ks * 256 + 64];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        nth0[r] = -thr_scaled(theta[row0 + 4 * lh + (r & 3) + 8 * (r >> 2)]);
+        nth1[r] = -thr_scaled(theta[row0 + 32 + 4 * lh + (r & 3) + 8 * (r >> 2)]);
+      }
+      lds_sync();  // (the listing of the unit before is done with the arrays)
+      const float ql = st.q_lam[row0 + lane];
+      qlam[lane] = ql;
+      qg[lane] = st.q_g[row0 + lane];
+      const bool live = row0 + (uint32_t)lane < st.nq;
+      float lo = live ? ql : __builtin_inff(), hi = live ? ql : -__builtin_inff();
+      // (a floor below -1.5 enters the accumulator clamped: the lambda bound does not apply to a group with such a row)
+      const unsigned long long clamped = __ballot(live && !(theta[row0 + lane] >= -1.5f));
+      if (clamped & (lane < 32 ? 0xFFFFFFFFull : 0xFFFFFFFF00000000ull)) {
+        lo = -__builtin_inff();
+        hi = __builtin_inff();
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        lo = __builtin_fminf(lo, __shfl_xor(lo, o, 64));
+        hi = __builtin_fmaxf(hi, __shfl_xor(hi, o, 64));
+      }
+      qlo0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 0));
+      qhi0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 0));
+      qlo1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 32));
+      qhi1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 32));
+      lds_sync();
+    }
+    // the flagged blocks of the unit in order; the fragments of the next one are asked for before this one is contracted
+    uint32_t st_i = (uint32_t)__builtin_ctzll(have), byte = (uint32_t)__builtin_amdgcn_readlane((int)my_bits, (int)(lane0 + st_i));
+    have &= have - 1;
+    auto block_at = [&](uint32_t stage_i, uint32_t nn, uint32_t *colbase) -> const f16x8 * {
+      const uint32_t step = s0 + stage_i, tile0 = 4 * (step >> 1) + 2 * (step & 1u);
+      *colbase = tile0 * kTileRows + nn * 32;
+      return P + ((size_t)(tile0 + (nn >> 2)) * KS * 4 + (nn & 3u)) * 64 + lane;
+    };
+    f16x8 fb[KS];
+    float tc;
+    uint32_t colbase;
+    {
+      const uint32_t nn = (uint32_t)__builtin_ctz(byte);
+      byte &= byte - 1;
+      const f16x8 *src = block_at(st_i, nn, &colbase);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fb[ks] = src[(size_t)ks * 256];
+      tc = st.x_lam[colbase + lc];
+    }
+    for (;;) {
+      bool more = true;
+      if (byte == 0) {
+        if (have == 0) more = false;
+        else {
+          st_i = (uint32_t)__builtin_ctzll(have);
+          byte = (uint32_t)__builtin_amdgcn_readlane((int)my_bits, (int)(lane0 + st_i));
+          have &= have - 1;
+        }
+      }
+      f16x8 fn[KS];
+      float tcn = 0.f;
+      uint32_t colbase_n = 0;
+      if (more) {
+        const uint32_t nn = (uint32_t)__builtin_ctz(byte);
+        byte &= byte - 1;
+        const f16x8 *src = block_at(st_i, nn, &colbase_n);
+        if (dbg & 2) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) fn[ks] = fb[ks];
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) fn[ks] = src[(size_t)ks * 256];
+        }
+        tcn = st.x_lam[colbase_n + lc];
+      }
+      {
+        v16f32 x;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks], fb[ks], ks == 0 ? nth0 : x, 0, 0, 0);
+        if (!(dbg & 1)) n_pass += emit(x, nth0, row0, false, colbase, tc) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], fb[ks], ks == 0 ? nth1 : x, 0, 0, 0);
+        if (!(dbg & 1)) n_pass += emit(x, nth1, row0 + 32, true, colbase, tc) ? 1 : 0;
+        else if (max16(x) == 12345.f) n_pass += 1;  // (keeps the products alive)
+        n_blk += 2;
+      }
+      if (!more) break;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fb[ks] = fn[ks];
+      tc = tcn;
+      colbase = colbase_n;
+    }
+   }
+  }
+  flush_queue();
+  if (lane == 0 && stamps) {
+    atomicAdd(stamps + 5, n_blk);
+    atomicAdd(stamps + 7, n_pass);
+  }
+}
+
 }  // namespace
 
 // 16-B vectors of an f16 image with `tiles` 128-row tiles
@@ -1323,6 +1594,35 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq, self_ids};
   ProfScope ps(ctx, prof_name);
+  // (not the second pass of an item graph -- self_ids --: its open rows come from everywhere, a slice's stages are nearly all flagged
+  // and sharing them through LDS is what pays there: 0.70 ms against 0.83 at 1 M rows)
+  if (mask && KS == 8 && ctx->opt_search_scan_slices > 0 && !self_ids && !(ctx->opt_debug & 8)) {
+    // behind the first pass: a wave per (slice of 64 queries, a few stages of 256 columns), nothing shared (scan_slices_f16_kernel)
+    const uint32_t Ws = (uint32_t)std::min<int64_t>(ctx->opt_search_scan_slices, 64);  // stages of 256 columns per unit
+    const uint64_t s_units = (uint64_t)((2 * T2 + Ws - 1) / Ws) * a_supers * 8;
+    if (s_units < (1ull << 31)) {
+      DevBuf<uint32_t> unit_list, flags;
+      DevBuf<uint64_t> off;
+      AS_TRY(unit_list.alloc(ctx, s_units + 1));
+      AS_TRY(flags.alloc(ctx, s_units + 1));
+      AS_TRY(off.alloc(ctx, s_units + 1));
+      hipLaunchKernelGGL(scan_slice_flags_kernel, dim3((unsigned)cdiv(s_units, (uint64_t)256)), dim3(256), 0, ctx->stream, (const unsigned long long *)mask, T2,
+                         a_supers, Ws, flags.p);
+      AS_TRY(exclusive_scan_u32_u64(ctx, flags.p, s_units, off.p));
+      hipLaunchKernelGGL(scan_slice_list_kernel, dim3((unsigned)cdiv(s_units, (uint64_t)256)), dim3(256), 0, ctx->stream, (const uint32_t *)flags.p,
+                         (const uint64_t *)off.p, (uint32_t)s_units, unit_list.p);
+      if (ctx->opt_debug & 0x400000) {  // diagnostic: how many units hold a block
+        uint32_t h = 0;
+        AS_HIP(ctx, copy_d2h(ctx, &h, unit_list.p, sizeof(h)));
+        std::fprintf(stderr, "[scan_slices] %u of %llu units hold a flagged block (G %u)\n", h, (unsigned long long)s_units, Ws);
+      }
+      hipLaunchKernelGGL(scan_slices_f16_kernel<8>, dim3(512), dim3(64 * kSliceWaves), 0, ctx->stream, (const f16x8 *)P, (const f16x8 *)PQ, T2, a_supers, Ws, n,
+                         cos_floor, cap, cnt, cand, unit_counter, st, perm, (const unsigned long long *)mask, perm_a, (const uint32_t *)unit_list.p,
+                         stamps.p, (int)(ctx->opt_debug >> 20) & 3, (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_search_scan_run, 16)));
+      AS_HIP(ctx, hipGetLastError());
+      return AS_OK;
+    }
+  }
   // (diagnostics compiled out unless a debug bit asks for them: the product instantiation, as in the build's first pass)
   const bool diag = ctx->opt_debug != 0;
 #define AS_LAUNCH(K, M, DG)                                                                                               \

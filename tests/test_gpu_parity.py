@@ -1467,6 +1467,39 @@ def test_search_scan_in_the_order_of_the_lambdas(ctx, n, d, nq, k, alpha, spread
         assert np.array_equal(np.asarray(res[1][1])[j], osc)
 
 
+@pytest.mark.parametrize("n,nq,k,alpha,run", [(131_072, 4133, 10, 0.7, 1), (70_001, 2049, 3, 1.0, 4), (200_000, 10_000, 10, 0.3, 1)])
+def test_search_scan_with_a_wave_per_slice_of_queries(ctx, n, nq, k, alpha, run):
+    """The scan of a re-searched index of 128-wide items behind the int8 first pass, a wave on its own per (64 queries, one column
+    super tile) with the fragments of a flagged block straight from the image ("search_scan_slices", round 6, mfma_join_f16.hip:
+    scan_slices_f16_kernel), gives what the form that shares a stage of columns among the eight waves of a workgroup gives, and the
+    oracle's results: batches that end inside a slice of 64 and inside a super tile, runs of one and of four units a draw."""
+    X, _ = synth.mixture(n, 128, seed=23, n_clusters=40, rank=6)
+    rng = np.random.default_rng(5)
+    lam = rng.random(n) * 0.4
+    qi = synth.query_indices(n, nq, seed=8)
+    Q = X[qi] * 1.03 + rng.normal(size=(nq, 128)) * 0.01
+    lq = lam[qi] + rng.normal(size=nq) * 0.02
+    asp = A.ArrowSpace(X, A.TauMode.Median, ctx)
+    asp.update_lambdas(lam)
+    idx1, sc1 = asp.search_lambda_aware_batch(Q, lq, k, alpha)  # (first search: the image in the order of the items, no first pass)
+    assert ctx.stat("search_scan_prefilter") == 0
+    ctx.set_option("search_scan_run", run)
+    try:
+        idx2, sc2 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+        assert ctx.stat("search_scan_order") == 1 and ctx.stat("search_scan_prefilter") == 1
+        ctx.set_option("search_scan_slices", 0)
+        idx3, sc3 = asp.search_lambda_aware_batch(Q, lq, k, alpha)
+        assert ctx.stat("search_scan_prefilter") == 1
+    finally:
+        ctx.set_option("search_scan_slices", 2)
+        ctx.set_option("search_scan_run", 1)
+    assert np.array_equal(idx1, idx2) and np.array_equal(sc1, sc2)
+    assert np.array_equal(idx1, idx3) and np.array_equal(sc1, sc3)
+    for j in [0, 63, 64, nq - 1] + list(rng.choice(nq, size=6, replace=False)):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], float(lq[j]), k, alpha)
+        assert np.array_equal(idx2[j], oi.astype(np.int64)) and np.array_equal(sc2[j], osc)
+
+
 @pytest.mark.parametrize("n,d,nq,k,alpha", [(70_000, 128, 2500, 10, 0.7), (66_000, 64, 2100, 5, 1.0), (131_072, 100, 3000, 10, 0.4)])
 def test_search_scan_on_an_ordered_index(ctx, n, d, nq, k, alpha):
     """An index of 65,536 items or more that is searched again keeps its f16 image grouped by direction, orders large query
