@@ -307,6 +307,10 @@ class ShardedArrowSpace:
                       for r in range(self.world)]
         self.lambdas = None
         self.index = None
+        # one rank: the index built behind the item graph is over the same rows, untouched in between -- the build keeps its row order
+        # and images for it (include/arrowspace_hip.h: "keep_join_images"), and the first search runs on them
+        if self.world == 1 and libcomm is None and hasattr(ops, "ctx"):
+            ops.ctx.set_option("keep_join_images", 1)
 
     # -- item graph: n x n Laplacian over the items (build_laplacian_matrix on untransposed rows)
     def build_item_graph(self):

@@ -515,6 +515,7 @@ void as_ctx_destroy(as_ctx *ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   join_session_close(ctx);
   if (ctx->join_order) (void)hipFree(ctx->join_order);
+  join_keep_clear(ctx);
   ctx->deferred.clear();  // (their blocks go to the cache that is freed next)
   for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
   delete ctx;
@@ -612,6 +613,10 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_theta_rows64") ctx->opt_join_theta_rows64 = value;
   else if (n == "join_one_sided_block") ctx->opt_join_one_sided_block = value;
   else if (n == "sharded_order_assign") ctx->opt_sharded_order_assign = value;
+  else if (n == "keep_join_images") {
+    ctx->opt_keep_join_images = value;
+    if (!value) join_keep_clear(ctx);
+  } else if (n == "index_adopt_join_images") ctx->opt_index_adopt_join_images = value;
   else if (n == "search_scan_run") ctx->opt_search_scan_run = value;
   else if (n == "search_scan_slices") ctx->opt_search_scan_slices = value;
   else if (n == "join_masked_block") ctx->opt_join_masked_block = value;
@@ -1179,6 +1184,15 @@ int as_select_tau(as_ctx *ctx, const double *rows, uint64_t n_rows, uint64_t len
 
 // ---- search --------------------------------------------------------------------------------
 
+// (as_ctx::JoinKeep: what a build kept for an index of its rows)
+__global__ void count_differing_u64_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, uint64_t n,
+                                           unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += a[i] != b[i] ? 1ull : 0ull;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uint64_t n_items, uint64_t n_features,
                     as_index **out) {
   AS_TRY(check_ctx(ctx));
@@ -1208,6 +1222,37 @@ int as_index_create(as_ctx *ctx, const double *items, const double *lambdas, uin
   }
   AS_HIP(ctx, handle_malloc((void **)&ix->norms, sizeof(double) * n_items));
   AS_TRY(row_norms(ctx, ix->items, n_items, n_features, ix->norms));
+  // the order and the images of the item-graph build of these very rows, where the context kept them ("keep_join_images"): the same
+  // device pointer, the same shape and, row by row, the same norms -- the caller's side of it is not to have written to the rows in
+  // between (include/arrowspace_hip.h).  They move to the index; the first search then scans the ordered image behind the int8 pass.
+  ctx->stats["index_adopted_join_images"] = 0;
+  as_ctx::JoinKeep &jk = ctx->join_keep;
+  if (jk.complete && ctx->opt_index_adopt_join_images && jk.rows == (const void *)ix->items && jk.n == n_items && jk.d == n_features) {
+    DevBuf<unsigned long long> differ;
+    AS_TRY(differ.alloc(ctx, 1));
+    AS_HIP(ctx, hipMemsetAsync(differ.p, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(count_differing_u64_kernel, dim3(std::min<uint64_t>(cdiv(n_items, 256), 1024)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)ix->norms, (const unsigned long long *)jk.norms, n_items, differ.p);
+    unsigned long long h = 1;
+    AS_HIP(ctx, copy_d2h(ctx, &h, differ.p, sizeof(h)));
+    if (h == 0) {
+      ix->packedh = jk.packedh;
+      ix->f16_err = jk.f16_err;
+      ix->scan_perm = jk.perm;
+      ix->scan_piv = jk.piv;
+      ix->scan_np = jk.np;
+      ix->rot_qw = jk.rot_qw;
+      ix->packed8 = jk.packed8;
+      ix->rot_err = jk.rot_err;
+      ix->rot_state = 1;
+      ix->z_space = true;
+      jk.packedh = jk.packed8 = nullptr;
+      jk.perm = nullptr;
+      jk.piv = jk.rot_qw = nullptr;
+      ctx->stats["index_adopted_join_images"] = 1;
+    }
+    join_keep_clear(ctx);
+  }
   AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = ix;
   return AS_OK;

@@ -136,6 +136,8 @@ struct as_ctx {
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
   int64_t opt_join_basis_sample = 16384; // rotated coordinates: rows of the strided sample the directions are found on
+  int64_t opt_keep_join_images = 0;    // an item-graph build keeps its order and images for an index of the same rows (as_ctx::JoinKeep; ~300 MB per million rows)
+  int64_t opt_index_adopt_join_images = 1;  // as_index_create takes them over when the items are those rows (same device pointer, shape and norms)
   int64_t opt_search_scan_run = 1;     // ... units a wave draws at a time (consecutive ones: of one slice)
   int64_t opt_search_scan_slices = 2;  // the one-sided f16 scan behind a first pass: a wave per (64 queries, this many stages of 256 columns), nothing shared (0: a workgroup per 512 queries, stages through LDS)
   int64_t opt_join_masked_block = 0;  // column super tiles per work unit of the masked f16 pass alone (0: "join_block")
@@ -203,6 +205,24 @@ struct as_ctx {
   // graph it returns, where the item-graph lambda kernels visit the rows in it (signal_lambda.hip)
   uint32_t *join_order = nullptr;
   uint64_t join_order_n = 0, join_order_cap = 0, join_order_seq = 0;
+  // "keep_join_images": what the last item-graph build (one GPU, rows of 128 values, the join on an image in its own order) leaves
+  // for an index of the SAME rows -- the order, the f16 image in it, the pivots of the order, the 31 directions, the rotated int8
+  // image by position, the norms (to tell the rows apart from others) -- so that the index's first search runs on the ordered
+  // image behind the int8 first pass instead of finding all of that again (as_index_create adopts them: "index_adopt_join_images")
+  struct JoinKeep {
+    const void *rows = nullptr;
+    uint64_t n = 0, d = 0;
+    void *packedh = nullptr, *packed8 = nullptr;
+    uint32_t *perm = nullptr;
+    float *piv = nullptr, *rot_qw = nullptr;
+    double *norms = nullptr;
+    uint32_t np = 0;
+    double rot_err = -1.0, f16_err = -1.0;
+    bool complete = false;
+  } join_keep;
+  void *keep_p8_dst = nullptr;   // where the first pass of the build in progress leaves a copy of its int8 image (or null)
+  double keep_p8_err = -1.0;
+  bool keep_p8_done = false;
   // stats of the last call
   std::map<std::string, int64_t> stats;
   // counters of kernels that nobody decides anything by (blocks contracted / flagged / listed): read back with the NEXT read-back
@@ -280,6 +300,12 @@ struct as_index {
                                     // project a batch of queries the same way (the ordered images of wide items, round 5)
   double rot_err = -1.0;            // its largest quantisation error norm
   int rot_state = 0;                // 0 not tried, 1 usable, -1 the directions do not carry the items
+  // adopted from the item-graph build of the same rows (as_ctx::JoinKeep): scan_perm / packedh / packed8 are that build's, the
+  // directions are rot_qw (31 x 128, rotate_wide.hip) and scan_piv holds scan_np pivots of 32 rotated coordinates -- a batch of queries
+  // is projected, ordered and packed the way the batches of wide items are
+  bool z_space = false;
+  uint32_t scan_np = 256;
+  int nat_state = 0;                // z_space: the directions of the filter of the streaming scan (rot_q), 0 not tried, 1 usable, -1 not
   std::atomic<uint32_t> scan_calls{0};  // searches run on this index so far
   uint32_t scan_ns = 0;
 };
@@ -628,6 +654,17 @@ template <class T>
 inline hipError_t handle_malloc(T **p, size_t bytes) {
   return handle_malloc(reinterpret_cast<void **>(p), bytes);
 }
+// what a build kept for an index of its rows (as_ctx::JoinKeep): released
+inline void join_keep_clear(as_ctx *ctx) {
+  as_ctx::JoinKeep &k = ctx->join_keep;
+  if (k.packedh) (void)handle_free(k.packedh);
+  if (k.packed8) (void)handle_free(k.packed8);
+  if (k.perm) (void)handle_free(k.perm);
+  if (k.piv) (void)handle_free(k.piv);
+  if (k.rot_qw) (void)handle_free(k.rot_qw);
+  if (k.norms) (void)handle_free(k.norms);
+  k = as_ctx::JoinKeep{};
+}
 
 struct OwnJoin {
   DevBuf<unsigned char> P16own, Phown;                        // split-bf16 / f16 image of all rows (Phown in the order `perm`)
@@ -641,6 +678,7 @@ struct OwnJoin {
   DevBuf<float> theta_band_own;         // by row: what the row's own neighbourhood certifies, less twice the bound (NaN: not computed); the second pass's floor
   DevBuf<uint32_t> perm_own, inv_own;                         // image position -> row; row -> image position (filled by whoever needs it)
   DevBuf<double> rot_z, rot_norm;                             // rotated coordinates of the rows (rotate_wide.hip), n x 32, and their norms
+  DevBuf<float> rot_q;                                        // the 31 directions they were found on (31 x rotated_wide_pitch(d))
   DevBuf<float> order_piv;                                    // the pivots of the order found on them (np x 32), where the rows of each begin
   DevBuf<uint32_t> order_starts;
   DevBuf<uint32_t> order_near;                                // the 16 nearest pivot groups of every group (np x 16), where the chain of the order has them

@@ -259,6 +259,11 @@ int knn_join_pairs(as_ctx *ctx, const double *rows, const double *norms, uint32_
             ProfScope ps(ctx, "knn_join_prefilter_pack");
             AS_TRY(pack_rotated_from_z(ctx, rot_z, image_perm ? image_perm : perm, n, tiles, P8.p, &err));
           }
+          if (ctx->keep_p8_dst && I_begin == 0 && I_end == T2) {  // ("keep_join_images": a copy for an index of these rows)
+            AS_HIP(ctx, hipMemcpyAsync(ctx->keep_p8_dst, P8.p, rotated_image_bytes(tiles), hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->keep_p8_err = err;
+            ctx->keep_p8_done = true;
+          }
           // in front of it, on an image ordered by direction: which pairs of 128-position tiles can hold a pair at all (a cone
           // around each tile's direction against the exact products of the other tile's rows with it: cone_tiles.hip).  Where the
           // bound keeps most pairs (data without directions to tell apart) the pass sweeps everything as before.
@@ -445,7 +450,8 @@ int own_join_prepare(as_ctx *ctx, const double *rows, const double *norms, uint3
       rp.Hrow = oj.Hrow.p;
       rp.err_rows = oj.err_by_row.p;
     }
-    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail, rows ? nullptr : sr, nullptr, &rp));
+    AS_TRY(oj.rot_q.alloc(ctx, (size_t)31 * rotated_wide_pitch(d)));  // (kept: an index of these rows projects its query batches on them)
+    AS_TRY(rotated_rows_wide(ctx, rows, norms, n, d, oj.rot_z.p, oj.rot_norm.p, &tail, rows ? nullptr : sr, oj.rot_q.p, &rp));
     if (!rp.done) oj.Hrow.release(), oj.err_by_row.release();
     ctx->stats["knn_join_prefilter_tail_e6"] = (int64_t)(tail * 1e6);
     // Measured at 1 M x 128 (scripts/time_hard.py: mixtures of rank 16 ... 128 with 4 ... 50 000 clusters, duplicated rows, plain
@@ -866,7 +872,53 @@ int knn_mfma(as_ctx *ctx, const double *rows, const double *norms, uint64_t n64,
         AS_TRY(oj_local.inv_own.alloc(ctx, n));
         hipLaunchKernelGGL(invert_perm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, oj_local.perm_own.p, n, oj_local.inv_own.p);
       }
-      AS_TRY(own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos));
+      // "keep_join_images": the order and the images stay with the context for an index of these rows (common.h: as_ctx::JoinKeep)
+      join_keep_clear(ctx);
+      const bool keeping = ctx->opt_keep_join_images && lists_by_pos && oj_local.wide_pre && oj_local.rot_q.p && oj_local.order_piv.p &&
+                           oj_local.order_np && oj_local.Phown.p && is_device_ptr(rows);
+      const uint32_t keep_tiles = packed_tiles_f16(n);
+      if (keeping) {
+        as_ctx::JoinKeep &jk = ctx->join_keep;
+        AS_HIP(ctx, handle_malloc(&jk.packed8, rotated_image_bytes(keep_tiles)));
+        ctx->keep_p8_dst = jk.packed8;
+        ctx->keep_p8_done = false;
+      }
+      {
+        const int rc_pairs = own_join_pairs(ctx, rows, norms, n, d, 0, n, oj_local, cnt_own.p, cand_own.p, lists_by_pos);
+        ctx->keep_p8_dst = nullptr;
+        if (rc_pairs != AS_OK) {
+          join_keep_clear(ctx);
+          return rc_pairs;
+        }
+      }
+      if (keeping && ctx->keep_p8_done) {
+        as_ctx::JoinKeep &jk = ctx->join_keep;
+        const size_t img_bytes = (size_t)packed_vecs_f16(keep_tiles, d) * 16, piv_bytes = sizeof(float) * (size_t)oj_local.order_np * 32,
+                     q_bytes = sizeof(float) * (size_t)31 * rotated_wide_pitch(d);
+        bool ok = handle_malloc(&jk.packedh, img_bytes) == hipSuccess && handle_malloc((void **)&jk.perm, sizeof(uint32_t) * (size_t)n) == hipSuccess &&
+                  handle_malloc((void **)&jk.piv, piv_bytes) == hipSuccess && handle_malloc((void **)&jk.rot_qw, q_bytes) == hipSuccess &&
+                  handle_malloc((void **)&jk.norms, sizeof(double) * (size_t)n) == hipSuccess;
+        ok = ok && hipMemcpyAsync(jk.packedh, oj_local.Phown.p, img_bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(jk.perm, oj_local.perm_own.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(jk.piv, oj_local.order_piv.p, piv_bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(jk.rot_qw, oj_local.rot_q.p, q_bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(jk.norms, norms, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+        if (ok) {
+          jk.rows = rows;
+          jk.n = n;
+          jk.d = d;
+          jk.np = oj_local.order_np;
+          jk.rot_err = ctx->keep_p8_err;
+          jk.f16_err = ctx->f16_err;
+          jk.complete = true;
+        } else {
+          (void)hipGetLastError();
+          join_keep_clear(ctx);  // (no room: the index finds its own)
+        }
+      } else if (keeping) {
+        join_keep_clear(ctx);
+      }
+      ctx->stats["knn_join_images_kept"] = ctx->join_keep.complete ? 1 : 0;
       if ((ctx->opt_debug & 0xC0FF & ~(int64_t)(8 | 16 | 32 | 64)) || (ctx->opt_debug & 0xE000000)) return AS_OK;  // timing experiment (ablation bits): the join only, outputs undefined
       local = JoinSources{nullptr, oj_local.theta_own.p, 1, cap, cnt_own.p, cand_own.p, oj_local.have_theta2 ? oj_local.theta2_own.p : nullptr,
                           oj_local.P16own.p, oj_local.Phown.p};

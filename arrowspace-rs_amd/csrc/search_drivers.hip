@@ -116,8 +116,11 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
     // pass then streams the ~1-3 % of the items that can reach some query's cut instead of all of them
     StreamFilter flt{};
     const StreamFilter *use_filter = nullptr;
-    if (ctx->opt_search_stream_filter && prior_calls >= 1 && alpha > 0.0 && alpha <= 1.0 && ix->rot_state >= 0 && ix->weird_items != 1) {
-      AS_IX_BUILD(ix->weird_items < 0 || (ix->weird_items == 0 && ix->rot_state == 0) || (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat),
+    // (an index that adopted the images of its item-graph build -- z_space -- has that build's directions, in another form: the
+    // filter's own, for the image in the order of the items, are found here like on any index, their state kept apart in nat_state)
+    auto nat_state = [&]() -> int { return ix->z_space ? ix->nat_state : ix->rot_state; };
+    if (ctx->opt_search_stream_filter && prior_calls >= 1 && alpha > 0.0 && alpha <= 1.0 && nat_state() >= 0 && ix->weird_items != 1) {
+      AS_IX_BUILD(ix->weird_items < 0 || (ix->weird_items == 0 && nat_state() == 0) || (ix->weird_items == 0 && nat_state() == 1 && !ix->packed8_nat),
       if (ix->weird_items < 0) {  // (a non-finite norm or lambda must reach the exact arithmetic: no filter for such an index)
         DevBuf<int> wc;
         AS_TRY(wc.alloc(ctx, 1));
@@ -128,19 +131,19 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
         AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ix->weird_items = h ? 1 : 0;
       }
-      if (ix->weird_items == 0 && ix->rot_state == 0) {
+      if (ix->weird_items == 0 && nat_state() == 0) {
         double tail = 1.0;
         if (!ix->rot_q) AS_HIP(ctx, handle_malloc((void **)&ix->rot_q, sizeof(float) * 32 * 128));  // (kept on failure: the next call reuses it)
         AS_TRY(rotated_basis(ctx, ix->items, ix->norms, n, d, ix->rot_q, &tail));
-        ix->rot_state = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
+        (ix->z_space ? ix->nat_state : ix->rot_state) = tail <= (double)ctx->opt_search_rot_tail_e3 * 1e-3 ? 1 : -1;
       }
-      if (ix->weird_items == 0 && ix->rot_state == 1 && !ix->packed8_nat) {
+      if (ix->weird_items == 0 && nat_state() == 1 && !ix->packed8_nat) {
         const uint32_t tiles = packed_tiles_f16(n);
         AS_HIP(ctx, handle_malloc(&ix->packed8_nat, rotated_image_bytes(tiles)));
         AS_TRY(rotated_image_pack(ctx, ix->items, ix->norms, nullptr, n, d, ix->rot_q, ix->packed8_nat, tiles, &ix->rot_err_nat));
       }
       )
-      if (ix->weird_items == 0 && ix->rot_state == 1 && ix->packed8_nat) {
+      if (ix->weird_items == 0 && nat_state() == 1 && ix->packed8_nat) {
         flt = StreamFilter{ix->packed8_nat, (float)(ix->rot_err_nat * (1.0 + 1e-6)), ix->rot_q, q_norms, q_lambdas, ix->norms, ix->lambdas, alpha};
         use_filter = &flt;
       }
@@ -383,12 +386,21 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       AS_TRY(zqn.alloc(ctx, nq));
       AS_TRY(rotated_project_wide(ctx, queries, q_norms, nq, d, ix->rot_qw, Zq.p, zqn.p));
     }
-    const bool q_by_pivots = (scan_h && ix->scan_perm && nq >= 2048) || (wide_pre && nq >= 2048);
+    // an index with the images of its item-graph build (z_space, up to 128 columns): a batch is projected on that build's directions
+    // like a batch for wide items -- its order from the build's pivots, its int8 image from the coordinates
+    const bool z_pre = scan_h && ix->z_space && ix->scan_perm && ix->rot_state == 1 && ix->packed8 && ix->rot_qw && ctx->opt_search_prefilter;
+    if (z_pre) {
+      AS_TRY(Zq.alloc(ctx, (size_t)nq * 32));
+      AS_TRY(zqn.alloc(ctx, nq));
+      AS_TRY(rotated_project_wide(ctx, queries, q_norms, nq, d, ix->rot_qw, Zq.p, zqn.p));
+    }
+    const bool q_by_pivots = (scan_h && ix->scan_perm && nq >= 2048 && (!ix->z_space || z_pre)) || (wide_pre && nq >= 2048);
     const bool q_by_lambda = scan_h && !q_by_pivots && nq >= 1024 && ctx->opt_search_lambda_order && is_device_ptr(q_lambdas);
     const bool q_order = q_by_pivots || q_by_lambda;
     if (q_order) {
       AS_TRY(qperm.alloc(ctx, nq));
-      if (q_by_pivots && wide_pre) AS_TRY(order_by_pivots(ctx, Zq.p, nq, 32, ix->scan_piv, qperm.p));
+      if (q_by_pivots && z_pre) AS_TRY(order_by_pivots(ctx, Zq.p, nq, 32, ix->scan_piv, qperm.p, ix->scan_np));
+      else if (q_by_pivots && wide_pre) AS_TRY(order_by_pivots(ctx, Zq.p, nq, 32, ix->scan_piv, qperm.p));
       else if (q_by_pivots) AS_TRY(order_by_pivots(ctx, queries, nq, d, ix->scan_piv, qperm.p));
       else AS_TRY(order_by_value(ctx, q_lambdas, nq, qperm.p));
     }
@@ -444,11 +456,12 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       // int8 first pass on the rotated images of the items (kept with the index) and of this batch: which blocks can hold a
       // pair whose cosine alone reaches what the query's guess asks for
       DevBuf<unsigned char> PQ8, mask;
-      const bool pre = ix->scan_perm && ix->rot_state == 1 && ctx->opt_search_prefilter;
+      const bool pre = ix->scan_perm && ix->rot_state == 1 && ctx->opt_search_prefilter && (!ix->z_space || z_pre);
       if (pre) {
         double eq = 0.0;
         AS_TRY(PQ8.alloc(ctx, rotated_image_bytes(a_alloc)));
-        AS_TRY(rotated_image_pack(ctx, queries, q_norms, q_order ? qperm.p : nullptr, nq, d, ix->rot_q, PQ8.p, a_alloc, &eq));
+        if (z_pre) AS_TRY(pack_rotated_from_z(ctx, Zq.p, q_order ? qperm.p : nullptr, nq, a_alloc, PQ8.p, &eq));
+        else AS_TRY(rotated_image_pack(ctx, queries, q_norms, q_order ? qperm.p : nullptr, nq, d, ix->rot_q, PQ8.p, a_alloc, &eq));
         const double E = std::max(eq, ix->rot_err), delta8 = (2.0 * E + E * E) * (1.0 + 1e-6) + 1e-4;
         const uint32_t T2i = (n + 511) / 512, a_supers = a_alloc / 4;
         AS_TRY(mask.alloc(ctx, (size_t)a_supers * 2 * T2i * 8));

@@ -29,5 +29,5 @@ for rep in range(5):
     sas.search(Q, lq, 10, 0.7)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     pr = ctx.profile_all(); ctx.profile(False)
-    print("search %d: prepare %.3f ms  search %.3f ms  " % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3) + "  ".join("%s %.3f" % (k, v[0]) for k, v in sorted(pr.items()) if k.startswith("search") or "pack" in k or "order" in k or "basis" in k),
-          " prefilter", ctx.stat("search_scan_prefilter"), "order", ctx.stat("search_scan_order"), flush=True)
+    print("search %d: prepare %.3f ms  search %.3f ms  " % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3) + "  ".join("%s %.3f" % (k, v[0]) for k, v in sorted(pr.items())),
+          " prefilter", ctx.stat("search_scan_prefilter"), "order", ctx.stat("search_scan_order"), "adopted", ctx.stat("index_adopted_join_images"), "kept", ctx.stat("knn_join_images_kept"), flush=True)

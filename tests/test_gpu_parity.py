@@ -1467,6 +1467,78 @@ def test_search_scan_in_the_order_of_the_lambdas(ctx, n, d, nq, k, alpha, spread
         assert np.array_equal(np.asarray(res[1][1])[j], osc)
 
 
+@pytest.mark.parametrize("n,nq,k,alpha", [(131_072, 4133, 10, 0.7), (70_001, 2500, 5, 1.0), (90_000, 37, 10, 0.4)])
+def test_index_adopts_the_images_of_the_item_graph_build(ctx, join_on, n, nq, k, alpha):
+    """An item-graph build of 128-wide rows can keep its row order, its f16 image, its pivots, its 31 directions and its rotated int8
+    image for an index of the SAME rows ("keep_join_images", round 6; as_index_create adopts them when pointer, shape and row norms
+    agree): the FIRST search then runs on the ordered image behind the int8 first pass -- the batch projected on the build's
+    directions, ordered by its pivots -- and gives what an index that found everything itself gives, and the oracle's results; so do
+    later searches and small batches (whose filter finds its own directions).  Rows changed in between, other rows at another address
+    and a build without the option leave the index on its own."""
+    import torch
+    X, _ = synth.mixture(n, 128, seed=41, n_clusters=40, rank=6)
+    rng = np.random.default_rng(9)
+    lam = rng.random(n) * 0.4
+    qi = synth.query_indices(n, nq, seed=3)
+    Q = X[qi] * 1.03 + rng.normal(size=(nq, 128)) * 0.01
+    lq = lam[qi] + rng.normal(size=nq) * 0.02
+    gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
+    Xd = torch.from_numpy(X).cuda()
+    lamd = torch.from_numpy(lam).cuda()
+
+    def index_of(rows_d):
+        asp = A.ArrowSpace(rows_d, A.TauMode.Median, ctx)
+        asp.update_lambdas(lamd)
+        asp._ensure_index()
+        return asp
+
+    ref = index_of(Xd)  # no build before it: on its own
+    assert ctx.stat("index_adopted_join_images") == 0
+    idx0, sc0 = ref.search_lambda_aware_batch(Q, lq, k, alpha)
+    idx0, sc0 = np.asarray(idx0.cpu() if torch.is_tensor(idx0) else idx0), np.asarray(sc0.cpu() if torch.is_tensor(sc0) else sc0)
+    for j in [0, nq - 1] + list(rng.choice(nq, size=5, replace=False)):
+        oi, osc = O.search_lambda_aware(X, lam, Q[j], float(lq[j]), k, alpha)
+        assert np.array_equal(idx0[j].astype(np.int64), oi.astype(np.int64)) and np.array_equal(sc0[j], osc)
+
+    def same(res):
+        i, s_ = res
+        i = np.asarray(i.cpu() if torch.is_tensor(i) else i)
+        s_ = np.asarray(s_.cpu() if torch.is_tensor(s_) else s_)
+        return np.array_equal(i, idx0) and np.array_equal(s_, sc0)
+
+    ctx.set_option("keep_join_images", 1)
+    try:
+        A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+        assert ctx.stat("knn_join_images_kept") == 1
+        asp = index_of(Xd)
+        assert ctx.stat("index_adopted_join_images") == 1
+        r1 = asp.search_lambda_aware_batch(Q, lq, k, alpha)  # the FIRST search of the index
+        if nq >= 2048:
+            assert ctx.stat("search_scan_prefilter") == 1 and ctx.stat("search_scan_order") == 1
+        assert same(r1)
+        assert same(asp.search_lambda_aware_batch(Q, lq, k, alpha))
+        i5, s5 = asp.search_lambda_aware_batch(Q[:5], lq[:5], k, alpha)  # a small batch: the streaming scan, its filter's own directions
+        assert np.array_equal(np.asarray(i5.cpu() if torch.is_tensor(i5) else i5), idx0[:5])
+        assert same(asp.search_lambda_aware_batch(Q, lq, k, alpha))
+        # the same rows at another address: nothing is adopted (and what was kept is gone with the first index)
+        A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+        other = index_of(Xd.clone())
+        assert ctx.stat("index_adopted_join_images") == 0
+        assert same(other.search_lambda_aware_batch(Q, lq, k, alpha))
+        # a row rewritten between the build and the index: its norm differs, nothing is adopted
+        A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+        Xd[12345] *= 1.5
+        changed = index_of(Xd)
+        assert ctx.stat("index_adopted_join_images") == 0
+        Xd[12345] /= 1.5
+    finally:
+        ctx.set_option("keep_join_images", 0)
+    A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+    assert ctx.stat("knn_join_images_kept") == 0
+    index_of(Xd)
+    assert ctx.stat("index_adopted_join_images") == 0
+
+
 @pytest.mark.parametrize("n,nq,k,alpha,run", [(131_072, 4133, 10, 0.7, 1), (70_001, 2049, 3, 1.0, 4), (200_000, 10_000, 10, 0.3, 1)])
 def test_search_scan_with_a_wave_per_slice_of_queries(ctx, n, nq, k, alpha, run):
     """The scan of a re-searched index of 128-wide items behind the int8 first pass, a wave on its own per (64 queries, one column
