@@ -128,6 +128,13 @@ class HipOps:
     def laplacian_from_knn(self, idx, dist_, gp):
         return A.laplacian_from_knn(idx, dist_, gp, ctx=self.ctx)
 
+    def build_laplacian(self, X_full, gp):
+        """The whole item graph in one call (as_build_laplacian): the neighbour table stays in the library's 32-bit form between the
+        search and the assembly, the matrix is known to be symmetric (the library's own distances) and carries the order of the
+        join for the item-graph lambda."""
+        A._adopt_torch_stream(self.ctx)
+        return A.build_laplacian_matrix(X_full, gp, ctx=self.ctx).matrix
+
     def laplacian_rows(self, idx_all, dist_all, gp, row_begin, row_count):
         """This rank's row block of the Laplacian from the all-gathered neighbour table (as_laplacian_from_knn_rows)."""
         A._adopt_torch_stream(self.ctx)
@@ -320,6 +327,8 @@ class ShardedArrowSpace:
         ops, gp, n = self.ops, self.gp, self.n
         if self.libcomm is not None:
             return self.libcomm.build_laplacian(self.X, n, gp)
+        if not _collectives_on(self.world) and hasattr(ops, "build_laplacian") and not getattr(gp, "normalise", False):
+            return ops.build_laplacian(self.X, gp)                        # one rank: one call
         X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
         rows_here = self.hi - self.lo
         K = gp.topk + 1
