@@ -165,7 +165,7 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   "sharded_own_rows" (1) a sharded build prepares the join from the ranks' own rows; "sharded_order_assign" (1) ... and finds
  *   the pivots of own rows only (assignments all-gathered); "keep_join_images" (0) an item-graph build (one GPU, rows of 128 values) keeps its row order, the f16
  *   image in it, the pivots, the 31 directions and the rotated int8 image with the context (~300 MB per million rows, until the next
- *   build, as_index_create or 0 here); "index_adopt_join_images" (1) as_index_create takes them over when its items are those rows --
+ *   build, as_index_create or 0 here), "keep_join_images_min_rows" (262144) from this many rows; "index_adopt_join_images" (1) as_index_create takes them over when its items are those rows --
  *   the same device pointer, shape and row norms; THE CALLER MUST NOT HAVE WRITTEN TO THE ROWS IN BETWEEN -- and the first search then
  *   runs on the ordered image behind the int8 first pass (stat index_adopted_join_images);
  *   "search_scan_run" (1) units a wave of that scan draws at a time; "search_scan_slices" (2) the one-sided f16 scan behind a first pass: a wave per (64 queries, N stages of 256 columns) on its

@@ -1507,6 +1507,7 @@ def test_index_adopts_the_images_of_the_item_graph_build(ctx, join_on, n, nq, k,
         return np.array_equal(i, idx0) and np.array_equal(s_, sc0)
 
     ctx.set_option("keep_join_images", 1)
+    ctx.set_option("keep_join_images_min_rows", 65536)  # (the default keeps them from 2^18 rows)
     try:
         A.build_laplacian_matrix(Xd, gp, ctx=ctx)
         assert ctx.stat("knn_join_images_kept") == 1
@@ -1531,8 +1532,12 @@ def test_index_adopts_the_images_of_the_item_graph_build(ctx, join_on, n, nq, k,
         changed = index_of(Xd)
         assert ctx.stat("index_adopted_join_images") == 0
         Xd[12345] /= 1.5
+        ctx.set_option("keep_join_images_min_rows", 262144)
+        A.build_laplacian_matrix(Xd, gp, ctx=ctx)
+        assert ctx.stat("knn_join_images_kept") == 0  # fewer rows than the default asks for
     finally:
         ctx.set_option("keep_join_images", 0)
+        ctx.set_option("keep_join_images_min_rows", 262144)
     A.build_laplacian_matrix(Xd, gp, ctx=ctx)
     assert ctx.stat("knn_join_images_kept") == 0
     index_of(Xd)
