@@ -398,8 +398,18 @@ inline hipError_t copy_d2h(as_ctx *ctx, void *dst, const void *src, size_t bytes
   hipError_t e = ensure_pinned(ctx);
   if (bytes <= kStageSlot) {
     if (e == hipSuccess && bytes) {
+      // (with the profile on: the longest the host spent in the two calls of a read-back -- stats "host_max_us_readback_copy" /
+      // "..._wait": a wait far longer than the stage's GPU time is the host being held up, not the GPU)
+      const auto t0 = std::chrono::steady_clock::now();
       e = hipMemcpyAsync(ctx->pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+      const auto t1 = std::chrono::steady_clock::now();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (ctx->prof_on) {
+        const auto t2 = std::chrono::steady_clock::now();
+        int64_t &mc = ctx->stats["host_max_us_readback_copy"], &mw = ctx->stats["host_max_us_readback_wait"];
+        mc = std::max<int64_t>(mc, std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count());
+        mw = std::max<int64_t>(mw, std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count());
+      }
       if (e == hipSuccess) std::memcpy(dst, ctx->pinned, bytes);
     }
     return e;
@@ -571,8 +581,10 @@ struct ProfScope {
   PendingEvent ev;
   bool active;
   const char *outer = nullptr;
+  std::chrono::steady_clock::time_point host_t0;  // (with the profile on: the HOST's time inside the stage too, stat "host_us_in_<stage>")
   ProfScope(as_ctx *c, const char *name) : ctx(c), active(c->prof_on) {
     if (!active) return;
+    host_t0 = std::chrono::steady_clock::now();
     ev.name = name;
     outer = ctx->cur_scope;
     ctx->cur_scope = name;
@@ -584,6 +596,8 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (!active) return;
+    ctx->stats[std::string("host_us_in_") + ev.name] +=
+        (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - host_t0).count();
     ctx->cur_scope = outer;
     (void)hipEventRecord(ev.stop, ctx->stream);
     ctx->pending.push_back(ev);

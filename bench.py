@@ -259,11 +259,23 @@ def recorded_traffic(kernel_substr, n, d):
     return best
 
 
+def settle_after_generator():
+    """The torch generator of the synthetic rows (RNG, gathers, several GB of fresh allocations) leaves the GPU queue with one pause of
+    40 - 100 ms somewhere in the 50 - 150 ms behind it (round 6, scripts/attic/stall_probe.py: with the matrix generated a second
+    earlier the pause never falls into a timed call, 0 of 16 runs against 11 of 24; it is the generator's, not the library's: allocator,
+    interpreter GC, interrupts, scratch of the lambda kernel and every bench leg in front were ruled out one by one -- DESIGN.md
+    section 5).  Generating data is no part of any timed region: wait it out."""
+    import torch
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+
+
 def config_leg(A, D, synth, ctx, dev, n, d, nq, taumode, k, alpha, rank=8, clusters=256, reps=2, seed=42, search=True, lambdas=True):
     """One BASELINE config (or one geometry of the sweep) on this GPU through the same calls as the timed region: item graph,
     reference-mapping lambdas, a query batch.  Wall times of `reps` repetitions behind one warm-up; the profile of the last one."""
     ops = D.HipOps(ctx)
     X, cent = synth.mixture_device(n, d, dev, seed=seed, n_clusters=clusters, rank=rank)
+    settle_after_generator()
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
     sas = D.ShardedArrowSpace(ops, X, n, gp, taumode)
     Q = None
@@ -365,6 +377,7 @@ def main():
     lo, hi = D.shard_range(n, rank, world)
     # seeded mixture rows, generated on the device (the numpy form of the same generator takes 35 s per 1 M x 128)
     Xd, cent = synth.mixture_device(hi - lo, d, dev, seed=42, row_start=lo)
+    settle_after_generator()
     qidx = synth.query_indices(n, nq, seed=42)
     Q = torch.from_numpy(synth.mixture_at(qidx, d, seed=42) * 1.02).to(dev)
     gp = A.GraphParams(0.5, 16, 16, 2.0, 0.25)
@@ -590,16 +603,27 @@ def main():
         hard = {}
         try:
             Xh, _ = synth.mixture_device(n, d, dev, seed=43, n_clusters=4096, rank=64)
+            settle_after_generator()
             A.build_laplacian_matrix(Xh, gp, ctx=ctx)   # warm
             ctx.synchronize()
-            each_h = []
+            each_h, alloc_h = [], []
+            alloc_keys = ("handle_cache_malloc_us", "handle_cache_free_us", "handle_cache_wait_us", "handle_cache_mallocs", "workspace_malloc_us", "workspace_mallocs")
             for _ in range(5):
+                a0 = [ctx.stat(k) for k in alloc_keys]
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
                 t0 = time.perf_counter()
                 glh = A.build_laplacian_matrix(Xh, gp, ctx=ctx)
+                t_ret = time.perf_counter()
+                ev1.record()
                 ctx.synchronize()
                 each_h.append(time.perf_counter() - t0)
+                alloc_h.append({k: ctx.stat(k) - v for k, v in zip(alloc_keys, a0)})   # (what the allocator cost inside the call)
+                alloc_h[-1]["gpu_timeline_ms"] = round(ev0.elapsed_time(ev1), 3)
+                alloc_h[-1]["call_returned_after_ms"] = round((t_ret - t0) * 1e3, 3)
             t_hard = sorted(each_h)[2]   # (the median call: see config_leg)
             hard = {"value": n / t_hard, "unit": "items/s", "build_ms": t_hard * 1e3, "build_ms_each": [round(e * 1e3, 3) for e in each_h],
+                    "allocator_inside_each": alloc_h,
                     "item_graph_nnz": int(glh.matrix.nnz()),
                     "data": "rank-64 / 4096-cluster Gaussian mixture (seed 43), same n, d and graph parameters; item graph only "
                             "(the lambda pass adds 0.4 ms)",
