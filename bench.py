@@ -267,7 +267,7 @@ def settle_after_generator():
     section 5).  Generating data is no part of any timed region: wait it out."""
     import torch
     torch.cuda.synchronize()
-    time.sleep(0.5)
+    time.sleep(1.0)
 
 
 def config_leg(A, D, synth, ctx, dev, n, d, nq, taumode, k, alpha, rank=8, clusters=256, reps=2, seed=42, search=True, lambdas=True):
