@@ -529,17 +529,14 @@ int search_mfma(as_ctx *ctx, as_index *ix, const double *queries, const double *
       }
       AS_HIP(ctx, hipGetLastError());
     }
-    {  // statistics: candidates per query
-      DevBuf<unsigned long long> st;
-      AS_TRY(st.alloc(ctx, 3));
-      AS_HIP(ctx, hipMemsetAsync(st.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
-      hipLaunchKernelGGL(join_count_stats_kernel, dim3(64), dim3(256), 0, ctx->stream, cnt.p, nq, cap, st.p);
-      unsigned long long h[3] = {0, 0, 0};
-      AS_HIP(ctx, copy_d2h(ctx, h, st.p, sizeof(h)));
-      AS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      ctx->stats["search_scan_candidates"] = (int64_t)h[0];
-      ctx->stats["search_scan_max_per_query"] = (int64_t)h[1];
-      ctx->stats["search_scan_overflow_queries"] = (int64_t)h[2];
+    {  // statistics: candidates per query (read back with the count of open queries just below: one wait for the stream, not two)
+      auto parked = std::make_unique<DeferredStat>();
+      AS_TRY(parked->buf.alloc(ctx, 3));
+      AS_HIP(ctx, hipMemsetAsync(parked->buf.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(join_count_stats_kernel, dim3(64), dim3(256), 0, ctx->stream, cnt.p, nq, cap, parked->buf.p);
+      parked->host.resize(3);
+      parked->keys = {{"search_scan_candidates", 0}, {"search_scan_max_per_query", 1}, {"search_scan_overflow_queries", 2}};
+      ctx->deferred.push_back(std::move(parked));
     }
     AS_TRY(read_u32(ctx, fail_count.p, &n_fail));
     ctx->stats["search_scan_uncertified_first"] = n_fail;
