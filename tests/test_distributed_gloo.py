@@ -358,3 +358,45 @@ def test_item_graph_lambda_sums_shard_by_row_blocks(tmp_path, n, world):
     for lam in lams:
         np.testing.assert_allclose(lam, want, rtol=1e-12, atol=1e-300)
         assert np.array_equal(lam, lams[0])   # bit-identical across the ranks
+
+
+def test_one_rank_builds_the_item_graph_in_one_call_and_keeps_the_images_for_its_index():
+    """Host logic of ShardedArrowSpace on ONE rank (no process group): a backend that offers `build_laplacian` gets the whole item graph
+    in one call -- no neighbour table crosses the Python layer -- unless the graph parameters ask for normalised rows (the two-step
+    form then, as before), and a backend with a context is told to keep the build's images for the index that follows
+    (include/arrowspace_hip.h: "keep_join_images").  A backend without either (the oracle backend above) takes the old path."""
+    calls = []
+
+    class FakeCtx:
+        def set_option(self, name, value):
+            calls.append(("option", name, value))
+
+    class FakeOps(OracleOps):
+        def __init__(self):
+            super().__init__(False)
+            self.ctx = FakeCtx()
+
+        def build_laplacian(self, X_full, gp):
+            calls.append(("build_laplacian", tuple(X_full.shape)))
+            return "graph"
+
+        def knn_rows(self, X_full, row_begin, row_count, gp):
+            calls.append(("knn_rows", row_begin, row_count))
+            return super().knn_rows(X_full, row_begin, row_count, gp)
+
+    X, _ = synth.mixture(300, 16, seed=5, n_clusters=4, rank=3)
+    gp = A.GraphParams(0.5, 8, 8, 2.0, 0.25)
+    sas = D.ShardedArrowSpace(FakeOps(), torch.from_numpy(X), 300, gp, A.TauMode.Median)
+    assert ("option", "keep_join_images", 1) in calls
+    assert sas.build_item_graph() == "graph"
+    assert ("build_laplacian", (300, 16)) in calls and not any(c[0] == "knn_rows" for c in calls)
+    # normalised rows: the one-call form is not taken
+    calls.clear()
+    gpn = A.GraphParams(0.5, 8, 8, 2.0, 0.25, True, False)
+    sas_n = D.ShardedArrowSpace(FakeOps(), torch.from_numpy(X), 300, gpn, A.TauMode.Median)
+    sas_n.build_item_graph()
+    assert any(c[0] == "knn_rows" for c in calls) and not any(c[0] == "build_laplacian" for c in calls)
+    # a backend without a context or a one-call build: nothing is set, the two-step form runs
+    plain = D.ShardedArrowSpace(OracleOps(False), torch.from_numpy(X), 300, gp, A.TauMode.Median)
+    gl = plain.build_item_graph()
+    assert gl is not None
