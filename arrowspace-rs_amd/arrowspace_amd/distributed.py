@@ -315,9 +315,9 @@ class ShardedArrowSpace:
         self.lambdas = None
         self.index = None
         # one rank: the index built behind the item graph is over the same rows, untouched in between -- the build keeps its row order
-        # and images for it (include/arrowspace_hip.h: "keep_join_images"), and the first search runs on them
-        if self.world == 1 and libcomm is None and hasattr(ops, "ctx"):
-            ops.ctx.set_option("keep_join_images", 1)
+        # and images for it (include/arrowspace_hip.h: "keep_join_images"), and the first search runs on them.  The option is on from
+        # the build to the creation of the index only (build_item_graph / build_lambdas below).
+        self._keep_images = self.world == 1 and libcomm is None and hasattr(ops, "ctx")
 
     # -- item graph: n x n Laplacian over the items (build_laplacian_matrix on untransposed rows)
     def build_item_graph(self):
@@ -327,6 +327,8 @@ class ShardedArrowSpace:
         ops, gp, n = self.ops, self.gp, self.n
         if self.libcomm is not None:
             return self.libcomm.build_laplacian(self.X, n, gp)
+        if self._keep_images:
+            ops.ctx.set_option("keep_join_images", 1)
         if not _collectives_on(self.world) and hasattr(ops, "build_laplacian") and not getattr(gp, "normalise", False):
             return ops.build_laplacian(self.X, gp)                        # one rank: one call
         X_full = all_gather_rows(self.X, self.sizes)                      # RCCL all-gather #1
@@ -392,6 +394,8 @@ class ShardedArrowSpace:
             stats = torch.cat([mm, sm])
         self.lambda_stats = (float(stats[0]), float(-stats[1]), float(stats[2]) / self.n)
         self.index = self.ops.make_index(self.X, self.lambdas, self.taumode, self.lo) if self.hi > self.lo else None
+        if self._keep_images:
+            self.ops.ctx.set_option("keep_join_images", 0)               # (adopted by the index, or released)
         return self.gl
 
     def prepare_queries(self, queries):

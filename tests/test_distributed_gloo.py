@@ -387,8 +387,8 @@ def test_one_rank_builds_the_item_graph_in_one_call_and_keeps_the_images_for_its
     X, _ = synth.mixture(300, 16, seed=5, n_clusters=4, rank=3)
     gp = A.GraphParams(0.5, 8, 8, 2.0, 0.25)
     sas = D.ShardedArrowSpace(FakeOps(), torch.from_numpy(X), 300, gp, A.TauMode.Median)
-    assert ("option", "keep_join_images", 1) in calls
     assert sas.build_item_graph() == "graph"
+    assert ("option", "keep_join_images", 1) in calls  # (on from the build ... to the creation of the index: build_lambdas sets it back)
     assert ("build_laplacian", (300, 16)) in calls and not any(c[0] == "knn_rows" for c in calls)
     # normalised rows: the one-call form is not taken
     calls.clear()
