@@ -265,14 +265,15 @@ __global__ __launch_bounds__(256) void zproj_rows128_kernel(const double *__rest
 //    the wave's 32 values of Q in registers) -- and the two halves meet in LDS in a fixed order.
 // err_rows: the plane error of each row BY ROW; err_bits: the largest.  Grid: ceil(n / 64) blocks.
 typedef float zp_v16f32 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void zproj_pack_rows128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
+__global__ __launch_bounds__(256, 4) void zproj_pack_rows128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint32_t n,
                                                                  const float *__restrict__ Q, uint32_t pitch, double *__restrict__ out,
                                                                  double *__restrict__ tail_part, _Float16 *__restrict__ Hrow,
                                                                  float *__restrict__ err_rows, unsigned int *__restrict__ err_bits) {
   constexpr float kScale = 128.f;  // (kOperandScale of mfma_join_f16.hip: unit rows are stored times 2^7)
+  // (the products take the place of the operand once every wave has read it: 33 KB a workgroup instead of 50, four workgroups a CU)
   __shared__ float xf[64 * 129];
-  __shared__ float zs[64 * 33];
-  __shared__ float zp[64 * 33];   // the partial products of the upper k half
+  float *zs = xf;             // 64 x 33
+  float *zp = xf + 64 * 33;   // the partial products of the upper k half
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lh = lane >> 5, lc = lane & 31;
   const uint32_t row0 = blockIdx.x * 64u;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256) void zproj_pack_rows128_kernel(const double *_
 #pragma unroll
     for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t], qreg[t], acc, 0, 0, 0);
     // acc[r] of lane (lh, lc) = the product of row 32 g + 4 lh + (r & 3) + 8 (r >> 2) with direction lc over the wave's k half
+    __syncthreads();  // (every wave is done with the operand: its place is the products' now)
     float *dstz = h ? zp : zs;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dstz[(32 * g + 4 * lh + (r & 3) + 8 * (r >> 2)) * 33 + lc] = acc[r];
