@@ -70,7 +70,7 @@ constexpr int kRpCounters = kRpPairsAt + kRpPairSlots;  // ([4 .. 8]: why rows w
 __device__ __forceinline__ uint32_t rp_half_mask(unsigned long long bal, int half) { return (uint32_t)(half ? (bal >> 32) : bal); }
 
 template <int SLOTS>
-__global__ __launch_bounds__(256) void rerank_link_kernel(uint32_t row_begin, uint32_t row_count, uint32_t *__restrict__ records,
+__global__ __launch_bounds__(256, 8) void rerank_link_kernel(uint32_t row_begin, uint32_t row_count, uint32_t *__restrict__ records,
                                                           const uint32_t *__restrict__ a_ids, const uint32_t *__restrict__ order,
                                                           const uint32_t *__restrict__ row2rec, int share, uint32_t *__restrict__ meta,
                                                           uint32_t *__restrict__ rowpos, uint32_t *__restrict__ seg_batches,
