@@ -618,6 +618,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
     if (!value) join_keep_clear(ctx);
   } else if (n == "keep_join_images_min_rows") ctx->opt_keep_join_images_min_rows = value;
   else if (n == "index_adopt_join_images") ctx->opt_index_adopt_join_images = value;
+  else if (n == "join_second_slices") ctx->opt_join_second_slices = value;
   else if (n == "search_scan_run") ctx->opt_search_scan_run = value;
   else if (n == "search_scan_slices") ctx->opt_search_scan_slices = value;
   else if (n == "join_masked_block") ctx->opt_join_masked_block = value;

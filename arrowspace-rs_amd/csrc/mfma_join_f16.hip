@@ -1588,9 +1588,10 @@ int join_f16_search(as_ctx *ctx, const void *P, uint32_t n, uint32_t d, const vo
   AS_HIP(ctx, hipMemsetAsync(stamps.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
   const F16SearchTerm st{q_lam, g_minus_beta, x_lam, alpha, beta, nq, self_ids};
   ProfScope ps(ctx, prof_name);
-  // (not the second pass of an item graph -- self_ids --: its open rows come from everywhere, a slice's stages are nearly all flagged
-  // and sharing them through LDS is what pays there: 0.70 ms against 0.83 at 1 M rows)
-  if (mask && KS == 8 && ctx->opt_search_scan_slices > 0 && !self_ids && !(ctx->opt_debug & 8)) {
+  // (the second pass of an item graph -- self_ids -- too, "join_second_slices": its open rows are in the order of the image, a slice of
+  // 64 of them spans a few per cent of the columns: 0.70 -> 0.5 ms at 1 M rows.  The first version of this kernel -- runs of units
+  // from an unordered list, four column super tiles a unit -- had lost there, 0.83.)
+  if (mask && KS == 8 && ctx->opt_search_scan_slices > 0 && (!self_ids || ctx->opt_join_second_slices) && !(ctx->opt_debug & 8)) {
     // behind the first pass: a wave per (slice of 64 queries, a few stages of 256 columns), nothing shared (scan_slices_f16_kernel)
     const uint32_t Ws = (uint32_t)std::min<int64_t>(ctx->opt_search_scan_slices, 64);  // stages of 256 columns per unit
     const uint64_t s_units = (uint64_t)((2 * T2 + Ws - 1) / Ws) * a_supers * 8;

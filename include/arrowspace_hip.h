@@ -168,6 +168,7 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   build, as_index_create or 0 here), "keep_join_images_min_rows" (262144) from this many rows; "index_adopt_join_images" (1) as_index_create takes them over when its items are those rows --
  *   the same device pointer, shape and row norms; THE CALLER MUST NOT HAVE WRITTEN TO THE ROWS IN BETWEEN -- and the first search then
  *   runs on the ordered image behind the int8 first pass (stat index_adopted_join_images);
+ *   "join_second_slices" (1) the second pass of an item graph on that scan too;
  *   "search_scan_run" (1) units a wave of that scan draws at a time; "search_scan_slices" (2) the one-sided f16 scan behind a first pass: a wave per (64 queries, N stages of 256 columns) on its
  *   own (0: a workgroup per 512 queries, a stage of columns shared through LDS); "join_masked_block" (0) column super tiles per work unit of the masked f16 pass alone (0: "join_block", narrower for a
  *   short range of rows); "rerank_prune_halves" (1) the re-rank's pruning takes a row per half wave, lists of at most 128 entries in registers;
