@@ -613,6 +613,7 @@ int as_ctx_set_option(as_ctx *ctx, const char *name, int64_t value) {
   else if (n == "join_theta_rows64") ctx->opt_join_theta_rows64 = value;
   else if (n == "join_one_sided_block") ctx->opt_join_one_sided_block = value;
   else if (n == "sharded_order_assign") ctx->opt_sharded_order_assign = value;
+  else if (n == "join_basis_fused") ctx->opt_join_basis_fused = value;
   else if (n == "keep_join_images") {
     ctx->opt_keep_join_images = value;
     if (!value) join_keep_clear(ctx);

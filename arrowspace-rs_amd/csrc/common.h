@@ -136,6 +136,7 @@ struct as_ctx {
   int64_t opt_rerank_image_order = 1;    // re-rank of rows wider than 128: records in the order of the join's image (0: in row order)
   int64_t opt_keep_open_rows = 0;  // diagnostic: the ids of the rows the first re-rank leaves open are kept as stats (mfma_drivers.hip)
   int64_t opt_join_basis_sample = 16384; // rotated coordinates: rows of the strided sample the directions are found on
+  int64_t opt_join_basis_fused = 1;    // rows of 128 values: a round of the basis' subspace iteration in one kernel (0: coordinates, then Y = S^T Z, two kernels)
   int64_t opt_keep_join_images = 0;    // an item-graph build keeps its order and images for an index of the same rows (as_ctx::JoinKeep; ~300 MB per million rows)
   int64_t opt_keep_join_images_min_rows = 262144;  // ... from this many rows
   int64_t opt_index_adopt_join_images = 1;  // as_index_create takes them over when the items are those rows (same device pointer, shape and norms)

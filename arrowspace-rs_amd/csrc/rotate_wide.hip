@@ -395,6 +395,67 @@ __global__ __launch_bounds__(256, 4) void zproj_pack_rows128_kernel(const double
   if (tail_part && lane == 0) tail_part[blockIdx.x * 4 + wv] = tails;
 }
 
+// One round of the subspace iteration on a sample of rows of exactly 128 values in ONE kernel (round 6): zproj_kernel (a wave a row,
+// 186 shuffles a row) + yacc_kernel (32 of its 256 threads at work at 128 columns) took 54 + 37 us for 16 384 sample rows, four
+// times a build.  Here a workgroup stages 64 sample rows as f32 unit rows in LDS, a thread takes eight directions of one row for the
+// coordinates (the row's values come conflict-free out of LDS, the directions are a broadcast), and then 15.5 of the 31 x 128
+// elements of the block's part of Y = S^T Z, each a sum over its 64 rows in row order.  yreduce_kernel adds the blocks' parts in its
+// fixed tree.  (f32 sums in another order than the two kernels': the directions differ in their last bits -- any basis orthonormal
+// to 1e-6 serves, and this one is the same in every run and on every rank.)
+__global__ __launch_bounds__(256) void zy_sample128_kernel(const double *__restrict__ R, const double *__restrict__ norms, uint64_t stride, uint32_t count,
+                                                           const float *__restrict__ Q, uint32_t pitch, float *__restrict__ Ypart) {
+  __shared__ float s_u[64 * 129];
+  __shared__ float s_q[kDirs * 129];
+  __shared__ float s_z[64 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t i0 = blockIdx.x * 64u;
+  for (int e = tid; e < kDirs * 128; e += 256) s_q[(e >> 7) * 129 + (e & 127)] = Q[(size_t)(e >> 7) * pitch + (e & 127)];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {  // wave wv takes rows wv, wv + 4, ...: lane l the values 2 l, 2 l + 1
+    const uint32_t lr = (uint32_t)(4 * q + wv), i = i0 + lr;
+    float f0 = 0.f, f1 = 0.f;
+    if (i < count) {
+      const uint64_t row = (uint64_t)i * stride;
+      const double nr = norms[row];
+      if (nr > 0.0 && nr < __builtin_inf()) {
+        const d2 v = reinterpret_cast<const d2 *>(R + row * 128)[lane];
+        f0 = (float)(v.x / nr);
+        f1 = (float)(v.y / nr);
+        f0 = f0 == f0 ? f0 : 0.f;
+        f1 = f1 == f1 ? f1 : 0.f;
+      }
+    }
+    s_u[lr * 129 + 2 * lane] = f0;
+    s_u[lr * 129 + 2 * lane + 1] = f1;
+  }
+  __syncthreads();
+  {  // coordinates: thread (row rr, part) -> directions 8 part .. 8 part + 7
+    const int rr = tid >> 2, part = tid & 3;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int k = 0; k < 128; ++k) {
+      const float x = s_u[rr * 129 + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (8 * part + j < kDirs) a[j] = __builtin_fmaf(x, s_q[(8 * part + j) * 129 + k], a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (8 * part + j < kDirs) s_z[rr * 33 + 8 * part + j] = a[j];
+  }
+  __syncthreads();
+  float *yp = Ypart + (size_t)blockIdx.x * kDirs * pitch;
+  for (int e = tid; e < kDirs * 128; e += 256) {  // (dir, k): consecutive threads consecutive k
+    const int dir = e >> 7, k = e & 127;
+    float y = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) y = __builtin_fmaf(s_z[r * 33 + dir], s_u[r * 129 + k], y);
+    yp[(size_t)dir * pitch + k] = y;
+  }
+}
+
 // Y[block][dir][k] = sum over the sample rows of the block (i = block, block + grid, ...: a fixed order) of z[row][dir] * u[row][k];
 // yreduce_kernel adds the blocks' parts in block order.  (Was a float atomicAdd into one Y: the directions differed in their last
 // bits from run to run, and with them the row order and the routing of rows through the stages.)
@@ -679,7 +740,9 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   DevBuf<float> Qd, Yd, Ypart;
   DevBuf<double> Zs, tpart;
   DevBuf<unsigned int> err_bits;
-  const uint32_t y_blocks = std::min<uint32_t>(ns, 512);
+  // (rows of exactly 128 values: a round of the iteration is one kernel over blocks of 64 sample rows, zy_sample128_kernel)
+  const bool fused_round = d == 128 && ctx->opt_join_basis_fused && (((uintptr_t)(sr ? sr->own : rows)) & 15) == 0;
+  const uint32_t y_blocks = fused_round ? (uint32_t)cdiv(ns, 64) : std::min<uint32_t>(ns, 512);
   // (128 aligned columns: zproj_rows128_kernel, blocks of 64 rows; other widths up to 128: blocks of 256)
   const bool rows128 = d == 128 && (((uintptr_t)(sr ? sr->own : rows)) & 15) == 0 && !(ctx->opt_debug & 2048);
   const uint32_t z_rows = rows128 ? 64u : 256u;
@@ -763,11 +826,15 @@ int rotated_rows_wide(as_ctx *ctx, const double *rows, const double *norms, uint
   const int iters = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_join_basis_iters, 8));
   for (int it = 0; it < iters; ++it) {  // Q <- orth(S^T S Q)
     AS_HIP(ctx, hipMemcpyAsync(Qd.p, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    AS_HIP(ctx, hipMemsetAsync(Ypart.p, 0, (size_t)y_blocks * kDirs * pitch * sizeof(float), ctx->stream));  // (columns d .. pitch stay 0)
-    AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, s_rows, s_norms, (uint64_t)0, s_stride, ns, d, (const float *)Qd.p,
-                        pitch, Zs.p, (double *)nullptr));
-    hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, s_rows, s_norms, s_stride, ns, d,
-                       (const double *)Zs.p, pitch, Ypart.p);
+    if (fused_round) {
+      hipLaunchKernelGGL(zy_sample128_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, s_rows, s_norms, s_stride, ns, (const float *)Qd.p, pitch, Ypart.p);
+    } else {
+      AS_HIP(ctx, hipMemsetAsync(Ypart.p, 0, (size_t)y_blocks * kDirs * pitch * sizeof(float), ctx->stream));  // (columns d .. pitch stay 0)
+      AS_TRY(launch_zproj(ctx, nv, std::min<uint32_t>(cdiv(ns, 4), 1024), lds, s_rows, s_norms, (uint64_t)0, s_stride, ns, d, (const float *)Qd.p,
+                          pitch, Zs.p, (double *)nullptr));
+      hipLaunchKernelGGL(yacc_kernel, dim3(y_blocks), dim3(256), 0, ctx->stream, s_rows, s_norms, s_stride, ns, d,
+                         (const double *)Zs.p, pitch, Ypart.p);
+    }
     hipLaunchKernelGGL(yreduce_kernel, dim3(cdiv((uint32_t)kDirs * pitch, 16)), dim3(256), 0, ctx->stream, (const float *)Ypart.p, y_blocks,
                        (uint32_t)kDirs * pitch, Yd.p);
     AS_HIP(ctx, hipGetLastError());

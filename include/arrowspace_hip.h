@@ -163,7 +163,8 @@ int as_ctx_synchronize(as_ctx *ctx);
  *   staged and the quick streaming form; "signal_min_len" (9000), "signal_tau_bracket" (1), "signal_tau_overlap" (1) item-graph
  *   lambda: from which signal length as_compute_taumode takes it, the order statistics from a sampled bracket, on a side stream;
  *   "sharded_own_rows" (1) a sharded build prepares the join from the ranks' own rows; "sharded_order_assign" (1) ... and finds
- *   the pivots of own rows only (assignments all-gathered); "keep_join_images" (0) an item-graph build (one GPU, rows of 128 values) keeps its row order, the f16
+ *   the pivots of own rows only (assignments all-gathered); "join_basis_fused" (1) rows of 128 values: a round of the subspace iteration that finds the 31 directions in
+ *   one kernel (0: two); "keep_join_images" (0) an item-graph build (one GPU, rows of 128 values) keeps its row order, the f16
  *   image in it, the pivots, the 31 directions and the rotated int8 image with the context (~300 MB per million rows, until the next
  *   build, as_index_create or 0 here), "keep_join_images_min_rows" (262144) from this many rows; "index_adopt_join_images" (1) as_index_create takes them over when its items are those rows --
  *   the same device pointer, shape and row norms; THE CALLER MUST NOT HAVE WRITTEN TO THE ROWS IN BETWEEN -- and the first search then
