@@ -966,15 +966,19 @@ __global__ __launch_bounds__(1024) void sort_chunks_kernel(const double *__restr
   __shared__ unsigned long long s_k[kSortChunk];
   __shared__ uint32_t s_i[kSortChunk];
   const uint32_t base = blockIdx.x * kSortChunk;
-  for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+  // (the network spans the next power of two of what the chunk holds, not the whole chunk: the ~1 600 open rows of a second pass are
+  // sorted in 66 rounds over 2 048 slots instead of 91 over 8 192 -- 75 -> 15 us)
+  uint32_t lim = 2;
+  while (lim < kSortChunk && base + lim < n) lim <<= 1;
+  for (uint32_t t = threadIdx.x; t < lim; t += 1024) {
     const uint32_t g = base + t;
     s_k[t] = g < n ? value_key(v[g]) : ~0ull;
     s_i[t] = g < n ? g : 0xFFFFFFFFu;  // padding sorts behind everything (a NaN has key ~0 too, and a smaller index)
   }
   __syncthreads();
-  for (uint32_t k = 2; k <= kSortChunk; k <<= 1)
+  for (uint32_t k = 2; k <= lim; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+      for (uint32_t t = threadIdx.x; t < lim; t += 1024) {
         const uint32_t p = t ^ j;
         if (p > t) {
           const unsigned long long ka = s_k[t], kb = s_k[p];
@@ -988,7 +992,7 @@ __global__ __launch_bounds__(1024) void sort_chunks_kernel(const double *__restr
       }
       __syncthreads();
     }
-  for (uint32_t t = threadIdx.x; t < kSortChunk; t += 1024) {
+  for (uint32_t t = threadIdx.x; t < lim; t += 1024) {
     const uint32_t g = base + t;
     if (g < n) {
       keys[g] = s_k[t];
