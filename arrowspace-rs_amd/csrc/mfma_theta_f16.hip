@@ -512,36 +512,24 @@ __global__ __launch_bounds__(256, 2) void theta_f16x2_kernel(const f16x8 *__rest
 
 
 // the thresholds from the bins the parts of the sample left: maxima over the parts, then the selection of theta_f16_kernel
-__global__ __launch_bounds__(64) void theta_bins_select_kernel(const float *__restrict__ bins, uint32_t row_count, uint32_t parts, uint32_t m,
-                                                               float *__restrict__ theta_out, uint32_t m2, float *__restrict__ theta2_out) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= row_count) return;
-  float vals[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) vals[c] = -__builtin_inff();
-  for (uint32_t p = 0; p < parts; ++p) {
-    const float *src = bins + ((size_t)row * parts + p) * 64;
-#pragma unroll
-    for (int c = 0; c < 64; ++c) vals[c] = __builtin_fmaxf(vals[c], src[c]);
+// (a wave a row, a lane a bin -- round 6: a thread a row with its 64 bins in registers read 256 B per lane per part and ran m rounds of
+// remove-the-maximum, 40 us for the ~2 000 rows of a check on 35 waves; here the parts arrive as coalesced 256-byte rows, and a bin's
+// rank in the descending order -- bins with a larger value, or the same value at a lower index -- is counted against the 64 lanes:
+// the m-th largest value is the bin of rank m - 1, whichever way equal values are numbered)
+__global__ __launch_bounds__(256) void theta_bins_select_kernel(const float *__restrict__ bins, uint32_t row_count, uint32_t parts, uint32_t m,
+                                                                float *__restrict__ theta_out, uint32_t m2, float *__restrict__ theta2_out) {
+  const uint32_t lane = threadIdx.x & 63u, row = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (row >= row_count) return;  // (the wave's)
+  float v = -__builtin_inff();
+  for (uint32_t p = 0; p < parts; ++p) v = __builtin_fmaxf(v, bins[((size_t)row * parts + p) * 64 + lane]);
+  uint32_t rank = 0;
+  for (uint32_t c = 0; c < 64; ++c) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)c));
+    rank += (o > v || (o == v && c < lane)) ? 1u : 0u;
   }
-  float t = -__builtin_inff(), t1 = -__builtin_inff();
   const uint32_t mm = theta2_out ? max(m, m2) : m;
-  for (uint32_t k = 0; k < mm; ++k) {
-    float best = -__builtin_inff();
-    int at = 0;
-#pragma unroll
-    for (int c = 0; c < 64; ++c) {
-      const bool gt = vals[c] > best;
-      best = gt ? vals[c] : best;
-      at = gt ? c : at;
-    }
-    t = best;
-    if (k + 1 == m) t1 = best;
-#pragma unroll
-    for (int c = 0; c < 64; ++c) vals[c] = c == at ? -__builtin_inff() : vals[c];
-  }
-  if (theta2_out) theta2_out[row] = t * (1.f / 16384.f);
-  theta_out[row] = t1 * (1.f / 16384.f);
+  if (rank + 1 == m) theta_out[row] = v * (1.f / 16384.f);
+  if (theta2_out && rank + 1 == mm) theta2_out[row] = v * (1.f / 16384.f);
 }
 
 // ---- the sample by pivot group (own join with the row order found on the rotated coordinates, row_order.hip) -------------------
@@ -712,7 +700,7 @@ int join_thresholds_f16(as_ctx *ctx, const double *rows, const double *norms, ui
   }
 #undef AS_THETA
   if (parts > 1)
-    hipLaunchKernelGGL(theta_bins_select_kernel, dim3(cdiv(row_count, 64)), dim3(64), 0, ctx->stream, (const float *)bins.p, row_count, parts, m,
+    hipLaunchKernelGGL(theta_bins_select_kernel, dim3(cdiv(row_count, 4)), dim3(256), 0, ctx->stream, (const float *)bins.p, row_count, parts, m,
                        theta_out, m2, theta2_out);
   AS_HIP(ctx, hipGetLastError());
   // (no synchronisation to hand the workspace back: a block returned to the cache is reused by later work on this same stream only)
